@@ -1,0 +1,38 @@
+# Top-level build.  `make` builds the product library (HIP, gfx950) and the
+# oracle (test infrastructure); `make ref` builds oracle/_ref from /root/reference
+# when that tree is present (this container only).
+HIPCC ?= /opt/rocm/bin/hipcc
+CXX   ?= g++
+ARCH  ?= gfx950
+
+CSRC := plade_amd/csrc
+HIP_SRCS := $(wildcard $(CSRC)/*.hip)
+HIP_OBJS := $(patsubst $(CSRC)/%.hip,build/%.o,$(HIP_SRCS))
+HIP_HDRS := $(wildcard $(CSRC)/*.h) $(wildcard $(CSRC)/*.cuh) include/plade_hip.h
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -Iinclude -I$(CSRC) -Wno-unused-result
+
+all: lib oracle cli
+
+lib: plade_amd/libplade_hip.so
+oracle: oracle/libplade_oracle.so
+cli: plade_amd/PLADE
+
+build/%.o: $(CSRC)/%.hip $(HIP_HDRS)
+	@mkdir -p build
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+plade_amd/libplade_hip.so: $(HIP_OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^
+
+plade_amd/PLADE: $(CSRC)/main.cpp $(CSRC)/plade.h plade_amd/libplade_hip.so
+	$(HIPCC) -O2 -std=c++17 -Iinclude -I$(CSRC) $(CSRC)/main.cpp -o $@ -Lplade_amd -lplade_hip -Wl,-rpath,'$$ORIGIN'
+
+oracle/libplade_oracle.so: oracle/plade_oracle.cpp oracle/plade_oracle.h oracle/orc_math.h
+	$(CXX) -O2 -std=c++14 -fPIC -ffp-contract=off -shared -o $@ oracle/plade_oracle.cpp
+
+ref:
+	@if [ -d /root/reference/code/3rd_party ]; then $(MAKE) -C oracle/ref -j8; else echo "no /root/reference: using prebuilt oracle/_ref"; fi
+
+clean:
+	rm -rf build plade_amd/libplade_hip.so plade_amd/PLADE oracle/libplade_oracle.so
+.PHONY: all lib oracle cli ref clean

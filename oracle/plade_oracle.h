@@ -1,0 +1,73 @@
+/* oracle/plade_oracle.h -- TEST INFRASTRUCTURE ONLY.
+ *
+ * C entry points of the CPU restatement of PLADE's registration hot path
+ * (oracle/plade_oracle.cpp).  Only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may load this library; the product (plade_amd/,
+ * libplade_hip.so) never links, imports or calls it.
+ */
+#ifndef PLADE_ORACLE_H
+#define PLADE_ORACLE_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* A3: one plane hypothesis (n, dist = n.p0) against N points (pos_nrm N x 6). */
+int orc_score_plane(const float *pos_nrm, const int32_t *shape_index, int n, const float *plane4,
+                    float eps, float cos_thresh, int32_t *idx_out, int32_t *count_out);
+/* Plane::Init(p1,p2,p3) (ransac/Plane.cpp:29-38); returns 0 if degenerate. */
+int orc_plane_from_points(const float *tri9, float *plane4);
+/* A4: largest connected component of the inlier bitmap; returns kept count. */
+int orc_connected_component(const float *pos_nrm, int n, const float *normal3, const float *point3,
+                            const int32_t *indices, int m, float bitmap_eps, int do_filtering,
+                            int32_t *kept_out);
+/* A5: LS refit -> normal(3), mean(3), dist. */
+int orc_ls_fit(const float *pos_nrm, int n, const int32_t *indices, int m, float *out7);
+float orc_weighted_score(const float *pos_nrm, int n, const float *normal3, const float *point3,
+                         const int32_t *indices, int m, float eps);
+float orc_cloud_scale(const float *pos_nrm, int n);
+
+/* A13 */
+float orc_average_spacing(const float *xyz, int n, int stride_floats, int k, int samples);
+/* sort_mode 0: std::sort (PCL-faithful, unstable); 1: stable (ascending point index). */
+int orc_voxel_downsample(const float *xyz, int n, int stride_floats, float leaf, int sort_mode,
+                         float *out_xyz, int32_t *n_out);
+/* util.h:186-248: center(3), whd (width,height,depth doubles), corners (8x3, may be NULL) */
+int orc_bounding_box(const float *xyz, int n, float *center3, double *whd3, float *corners24);
+
+/* A6 */
+int orc_intersection_line(const float *plane_a4, const float *plane_b4, float *vec3, float *point3);
+int orc_closest_points(const float *u1, const float *p1, const float *u2, const float *p2,
+                       float *q1, float *q2, double *len);
+/* A7: all target descriptors within `radius` of each query; sorted (query, dist2, index). */
+int64_t orc_match_descriptors(const float *qry, int dq, const float *tgt, int dt, float radius,
+                              int64_t *offsets_out, int32_t *nbr_out, double *dist2_out,
+                              int64_t cap);
+/* A8 */
+void orc_umeyama3(const float *src9, const float *dst9, float *R9);
+void orc_selfadjoint_eig3(const float *cov9, float *evals3, float *evecs9);
+/* A12: u32 count for one candidate (T 4x4 row-major, centre = R c_s + T). */
+int orc_overlap_count(const float *src_ds, int ns, const float *tgt_ds, int nt, const float *T16,
+                      const float *center3, float src_radius, float inlier_dist);
+
+/* Whole deterministic stage: registration(T, target, source, target_planes, source_planes)
+ * (code/PLADE/plade.cpp:31-580).  Planes: P x 4 (n,d); offsets P+1; point indices.
+ * voxel_sort_mode as orc_voxel_downsample.  max_candidates = 200 (plade.cpp:54).
+ * Returns 1 on success, 0 on "registration failed".  The handle keeps named
+ * intermediate arrays for stage-level parity tests (orc_dump_get). */
+typedef struct orc_reg orc_reg;
+orc_reg *orc_reg_create(void);
+void orc_reg_destroy(orc_reg *);
+int orc_registration(orc_reg *h, const float *tgt_pos_nrm, int nt, const float *src_pos_nrm, int ns,
+                     const float *tgt_planes, const int32_t *tgt_offsets, const int32_t *tgt_idx,
+                     int pt, const float *src_planes, const int32_t *src_offsets,
+                     const int32_t *src_idx, int ps, int voxel_sort_mode, int max_candidates,
+                     float *T16_out);
+/* name -> (ptr, nbytes); returns 0 if found */
+int orc_dump_get(orc_reg *h, const char *name, const void **ptr, int64_t *nbytes);
+/* seconds spent per stage in the last orc_registration: name list via orc_dump "timing_names" */
+
+#ifdef __cplusplus
+}
+#endif
+#endif
