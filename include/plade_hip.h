@@ -1,0 +1,145 @@
+/* include/plade_hip.h -- C ABI of libplade_hip.so, the MI355X (gfx950) implementation of
+ * PLADE's registration hot path.  Plain pointers and sizes only; every entry point
+ * returns 0 on success and a negative PLADE_E* code on failure (never throws).
+ *
+ * The reference (chsl/PLADE) has no FFI layer; these symbols are cut at the internal
+ * seams listed in SURVEY.md section 8b.  Each declaration cites the reference
+ * interface it replaces (paths relative to the reference tree).
+ *
+ * Host pointers unless a parameter is documented as a plade_cloud handle.
+ * One plade_ctx per host thread / device stream; a ctx is not re-entrant.
+ */
+#ifndef PLADE_HIP_H
+#define PLADE_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PLADE_OK 0
+#define PLADE_EINVAL (-1)   /* bad argument */
+#define PLADE_EDEVICE (-2)  /* HIP runtime error / no gfx950 device */
+#define PLADE_ECAP (-3)     /* caller-provided capacity too small */
+#define PLADE_EFAIL (-4)    /* registration failed (reference returns false) */
+#define PLADE_ELIMIT (-5)   /* internal limit exceeded */
+
+typedef struct plade_ctx plade_ctx;
+typedef struct plade_cloud plade_cloud; /* device-resident oriented point cloud */
+
+/* Context: owns the HIP stream, scratch pools and the debug dump. */
+int plade_ctx_create(int device, plade_ctx **out);
+void plade_ctx_destroy(plade_ctx *ctx);
+const char *plade_last_error(const plade_ctx *ctx);
+const char *plade_version(void);
+
+/* Tunables that are hard-coded literals in the reference (defaults = reference values):
+ *   max_planes      40     code/PLADE/plade.cpp:604   (extract(): top-40 cap)
+ *   min_planes      10     code/PLADE/plade.cpp:603
+ *   max_candidates  200    code/PLADE/plade.cpp:54    (maxCandidateResultNum)
+ *   init_min_support 10000 code/PLADE/plade.cpp:602
+ *   orient_normals  1      0 = reference behaviour (plane_extraction.cpp:43-58 correct_normal is a
+ *                          NaN no-op: plane normal keeps the LS-fit sign); 1 = the evident intent:
+ *                          flip the plane normal to agree with the mean inlier point normal.
+ *   ransac_seed     fixed  the reference seeds from time(NULL) (RansacShapeDetector.cpp:463-464)
+ *   dump            0      keep named intermediates for plade_dump_get (tests)            */
+typedef struct plade_params {
+    int32_t max_planes;
+    int32_t min_planes;
+    int32_t max_candidates;
+    int32_t init_min_support;
+    int32_t orient_normals;
+    int32_t dump;
+    uint64_t ransac_seed;
+} plade_params;
+void plade_default_params(plade_params *p);
+int plade_set_params(plade_ctx *ctx, const plade_params *p);
+
+/* ---- seam S1a: plane scoring ------------------------------------------------------------
+ * Replaces m_shape->Visit(&scoreVisitor) (code/3rd_party/ransac/Candidate.h:174,290) =
+ * ScorePrimitiveShapeVisitorImpl::operator() (ransac/ScorePrimitiveShapeVisitor.h:39-46) with
+ * FlatNormalThreshPointCompatibilityFunc (ransac/FlatNormalThreshPointCompatibilityFunc.h:14-23):
+ * inlier <=> shape_index[i] == -1 && |dist - n.p_i| < eps && |n.n_i| >= cos_thresh.
+ * pos_nrm: N x 6 (x y z nx ny nz); shape_index may be NULL (all unassigned);
+ * planes: H x 4 = (n, dist = n.p0); counts: H; idx_out (optional): H x cap, ascending point
+ * index per hypothesis (rows are truncated at cap; counts stay exact). */
+int plade_score_planes(plade_ctx *ctx, const float *pos_nrm, const int32_t *shape_index, uint32_t n,
+                       const float *planes, uint32_t h, float eps, float cos_thresh,
+                       uint32_t *counts, uint32_t *idx_out, uint32_t cap);
+
+/* ---- seam S1b: whole plane-extraction stage --------------------------------------------
+ * Replaces PlaneExtraction::detect (code/PLADE/plane_extraction.cpp:173-200 -> :61-168 ->
+ * RansacShapeDetector::Detect, ransac/RansacShapeDetector.cpp:455-907).
+ * dist_rel/bitmap_rel are relative to max(dx,dy) of the bbox (the reference's Z-ignoring scale,
+ * plane_extraction.cpp:71-80).  Output: planes_out P x 4 = (unit n, d = -n.p); offsets_out P+1;
+ * idx_out = original point indices of each plane's support (capacity n). */
+int plade_extract_planes(plade_ctx *ctx, const float *pos_nrm, uint32_t n, uint32_t min_support,
+                         float dist_rel, float bitmap_rel, float cos_thresh, float overlook_p,
+                         float *planes_out, int32_t *offsets_out, int32_t *idx_out,
+                         uint32_t max_planes, uint32_t *n_planes_out);
+
+/* ---- seam S2: descriptor match ------------------------------------------------------------
+ * Replaces the kdtree22.find_neighbors loop (code/PLADE/util.cpp:133-293, call at :163) =
+ * KdTreeSearchNDim<VectorXf,8>::find_neighbors(p, 0, radius, ...) (ann_1.1.2/include/ANN/ANN.h:
+ * 978-1029): all target descriptors with sum_d (double(q_d)-double(t_d))^2 <= double(float(r*r)).
+ * Output sorted by (query, dist2, target index); offsets: Dq+1; t_idx/dist2 capacity `cap`
+ * (may be NULL with cap 0 to size the result); *n_pairs receives the exact total. */
+int plade_match_descriptors(plade_ctx *ctx, const float *src, uint32_t ds, const float *tgt,
+                            uint32_t dt, float radius, int64_t *offsets, uint32_t *t_idx,
+                            double *dist2, uint64_t cap, uint64_t *n_pairs);
+
+/* ---- seam S3: candidate verification ------------------------------------------------------
+ * Replaces the loop code/PLADE/plade.cpp:547-564: per candidate k,
+ *   count_k = #{ p in src_ds : exists t in tgt_ds with |t - c_k|^2 < float(R^2) and
+ *                              |t - T_k p|^2 < float(leaf^2) }
+ * (ComputeOverlap, code/PLADE/util.h:611-647; pcl transformPointCloud, FLANN strict <).
+ * T: K x 16 row-major; centers: K x 3 (= R c_s + T, formed by the caller as plade.cpp:555);
+ * counts[k] = -1 when the coarse sphere holds no target point (overlap ratio 0). */
+int plade_overlap_counts(plade_ctx *ctx, const float *src_ds, uint32_t n_s, const float *tgt_ds,
+                         uint32_t n_t, const float *T, uint32_t k, const float *centers,
+                         float src_radius, float inlier_dist, int32_t *counts);
+
+/* ---- supporting stage entry points (A13) ------------------------------------------------- */
+/* average_spacing(cloud, k) (code/PLADE/util.cpp:1619-1648); xyz read with `stride` floats. */
+int plade_average_spacing(plade_ctx *ctx, const float *xyz, uint32_t n, uint32_t stride,
+                          uint32_t k, uint32_t samples, float *spacing_out);
+/* DownSamplePointCloud -> pcl::VoxelGrid (code/PLADE/util.h:161-184); out capacity n. */
+int plade_voxel_downsample(plade_ctx *ctx, const float *xyz, uint32_t n, uint32_t stride, float leaf,
+                           float *out_xyz, uint32_t *n_out);
+
+/* ---- registration() overloads (code/PLADE/plade.h) ---------------------------------------- */
+/* plade.h:74-79  registration(T, target, source, target_planes, source_planes) -- the
+ * deterministic parity boundary.  planes: P x 4 (n, d), offsets P+1, idx. T16: row-major 4x4. */
+int plade_registration_planes(plade_ctx *ctx, const float *tgt_pos_nrm, uint32_t n_t,
+                              const float *src_pos_nrm, uint32_t n_s, const float *tgt_planes,
+                              const int32_t *tgt_offsets, const int32_t *tgt_idx, uint32_t p_t,
+                              const float *src_planes, const int32_t *src_offsets,
+                              const int32_t *src_idx, uint32_t p_s, float *T16);
+/* plade.h:58-61  registration(T, target, source): auto-tuned plane extraction (plade.cpp:602-662) */
+int plade_registration(plade_ctx *ctx, const float *tgt_pos_nrm, uint32_t n_t,
+                       const float *src_pos_nrm, uint32_t n_s, float *T16);
+/* plade.h:91-96  registration(T, target, source, min_support_target, min_support_source) */
+int plade_registration_minsupport(plade_ctx *ctx, const float *tgt_pos_nrm, uint32_t n_t,
+                                  const float *src_pos_nrm, uint32_t n_s, int32_t min_support_t,
+                                  int32_t min_support_s, float *T16);
+
+/* Device-resident clouds: upload once, register many times (bench: inputs resident in HBM). */
+int plade_cloud_upload(plade_ctx *ctx, const float *pos_nrm, uint32_t n, plade_cloud **out);
+void plade_cloud_free(plade_ctx *ctx, plade_cloud *c);
+int plade_registration_dev(plade_ctx *ctx, plade_cloud *tgt, plade_cloud *src, float *T16);
+
+/* ---- instrumentation ---------------------------------------------------------------------- */
+/* Named intermediates of the last registration (when params.dump != 0). Returns 0 if found;
+ * the pointer stays valid until the next call on this ctx. */
+int plade_dump_get(plade_ctx *ctx, const char *name, const void **ptr, int64_t *nbytes);
+/* Per-stage GPU/host seconds and byte counts of the last registration:
+ * names is a ';'-separated list, values has one double per name. */
+int plade_stats_get(plade_ctx *ctx, const char **names, const double **values, int32_t *count);
+/* Times `iters` launches of one hot kernel on resident synthetic-shaped data with HIP events on
+ * the ctx stream (used by bench.py for the roofline figure): which = "score" | "overlap" | "match". */
+int plade_kernel_time(plade_ctx *ctx, const char *which, int iters, double *avg_seconds,
+                      double *algorithmic_bytes_per_launch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PLADE_HIP_H */

@@ -1,0 +1,300 @@
+"""plade_amd -- MI355X (gfx950) implementation of PLADE's registration hot path.
+
+This package is a thin ctypes binding over the C ABI of ``libplade_hip.so`` (declared in
+``include/plade_hip.h``).  There is no CPU fallback: importing the package is cheap, but creating
+a :class:`Context` fails loudly when the HIP library or a GPU is missing.
+"""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libplade_hip.so")
+
+PLADE_OK = 0
+PLADE_EINVAL, PLADE_EDEVICE, PLADE_ECAP, PLADE_EFAIL, PLADE_ELIMIT = -1, -2, -3, -4, -5
+
+# every symbol include/plade_hip.h declares (checked by tests/test_abi.py)
+ABI_SYMBOLS = [
+    "plade_ctx_create", "plade_ctx_destroy", "plade_last_error", "plade_version", "plade_default_params",
+    "plade_set_params", "plade_score_planes", "plade_extract_planes", "plade_match_descriptors",
+    "plade_overlap_counts", "plade_average_spacing", "plade_voxel_downsample", "plade_registration_planes",
+    "plade_registration", "plade_registration_minsupport", "plade_cloud_upload", "plade_cloud_free",
+    "plade_registration_dev", "plade_dump_get", "plade_stats_get", "plade_kernel_time",
+]
+
+
+class PladeError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libplade_hip error {code}: {msg}")
+        self.code = code
+
+
+class Params(C.Structure):
+    _fields_ = [("max_planes", C.c_int32), ("min_planes", C.c_int32), ("max_candidates", C.c_int32),
+                ("init_min_support", C.c_int32), ("orient_normals", C.c_int32), ("dump", C.c_int32),
+                ("ransac_seed", C.c_uint64)]
+
+
+_lib = None
+
+
+def load_library(path=LIB_PATH):
+    """Load libplade_hip.so; raises if it has not been built (no fallback path exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(path):
+        raise FileNotFoundError(f"{path} is missing: build it with `make lib` or __graft_entry__.build(); "
+                                "plade_amd has no CPU fallback")
+    L = C.CDLL(path)
+    p, f, i32, u32, u64 = C.c_void_p, C.c_float, C.c_int32, C.c_uint32, C.c_uint64
+    def sig(name, argtypes=None, restype=None):
+        # a symbol missing from the library is reported by Context/_need, never silently replaced
+        fn = getattr(L, name, None)
+        if fn is None:
+            return
+        if argtypes is not None:
+            fn.argtypes = argtypes
+        if restype is not None:
+            fn.restype = restype
+
+    sig("plade_version", restype=C.c_char_p)
+    sig("plade_last_error", restype=C.c_char_p)
+    sig("plade_last_error", argtypes=[p])
+    sig("plade_ctx_create", argtypes=[C.c_int, C.POINTER(p)])
+    sig("plade_ctx_destroy", argtypes=[p])
+    sig("plade_default_params", argtypes=[C.POINTER(Params)])
+    sig("plade_set_params", argtypes=[p, C.POINTER(Params)])
+    sig("plade_score_planes", argtypes=[p, p, p, u32, p, u32, f, f, p, p, u32])
+    sig("plade_extract_planes", argtypes=[p, p, u32, u32, f, f, f, f, p, p, p, u32, p])
+    sig("plade_match_descriptors", argtypes=[p, p, u32, p, u32, f, p, p, p, u64, p])
+    sig("plade_overlap_counts", argtypes=[p, p, u32, p, u32, p, u32, p, f, f, p])
+    sig("plade_average_spacing", argtypes=[p, p, u32, u32, u32, u32, p])
+    sig("plade_voxel_downsample", argtypes=[p, p, u32, u32, f, p, p])
+    sig("plade_registration_planes", argtypes=[p, p, u32, p, u32, p, p, p, u32, p, p, p, u32, p])
+    sig("plade_registration", argtypes=[p, p, u32, p, u32, p])
+    sig("plade_registration_minsupport", argtypes=[p, p, u32, p, u32, i32, i32, p])
+    sig("plade_cloud_upload", argtypes=[p, p, u32, C.POINTER(p)])
+    sig("plade_cloud_free", argtypes=[p, p])
+    sig("plade_registration_dev", argtypes=[p, p, p, p])
+    sig("plade_dump_get", argtypes=[p, C.c_char_p, C.POINTER(p), C.POINTER(C.c_int64)])
+    sig("plade_stats_get", argtypes=[p, C.POINTER(C.c_char_p), C.POINTER(C.POINTER(C.c_double)), C.POINTER(i32)])
+    sig("plade_kernel_time", argtypes=[p, C.c_char_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)])
+    _lib = L
+    return L
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+# name -> dtype of the intermediates plade_dump_get can return (same names as the oracle's dump)
+DUMP_FIELDS = {
+    "average_spacing": np.float32, "scale": np.float32,
+    "tgt_ds": np.float32, "src_ds": np.float32, "tgt_bcenter": np.float32, "src_bcenter": np.float32,
+    "tgt_radius": np.float64, "src_radius": np.float64,
+    "tgt_plane_center_radius": np.float32, "src_plane_center_radius": np.float32,
+    "tgt_plane_four": np.float32, "src_plane_four": np.float32,
+    "tgt_plane_ds_offsets": np.int32, "src_plane_ds_offsets": np.int32,
+    "tgt_plane_ds": np.float32, "src_plane_ds": np.float32,
+    "tgt_lines": np.float32, "src_lines": np.float32,
+    "tgt_desc": np.float32, "src_desc": np.float32,
+    "match_offsets": np.int64, "match_nbr": np.int32, "match_dist2": np.float64,
+    "initial_RT": np.float32, "cluster_sizes": np.int32, "cluster_seeds": np.int32,
+    "plane_match_counts": np.int32, "pen_tested": np.int32, "pen_flags": np.int32,
+    "candidates": np.float32, "candidate_centers": np.float32, "overlap_counts": np.int32,
+    "scores": np.float32, "best_index": np.int32,
+    "tgt_planes": np.float32, "tgt_plane_offsets": np.int32, "tgt_plane_idx": np.int32,
+    "src_planes": np.float32, "src_plane_offsets": np.int32, "src_plane_idx": np.int32,
+}
+
+
+class Cloud:
+    """Device-resident oriented point cloud (plade_cloud)."""
+
+    def __init__(self, ctx, pos_nrm):
+        self.ctx = ctx
+        a = _f32(pos_nrm)
+        assert a.ndim == 2 and a.shape[1] == 6
+        self.n = len(a)
+        self.h = C.c_void_p()
+        ctx._check(ctx.L.plade_cloud_upload(ctx.h, _ptr(a), self.n, C.byref(self.h)))
+
+    def free(self):
+        if self.h:
+            self.ctx.L.plade_cloud_free(self.ctx.h, self.h)
+            self.h = C.c_void_p()
+
+
+class Context:
+    """One HIP stream + scratch pools on one GPU (plade_ctx)."""
+
+    def __init__(self, device=0, **params):
+        self.L = load_library()
+        self.h = C.c_void_p()
+        rc = self.L.plade_ctx_create(device, C.byref(self.h))
+        if rc != 0:
+            raise PladeError(rc, "plade_ctx_create failed (no gfx950 device visible?)")
+        self.params = Params()
+        self.L.plade_default_params(C.byref(self.params))
+        if params:
+            self.set_params(**params)
+
+    def close(self):
+        if self.h:
+            self.L.plade_ctx_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, allow=()):
+        if rc != 0 and rc not in allow:
+            raise PladeError(rc, self.L.plade_last_error(self.h).decode(errors="replace"))
+        return rc
+
+    def set_params(self, **kw):
+        for k, v in kw.items():
+            setattr(self.params, k, v)
+        self._check(self.L.plade_set_params(self.h, C.byref(self.params)))
+
+    # ---- seams -----------------------------------------------------------------------------
+    def score_planes(self, pos_nrm, shape_index, planes, eps, cos_thresh, want_indices=False):
+        pn = _f32(pos_nrm)
+        pl = _f32(planes).reshape(-1, 4)
+        si = _i32(shape_index) if shape_index is not None else None
+        n, h = len(pn), len(pl)
+        counts = np.zeros(h, np.uint32)
+        idx = np.zeros((h, n), np.uint32) if want_indices else None
+        self._check(self.L.plade_score_planes(self.h, _ptr(pn), _ptr(si), n, _ptr(pl), h, eps, cos_thresh,
+                                              _ptr(counts), _ptr(idx), n if want_indices else 0))
+        if want_indices:
+            return counts, [idx[j, : counts[j]].astype(np.int32) for j in range(h)]
+        return counts
+
+    def extract_planes(self, pos_nrm, min_support, dist_rel=0.005, bitmap_rel=0.02, cos_thresh=0.8,
+                       overlook=0.001, max_planes=256):
+        pn = _f32(pos_nrm)
+        n = len(pn)
+        planes = np.zeros((max_planes, 4), np.float32)
+        offs = np.zeros(max_planes + 1, np.int32)
+        idx = np.zeros(n, np.int32)
+        npl = C.c_uint32()
+        self._check(self.L.plade_extract_planes(self.h, _ptr(pn), n, min_support, dist_rel, bitmap_rel, cos_thresh,
+                                                overlook, _ptr(planes), _ptr(offs), _ptr(idx), max_planes,
+                                                C.byref(npl)))
+        p = npl.value
+        return planes[:p].copy(), offs[: p + 1].copy(), idx[: offs[p]].copy()
+
+    def match_descriptors(self, qry, tgt, radius=0.04):
+        q = _f32(qry).reshape(-1, 8)
+        t = _f32(tgt).reshape(-1, 8)
+        off = np.zeros(len(q) + 1, np.int64)
+        total = C.c_uint64()
+        self._check(self.L.plade_match_descriptors(self.h, _ptr(q), len(q), _ptr(t), len(t), radius, _ptr(off), None,
+                                                   None, 0, C.byref(total)))
+        m = total.value
+        nbr = np.zeros(max(m, 1), np.uint32)
+        d2 = np.zeros(max(m, 1), np.float64)
+        self._check(self.L.plade_match_descriptors(self.h, _ptr(q), len(q), _ptr(t), len(t), radius, _ptr(off),
+                                                   _ptr(nbr), _ptr(d2), m, C.byref(total)))
+        return off, nbr[:m].astype(np.int32), d2[:m]
+
+    def overlap_counts(self, src_ds, tgt_ds, T, centers, src_radius, inlier_dist):
+        s, t = _f32(src_ds), _f32(tgt_ds)
+        T = _f32(T).reshape(-1, 16)
+        c = _f32(centers).reshape(-1, 3)
+        counts = np.zeros(len(T), np.int32)
+        self._check(self.L.plade_overlap_counts(self.h, _ptr(s), len(s), _ptr(t), len(t), _ptr(T), len(T), _ptr(c),
+                                                src_radius, inlier_dist, _ptr(counts)))
+        return counts
+
+    def average_spacing(self, pts, k=6, samples=10000):
+        a = _f32(pts)
+        out = C.c_float()
+        self._check(self.L.plade_average_spacing(self.h, _ptr(a), len(a), a.shape[1], k, samples, C.byref(out)))
+        return np.float32(out.value)
+
+    def voxel_downsample(self, pts, leaf):
+        a = _f32(pts)
+        out = np.zeros((len(a), 3), np.float32)
+        n = C.c_uint32()
+        self._check(self.L.plade_voxel_downsample(self.h, _ptr(a), len(a), a.shape[1], leaf, _ptr(out), C.byref(n)))
+        return out[: n.value].copy()
+
+    # ---- registration() overloads (code/PLADE/plade.h) --------------------------------------
+    def registration_planes(self, tgt, src, tgt_planes, src_planes):
+        """plade.h:74.  Returns (ok, T 4x4)."""
+        tgt, src = _f32(tgt), _f32(src)
+        tc, to, ti = _f32(tgt_planes[0]), _i32(tgt_planes[1]), _i32(tgt_planes[2])
+        sc, so, si = _f32(src_planes[0]), _i32(src_planes[1]), _i32(src_planes[2])
+        T = np.zeros((4, 4), np.float32)
+        rc = self._check(self.L.plade_registration_planes(self.h, _ptr(tgt), len(tgt), _ptr(src), len(src), _ptr(tc),
+                                                          _ptr(to), _ptr(ti), len(tc), _ptr(sc), _ptr(so), _ptr(si),
+                                                          len(sc), _ptr(T)), allow=(PLADE_EFAIL,))
+        return rc == 0, T
+
+    def registration(self, tgt, src):
+        """plade.h:58.  Returns (ok, T 4x4)."""
+        tgt, src = _f32(tgt), _f32(src)
+        T = np.zeros((4, 4), np.float32)
+        rc = self._check(self.L.plade_registration(self.h, _ptr(tgt), len(tgt), _ptr(src), len(src), _ptr(T)),
+                         allow=(PLADE_EFAIL,))
+        return rc == 0, T
+
+    def registration_minsupport(self, tgt, src, ms_t, ms_s):
+        """plade.h:91."""
+        tgt, src = _f32(tgt), _f32(src)
+        T = np.zeros((4, 4), np.float32)
+        rc = self._check(self.L.plade_registration_minsupport(self.h, _ptr(tgt), len(tgt), _ptr(src), len(src), ms_t,
+                                                              ms_s, _ptr(T)), allow=(PLADE_EFAIL,))
+        return rc == 0, T
+
+    def upload(self, pos_nrm):
+        return Cloud(self, pos_nrm)
+
+    def registration_dev(self, tgt_cloud, src_cloud):
+        T = np.zeros((4, 4), np.float32)
+        rc = self._check(self.L.plade_registration_dev(self.h, tgt_cloud.h, src_cloud.h, _ptr(T)), allow=(PLADE_EFAIL,))
+        return rc == 0, T
+
+    # ---- instrumentation ---------------------------------------------------------------------
+    def dump(self):
+        out = {}
+        for name, dt in DUMP_FIELDS.items():
+            ptr = C.c_void_p()
+            nb = C.c_int64()
+            if self.L.plade_dump_get(self.h, name.encode(), C.byref(ptr), C.byref(nb)) != 0:
+                continue
+            if nb.value == 0 or not ptr.value:
+                out[name] = np.zeros(0, dt)
+                continue
+            buf = (C.c_char * nb.value).from_address(ptr.value)
+            out[name] = np.frombuffer(bytes(buf), dtype=dt).copy()
+        return out
+
+    def stats(self):
+        names = C.c_char_p()
+        vals = C.POINTER(C.c_double)()
+        cnt = C.c_int32()
+        self._check(self.L.plade_stats_get(self.h, C.byref(names), C.byref(vals), C.byref(cnt)))
+        ns = names.value.decode().strip(";").split(";") if cnt.value else []
+        return {ns[i]: vals[i] for i in range(cnt.value)}
+
+    def kernel_time(self, which, iters=20):
+        t = C.c_double()
+        b = C.c_double()
+        self._check(self.L.plade_kernel_time(self.h, which.encode(), iters, C.byref(t), C.byref(b)))
+        return t.value, b.value

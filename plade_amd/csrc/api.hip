@@ -1,0 +1,67 @@
+// plade_amd/csrc/api.hip -- context management and instrumentation entry points of the C ABI.
+#include "ctx.h"
+
+using namespace plade;
+
+extern "C" void plade_default_params(plade_params *p) {
+    if (!p) return;
+    p->max_planes = 40;         // code/PLADE/plade.cpp:604
+    p->min_planes = 10;         // code/PLADE/plade.cpp:603
+    p->max_candidates = 200;    // code/PLADE/plade.cpp:54
+    p->init_min_support = 10000;  // code/PLADE/plade.cpp:602
+    p->orient_normals = 1;
+    p->dump = 0;
+    p->ransac_seed = 0x9E3779B97F4A7C15ull;
+}
+
+extern "C" const char *plade_version(void) { return "plade-hip 0.1 (gfx950)"; }
+
+extern "C" int plade_ctx_create(int device, plade_ctx **out) {
+    if (!out) return PLADE_EINVAL;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) return PLADE_EDEVICE;
+    if (hipSetDevice(device) != hipSuccess) return PLADE_EDEVICE;
+    plade_ctx *c = new plade_ctx;
+    c->device = device;
+    plade_default_params(&c->params);
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return PLADE_EDEVICE; }
+    *out = c;
+    return PLADE_OK;
+}
+
+extern "C" void plade_ctx_destroy(plade_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" const char *plade_last_error(const plade_ctx *ctx) { return ctx ? ctx->last_error.c_str() : "null ctx"; }
+
+extern "C" int plade_set_params(plade_ctx *ctx, const plade_params *p) {
+    if (!ctx || !p) return PLADE_EINVAL;
+    if (p->max_planes < 1 || p->min_planes < 0 || p->max_candidates < 1 || p->init_min_support < 1) return PLADE_EINVAL;
+    ctx->params = *p;
+    return PLADE_OK;
+}
+
+extern "C" int plade_dump_get(plade_ctx *ctx, const char *name, const void **ptr, int64_t *nbytes) {
+    if (!ctx || !name || !ptr || !nbytes) return PLADE_EINVAL;
+    auto it = ctx->dump.find(name);
+    if (it == ctx->dump.end()) return PLADE_EINVAL;
+    *ptr = it->second.data();
+    *nbytes = (int64_t)it->second.size();
+    return PLADE_OK;
+}
+
+extern "C" int plade_stats_get(plade_ctx *ctx, const char **names, const double **values, int32_t *count) {
+    if (!ctx || !names || !values || !count) return PLADE_EINVAL;
+    ctx->stats.joined.clear();
+    for (auto &n : ctx->stats.names) { ctx->stats.joined += n; ctx->stats.joined += ";"; }
+    *names = ctx->stats.joined.c_str();
+    *values = ctx->stats.values.data();
+    *count = (int32_t)ctx->stats.values.size();
+    return PLADE_OK;
+}

@@ -1,0 +1,139 @@
+// plade_amd/csrc/common.h -- shared host/device helpers of libplade_hip.so (gfx950 only).
+//
+// fp32 expressions follow the evaluation order of the reference's Eigen 3.4 / PCL /
+// Schnabel code so that integer decisions taken on the GPU agree with the CPU path
+// bit for bit (the library is compiled with -ffp-contract=off; + - * / sqrt are
+// correctly rounded on CDNA4).  Conventions:
+//   fixed-size Eigen 3-vector reductions:  x0 + (x1 + x2)
+//   dynamic-size Eigen reductions and Schnabel's Vec3f::dot:  (x0 + x1) + x2
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <cmath>
+#include <cfloat>
+#include <string>
+#include <vector>
+#include <map>
+#include <chrono>
+
+#define HD __host__ __device__ __forceinline__
+
+namespace plade {
+
+struct f3 {
+    float x, y, z;
+    HD f3() : x(0.f), y(0.f), z(0.f) {}
+    HD f3(float a, float b, float c) : x(a), y(b), z(c) {}
+};
+HD f3 operator+(f3 a, f3 b) { return f3(a.x + b.x, a.y + b.y, a.z + b.z); }
+HD f3 operator-(f3 a, f3 b) { return f3(a.x - b.x, a.y - b.y, a.z - b.z); }
+HD f3 operator-(f3 a) { return f3(-a.x, -a.y, -a.z); }
+HD f3 operator*(float s, f3 a) { return f3(s * a.x, s * a.y, s * a.z); }
+HD f3 operator/(f3 a, float s) { return f3(a.x / s, a.y / s, a.z / s); }
+HD float dot_e(f3 a, f3 b) { return a.x * b.x + (a.y * b.y + a.z * b.z); }     // Eigen fixed-size
+HD float dot_s(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }     // sequential
+HD float sqn_e(f3 a) { return dot_e(a, a); }
+HD float norm_e(f3 a) { return sqrtf(sqn_e(a)); }
+HD f3 cross(f3 a, f3 b) { return f3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+HD f3 normalized_e(f3 a) {  // Eigen MatrixBase::normalize()
+    float z = sqn_e(a);
+    if (z > 0.f) { float s = sqrtf(z); return a / s; }
+    return a;
+}
+
+struct m3 { float m[3][3]; };
+HD f3 mul_e(const m3 &R, f3 v) {
+    return f3(R.m[0][0] * v.x + (R.m[0][1] * v.y + R.m[0][2] * v.z),
+              R.m[1][0] * v.x + (R.m[1][1] * v.y + R.m[1][2] * v.z),
+              R.m[2][0] * v.x + (R.m[2][1] * v.y + R.m[2][2] * v.z));
+}
+// pcl::transformPointCloud dense branch (pcl-1.8.1/common/include/pcl/common/impl/transforms.hpp:69-71)
+HD f3 pcl_xform(const float *T, f3 p) {
+    return f3(T[0] * p.x + T[1] * p.y + T[2] * p.z + T[3], T[4] * p.x + T[5] * p.y + T[6] * p.z + T[7],
+              T[8] * p.x + T[9] * p.y + T[10] * p.z + T[11]);
+}
+// FLANN L2_Simple<float> (flann/algorithms/dist.h:74-98)
+HD float flann_d2(f3 q, f3 p) {
+    float ax = q.x - p.x, ay = q.y - p.y, az = q.z - p.z;
+    float r = ax * ax;
+    r += ay * ay;
+    r += az * az;
+    return r;
+}
+// pcl::KdTreeFLANN::radiusSearch squared radius (kdtree_flann.hpp:193)
+inline float pcl_r2(double radius) { return static_cast<float>(radius * radius); }
+
+// ---------------------------------------------------------------------------
+struct Err {
+    int code;
+    std::string msg;
+};
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess) {                                                                \
+            throw plade::Err{-2, std::string(#expr) + ": " + hipGetErrorString(_e)};           \
+        }                                                                                      \
+    } while (0)
+
+#define PLADE_REQUIRE(cond, code, text)                        \
+    do {                                                       \
+        if (!(cond)) throw plade::Err{(code), std::string(text)}; \
+    } while (0)
+
+// grow-only device buffer
+template <class T>
+struct DBuf {
+    T *p = nullptr;
+    size_t cap = 0;
+    ~DBuf() { if (p) (void)hipFree(p); }
+    DBuf() = default;
+    DBuf(const DBuf &) = delete;
+    DBuf &operator=(const DBuf &) = delete;
+    T *ensure(size_t n) {
+        if (n > cap) {
+            if (p) HIP_TRY(hipFree(p));
+            p = nullptr;
+            size_t want = n + n / 4 + 64;
+            HIP_TRY(hipMalloc((void **)&p, want * sizeof(T)));
+            cap = want;
+        }
+        return p;
+    }
+    operator T *() const { return p; }
+};
+
+// pinned host buffer
+template <class T>
+struct HBuf {
+    T *p = nullptr;
+    size_t cap = 0;
+    ~HBuf() { if (p) (void)hipHostFree(p); }
+    HBuf() = default;
+    HBuf(const HBuf &) = delete;
+    HBuf &operator=(const HBuf &) = delete;
+    T *ensure(size_t n) {
+        if (n > cap) {
+            if (p) HIP_TRY(hipHostFree(p));
+            p = nullptr;
+            size_t want = n + n / 4 + 64;
+            HIP_TRY(hipHostMalloc((void **)&p, want * sizeof(T), hipHostMallocDefault));
+            cap = want;
+        }
+        return p;
+    }
+    T &operator[](size_t i) { return p[i]; }
+    operator T *() const { return p; }
+};
+
+inline unsigned cdiv(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
+
+using Clock = std::chrono::steady_clock;
+inline double secs_since(Clock::time_point t0) {
+    return std::chrono::duration<double>(Clock::now() - t0).count();
+}
+
+}  // namespace plade

@@ -1,0 +1,101 @@
+// plade_amd/csrc/ctx.h -- the plade_ctx object behind the C ABI.
+#pragma once
+#include "common.h"
+#include "plade_hip.h"
+
+namespace plade {
+
+// Device-resident oriented cloud in SoA form (coalesced 16 B/lane loads in every scan kernel).
+struct CloudDev {
+    uint32_t n = 0;
+    DBuf<float> soa;  // 6 planes of n floats: x | y | z | nx | ny | nz  (each padded to 4)
+    size_t pitch = 0; // floats per plane (n rounded up to 4)
+    const float *x() const { return soa.p; }
+    const float *y() const { return soa.p + pitch; }
+    const float *z() const { return soa.p + 2 * pitch; }
+    const float *nx() const { return soa.p + 3 * pitch; }
+    const float *ny() const { return soa.p + 4 * pitch; }
+    const float *nz() const { return soa.p + 5 * pitch; }
+};
+
+struct Stats {
+    std::vector<std::string> names;
+    std::vector<double> values;
+    std::string joined;
+    void clear() { names.clear(); values.clear(); }
+    void add(const std::string &n, double v) {
+        for (size_t i = 0; i < names.size(); ++i)
+            if (names[i] == n) { values[i] += v; return; }
+        names.push_back(n);
+        values.push_back(v);
+    }
+};
+
+}  // namespace plade
+
+struct plade_cloud {
+    plade::CloudDev dev;
+    std::vector<float> host_copy;  // pos_nrm kept for the small host-side gathers
+};
+
+struct plade_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    plade_params params;
+    std::string last_error;
+    std::map<std::string, std::vector<char>> dump;
+    plade::Stats stats;
+    // generic scratch
+    plade::DBuf<char> scratch[8];
+    plade::HBuf<char> pinned[4];
+
+    template <class T>
+    void put(const std::string &name, const T *data, size_t count) {
+        if (!params.dump) return;
+        std::vector<char> &b = dump[name];
+        b.resize(count * sizeof(T));
+        if (count) memcpy(b.data(), data, count * sizeof(T));
+    }
+    template <class T>
+    void put1(const std::string &name, T v) { put(name, &v, 1); }
+    // copy a device array into the dump (sync)
+    template <class T>
+    void put_dev(const std::string &name, const T *dptr, size_t count) {
+        if (!params.dump) return;
+        std::vector<T> h(count);
+        if (count) HIP_TRY(hipMemcpyAsync(h.data(), dptr, count * sizeof(T), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        put(name, h.data(), count);
+    }
+};
+
+namespace plade {
+
+// run `body`, translate exceptions into C error codes
+template <class F>
+int guarded(plade_ctx *ctx, F body) {
+    if (!ctx) return PLADE_EINVAL;
+    try {
+        return body();
+    } catch (const Err &e) {
+        ctx->last_error = e.msg;
+        return e.code;
+    } catch (const std::exception &e) {
+        ctx->last_error = e.what();
+        return PLADE_EDEVICE;
+    }
+}
+
+struct StageTimer {
+    plade_ctx *ctx;
+    const char *name;
+    Clock::time_point t0;
+    StageTimer(plade_ctx *c, const char *n) : ctx(c), name(n), t0(Clock::now()) {}
+    ~StageTimer() { ctx->stats.add(name, secs_since(t0)); }
+};
+
+// ---- kernels / stages implemented across the .hip files ----------------------------------
+// cloud upload: AoS N x 6 (host) -> SoA on device
+void cloud_upload(plade_ctx *ctx, const float *pos_nrm, uint32_t n, CloudDev &out);
+
+}  // namespace plade

@@ -1,0 +1,163 @@
+// plade_amd/csrc/k_match.hip -- K5: all-pairs 8-D descriptor radius match.
+//
+// Reference: KdTreeSearchNDim<VectorXf,8>::find_neighbors(p, 0, 0.04, ...)
+// (code/3rd_party/ann_1.1.2/include/ANN/ANN.h:978-1029; leaf test
+// ann_1.1.2/src/kd_fix_rad_search.cpp:148-183; call site code/PLADE/util.cpp:163):
+// coordinates widened to double, squared distance accumulated in dimension order, in range
+// <=> dist <= double(float(r*r)); results ascending by distance.  Ties between value-identical
+// distances come out in ascending target index here (ANN's order for exact ties is kd-tree
+// traversal dependent: documented in DESIGN.md).
+//
+// GPU mapping: exact fp64 brute force.  One lane owns one query (8 doubles in VGPRs), target
+// tiles are staged through LDS and read as wave-wide broadcasts; a count pass sizes the output,
+// an exclusive scan places it, a fill pass writes (target, dist2) in ascending target order, and
+// two stable radix sorts (by dist2 bits, then by query) give the reference order.
+#include "match.h"
+#include "prims.h"
+
+namespace plade {
+
+constexpr int MT_TPB = 256;
+constexpr int MT_TILE = 256;   // targets per LDS tile
+constexpr int MT_CHUNK = 4096; // targets per block (grid.y)
+
+template <bool FILL>
+__global__ __launch_bounds__(MT_TPB) void k_match(const float *__restrict__ qry, uint32_t dq,
+                                                  const float *__restrict__ tgt, uint32_t dt, double sq_rad,
+                                                  uint32_t nch, uint32_t *__restrict__ cnt /* dq*nch */,
+                                                  const uint32_t *__restrict__ offs /* dq*nch */,
+                                                  uint32_t *__restrict__ t_idx, double *__restrict__ d2_out,
+                                                  uint32_t *__restrict__ q_idx) {
+    __shared__ float s_t[MT_TILE][8];
+    const uint32_t q = blockIdx.x * MT_TPB + threadIdx.x;
+    const bool live = q < dq;
+    double qd[8];
+#pragma unroll
+    for (int d = 0; d < 8; ++d) qd[d] = live ? (double)qry[(size_t)q * 8 + d] : 0.0;
+    const uint32_t t_begin = blockIdx.y * MT_CHUNK;
+    const uint32_t t_end = min(dt, t_begin + MT_CHUNK);
+    uint32_t c = 0;
+    uint32_t wpos = (FILL && live) ? offs[(size_t)q * nch + blockIdx.y] : 0u;
+    for (uint32_t t0 = t_begin; t0 < t_end; t0 += MT_TILE) {
+        const uint32_t tn = min((uint32_t)MT_TILE, t_end - t0);
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < tn * 8; i += MT_TPB) (&s_t[0][0])[i] = tgt[(size_t)t0 * 8 + i];
+        __syncthreads();
+        if (live)
+            for (uint32_t j = 0; j < tn; ++j) {
+                double dist = 0.0;
+#pragma unroll
+                for (int d = 0; d < 8; ++d) {
+                    double t = qd[d] - (double)s_t[j][d];
+                    dist += t * t;
+                }
+                if (dist <= sq_rad) {
+                    if (FILL) {
+                        t_idx[wpos] = t0 + j;
+                        d2_out[wpos] = dist;
+                        q_idx[wpos] = q;
+                        ++wpos;
+                    } else ++c;
+                }
+            }
+    }
+    if (!FILL && live) cnt[(size_t)q * nch + blockIdx.y] = c;
+}
+
+__global__ void k_d2_keys(const double *__restrict__ d2, uint32_t m, uint64_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    keys[i] = (uint64_t)__double_as_longlong(d2[i]);  // non-negative doubles order as their bit patterns
+    vals[i] = i;
+}
+__global__ void k_gather_u32(const uint32_t *__restrict__ src, const uint32_t *__restrict__ perm, uint32_t m,
+                             uint32_t *__restrict__ dst) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) dst[i] = src[perm[i]];
+}
+__global__ void k_gather_final(const uint32_t *__restrict__ t_idx, const double *__restrict__ d2,
+                               const uint32_t *__restrict__ perm, uint32_t m, uint32_t *__restrict__ t_out,
+                               double *__restrict__ d2_out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    uint32_t p = perm[i];
+    t_out[i] = t_idx[p];
+    d2_out[i] = d2[p];
+}
+__global__ void k_query_offsets(const uint32_t *__restrict__ offs, uint32_t dq, uint32_t nch, uint32_t total,
+                                int64_t *__restrict__ out) {
+    uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < dq) out[q] = offs[(size_t)q * nch];
+    if (q == dq) out[q] = total;
+}
+
+uint64_t MatchResult::run(plade_ctx *ctx, const float *d_qry, uint32_t dq, const float *d_tgt, uint32_t dt,
+                          float radius) {
+    total = 0;
+    offsets.ensure((size_t)dq + 1);
+    if (dq == 0) { HIP_TRY(hipMemsetAsync(offsets.p, 0, 8, ctx->stream)); return 0; }
+    if (radius < 0.f || dt == 0) { HIP_TRY(hipMemsetAsync(offsets.p, 0, ((size_t)dq + 1) * 8, ctx->stream)); return 0; }
+    const float sq_rad_f = radius * radius;  // ANN.h:987 `float sqRad = radius*radius`
+    const double sq_rad = sq_rad_f;
+    const uint32_t nch = cdiv(dt, MT_CHUNK);
+    const size_t ncnt = (size_t)dq * nch;
+    PLADE_REQUIRE(ncnt < (1ull << 31), PLADE_ELIMIT, "match: too many (query, chunk) cells");
+    cnt.ensure(ncnt + 1); offs.ensure(ncnt + 1);
+    dim3 grid(cdiv(dq, MT_TPB), nch);
+    hipLaunchKernelGGL(k_match<false>, grid, dim3(MT_TPB), 0, ctx->stream, d_qry, dq, d_tgt, dt, sq_rad, nch, cnt.p,
+                       (const uint32_t *)nullptr, (uint32_t *)nullptr, (double *)nullptr, (uint32_t *)nullptr);
+    HIP_TRY(hipMemsetAsync(cnt.p + ncnt, 0, 4, ctx->stream));
+    exclusive_scan_u32(ctx, cnt.p, offs.p, ncnt + 1);
+    uint32_t tot32 = 0;
+    HIP_TRY(hipMemcpyAsync(&tot32, offs.p + ncnt, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    total = tot32;
+    hipLaunchKernelGGL(k_query_offsets, dim3(cdiv(dq + 1, 256)), dim3(256), 0, ctx->stream, offs.p, dq, nch, tot32,
+                       offsets.p);
+    if (total == 0) return 0;
+    const uint32_t m = tot32;
+    t_raw.ensure(m); d2_raw.ensure(m); q_raw.ensure(m);
+    hipLaunchKernelGGL(k_match<true>, grid, dim3(MT_TPB), 0, ctx->stream, d_qry, dq, d_tgt, dt, sq_rad, nch, cnt.p, offs.p,
+                       t_raw.p, d2_raw.p, q_raw.p);
+    // order inside each query: (dist2, target index).  Entries are already in ascending target
+    // order per query, so a stable sort by dist2 followed by a stable sort by query is enough.
+    k64a.ensure(m); k64b.ensure(m); v32a.ensure(m); v32b.ensure(m); k32a.ensure(m); k32b.ensure(m);
+    hipLaunchKernelGGL(k_d2_keys, dim3(cdiv(m, 256)), dim3(256), 0, ctx->stream, d2_raw.p, m, k64a.p, v32a.p);
+    sort_pairs_u64(ctx, k64a.p, k64b.p, v32a.p, v32b.p, m, 64);
+    hipLaunchKernelGGL(k_gather_u32, dim3(cdiv(m, 256)), dim3(256), 0, ctx->stream, q_raw.p, v32b.p, m, k32a.p);
+    int qbits = 1;
+    while ((1ull << qbits) < dq) ++qbits;
+    sort_pairs_u32(ctx, k32a.p, k32b.p, v32b.p, v32a.p, m, qbits);
+    t_idx.ensure(m); dist2.ensure(m);
+    hipLaunchKernelGGL(k_gather_final, dim3(cdiv(m, 256)), dim3(256), 0, ctx->stream, t_raw.p, d2_raw.p, v32a.p, m,
+                       t_idx.p, dist2.p);
+    q_idx_sorted = k32b.p;
+    HIP_TRY(hipGetLastError());
+    return total;
+}
+
+}  // namespace plade
+
+using namespace plade;
+
+// ---- C ABI: seam S2 ------------------------------------------------------------------------
+extern "C" int plade_match_descriptors(plade_ctx *ctx, const float *src, uint32_t ds, const float *tgt, uint32_t dt,
+                                       float radius, int64_t *offsets, uint32_t *t_idx, double *dist2, uint64_t cap,
+                                       uint64_t *n_pairs) {
+    return guarded(ctx, [&]() -> int {
+        PLADE_REQUIRE(offsets && n_pairs && (src || !ds) && (tgt || !dt), PLADE_EINVAL, "plade_match_descriptors: null argument");
+        DBuf<float> d_q, d_t;
+        d_q.ensure((size_t)ds * 8 + 8); d_t.ensure((size_t)dt * 8 + 8);
+        if (ds) HIP_TRY(hipMemcpyAsync(d_q.p, src, (size_t)ds * 32, hipMemcpyHostToDevice, ctx->stream));
+        if (dt) HIP_TRY(hipMemcpyAsync(d_t.p, tgt, (size_t)dt * 32, hipMemcpyHostToDevice, ctx->stream));
+        MatchResult r;
+        uint64_t total = r.run(ctx, d_q.p, ds, d_t.p, dt, radius);
+        *n_pairs = total;
+        HIP_TRY(hipMemcpyAsync(offsets, r.offsets.p, ((size_t)ds + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+        uint64_t w = total < cap ? total : cap;
+        if (w && t_idx) HIP_TRY(hipMemcpyAsync(t_idx, r.t_idx.p, w * 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (w && dist2) HIP_TRY(hipMemcpyAsync(dist2, r.dist2.p, w * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        return (total > cap && (t_idx || dist2) && cap) ? PLADE_ECAP : PLADE_OK;
+    });
+}

@@ -1,0 +1,268 @@
+// plade_amd/csrc/k_overlap.hip -- K8: per-candidate overlap counting on gfx950.
+//
+// Reference: the verification loop code/PLADE/plade.cpp:547-564 calling
+// ComputeOverlap<PointXYZ> (code/PLADE/util.h:611-647):
+//   U_k   = { t in tgt_ds : |c_k - t|^2 < float(R_s^2) }                    (coarse sphere)
+//   cnt_k = #{ p in src_ds : exists t in U_k with |T_k p - t|^2 < float(leaf^2) }
+// with FLANN's fp32 L2_Simple accumulation and strict `<` (flann/algorithms/dist.h:84-90,
+// flann/util/result_set.h:479,582), pcl::transformPointCloud's expression order
+// (pcl-1.8.1/common/include/pcl/common/impl/transforms.hpp:69-71) and the squared radii formed as
+// float(double(r)*double(r)) (pcl-1.8.1/kdtree/include/pcl/kdtree/impl/kdtree_flann.hpp:193).
+//
+// GPU mapping: the two kd-trees per candidate are replaced by ONE uniform grid over tgt_ds
+// (cell >= leaf, so a 27-cell probe is exhaustive); the predicate is evaluated on the same fp32
+// distances, so counts are bit-exact.  One lane = one source point, candidates staged in LDS
+// (12 floats of T + centre), source stream fully coalesced, hit flags reduced with
+// __ballot/s_bcnt and one atomicAdd per wave per candidate.  The grid (a few MB) lives in L2/MALL.
+#include "overlap.h"
+#include "prims.h"
+
+namespace plade {
+
+struct GridParams {
+    float mnx, mny, mnz, inv;
+    int dx, dy, dz;
+};
+
+__global__ void k_minmax3(const float *__restrict__ xyz, uint32_t n, uint32_t stride, float *__restrict__ out6) {
+    // out6 initialised to (+inf x3, -inf x3) as ordered ints by the host
+    __shared__ float s[6][4];
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        for (int k = 0; k < 3; ++k) {
+            float v = xyz[(size_t)i * stride + k];
+            mn[k] = fminf(mn[k], v);
+            mx[k] = fmaxf(mx[k], v);
+        }
+    for (int k = 0; k < 3; ++k)
+        for (int d = 32; d >= 1; d >>= 1) {
+            mn[k] = fminf(mn[k], __shfl_xor(mn[k], d, 64));
+            mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], d, 64));
+        }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) for (int k = 0; k < 3; ++k) { s[k][wave] = mn[k]; s[3 + k][wave] = mx[k]; }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        int k = threadIdx.x;
+        float v = s[k][0];
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) v = k < 3 ? fminf(v, s[k][w]) : fmaxf(v, s[k][w]);
+        // float atomic min/max through the order-preserving int mapping
+        int iv = __float_as_int(v);
+        iv = iv >= 0 ? iv : iv ^ 0x7fffffff;
+        if (k < 3) atomicMin(reinterpret_cast<int *>(out6) + k, iv);
+        else atomicMax(reinterpret_cast<int *>(out6) + k, iv);
+    }
+}
+
+__global__ void k_cell_ids(const float *__restrict__ xyz, uint32_t n, uint32_t stride, GridParams g,
+                           uint32_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float x = xyz[(size_t)i * stride], y = xyz[(size_t)i * stride + 1], z = xyz[(size_t)i * stride + 2];
+    int cx = min(max((int)floorf((x - g.mnx) * g.inv), 0), g.dx - 1);
+    int cy = min(max((int)floorf((y - g.mny) * g.inv), 0), g.dy - 1);
+    int cz = min(max((int)floorf((z - g.mnz) * g.inv), 0), g.dz - 1);
+    keys[i] = (uint32_t)(cx + g.dx * (cy + g.dy * cz));
+    vals[i] = i;
+}
+
+__global__ void k_gather_cells(const float *__restrict__ xyz, uint32_t stride, const uint32_t *__restrict__ keys,
+                               const uint32_t *__restrict__ vals, uint32_t n, float4 *__restrict__ sorted,
+                               uint32_t *__restrict__ cell_start, uint32_t *__restrict__ cell_end) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t v = vals[i];
+    sorted[i] = make_float4(xyz[(size_t)v * stride], xyz[(size_t)v * stride + 1], xyz[(size_t)v * stride + 2],
+                            __uint_as_float(v));
+    uint32_t k = keys[i];
+    if (i == 0 || keys[i - 1] != k) cell_start[k] = i;
+    if (i == n - 1 || keys[i + 1] != k) cell_end[k] = i + 1;
+}
+
+void TargetGrid::build(plade_ctx *ctx, const float *d_xyz, uint32_t n_pts, uint32_t stride, float min_cell) {
+    n = n_pts;
+    if (n == 0) return;
+    float init[6];
+    int iinit[6];
+    for (int k = 0; k < 3; ++k) {
+        float a = INFINITY, b = -INFINITY;
+        int ia, ib;
+        memcpy(&ia, &a, 4); memcpy(&ib, &b, 4);
+        iinit[k] = ia >= 0 ? ia : ia ^ 0x7fffffff;
+        iinit[3 + k] = ib >= 0 ? ib : ib ^ 0x7fffffff;
+    }
+    bbox.ensure(6);
+    HIP_TRY(hipMemcpyAsync(bbox.p, iinit, 24, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_minmax3, dim3(std::min(cdiv(n, 256), 1024u)), dim3(256), 0, ctx->stream, d_xyz, n, stride,
+                       bbox.p);
+    int ih[6];
+    HIP_TRY(hipMemcpyAsync(ih, bbox.p, 24, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (int k = 0; k < 6; ++k) {
+        int v = ih[k] >= 0 ? ih[k] : ih[k] ^ 0x7fffffff;
+        memcpy(&init[k], &v, 4);
+    }
+    // cell strictly larger than the probe radius so a +-1 cell probe is exhaustive even with the
+    // fp32 rounding of the cell coordinate
+    float cell = min_cell * 1.001f;
+    if (!(cell > 0.f)) cell = 1.f;
+    for (;;) {
+        double ex = std::floor((init[3] - init[0]) / cell) + 1, ey = std::floor((init[4] - init[1]) / cell) + 1,
+               ez = std::floor((init[5] - init[2]) / cell) + 1;
+        if (ex * ey * ez <= 48.0e6) { gp.dx = (int)ex; gp.dy = (int)ey; gp.dz = (int)ez; break; }
+        cell *= 1.26f;
+    }
+    gp.mnx = init[0]; gp.mny = init[1]; gp.mnz = init[2];
+    gp.inv = 1.f / cell;
+    ncells = (size_t)gp.dx * gp.dy * gp.dz;
+    keys.ensure(n); keys2.ensure(n); vals.ensure(n); vals2.ensure(n);
+    sorted.ensure(n);
+    cell_start.ensure(ncells); cell_end.ensure(ncells);
+    HIP_TRY(hipMemsetAsync(cell_start.p, 0, ncells * 4, ctx->stream));
+    HIP_TRY(hipMemsetAsync(cell_end.p, 0, ncells * 4, ctx->stream));
+    GridParams g{gp.mnx, gp.mny, gp.mnz, gp.inv, gp.dx, gp.dy, gp.dz};
+    hipLaunchKernelGGL(k_cell_ids, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, d_xyz, n, stride, g, keys.p, vals.p);
+    int bits = 1;
+    while (((size_t)1 << bits) < ncells) ++bits;
+    sort_pairs_u32(ctx, keys.p, keys2.p, vals.p, vals2.p, n, bits);
+    hipLaunchKernelGGL(k_gather_cells, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, d_xyz, stride, keys2.p, vals2.p, n,
+                       sorted.p, cell_start.p, cell_end.p);
+    HIP_TRY(hipGetLastError());
+}
+
+constexpr int OV_TPB = 256;
+constexpr int OV_KCH = 8;
+
+__global__ __launch_bounds__(OV_TPB) void k_overlap(const float *__restrict__ sx, const float *__restrict__ sy,
+                                                    const float *__restrict__ sz, uint32_t n_s,
+                                                    const float4 *__restrict__ tgt, const uint32_t *__restrict__ cstart,
+                                                    const uint32_t *__restrict__ cend, GridParams g,
+                                                    const float *__restrict__ T /*K x 16*/,
+                                                    const float *__restrict__ centers /*K x 3*/, uint32_t K, float R2,
+                                                    float r2, int32_t *__restrict__ counts) {
+    __shared__ float s_T[OV_KCH][12];
+    __shared__ float s_c[OV_KCH][3];
+    const uint32_t k0 = blockIdx.y * OV_KCH;
+    const uint32_t kc = min((uint32_t)OV_KCH, K - k0);
+    for (uint32_t i = threadIdx.x; i < kc * 12; i += OV_TPB) s_T[i / 12][i % 12] = T[(size_t)(k0 + i / 12) * 16 + i % 12];
+    for (uint32_t i = threadIdx.x; i < kc * 3; i += OV_TPB) s_c[i / 3][i % 3] = centers[(size_t)(k0 + i / 3) * 3 + i % 3];
+    __syncthreads();
+    const uint32_t i = blockIdx.x * OV_TPB + threadIdx.x;
+    const bool live = i < n_s;
+    f3 p = live ? f3(sx[i], sy[i], sz[i]) : f3();
+    const int lane = threadIdx.x & 63;
+    for (uint32_t kk = 0; kk < kc; ++kk) {
+        bool hit = false;
+        if (live) {
+            const f3 q = pcl_xform(s_T[kk], p);
+            const f3 c(s_c[kk][0], s_c[kk][1], s_c[kk][2]);
+            const int cx = (int)floorf((q.x - g.mnx) * g.inv), cy = (int)floorf((q.y - g.mny) * g.inv),
+                      cz = (int)floorf((q.z - g.mnz) * g.inv);
+            const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.dx - 1);
+            const int y0 = max(cy - 1, 0), y1 = min(cy + 1, g.dy - 1);
+            const int z0 = max(cz - 1, 0), z1 = min(cz + 1, g.dz - 1);
+            for (int zz = z0; zz <= z1 && !hit; ++zz)
+                for (int yy = y0; yy <= y1 && !hit; ++yy) {
+                    const int base = g.dx * (yy + g.dy * zz);
+                    for (int xx = x0; xx <= x1 && !hit; ++xx) {
+                        const uint32_t b = cstart[base + xx], e = cend[base + xx];
+                        for (uint32_t j = b; j < e; ++j) {
+                            const float4 t4 = tgt[j];
+                            const f3 t(t4.x, t4.y, t4.z);
+                            if (flann_d2(q, t) < r2 && flann_d2(c, t) < R2) { hit = true; break; }
+                        }
+                    }
+                }
+        }
+        const uint32_t c = (uint32_t)__popcll(__ballot(hit));
+        if (lane == 0 && c) atomicAdd(&counts[k0 + kk], (int32_t)c);
+    }
+}
+
+// does the coarse sphere of candidate k contain any target point?  (util.h:621-625)
+__global__ __launch_bounds__(256) void k_sphere_any(const float4 *__restrict__ tgt, uint32_t n_t,
+                                                    const float *__restrict__ centers, uint32_t K, float R2,
+                                                    uint32_t *__restrict__ any) {
+    extern __shared__ float s_cc[];
+    for (uint32_t i = threadIdx.x; i < K * 3; i += blockDim.x) s_cc[i] = centers[i];
+    __syncthreads();
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = i < n_t;
+    const float4 t4 = live ? tgt[i] : make_float4(0, 0, 0, 0);
+    const f3 t(t4.x, t4.y, t4.z);
+    const int lane = threadIdx.x & 63;
+    for (uint32_t k = 0; k < K; ++k) {
+        const f3 c(s_cc[3 * k], s_cc[3 * k + 1], s_cc[3 * k + 2]);
+        bool in = live && flann_d2(c, t) < R2;
+        if (__ballot(in) && lane == 0) any[k] = 1u;
+    }
+}
+
+void overlap_counts(plade_ctx *ctx, const float *d_sx, const float *d_sy, const float *d_sz, uint32_t n_s,
+                    const TargetGrid &grid, const float *d_T, const float *d_centers, uint32_t K, float src_radius,
+                    float inlier_dist, int32_t *d_counts, uint32_t *d_any) {
+    HIP_TRY(hipMemsetAsync(d_counts, 0, (size_t)K * 4, ctx->stream));
+    HIP_TRY(hipMemsetAsync(d_any, 0, (size_t)K * 4, ctx->stream));
+    if (K == 0 || grid.n == 0) return;
+    const float R2 = pcl_r2((double)src_radius), r2 = pcl_r2((double)inlier_dist);
+    GridParams g{grid.gp.mnx, grid.gp.mny, grid.gp.mnz, grid.gp.inv, grid.gp.dx, grid.gp.dy, grid.gp.dz};
+    // sphere test in chunks of <= 2048 candidates (LDS)
+    for (uint32_t k0 = 0; k0 < K; k0 += 2048) {
+        uint32_t kc = std::min(2048u, K - k0);
+        hipLaunchKernelGGL(k_sphere_any, dim3(cdiv(grid.n, 256)), dim3(256), kc * 12, ctx->stream, grid.sorted.p, grid.n,
+                           d_centers + (size_t)k0 * 3, kc, R2, d_any + k0);
+    }
+    if (n_s) {
+        dim3 gr(cdiv(n_s, OV_TPB), cdiv(K, OV_KCH));
+        hipLaunchKernelGGL(k_overlap, gr, dim3(OV_TPB), 0, ctx->stream, d_sx, d_sy, d_sz, n_s, grid.sorted.p,
+                           grid.cell_start.p, grid.cell_end.p, g, d_T, d_centers, K, R2, r2, d_counts);
+    }
+    HIP_TRY(hipGetLastError());
+}
+
+__global__ void k_deinterleave3(const float *__restrict__ xyz, uint32_t n, float *__restrict__ x, float *__restrict__ y,
+                                float *__restrict__ z) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    x[i] = xyz[3 * (size_t)i]; y[i] = xyz[3 * (size_t)i + 1]; z[i] = xyz[3 * (size_t)i + 2];
+}
+
+void deinterleave3(plade_ctx *ctx, const float *d_xyz, uint32_t n, float *d_x, float *d_y, float *d_z) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_deinterleave3, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, d_xyz, n, d_x, d_y, d_z);
+    HIP_TRY(hipGetLastError());
+}
+
+}  // namespace plade
+
+using namespace plade;
+
+// ---- C ABI: seam S3 ------------------------------------------------------------------------
+extern "C" int plade_overlap_counts(plade_ctx *ctx, const float *src_ds, uint32_t n_s, const float *tgt_ds,
+                                    uint32_t n_t, const float *T, uint32_t k, const float *centers, float src_radius,
+                                    float inlier_dist, int32_t *counts) {
+    return guarded(ctx, [&]() -> int {
+        PLADE_REQUIRE(src_ds && tgt_ds && T && centers && counts, PLADE_EINVAL, "plade_overlap_counts: null argument");
+        DBuf<float> d_src, d_tgt, d_soa, d_T, d_c;
+        DBuf<int32_t> d_counts;
+        DBuf<uint32_t> d_any;
+        d_src.ensure((size_t)n_s * 3 + 4); d_tgt.ensure((size_t)n_t * 3 + 4); d_soa.ensure((size_t)n_s * 3 + 4);
+        d_T.ensure((size_t)k * 16 + 4); d_c.ensure((size_t)k * 3 + 4); d_counts.ensure(k + 1); d_any.ensure(k + 1);
+        HIP_TRY(hipMemcpyAsync(d_src.p, src_ds, (size_t)n_s * 12, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(d_tgt.p, tgt_ds, (size_t)n_t * 12, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(d_T.p, T, (size_t)k * 64, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(d_c.p, centers, (size_t)k * 12, hipMemcpyHostToDevice, ctx->stream));
+        deinterleave3(ctx, d_src.p, n_s, d_soa.p, d_soa.p + n_s, d_soa.p + 2 * (size_t)n_s);
+        TargetGrid grid;
+        grid.build(ctx, d_tgt.p, n_t, 3, inlier_dist);
+        overlap_counts(ctx, d_soa.p, d_soa.p + n_s, d_soa.p + 2 * (size_t)n_s, n_s, grid, d_T.p, d_c.p, k, src_radius,
+                       inlier_dist, d_counts.p, d_any.p);
+        std::vector<uint32_t> any(k);
+        HIP_TRY(hipMemcpyAsync(counts, d_counts.p, (size_t)k * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(any.data(), d_any.p, (size_t)k * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        for (uint32_t i = 0; i < k; ++i)
+            if (!any[i]) counts[i] = -1;
+        return PLADE_OK;
+    });
+}

@@ -1,0 +1,25 @@
+// plade_amd/csrc/overlap.h -- K8 overlap counting + the uniform target grid it probes.
+#pragma once
+#include "ctx.h"
+
+namespace plade {
+
+struct TargetGrid {
+    struct { float mnx, mny, mnz, inv; int dx, dy, dz; } gp;
+    uint32_t n = 0;
+    size_t ncells = 0;
+    DBuf<float> bbox;
+    DBuf<uint32_t> keys, keys2, vals, vals2, cell_start, cell_end;
+    DBuf<float4> sorted;  // target points in cell order: (x, y, z, bitcast original index)
+    // d_xyz: device pointer, `stride` floats between points; min_cell = largest probe radius used.
+    void build(plade_ctx *ctx, const float *d_xyz, uint32_t n_pts, uint32_t stride, float min_cell);
+};
+
+// counts[k] (device, int32) and any[k] (device, 1 when the coarse sphere is non-empty)
+void overlap_counts(plade_ctx *ctx, const float *d_sx, const float *d_sy, const float *d_sz, uint32_t n_s,
+                    const TargetGrid &grid, const float *d_T, const float *d_centers, uint32_t K, float src_radius,
+                    float inlier_dist, int32_t *d_counts, uint32_t *d_any);
+
+void deinterleave3(plade_ctx *ctx, const float *d_xyz, uint32_t n, float *d_x, float *d_y, float *d_z);
+
+}  // namespace plade

@@ -1,0 +1,129 @@
+"""Deterministic synthetic indoor scan pairs (SURVEY.md section 8d -- the reference
+ships no generator, this is the spec): a 10 x 8 x 3 m box room (6 faces) plus 8
+axis-aligned furniture boxes with 3 visible faces each (~30 planes, each >= ~1 %
+of the points), position noise N(0, 5 mm) along the normal, oriented normals with
+N(0, 0.02) jitter, 3 % uniform outliers.  Target = whole scene (seed A); source =
+the same scene re-sampled (seed B), cropped to an oblique half-space and moved by
+a seeded ground-truth SE(3).  Scene centred on the origin to keep fp32 noise small.
+"""
+import numpy as np
+
+ROOM = np.array([10.0, 8.0, 3.0])
+
+
+def _furniture(rng, n_boxes):
+    """Non-overlapping boxes standing on the floor; returns (lo, hi) corner arrays."""
+    boxes = []
+    tries = 0
+    while len(boxes) < n_boxes and tries < 10000:
+        tries += 1
+        size = np.array([rng.uniform(1.4, 2.2), rng.uniform(1.2, 1.9), rng.uniform(1.2, 2.2)])
+        lo_xy = np.array([rng.uniform(-ROOM[0] / 2 + 0.15, ROOM[0] / 2 - 0.15 - size[0]),
+                          rng.uniform(-ROOM[1] / 2 + 0.15, ROOM[1] / 2 - 0.15 - size[1])])
+        lo = np.array([lo_xy[0], lo_xy[1], -ROOM[2] / 2])
+        hi = lo + size
+        ok = True
+        for (l2, h2) in boxes:
+            if np.all(lo[:2] < h2[:2] + 0.25) and np.all(hi[:2] > l2[:2] - 0.25):
+                ok = False
+                break
+        if ok:
+            boxes.append((lo, hi))
+    return boxes
+
+
+def _faces(scene_seed, n_boxes):
+    """List of faces: (origin, edge_u, edge_v, normal, weight)."""
+    rng = np.random.default_rng(scene_seed)
+    h = ROOM / 2
+    faces = []
+    # room faces, normals pointing to the interior
+    for ax in range(3):
+        u, v = [a for a in range(3) if a != ax]
+        for sgn in (-1, 1):
+            o = -h.copy()
+            o[ax] = sgn * h[ax]
+            eu = np.zeros(3); eu[u] = ROOM[u]
+            ev = np.zeros(3); ev[v] = ROOM[v]
+            nrm = np.zeros(3); nrm[ax] = -sgn
+            faces.append((o, eu, ev, nrm, ROOM[u] * ROOM[v]))
+    # furniture: top + two sides chosen per box, normals pointing out of the box (into the room)
+    for (lo, hi) in _furniture(rng, n_boxes):
+        size = hi - lo
+        sx = rng.choice([-1, 1]); sy = rng.choice([-1, 1])
+        # top
+        o = np.array([lo[0], lo[1], hi[2]])
+        faces.append((o, np.array([size[0], 0, 0]), np.array([0, size[1], 0]), np.array([0, 0, 1.0]), None))
+        # x side
+        x = hi[0] if sx > 0 else lo[0]
+        faces.append((np.array([x, lo[1], lo[2]]), np.array([0, size[1], 0]), np.array([0, 0, size[2]]),
+                      np.array([float(sx), 0, 0]), None))
+        y = hi[1] if sy > 0 else lo[1]
+        faces.append((np.array([lo[0], y, lo[2]]), np.array([size[0], 0, 0]), np.array([0, 0, size[2]]),
+                      np.array([0, float(sy), 0]), None))
+    room_area = sum(f[4] for f in faces[:6])
+    n_f = len(faces) - 6
+    # furniture faces share 30 % of the plane points equally (each >= 1 % for <= 24 faces x 1.25 %)
+    out = []
+    for i, (o, eu, ev, nrm, w) in enumerate(faces):
+        if i < 6:
+            wt = 0.70 * w / room_area
+        else:
+            wt = 0.30 / max(n_f, 1)
+        out.append((o, eu, ev, nrm, wt))
+    return out
+
+
+def sample_scene(n, scene_seed=0, sample_seed=1, n_boxes=8, noise=0.005, normal_jitter=0.02, outliers=0.03):
+    faces = _faces(scene_seed, n_boxes)
+    rng = np.random.default_rng(sample_seed)
+    n_out = int(round(n * outliers))
+    n_in = n - n_out
+    w = np.array([f[4] for f in faces])
+    w = w / w.sum()
+    counts = np.floor(w * n_in).astype(int)
+    counts[0] += n_in - counts.sum()
+    pts = np.empty((n, 3)); nrm = np.empty((n, 3))
+    k = 0
+    for (o, eu, ev, fn, _), c in zip(faces, counts):
+        a = rng.random(c)[:, None]; b = rng.random(c)[:, None]
+        p = o + a * eu + b * ev + fn * rng.normal(0, noise, c)[:, None]
+        nn = fn + rng.normal(0, normal_jitter, (c, 3))
+        nn /= np.linalg.norm(nn, axis=1, keepdims=True)
+        pts[k:k + c] = p; nrm[k:k + c] = nn
+        k += c
+    pts[k:] = (rng.random((n_out, 3)) - 0.5) * ROOM
+    nn = rng.normal(size=(n_out, 3)); nn /= np.linalg.norm(nn, axis=1, keepdims=True)
+    nrm[k:] = nn
+    perm = rng.permutation(n)
+    return np.concatenate([pts[perm], nrm[perm]], axis=1).astype(np.float32)
+
+
+def random_se3(seed, max_t=5.0):
+    rng = np.random.default_rng(seed)
+    q = rng.normal(size=4); q /= np.linalg.norm(q)
+    w, x, y, z = q
+    R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                  [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                  [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+    T = np.eye(4)
+    T[:3, :3] = R
+    T[:3, 3] = rng.uniform(-max_t, max_t, 3)
+    return T
+
+
+def make_pair(n, seed=0, n_boxes=8, keep=0.6):
+    """Returns (target N x 6, source ~N x 6, T_gt 4x4) with T_gt mapping source -> target."""
+    target = sample_scene(n, scene_seed=1000 + seed, sample_seed=2 * seed + 1, n_boxes=n_boxes)
+    full = sample_scene(int(n / keep), scene_seed=1000 + seed, sample_seed=2 * seed + 2, n_boxes=n_boxes)
+    rng = np.random.default_rng(5000 + seed)
+    d = np.array([1.0, 0.35 * rng.uniform(-1, 1), 0.0]); d /= np.linalg.norm(d)
+    proj = full[:, :3] @ d
+    cut = np.quantile(proj, keep)
+    src_scene = full[proj <= cut]
+    T = random_se3(9000 + seed)  # source -> target
+    Ti = np.linalg.inv(T)
+    p = src_scene[:, :3].astype(np.float64) @ Ti[:3, :3].T + Ti[:3, 3]
+    nn = src_scene[:, 3:].astype(np.float64) @ Ti[:3, :3].T
+    source = np.concatenate([p, nn], axis=1).astype(np.float32)
+    return target, source, T.astype(np.float64)

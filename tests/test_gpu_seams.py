@@ -1,0 +1,102 @@
+"""Parity of the three seam kernels (S1a score, S2 match, S3 overlap) against the oracle,
+called through the C ABI of libplade_hip.so.  Bit-exact integer outputs."""
+import numpy as np
+import pytest
+
+from plade_amd.synth import sample_scene
+
+pytestmark = pytest.mark.gpu
+
+
+def _hyps(rng, cloud, h):
+    tri = cloud[rng.integers(0, len(cloud), (h, 3)), :3].reshape(h, 9)
+    return tri
+
+
+@pytest.mark.parametrize("n,h", [(1, 3), (1023, 5), (1024, 7), (1025, 130), (50000, 40)])
+def test_score_planes_bit_exact(ctx, oracle, n, h):
+    rng = np.random.default_rng(n + h)
+    cloud = sample_scene(max(n, 64), scene_seed=3, sample_seed=n)[:n]
+    si = np.full(n, -1, np.int32)
+    si[rng.random(n) < 0.2] = 2
+    planes = []
+    base = sample_scene(4096, scene_seed=3, sample_seed=99)
+    for t in _hyps(rng, base, h):
+        ok, pl = oracle.plane_from_points(t)
+        planes.append(pl if ok else np.array([0, 0, 1, 0.3], np.float32))
+    planes = np.array(planes, np.float32)
+    eps, cos_t = 0.05, 0.8
+    counts, lists = ctx.score_planes(cloud, si, planes, eps, cos_t, want_indices=True)
+    for j in range(h):
+        ref = oracle.score_plane(cloud, si, planes[j], eps, cos_t)
+        assert counts[j] == len(ref)
+        assert np.array_equal(lists[j], ref)
+    # no shape index
+    counts2 = ctx.score_planes(cloud, None, planes, eps, cos_t)
+    for j in range(min(h, 8)):
+        assert counts2[j] == len(oracle.score_plane(cloud, None, planes[j], eps, cos_t))
+
+
+def test_score_planes_empty(ctx):
+    counts = ctx.score_planes(np.zeros((0, 6), np.float32), None, np.array([[0, 0, 1, 0]], np.float32), 0.1, 0.8)
+    assert counts[0] == 0
+
+
+@pytest.mark.parametrize("dq,dt", [(0, 10), (7, 0), (300, 5000), (1000, 9000)])
+def test_match_descriptors_exact(ctx, oracle, dq, dt):
+    rng = np.random.default_rng(dq * 7 + dt)
+    t = (rng.random((dt, 8)) * 0.25).astype(np.float32)
+    if dt >= 200:
+        t[100:200] = t[0:100]  # exact duplicates -> distance ties
+    q = (rng.random((dq, 8)) * 0.25).astype(np.float32)
+    if dq and dt:
+        k = min(dq, dt) // 2
+        q[:k] = t[:k] + rng.normal(0, 0.01, (k, 8)).astype(np.float32)
+        q[-1] = t[0]
+    o1, n1, d1 = oracle.match_descriptors(q, t, 0.04)
+    o2, n2, d2 = ctx.match_descriptors(q, t, 0.04)
+    assert np.array_equal(o1, o2)
+    assert np.array_equal(n1, n2)
+    assert np.array_equal(d1, d2)  # fp64 distances bit-identical
+
+
+def test_match_radius_boundary(ctx, oracle):
+    # distances straddling r^2 = float(0.04f*0.04f): membership uses <= in double
+    r2 = float(np.float32(0.04) * np.float32(0.04))
+    base = np.zeros((1, 8), np.float32)
+    t = np.zeros((64, 8), np.float32)
+    for i in range(64):
+        t[i, 0] = np.float32(np.sqrt(r2)) + np.float32((i - 32) * 1e-9)
+    o1, n1, d1 = oracle.match_descriptors(base, t, 0.04)
+    o2, n2, d2 = ctx.match_descriptors(base, t, 0.04)
+    assert np.array_equal(n1, n2) and np.array_equal(d1, d2)
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_overlap_counts_bit_exact(ctx, oracle, seed):
+    rng = np.random.default_rng(seed)
+    cloud = sample_scene(60000, scene_seed=5, sample_seed=seed)
+    leaf = np.float32(0.12)
+    tg = oracle.voxel_downsample(cloud, leaf, 1)
+    sr = (tg + rng.normal(0, 0.03, tg.shape)).astype(np.float32)[:: 2]
+    K = 19
+    Ts, cs = [], []
+    for k in range(K):
+        ang = rng.normal(0, 0.03 if k % 3 else 0.5)
+        c, s = np.cos(ang), np.sin(ang)
+        T = np.eye(4, dtype=np.float32)
+        T[:2, :2] = [[c, -s], [s, c]]
+        T[:3, 3] = rng.normal(0, 0.1 if k % 2 else 2.0, 3)
+        Ts.append(T)
+        cs.append((T[:3, :3] @ np.array([0.1, 0.2, 0.0], np.float32) + T[:3, 3]).astype(np.float32))
+    Ts = np.array(Ts, np.float32)
+    cs = np.array(cs, np.float32)
+    # one candidate whose coarse sphere is empty
+    Ts[-1, :3, 3] = 500.0
+    cs[-1] = 500.0
+    radius = np.float32(4.0)
+    got = ctx.overlap_counts(sr, tg, Ts, cs, radius, leaf)
+    for k in range(K):
+        ref = oracle.overlap_count(sr, tg, Ts[k], cs[k], radius, leaf)
+        assert got[k] == ref, (k, got[k], ref)
+    assert got[-1] == -1
