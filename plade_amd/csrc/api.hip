@@ -1,5 +1,6 @@
 // plade_amd/csrc/api.hip -- context management and instrumentation entry points of the C ABI.
 #include "ctx.h"
+#include "pipeline.h"
 
 using namespace plade;
 
@@ -34,6 +35,7 @@ extern "C" void plade_ctx_destroy(plade_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->reg_work) plade::registration_work_destroy(ctx->reg_work);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

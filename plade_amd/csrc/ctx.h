@@ -9,7 +9,9 @@ namespace plade {
 struct CloudDev {
     uint32_t n = 0;
     DBuf<float> soa;  // 6 planes of n floats: x | y | z | nx | ny | nz  (each padded to 4)
+    DBuf<float> aos;  // the N x 6 input layout (x y z nx ny nz), kept for the gather-style stages
     size_t pitch = 0; // floats per plane (n rounded up to 4)
+    float bbmin[3] = {0, 0, 0}, bbmax[3] = {0, 0, 0};
     const float *x() const { return soa.p; }
     const float *y() const { return soa.p + pitch; }
     const float *z() const { return soa.p + 2 * pitch; }
@@ -38,8 +40,12 @@ struct plade_cloud {
     std::vector<float> host_copy;  // pos_nrm kept for the small host-side gathers
 };
 
+namespace plade { struct RegistrationWork; struct RansacWork; }
+
 struct plade_ctx {
     int device = 0;
+    plade::RegistrationWork *reg_work = nullptr;
+    plade::RansacWork *ransac_work = nullptr;
     hipStream_t stream = nullptr;
     plade_params params;
     std::string last_error;

@@ -13,6 +13,7 @@
 // __ballot + s_bcnt (one LDS write per wave per hypothesis, one global atomic per block per
 // hypothesis).  HBM-bound: 28 B per point per pass (12 pos + 12 normal + 4 shapeIndex).
 #include "score.h"
+#include "voxel.h"
 
 namespace plade {
 
@@ -245,10 +246,11 @@ void cloud_upload(plade_ctx *ctx, const float *pos_nrm, uint32_t n, CloudDev &ou
     out.pitch = ((size_t)n + 3) & ~(size_t)3;
     out.soa.ensure(6 * out.pitch + 4);
     if (n == 0) return;
-    float *stage = reinterpret_cast<float *>(ctx->scratch[0].ensure((size_t)n * 24));
+    float *stage = out.aos.ensure((size_t)n * 6 + 8);
     HIP_TRY(hipMemcpyAsync(stage, pos_nrm, (size_t)n * 24, hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(k_aos_to_soa, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, stage, n, out.pitch, out.soa.p);
     HIP_TRY(hipGetLastError());
+    bbox_host(ctx, stage, n, 6, out.bbmin, out.bbmax);
 }
 
 }  // namespace plade

@@ -1,0 +1,451 @@
+// plade_amd/csrc/pipeline.hip -- host orchestration of
+//   registration(T, target, source, target_planes, source_planes)   code/PLADE/plade.cpp:31-580
+// on one MI355X: every data-parallel stage is a HIP kernel (K1..K9, see the k_*.hip files); the host
+// keeps what the reference's host keeps -- control flow, the per-plane PCA boxes of the (small)
+// voxel-downsampled clouds, plane/plane intersection lines (P^2/2 of them) and the two std::sort
+// calls whose tie order is part of the result.
+#include "pipeline.h"
+#include "hostgeom.h"
+#include "prims.h"
+#include <algorithm>
+#include <numeric>
+
+namespace plade {
+
+namespace {
+
+struct LengthIndex { float length; int index; };   // util.h:347-350
+inline bool cmp_greater(const LengthIndex &a, const LengthIndex &b) { return a.length > b.length; }  // util.h:360-365
+
+__global__ void k_gather_rt(const float4 *__restrict__ rt, const uint32_t *__restrict__ ids, uint32_t n,
+                            float *__restrict__ out /* n x 12 */) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t k = ids[i];
+    const float4 r0 = rt[4 * (size_t)k], r1 = rt[4 * (size_t)k + 1], r2 = rt[4 * (size_t)k + 2];
+    float *o = out + 12 * (size_t)i;
+    o[0] = r0.x; o[1] = r0.y; o[2] = r0.z; o[3] = r1.x; o[4] = r1.y; o[5] = r1.z; o[6] = r2.x; o[7] = r2.y; o[8] = r2.z;
+    o[9] = r0.w; o[10] = r1.w; o[11] = r2.w;
+}
+
+__global__ void k_expand_groups(const uint32_t *__restrict__ offsets, uint32_t n_groups, uint32_t n_items,
+                                uint32_t *__restrict__ group_of) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_items) return;
+    uint32_t lo = 0, hi = n_groups;  // last g with offsets[g] <= i
+    while (hi - lo > 1) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (offsets[mid] <= i) lo = mid; else hi = mid;
+    }
+    group_of[i] = lo;
+}
+
+// per-cloud preparation: code/PLADE/plade.cpp:75-172 (target) / :290-381 (source)
+struct Side {
+    std::vector<float> ds;       // host copy of the whole-cloud downsample, n_ds x 3
+    DBuf<float> d_ds;            // device AoS
+    DBuf<float> d_ds_soa;        // device SoA x|y|z
+    uint32_t n_ds = 0;
+    f3 bcenter;
+    double radius = 0;
+    PlaneGeomHost geom;
+    PlaneCloudsDev pcl;
+    std::vector<float> plane_ds; // host copy
+    std::vector<float> normals;  // P x 3
+    LineTableHost lines;
+    VoxelWork vox_all, vox_planes;
+    DBuf<uint32_t> d_items, d_groups, d_offs;
+};
+
+void make_line_table(const float *coef, uint32_t P, f3 bcenter, double radius, LineTableHost &lt) {
+    lt = LineTableHost();
+    for (uint32_t i = 0; i < P; ++i)
+        for (uint32_t j = i + 1; j < P; ++j) {
+            f3 vec, pt;
+            if (!plane_plane_line(coef + 4 * (size_t)i, coef + 4 * (size_t)j, vec, pt)) continue;  // plade.cpp:133-136
+            // plade.cpp:137-142: drop lines farther than `radius` from the bounding-box centre
+            const f3 tv = pt - bcenter;
+            const double dt = dot_e(tv, vec);
+            const double distance = std::sqrt((double)sqn_e(tv) - dt * dt);
+            if (distance > radius) continue;
+            // two ComputeMeanDistanceOfLine2Plane calls (plade.cpp:146-154 -> util.h:396) re-normalise the vector
+            f3 v3 = normalized_e(normalized_e(vec));
+            // iterates 3, 4, ... until the sequence repeats
+            std::vector<f3> its;
+            its.push_back(v3);
+            int start = -1;
+            for (int it = 0; it < 64 && start < 0; ++it) {
+                f3 nx = normalized_e(its.back());
+                for (size_t s = 0; s < its.size(); ++s)
+                    if (its[s].x == nx.x && its[s].y == nx.y && its[s].z == nx.z) { start = (int)s; break; }
+                if (start < 0) its.push_back(nx);
+            }
+            PLADE_REQUIRE(start >= 0, PLADE_ELIMIT, "line direction normalisation did not settle");
+            lt.it_off.push_back((int32_t)(lt.iter.size() / 3));
+            lt.it_len.push_back((int32_t)its.size());
+            lt.it_start.push_back(start);
+            lt.it_period.push_back((int32_t)its.size() - start);
+            for (auto &v : its) { lt.iter.push_back(v.x); lt.iter.push_back(v.y); lt.iter.push_back(v.z); }
+            lt.pt.push_back(pt.x); lt.pt.push_back(pt.y); lt.pt.push_back(pt.z);
+            lt.sp.push_back((int32_t)i); lt.sp.push_back((int32_t)j);
+            ++lt.L;
+        }
+}
+
+bool prepare_side(plade_ctx *ctx, const char *tag, const CloudDev &cloud, const PlaneSetView &pl, float leaf, Side &S) {
+    const uint32_t P = pl.P;
+    // whole cloud: DownSamplePointCloud (plade.cpp:77-79 / :292-294)
+    S.n_ds = S.vox_all.run(ctx, cloud.aos.p, 6, nullptr, nullptr, cloud.n, 1, leaf, cloud.bbmin, cloud.bbmax);
+    if (S.n_ds == 0) return false;
+    S.ds.resize(3 * (size_t)S.n_ds);
+    S.d_ds.ensure(3 * (size_t)S.n_ds + 4);
+    S.d_ds_soa.ensure(3 * (size_t)S.n_ds + 4);
+    HIP_TRY(hipMemcpyAsync(S.d_ds.p, S.vox_all.out_xyz.p, 12 * (size_t)S.n_ds, hipMemcpyDeviceToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(S.ds.data(), S.vox_all.out_xyz.p, 12 * (size_t)S.n_ds, hipMemcpyDeviceToHost, ctx->stream));
+    deinterleave3(ctx, S.d_ds.p, S.n_ds, S.d_ds_soa.p, S.d_ds_soa.p + S.n_ds, S.d_ds_soa.p + 2 * (size_t)S.n_ds);
+    // per-plane clouds in one pass (plade.cpp:93-105 / :308-319)
+    const uint32_t n_items = (uint32_t)pl.offsets[P];
+    S.d_items.ensure((size_t)n_items + 4); S.d_groups.ensure((size_t)n_items + 4); S.d_offs.ensure((size_t)P + 2);
+    if (pl.d_idx) HIP_TRY(hipMemcpyAsync(S.d_items.p, pl.d_idx, 4 * (size_t)n_items, hipMemcpyDeviceToDevice, ctx->stream));
+    else HIP_TRY(hipMemcpyAsync(S.d_items.p, pl.idx, 4 * (size_t)n_items, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(S.d_offs.p, pl.offsets, 4 * ((size_t)P + 1), hipMemcpyHostToDevice, ctx->stream));
+    if (n_items)
+        hipLaunchKernelGGL(k_expand_groups, dim3(cdiv(n_items, 256)), dim3(256), 0, ctx->stream, S.d_offs.p, P, n_items,
+                           S.d_groups.p);
+    const uint32_t n_pds = S.vox_planes.run(ctx, cloud.aos.p, 6, S.d_items.p, S.d_groups.p, n_items, P, leaf, cloud.bbmin,
+                                            cloud.bbmax);
+    S.plane_ds.resize(3 * (size_t)n_pds);
+    S.pcl.off.resize((size_t)P + 1);
+    S.pcl.xyz.ensure(3 * (size_t)n_pds + 4);
+    S.pcl.d_off.ensure((size_t)P + 2);
+    HIP_TRY(hipMemcpyAsync(S.pcl.xyz.p, S.vox_planes.out_xyz.p, 12 * (size_t)n_pds, hipMemcpyDeviceToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(S.pcl.d_off.p, S.vox_planes.group_offsets.p, 4 * ((size_t)P + 1), hipMemcpyDeviceToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(S.plane_ds.data(), S.vox_planes.out_xyz.p, 12 * (size_t)n_pds, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(S.pcl.off.data(), S.vox_planes.group_offsets.p, 4 * ((size_t)P + 1), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    // ComputeBoundingBox of the whole downsampled cloud (plade.cpp:81-84 / :295-299)
+    Obb ob;
+    if (!oriented_bbox(S.ds.data(), S.n_ds, ob, false)) return false;
+    S.bcenter = ob.center;
+    S.radius = std::max(std::max(ob.width, ob.height), ob.depth) / 2;
+    // per plane (plade.cpp:106-117 / :320-330)
+    S.geom.P = P;
+    S.geom.coef.assign(pl.coef, pl.coef + 4 * (size_t)P);
+    S.geom.center.assign(3 * (size_t)P, 0.f);
+    S.geom.radius.assign(P, 0.f);
+    S.geom.four.assign(12 * (size_t)P, 0.f);
+    S.normals.resize(3 * (size_t)P);
+    for (uint32_t i = 0; i < P; ++i) {
+        for (int k = 0; k < 3; ++k) S.normals[3 * i + k] = pl.coef[4 * (size_t)i + k];
+        const uint32_t b = S.pcl.off[i], e = S.pcl.off[i + 1];
+        Obb pb;
+        if (!oriented_bbox(S.plane_ds.data() + 3 * (size_t)b, e - b, pb, true)) continue;  // empty plane: boxes stay zero
+        f3 four[4];
+        for (int k = 0; k < 4; ++k) {
+            four[k] = project_to_plane(pb.corners[k], pl.coef + 4 * (size_t)i);
+            S.geom.four[12 * (size_t)i + 3 * k] = four[k].x;
+            S.geom.four[12 * (size_t)i + 3 * k + 1] = four[k].y;
+            S.geom.four[12 * (size_t)i + 3 * k + 2] = four[k].z;
+        }
+        const f3 cen = (four[0] + four[2]) / 2.f;
+        S.geom.center[3 * i] = cen.x; S.geom.center[3 * i + 1] = cen.y; S.geom.center[3 * i + 2] = cen.z;
+        S.geom.radius[i] = norm_e(four[0] - four[2]) / 2.f;
+    }
+    make_line_table(pl.coef, P, S.bcenter, S.radius, S.lines);
+    if (ctx->params.dump) {
+        const std::string t(tag);
+        ctx->put(t + "_ds", S.ds.data(), S.ds.size());
+        ctx->put(t + "_bcenter", &S.bcenter.x, 3);
+        ctx->put1(t + "_radius", S.radius);
+        std::vector<float> pcr(4 * (size_t)P);
+        for (uint32_t i = 0; i < P; ++i) { for (int k = 0; k < 3; ++k) pcr[4 * i + k] = S.geom.center[3 * i + k]; pcr[4 * i + 3] = S.geom.radius[i]; }
+        ctx->put(t + "_plane_center_radius", pcr.data(), pcr.size());
+        ctx->put(t + "_plane_four", S.geom.four.data(), S.geom.four.size());
+        std::vector<int32_t> off(S.pcl.off.begin(), S.pcl.off.end());
+        ctx->put(t + "_plane_ds_offsets", off.data(), off.size());
+        ctx->put(t + "_plane_ds", S.plane_ds.data(), S.plane_ds.size());
+        std::vector<float> ld(8 * (size_t)S.lines.L);
+        for (uint32_t l = 0; l < S.lines.L; ++l) {
+            const float *v = &S.lines.iter[3 * (size_t)S.lines.it_off[l]];
+            ld[8 * l] = v[0]; ld[8 * l + 1] = v[1]; ld[8 * l + 2] = v[2];
+            ld[8 * l + 3] = S.lines.pt[3 * l]; ld[8 * l + 4] = S.lines.pt[3 * l + 1]; ld[8 * l + 5] = S.lines.pt[3 * l + 2];
+            ld[8 * l + 6] = (float)S.lines.sp[2 * l]; ld[8 * l + 7] = (float)S.lines.sp[2 * l + 1];
+        }
+        ctx->put(t + "_lines", ld.data(), ld.size());
+    }
+    return true;
+}
+
+}  // namespace
+
+struct RegistrationWork {
+    Side M, C;  // main (target), current (source)
+    PairTableDev tgt_pairs, src_pairs;
+    MatchResult match;
+    CandidateSet cand;
+    TargetGrid grid;
+    DBuf<uint32_t> d_ids;
+    DBuf<float> d_rt12, d_T16, d_centers;
+    DBuf<int32_t> d_counts;
+    DBuf<uint32_t> d_any;
+};
+
+RegistrationWork *registration_work_create() { return new RegistrationWork; }
+void registration_work_destroy(RegistrationWork *w) { delete w; }
+
+bool run_registration(plade_ctx *ctx, RegistrationWork &W, const CloudDev &tgt, const CloudDev &src,
+                      const PlaneSetView &tp, const PlaneSetView &sp, float *T16_out) {
+    for (int i = 0; i < 16; ++i) T16_out[i] = (i % 5 == 0) ? 1.f : 0.f;
+    const int max_candidates = ctx->params.max_candidates;
+    Side &M = W.M, &C = W.C;
+
+    // plade.cpp:41
+    float average_space;
+    {
+        StageTimer t(ctx, "t_spacing");
+        average_space = average_spacing_dev(ctx, src.x(), src.y(), src.z(), src.n, 6, 10000);
+    }
+    ctx->put1("average_spacing", average_space);
+    // plade.cpp:46-56
+    const float downSampleDistance = average_space * 4;
+    const float lengthThreshold = average_space * 5;
+    const float angleThreshold = 5.0 / 180 * M_PI;
+    const float cosAngleThreshold = cos(angleThreshold);
+    const float scale = lengthThreshold / cos(M_PI_2 - angleThreshold);
+    ctx->put1("scale", scale);
+
+    {
+        StageTimer t(ctx, "t_prepare");
+        if (!prepare_side(ctx, "tgt", tgt, tp, downSampleDistance, M)) return false;
+        if (!prepare_side(ctx, "src", src, sp, downSampleDistance, C)) return false;
+    }
+    {
+        StageTimer t(ctx, "t_descriptors");
+        build_pair_table(ctx, M.lines, M.normals.data(), tp.P, scale, true, W.tgt_pairs);
+        build_pair_table(ctx, C.lines, C.normals.data(), sp.P, scale, false, W.src_pairs);
+        if (ctx->params.dump) {
+            ctx->put_dev("tgt_desc", W.tgt_pairs.desc.p, 8 * (size_t)W.tgt_pairs.count);
+            ctx->put_dev("src_desc", W.src_pairs.desc.p, 8 * (size_t)W.src_pairs.count);
+        }
+    }
+    uint64_t n_match;
+    {
+        StageTimer t(ctx, "t_match");
+        n_match = W.match.run(ctx, W.src_pairs.desc.p, W.src_pairs.count, W.tgt_pairs.desc.p, W.tgt_pairs.count, 0.04f);
+        if (ctx->params.dump) {
+            ctx->put_dev("match_offsets", W.match.offsets.p, (size_t)W.src_pairs.count + 1);
+            ctx->put_dev("match_nbr", (const int32_t *)W.match.t_idx.p, n_match);
+            ctx->put_dev("match_dist2", W.match.dist2.p, n_match);
+        }
+    }
+    ctx->stats.add("n_descriptors_tgt", W.tgt_pairs.count);
+    ctx->stats.add("n_descriptors_src", W.src_pairs.count);
+    ctx->stats.add("n_matches", (double)n_match);
+    PLADE_REQUIRE(n_match < (1ull << 31), PLADE_ELIMIT, "too many descriptor matches");
+    {
+        StageTimer t(ctx, "t_transforms");
+        build_transforms(ctx, W.src_pairs, W.tgt_pairs, W.match.q_idx_sorted, W.match.t_idx.p, (uint32_t)n_match, W.cand);
+        if (ctx->params.dump && n_match) {
+            std::vector<float4> h(4 * (size_t)n_match);
+            HIP_TRY(hipMemcpy(h.data(), W.cand.rt.p, 64 * (size_t)n_match, hipMemcpyDeviceToHost));
+            std::vector<float> rt(12 * (size_t)n_match);
+            for (size_t i = 0; i < n_match; ++i) {
+                for (int r = 0; r < 3; ++r) {
+                    rt[12 * i + 3 * r] = h[4 * i + r].x; rt[12 * i + 3 * r + 1] = h[4 * i + r].y; rt[12 * i + 3 * r + 2] = h[4 * i + r].z;
+                    rt[12 * i + 9 + r] = h[4 * i + r].w;
+                }
+            }
+            ctx->put("initial_RT", rt.data(), rt.size());
+        }
+    }
+    std::vector<uint32_t> seeds, sizes;
+    std::vector<int32_t> pcounts;
+    {
+        StageTimer t(ctx, "t_cluster");
+        // util.cpp:331: ClusterTransformation(Rs, Ts, lengthThreshold / 2, angleThreshold / 2) with the
+        // Parameter fields held as double
+        const float distanceThreshold = (float)((double)lengthThreshold / 2);
+        const float g_angle = (float)((double)angleThreshold / 2);
+        cluster_transforms(ctx, W.cand, distanceThreshold, g_angle);
+    }
+    const uint32_t nC = W.cand.n_clusters;
+    ctx->stats.add("n_clusters", nC);
+    {
+        StageTimer t(ctx, "t_plane_consistency");
+        const float sbc[3] = {C.bcenter.x, C.bcenter.y, C.bcenter.z}, tbc[3] = {M.bcenter.x, M.bcenter.y, M.bcenter.z};
+        plane_consistency(ctx, W.cand, C.geom, M.geom, sbc, tbc, (float)M.radius, (float)(double)cosAngleThreshold,
+                          lengthThreshold);
+        seeds.resize(nC); sizes.resize(nC); pcounts.resize(nC);
+        if (nC) {
+            HIP_TRY(hipMemcpyAsync(seeds.data(), W.cand.seeds.p, 4 * (size_t)nC, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(hipMemcpyAsync(sizes.data(), W.cand.sizes.p, 4 * (size_t)nC, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(hipMemcpyAsync(pcounts.data(), W.cand.plane_counts.p, 4 * (size_t)nC, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+        }
+    }
+    if (ctx->params.dump) {
+        std::vector<int32_t> a(sizes.begin(), sizes.end()), b(seeds.begin(), seeds.end());
+        ctx->put("cluster_sizes", a.data(), a.size());
+        ctx->put("cluster_seeds", b.data(), b.size());
+    }
+    // util.cpp:335-401: clusters by size (std::sort with myCompareGreater), centre gate, plane counts
+    std::vector<int> cand_cluster;   // cluster index per entry of `matches`
+    std::vector<int> match_counts;
+    {
+        StageTimer t(ctx, "t_host_select");
+        std::vector<LengthIndex> sortVec(nC);
+        for (uint32_t i = 0; i < nC; ++i) { sortVec[i].index = (int)i; sortVec[i].length = (float)sizes[i]; }
+        std::sort(sortVec.begin(), sortVec.end(), cmp_greater);
+        cand_cluster.reserve(nC);
+        match_counts.reserve(nC);
+        for (uint32_t i = 0; i < nC; ++i) {
+            const int c = sortVec[i].index;
+            if (pcounts[c] < 0) continue;
+            cand_cluster.push_back(c);
+            match_counts.push_back(pcounts[c]);
+        }
+    }
+    ctx->put("plane_match_counts", match_counts.data(), match_counts.size());
+    // util.cpp:403-445
+    size_t maxMatchNum = 0;
+    for (int v : match_counts) maxMatchNum = std::max(maxMatchNum, (size_t)v);
+    std::vector<std::vector<int>> matchedPlanes;
+    if (maxMatchNum > 0) {
+        int matchedCount = 0;
+        for (size_t i = maxMatchNum; i >= 2; i--) {
+            std::vector<int> tmp;
+            for (size_t j = 0; j < match_counts.size(); ++j)
+                if (i == (size_t)match_counts[j]) { tmp.push_back((int)j); matchedCount++; }
+            matchedPlanes.push_back(tmp);
+            if (matchedCount >= max_candidates) break;
+        }
+    }
+    // util.cpp:449-459: at most max_candidates + 1 candidates reach the penetration test
+    std::vector<int> tested;
+    {
+        int count = 0;
+        bool stop = false;
+        for (size_t m = 0; m < matchedPlanes.size() && !stop; ++m)
+            for (size_t i = 0; i < matchedPlanes[m].size(); ++i) {
+                if (count++ > max_candidates) { stop = true; break; }
+                tested.push_back(matchedPlanes[m][i]);
+            }
+    }
+    const uint32_t K = (uint32_t)tested.size();
+    ctx->put("pen_tested", tested.data(), tested.size());
+    ctx->stats.add("n_candidates_tested", K);
+    if (K == 0) return false;
+    // fetch the (R, T) of the tested candidates
+    std::vector<float> rt12(12 * (size_t)K);
+    {
+        std::vector<uint32_t> ids(K);
+        for (uint32_t i = 0; i < K; ++i) ids[i] = seeds[cand_cluster[tested[i]]];
+        W.d_ids.ensure(K);
+        W.d_rt12.ensure(12 * (size_t)K);
+        HIP_TRY(hipMemcpyAsync(W.d_ids.p, ids.data(), 4 * (size_t)K, hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(k_gather_rt, dim3(cdiv(K, 64)), dim3(64), 0, ctx->stream, W.cand.rt.p, W.d_ids.p, K, W.d_rt12.p);
+        HIP_TRY(hipMemcpyAsync(rt12.data(), W.d_rt12.p, 48 * (size_t)K, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    std::vector<int32_t> penflags;
+    {
+        StageTimer t(ctx, "t_penetration");
+        penetration_filter(ctx, rt12.data(), K, C.geom, M.geom, C.pcl, M.pcl, lengthThreshold, angleThreshold, penflags);
+    }
+    ctx->put("pen_flags", penflags.data(), penflags.size());
+    // survivors = MatchedResult list (util.cpp:513-517)
+    std::vector<uint32_t> surv;
+    for (uint32_t i = 0; i < K; ++i) if (!penflags[i]) surv.push_back(i);
+    const uint32_t Kv = (uint32_t)surv.size();
+    ctx->stats.add("n_candidates_verified", Kv);
+    if (Kv == 0) return false;  // plade.cpp:537-540
+    // plade.cpp:545-575 verification
+    std::vector<float> T16(16 * (size_t)Kv), centers(3 * (size_t)Kv);
+    for (uint32_t i = 0; i < Kv; ++i) {
+        const float *r = &rt12[12 * (size_t)surv[i]];
+        float *T = &T16[16 * (size_t)i];
+        m3 R;
+        for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) { R.m[a][b] = r[3 * a + b]; T[4 * a + b] = r[3 * a + b]; }
+        T[3] = r[9]; T[7] = r[10]; T[11] = r[11];
+        T[12] = T[13] = T[14] = 0.f; T[15] = 1.f;
+        const f3 cc = mul_e(R, C.bcenter) + f3(r[9], r[10], r[11]);  // plade.cpp:555
+        centers[3 * i] = cc.x; centers[3 * i + 1] = cc.y; centers[3 * i + 2] = cc.z;
+    }
+    std::vector<int32_t> counts(Kv);
+    {
+        StageTimer t(ctx, "t_verify");
+        W.d_T16.ensure(16 * (size_t)Kv); W.d_centers.ensure(3 * (size_t)Kv); W.d_counts.ensure(Kv); W.d_any.ensure(Kv);
+        HIP_TRY(hipMemcpyAsync(W.d_T16.p, T16.data(), 64 * (size_t)Kv, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(W.d_centers.p, centers.data(), 12 * (size_t)Kv, hipMemcpyHostToDevice, ctx->stream));
+        W.grid.build(ctx, M.d_ds.p, M.n_ds, 3, downSampleDistance);
+        overlap_counts(ctx, C.d_ds_soa.p, C.d_ds_soa.p + C.n_ds, C.d_ds_soa.p + 2 * (size_t)C.n_ds, C.n_ds, W.grid, W.d_T16.p,
+                       W.d_centers.p, Kv, (float)C.radius, downSampleDistance, W.d_counts.p, W.d_any.p);
+        std::vector<uint32_t> any(Kv);
+        HIP_TRY(hipMemcpyAsync(counts.data(), W.d_counts.p, 4 * (size_t)Kv, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(any.data(), W.d_any.p, 4 * (size_t)Kv, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        for (uint32_t i = 0; i < Kv; ++i) if (!any[i]) counts[i] = -1;
+    }
+    std::vector<LengthIndex> ov(Kv);
+    std::vector<float> scores(Kv);
+    const size_t denom = std::min<size_t>(C.n_ds, M.n_ds);
+    for (uint32_t i = 0; i < Kv; ++i) {
+        float ratio = 0.f;
+        if (counts[i] >= 0) ratio = (float)(double(counts[i]) / denom);                     // util.h:644
+        const int matched = match_counts[tested[surv[i]]];
+        ov[i].index = (int)i;
+        ov[i].length = (float)(0.2 * (matched / double(sp.P)) + 0.8 * ratio);               // plade.cpp:561-562
+        scores[i] = ov[i].length;
+    }
+    ctx->put("candidates", T16.data(), T16.size());
+    ctx->put("candidate_centers", centers.data(), centers.size());
+    ctx->put("overlap_counts", counts.data(), counts.size());
+    ctx->put("scores", scores.data(), scores.size());
+    std::sort(ov.begin(), ov.end(), cmp_greater);                                             // plade.cpp:565
+    const int best = ov[0].index;
+    ctx->put1("best_index", (int32_t)best);
+    memcpy(T16_out, &T16[16 * (size_t)best], 64);
+    // roofline bookkeeping: algorithmic bytes of the verify stage
+    ctx->stats.add("bytes_verify", (double)Kv * C.n_ds * 12.0 + (double)M.n_ds * 12.0);
+    return true;
+}
+
+}  // namespace plade
+
+using namespace plade;
+
+static void validate_planes(const float *coef, const int32_t *off, const int32_t *idx, uint32_t P, uint32_t n, const char *who) {
+    PLADE_REQUIRE(coef && off && (idx || off[P] == 0), PLADE_EINVAL, std::string(who) + ": null plane arrays");
+    PLADE_REQUIRE(off[0] == 0, PLADE_EINVAL, std::string(who) + ": offsets[0] must be 0");
+    for (uint32_t i = 0; i < P; ++i) PLADE_REQUIRE(off[i + 1] >= off[i], PLADE_EINVAL, std::string(who) + ": offsets must be non-decreasing");
+    for (int32_t i = 0; i < off[P]; ++i) PLADE_REQUIRE(idx[i] >= 0 && (uint32_t)idx[i] < n, PLADE_EINVAL, std::string(who) + ": point index out of range");
+}
+
+// ---- C ABI: plade.h:74-79 ---------------------------------------------------------------------
+extern "C" int plade_registration_planes(plade_ctx *ctx, const float *tgt_pos_nrm, uint32_t n_t, const float *src_pos_nrm,
+                                         uint32_t n_s, const float *tgt_planes, const int32_t *tgt_offsets,
+                                         const int32_t *tgt_idx, uint32_t p_t, const float *src_planes,
+                                         const int32_t *src_offsets, const int32_t *src_idx, uint32_t p_s, float *T16) {
+    return guarded(ctx, [&]() -> int {
+        PLADE_REQUIRE(tgt_pos_nrm && src_pos_nrm && T16 && n_t && n_s, PLADE_EINVAL, "plade_registration_planes: bad cloud arguments");
+        validate_planes(tgt_planes, tgt_offsets, tgt_idx, p_t, n_t, "target planes");
+        validate_planes(src_planes, src_offsets, src_idx, p_s, n_s, "source planes");
+        ctx->stats.clear();
+        ctx->dump.clear();
+        if (!ctx->reg_work) ctx->reg_work = registration_work_create();
+        CloudDev tgt, src;
+        {
+            StageTimer t(ctx, "t_upload");
+            cloud_upload(ctx, tgt_pos_nrm, n_t, tgt);
+            cloud_upload(ctx, src_pos_nrm, n_s, src);
+        }
+        PlaneSetView tp, sp;
+        tp.coef = tgt_planes; tp.offsets = tgt_offsets; tp.idx = tgt_idx; tp.P = p_t;
+        sp.coef = src_planes; sp.offsets = src_offsets; sp.idx = src_idx; sp.P = p_s;
+        Clock::time_point t0 = Clock::now();
+        const bool ok = run_registration(ctx, *ctx->reg_work, tgt, src, tp, sp, T16);
+        ctx->stats.add("t_registration", secs_since(t0));
+        if (!ok) { ctx->last_error = "registration failed: no matched result found"; return PLADE_EFAIL; }
+        return PLADE_OK;
+    });
+}

@@ -1,0 +1,86 @@
+// plade_amd/csrc/stages.h -- device stages of registration(T, target, source, target_planes,
+// source_planes) (code/PLADE/plade.cpp:31-580) between the seam kernels.
+#pragma once
+#include "ctx.h"
+#include "geom.h"
+
+namespace plade {
+
+// ---- K4: intersection-line pair tables + "22" descriptors ----------------------
+// Host-prepared line table.  The reference re-normalises the stored direction vector in place
+// every time a line takes part in ComputeNearstTwoPointsOfTwo3DLine (util.cpp:1171-1172 through
+// non-const references), so a pair (i, j) sees the k-th normalisation iterate of each line with k
+// depending on the call order.  `iter` holds, per line, the iterates number 3, 4, ... until the
+// sequence repeats (fixed point: period 1); iterate k >= 3 is iter[off + idx(k)].
+struct LineTableHost {
+    std::vector<float> pt;        // L x 3
+    std::vector<int32_t> sp;      // L x 2 support planes
+    std::vector<float> iter;      // concatenated iterates (x,y,z)
+    std::vector<int32_t> it_off, it_len, it_start, it_period;  // per line
+    uint32_t L = 0;
+};
+
+struct PairTableDev {
+    uint32_t count = 0;           // D: number of descriptors kept
+    DBuf<float> desc;             // D x 8
+    DBuf<float> lv1, lv2, p1;     // D x 3 each: PAIRLINE::lineVec1, lineVec2, linePoints1
+    // scratch
+    DBuf<float> all_desc, all_lv1, all_lv2, all_p1;
+    DBuf<uint32_t> flags, pos;
+    DBuf<float> d_pt, d_iter, d_normals;
+    DBuf<int32_t> d_sp, d_it;
+};
+
+// target = true: all ordered pairs i != j (ConstructPairLinesKdTree, util.cpp:774-826);
+// target = false: pairs i < j (plade.cpp:454-482, 511-521; util.cpp:133-168).
+void build_pair_table(plade_ctx *ctx, const LineTableHost &lt, const float *normals /*P x 3 host*/, uint32_t P,
+                      float scale, bool target, PairTableDev &out);
+
+// ---- K6 + clustering + K7 ---------------------------------------------------------------------
+struct CandidateSet {
+    uint32_t m = 0;               // initial transforms (one per match)
+    DBuf<float4> rt;              // m x 4 float4: rows of [R | T] then (roll, pitch, yaw, 0)
+    uint32_t n_clusters = 0;
+    DBuf<uint32_t> parent, sizes_all, seeds, sizes;  // seeds/sizes: n_clusters, seed ascending
+    DBuf<uint32_t> flags, pos;
+    DBuf<uint64_t> ckeys, ckeys2, ucell_keys;
+    DBuf<uint32_t> cvals, cvals2, ucell_start, cflags, cpos;
+    DBuf<int32_t> plane_counts;   // per cluster (seed order): matched plane pairs, -1 = centre gate failed
+};
+
+// one (R, T) per (query, neighbour) in match order (util.cpp:303-327)
+void build_transforms(plade_ctx *ctx, const PairTableDev &src, const PairTableDev &tgt, const uint32_t *d_q_idx,
+                      const uint32_t *d_t_idx, uint32_t m, CandidateSet &cs);
+// ClusterTransformation (util.cpp:1245-1277): connected components under
+// |T_a - T_b|^2 < float(r^2)  &&  |euler_a - euler_b|^2 < angle_gate
+void cluster_transforms(plade_ctx *ctx, CandidateSet &cs, float dist_threshold, float angle_gate);
+
+struct PlaneGeomHost {            // per cloud side
+    std::vector<float> coef;      // P x 4
+    std::vector<float> center;    // P x 3
+    std::vector<float> radius;    // P
+    std::vector<float> four;      // P x 4 x 3
+    uint32_t P = 0;
+};
+// plane-consistency count per cluster seed (util.cpp:359-401)
+void plane_consistency(plade_ctx *ctx, CandidateSet &cs, const PlaneGeomHost &src, const PlaneGeomHost &tgt,
+                       const float src_bcenter[3], const float tgt_bcenter[3], float max_radius, float cos_angle_th,
+                       float length_threshold);
+
+// ---- penetration filter (util.cpp:450-519, AreTwoPlanesPenetrable :1279-1458) -------------------
+struct PlaneCloudsDev {           // per-plane voxel-downsampled points, concatenated
+    DBuf<float> xyz;              // total x 3
+    std::vector<uint32_t> off;    // P + 1 (host)
+    DBuf<uint32_t> d_off;
+};
+// flags_out[k] = 1 when candidate k has a penetrating plane pair
+void penetration_filter(plade_ctx *ctx, const float *cand_rt_host /*K x 12: R row-major, T*/, uint32_t K,
+                        const PlaneGeomHost &src, const PlaneGeomHost &tgt, const PlaneCloudsDev &src_pts,
+                        const PlaneCloudsDev &tgt_pts, float length_threshold, float angle_threshold,
+                        std::vector<int32_t> &flags_out);
+
+// generic: positions of set flags (ordered); returns count (sync)
+uint32_t compact_flags(plade_ctx *ctx, const uint32_t *d_flags, uint32_t n, DBuf<uint32_t> &pos_scratch,
+                       DBuf<uint32_t> &out_idx);
+
+}  // namespace plade

@@ -1,0 +1,24 @@
+// plade_amd/csrc/voxel.h -- K9 voxel-grid downsampling and average spacing.
+#pragma once
+#include "ctx.h"
+
+namespace plade {
+
+struct VoxelWork {
+    uint32_t n_out = 0;
+    DBuf<uint64_t> keys, keys2;
+    DBuf<uint32_t> vals, vals2, flags, seg, heads, seg_group, group_offsets;
+    DBuf<float> out_xyz;  // n_out x 3, ordered by (group, k, j, i)
+    // items: item i refers to point item_point[i] (or i when null) of the strided xyz array and
+    // belongs to group item_group[i] (or 0).  Items of a voxel are summed in ascending item order.
+    uint32_t run(plade_ctx *ctx, const float *d_xyz, uint32_t stride, const uint32_t *d_item_point,
+                 const uint32_t *d_item_group, uint32_t n_items, uint32_t n_groups, float leaf,
+                 const float bbox_min[3], const float bbox_max[3]);
+};
+
+float average_spacing_dev(plade_ctx *ctx, const float *d_x, const float *d_y, const float *d_z, uint32_t n, int k,
+                          uint32_t samples);
+// min/max of a strided device xyz array, returned on the host
+void bbox_host(plade_ctx *ctx, const float *d_xyz, uint32_t n, uint32_t stride, float mn[3], float mx[3]);
+
+}  // namespace plade

@@ -74,7 +74,9 @@ def _faces(scene_seed, n_boxes):
     return out
 
 
-def sample_scene(n, scene_seed=0, sample_seed=1, n_boxes=8, noise=0.005, normal_jitter=0.02, outliers=0.03):
+def sample_scene(n, scene_seed=0, sample_seed=1, n_boxes=8, noise=0.005, normal_jitter=0.02, outliers=0.03,
+                 return_labels=False):
+    """N x 6 float32 cloud; with return_labels also the generating face id per point (-1 = outlier)."""
     faces = _faces(scene_seed, n_boxes)
     rng = np.random.default_rng(sample_seed)
     n_out = int(round(n * outliers))
@@ -84,8 +86,10 @@ def sample_scene(n, scene_seed=0, sample_seed=1, n_boxes=8, noise=0.005, normal_
     counts = np.floor(w * n_in).astype(int)
     counts[0] += n_in - counts.sum()
     pts = np.empty((n, 3)); nrm = np.empty((n, 3))
+    labels = np.full(n, -1, np.int32)
     k = 0
-    for (o, eu, ev, fn, _), c in zip(faces, counts):
+    for fi, ((o, eu, ev, fn, _), c) in enumerate(zip(faces, counts)):
+        labels[k:k + c] = fi
         a = rng.random(c)[:, None]; b = rng.random(c)[:, None]
         p = o + a * eu + b * ev + fn * rng.normal(0, noise, c)[:, None]
         nn = fn + rng.normal(0, normal_jitter, (c, 3))
@@ -96,7 +100,10 @@ def sample_scene(n, scene_seed=0, sample_seed=1, n_boxes=8, noise=0.005, normal_
     nn = rng.normal(size=(n_out, 3)); nn /= np.linalg.norm(nn, axis=1, keepdims=True)
     nrm[k:] = nn
     perm = rng.permutation(n)
-    return np.concatenate([pts[perm], nrm[perm]], axis=1).astype(np.float32)
+    cloud = np.concatenate([pts[perm], nrm[perm]], axis=1).astype(np.float32)
+    if return_labels:
+        return cloud, labels[perm]
+    return cloud
 
 
 def random_se3(seed, max_t=5.0):
@@ -112,18 +119,45 @@ def random_se3(seed, max_t=5.0):
     return T
 
 
-def make_pair(n, seed=0, n_boxes=8, keep=0.6):
-    """Returns (target N x 6, source ~N x 6, T_gt 4x4) with T_gt mapping source -> target."""
-    target = sample_scene(n, scene_seed=1000 + seed, sample_seed=2 * seed + 1, n_boxes=n_boxes)
-    full = sample_scene(int(n / keep), scene_seed=1000 + seed, sample_seed=2 * seed + 2, n_boxes=n_boxes)
+def planes_from_labels(cloud, labels, min_points=50):
+    """Ground-truth plane sets for the planes-given boundary (plade.h:74): per generating face an
+    LS plane (unit n oriented like the mean point normal, d = -n.mean) and its point index list.
+    Returns (coef P x 4 float32, offsets P+1 int32, idx int32)."""
+    coef, offs, idx = [], [0], []
+    for f in np.unique(labels[labels >= 0]):
+        ids = np.nonzero(labels == f)[0].astype(np.int32)
+        if len(ids) < min_points:
+            continue
+        p = cloud[ids, :3].astype(np.float64)
+        c = p.mean(0)
+        _, _, vt = np.linalg.svd(p - c, full_matrices=False)
+        nrm = vt[2]
+        if cloud[ids, 3:].astype(np.float64).mean(0) @ nrm < 0:
+            nrm = -nrm
+        coef.append([nrm[0], nrm[1], nrm[2], -(nrm @ c)])
+        idx.append(ids)
+        offs.append(offs[-1] + len(ids))
+    return (np.asarray(coef, np.float32), np.asarray(offs, np.int32),
+            np.concatenate(idx).astype(np.int32) if idx else np.zeros(0, np.int32))
+
+
+def make_pair(n, seed=0, n_boxes=8, keep=0.6, return_labels=False):
+    """Returns (target N x 6, source ~N x 6, T_gt 4x4) with T_gt mapping source -> target
+    (+ the per-point face labels of both clouds when return_labels)."""
+    target, tl = sample_scene(n, scene_seed=1000 + seed, sample_seed=2 * seed + 1, n_boxes=n_boxes, return_labels=True)
+    full, fl = sample_scene(int(n / keep), scene_seed=1000 + seed, sample_seed=2 * seed + 2, n_boxes=n_boxes,
+                            return_labels=True)
     rng = np.random.default_rng(5000 + seed)
     d = np.array([1.0, 0.35 * rng.uniform(-1, 1), 0.0]); d /= np.linalg.norm(d)
     proj = full[:, :3] @ d
     cut = np.quantile(proj, keep)
     src_scene = full[proj <= cut]
+    sl = fl[proj <= cut]
     T = random_se3(9000 + seed)  # source -> target
     Ti = np.linalg.inv(T)
     p = src_scene[:, :3].astype(np.float64) @ Ti[:3, :3].T + Ti[:3, 3]
     nn = src_scene[:, 3:].astype(np.float64) @ Ti[:3, :3].T
     source = np.concatenate([p, nn], axis=1).astype(np.float32)
+    if return_labels:
+        return target, source, T.astype(np.float64), tl, sl
     return target, source, T.astype(np.float64)
