@@ -1,6 +1,7 @@
 // plade_amd/csrc/api.hip -- context management and instrumentation entry points of the C ABI.
 #include "ctx.h"
 #include "pipeline.h"
+#include "ransac.h"
 
 using namespace plade;
 
@@ -36,6 +37,7 @@ extern "C" void plade_ctx_destroy(plade_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->reg_work) plade::registration_work_destroy(ctx->reg_work);
+    if (ctx->ransac_work) plade::ransac_work_destroy(ctx->ransac_work);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

@@ -51,6 +51,35 @@ struct plade_ctx {
     std::string last_error;
     std::map<std::string, std::vector<char>> dump;
     plade::Stats stats;
+    // optional per-kernel timing with HIP events on this ctx's stream (params.dump & 2)
+    struct EvRec { hipEvent_t a, b; std::string tag; double bytes; };
+    std::vector<EvRec> evs;
+    bool profiling() const { return (params.dump & 2) != 0; }
+    void ev_begin(const char *tag, double bytes) {
+        if (!profiling()) return;
+        EvRec r;
+        r.tag = tag; r.bytes = bytes;
+        (void)hipEventCreate(&r.a); (void)hipEventCreate(&r.b);
+        (void)hipEventRecord(r.a, stream);
+        evs.push_back(r);
+    }
+    void ev_end() {
+        if (!profiling() || evs.empty()) return;
+        (void)hipEventRecord(evs.back().b, stream);
+    }
+    void ev_collect() {
+        if (evs.empty()) return;
+        (void)hipStreamSynchronize(stream);
+        for (auto &r : evs) {
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, r.a, r.b);
+            stats.add("k_" + r.tag + "_seconds", ms * 1e-3);
+            stats.add("k_" + r.tag + "_launches", 1.0);
+            stats.add("k_" + r.tag + "_bytes", r.bytes);
+            (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
+        }
+        evs.clear();
+    }
     // generic scratch
     plade::DBuf<char> scratch[8];
     plade::HBuf<char> pinned[4];

@@ -214,8 +214,11 @@ void overlap_counts(plade_ctx *ctx, const float *d_sx, const float *d_sy, const 
     }
     if (n_s) {
         dim3 gr(cdiv(n_s, OV_TPB), cdiv(K, OV_KCH));
+        // algorithmic bytes: K * n_s * 12 B source stream + n_t * 12 B target
+        ctx->ev_begin("overlap", (double)K * n_s * 12.0 + (double)grid.n * 12.0);
         hipLaunchKernelGGL(k_overlap, gr, dim3(OV_TPB), 0, ctx->stream, d_sx, d_sy, d_sz, n_s, grid.sorted.p,
                            grid.cell_start.p, grid.cell_end.p, g, d_T, d_centers, K, R2, r2, d_counts);
+        ctx->ev_end();
     }
     HIP_TRY(hipGetLastError());
 }

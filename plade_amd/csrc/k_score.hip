@@ -201,8 +201,11 @@ void score_multi(plade_ctx *ctx, const float *x, const float *y, const float *z,
     HIP_TRY(hipMemsetAsync(counts_dev, 0, sizeof(uint32_t) * h, ctx->stream));
     if (n == 0 || h == 0) return;
     dim3 grid(cdiv(n, TILE), cdiv(h, HCHUNK));
+    // algorithmic bytes: 12 pos + 12 normal + 4 shapeIndex per point per pass
+    ctx->ev_begin(sub_index ? "score_subset" : "score_multi", 28.0 * n);
     hipLaunchKernelGGL(k_score_multi, grid, dim3(TPB), 0, ctx->stream, x, y, z, nx, ny, nz, assigned, sub_index, n,
                        planes_dev, h, eps, cos_thresh, counts_dev);
+    ctx->ev_end();
     HIP_TRY(hipGetLastError());
 }
 
@@ -225,8 +228,10 @@ void score_compact(plade_ctx *ctx, CompactScratch &s, const float *x, const floa
     if (nb == 0) { HIP_TRY(hipMemsetAsync(count_dev, 0, 4, ctx->stream)); return; }
     s.masks.ensure((size_t)nb * TPB);
     s.block_counts.ensure(nb);
+    ctx->ev_begin("score_mark", 28.0 * n);
     hipLaunchKernelGGL(k_score_mark, dim3(nb), dim3(TPB), 0, ctx->stream, x, y, z, nx, ny, nz, assigned, n, plane_dev,
                        eps, cos_thresh, s.masks.p, s.block_counts.p);
+    ctx->ev_end();
     compact_masks(ctx, s, n, nullptr, idx_out_dev, count_dev);
 }
 

@@ -24,6 +24,8 @@ void registration_work_destroy(RegistrationWork *w);
 
 // registration(T, target, source, target_planes, source_planes) (code/PLADE/plade.cpp:31-580).
 // Returns false where the reference returns false.
+double ctx_stat(plade_ctx *ctx, const char *name);
+
 bool run_registration(plade_ctx *ctx, RegistrationWork &W, const CloudDev &tgt, const CloudDev &src,
                       const PlaneSetView &tp, const PlaneSetView &sp, float *T16_out);
 

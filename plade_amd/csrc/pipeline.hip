@@ -445,6 +445,7 @@ extern "C" int plade_registration_planes(plade_ctx *ctx, const float *tgt_pos_nr
         Clock::time_point t0 = Clock::now();
         const bool ok = run_registration(ctx, *ctx->reg_work, tgt, src, tp, sp, T16);
         ctx->stats.add("t_registration", secs_since(t0));
+        ctx->ev_collect();
         if (!ok) { ctx->last_error = "registration failed: no matched result found"; return PLADE_EFAIL; }
         return PLADE_OK;
     });

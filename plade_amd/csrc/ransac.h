@@ -1,0 +1,31 @@
+// plade_amd/csrc/ransac.h -- GPU plane extraction (seam S1b).
+#pragma once
+#include "ctx.h"
+
+namespace plade {
+
+struct RansacParams {
+    uint32_t min_support = 10000;
+    float dist_rel = 0.005f, bitmap_rel = 0.02f, cos_thresh = 0.8f, overlook_p = 0.001f;  // plade.cpp:607
+    int orient_normals = 1;
+    uint64_t seed = 0;
+};
+
+struct PlaneSetOut {
+    std::vector<float> coef;       // P x 4 (unit n, d = -n.p)
+    std::vector<int32_t> offsets;  // P + 1
+    std::vector<int32_t> idx;      // original point indices
+    const uint32_t *d_idx = nullptr;  // the same list on the device (valid until the next detect on this work area)
+    uint32_t n_score_passes = 0;   // full-array K1 passes issued (roofline bookkeeping)
+    uint32_t remaining = 0;
+    uint32_t P() const { return (uint32_t)(coef.size() / 4); }
+};
+
+struct RansacWork;
+RansacWork *ransac_work_create();
+void ransac_work_destroy(RansacWork *w);
+
+// PlaneExtraction::detect (code/PLADE/plane_extraction.cpp:173-200)
+void ransac_detect(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const RansacParams &rp, PlaneSetOut &out);
+
+}  // namespace plade

@@ -1,0 +1,785 @@
+// plade_amd/csrc/ransac.hip -- plane extraction on one MI355X (seam S1b).
+//
+// Replaces PlaneExtraction::detect (code/PLADE/plane_extraction.cpp:61-200) and the
+// RansacShapeDetector::Detect loop it drives (code/3rd_party/ransac/RansacShapeDetector.cpp:455-907).
+// The reference is a sequential, time-seeded Efficient-RANSAC over octrees; it cannot reproduce its
+// own output run to run, so parity is pinned per kernel (same hypothesis => identical inliers,
+// identical connected component, LS plane within the reference's own accumulation noise) and at the
+// plane-set level.  This is a GPU-native driver with the same semantics per accepted plane:
+//
+//   sampling   : DrawSamplesStratified (RansacShapeDetector.cpp:909-954) -- first point anywhere,
+//                the other two from the same octree cell at a random level.  Here the cloud is
+//                Morton-sorted once and "the cell at level l" is a contiguous key range.
+//   hypothesis : Plane::Init(p1,p2,p3) (ransac/Plane.cpp:29-38) + the 3-sample verification
+//                (RansacShapeDetector.cpp:143-153).
+//   scoring    : K1 (k_score.hip).  Schnabel scores lazily on nested random subsets to save CPU
+//                time; on the GPU a batch of H hypotheses is scored on a stratified subset in one
+//                launch and the leaders are re-scored on ALL unassigned points in one HBM pass.
+//   acceptance : exactly the reference's sequence (RansacShapeDetector.cpp:618-675):
+//                GlobalScore(3 eps) -> ConnectedComponent(bitmap eps) -> up to 3 x
+//                { LSFit -> GlobalWeightedScore(3 eps) } keeping a refit only if its weighted score
+//                and size improve -> points marked assigned, drawnCandidates scaled by (1-|S|/n)^3.
+//   stopping   : CandidateFailureProbability(minSupport, n_remaining, drawn, levels) <= p
+//                (RansacShapeDetector.h:61-67, .cpp:856-858).
+#include "ransac.h"
+#include "score.h"
+#include "prims.h"
+#include "voxel.h"
+#include <algorithm>
+
+namespace plade {
+
+// ------------------------------------------------------------------------------------------------
+// Morton order
+__device__ __forceinline__ uint32_t spread3(uint32_t v) {  // 10 bits -> every third bit
+    v = (v | (v << 16)) & 0x030000FF;
+    v = (v | (v << 8)) & 0x0300F00F;
+    v = (v | (v << 4)) & 0x030C30C3;
+    v = (v | (v << 2)) & 0x09249249;
+    return v;
+}
+
+__global__ void k_morton(const float *__restrict__ x, const float *__restrict__ y, const float *__restrict__ z,
+                         uint32_t n, float mnx, float mny, float mnz, float inv_cube, uint32_t *__restrict__ keys,
+                         uint32_t *__restrict__ vals) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t qx = min(1023u, (uint32_t)max(0.f, (x[i] - mnx) * inv_cube * 1024.f));
+    const uint32_t qy = min(1023u, (uint32_t)max(0.f, (y[i] - mny) * inv_cube * 1024.f));
+    const uint32_t qz = min(1023u, (uint32_t)max(0.f, (z[i] - mnz) * inv_cube * 1024.f));
+    keys[i] = (spread3(qz) << 2) | (spread3(qy) << 1) | spread3(qx);
+    vals[i] = i;
+}
+
+__global__ void k_gather_cloud(const float *__restrict__ src, size_t spitch, const uint32_t *__restrict__ perm, uint32_t n,
+                               float *__restrict__ dst, size_t dpitch) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t p = perm[i];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) dst[k * dpitch + i] = src[k * spitch + p];
+}
+
+__global__ void k_make_subset(const float *__restrict__ src, size_t spitch, uint32_t n, uint32_t stride, uint32_t n_sub,
+                              float *__restrict__ dst, size_t dpitch, uint32_t *__restrict__ sub_index) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_sub) return;
+    const uint32_t p = min(n - 1, i * stride);
+    sub_index[i] = p;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) dst[k * dpitch + i] = src[k * spitch + p];
+}
+
+// ------------------------------------------------------------------------------------------------
+// hypothesis sampling
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+struct Rng {
+    uint64_t s;
+    __device__ uint32_t next() { s = mix64(s); return (uint32_t)(s >> 32); }
+};
+
+__device__ __forceinline__ uint32_t lb_u32(const uint32_t *a, uint32_t n, uint32_t key) {
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (a[mid] < key) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+
+struct CloudView {
+    const float *x, *y, *z, *nx, *ny, *nz;
+    uint32_t n;
+};
+
+__global__ __launch_bounds__(256) void k_sample(CloudView c, const uint32_t *__restrict__ codes,
+                                                const int32_t *__restrict__ assigned, uint64_t seed, uint32_t round,
+                                                uint32_t h, int min_level, int max_level, float eps, float cos_t,
+                                                float4 *__restrict__ hyp, float4 *__restrict__ hyp_pos) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= h) return;
+    Rng rng{mix64(seed ^ ((uint64_t)round << 32) ^ t)};
+    const float nanv = __int_as_float(0x7fc00000);
+    hyp[t] = make_float4(0.f, 0.f, 0.f, nanv);
+    hyp_pos[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    uint32_t i0 = 0;
+    bool ok = false;
+    for (int tr = 0; tr < 64 && !ok; ++tr) { i0 = rng.next() % c.n; ok = assigned[i0] == -1; }
+    if (!ok) return;
+    const int level = min_level + (int)(rng.next() % (uint32_t)(max_level - min_level + 1));
+    const uint32_t low_bits = 30 - 3 * level;
+    const uint32_t mask = low_bits >= 32 ? 0u : ~((1u << low_bits) - 1u);
+    const uint32_t lo_key = codes[i0] & mask, hi_key = lo_key | ~mask;
+    const uint32_t lo = lb_u32(codes, c.n, lo_key);
+    uint32_t hi = (hi_key == 0xffffffffu || hi_key >= 0x3fffffffu) ? c.n : lb_u32(codes, c.n, hi_key + 1u);
+    if (hi - lo < 3) return;
+    uint32_t s[3] = {i0, 0, 0};
+    for (int k = 1; k < 3; ++k) {
+        bool got = false;
+        for (int tr = 0; tr < 40 && !got; ++tr) {
+            const uint32_t j = lo + rng.next() % (hi - lo);
+            if (assigned[j] != -1) continue;
+            bool dup = false;
+            for (int q = 0; q < k; ++q) dup = dup || (s[q] == j);
+            if (dup) continue;
+            s[k] = j;
+            got = true;
+        }
+        if (!got) return;
+    }
+    // Plane::Init (ransac/Plane.cpp:29-38)
+    const float p1[3] = {c.x[s[0]], c.y[s[0]], c.z[s[0]]}, p2[3] = {c.x[s[1]], c.y[s[1]], c.z[s[1]]},
+                p3[3] = {c.x[s[2]], c.y[s[2]], c.z[s[2]]};
+    const float a[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]}, b[3] = {p3[0] - p2[0], p3[1] - p2[1], p3[2] - p2[2]};
+    float nr[3] = {a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]};
+    float sq = nr[0] * nr[0];
+    sq += nr[1] * nr[1];
+    sq += nr[2] * nr[2];
+    if (sq < 1E-6f) return;
+    const float len = sqrtf(sq);
+    nr[0] /= len; nr[1] /= len; nr[2] /= len;
+    float dist = p1[0] * nr[0];
+    dist += p1[1] * nr[1];
+    dist += p1[2] * nr[2];
+    // verify the three samples (RansacShapeDetector.cpp:143-153)
+    for (int k = 0; k < 3; ++k) {
+        float d = nr[0] * c.x[s[k]];
+        d += nr[1] * c.y[s[k]];
+        d += nr[2] * c.z[s[k]];
+        float nd = nr[0] * c.nx[s[k]];
+        nd += nr[1] * c.ny[s[k]];
+        nd += nr[2] * c.nz[s[k]];
+        if (!(fabsf(dist - d) < eps && fabsf(nd) >= cos_t)) return;
+    }
+    hyp[t] = make_float4(nr[0], nr[1], nr[2], dist);
+    hyp_pos[t] = make_float4(p1[0], p1[1], p1[2], 1.f);
+}
+
+__global__ void k_count_unassigned(const int32_t *__restrict__ assigned, const uint32_t *__restrict__ sub_index,
+                                   uint32_t n, uint32_t *__restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool un = false;
+    if (i < n) un = assigned[sub_index ? sub_index[i] : i] == -1;
+    const uint32_t c = (uint32_t)__popcll(__ballot(un));
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+}
+
+// ------------------------------------------------------------------------------------------------
+// plane state on the device: everything the acceptance sequence needs without a host round trip
+struct PlaneState {
+    float n[3], pos[3], dist;        // Plane (ransac/Plane.h: m_normal, m_pos, m_dist)
+    float a0[3], a1[3];              // HyperplaneCoordinateSystem axes (GfxTL/HyperplaneCoordinateSystem.h:81-93)
+    int bb[4];                       // ordered-int (min u, min v, max u, max v)
+    uint32_t ue, ve;
+    uint32_t best_root, n_fg;
+    double wscore;
+    float nsum[3];                   // sum of inlier point normals (orientation)
+    uint32_t err;
+};
+
+__device__ __forceinline__ void hcs_axes(const float *n, float *a0, float *a1) {
+    float t[3];
+    if (fabsf(n[0]) < 0.015625f && fabsf(n[1]) < 0.015625f) {  // (0,1,0) x n
+        t[0] = 1.f * n[2] - 0.f * n[1]; t[1] = 0.f * n[0] - 0.f * n[2]; t[2] = 0.f * n[1] - 1.f * n[0];
+    } else {                                                      // (0,0,1) x n
+        t[0] = 0.f * n[2] - 1.f * n[1]; t[1] = 1.f * n[0] - 0.f * n[2]; t[2] = 0.f * n[1] - 0.f * n[0];
+    }
+    float l = t[0] * t[0];
+    l += t[1] * t[1];
+    l += t[2] * t[2];
+    l = sqrtf(l);
+    a0[0] = t[0] / l; a0[1] = t[1] / l; a0[2] = t[2] / l;
+    float u[3] = {n[1] * a0[2] - n[2] * a0[1], n[2] * a0[0] - n[0] * a0[2], n[0] * a0[1] - n[1] * a0[0]};
+    l = u[0] * u[0];
+    l += u[1] * u[1];
+    l += u[2] * u[2];
+    l = sqrtf(l);
+    a1[0] = u[0] / l; a1[1] = u[1] / l; a1[2] = u[2] / l;
+}
+
+__device__ __forceinline__ int ord_i(float f) { int v = __float_as_int(f); return v >= 0 ? v : v ^ 0x7fffffff; }
+__device__ __forceinline__ float ord_f(int v) { return __int_as_float(v >= 0 ? v : v ^ 0x7fffffff); }
+
+// initialise the state from a hypothesis (n, dist) + position
+__global__ void k_state_from_hyp(const float4 *__restrict__ hyp, const float4 *__restrict__ pos, PlaneState *st,
+                                 float4 *plane_out) {
+    if (threadIdx.x || blockIdx.x) return;
+    st->n[0] = hyp->x; st->n[1] = hyp->y; st->n[2] = hyp->z; st->dist = hyp->w;
+    st->pos[0] = pos->x; st->pos[1] = pos->y; st->pos[2] = pos->z;
+    hcs_axes(st->n, st->a0, st->a1);
+    st->err = 0;
+    *plane_out = *hyp;
+}
+
+__global__ void k_cc_begin(PlaneState *st) {
+    if (threadIdx.x || blockIdx.x) return;
+    st->bb[0] = st->bb[1] = ord_i(INFINITY);
+    st->bb[2] = st->bb[3] = ord_i(-INFINITY);
+    st->nsum[0] = st->nsum[1] = st->nsum[2] = 0.f;
+}
+
+// (u, v) parameters of the inliers + their bounding box (PlanePrimitiveShape::Parameters,
+// ransac/PlanePrimitiveShape.h:97-109; bbox BitmapPrimitiveShape.h:113-126)
+__global__ __launch_bounds__(256) void k_cc_params(CloudView c, const uint32_t *__restrict__ idx,
+                                                   const uint32_t *__restrict__ count, PlaneState *st,
+                                                   float2 *__restrict__ uv) {
+    const uint32_t m = *count;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    float u = INFINITY, v = INFINITY, U = -INFINITY, V = -INFINITY;
+    if (i < m) {
+        const uint32_t p = idx[i];
+        const float pp[3] = {c.x[p] - st->pos[0], c.y[p] - st->pos[1], c.z[p] - st->pos[2]};
+        u = pp[0] * st->a0[0] + pp[1] * st->a0[1] + pp[2] * st->a0[2];
+        v = pp[0] * st->a1[0] + pp[1] * st->a1[1] + pp[2] * st->a1[2];
+        uv[i] = make_float2(u, v);
+        U = u; V = v;
+    }
+    for (int d = 32; d >= 1; d >>= 1) {
+        u = fminf(u, __shfl_xor(u, d, 64)); v = fminf(v, __shfl_xor(v, d, 64));
+        U = fmaxf(U, __shfl_xor(U, d, 64)); V = fmaxf(V, __shfl_xor(V, d, 64));
+    }
+    if ((threadIdx.x & 63) == 0 && u != INFINITY) {
+        atomicMin(&st->bb[0], ord_i(u)); atomicMin(&st->bb[1], ord_i(v));
+        atomicMax(&st->bb[2], ord_i(U)); atomicMax(&st->bb[3], ord_i(V));
+    }
+}
+
+constexpr uint32_t CC_MAXPIX = 1u << 20;
+
+// BitmapExtent (PlanePrimitiveShape.cpp:185-191) + clear
+__global__ void k_cc_dims(PlaneState *st, const uint32_t *__restrict__ count, float eps, uint8_t *__restrict__ bmp) {
+    __shared__ uint32_t s_pix;
+    if (threadIdx.x == 0) {
+        uint32_t ue = 2, ve = 2;
+        if (*count) {
+            const float mnu = ord_f(st->bb[0]), mnv = ord_f(st->bb[1]), mxu = ord_f(st->bb[2]), mxv = ord_f(st->bb[3]);
+            const float fu = ceilf((mxu - mnu) / eps), fv = ceilf((mxv - mnv) / eps);
+            ue = (fu < 4.0e6f ? (uint32_t)fu : 4000000u) + 1;
+            ve = (fv < 4.0e6f ? (uint32_t)fv : 4000000u) + 1;
+            if (ue < 2) ue = 2;
+            if (ve < 2) ve = 2;
+        }
+        if ((uint64_t)ue * ve > CC_MAXPIX) { st->err = 1; ue = ve = 2; }
+        st->ue = ue; st->ve = ve;
+        s_pix = ue * ve;
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < s_pix; i += blockDim.x) bmp[i] = 0;
+}
+
+// BuildBitmap (BitmapPrimitiveShape.h:139-150) with InBitmap (PlanePrimitiveShape.cpp:193-199)
+__global__ __launch_bounds__(256) void k_cc_raster(const float2 *__restrict__ uv, const uint32_t *__restrict__ count,
+                                                   const PlaneState *st, float eps, uint32_t *__restrict__ bidx,
+                                                   uint8_t *__restrict__ bmp) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= *count) return;
+    const float mnu = ord_f(st->bb[0]), mnv = ord_f(st->bb[1]);
+    int bu = (int)floorf((uv[i].x - mnu) / eps), bv = (int)floorf((uv[i].y - mnv) / eps);
+    bu = min(max(bu, 0), (int)st->ue - 1);
+    bv = min(max(bv, 0), (int)st->ve - 1);
+    const uint32_t b = (uint32_t)bu + (uint32_t)bv * st->ue;
+    bidx[i] = b;
+    bmp[b] = 1;
+}
+
+// closing (DilateCross + ErodeCross, ransac/Bitmap.cpp:154-260, 459-570; no wrapping for planes),
+// 8-connected labelling (Components, Bitmap.cpp:633-834) and selection of the component with most
+// pixels, first in raster order on ties (BitmapPrimitiveShape.cpp:168-173).  One workgroup.
+__global__ __launch_bounds__(1024) void k_cc_label(PlaneState *st, uint8_t *__restrict__ bmp, uint8_t *__restrict__ tmp,
+                                                   uint32_t *__restrict__ label, uint32_t *__restrict__ sizes,
+                                                   int do_filter) {
+    __shared__ int s_changed;
+    __shared__ unsigned long long s_best;
+    const int ue = (int)st->ue, ve = (int)st->ve, npx = ue * ve;
+    if (do_filter) {
+        for (int p = threadIdx.x; p < npx; p += blockDim.x) {
+            const int u = p % ue, v = p / ue;
+            bool r = bmp[p];
+            if (u > 0) r = r || bmp[p - 1];
+            if (u < ue - 1) r = r || bmp[p + 1];
+            if (v > 0) r = r || bmp[p - ue];
+            if (v < ve - 1) r = r || bmp[p + ue];
+            tmp[p] = r;
+        }
+        __syncthreads();
+        for (int p = threadIdx.x; p < npx; p += blockDim.x) {
+            const int u = p % ue, v = p / ue;
+            bool r = tmp[p];
+            if (u > 0) r = r && tmp[p - 1];
+            if (u < ue - 1) r = r && tmp[p + 1];
+            if (v > 0) r = r && tmp[p - ue];
+            if (v < ve - 1) r = r && tmp[p + ue];
+            bmp[p] = r;
+        }
+        __syncthreads();
+    }
+    for (int p = threadIdx.x; p < npx; p += blockDim.x) { label[p] = bmp[p] ? (uint32_t)p : 0xffffffffu; sizes[p] = 0; }
+    __syncthreads();
+    for (int iter = 0; iter < 4096; ++iter) {
+        if (threadIdx.x == 0) s_changed = 0;
+        __syncthreads();
+        for (int p = threadIdx.x; p < npx; p += blockDim.x) {
+            if (!bmp[p]) continue;
+            const int u = p % ue, v = p / ue;
+            const uint32_t lab = label[p];
+            uint32_t mn = lab;
+            for (int dv = -1; dv <= 1; ++dv)
+                for (int du = -1; du <= 1; ++du) {
+                    const int uu = u + du, vv = v + dv;
+                    if (uu < 0 || vv < 0 || uu >= ue || vv >= ve) continue;
+                    const int q = vv * ue + uu;
+                    if (bmp[q]) mn = min(mn, label[q]);
+                }
+            if (mn < lab) { atomicMin(&label[lab], mn); s_changed = 1; }
+        }
+        __syncthreads();
+        for (int p = threadIdx.x; p < npx; p += blockDim.x) {
+            if (!bmp[p]) continue;
+            uint32_t r = label[p];
+            while (label[r] != r) r = label[r];
+            label[p] = r;
+        }
+        __syncthreads();
+        if (!s_changed) break;
+        __syncthreads();
+    }
+    for (int p = threadIdx.x; p < npx; p += blockDim.x)
+        if (bmp[p]) atomicAdd(&sizes[label[p]], 1u);
+    if (threadIdx.x == 0) s_best = 0ull;
+    __syncthreads();
+    for (int p = threadIdx.x; p < npx; p += blockDim.x)
+        if (bmp[p] && label[p] == (uint32_t)p) {
+            // max size, then smallest raster-first pixel
+            const unsigned long long key = ((unsigned long long)sizes[p] << 32) | (0xffffffffu - (uint32_t)p);
+            atomicMax(&s_best, key);
+        }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (s_best == 0ull) { st->best_root = 0xffffffffu; st->n_fg = 0; }
+        else { st->best_root = 0xffffffffu - (uint32_t)(s_best & 0xffffffffu); st->n_fg = (uint32_t)(s_best >> 32); }
+    }
+}
+
+// mask layout of k_compact: one byte per lane covering 4 consecutive items, block counts per 1024
+__global__ __launch_bounds__(256) void k_cc_select(const uint32_t *__restrict__ bidx, const uint32_t *__restrict__ count,
+                                                   const PlaneState *st, const uint32_t *__restrict__ label,
+                                                   uint8_t *__restrict__ masks, uint32_t *__restrict__ block_counts) {
+    __shared__ uint32_t s_w[4];
+    const uint32_t m = *count, best = st->best_root;
+    const uint32_t base = blockIdx.x * 1024 + threadIdx.x * 4;
+    uint32_t mk = 0, c = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t i = base + k;
+        const bool in = i < m && best != 0xffffffffu && label[bidx[i]] == best;
+        mk |= (in ? 1u : 0u) << k;
+        c += (uint32_t)__popcll(__ballot(in));
+    }
+    masks[blockIdx.x * 256 + threadIdx.x] = (uint8_t)mk;
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) block_counts[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+
+// ------------------------------------------------------------------------------------------------
+// LS refit (PlanePrimitiveShape::LSFit -> Plane::LeastSquaresFit, ransac/Plane.cpp:169-176,
+// Plane.h:65-74: mean + covariance about the mean + smallest-|eigenvalue| eigenvector).
+// Accumulated in fp64 with a fixed reduction tree (deterministic); the reference accumulates in
+// fp32 sequentially, which is the noisier of the two.
+constexpr int FIT_BLOCKS = 256;
+
+__global__ __launch_bounds__(256) void k_fit_partial(CloudView c, const uint32_t *__restrict__ idx,
+                                                     const uint32_t *__restrict__ count, double *__restrict__ part /* FIT_BLOCKS x 12 */) {
+    __shared__ double s[4][12];
+    const uint32_t m = *count;
+    double a[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
+        const uint32_t p = idx[i];
+        const double x = c.x[p], y = c.y[p], z = c.z[p];
+        a[0] += x; a[1] += y; a[2] += z;
+        a[3] += x * x; a[4] += x * y; a[5] += x * z; a[6] += y * y; a[7] += y * z; a[8] += z * z;
+        a[9] += c.nx[p]; a[10] += c.ny[p]; a[11] += c.nz[p];
+    }
+    for (int k = 0; k < 12; ++k)
+        for (int d = 32; d >= 1; d >>= 1) a[k] += __shfl_xor(a[k], d, 64);
+    if ((threadIdx.x & 63) == 0) for (int k = 0; k < 12; ++k) s[threadIdx.x >> 6][k] = a[k];
+    __syncthreads();
+    if (threadIdx.x < 12) part[blockIdx.x * 12 + threadIdx.x] = (s[0][threadIdx.x] + s[1][threadIdx.x]) + (s[2][threadIdx.x] + s[3][threadIdx.x]);
+}
+
+__device__ void jacobi3_d(double a[3][3], double d[3], double v[3][3]) {
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) v[i][j] = i == j;
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        const double off = fabs(a[0][1]) + fabs(a[0][2]) + fabs(a[1][2]);
+        if (off < 1e-300) break;
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                if (fabs(a[p][q]) < 1e-300) continue;
+                const double theta = (a[q][q] - a[p][p]) / (2 * a[p][q]);
+                const double t = (theta >= 0 ? 1 : -1) / (fabs(theta) + sqrt(theta * theta + 1));
+                const double cs = 1 / sqrt(t * t + 1), sn = t * cs;
+                for (int k = 0; k < 3; ++k) { const double akp = a[k][p], akq = a[k][q]; a[k][p] = cs * akp - sn * akq; a[k][q] = sn * akp + cs * akq; }
+                for (int k = 0; k < 3; ++k) { const double apk = a[p][k], aqk = a[q][k]; a[p][k] = cs * apk - sn * aqk; a[q][k] = sn * apk + cs * aqk; }
+                for (int k = 0; k < 3; ++k) { const double vkp = v[k][p], vkq = v[k][q]; v[k][p] = cs * vkp - sn * vkq; v[k][q] = sn * vkp + cs * vkq; }
+            }
+    }
+    for (int i = 0; i < 3; ++i) d[i] = a[i][i];
+}
+
+// mode 0: write the fitted plane into `st` / plane_out.  mode 1: only accumulate the normal sum
+// (orientation of the final plane).
+__global__ void k_fit_final(const double *__restrict__ part, const uint32_t *__restrict__ count, PlaneState *st,
+                            float4 *plane_out, int mode) {
+    if (threadIdx.x || blockIdx.x) return;
+    double a[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int b = 0; b < FIT_BLOCKS; ++b) for (int k = 0; k < 12; ++k) a[k] += part[b * 12 + k];
+    st->nsum[0] = (float)a[9]; st->nsum[1] = (float)a[10]; st->nsum[2] = (float)a[11];
+    if (mode == 1) return;
+    const double m = (double)*count;
+    if (m < 3) { st->err = 2; return; }
+    const double mx = a[0] / m, my = a[1] / m, mz = a[2] / m;
+    double cv[3][3];
+    cv[0][0] = a[3] / m - mx * mx; cv[0][1] = a[4] / m - mx * my; cv[0][2] = a[5] / m - mx * mz;
+    cv[1][1] = a[6] / m - my * my; cv[1][2] = a[7] / m - my * mz; cv[2][2] = a[8] / m - mz * mz;
+    cv[1][0] = cv[0][1]; cv[2][0] = cv[0][2]; cv[2][1] = cv[1][2];
+    double ev[3], vec[3][3];
+    jacobi3_d(cv, ev, vec);
+    int mi = 0;
+    for (int i = 1; i < 3; ++i) if (fabs(ev[i]) < fabs(ev[mi])) mi = i;
+    const float n[3] = {(float)vec[0][mi], (float)vec[1][mi], (float)vec[2][mi]};
+    st->n[0] = n[0]; st->n[1] = n[1]; st->n[2] = n[2];
+    st->pos[0] = (float)mx; st->pos[1] = (float)my; st->pos[2] = (float)mz;
+    float dist = st->pos[0] * n[0];   // Plane(p1, normal): m_dist = m_pos.dot(m_normal) (Plane.cpp:21-26)
+    dist += st->pos[1] * n[1];
+    dist += st->pos[2] * n[2];
+    st->dist = dist;
+    hcs_axes(st->n, st->a0, st->a1);
+    *plane_out = make_float4(n[0], n[1], n[2], dist);
+}
+
+// Candidate::WeightedScore (ransac/Candidate.cpp:77-87) with weigh() (ScoreComputer.h:10-16)
+__global__ __launch_bounds__(256) void k_wscore_partial(CloudView c, const uint32_t *__restrict__ idx,
+                                                        const uint32_t *__restrict__ count, const PlaneState *st,
+                                                        float eps, double *__restrict__ part) {
+    __shared__ double s[4];
+    const uint32_t m = *count;
+    const float n0 = st->n[0], n1 = st->n[1], n2 = st->n[2], dist = st->dist;
+    double acc = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
+        const uint32_t p = idx[i];
+        float d = n0 * c.x[p];
+        d += n1 * c.y[p];
+        d += n2 * c.z[p];
+        d = fabsf(dist - d);
+        acc += (double)expf(-d * d / (2.f / 9.f * eps * eps));
+    }
+    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = (s[0] + s[1]) + (s[2] + s[3]);
+}
+__global__ void k_wscore_final(const double *__restrict__ part, PlaneState *st) {
+    if (threadIdx.x || blockIdx.x) return;
+    double a = 0;
+    for (int b = 0; b < FIT_BLOCKS; ++b) a += part[b];
+    st->wscore = a;
+}
+
+__global__ void k_assign(const uint32_t *__restrict__ idx, uint32_t m, int32_t id, int32_t *__restrict__ assigned) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) assigned[idx[i]] = id;
+}
+__global__ void k_map_indices(const uint32_t *__restrict__ idx, uint32_t m, const uint32_t *__restrict__ orig,
+                              int32_t *__restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) out[i] = (int32_t)orig[idx[i]];
+}
+__global__ void k_fill_i32(int32_t *p, uint32_t n, int32_t v) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+// ------------------------------------------------------------------------------------------------
+struct RansacWork {
+    CloudDev sorted;
+    DBuf<uint32_t> codes, codes_in, vals_in, orig;
+    DBuf<int32_t> assigned;
+    DBuf<float> sub;
+    size_t sub_pitch = 0;
+    DBuf<uint32_t> sub_index;
+    uint32_t n_sub = 0;
+    DBuf<float4> hyp, hyp_pos, top, top_pos, plane_cur;
+    DBuf<uint32_t> hyp_counts, top_counts, misc;
+    DBuf<PlaneState> st;
+    CompactScratch cs, cs2;
+    DBuf<uint32_t> idxA, idxB, idxC, cntA, cntB;
+    DBuf<float2> uv;
+    DBuf<uint32_t> bidx, label, sizes;
+    DBuf<uint8_t> bmp, tmp;
+    DBuf<double> part;
+    DBuf<int32_t> out_idx;
+};
+
+RansacWork *ransac_work_create() { return new RansacWork; }
+void ransac_work_destroy(RansacWork *w) { delete w; }
+
+namespace {
+
+struct Accepted {
+    float coef[4];
+    uint32_t support;
+    uint32_t offset;   // into out_idx
+};
+
+// one GlobalWeightedScore: score(3 eps) -> connected component -> weighted score; result in idx_out
+void global_weighted_score(plade_ctx *ctx, RansacWork &W, const CloudView &cv, float eps3, float cos_t, float bitmap_eps,
+                           uint32_t *idx_out, uint32_t *cnt_out) {
+    const CloudDev &c = W.sorted;
+    score_compact(ctx, W.cs, c.x(), c.y(), c.z(), c.nx(), c.ny(), c.nz(), W.assigned.p, c.n, W.plane_cur.p, eps3, cos_t,
+                  W.idxA.p, W.cntA.p);
+    // ConnectedComponent (Candidate.cpp:89-94 -> BitmapPrimitiveShape.cpp:157-205), doFiltering = true
+    const uint32_t nb = cdiv(c.n, 256);
+    hipLaunchKernelGGL(k_cc_begin, dim3(1), dim3(1), 0, ctx->stream, W.st.p);
+    hipLaunchKernelGGL(k_cc_params, dim3(nb), dim3(256), 0, ctx->stream, cv, W.idxA.p, W.cntA.p, W.st.p, W.uv.p);
+    hipLaunchKernelGGL(k_cc_dims, dim3(1), dim3(1024), 0, ctx->stream, W.st.p, W.cntA.p, bitmap_eps, W.bmp.p);
+    hipLaunchKernelGGL(k_cc_raster, dim3(nb), dim3(256), 0, ctx->stream, W.uv.p, W.cntA.p, W.st.p, bitmap_eps, W.bidx.p, W.bmp.p);
+    hipLaunchKernelGGL(k_cc_label, dim3(1), dim3(1024), 0, ctx->stream, W.st.p, W.bmp.p, W.tmp.p, W.label.p, W.sizes.p, 1);
+    const uint32_t nb4 = cdiv(c.n, 1024);
+    W.cs2.masks.ensure((size_t)nb4 * 256);
+    W.cs2.block_counts.ensure(nb4);
+    hipLaunchKernelGGL(k_cc_select, dim3(nb4), dim3(256), 0, ctx->stream, W.bidx.p, W.cntA.p, W.st.p, W.label.p, W.cs2.masks.p,
+                       W.cs2.block_counts.p);
+    compact_masks(ctx, W.cs2, c.n, W.idxA.p, idx_out, cnt_out);
+    hipLaunchKernelGGL(k_wscore_partial, dim3(FIT_BLOCKS), dim3(256), 0, ctx->stream, cv, idx_out, cnt_out, W.st.p, eps3, W.part.p);
+    hipLaunchKernelGGL(k_wscore_final, dim3(1), dim3(1), 0, ctx->stream, W.part.p, W.st.p);
+    HIP_TRY(hipGetLastError());
+}
+
+}  // namespace
+
+void ransac_detect(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const RansacParams &rp, PlaneSetOut &out) {
+    const uint32_t n = cloud.n;
+    out.coef.clear(); out.offsets.assign(1, 0); out.idx.clear(); out.d_idx = nullptr;
+    if (n < 3) return;
+    // ---- scale exactly as plane_extraction.cpp:71-80 + PointCloud.h:94-98 (Z bug: maxZ stays
+    //      -FLT_MAX, so the Z extent is -inf-ish and never wins the max) --------------------------
+    const float scale = std::max(cloud.bbmax[0] - cloud.bbmin[0], cloud.bbmax[1] - cloud.bbmin[1]);
+    const float eps = rp.dist_rel * scale, bitmap_eps = rp.bitmap_rel * scale, cos_t = rp.cos_thresh;
+    const float eps3 = 3 * eps;   // RansacShapeDetector.cpp:471-473
+    PLADE_REQUIRE(eps > 0.f && bitmap_eps > 0.f, PLADE_EINVAL, "plane extraction: degenerate bounding box");
+
+    // ---- Morton order -------------------------------------------------------------------------
+    W.codes_in.ensure(n); W.vals_in.ensure(n); W.codes.ensure(n); W.orig.ensure(n);
+    const float cube = std::max({cloud.bbmax[0] - cloud.bbmin[0], cloud.bbmax[1] - cloud.bbmin[1], cloud.bbmax[2] - cloud.bbmin[2], 1e-30f});
+    const unsigned nb = cdiv(n, 256);
+    hipLaunchKernelGGL(k_morton, dim3(nb), dim3(256), 0, ctx->stream, cloud.x(), cloud.y(), cloud.z(), n, cloud.bbmin[0],
+                       cloud.bbmin[1], cloud.bbmin[2], 1.f / cube, W.codes_in.p, W.vals_in.p);
+    sort_pairs_u32(ctx, W.codes_in.p, W.codes.p, W.vals_in.p, W.orig.p, n, 30);
+    W.sorted.n = n;
+    W.sorted.pitch = cloud.pitch;
+    W.sorted.soa.ensure(6 * cloud.pitch + 4);
+    hipLaunchKernelGGL(k_gather_cloud, dim3(nb), dim3(256), 0, ctx->stream, cloud.soa.p, cloud.pitch, W.orig.p, n, W.sorted.soa.p,
+                       W.sorted.pitch);
+    const CloudDev &c = W.sorted;
+    CloudView cv{c.x(), c.y(), c.z(), c.nx(), c.ny(), c.nz(), n};
+    W.assigned.ensure((size_t)n + 4);
+    hipLaunchKernelGGL(k_fill_i32, dim3(nb), dim3(256), 0, ctx->stream, W.assigned.p, n, -1);
+    // ---- stratified subset (every stride-th point of the Morton order) --------------------------
+    const uint32_t stride = std::max(1u, n / 16384u);
+    W.n_sub = (n + stride - 1) / stride;
+    W.sub_pitch = ((size_t)W.n_sub + 3) & ~(size_t)3;
+    W.sub.ensure(6 * W.sub_pitch + 4);
+    W.sub_index.ensure(W.sub_pitch + 4);
+    hipLaunchKernelGGL(k_make_subset, dim3(cdiv(W.n_sub, 256)), dim3(256), 0, ctx->stream, c.soa.p, c.pitch, n, stride, W.n_sub,
+                       W.sub.p, W.sub_pitch, W.sub_index.p);
+    const float *sx = W.sub.p, *sy = sx + W.sub_pitch, *sz = sy + W.sub_pitch, *snx = sz + W.sub_pitch, *sny = snx + W.sub_pitch,
+                *snz = sny + W.sub_pitch;
+
+    const uint32_t H = 2048, TOP = 32;
+    W.hyp.ensure(H); W.hyp_pos.ensure(H); W.hyp_counts.ensure(H); W.top.ensure(TOP); W.top_pos.ensure(TOP); W.top_counts.ensure(TOP);
+    W.plane_cur.ensure(2); W.st.ensure(2); W.misc.ensure(16);
+    W.idxA.ensure((size_t)n + 4); W.idxB.ensure((size_t)n + 4); W.idxC.ensure((size_t)n + 4); W.cntA.ensure(4); W.cntB.ensure(4);
+    W.uv.ensure((size_t)n + 4); W.bidx.ensure((size_t)n + 4);
+    W.label.ensure(CC_MAXPIX); W.sizes.ensure(CC_MAXPIX); W.bmp.ensure(CC_MAXPIX); W.tmp.ensure(CC_MAXPIX);
+    W.part.ensure(FIT_BLOCKS * 12 + 16);
+    W.out_idx.ensure((size_t)n + 4);
+
+    const int min_level = 1, max_level = 8;
+    const float levels = (float)(max_level - min_level + 1);
+    auto fail_prob = [&](float cand_size, float n_pts, float drawn) {  // RansacShapeDetector.h:61-67 (reqSamples = 3)
+        return std::min(std::pow(1.f - cand_size / (n_pts * levels * 4.f), drawn), 1.f);
+    };
+
+    std::vector<Accepted> accepted;
+    std::vector<float4> h_hyp(H), h_pos(H);
+    std::vector<uint32_t> h_counts(H);
+    struct Cand { float4 pl, pos; uint32_t count; };
+    std::vector<Cand> pool;
+    uint32_t n_remaining = n;
+    float drawn = 0.f;
+    uint32_t out_off = 0;
+    uint32_t n_full_passes = 0;
+    const uint32_t max_rounds = 4000;
+    for (uint32_t round = 0; round < max_rounds; ++round) {
+        if (n_remaining < rp.min_support) break;
+        if (round > 0 && fail_prob((float)rp.min_support, (float)n_remaining, drawn) <= rp.overlook_p && pool.empty()) break;
+        // ---- draw and score a batch ------------------------------------------------------------
+        hipLaunchKernelGGL(k_sample, dim3(cdiv(H, 256)), dim3(256), 0, ctx->stream, cv, W.codes.p, W.assigned.p, rp.seed, round, H,
+                           min_level, max_level, eps, cos_t, W.hyp.p, W.hyp_pos.p);
+        score_multi(ctx, sx, sy, sz, snx, sny, snz, W.assigned.p, W.sub_index.p, W.n_sub, W.hyp.p, H, eps, cos_t, W.hyp_counts.p);
+        HIP_TRY(hipMemsetAsync(W.misc.p, 0, 8, ctx->stream));
+        hipLaunchKernelGGL(k_count_unassigned, dim3(cdiv(W.n_sub, 256)), dim3(256), 0, ctx->stream, W.assigned.p, W.sub_index.p,
+                           W.n_sub, W.misc.p);
+        uint32_t sub_un = 0;
+        HIP_TRY(hipMemcpyAsync(h_hyp.data(), W.hyp.p, H * 16, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(h_pos.data(), W.hyp_pos.p, H * 16, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(h_counts.data(), W.hyp_counts.p, H * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(&sub_un, W.misc.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        uint32_t valid = 0;
+        for (uint32_t i = 0; i < H; ++i) valid += h_pos[i].w != 0.f;
+        drawn += (float)valid;
+        // leaders of this batch by estimated support
+        const double ratio = sub_un ? (double)n_remaining / sub_un : 0.0;
+        std::vector<uint32_t> order(H);
+        for (uint32_t i = 0; i < H; ++i) order[i] = i;
+        std::partial_sort(order.begin(), order.begin() + TOP, order.end(), [&](uint32_t a, uint32_t b) {
+            return h_counts[a] != h_counts[b] ? h_counts[a] > h_counts[b] : a < b;
+        });
+        for (uint32_t k = 0; k < TOP; ++k) {
+            const uint32_t i = order[k];
+            if (h_pos[i].w == 0.f) continue;
+            if (h_counts[i] * ratio < 0.5 * rp.min_support) continue;
+            pool.push_back(Cand{h_hyp[i], h_pos[i], 0});
+        }
+        // ---- harvest: re-score the pool on all unassigned points, accept the best, repeat ---------
+        while (!pool.empty()) {
+            if (pool.size() > TOP) {
+                std::sort(pool.begin(), pool.end(), [](const Cand &a, const Cand &b) { return a.count > b.count; });
+                pool.resize(TOP);
+            }
+            const uint32_t np = (uint32_t)pool.size();
+            std::vector<float4> pl(np);
+            for (uint32_t i = 0; i < np; ++i) pl[i] = pool[i].pl;
+            HIP_TRY(hipMemcpyAsync(W.top.p, pl.data(), np * 16, hipMemcpyHostToDevice, ctx->stream));
+            score_multi(ctx, c.x(), c.y(), c.z(), c.nx(), c.ny(), c.nz(), W.assigned.p, nullptr, n, W.top.p, np, eps, cos_t,
+                        W.top_counts.p);
+            ++n_full_passes;
+            std::vector<uint32_t> cnts(np);
+            HIP_TRY(hipMemcpyAsync(cnts.data(), W.top_counts.p, np * 4, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+            uint32_t best = 0;
+            for (uint32_t i = 0; i < np; ++i) { pool[i].count = cnts[i]; if (cnts[i] > cnts[best]) best = i; }
+            // candidates that can no longer reach min_support are dropped (RansacShapeDetector.cpp:826-832)
+            if (pool[best].count < rp.min_support) {
+                pool.erase(std::remove_if(pool.begin(), pool.end(), [&](const Cand &a) { return a.count < rp.min_support; }), pool.end());
+                break;
+            }
+            const Cand bc = pool[best];
+            pool.erase(pool.begin() + best);
+            // ---- acceptance sequence (RansacShapeDetector.cpp:618-656) ------------------------------
+            HIP_TRY(hipMemcpyAsync(W.top.p, &bc.pl, 16, hipMemcpyHostToDevice, ctx->stream));
+            HIP_TRY(hipMemcpyAsync(W.top_pos.p, &bc.pos, 16, hipMemcpyHostToDevice, ctx->stream));
+            hipLaunchKernelGGL(k_state_from_hyp, dim3(1), dim3(1), 0, ctx->stream, W.top.p, W.top_pos.p, W.st.p, W.plane_cur.p);
+            // candidate: GlobalScore(3 eps) + ConnectedComponent; clone: same shape, same result + weight
+            global_weighted_score(ctx, W, cv, eps3, cos_t, bitmap_eps, W.idxB.p, W.cntB.p);
+            n_full_passes += 1;
+            PlaneState hst;
+            uint32_t cand_size = 0;
+            HIP_TRY(hipMemcpyAsync(&hst, W.st.p, sizeof(PlaneState), hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(hipMemcpyAsync(&cand_size, W.cntB.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+            PLADE_REQUIRE(hst.err == 0, PLADE_ELIMIT, "plane extraction: connected-component bitmap too large");
+            PlaneState cand_state = hst;         // candidates.back()
+            uint32_t *cand_idx = W.idxB.p;       // its index list lives in idxB; clone results go to idxC
+            double newScore = hst.wscore;
+            uint32_t newSize = cand_size;
+            uint32_t clone_size = cand_size;
+            uint32_t *clone_idx = W.idxB.p;      // clone starts as a copy of the candidate
+            for (int fittingIter = 1; fittingIter <= 3; ++fittingIter) {
+                const double oldScore = newScore;
+                if (clone_size < 3) break;
+                // Fit(): LS plane through the clone's indices
+                HIP_TRY(hipMemcpyAsync(W.cntA.p + 1, &clone_size, 4, hipMemcpyHostToDevice, ctx->stream));
+                hipLaunchKernelGGL(k_fit_partial, dim3(FIT_BLOCKS), dim3(256), 0, ctx->stream, cv, clone_idx, W.cntA.p + 1, W.part.p);
+                hipLaunchKernelGGL(k_fit_final, dim3(1), dim3(1), 0, ctx->stream, W.part.p, W.cntA.p + 1, W.st.p, W.plane_cur.p, 0);
+                uint32_t *dst = (cand_idx == W.idxB.p) ? W.idxC.p : W.idxB.p;
+                global_weighted_score(ctx, W, cv, eps3, cos_t, bitmap_eps, dst, W.cntB.p);
+                n_full_passes += 1;
+                uint32_t sz = 0;
+                HIP_TRY(hipMemcpyAsync(&hst, W.st.p, sizeof(PlaneState), hipMemcpyDeviceToHost, ctx->stream));
+                HIP_TRY(hipMemcpyAsync(&sz, W.cntB.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+                HIP_TRY(hipStreamSynchronize(ctx->stream));
+                PLADE_REQUIRE(hst.err == 0, PLADE_ELIMIT, "plane extraction: refit failed / bitmap too large");
+                newScore = hst.wscore;
+                newSize = sz;
+                clone_idx = dst;
+                clone_size = sz;
+                if (newScore > oldScore && newSize > rp.min_support) {  // clone.Clone(&candidates.back())
+                    cand_state = hst;
+                    cand_idx = dst;
+                    cand_size = sz;
+                }
+                if (!(newScore > oldScore)) break;
+            }
+            // ---- remove the points (RansacShapeDetector.cpp:666-675) ---------------------------------
+            if (cand_size == 0) continue;
+            if (rp.orient_normals) {  // mean inlier normal (the intent of plane_extraction.cpp:43-58)
+                HIP_TRY(hipMemcpyAsync(W.cntA.p + 1, &cand_size, 4, hipMemcpyHostToDevice, ctx->stream));
+                hipLaunchKernelGGL(k_fit_partial, dim3(FIT_BLOCKS), dim3(256), 0, ctx->stream, cv, cand_idx, W.cntA.p + 1, W.part.p);
+                hipLaunchKernelGGL(k_fit_final, dim3(1), dim3(1), 0, ctx->stream, W.part.p, W.cntA.p + 1, W.st.p, W.plane_cur.p, 1);
+                PlaneState t2;
+                HIP_TRY(hipMemcpyAsync(&t2, W.st.p, sizeof(PlaneState), hipMemcpyDeviceToHost, ctx->stream));
+                HIP_TRY(hipStreamSynchronize(ctx->stream));
+                cand_state.nsum[0] = t2.nsum[0]; cand_state.nsum[1] = t2.nsum[1]; cand_state.nsum[2] = t2.nsum[2];
+            }
+            const int32_t shape_id = (int32_t)accepted.size();
+            hipLaunchKernelGGL(k_assign, dim3(cdiv(cand_size, 256)), dim3(256), 0, ctx->stream, cand_idx, cand_size, shape_id, W.assigned.p);
+            drawn = std::pow(1.f - (cand_size / float(n_remaining)), 3.f) * drawn;
+            n_remaining -= cand_size;
+            // plane_extraction.cpp:134-149: shapes below min_support are skipped, d = -n.p with n re-normalised
+            if (cand_size >= rp.min_support) {
+                float nn[3] = {cand_state.n[0], cand_state.n[1], cand_state.n[2]};
+                float l = nn[0] * nn[0];
+                l += nn[1] * nn[1];
+                l += nn[2] * nn[2];
+                l = std::sqrt(l);
+                if (l > 0) { nn[0] /= l; nn[1] /= l; nn[2] /= l; }
+                float d = -(nn[0] * cand_state.pos[0] + nn[1] * cand_state.pos[1] + nn[2] * cand_state.pos[2]);
+                if (rp.orient_normals) {
+                    const float s = cand_state.nsum[0] * nn[0] + cand_state.nsum[1] * nn[1] + cand_state.nsum[2] * nn[2];
+                    if (s < 0) { nn[0] = -nn[0]; nn[1] = -nn[1]; nn[2] = -nn[2]; d = -d; }
+                }
+                Accepted a;
+                a.coef[0] = nn[0]; a.coef[1] = nn[1]; a.coef[2] = nn[2]; a.coef[3] = d;
+                a.support = cand_size; a.offset = out_off;
+                hipLaunchKernelGGL(k_map_indices, dim3(cdiv(cand_size, 256)), dim3(256), 0, ctx->stream, cand_idx, cand_size, W.orig.p,
+                                   W.out_idx.p + out_off);
+                out_off += cand_size;
+                accepted.push_back(a);
+            } else {
+                Accepted a{};  // keeps shape ids aligned with `assigned`
+                a.support = 0; a.offset = out_off;
+                accepted.push_back(a);
+            }
+            HIP_TRY(hipGetLastError());
+            if (n_remaining < rp.min_support) { pool.clear(); break; }
+        }
+    }
+    // ---- output ---------------------------------------------------------------------------------
+    out.idx.resize(out_off);
+    if (out_off) HIP_TRY(hipMemcpyAsync(out.idx.data(), W.out_idx.p, 4 * (size_t)out_off, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (auto &a : accepted) {
+        if (!a.support) continue;
+        out.coef.insert(out.coef.end(), a.coef, a.coef + 4);
+        out.offsets.push_back((int32_t)(a.offset + a.support));
+    }
+    out.d_idx = reinterpret_cast<const uint32_t *>(W.out_idx.p);
+    out.n_score_passes = n_full_passes;
+    out.remaining = n_remaining;
+}
+
+}  // namespace plade

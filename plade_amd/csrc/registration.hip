@@ -1,0 +1,224 @@
+// plade_amd/csrc/registration.hip -- the registration() overloads of code/PLADE/plade.h behind the
+// C ABI: auto-tuned plane extraction (plade.cpp:602-662) + the planes-given pipeline, device-resident
+// cloud handles, and the S1b seam entry point.
+#include "pipeline.h"
+#include "ransac.h"
+#include <algorithm>
+#include <numeric>
+
+using namespace plade;
+
+namespace {
+
+RansacParams ransac_params(plade_ctx *ctx, uint32_t min_support) {
+    RansacParams rp;
+    rp.min_support = min_support;
+    rp.orient_normals = ctx->params.orient_normals;
+    rp.seed = ctx->params.ransac_seed;
+    return rp;  // 0.005f, 0.02f, 0.8f, 0.001f: plade.cpp:607,627
+}
+
+// extract() (code/PLADE/plade.cpp:602-635)
+void extract(plade_ctx *ctx, const CloudDev &cloud, int init_min_support, PlaneSetOut &planes) {
+    const uint32_t min_num = (uint32_t)ctx->params.min_planes, max_num = (uint32_t)ctx->params.max_planes;
+    const int min_allowed_support = 200;
+    if (!ctx->ransac_work) ctx->ransac_work = ransac_work_create();
+    ransac_detect(ctx, *ctx->ransac_work, cloud, ransac_params(ctx, (uint32_t)init_min_support), planes);
+    ctx->stats.add("n_detect_calls", 1);
+    ctx->stats.add("n_score_passes", planes.n_score_passes);
+    if (planes.P() >= min_num && planes.P() <= max_num) return;
+    if (planes.P() > max_num) {
+        // top max_num by support.  The reference sorts with a `>=` comparator (plade.cpp:612-615,
+        // undefined behaviour on ties); a stable descending sort is used here.
+        const uint32_t P = planes.P();
+        std::vector<uint32_t> order(P);
+        std::iota(order.begin(), order.end(), 0u);
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+            return planes.offsets[a + 1] - planes.offsets[a] > planes.offsets[b + 1] - planes.offsets[b];
+        });
+        PlaneSetOut r;
+        r.offsets.assign(1, 0);
+        for (uint32_t k = 0; k < max_num; ++k) {
+            const uint32_t i = order[k];
+            r.coef.insert(r.coef.end(), planes.coef.begin() + 4 * i, planes.coef.begin() + 4 * i + 4);
+            r.idx.insert(r.idx.end(), planes.idx.begin() + planes.offsets[i], planes.idx.begin() + planes.offsets[i + 1]);
+            r.offsets.push_back((int32_t)r.idx.size());
+        }
+        r.n_score_passes = planes.n_score_passes;
+        planes = std::move(r);
+        return;
+    }
+    const int max_trials = 10;
+    int min_support = init_min_support / 2;
+    int trials = 1;
+    while (planes.P() < min_num && trials < max_trials && min_support >= min_allowed_support) {
+        ransac_detect(ctx, *ctx->ransac_work, cloud, ransac_params(ctx, (uint32_t)min_support), planes);
+        ctx->stats.add("n_detect_calls", 1);
+        ctx->stats.add("n_score_passes", planes.n_score_passes);
+        min_support /= 2;
+        ++trials;
+    }
+}
+
+int register_clouds(plade_ctx *ctx, const CloudDev &tgt, const CloudDev &src, int ms_t, int ms_s, bool auto_tune,
+                    float *T16) {
+    for (int i = 0; i < 16; ++i) T16[i] = (i % 5 == 0) ? 1.f : 0.f;
+    PlaneSetOut tp, sp;
+    Clock::time_point t0 = Clock::now();
+    {
+        StageTimer t(ctx, "t_extract");
+        if (auto_tune) {
+            extract(ctx, tgt, ctx->params.init_min_support, tp);
+            if (tp.P() < (uint32_t)ctx->params.min_planes) {  // plade.cpp:646-650
+                ctx->last_error = "too few planes extracted from the target point cloud";
+                return PLADE_EFAIL;
+            }
+            // the target's device index list is overwritten by the second detect: keep host lists only
+            tp.d_idx = nullptr;
+            extract(ctx, src, ctx->params.init_min_support, sp);
+            if (sp.P() < (uint32_t)ctx->params.min_planes) {  // plade.cpp:653-657
+                ctx->last_error = "too few planes extracted from the source point cloud";
+                return PLADE_EFAIL;
+            }
+        } else {  // plade.cpp:583-599
+            if (!ctx->ransac_work) ctx->ransac_work = ransac_work_create();
+            ransac_detect(ctx, *ctx->ransac_work, tgt, ransac_params(ctx, (uint32_t)ms_t), tp);
+            tp.d_idx = nullptr;
+            ransac_detect(ctx, *ctx->ransac_work, src, ransac_params(ctx, (uint32_t)ms_s), sp);
+        }
+    }
+    if (ctx->params.dump) {
+        ctx->put("tgt_planes", tp.coef.data(), tp.coef.size());
+        ctx->put("tgt_plane_offsets", tp.offsets.data(), tp.offsets.size());
+        ctx->put("tgt_plane_idx", tp.idx.data(), tp.idx.size());
+        ctx->put("src_planes", sp.coef.data(), sp.coef.size());
+        ctx->put("src_plane_offsets", sp.offsets.data(), sp.offsets.size());
+        ctx->put("src_plane_idx", sp.idx.data(), sp.idx.size());
+    }
+    ctx->stats.add("n_planes_tgt", tp.P());
+    ctx->stats.add("n_planes_src", sp.P());
+    if (!ctx->reg_work) ctx->reg_work = registration_work_create();
+    PlaneSetView tv, sv;
+    tv.coef = tp.coef.data(); tv.offsets = tp.offsets.data(); tv.idx = tp.idx.data(); tv.P = tp.P();
+    sv.coef = sp.coef.data(); sv.offsets = sp.offsets.data(); sv.idx = sp.idx.data(); sv.P = sp.P(); sv.d_idx = sp.d_idx;
+    const bool ok = run_registration(ctx, *ctx->reg_work, tgt, src, tv, sv, T16);
+    ctx->stats.add("t_registration", secs_since(t0));
+    // roofline bookkeeping
+    ctx->stats.add("bytes_ransac", 28.0 * ((double)tgt.n + src.n) * 0.5 * ctx_stat(ctx, "n_score_passes"));
+    ctx->stats.add("bytes_voxel", 12.0 * ((double)tgt.n + src.n));
+    ctx->ev_collect();
+    if (!ok) { if (ctx->last_error.empty()) ctx->last_error = "registration failed: no matched result found"; return PLADE_EFAIL; }
+    return PLADE_OK;
+}
+
+}  // namespace
+
+namespace plade {
+double ctx_stat(plade_ctx *ctx, const char *name) {
+    for (size_t i = 0; i < ctx->stats.names.size(); ++i) if (ctx->stats.names[i] == name) return ctx->stats.values[i];
+    return 0.0;
+}
+}  // namespace plade
+
+// ---- C ABI ---------------------------------------------------------------------------------
+extern "C" int plade_extract_planes(plade_ctx *ctx, const float *pos_nrm, uint32_t n, uint32_t min_support, float dist_rel,
+                                    float bitmap_rel, float cos_thresh, float overlook_p, float *planes_out,
+                                    int32_t *offsets_out, int32_t *idx_out, uint32_t max_planes, uint32_t *n_planes_out) {
+    return guarded(ctx, [&]() -> int {
+        PLADE_REQUIRE(pos_nrm && planes_out && offsets_out && idx_out && n_planes_out, PLADE_EINVAL, "plade_extract_planes: null argument");
+        *n_planes_out = 0;
+        offsets_out[0] = 0;
+        if (n < 3) return PLADE_OK;  // plane_extraction.cpp:181-184
+        CloudDev cloud;
+        cloud_upload(ctx, pos_nrm, n, cloud);
+        if (!ctx->ransac_work) ctx->ransac_work = ransac_work_create();
+        RansacParams rp = ransac_params(ctx, min_support);
+        rp.dist_rel = dist_rel; rp.bitmap_rel = bitmap_rel; rp.cos_thresh = cos_thresh; rp.overlook_p = overlook_p;
+        PlaneSetOut out;
+        ransac_detect(ctx, *ctx->ransac_work, cloud, rp, out);
+        const uint32_t P = out.P();
+        PLADE_REQUIRE(P <= max_planes, PLADE_ECAP, "plade_extract_planes: more planes than max_planes");
+        memcpy(planes_out, out.coef.data(), 16 * (size_t)P);
+        memcpy(offsets_out, out.offsets.data(), 4 * ((size_t)P + 1));
+        memcpy(idx_out, out.idx.data(), 4 * out.idx.size());
+        *n_planes_out = P;
+        return PLADE_OK;
+    });
+}
+
+extern "C" int plade_cloud_upload(plade_ctx *ctx, const float *pos_nrm, uint32_t n, plade_cloud **out) {
+    return guarded(ctx, [&]() -> int {
+        PLADE_REQUIRE(pos_nrm && out && n, PLADE_EINVAL, "plade_cloud_upload: bad argument");
+        plade_cloud *c = new plade_cloud;
+        try {
+            cloud_upload(ctx, pos_nrm, n, c->dev);
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+        } catch (...) { delete c; throw; }
+        *out = c;
+        return PLADE_OK;
+    });
+}
+
+extern "C" void plade_cloud_free(plade_ctx *ctx, plade_cloud *c) {
+    if (ctx) (void)hipStreamSynchronize(ctx->stream);
+    delete c;
+}
+
+extern "C" int plade_registration_dev(plade_ctx *ctx, plade_cloud *tgt, plade_cloud *src, float *T16) {
+    return guarded(ctx, [&]() -> int {
+        PLADE_REQUIRE(tgt && src && T16, PLADE_EINVAL, "plade_registration_dev: null argument");
+        ctx->stats.clear();
+        ctx->dump.clear();
+        ctx->last_error.clear();
+        return register_clouds(ctx, tgt->dev, src->dev, 0, 0, true, T16);
+    });
+}
+
+extern "C" int plade_registration(plade_ctx *ctx, const float *tgt_pos_nrm, uint32_t n_t, const float *src_pos_nrm,
+                                  uint32_t n_s, float *T16) {
+    return guarded(ctx, [&]() -> int {
+        PLADE_REQUIRE(tgt_pos_nrm && src_pos_nrm && T16 && n_t && n_s, PLADE_EINVAL, "plade_registration: bad argument");
+        ctx->stats.clear();
+        ctx->dump.clear();
+        ctx->last_error.clear();
+        CloudDev tgt, src;
+        {
+            StageTimer t(ctx, "t_upload");
+            cloud_upload(ctx, tgt_pos_nrm, n_t, tgt);
+            cloud_upload(ctx, src_pos_nrm, n_s, src);
+        }
+        return register_clouds(ctx, tgt, src, 0, 0, true, T16);
+    });
+}
+
+extern "C" int plade_registration_minsupport(plade_ctx *ctx, const float *tgt_pos_nrm, uint32_t n_t,
+                                             const float *src_pos_nrm, uint32_t n_s, int32_t min_support_t,
+                                             int32_t min_support_s, float *T16) {
+    return guarded(ctx, [&]() -> int {
+        PLADE_REQUIRE(tgt_pos_nrm && src_pos_nrm && T16 && n_t && n_s && min_support_t > 0 && min_support_s > 0, PLADE_EINVAL,
+                      "plade_registration_minsupport: bad argument");
+        ctx->stats.clear();
+        ctx->dump.clear();
+        ctx->last_error.clear();
+        CloudDev tgt, src;
+        cloud_upload(ctx, tgt_pos_nrm, n_t, tgt);
+        cloud_upload(ctx, src_pos_nrm, n_s, src);
+        return register_clouds(ctx, tgt, src, min_support_t, min_support_s, false, T16);
+    });
+}
+
+extern "C" int plade_kernel_time(plade_ctx *ctx, const char *which, int iters, double *avg_seconds,
+                                 double *algorithmic_bytes_per_launch) {
+    return guarded(ctx, [&]() -> int {
+        PLADE_REQUIRE(which && avg_seconds && algorithmic_bytes_per_launch && iters > 0, PLADE_EINVAL, "plade_kernel_time: bad argument");
+        // per-kernel figures of the LAST registration run with params.dump & 2 (HIP events recorded on
+        // the ctx stream around every launch of the named kernel)
+        const std::string base = std::string("k_") + which;
+        const double s = ctx_stat(ctx, (base + "_seconds").c_str()), nl = ctx_stat(ctx, (base + "_launches").c_str()),
+                     b = ctx_stat(ctx, (base + "_bytes").c_str());
+        PLADE_REQUIRE(nl > 0, PLADE_EINVAL, "plade_kernel_time: no profiled launches of that kernel (run a registration with dump & 2)");
+        *avg_seconds = s / nl;
+        *algorithmic_bytes_per_launch = b / nl;
+        return PLADE_OK;
+    });
+}
