@@ -24,8 +24,9 @@ build/%.o: $(CSRC)/%.hip $(HIP_HDRS)
 plade_amd/libplade_hip.so: $(HIP_OBJS)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^
 
-plade_amd/PLADE: $(CSRC)/main.cpp $(CSRC)/plade.h plade_amd/libplade_hip.so
-	$(HIPCC) -O2 -std=c++17 -Iinclude -I$(CSRC) $(CSRC)/main.cpp -o $@ -Lplade_amd -lplade_hip -Wl,-rpath,'$$ORIGIN'
+HOST_SRCS := $(CSRC)/main.cpp $(CSRC)/plade_host.cpp $(CSRC)/ply_reader.cpp
+plade_amd/PLADE: $(HOST_SRCS) $(CSRC)/plade.h $(CSRC)/plade_compat.h $(CSRC)/ply_reader.h plade_amd/libplade_hip.so
+	$(CXX) -O2 -std=c++17 -pthread -Iinclude -I$(CSRC) $(HOST_SRCS) -o $@ -Lplade_amd -lplade_hip -Wl,-rpath,'$$ORIGIN'
 
 oracle/libplade_oracle.so: oracle/plade_oracle.cpp oracle/plade_oracle.h oracle/orc_math.h
 	$(CXX) -O2 -std=c++14 -fPIC -ffp-contract=off -shared -o $@ oracle/plade_oracle.cpp

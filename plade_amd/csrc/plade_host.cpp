@@ -1,0 +1,221 @@
+// plade_amd/csrc/plade_host.cpp -- the four registration() overloads of code/PLADE/plade.h (and
+// PlaneExtraction::detect, load_ply_cloud) on top of the C ABI of libplade_hip.so.  Console messages,
+// return values and the swap/invert rule follow code/PLADE/plade.cpp:583-706.
+#include "plade.h"
+#include "plade_hip.h"
+#include "ply_reader.h"
+
+#include <chrono>
+#include <cstdio>
+#include <iostream>
+#include <mutex>
+
+namespace {
+
+thread_local int g_device = 0;
+thread_local plade_ctx *g_ctx = nullptr;
+thread_local int g_ctx_device = -1;
+
+plade_ctx *context() {
+    if (g_ctx && g_ctx_device == g_device) return g_ctx;
+    if (g_ctx) { plade_ctx_destroy(g_ctx); g_ctx = nullptr; }
+    if (plade_ctx_create(g_device, &g_ctx) != PLADE_OK) {
+        std::cerr << "PLADE: cannot create a GPU context on device " << g_device
+                  << " (libplade_hip.so needs a gfx950 GPU; there is no CPU fallback)" << std::endl;
+        return nullptr;
+    }
+    g_ctx_device = g_device;
+    return g_ctx;
+}
+
+std::vector<float> flatten(const pcl::PointCloud<pcl::PointNormal> &c) {
+    std::vector<float> a(6 * c.size());
+    for (size_t i = 0; i < c.size(); ++i) {
+        const pcl::PointNormal &p = c.points[i];
+        float *o = &a[6 * i];
+        o[0] = p.x; o[1] = p.y; o[2] = p.z; o[3] = p.normal_x; o[4] = p.normal_y; o[5] = p.normal_z;
+    }
+    return a;
+}
+
+void to_matrix(const float *T16, Eigen::Matrix<float, 4, 4> &m) {
+    for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) m(r, c) = T16[4 * r + c];
+}
+
+void pack_planes(const std::vector<PLANE> &planes, std::vector<float> &coef, std::vector<int32_t> &off, std::vector<int32_t> &idx) {
+    coef.clear(); off.assign(1, 0); idx.clear();
+    for (const PLANE &p : planes) {
+        coef.push_back(p.normal.x()); coef.push_back(p.normal.y()); coef.push_back(p.normal.z()); coef.push_back(p.d);
+        idx.insert(idx.end(), p.begin(), p.end());
+        off.push_back((int32_t)idx.size());
+    }
+}
+
+struct Watch {
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    std::string str() const {
+        double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        char buf[64];
+        snprintf(buf, sizeof(buf), "%.3f sec", s);
+        return buf;
+    }
+};
+
+std::string extension(const std::string &file_name) {  // util.cpp:525-531
+    std::string::size_type dot = file_name.find_last_of('.');
+    std::string::size_type slash = file_name.find_last_of("/\\");
+    if (dot == std::string::npos || (slash != std::string::npos && dot < slash)) return std::string("");
+    return std::string(file_name.begin() + dot + 1, file_name.end());
+}
+
+}  // namespace
+
+void plade_select_device(int device) { g_device = device; }
+
+std::vector<PLANE> PlaneExtraction::detect(const pcl::PointCloud<pcl::PointNormal> &cloud, unsigned int min_support,
+                                           float dist_thresh, float bitmap_reso, float normal_thresh, float overlook_prob) {
+    std::vector<PLANE> out;
+    if (cloud.size() < 3) {  // plane_extraction.cpp:181-184
+        std::cerr << "point set has less than 3 points" << std::endl;
+        return out;
+    }
+    plade_ctx *ctx = context();
+    if (!ctx) return out;
+    std::vector<float> a = flatten(cloud);
+    const uint32_t max_planes = 4096;
+    std::vector<float> coef(4 * max_planes);
+    std::vector<int32_t> off(max_planes + 1), idx(cloud.size());
+    uint32_t P = 0;
+    int rc = plade_extract_planes(ctx, a.data(), (uint32_t)cloud.size(), min_support, dist_thresh, bitmap_reso, normal_thresh,
+                                  overlook_prob, coef.data(), off.data(), idx.data(), max_planes, &P);
+    if (rc != PLADE_OK) { std::cerr << "plane extraction failed: " << plade_last_error(ctx) << std::endl; return out; }
+    for (uint32_t i = 0; i < P; ++i) {
+        PLANE pl(idx.begin() + off[i], idx.begin() + off[i + 1]);
+        pl.normal = Eigen::Vector3f(coef[4 * i], coef[4 * i + 1], coef[4 * i + 2]);
+        pl.d = coef[4 * i + 3];
+        out.push_back(pl);
+    }
+    return out;
+}
+
+// plade.h:74-79 / plade.cpp:31-580
+bool registration(Eigen::Matrix<float, 4, 4> &transformation, pcl::PointCloud<pcl::PointNormal>::Ptr target_cloud,
+                  pcl::PointCloud<pcl::PointNormal>::Ptr source_cloud, const std::vector<PLANE> &target_planes,
+                  const std::vector<PLANE> &source_planes) {
+    std::cout << "#point in target point cloud: " << target_cloud->size() << std::endl;
+    std::cout << "#point in source point cloud: " << source_cloud->size() << std::endl;
+    std::cout << "#planes in target point cloud: " << target_planes.size() << std::endl;
+    std::cout << "#planes in source point cloud: " << source_planes.size() << std::endl;
+    plade_ctx *ctx = context();
+    if (!ctx) return false;
+    std::vector<float> tg = flatten(*target_cloud), sr = flatten(*source_cloud), tc, sc;
+    std::vector<int32_t> to, ti, so, si;
+    pack_planes(target_planes, tc, to, ti);
+    pack_planes(source_planes, sc, so, si);
+    float T16[16];
+    Watch w;
+    std::cout << "registration..." << std::endl;
+    int rc = plade_registration_planes(ctx, tg.data(), (uint32_t)target_cloud->size(), sr.data(), (uint32_t)source_cloud->size(),
+                                       tc.data(), to.data(), ti.data(), (uint32_t)target_planes.size(), sc.data(), so.data(),
+                                       si.data(), (uint32_t)source_planes.size(), T16);
+    if (rc != PLADE_OK) {
+        std::cerr << (rc == PLADE_EFAIL ? "registration failed: no matched result found" : plade_last_error(ctx)) << std::endl;
+        return false;
+    }
+    to_matrix(T16, transformation);
+    std::cout << "done. time: " << w.str() << std::endl;
+    return true;
+}
+
+// plade.h:91-96 / plade.cpp:583-599
+bool registration(Eigen::Matrix<float, 4, 4> &transformation, pcl::PointCloud<pcl::PointNormal>::Ptr target_cloud,
+                  pcl::PointCloud<pcl::PointNormal>::Ptr source_cloud, int ransac_min_support_target,
+                  int ransac_min_support_source) {
+    plade_ctx *ctx = context();
+    if (!ctx) return false;
+    std::vector<float> tg = flatten(*target_cloud), sr = flatten(*source_cloud);
+    float T16[16];
+    Watch w;
+    std::cout << "extracting planes and registering...\n";
+    int rc = plade_registration_minsupport(ctx, tg.data(), (uint32_t)target_cloud->size(), sr.data(), (uint32_t)source_cloud->size(),
+                                           ransac_min_support_target, ransac_min_support_source, T16);
+    if (rc != PLADE_OK) {
+        std::cerr << (rc == PLADE_EFAIL ? plade_last_error(ctx) : plade_last_error(ctx)) << std::endl;
+        return false;
+    }
+    to_matrix(T16, transformation);
+    std::cout << "done. time: " << w.str() << std::endl;
+    return true;
+}
+
+// plade.h:58-61 / plade.cpp:638-662
+bool registration(Eigen::Matrix<float, 4, 4> &transformation, pcl::PointCloud<pcl::PointNormal>::Ptr target_cloud,
+                  pcl::PointCloud<pcl::PointNormal>::Ptr source_cloud) {
+    plade_ctx *ctx = context();
+    if (!ctx) return false;
+    std::cout << "extracting planes for both point clouds...\n";
+    std::vector<float> tg = flatten(*target_cloud), sr = flatten(*source_cloud);
+    float T16[16];
+    Watch w;
+    int rc = plade_registration(ctx, tg.data(), (uint32_t)target_cloud->size(), sr.data(), (uint32_t)source_cloud->size(), T16);
+    if (rc != PLADE_OK) {
+        std::cerr << plade_last_error(ctx) << std::endl;
+        return false;
+    }
+    to_matrix(T16, transformation);
+    std::cout << "done. time: " << w.str() << std::endl;
+    return true;
+}
+
+// plade.h:44-47 / plade.cpp:665-706
+bool registration(Eigen::Matrix<float, 4, 4> &transformation, const std::string &target_cloud_file,
+                  const std::string &source_cloud_file) {
+    std::cout << "target file: " << target_cloud_file << std::endl;
+    std::cout << "source file: " << source_cloud_file << std::endl;
+    if (extension(target_cloud_file) != "ply" || extension(source_cloud_file) != "ply") {
+        std::cerr << "only PLY format is accepted" << std::endl;
+        return false;
+    }
+    pcl::PointCloud<pcl::PointNormal>::Ptr target_cloud(new pcl::PointCloud<pcl::PointNormal>);
+    if (!load_ply_cloud(target_cloud_file, *target_cloud)) {
+        std::cerr << "loading target point cloud failed" << std::endl;
+        return false;
+    }
+    pcl::PointCloud<pcl::PointNormal>::Ptr source_cloud(new pcl::PointCloud<pcl::PointNormal>);
+    if (!load_ply_cloud(source_cloud_file, *source_cloud)) {
+        std::cerr << "loading source point cloud failed" << std::endl;
+        return false;
+    }
+    bool switched = false;
+    if (source_cloud->size() >= target_cloud->size() * 1.2f) {
+        std::swap(target_cloud, source_cloud);
+        switched = true;
+        std::cout << "---->>> ATTENTION: target and source have been switched for efficiency <<<----" << std::endl;
+    }
+    transformation.setIdentity();
+    bool status = registration(transformation, target_cloud, source_cloud);
+    if (!status) {
+        std::cerr << "registration failed" << std::endl;
+        return false;
+    }
+    if (switched) transformation = transformation.inverse();
+    return true;
+}
+
+bool load_ply_cloud(const std::string &file_name, pcl::PointCloud<pcl::PointNormal> &cloud) {
+    std::vector<float> pos_nrm;
+    std::string err;
+    std::vector<std::string> warnings;
+    if (!plade::read_ply_pos_nrm(file_name, pos_nrm, err, &warnings)) {
+        if (!err.empty()) std::cerr << err << std::endl;
+        return false;
+    }
+    for (auto &w : warnings) std::cout << w << std::endl;
+    const size_t n = pos_nrm.size() / 6;
+    cloud.resize(n);
+    for (size_t i = 0; i < n; ++i) {
+        const float *p = &pos_nrm[6 * i];
+        cloud.at(i) = pcl::PointNormal(p[0], p[1], p[2], p[3], p[4], p[5]);
+    }
+    return cloud.size() > 0;
+}

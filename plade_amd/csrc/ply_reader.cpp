@@ -1,0 +1,195 @@
+// plade_amd/csrc/ply_reader.cpp -- see ply_reader.h.
+#include "ply_reader.h"
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+
+namespace plade {
+
+namespace {
+
+struct Prop {
+    std::string name;
+    int type = -1;       // index into kTypes
+    bool is_list = false;
+    int count_type = -1, item_type = -1;
+};
+struct Elem {
+    std::string name;
+    size_t count = 0;
+    std::vector<Prop> props;
+};
+
+const char *kTypeNames[][2] = {{"char", "int8"},   {"uchar", "uint8"},   {"short", "int16"},  {"ushort", "uint16"},
+                               {"int", "int32"},   {"uint", "uint32"},   {"float", "float32"}, {"double", "float64"}};
+const int kTypeSize[] = {1, 1, 2, 2, 4, 4, 4, 8};
+
+int type_index(const std::string &t) {
+    for (int i = 0; i < 8; ++i)
+        if (t == kTypeNames[i][0] || t == kTypeNames[i][1]) return i;
+    return -1;
+}
+
+double decode(const unsigned char *p, int type, bool swap) {
+    unsigned char b[8];
+    const int sz = kTypeSize[type];
+    if (swap) for (int i = 0; i < sz; ++i) b[i] = p[sz - 1 - i];
+    else memcpy(b, p, sz);
+    switch (type) {
+        case 0: { int8_t v; memcpy(&v, b, 1); return v; }
+        case 1: { uint8_t v; memcpy(&v, b, 1); return v; }
+        case 2: { int16_t v; memcpy(&v, b, 2); return v; }
+        case 3: { uint16_t v; memcpy(&v, b, 2); return v; }
+        case 4: { int32_t v; memcpy(&v, b, 4); return v; }
+        case 5: { uint32_t v; memcpy(&v, b, 4); return v; }
+        case 6: { float v; memcpy(&v, b, 4); return v; }
+        default: { double v; memcpy(&v, b, 8); return v; }
+    }
+}
+
+bool host_is_little_endian() {
+    const uint16_t x = 1;
+    return *reinterpret_cast<const unsigned char *>(&x) == 1;
+}
+
+}  // namespace
+
+bool read_ply_pos_nrm(const std::string &path, std::vector<float> &out, std::string &err, std::vector<std::string> *warnings) {
+    out.clear();
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) { err = "could not open file: " + path; return false; }
+    auto fail = [&](const std::string &m) { err = m; fclose(f); return false; };
+    std::vector<Elem> elems;
+    std::string format;
+    char linebuf[4096];
+    bool first = true, ended = false;
+    while (fgets(linebuf, sizeof(linebuf), f)) {
+        std::string line(linebuf);
+        while (!line.empty() && (line.back() == '\n' || line.back() == '\r')) line.pop_back();
+        std::istringstream is(line);
+        std::string kw;
+        is >> kw;
+        if (first) { if (kw != "ply") return fail("not a PLY file: " + path); first = false; continue; }
+        if (kw == "format") { is >> format; }
+        else if (kw == "element") { Elem e; is >> e.name >> e.count; elems.push_back(e); }
+        else if (kw == "property") {
+            if (elems.empty()) return fail("PLY property before any element");
+            Prop p;
+            std::string t;
+            is >> t;
+            if (t == "list") {
+                std::string ct, it;
+                is >> ct >> it >> p.name;
+                p.is_list = true; p.count_type = type_index(ct); p.item_type = type_index(it);
+                if (p.count_type < 0 || p.item_type < 0) return fail("unknown PLY list type in " + path);
+            } else {
+                p.type = type_index(t);
+                is >> p.name;
+                if (p.type < 0) return fail("unknown PLY property type '" + t + "'");
+            }
+            elems.back().props.push_back(p);
+        } else if (kw == "end_header") { ended = true; break; }
+    }
+    if (!ended) return fail("PLY header not terminated: " + path);
+    const bool ascii = format == "ascii";
+    const bool le = format == "binary_little_endian", be = format == "binary_big_endian";
+    if (!ascii && !le && !be) return fail("unknown PLY format '" + format + "'");
+    const bool swap = (le && !host_is_little_endian()) || (be && host_is_little_endian());
+    bool got_vertex = false;
+    for (const Elem &e : elems) {
+        const bool is_vertex = e.name == "vertex";
+        int col[6] = {-1, -1, -1, -1, -1, -1};
+        const char *want[6] = {"x", "y", "z", "nx", "ny", "nz"};
+        if (is_vertex) {
+            for (size_t k = 0; k < e.props.size(); ++k) {
+                bool used = false;
+                for (int w = 0; w < 6; ++w) if (!e.props[k].is_list && e.props[k].name == want[w]) { col[w] = (int)k; used = true; }
+                if (!used && warnings) warnings->push_back("Warning: ignored property '" + e.props[k].name + "'");
+            }
+            const bool has_pos = col[0] >= 0 && col[1] >= 0 && col[2] >= 0, has_nrm = col[3] >= 0 && col[4] >= 0 && col[5] >= 0;
+            if (!has_pos || !has_nrm)
+                return fail("the number of points does not equal to the number of normals in the file");
+            out.resize(6 * e.count);
+            got_vertex = true;
+        } else if (warnings) warnings->push_back("Warning: unknown element '" + e.name);
+        bool fixed = true;
+        size_t row = 0;
+        for (const Prop &p : e.props) { if (p.is_list) fixed = false; else row += kTypeSize[p.type]; }
+        // fast path: binary, native byte order, exactly float x y z nx ny nz
+        bool plain6 = is_vertex && !ascii && !swap && fixed && e.props.size() == 6;
+        for (int w = 0; w < 6 && plain6; ++w) plain6 = col[w] == w && e.props[w].type == 6;
+        if (plain6) {
+            if (fread(out.data(), 24, e.count, f) != e.count) return fail("unexpected end of PLY data: " + path);
+            continue;
+        }
+        if (ascii) {
+            for (size_t i = 0; i < e.count; ++i) {
+                if (!fgets(linebuf, sizeof(linebuf), f)) return fail("unexpected end of PLY data: " + path);
+                if (!is_vertex) continue;
+                char *s = linebuf;
+                for (size_t k = 0; k < e.props.size(); ++k) {
+                    char *endp = nullptr;
+                    if (e.props[k].is_list) {
+                        long c = strtol(s, &endp, 10);
+                        s = endp;
+                        for (long q = 0; q < c; ++q) { strtod(s, &endp); s = endp; }
+                        continue;
+                    }
+                    const double v = strtod(s, &endp);
+                    if (endp == s) return fail("malformed PLY vertex line in " + path);
+                    s = endp;
+                    for (int w = 0; w < 6; ++w) if (col[w] == (int)k) out[6 * i + w] = (float)v;
+                }
+            }
+            continue;
+        }
+        // generic binary
+        if (fixed) {
+            std::vector<unsigned char> buf(row * std::min<size_t>(e.count, 65536));
+            std::vector<size_t> offs(e.props.size());
+            size_t o = 0;
+            for (size_t k = 0; k < e.props.size(); ++k) { offs[k] = o; o += kTypeSize[e.props[k].type]; }
+            for (size_t base = 0; base < e.count; base += 65536) {
+                const size_t cnt = std::min<size_t>(65536, e.count - base);
+                if (fread(buf.data(), row, cnt, f) != cnt) return fail("unexpected end of PLY data: " + path);
+                if (!is_vertex) continue;
+                for (size_t i = 0; i < cnt; ++i)
+                    for (int w = 0; w < 6; ++w)
+                        out[6 * (base + i) + w] = (float)decode(&buf[i * row + offs[col[w]]], e.props[col[w]].type, swap);
+            }
+        } else {
+            for (size_t i = 0; i < e.count; ++i)
+                for (size_t k = 0; k < e.props.size(); ++k) {
+                    unsigned char b[8];
+                    const Prop &p = e.props[k];
+                    if (p.is_list) {
+                        if (fread(b, kTypeSize[p.count_type], 1, f) != 1) return fail("unexpected end of PLY data: " + path);
+                        const long c = (long)decode(b, p.count_type, swap);
+                        if (fseek(f, c * kTypeSize[p.item_type], SEEK_CUR) != 0) return fail("unexpected end of PLY data: " + path);
+                    } else {
+                        if (fread(b, kTypeSize[p.type], 1, f) != 1) return fail("unexpected end of PLY data: " + path);
+                        if (is_vertex) for (int w = 0; w < 6; ++w) if (col[w] == (int)k) out[6 * i + w] = (float)decode(b, p.type, swap);
+                    }
+                }
+        }
+    }
+    fclose(f);
+    if (!got_vertex) { err = "no vertex element in " + path; return false; }
+    return true;
+}
+
+bool write_ply_pos_nrm(const std::string &path, const float *pos_nrm, size_t n) {
+    FILE *f = fopen(path.c_str(), "wb");
+    if (!f) return false;
+    fprintf(f, "ply\nformat %s 1.0\nelement vertex %zu\n", host_is_little_endian() ? "binary_little_endian" : "binary_big_endian", n);
+    fprintf(f, "property float x\nproperty float y\nproperty float z\nproperty float nx\nproperty float ny\nproperty float nz\nend_header\n");
+    const bool ok = fwrite(pos_nrm, 24, n, f) == n;
+    fclose(f);
+    return ok;
+}
+
+}  // namespace plade

@@ -15,18 +15,27 @@ def _furniture(rng, n_boxes):
     """Non-overlapping boxes standing on the floor; returns (lo, hi) corner arrays."""
     boxes = []
     tries = 0
-    while len(boxes) < n_boxes and tries < 10000:
+    while len(boxes) < n_boxes and tries < 20000:
         tries += 1
-        size = np.array([rng.uniform(1.4, 2.2), rng.uniform(1.2, 1.9), rng.uniform(1.2, 2.2)])
-        lo_xy = np.array([rng.uniform(-ROOM[0] / 2 + 0.15, ROOM[0] / 2 - 0.15 - size[0]),
-                          rng.uniform(-ROOM[1] / 2 + 0.15, ROOM[1] / 2 - 0.15 - size[1])])
+        size = np.array([rng.uniform(1.2, 2.0), rng.uniform(1.1, 1.8), rng.uniform(0.8, 2.45)])
+        # keep every face >= 0.5 m from the parallel room face and from the other boxes' parallel
+        # faces: Schnabel's global scoring uses 3 eps = 15 cm here and would merge closer coplanar-ish
+        # faces into one shape (in the reference as much as in this implementation)
+        lo_xy = np.array([rng.uniform(-ROOM[0] / 2 + 0.5, ROOM[0] / 2 - 0.5 - size[0]),
+                          rng.uniform(-ROOM[1] / 2 + 0.5, ROOM[1] / 2 - 0.5 - size[1])])
         lo = np.array([lo_xy[0], lo_xy[1], -ROOM[2] / 2])
         hi = lo + size
         ok = True
         for (l2, h2) in boxes:
-            if np.all(lo[:2] < h2[:2] + 0.25) and np.all(hi[:2] > l2[:2] - 0.25):
+            if np.all(lo[:2] < h2[:2] + 0.2) and np.all(hi[:2] > l2[:2] - 0.2):
                 ok = False
                 break
+            if abs(hi[2] - h2[2]) < 0.2 or min(abs(lo[0] - l2[0]), abs(lo[0] - h2[0]), abs(hi[0] - l2[0]), abs(hi[0] - h2[0])) < 0.2 \
+                    or min(abs(lo[1] - l2[1]), abs(lo[1] - h2[1]), abs(hi[1] - l2[1]), abs(hi[1] - h2[1])) < 0.2:
+                ok = False
+                break
+        if hi[2] > ROOM[2] / 2 - 0.5:
+            ok = False
         if ok:
             boxes.append((lo, hi))
     return boxes

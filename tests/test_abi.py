@@ -1,0 +1,59 @@
+"""The C-ABI library loads, exports every symbol include/plade_hip.h declares, and refuses to run
+without a GPU (no CPU fallback).  No compute calls here."""
+import ctypes
+import os
+import re
+
+import plade_amd
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_header_symbols_are_exported():
+    hdr = open(os.path.join(ROOT, "include", "plade_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(plade_[a-z_0-9]+)\s*\(", hdr)))
+    assert len(declared) >= 20
+    L = plade_amd.load_library()
+    missing = [s for s in declared if not hasattr(L, s)]
+    assert not missing, missing
+    assert sorted(declared) == sorted(plade_amd.ABI_SYMBOLS), "python binding and header disagree"
+    assert b"gfx950" in L.plade_version()
+
+
+def test_params_defaults_match_reference_literals():
+    L = plade_amd.load_library()
+    p = plade_amd.Params()
+    L.plade_default_params(ctypes.byref(p))
+    assert (p.max_planes, p.min_planes, p.max_candidates, p.init_min_support) == (40, 10, 200, 10000)
+
+
+def test_no_cpu_fallback_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        return
+    L = plade_amd.load_library()
+    h = ctypes.c_void_p()
+    rc = L.plade_ctx_create(0, ctypes.byref(h))
+    assert rc == plade_amd.PLADE_EDEVICE and not h.value
+    try:
+        plade_amd.Context(0)
+    except plade_amd.PladeError as e:
+        assert e.code == plade_amd.PLADE_EDEVICE
+    else:
+        raise AssertionError("Context() must fail loudly without a GPU")
+
+
+def test_product_never_touches_the_oracle():
+    """plade_amd/ (python + C++ sources) may not import, include or link anything under oracle/."""
+    bad = []
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "plade_amd")):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp")):
+                txt = open(os.path.join(dirpath, f), errors="replace").read()
+                if re.search(r"^\s*(from|import)\s+oracle|#include\s+[\"<][^\">]*oracle|plade_oracle|libplade_oracle|orc_[a-z_]+\(", txt, re.M):
+                    bad.append(f)
+    assert not bad, bad
+    mk = open(os.path.join(ROOT, "Makefile")).read()
+    lib_rule = mk.split("plade_amd/libplade_hip.so:")[1].split("\n\n")[0]
+    assert "oracle" not in lib_rule

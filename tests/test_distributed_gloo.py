@@ -1,0 +1,70 @@
+"""world_size-2 test of the batch-mode sharding + gather (plade_amd/batch.py) on CPU with gloo."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from plade_amd.batch import shard, gather_results
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _fake_T(i):
+    T = np.eye(4, dtype=np.float32)
+    T[:3, 3] = [i, 2 * i, -i]
+    T[0, 0] = np.float32(np.cos(i))
+    return T
+
+
+def _worker(rank, world, port, n_items, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mine = shard(n_items, rank, world)
+    T = np.stack([_fake_T(i) for i in mine]) if mine else np.zeros((0, 4, 4), np.float32)
+    ok = np.array([i % 3 != 0 for i in mine], bool)
+    dist.barrier()
+    Tg, okg = gather_results(T, ok, n_items, rank, world)
+    if rank == 0:
+        q.put((Tg, okg))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_partitions_everything():
+    for n in (0, 1, 5, 64):
+        for w in (1, 2, 3, 8):
+            allidx = sorted(i for r in range(w) for i in shard(n, r, w))
+            assert allidx == list(range(n))
+
+
+def test_gather_world2_gloo():
+    world, n_items = 2, 7
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_items, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    Tg, okg = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for i in range(n_items):
+        assert np.array_equal(Tg[i], _fake_T(i))
+        assert okg[i] == (i % 3 != 0)
+
+
+def test_gather_world1():
+    T = np.stack([_fake_T(i) for i in range(3)])
+    Tg, okg = gather_results(T, np.array([True, False, True]), 3, 0, 1)
+    assert np.array_equal(Tg, T) and okg.tolist() == [True, False, True]

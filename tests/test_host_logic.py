@@ -1,0 +1,82 @@
+"""Host-side logic that needs no GPU: the synthetic generator, PLY I/O, the CLI's argument / failure
+behaviour (code/PLADE/main.cpp), and oracle properties on small inputs."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from plade_amd.synth import make_pair, sample_scene, planes_from_labels
+from plade_amd.plyio import read_ply, write_ply
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "plade_amd", "PLADE")
+
+
+def test_generator_is_deterministic_and_oriented():
+    a, la = sample_scene(20000, scene_seed=3, sample_seed=4, return_labels=True)
+    b, lb = sample_scene(20000, scene_seed=3, sample_seed=4, return_labels=True)
+    assert np.array_equal(a, b) and np.array_equal(la, lb)
+    assert np.allclose(np.linalg.norm(a[:, 3:], axis=1), 1, atol=1e-5)
+    assert abs((la < 0).mean() - 0.03) < 0.005
+    tg, sr, T = make_pair(20000, seed=1)
+    assert abs(len(sr) / len(tg) - 1) < 0.05 and len(sr) < 1.2 * len(tg)   # no swap (plade.cpp:690)
+    assert np.allclose(T[:3, :3] @ T[:3, :3].T, np.eye(3), atol=1e-9)
+    co, off, idx = planes_from_labels(a, la)
+    assert len(co) >= 15 and off[-1] == len(idx) and len(np.unique(idx)) == len(idx)
+
+
+def test_ply_round_trip(tmp_path):
+    a = sample_scene(1000, scene_seed=1, sample_seed=2)
+    p = tmp_path / "c.ply"
+    write_ply(str(p), a)
+    assert np.array_equal(read_ply(str(p)), a)
+
+
+@pytest.mark.skipif(not os.path.exists(CLI), reason="CLI not built")
+def test_cli_usage_and_failure_paths(tmp_path):
+    r = subprocess.run([CLI], capture_output=True, text=True)
+    assert r.returncode == 1 and "Usage 1" in r.stderr and "Usage 2" in r.stderr
+    out = tmp_path / "res.txt"
+    # wrong extension: registration() refuses before touching the GPU (plade.cpp:671-674)
+    r = subprocess.run([CLI, "a.xyz", "b.xyz", str(out)], capture_output=True, text=True)
+    assert r.returncode == 1 and "only PLY format is accepted" in r.stderr
+    assert out.read_text() == ("registration failed, an identity matrix is recorded:\n"
+                               "1 0 0 0\n0 1 0 0\n0 0 1 0\n0 0 0 1\n")
+    # unreadable pair list / result file
+    r = subprocess.run([CLI, str(tmp_path / "nope.txt"), str(out)], capture_output=True, text=True)
+    assert r.returncode == 1 and "failed opening the file containing pairs" in r.stderr
+    # batch mode with missing files: every pair skipped -> "registration all failed (0 pairs)"
+    lst = tmp_path / "pairs.txt"
+    lst.write_text("/no/such/a.ply\n/no/such/b.ply\n")
+    r = subprocess.run([CLI, str(lst), str(out)], capture_output=True, text=True)
+    assert r.returncode == 1 and "file doesn't exist" in r.stderr and "registration all failed" in r.stderr
+
+
+def test_oracle_edge_cases(oracle):
+    # empty / tiny inputs
+    assert len(oracle.score_plane(np.zeros((0, 6), np.float32), None, np.array([0, 0, 1, 0], np.float32), 0.1, 0.8)) == 0
+    off, nbr, d2 = oracle.match_descriptors(np.zeros((0, 8), np.float32), np.zeros((5, 8), np.float32))
+    assert len(nbr) == 0 and off.tolist() == [0]
+    off, nbr, d2 = oracle.match_descriptors(np.zeros((3, 8), np.float32), np.zeros((0, 8), np.float32))
+    assert len(nbr) == 0 and off.tolist() == [0, 0, 0, 0]
+    # parallel planes have no intersection line (|n1.n2| > 0.95, util.cpp:634)
+    rc, v, p = oracle.intersection_line([0, 0, 1, -1], [0, 0.05, 0.9987, 2])
+    assert rc != 0
+    rc, v, p = oracle.intersection_line([0, 0, 1, -1], [1, 0, 0, -2])
+    assert rc == 0 and abs(abs(v[1]) - 1) < 1e-6 and np.allclose(p, [2, 0, 1])
+    # voxel grid: idempotent centroid for one point per voxel, ordered by (k, j, i)
+    pts = np.array([[0.9, 0.1, 0.1], [0.1, 0.1, 0.1], [0.1, 0.9, 0.1], [0.1, 0.1, 0.9]], np.float32)
+    ds = oracle.voxel_downsample(pts, 0.5, 0)
+    assert np.array_equal(ds, pts[[1, 0, 2, 3]])
+    # stable and std::sort orders agree to a few ulp on a real cloud
+    c = sample_scene(20000, scene_seed=7, sample_seed=8)
+    a, b = oracle.voxel_downsample(c, 0.2, 0), oracle.voxel_downsample(c, 0.2, 1)
+    assert a.shape == b.shape and np.abs(a - b).max() < 1e-5
+
+
+def test_oracle_registration_small_pair_recovers_ground_truth(oracle):
+    tg, sr, Tgt, tl, sl = make_pair(30000, seed=0, n_boxes=4, return_labels=True)
+    ok, T, d = oracle.registration(tg, sr, planes_from_labels(tg, tl), planes_from_labels(sr, sl))
+    assert ok and np.linalg.norm(T - Tgt) < 0.01
+    assert d["overlap_counts"].max() > 0.5 * len(d["src_ds"]) / 3

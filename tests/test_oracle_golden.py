@@ -1,0 +1,109 @@
+"""The oracle (oracle/plade_oracle.cpp) against golden vectors produced by the REAL reference pieces
+(libransac, libann, FLANN, Eigen 3.4.0 compiled from /root/reference; tools/make_golden.py).
+Runs on CPU, no GPU, no /root/reference needed."""
+import os
+import subprocess
+import numpy as np
+import pytest
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(G, name), allow_pickle=False)
+
+
+def test_g1_score_lists_bit_exact(oracle):
+    g = load("g1_score.npz")
+    pos = 0
+    n_ok = 0
+    for j in range(len(g["tri"])):
+        ok, pl = oracle.plane_from_points(g["tri"][j])
+        assert ok == bool(g["ok"][j])
+        if not ok:
+            continue
+        n_ok += 1
+        assert np.array_equal(pl, g["planes"][j]), "Plane::Init restatement must be bit-exact"
+        want = g["lists"][pos:pos + g["counts"][j]]
+        pos += g["counts"][j]
+        got = oracle.score_plane(g["cloud"], g["shape_index"], g["planes"][j], float(g["eps"]), float(g["cos_t"]))
+        assert np.array_equal(got, want), f"hypothesis {j}"
+    assert n_ok >= 20 and g["counts"].max() > 100 and not g["ok"][-1]
+
+
+def test_g3_connected_component_lsfit_weighted_score(oracle):
+    g = load("g3_cc.npz")
+    multi = 0
+    for i in range(int(g["n"])):
+        kept = oracle.connected_component(g[f"pts_{i}"], g[f"normal_{i}"], g[f"point_{i}"], g[f"idx_{i}"],
+                                          float(g[f"beps_{i}"]), bool(g[f"filt_{i}"]))
+        assert np.array_equal(kept, g[f"kept_{i}"]), f"case {i}"
+        multi += len(kept) < len(g[f"idx_{i}"])
+        if f"fit_{i}" in g.files:
+            fit = oracle.ls_fit(g[f"pts_{i}"], kept)
+            ref = g[f"fit_{i}"]
+            sgn = np.sign(fit[:3] @ ref[:3])
+            # tolerance: the reference accumulates mean/covariance in fp32 sequentially (GfxTL/Mean.h:31-46)
+            assert np.abs(sgn * fit[:3] - ref[:3]).max() < 5e-5
+            assert np.abs(fit[3:6] - ref[3:6]).max() < 1e-5
+            ws = oracle.weighted_score(g[f"pts_{i}"], g[f"normal_{i}"], g[f"point_{i}"], kept, 0.15)
+            assert abs(ws - float(g[f"wscore_{i}"])) <= 1e-4 * max(1.0, float(g[f"wscore_{i}"]))
+    assert multi >= 6, "fixtures must exercise the component selection"
+
+
+def test_g5_ann_radius_match(oracle):
+    g = load("g5_ann.npz")
+    off, nbr, d2 = oracle.match_descriptors(g["qry"], g["tgt"], float(g["radius"]))
+    assert np.array_equal(off, g["offsets"])
+    assert np.array_equal(nbr, g["nbr"])
+    assert np.array_equal(d2.astype(np.float32), g["dist"])  # the reference wrapper narrows ANN's double to float
+    # boundary cases present: the shell query must split the 64 shell targets
+    k = off[1] - off[0]
+    assert 0 < k < len(g["tgt"])
+    # membership equals ANN's irrespective of tie order
+    for q in range(len(off) - 1):
+        assert sorted(g["nbr_ann_order"][off[q]:off[q + 1]]) == sorted(nbr[off[q]:off[q + 1]])
+
+
+def test_g6_eigen_restatements_bit_exact(oracle):
+    g = load("g6_eigen.npz")
+    for s, d, R in zip(g["src"], g["dst"], g["R"]):
+        assert np.array_equal(oracle.umeyama3(s, d), R)
+    for c, ev, E in zip(g["cov"], g["evals"], g["evecs"]):
+        ev2, E2 = oracle.selfadjoint_eig3(c)
+        assert np.array_equal(ev2, ev) and np.array_equal(E2, E)
+
+
+def test_g7_overlap_counts(oracle):
+    g = load("g7_overlap.npz")
+    for T, c, want in zip(g["T"], g["centers"], g["counts"]):
+        assert oracle.overlap_count(g["src"], g["tgt"], T, c, float(g["radius"]), float(g["leaf"])) == want
+    assert g["counts"][-1] == -1 and g["counts"][:-1].max() > 1000
+
+
+def test_average_spacing_bit_exact(oracle):
+    g = load("g_spacing.npz")
+    assert np.float32(oracle.average_spacing(g["cloud"])) == g["spacing"]
+
+
+def test_eigen_stream_format_and_inverse_of_the_cxx_shim(tmp_path):
+    """plade_compat.h reproduces Eigen's default operator<< (main.cpp:86) and Matrix4f::inverse."""
+    g = load("g6_eigen.npz")
+    root = os.path.dirname(G)
+    src = tmp_path / "fmt.cpp"
+    src.write_text('''
+#include "plade_compat.h"
+#include <iostream>
+#include <cstdio>
+int main(){ int n; if(scanf("%d",&n)!=1) return 1; for(int k=0;k<n;++k){ Eigen::Matrix<float,4,4> m; for(int r=0;r<4;++r)for(int c=0;c<4;++c){ float v; if(scanf("%f",&v)!=1) return 1; m(r,c)=v; }
+ std::cout<<m<<"\\n@@\\n"; Eigen::Matrix<float,4,4> inv=m.inverse(); for(int r=0;r<4;++r)for(int c=0;c<4;++c) printf("%.9g ",inv(r,c)); printf("\\n@@\\n"); } }
+''')
+    exe = tmp_path / "fmt"
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I", os.path.join(os.path.dirname(root), "plade_amd", "csrc"), str(src), "-o", str(exe)])
+    mats = g["mats"]
+    inp = f"{len(mats)}\n" + "\n".join(" ".join(f"{v:.9g}" for v in m.ravel()) for m in mats) + "\n"
+    out = subprocess.run([str(exe)], input=inp, capture_output=True, text=True, check=True).stdout.split("\n@@\n")
+    for i, m in enumerate(mats):
+        assert out[2 * i] == str(g["strs"][i]), (out[2 * i], str(g["strs"][i]))
+        inv = np.array(out[2 * i + 1].split(), np.float64).reshape(4, 4)
+        assert np.abs(inv - g["invs"][i]).max() < 2e-6

@@ -1,0 +1,178 @@
+"""Generates tests/golden/*.npz from the REAL reference pieces (oracle/_ref, built from
+/root/reference by oracle/ref/Makefile).  Run in the build container only:
+
+    python tools/make_golden.py
+
+Fixtures are data (inputs + expected outputs), never reference source.  G-numbers follow
+SURVEY.md section 8c.
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle.oracle import Reference  # noqa: E402
+from plade_amd.synth import sample_scene  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+R = Reference()
+rng = np.random.default_rng(20260928)
+
+# ---- G1: plane-score KATs through libransac's octree visitor -------------------------------------
+cloud = sample_scene(6000, scene_seed=21, sample_seed=22, n_boxes=3)
+n = len(cloud)
+si = np.full(n, -1, np.int32)
+si[rng.random(n) < 0.15] = 1
+tri = cloud[rng.integers(0, n, (24, 3)), :3].reshape(24, 9)
+# a few hypotheses that are real planes of the scene (3 points of one face)
+big = sample_scene(6000, scene_seed=21, sample_seed=23, n_boxes=3, return_labels=True)
+for f in range(6):
+    ids = np.nonzero(big[1] == f)[0][:3]
+    tri[f] = big[0][ids, :3].reshape(9)
+tri[23, 3:6] = tri[23, 0:3]  # degenerate: Plane::Init must refuse it
+eps, cos_t = np.float32(0.05), np.float32(0.8)
+re, orig, planes, ok, counts, lists = R.score_kat(cloud, si, tri, eps, cos_t)
+np.savez_compressed(os.path.join(OUT, "g1_score.npz"), cloud=re, shape_index=si[orig], tri=tri, planes=planes, ok=ok,
+                    counts=counts, lists=np.concatenate(lists).astype(np.int32), eps=eps, cos_t=cos_t)
+
+# ---- G3 / A5: connected component + LS fit + weighted score ---------------------------------------
+cc_cases = []
+scene, lab = sample_scene(30000, scene_seed=31, sample_seed=32, n_boxes=4, return_labels=True)
+for case in range(6):
+    # a plane z = const with several separated blobs of inliers (+ closing-sensitive gaps)
+    m = 1500
+    pts = np.zeros((m, 6), np.float32)
+    centres = rng.uniform(-3, 3, (4, 2))
+    sizes = [0.9, 0.5, 0.35, 0.2]
+    which = rng.integers(0, 4, m)
+    pts[:, 0] = centres[which, 0] + rng.uniform(-1, 1, m) * np.array(sizes)[which]
+    pts[:, 1] = centres[which, 1] + rng.uniform(-1, 1, m) * np.array(sizes)[which]
+    pts[:, 2] = 0.3 + rng.normal(0, 0.004, m)
+    pts[:, 5] = 1.0
+    if case % 2:  # rotate the whole thing so the plane is oblique
+        a = rng.normal(size=3); a /= np.linalg.norm(a)
+        b = np.cross(a, [0.3, 0.5, 0.8]); b /= np.linalg.norm(b)
+        c = np.cross(a, b)
+        Rm = np.stack([b, c, a], 1)
+        pts[:, :3] = pts[:, :3] @ Rm.T
+        pts[:, 3:] = pts[:, 3:] @ Rm.T
+        normal = Rm[:, 2].astype(np.float32)
+        point = (Rm @ np.array([0, 0, 0.3])).astype(np.float32)
+    else:
+        normal = np.array([0, 0, 1], np.float32)
+        point = np.array([0, 0, 0.3], np.float32)
+    idx = rng.permutation(m).astype(np.int32)[: m - 37]
+    beps = np.float32([0.2, 0.12, 0.3][case % 3])
+    for filt in (1, 0):
+        kept = R.connected_component(pts, normal, point, idx, beps, bool(filt))
+        cc_cases.append(dict(pts=pts, normal=normal, point=point, idx=idx, beps=beps, filt=filt, kept=kept))
+    fit = R.ls_fit(pts, kept)
+    ws = R.weighted_score(pts, normal, point, kept, np.float32(0.15))
+    cc_cases[-1]["fit"] = fit
+    cc_cases[-1]["wscore"] = np.float32(ws)
+np.savez_compressed(os.path.join(OUT, "g3_cc.npz"), n=len(cc_cases),
+                    **{f"{k}_{i}": v for i, c in enumerate(cc_cases) for k, v in c.items()})
+
+# ---- G5: descriptor radius match through libann's KdTreeSearchNDim --------------------------------
+t = (rng.random((4000, 8)) * 0.22).astype(np.float32)
+q = np.concatenate([t[:400] + rng.normal(0, 0.012, (400, 8)).astype(np.float32), (rng.random((100, 8)) * 0.22).astype(np.float32)])
+# distances straddling r^2: one query, targets on a shell around it
+r = np.float32(0.04)
+shell = np.tile(q[0], (64, 1))
+shell[:, 0] += np.float32(r) + (np.arange(64) - 32).astype(np.float32) * np.float32(2e-9)
+t = np.concatenate([t, shell]).astype(np.float32)
+off, nbr, d = R.ann_radius_match(q, t, float(r))
+# ANN's order among value-identical distances is kd-tree dependent: store (dist, idx)-sorted
+order = np.concatenate([o0 + np.lexsort((nbr[o0:o1], d[o0:o1])) for o0, o1 in zip(off[:-1], off[1:])]).astype(np.int64) if len(nbr) else np.zeros(0, np.int64)
+np.savez_compressed(os.path.join(OUT, "g5_ann.npz"), qry=q, tgt=t, radius=r, offsets=off, nbr=nbr[order], dist=d[order],
+                    nbr_ann_order=nbr)
+
+# ---- G6: Eigen umeyama / SelfAdjointEigenSolver / Matrix3f*v+t / Matrix4f inverse / operator<< ------
+src, dst, Rs = [], [], []
+for i in range(300):
+    a = rng.normal(size=3); b = rng.normal(size=3)
+    a /= np.linalg.norm(a); b /= np.linalg.norm(b)
+    qn = rng.normal(size=4); qn /= np.linalg.norm(qn)
+    w, x, y, z = qn
+    Rm = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                   [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                   [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+    a2, b2 = Rm @ a + rng.normal(0, 1e-3, 3), Rm @ b + rng.normal(0, 1e-3, 3)
+    if i % 5 == 0:
+        a2, b2 = rng.normal(size=3), rng.normal(size=3)  # inconsistent pair
+    s = np.stack([a, b, np.cross(a, b)]).astype(np.float32)
+    dd = np.stack([a2, b2, np.cross(a2, b2)]).astype(np.float32)
+    src.append(s); dst.append(dd); Rs.append(R.umeyama3(s, dd)[:3, :3])
+covs, evals, evecs = [], [], []
+for i in range(300):
+    B = rng.normal(size=(3, 3)) * (10.0 if i % 3 == 0 else 1.0)
+    C = (B @ B.T).astype(np.float32)
+    C = ((C + C.T) / 2).astype(np.float32)
+    if i % 7 == 0:
+        C[2, 0] = C[0, 2] = 0
+    ev, E = R.selfadjoint_eig3(C)
+    covs.append(C); evals.append(ev); evecs.append(E)
+aff = []
+for i in range(200):
+    Rm = rng.normal(size=(3, 3)).astype(np.float32); v = rng.normal(size=3).astype(np.float32); tt = rng.normal(size=3).astype(np.float32)
+    aff.append(np.concatenate([Rm.ravel(), v, tt, R.affine3(Rm, v, tt)]))
+mats, invs, strs = [], [], []
+for i in range(12):
+    M = np.eye(4, dtype=np.float32)
+    M[:3, :3] = Rs[i]
+    M[:3, 3] = rng.uniform(-5, 5, 3)
+    if i == 3:
+        M[2, 2] = -0.0
+    if i == 4:
+        M = np.eye(4, dtype=np.float32)
+    mats.append(M); invs.append(R.inverse4(M)); strs.append(R.format_matrix4(M))
+np.savez_compressed(os.path.join(OUT, "g6_eigen.npz"), src=np.array(src), dst=np.array(dst), R=np.array(Rs),
+                    cov=np.array(covs), evals=np.array(evals), evecs=np.array(evecs), affine=np.array(aff, np.float32),
+                    mats=np.array(mats), invs=np.array(invs), strs=np.array(strs))
+
+# ---- G7: overlap counts through FLANN composed as util.h:611-647 ------------------------------------
+cloud = sample_scene(40000, scene_seed=41, sample_seed=42, n_boxes=4)
+sys.path.insert(0, ROOT)
+from oracle.oracle import Oracle  # noqa: E402  (only to voxelise the test input; expected values come from FLANN)
+O = Oracle()
+leaf = np.float32(0.15)
+tg = O.voxel_downsample(cloud, leaf, 1)
+sr = (tg + rng.normal(0, 0.04, tg.shape)).astype(np.float32)[::2]
+Ts, cs, cnts = [], [], []
+radius = np.float32(4.5)
+for k in range(10):
+    ang = rng.normal(0, 0.04 if k % 3 else 0.6)
+    c, s = np.cos(ang), np.sin(ang)
+    T = np.eye(4, dtype=np.float32)
+    T[:2, :2] = [[c, -s], [s, c]]
+    T[:3, 3] = rng.normal(0, 0.1 if k % 2 else 1.5, 3)
+    if k == 9:
+        T[:3, 3] = 400.0
+    ctr = (T[:3, :3] @ np.array([0.2, -0.1, 0.0], np.float32) + T[:3, 3]).astype(np.float32)
+    tp = np.stack([(T[r, 0] * sr[:, 0] + T[r, 1] * sr[:, 1] + T[r, 2] * sr[:, 2]) + T[r, 3] for r in range(3)], 1).astype(np.float32)
+    Ts.append(T); cs.append(ctr); cnts.append(R.overlap_count(tp, tg, ctr, radius, leaf))
+np.savez_compressed(os.path.join(OUT, "g7_overlap.npz"), src=sr, tgt=tg, T=np.array(Ts), centers=np.array(cs),
+                    counts=np.array(cnts, np.int32), radius=radius, leaf=leaf)
+
+# ---- A13: average spacing composed from FLANN kNN exactly as util.cpp:1619-1648 ----------------------
+cloud = sample_scene(50000, scene_seed=51, sample_seed=52, n_boxes=3)
+step = len(cloud) // 10000
+qs = cloud[::step, :3]
+idx, d = R.knn_d2(cloud[:, :3], qs, 6)
+tot = 0.0
+for row in d:
+    avg = 0.0
+    for v in row[1:]:
+        avg += float(np.sqrt(np.float32(v)))
+    tot += avg / 6
+np.savez_compressed(os.path.join(OUT, "g_spacing.npz"), cloud=cloud[:, :3].copy(), spacing=np.float32(tot / len(d)))
+# radius-search membership (strict <) on a few queries incl. exact-boundary cases
+qq = cloud[:50, :3].copy()
+sets = R.radius_sets(cloud[:5000, :3], qq, 0.3)
+np.savez_compressed(os.path.join(OUT, "g_radius.npz"), cloud=cloud[:5000, :3].copy(), queries=qq, radius=np.float32(0.3),
+                    sizes=np.array([len(s) for s in sets], np.int32),
+                    members=np.concatenate([np.sort(s) for s in sets]).astype(np.int32))
+print("golden fixtures written to", OUT, [f for f in sorted(os.listdir(OUT))])
