@@ -79,11 +79,15 @@ __global__ void k_gather_cells(const float *__restrict__ xyz, uint32_t stride, c
     if (i == n - 1 || keys[i + 1] != k) cell_end[k] = i + 1;
 }
 
-void TargetGrid::build(plade_ctx *ctx, const float *d_xyz, uint32_t n_pts, uint32_t stride, float min_cell) {
+void TargetGrid::build(plade_ctx *ctx, const float *d_xyz, uint32_t n_pts, uint32_t stride, float min_cell,
+                       const float *bbox_min, const float *bbox_max) {
     n = n_pts;
     if (n == 0) return;
     float init[6];
     int iinit[6];
+    if (bbox_min && bbox_max) {
+        for (int k = 0; k < 3; ++k) { init[k] = bbox_min[k]; init[3 + k] = bbox_max[k]; }
+    } else {
     for (int k = 0; k < 3; ++k) {
         float a = INFINITY, b = -INFINITY;
         int ia, ib;
@@ -101,6 +105,7 @@ void TargetGrid::build(plade_ctx *ctx, const float *d_xyz, uint32_t n_pts, uint3
     for (int k = 0; k < 6; ++k) {
         int v = ih[k] >= 0 ? ih[k] : ih[k] ^ 0x7fffffff;
         memcpy(&init[k], &v, 4);
+    }
     }
     // cell strictly larger than the probe radius so a +-1 cell probe is exhaustive even with the
     // fp32 rounding of the cell coordinate

@@ -20,7 +20,7 @@ namespace plade {
 constexpr int TPB = 256;
 constexpr int PPT = 4;
 constexpr int TILE = TPB * PPT;  // 1024 points per block
-constexpr int HCHUNK = 128;
+constexpr int HCHUNK = 32;
 
 __device__ __forceinline__ bool compatible(float4 pl, float px, float py, float pz, float qx, float qy, float qz,
                                            float eps, float cos_t) {
@@ -138,43 +138,21 @@ __global__ __launch_bounds__(TPB) void k_score_mark(const float *__restrict__ x,
     if (threadIdx.x == 0) block_counts[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
 }
 
-// exclusive scan of block counts, single block; also writes the grand total
-__global__ __launch_bounds__(1024) void k_scan_blocks(const uint32_t *__restrict__ in, uint32_t nb,
-                                                      uint32_t *__restrict__ out, uint32_t *__restrict__ total) {
-    __shared__ uint32_t s_wave[16];
-    __shared__ uint32_t s_carry;
-    if (threadIdx.x == 0) s_carry = 0;
-    __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (uint32_t base = 0; base < nb; base += 1024) {
-        uint32_t i = base + threadIdx.x;
-        uint32_t v = i < nb ? in[i] : 0u;
-        uint32_t incl = v;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            uint32_t o = __shfl_up(incl, d, 64);
-            if (lane >= d) incl += o;
-        }
-        if (lane == 63) s_wave[wave] = incl;
-        __syncthreads();
-        uint32_t woff = 0;
-        for (int w = 0; w < wave; ++w) woff += s_wave[w];
-        uint32_t carry = s_carry;
-        if (i < nb) out[i] = carry + woff + incl - v;
-        __syncthreads();
-        if (threadIdx.x == 1023) s_carry = carry + woff + incl;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) *total = s_carry;
-}
-
+// ordered compaction; every block derives its output offset from the preceding blocks' counts itself
+// (nb is ~1e3, the count array is L2 resident), which saves a dependent launch per compaction
 __global__ __launch_bounds__(TPB) void k_compact(const uint8_t *__restrict__ masks,
-                                                 const uint32_t *__restrict__ block_offsets, uint32_t n,
-                                                 const uint32_t *__restrict__ values, uint32_t *__restrict__ out) {
+                                                 const uint32_t *__restrict__ block_counts, uint32_t nb,
+                                                 const uint32_t *__restrict__ values, uint32_t *__restrict__ out,
+                                                 uint32_t *__restrict__ total) {
     __shared__ uint32_t s_w[TPB / 64];
+    __shared__ uint32_t s_base[TPB / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t pre = 0;
+    for (uint32_t b = threadIdx.x; b < blockIdx.x; b += TPB) pre += block_counts[b];
+    for (int d = 32; d >= 1; d >>= 1) pre += __shfl_xor(pre, d, 64);
+    if (lane == 0) s_base[wave] = pre;
     const uint32_t m = masks[blockIdx.x * TPB + threadIdx.x];
     const uint32_t c = __popc(m);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t incl = c;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -183,16 +161,17 @@ __global__ __launch_bounds__(TPB) void k_compact(const uint8_t *__restrict__ mas
     }
     if (lane == 63) s_w[wave] = incl;
     __syncthreads();
-    uint32_t off = block_offsets[blockIdx.x] + incl - c;
+    const uint32_t base = s_base[0] + s_base[1] + s_base[2] + s_base[3];
+    uint32_t off = base + incl - c;
     for (int w = 0; w < wave; ++w) off += s_w[w];
-    const uint32_t base = blockIdx.x * TILE + threadIdx.x * PPT;
+    if (blockIdx.x == nb - 1 && threadIdx.x == TPB - 1) *total = off + c;
+    const uint32_t first = blockIdx.x * TILE + threadIdx.x * PPT;
 #pragma unroll
     for (int k = 0; k < PPT; ++k)
         if (m & (1u << k)) {
-            uint32_t i = base + k;
+            uint32_t i = first + k;
             out[off++] = values ? values[i] : i;
         }
-    (void)n;
 }
 
 void score_multi(plade_ctx *ctx, const float *x, const float *y, const float *z, const float *nx, const float *ny,
@@ -213,11 +192,9 @@ void compact_masks(plade_ctx *ctx, CompactScratch &s, uint32_t n, const uint32_t
                    uint32_t *count_dev) {
     const uint32_t nb = cdiv(n, TILE);
     if (nb == 0) { HIP_TRY(hipMemsetAsync(count_dev, 0, 4, ctx->stream)); return; }
-    s.block_offsets.ensure(nb);
-    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, ctx->stream, s.block_counts.p, nb, s.block_offsets.p,
-                       count_dev);
-    hipLaunchKernelGGL(k_compact, dim3(nb), dim3(TPB), 0, ctx->stream, s.masks.p, s.block_offsets.p, n, values,
-                       idx_out_dev);
+    hipLaunchKernelGGL(k_compact, dim3(nb), dim3(TPB), 0, ctx->stream, s.masks.p, s.block_counts.p, nb, values,
+                       idx_out_dev, count_dev);
+    (void)n;
     HIP_TRY(hipGetLastError());
 }
 

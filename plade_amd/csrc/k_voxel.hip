@@ -14,6 +14,7 @@
 //     double.  Exact brute-force kNN on the GPU: the k smallest fp32 distances are the same numbers
 //     whatever search structure finds them.
 #include "voxel.h"
+#include "overlap.h"
 #include "prims.h"
 
 namespace plade {
@@ -140,99 +141,103 @@ uint32_t VoxelWork::run(plade_ctx *ctx, const float *d_xyz, uint32_t stride, con
 }
 
 // ------------------------------------------------------------------------------------------------
-// average spacing
-constexpr int SP_TPB = 256;
-constexpr int SP_QB = 8;    // queries per block
+// average spacing: exact k nearest neighbours through a uniform grid, one wavefront per query.
+// Lanes sweep the cells of the current Chebyshev ring in parallel and keep private ascending top-K
+// lists; after each ring the wave extracts its K best by repeated arg-min and stops once the K-th
+// distance is closer than anything an outer ring could hold.
 constexpr int SP_K = 8;     // max k supported
 
-__global__ __launch_bounds__(SP_TPB) void k_knn_spacing(const float *__restrict__ x, const float *__restrict__ y,
-                                                        const float *__restrict__ z, uint32_t n, uint32_t step,
-                                                        uint32_t nq, int k, double *__restrict__ avg_out,
-                                                        uint32_t *__restrict__ nbs_out) {
-    __shared__ float s_q[SP_QB][3];
-    const uint32_t q0 = blockIdx.x * SP_QB;
-    if (threadIdx.x < SP_QB * 3) {
-        uint32_t qi = q0 + threadIdx.x / 3;
-        uint32_t pi = (qi < nq) ? qi * step : 0;
-        const float *src = (threadIdx.x % 3 == 0) ? x : (threadIdx.x % 3 == 1 ? y : z);
-        s_q[threadIdx.x / 3][threadIdx.x % 3] = src[pi];
-    }
-    __syncthreads();
-    f3 q[SP_QB];
-    float best[SP_QB][SP_K];
+struct SpGrid { float mnx, mny, mnz, inv, cell; int dx, dy, dz; };
+
+__global__ __launch_bounds__(256) void k_knn_grid(const float4 *__restrict__ pts, const uint32_t *__restrict__ cstart,
+                                                  const uint32_t *__restrict__ cend, SpGrid g,
+                                                  const float *__restrict__ aos, uint32_t stride_f, uint32_t n,
+                                                  uint32_t step, uint32_t nq, int k, double *__restrict__ avg_out,
+                                                  uint32_t *__restrict__ nbs_out) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t qi = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (qi >= nq) return;
+    const uint32_t pi = min(n - 1, qi * step);
+    const f3 q(aos[(size_t)pi * stride_f], aos[(size_t)pi * stride_f + 1], aos[(size_t)pi * stride_f + 2]);
+    const int cx = min(max((int)floorf((q.x - g.mnx) * g.inv), 0), g.dx - 1);
+    const int cy = min(max((int)floorf((q.y - g.mny) * g.inv), 0), g.dy - 1);
+    const int cz = min(max((int)floorf((q.z - g.mnz) * g.inv), 0), g.dz - 1);
+    float best[SP_K];
 #pragma unroll
-    for (int a = 0; a < SP_QB; ++a) {
-        q[a] = f3(s_q[a][0], s_q[a][1], s_q[a][2]);
+    for (int b = 0; b < SP_K; ++b) best[b] = INFINITY;
+    float kth[SP_K];
+    int found = 0;
+    const int max_ring = max(g.dx, max(g.dy, g.dz));
+    for (int ring = 0; ring <= max_ring; ++ring) {
+        const int w = 2 * ring + 1;
+        for (int t = lane; t < w * w * w; t += 64) {
+            const int ddx = t % w - ring, ddy = (t / w) % w - ring, ddz = t / (w * w) - ring;
+            if (max(abs(ddx), max(abs(ddy), abs(ddz))) != ring) continue;
+            const int x = cx + ddx, y = cy + ddy, z = cz + ddz;
+            if (x < 0 || y < 0 || z < 0 || x >= g.dx || y >= g.dy || z >= g.dz) continue;
+            const int c = x + g.dx * (y + g.dy * z);
+            for (uint32_t j = cstart[c]; j < cend[c]; ++j) {
+                const float4 p4 = pts[j];
+                float d = flann_d2(q, f3(p4.x, p4.y, p4.z));
+                if (d < best[SP_K - 1]) {
 #pragma unroll
-        for (int b = 0; b < SP_K; ++b) best[a][b] = INFINITY;
-    }
-    for (uint32_t i = threadIdx.x; i < n; i += SP_TPB) {
-        const f3 p(x[i], y[i], z[i]);
-#pragma unroll
-        for (int a = 0; a < SP_QB; ++a) {
-            float d = flann_d2(q[a], p);
-            if (d < best[a][SP_K - 1]) {
-                // insertion into the ascending list (only the first k entries are ever read back)
-#pragma unroll
-                for (int b = 0; b < SP_K; ++b) {
-                    if (d < best[a][b]) { float t = best[a][b]; best[a][b] = d; d = t; }
+                    for (int b = 0; b < SP_K; ++b)
+                        if (d < best[b]) { float tt = best[b]; best[b] = d; d = tt; }
                 }
             }
         }
-    }
-    // merge: each query is reduced by selecting the global minimum k times.  Lists are ascending, so
-    // every thread only ever offers its current head.
-    __shared__ float s_min[SP_TPB / 64];
-    __shared__ int s_arg[SP_TPB / 64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int a = 0; a < SP_QB; ++a) {
-        const uint32_t qi = q0 + a;
+        // wave-wide K smallest (lists are ascending: every lane offers its current head)
         int head = 0;
-        double avg = 0.0;
-        int found = 0;
+        found = 0;
         for (int r = 0; r < k; ++r) {
             float v = INFINITY;
 #pragma unroll
-            for (int b = 0; b < SP_K; ++b) if (b == head) v = best[a][b];
-            if (head >= SP_K) v = INFINITY;
-            // wave arg-min
+            for (int b = 0; b < SP_K; ++b) if (b == head) v = best[b];
             float mv = v;
-            int mi = threadIdx.x;
+            int ml = lane;
             for (int d = 32; d >= 1; d >>= 1) {
-                float ov = __shfl_xor(mv, d, 64);
-                int oi = __shfl_xor(mi, d, 64);
-                if (ov < mv || (ov == mv && oi < mi)) { mv = ov; mi = oi; }
+                const float ov = __shfl_xor(mv, d, 64);
+                const int ol = __shfl_xor(ml, d, 64);
+                if (ov < mv || (ov == mv && ol < ml)) { mv = ov; ml = ol; }
             }
-            if (lane == 0) { s_min[wave] = mv; s_arg[wave] = mi; }
-            __syncthreads();
-            float bv = s_min[0];
-            int bi = s_arg[0];
-            for (int w = 1; w < SP_TPB / 64; ++w)
-                if (s_min[w] < bv || (s_min[w] == bv && s_arg[w] < bi)) { bv = s_min[w]; bi = s_arg[w]; }
-            __syncthreads();
-            if (bv == INFINITY) break;
-            if ((int)threadIdx.x == bi) ++head;
+            if (mv == INFINITY) break;
+            if (lane == ml) ++head;
+            kth[r] = mv;
             ++found;
-            if (r >= 1) avg += (double)sqrtf(bv);  // util.cpp:1640-1642: starts from 1 to exclude itself
         }
-        if (threadIdx.x == 0 && qi < nq) {
-            avg_out[qi] = avg;
-            nbs_out[qi] = (uint32_t)found;
-        }
+        // everything in ring+1 and beyond is at least ring*cell away from q
+        const float bound = (float)ring * g.cell * 0.999f;
+        if (found == k && kth[k - 1] < bound * bound) break;
+    }
+    if (lane == 0) {
+        double avg = 0.0;
+        for (int r = 1; r < found; ++r) avg += (double)sqrtf(kth[r]);  // util.cpp:1640-1642: starts from 1 to exclude itself
+        avg_out[qi] = avg;
+        nbs_out[qi] = (uint32_t)found;
     }
 }
 
-float average_spacing_dev(plade_ctx *ctx, const float *d_x, const float *d_y, const float *d_z, uint32_t n, int k,
-                          uint32_t samples) {
+float average_spacing_dev(plade_ctx *ctx, const float *d_aos, uint32_t stride_f, uint32_t n, const float *bbmin,
+                          const float *bbmax, int k, uint32_t samples, TargetGrid &grid) {
     PLADE_REQUIRE(k >= 1 && k <= SP_K, PLADE_ELIMIT, "average_spacing: k must be in [1, 8]");
     if (n == 0) return 0.f;
     size_t step = 1;
     if (n > samples) step = n / samples;
     const uint32_t nq = (uint32_t)((n + step - 1) / step);
+    // cell ~ 2 x the spacing of a surface-like cloud filling its bounding box faces
+    const double ex = std::max(1e-9, (double)bbmax[0] - bbmin[0]), ey = std::max(1e-9, (double)bbmax[1] - bbmin[1]),
+                 ez = std::max(1e-9, (double)bbmax[2] - bbmin[2]);
+    const double area = 2 * (ex * ey + ey * ez + ex * ez);
+    float cell = (float)(2.0 * std::sqrt(area / (double)n));
+    if (!(cell > 0.f)) cell = 1.f;
+    grid.build(ctx, d_aos, n, stride_f, cell, bbmin, bbmax);
+    SpGrid g{grid.gp.mnx, grid.gp.mny, grid.gp.mnz, grid.gp.inv, 1.f / grid.gp.inv, grid.gp.dx, grid.gp.dy, grid.gp.dz};
     double *d_avg = reinterpret_cast<double *>(ctx->scratch[1].ensure((size_t)nq * 8 + 8));
     uint32_t *d_nbs = reinterpret_cast<uint32_t *>(ctx->scratch[2].ensure((size_t)nq * 4 + 8));
-    hipLaunchKernelGGL(k_knn_spacing, dim3(cdiv(nq, SP_QB)), dim3(SP_TPB), 0, ctx->stream, d_x, d_y, d_z, n,
-                       (uint32_t)step, nq, k, d_avg, d_nbs);
+    ctx->ev_begin("knn_spacing", 12.0 * n);
+    hipLaunchKernelGGL(k_knn_grid, dim3(cdiv(nq, 4)), dim3(256), 0, ctx->stream, grid.sorted.p, grid.cell_start.p,
+                       grid.cell_end.p, g, d_aos, stride_f, n, (uint32_t)step, nq, k, d_avg, d_nbs);
+    ctx->ev_end();
     HIP_TRY(hipGetLastError());
     std::vector<double> avg(nq);
     std::vector<uint32_t> nbs(nq);
@@ -310,13 +315,15 @@ extern "C" int plade_average_spacing(plade_ctx *ctx, const float *xyz, uint32_t 
                                      uint32_t samples, float *spacing_out) {
     return guarded(ctx, [&]() -> int {
         PLADE_REQUIRE(xyz && spacing_out && stride >= 3 && samples >= 1, PLADE_EINVAL, "plade_average_spacing: bad argument");
-        DBuf<float> d_in, d_soa;
+        *spacing_out = 0.f;
+        if (n == 0) return PLADE_OK;
+        DBuf<float> d_in;
         d_in.ensure((size_t)n * stride + 4);
-        d_soa.ensure((size_t)n * 3 + 4);
         HIP_TRY(hipMemcpyAsync(d_in.p, xyz, (size_t)n * stride * 4, hipMemcpyHostToDevice, ctx->stream));
-        if (n) hipLaunchKernelGGL(k_strided_to_soa, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, d_in.p, n, stride, d_soa.p,
-                                  d_soa.p + n, d_soa.p + 2 * (size_t)n);
-        *spacing_out = average_spacing_dev(ctx, d_soa.p, d_soa.p + n, d_soa.p + 2 * (size_t)n, n, (int)k, samples);
+        float mn[3], mx[3];
+        bbox_host(ctx, d_in.p, n, stride, mn, mx);
+        TargetGrid grid;
+        *spacing_out = average_spacing_dev(ctx, d_in.p, stride, n, mn, mx, (int)k, samples, grid);
         return PLADE_OK;
     });
 }

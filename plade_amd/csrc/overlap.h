@@ -12,7 +12,8 @@ struct TargetGrid {
     DBuf<uint32_t> keys, keys2, vals, vals2, cell_start, cell_end;
     DBuf<float4> sorted;  // target points in cell order: (x, y, z, bitcast original index)
     // d_xyz: device pointer, `stride` floats between points; min_cell = largest probe radius used.
-    void build(plade_ctx *ctx, const float *d_xyz, uint32_t n_pts, uint32_t stride, float min_cell);
+    void build(plade_ctx *ctx, const float *d_xyz, uint32_t n_pts, uint32_t stride, float min_cell,
+               const float *bbox_min = nullptr, const float *bbox_max = nullptr);  // known bbox skips a device round trip
 };
 
 // counts[k] (device, int32) and any[k] (device, 1 when the coarse sphere is non-empty)

@@ -183,7 +183,7 @@ struct RegistrationWork {
     PairTableDev tgt_pairs, src_pairs;
     MatchResult match;
     CandidateSet cand;
-    TargetGrid grid;
+    TargetGrid grid, sp_grid;
     DBuf<uint32_t> d_ids;
     DBuf<float> d_rt12, d_T16, d_centers;
     DBuf<int32_t> d_counts;
@@ -203,7 +203,7 @@ bool run_registration(plade_ctx *ctx, RegistrationWork &W, const CloudDev &tgt, 
     float average_space;
     {
         StageTimer t(ctx, "t_spacing");
-        average_space = average_spacing_dev(ctx, src.x(), src.y(), src.z(), src.n, 6, 10000);
+        average_space = average_spacing_dev(ctx, src.aos.p, 6, src.n, src.bbmin, src.bbmax, 6, 10000, W.sp_grid);
     }
     ctx->put1("average_spacing", average_space);
     // plade.cpp:46-56

@@ -210,14 +210,9 @@ __global__ void k_state_from_hyp(const float4 *__restrict__ hyp, const float4 *_
     st->pos[0] = pos->x; st->pos[1] = pos->y; st->pos[2] = pos->z;
     hcs_axes(st->n, st->a0, st->a1);
     st->err = 0;
-    *plane_out = *hyp;
-}
-
-__global__ void k_cc_begin(PlaneState *st) {
-    if (threadIdx.x || blockIdx.x) return;
     st->bb[0] = st->bb[1] = ord_i(INFINITY);
     st->bb[2] = st->bb[3] = ord_i(-INFINITY);
-    st->nsum[0] = st->nsum[1] = st->nsum[2] = 0.f;
+    *plane_out = *hyp;
 }
 
 // (u, v) parameters of the inliers + their bounding box (PlanePrimitiveShape::Parameters,
@@ -248,38 +243,37 @@ __global__ __launch_bounds__(256) void k_cc_params(CloudView c, const uint32_t *
 
 constexpr uint32_t CC_MAXPIX = 1u << 20;
 
-// BitmapExtent (PlanePrimitiveShape.cpp:185-191) + clear
-__global__ void k_cc_dims(PlaneState *st, const uint32_t *__restrict__ count, float eps, uint8_t *__restrict__ bmp) {
-    __shared__ uint32_t s_pix;
-    if (threadIdx.x == 0) {
-        uint32_t ue = 2, ve = 2;
-        if (*count) {
-            const float mnu = ord_f(st->bb[0]), mnv = ord_f(st->bb[1]), mxu = ord_f(st->bb[2]), mxv = ord_f(st->bb[3]);
-            const float fu = ceilf((mxu - mnu) / eps), fv = ceilf((mxv - mnv) / eps);
-            ue = (fu < 4.0e6f ? (uint32_t)fu : 4000000u) + 1;
-            ve = (fv < 4.0e6f ? (uint32_t)fv : 4000000u) + 1;
-            if (ue < 2) ue = 2;
-            if (ve < 2) ve = 2;
-        }
-        if ((uint64_t)ue * ve > CC_MAXPIX) { st->err = 1; ue = ve = 2; }
-        st->ue = ue; st->ve = ve;
-        s_pix = ue * ve;
+// BitmapExtent (PlanePrimitiveShape.cpp:185-191)
+__device__ __forceinline__ bool cc_dims(const PlaneState *st, uint32_t count, float eps, uint32_t &ue, uint32_t &ve) {
+    ue = 2; ve = 2;
+    if (count) {
+        const float mnu = ord_f(st->bb[0]), mnv = ord_f(st->bb[1]), mxu = ord_f(st->bb[2]), mxv = ord_f(st->bb[3]);
+        const float fu = ceilf((mxu - mnu) / eps), fv = ceilf((mxv - mnv) / eps);
+        ue = (fu < 4.0e6f ? (uint32_t)fu : 4000000u) + 1;
+        ve = (fv < 4.0e6f ? (uint32_t)fv : 4000000u) + 1;
+        if (ue < 2) ue = 2;
+        if (ve < 2) ve = 2;
     }
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < s_pix; i += blockDim.x) bmp[i] = 0;
+    if ((uint64_t)ue * ve > CC_MAXPIX) { ue = ve = 2; return false; }
+    return true;
 }
 
-// BuildBitmap (BitmapPrimitiveShape.h:139-150) with InBitmap (PlanePrimitiveShape.cpp:193-199)
+// BuildBitmap (BitmapPrimitiveShape.h:139-150) with InBitmap (PlanePrimitiveShape.cpp:193-199).
+// The bitmap is all-zero on entry (k_cc_label clears what it used).
 __global__ __launch_bounds__(256) void k_cc_raster(const float2 *__restrict__ uv, const uint32_t *__restrict__ count,
-                                                   const PlaneState *st, float eps, uint32_t *__restrict__ bidx,
+                                                   PlaneState *st, float eps, uint32_t *__restrict__ bidx,
                                                    uint8_t *__restrict__ bmp) {
+    const uint32_t m = *count;
+    uint32_t ue, ve;
+    const bool ok = cc_dims(st, m, eps, ue, ve);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { st->ue = ue; st->ve = ve; if (!ok) st->err = 1; }
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= *count) return;
+    if (i >= m || !ok) return;
     const float mnu = ord_f(st->bb[0]), mnv = ord_f(st->bb[1]);
     int bu = (int)floorf((uv[i].x - mnu) / eps), bv = (int)floorf((uv[i].y - mnv) / eps);
-    bu = min(max(bu, 0), (int)st->ue - 1);
-    bv = min(max(bv, 0), (int)st->ve - 1);
-    const uint32_t b = (uint32_t)bu + (uint32_t)bv * st->ue;
+    bu = min(max(bu, 0), (int)ue - 1);
+    bv = min(max(bv, 0), (int)ve - 1);
+    const uint32_t b = (uint32_t)bu + (uint32_t)bv * ue;
     bidx[i] = b;
     bmp[b] = 1;
 }
@@ -360,6 +354,7 @@ __global__ __launch_bounds__(1024) void k_cc_label(PlaneState *st, uint8_t *__re
         if (s_best == 0ull) { st->best_root = 0xffffffffu; st->n_fg = 0; }
         else { st->best_root = 0xffffffffu - (uint32_t)(s_best & 0xffffffffu); st->n_fg = (uint32_t)(s_best >> 32); }
     }
+    for (int p = threadIdx.x; p < npx; p += blockDim.x) bmp[p] = 0;  // leave the bitmap clean for the next raster
 }
 
 // mask layout of k_compact: one byte per lane covering 4 consecutive items, block counts per 1024
@@ -428,17 +423,21 @@ __device__ void jacobi3_d(double a[3][3], double d[3], double v[3][3]) {
     for (int i = 0; i < 3; ++i) d[i] = a[i][i];
 }
 
-// mode 0: write the fitted plane into `st` / plane_out.  mode 1: only accumulate the normal sum
-// (orientation of the final plane).
+// Sums the per-block partials of the index list `count` belongs to; nsum_out receives the sum of the
+// list's point normals (orientation).  mode 0 additionally writes the fitted plane into `st` (the NEXT
+// slot's state) / plane_out.
 __global__ void k_fit_final(const double *__restrict__ part, const uint32_t *__restrict__ count, PlaneState *st,
-                            float4 *plane_out, int mode) {
+                            float4 *plane_out, float *__restrict__ nsum_out, int mode) {
     if (threadIdx.x || blockIdx.x) return;
     double a[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (int b = 0; b < FIT_BLOCKS; ++b) for (int k = 0; k < 12; ++k) a[k] += part[b * 12 + k];
-    st->nsum[0] = (float)a[9]; st->nsum[1] = (float)a[10]; st->nsum[2] = (float)a[11];
+    nsum_out[0] = (float)a[9]; nsum_out[1] = (float)a[10]; nsum_out[2] = (float)a[11];
     if (mode == 1) return;
+    st->err = 0;
+    st->bb[0] = st->bb[1] = ord_i(INFINITY);
+    st->bb[2] = st->bb[3] = ord_i(-INFINITY);
     const double m = (double)*count;
-    if (m < 3) { st->err = 2; return; }
+    if (m < 3) { st->err = 2; *plane_out = make_float4(0.f, 0.f, 0.f, __int_as_float(0x7fc00000)); return; }
     const double mx = a[0] / m, my = a[1] / m, mz = a[2] / m;
     double cv[3][3];
     cv[0][0] = a[3] / m - mx * mx; cv[0][1] = a[4] / m - mx * my; cv[0][2] = a[5] / m - mx * mz;
@@ -480,11 +479,12 @@ __global__ __launch_bounds__(256) void k_wscore_partial(CloudView c, const uint3
     __syncthreads();
     if (threadIdx.x == 0) part[blockIdx.x] = (s[0] + s[1]) + (s[2] + s[3]);
 }
-__global__ void k_wscore_final(const double *__restrict__ part, PlaneState *st) {
-    if (threadIdx.x || blockIdx.x) return;
+// one launch sums the partials of all four slots
+__global__ void k_wscore_final(const double *__restrict__ part /* 4 x FIT_BLOCKS */, PlaneState *st /* 4 */) {
+    if (blockIdx.x || threadIdx.x >= 4) return;
     double a = 0;
-    for (int b = 0; b < FIT_BLOCKS; ++b) a += part[b];
-    st->wscore = a;
+    for (int b = 0; b < FIT_BLOCKS; ++b) a += part[threadIdx.x * FIT_BLOCKS + b];
+    st[threadIdx.x].wscore = a;
 }
 
 __global__ void k_assign(const uint32_t *__restrict__ idx, uint32_t m, int32_t id, int32_t *__restrict__ assigned) {
@@ -512,14 +512,17 @@ struct RansacWork {
     uint32_t n_sub = 0;
     DBuf<float4> hyp, hyp_pos, top, top_pos, plane_cur;
     DBuf<uint32_t> hyp_counts, top_counts, misc;
-    DBuf<PlaneState> st;
+    DBuf<PlaneState> st;            // 4 slots: candidate + 3 refits
     CompactScratch cs, cs2;
-    DBuf<uint32_t> idxA, idxB, idxC, cntA, cntB;
+    DBuf<uint32_t> idxA, cntA;      // score(3 eps) list before the connected component
+    DBuf<uint32_t> idxS[4], cntS;   // per-slot result lists / counts
+    DBuf<float> nsum;               // 4 x 3
     DBuf<float2> uv;
     DBuf<uint32_t> bidx, label, sizes;
     DBuf<uint8_t> bmp, tmp;
-    DBuf<double> part;
+    DBuf<double> part, part_ws;
     DBuf<int32_t> out_idx;
+    HBuf<char> pinned;
 };
 
 RansacWork *ransac_work_create() { return new RansacWork; }
@@ -533,28 +536,31 @@ struct Accepted {
     uint32_t offset;   // into out_idx
 };
 
-// one GlobalWeightedScore: score(3 eps) -> connected component -> weighted score; result in idx_out
-void global_weighted_score(plade_ctx *ctx, RansacWork &W, const CloudView &cv, float eps3, float cos_t, float bitmap_eps,
-                           uint32_t *idx_out, uint32_t *cnt_out) {
+// GlobalWeightedScore of slot k (Candidate.h:293-302): score(3 eps) -> ConnectedComponent -> weighted
+// score.  Plane from plane_cur[k] / st[k]; results in idxS[k], cntS[k], part_ws[k].
+void global_weighted_score(plade_ctx *ctx, RansacWork &W, const CloudView &cv, int k, float eps3, float cos_t,
+                           float bitmap_eps) {
     const CloudDev &c = W.sorted;
-    score_compact(ctx, W.cs, c.x(), c.y(), c.z(), c.nx(), c.ny(), c.nz(), W.assigned.p, c.n, W.plane_cur.p, eps3, cos_t,
+    PlaneState *st = W.st.p + k;
+    score_compact(ctx, W.cs, c.x(), c.y(), c.z(), c.nx(), c.ny(), c.nz(), W.assigned.p, c.n, W.plane_cur.p + k, eps3, cos_t,
                   W.idxA.p, W.cntA.p);
-    // ConnectedComponent (Candidate.cpp:89-94 -> BitmapPrimitiveShape.cpp:157-205), doFiltering = true
     const uint32_t nb = cdiv(c.n, 256);
-    hipLaunchKernelGGL(k_cc_begin, dim3(1), dim3(1), 0, ctx->stream, W.st.p);
-    hipLaunchKernelGGL(k_cc_params, dim3(nb), dim3(256), 0, ctx->stream, cv, W.idxA.p, W.cntA.p, W.st.p, W.uv.p);
-    hipLaunchKernelGGL(k_cc_dims, dim3(1), dim3(1024), 0, ctx->stream, W.st.p, W.cntA.p, bitmap_eps, W.bmp.p);
-    hipLaunchKernelGGL(k_cc_raster, dim3(nb), dim3(256), 0, ctx->stream, W.uv.p, W.cntA.p, W.st.p, bitmap_eps, W.bidx.p, W.bmp.p);
-    hipLaunchKernelGGL(k_cc_label, dim3(1), dim3(1024), 0, ctx->stream, W.st.p, W.bmp.p, W.tmp.p, W.label.p, W.sizes.p, 1);
+    hipLaunchKernelGGL(k_cc_params, dim3(nb), dim3(256), 0, ctx->stream, cv, W.idxA.p, W.cntA.p, st, W.uv.p);
+    hipLaunchKernelGGL(k_cc_raster, dim3(nb), dim3(256), 0, ctx->stream, W.uv.p, W.cntA.p, st, bitmap_eps, W.bidx.p, W.bmp.p);
+    hipLaunchKernelGGL(k_cc_label, dim3(1), dim3(1024), 0, ctx->stream, st, W.bmp.p, W.tmp.p, W.label.p, W.sizes.p, 1);
     const uint32_t nb4 = cdiv(c.n, 1024);
-    W.cs2.masks.ensure((size_t)nb4 * 256);
-    W.cs2.block_counts.ensure(nb4);
-    hipLaunchKernelGGL(k_cc_select, dim3(nb4), dim3(256), 0, ctx->stream, W.bidx.p, W.cntA.p, W.st.p, W.label.p, W.cs2.masks.p,
+    hipLaunchKernelGGL(k_cc_select, dim3(nb4), dim3(256), 0, ctx->stream, W.bidx.p, W.cntA.p, st, W.label.p, W.cs2.masks.p,
                        W.cs2.block_counts.p);
-    compact_masks(ctx, W.cs2, c.n, W.idxA.p, idx_out, cnt_out);
-    hipLaunchKernelGGL(k_wscore_partial, dim3(FIT_BLOCKS), dim3(256), 0, ctx->stream, cv, idx_out, cnt_out, W.st.p, eps3, W.part.p);
-    hipLaunchKernelGGL(k_wscore_final, dim3(1), dim3(1), 0, ctx->stream, W.part.p, W.st.p);
-    HIP_TRY(hipGetLastError());
+    compact_masks(ctx, W.cs2, c.n, W.idxA.p, W.idxS[k].p, W.cntS.p + k);
+    hipLaunchKernelGGL(k_wscore_partial, dim3(FIT_BLOCKS), dim3(256), 0, ctx->stream, cv, W.idxS[k].p, W.cntS.p + k, st, eps3,
+                       W.part_ws.p + (size_t)k * FIT_BLOCKS);
+}
+
+inline bool same_plane(const float4 &a, const float4 &b, float eps) {
+    const float c = a.x * b.x + a.y * b.y + a.z * b.z;
+    if (std::fabs(c) < 0.995f) return false;
+    const float db = c >= 0 ? b.w : -b.w;
+    return std::fabs(a.w - db) < 2 * eps;
 }
 
 }  // namespace
@@ -562,9 +568,10 @@ void global_weighted_score(plade_ctx *ctx, RansacWork &W, const CloudView &cv, f
 void ransac_detect(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const RansacParams &rp, PlaneSetOut &out) {
     const uint32_t n = cloud.n;
     out.coef.clear(); out.offsets.assign(1, 0); out.idx.clear(); out.d_idx = nullptr;
+    out.n_score_passes = 0; out.remaining = n;
     if (n < 3) return;
     // ---- scale exactly as plane_extraction.cpp:71-80 + PointCloud.h:94-98 (Z bug: maxZ stays
-    //      -FLT_MAX, so the Z extent is -inf-ish and never wins the max) --------------------------
+    //      -FLT_MAX, so the Z extent never wins the max) ------------------------------------------
     const float scale = std::max(cloud.bbmax[0] - cloud.bbmin[0], cloud.bbmax[1] - cloud.bbmin[1]);
     const float eps = rp.dist_rel * scale, bitmap_eps = rp.bitmap_rel * scale, cos_t = rp.cos_thresh;
     const float eps3 = 3 * eps;   // RansacShapeDetector.cpp:471-473
@@ -597,14 +604,19 @@ void ransac_detect(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const R
     const float *sx = W.sub.p, *sy = sx + W.sub_pitch, *sz = sy + W.sub_pitch, *snx = sz + W.sub_pitch, *sny = snx + W.sub_pitch,
                 *snz = sny + W.sub_pitch;
 
-    const uint32_t H = 2048, TOP = 32;
+    const uint32_t H = 4096, TOP = 48;
     W.hyp.ensure(H); W.hyp_pos.ensure(H); W.hyp_counts.ensure(H); W.top.ensure(TOP); W.top_pos.ensure(TOP); W.top_counts.ensure(TOP);
-    W.plane_cur.ensure(2); W.st.ensure(2); W.misc.ensure(16);
-    W.idxA.ensure((size_t)n + 4); W.idxB.ensure((size_t)n + 4); W.idxC.ensure((size_t)n + 4); W.cntA.ensure(4); W.cntB.ensure(4);
+    W.plane_cur.ensure(4); W.st.ensure(4); W.misc.ensure(16); W.nsum.ensure(16);
+    W.idxA.ensure((size_t)n + 4); W.cntA.ensure(8); W.cntS.ensure(8);
+    for (int k = 0; k < 4; ++k) W.idxS[k].ensure((size_t)n + 4);
     W.uv.ensure((size_t)n + 4); W.bidx.ensure((size_t)n + 4);
+    const bool fresh_bitmap = W.bmp.cap < CC_MAXPIX;
     W.label.ensure(CC_MAXPIX); W.sizes.ensure(CC_MAXPIX); W.bmp.ensure(CC_MAXPIX); W.tmp.ensure(CC_MAXPIX);
-    W.part.ensure(FIT_BLOCKS * 12 + 16);
+    if (fresh_bitmap) HIP_TRY(hipMemsetAsync(W.bmp.p, 0, W.bmp.cap, ctx->stream));
+    W.part.ensure(FIT_BLOCKS * 12 + 16); W.part_ws.ensure(4 * FIT_BLOCKS + 16);
     W.out_idx.ensure((size_t)n + 4);
+    W.cs2.masks.ensure((size_t)cdiv(n, 1024) * 256);
+    W.cs2.block_counts.ensure(cdiv(n, 1024));
 
     const int min_level = 1, max_level = 8;
     const float levels = (float)(max_level - min_level + 1);
@@ -641,25 +653,23 @@ void ransac_detect(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const R
         uint32_t valid = 0;
         for (uint32_t i = 0; i < H; ++i) valid += h_pos[i].w != 0.f;
         drawn += (float)valid;
-        // leaders of this batch by estimated support
+        // leaders of this batch by estimated support, one representative per distinct plane
         const double ratio = sub_un ? (double)n_remaining / sub_un : 0.0;
-        std::vector<uint32_t> order(H);
-        for (uint32_t i = 0; i < H; ++i) order[i] = i;
-        std::partial_sort(order.begin(), order.begin() + TOP, order.end(), [&](uint32_t a, uint32_t b) {
+        std::vector<uint32_t> order;
+        order.reserve(H);
+        for (uint32_t i = 0; i < H; ++i)
+            if (h_pos[i].w != 0.f && h_counts[i] * ratio >= 0.5 * rp.min_support) order.push_back(i);
+        std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
             return h_counts[a] != h_counts[b] ? h_counts[a] > h_counts[b] : a < b;
         });
-        for (uint32_t k = 0; k < TOP; ++k) {
-            const uint32_t i = order[k];
-            if (h_pos[i].w == 0.f) continue;
-            if (h_counts[i] * ratio < 0.5 * rp.min_support) continue;
-            pool.push_back(Cand{h_hyp[i], h_pos[i], 0});
+        for (uint32_t i : order) {
+            if (pool.size() >= TOP) break;
+            bool dup = false;
+            for (const Cand &pc : pool) if (same_plane(pc.pl, h_hyp[i], eps)) { dup = true; break; }
+            if (!dup) pool.push_back(Cand{h_hyp[i], h_pos[i], 0});
         }
         // ---- harvest: re-score the pool on all unassigned points, accept the best, repeat ---------
         while (!pool.empty()) {
-            if (pool.size() > TOP) {
-                std::sort(pool.begin(), pool.end(), [](const Cand &a, const Cand &b) { return a.count > b.count; });
-                pool.resize(TOP);
-            }
             const uint32_t np = (uint32_t)pool.size();
             std::vector<float4> pl(np);
             for (uint32_t i = 0; i < np; ++i) pl[i] = pool[i].pl;
@@ -673,73 +683,58 @@ void ransac_detect(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const R
             uint32_t best = 0;
             for (uint32_t i = 0; i < np; ++i) { pool[i].count = cnts[i]; if (cnts[i] > cnts[best]) best = i; }
             // candidates that can no longer reach min_support are dropped (RansacShapeDetector.cpp:826-832)
-            if (pool[best].count < rp.min_support) {
-                pool.erase(std::remove_if(pool.begin(), pool.end(), [&](const Cand &a) { return a.count < rp.min_support; }), pool.end());
-                break;
-            }
+            if (pool[best].count < rp.min_support) { pool.clear(); break; }
             const Cand bc = pool[best];
             pool.erase(pool.begin() + best);
-            // ---- acceptance sequence (RansacShapeDetector.cpp:618-656) ------------------------------
+            pool.erase(std::remove_if(pool.begin(), pool.end(), [&](const Cand &a) { return a.count < rp.min_support; }), pool.end());
+            // ---- acceptance sequence (RansacShapeDetector.cpp:618-656), all four slots enqueued ---------
+            // slot 0 = the candidate (GlobalScore(3 eps) + ConnectedComponent; its clone's first
+            // GlobalWeightedScore is the same computation), slot k = k-th LS refit of slot k-1's points.
             HIP_TRY(hipMemcpyAsync(W.top.p, &bc.pl, 16, hipMemcpyHostToDevice, ctx->stream));
             HIP_TRY(hipMemcpyAsync(W.top_pos.p, &bc.pos, 16, hipMemcpyHostToDevice, ctx->stream));
             hipLaunchKernelGGL(k_state_from_hyp, dim3(1), dim3(1), 0, ctx->stream, W.top.p, W.top_pos.p, W.st.p, W.plane_cur.p);
-            // candidate: GlobalScore(3 eps) + ConnectedComponent; clone: same shape, same result + weight
-            global_weighted_score(ctx, W, cv, eps3, cos_t, bitmap_eps, W.idxB.p, W.cntB.p);
-            n_full_passes += 1;
-            PlaneState hst;
-            uint32_t cand_size = 0;
-            HIP_TRY(hipMemcpyAsync(&hst, W.st.p, sizeof(PlaneState), hipMemcpyDeviceToHost, ctx->stream));
-            HIP_TRY(hipMemcpyAsync(&cand_size, W.cntB.p, 4, hipMemcpyDeviceToHost, ctx->stream));
-            HIP_TRY(hipStreamSynchronize(ctx->stream));
-            PLADE_REQUIRE(hst.err == 0, PLADE_ELIMIT, "plane extraction: connected-component bitmap too large");
-            PlaneState cand_state = hst;         // candidates.back()
-            uint32_t *cand_idx = W.idxB.p;       // its index list lives in idxB; clone results go to idxC
-            double newScore = hst.wscore;
-            uint32_t newSize = cand_size;
-            uint32_t clone_size = cand_size;
-            uint32_t *clone_idx = W.idxB.p;      // clone starts as a copy of the candidate
-            for (int fittingIter = 1; fittingIter <= 3; ++fittingIter) {
-                const double oldScore = newScore;
-                if (clone_size < 3) break;
-                // Fit(): LS plane through the clone's indices
-                HIP_TRY(hipMemcpyAsync(W.cntA.p + 1, &clone_size, 4, hipMemcpyHostToDevice, ctx->stream));
-                hipLaunchKernelGGL(k_fit_partial, dim3(FIT_BLOCKS), dim3(256), 0, ctx->stream, cv, clone_idx, W.cntA.p + 1, W.part.p);
-                hipLaunchKernelGGL(k_fit_final, dim3(1), dim3(1), 0, ctx->stream, W.part.p, W.cntA.p + 1, W.st.p, W.plane_cur.p, 0);
-                uint32_t *dst = (cand_idx == W.idxB.p) ? W.idxC.p : W.idxB.p;
-                global_weighted_score(ctx, W, cv, eps3, cos_t, bitmap_eps, dst, W.cntB.p);
-                n_full_passes += 1;
-                uint32_t sz = 0;
-                HIP_TRY(hipMemcpyAsync(&hst, W.st.p, sizeof(PlaneState), hipMemcpyDeviceToHost, ctx->stream));
-                HIP_TRY(hipMemcpyAsync(&sz, W.cntB.p, 4, hipMemcpyDeviceToHost, ctx->stream));
-                HIP_TRY(hipStreamSynchronize(ctx->stream));
-                PLADE_REQUIRE(hst.err == 0, PLADE_ELIMIT, "plane extraction: refit failed / bitmap too large");
-                newScore = hst.wscore;
-                newSize = sz;
-                clone_idx = dst;
-                clone_size = sz;
-                if (newScore > oldScore && newSize > rp.min_support) {  // clone.Clone(&candidates.back())
-                    cand_state = hst;
-                    cand_idx = dst;
-                    cand_size = sz;
-                }
-                if (!(newScore > oldScore)) break;
+            for (int k = 0; k < 4; ++k) {
+                global_weighted_score(ctx, W, cv, k, eps3, cos_t, bitmap_eps);
+                hipLaunchKernelGGL(k_fit_partial, dim3(FIT_BLOCKS), dim3(256), 0, ctx->stream, cv, W.idxS[k].p, W.cntS.p + k, W.part.p);
+                hipLaunchKernelGGL(k_fit_final, dim3(1), dim3(1), 0, ctx->stream, W.part.p, W.cntS.p + k, W.st.p + std::min(k + 1, 3),
+                                   W.plane_cur.p + std::min(k + 1, 3), W.nsum.p + 3 * k, k < 3 ? 0 : 1);
             }
+            hipLaunchKernelGGL(k_wscore_final, dim3(1), dim3(64), 0, ctx->stream, W.part_ws.p, W.st.p);
+            n_full_passes += 4;
+            PlaneState hst[4];
+            uint32_t hcnt[4];
+            float hns[12];
+            HIP_TRY(hipMemcpyAsync(hst, W.st.p, 4 * sizeof(PlaneState), hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(hipMemcpyAsync(hcnt, W.cntS.p, 16, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(hipMemcpyAsync(hns, W.nsum.p, 48, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+            HIP_TRY(hipGetLastError());
+            PLADE_REQUIRE(hst[0].err != 1, PLADE_ELIMIT, "plane extraction: connected-component bitmap too large");
+            // replay of the reference's refit loop on the four results
+            int final_slot = 0;
+            {
+                double newScore = hst[0].wscore;
+                for (int fittingIter = 1; fittingIter <= 3; ++fittingIter) {
+                    const double oldScore = newScore;
+                    if (hcnt[fittingIter - 1] < 3 || hst[fittingIter].err) break;   // LSFit impossible
+                    newScore = hst[fittingIter].wscore;
+                    const uint32_t newSize = hcnt[fittingIter];
+                    if (newScore > oldScore && newSize > rp.min_support) final_slot = fittingIter;  // clone.Clone(&candidates.back())
+                    if (!(newScore > oldScore)) break;
+                }
+            }
+            const PlaneState &cand_state = hst[final_slot];
+            const uint32_t cand_size = hcnt[final_slot];
+            uint32_t *cand_idx = W.idxS[final_slot].p;
             // ---- remove the points (RansacShapeDetector.cpp:666-675) ---------------------------------
             if (cand_size == 0) continue;
-            if (rp.orient_normals) {  // mean inlier normal (the intent of plane_extraction.cpp:43-58)
-                HIP_TRY(hipMemcpyAsync(W.cntA.p + 1, &cand_size, 4, hipMemcpyHostToDevice, ctx->stream));
-                hipLaunchKernelGGL(k_fit_partial, dim3(FIT_BLOCKS), dim3(256), 0, ctx->stream, cv, cand_idx, W.cntA.p + 1, W.part.p);
-                hipLaunchKernelGGL(k_fit_final, dim3(1), dim3(1), 0, ctx->stream, W.part.p, W.cntA.p + 1, W.st.p, W.plane_cur.p, 1);
-                PlaneState t2;
-                HIP_TRY(hipMemcpyAsync(&t2, W.st.p, sizeof(PlaneState), hipMemcpyDeviceToHost, ctx->stream));
-                HIP_TRY(hipStreamSynchronize(ctx->stream));
-                cand_state.nsum[0] = t2.nsum[0]; cand_state.nsum[1] = t2.nsum[1]; cand_state.nsum[2] = t2.nsum[2];
-            }
             const int32_t shape_id = (int32_t)accepted.size();
             hipLaunchKernelGGL(k_assign, dim3(cdiv(cand_size, 256)), dim3(256), 0, ctx->stream, cand_idx, cand_size, shape_id, W.assigned.p);
             drawn = std::pow(1.f - (cand_size / float(n_remaining)), 3.f) * drawn;
             n_remaining -= cand_size;
             // plane_extraction.cpp:134-149: shapes below min_support are skipped, d = -n.p with n re-normalised
+            Accepted a{};
+            a.support = 0; a.offset = out_off;
             if (cand_size >= rp.min_support) {
                 float nn[3] = {cand_state.n[0], cand_state.n[1], cand_state.n[2]};
                 float l = nn[0] * nn[0];
@@ -748,23 +743,17 @@ void ransac_detect(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const R
                 l = std::sqrt(l);
                 if (l > 0) { nn[0] /= l; nn[1] /= l; nn[2] /= l; }
                 float d = -(nn[0] * cand_state.pos[0] + nn[1] * cand_state.pos[1] + nn[2] * cand_state.pos[2]);
-                if (rp.orient_normals) {
-                    const float s = cand_state.nsum[0] * nn[0] + cand_state.nsum[1] * nn[1] + cand_state.nsum[2] * nn[2];
-                    if (s < 0) { nn[0] = -nn[0]; nn[1] = -nn[1]; nn[2] = -nn[2]; d = -d; }
+                if (rp.orient_normals) {  // mean inlier normal (the intent of plane_extraction.cpp:43-58)
+                    const float *ns = hns + 3 * final_slot;
+                    if (ns[0] * nn[0] + ns[1] * nn[1] + ns[2] * nn[2] < 0) { nn[0] = -nn[0]; nn[1] = -nn[1]; nn[2] = -nn[2]; d = -d; }
                 }
-                Accepted a;
                 a.coef[0] = nn[0]; a.coef[1] = nn[1]; a.coef[2] = nn[2]; a.coef[3] = d;
-                a.support = cand_size; a.offset = out_off;
+                a.support = cand_size;
                 hipLaunchKernelGGL(k_map_indices, dim3(cdiv(cand_size, 256)), dim3(256), 0, ctx->stream, cand_idx, cand_size, W.orig.p,
                                    W.out_idx.p + out_off);
                 out_off += cand_size;
-                accepted.push_back(a);
-            } else {
-                Accepted a{};  // keeps shape ids aligned with `assigned`
-                a.support = 0; a.offset = out_off;
-                accepted.push_back(a);
             }
-            HIP_TRY(hipGetLastError());
+            accepted.push_back(a);
             if (n_remaining < rp.min_support) { pool.clear(); break; }
         }
     }

@@ -16,8 +16,10 @@ struct VoxelWork {
                  const float bbox_min[3], const float bbox_max[3]);
 };
 
-float average_spacing_dev(plade_ctx *ctx, const float *d_x, const float *d_y, const float *d_z, uint32_t n, int k,
-                          uint32_t samples);
+struct TargetGrid;
+// average_spacing (code/PLADE/util.cpp:1619-1648) of a strided device xyz array with known bbox
+float average_spacing_dev(plade_ctx *ctx, const float *d_aos, uint32_t stride_f, uint32_t n, const float *bbmin,
+                          const float *bbmax, int k, uint32_t samples, TargetGrid &grid);
 // min/max of a strided device xyz array, returned on the host
 void bbox_host(plade_ctx *ctx, const float *d_xyz, uint32_t n, uint32_t stride, float mn[3], float mx[3]);
 

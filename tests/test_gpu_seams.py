@@ -100,3 +100,27 @@ def test_overlap_counts_bit_exact(ctx, oracle, seed):
         ref = oracle.overlap_count(sr, tg, Ts[k], cs[k], radius, leaf)
         assert got[k] == ref, (k, got[k], ref)
     assert got[-1] == -1
+
+
+@pytest.mark.parametrize("n", [5, 700, 20000, 150000])
+def test_average_spacing_bit_exact(ctx, oracle, n):
+    cloud = sample_scene(max(n, 64), scene_seed=6, sample_seed=n)[:n]
+    assert ctx.average_spacing(cloud) == np.float32(oracle.average_spacing(cloud))
+    # xyz-only input with a different stride
+    assert ctx.average_spacing(cloud[:, :3].copy()) == np.float32(oracle.average_spacing(cloud[:, :3].copy()))
+
+
+def test_average_spacing_golden(ctx):
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g_spacing.npz"))
+    assert ctx.average_spacing(g["cloud"]) == g["spacing"]  # value composed from the reference's FLANN kNN
+
+
+@pytest.mark.parametrize("n,leaf", [(1, 0.1), (3000, 0.05), (3000, 50.0), (80000, 0.12)])
+def test_voxel_downsample_bit_exact(ctx, oracle, n, leaf):
+    cloud = sample_scene(max(n, 64), scene_seed=8, sample_seed=n)[:n]
+    got = ctx.voxel_downsample(cloud, leaf)
+    want = oracle.voxel_downsample(cloud, leaf, 1)   # stable in-voxel order
+    assert got.shape == want.shape and np.array_equal(got, want)
+    faithful = oracle.voxel_downsample(cloud, leaf, 0)  # PCL's std::sort order: same voxels, <= few ulp apart
+    assert faithful.shape == got.shape and np.abs(faithful - got).max() <= 1e-5
