@@ -129,6 +129,34 @@ struct HBuf {
     operator T *() const { return p; }
 };
 
+#ifdef __HIPCC__
+// order-preserving float <-> int mapping for atomicMin/atomicMax on floats
+__device__ __forceinline__ int ordered_int(float f) { int v = __float_as_int(f); return v >= 0 ? v : v ^ 0x7fffffff; }
+__device__ __forceinline__ float ordered_float(int v) { return __int_as_float(v >= 0 ? v : v ^ 0x7fffffff); }
+// Commit per-lane minima/maxima (K of each) to global ordered-int slots out[0..K) (min) and
+// out[K..2K) (max): wave shuffle reduce -> LDS -> one lane per slot, and the atomic is only issued
+// when it would change the stored value (after the first few blocks almost never).
+template <int K>
+__device__ __forceinline__ void block_minmax_commit(float (&mn)[K], float (&mx)[K], int *out, float (*s_lds)[8]) {
+    for (int k = 0; k < K; ++k)
+        for (int d = 32; d >= 1; d >>= 1) {
+            mn[k] = fminf(mn[k], __shfl_xor(mn[k], d, 64));
+            mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], d, 64));
+        }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    if (lane == 0) for (int k = 0; k < K; ++k) { s_lds[k][wave] = mn[k]; s_lds[K + k][wave] = mx[k]; }
+    __syncthreads();
+    if ((int)threadIdx.x < 2 * K) {
+        const int k = threadIdx.x;
+        float v = s_lds[k][0];
+        for (int w = 1; w < nw; ++w) v = k < K ? fminf(v, s_lds[k][w]) : fmaxf(v, s_lds[k][w]);
+        const int iv = ordered_int(v);
+        if (k < K) { if (iv < out[k]) atomicMin(&out[k], iv); }
+        else { if (iv > out[k]) atomicMax(&out[k], iv); }
+    }
+}
+#endif
+
 inline unsigned cdiv(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
 
 using Clock = std::chrono::steady_clock;

@@ -64,25 +64,14 @@ __device__ __forceinline__ uint64_t cell_key(int cx, int cy, int cz) {
     return ((uint64_t)(uint32_t)cz << 42) | ((uint64_t)(uint32_t)cy << 21) | (uint64_t)(uint32_t)cx;
 }
 
-__global__ void k_t_minmax(const float4 *__restrict__ rt, uint32_t m, int *__restrict__ out6) {
+__global__ __launch_bounds__(256) void k_t_minmax(const float4 *__restrict__ rt, uint32_t m, int *__restrict__ out6) {
+    __shared__ float s_lds[6][8];
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
         const float v[3] = {rt[4 * (size_t)i].w, rt[4 * (size_t)i + 1].w, rt[4 * (size_t)i + 2].w};
         for (int k = 0; k < 3; ++k) { mn[k] = fminf(mn[k], v[k]); mx[k] = fmaxf(mx[k], v[k]); }
     }
-    for (int k = 0; k < 3; ++k) {
-        for (int d = 32; d >= 1; d >>= 1) {
-            mn[k] = fminf(mn[k], __shfl_xor(mn[k], d, 64));
-            mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], d, 64));
-        }
-        if ((threadIdx.x & 63) == 0) {
-            int a = __float_as_int(mn[k]), b = __float_as_int(mx[k]);
-            a = a >= 0 ? a : a ^ 0x7fffffff;
-            b = b >= 0 ? b : b ^ 0x7fffffff;
-            atomicMin(&out6[k], a);
-            atomicMax(&out6[3 + k], b);
-        }
-    }
+    block_minmax_commit<3>(mn, mx, out6, s_lds);
 }
 
 __global__ void k_t_keys(const float4 *__restrict__ rt, uint32_t m, HashGrid g, uint64_t *__restrict__ keys,
@@ -202,7 +191,7 @@ void cluster_transforms(plade_ctx *ctx, CandidateSet &cs, float dist_threshold, 
     }
     int *d6 = reinterpret_cast<int *>(ctx->scratch[3].ensure(64));
     HIP_TRY(hipMemcpyAsync(d6, init, 24, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_t_minmax, dim3(std::min(cdiv(m, 256), 1024u)), dim3(256), 0, ctx->stream, cs.rt.p, m, d6);
+    hipLaunchKernelGGL(k_t_minmax, dim3(std::min(cdiv(m, 1024), 512u)), dim3(256), 0, ctx->stream, cs.rt.p, m, d6);
     int out[6];
     HIP_TRY(hipMemcpyAsync(out, d6, 24, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));

@@ -24,9 +24,9 @@ struct GridParams {
     int dx, dy, dz;
 };
 
-__global__ void k_minmax3(const float *__restrict__ xyz, uint32_t n, uint32_t stride, float *__restrict__ out6) {
+__global__ __launch_bounds__(256) void k_minmax3(const float *__restrict__ xyz, uint32_t n, uint32_t stride, float *__restrict__ out6) {
     // out6 initialised to (+inf x3, -inf x3) as ordered ints by the host
-    __shared__ float s[6][4];
+    __shared__ float s_lds[6][8];
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
         for (int k = 0; k < 3; ++k) {
@@ -34,24 +34,7 @@ __global__ void k_minmax3(const float *__restrict__ xyz, uint32_t n, uint32_t st
             mn[k] = fminf(mn[k], v);
             mx[k] = fmaxf(mx[k], v);
         }
-    for (int k = 0; k < 3; ++k)
-        for (int d = 32; d >= 1; d >>= 1) {
-            mn[k] = fminf(mn[k], __shfl_xor(mn[k], d, 64));
-            mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], d, 64));
-        }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) for (int k = 0; k < 3; ++k) { s[k][wave] = mn[k]; s[3 + k][wave] = mx[k]; }
-    __syncthreads();
-    if (threadIdx.x < 6) {
-        int k = threadIdx.x;
-        float v = s[k][0];
-        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) v = k < 3 ? fminf(v, s[k][w]) : fmaxf(v, s[k][w]);
-        // float atomic min/max through the order-preserving int mapping
-        int iv = __float_as_int(v);
-        iv = iv >= 0 ? iv : iv ^ 0x7fffffff;
-        if (k < 3) atomicMin(reinterpret_cast<int *>(out6) + k, iv);
-        else atomicMax(reinterpret_cast<int *>(out6) + k, iv);
-    }
+    block_minmax_commit<3>(mn, mx, reinterpret_cast<int *>(out6), s_lds);
 }
 
 __global__ void k_cell_ids(const float *__restrict__ xyz, uint32_t n, uint32_t stride, GridParams g,

@@ -264,7 +264,8 @@ __global__ void k_strided_to_soa(const float *__restrict__ in, uint32_t n, uint3
 }
 
 
-__global__ void k_minmax3_v(const float *__restrict__ xyz, uint32_t n, uint32_t stride, int *__restrict__ out6) {
+__global__ __launch_bounds__(256) void k_minmax3_v(const float *__restrict__ xyz, uint32_t n, uint32_t stride, int *__restrict__ out6) {
+    __shared__ float s_lds[6][8];
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
         for (int k = 0; k < 3; ++k) {
@@ -272,19 +273,7 @@ __global__ void k_minmax3_v(const float *__restrict__ xyz, uint32_t n, uint32_t 
             mn[k] = fminf(mn[k], v);
             mx[k] = fmaxf(mx[k], v);
         }
-    for (int k = 0; k < 3; ++k) {
-        for (int d = 32; d >= 1; d >>= 1) {
-            mn[k] = fminf(mn[k], __shfl_xor(mn[k], d, 64));
-            mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], d, 64));
-        }
-        if ((threadIdx.x & 63) == 0) {
-            int a = __float_as_int(mn[k]), b = __float_as_int(mx[k]);
-            a = a >= 0 ? a : a ^ 0x7fffffff;
-            b = b >= 0 ? b : b ^ 0x7fffffff;
-            atomicMin(&out6[k], a);
-            atomicMax(&out6[3 + k], b);
-        }
-    }
+    block_minmax_commit<3>(mn, mx, out6, s_lds);
 }
 
 void bbox_host(plade_ctx *ctx, const float *d_xyz, uint32_t n, uint32_t stride, float mn[3], float mx[3]) {
@@ -295,7 +284,7 @@ void bbox_host(plade_ctx *ctx, const float *d_xyz, uint32_t n, uint32_t stride, 
     for (int k = 0; k < 3; ++k) { init[k] = a; init[3 + k] = b ^ 0x7fffffff; }
     int *d = reinterpret_cast<int *>(ctx->scratch[3].ensure(64));
     HIP_TRY(hipMemcpyAsync(d, init, 24, hipMemcpyHostToDevice, ctx->stream));
-    if (n) hipLaunchKernelGGL(k_minmax3_v, dim3(std::min(cdiv(n, 256), 2048u)), dim3(256), 0, ctx->stream, d_xyz, n, stride, d);
+    if (n) hipLaunchKernelGGL(k_minmax3_v, dim3(std::min(cdiv(n, 1024), 1024u)), dim3(256), 0, ctx->stream, d_xyz, n, stride, d);
     int out[6];
     HIP_TRY(hipMemcpyAsync(out, d, 24, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));

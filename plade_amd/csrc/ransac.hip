@@ -129,6 +129,9 @@ __global__ __launch_bounds__(256) void k_sample(CloudView c, const uint32_t *__r
         }
         if (!got) return;
     }
+    // three samples drawn: this counts as a generated candidate (genCands, RansacShapeDetector.cpp:122-125)
+    // whether or not the plane survives construction / verification below
+    hyp_pos[t] = make_float4(0.f, 0.f, 0.f, 2.f);
     // Plane::Init (ransac/Plane.cpp:29-38)
     const float p1[3] = {c.x[s[0]], c.y[s[0]], c.z[s[0]]}, p2[3] = {c.x[s[1]], c.y[s[1]], c.z[s[1]]},
                 p3[3] = {c.x[s[2]], c.y[s[2]], c.z[s[2]]};
@@ -231,14 +234,9 @@ __global__ __launch_bounds__(256) void k_cc_params(CloudView c, const uint32_t *
         uv[i] = make_float2(u, v);
         U = u; V = v;
     }
-    for (int d = 32; d >= 1; d >>= 1) {
-        u = fminf(u, __shfl_xor(u, d, 64)); v = fminf(v, __shfl_xor(v, d, 64));
-        U = fmaxf(U, __shfl_xor(U, d, 64)); V = fmaxf(V, __shfl_xor(V, d, 64));
-    }
-    if ((threadIdx.x & 63) == 0 && u != INFINITY) {
-        atomicMin(&st->bb[0], ord_i(u)); atomicMin(&st->bb[1], ord_i(v));
-        atomicMax(&st->bb[2], ord_i(U)); atomicMax(&st->bb[3], ord_i(V));
-    }
+    __shared__ float s_lds[4][8];
+    float mn[2] = {u, v}, mx[2] = {U, V};
+    block_minmax_commit<2>(mn, mx, st->bb, s_lds);
 }
 
 constexpr uint32_t CC_MAXPIX = 1u << 20;
@@ -280,13 +278,26 @@ __global__ __launch_bounds__(256) void k_cc_raster(const float2 *__restrict__ uv
 
 // closing (DilateCross + ErodeCross, ransac/Bitmap.cpp:154-260, 459-570; no wrapping for planes),
 // 8-connected labelling (Components, Bitmap.cpp:633-834) and selection of the component with most
-// pixels, first in raster order on ties (BitmapPrimitiveShape.cpp:168-173).  One workgroup.
-__global__ __launch_bounds__(1024) void k_cc_label(PlaneState *st, uint8_t *__restrict__ bmp, uint8_t *__restrict__ tmp,
-                                                   uint32_t *__restrict__ label, uint32_t *__restrict__ sizes,
+// pixels, first in raster order on ties (BitmapPrimitiveShape.cpp:168-173).  One workgroup; bitmaps of
+// up to CC_LDS_PIX pixels (every realistic plane at bitmap eps = 2 % of the scene) live in LDS.
+constexpr int CC_LDS_PIX = 8192;
+
+__global__ __launch_bounds__(1024) void k_cc_label(PlaneState *st, uint8_t *__restrict__ g_bmp, uint8_t *__restrict__ g_tmp,
+                                                   uint32_t *__restrict__ g_label, uint32_t *__restrict__ g_sizes,
                                                    int do_filter) {
     __shared__ int s_changed;
     __shared__ unsigned long long s_best;
+    __shared__ uint32_t s_label[CC_LDS_PIX];
+    __shared__ uint32_t s_sizes[CC_LDS_PIX];
+    __shared__ uint8_t s_bmp[CC_LDS_PIX], s_tmp[CC_LDS_PIX];
     const int ue = (int)st->ue, ve = (int)st->ve, npx = ue * ve;
+    const bool in_lds = npx <= CC_LDS_PIX;
+    uint8_t *bmp = in_lds ? s_bmp : g_bmp, *tmp = in_lds ? s_tmp : g_tmp;
+    uint32_t *label = in_lds ? s_label : g_label, *sizes = in_lds ? s_sizes : g_sizes;
+    if (in_lds) {
+        for (int p = threadIdx.x; p < npx; p += blockDim.x) { s_bmp[p] = g_bmp[p]; g_bmp[p] = 0; }  // also leaves it clean
+        __syncthreads();
+    }
     if (do_filter) {
         for (int p = threadIdx.x; p < npx; p += blockDim.x) {
             const int u = p % ue, v = p / ue;
@@ -354,7 +365,9 @@ __global__ __launch_bounds__(1024) void k_cc_label(PlaneState *st, uint8_t *__re
         if (s_best == 0ull) { st->best_root = 0xffffffffu; st->n_fg = 0; }
         else { st->best_root = 0xffffffffu - (uint32_t)(s_best & 0xffffffffu); st->n_fg = (uint32_t)(s_best >> 32); }
     }
-    for (int p = threadIdx.x; p < npx; p += blockDim.x) bmp[p] = 0;  // leave the bitmap clean for the next raster
+    // k_cc_select reads the labels from global memory; the bitmap is left all-zero for the next raster
+    if (in_lds) { for (int p = threadIdx.x; p < npx; p += blockDim.x) g_label[p] = s_label[p]; }
+    else { for (int p = threadIdx.x; p < npx; p += blockDim.x) g_bmp[p] = 0; }
 }
 
 // mask layout of k_compact: one byte per lane covering 4 consecutive items, block counts per 1024
@@ -423,14 +436,21 @@ __device__ void jacobi3_d(double a[3][3], double d[3], double v[3][3]) {
     for (int i = 0; i < 3; ++i) d[i] = a[i][i];
 }
 
-// Sums the per-block partials of the index list `count` belongs to; nsum_out receives the sum of the
-// list's point normals (orientation).  mode 0 additionally writes the fitted plane into `st` (the NEXT
-// slot's state) / plane_out.
-__global__ void k_fit_final(const double *__restrict__ part, const uint32_t *__restrict__ count, PlaneState *st,
-                            float4 *plane_out, float *__restrict__ nsum_out, int mode) {
-    if (threadIdx.x || blockIdx.x) return;
-    double a[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (int b = 0; b < FIT_BLOCKS; ++b) for (int k = 0; k < 12; ++k) a[k] += part[b * 12 + k];
+// Sums the per-block partials of the index list `count` belongs to (fixed tree => deterministic);
+// nsum_out receives the sum of the list's point normals (orientation).  mode 0 additionally writes the
+// fitted plane into `st` (the NEXT slot's state) / plane_out.  One workgroup of FIT_BLOCKS lanes.
+__global__ __launch_bounds__(FIT_BLOCKS) void k_fit_final(const double *__restrict__ part, const uint32_t *__restrict__ count,
+                                                          PlaneState *st, float4 *plane_out, float *__restrict__ nsum_out,
+                                                          int mode) {
+    __shared__ double s_red[FIT_BLOCKS / 64][12];
+    double a[12];
+    for (int k = 0; k < 12; ++k) a[k] = part[threadIdx.x * 12 + k];
+    for (int k = 0; k < 12; ++k)
+        for (int d = 32; d >= 1; d >>= 1) a[k] += __shfl_xor(a[k], d, 64);
+    if ((threadIdx.x & 63) == 0) for (int k = 0; k < 12; ++k) s_red[threadIdx.x >> 6][k] = a[k];
+    __syncthreads();
+    if (threadIdx.x) return;
+    for (int k = 0; k < 12; ++k) a[k] = (s_red[0][k] + s_red[1][k]) + (s_red[2][k] + s_red[3][k]);
     nsum_out[0] = (float)a[9]; nsum_out[1] = (float)a[10]; nsum_out[2] = (float)a[11];
     if (mode == 1) return;
     st->err = 0;
@@ -480,11 +500,12 @@ __global__ __launch_bounds__(256) void k_wscore_partial(CloudView c, const uint3
     if (threadIdx.x == 0) part[blockIdx.x] = (s[0] + s[1]) + (s[2] + s[3]);
 }
 // one launch sums the partials of all four slots
-__global__ void k_wscore_final(const double *__restrict__ part /* 4 x FIT_BLOCKS */, PlaneState *st /* 4 */) {
-    if (blockIdx.x || threadIdx.x >= 4) return;
+__global__ __launch_bounds__(256) void k_wscore_final(const double *__restrict__ part /* 4 x FIT_BLOCKS */, PlaneState *st /* 4 */) {
+    const int slot = threadIdx.x >> 6, lane = threadIdx.x & 63;  // one wave per slot
     double a = 0;
-    for (int b = 0; b < FIT_BLOCKS; ++b) a += part[threadIdx.x * FIT_BLOCKS + b];
-    st[threadIdx.x].wscore = a;
+    for (int b = lane; b < FIT_BLOCKS; b += 64) a += part[slot * FIT_BLOCKS + b];
+    for (int d = 32; d >= 1; d >>= 1) a += __shfl_xor(a, d, 64);
+    if (lane == 0) st[slot].wscore = a;
 }
 
 __global__ void k_assign(const uint32_t *__restrict__ idx, uint32_t m, int32_t id, int32_t *__restrict__ assigned) {
@@ -510,13 +531,17 @@ struct RansacWork {
     size_t sub_pitch = 0;
     DBuf<uint32_t> sub_index;
     uint32_t n_sub = 0;
-    DBuf<float4> hyp, hyp_pos, top, top_pos, plane_cur;
-    DBuf<uint32_t> hyp_counts, top_counts, misc;
-    DBuf<PlaneState> st;            // 4 slots: candidate + 3 refits
+    DBuf<char> round_block, accept_block;   // contiguous: one D2H copy per host decision
+    float4 *hyp = nullptr, *hyp_pos = nullptr;
+    uint32_t *hyp_counts = nullptr, *misc = nullptr;
+    PlaneState *st = nullptr;       // 4 slots: candidate + 3 refits
+    uint32_t *cntS = nullptr;       // per-slot result counts
+    float *nsum = nullptr;          // 4 x 3
+    DBuf<float4> top, top_pos, plane_cur;
+    DBuf<uint32_t> top_counts;
     CompactScratch cs, cs2;
     DBuf<uint32_t> idxA, cntA;      // score(3 eps) list before the connected component
-    DBuf<uint32_t> idxS[4], cntS;   // per-slot result lists / counts
-    DBuf<float> nsum;               // 4 x 3
+    DBuf<uint32_t> idxS[4];         // per-slot result lists
     DBuf<float2> uv;
     DBuf<uint32_t> bidx, label, sizes;
     DBuf<uint8_t> bmp, tmp;
@@ -541,7 +566,7 @@ struct Accepted {
 void global_weighted_score(plade_ctx *ctx, RansacWork &W, const CloudView &cv, int k, float eps3, float cos_t,
                            float bitmap_eps) {
     const CloudDev &c = W.sorted;
-    PlaneState *st = W.st.p + k;
+    PlaneState *st = W.st + k;
     score_compact(ctx, W.cs, c.x(), c.y(), c.z(), c.nx(), c.ny(), c.nz(), W.assigned.p, c.n, W.plane_cur.p + k, eps3, cos_t,
                   W.idxA.p, W.cntA.p);
     const uint32_t nb = cdiv(c.n, 256);
@@ -551,8 +576,8 @@ void global_weighted_score(plade_ctx *ctx, RansacWork &W, const CloudView &cv, i
     const uint32_t nb4 = cdiv(c.n, 1024);
     hipLaunchKernelGGL(k_cc_select, dim3(nb4), dim3(256), 0, ctx->stream, W.bidx.p, W.cntA.p, st, W.label.p, W.cs2.masks.p,
                        W.cs2.block_counts.p);
-    compact_masks(ctx, W.cs2, c.n, W.idxA.p, W.idxS[k].p, W.cntS.p + k);
-    hipLaunchKernelGGL(k_wscore_partial, dim3(FIT_BLOCKS), dim3(256), 0, ctx->stream, cv, W.idxS[k].p, W.cntS.p + k, st, eps3,
+    compact_masks(ctx, W.cs2, c.n, W.idxA.p, W.idxS[k].p, W.cntS + k);
+    hipLaunchKernelGGL(k_wscore_partial, dim3(FIT_BLOCKS), dim3(256), 0, ctx->stream, cv, W.idxS[k].p, W.cntS + k, st, eps3,
                        W.part_ws.p + (size_t)k * FIT_BLOCKS);
 }
 
@@ -605,9 +630,21 @@ void ransac_detect(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const R
                 *snz = sny + W.sub_pitch;
 
     const uint32_t H = 4096, TOP = 48;
-    W.hyp.ensure(H); W.hyp_pos.ensure(H); W.hyp_counts.ensure(H); W.top.ensure(TOP); W.top_pos.ensure(TOP); W.top_counts.ensure(TOP);
-    W.plane_cur.ensure(4); W.st.ensure(4); W.misc.ensure(16); W.nsum.ensure(16);
-    W.idxA.ensure((size_t)n + 4); W.cntA.ensure(8); W.cntS.ensure(8);
+    const size_t round_bytes = (size_t)H * 36 + 64;
+    char *rb = W.round_block.ensure(round_bytes);
+    W.hyp = reinterpret_cast<float4 *>(rb);
+    W.hyp_pos = W.hyp + H;
+    W.hyp_counts = reinterpret_cast<uint32_t *>(W.hyp_pos + H);
+    W.misc = W.hyp_counts + H;
+    const size_t accept_bytes = 4 * sizeof(PlaneState) + 16 + 48;
+    char *ab = W.accept_block.ensure(accept_bytes + 64);
+    W.st = reinterpret_cast<PlaneState *>(ab);
+    W.cntS = reinterpret_cast<uint32_t *>(ab + 4 * sizeof(PlaneState));
+    W.nsum = reinterpret_cast<float *>(ab + 4 * sizeof(PlaneState) + 16);
+    W.top.ensure(TOP); W.top_pos.ensure(TOP); W.top_counts.ensure(TOP);
+    W.plane_cur.ensure(4);
+    W.idxA.ensure((size_t)n + 4); W.cntA.ensure(8);
+    char *pin = W.pinned.ensure(round_bytes + accept_bytes + 256);
     for (int k = 0; k < 4; ++k) W.idxS[k].ensure((size_t)n + 4);
     W.uv.ensure((size_t)n + 4); W.bidx.ensure((size_t)n + 4);
     const bool fresh_bitmap = W.bmp.cap < CC_MAXPIX;
@@ -624,6 +661,11 @@ void ransac_detect(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const R
         return std::min(std::pow(1.f - cand_size / (n_pts * levels * 4.f), drawn), 1.f);
     };
 
+    Clock::time_point t_setup = Clock::now();
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->stats.add("ransac_t_setup", secs_since(t_setup));
+    double t_sample = 0, t_rescore = 0, t_accept = 0;
+    uint32_t n_rounds = 0, n_accepts = 0;
     std::vector<Accepted> accepted;
     std::vector<float4> h_hyp(H), h_pos(H);
     std::vector<uint32_t> h_counts(H);
@@ -638,27 +680,34 @@ void ransac_detect(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const R
         if (n_remaining < rp.min_support) break;
         if (round > 0 && fail_prob((float)rp.min_support, (float)n_remaining, drawn) <= rp.overlook_p && pool.empty()) break;
         // ---- draw and score a batch ------------------------------------------------------------
+        ++n_rounds;
+        Clock::time_point t_s0 = Clock::now();
         hipLaunchKernelGGL(k_sample, dim3(cdiv(H, 256)), dim3(256), 0, ctx->stream, cv, W.codes.p, W.assigned.p, rp.seed, round, H,
-                           min_level, max_level, eps, cos_t, W.hyp.p, W.hyp_pos.p);
-        score_multi(ctx, sx, sy, sz, snx, sny, snz, W.assigned.p, W.sub_index.p, W.n_sub, W.hyp.p, H, eps, cos_t, W.hyp_counts.p);
-        HIP_TRY(hipMemsetAsync(W.misc.p, 0, 8, ctx->stream));
+                           min_level, max_level, eps, cos_t, W.hyp, W.hyp_pos);
+        score_multi(ctx, sx, sy, sz, snx, sny, snz, W.assigned.p, W.sub_index.p, W.n_sub, W.hyp, H, eps, cos_t, W.hyp_counts);
+        HIP_TRY(hipMemsetAsync(W.misc, 0, 4, ctx->stream));
         hipLaunchKernelGGL(k_count_unassigned, dim3(cdiv(W.n_sub, 256)), dim3(256), 0, ctx->stream, W.assigned.p, W.sub_index.p,
-                           W.n_sub, W.misc.p);
+                           W.n_sub, W.misc);
         uint32_t sub_un = 0;
-        HIP_TRY(hipMemcpyAsync(h_hyp.data(), W.hyp.p, H * 16, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(hipMemcpyAsync(h_pos.data(), W.hyp_pos.p, H * 16, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(hipMemcpyAsync(h_counts.data(), W.hyp_counts.p, H * 4, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(hipMemcpyAsync(&sub_un, W.misc.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(pin, rb, (size_t)H * 36 + 4, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
+        memcpy(h_hyp.data(), pin, (size_t)H * 16);
+        memcpy(h_pos.data(), pin + (size_t)H * 16, (size_t)H * 16);
+        memcpy(h_counts.data(), pin + (size_t)H * 32, (size_t)H * 4);
+        memcpy(&sub_un, pin + (size_t)H * 36, 4);
+        t_sample += secs_since(t_s0);
         uint32_t valid = 0;
-        for (uint32_t i = 0; i < H; ++i) valid += h_pos[i].w != 0.f;
+        for (uint32_t i = 0; i < H; ++i) valid += h_pos[i].w != 0.f;   // w: 0 no samples, 1 verified plane, 2 drawn but rejected
         drawn += (float)valid;
+        if (getenv("PLADE_DEBUG_RANSAC"))
+            fprintf(stderr, "[ransac] round %u valid %u drawn %.0f n_rem %u accepted %zu failprob %.4g\n", round, valid, drawn,
+                    n_remaining, accepted.size(), fail_prob((float)rp.min_support, (float)n_remaining, drawn));
         // leaders of this batch by estimated support, one representative per distinct plane
         const double ratio = sub_un ? (double)n_remaining / sub_un : 0.0;
         std::vector<uint32_t> order;
         order.reserve(H);
         for (uint32_t i = 0; i < H; ++i)
-            if (h_pos[i].w != 0.f && h_counts[i] * ratio >= 0.5 * rp.min_support) order.push_back(i);
+            if (h_pos[i].w == 1.f && h_counts[i] * ratio >= 0.5 * rp.min_support) order.push_back(i);
         std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
             return h_counts[a] != h_counts[b] ? h_counts[a] > h_counts[b] : a < b;
         });
@@ -670,6 +719,7 @@ void ransac_detect(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const R
         }
         // ---- harvest: re-score the pool on all unassigned points, accept the best, repeat ---------
         while (!pool.empty()) {
+            Clock::time_point t_r0 = Clock::now();
             const uint32_t np = (uint32_t)pool.size();
             std::vector<float4> pl(np);
             for (uint32_t i = 0; i < np; ++i) pl[i] = pool[i].pl;
@@ -680,6 +730,7 @@ void ransac_detect(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const R
             std::vector<uint32_t> cnts(np);
             HIP_TRY(hipMemcpyAsync(cnts.data(), W.top_counts.p, np * 4, hipMemcpyDeviceToHost, ctx->stream));
             HIP_TRY(hipStreamSynchronize(ctx->stream));
+            t_rescore += secs_since(t_r0);
             uint32_t best = 0;
             for (uint32_t i = 0; i < np; ++i) { pool[i].count = cnts[i]; if (cnts[i] > cnts[best]) best = i; }
             // candidates that can no longer reach min_support are dropped (RansacShapeDetector.cpp:826-832)
@@ -690,25 +741,29 @@ void ransac_detect(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const R
             // ---- acceptance sequence (RansacShapeDetector.cpp:618-656), all four slots enqueued ---------
             // slot 0 = the candidate (GlobalScore(3 eps) + ConnectedComponent; its clone's first
             // GlobalWeightedScore is the same computation), slot k = k-th LS refit of slot k-1's points.
-            HIP_TRY(hipMemcpyAsync(W.top.p, &bc.pl, 16, hipMemcpyHostToDevice, ctx->stream));
-            HIP_TRY(hipMemcpyAsync(W.top_pos.p, &bc.pos, 16, hipMemcpyHostToDevice, ctx->stream));
-            hipLaunchKernelGGL(k_state_from_hyp, dim3(1), dim3(1), 0, ctx->stream, W.top.p, W.top_pos.p, W.st.p, W.plane_cur.p);
+            Clock::time_point t_a0 = Clock::now();
+            ++n_accepts;
+            float4 two[2] = {bc.pl, bc.pos};
+            HIP_TRY(hipMemcpyAsync(W.top.p, two, 32, hipMemcpyHostToDevice, ctx->stream));
+            hipLaunchKernelGGL(k_state_from_hyp, dim3(1), dim3(1), 0, ctx->stream, W.top.p, W.top.p + 1, W.st, W.plane_cur.p);
             for (int k = 0; k < 4; ++k) {
                 global_weighted_score(ctx, W, cv, k, eps3, cos_t, bitmap_eps);
-                hipLaunchKernelGGL(k_fit_partial, dim3(FIT_BLOCKS), dim3(256), 0, ctx->stream, cv, W.idxS[k].p, W.cntS.p + k, W.part.p);
-                hipLaunchKernelGGL(k_fit_final, dim3(1), dim3(1), 0, ctx->stream, W.part.p, W.cntS.p + k, W.st.p + std::min(k + 1, 3),
-                                   W.plane_cur.p + std::min(k + 1, 3), W.nsum.p + 3 * k, k < 3 ? 0 : 1);
+                hipLaunchKernelGGL(k_fit_partial, dim3(FIT_BLOCKS), dim3(256), 0, ctx->stream, cv, W.idxS[k].p, W.cntS + k, W.part.p);
+                hipLaunchKernelGGL(k_fit_final, dim3(1), dim3(FIT_BLOCKS), 0, ctx->stream, W.part.p, W.cntS + k, W.st + std::min(k + 1, 3),
+                                   W.plane_cur.p + std::min(k + 1, 3), W.nsum + 3 * k, k < 3 ? 0 : 1);
             }
-            hipLaunchKernelGGL(k_wscore_final, dim3(1), dim3(64), 0, ctx->stream, W.part_ws.p, W.st.p);
+            hipLaunchKernelGGL(k_wscore_final, dim3(1), dim3(256), 0, ctx->stream, W.part_ws.p, W.st);
             n_full_passes += 4;
             PlaneState hst[4];
             uint32_t hcnt[4];
             float hns[12];
-            HIP_TRY(hipMemcpyAsync(hst, W.st.p, 4 * sizeof(PlaneState), hipMemcpyDeviceToHost, ctx->stream));
-            HIP_TRY(hipMemcpyAsync(hcnt, W.cntS.p, 16, hipMemcpyDeviceToHost, ctx->stream));
-            HIP_TRY(hipMemcpyAsync(hns, W.nsum.p, 48, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(hipMemcpyAsync(pin, ab, accept_bytes, hipMemcpyDeviceToHost, ctx->stream));
             HIP_TRY(hipStreamSynchronize(ctx->stream));
+            memcpy(hst, pin, 4 * sizeof(PlaneState));
+            memcpy(hcnt, pin + 4 * sizeof(PlaneState), 16);
+            memcpy(hns, pin + 4 * sizeof(PlaneState) + 16, 48);
             HIP_TRY(hipGetLastError());
+            t_accept += secs_since(t_a0);
             PLADE_REQUIRE(hst[0].err != 1, PLADE_ELIMIT, "plane extraction: connected-component bitmap too large");
             // replay of the reference's refit loop on the four results
             int final_slot = 0;
@@ -725,6 +780,10 @@ void ransac_detect(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const R
             }
             const PlaneState &cand_state = hst[final_slot];
             const uint32_t cand_size = hcnt[final_slot];
+            if (getenv("PLADE_DEBUG_RANSAC"))
+                fprintf(stderr, "[ransac]   accept: eps-count %u sizes %u %u %u %u wscore %.1f %.1f %.1f %.1f final slot %d bitmap %ux%u\n",
+                        bc.count, hcnt[0], hcnt[1], hcnt[2], hcnt[3], hst[0].wscore, hst[1].wscore, hst[2].wscore, hst[3].wscore,
+                        final_slot, hst[final_slot].ue, hst[final_slot].ve);
             uint32_t *cand_idx = W.idxS[final_slot].p;
             // ---- remove the points (RansacShapeDetector.cpp:666-675) ---------------------------------
             if (cand_size == 0) continue;
@@ -757,6 +816,11 @@ void ransac_detect(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const R
             if (n_remaining < rp.min_support) { pool.clear(); break; }
         }
     }
+    ctx->stats.add("ransac_t_sample", t_sample);
+    ctx->stats.add("ransac_t_rescore", t_rescore);
+    ctx->stats.add("ransac_t_accept", t_accept);
+    ctx->stats.add("ransac_rounds", n_rounds);
+    ctx->stats.add("ransac_accepts", n_accepts);
     // ---- output ---------------------------------------------------------------------------------
     out.idx.resize(out_off);
     if (out_off) HIP_TRY(hipMemcpyAsync(out.idx.data(), W.out_idx.p, 4 * (size_t)out_off, hipMemcpyDeviceToHost, ctx->stream));

@@ -1,7 +1,8 @@
 """Quick timing of the full GPU registration on a synthetic pair (development helper)."""
 import sys, time
 import numpy as np
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import plade_amd
 from plade_amd.synth import make_pair
 
