@@ -34,6 +34,26 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
 
+def pmc_traffic(tag):
+    """HBM bytes per launch of the roofline kernel from the committed PMC summary (separate
+    `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this same command, FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for gfx950; tools/summarize_profiles.py).  None if no summary exists."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm.csv")))
+    if not files:
+        return None, None
+    sym = {"score_mark": "k_score_mark", "score_multi": "k_score_multi", "score_subset": "k_score_multi",
+           "overlap": "k_overlap", "knn_spacing": "k_knn_grid"}.get(tag, tag)
+    with open(files[-1]) as f:
+        for r in csv.DictReader(f):
+            if sym + "(" in r["kernel"]:
+                rd = float(r["hbm_read_bytes(FETCH_SIZE*1024*2)"])
+                wr = float(r["hbm_write_bytes(WRITE_SIZE*1024)"])
+                return rd + wr, os.path.relpath(files[-1], ROOT)
+    return None, None
+
+
 def cpu_baseline(n_points, pairs, budget_s=25.0):
     """Single-thread CPU registrations/sec on a bounded sample (rank 0, N = 1 only)."""
     from oracle.oracle import Oracle, Reference, have_reference
@@ -187,11 +207,17 @@ def main():
         if best is not None:
             secs, nl, by = st[f"k_{best}_seconds"], st[f"k_{best}_launches"], st[f"k_{best}_bytes"]
             achieved = by / secs / 1e9
+            traffic, traffic_src = pmc_traffic(best)
             roofline = {"bound": "hbm", "kernel": best, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                         "launches_per_step": int(nl), "avg_launch_us": secs / nl * 1e6,
                         "algorithmic_bytes_per_launch": by / nl}
         stage_times = {k: v for k, v in st.items() if k.startswith("t_")}
+        b_total = st.get("bytes_ransac", 0.0) + st.get("bytes_voxel", 0.0) + st.get("bytes_verify", 0.0)
+        if roofline is not None:
+            # B_total / t_registration against the HBM peak (whole-step figure)
+            roofline["step_algorithmic_bytes"] = b_total
+            roofline["step_frac_of_hbm_peak"] = b_total / st.get("t_registration", float("inf")) / 1e9 / HBM_PEAK_GBS
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:

@@ -338,9 +338,10 @@ int connected_component(const float *pos_nrm, const float *normal, const float *
 // parity bar for this row is a tolerance (tests/test_oracle_vs_ref.py).
 void jacobi_sym3(double a[3][3], double d[3], double v[3][3]) {
     for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) v[i][j] = i == j;
+    const double scale = std::fabs(a[0][0]) + std::fabs(a[1][1]) + std::fabs(a[2][2]);
     for (int sweep = 0; sweep < 60; ++sweep) {
         double off = std::fabs(a[0][1]) + std::fabs(a[0][2]) + std::fabs(a[1][2]);
-        if (off < 1e-300) break;
+        if (off <= 1e-24 * scale) break;
         for (int p = 0; p < 2; ++p)
             for (int q = p + 1; q < 3; ++q) {
                 if (std::fabs(a[p][q]) < 1e-300) continue;

@@ -224,18 +224,20 @@ __global__ __launch_bounds__(256) void k_cc_params(CloudView c, const uint32_t *
                                                    const uint32_t *__restrict__ count, PlaneState *st,
                                                    float2 *__restrict__ uv) {
     const uint32_t m = *count;
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    float u = INFINITY, v = INFINITY, U = -INFINITY, V = -INFINITY;
-    if (i < m) {
-        const uint32_t p = idx[i];
-        const float pp[3] = {c.x[p] - st->pos[0], c.y[p] - st->pos[1], c.z[p] - st->pos[2]};
-        u = pp[0] * st->a0[0] + pp[1] * st->a0[1] + pp[2] * st->a0[2];
-        v = pp[0] * st->a1[0] + pp[1] * st->a1[1] + pp[2] * st->a1[2];
-        uv[i] = make_float2(u, v);
-        U = u; V = v;
-    }
+    if (blockIdx.x * blockDim.x >= m) return;  // whole block beyond the list (uniform)
     __shared__ float s_lds[4][8];
-    float mn[2] = {u, v}, mx[2] = {U, V};
+    float mn[2] = {INFINITY, INFINITY}, mx[2] = {-INFINITY, -INFINITY};
+    const float px = st->pos[0], py = st->pos[1], pz = st->pos[2];
+    const float a00 = st->a0[0], a01 = st->a0[1], a02 = st->a0[2], a10 = st->a1[0], a11 = st->a1[1], a12 = st->a1[2];
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
+        const uint32_t p = idx[i];
+        const float pp[3] = {c.x[p] - px, c.y[p] - py, c.z[p] - pz};
+        const float u = pp[0] * a00 + pp[1] * a01 + pp[2] * a02;
+        const float v = pp[0] * a10 + pp[1] * a11 + pp[2] * a12;
+        uv[i] = make_float2(u, v);
+        mn[0] = fminf(mn[0], u); mn[1] = fminf(mn[1], v);
+        mx[0] = fmaxf(mx[0], u); mx[1] = fmaxf(mx[1], v);
+    }
     block_minmax_commit<2>(mn, mx, st->bb, s_lds);
 }
 
@@ -419,9 +421,10 @@ __global__ __launch_bounds__(256) void k_fit_partial(CloudView c, const uint32_t
 
 __device__ void jacobi3_d(double a[3][3], double d[3], double v[3][3]) {
     for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) v[i][j] = i == j;
+    const double scale = fabs(a[0][0]) + fabs(a[1][1]) + fabs(a[2][2]);
     for (int sweep = 0; sweep < 60; ++sweep) {
         const double off = fabs(a[0][1]) + fabs(a[0][2]) + fabs(a[1][2]);
-        if (off < 1e-300) break;
+        if (off <= 1e-24 * scale) break;   // far below fp64 resolution of the eigenvectors (quadratic convergence)
         for (int p = 0; p < 2; ++p)
             for (int q = p + 1; q < 3; ++q) {
                 if (fabs(a[p][q]) < 1e-300) continue;
@@ -570,7 +573,7 @@ void global_weighted_score(plade_ctx *ctx, RansacWork &W, const CloudView &cv, i
     score_compact(ctx, W.cs, c.x(), c.y(), c.z(), c.nx(), c.ny(), c.nz(), W.assigned.p, c.n, W.plane_cur.p + k, eps3, cos_t,
                   W.idxA.p, W.cntA.p);
     const uint32_t nb = cdiv(c.n, 256);
-    hipLaunchKernelGGL(k_cc_params, dim3(nb), dim3(256), 0, ctx->stream, cv, W.idxA.p, W.cntA.p, st, W.uv.p);
+    hipLaunchKernelGGL(k_cc_params, dim3(std::min(nb, 512u)), dim3(256), 0, ctx->stream, cv, W.idxA.p, W.cntA.p, st, W.uv.p);
     hipLaunchKernelGGL(k_cc_raster, dim3(nb), dim3(256), 0, ctx->stream, W.uv.p, W.cntA.p, st, bitmap_eps, W.bidx.p, W.bmp.p);
     hipLaunchKernelGGL(k_cc_label, dim3(1), dim3(1024), 0, ctx->stream, st, W.bmp.p, W.tmp.p, W.label.p, W.sizes.p, 1);
     const uint32_t nb4 = cdiv(c.n, 1024);
