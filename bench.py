@@ -164,15 +164,17 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     n_ok = 0
+    oks = []
     for i in range(args.steps):
         ok, T = step(i)
         n_ok += int(ok)
+        oks.append(ok)
         results.append(T)
-    # gather the per-pair 4x4 results on rank 0 (the only exchange the path needs)
-    res = torch.from_numpy(np.stack(results)).to(dev)
-    if world > 1:
-        gathered = [torch.empty_like(res) for _ in range(world)] if rank == 0 else None
-        dist.gather(res, gathered, dst=0)
+    # gather the per-pair 4x4 results on rank 0 in input order (the only exchange the path needs;
+    # plade_amd/batch.py, covered on CPU by tests/test_distributed_gloo.py with gloo)
+    from plade_amd.batch import gather_results
+    all_T, all_ok = gather_results(np.stack(results), np.array(oks, bool), world * args.steps, rank, world,
+                                   device=dev if world > 1 else None)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

@@ -34,6 +34,7 @@ extern "C" int plade_ctx_create(int device, plade_ctx **out) {
 
 extern "C" void plade_ctx_destroy(plade_ctx *ctx) {
     if (!ctx) return;
+    if (ctx->aux) { plade_ctx_destroy(ctx->aux); ctx->aux = nullptr; }
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->reg_work) plade::registration_work_destroy(ctx->reg_work);

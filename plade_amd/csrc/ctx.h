@@ -31,6 +31,7 @@ struct Stats {
         names.push_back(n);
         values.push_back(v);
     }
+    void merge(const Stats &o) { for (size_t i = 0; i < o.names.size(); ++i) add(o.names[i], o.values[i]); }
 };
 
 }  // namespace plade
@@ -46,6 +47,8 @@ struct plade_ctx {
     int device = 0;
     plade::RegistrationWork *reg_work = nullptr;
     plade::RansacWork *ransac_work = nullptr;
+    plade_ctx *aux = nullptr;   // second stream + work areas: the source cloud's plane extraction runs
+                                // concurrently with the target's (independent until the line stage)
     hipStream_t stream = nullptr;
     plade_params params;
     std::string last_error;

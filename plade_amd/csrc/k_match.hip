@@ -17,9 +17,9 @@
 
 namespace plade {
 
-constexpr int MT_TPB = 256;
-constexpr int MT_TILE = 256;   // targets per LDS tile
-constexpr int MT_CHUNK = 4096; // targets per block (grid.y)
+constexpr int MT_TPB = 64;    // one wave of queries per workgroup
+constexpr int MT_TILE = 128;   // targets per LDS tile
+constexpr int MT_CHUNK = 512;  // targets per block (grid.y)
 
 template <bool FILL>
 __global__ __launch_bounds__(MT_TPB) void k_match(const float *__restrict__ qry, uint32_t dq,

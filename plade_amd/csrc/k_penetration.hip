@@ -105,9 +105,10 @@ __global__ __launch_bounds__(256) void k_pen_setup(PenTables tb, float len_th, f
     items[slot] = it;
 }
 
-constexpr int PEN_MAXS = 4096;
+constexpr int PEN_MAXS = 1024;
+constexpr int PEN_TPB = 64;   // one wavefront per surviving triple
 
-__global__ __launch_bounds__(256) void k_pen_walk(const PenItem *__restrict__ items, uint32_t n_items, PenTables tb,
+__global__ __launch_bounds__(PEN_TPB) void k_pen_walk(const PenItem *__restrict__ items, uint32_t n_items, PenTables tb,
                                                   const float *__restrict__ s_xyz, const uint32_t *__restrict__ s_off,
                                                   const float *__restrict__ t_xyz, const uint32_t *__restrict__ t_off,
                                                   float search_radius, int min_points, float min_distance,
@@ -152,6 +153,8 @@ __global__ __launch_bounds__(256) void k_pen_walk(const PenItem *__restrict__ it
             else p = pcl_xform(T12, f3(s_xyz[3 * (size_t)i], s_xyz[3 * (size_t)i + 1], s_xyz[3 * (size_t)i + 2]));
             const f3 d = p - start;
             const float t = d.x * direc.x + d.y * direc.y + d.z * direc.z;
+            // conservative reject: farther than r/2 (+2 %) from the line => within r/2 of no step point
+            if ((d.x * d.x + d.y * d.y + d.z * d.z) - t * t > half_r2 * 1.02f + 1e-12f) continue;
             const int kc = (int)floorf(t * inv_r);
             for (int kk = max(kc - 2, 0); kk <= min(kc + 3, nsteps - 1); ++kk) {
                 const float dist = s_dist[kk];
@@ -170,6 +173,7 @@ __global__ __launch_bounds__(256) void k_pen_walk(const PenItem *__restrict__ it
             else p = f3(t_xyz[3 * (size_t)i], t_xyz[3 * (size_t)i + 1], t_xyz[3 * (size_t)i + 2]);
             const f3 d = p - start;
             const float t = d.x * direc.x + d.y * direc.y + d.z * direc.z;
+            if ((d.x * d.x + d.y * d.y + d.z * d.z) - t * t > full_r2 * 1.02f + 1e-12f) continue;
             const int kc = (int)floorf(t * inv_r);
             bool hit = false;
             for (int kk = max(kc - 2, 0); kk <= min(kc + 3, nsteps - 1) && !hit; ++kk) {
@@ -238,7 +242,7 @@ void penetration_filter(plade_ctx *ctx, const float *cand_rt_host, uint32_t K, c
         // AreTwoPlanesPenetrable(..., searchRadius = lengthThreshold, minPointsNum = 10, minDistance = lengthThreshold / 2)
         const float search_radius = (float)(double)length_threshold;
         const float min_distance = (float)((double)length_threshold / 2);
-        hipLaunchKernelGGL(k_pen_walk, dim3(n_items), dim3(256), 0, ctx->stream, d_items, n_items, tb, src_pts.xyz.p,
+        hipLaunchKernelGGL(k_pen_walk, dim3(n_items), dim3(PEN_TPB), 0, ctx->stream, d_items, n_items, tb, src_pts.xyz.p,
                            src_pts.d_off.p, tgt_pts.xyz.p, tgt_pts.d_off.p, search_radius, 10, min_distance, d_flags,
                            d_over);
     }
@@ -246,7 +250,7 @@ void penetration_filter(plade_ctx *ctx, const float *cand_rt_host, uint32_t K, c
     HIP_TRY(hipMemcpyAsync(out.data(), d_over, ((size_t)K + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     HIP_TRY(hipGetLastError());
-    PLADE_REQUIRE(out[0] == 0, PLADE_ELIMIT, "penetration: intersection segment longer than 4096 search steps");
+    PLADE_REQUIRE(out[0] == 0, PLADE_ELIMIT, "penetration: intersection segment longer than 1024 search steps");
     for (uint32_t k = 0; k < K; ++k) flags_out[k] = out[k + 1] ? 1 : 0;
 }
 

@@ -22,7 +22,7 @@ namespace plade {
 // ------------------------------------------------------------------------------------------------
 __global__ void k_voxel_keys(const float *__restrict__ xyz, uint32_t stride, const uint32_t *__restrict__ item_point,
                              const uint32_t *__restrict__ item_group, uint32_t n_items, float inv, int lminx, int lminy,
-                             int lminz, uint64_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+                             int lminz, int bx, int by, int bz, uint64_t *__restrict__ keys, uint32_t *__restrict__ vals) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_items) return;
     const uint32_t p = item_point ? item_point[i] : i;
@@ -32,7 +32,7 @@ __global__ void k_voxel_keys(const float *__restrict__ xyz, uint32_t stride, con
     const uint64_t ly = (uint64_t)((int)floorf(y * inv) - lminy);
     const uint64_t lz = (uint64_t)((int)floorf(z * inv) - lminz);
     const uint64_t g = item_group ? item_group[i] : 0u;
-    keys[i] = (g << 54) | (lz << 36) | (ly << 18) | lx;
+    keys[i] = (g << (bx + by + bz)) | (lz << (bx + by)) | (ly << bx) | lx;
     vals[i] = i;
 }
 
@@ -52,7 +52,7 @@ __global__ void k_heads(const uint32_t *__restrict__ flags, const uint32_t *__re
 __global__ void k_voxel_centroids(const float *__restrict__ xyz, uint32_t stride,
                                   const uint32_t *__restrict__ item_point, const uint64_t *__restrict__ keys,
                                   const uint32_t *__restrict__ vals, const uint32_t *__restrict__ heads,
-                                  uint32_t n_seg, uint32_t n_items, float *__restrict__ out_xyz,
+                                  uint32_t n_seg, uint32_t n_items, int group_shift, float *__restrict__ out_xyz,
                                   uint32_t *__restrict__ out_group) {
     uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_seg) return;
@@ -69,7 +69,7 @@ __global__ void k_voxel_centroids(const float *__restrict__ xyz, uint32_t stride
     out_xyz[3 * (size_t)s] = ax / cnt;
     out_xyz[3 * (size_t)s + 1] = ay / cnt;
     out_xyz[3 * (size_t)s + 2] = az / cnt;
-    if (out_group) out_group[s] = (uint32_t)(keys[b] >> 54);
+    if (out_group) out_group[s] = (uint32_t)(keys[b] >> group_shift);
 }
 
 __global__ void k_group_offsets(const uint32_t *__restrict__ seg_group, uint32_t n_seg, uint32_t n_groups,
@@ -108,14 +108,18 @@ uint32_t VoxelWork::run(plade_ctx *ctx, const float *d_xyz, uint32_t stride, con
                 dz = (int64_t)((bbox_max[2] - bbox_min[2]) * inv) + 1;
         PLADE_REQUIRE(dx * dy * dz <= (int64_t)INT32_MAX, PLADE_ELIMIT, "voxel: leaf size too small for the data extent");
     }
+    // key = (group | k | j | i) packed with just enough bits per field: the radix sort cost is
+    // proportional to the key width
+    auto bits_for = [](int64_t range) { int b = 1; while (((int64_t)1 << b) <= range) ++b; return b; };
+    const int bx = bits_for((int64_t)lmax[0] - lmin[0]), by = bits_for((int64_t)lmax[1] - lmin[1]), bz = bits_for((int64_t)lmax[2] - lmin[2]);
     keys.ensure(n_items); keys2.ensure(n_items); vals.ensure(n_items); vals2.ensure(n_items);
     flags.ensure((size_t)n_items + 1); seg.ensure((size_t)n_items + 1);
     const unsigned nb = cdiv(n_items, 256);
     hipLaunchKernelGGL(k_voxel_keys, dim3(nb), dim3(256), 0, ctx->stream, d_xyz, stride, d_item_point, d_item_group,
-                       n_items, inv, lmin[0], lmin[1], lmin[2], keys.p, vals.p);
+                       n_items, inv, lmin[0], lmin[1], lmin[2], bx, by, bz, keys.p, vals.p);
     int gbits = 0;
     while ((1u << gbits) < n_groups) ++gbits;
-    sort_pairs_u64(ctx, keys.p, keys2.p, vals.p, vals2.p, n_items, 54 + gbits);
+    sort_pairs_u64(ctx, keys.p, keys2.p, vals.p, vals2.p, n_items, bx + by + bz + gbits);
     hipLaunchKernelGGL(k_head_flags, dim3(nb), dim3(256), 0, ctx->stream, keys2.p, n_items, flags.p);
     HIP_TRY(hipMemsetAsync(flags.p + n_items, 0, 4, ctx->stream));
     exclusive_scan_u32(ctx, flags.p, seg.p, (size_t)n_items + 1);
@@ -127,7 +131,7 @@ uint32_t VoxelWork::run(plade_ctx *ctx, const float *d_xyz, uint32_t stride, con
     out_xyz.ensure((size_t)n_seg * 3 + 4);
     seg_group.ensure((size_t)n_seg + 1);
     hipLaunchKernelGGL(k_voxel_centroids, dim3(cdiv(n_seg, 128)), dim3(128), 0, ctx->stream, d_xyz, stride, d_item_point,
-                       keys2.p, vals2.p, heads.p, n_seg, n_items, out_xyz.p, seg_group.p);
+                       keys2.p, vals2.p, heads.p, n_seg, n_items, bx + by + bz, out_xyz.p, seg_group.p);
     group_offsets.ensure((size_t)n_groups + 2);
     std::vector<uint32_t> init(n_groups + 1, n_seg);
     HIP_TRY(hipMemcpyAsync(group_offsets.p, init.data(), (n_groups + 1) * 4, hipMemcpyHostToDevice, ctx->stream));

@@ -9,6 +9,7 @@
 #include "prims.h"
 #include <algorithm>
 #include <numeric>
+#include <thread>
 
 namespace plade {
 
@@ -215,9 +216,33 @@ bool run_registration(plade_ctx *ctx, RegistrationWork &W, const CloudDev &tgt, 
     ctx->put1("scale", scale);
 
     {
+        // the two sides are independent until the descriptor match: the source side runs on the
+        // auxiliary stream / a second host thread
         StageTimer t(ctx, "t_prepare");
-        if (!prepare_side(ctx, "tgt", tgt, tp, downSampleDistance, M)) return false;
-        if (!prepare_side(ctx, "src", src, sp, downSampleDistance, C)) return false;
+        if (!ctx->aux) {
+            plade_ctx *a = nullptr;
+            PLADE_REQUIRE(plade_ctx_create(ctx->device, &a) == PLADE_OK, PLADE_EDEVICE, "cannot create the auxiliary stream");
+            ctx->aux = a;
+        }
+        plade_ctx *aux = ctx->aux;
+        aux->params = ctx->params;
+        aux->dump.clear();
+        aux->stats.clear();
+        bool ok_c = false, ok_m = false;
+        Err aux_err{0, ""}, main_err{0, ""};
+        std::thread th([&]() {
+            (void)hipSetDevice(ctx->device);
+            try { ok_c = prepare_side(aux, "src", src, sp, downSampleDistance, C); }
+            catch (const Err &e) { aux_err = e; }
+            catch (const std::exception &e) { aux_err = Err{PLADE_EDEVICE, e.what()}; }
+        });
+        try { ok_m = prepare_side(ctx, "tgt", tgt, tp, downSampleDistance, M); } catch (const Err &e) { main_err = e; }
+        th.join();
+        for (auto &kv : aux->dump) ctx->dump[kv.first] = kv.second;
+        ctx->stats.merge(aux->stats);
+        if (main_err.code) throw main_err;
+        if (aux_err.code) throw aux_err;
+        if (!ok_m || !ok_c) return false;
     }
     {
         StageTimer t(ctx, "t_descriptors");

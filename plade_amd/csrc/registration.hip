@@ -5,6 +5,7 @@
 #include "ransac.h"
 #include <algorithm>
 #include <numeric>
+#include <thread>
 
 using namespace plade;
 
@@ -67,25 +68,48 @@ int register_clouds(plade_ctx *ctx, const CloudDev &tgt, const CloudDev &src, in
     Clock::time_point t0 = Clock::now();
     {
         StageTimer t(ctx, "t_extract");
+        // The two clouds' extractions are independent (plade.cpp:645-657 runs them back to back): the
+        // source runs on a second stream / host thread so their many small launches interleave on the GPU.
+        if (!ctx->aux) {
+            plade_ctx *a = nullptr;
+            PLADE_REQUIRE(plade_ctx_create(ctx->device, &a) == PLADE_OK, PLADE_EDEVICE, "cannot create the auxiliary stream");
+            ctx->aux = a;
+        }
+        plade_ctx *aux = ctx->aux;
+        aux->params = ctx->params;
+        aux->stats.clear();
+        Err aux_err{0, ""};
+        auto one = [&](plade_ctx *c, const CloudDev &cloud, int ms, PlaneSetOut &out) {
+            if (auto_tune) extract(c, cloud, c->params.init_min_support, out);
+            else {  // plade.cpp:583-599
+                if (!c->ransac_work) c->ransac_work = ransac_work_create();
+                ransac_detect(c, *c->ransac_work, cloud, ransac_params(c, (uint32_t)ms), out);
+            }
+        };
+        std::thread th([&]() {
+            (void)hipSetDevice(ctx->device);
+            try { one(aux, src, ms_s, sp); }
+            catch (const Err &e) { aux_err = e; }
+            catch (const std::exception &e) { aux_err = Err{PLADE_EDEVICE, e.what()}; }
+        });
+        Err main_err{0, ""};
+        try { one(ctx, tgt, ms_t, tp); } catch (const Err &e) { main_err = e; }
+        th.join();
+        aux->ev_collect();
+        ctx->stats.merge(aux->stats);
+        if (main_err.code) throw main_err;
+        if (aux_err.code) throw aux_err;
         if (auto_tune) {
-            extract(ctx, tgt, ctx->params.init_min_support, tp);
             if (tp.P() < (uint32_t)ctx->params.min_planes) {  // plade.cpp:646-650
                 ctx->last_error = "too few planes extracted from the target point cloud";
                 return PLADE_EFAIL;
             }
-            // the target's device index list is overwritten by the second detect: keep host lists only
-            tp.d_idx = nullptr;
-            extract(ctx, src, ctx->params.init_min_support, sp);
             if (sp.P() < (uint32_t)ctx->params.min_planes) {  // plade.cpp:653-657
                 ctx->last_error = "too few planes extracted from the source point cloud";
                 return PLADE_EFAIL;
             }
-        } else {  // plade.cpp:583-599
-            if (!ctx->ransac_work) ctx->ransac_work = ransac_work_create();
-            ransac_detect(ctx, *ctx->ransac_work, tgt, ransac_params(ctx, (uint32_t)ms_t), tp);
-            tp.d_idx = nullptr;
-            ransac_detect(ctx, *ctx->ransac_work, src, ransac_params(ctx, (uint32_t)ms_s), sp);
         }
+        // the device index lists live in the two separate work areas and stay valid for the next stage
     }
     if (ctx->params.dump) {
         ctx->put("tgt_planes", tp.coef.data(), tp.coef.size());
@@ -101,6 +125,7 @@ int register_clouds(plade_ctx *ctx, const CloudDev &tgt, const CloudDev &src, in
     PlaneSetView tv, sv;
     tv.coef = tp.coef.data(); tv.offsets = tp.offsets.data(); tv.idx = tp.idx.data(); tv.P = tp.P();
     sv.coef = sp.coef.data(); sv.offsets = sp.offsets.data(); sv.idx = sp.idx.data(); sv.P = sp.P(); sv.d_idx = sp.d_idx;
+    tv.d_idx = tp.d_idx;
     const bool ok = run_registration(ctx, *ctx->reg_work, tgt, src, tv, sv, T16);
     ctx->stats.add("t_registration", secs_since(t0));
     // roofline bookkeeping
