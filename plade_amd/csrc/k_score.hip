@@ -119,8 +119,10 @@ __global__ __launch_bounds__(TPB) void k_score_mark(const float *__restrict__ x,
                                                     const float *__restrict__ ny, const float *__restrict__ nz,
                                                     const int32_t *__restrict__ assigned, uint32_t n,
                                                     const float4 *__restrict__ plane, float eps, float cos_t,
-                                                    uint8_t *__restrict__ masks, uint32_t *__restrict__ block_counts) {
+                                                    uint8_t *__restrict__ masks, uint32_t *__restrict__ block_counts,
+                                                    const uint32_t *__restrict__ skip) {
     __shared__ uint32_t s_w[TPB / 64];
+    if (skip && *skip) return;
     const float4 pl = plane[0];
     Tile t;
     load_tile(t, x, y, z, nx, ny, nz, assigned, nullptr, n, blockIdx.x * TILE + threadIdx.x * PPT);
@@ -143,9 +145,10 @@ __global__ __launch_bounds__(TPB) void k_score_mark(const float *__restrict__ x,
 __global__ __launch_bounds__(TPB) void k_compact(const uint8_t *__restrict__ masks,
                                                  const uint32_t *__restrict__ block_counts, uint32_t nb,
                                                  const uint32_t *__restrict__ values, uint32_t *__restrict__ out,
-                                                 uint32_t *__restrict__ total) {
+                                                 uint32_t *__restrict__ total, const uint32_t *__restrict__ skip) {
     __shared__ uint32_t s_w[TPB / 64];
     __shared__ uint32_t s_base[TPB / 64];
+    if (skip && *skip) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t pre = 0;
     for (uint32_t b = threadIdx.x; b < blockIdx.x; b += TPB) pre += block_counts[b];
@@ -189,27 +192,27 @@ void score_multi(plade_ctx *ctx, const float *x, const float *y, const float *z,
 }
 
 void compact_masks(plade_ctx *ctx, CompactScratch &s, uint32_t n, const uint32_t *values, uint32_t *idx_out_dev,
-                   uint32_t *count_dev) {
+                   uint32_t *count_dev, const uint32_t *skip_flag) {
     const uint32_t nb = cdiv(n, TILE);
     if (nb == 0) { HIP_TRY(hipMemsetAsync(count_dev, 0, 4, ctx->stream)); return; }
     hipLaunchKernelGGL(k_compact, dim3(nb), dim3(TPB), 0, ctx->stream, s.masks.p, s.block_counts.p, nb, values,
-                       idx_out_dev, count_dev);
+                       idx_out_dev, count_dev, skip_flag);
     (void)n;
     HIP_TRY(hipGetLastError());
 }
 
 void score_compact(plade_ctx *ctx, CompactScratch &s, const float *x, const float *y, const float *z, const float *nx,
                    const float *ny, const float *nz, const int32_t *assigned, uint32_t n, const float4 *plane_dev,
-                   float eps, float cos_thresh, uint32_t *idx_out_dev, uint32_t *count_dev) {
+                   float eps, float cos_thresh, uint32_t *idx_out_dev, uint32_t *count_dev, const uint32_t *skip_flag) {
     const uint32_t nb = cdiv(n, TILE);
     if (nb == 0) { HIP_TRY(hipMemsetAsync(count_dev, 0, 4, ctx->stream)); return; }
     s.masks.ensure((size_t)nb * TPB);
     s.block_counts.ensure(nb);
     ctx->ev_begin("score_mark", 28.0 * n);
     hipLaunchKernelGGL(k_score_mark, dim3(nb), dim3(TPB), 0, ctx->stream, x, y, z, nx, ny, nz, assigned, n, plane_dev,
-                       eps, cos_thresh, s.masks.p, s.block_counts.p);
+                       eps, cos_thresh, s.masks.p, s.block_counts.p, skip_flag);
     ctx->ev_end();
-    compact_masks(ctx, s, n, nullptr, idx_out_dev, count_dev);
+    compact_masks(ctx, s, n, nullptr, idx_out_dev, count_dev, skip_flag);
 }
 
 // ---------------------------------------------------------------------------------------------

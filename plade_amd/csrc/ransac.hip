@@ -180,6 +180,7 @@ struct PlaneState {
     double wscore;
     float nsum[3];                   // sum of inlier point normals (orientation)
     uint32_t err;
+    uint32_t converged;              // refit chain: this slot's plane is bitwise the previous slot's
 };
 
 __device__ __forceinline__ void hcs_axes(const float *n, float *a0, float *a1) {
@@ -213,6 +214,7 @@ __global__ void k_state_from_hyp(const float4 *__restrict__ hyp, const float4 *_
     st->pos[0] = pos->x; st->pos[1] = pos->y; st->pos[2] = pos->z;
     hcs_axes(st->n, st->a0, st->a1);
     st->err = 0;
+    st->converged = 0;
     st->bb[0] = st->bb[1] = ord_i(INFINITY);
     st->bb[2] = st->bb[3] = ord_i(-INFINITY);
     *plane_out = *hyp;
@@ -223,6 +225,7 @@ __global__ void k_state_from_hyp(const float4 *__restrict__ hyp, const float4 *_
 __global__ __launch_bounds__(256) void k_cc_params(CloudView c, const uint32_t *__restrict__ idx,
                                                    const uint32_t *__restrict__ count, PlaneState *st,
                                                    float2 *__restrict__ uv) {
+    if (st->converged) return;
     const uint32_t m = *count;
     if (blockIdx.x * blockDim.x >= m) return;  // whole block beyond the list (uniform)
     __shared__ float s_lds[4][8];
@@ -263,6 +266,7 @@ __device__ __forceinline__ bool cc_dims(const PlaneState *st, uint32_t count, fl
 __global__ __launch_bounds__(256) void k_cc_raster(const float2 *__restrict__ uv, const uint32_t *__restrict__ count,
                                                    PlaneState *st, float eps, uint32_t *__restrict__ bidx,
                                                    uint8_t *__restrict__ bmp) {
+    if (st->converged) return;
     const uint32_t m = *count;
     uint32_t ue, ve;
     const bool ok = cc_dims(st, m, eps, ue, ve);
@@ -292,6 +296,7 @@ __global__ __launch_bounds__(1024) void k_cc_label(PlaneState *st, uint8_t *__re
     __shared__ uint32_t s_label[CC_LDS_PIX];
     __shared__ uint32_t s_sizes[CC_LDS_PIX];
     __shared__ uint8_t s_bmp[CC_LDS_PIX], s_tmp[CC_LDS_PIX];
+    if (st->converged) return;
     const int ue = (int)st->ue, ve = (int)st->ve, npx = ue * ve;
     const bool in_lds = npx <= CC_LDS_PIX;
     uint8_t *bmp = in_lds ? s_bmp : g_bmp, *tmp = in_lds ? s_tmp : g_tmp;
@@ -377,6 +382,7 @@ __global__ __launch_bounds__(256) void k_cc_select(const uint32_t *__restrict__ 
                                                    const PlaneState *st, const uint32_t *__restrict__ label,
                                                    uint8_t *__restrict__ masks, uint32_t *__restrict__ block_counts) {
     __shared__ uint32_t s_w[4];
+    if (st->converged) return;
     const uint32_t m = *count, best = st->best_root;
     const uint32_t base = blockIdx.x * 1024 + threadIdx.x * 4;
     uint32_t mk = 0, c = 0;
@@ -401,8 +407,10 @@ __global__ __launch_bounds__(256) void k_cc_select(const uint32_t *__restrict__ 
 constexpr int FIT_BLOCKS = 256;
 
 __global__ __launch_bounds__(256) void k_fit_partial(CloudView c, const uint32_t *__restrict__ idx,
-                                                     const uint32_t *__restrict__ count, double *__restrict__ part /* FIT_BLOCKS x 12 */) {
+                                                     const uint32_t *__restrict__ count, double *__restrict__ part /* FIT_BLOCKS x 12 */,
+                                                     const PlaneState *__restrict__ st) {
     __shared__ double s[4][12];
+    if (st->converged) return;
     const uint32_t m = *count;
     double a[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
@@ -442,10 +450,20 @@ __device__ void jacobi3_d(double a[3][3], double d[3], double v[3][3]) {
 // Sums the per-block partials of the index list `count` belongs to (fixed tree => deterministic);
 // nsum_out receives the sum of the list's point normals (orientation).  mode 0 additionally writes the
 // fitted plane into `st` (the NEXT slot's state) / plane_out.  One workgroup of FIT_BLOCKS lanes.
+// `cur` is the state of the slot whose list was just reduced; when the new plane is bitwise equal to
+// cur's plane the chain has converged: every later slot would reproduce cur's results, so they are
+// flagged and their kernels return immediately.
 __global__ __launch_bounds__(FIT_BLOCKS) void k_fit_final(const double *__restrict__ part, const uint32_t *__restrict__ count,
-                                                          PlaneState *st, float4 *plane_out, float *__restrict__ nsum_out,
-                                                          int mode) {
+                                                          const PlaneState *cur, PlaneState *st, float4 *plane_out,
+                                                          float *__restrict__ nsum_out, int mode) {
     __shared__ double s_red[FIT_BLOCKS / 64][12];
+    if (cur->converged) {
+        if (threadIdx.x == 0) {
+            nsum_out[0] = nsum_out[-3]; nsum_out[1] = nsum_out[-2]; nsum_out[2] = nsum_out[-1];
+            if (mode == 0) { st->converged = 1; st->err = 0; *plane_out = plane_out[-1]; }
+        }
+        return;
+    }
     double a[12];
     for (int k = 0; k < 12; ++k) a[k] = part[threadIdx.x * 12 + k];
     for (int k = 0; k < 12; ++k)
@@ -479,6 +497,8 @@ __global__ __launch_bounds__(FIT_BLOCKS) void k_fit_final(const double *__restri
     st->dist = dist;
     hcs_axes(st->n, st->a0, st->a1);
     *plane_out = make_float4(n[0], n[1], n[2], dist);
+    st->converged = (n[0] == cur->n[0] && n[1] == cur->n[1] && n[2] == cur->n[2] && dist == cur->dist &&
+                     st->pos[0] == cur->pos[0] && st->pos[1] == cur->pos[1] && st->pos[2] == cur->pos[2]) ? 1u : 0u;
 }
 
 // Candidate::WeightedScore (ransac/Candidate.cpp:77-87) with weigh() (ScoreComputer.h:10-16)
@@ -486,6 +506,7 @@ __global__ __launch_bounds__(256) void k_wscore_partial(CloudView c, const uint3
                                                         const uint32_t *__restrict__ count, const PlaneState *st,
                                                         float eps, double *__restrict__ part) {
     __shared__ double s[4];
+    if (st->converged) return;
     const uint32_t m = *count;
     const float n0 = st->n[0], n1 = st->n[1], n2 = st->n[2], dist = st->dist;
     double acc = 0;
@@ -503,12 +524,20 @@ __global__ __launch_bounds__(256) void k_wscore_partial(CloudView c, const uint3
     if (threadIdx.x == 0) part[blockIdx.x] = (s[0] + s[1]) + (s[2] + s[3]);
 }
 // one launch sums the partials of all four slots
-__global__ __launch_bounds__(256) void k_wscore_final(const double *__restrict__ part /* 4 x FIT_BLOCKS */, PlaneState *st /* 4 */) {
+__global__ __launch_bounds__(256) void k_wscore_final(const double *__restrict__ part /* 4 x FIT_BLOCKS */, PlaneState *st /* 4 */,
+                                                      uint32_t *__restrict__ cnt /* 4 */) {
+    __shared__ double s_ws[4];
     const int slot = threadIdx.x >> 6, lane = threadIdx.x & 63;  // one wave per slot
     double a = 0;
     for (int b = lane; b < FIT_BLOCKS; b += 64) a += part[slot * FIT_BLOCKS + b];
     for (int d = 32; d >= 1; d >>= 1) a += __shfl_xor(a, d, 64);
-    if (lane == 0) st[slot].wscore = a;
+    if (lane == 0) s_ws[slot] = a;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        for (int k = 0; k < 4; ++k) {
+            if (k > 0 && st[k].converged) { st[k].wscore = st[k - 1].wscore; cnt[k] = cnt[k - 1]; st[k].ue = st[k - 1].ue; st[k].ve = st[k - 1].ve; }
+            else st[k].wscore = s_ws[k];
+        }
 }
 
 __global__ void k_assign(const uint32_t *__restrict__ idx, uint32_t m, int32_t id, int32_t *__restrict__ assigned) {
@@ -551,6 +580,11 @@ struct RansacWork {
     DBuf<double> part, part_ws;
     DBuf<int32_t> out_idx;
     HBuf<char> pinned;
+    // the acceptance sequence (~40 launches, all arguments in device memory) as a hipGraph: replayed
+    // once per accepted plane instead of re-issuing the launches from the host
+    hipGraphExec_t accept_exec = nullptr;
+    std::vector<uint64_t> accept_key;
+    ~RansacWork() { if (accept_exec) (void)hipGraphExecDestroy(accept_exec); }
 };
 
 RansacWork *ransac_work_create() { return new RansacWork; }
@@ -570,18 +604,31 @@ void global_weighted_score(plade_ctx *ctx, RansacWork &W, const CloudView &cv, i
                            float bitmap_eps) {
     const CloudDev &c = W.sorted;
     PlaneState *st = W.st + k;
+    const uint32_t *skip = &st->converged;
     score_compact(ctx, W.cs, c.x(), c.y(), c.z(), c.nx(), c.ny(), c.nz(), W.assigned.p, c.n, W.plane_cur.p + k, eps3, cos_t,
-                  W.idxA.p, W.cntA.p);
+                  W.idxA.p, W.cntA.p, skip);
     const uint32_t nb = cdiv(c.n, 256);
-    hipLaunchKernelGGL(k_cc_params, dim3(std::min(nb, 512u)), dim3(256), 0, ctx->stream, cv, W.idxA.p, W.cntA.p, st, W.uv.p);
+    hipLaunchKernelGGL(k_cc_params, dim3(std::min(nb, 256u)), dim3(256), 0, ctx->stream, cv, W.idxA.p, W.cntA.p, st, W.uv.p);
     hipLaunchKernelGGL(k_cc_raster, dim3(nb), dim3(256), 0, ctx->stream, W.uv.p, W.cntA.p, st, bitmap_eps, W.bidx.p, W.bmp.p);
     hipLaunchKernelGGL(k_cc_label, dim3(1), dim3(1024), 0, ctx->stream, st, W.bmp.p, W.tmp.p, W.label.p, W.sizes.p, 1);
     const uint32_t nb4 = cdiv(c.n, 1024);
     hipLaunchKernelGGL(k_cc_select, dim3(nb4), dim3(256), 0, ctx->stream, W.bidx.p, W.cntA.p, st, W.label.p, W.cs2.masks.p,
                        W.cs2.block_counts.p);
-    compact_masks(ctx, W.cs2, c.n, W.idxA.p, W.idxS[k].p, W.cntS + k);
+    compact_masks(ctx, W.cs2, c.n, W.idxA.p, W.idxS[k].p, W.cntS + k, skip);
     hipLaunchKernelGGL(k_wscore_partial, dim3(FIT_BLOCKS), dim3(256), 0, ctx->stream, cv, W.idxS[k].p, W.cntS + k, st, eps3,
                        W.part_ws.p + (size_t)k * FIT_BLOCKS);
+}
+
+void enqueue_accept(plade_ctx *ctx, RansacWork &W, const CloudView &cv, float eps3, float cos_t, float bitmap_eps) {
+    hipLaunchKernelGGL(k_state_from_hyp, dim3(1), dim3(1), 0, ctx->stream, W.top.p, W.top.p + 1, W.st, W.plane_cur.p);
+    for (int k = 0; k < 4; ++k) {
+        global_weighted_score(ctx, W, cv, k, eps3, cos_t, bitmap_eps);
+        hipLaunchKernelGGL(k_fit_partial, dim3(FIT_BLOCKS), dim3(256), 0, ctx->stream, cv, W.idxS[k].p, W.cntS + k, W.part.p,
+                           W.st + k);
+        hipLaunchKernelGGL(k_fit_final, dim3(1), dim3(FIT_BLOCKS), 0, ctx->stream, W.part.p, W.cntS + k, W.st + k,
+                           W.st + std::min(k + 1, 3), W.plane_cur.p + std::min(k + 1, 3), W.nsum + 3 * k, k < 3 ? 0 : 1);
+    }
+    hipLaunchKernelGGL(k_wscore_final, dim3(1), dim3(256), 0, ctx->stream, W.part_ws.p, W.st, W.cntS);
 }
 
 inline bool same_plane(const float4 &a, const float4 &b, float eps) {
@@ -658,6 +705,31 @@ void ransac_detect(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const R
     W.cs2.masks.ensure((size_t)cdiv(n, 1024) * 256);
     W.cs2.block_counts.ensure(cdiv(n, 1024));
 
+    // ---- acceptance sequence as a graph (skipped when per-kernel event timing is on) -------------------
+    {
+        auto bits = [](float f) { uint32_t u; memcpy(&u, &f, 4); return (uint64_t)u; };
+        std::vector<uint64_t> key = {n, bits(eps3), bits(cos_t), bits(bitmap_eps), (uint64_t)c.soa.p, (uint64_t)W.assigned.p,
+                                     (uint64_t)W.idxA.p, (uint64_t)W.idxS[0].p, (uint64_t)W.idxS[1].p, (uint64_t)W.idxS[2].p,
+                                     (uint64_t)W.idxS[3].p, (uint64_t)W.uv.p, (uint64_t)W.bidx.p, (uint64_t)W.bmp.p, (uint64_t)W.label.p,
+                                     (uint64_t)W.st, (uint64_t)W.top.p, (uint64_t)W.plane_cur.p, (uint64_t)W.part.p, (uint64_t)W.part_ws.p,
+                                     (uint64_t)W.cs.masks.p, (uint64_t)W.cs2.masks.p, (uint64_t)ctx->stream};
+        W.cs.masks.ensure((size_t)cdiv(n, 1024) * 256);
+        W.cs.block_counts.ensure(cdiv(n, 1024));
+        key.push_back((uint64_t)W.cs.masks.p); key.push_back((uint64_t)W.cs.block_counts.p); key.push_back((uint64_t)W.cs2.block_counts.p);
+        if (ctx->profiling() || getenv("PLADE_NO_GRAPH")) {
+            if (W.accept_exec) { (void)hipGraphExecDestroy(W.accept_exec); W.accept_exec = nullptr; W.accept_key.clear(); }
+        } else if (!W.accept_exec || key != W.accept_key) {
+            if (W.accept_exec) { (void)hipGraphExecDestroy(W.accept_exec); W.accept_exec = nullptr; }
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+            hipGraph_t graph = nullptr;
+            HIP_TRY(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+            enqueue_accept(ctx, W, cv, eps3, cos_t, bitmap_eps);
+            HIP_TRY(hipStreamEndCapture(ctx->stream, &graph));
+            HIP_TRY(hipGraphInstantiate(&W.accept_exec, graph, nullptr, nullptr, 0));
+            (void)hipGraphDestroy(graph);
+            W.accept_key = key;
+        }
+    }
     const int min_level = 1, max_level = 8;
     const float levels = (float)(max_level - min_level + 1);
     auto fail_prob = [&](float cand_size, float n_pts, float drawn) {  // RansacShapeDetector.h:61-67 (reqSamples = 3)
@@ -748,14 +820,8 @@ void ransac_detect(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const R
             ++n_accepts;
             float4 two[2] = {bc.pl, bc.pos};
             HIP_TRY(hipMemcpyAsync(W.top.p, two, 32, hipMemcpyHostToDevice, ctx->stream));
-            hipLaunchKernelGGL(k_state_from_hyp, dim3(1), dim3(1), 0, ctx->stream, W.top.p, W.top.p + 1, W.st, W.plane_cur.p);
-            for (int k = 0; k < 4; ++k) {
-                global_weighted_score(ctx, W, cv, k, eps3, cos_t, bitmap_eps);
-                hipLaunchKernelGGL(k_fit_partial, dim3(FIT_BLOCKS), dim3(256), 0, ctx->stream, cv, W.idxS[k].p, W.cntS + k, W.part.p);
-                hipLaunchKernelGGL(k_fit_final, dim3(1), dim3(FIT_BLOCKS), 0, ctx->stream, W.part.p, W.cntS + k, W.st + std::min(k + 1, 3),
-                                   W.plane_cur.p + std::min(k + 1, 3), W.nsum + 3 * k, k < 3 ? 0 : 1);
-            }
-            hipLaunchKernelGGL(k_wscore_final, dim3(1), dim3(256), 0, ctx->stream, W.part_ws.p, W.st);
+            if (W.accept_exec) HIP_TRY(hipGraphLaunch(W.accept_exec, ctx->stream));
+            else enqueue_accept(ctx, W, cv, eps3, cos_t, bitmap_eps);
             n_full_passes += 4;
             PlaneState hst[4];
             uint32_t hcnt[4];

@@ -23,11 +23,13 @@ struct CompactScratch {
 void score_compact(plade_ctx *ctx, CompactScratch &s, const float *x, const float *y, const float *z,
                    const float *nx, const float *ny, const float *nz, const int32_t *assigned, uint32_t n,
                    const float4 *plane_dev, float eps, float cos_thresh, uint32_t *idx_out_dev,
-                   uint32_t *count_dev);
+                   uint32_t *count_dev, const uint32_t *skip_flag = nullptr);
 
 // Generic ordered compaction of a precomputed mask array (1 bit per point in groups of 4:
 // masks[i/4] bit (i%4)); used by the connected-component filter too.
 void compact_masks(plade_ctx *ctx, CompactScratch &s, uint32_t n, const uint32_t *values_or_null,
-                   uint32_t *idx_out_dev, uint32_t *count_dev);
+                   uint32_t *idx_out_dev, uint32_t *count_dev, const uint32_t *skip_flag = nullptr);
+// skip_flag (device, nullable): when *skip_flag != 0 the kernels return immediately and leave their
+// outputs untouched (used by the refit chain once it has converged).
 
 }  // namespace plade
