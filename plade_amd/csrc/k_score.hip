@@ -140,6 +140,39 @@ __global__ __launch_bounds__(TPB) void k_score_mark(const float *__restrict__ x,
     if (threadIdx.x == 0) block_counts[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
 }
 
+// the same for a batch of hypotheses: the tile is loaded once and tested against every job's plane
+constexpr int MARK_MAXJ = 16;
+__global__ __launch_bounds__(TPB) void k_score_mark_batch(const float *__restrict__ x, const float *__restrict__ y,
+                                                          const float *__restrict__ z, const float *__restrict__ nx,
+                                                          const float *__restrict__ ny, const float *__restrict__ nz,
+                                                          const int32_t *__restrict__ assigned, uint32_t n,
+                                                          const MarkJob *__restrict__ jobs, uint32_t nj, float eps, float cos_t) {
+    __shared__ uint32_t s_w[MARK_MAXJ][TPB / 64];
+    Tile t;
+    load_tile(t, x, y, z, nx, ny, nz, assigned, nullptr, n, blockIdx.x * TILE + threadIdx.x * PPT);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (uint32_t j = 0; j < nj; ++j) {
+        const MarkJob jb = jobs[j];
+        if (jb.skip && *jb.skip) continue;   // uniform
+        const float4 pl = jb.plane[0];
+        uint32_t m = 0, c = 0;
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            bool in = t.valid[k] && compatible(pl, t.px[k], t.py[k], t.pz[k], t.qx[k], t.qy[k], t.qz[k], eps, cos_t);
+            m |= (in ? 1u : 0u) << k;
+            c += (uint32_t)__popcll(__ballot(in));
+        }
+        jb.masks[blockIdx.x * TPB + threadIdx.x] = (uint8_t)m;
+        if (lane == 0) s_w[j][wave] = c;
+    }
+    __syncthreads();
+    if (threadIdx.x < nj) {
+        const MarkJob jb = jobs[threadIdx.x];
+        if (!(jb.skip && *jb.skip))
+            jb.block_counts[blockIdx.x] = s_w[threadIdx.x][0] + s_w[threadIdx.x][1] + s_w[threadIdx.x][2] + s_w[threadIdx.x][3];
+    }
+}
+
 // ordered compaction; every block derives its output offset from the preceding blocks' counts itself
 // (nb is ~1e3, the count array is L2 resident), which saves a dependent launch per compaction
 __global__ __launch_bounds__(TPB) void k_compact(const uint8_t *__restrict__ masks,
@@ -175,6 +208,59 @@ __global__ __launch_bounds__(TPB) void k_compact(const uint8_t *__restrict__ mas
             uint32_t i = first + k;
             out[off++] = values ? values[i] : i;
         }
+}
+
+// batched form of k_compact: job blockIdx.y
+__global__ __launch_bounds__(TPB) void k_compact_batch(const CompactJob *__restrict__ jobs, uint32_t nb) {
+    __shared__ uint32_t s_w[TPB / 64];
+    __shared__ uint32_t s_base[TPB / 64];
+    const CompactJob jb = jobs[blockIdx.y];
+    if (jb.skip && *jb.skip) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t pre = 0;
+    for (uint32_t b = threadIdx.x; b < blockIdx.x; b += TPB) pre += jb.block_counts[b];
+    for (int d = 32; d >= 1; d >>= 1) pre += __shfl_xor(pre, d, 64);
+    if (lane == 0) s_base[wave] = pre;
+    const uint32_t m = jb.masks[blockIdx.x * TPB + threadIdx.x];
+    const uint32_t c = __popc(m);
+    uint32_t incl = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t o = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += o;
+    }
+    if (lane == 63) s_w[wave] = incl;
+    __syncthreads();
+    const uint32_t base = s_base[0] + s_base[1] + s_base[2] + s_base[3];
+    uint32_t off = base + incl - c;
+    for (int w = 0; w < wave; ++w) off += s_w[w];
+    if (blockIdx.x == nb - 1 && threadIdx.x == TPB - 1) *jb.total = off + c;
+    const uint32_t first = blockIdx.x * TILE + threadIdx.x * PPT;
+#pragma unroll
+    for (int k = 0; k < PPT; ++k)
+        if (m & (1u << k)) {
+            uint32_t i = first + k;
+            jb.out[off++] = jb.values ? jb.values[i] : i;
+        }
+}
+
+void score_mark_batch(plade_ctx *ctx, const float *x, const float *y, const float *z, const float *nx, const float *ny,
+                      const float *nz, const int32_t *assigned, uint32_t n, const MarkJob *jobs_dev, uint32_t nj, float eps,
+                      float cos_thresh) {
+    PLADE_REQUIRE(nj <= (uint32_t)MARK_MAXJ, PLADE_EINVAL, "score_mark_batch: too many jobs");
+    const uint32_t nb = cdiv(n, TILE);
+    if (nb == 0 || nj == 0) return;
+    // algorithmic bytes: the cloud once (28 B/point) + one mask byte per 4 points per hypothesis
+    ctx->ev_begin("score_mark", 28.0 * n + 0.25 * n * nj);
+    hipLaunchKernelGGL(k_score_mark_batch, dim3(nb), dim3(TPB), 0, ctx->stream, x, y, z, nx, ny, nz, assigned, n, jobs_dev, nj,
+                       eps, cos_thresh);
+    ctx->ev_end();
+}
+
+void compact_batch(plade_ctx *ctx, uint32_t n, const CompactJob *jobs_dev, uint32_t nj) {
+    const uint32_t nb = cdiv(n, TILE);
+    if (nb == 0 || nj == 0) return;
+    hipLaunchKernelGGL(k_compact_batch, dim3(nb, nj), dim3(TPB), 0, ctx->stream, jobs_dev, nb);
 }
 
 void score_multi(plade_ctx *ctx, const float *x, const float *y, const float *z, const float *nx, const float *ny,

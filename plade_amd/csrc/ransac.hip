@@ -26,6 +26,7 @@
 #include "prims.h"
 #include "voxel.h"
 #include <algorithm>
+#include <memory>
 
 namespace plade {
 
@@ -51,13 +52,16 @@ __global__ void k_morton(const float *__restrict__ x, const float *__restrict__ 
     vals[i] = i;
 }
 
-__global__ void k_gather_cloud(const float *__restrict__ src, size_t spitch, const uint32_t *__restrict__ perm, uint32_t n,
+// Morton-order gather from the AoS copy (24 contiguous bytes per point: one or two 64 B sectors per
+// point instead of six scattered 4 B reads from the SoA planes)
+__global__ void k_gather_cloud(const float *__restrict__ aos, const uint32_t *__restrict__ perm, uint32_t n,
                                float *__restrict__ dst, size_t dpitch) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const uint32_t p = perm[i];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) dst[k * dpitch + i] = src[k * spitch + p];
+    const float2 *p = reinterpret_cast<const float2 *>(aos + 6 * (size_t)perm[i]);
+    const float2 a = p[0], b = p[1], c = p[2];
+    dst[i] = a.x; dst[dpitch + i] = a.y; dst[2 * dpitch + i] = b.x;
+    dst[3 * dpitch + i] = b.y; dst[4 * dpitch + i] = c.x; dst[5 * dpitch + i] = c.y;
 }
 
 __global__ void k_make_subset(const float *__restrict__ src, size_t spitch, uint32_t n, uint32_t stride, uint32_t n_sub,
@@ -183,6 +187,25 @@ struct PlaneState {
     uint32_t converged;              // refit chain: this slot's plane is bitwise the previous slot's
 };
 
+// Device-visible buffers of one acceptance chain.  Every kernel of the acceptance sequence takes the
+// table of chains and handles chain blockIdx.y (slot k of it): one launch serves the whole batch of
+// candidates that are accepted together.
+struct ChainDev {
+    PlaneState *st;        // 4 slots: candidate + 3 refits
+    uint32_t *cntS;        // per-slot result counts
+    float *nsum;           // 4 x 3
+    float4 *top;           // hypothesis (n, dist), position
+    float4 *plane_cur;     // 4
+    uint32_t *idxA, *cntA; // score(3 eps) list before the connected component
+    uint32_t *idxS[4];     // per-slot result lists
+    float2 *uv;
+    uint32_t *bidx, *label, *sizes;
+    uint8_t *bmp, *tmp;
+    uint8_t *masks2;       // connected-component selection masks
+    uint32_t *bc2;
+    double *part, *part_ws;
+};
+
 __device__ __forceinline__ void hcs_axes(const float *n, float *a0, float *a1) {
     float t[3];
     if (fabsf(n[0]) < 0.015625f && fabsf(n[1]) < 0.015625f) {  // (0,1,0) x n
@@ -207,9 +230,12 @@ __device__ __forceinline__ int ord_i(float f) { int v = __float_as_int(f); retur
 __device__ __forceinline__ float ord_f(int v) { return __int_as_float(v >= 0 ? v : v ^ 0x7fffffff); }
 
 // initialise the state from a hypothesis (n, dist) + position
-__global__ void k_state_from_hyp(const float4 *__restrict__ hyp, const float4 *__restrict__ pos, PlaneState *st,
-                                 float4 *plane_out) {
-    if (threadIdx.x || blockIdx.x) return;
+__global__ void k_state_from_hyp(const ChainDev *__restrict__ chains) {
+    if (threadIdx.x) return;
+    const ChainDev &C = chains[blockIdx.x];
+    const float4 *hyp = C.top, *pos = C.top + 1;
+    PlaneState *st = C.st;
+    float4 *plane_out = C.plane_cur;
     st->n[0] = hyp->x; st->n[1] = hyp->y; st->n[2] = hyp->z; st->dist = hyp->w;
     st->pos[0] = pos->x; st->pos[1] = pos->y; st->pos[2] = pos->z;
     hcs_axes(st->n, st->a0, st->a1);
@@ -222,10 +248,12 @@ __global__ void k_state_from_hyp(const float4 *__restrict__ hyp, const float4 *_
 
 // (u, v) parameters of the inliers + their bounding box (PlanePrimitiveShape::Parameters,
 // ransac/PlanePrimitiveShape.h:97-109; bbox BitmapPrimitiveShape.h:113-126)
-__global__ __launch_bounds__(256) void k_cc_params(CloudView c, const uint32_t *__restrict__ idx,
-                                                   const uint32_t *__restrict__ count, PlaneState *st,
-                                                   float2 *__restrict__ uv) {
+__global__ __launch_bounds__(256) void k_cc_params(CloudView c, const ChainDev *__restrict__ chains, int k) {
+    const ChainDev &C = chains[blockIdx.y];
+    PlaneState *st = C.st + k;
     if (st->converged) return;
+    const uint32_t *__restrict__ idx = C.idxA, *__restrict__ count = C.cntA;
+    float2 *__restrict__ uv = C.uv;
     const uint32_t m = *count;
     if (blockIdx.x * blockDim.x >= m) return;  // whole block beyond the list (uniform)
     __shared__ float s_lds[4][8];
@@ -263,10 +291,14 @@ __device__ __forceinline__ bool cc_dims(const PlaneState *st, uint32_t count, fl
 
 // BuildBitmap (BitmapPrimitiveShape.h:139-150) with InBitmap (PlanePrimitiveShape.cpp:193-199).
 // The bitmap is all-zero on entry (k_cc_label clears what it used).
-__global__ __launch_bounds__(256) void k_cc_raster(const float2 *__restrict__ uv, const uint32_t *__restrict__ count,
-                                                   PlaneState *st, float eps, uint32_t *__restrict__ bidx,
-                                                   uint8_t *__restrict__ bmp) {
+__global__ __launch_bounds__(256) void k_cc_raster(const ChainDev *__restrict__ chains, int k, float eps) {
+    const ChainDev &C = chains[blockIdx.y];
+    PlaneState *st = C.st + k;
     if (st->converged) return;
+    const float2 *__restrict__ uv = C.uv;
+    const uint32_t *__restrict__ count = C.cntA;
+    uint32_t *__restrict__ bidx = C.bidx;
+    uint8_t *__restrict__ bmp = C.bmp;
     const uint32_t m = *count;
     uint32_t ue, ve;
     const bool ok = cc_dims(st, m, eps, ue, ve);
@@ -288,9 +320,11 @@ __global__ __launch_bounds__(256) void k_cc_raster(const float2 *__restrict__ uv
 // up to CC_LDS_PIX pixels (every realistic plane at bitmap eps = 2 % of the scene) live in LDS.
 constexpr int CC_LDS_PIX = 8192;
 
-__global__ __launch_bounds__(1024) void k_cc_label(PlaneState *st, uint8_t *__restrict__ g_bmp, uint8_t *__restrict__ g_tmp,
-                                                   uint32_t *__restrict__ g_label, uint32_t *__restrict__ g_sizes,
-                                                   int do_filter) {
+__global__ __launch_bounds__(1024) void k_cc_label(const ChainDev *__restrict__ chains, int k, int do_filter) {
+    const ChainDev &C = chains[blockIdx.x];
+    PlaneState *st = C.st + k;
+    uint8_t *__restrict__ g_bmp = C.bmp, *__restrict__ g_tmp = C.tmp;
+    uint32_t *__restrict__ g_label = C.label, *__restrict__ g_sizes = C.sizes;
     __shared__ int s_changed;
     __shared__ unsigned long long s_best;
     __shared__ uint32_t s_label[CC_LDS_PIX];
@@ -378,11 +412,14 @@ __global__ __launch_bounds__(1024) void k_cc_label(PlaneState *st, uint8_t *__re
 }
 
 // mask layout of k_compact: one byte per lane covering 4 consecutive items, block counts per 1024
-__global__ __launch_bounds__(256) void k_cc_select(const uint32_t *__restrict__ bidx, const uint32_t *__restrict__ count,
-                                                   const PlaneState *st, const uint32_t *__restrict__ label,
-                                                   uint8_t *__restrict__ masks, uint32_t *__restrict__ block_counts) {
+__global__ __launch_bounds__(256) void k_cc_select(const ChainDev *__restrict__ chains, int k) {
     __shared__ uint32_t s_w[4];
+    const ChainDev &C = chains[blockIdx.y];
+    const PlaneState *st = C.st + k;
     if (st->converged) return;
+    const uint32_t *__restrict__ bidx = C.bidx, *__restrict__ count = C.cntA, *__restrict__ label = C.label;
+    uint8_t *__restrict__ masks = C.masks2;
+    uint32_t *__restrict__ block_counts = C.bc2;
     const uint32_t m = *count, best = st->best_root;
     const uint32_t base = blockIdx.x * 1024 + threadIdx.x * 4;
     uint32_t mk = 0, c = 0;
@@ -406,11 +443,13 @@ __global__ __launch_bounds__(256) void k_cc_select(const uint32_t *__restrict__ 
 // fp32 sequentially, which is the noisier of the two.
 constexpr int FIT_BLOCKS = 256;
 
-__global__ __launch_bounds__(256) void k_fit_partial(CloudView c, const uint32_t *__restrict__ idx,
-                                                     const uint32_t *__restrict__ count, double *__restrict__ part /* FIT_BLOCKS x 12 */,
-                                                     const PlaneState *__restrict__ st) {
+__global__ __launch_bounds__(256) void k_fit_partial(CloudView c, const ChainDev *__restrict__ chains, int k) {
     __shared__ double s[4][12];
+    const ChainDev &C = chains[blockIdx.y];
+    const PlaneState *st = C.st + k;
     if (st->converged) return;
+    const uint32_t *__restrict__ idx = C.idxS[k], *__restrict__ count = C.cntS + k;
+    double *__restrict__ part = C.part;   // FIT_BLOCKS x 12
     const uint32_t m = *count;
     double a[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
@@ -453,10 +492,16 @@ __device__ void jacobi3_d(double a[3][3], double d[3], double v[3][3]) {
 // `cur` is the state of the slot whose list was just reduced; when the new plane is bitwise equal to
 // cur's plane the chain has converged: every later slot would reproduce cur's results, so they are
 // flagged and their kernels return immediately.
-__global__ __launch_bounds__(FIT_BLOCKS) void k_fit_final(const double *__restrict__ part, const uint32_t *__restrict__ count,
-                                                          const PlaneState *cur, PlaneState *st, float4 *plane_out,
-                                                          float *__restrict__ nsum_out, int mode) {
+__global__ __launch_bounds__(FIT_BLOCKS) void k_fit_final(const ChainDev *__restrict__ chains, int k) {
     __shared__ double s_red[FIT_BLOCKS / 64][12];
+    const ChainDev &C = chains[blockIdx.x];
+    const int kn = k < 3 ? k + 1 : 3, mode = k < 3 ? 0 : 1;
+    const double *__restrict__ part = C.part;
+    const uint32_t *__restrict__ count = C.cntS + k;
+    const PlaneState *cur = C.st + k;
+    PlaneState *st = C.st + kn;
+    float4 *plane_out = C.plane_cur + kn;
+    float *__restrict__ nsum_out = C.nsum + 3 * k;
     if (cur->converged) {
         if (threadIdx.x == 0) {
             nsum_out[0] = nsum_out[-3]; nsum_out[1] = nsum_out[-2]; nsum_out[2] = nsum_out[-1];
@@ -502,11 +547,13 @@ __global__ __launch_bounds__(FIT_BLOCKS) void k_fit_final(const double *__restri
 }
 
 // Candidate::WeightedScore (ransac/Candidate.cpp:77-87) with weigh() (ScoreComputer.h:10-16)
-__global__ __launch_bounds__(256) void k_wscore_partial(CloudView c, const uint32_t *__restrict__ idx,
-                                                        const uint32_t *__restrict__ count, const PlaneState *st,
-                                                        float eps, double *__restrict__ part) {
+__global__ __launch_bounds__(256) void k_wscore_partial(CloudView c, const ChainDev *__restrict__ chains, int k, float eps) {
     __shared__ double s[4];
+    const ChainDev &C = chains[blockIdx.y];
+    const PlaneState *st = C.st + k;
     if (st->converged) return;
+    const uint32_t *__restrict__ idx = C.idxS[k], *__restrict__ count = C.cntS + k;
+    double *__restrict__ part = C.part_ws + (size_t)k * FIT_BLOCKS;
     const uint32_t m = *count;
     const float n0 = st->n[0], n1 = st->n[1], n2 = st->n[2], dist = st->dist;
     double acc = 0;
@@ -524,9 +571,12 @@ __global__ __launch_bounds__(256) void k_wscore_partial(CloudView c, const uint3
     if (threadIdx.x == 0) part[blockIdx.x] = (s[0] + s[1]) + (s[2] + s[3]);
 }
 // one launch sums the partials of all four slots
-__global__ __launch_bounds__(256) void k_wscore_final(const double *__restrict__ part /* 4 x FIT_BLOCKS */, PlaneState *st /* 4 */,
-                                                      uint32_t *__restrict__ cnt /* 4 */) {
+__global__ __launch_bounds__(256) void k_wscore_final(const ChainDev *__restrict__ chains) {
     __shared__ double s_ws[4];
+    const ChainDev &C = chains[blockIdx.x];
+    const double *__restrict__ part = C.part_ws;   // 4 x FIT_BLOCKS
+    PlaneState *st = C.st;
+    uint32_t *__restrict__ cnt = C.cntS;
     const int slot = threadIdx.x >> 6, lane = threadIdx.x & 63;  // one wave per slot
     double a = 0;
     for (int b = lane; b < FIT_BLOCKS; b += 64) a += part[slot * FIT_BLOCKS + b];
@@ -555,6 +605,23 @@ __global__ void k_fill_i32(int32_t *p, uint32_t n, int32_t v) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// One acceptance chain: everything the reference's per-candidate sequence touches.  Several candidates
+// whose supports provably cannot overlap are accepted together: every kernel of the sequence is
+// launched once for the whole batch (chain = blockIdx.y), the scoring pass reads the cloud once.
+struct Chain {
+    DBuf<float4> plane_cur;
+    CompactScratch cs, cs2;
+    DBuf<uint32_t> idxA, cntA;       // score(3 eps) list before the connected component
+    DBuf<uint32_t> idxS[4];          // per-slot result lists
+    DBuf<float2> uv;
+    DBuf<uint32_t> bidx, label, sizes;
+    DBuf<uint8_t> bmp, tmp;
+    DBuf<double> part, part_ws;
+};
+
+constexpr size_t ACCEPT_BYTES = 4 * sizeof(PlaneState) + 16 + 48;   // states, counts, normal sums
+constexpr size_t ACCEPT_STRIDE = (ACCEPT_BYTES + 63) & ~(size_t)63;
+
 struct RansacWork {
     CloudDev sorted;
     DBuf<uint32_t> codes, codes_in, vals_in, orig;
@@ -563,28 +630,32 @@ struct RansacWork {
     size_t sub_pitch = 0;
     DBuf<uint32_t> sub_index;
     uint32_t n_sub = 0;
-    DBuf<char> round_block, accept_block;   // contiguous: one D2H copy per host decision
+    DBuf<char> round_block;          // contiguous hypotheses / positions / counts: one D2H per round
     float4 *hyp = nullptr, *hyp_pos = nullptr;
     uint32_t *hyp_counts = nullptr, *misc = nullptr;
-    PlaneState *st = nullptr;       // 4 slots: candidate + 3 refits
-    uint32_t *cntS = nullptr;       // per-slot result counts
-    float *nsum = nullptr;          // 4 x 3
-    DBuf<float4> top, top_pos, plane_cur;
+    DBuf<float4> top;
     DBuf<uint32_t> top_counts;
-    CompactScratch cs, cs2;
-    DBuf<uint32_t> idxA, cntA;      // score(3 eps) list before the connected component
-    DBuf<uint32_t> idxS[4];         // per-slot result lists
-    DBuf<float2> uv;
-    DBuf<uint32_t> bidx, label, sizes;
-    DBuf<uint8_t> bmp, tmp;
-    DBuf<double> part, part_ws;
     DBuf<int32_t> out_idx;
     HBuf<char> pinned;
-    // the acceptance sequence (~40 launches, all arguments in device memory) as a hipGraph: replayed
-    // once per accepted plane instead of re-issuing the launches from the host
-    hipGraphExec_t accept_exec = nullptr;
-    std::vector<uint64_t> accept_key;
-    ~RansacWork() { if (accept_exec) (void)hipGraphExecDestroy(accept_exec); }
+    // acceptance chains
+    std::vector<std::unique_ptr<Chain>> chains;
+    DBuf<char> accept_block;         // B x ACCEPT_STRIDE: one D2H copy per batch
+    DBuf<float4> cand_in;            // B x (hypothesis, position): one H2D copy per batch
+    DBuf<ChainDev> chain_tab;
+    DBuf<MarkJob> mark_jobs;         // [slot][chain]
+    DBuf<CompactJob> compact_jobs;   // [slot][A|S][chain]
+    HBuf<char> pinned_accept;
+    uint32_t B = 0;
+    std::vector<uint64_t> tab_key;
+    // the acceptance sequence (~40 launches, all arguments in device memory) as hipGraphs, one per
+    // batch size: replayed instead of re-issuing the launches from the host
+    std::vector<hipGraphExec_t> exec;
+    std::vector<uint64_t> exec_key;
+    void drop_graphs() {
+        for (hipGraphExec_t e : exec) if (e) (void)hipGraphExecDestroy(e);
+        exec.clear();
+    }
+    ~RansacWork() { drop_graphs(); }
 };
 
 RansacWork *ransac_work_create() { return new RansacWork; }
@@ -598,37 +669,116 @@ struct Accepted {
     uint32_t offset;   // into out_idx
 };
 
-// GlobalWeightedScore of slot k (Candidate.h:293-302): score(3 eps) -> ConnectedComponent -> weighted
-// score.  Plane from plane_cur[k] / st[k]; results in idxS[k], cntS[k], part_ws[k].
-void global_weighted_score(plade_ctx *ctx, RansacWork &W, const CloudView &cv, int k, float eps3, float cos_t,
-                           float bitmap_eps) {
+// The whole per-candidate sequence of RansacShapeDetector.cpp:618-656 for `nc` chains x four slots, no
+// host round trip: slot 0 = the candidate (GlobalScore(3 eps) + ConnectedComponent; its clone's first
+// GlobalWeightedScore is the same computation), slot k = k-th LS refit of slot k-1's points.  Per slot:
+// GlobalWeightedScore (Candidate.h:293-302) = score(3 eps) -> ConnectedComponent -> weighted score,
+// then the LS fit of the result list.
+void enqueue_accept(plade_ctx *ctx, RansacWork &W, const CloudView &cv, uint32_t nc, float eps3, float cos_t, float bitmap_eps) {
     const CloudDev &c = W.sorted;
-    PlaneState *st = W.st + k;
-    const uint32_t *skip = &st->converged;
-    score_compact(ctx, W.cs, c.x(), c.y(), c.z(), c.nx(), c.ny(), c.nz(), W.assigned.p, c.n, W.plane_cur.p + k, eps3, cos_t,
-                  W.idxA.p, W.cntA.p, skip);
-    const uint32_t nb = cdiv(c.n, 256);
-    hipLaunchKernelGGL(k_cc_params, dim3(std::min(nb, 256u)), dim3(256), 0, ctx->stream, cv, W.idxA.p, W.cntA.p, st, W.uv.p);
-    hipLaunchKernelGGL(k_cc_raster, dim3(nb), dim3(256), 0, ctx->stream, W.uv.p, W.cntA.p, st, bitmap_eps, W.bidx.p, W.bmp.p);
-    hipLaunchKernelGGL(k_cc_label, dim3(1), dim3(1024), 0, ctx->stream, st, W.bmp.p, W.tmp.p, W.label.p, W.sizes.p, 1);
-    const uint32_t nb4 = cdiv(c.n, 1024);
-    hipLaunchKernelGGL(k_cc_select, dim3(nb4), dim3(256), 0, ctx->stream, W.bidx.p, W.cntA.p, st, W.label.p, W.cs2.masks.p,
-                       W.cs2.block_counts.p);
-    compact_masks(ctx, W.cs2, c.n, W.idxA.p, W.idxS[k].p, W.cntS + k, skip);
-    hipLaunchKernelGGL(k_wscore_partial, dim3(FIT_BLOCKS), dim3(256), 0, ctx->stream, cv, W.idxS[k].p, W.cntS + k, st, eps3,
-                       W.part_ws.p + (size_t)k * FIT_BLOCKS);
+    hipStream_t st = ctx->stream;
+    const ChainDev *tab = W.chain_tab.p;
+    const uint32_t B = W.B;
+    const uint32_t nb = cdiv(c.n, 256), nb4 = cdiv(c.n, 1024);
+    hipLaunchKernelGGL(k_state_from_hyp, dim3(nc), dim3(64), 0, st, tab);
+    for (int k = 0; k < 4; ++k) {
+        score_mark_batch(ctx, c.x(), c.y(), c.z(), c.nx(), c.ny(), c.nz(), W.assigned.p, c.n, W.mark_jobs.p + (size_t)k * B, nc, eps3,
+                         cos_t);
+        compact_batch(ctx, c.n, W.compact_jobs.p + (size_t)(2 * k) * B, nc);
+        hipLaunchKernelGGL(k_cc_params, dim3(std::min(nb, 256u), nc), dim3(256), 0, st, cv, tab, k);
+        hipLaunchKernelGGL(k_cc_raster, dim3(nb, nc), dim3(256), 0, st, tab, k, bitmap_eps);
+        hipLaunchKernelGGL(k_cc_label, dim3(nc), dim3(1024), 0, st, tab, k, 1);
+        hipLaunchKernelGGL(k_cc_select, dim3(nb4, nc), dim3(256), 0, st, tab, k);
+        compact_batch(ctx, c.n, W.compact_jobs.p + (size_t)(2 * k + 1) * B, nc);
+        hipLaunchKernelGGL(k_wscore_partial, dim3(FIT_BLOCKS, nc), dim3(256), 0, st, cv, tab, k, eps3);
+        hipLaunchKernelGGL(k_fit_partial, dim3(FIT_BLOCKS, nc), dim3(256), 0, st, cv, tab, k);
+        hipLaunchKernelGGL(k_fit_final, dim3(nc), dim3(FIT_BLOCKS), 0, st, tab, k);
+    }
+    hipLaunchKernelGGL(k_wscore_final, dim3(nc), dim3(256), 0, st, tab);
 }
 
-void enqueue_accept(plade_ctx *ctx, RansacWork &W, const CloudView &cv, float eps3, float cos_t, float bitmap_eps) {
-    hipLaunchKernelGGL(k_state_from_hyp, dim3(1), dim3(1), 0, ctx->stream, W.top.p, W.top.p + 1, W.st, W.plane_cur.p);
-    for (int k = 0; k < 4; ++k) {
-        global_weighted_score(ctx, W, cv, k, eps3, cos_t, bitmap_eps);
-        hipLaunchKernelGGL(k_fit_partial, dim3(FIT_BLOCKS), dim3(256), 0, ctx->stream, cv, W.idxS[k].p, W.cntS + k, W.part.p,
-                           W.st + k);
-        hipLaunchKernelGGL(k_fit_final, dim3(1), dim3(FIT_BLOCKS), 0, ctx->stream, W.part.p, W.cntS + k, W.st + k,
-                           W.st + std::min(k + 1, 3), W.plane_cur.p + std::min(k + 1, 3), W.nsum + 3 * k, k < 3 ? 0 : 1);
+void chains_prepare(plade_ctx *ctx, RansacWork &W, uint32_t B, uint32_t n, float eps3, float cos_t, float bitmap_eps) {
+    W.B = B;
+    while (W.chains.size() < B) W.chains.emplace_back(new Chain);
+    char *ab = W.accept_block.ensure(B * ACCEPT_STRIDE);
+    W.cand_in.ensure(2 * B);
+    W.pinned_accept.ensure(B * ACCEPT_STRIDE + 64);
+    std::vector<ChainDev> tab(B);
+    std::vector<MarkJob> mj(4 * (size_t)B);
+    std::vector<CompactJob> cj(8 * (size_t)B);
+    const uint32_t nb4 = cdiv(n, 1024);
+    bool fresh_bitmap = false;
+    for (uint32_t b = 0; b < B; ++b) {
+        Chain &C = *W.chains[b];
+        ChainDev &D = tab[b];
+        char *base = ab + b * ACCEPT_STRIDE;
+        D.st = reinterpret_cast<PlaneState *>(base);
+        D.cntS = reinterpret_cast<uint32_t *>(base + 4 * sizeof(PlaneState));
+        D.nsum = reinterpret_cast<float *>(base + 4 * sizeof(PlaneState) + 16);
+        D.top = W.cand_in.p + 2 * b;
+        D.plane_cur = C.plane_cur.ensure(4);
+        D.idxA = C.idxA.ensure((size_t)n + 4);
+        D.cntA = C.cntA.ensure(8);
+        for (int k = 0; k < 4; ++k) D.idxS[k] = C.idxS[k].ensure((size_t)n + 4);
+        D.uv = C.uv.ensure((size_t)n + 4);
+        D.bidx = C.bidx.ensure((size_t)n + 4);
+        fresh_bitmap = fresh_bitmap || C.bmp.cap < CC_MAXPIX;
+        const bool fresh = C.bmp.cap < CC_MAXPIX;
+        D.label = C.label.ensure(CC_MAXPIX); D.sizes = C.sizes.ensure(CC_MAXPIX);
+        D.bmp = C.bmp.ensure(CC_MAXPIX); D.tmp = C.tmp.ensure(CC_MAXPIX);
+        if (fresh) HIP_TRY(hipMemsetAsync(C.bmp.p, 0, C.bmp.cap, ctx->stream));
+        D.part = C.part.ensure(FIT_BLOCKS * 12 + 16);
+        D.part_ws = C.part_ws.ensure(4 * FIT_BLOCKS + 16);
+        C.cs.masks.ensure((size_t)nb4 * 256 + 16); C.cs.block_counts.ensure(nb4 + 4);
+        D.masks2 = C.cs2.masks.ensure((size_t)nb4 * 256 + 16);
+        D.bc2 = C.cs2.block_counts.ensure(nb4 + 4);
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t *skip = &D.st[k].converged;
+            mj[(size_t)k * B + b] = MarkJob{D.plane_cur + k, C.cs.masks.p, C.cs.block_counts.p, skip};
+            cj[(size_t)(2 * k) * B + b] = CompactJob{C.cs.masks.p, C.cs.block_counts.p, nullptr, D.idxA, D.cntA, skip};
+            cj[(size_t)(2 * k + 1) * B + b] = CompactJob{D.masks2, D.bc2, D.idxA, D.idxS[k], D.cntS + k, skip};
+        }
     }
-    hipLaunchKernelGGL(k_wscore_final, dim3(1), dim3(256), 0, ctx->stream, W.part_ws.p, W.st, W.cntS);
+    // (re)upload the tables only when a pointer moved
+    std::vector<uint64_t> key;
+    key.reserve(tab.size() * sizeof(ChainDev) / 8 + 8);
+    for (const ChainDev &D : tab) {
+        const uint64_t *w = reinterpret_cast<const uint64_t *>(&D);
+        key.insert(key.end(), w, w + sizeof(ChainDev) / 8);
+    }
+    key.push_back((uint64_t)W.chains[0]->cs.masks.p);
+    W.chain_tab.ensure(B); W.mark_jobs.ensure(4 * (size_t)B); W.compact_jobs.ensure(8 * (size_t)B);
+    key.push_back((uint64_t)W.chain_tab.p); key.push_back((uint64_t)W.mark_jobs.p); key.push_back((uint64_t)W.compact_jobs.p);
+    if (key != W.tab_key) {
+        HIP_TRY(hipMemcpyAsync(W.chain_tab.p, tab.data(), B * sizeof(ChainDev), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(W.mark_jobs.p, mj.data(), mj.size() * sizeof(MarkJob), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(W.compact_jobs.p, cj.data(), cj.size() * sizeof(CompactJob), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        W.tab_key = key;
+        W.drop_graphs();
+    }
+    // graphs are keyed on everything baked into the captured launches
+    auto bits = [](float f) { uint32_t u; memcpy(&u, &f, 4); return (uint64_t)u; };
+    std::vector<uint64_t> gkey = {n, B, bits(eps3), bits(cos_t), bits(bitmap_eps), (uint64_t)W.sorted.soa.p, (uint64_t)W.assigned.p,
+                                  (uint64_t)ctx->stream};
+    if (gkey != W.exec_key || ctx->profiling() || getenv("PLADE_NO_GRAPH")) W.drop_graphs();
+    W.exec_key = gkey;
+    (void)fresh_bitmap;
+}
+
+// graph for a batch of nc chains (captured lazily)
+hipGraphExec_t accept_graph(plade_ctx *ctx, RansacWork &W, const CloudView &cv, uint32_t nc, float eps3, float cos_t, float bitmap_eps) {
+    if (ctx->profiling() || getenv("PLADE_NO_GRAPH")) return nullptr;
+    if (W.exec.size() <= nc) W.exec.resize(nc + 1, nullptr);
+    if (!W.exec[nc]) {
+        hipGraph_t graph = nullptr;
+        HIP_TRY(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+        enqueue_accept(ctx, W, cv, nc, eps3, cos_t, bitmap_eps);
+        HIP_TRY(hipStreamEndCapture(ctx->stream, &graph));
+        HIP_TRY(hipGraphInstantiate(&W.exec[nc], graph, nullptr, nullptr, 0));
+        (void)hipGraphDestroy(graph);
+    }
+    return W.exec[nc];
 }
 
 inline bool same_plane(const float4 &a, const float4 &b, float eps) {
@@ -636,6 +786,29 @@ inline bool same_plane(const float4 &a, const float4 &b, float eps) {
     if (std::fabs(c) < 0.995f) return false;
     const float db = c >= 0 ? b.w : -b.w;
     return std::fabs(a.w - db) < 2 * eps;
+}
+
+// Can a point be an inlier (|dist| < 3 eps AND |n.n_p| >= cos_t) of both planes?  Provably not when
+//  (a) the normals are far apart: n_p within acos(cos_t) of both +-n_a and +-n_b needs
+//      angle(n_a, n_b) <= 2 acos(cos_t) (or its supplement); a 5 degree margin covers the refits; or
+//  (b) the planes are nearly parallel and, everywhere inside the cloud's bounding box, more than
+//      8 eps apart (the two 3 eps bands plus refit drift cannot meet): the difference of the signed
+//      distances is linear in p, so constant sign at the 8 corners + min |.| at a corner decide it.
+// Anything else counts as a conflict and the two candidates are accepted one after the other.
+inline bool conflict_free(const float4 &a, const float4 &b, float eps, float cos_t, const float *bbmin, const float *bbmax) {
+    const float c = std::fabs(a.x * b.x + a.y * b.y + a.z * b.z);
+    const float two_theta = 2.f * std::acos(std::min(1.f, cos_t)) + 0.0873f;
+    if (two_theta < 1.5707f && c < std::cos(two_theta)) return true;
+    if (c < 0.97f) return false;
+    const float s = (a.x * b.x + a.y * b.y + a.z * b.z) >= 0 ? 1.f : -1.f;
+    float mn = INFINITY, mx = -INFINITY;
+    for (int k = 0; k < 8; ++k) {
+        const float px = (k & 1) ? bbmax[0] : bbmin[0], py = (k & 2) ? bbmax[1] : bbmin[1], pz = (k & 4) ? bbmax[2] : bbmin[2];
+        const float da = a.x * px + a.y * py + a.z * pz - a.w, db = s * (b.x * px + b.y * py + b.z * pz) - s * b.w;
+        mn = std::min(mn, da - db);
+        mx = std::max(mx, da - db);
+    }
+    return (mn > 8 * eps) || (mx < -8 * eps);
 }
 
 }  // namespace
@@ -662,8 +835,7 @@ void ransac_detect(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const R
     W.sorted.n = n;
     W.sorted.pitch = cloud.pitch;
     W.sorted.soa.ensure(6 * cloud.pitch + 4);
-    hipLaunchKernelGGL(k_gather_cloud, dim3(nb), dim3(256), 0, ctx->stream, cloud.soa.p, cloud.pitch, W.orig.p, n, W.sorted.soa.p,
-                       W.sorted.pitch);
+    hipLaunchKernelGGL(k_gather_cloud, dim3(nb), dim3(256), 0, ctx->stream, cloud.aos.p, W.orig.p, n, W.sorted.soa.p, W.sorted.pitch);
     const CloudDev &c = W.sorted;
     CloudView cv{c.x(), c.y(), c.z(), c.nx(), c.ny(), c.nz(), n};
     W.assigned.ensure((size_t)n + 4);
@@ -686,61 +858,22 @@ void ransac_detect(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const R
     W.hyp_pos = W.hyp + H;
     W.hyp_counts = reinterpret_cast<uint32_t *>(W.hyp_pos + H);
     W.misc = W.hyp_counts + H;
-    const size_t accept_bytes = 4 * sizeof(PlaneState) + 16 + 48;
-    char *ab = W.accept_block.ensure(accept_bytes + 64);
-    W.st = reinterpret_cast<PlaneState *>(ab);
-    W.cntS = reinterpret_cast<uint32_t *>(ab + 4 * sizeof(PlaneState));
-    W.nsum = reinterpret_cast<float *>(ab + 4 * sizeof(PlaneState) + 16);
-    W.top.ensure(TOP); W.top_pos.ensure(TOP); W.top_counts.ensure(TOP);
-    W.plane_cur.ensure(4);
-    W.idxA.ensure((size_t)n + 4); W.cntA.ensure(8);
-    char *pin = W.pinned.ensure(round_bytes + accept_bytes + 256);
-    for (int k = 0; k < 4; ++k) W.idxS[k].ensure((size_t)n + 4);
-    W.uv.ensure((size_t)n + 4); W.bidx.ensure((size_t)n + 4);
-    const bool fresh_bitmap = W.bmp.cap < CC_MAXPIX;
-    W.label.ensure(CC_MAXPIX); W.sizes.ensure(CC_MAXPIX); W.bmp.ensure(CC_MAXPIX); W.tmp.ensure(CC_MAXPIX);
-    if (fresh_bitmap) HIP_TRY(hipMemsetAsync(W.bmp.p, 0, W.bmp.cap, ctx->stream));
-    W.part.ensure(FIT_BLOCKS * 12 + 16); W.part_ws.ensure(4 * FIT_BLOCKS + 16);
+    W.top.ensure(TOP); W.top_counts.ensure(TOP);
+    char *pin = W.pinned.ensure(round_bytes + 256);
     W.out_idx.ensure((size_t)n + 4);
-    W.cs2.masks.ensure((size_t)cdiv(n, 1024) * 256);
-    W.cs2.block_counts.ensure(cdiv(n, 1024));
+    // ---- acceptance chains ------------------------------------------------------------------------
+    uint32_t B = 8;
+    if (const char *e = getenv("PLADE_RANSAC_CHAINS")) B = (uint32_t)std::max(1, std::min(16, atoi(e)));
+    chains_prepare(ctx, W, B, n, eps3, cos_t, bitmap_eps);
 
-    // ---- acceptance sequence as a graph (skipped when per-kernel event timing is on) -------------------
-    {
-        auto bits = [](float f) { uint32_t u; memcpy(&u, &f, 4); return (uint64_t)u; };
-        std::vector<uint64_t> key = {n, bits(eps3), bits(cos_t), bits(bitmap_eps), (uint64_t)c.soa.p, (uint64_t)W.assigned.p,
-                                     (uint64_t)W.idxA.p, (uint64_t)W.idxS[0].p, (uint64_t)W.idxS[1].p, (uint64_t)W.idxS[2].p,
-                                     (uint64_t)W.idxS[3].p, (uint64_t)W.uv.p, (uint64_t)W.bidx.p, (uint64_t)W.bmp.p, (uint64_t)W.label.p,
-                                     (uint64_t)W.st, (uint64_t)W.top.p, (uint64_t)W.plane_cur.p, (uint64_t)W.part.p, (uint64_t)W.part_ws.p,
-                                     (uint64_t)W.cs.masks.p, (uint64_t)W.cs2.masks.p, (uint64_t)ctx->stream};
-        W.cs.masks.ensure((size_t)cdiv(n, 1024) * 256);
-        W.cs.block_counts.ensure(cdiv(n, 1024));
-        key.push_back((uint64_t)W.cs.masks.p); key.push_back((uint64_t)W.cs.block_counts.p); key.push_back((uint64_t)W.cs2.block_counts.p);
-        if (ctx->profiling() || getenv("PLADE_NO_GRAPH")) {
-            if (W.accept_exec) { (void)hipGraphExecDestroy(W.accept_exec); W.accept_exec = nullptr; W.accept_key.clear(); }
-        } else if (!W.accept_exec || key != W.accept_key) {
-            if (W.accept_exec) { (void)hipGraphExecDestroy(W.accept_exec); W.accept_exec = nullptr; }
-            HIP_TRY(hipStreamSynchronize(ctx->stream));
-            hipGraph_t graph = nullptr;
-            HIP_TRY(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
-            enqueue_accept(ctx, W, cv, eps3, cos_t, bitmap_eps);
-            HIP_TRY(hipStreamEndCapture(ctx->stream, &graph));
-            HIP_TRY(hipGraphInstantiate(&W.accept_exec, graph, nullptr, nullptr, 0));
-            (void)hipGraphDestroy(graph);
-            W.accept_key = key;
-        }
-    }
     const int min_level = 1, max_level = 8;
     const float levels = (float)(max_level - min_level + 1);
     auto fail_prob = [&](float cand_size, float n_pts, float drawn) {  // RansacShapeDetector.h:61-67 (reqSamples = 3)
         return std::min(std::pow(1.f - cand_size / (n_pts * levels * 4.f), drawn), 1.f);
     };
 
-    Clock::time_point t_setup = Clock::now();
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    ctx->stats.add("ransac_t_setup", secs_since(t_setup));
     double t_sample = 0, t_rescore = 0, t_accept = 0;
-    uint32_t n_rounds = 0, n_accepts = 0;
+    uint32_t n_rounds = 0, n_accepts = 0, n_batches = 0;
     std::vector<Accepted> accepted;
     std::vector<float4> h_hyp(H), h_pos(H);
     std::vector<uint32_t> h_counts(H);
@@ -751,6 +884,7 @@ void ransac_detect(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const R
     uint32_t out_off = 0;
     uint32_t n_full_passes = 0;
     const uint32_t max_rounds = 4000;
+    const bool dbg = getenv("PLADE_DEBUG_RANSAC") != nullptr;
     for (uint32_t round = 0; round < max_rounds; ++round) {
         if (n_remaining < rp.min_support) break;
         if (round > 0 && fail_prob((float)rp.min_support, (float)n_remaining, drawn) <= rp.overlook_p && pool.empty()) break;
@@ -774,7 +908,7 @@ void ransac_detect(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const R
         uint32_t valid = 0;
         for (uint32_t i = 0; i < H; ++i) valid += h_pos[i].w != 0.f;   // w: 0 no samples, 1 verified plane, 2 drawn but rejected
         drawn += (float)valid;
-        if (getenv("PLADE_DEBUG_RANSAC"))
+        if (dbg)
             fprintf(stderr, "[ransac] round %u valid %u drawn %.0f n_rem %u accepted %zu failprob %.4g\n", round, valid, drawn,
                     n_remaining, accepted.size(), fail_prob((float)rp.min_support, (float)n_remaining, drawn));
         // leaders of this batch by estimated support, one representative per distinct plane
@@ -792,7 +926,7 @@ void ransac_detect(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const R
             for (const Cand &pc : pool) if (same_plane(pc.pl, h_hyp[i], eps)) { dup = true; break; }
             if (!dup) pool.push_back(Cand{h_hyp[i], h_pos[i], 0});
         }
-        // ---- harvest: re-score the pool on all unassigned points, accept the best, repeat ---------
+        // ---- harvest: re-score the pool on all unassigned points, accept the leaders, repeat ----------
         while (!pool.empty()) {
             Clock::time_point t_r0 = Clock::now();
             const uint32_t np = (uint32_t)pool.size();
@@ -806,82 +940,95 @@ void ransac_detect(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const R
             HIP_TRY(hipMemcpyAsync(cnts.data(), W.top_counts.p, np * 4, hipMemcpyDeviceToHost, ctx->stream));
             HIP_TRY(hipStreamSynchronize(ctx->stream));
             t_rescore += secs_since(t_r0);
-            uint32_t best = 0;
-            for (uint32_t i = 0; i < np; ++i) { pool[i].count = cnts[i]; if (cnts[i] > cnts[best]) best = i; }
+            for (uint32_t i = 0; i < np; ++i) pool[i].count = cnts[i];
             // candidates that can no longer reach min_support are dropped (RansacShapeDetector.cpp:826-832)
-            if (pool[best].count < rp.min_support) { pool.clear(); break; }
-            const Cand bc = pool[best];
-            pool.erase(pool.begin() + best);
             pool.erase(std::remove_if(pool.begin(), pool.end(), [&](const Cand &a) { return a.count < rp.min_support; }), pool.end());
-            // ---- acceptance sequence (RansacShapeDetector.cpp:618-656), all four slots enqueued ---------
-            // slot 0 = the candidate (GlobalScore(3 eps) + ConnectedComponent; its clone's first
-            // GlobalWeightedScore is the same computation), slot k = k-th LS refit of slot k-1's points.
+            if (pool.empty()) break;
+            std::stable_sort(pool.begin(), pool.end(), [](const Cand &a, const Cand &b) { return a.count > b.count; });
+            // the best candidate plus every further one whose support provably cannot touch the supports
+            // already in the batch: accepting them concurrently equals accepting them one by one
+            std::vector<uint32_t> batch{0};
+            for (uint32_t i = 1; i < pool.size() && batch.size() < B; ++i) {
+                bool ok = true;
+                for (uint32_t j : batch) ok = ok && conflict_free(pool[i].pl, pool[j].pl, eps, cos_t, cloud.bbmin, cloud.bbmax);
+                if (ok) batch.push_back(i);
+            }
             Clock::time_point t_a0 = Clock::now();
-            ++n_accepts;
-            float4 two[2] = {bc.pl, bc.pos};
-            HIP_TRY(hipMemcpyAsync(W.top.p, two, 32, hipMemcpyHostToDevice, ctx->stream));
-            if (W.accept_exec) HIP_TRY(hipGraphLaunch(W.accept_exec, ctx->stream));
-            else enqueue_accept(ctx, W, cv, eps3, cos_t, bitmap_eps);
-            n_full_passes += 4;
-            PlaneState hst[4];
-            uint32_t hcnt[4];
-            float hns[12];
-            HIP_TRY(hipMemcpyAsync(pin, ab, accept_bytes, hipMemcpyDeviceToHost, ctx->stream));
+            ++n_batches;
+            const uint32_t nc = (uint32_t)batch.size();
+            std::vector<float4> h_in(2 * nc);
+            for (uint32_t b = 0; b < nc; ++b) { h_in[2 * b] = pool[batch[b]].pl; h_in[2 * b + 1] = pool[batch[b]].pos; }
+            HIP_TRY(hipMemcpyAsync(W.cand_in.p, h_in.data(), 32 * nc, hipMemcpyHostToDevice, ctx->stream));
+            if (hipGraphExec_t g = accept_graph(ctx, W, cv, nc, eps3, cos_t, bitmap_eps)) HIP_TRY(hipGraphLaunch(g, ctx->stream));
+            else enqueue_accept(ctx, W, cv, nc, eps3, cos_t, bitmap_eps);
+            HIP_TRY(hipMemcpyAsync(W.pinned_accept.p, W.accept_block.p, nc * ACCEPT_STRIDE, hipMemcpyDeviceToHost, ctx->stream));
             HIP_TRY(hipStreamSynchronize(ctx->stream));
-            memcpy(hst, pin, 4 * sizeof(PlaneState));
-            memcpy(hcnt, pin + 4 * sizeof(PlaneState), 16);
-            memcpy(hns, pin + 4 * sizeof(PlaneState) + 16, 48);
             HIP_TRY(hipGetLastError());
+            n_full_passes += 4 * (uint32_t)batch.size();
             t_accept += secs_since(t_a0);
-            PLADE_REQUIRE(hst[0].err != 1, PLADE_ELIMIT, "plane extraction: connected-component bitmap too large");
-            // replay of the reference's refit loop on the four results
-            int final_slot = 0;
-            {
-                double newScore = hst[0].wscore;
-                for (int fittingIter = 1; fittingIter <= 3; ++fittingIter) {
-                    const double oldScore = newScore;
-                    if (hcnt[fittingIter - 1] < 3 || hst[fittingIter].err) break;   // LSFit impossible
-                    newScore = hst[fittingIter].wscore;
-                    const uint32_t newSize = hcnt[fittingIter];
-                    if (newScore > oldScore && newSize > rp.min_support) final_slot = fittingIter;  // clone.Clone(&candidates.back())
-                    if (!(newScore > oldScore)) break;
+            for (size_t b = 0; b < batch.size(); ++b) {
+                Chain &C = *W.chains[b];
+                const Cand &bc = pool[batch[b]];
+                ++n_accepts;
+                PlaneState hst[4];
+                uint32_t hcnt[4];
+                float hns[12];
+                const char *hb = W.pinned_accept.p + b * ACCEPT_STRIDE;
+                memcpy(hst, hb, 4 * sizeof(PlaneState));
+                memcpy(hcnt, hb + 4 * sizeof(PlaneState), 16);
+                memcpy(hns, hb + 4 * sizeof(PlaneState) + 16, 48);
+                PLADE_REQUIRE(hst[0].err != 1, PLADE_ELIMIT, "plane extraction: connected-component bitmap too large");
+                // replay of the reference's refit loop on the four results
+                int final_slot = 0;
+                {
+                    double newScore = hst[0].wscore;
+                    for (int fittingIter = 1; fittingIter <= 3; ++fittingIter) {
+                        const double oldScore = newScore;
+                        if (hcnt[fittingIter - 1] < 3 || hst[fittingIter].err) break;   // LSFit impossible
+                        newScore = hst[fittingIter].wscore;
+                        const uint32_t newSize = hcnt[fittingIter];
+                        if (newScore > oldScore && newSize > rp.min_support) final_slot = fittingIter;  // clone.Clone(&candidates.back())
+                        if (!(newScore > oldScore)) break;
+                    }
                 }
-            }
-            const PlaneState &cand_state = hst[final_slot];
-            const uint32_t cand_size = hcnt[final_slot];
-            if (getenv("PLADE_DEBUG_RANSAC"))
-                fprintf(stderr, "[ransac]   accept: eps-count %u sizes %u %u %u %u wscore %.1f %.1f %.1f %.1f final slot %d bitmap %ux%u\n",
-                        bc.count, hcnt[0], hcnt[1], hcnt[2], hcnt[3], hst[0].wscore, hst[1].wscore, hst[2].wscore, hst[3].wscore,
-                        final_slot, hst[final_slot].ue, hst[final_slot].ve);
-            uint32_t *cand_idx = W.idxS[final_slot].p;
-            // ---- remove the points (RansacShapeDetector.cpp:666-675) ---------------------------------
-            if (cand_size == 0) continue;
-            const int32_t shape_id = (int32_t)accepted.size();
-            hipLaunchKernelGGL(k_assign, dim3(cdiv(cand_size, 256)), dim3(256), 0, ctx->stream, cand_idx, cand_size, shape_id, W.assigned.p);
-            drawn = std::pow(1.f - (cand_size / float(n_remaining)), 3.f) * drawn;
-            n_remaining -= cand_size;
-            // plane_extraction.cpp:134-149: shapes below min_support are skipped, d = -n.p with n re-normalised
-            Accepted a{};
-            a.support = 0; a.offset = out_off;
-            if (cand_size >= rp.min_support) {
-                float nn[3] = {cand_state.n[0], cand_state.n[1], cand_state.n[2]};
-                float l = nn[0] * nn[0];
-                l += nn[1] * nn[1];
-                l += nn[2] * nn[2];
-                l = std::sqrt(l);
-                if (l > 0) { nn[0] /= l; nn[1] /= l; nn[2] /= l; }
-                float d = -(nn[0] * cand_state.pos[0] + nn[1] * cand_state.pos[1] + nn[2] * cand_state.pos[2]);
-                if (rp.orient_normals) {  // mean inlier normal (the intent of plane_extraction.cpp:43-58)
-                    const float *ns = hns + 3 * final_slot;
-                    if (ns[0] * nn[0] + ns[1] * nn[1] + ns[2] * nn[2] < 0) { nn[0] = -nn[0]; nn[1] = -nn[1]; nn[2] = -nn[2]; d = -d; }
+                const PlaneState &cand_state = hst[final_slot];
+                const uint32_t cand_size = hcnt[final_slot];
+                uint32_t *cand_idx = C.idxS[final_slot].p;
+                if (dbg)
+                    fprintf(stderr, "[ransac]   accept[%zu/%zu]: eps-count %u sizes %u %u %u %u wscore %.1f %.1f %.1f %.1f final slot %d bitmap %ux%u\n",
+                            b, batch.size(), bc.count, hcnt[0], hcnt[1], hcnt[2], hcnt[3], hst[0].wscore, hst[1].wscore, hst[2].wscore,
+                            hst[3].wscore, final_slot, hst[final_slot].ue, hst[final_slot].ve);
+                // ---- remove the points (RansacShapeDetector.cpp:666-675) ---------------------------------
+                if (cand_size == 0) continue;
+                const int32_t shape_id = (int32_t)accepted.size();
+                hipLaunchKernelGGL(k_assign, dim3(cdiv(cand_size, 256)), dim3(256), 0, ctx->stream, cand_idx, cand_size, shape_id, W.assigned.p);
+                drawn = std::pow(1.f - (cand_size / float(n_remaining)), 3.f) * drawn;
+                n_remaining -= std::min(n_remaining, cand_size);
+                // plane_extraction.cpp:134-149: shapes below min_support are skipped, d = -n.p with n re-normalised
+                Accepted a{};
+                a.support = 0; a.offset = out_off;
+                if (cand_size >= rp.min_support) {
+                    float nn[3] = {cand_state.n[0], cand_state.n[1], cand_state.n[2]};
+                    float l = nn[0] * nn[0];
+                    l += nn[1] * nn[1];
+                    l += nn[2] * nn[2];
+                    l = std::sqrt(l);
+                    if (l > 0) { nn[0] /= l; nn[1] /= l; nn[2] /= l; }
+                    float d = -(nn[0] * cand_state.pos[0] + nn[1] * cand_state.pos[1] + nn[2] * cand_state.pos[2]);
+                    if (rp.orient_normals) {  // mean inlier normal (the intent of plane_extraction.cpp:43-58)
+                        const float *ns = hns + 3 * final_slot;
+                        if (ns[0] * nn[0] + ns[1] * nn[1] + ns[2] * nn[2] < 0) { nn[0] = -nn[0]; nn[1] = -nn[1]; nn[2] = -nn[2]; d = -d; }
+                    }
+                    a.coef[0] = nn[0]; a.coef[1] = nn[1]; a.coef[2] = nn[2]; a.coef[3] = d;
+                    a.support = cand_size;
+                    hipLaunchKernelGGL(k_map_indices, dim3(cdiv(cand_size, 256)), dim3(256), 0, ctx->stream, cand_idx, cand_size, W.orig.p,
+                                       W.out_idx.p + out_off);
+                    out_off += cand_size;
                 }
-                a.coef[0] = nn[0]; a.coef[1] = nn[1]; a.coef[2] = nn[2]; a.coef[3] = d;
-                a.support = cand_size;
-                hipLaunchKernelGGL(k_map_indices, dim3(cdiv(cand_size, 256)), dim3(256), 0, ctx->stream, cand_idx, cand_size, W.orig.p,
-                                   W.out_idx.p + out_off);
-                out_off += cand_size;
+                accepted.push_back(a);
             }
-            accepted.push_back(a);
+            // drop the batch from the pool (indices are ascending)
+            for (size_t b = batch.size(); b-- > 0;) pool.erase(pool.begin() + batch[b]);
             if (n_remaining < rp.min_support) { pool.clear(); break; }
         }
     }
@@ -890,6 +1037,7 @@ void ransac_detect(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const R
     ctx->stats.add("ransac_t_accept", t_accept);
     ctx->stats.add("ransac_rounds", n_rounds);
     ctx->stats.add("ransac_accepts", n_accepts);
+    ctx->stats.add("ransac_batches", n_batches);
     // ---- output ---------------------------------------------------------------------------------
     out.idx.resize(out_off);
     if (out_off) HIP_TRY(hipMemcpyAsync(out.idx.data(), W.out_idx.p, 4 * (size_t)out_off, hipMemcpyDeviceToHost, ctx->stream));

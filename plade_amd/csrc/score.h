@@ -18,7 +18,6 @@ void score_multi(plade_ctx *ctx, const float *x, const float *y, const float *z,
 struct CompactScratch {
     DBuf<uint8_t> masks;
     DBuf<uint32_t> block_counts;
-    DBuf<uint32_t> block_offsets;
 };
 void score_compact(plade_ctx *ctx, CompactScratch &s, const float *x, const float *y, const float *z,
                    const float *nx, const float *ny, const float *nz, const int32_t *assigned, uint32_t n,
@@ -31,5 +30,26 @@ void compact_masks(plade_ctx *ctx, CompactScratch &s, uint32_t n, const uint32_t
                    uint32_t *idx_out_dev, uint32_t *count_dev, const uint32_t *skip_flag = nullptr);
 // skip_flag (device, nullable): when *skip_flag != 0 the kernels return immediately and leave their
 // outputs untouched (used by the refit chain once it has converged).
+
+// Batched forms (one launch for up to 16 hypotheses; the cloud is read once).  The job tables live in
+// device memory; masks hold cdiv(n,1024)*256 bytes, block_counts cdiv(n,1024) words per job.
+struct MarkJob {
+    const float4 *plane;
+    uint8_t *masks;
+    uint32_t *block_counts;
+    const uint32_t *skip;      // nullable
+};
+struct CompactJob {
+    const uint8_t *masks;
+    const uint32_t *block_counts;
+    const uint32_t *values;    // nullable: emit the point index itself
+    uint32_t *out;
+    uint32_t *total;
+    const uint32_t *skip;      // nullable
+};
+void score_mark_batch(plade_ctx *ctx, const float *x, const float *y, const float *z, const float *nx, const float *ny,
+                      const float *nz, const int32_t *assigned, uint32_t n, const MarkJob *jobs_dev, uint32_t nj, float eps,
+                      float cos_thresh);
+void compact_batch(plade_ctx *ctx, uint32_t n, const CompactJob *jobs_dev, uint32_t nj);
 
 }  // namespace plade
