@@ -23,9 +23,11 @@ __global__ __launch_bounds__(256) void k_transforms(const float *__restrict__ q_
                                                     const float *__restrict__ q_p1, const float *__restrict__ t_lv1,
                                                     const float *__restrict__ t_lv2, const float *__restrict__ t_p1,
                                                     const uint32_t *__restrict__ q_idx, const uint32_t *__restrict__ t_idx,
-                                                    uint32_t m, float4 *__restrict__ rt) {
+                                                    uint32_t m, float4 *__restrict__ rt, int *__restrict__ t_minmax6) {
+    __shared__ float s_lds[6][8];
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= m) return;
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    if (i < m) {
     const uint32_t q = q_idx[i], t = t_idx[i];
     f3 s[3], d[3];
     s[0] = f3(q_lv1[3 * q], q_lv1[3 * q + 1], q_lv1[3 * q + 2]);
@@ -43,6 +45,10 @@ __global__ __launch_bounds__(256) void k_transforms(const float *__restrict__ q_
     rt[4 * (size_t)i + 1] = make_float4(R.m[1][0], R.m[1][1], R.m[1][2], T.y);
     rt[4 * (size_t)i + 2] = make_float4(R.m[2][0], R.m[2][1], R.m[2][2], T.z);
     rt[4 * (size_t)i + 3] = make_float4(roll, pitch, yaw, 0.f);
+    mn[0] = mx[0] = T.x; mn[1] = mx[1] = T.y; mn[2] = mx[2] = T.z;
+    }
+    // bounding box of the translations for the clustering grid (ordered-int atomics)
+    block_minmax_commit<3>(mn, mx, t_minmax6, s_lds);
 }
 
 void build_transforms(plade_ctx *ctx, const PairTableDev &src, const PairTableDev &tgt, const uint32_t *d_q_idx,
@@ -50,50 +56,44 @@ void build_transforms(plade_ctx *ctx, const PairTableDev &src, const PairTableDe
     cs.m = m;
     cs.rt.ensure(4 * (size_t)m + 4);
     if (!m) return;
+    int init[6];
+    {
+        float pinf = INFINITY, ninf = -INFINITY;
+        int a, b;
+        memcpy(&a, &pinf, 4); memcpy(&b, &ninf, 4);
+        for (int k = 0; k < 3; ++k) { init[k] = a; init[3 + k] = b ^ 0x7fffffff; }
+    }
+    cs.t_minmax.ensure(8);
+    HIP_TRY(hipMemcpyAsync(cs.t_minmax.p, init, 24, hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(k_transforms, dim3(cdiv(m, 256)), dim3(256), 0, ctx->stream, src.lv1.p, src.lv2.p, src.p1.p,
-                       tgt.lv1.p, tgt.lv2.p, tgt.p1.p, d_q_idx, d_t_idx, m, cs.rt.p);
+                       tgt.lv1.p, tgt.lv2.p, tgt.p1.p, d_q_idx, d_t_idx, m, cs.rt.p, cs.t_minmax.p);
     HIP_TRY(hipGetLastError());
 }
 
 // ------------------------------------------------------------------------------------------------
+// cells of edge >= the cluster radius over the translations' bounding box; keys packed to the bits the
+// extents need (x lowest, so the three x-neighbours of a cell row are one contiguous key range)
 struct HashGrid {
     float mnx, mny, mnz, inv;
+    int bx, bxy;   // shifts of the y and z fields
 };
 
-__device__ __forceinline__ uint64_t cell_key(int cx, int cy, int cz) {
-    return ((uint64_t)(uint32_t)cz << 42) | ((uint64_t)(uint32_t)cy << 21) | (uint64_t)(uint32_t)cx;
+__device__ __forceinline__ uint64_t cell_key(const HashGrid &g, int cx, int cy, int cz) {
+    return ((uint64_t)(uint32_t)cz << g.bxy) | ((uint64_t)(uint32_t)cy << g.bx) | (uint64_t)(uint32_t)cx;
 }
 
-__global__ __launch_bounds__(256) void k_t_minmax(const float4 *__restrict__ rt, uint32_t m, int *__restrict__ out6) {
-    __shared__ float s_lds[6][8];
-    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
-        const float v[3] = {rt[4 * (size_t)i].w, rt[4 * (size_t)i + 1].w, rt[4 * (size_t)i + 2].w};
-        for (int k = 0; k < 3; ++k) { mn[k] = fminf(mn[k], v[k]); mx[k] = fmaxf(mx[k], v[k]); }
-    }
-    block_minmax_commit<3>(mn, mx, out6, s_lds);
-}
-
+// keys + union-find / size initialisation
 __global__ void k_t_keys(const float4 *__restrict__ rt, uint32_t m, HashGrid g, uint64_t *__restrict__ keys,
-                         uint32_t *__restrict__ vals) {
+                         uint32_t *__restrict__ vals, uint32_t *__restrict__ parent, uint32_t *__restrict__ sizes) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= m) return;
     const int cx = (int)floorf((rt[4 * (size_t)i].w - g.mnx) * g.inv) + 1;
     const int cy = (int)floorf((rt[4 * (size_t)i + 1].w - g.mny) * g.inv) + 1;
     const int cz = (int)floorf((rt[4 * (size_t)i + 2].w - g.mnz) * g.inv) + 1;
-    keys[i] = cell_key(cx, cy, cz);
+    keys[i] = cell_key(g, cx, cy, cz);
     vals[i] = i;
-}
-
-__global__ void k_cell_heads(const uint64_t *__restrict__ keys, uint32_t m, uint32_t *__restrict__ flags) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < m) flags[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u;
-}
-__global__ void k_cell_unique(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ flags,
-                              const uint32_t *__restrict__ pos, uint32_t m, uint64_t *__restrict__ ukeys,
-                              uint32_t *__restrict__ ustart) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < m && flags[i]) { ukeys[pos[i]] = keys[i]; ustart[pos[i]] = i; }
+    parent[i] = i;
+    sizes[i] = 0;
 }
 
 __device__ __forceinline__ uint32_t uf_find(uint32_t *parent, uint32_t x) {
@@ -125,47 +125,63 @@ __device__ __forceinline__ uint32_t lower_bound_u64(const uint64_t *a, uint32_t 
     return lo;
 }
 
-// one lane per node (in sorted-cell order so a wave walks neighbouring cells together)
-__global__ __launch_bounds__(256) void k_cluster_edges(const float4 *__restrict__ rt, const uint32_t *__restrict__ order,
-                                                       uint32_t m, const uint64_t *__restrict__ ukeys,
-                                                       const uint32_t *__restrict__ ustart, uint32_t ncell,
-                                                       const uint64_t *__restrict__ skeys, float r2, float gate,
-                                                       uint32_t *__restrict__ parent) {
+// After the sort: nodes gathered into cell order (translation + original index, Euler angles), and for the
+// first node of every cell the nine spans [lo, hi) of sorted positions covering its 27-neighbourhood.
+__global__ __launch_bounds__(256) void k_cell_spans(const float4 *__restrict__ rt, const uint32_t *__restrict__ order,
+                                                    const uint64_t *__restrict__ skeys, uint32_t m, HashGrid g,
+                                                    float4 *__restrict__ st, float4 *__restrict__ se,
+                                                    uint2 *__restrict__ spans /* m x 9, rows of cell heads only */) {
     const uint32_t si = blockIdx.x * blockDim.x + threadIdx.x;
     if (si >= m) return;
     const uint32_t a = order[si];
-    const f3 ta(rt[4 * (size_t)a].w, rt[4 * (size_t)a + 1].w, rt[4 * (size_t)a + 2].w);
-    const float4 ea = rt[4 * (size_t)a + 3];
+    st[si] = make_float4(rt[4 * (size_t)a].w, rt[4 * (size_t)a + 1].w, rt[4 * (size_t)a + 2].w, __uint_as_float(a));
+    se[si] = rt[4 * (size_t)a + 3];
     const uint64_t key = skeys[si];
-    const int cx = (int)(key & 0x1fffff), cy = (int)((key >> 21) & 0x1fffff), cz = (int)(key >> 42);
+    if (si && skeys[si - 1] == key) return;
+    const uint64_t mx_ = (1ull << g.bx) - 1, my_ = (1ull << (g.bxy - g.bx)) - 1;
+    const int cx = (int)(key & mx_), cy = (int)((key >> g.bx) & my_), cz = (int)(key >> g.bxy);
+    int r = 0;
     for (int dz = -1; dz <= 1; ++dz)
-        for (int dy = -1; dy <= 1; ++dy) {
-            const uint64_t k0 = cell_key(cx - 1, cy + dy, cz + dz), k1 = cell_key(cx + 1, cy + dy, cz + dz);
-            uint32_t c = lower_bound_u64(ukeys, ncell, k0);
-            for (; c < ncell && ukeys[c] <= k1; ++c) {
-                const uint32_t b0 = ustart[c], b1 = (c + 1 < ncell) ? ustart[c + 1] : m;
-                for (uint32_t j = b0; j < b1; ++j) {
-                    const uint32_t b = order[j];
-                    if (b >= a) continue;  // every undirected edge once
-                    const f3 tb(rt[4 * (size_t)b].w, rt[4 * (size_t)b + 1].w, rt[4 * (size_t)b + 2].w);
-                    if (!(flann_d2(ta, tb) < r2)) continue;
-                    const float4 eb = rt[4 * (size_t)b + 3];
-                    const float t0 = ea.x - eb.x, t1 = ea.y - eb.y, t2 = ea.z - eb.z;
-                    const float sq = (t0 * t0 + t1 * t1) + t2 * t2;  // Eigen::VectorXf(3).squaredNorm()
-                    if (sq < gate) uf_union(parent, a, b);
-                }
-            }
+        for (int dy = -1; dy <= 1; ++dy, ++r) {
+            const uint64_t k0 = cell_key(g, cx - 1, cy + dy, cz + dz), k1 = cell_key(g, cx + 1, cy + dy, cz + dz);
+            const uint32_t lo = lower_bound_u64(skeys, m, k0);
+            uint32_t hi = lo;
+            if (lo < m && skeys[lo] <= k1) hi = lower_bound_u64(skeys, m, k1 + 1);
+            spans[(size_t)si * 9 + r] = make_uint2(lo, hi);
         }
 }
 
-__global__ void k_iota(uint32_t *p, uint32_t n) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = i;
+// one lane per node in cell order: lanes of a wave share cells, so their span walks read the same
+// addresses (broadcast) and stay converged
+__global__ __launch_bounds__(256) void k_cluster_edges(const float4 *__restrict__ st, const float4 *__restrict__ se,
+                                                       const uint64_t *__restrict__ skeys, const uint2 *__restrict__ spans,
+                                                       uint32_t m, float r2, float gate, uint32_t *__restrict__ parent) {
+    const uint32_t si = blockIdx.x * blockDim.x + threadIdx.x;
+    if (si >= m) return;
+    const float4 pa = st[si];
+    const float4 ea = se[si];
+    const uint32_t a = __float_as_uint(pa.w);
+    const f3 ta(pa.x, pa.y, pa.z);
+    const uint32_t head = lower_bound_u64(skeys, m, skeys[si]);
+    for (int r = 0; r < 9; ++r) {
+        const uint2 sp = spans[(size_t)head * 9 + r];
+        for (uint32_t j = sp.x; j < sp.y; ++j) {
+            const float4 pb = st[j];
+            const uint32_t b = __float_as_uint(pb.w);
+            if (b >= a) continue;  // every undirected edge once
+            if (!(flann_d2(ta, f3(pb.x, pb.y, pb.z)) < r2)) continue;
+            const float4 eb = se[j];
+            const float t0 = ea.x - eb.x, t1 = ea.y - eb.y, t2 = ea.z - eb.z;
+            const float sq = (t0 * t0 + t1 * t1) + t2 * t2;  // Eigen::VectorXf(3).squaredNorm()
+            if (sq < gate) uf_union(parent, a, b);
+        }
+    }
 }
+
 __global__ void k_flatten(uint32_t *__restrict__ parent, uint32_t n, uint32_t *__restrict__ sizes,
                           uint32_t *__restrict__ root_flags) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    if (i >= n) { if (i == n) root_flags[n] = 0; return; }
     uint32_t r = i;
     while (parent[r] != r) r = parent[r];
     atomicAdd(&sizes[r], 1u);
@@ -177,23 +193,19 @@ __global__ void k_gather_sizes(const uint32_t *__restrict__ seeds, uint32_t n, c
     if (i < n) out[i] = sizes_all[seeds[i]];
 }
 
+static int bits_for(double cells) {
+    int b = 1;
+    while ((double)(1ull << b) < cells) ++b;
+    return b;
+}
+
 void cluster_transforms(plade_ctx *ctx, CandidateSet &cs, float dist_threshold, float angle_gate) {
     const uint32_t m = cs.m;
     cs.n_clusters = 0;
     if (!m) return;
-    // bbox of the translations
-    int init[6];
-    {
-        float pinf = INFINITY, ninf = -INFINITY;
-        int a, b;
-        memcpy(&a, &pinf, 4); memcpy(&b, &ninf, 4);
-        for (int k = 0; k < 3; ++k) { init[k] = a; init[3 + k] = b ^ 0x7fffffff; }
-    }
-    int *d6 = reinterpret_cast<int *>(ctx->scratch[3].ensure(64));
-    HIP_TRY(hipMemcpyAsync(d6, init, 24, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_t_minmax, dim3(std::min(cdiv(m, 1024), 512u)), dim3(256), 0, ctx->stream, cs.rt.p, m, d6);
+    // bbox of the translations (reduced inside k_transforms)
     int out[6];
-    HIP_TRY(hipMemcpyAsync(out, d6, 24, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(out, cs.t_minmax.p, 24, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     float mn[3], mx[3];
     for (int k = 0; k < 6; ++k) {
@@ -205,33 +217,26 @@ void cluster_transforms(plade_ctx *ctx, CandidateSet &cs, float dist_threshold, 
     const float r2 = pcl_r2((double)dist_threshold);  // setClusterTolerance -> radiusSearch(double) -> float(r*r)
     float cell = dist_threshold * 1.001f;
     if (!(cell > 0.f)) cell = 1.f;
-    for (;;) {  // 21-bit cell coordinates (+1 offset, +1 probe margin)
+    for (;;) {  // at most 21 bits per axis (+1 offset, +1 probe margin)
         double ext = std::max({(double)mx[0] - mn[0], (double)mx[1] - mn[1], (double)mx[2] - mn[2]});
         if (ext / cell + 4 < (double)(1 << 21)) break;
         cell *= 2.f;
     }
-    HashGrid g{mn[0], mn[1], mn[2], 1.f / cell};
+    const int bx = bits_for(((double)mx[0] - mn[0]) / cell + 4), by = bits_for(((double)mx[1] - mn[1]) / cell + 4),
+              bz = bits_for(((double)mx[2] - mn[2]) / cell + 4);
+    HashGrid g{mn[0], mn[1], mn[2], 1.f / cell, bx, bx + by};
     cs.ckeys.ensure(m); cs.ckeys2.ensure(m); cs.cvals.ensure(m); cs.cvals2.ensure(m);
-    cs.cflags.ensure((size_t)m + 1); cs.cpos.ensure((size_t)m + 1);
-    const unsigned nb = cdiv(m, 256);
-    hipLaunchKernelGGL(k_t_keys, dim3(nb), dim3(256), 0, ctx->stream, cs.rt.p, m, g, cs.ckeys.p, cs.cvals.p);
-    sort_pairs_u64(ctx, cs.ckeys.p, cs.ckeys2.p, cs.cvals.p, cs.cvals2.p, m, 63);
-    hipLaunchKernelGGL(k_cell_heads, dim3(nb), dim3(256), 0, ctx->stream, cs.ckeys2.p, m, cs.cflags.p);
-    HIP_TRY(hipMemsetAsync(cs.cflags.p + m, 0, 4, ctx->stream));
-    exclusive_scan_u32(ctx, cs.cflags.p, cs.cpos.p, (size_t)m + 1);
-    uint32_t ncell = 0;
-    HIP_TRY(hipMemcpyAsync(&ncell, cs.cpos.p + m, 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    cs.ucell_keys.ensure((size_t)ncell + 1); cs.ucell_start.ensure((size_t)ncell + 1);
-    hipLaunchKernelGGL(k_cell_unique, dim3(nb), dim3(256), 0, ctx->stream, cs.ckeys2.p, cs.cflags.p, cs.cpos.p, m,
-                       cs.ucell_keys.p, cs.ucell_start.p);
     cs.parent.ensure(m); cs.sizes_all.ensure(m); cs.flags.ensure((size_t)m + 1);
-    hipLaunchKernelGGL(k_iota, dim3(nb), dim3(256), 0, ctx->stream, cs.parent.p, m);
-    hipLaunchKernelGGL(k_cluster_edges, dim3(nb), dim3(256), 0, ctx->stream, cs.rt.p, cs.cvals2.p, m, cs.ucell_keys.p,
-                       cs.ucell_start.p, ncell, cs.ckeys2.p, r2, angle_gate, cs.parent.p);
-    HIP_TRY(hipMemsetAsync(cs.sizes_all.p, 0, (size_t)m * 4, ctx->stream));
-    hipLaunchKernelGGL(k_flatten, dim3(nb), dim3(256), 0, ctx->stream, cs.parent.p, m, cs.sizes_all.p, cs.flags.p);
-    HIP_TRY(hipMemsetAsync(cs.flags.p + m, 0, 4, ctx->stream));
+    cs.st.ensure(m); cs.se.ensure(m); cs.spans.ensure((size_t)m * 9);
+    const unsigned nb = cdiv(m, 256);
+    hipLaunchKernelGGL(k_t_keys, dim3(nb), dim3(256), 0, ctx->stream, cs.rt.p, m, g, cs.ckeys.p, cs.cvals.p, cs.parent.p,
+                       cs.sizes_all.p);
+    sort_pairs_u64(ctx, cs.ckeys.p, cs.ckeys2.p, cs.cvals.p, cs.cvals2.p, m, bx + by + bz);
+    hipLaunchKernelGGL(k_cell_spans, dim3(nb), dim3(256), 0, ctx->stream, cs.rt.p, cs.cvals2.p, cs.ckeys2.p, m, g, cs.st.p,
+                       cs.se.p, cs.spans.p);
+    hipLaunchKernelGGL(k_cluster_edges, dim3(nb), dim3(256), 0, ctx->stream, cs.st.p, cs.se.p, cs.ckeys2.p, cs.spans.p, m, r2,
+                       angle_gate, cs.parent.p);
+    hipLaunchKernelGGL(k_flatten, dim3(cdiv(m + 1, 256)), dim3(256), 0, ctx->stream, cs.parent.p, m, cs.sizes_all.p, cs.flags.p);
     cs.n_clusters = compact_flags(ctx, cs.flags.p, m, cs.pos, cs.seeds);
     cs.sizes.ensure((size_t)cs.n_clusters + 1);
     if (cs.n_clusters)
@@ -241,14 +246,6 @@ void cluster_transforms(plade_ctx *ctx, CandidateSet &cs, float dist_threshold, 
 }
 
 // ------------------------------------------------------------------------------------------------
-constexpr int PC_MAXP = 128;
-
-struct PlaneTab {
-    float coef[PC_MAXP][4];
-    float cen[PC_MAXP][3];
-    float rad[PC_MAXP];
-};
-
 __global__ __launch_bounds__(256) void k_plane_consistency(const float4 *__restrict__ rt, const uint32_t *__restrict__ seeds,
                                                            uint32_t n_clusters, const float *__restrict__ s_tab,
                                                            uint32_t ps, const float *__restrict__ t_tab, uint32_t pt,

@@ -84,11 +84,39 @@ __global__ void k_gather_final(const uint32_t *__restrict__ t_idx, const double 
     t_out[i] = t_idx[p];
     d2_out[i] = d2[p];
 }
-__global__ void k_query_offsets(const uint32_t *__restrict__ offs, uint32_t dq, uint32_t nch, uint32_t total,
-                                int64_t *__restrict__ out) {
+// per-query offsets + {total, longest per-query list} for the host
+__global__ void k_query_offsets(const uint32_t *__restrict__ offs, uint32_t dq, uint32_t nch, int64_t *__restrict__ out,
+                                uint32_t *__restrict__ info /* [0] total, [1] max list (zeroed) */) {
     uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q < dq) out[q] = offs[(size_t)q * nch];
-    if (q == dq) out[q] = total;
+    const uint32_t total = offs[(size_t)dq * nch];
+    if (q < dq) {
+        const uint32_t b = offs[(size_t)q * nch], e = offs[(size_t)(q + 1) * nch];
+        out[q] = b;
+        atomicMax(&info[1], e - b);
+    }
+    if (q == dq) { out[q] = total; info[0] = total; }
+}
+
+// Order inside each query's list: (dist2, target index).  The fill pass already wrote the lists query by
+// query in ascending target order, so each entry's final place is its rank by (dist2, position) inside
+// its own list: one wave per query, O(len^2 / 64) compares (lists are tens to hundreds of entries).
+constexpr uint32_t RANK_MAX_LIST = 4096;
+__global__ __launch_bounds__(256) void k_rank_lists(const int64_t *__restrict__ offsets, uint32_t dq,
+                                                    const uint32_t *__restrict__ t_raw, const double *__restrict__ d2_raw,
+                                                    uint32_t *__restrict__ t_out, double *__restrict__ d2_out) {
+    const uint32_t q = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (q >= dq) return;
+    const uint32_t b = (uint32_t)offsets[q], e = (uint32_t)offsets[q + 1];
+    for (uint32_t i = b + lane; i < e; i += 64) {
+        const double di = d2_raw[i];
+        uint32_t rank = 0;
+        for (uint32_t j = b; j < e; ++j) {
+            const double dj = d2_raw[j];
+            rank += (dj < di || (dj == di && j < i)) ? 1u : 0u;
+        }
+        t_out[b + rank] = t_raw[i];
+        d2_out[b + rank] = di;
+    }
 }
 
 uint64_t MatchResult::run(plade_ctx *ctx, const float *d_qry, uint32_t dq, const float *d_tgt, uint32_t dt,
@@ -108,19 +136,28 @@ uint64_t MatchResult::run(plade_ctx *ctx, const float *d_qry, uint32_t dq, const
                        (const uint32_t *)nullptr, (uint32_t *)nullptr, (double *)nullptr, (uint32_t *)nullptr);
     HIP_TRY(hipMemsetAsync(cnt.p + ncnt, 0, 4, ctx->stream));
     exclusive_scan_u32(ctx, cnt.p, offs.p, ncnt + 1);
-    uint32_t tot32 = 0;
-    HIP_TRY(hipMemcpyAsync(&tot32, offs.p + ncnt, 4, hipMemcpyDeviceToHost, ctx->stream));
+    info.ensure(2);
+    HIP_TRY(hipMemsetAsync(info.p, 0, 8, ctx->stream));
+    hipLaunchKernelGGL(k_query_offsets, dim3(cdiv(dq + 1, 256)), dim3(256), 0, ctx->stream, offs.p, dq, nch, offsets.p, info.p);
+    uint32_t h_info[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(h_info, info.p, 8, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    const uint32_t tot32 = h_info[0], max_list = h_info[1];
     total = tot32;
-    hipLaunchKernelGGL(k_query_offsets, dim3(cdiv(dq + 1, 256)), dim3(256), 0, ctx->stream, offs.p, dq, nch, tot32,
-                       offsets.p);
     if (total == 0) return 0;
     const uint32_t m = tot32;
     t_raw.ensure(m); d2_raw.ensure(m); q_raw.ensure(m);
     hipLaunchKernelGGL(k_match<true>, grid, dim3(MT_TPB), 0, ctx->stream, d_qry, dq, d_tgt, dt, sq_rad, nch, cnt.p, offs.p,
                        t_raw.p, d2_raw.p, q_raw.p);
-    // order inside each query: (dist2, target index).  Entries are already in ascending target
-    // order per query, so a stable sort by dist2 followed by a stable sort by query is enough.
+    t_idx.ensure(m); dist2.ensure(m);
+    q_idx_sorted = q_raw.p;   // lists are contiguous per query
+    if (max_list <= RANK_MAX_LIST) {
+        hipLaunchKernelGGL(k_rank_lists, dim3(cdiv(dq, 4)), dim3(256), 0, ctx->stream, offsets.p, dq, t_raw.p, d2_raw.p, t_idx.p,
+                           dist2.p);
+        HIP_TRY(hipGetLastError());
+        return total;
+    }
+    // very long lists: a stable sort by dist2 followed by a stable sort by query
     k64a.ensure(m); k64b.ensure(m); v32a.ensure(m); v32b.ensure(m); k32a.ensure(m); k32b.ensure(m);
     hipLaunchKernelGGL(k_d2_keys, dim3(cdiv(m, 256)), dim3(256), 0, ctx->stream, d2_raw.p, m, k64a.p, v32a.p);
     sort_pairs_u64(ctx, k64a.p, k64b.p, v32a.p, v32b.p, m, 64);
@@ -128,7 +165,6 @@ uint64_t MatchResult::run(plade_ctx *ctx, const float *d_qry, uint32_t dq, const
     int qbits = 1;
     while ((1ull << qbits) < dq) ++qbits;
     sort_pairs_u32(ctx, k32a.p, k32b.p, v32b.p, v32a.p, m, qbits);
-    t_idx.ensure(m); dist2.ensure(m);
     hipLaunchKernelGGL(k_gather_final, dim3(cdiv(m, 256)), dim3(256), 0, ctx->stream, t_raw.p, d2_raw.p, v32a.p, m,
                        t_idx.p, dist2.p);
     q_idx_sorted = k32b.p;

@@ -118,6 +118,9 @@ __global__ __launch_bounds__(PEN_TPB) void k_pen_walk(const PenItem *__restrict_
     __shared__ int s_n, s_pos, s_neg;
     if (blockIdx.x >= n_items) return;
     const PenItem it = items[blockIdx.x];
+    // the verdict per candidate is an OR over its items: once one item has rejected the candidate the
+    // others cannot change it
+    if (__atomic_load_n(&cand_flags[it.k], __ATOMIC_RELAXED)) return;
     const f3 start(it.sx, it.sy, it.sz), direc(it.dx, it.dy, it.dz);
     if (threadIdx.x == 0) {
         int n = 0;

@@ -11,7 +11,7 @@ struct MatchResult {
     DBuf<double> dist2;
     const uint32_t *q_idx_sorted = nullptr;  // total: query id per sorted entry
     // scratch
-    DBuf<uint32_t> cnt, offs, t_raw, q_raw, v32a, v32b, k32a, k32b;
+    DBuf<uint32_t> cnt, offs, t_raw, q_raw, v32a, v32b, k32a, k32b, info;
     DBuf<double> d2_raw;
     DBuf<uint64_t> k64a, k64b;
     uint64_t run(plade_ctx *ctx, const float *d_qry, uint32_t dq, const float *d_tgt, uint32_t dt, float radius);

@@ -27,6 +27,8 @@ void registration_work_destroy(RegistrationWork *w);
 double ctx_stat(plade_ctx *ctx, const char *name);
 
 bool run_registration(plade_ctx *ctx, RegistrationWork &W, const CloudDev &tgt, const CloudDev &src,
-                      const PlaneSetView &tp, const PlaneSetView &sp, float *T16_out);
+                      const PlaneSetView &tp, const PlaneSetView &sp, float *T16_out, const float *spacing_or_null);
+// average point spacing of the source cloud (plade.cpp:41); may run ahead of run_registration on another ctx
+float source_spacing(plade_ctx *ctx, RegistrationWork &W, const CloudDev &src);
 
 }  // namespace plade

@@ -95,6 +95,7 @@ void make_line_table(const float *coef, uint32_t P, f3 bcenter, double radius, L
 
 bool prepare_side(plade_ctx *ctx, const char *tag, const CloudDev &cloud, const PlaneSetView &pl, float leaf, Side &S) {
     const uint32_t P = pl.P;
+    Clock::time_point tp0 = Clock::now();
     // whole cloud: DownSamplePointCloud (plade.cpp:77-79 / :292-294)
     S.n_ds = S.vox_all.run(ctx, cloud.aos.p, 6, nullptr, nullptr, cloud.n, 1, leaf, cloud.bbmin, cloud.bbmax);
     if (S.n_ds == 0) return false;
@@ -124,6 +125,8 @@ bool prepare_side(plade_ctx *ctx, const char *tag, const CloudDev &cloud, const 
     HIP_TRY(hipMemcpyAsync(S.plane_ds.data(), S.vox_planes.out_xyz.p, 12 * (size_t)n_pds, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipMemcpyAsync(S.pcl.off.data(), S.vox_planes.group_offsets.p, 4 * ((size_t)P + 1), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->stats.add(std::string("t_prep_voxel_") + tag, secs_since(tp0));
+    tp0 = Clock::now();
     // ComputeBoundingBox of the whole downsampled cloud (plade.cpp:81-84 / :295-299)
     Obb ob;
     if (!oriented_bbox(S.ds.data(), S.n_ds, ob, false)) return false;
@@ -152,7 +155,10 @@ bool prepare_side(plade_ctx *ctx, const char *tag, const CloudDev &cloud, const 
         S.geom.center[3 * i] = cen.x; S.geom.center[3 * i + 1] = cen.y; S.geom.center[3 * i + 2] = cen.z;
         S.geom.radius[i] = norm_e(four[0] - four[2]) / 2.f;
     }
+    ctx->stats.add(std::string("t_prep_obb_") + tag, secs_since(tp0));
+    tp0 = Clock::now();
     make_line_table(pl.coef, P, S.bcenter, S.radius, S.lines);
+    ctx->stats.add(std::string("t_prep_lines_") + tag, secs_since(tp0));
     if (ctx->params.dump) {
         const std::string t(tag);
         ctx->put(t + "_ds", S.ds.data(), S.ds.size());
@@ -194,18 +200,19 @@ struct RegistrationWork {
 RegistrationWork *registration_work_create() { return new RegistrationWork; }
 void registration_work_destroy(RegistrationWork *w) { delete w; }
 
+float source_spacing(plade_ctx *ctx, RegistrationWork &W, const CloudDev &src) {
+    StageTimer t(ctx, "t_spacing");
+    return average_spacing_dev(ctx, src.aos.p, 6, src.n, src.bbmin, src.bbmax, 6, 10000, W.sp_grid);
+}
+
 bool run_registration(plade_ctx *ctx, RegistrationWork &W, const CloudDev &tgt, const CloudDev &src,
-                      const PlaneSetView &tp, const PlaneSetView &sp, float *T16_out) {
+                      const PlaneSetView &tp, const PlaneSetView &sp, float *T16_out, const float *spacing_or_null) {
     for (int i = 0; i < 16; ++i) T16_out[i] = (i % 5 == 0) ? 1.f : 0.f;
     const int max_candidates = ctx->params.max_candidates;
     Side &M = W.M, &C = W.C;
 
     // plade.cpp:41
-    float average_space;
-    {
-        StageTimer t(ctx, "t_spacing");
-        average_space = average_spacing_dev(ctx, src.aos.p, 6, src.n, src.bbmin, src.bbmax, 6, 10000, W.sp_grid);
-    }
+    const float average_space = spacing_or_null ? *spacing_or_null : source_spacing(ctx, W, src);
     ctx->put1("average_spacing", average_space);
     // plade.cpp:46-56
     const float downSampleDistance = average_space * 4;
@@ -295,32 +302,29 @@ bool run_registration(plade_ctx *ctx, RegistrationWork &W, const CloudDev &tgt, 
     }
     const uint32_t nC = W.cand.n_clusters;
     ctx->stats.add("n_clusters", nC);
-    {
-        StageTimer t(ctx, "t_plane_consistency");
-        const float sbc[3] = {C.bcenter.x, C.bcenter.y, C.bcenter.z}, tbc[3] = {M.bcenter.x, M.bcenter.y, M.bcenter.z};
-        plane_consistency(ctx, W.cand, C.geom, M.geom, sbc, tbc, (float)M.radius, (float)(double)cosAngleThreshold,
-                          lengthThreshold);
-        seeds.resize(nC); sizes.resize(nC); pcounts.resize(nC);
-        if (nC) {
-            HIP_TRY(hipMemcpyAsync(seeds.data(), W.cand.seeds.p, 4 * (size_t)nC, hipMemcpyDeviceToHost, ctx->stream));
-            HIP_TRY(hipMemcpyAsync(sizes.data(), W.cand.sizes.p, 4 * (size_t)nC, hipMemcpyDeviceToHost, ctx->stream));
-            HIP_TRY(hipMemcpyAsync(pcounts.data(), W.cand.plane_counts.p, 4 * (size_t)nC, hipMemcpyDeviceToHost, ctx->stream));
-            HIP_TRY(hipStreamSynchronize(ctx->stream));
-        }
-    }
-    if (ctx->params.dump) {
-        std::vector<int32_t> a(sizes.begin(), sizes.end()), b(seeds.begin(), seeds.end());
-        ctx->put("cluster_sizes", a.data(), a.size());
-        ctx->put("cluster_seeds", b.data(), b.size());
-    }
-    // util.cpp:335-401: clusters by size (std::sort with myCompareGreater), centre gate, plane counts
+    // util.cpp:335-401: clusters by size (std::sort with myCompareGreater), centre gate, plane counts.
+    // The sort only needs the sizes, so it runs on the host while the plane-consistency kernel runs.
     std::vector<int> cand_cluster;   // cluster index per entry of `matches`
     std::vector<int> match_counts;
     {
-        StageTimer t(ctx, "t_host_select");
+        StageTimer t(ctx, "t_plane_consistency");
+        seeds.resize(nC); sizes.resize(nC); pcounts.resize(nC);
+        if (nC) {
+            HIP_TRY(hipMemcpyAsync(sizes.data(), W.cand.sizes.p, 4 * (size_t)nC, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+        }
+        const float sbc[3] = {C.bcenter.x, C.bcenter.y, C.bcenter.z}, tbc[3] = {M.bcenter.x, M.bcenter.y, M.bcenter.z};
+        plane_consistency(ctx, W.cand, C.geom, M.geom, sbc, tbc, (float)M.radius, (float)(double)cosAngleThreshold,
+                          lengthThreshold);
+        if (nC) {
+            HIP_TRY(hipMemcpyAsync(seeds.data(), W.cand.seeds.p, 4 * (size_t)nC, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(hipMemcpyAsync(pcounts.data(), W.cand.plane_counts.p, 4 * (size_t)nC, hipMemcpyDeviceToHost, ctx->stream));
+        }
         std::vector<LengthIndex> sortVec(nC);
         for (uint32_t i = 0; i < nC; ++i) { sortVec[i].index = (int)i; sortVec[i].length = (float)sizes[i]; }
-        std::sort(sortVec.begin(), sortVec.end(), cmp_greater);
+        // same comparisons as cmp_greater, as an inlinable functor: std::sort's result is identical
+        std::sort(sortVec.begin(), sortVec.end(), [](const LengthIndex &a, const LengthIndex &b) { return a.length > b.length; });
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
         cand_cluster.reserve(nC);
         match_counts.reserve(nC);
         for (uint32_t i = 0; i < nC; ++i) {
@@ -329,6 +333,11 @@ bool run_registration(plade_ctx *ctx, RegistrationWork &W, const CloudDev &tgt, 
             cand_cluster.push_back(c);
             match_counts.push_back(pcounts[c]);
         }
+    }
+    if (ctx->params.dump) {
+        std::vector<int32_t> a(sizes.begin(), sizes.end()), b(seeds.begin(), seeds.end());
+        ctx->put("cluster_sizes", a.data(), a.size());
+        ctx->put("cluster_seeds", b.data(), b.size());
     }
     ctx->put("plane_match_counts", match_counts.data(), match_counts.size());
     // util.cpp:403-445
@@ -468,7 +477,7 @@ extern "C" int plade_registration_planes(plade_ctx *ctx, const float *tgt_pos_nr
         tp.coef = tgt_planes; tp.offsets = tgt_offsets; tp.idx = tgt_idx; tp.P = p_t;
         sp.coef = src_planes; sp.offsets = src_offsets; sp.idx = src_idx; sp.P = p_s;
         Clock::time_point t0 = Clock::now();
-        const bool ok = run_registration(ctx, *ctx->reg_work, tgt, src, tp, sp, T16);
+        const bool ok = run_registration(ctx, *ctx->reg_work, tgt, src, tp, sp, T16, nullptr);
         ctx->stats.add("t_registration", secs_since(t0));
         ctx->ev_collect();
         if (!ok) { ctx->last_error = "registration failed: no matched result found"; return PLADE_EFAIL; }

@@ -9,6 +9,7 @@ struct RansacParams {
     float dist_rel = 0.005f, bitmap_rel = 0.02f, cos_thresh = 0.8f, overlook_p = 0.001f;  // plade.cpp:607
     int orient_normals = 1;
     uint64_t seed = 0;
+    bool host_indices = true;   // also copy the inlier index lists to the host (PlaneSetOut::idx)
 };
 
 struct PlaneSetOut {
@@ -19,6 +20,16 @@ struct PlaneSetOut {
     uint32_t n_score_passes = 0;   // full-array K1 passes issued (roofline bookkeeping)
     uint32_t remaining = 0;
     uint32_t P() const { return (uint32_t)(coef.size() / 4); }
+    // make `idx` valid when the detect call skipped the host copy
+    void fetch_indices(hipStream_t stream) {
+        const size_t m = offsets.empty() ? 0 : (size_t)offsets.back();
+        if (idx.size() == m || !d_idx) return;
+        idx.resize(m);
+        if (m) {
+            (void)hipMemcpyAsync(idx.data(), d_idx, 4 * m, hipMemcpyDeviceToHost, stream);
+            (void)hipStreamSynchronize(stream);
+        }
+    }
 };
 
 struct RansacWork;

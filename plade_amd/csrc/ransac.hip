@@ -1039,8 +1039,11 @@ void ransac_detect(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const R
     ctx->stats.add("ransac_accepts", n_accepts);
     ctx->stats.add("ransac_batches", n_batches);
     // ---- output ---------------------------------------------------------------------------------
-    out.idx.resize(out_off);
-    if (out_off) HIP_TRY(hipMemcpyAsync(out.idx.data(), W.out_idx.p, 4 * (size_t)out_off, hipMemcpyDeviceToHost, ctx->stream));
+    out.idx.clear();
+    if (rp.host_indices) {
+        out.idx.resize(out_off);
+        if (out_off) HIP_TRY(hipMemcpyAsync(out.idx.data(), W.out_idx.p, 4 * (size_t)out_off, hipMemcpyDeviceToHost, ctx->stream));
+    }
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     for (auto &a : accepted) {
         if (!a.support) continue;

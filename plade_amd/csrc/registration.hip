@@ -11,8 +11,9 @@ using namespace plade;
 
 namespace {
 
-RansacParams ransac_params(plade_ctx *ctx, uint32_t min_support) {
+RansacParams ransac_params(plade_ctx *ctx, uint32_t min_support, bool host_indices = true) {
     RansacParams rp;
+    rp.host_indices = host_indices;
     rp.min_support = min_support;
     rp.orient_normals = ctx->params.orient_normals;
     rp.seed = ctx->params.ransac_seed;
@@ -20,11 +21,11 @@ RansacParams ransac_params(plade_ctx *ctx, uint32_t min_support) {
 }
 
 // extract() (code/PLADE/plade.cpp:602-635)
-void extract(plade_ctx *ctx, const CloudDev &cloud, int init_min_support, PlaneSetOut &planes) {
+void extract(plade_ctx *ctx, const CloudDev &cloud, int init_min_support, PlaneSetOut &planes, bool host_indices) {
     const uint32_t min_num = (uint32_t)ctx->params.min_planes, max_num = (uint32_t)ctx->params.max_planes;
     const int min_allowed_support = 200;
     if (!ctx->ransac_work) ctx->ransac_work = ransac_work_create();
-    ransac_detect(ctx, *ctx->ransac_work, cloud, ransac_params(ctx, (uint32_t)init_min_support), planes);
+    ransac_detect(ctx, *ctx->ransac_work, cloud, ransac_params(ctx, (uint32_t)init_min_support, host_indices), planes);
     ctx->stats.add("n_detect_calls", 1);
     ctx->stats.add("n_score_passes", planes.n_score_passes);
     if (planes.P() >= min_num && planes.P() <= max_num) return;
@@ -32,6 +33,7 @@ void extract(plade_ctx *ctx, const CloudDev &cloud, int init_min_support, PlaneS
         // top max_num by support.  The reference sorts with a `>=` comparator (plade.cpp:612-615,
         // undefined behaviour on ties); a stable descending sort is used here.
         const uint32_t P = planes.P();
+        planes.fetch_indices(ctx->stream);
         std::vector<uint32_t> order(P);
         std::iota(order.begin(), order.end(), 0u);
         std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
@@ -53,7 +55,7 @@ void extract(plade_ctx *ctx, const CloudDev &cloud, int init_min_support, PlaneS
     int min_support = init_min_support / 2;
     int trials = 1;
     while (planes.P() < min_num && trials < max_trials && min_support >= min_allowed_support) {
-        ransac_detect(ctx, *ctx->ransac_work, cloud, ransac_params(ctx, (uint32_t)min_support), planes);
+        ransac_detect(ctx, *ctx->ransac_work, cloud, ransac_params(ctx, (uint32_t)min_support, host_indices), planes);
         ctx->stats.add("n_detect_calls", 1);
         ctx->stats.add("n_score_passes", planes.n_score_passes);
         min_support /= 2;
@@ -65,6 +67,8 @@ int register_clouds(plade_ctx *ctx, const CloudDev &tgt, const CloudDev &src, in
                     float *T16) {
     for (int i = 0; i < 16; ++i) T16[i] = (i % 5 == 0) ? 1.f : 0.f;
     PlaneSetOut tp, sp;
+    float spacing = 0.f;
+    bool have_spacing = false;
     Clock::time_point t0 = Clock::now();
     {
         StageTimer t(ctx, "t_extract");
@@ -79,16 +83,21 @@ int register_clouds(plade_ctx *ctx, const CloudDev &tgt, const CloudDev &src, in
         aux->params = ctx->params;
         aux->stats.clear();
         Err aux_err{0, ""};
+        if (!ctx->reg_work) ctx->reg_work = registration_work_create();
         auto one = [&](plade_ctx *c, const CloudDev &cloud, int ms, PlaneSetOut &out) {
-            if (auto_tune) extract(c, cloud, c->params.init_min_support, out);
+            // the next stage reads the index lists from the device; the host copy is only for dumps
+            const bool host_idx = c->params.dump != 0;
+            if (auto_tune) extract(c, cloud, c->params.init_min_support, out, host_idx);
             else {  // plade.cpp:583-599
                 if (!c->ransac_work) c->ransac_work = ransac_work_create();
-                ransac_detect(c, *c->ransac_work, cloud, ransac_params(c, (uint32_t)ms), out);
+                ransac_detect(c, *c->ransac_work, cloud, ransac_params(c, (uint32_t)ms, host_idx), out);
             }
         };
         std::thread th([&]() {
             (void)hipSetDevice(ctx->device);
-            try { one(aux, src, ms_s, sp); }
+            // the source side usually finishes first (fewer points / planes): it goes on with the point
+            // spacing (plade.cpp:41), which only needs the source cloud
+            try { one(aux, src, ms_s, sp); spacing = source_spacing(aux, *ctx->reg_work, src); have_spacing = true; }
             catch (const Err &e) { aux_err = e; }
             catch (const std::exception &e) { aux_err = Err{PLADE_EDEVICE, e.what()}; }
         });
@@ -121,12 +130,11 @@ int register_clouds(plade_ctx *ctx, const CloudDev &tgt, const CloudDev &src, in
     }
     ctx->stats.add("n_planes_tgt", tp.P());
     ctx->stats.add("n_planes_src", sp.P());
-    if (!ctx->reg_work) ctx->reg_work = registration_work_create();
     PlaneSetView tv, sv;
     tv.coef = tp.coef.data(); tv.offsets = tp.offsets.data(); tv.idx = tp.idx.data(); tv.P = tp.P();
     sv.coef = sp.coef.data(); sv.offsets = sp.offsets.data(); sv.idx = sp.idx.data(); sv.P = sp.P(); sv.d_idx = sp.d_idx;
     tv.d_idx = tp.d_idx;
-    const bool ok = run_registration(ctx, *ctx->reg_work, tgt, src, tv, sv, T16);
+    const bool ok = run_registration(ctx, *ctx->reg_work, tgt, src, tv, sv, T16, have_spacing ? &spacing : nullptr);
     ctx->stats.add("t_registration", secs_since(t0));
     // roofline bookkeeping
     ctx->stats.add("bytes_ransac", 28.0 * ((double)tgt.n + src.n) * 0.5 * ctx_stat(ctx, "n_score_passes"));
