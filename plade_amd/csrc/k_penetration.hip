@@ -7,8 +7,8 @@
 // which is what the GPU evaluates, all triples (candidate, i1, j1) in parallel:
 //   k_pen_setup : one lane per triple -- gate (util.cpp:487-492), plane/plane intersection line,
 //                 clipping against both plane rectangles, overlap interval -> compact work list
-//   k_pen_walk  : one workgroup per surviving triple -- the two kd-tree walks along the intersection
-//                 segment.  A radiusSearch(p, r, max_nn=2) < 2 gate is "fewer than two cloud points
+//   k_pen_walk  : one wavefront per surviving triple, four triples of the same plane pair per
+//                 workgroup -- the two kd-tree walks along the intersection segment.  A radiusSearch(p, r, max_nn=2) < 2 gate is "fewer than two cloud points
 //                 within r/2 of the step point"; the classified set is the union over gated steps of
 //                 the points within r, each counted once (checkIndex).  Both are order independent,
 //                 so brute-force fp32 distance tests (FLANN L2_Simple, strict <) reproduce the counts.
@@ -47,8 +47,9 @@ __device__ __forceinline__ int edge_hits(f3 lineVec, f3 linePoint, const f3 *c, 
     return n;
 }
 
+// items are grouped by plane pair: pair (i1, j1) owns slots [pair * K, pair * K + pair_count[pair])
 __global__ __launch_bounds__(256) void k_pen_setup(PenTables tb, float len_th, float ang_th, PenItem *__restrict__ items,
-                                                   uint32_t *__restrict__ n_items, uint32_t cap) {
+                                                   uint32_t *__restrict__ n_items, uint32_t *__restrict__ pair_count) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t total = (size_t)tb.K * tb.ps * tb.pt;
     if (idx >= total) return;
@@ -96,8 +97,9 @@ __global__ __launch_bounds__(256) void k_pen_setup(PenTables tb, float len_th, f
     if (0 == (ord[0] / 2 - ord[1] / 2)) return;  // no overlap of the two clipped segments
     const f3 sp = inter[ord[1]], ep = inter[ord[2]];
     const float length = norm_e(ep - sp);
-    const uint32_t slot = atomicAdd(n_items, 1u);
-    if (slot >= cap) return;
+    atomicAdd(n_items, 1u);
+    const uint32_t pair = i1 * tb.pt + j1;
+    const uint32_t slot = pair * tb.K + atomicAdd(&pair_count[pair], 1u);
     PenItem it;
     it.k = k; it.i1 = i1; it.j1 = j1;
     for (int q = 0; q < 4; ++q) it.plane1[q] = plane1[q];
@@ -105,96 +107,126 @@ __global__ __launch_bounds__(256) void k_pen_setup(PenTables tb, float len_th, f
     items[slot] = it;
 }
 
-constexpr int PEN_MAXS = 1024;
-constexpr int PEN_TPB = 64;   // one wavefront per surviving triple
+constexpr int PEN_MAXS = 1024;   // search steps along one intersection segment
+constexpr int PEN_G = 4;         // items (= wavefronts) per workgroup, all of the same plane pair
+constexpr int PEN_TPB = 64 * PEN_G;
+constexpr int PEN_UNROLL = 4;
 
-__global__ __launch_bounds__(PEN_TPB) void k_pen_walk(const PenItem *__restrict__ items, uint32_t n_items, PenTables tb,
-                                                  const float *__restrict__ s_xyz, const uint32_t *__restrict__ s_off,
-                                                  const float *__restrict__ t_xyz, const uint32_t *__restrict__ t_off,
-                                                  float search_radius, int min_points, float min_distance,
-                                                  uint32_t *__restrict__ cand_flags, uint32_t *__restrict__ overflow) {
-    __shared__ float s_dist[PEN_MAXS];
-    __shared__ uint32_t s_cnt[PEN_MAXS];
-    __shared__ int s_n, s_pos, s_neg;
-    if (blockIdx.x >= n_items) return;
-    const PenItem it = items[blockIdx.x];
+// One wavefront per item; the wavefronts of a workgroup belong to the same (source plane, target plane),
+// stream the same two plane clouds at the same time and so share them through the CU's L1 -- the L2
+// traffic, which bounds this kernel, drops by the group size.  Wavefronts are independent (wave-level
+// synchronisation only).
+// step_dist: the reference's `for (dist = 0; dist < length; dist += r)` sequence (util.cpp:1383, fp32
+// accumulation), PEN_MAXS + 1 entries computed once on the host -- it does not depend on the item.
+__global__ __launch_bounds__(PEN_TPB) void k_pen_walk(const PenItem *__restrict__ items, const uint32_t *__restrict__ pair_count,
+                                                      const uint32_t *__restrict__ pair_order, PenTables tb,
+                                                      const float *__restrict__ step_dist, const float *__restrict__ s_xyz, const uint32_t *__restrict__ s_off,
+                                                      const float *__restrict__ t_xyz, const uint32_t *__restrict__ t_off,
+                                                      float search_radius, int min_points, float min_distance,
+                                                      uint32_t *__restrict__ cand_flags, uint32_t *__restrict__ overflow) {
+    __shared__ uint32_t s_cnt_all[PEN_G][PEN_MAXS];
+    const uint32_t pair = pair_order[blockIdx.x];   // heaviest plane pairs first (longest-processing-time order)
+    const uint32_t cnt = pair_count[pair];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t slot = blockIdx.y * PEN_G + wave;
+    if (slot >= cnt) return;
+    uint32_t *s_cnt = s_cnt_all[wave];
+    const PenItem it = items[(size_t)pair * tb.K + slot];
     // the verdict per candidate is an OR over its items: once one item has rejected the candidate the
     // others cannot change it
     if (__atomic_load_n(&cand_flags[it.k], __ATOMIC_RELAXED)) return;
-    const f3 start(it.sx, it.sy, it.sz), direc(it.dx, it.dy, it.dz);
-    if (threadIdx.x == 0) {
-        int n = 0;
-        for (float dist = 0; dist < it.length; dist += search_radius) {  // util.cpp:1383 (fp32 accumulation)
-            if (n < PEN_MAXS) s_dist[n] = dist;
-            ++n;
-            if (n > PEN_MAXS) break;
-        }
-        if (n > PEN_MAXS) { atomicExch(overflow, 1u); n = PEN_MAXS; }
-        s_n = n;
+    // number of steps with dist < length (the sequence is increasing)
+    int nsteps;
+    {
+        int lo = 0, hi = PEN_MAXS;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (step_dist[mid] < it.length) lo = mid + 1; else hi = mid; }
+        if (lo == PEN_MAXS && step_dist[PEN_MAXS] < it.length && lane == 0) atomicExch(overflow, 1u);
+        nsteps = lo;
     }
-    __syncthreads();
-    const int nsteps = s_n;
     if (nsteps == 0) return;  // length <= 0: both walks see nothing -> positive/negative < minPoints
+    const f3 start(it.sx, it.sy, it.sz), direc(it.dx, it.dy, it.dz);
     const float half_r2 = (float)((double)(search_radius / 2) * (double)(search_radius / 2));
     const float full_r2 = (float)((double)search_radius * (double)search_radius);
     const float *c = tb.cand + 12 * (size_t)it.k;
     const float T12[12] = {c[0], c[1], c[2], c[9], c[3], c[4], c[5], c[10], c[6], c[7], c[8], c[11]};
-    const uint32_t sb = s_off[it.i1], se = s_off[it.i1 + 1], tb0 = t_off[it.j1], te = t_off[it.j1 + 1];
-    const float *tc = tb.t_coef + 4 * (size_t)it.j1;
+    const uint32_t i1 = pair / tb.pt, j1 = pair % tb.pt;
+    const uint32_t sb = s_off[i1], se = s_off[i1 + 1], tb0 = t_off[j1], te = t_off[j1 + 1];
+    const float *tc = tb.t_coef + 4 * (size_t)j1;
     const float inv_r = 1.f / search_radius;
 
     for (int pass = 0; pass < 2; ++pass) {
         // pass 0: gate = target plane cloud, classified = transformed source plane cloud vs plane2
         // pass 1: gate = transformed source plane cloud, classified = target plane cloud vs plane1
-        for (int i = threadIdx.x; i < nsteps; i += blockDim.x) s_cnt[i] = 0u;
-        if (threadIdx.x == 0) { s_pos = 0; s_neg = 0; }
-        __syncthreads();
+        for (int i = lane; i < nsteps; i += 64) s_cnt[i] = 0u;
+        __syncwarp();
         const uint32_t gb = pass == 0 ? tb0 : sb, ge = pass == 0 ? te : se;
-        for (uint32_t i = gb + threadIdx.x; i < ge; i += blockDim.x) {
-            f3 p;
-            if (pass == 0) p = f3(t_xyz[3 * (size_t)i], t_xyz[3 * (size_t)i + 1], t_xyz[3 * (size_t)i + 2]);
-            else p = pcl_xform(T12, f3(s_xyz[3 * (size_t)i], s_xyz[3 * (size_t)i + 1], s_xyz[3 * (size_t)i + 2]));
-            const f3 d = p - start;
-            const float t = d.x * direc.x + d.y * direc.y + d.z * direc.z;
-            // conservative reject: farther than r/2 (+2 %) from the line => within r/2 of no step point
-            if ((d.x * d.x + d.y * d.y + d.z * d.z) - t * t > half_r2 * 1.02f + 1e-12f) continue;
-            const int kc = (int)floorf(t * inv_r);
-            for (int kk = max(kc - 2, 0); kk <= min(kc + 3, nsteps - 1); ++kk) {
-                const float dist = s_dist[kk];
-                const f3 spt(start.x + dist * direc.x, start.y + dist * direc.y, start.z + dist * direc.z);
-                if (flann_d2(spt, p) < half_r2) atomicAdd(&s_cnt[kk], 1u);
+        const float *gxyz = pass == 0 ? t_xyz : s_xyz;
+        // four points per lane and trip: the twelve loads are issued together (the walk is latency bound)
+        for (uint32_t i0 = gb; i0 < ge; i0 += 64 * PEN_UNROLL) {
+            f3 raw[PEN_UNROLL];
+            bool ok[PEN_UNROLL];
+#pragma unroll
+            for (int u = 0; u < PEN_UNROLL; ++u) {
+                const uint32_t i = i0 + u * 64 + lane;
+                ok[u] = i < ge;
+                const size_t ii = ok[u] ? i : ge - 1;
+                raw[u] = f3(gxyz[3 * ii], gxyz[3 * ii + 1], gxyz[3 * ii + 2]);
+            }
+#pragma unroll
+            for (int u = 0; u < PEN_UNROLL; ++u) {
+                if (!ok[u]) continue;
+                const f3 p = pass == 0 ? raw[u] : pcl_xform(T12, raw[u]);
+                const f3 d = p - start;
+                const float t = d.x * direc.x + d.y * direc.y + d.z * direc.z;
+                // conservative reject: farther than r/2 (+2 %) from the line => within r/2 of no step point
+                if ((d.x * d.x + d.y * d.y + d.z * d.z) - t * t > half_r2 * 1.02f + 1e-12f) continue;
+                const int kc = (int)floorf(t * inv_r);
+                for (int kk = max(kc - 2, 0); kk <= min(kc + 3, nsteps - 1); ++kk) {
+                    const float dist = step_dist[kk];
+                    const f3 spt(start.x + dist * direc.x, start.y + dist * direc.y, start.z + dist * direc.z);
+                    if (flann_d2(spt, p) < half_r2) atomicAdd(&s_cnt[kk], 1u);
+                }
             }
         }
-        __syncthreads();
+        __syncwarp();
         const float pl0 = pass == 0 ? tc[0] : it.plane1[0], pl1 = pass == 0 ? tc[1] : it.plane1[1],
                     pl2 = pass == 0 ? tc[2] : it.plane1[2], pl3 = pass == 0 ? tc[3] : it.plane1[3];
         const uint32_t ab = pass == 0 ? sb : tb0, ae = pass == 0 ? se : te;
-        int lpos = 0, lneg = 0;
-        for (uint32_t i = ab + threadIdx.x; i < ae; i += blockDim.x) {
-            f3 p;
-            if (pass == 0) p = pcl_xform(T12, f3(s_xyz[3 * (size_t)i], s_xyz[3 * (size_t)i + 1], s_xyz[3 * (size_t)i + 2]));
-            else p = f3(t_xyz[3 * (size_t)i], t_xyz[3 * (size_t)i + 1], t_xyz[3 * (size_t)i + 2]);
-            const f3 d = p - start;
-            const float t = d.x * direc.x + d.y * direc.y + d.z * direc.z;
-            if ((d.x * d.x + d.y * d.y + d.z * d.z) - t * t > full_r2 * 1.02f + 1e-12f) continue;
-            const int kc = (int)floorf(t * inv_r);
-            bool hit = false;
-            for (int kk = max(kc - 2, 0); kk <= min(kc + 3, nsteps - 1) && !hit; ++kk) {
-                if (s_cnt[kk] < 2u) continue;
-                const float dist = s_dist[kk];
-                const f3 spt(start.x + dist * direc.x, start.y + dist * direc.y, start.z + dist * direc.z);
-                if (flann_d2(spt, p) < full_r2) hit = true;
+        int pos = 0, neg = 0;
+        const float *axyz = pass == 0 ? s_xyz : t_xyz;
+        for (uint32_t i0 = ab; i0 < ae; i0 += 64 * PEN_UNROLL) {
+            f3 raw[PEN_UNROLL];
+            bool ok[PEN_UNROLL];
+#pragma unroll
+            for (int u = 0; u < PEN_UNROLL; ++u) {
+                const uint32_t i = i0 + u * 64 + lane;
+                ok[u] = i < ae;
+                const size_t ii = ok[u] ? i : ae - 1;
+                raw[u] = f3(axyz[3 * ii], axyz[3 * ii + 1], axyz[3 * ii + 2]);
             }
-            if (hit) {
-                const float td = pl0 * p.x + pl1 * p.y + pl2 * p.z + pl3;
-                if (fabsf(td) > min_distance) { if (td >= 0) ++lpos; else ++lneg; }
+#pragma unroll
+            for (int u = 0; u < PEN_UNROLL; ++u) {
+                if (!ok[u]) continue;
+                const f3 p = pass == 0 ? pcl_xform(T12, raw[u]) : raw[u];
+                const f3 d = p - start;
+                const float t = d.x * direc.x + d.y * direc.y + d.z * direc.z;
+                if ((d.x * d.x + d.y * d.y + d.z * d.z) - t * t > full_r2 * 1.02f + 1e-12f) continue;
+                const int kc = (int)floorf(t * inv_r);
+                bool hit = false;
+                for (int kk = max(kc - 2, 0); kk <= min(kc + 3, nsteps - 1) && !hit; ++kk) {
+                    if (s_cnt[kk] < 2u) continue;
+                    const float dist = step_dist[kk];
+                    const f3 spt(start.x + dist * direc.x, start.y + dist * direc.y, start.z + dist * direc.z);
+                    if (flann_d2(spt, p) < full_r2) hit = true;
+                }
+                if (hit) {
+                    const float td = pl0 * p.x + pl1 * p.y + pl2 * p.z + pl3;
+                    if (fabsf(td) > min_distance) { if (td >= 0) ++pos; else ++neg; }
+                }
             }
         }
-        if (lpos) atomicAdd(&s_pos, lpos);
-        if (lneg) atomicAdd(&s_neg, lneg);
-        __syncthreads();
-        const int pos = s_pos, neg = s_neg;
-        __syncthreads();
+        for (int dlt = 32; dlt >= 1; dlt >>= 1) { pos += __shfl_xor(pos, dlt, 64); neg += __shfl_xor(neg, dlt, 64); }
+        __syncwarp();   // all reads of s_cnt done before the next pass clears it
         if (pass == 0) {
             if (pos < min_points || neg < min_points) return;
         } else {
@@ -202,7 +234,7 @@ __global__ __launch_bounds__(PEN_TPB) void k_pen_walk(const PenItem *__restrict_
         }
         if ((double)max(pos, neg) / (double)min(pos, neg + 1) > 5) return;
     }
-    if (threadIdx.x == 0) atomicOr(&cand_flags[it.k], 1u);
+    if (lane == 0) atomicOr(&cand_flags[it.k], 1u);
 }
 
 void penetration_filter(plade_ctx *ctx, const float *cand_rt_host, uint32_t K, const PlaneGeomHost &src,
@@ -232,29 +264,49 @@ void penetration_filter(plade_ctx *ctx, const float *cand_rt_host, uint32_t K, c
     const size_t total = (size_t)K * src.P * tgt.P;
     PLADE_REQUIRE(total < (1ull << 31), PLADE_ELIMIT, "penetration: too many (candidate, plane, plane) triples");
     PenItem *d_items = reinterpret_cast<PenItem *>(ctx->scratch[5].ensure(total * sizeof(PenItem) + 64));
-    uint32_t *d_ctr = reinterpret_cast<uint32_t *>(ctx->scratch[6].ensure(((size_t)K + 4) * 4));
-    HIP_TRY(hipMemsetAsync(d_ctr, 0, ((size_t)K + 4) * 4, ctx->stream));
-    uint32_t *d_n = d_ctr, *d_over = d_ctr + 1, *d_flags = d_ctr + 2;
-    hipLaunchKernelGGL(k_pen_setup, dim3(cdiv(total, 256)), dim3(256), 0, ctx->stream, tb, length_threshold,
-                       angle_threshold, d_items, d_n, (uint32_t)total);
-    uint32_t n_items = 0;
-    HIP_TRY(hipMemcpyAsync(&n_items, d_n, 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    ctx->stats.add("pen_items", (double)n_items);
-    if (n_items) {
-        // AreTwoPlanesPenetrable(..., searchRadius = lengthThreshold, minPointsNum = 10, minDistance = lengthThreshold / 2)
-        const float search_radius = (float)(double)length_threshold;
-        const float min_distance = (float)((double)length_threshold / 2);
-        hipLaunchKernelGGL(k_pen_walk, dim3(n_items), dim3(PEN_TPB), 0, ctx->stream, d_items, n_items, tb, src_pts.xyz.p,
-                           src_pts.d_off.p, tgt_pts.xyz.p, tgt_pts.d_off.p, search_radius, 10, min_distance, d_flags,
-                           d_over);
+    // AreTwoPlanesPenetrable(..., searchRadius = lengthThreshold, minPointsNum = 10, minDistance = lengthThreshold / 2)
+    const float search_radius = (float)(double)length_threshold;
+    const float min_distance = (float)((double)length_threshold / 2);
+    const uint32_t n_pairs = src.P * tgt.P;
+    // counters: [0] items, [1] overflow, [2 .. 2+K) candidate flags, then one count per plane pair; then the step table
+    const size_t n_ctr = (size_t)K + 2 + n_pairs;
+    uint32_t *d_ctr = reinterpret_cast<uint32_t *>(ctx->scratch[6].ensure((n_ctr + PEN_MAXS + 8 + n_pairs) * 4));
+    HIP_TRY(hipMemsetAsync(d_ctr, 0, n_ctr * 4, ctx->stream));
+    uint32_t *d_n = d_ctr, *d_over = d_ctr + 1, *d_flags = d_ctr + 2, *d_pair = d_ctr + 2 + K;
+    float *d_steps = reinterpret_cast<float *>(d_ctr + n_ctr);
+    uint32_t *d_order = reinterpret_cast<uint32_t *>(d_steps + PEN_MAXS + 2);
+    std::vector<uint32_t> order(n_pairs);
+    {
+        // an item's cost is proportional to the two plane clouds it streams
+        std::vector<uint32_t> w(n_pairs);
+        for (uint32_t i = 0; i < src.P; ++i)
+            for (uint32_t j = 0; j < tgt.P; ++j)
+                w[i * tgt.P + j] = (src_pts.off[i + 1] - src_pts.off[i]) + (tgt_pts.off[j + 1] - tgt_pts.off[j]);
+        for (uint32_t i = 0; i < n_pairs; ++i) order[i] = i;
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return w[a] > w[b]; });
     }
-    std::vector<uint32_t> out((size_t)K + 1);
-    HIP_TRY(hipMemcpyAsync(out.data(), d_over, ((size_t)K + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(d_order, order.data(), 4 * (size_t)n_pairs, hipMemcpyHostToDevice, ctx->stream));
+    std::vector<float> steps(PEN_MAXS + 1);
+    {
+        float dist = 0;
+        for (int i = 0; i <= PEN_MAXS; ++i) { steps[i] = dist; dist += search_radius; }  // util.cpp:1383
+    }
+    HIP_TRY(hipMemcpyAsync(d_steps, steps.data(), steps.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_pen_setup, dim3(cdiv(total, 256)), dim3(256), 0, ctx->stream, tb, length_threshold,
+                       angle_threshold, d_items, d_n, d_pair);
+    // a plane pair holds at most K items: grid.y covers the worst case, empty groups exit at once
+    ctx->ev_begin("pen_walk", 0.0);
+    hipLaunchKernelGGL(k_pen_walk, dim3(n_pairs, cdiv(K, PEN_G)), dim3(PEN_TPB), 0, ctx->stream, d_items, d_pair, d_order, tb, d_steps,
+                       src_pts.xyz.p, src_pts.d_off.p, tgt_pts.xyz.p, tgt_pts.d_off.p, search_radius, 10, min_distance, d_flags,
+                       d_over);
+    ctx->ev_end();
+    std::vector<uint32_t> out((size_t)K + 2);
+    HIP_TRY(hipMemcpyAsync(out.data(), d_ctr, ((size_t)K + 2) * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     HIP_TRY(hipGetLastError());
-    PLADE_REQUIRE(out[0] == 0, PLADE_ELIMIT, "penetration: intersection segment longer than 1024 search steps");
-    for (uint32_t k = 0; k < K; ++k) flags_out[k] = out[k + 1] ? 1 : 0;
+    ctx->stats.add("pen_items", (double)out[0]);
+    PLADE_REQUIRE(out[1] == 0, PLADE_ELIMIT, "penetration: intersection segment longer than 1024 search steps");
+    for (uint32_t k = 0; k < K; ++k) flags_out[k] = out[k + 2] ? 1 : 0;
 }
 
 }  // namespace plade
