@@ -234,8 +234,10 @@ void cluster_transforms(plade_ctx *ctx, CandidateSet &cs, float dist_threshold, 
     sort_pairs_u64(ctx, cs.ckeys.p, cs.ckeys2.p, cs.cvals.p, cs.cvals2.p, m, bx + by + bz);
     hipLaunchKernelGGL(k_cell_spans, dim3(nb), dim3(256), 0, ctx->stream, cs.rt.p, cs.cvals2.p, cs.ckeys2.p, m, g, cs.st.p,
                        cs.se.p, cs.spans.p);
+    ctx->ev_begin("cluster_edges", 0.0);   // latency / atomics bound, no HBM figure
     hipLaunchKernelGGL(k_cluster_edges, dim3(nb), dim3(256), 0, ctx->stream, cs.st.p, cs.se.p, cs.ckeys2.p, cs.spans.p, m, r2,
                        angle_gate, cs.parent.p);
+    ctx->ev_end();
     hipLaunchKernelGGL(k_flatten, dim3(cdiv(m + 1, 256)), dim3(256), 0, ctx->stream, cs.parent.p, m, cs.sizes_all.p, cs.flags.p);
     cs.n_clusters = compact_flags(ctx, cs.flags.p, m, cs.pos, cs.seeds);
     cs.sizes.ensure((size_t)cs.n_clusters + 1);

@@ -20,7 +20,7 @@ namespace plade {
 constexpr int TPB = 256;
 constexpr int PPT = 4;
 constexpr int TILE = TPB * PPT;  // 1024 points per block
-constexpr int HCHUNK = 32;
+constexpr int HCHUNK = 64;   // >= the RANSAC candidate pool (48): a re-score pass reads the cloud once
 
 __device__ __forceinline__ bool compatible(float4 pl, float px, float py, float pz, float qx, float qy, float qz,
                                            float eps, float cos_t) {
@@ -79,7 +79,9 @@ __device__ __forceinline__ void load_tile(Tile &t, const float *x, const float *
     }
 }
 
-// grid: (tiles, hypothesis chunks)
+// grid: (tiles, hypothesis chunks).  SUB: the cloud is the gathered RANSAC subset (shapeIndex looked up
+// through sub_index); a separate symbol so that profiles keep the two call shapes apart.
+template <bool SUB>
 __global__ __launch_bounds__(TPB) void k_score_multi(const float *__restrict__ x, const float *__restrict__ y,
                                                      const float *__restrict__ z, const float *__restrict__ nx,
                                                      const float *__restrict__ ny, const float *__restrict__ nz,
@@ -93,7 +95,7 @@ __global__ __launch_bounds__(TPB) void k_score_multi(const float *__restrict__ x
     const uint32_t hc = min((uint32_t)HCHUNK, h - h0);
     if (threadIdx.x < hc) s_pl[threadIdx.x] = planes[h0 + threadIdx.x];
     Tile t;
-    load_tile(t, x, y, z, nx, ny, nz, assigned, sub_index, n, blockIdx.x * TILE + threadIdx.x * PPT);
+    load_tile(t, x, y, z, nx, ny, nz, assigned, SUB ? sub_index : nullptr, n, blockIdx.x * TILE + threadIdx.x * PPT);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (uint32_t hh = 0; hh < hc; ++hh) {
@@ -211,9 +213,12 @@ __global__ __launch_bounds__(TPB) void k_compact(const uint8_t *__restrict__ mas
 }
 
 // batched form of k_compact: job blockIdx.y
-__global__ __launch_bounds__(TPB) void k_compact_batch(const CompactJob *__restrict__ jobs, uint32_t nb) {
+__global__ __launch_bounds__(TPB) void k_compact_batch(const CompactJob *__restrict__ jobs, uint32_t nb,
+                                                       const float *__restrict__ px, const float *__restrict__ py,
+                                                       const float *__restrict__ pz) {
     __shared__ uint32_t s_w[TPB / 64];
     __shared__ uint32_t s_base[TPB / 64];
+    __shared__ float s_mm[4][8];
     const CompactJob jb = jobs[blockIdx.y];
     if (jb.skip && *jb.skip) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -236,12 +241,33 @@ __global__ __launch_bounds__(TPB) void k_compact_batch(const CompactJob *__restr
     for (int w = 0; w < wave; ++w) off += s_w[w];
     if (blockIdx.x == nb - 1 && threadIdx.x == TPB - 1) *jb.total = off + c;
     const uint32_t first = blockIdx.x * TILE + threadIdx.x * PPT;
+    if (!jb.frame) {
+#pragma unroll
+        for (int k = 0; k < PPT; ++k)
+            if (m & (1u << k)) {
+                uint32_t i = first + k;
+                jb.out[off++] = jb.values ? jb.values[i] : i;
+            }
+        return;
+    }
+    const float ox = jb.frame[0], oy = jb.frame[1], oz = jb.frame[2];
+    const float a00 = jb.frame[4], a01 = jb.frame[5], a02 = jb.frame[6], a10 = jb.frame[7], a11 = jb.frame[8], a12 = jb.frame[9];
+    float mn[2] = {INFINITY, INFINITY}, mx[2] = {-INFINITY, -INFINITY};
 #pragma unroll
     for (int k = 0; k < PPT; ++k)
         if (m & (1u << k)) {
-            uint32_t i = first + k;
-            jb.out[off++] = jb.values ? jb.values[i] : i;
+            const uint32_t i = first + k;
+            const uint32_t p = jb.values ? jb.values[i] : i;
+            const float pp[3] = {px[p] - ox, py[p] - oy, pz[p] - oz};
+            const float u = pp[0] * a00 + pp[1] * a01 + pp[2] * a02;
+            const float v = pp[0] * a10 + pp[1] * a11 + pp[2] * a12;
+            jb.out[off] = p;
+            jb.uv[off] = make_float2(u, v);
+            ++off;
+            mn[0] = fminf(mn[0], u); mn[1] = fminf(mn[1], v);
+            mx[0] = fmaxf(mx[0], u); mx[1] = fmaxf(mx[1], v);
         }
+    block_minmax_commit<2>(mn, mx, jb.bbox, s_mm);
 }
 
 void score_mark_batch(plade_ctx *ctx, const float *x, const float *y, const float *z, const float *nx, const float *ny,
@@ -257,10 +283,11 @@ void score_mark_batch(plade_ctx *ctx, const float *x, const float *y, const floa
     ctx->ev_end();
 }
 
-void compact_batch(plade_ctx *ctx, uint32_t n, const CompactJob *jobs_dev, uint32_t nj) {
+void compact_batch(plade_ctx *ctx, uint32_t n, const CompactJob *jobs_dev, uint32_t nj, const float *x, const float *y,
+                   const float *z) {
     const uint32_t nb = cdiv(n, TILE);
     if (nb == 0 || nj == 0) return;
-    hipLaunchKernelGGL(k_compact_batch, dim3(nb, nj), dim3(TPB), 0, ctx->stream, jobs_dev, nb);
+    hipLaunchKernelGGL(k_compact_batch, dim3(nb, nj), dim3(TPB), 0, ctx->stream, jobs_dev, nb, x, y, z);
 }
 
 void score_multi(plade_ctx *ctx, const float *x, const float *y, const float *z, const float *nx, const float *ny,
@@ -271,8 +298,12 @@ void score_multi(plade_ctx *ctx, const float *x, const float *y, const float *z,
     dim3 grid(cdiv(n, TILE), cdiv(h, HCHUNK));
     // algorithmic bytes: 12 pos + 12 normal + 4 shapeIndex per point per pass
     ctx->ev_begin(sub_index ? "score_subset" : "score_multi", 28.0 * n);
-    hipLaunchKernelGGL(k_score_multi, grid, dim3(TPB), 0, ctx->stream, x, y, z, nx, ny, nz, assigned, sub_index, n,
-                       planes_dev, h, eps, cos_thresh, counts_dev);
+    if (sub_index)
+        hipLaunchKernelGGL(k_score_multi<true>, grid, dim3(TPB), 0, ctx->stream, x, y, z, nx, ny, nz, assigned, sub_index, n,
+                           planes_dev, h, eps, cos_thresh, counts_dev);
+    else
+        hipLaunchKernelGGL(k_score_multi<false>, grid, dim3(TPB), 0, ctx->stream, x, y, z, nx, ny, nz, assigned, sub_index, n,
+                           planes_dev, h, eps, cos_thresh, counts_dev);
     ctx->ev_end();
     HIP_TRY(hipGetLastError());
 }

@@ -26,6 +26,7 @@
 #include "prims.h"
 #include "voxel.h"
 #include <algorithm>
+#include <map>
 #include <memory>
 
 namespace plade {
@@ -246,32 +247,6 @@ __global__ void k_state_from_hyp(const ChainDev *__restrict__ chains) {
     *plane_out = *hyp;
 }
 
-// (u, v) parameters of the inliers + their bounding box (PlanePrimitiveShape::Parameters,
-// ransac/PlanePrimitiveShape.h:97-109; bbox BitmapPrimitiveShape.h:113-126)
-__global__ __launch_bounds__(256) void k_cc_params(CloudView c, const ChainDev *__restrict__ chains, int k) {
-    const ChainDev &C = chains[blockIdx.y];
-    PlaneState *st = C.st + k;
-    if (st->converged) return;
-    const uint32_t *__restrict__ idx = C.idxA, *__restrict__ count = C.cntA;
-    float2 *__restrict__ uv = C.uv;
-    const uint32_t m = *count;
-    if (blockIdx.x * blockDim.x >= m) return;  // whole block beyond the list (uniform)
-    __shared__ float s_lds[4][8];
-    float mn[2] = {INFINITY, INFINITY}, mx[2] = {-INFINITY, -INFINITY};
-    const float px = st->pos[0], py = st->pos[1], pz = st->pos[2];
-    const float a00 = st->a0[0], a01 = st->a0[1], a02 = st->a0[2], a10 = st->a1[0], a11 = st->a1[1], a12 = st->a1[2];
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
-        const uint32_t p = idx[i];
-        const float pp[3] = {c.x[p] - px, c.y[p] - py, c.z[p] - pz};
-        const float u = pp[0] * a00 + pp[1] * a01 + pp[2] * a02;
-        const float v = pp[0] * a10 + pp[1] * a11 + pp[2] * a12;
-        uv[i] = make_float2(u, v);
-        mn[0] = fminf(mn[0], u); mn[1] = fminf(mn[1], v);
-        mx[0] = fmaxf(mx[0], u); mx[1] = fmaxf(mx[1], v);
-    }
-    block_minmax_commit<2>(mn, mx, st->bb, s_lds);
-}
-
 constexpr uint32_t CC_MAXPIX = 1u << 20;
 
 // BitmapExtent (PlanePrimitiveShape.cpp:185-191)
@@ -325,7 +300,6 @@ __global__ __launch_bounds__(1024) void k_cc_label(const ChainDev *__restrict__ 
     PlaneState *st = C.st + k;
     uint8_t *__restrict__ g_bmp = C.bmp, *__restrict__ g_tmp = C.tmp;
     uint32_t *__restrict__ g_label = C.label, *__restrict__ g_sizes = C.sizes;
-    __shared__ int s_changed;
     __shared__ unsigned long long s_best;
     __shared__ uint32_t s_label[CC_LDS_PIX];
     __shared__ uint32_t s_sizes[CC_LDS_PIX];
@@ -361,36 +335,38 @@ __global__ __launch_bounds__(1024) void k_cc_label(const ChainDev *__restrict__ 
         }
         __syncthreads();
     }
+    // 8-connected labelling by lock-free union-find: every foreground pixel is united with its W, NW, N,
+    // NE neighbours; the smaller index always becomes the parent, so a component's root is its first
+    // pixel in raster order
     for (int p = threadIdx.x; p < npx; p += blockDim.x) { label[p] = bmp[p] ? (uint32_t)p : 0xffffffffu; sizes[p] = 0; }
     __syncthreads();
-    for (int iter = 0; iter < 4096; ++iter) {
-        if (threadIdx.x == 0) s_changed = 0;
-        __syncthreads();
-        for (int p = threadIdx.x; p < npx; p += blockDim.x) {
-            if (!bmp[p]) continue;
-            const int u = p % ue, v = p / ue;
-            const uint32_t lab = label[p];
-            uint32_t mn = lab;
-            for (int dv = -1; dv <= 1; ++dv)
-                for (int du = -1; du <= 1; ++du) {
-                    const int uu = u + du, vv = v + dv;
-                    if (uu < 0 || vv < 0 || uu >= ue || vv >= ve) continue;
-                    const int q = vv * ue + uu;
-                    if (bmp[q]) mn = min(mn, label[q]);
-                }
-            if (mn < lab) { atomicMin(&label[lab], mn); s_changed = 1; }
+    for (int p = threadIdx.x; p < npx; p += blockDim.x) {
+        if (!bmp[p]) continue;
+        const int u = p % ue, v = p / ue;
+        const int nb[4] = {u > 0 ? p - 1 : -1, (u > 0 && v > 0) ? p - ue - 1 : -1, v > 0 ? p - ue : -1,
+                           (u < ue - 1 && v > 0) ? p - ue + 1 : -1};
+        for (int e = 0; e < 4; ++e) {
+            if (nb[e] < 0 || !bmp[nb[e]]) continue;
+            uint32_t a = (uint32_t)p, b = (uint32_t)nb[e];
+            for (;;) {
+                while (label[a] != a) a = label[a];
+                while (label[b] != b) b = label[b];
+                if (a == b) break;
+                if (a < b) { const uint32_t t = a; a = b; b = t; }   // a > b: hang a under b
+                const uint32_t old = atomicMin(&label[a], b);
+                if (old == a) break;
+                a = old;
+            }
         }
-        __syncthreads();
-        for (int p = threadIdx.x; p < npx; p += blockDim.x) {
-            if (!bmp[p]) continue;
-            uint32_t r = label[p];
-            while (label[r] != r) r = label[r];
-            label[p] = r;
-        }
-        __syncthreads();
-        if (!s_changed) break;
-        __syncthreads();
     }
+    __syncthreads();
+    for (int p = threadIdx.x; p < npx; p += blockDim.x) {
+        if (!bmp[p]) continue;
+        uint32_t r = label[p];
+        while (label[r] != r) r = label[r];
+        label[p] = r;   // races only write the final root or an ancestor: harmless
+    }
+    __syncthreads();
     for (int p = threadIdx.x; p < npx; p += blockDim.x)
         if (bmp[p]) atomicAdd(&sizes[label[p]], 1u);
     if (threadIdx.x == 0) s_best = 0ull;
@@ -443,27 +419,38 @@ __global__ __launch_bounds__(256) void k_cc_select(const ChainDev *__restrict__ 
 // fp32 sequentially, which is the noisier of the two.
 constexpr int FIT_BLOCKS = 256;
 
-__global__ __launch_bounds__(256) void k_fit_partial(CloudView c, const ChainDev *__restrict__ chains, int k) {
-    __shared__ double s[4][12];
+// One pass over slot k's result list: the LS-fit moments (12 sums) and Candidate::WeightedScore
+// (ransac/Candidate.cpp:77-87 with weigh(), ScoreComputer.h:10-16) of the slot's plane.
+__global__ __launch_bounds__(256) void k_fit_partial(CloudView c, const ChainDev *__restrict__ chains, int k, float eps) {
+    __shared__ double s[4][13];
     const ChainDev &C = chains[blockIdx.y];
     const PlaneState *st = C.st + k;
     if (st->converged) return;
     const uint32_t *__restrict__ idx = C.idxS[k], *__restrict__ count = C.cntS + k;
     double *__restrict__ part = C.part;   // FIT_BLOCKS x 12
+    double *__restrict__ part_ws = C.part_ws + (size_t)k * FIT_BLOCKS;
     const uint32_t m = *count;
-    double a[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const float n0 = st->n[0], n1 = st->n[1], n2 = st->n[2], dist = st->dist;
+    double a[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
         const uint32_t p = idx[i];
-        const double x = c.x[p], y = c.y[p], z = c.z[p];
+        const float fx = c.x[p], fy = c.y[p], fz = c.z[p];
+        const double x = fx, y = fy, z = fz;
         a[0] += x; a[1] += y; a[2] += z;
         a[3] += x * x; a[4] += x * y; a[5] += x * z; a[6] += y * y; a[7] += y * z; a[8] += z * z;
         a[9] += c.nx[p]; a[10] += c.ny[p]; a[11] += c.nz[p];
+        float d = n0 * fx;
+        d += n1 * fy;
+        d += n2 * fz;
+        d = fabsf(dist - d);
+        a[12] += (double)expf(-d * d / (2.f / 9.f * eps * eps));
     }
-    for (int k = 0; k < 12; ++k)
-        for (int d = 32; d >= 1; d >>= 1) a[k] += __shfl_xor(a[k], d, 64);
-    if ((threadIdx.x & 63) == 0) for (int k = 0; k < 12; ++k) s[threadIdx.x >> 6][k] = a[k];
+    for (int q = 0; q < 13; ++q)
+        for (int d = 32; d >= 1; d >>= 1) a[q] += __shfl_xor(a[q], d, 64);
+    if ((threadIdx.x & 63) == 0) for (int q = 0; q < 13; ++q) s[threadIdx.x >> 6][q] = a[q];
     __syncthreads();
     if (threadIdx.x < 12) part[blockIdx.x * 12 + threadIdx.x] = (s[0][threadIdx.x] + s[1][threadIdx.x]) + (s[2][threadIdx.x] + s[3][threadIdx.x]);
+    if (threadIdx.x == 12) part_ws[blockIdx.x] = (s[0][12] + s[1][12]) + (s[2][12] + s[3][12]);
 }
 
 __device__ void jacobi3_d(double a[3][3], double d[3], double v[3][3]) {
@@ -486,15 +473,31 @@ __device__ void jacobi3_d(double a[3][3], double d[3], double v[3][3]) {
     for (int i = 0; i < 3; ++i) d[i] = a[i][i];
 }
 
+// sums the weighted-score partials of all four slots (one wave per slot; called by the last k_fit_final)
+__device__ void wscore_final(const ChainDev &C, double *s_ws /* 4, shared */) {
+    const double *__restrict__ part = C.part_ws;   // 4 x FIT_BLOCKS
+    PlaneState *st = C.st;
+    uint32_t *__restrict__ cnt = C.cntS;
+    const int slot = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double a = 0;
+    for (int b = lane; b < FIT_BLOCKS; b += 64) a += part[slot * FIT_BLOCKS + b];
+    for (int d = 32; d >= 1; d >>= 1) a += __shfl_xor(a, d, 64);
+    if (lane == 0) s_ws[slot] = a;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        for (int k = 0; k < 4; ++k) {
+            if (k > 0 && st[k].converged) { st[k].wscore = st[k - 1].wscore; cnt[k] = cnt[k - 1]; st[k].ue = st[k - 1].ue; st[k].ve = st[k - 1].ve; }
+            else st[k].wscore = s_ws[k];
+        }
+}
+
 // Sums the per-block partials of the index list `count` belongs to (fixed tree => deterministic);
 // nsum_out receives the sum of the list's point normals (orientation).  mode 0 additionally writes the
 // fitted plane into `st` (the NEXT slot's state) / plane_out.  One workgroup of FIT_BLOCKS lanes.
 // `cur` is the state of the slot whose list was just reduced; when the new plane is bitwise equal to
 // cur's plane the chain has converged: every later slot would reproduce cur's results, so they are
 // flagged and their kernels return immediately.
-__global__ __launch_bounds__(FIT_BLOCKS) void k_fit_final(const ChainDev *__restrict__ chains, int k) {
-    __shared__ double s_red[FIT_BLOCKS / 64][12];
-    const ChainDev &C = chains[blockIdx.x];
+__device__ void fit_final(const ChainDev &C, int k, double (*s_red)[12]) {
     const int kn = k < 3 ? k + 1 : 3, mode = k < 3 ? 0 : 1;
     const double *__restrict__ part = C.part;
     const uint32_t *__restrict__ count = C.cntS + k;
@@ -546,48 +549,15 @@ __global__ __launch_bounds__(FIT_BLOCKS) void k_fit_final(const ChainDev *__rest
                      st->pos[0] == cur->pos[0] && st->pos[1] == cur->pos[1] && st->pos[2] == cur->pos[2]) ? 1u : 0u;
 }
 
-// Candidate::WeightedScore (ransac/Candidate.cpp:77-87) with weigh() (ScoreComputer.h:10-16)
-__global__ __launch_bounds__(256) void k_wscore_partial(CloudView c, const ChainDev *__restrict__ chains, int k, float eps) {
-    __shared__ double s[4];
-    const ChainDev &C = chains[blockIdx.y];
-    const PlaneState *st = C.st + k;
-    if (st->converged) return;
-    const uint32_t *__restrict__ idx = C.idxS[k], *__restrict__ count = C.cntS + k;
-    double *__restrict__ part = C.part_ws + (size_t)k * FIT_BLOCKS;
-    const uint32_t m = *count;
-    const float n0 = st->n[0], n1 = st->n[1], n2 = st->n[2], dist = st->dist;
-    double acc = 0;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
-        const uint32_t p = idx[i];
-        float d = n0 * c.x[p];
-        d += n1 * c.y[p];
-        d += n2 * c.z[p];
-        d = fabsf(dist - d);
-        acc += (double)expf(-d * d / (2.f / 9.f * eps * eps));
-    }
-    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
-    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) part[blockIdx.x] = (s[0] + s[1]) + (s[2] + s[3]);
-}
-// one launch sums the partials of all four slots
-__global__ __launch_bounds__(256) void k_wscore_final(const ChainDev *__restrict__ chains) {
+__global__ __launch_bounds__(FIT_BLOCKS) void k_fit_final(const ChainDev *__restrict__ chains, int k) {
+    __shared__ double s_red[FIT_BLOCKS / 64][12];
     __shared__ double s_ws[4];
     const ChainDev &C = chains[blockIdx.x];
-    const double *__restrict__ part = C.part_ws;   // 4 x FIT_BLOCKS
-    PlaneState *st = C.st;
-    uint32_t *__restrict__ cnt = C.cntS;
-    const int slot = threadIdx.x >> 6, lane = threadIdx.x & 63;  // one wave per slot
-    double a = 0;
-    for (int b = lane; b < FIT_BLOCKS; b += 64) a += part[slot * FIT_BLOCKS + b];
-    for (int d = 32; d >= 1; d >>= 1) a += __shfl_xor(a, d, 64);
-    if (lane == 0) s_ws[slot] = a;
-    __syncthreads();
-    if (threadIdx.x == 0)
-        for (int k = 0; k < 4; ++k) {
-            if (k > 0 && st[k].converged) { st[k].wscore = st[k - 1].wscore; cnt[k] = cnt[k - 1]; st[k].ue = st[k - 1].ue; st[k].ve = st[k - 1].ve; }
-            else st[k].wscore = s_ws[k];
-        }
+    fit_final(C, k, s_red);
+    if (k == 3) {   // last slot: also close the four weighted scores
+        __syncthreads();
+        wscore_final(C, s_ws);
+    }
 }
 
 __global__ void k_assign(const uint32_t *__restrict__ idx, uint32_t m, int32_t id, int32_t *__restrict__ assigned) {
@@ -647,13 +617,15 @@ struct RansacWork {
     HBuf<char> pinned_accept;
     uint32_t B = 0;
     std::vector<uint64_t> tab_key;
-    // the acceptance sequence (~40 launches, all arguments in device memory) as hipGraphs, one per
-    // batch size: replayed instead of re-issuing the launches from the host
-    std::vector<hipGraphExec_t> exec;
-    std::vector<uint64_t> exec_key;
+    // the acceptance sequence (~33 launches, all arguments in device memory) as hipGraphs, one per
+    // (cloud size / thresholds, batch size): replayed instead of re-issuing the launches from the host
+    std::map<std::vector<uint64_t>, std::vector<hipGraphExec_t>> graphs;
+    std::vector<hipGraphExec_t> *exec = nullptr;   // the entry of the current detect call
     void drop_graphs() {
-        for (hipGraphExec_t e : exec) if (e) (void)hipGraphExecDestroy(e);
-        exec.clear();
+        for (auto &kv : graphs)
+            for (hipGraphExec_t e : kv.second) if (e) (void)hipGraphExecDestroy(e);
+        graphs.clear();
+        exec = nullptr;
     }
     ~RansacWork() { drop_graphs(); }
 };
@@ -684,17 +656,14 @@ void enqueue_accept(plade_ctx *ctx, RansacWork &W, const CloudView &cv, uint32_t
     for (int k = 0; k < 4; ++k) {
         score_mark_batch(ctx, c.x(), c.y(), c.z(), c.nx(), c.ny(), c.nz(), W.assigned.p, c.n, W.mark_jobs.p + (size_t)k * B, nc, eps3,
                          cos_t);
-        compact_batch(ctx, c.n, W.compact_jobs.p + (size_t)(2 * k) * B, nc);
-        hipLaunchKernelGGL(k_cc_params, dim3(std::min(nb, 256u), nc), dim3(256), 0, st, cv, tab, k);
+        compact_batch(ctx, c.n, W.compact_jobs.p + (size_t)(2 * k) * B, nc, c.x(), c.y(), c.z());
         hipLaunchKernelGGL(k_cc_raster, dim3(nb, nc), dim3(256), 0, st, tab, k, bitmap_eps);
         hipLaunchKernelGGL(k_cc_label, dim3(nc), dim3(1024), 0, st, tab, k, 1);
         hipLaunchKernelGGL(k_cc_select, dim3(nb4, nc), dim3(256), 0, st, tab, k);
         compact_batch(ctx, c.n, W.compact_jobs.p + (size_t)(2 * k + 1) * B, nc);
-        hipLaunchKernelGGL(k_wscore_partial, dim3(FIT_BLOCKS, nc), dim3(256), 0, st, cv, tab, k, eps3);
-        hipLaunchKernelGGL(k_fit_partial, dim3(FIT_BLOCKS, nc), dim3(256), 0, st, cv, tab, k);
+        hipLaunchKernelGGL(k_fit_partial, dim3(FIT_BLOCKS, nc), dim3(256), 0, st, cv, tab, k, eps3);
         hipLaunchKernelGGL(k_fit_final, dim3(nc), dim3(FIT_BLOCKS), 0, st, tab, k);
     }
-    hipLaunchKernelGGL(k_wscore_final, dim3(nc), dim3(256), 0, st, tab);
 }
 
 void chains_prepare(plade_ctx *ctx, RansacWork &W, uint32_t B, uint32_t n, float eps3, float cos_t, float bitmap_eps) {
@@ -735,8 +704,10 @@ void chains_prepare(plade_ctx *ctx, RansacWork &W, uint32_t B, uint32_t n, float
         for (int k = 0; k < 4; ++k) {
             const uint32_t *skip = &D.st[k].converged;
             mj[(size_t)k * B + b] = MarkJob{D.plane_cur + k, C.cs.masks.p, C.cs.block_counts.p, skip};
-            cj[(size_t)(2 * k) * B + b] = CompactJob{C.cs.masks.p, C.cs.block_counts.p, nullptr, D.idxA, D.cntA, skip};
-            cj[(size_t)(2 * k + 1) * B + b] = CompactJob{D.masks2, D.bc2, D.idxA, D.idxS[k], D.cntS + k, skip};
+            // score list + its (u, v) parameters in slot k's plane frame (PlaneState: pos, dist, a0, a1, bb)
+            cj[(size_t)(2 * k) * B + b] = CompactJob{C.cs.masks.p, C.cs.block_counts.p, nullptr, D.idxA, D.cntA, skip,
+                                                     D.st[k].pos, D.uv, D.st[k].bb};
+            cj[(size_t)(2 * k + 1) * B + b] = CompactJob{D.masks2, D.bc2, D.idxA, D.idxS[k], D.cntS + k, skip, nullptr, nullptr, nullptr};
         }
     }
     // (re)upload the tables only when a pointer moved
@@ -761,24 +732,25 @@ void chains_prepare(plade_ctx *ctx, RansacWork &W, uint32_t B, uint32_t n, float
     auto bits = [](float f) { uint32_t u; memcpy(&u, &f, 4); return (uint64_t)u; };
     std::vector<uint64_t> gkey = {n, B, bits(eps3), bits(cos_t), bits(bitmap_eps), (uint64_t)W.sorted.soa.p, (uint64_t)W.assigned.p,
                                   (uint64_t)ctx->stream};
-    if (gkey != W.exec_key || ctx->profiling() || getenv("PLADE_NO_GRAPH")) W.drop_graphs();
-    W.exec_key = gkey;
+    if (W.graphs.size() > 16) W.drop_graphs();   // bounded cache (a batch of differently sized clouds)
+    W.exec = &W.graphs[gkey];
     (void)fresh_bitmap;
 }
 
 // graph for a batch of nc chains (captured lazily)
 hipGraphExec_t accept_graph(plade_ctx *ctx, RansacWork &W, const CloudView &cv, uint32_t nc, float eps3, float cos_t, float bitmap_eps) {
     if (ctx->profiling() || getenv("PLADE_NO_GRAPH")) return nullptr;
-    if (W.exec.size() <= nc) W.exec.resize(nc + 1, nullptr);
-    if (!W.exec[nc]) {
+    std::vector<hipGraphExec_t> &ex = *W.exec;
+    if (ex.size() <= nc) ex.resize(nc + 1, nullptr);
+    if (!ex[nc]) {
         hipGraph_t graph = nullptr;
         HIP_TRY(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
         enqueue_accept(ctx, W, cv, nc, eps3, cos_t, bitmap_eps);
         HIP_TRY(hipStreamEndCapture(ctx->stream, &graph));
-        HIP_TRY(hipGraphInstantiate(&W.exec[nc], graph, nullptr, nullptr, 0));
+        HIP_TRY(hipGraphInstantiate(&ex[nc], graph, nullptr, nullptr, 0));
         (void)hipGraphDestroy(graph);
     }
-    return W.exec[nc];
+    return ex[nc];
 }
 
 inline bool same_plane(const float4 &a, const float4 &b, float eps) {
@@ -815,6 +787,7 @@ inline bool conflict_free(const float4 &a, const float4 &b, float eps, float cos
 
 void ransac_detect(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const RansacParams &rp, PlaneSetOut &out) {
     const uint32_t n = cloud.n;
+    Clock::time_point t_setup0 = Clock::now();
     out.coef.clear(); out.offsets.assign(1, 0); out.idx.clear(); out.d_idx = nullptr;
     out.n_score_passes = 0; out.remaining = n;
     if (n < 3) return;
@@ -866,6 +839,8 @@ void ransac_detect(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const R
     if (const char *e = getenv("PLADE_RANSAC_CHAINS")) B = (uint32_t)std::max(1, std::min(16, atoi(e)));
     chains_prepare(ctx, W, B, n, eps3, cos_t, bitmap_eps);
 
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->stats.add("ransac_t_setup", secs_since(t_setup0));
     const int min_level = 1, max_level = 8;
     const float levels = (float)(max_level - min_level + 1);
     auto fail_prob = [&](float cand_size, float n_pts, float drawn) {  // RansacShapeDetector.h:61-67 (reqSamples = 3)

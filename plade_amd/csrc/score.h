@@ -46,10 +46,17 @@ struct CompactJob {
     uint32_t *out;
     uint32_t *total;
     const uint32_t *skip;      // nullable
+    // optional fused plane parametrisation of the emitted points (PlanePrimitiveShape::Parameters,
+    // ransac/PlanePrimitiveShape.h:97-109): uv[j] of the j-th emitted index and the (u, v) bounding box
+    const float *frame;        // nullable: pos(3), unused(1), axis0(3), axis1(3)
+    float2 *uv;
+    int *bbox;                 // ordered-int min u, min v, max u, max v
 };
 void score_mark_batch(plade_ctx *ctx, const float *x, const float *y, const float *z, const float *nx, const float *ny,
                       const float *nz, const int32_t *assigned, uint32_t n, const MarkJob *jobs_dev, uint32_t nj, float eps,
                       float cos_thresh);
-void compact_batch(plade_ctx *ctx, uint32_t n, const CompactJob *jobs_dev, uint32_t nj);
+// x, y, z: the cloud the indices refer to (only read by jobs with a frame)
+void compact_batch(plade_ctx *ctx, uint32_t n, const CompactJob *jobs_dev, uint32_t nj, const float *x = nullptr,
+                   const float *y = nullptr, const float *z = nullptr);
 
 }  // namespace plade
