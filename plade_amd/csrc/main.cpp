@@ -2,8 +2,10 @@
 // arguments, same result-file grammar, same exit codes.
 //   PLADE target.ply source.ply result.txt      register one pair
 //   PLADE file_pairs.txt result.txt             batch mode
-// Batch mode additionally shards the pairs over the GPUs of the node when PLADE_GPUS=N is set (one
-// worker thread + one plade_ctx per GPU; pairs are independent, results are written in input order).
+// Batch mode additionally shards the pairs over the GPUs of the node when PLADE_GPUS=N is set, with
+// PLADE_INFLIGHT=M (default 4) worker threads per GPU, each with its own plade_ctx: pairs are independent,
+// one registration alone is latency-bound, and PLY parsing of one pair overlaps the GPU work of the others.
+// Results are written in input order.
 #include "plade.h"
 
 #include <atomic>
@@ -91,6 +93,9 @@ int main(int argc, char **argv) {
     }
     const char *env = getenv("PLADE_GPUS");
     const int n_gpus = std::max(1, env ? atoi(env) : 1);
+    const char *env_m = getenv("PLADE_INFLIGHT");
+    const int per_gpu = std::max(1, env_m ? atoi(env_m) : 4);
+    const int n_workers = (int)std::min<size_t>((size_t)n_gpus * per_gpu, std::max<size_t>(pairs.size(), 1));
     std::vector<Eigen::Matrix<float, 4, 4>> results(pairs.size());
     std::vector<char> status(pairs.size(), 0);
     std::atomic<size_t> next(0);
@@ -102,10 +107,10 @@ int main(int argc, char **argv) {
             status[i] = registration(results[i], pairs[i].first, pairs[i].second) ? 1 : 0;
         }
     };
-    if (n_gpus == 1) worker(0);
+    if (n_workers == 1) worker(0);
     else {
         std::vector<std::thread> th;
-        for (int g = 0; g < n_gpus; ++g) th.emplace_back(worker, g);
+        for (int w = 0; w < n_workers; ++w) th.emplace_back(worker, w % n_gpus);
         for (auto &t : th) t.join();
     }
     int count_success = 0, count_failure = 0;
