@@ -66,6 +66,21 @@ int plade_score_planes(plade_ctx *ctx, const float *pos_nrm, const int32_t *shap
                        const float *planes, uint32_t h, float eps, float cos_thresh,
                        uint32_t *counts, uint32_t *idx_out, uint32_t cap);
 
+/* ---- seam S1c: connected component + LS refit of one plane candidate ---------------------
+ * Replaces PlanePrimitiveShape/BitmapPrimitiveShape::ConnectedComponent
+ * (ransac/BitmapPrimitiveShape.cpp:97-265, PlanePrimitiveShape.cpp:164-207), followed by
+ * PlanePrimitiveShape::LSFit (PlanePrimitiveShape.cpp:98-111 -> Plane::LeastSquaresFit, Plane.cpp:169-176)
+ * and Candidate::WeightedScore (Candidate.cpp:77-87) on the kept points -- the per-slot body of the
+ * acceptance loop RansacShapeDetector.cpp:618-656.
+ * plane = Plane(point, normal); idx: m distinct point indices (the score list, any order); kept_out (cap m):
+ * the indices of the largest 8-connected bitmap component in list order, n_kept their number;
+ * fit_out[7] = LS plane of the kept points (unit normal, mean, dist = mean.normal);
+ * wscore_out = sum over kept points of exp(-d^2 / (2/9 w_eps^2)) against the INPUT plane. */
+int plade_plane_component(plade_ctx *ctx, const float *pos_nrm, uint32_t n, const float normal[3],
+                          const float point[3], const int32_t *idx, uint32_t m, float bitmap_eps,
+                          int closing_filter, float w_eps, int32_t *kept_out, uint32_t *n_kept,
+                          float *fit_out, double *wscore_out);
+
 /* ---- seam S1b: whole plane-extraction stage --------------------------------------------
  * Replaces PlaneExtraction::detect (code/PLADE/plane_extraction.cpp:173-200 -> :61-168 ->
  * RansacShapeDetector::Detect, ransac/RansacShapeDetector.cpp:455-907).

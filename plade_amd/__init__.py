@@ -20,7 +20,7 @@ ABI_SYMBOLS = [
     "plade_set_params", "plade_score_planes", "plade_extract_planes", "plade_match_descriptors",
     "plade_overlap_counts", "plade_average_spacing", "plade_voxel_downsample", "plade_registration_planes",
     "plade_registration", "plade_registration_minsupport", "plade_cloud_upload", "plade_cloud_free",
-    "plade_registration_dev", "plade_dump_get", "plade_stats_get", "plade_kernel_time",
+    "plade_registration_dev", "plade_dump_get", "plade_stats_get", "plade_kernel_time", "plade_plane_component",
 ]
 
 
@@ -81,6 +81,7 @@ def load_library(path=LIB_PATH):
     sig("plade_dump_get", argtypes=[p, C.c_char_p, C.POINTER(p), C.POINTER(C.c_int64)])
     sig("plade_stats_get", argtypes=[p, C.POINTER(C.c_char_p), C.POINTER(C.POINTER(C.c_double)), C.POINTER(i32)])
     sig("plade_kernel_time", argtypes=[p, C.c_char_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)])
+    sig("plade_plane_component", argtypes=[p, p, u32, p, p, p, u32, f, C.c_int, f, p, p, p, p])
     _lib = L
     return L
 
@@ -183,6 +184,18 @@ class Context:
         if want_indices:
             return counts, [idx[j, : counts[j]].astype(np.int32) for j in range(h)]
         return counts
+
+    def plane_component(self, pos_nrm, normal, point, idx, bitmap_eps, closing_filter, w_eps):
+        """Seam S1c: (kept indices, LS fit[7], weighted score) of one plane candidate's score list."""
+        pn, nn, pp, ii = _f32(pos_nrm), _f32(normal), _f32(point), _i32(idx)
+        kept = np.zeros(max(len(ii), 1), np.int32)
+        nk = C.c_uint32()
+        fit = np.zeros(7, np.float32)
+        ws = C.c_double()
+        self._check(self.L.plade_plane_component(self.h, _ptr(pn), len(pn), _ptr(nn), _ptr(pp), _ptr(ii), len(ii),
+                                                 C.c_float(bitmap_eps), int(closing_filter), C.c_float(w_eps), _ptr(kept),
+                                                 C.byref(nk), _ptr(fit), C.byref(ws)))
+        return kept[: nk.value].copy(), fit, ws.value
 
     def extract_planes(self, pos_nrm, min_support, dist_rel=0.005, bitmap_rel=0.02, cos_thresh=0.8,
                        overlook=0.001, max_planes=256):

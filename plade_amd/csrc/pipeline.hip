@@ -210,6 +210,9 @@ bool run_registration(plade_ctx *ctx, RegistrationWork &W, const CloudDev &tgt, 
     for (int i = 0; i < 16; ++i) T16_out[i] = (i % 5 == 0) ? 1.f : 0.f;
     const int max_candidates = ctx->params.max_candidates;
     Side &M = W.M, &C = W.C;
+    // without planes there are no intersection lines, no descriptors and no candidate: the reference
+    // ends in "no matched result found" (plade.cpp:537-540)
+    if (tp.P == 0 || sp.P == 0) return false;
 
     // plade.cpp:41
     const float average_space = spacing_or_null ? *spacing_or_null : source_spacing(ctx, W, src);

@@ -36,6 +36,17 @@ struct RansacWork;
 RansacWork *ransac_work_create();
 void ransac_work_destroy(RansacWork *w);
 
+// One slot of the acceptance chain on a caller-given score list (seam S1c): connected component of the
+// list in the plane's bitmap, LS fit of the kept points, weighted score against the input plane.
+struct ComponentOut {
+    std::vector<int32_t> kept;
+    float fit[7];      // unit normal, mean, dist
+    double wscore;
+    uint32_t err;      // 1: bitmap too large
+};
+void plane_component(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const float normal[3], const float point[3],
+                     const int32_t *idx, uint32_t m, float bitmap_eps, bool closing_filter, float w_eps, ComponentOut &out);
+
 // PlaneExtraction::detect (code/PLADE/plane_extraction.cpp:173-200)
 void ransac_detect(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const RansacParams &rp, PlaneSetOut &out);
 

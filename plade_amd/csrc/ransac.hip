@@ -612,6 +612,7 @@ struct RansacWork {
     DBuf<char> accept_block;         // B x ACCEPT_STRIDE: one D2H copy per batch
     DBuf<float4> cand_in;            // B x (hypothesis, position): one H2D copy per batch
     DBuf<ChainDev> chain_tab;
+    std::vector<ChainDev> h_tab;
     DBuf<MarkJob> mark_jobs;         // [slot][chain]
     DBuf<CompactJob> compact_jobs;   // [slot][A|S][chain]
     HBuf<char> pinned_accept;
@@ -720,6 +721,7 @@ void chains_prepare(plade_ctx *ctx, RansacWork &W, uint32_t B, uint32_t n, float
     key.push_back((uint64_t)W.chains[0]->cs.masks.p);
     W.chain_tab.ensure(B); W.mark_jobs.ensure(4 * (size_t)B); W.compact_jobs.ensure(8 * (size_t)B);
     key.push_back((uint64_t)W.chain_tab.p); key.push_back((uint64_t)W.mark_jobs.p); key.push_back((uint64_t)W.compact_jobs.p);
+    W.h_tab = tab;
     if (key != W.tab_key) {
         HIP_TRY(hipMemcpyAsync(W.chain_tab.p, tab.data(), B * sizeof(ChainDev), hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(hipMemcpyAsync(W.mark_jobs.p, mj.data(), mj.size() * sizeof(MarkJob), hipMemcpyHostToDevice, ctx->stream));
@@ -784,6 +786,70 @@ inline bool conflict_free(const float4 &a, const float4 &b, float eps, float cos
 }
 
 }  // namespace
+
+__global__ void k_list_masks(uint32_t m, uint32_t nb, uint8_t *__restrict__ masks, uint32_t *__restrict__ block_counts) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;   // one mask byte per 4 list positions
+    if (t < nb * 256) {
+        const uint32_t first = t * 4;
+        masks[t] = first >= m ? 0 : (m - first >= 4 ? 0xF : (uint8_t)((1u << (m - first)) - 1));
+    }
+    if (t < nb) { const uint32_t b0 = t * 1024; block_counts[t] = b0 >= m ? 0 : min(1024u, m - b0); }
+}
+
+void plane_component(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const float normal[3], const float point[3],
+                     const int32_t *idx, uint32_t m, float bitmap_eps, bool closing_filter, float w_eps, ComponentOut &out) {
+    out.kept.clear();
+    out.wscore = 0;
+    out.err = 0;
+    for (float &f : out.fit) f = 0.f;
+    const uint32_t n = cloud.n;
+    PLADE_REQUIRE(m <= n && bitmap_eps > 0.f, PLADE_EINVAL, "plane_component: bad argument");
+    if (m == 0) return;
+    chains_prepare(ctx, W, 1, n, 0.f, 0.f, 0.f);
+    const ChainDev &D = W.h_tab[0];
+    Chain &C = *W.chains[0];
+    hipStream_t st = ctx->stream;
+    CloudView cv{cloud.x(), cloud.y(), cloud.z(), cloud.nx(), cloud.ny(), cloud.nz(), n};
+    // Plane(point, normal): dist = point . normal with Vec3f::dot's left-to-right sum (Plane.cpp:21-26)
+    float dist = point[0] * normal[0];
+    dist += point[1] * normal[1];
+    dist += point[2] * normal[2];
+    const float4 two[2] = {make_float4(normal[0], normal[1], normal[2], dist), make_float4(point[0], point[1], point[2], 0.f)};
+    HIP_TRY(hipMemcpyAsync(W.cand_in.p, two, 32, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_state_from_hyp, dim3(1), dim3(64), 0, st, W.chain_tab.p);
+    // the list as an all-ones mask over list positions, values = the caller's indices
+    DBuf<uint32_t> d_idx;
+    d_idx.ensure((size_t)n + 4);
+    HIP_TRY(hipMemcpyAsync(d_idx.p, idx, 4 * (size_t)m, hipMemcpyHostToDevice, st));
+    const uint32_t nb4 = cdiv(n, 1024);
+    hipLaunchKernelGGL(k_list_masks, dim3(cdiv(nb4 * 256, 256)), dim3(256), 0, st, m, nb4, C.cs.masks.p, C.cs.block_counts.p);
+    DBuf<CompactJob> job;
+    job.ensure(1);
+    const CompactJob hj{C.cs.masks.p, C.cs.block_counts.p, d_idx.p, D.idxA, D.cntA, nullptr, D.st[0].pos, D.uv, D.st[0].bb};
+    HIP_TRY(hipMemcpyAsync(job.p, &hj, sizeof(hj), hipMemcpyHostToDevice, st));
+    compact_batch(ctx, n, job.p, 1, cv.x, cv.y, cv.z);
+    hipLaunchKernelGGL(k_cc_raster, dim3(cdiv(n, 256), 1), dim3(256), 0, st, W.chain_tab.p, 0, bitmap_eps);
+    hipLaunchKernelGGL(k_cc_label, dim3(1), dim3(1024), 0, st, W.chain_tab.p, 0, closing_filter ? 1 : 0);
+    hipLaunchKernelGGL(k_cc_select, dim3(nb4, 1), dim3(256), 0, st, W.chain_tab.p, 0);
+    compact_batch(ctx, n, W.compact_jobs.p + (size_t)1 * W.B, 1);
+    hipLaunchKernelGGL(k_fit_partial, dim3(FIT_BLOCKS, 1), dim3(256), 0, st, cv, W.chain_tab.p, 0, w_eps);
+    hipLaunchKernelGGL(k_fit_final, dim3(1), dim3(FIT_BLOCKS), 0, st, W.chain_tab.p, 0);
+    PlaneState hst[2];
+    uint32_t nk = 0;
+    std::vector<double> ws(FIT_BLOCKS);
+    HIP_TRY(hipMemcpyAsync(hst, D.st, 2 * sizeof(PlaneState), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(&nk, D.cntS, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(ws.data(), D.part_ws, 8 * FIT_BLOCKS, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipGetLastError());
+    out.err = hst[0].err;
+    if (out.err) return;
+    out.kept.resize(nk);
+    if (nk) HIP_TRY(hipMemcpy(out.kept.data(), D.idxS[0], 4 * (size_t)nk, hipMemcpyDeviceToHost));
+    for (int k = 0; k < 3; ++k) { out.fit[k] = hst[1].n[k]; out.fit[3 + k] = hst[1].pos[k]; }
+    out.fit[6] = hst[1].dist;
+    for (int b = 0; b < FIT_BLOCKS; ++b) out.wscore += ws[b];
+}
 
 void ransac_detect(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const RansacParams &rp, PlaneSetOut &out) {
     const uint32_t n = cloud.n;

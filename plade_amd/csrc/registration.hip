@@ -240,6 +240,34 @@ extern "C" int plade_registration_minsupport(plade_ctx *ctx, const float *tgt_po
     });
 }
 
+extern "C" int plade_plane_component(plade_ctx *ctx, const float *pos_nrm, uint32_t n, const float *normal, const float *point,
+                                     const int32_t *idx, uint32_t m, float bitmap_eps, int closing_filter, float w_eps,
+                                     int32_t *kept_out, uint32_t *n_kept, float *fit_out, double *wscore_out) {
+    return guarded(ctx, [&]() -> int {
+        PLADE_REQUIRE(pos_nrm && normal && point && (idx || !m) && n_kept && (kept_out || !m), PLADE_EINVAL,
+                      "plade_plane_component: null argument");
+        {
+            std::vector<uint8_t> seen(n, 0);
+            for (uint32_t i = 0; i < m; ++i) {
+                PLADE_REQUIRE(idx[i] >= 0 && (uint32_t)idx[i] < n && !seen[idx[i]], PLADE_EINVAL,
+                              "plade_plane_component: indices must be distinct and inside the cloud");
+                seen[idx[i]] = 1;
+            }
+        }
+        CloudDev cloud;
+        cloud_upload(ctx, pos_nrm, n, cloud);
+        if (!ctx->ransac_work) ctx->ransac_work = ransac_work_create();
+        ComponentOut out;
+        plane_component(ctx, *ctx->ransac_work, cloud, normal, point, idx, m, bitmap_eps, closing_filter != 0, w_eps, out);
+        PLADE_REQUIRE(out.err == 0, PLADE_ELIMIT, "plane component: bitmap too large");
+        *n_kept = (uint32_t)out.kept.size();
+        if (!out.kept.empty()) memcpy(kept_out, out.kept.data(), 4 * out.kept.size());
+        if (fit_out) memcpy(fit_out, out.fit, sizeof(out.fit));
+        if (wscore_out) *wscore_out = out.wscore;
+        return PLADE_OK;
+    });
+}
+
 extern "C" int plade_kernel_time(plade_ctx *ctx, const char *which, int iters, double *avg_seconds,
                                  double *algorithmic_bytes_per_launch) {
     return guarded(ctx, [&]() -> int {

@@ -1,0 +1,82 @@
+"""The HIP path against the committed golden vectors (tests/golden/, produced by the REAL reference
+pieces -- libransac, libann, FLANN -- with tools/make_golden.py), called through the C ABI.
+Bit-exact integer outputs; no oracle involved."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(G, name), allow_pickle=False)
+
+
+def test_g1_score_lists_from_libransac(ctx):
+    """K1 vs ScorePrimitiveShapeVisitor of libransac: counts and ordered index lists."""
+    g = load("g1_score.npz")
+    ok = g["ok"].astype(bool)
+    planes = g["planes"][ok]
+    counts, lists = ctx.score_planes(g["cloud"], g["shape_index"], planes, float(g["eps"]), float(g["cos_t"]),
+                                     want_indices=True)
+    want_counts = g["counts"][ok]
+    assert np.array_equal(counts.astype(np.int32), want_counts)
+    pos = k = 0
+    for j, c in enumerate(g["counts"]):
+        if not ok[j]:
+            continue
+        assert np.array_equal(lists[k], g["lists"][pos:pos + c]), f"hypothesis {j}"
+        pos += c
+        k += 1
+
+
+def test_g5_descriptor_match_from_libann(ctx):
+    """K5 vs ANN's fixed-radius search: membership, (dist, index) order, fp64 distances."""
+    g = load("g5_ann.npz")
+    off, nbr, d2 = ctx.match_descriptors(g["qry"], g["tgt"], float(g["radius"]))
+    assert np.array_equal(off, g["offsets"])
+    assert np.array_equal(nbr, g["nbr"])
+    assert np.array_equal(d2.astype(np.float32), g["dist"])
+    for q in range(len(off) - 1):  # ANN's own tie order differs only inside exact ties
+        assert sorted(g["nbr_ann_order"][off[q]:off[q + 1]]) == sorted(nbr[off[q]:off[q + 1]])
+
+
+def test_g7_overlap_counts_from_flann(ctx):
+    """K8 vs FLANN radius searches composed as util.h:611-647."""
+    g = load("g7_overlap.npz")
+    got = ctx.overlap_counts(g["src"], g["tgt"], g["T"], g["centers"], float(g["radius"]), float(g["leaf"]))
+    assert np.array_equal(got, g["counts"])
+
+
+def test_g_radius_sets_via_overlap_kernel(ctx):
+    """FLANN radius-search membership (g_radius.npz) seen through K8: with the identity transform and
+    the query as the only source point, count = 1 iff the query has a target point within the radius."""
+    g = load("g_radius.npz")
+    r = float(g["radius"])
+    T = np.eye(4, dtype=np.float32)[None]
+    for q, size in zip(g["queries"][:20], g["sizes"][:20]):
+        got = ctx.overlap_counts(q[None, :], g["cloud"], T, q[None, :], np.float32(1e6), np.float32(r))
+        assert got[0] == (1 if size > 0 else 0)
+
+
+def test_g3_connected_component_lsfit_wscore_from_libransac(ctx):
+    """K2/K3 (seam S1c) vs libransac's ConnectedComponent, LSFit and WeightedScore."""
+    g = load("g3_cc.npz")
+    multi = 0
+    for i in range(int(g["n"])):
+        kept, fit, ws = ctx.plane_component(g[f"pts_{i}"], g[f"normal_{i}"], g[f"point_{i}"], g[f"idx_{i}"],
+                                            float(g[f"beps_{i}"]), bool(g[f"filt_{i}"]), 0.15)
+        assert np.array_equal(kept, g[f"kept_{i}"]), f"case {i}"       # integer output: bit-exact
+        multi += len(kept) < len(g[f"idx_{i}"])
+        if f"fit_{i}" in g.files:
+            ref = g[f"fit_{i}"]
+            sgn = np.sign(fit[:3] @ ref[:3])
+            # the reference accumulates mean/covariance sequentially in fp32 (GfxTL/Mean.h:31-46), the
+            # kernel in fp64 with a fixed tree: tolerance = the reference's own rounding noise
+            assert np.abs(sgn * fit[:3] - ref[:3]).max() < 5e-5
+            assert np.abs(fit[3:6] - ref[3:6]).max() < 1e-5
+            assert abs(ws - float(g[f"wscore_{i}"])) <= 1e-4 * max(1.0, float(g[f"wscore_{i}"]))
+    assert multi >= 6

@@ -1,0 +1,165 @@
+"""Full-size (BASELINE configs[2]: 1M-point clouds) checks of the HIP path through size-independent
+properties and a vectorised numpy restatement (IEEE fp32 element-wise, same operation order), where the
+C oracle would take minutes."""
+import numpy as np
+import pytest
+
+from plade_amd.synth import make_pair, sample_scene
+
+pytestmark = pytest.mark.gpu
+
+N = 1000000
+
+
+@pytest.fixture(scope="module")
+def big_pair():
+    return make_pair(N, seed=0)
+
+
+def _np_compatible(cloud, si, pl, eps, cos_t):
+    """FlatNormalThreshPointCompatibilityFunc in numpy fp32, left-to-right sums (ransac/basic.h:80-86)."""
+    f = np.float32
+    x, y, z, nx, ny, nz = (cloud[:, k] for k in range(6))
+    d = (f(pl[0]) * x + f(pl[1]) * y) + f(pl[2]) * z
+    dist = np.abs(f(pl[3]) - d)
+    nd = (f(pl[0]) * nx + f(pl[1]) * ny) + f(pl[2]) * nz
+    ok = (dist < f(eps)) & (np.abs(nd) >= f(cos_t))
+    if si is not None:
+        ok &= si == -1
+    return np.flatnonzero(ok).astype(np.int32)
+
+
+def test_k1_full_size_lists_equal_numpy_restatement(ctx, big_pair):
+    cloud = big_pair[0]
+    assert len(cloud) == N
+    rng = np.random.default_rng(1)
+    si = np.full(N, -1, np.int32)
+    si[rng.random(N) < 0.3] = 1
+    planes = []
+    for ax in range(3):   # the most populated axis-aligned planes of the scene (dist = n.p)
+        sel = cloud[np.abs(cloud[:, 3 + ax]) > 0.95, ax]
+        hist, edges = np.histogram(sel, bins=400)
+        for b in np.argsort(hist)[-2:]:
+            n = np.zeros(4, np.float32)
+            n[ax] = 1
+            n[3] = 0.5 * (edges[b] + edges[b + 1])
+            planes.append(n)
+    planes = np.array(planes + [[0.6, 0.8, 0, 1.0]], np.float32)
+    eps, cos_t = np.float32(0.05), np.float32(0.8)
+    counts, lists = ctx.score_planes(cloud, si, planes, eps, cos_t, want_indices=True)
+    total = 0
+    for j, pl in enumerate(planes):
+        ref = _np_compatible(cloud, si, pl, eps, cos_t)
+        assert counts[j] == len(ref) and np.array_equal(lists[j], ref), j
+        total += len(ref)
+    assert total > 100000
+    # partition: masked + complement = unmasked ; monotone in eps (lists nest)
+    c_all = ctx.score_planes(cloud, None, planes, eps, cos_t)
+    c_cmp = ctx.score_planes(cloud, np.where(si == -1, 1, -1).astype(np.int32), planes, eps, cos_t)
+    assert np.array_equal(c_all, counts + c_cmp)
+    c_wide, l_wide = ctx.score_planes(cloud, si, planes[:2], 3 * eps, cos_t, want_indices=True)
+    for j in range(2):
+        assert np.isin(lists[j], l_wide[j]).all() and c_wide[j] >= counts[j]
+
+
+def test_voxel_grid_full_size_properties(ctx, big_pair):
+    cloud = big_pair[0]
+    leaf = np.float32(0.05)
+    ds = ctx.voxel_downsample(cloud, leaf)
+    xyz = cloud[:, :3]
+    # one output per occupied leaf, in voxel-index order (voxel_grid.hpp:214-450 index arithmetic in fp32)
+    inv = np.float32(1.0) / leaf
+    mn = np.floor(xyz.min(0) * inv).astype(np.int64)
+    ijk = np.floor(xyz * inv).astype(np.int64) - mn
+    dims = ijk.max(0) + 1
+    key = ijk[:, 0] + ijk[:, 1] * dims[0] + ijk[:, 2] * dims[0] * dims[1]
+    ukey, cnt = np.unique(key, return_counts=True)
+    assert len(ds) == len(ukey)
+    # every centroid lies in the leaf it came from, outputs ordered by leaf index
+    dk = np.floor(ds.astype(np.float64) / float(leaf) + 1e-4).astype(np.int64) - mn
+    dk2 = np.floor(ds.astype(np.float64) / float(leaf) - 1e-4).astype(np.int64) - mn
+    k1 = dk[:, 0] + dk[:, 1] * dims[0] + dk[:, 2] * dims[0] * dims[1]
+    k2 = dk2[:, 0] + dk2[:, 1] * dims[0] + dk2[:, 2] * dims[0] * dims[1]
+    assert ((k1 == ukey) | (k2 == ukey)).all()
+    # count-weighted mean of the centroids = mean of the points (a checksum of checksums)
+    w = (ds.astype(np.float64) * cnt[:, None]).sum(0) / N
+    assert np.abs(w - xyz.astype(np.float64).mean(0)).max() < 1e-5
+    # a second pass over single-point leaves reproduces its input bit for bit (idempotence)
+    inner = ds[((k1 == ukey) & (k2 == ukey))]
+    again = ctx.voxel_downsample(inner, leaf)
+    assert again.shape == inner.shape and np.array_equal(again, inner)
+
+
+def test_match_full_table_symmetry(ctx):
+    """|a-b|^2 <= r^2 is symmetric: match(A,B) lists the transposed pairs of match(B,A), same fp64 distances."""
+    rng = np.random.default_rng(2)
+    a = (rng.random((6000, 8)) * 0.3).astype(np.float32)
+    b = (rng.random((9000, 8)) * 0.3).astype(np.float32)
+    b[:3000] = a[:3000] + rng.normal(0, 0.008, (3000, 8)).astype(np.float32)
+    o1, n1, d1 = ctx.match_descriptors(a, b)
+    o2, n2, d2 = ctx.match_descriptors(b, a)
+    q1 = np.repeat(np.arange(len(a)), np.diff(o1))
+    q2 = np.repeat(np.arange(len(b)), np.diff(o2))
+    p1 = set(zip(q1.tolist(), n1.tolist(), d1.tolist()))
+    p2 = set(zip(n2.tolist(), q2.tolist(), d2.tolist()))
+    assert len(p1) == len(n1) > 2000 and p1 == p2
+    for q in range(0, len(a), 97):   # ascending distance inside every list
+        seg = d1[o1[q]:o1[q + 1]]
+        assert (np.diff(seg) >= 0).all()
+
+
+def test_overlap_full_size_properties(ctx, big_pair):
+    tg = ctx.voxel_downsample(big_pair[0], 0.04)
+    assert len(tg) > 50000
+    leaf = np.float32(0.04)
+    I = np.eye(4, dtype=np.float32)
+    far = I.copy(); far[:3, 3] = 1000
+    shift = I.copy(); shift[0, 3] = 0.02
+    T = np.stack([I, far, shift])
+    c0 = tg.mean(0).astype(np.float32)
+    centers = np.stack([c0, c0 + 1000, c0])
+    big = np.float32(100.0)
+    got = ctx.overlap_counts(tg, tg, T, centers, big, leaf)
+    assert got[0] == len(tg)                 # every point finds itself (distance 0 < leaf^2)
+    assert got[1] == -1                      # empty coarse sphere (plade.cpp:556-557 -> ratio 0)
+    assert 0 < got[2] <= len(tg)
+    wider = ctx.overlap_counts(tg, tg, T[2:], centers[2:], big, np.float32(0.08))
+    assert wider[0] >= got[2]                # monotone in the inlier distance
+    small = ctx.overlap_counts(tg, tg, T[:1], centers[:1], np.float32(3.0), leaf)
+    assert 0 < small[0] < len(tg)            # the U-sphere restricts the target set
+
+
+def test_registration_full_size_ground_truth_determinism_equivariance(ctx, big_pair):
+    tg, sr, Tgt = big_pair
+    ok, T = ctx.registration(tg, sr)
+    assert ok and np.linalg.norm(T.astype(np.float64) - Tgt) < 1e-3
+    ok2, T2 = ctx.registration(tg, sr)
+    assert ok2 and np.array_equal(T, T2)     # fixed seed: bit-identical
+    ct, cs = ctx.upload(tg), ctx.upload(sr)
+    ok3, T3 = ctx.registration_dev(ct, cs)
+    ct.free(); cs.free()
+    assert ok3 and np.array_equal(T, T3)     # device-resident path = host-pointer path
+    # moving the source by a rigid G moves the answer to T G^-1
+    a = 0.4
+    G = np.eye(4)
+    G[:3, :3] = [[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]]
+    G[:3, 3] = [0.5, -1.0, 0.25]
+    sr2 = sr.copy()
+    sr2[:, :3] = (sr[:, :3].astype(np.float64) @ G[:3, :3].T + G[:3, 3]).astype(np.float32)
+    sr2[:, 3:] = (sr[:, 3:].astype(np.float64) @ G[:3, :3].T).astype(np.float32)
+    ok4, T4 = ctx.registration(tg, sr2)
+    assert ok4 and np.linalg.norm(T4.astype(np.float64) @ G - Tgt) < 2e-3
+
+
+def test_extract_planes_full_size_partition(ctx, oracle, big_pair):
+    cloud = big_pair[0]
+    coef, off, idx = ctx.extract_planes(cloud, 10000)
+    assert 10 <= len(coef) <= 60
+    assert len(np.unique(idx)) == len(idx) and idx.min() >= 0 and idx.max() < N
+    assert (np.diff(off) >= 10000).all()
+    eps3 = 3 * 0.005 * oracle.cloud_scale(cloud)
+    for p in range(len(coef)):
+        ids = idx[off[p]:off[p + 1]]
+        dist = np.abs(cloud[ids, :3] @ coef[p, :3] + coef[p, 3])
+        assert (dist < eps3 * 1.001).mean() > 0.999
+        assert cloud[ids, 3:].mean(0) @ coef[p, :3] > 0
