@@ -151,30 +151,29 @@ __global__ __launch_bounds__(256) void k_cell_spans(const float4 *__restrict__ r
         }
 }
 
-// one lane per node in cell order: lanes of a wave share cells, so their span walks read the same
-// addresses (broadcast) and stay converged
+// one lane per (node in cell order, neighbour row): nine lanes share a node, lanes of a wave share
+// cells, so their span walks read the same addresses (broadcast) and stay short
 __global__ __launch_bounds__(256) void k_cluster_edges(const float4 *__restrict__ st, const float4 *__restrict__ se,
                                                        const uint64_t *__restrict__ skeys, const uint2 *__restrict__ spans,
                                                        uint32_t m, float r2, float gate, uint32_t *__restrict__ parent) {
-    const uint32_t si = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t si = tid / 9u, r = tid - 9u * si;
     if (si >= m) return;
     const float4 pa = st[si];
     const float4 ea = se[si];
     const uint32_t a = __float_as_uint(pa.w);
     const f3 ta(pa.x, pa.y, pa.z);
     const uint32_t head = lower_bound_u64(skeys, m, skeys[si]);
-    for (int r = 0; r < 9; ++r) {
-        const uint2 sp = spans[(size_t)head * 9 + r];
-        for (uint32_t j = sp.x; j < sp.y; ++j) {
-            const float4 pb = st[j];
-            const uint32_t b = __float_as_uint(pb.w);
-            if (b >= a) continue;  // every undirected edge once
-            if (!(flann_d2(ta, f3(pb.x, pb.y, pb.z)) < r2)) continue;
-            const float4 eb = se[j];
-            const float t0 = ea.x - eb.x, t1 = ea.y - eb.y, t2 = ea.z - eb.z;
-            const float sq = (t0 * t0 + t1 * t1) + t2 * t2;  // Eigen::VectorXf(3).squaredNorm()
-            if (sq < gate) uf_union(parent, a, b);
-        }
+    const uint2 sp = spans[(size_t)head * 9 + r];
+    for (uint32_t j = sp.x; j < sp.y; ++j) {
+        const float4 pb = st[j];
+        const uint32_t b = __float_as_uint(pb.w);
+        if (b >= a) continue;  // every undirected edge once
+        if (!(flann_d2(ta, f3(pb.x, pb.y, pb.z)) < r2)) continue;
+        const float4 eb = se[j];
+        const float t0 = ea.x - eb.x, t1 = ea.y - eb.y, t2 = ea.z - eb.z;
+        const float sq = (t0 * t0 + t1 * t1) + t2 * t2;  // Eigen::VectorXf(3).squaredNorm()
+        if (sq < gate) uf_union(parent, a, b);
     }
 }
 
@@ -235,8 +234,8 @@ void cluster_transforms(plade_ctx *ctx, CandidateSet &cs, float dist_threshold, 
     hipLaunchKernelGGL(k_cell_spans, dim3(nb), dim3(256), 0, ctx->stream, cs.rt.p, cs.cvals2.p, cs.ckeys2.p, m, g, cs.st.p,
                        cs.se.p, cs.spans.p);
     ctx->ev_begin("cluster_edges", 0.0);   // latency / atomics bound, no HBM figure
-    hipLaunchKernelGGL(k_cluster_edges, dim3(nb), dim3(256), 0, ctx->stream, cs.st.p, cs.se.p, cs.ckeys2.p, cs.spans.p, m, r2,
-                       angle_gate, cs.parent.p);
+    hipLaunchKernelGGL(k_cluster_edges, dim3(cdiv((size_t)m * 9, 256)), dim3(256), 0, ctx->stream, cs.st.p, cs.se.p, cs.ckeys2.p,
+                       cs.spans.p, m, r2, angle_gate, cs.parent.p);
     ctx->ev_end();
     hipLaunchKernelGGL(k_flatten, dim3(cdiv(m + 1, 256)), dim3(256), 0, ctx->stream, cs.parent.p, m, cs.sizes_all.p, cs.flags.p);
     cs.n_clusters = compact_flags(ctx, cs.flags.p, m, cs.pos, cs.seeds);

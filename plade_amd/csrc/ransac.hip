@@ -33,7 +33,8 @@ namespace plade {
 
 // ------------------------------------------------------------------------------------------------
 // Morton order
-__device__ __forceinline__ uint32_t spread3(uint32_t v) {  // 10 bits -> every third bit
+// 8 bits per axis = the 8 octree levels the sampler draws from (24-bit keys: three radix passes)
+__device__ __forceinline__ uint32_t spread3(uint32_t v) {  // up to 10 bits -> every third bit
     v = (v | (v << 16)) & 0x030000FF;
     v = (v | (v << 8)) & 0x0300F00F;
     v = (v | (v << 4)) & 0x030C30C3;
@@ -46,9 +47,9 @@ __global__ void k_morton(const float *__restrict__ x, const float *__restrict__ 
                          uint32_t *__restrict__ vals) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const uint32_t qx = min(1023u, (uint32_t)max(0.f, (x[i] - mnx) * inv_cube * 1024.f));
-    const uint32_t qy = min(1023u, (uint32_t)max(0.f, (y[i] - mny) * inv_cube * 1024.f));
-    const uint32_t qz = min(1023u, (uint32_t)max(0.f, (z[i] - mnz) * inv_cube * 1024.f));
+    const uint32_t qx = min(255u, (uint32_t)max(0.f, (x[i] - mnx) * inv_cube * 256.f));
+    const uint32_t qy = min(255u, (uint32_t)max(0.f, (y[i] - mny) * inv_cube * 256.f));
+    const uint32_t qz = min(255u, (uint32_t)max(0.f, (z[i] - mnz) * inv_cube * 256.f));
     keys[i] = (spread3(qz) << 2) | (spread3(qy) << 1) | spread3(qx);
     vals[i] = i;
 }
@@ -114,11 +115,11 @@ __global__ __launch_bounds__(256) void k_sample(CloudView c, const uint32_t *__r
     for (int tr = 0; tr < 64 && !ok; ++tr) { i0 = rng.next() % c.n; ok = assigned[i0] == -1; }
     if (!ok) return;
     const int level = min_level + (int)(rng.next() % (uint32_t)(max_level - min_level + 1));
-    const uint32_t low_bits = 30 - 3 * level;
+    const uint32_t low_bits = 24 - 3 * level;
     const uint32_t mask = low_bits >= 32 ? 0u : ~((1u << low_bits) - 1u);
     const uint32_t lo_key = codes[i0] & mask, hi_key = lo_key | ~mask;
     const uint32_t lo = lb_u32(codes, c.n, lo_key);
-    uint32_t hi = (hi_key == 0xffffffffu || hi_key >= 0x3fffffffu) ? c.n : lb_u32(codes, c.n, hi_key + 1u);
+    uint32_t hi = (hi_key == 0xffffffffu || hi_key >= 0xffffffu) ? c.n : lb_u32(codes, c.n, hi_key + 1u);
     if (hi - lo < 3) return;
     uint32_t s[3] = {i0, 0, 0};
     for (int k = 1; k < 3; ++k) {
@@ -870,7 +871,7 @@ void ransac_detect(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const R
     const unsigned nb = cdiv(n, 256);
     hipLaunchKernelGGL(k_morton, dim3(nb), dim3(256), 0, ctx->stream, cloud.x(), cloud.y(), cloud.z(), n, cloud.bbmin[0],
                        cloud.bbmin[1], cloud.bbmin[2], 1.f / cube, W.codes_in.p, W.vals_in.p);
-    sort_pairs_u32(ctx, W.codes_in.p, W.codes.p, W.vals_in.p, W.orig.p, n, 30);
+    sort_pairs_u32(ctx, W.codes_in.p, W.codes.p, W.vals_in.p, W.orig.p, n, 24);
     W.sorted.n = n;
     W.sorted.pitch = cloud.pitch;
     W.sorted.soa.ensure(6 * cloud.pitch + 4);
