@@ -13,6 +13,8 @@
 //                 the points within r, each counted once (checkIndex).  Both are order independent,
 //                 so brute-force fp32 distance tests (FLANN L2_Simple, strict <) reproduce the counts.
 #include "stages.h"
+#include "prims.h"
+#include <algorithm>
 
 namespace plade {
 
@@ -108,20 +110,140 @@ __global__ __launch_bounds__(256) void k_pen_setup(PenTables tb, float len_th, f
 }
 
 constexpr int PEN_MAXS = 1024;   // search steps along one intersection segment
-constexpr int PEN_G = 4;         // items (= wavefronts) per workgroup, all of the same plane pair
+constexpr int PEN_G = 4;         // items (= wavefronts) per workgroup
 constexpr int PEN_TPB = 64 * PEN_G;
-constexpr int PEN_UNROLL = 4;
 
-// One wavefront per item; the wavefronts of a workgroup belong to the same (source plane, target plane),
-// stream the same two plane clouds at the same time and so share them through the CU's L1 -- the L2
-// traffic, which bounds this kernel, drops by the group size.  Wavefronts are independent (wave-level
-// synchronisation only).
-// step_dist: the reference's `for (dist = 0; dist < length; dist += r)` sequence (util.cpp:1383, fp32
-// accumulation), PEN_MAXS + 1 entries computed once on the host -- it does not depend on the item.
+// ---- in-plane grids ---------------------------------------------------------------------------
+// Only the points within the search radius of the intersection line matter to a walk, and that line lies
+// in both planes: each plane cloud is binned once into square cells of its own (u, v) frame, and a walk
+// visits the cells its segment crosses (+ the radius) instead of streaming the whole plane cloud.
+__device__ __forceinline__ void pen_uv(const PenFrame &f, f3 p, float &u, float &v) {
+    const float dx = p.x - f.o[0], dy = p.y - f.o[1], dz = p.z - f.o[2];
+    u = dx * f.eu[0] + dy * f.eu[1] + dz * f.eu[2];
+    v = dx * f.ev[0] + dy * f.ev[1] + dz * f.ev[2];
+}
+
+__global__ void k_pen_cell_keys(const float *__restrict__ xyz, uint32_t n, const uint32_t *__restrict__ off, uint32_t P,
+                                const PenFrame *__restrict__ frames, float inv_cell, uint32_t *__restrict__ keys,
+                                uint32_t *__restrict__ vals) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t lo = 0, hi = P;   // plane of point i: last g with off[g] <= i
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (off[mid] <= i) lo = mid; else hi = mid; }
+    const PenFrame f = frames[lo];
+    float u, v;
+    pen_uv(f, f3(xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2]), u, v);
+    const int cu = min(max((int)floorf(u * inv_cell) + 1, 0), f.nu - 1);   // one cell of margin on every side
+    const int cv = min(max((int)floorf(v * inv_cell) + 1, 0), f.nv - 1);
+    keys[i] = f.base + (uint32_t)cv * (uint32_t)f.nu + (uint32_t)cu;
+    vals[i] = i;
+}
+
+__global__ void k_pen_cell_fill(const float *__restrict__ xyz, const uint32_t *__restrict__ skeys,
+                                const uint32_t *__restrict__ svals, uint32_t n, uint32_t n_cells,
+                                float4 *__restrict__ pts, uint32_t *__restrict__ cell_start) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const uint32_t p = svals[i];
+        pts[i] = make_float4(xyz[3 * (size_t)p], xyz[3 * (size_t)p + 1], xyz[3 * (size_t)p + 2], 0.f);
+    }
+    if (i <= n_cells) {   // first sorted position with key >= i
+        uint32_t lo = 0, hi = n;
+        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (skeys[mid] < i) lo = mid + 1; else hi = mid; }
+        cell_start[i] = lo;
+    }
+}
+
+void build_pen_grid(plade_ctx *ctx, PlaneCloudsDev &pc, const PlaneGeomHost &geom, float cell) {
+    const uint32_t P = geom.P, n = pc.off[P];
+    std::vector<PenFrame> fr(P);
+    uint32_t total = 0;
+    for (uint32_t g = 0; g < P; ++g) {
+        const float *c = geom.four.data() + 12 * (size_t)g;
+        PenFrame &f = fr[g];
+        double eu[3], ev[3], lu = 0, lv = 0;
+        for (int k = 0; k < 3; ++k) { eu[k] = (double)c[3 + k] - c[k]; ev[k] = (double)c[9 + k] - c[k]; lu += eu[k] * eu[k]; lv += ev[k] * ev[k]; }
+        lu = std::sqrt(lu); lv = std::sqrt(lv);
+        for (int k = 0; k < 3; ++k) {
+            f.o[k] = c[k];
+            f.eu[k] = lu > 0 ? (float)(eu[k] / lu) : (k == 0);
+            f.ev[k] = lv > 0 ? (float)(ev[k] / lv) : (k == 1);
+        }
+        f.nu = (int)std::min(4096.0, std::floor(lu / cell) + 3);
+        f.nv = (int)std::min(4096.0, std::floor(lv / cell) + 3);
+        f.base = total;
+        total += (uint32_t)f.nu * (uint32_t)f.nv;
+    }
+    pc.n_cells = total;
+    pc.grid_cell = cell;
+    pc.frames.ensure(P);
+    HIP_TRY(hipMemcpyAsync(pc.frames.p, fr.data(), P * sizeof(PenFrame), hipMemcpyHostToDevice, ctx->stream));
+    pc.cell_pts.ensure((size_t)n + 1);
+    pc.cell_start.ensure((size_t)total + 2);
+    pc.ckeys.ensure((size_t)n + 1); pc.ckeys2.ensure((size_t)n + 1); pc.cvals.ensure((size_t)n + 1); pc.cvals2.ensure((size_t)n + 1);
+    if (n)
+        hipLaunchKernelGGL(k_pen_cell_keys, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, pc.xyz.p, n, pc.d_off.p, P, pc.frames.p,
+                           1.f / cell, pc.ckeys.p, pc.cvals.p);
+    int bits = 1;
+    while ((1ull << bits) < total) ++bits;
+    sort_pairs_u32(ctx, pc.ckeys.p, pc.ckeys2.p, pc.cvals.p, pc.cvals2.p, n, bits);
+    hipLaunchKernelGGL(k_pen_cell_fill, dim3(cdiv(std::max(n, total + 1), 256)), dim3(256), 0, ctx->stream, pc.xyz.p, pc.ckeys2.p,
+                       pc.cvals2.p, n, total, pc.cell_pts.p, pc.cell_start.p);
+    HIP_TRY(hipStreamSynchronize(ctx->stream));   // `fr` must outlive the copy
+}
+
+// Cells of one plane grid that can hold a point within `rr` of the segment start + t direc, t in [0, L]
+// (all in the plane cloud's own frame).  The line is walked along its major in-plane axis: lane-strided
+// columns (or rows), in each the cell range the line covers, widened by the radius.  fn(point) is called
+// once for every point of those cells.
+template <class Fn>
+__device__ __forceinline__ void pen_visit(const PenFrame &f, const float4 *__restrict__ pts, const uint32_t *__restrict__ cell_start,
+                                          f3 start, f3 direc, float L, float rr, float cell, int lane, Fn fn) {
+    float su, sv, eu_, ev_;
+    pen_uv(f, start, su, sv);
+    pen_uv(f, f3(start.x + L * direc.x, start.y + L * direc.y, start.z + L * direc.z), eu_, ev_);
+    const float inv = 1.f / cell;
+    const bool major_u = fabsf(eu_ - su) >= fabsf(ev_ - sv);
+    // a = coordinate along the major axis, b = along the minor one
+    const float a0 = major_u ? su : sv, a1 = major_u ? eu_ : ev_, b0 = major_u ? sv : su, b1 = major_u ? ev_ : eu_;
+    const int na = major_u ? f.nu : f.nv, nbm = major_u ? f.nv : f.nu;
+    const float pad = rr * 1.4143f + 0.02f * cell;   // perpendicular rr seen along the minor axis (slope <= 1) + rounding
+    const float amin = fminf(a0, a1) - rr - 0.02f * cell, amax = fmaxf(a0, a1) + rr + 0.02f * cell;
+    const int ca0 = max((int)floorf(amin * inv) + 1, 0), ca1 = min((int)floorf(amax * inv) + 1, na - 1);
+    const float da = a1 - a0;
+    const float slope = fabsf(da) > 1e-12f ? (b1 - b0) / da : 0.f;
+    for (int ca = ca0 + lane; ca <= ca1; ca += 64) {
+        // the part of the segment (extended by rr at both ends) inside this column
+        float lo = fmaxf((float)(ca - 1) * cell, amin), hi = fminf((float)ca * cell, amax);
+        if (hi < lo) { const float t = lo; lo = hi; hi = t; }
+        const float bl = b0 + (lo - a0) * slope, bh = b0 + (hi - a0) * slope;
+        const int cb0 = max((int)floorf((fminf(bl, bh) - pad) * inv) + 1, 0);
+        const int cb1 = min((int)floorf((fmaxf(bl, bh) + pad) * inv) + 1, nbm - 1);
+        for (int cb = cb0; cb <= cb1; ++cb) {
+            const uint32_t c = f.base + (major_u ? (uint32_t)cb * (uint32_t)f.nu + (uint32_t)ca
+                                                 : (uint32_t)ca * (uint32_t)f.nu + (uint32_t)cb);
+            const uint32_t pb = cell_start[c], pe = cell_start[c + 1];
+            for (uint32_t j = pb; j < pe; ++j) {
+                const float4 q = pts[j];
+                fn(f3(q.x, q.y, q.z));
+            }
+        }
+    }
+}
+
+struct PenSide {
+    const PenFrame *frames;
+    const float4 *pts;
+    const uint32_t *cell_start;
+};
+
+// One wavefront per item.  step_dist: the reference's `for (dist = 0; dist < length; dist += r)` sequence
+// (util.cpp:1383, fp32 accumulation), PEN_MAXS + 1 entries computed once on the host -- it does not depend
+// on the item.  All distance tests are the reference's arithmetic on the reference's operands (source
+// points moved by the candidate with pcl_xform); the grids only select which points are looked at.
 __global__ __launch_bounds__(PEN_TPB) void k_pen_walk(const PenItem *__restrict__ items, const uint32_t *__restrict__ pair_count,
                                                       const uint32_t *__restrict__ pair_order, PenTables tb,
-                                                      const float *__restrict__ step_dist, const float *__restrict__ s_xyz, const uint32_t *__restrict__ s_off,
-                                                      const float *__restrict__ t_xyz, const uint32_t *__restrict__ t_off,
+                                                      const float *__restrict__ step_dist, PenSide S, PenSide T_, float cell,
                                                       float search_radius, int min_points, float min_distance,
                                                       uint32_t *__restrict__ cand_flags, uint32_t *__restrict__ overflow) {
     __shared__ uint32_t s_cnt_all[PEN_G][PEN_MAXS];
@@ -150,81 +272,58 @@ __global__ __launch_bounds__(PEN_TPB) void k_pen_walk(const PenItem *__restrict_
     const float *c = tb.cand + 12 * (size_t)it.k;
     const float T12[12] = {c[0], c[1], c[2], c[9], c[3], c[4], c[5], c[10], c[6], c[7], c[8], c[11]};
     const uint32_t i1 = pair / tb.pt, j1 = pair % tb.pt;
-    const uint32_t sb = s_off[i1], se = s_off[i1 + 1], tb0 = t_off[j1], te = t_off[j1 + 1];
     const float *tc = tb.t_coef + 4 * (size_t)j1;
     const float inv_r = 1.f / search_radius;
+    const float L = step_dist[nsteps - 1];   // the last step point
+    // the segment in the source frame: p_s = R^T (p - T) (cell selection only)
+    const f3 ds(start.x - c[9], start.y - c[10], start.z - c[11]);
+    const f3 start_s(c[0] * ds.x + c[3] * ds.y + c[6] * ds.z, c[1] * ds.x + c[4] * ds.y + c[7] * ds.z,
+                     c[2] * ds.x + c[5] * ds.y + c[8] * ds.z);
+    const f3 direc_s(c[0] * direc.x + c[3] * direc.y + c[6] * direc.z, c[1] * direc.x + c[4] * direc.y + c[7] * direc.z,
+                     c[2] * direc.x + c[5] * direc.y + c[8] * direc.z);
+    const PenFrame fs = S.frames[i1], ft = T_.frames[j1];
 
     for (int pass = 0; pass < 2; ++pass) {
         // pass 0: gate = target plane cloud, classified = transformed source plane cloud vs plane2
         // pass 1: gate = transformed source plane cloud, classified = target plane cloud vs plane1
         for (int i = lane; i < nsteps; i += 64) s_cnt[i] = 0u;
         __syncwarp();
-        const uint32_t gb = pass == 0 ? tb0 : sb, ge = pass == 0 ? te : se;
-        const float *gxyz = pass == 0 ? t_xyz : s_xyz;
-        // four points per lane and trip: the twelve loads are issued together (the walk is latency bound)
-        for (uint32_t i0 = gb; i0 < ge; i0 += 64 * PEN_UNROLL) {
-            f3 raw[PEN_UNROLL];
-            bool ok[PEN_UNROLL];
-#pragma unroll
-            for (int u = 0; u < PEN_UNROLL; ++u) {
-                const uint32_t i = i0 + u * 64 + lane;
-                ok[u] = i < ge;
-                const size_t ii = ok[u] ? i : ge - 1;
-                raw[u] = f3(gxyz[3 * ii], gxyz[3 * ii + 1], gxyz[3 * ii + 2]);
+        auto gate = [&](f3 raw) {
+            const f3 p = pass == 0 ? raw : pcl_xform(T12, raw);
+            const f3 d = p - start;
+            const float t = d.x * direc.x + d.y * direc.y + d.z * direc.z;
+            const int kc = (int)floorf(t * inv_r);
+            for (int kk = max(kc - 2, 0); kk <= min(kc + 3, nsteps - 1); ++kk) {
+                const float dist = step_dist[kk];
+                const f3 spt(start.x + dist * direc.x, start.y + dist * direc.y, start.z + dist * direc.z);
+                if (flann_d2(spt, p) < half_r2) atomicAdd(&s_cnt[kk], 1u);
             }
-#pragma unroll
-            for (int u = 0; u < PEN_UNROLL; ++u) {
-                if (!ok[u]) continue;
-                const f3 p = pass == 0 ? raw[u] : pcl_xform(T12, raw[u]);
-                const f3 d = p - start;
-                const float t = d.x * direc.x + d.y * direc.y + d.z * direc.z;
-                // conservative reject: farther than r/2 (+2 %) from the line => within r/2 of no step point
-                if ((d.x * d.x + d.y * d.y + d.z * d.z) - t * t > half_r2 * 1.02f + 1e-12f) continue;
-                const int kc = (int)floorf(t * inv_r);
-                for (int kk = max(kc - 2, 0); kk <= min(kc + 3, nsteps - 1); ++kk) {
-                    const float dist = step_dist[kk];
-                    const f3 spt(start.x + dist * direc.x, start.y + dist * direc.y, start.z + dist * direc.z);
-                    if (flann_d2(spt, p) < half_r2) atomicAdd(&s_cnt[kk], 1u);
-                }
-            }
-        }
+        };
+        if (pass == 0) pen_visit(ft, T_.pts, T_.cell_start, start, direc, L, search_radius * 0.5f, cell, lane, gate);
+        else pen_visit(fs, S.pts, S.cell_start, start_s, direc_s, L, search_radius * 0.5f, cell, lane, gate);
         __syncwarp();
         const float pl0 = pass == 0 ? tc[0] : it.plane1[0], pl1 = pass == 0 ? tc[1] : it.plane1[1],
                     pl2 = pass == 0 ? tc[2] : it.plane1[2], pl3 = pass == 0 ? tc[3] : it.plane1[3];
-        const uint32_t ab = pass == 0 ? sb : tb0, ae = pass == 0 ? se : te;
         int pos = 0, neg = 0;
-        const float *axyz = pass == 0 ? s_xyz : t_xyz;
-        for (uint32_t i0 = ab; i0 < ae; i0 += 64 * PEN_UNROLL) {
-            f3 raw[PEN_UNROLL];
-            bool ok[PEN_UNROLL];
-#pragma unroll
-            for (int u = 0; u < PEN_UNROLL; ++u) {
-                const uint32_t i = i0 + u * 64 + lane;
-                ok[u] = i < ae;
-                const size_t ii = ok[u] ? i : ae - 1;
-                raw[u] = f3(axyz[3 * ii], axyz[3 * ii + 1], axyz[3 * ii + 2]);
+        auto classify = [&](f3 raw) {
+            const f3 p = pass == 0 ? pcl_xform(T12, raw) : raw;
+            const f3 d = p - start;
+            const float t = d.x * direc.x + d.y * direc.y + d.z * direc.z;
+            const int kc = (int)floorf(t * inv_r);
+            bool hit = false;
+            for (int kk = max(kc - 2, 0); kk <= min(kc + 3, nsteps - 1) && !hit; ++kk) {
+                if (s_cnt[kk] < 2u) continue;
+                const float dist = step_dist[kk];
+                const f3 spt(start.x + dist * direc.x, start.y + dist * direc.y, start.z + dist * direc.z);
+                if (flann_d2(spt, p) < full_r2) hit = true;
             }
-#pragma unroll
-            for (int u = 0; u < PEN_UNROLL; ++u) {
-                if (!ok[u]) continue;
-                const f3 p = pass == 0 ? pcl_xform(T12, raw[u]) : raw[u];
-                const f3 d = p - start;
-                const float t = d.x * direc.x + d.y * direc.y + d.z * direc.z;
-                if ((d.x * d.x + d.y * d.y + d.z * d.z) - t * t > full_r2 * 1.02f + 1e-12f) continue;
-                const int kc = (int)floorf(t * inv_r);
-                bool hit = false;
-                for (int kk = max(kc - 2, 0); kk <= min(kc + 3, nsteps - 1) && !hit; ++kk) {
-                    if (s_cnt[kk] < 2u) continue;
-                    const float dist = step_dist[kk];
-                    const f3 spt(start.x + dist * direc.x, start.y + dist * direc.y, start.z + dist * direc.z);
-                    if (flann_d2(spt, p) < full_r2) hit = true;
-                }
-                if (hit) {
-                    const float td = pl0 * p.x + pl1 * p.y + pl2 * p.z + pl3;
-                    if (fabsf(td) > min_distance) { if (td >= 0) ++pos; else ++neg; }
-                }
+            if (hit) {
+                const float td = pl0 * p.x + pl1 * p.y + pl2 * p.z + pl3;
+                if (fabsf(td) > min_distance) { if (td >= 0) ++pos; else ++neg; }
             }
-        }
+        };
+        if (pass == 0) pen_visit(fs, S.pts, S.cell_start, start_s, direc_s, L, search_radius, cell, lane, classify);
+        else pen_visit(ft, T_.pts, T_.cell_start, start, direc, L, search_radius, cell, lane, classify);
         for (int dlt = 32; dlt >= 1; dlt >>= 1) { pos += __shfl_xor(pos, dlt, 64); neg += __shfl_xor(neg, dlt, 64); }
         __syncwarp();   // all reads of s_cnt done before the next pass clears it
         if (pass == 0) {
@@ -238,7 +337,7 @@ __global__ __launch_bounds__(PEN_TPB) void k_pen_walk(const PenItem *__restrict_
 }
 
 void penetration_filter(plade_ctx *ctx, const float *cand_rt_host, uint32_t K, const PlaneGeomHost &src,
-                        const PlaneGeomHost &tgt, const PlaneCloudsDev &src_pts, const PlaneCloudsDev &tgt_pts,
+                        const PlaneGeomHost &tgt, PlaneCloudsDev &src_pts, PlaneCloudsDev &tgt_pts,
                         float length_threshold, float angle_threshold, std::vector<int32_t> &flags_out) {
     flags_out.assign(K, 0);
     if (!K || !src.P || !tgt.P) return;
@@ -294,11 +393,15 @@ void penetration_filter(plade_ctx *ctx, const float *cand_rt_host, uint32_t K, c
     HIP_TRY(hipMemcpyAsync(d_steps, steps.data(), steps.size() * 4, hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(k_pen_setup, dim3(cdiv(total, 256)), dim3(256), 0, ctx->stream, tb, length_threshold,
                        angle_threshold, d_items, d_n, d_pair);
+    // in-plane grids of both sides (cell = 2 r)
+    const float cell = pen_grid_cell(length_threshold);
+    if (src_pts.grid_cell != cell) build_pen_grid(ctx, src_pts, src, cell);   // normally built by prepare_side
+    if (tgt_pts.grid_cell != cell) build_pen_grid(ctx, tgt_pts, tgt, cell);
+    const PenSide sS{src_pts.frames.p, src_pts.cell_pts.p, src_pts.cell_start.p}, sT{tgt_pts.frames.p, tgt_pts.cell_pts.p, tgt_pts.cell_start.p};
     // a plane pair holds at most K items: grid.y covers the worst case, empty groups exit at once
     ctx->ev_begin("pen_walk", 0.0);
     hipLaunchKernelGGL(k_pen_walk, dim3(n_pairs, cdiv(K, PEN_G)), dim3(PEN_TPB), 0, ctx->stream, d_items, d_pair, d_order, tb, d_steps,
-                       src_pts.xyz.p, src_pts.d_off.p, tgt_pts.xyz.p, tgt_pts.d_off.p, search_radius, 10, min_distance, d_flags,
-                       d_over);
+                       sS, sT, cell, search_radius, 10, min_distance, d_flags, d_over);
     ctx->ev_end();
     std::vector<uint32_t> out((size_t)K + 2);
     HIP_TRY(hipMemcpyAsync(out.data(), d_ctr, ((size_t)K + 2) * 4, hipMemcpyDeviceToHost, ctx->stream));

@@ -93,7 +93,8 @@ void make_line_table(const float *coef, uint32_t P, f3 bcenter, double radius, L
         }
 }
 
-bool prepare_side(plade_ctx *ctx, const char *tag, const CloudDev &cloud, const PlaneSetView &pl, float leaf, Side &S) {
+bool prepare_side(plade_ctx *ctx, const char *tag, const CloudDev &cloud, const PlaneSetView &pl, float leaf, float pen_cell,
+                  Side &S) {
     const uint32_t P = pl.P;
     Clock::time_point tp0 = Clock::now();
     // whole cloud: DownSamplePointCloud (plade.cpp:77-79 / :292-294)
@@ -157,6 +158,8 @@ bool prepare_side(plade_ctx *ctx, const char *tag, const CloudDev &cloud, const 
     }
     ctx->stats.add(std::string("t_prep_obb_") + tag, secs_since(tp0));
     tp0 = Clock::now();
+    S.pcl.grid_cell = 0.f;
+    build_pen_grid(ctx, S.pcl, S.geom, pen_cell);   // in-plane grids for the penetration walk (A11)
     make_line_table(pl.coef, P, S.bcenter, S.radius, S.lines);
     ctx->stats.add(std::string("t_prep_lines_") + tag, secs_since(tp0));
     if (ctx->params.dump) {
@@ -242,11 +245,11 @@ bool run_registration(plade_ctx *ctx, RegistrationWork &W, const CloudDev &tgt, 
         Err aux_err{0, ""}, main_err{0, ""};
         std::thread th([&]() {
             (void)hipSetDevice(ctx->device);
-            try { ok_c = prepare_side(aux, "src", src, sp, downSampleDistance, C); }
+            try { ok_c = prepare_side(aux, "src", src, sp, downSampleDistance, pen_grid_cell(lengthThreshold), C); }
             catch (const Err &e) { aux_err = e; }
             catch (const std::exception &e) { aux_err = Err{PLADE_EDEVICE, e.what()}; }
         });
-        try { ok_m = prepare_side(ctx, "tgt", tgt, tp, downSampleDistance, M); } catch (const Err &e) { main_err = e; }
+        try { ok_m = prepare_side(ctx, "tgt", tgt, tp, downSampleDistance, pen_grid_cell(lengthThreshold), M); } catch (const Err &e) { main_err = e; }
         th.join();
         for (auto &kv : aux->dump) ctx->dump[kv.first] = kv.second;
         ctx->stats.merge(aux->stats);

@@ -71,15 +71,33 @@ void plane_consistency(plade_ctx *ctx, CandidateSet &cs, const PlaneGeomHost &sr
                        float length_threshold);
 
 // ---- penetration filter (util.cpp:450-519, AreTwoPlanesPenetrable :1279-1458) -------------------
+// in-plane frame + cell table of one plane cloud (penetration walk): cells of edge `cell` over the
+// plane's bounding rectangle, (u, v) measured from its first corner along its two edges
+struct PenFrame {
+    float o[3], eu[3], ev[3];
+    int nu, nv;
+    uint32_t base;                // first cell of this plane in the side's cell table
+};
 struct PlaneCloudsDev {           // per-plane voxel-downsampled points, concatenated
     DBuf<float> xyz;              // total x 3
     std::vector<uint32_t> off;    // P + 1 (host)
     DBuf<uint32_t> d_off;
+    // the same points binned into the in-plane grids (built by penetration_filter)
+    DBuf<PenFrame> frames;        // P
+    DBuf<float4> cell_pts;        // total, in cell order
+    DBuf<uint32_t> cell_start;    // n_cells + 1
+    DBuf<uint32_t> ckeys, ckeys2, cvals, cvals2;
+    uint32_t n_cells = 0;
+    float grid_cell = 0.f;        // cell edge the grid was built with (0 = not built)
 };
+// cell edge of the in-plane grids: twice the walk's search radius (= lengthThreshold, util.cpp:1279)
+inline float pen_grid_cell(float length_threshold) { return 2.f * (float)(double)length_threshold; }
+struct PlaneGeomHost;
+void build_pen_grid(plade_ctx *ctx, PlaneCloudsDev &pc, const PlaneGeomHost &geom, float cell);
 // flags_out[k] = 1 when candidate k has a penetrating plane pair
 void penetration_filter(plade_ctx *ctx, const float *cand_rt_host /*K x 12: R row-major, T*/, uint32_t K,
-                        const PlaneGeomHost &src, const PlaneGeomHost &tgt, const PlaneCloudsDev &src_pts,
-                        const PlaneCloudsDev &tgt_pts, float length_threshold, float angle_threshold,
+                        const PlaneGeomHost &src, const PlaneGeomHost &tgt, PlaneCloudsDev &src_pts,
+                        PlaneCloudsDev &tgt_pts, float length_threshold, float angle_threshold,
                         std::vector<int32_t> &flags_out);
 
 // generic: positions of set flags (ordered); returns count (sync)
