@@ -62,9 +62,37 @@ __global__ void k_gather_cells(const float *__restrict__ xyz, uint32_t stride, c
     if (i == n - 1 || keys[i + 1] != k) cell_end[k] = i + 1;
 }
 
+// compact occupancy index over the sorted cell keys
+__global__ void k_occ_bits(const uint32_t *__restrict__ keys, uint32_t n, unsigned long long *__restrict__ bits) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t k = keys[i];
+    if (i == 0 || keys[i - 1] != k) atomicOr(&bits[k >> 6], 1ull << (k & 63));
+}
+__global__ void k_occ_pop(const unsigned long long *__restrict__ bits, uint32_t nw, uint32_t *__restrict__ pop) {
+    const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w < nw) pop[w] = (uint32_t)__popcll(bits[w]);
+    if (w == nw) pop[w] = 0;
+}
+__global__ void k_occ_start(const float *__restrict__ xyz, uint32_t stride, const uint32_t *__restrict__ keys,
+                            const uint32_t *__restrict__ vals, uint32_t n, const unsigned long long *__restrict__ bits,
+                            const uint32_t *__restrict__ rank, uint32_t nw, float4 *__restrict__ sorted,
+                            uint32_t *__restrict__ occ_start) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t v = vals[i];
+    sorted[i] = make_float4(xyz[(size_t)v * stride], xyz[(size_t)v * stride + 1], xyz[(size_t)v * stride + 2],
+                            __uint_as_float(v));
+    const uint32_t k = keys[i];
+    if (i == 0 || keys[i - 1] != k)
+        occ_start[rank[k >> 6] + (uint32_t)__popcll(bits[k >> 6] & ((1ull << (k & 63)) - 1ull))] = i;
+    if (i == n - 1) occ_start[rank[nw]] = n;
+}
+
 void TargetGrid::build(plade_ctx *ctx, const float *d_xyz, uint32_t n_pts, uint32_t stride, float min_cell,
-                       const float *bbox_min, const float *bbox_max) {
+                       const float *bbox_min, const float *bbox_max, bool compact_index) {
     n = n_pts;
+    compact = compact_index;
     if (n == 0) return;
     float init[6];
     int iinit[6];
@@ -105,26 +133,40 @@ void TargetGrid::build(plade_ctx *ctx, const float *d_xyz, uint32_t n_pts, uint3
     ncells = (size_t)gp.dx * gp.dy * gp.dz;
     keys.ensure(n); keys2.ensure(n); vals.ensure(n); vals2.ensure(n);
     sorted.ensure(n);
-    cell_start.ensure(ncells); cell_end.ensure(ncells);
-    HIP_TRY(hipMemsetAsync(cell_start.p, 0, ncells * 4, ctx->stream));
-    HIP_TRY(hipMemsetAsync(cell_end.p, 0, ncells * 4, ctx->stream));
     GridParams g{gp.mnx, gp.mny, gp.mnz, gp.inv, gp.dx, gp.dy, gp.dz};
     hipLaunchKernelGGL(k_cell_ids, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, d_xyz, n, stride, g, keys.p, vals.p);
     int bits = 1;
     while (((size_t)1 << bits) < ncells) ++bits;
     sort_pairs_u32(ctx, keys.p, keys2.p, vals.p, vals2.p, n, bits);
+    if (compact) {
+        const uint32_t nw = (uint32_t)((ncells + 63) / 64);
+        occ_bits.ensure(nw + 1); occ_pop.ensure(nw + 2); occ_rank.ensure(nw + 2); occ_start.ensure((size_t)n + 2);
+        HIP_TRY(hipMemsetAsync(occ_bits.p, 0, ((size_t)nw + 1) * 8, ctx->stream));
+        hipLaunchKernelGGL(k_occ_bits, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, keys2.p, n, occ_bits.p);
+        hipLaunchKernelGGL(k_occ_pop, dim3(cdiv(nw + 1, 256)), dim3(256), 0, ctx->stream, occ_bits.p, nw, occ_pop.p);
+        exclusive_scan_u32(ctx, occ_pop.p, occ_rank.p, (size_t)nw + 1);
+        hipLaunchKernelGGL(k_occ_start, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, d_xyz, stride, keys2.p, vals2.p, n,
+                           occ_bits.p, occ_rank.p, nw, sorted.p, occ_start.p);
+        HIP_TRY(hipGetLastError());
+        return;
+    }
+    cell_start.ensure(ncells); cell_end.ensure(ncells);
+    HIP_TRY(hipMemsetAsync(cell_start.p, 0, ncells * 4, ctx->stream));
+    HIP_TRY(hipMemsetAsync(cell_end.p, 0, ncells * 4, ctx->stream));
     hipLaunchKernelGGL(k_gather_cells, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, d_xyz, stride, keys2.p, vals2.p, n,
                        sorted.p, cell_start.p, cell_end.p);
     HIP_TRY(hipGetLastError());
 }
 
 constexpr int OV_TPB = 256;
-constexpr int OV_KCH = 8;
+constexpr int OV_KCH = 2;   // candidates per workgroup: few, so that even ~10 candidates fill the GPU
 
 __global__ __launch_bounds__(OV_TPB) void k_overlap(const float *__restrict__ sx, const float *__restrict__ sy,
                                                     const float *__restrict__ sz, uint32_t n_s,
-                                                    const float4 *__restrict__ tgt, const uint32_t *__restrict__ cstart,
-                                                    const uint32_t *__restrict__ cend, GridParams g,
+                                                    const float4 *__restrict__ tgt,
+                                                    const unsigned long long *__restrict__ occ_bits,
+                                                    const uint32_t *__restrict__ occ_rank,
+                                                    const uint32_t *__restrict__ occ_start, GridParams g,
                                                     const float *__restrict__ T /*K x 16*/,
                                                     const float *__restrict__ centers /*K x 3*/, uint32_t K, float R2,
                                                     float r2, int32_t *__restrict__ counts) {
@@ -153,7 +195,11 @@ __global__ __launch_bounds__(OV_TPB) void k_overlap(const float *__restrict__ sx
                 for (int yy = y0; yy <= y1 && !hit; ++yy) {
                     const int base = g.dx * (yy + g.dy * zz);
                     for (int xx = x0; xx <= x1 && !hit; ++xx) {
-                        const uint32_t b = cstart[base + xx], e = cend[base + xx];
+                        const uint32_t cid = (uint32_t)(base + xx);
+                        const unsigned long long w = occ_bits[cid >> 6], bit = 1ull << (cid & 63);
+                        if (!(w & bit)) continue;
+                        const uint32_t rk = occ_rank[cid >> 6] + (uint32_t)__popcll(w & (bit - 1ull));
+                        const uint32_t b = occ_start[rk], e = occ_start[rk + 1];
                         for (uint32_t j = b; j < e; ++j) {
                             const float4 t4 = tgt[j];
                             const f3 t(t4.x, t4.y, t4.z);
@@ -204,8 +250,9 @@ void overlap_counts(plade_ctx *ctx, const float *d_sx, const float *d_sy, const 
         dim3 gr(cdiv(n_s, OV_TPB), cdiv(K, OV_KCH));
         // algorithmic bytes: K * n_s * 12 B source stream + n_t * 12 B target
         ctx->ev_begin("overlap", (double)K * n_s * 12.0 + (double)grid.n * 12.0);
+        PLADE_REQUIRE(grid.compact, PLADE_EINVAL, "overlap: the target grid needs the compact occupancy index");
         hipLaunchKernelGGL(k_overlap, gr, dim3(OV_TPB), 0, ctx->stream, d_sx, d_sy, d_sz, n_s, grid.sorted.p,
-                           grid.cell_start.p, grid.cell_end.p, g, d_T, d_centers, K, R2, r2, d_counts);
+                           grid.occ_bits.p, grid.occ_rank.p, grid.occ_start.p, g, d_T, d_centers, K, R2, r2, d_counts);
         ctx->ev_end();
     }
     HIP_TRY(hipGetLastError());
@@ -245,7 +292,7 @@ extern "C" int plade_overlap_counts(plade_ctx *ctx, const float *src_ds, uint32_
         HIP_TRY(hipMemcpyAsync(d_c.p, centers, (size_t)k * 12, hipMemcpyHostToDevice, ctx->stream));
         deinterleave3(ctx, d_src.p, n_s, d_soa.p, d_soa.p + n_s, d_soa.p + 2 * (size_t)n_s);
         TargetGrid grid;
-        grid.build(ctx, d_tgt.p, n_t, 3, inlier_dist);
+        grid.build(ctx, d_tgt.p, n_t, 3, inlier_dist, nullptr, nullptr, true);
         overlap_counts(ctx, d_soa.p, d_soa.p + n_s, d_soa.p + 2 * (size_t)n_s, n_s, grid, d_T.p, d_c.p, k, src_radius,
                        inlier_dist, d_counts.p, d_any.p);
         std::vector<uint32_t> any(k);

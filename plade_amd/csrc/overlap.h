@@ -11,9 +11,17 @@ struct TargetGrid {
     DBuf<float> bbox;
     DBuf<uint32_t> keys, keys2, vals, vals2, cell_start, cell_end;
     DBuf<float4> sorted;  // target points in cell order: (x, y, z, bitcast original index)
+    // compact occupancy index (build(..., compact = true)): surfaces fill a few percent of the cells, so the
+    // dense start/end tables (tens of MB, L2 misses on every probe) are replaced by one bit per cell, a
+    // rank per 64-cell word and the start offsets of the occupied cells only -- ~1 MB, L2 resident
+    DBuf<unsigned long long> occ_bits;   // ncells / 64 words
+    DBuf<uint32_t> occ_pop, occ_rank;    // per word: popcount, exclusive prefix (+ total)
+    DBuf<uint32_t> occ_start;            // per occupied cell (+ 1): first sorted position
+    bool compact = false;
     // d_xyz: device pointer, `stride` floats between points; min_cell = largest probe radius used.
     void build(plade_ctx *ctx, const float *d_xyz, uint32_t n_pts, uint32_t stride, float min_cell,
-               const float *bbox_min = nullptr, const float *bbox_max = nullptr);  // known bbox skips a device round trip
+               const float *bbox_min = nullptr, const float *bbox_max = nullptr,   // known bbox skips a device round trip
+               bool compact_index = false);
 };
 
 // counts[k] (device, int32) and any[k] (device, 1 when the coarse sphere is non-empty)

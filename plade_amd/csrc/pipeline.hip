@@ -417,7 +417,7 @@ bool run_registration(plade_ctx *ctx, RegistrationWork &W, const CloudDev &tgt, 
         W.d_T16.ensure(16 * (size_t)Kv); W.d_centers.ensure(3 * (size_t)Kv); W.d_counts.ensure(Kv); W.d_any.ensure(Kv);
         HIP_TRY(hipMemcpyAsync(W.d_T16.p, T16.data(), 64 * (size_t)Kv, hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(hipMemcpyAsync(W.d_centers.p, centers.data(), 12 * (size_t)Kv, hipMemcpyHostToDevice, ctx->stream));
-        W.grid.build(ctx, M.d_ds.p, M.n_ds, 3, downSampleDistance);
+        W.grid.build(ctx, M.d_ds.p, M.n_ds, 3, downSampleDistance, nullptr, nullptr, true);
         overlap_counts(ctx, C.d_ds_soa.p, C.d_ds_soa.p + C.n_ds, C.d_ds_soa.p + 2 * (size_t)C.n_ds, C.n_ds, W.grid, W.d_T16.p,
                        W.d_centers.p, Kv, (float)C.radius, downSampleDistance, W.d_counts.p, W.d_any.p);
         std::vector<uint32_t> any(Kv);
