@@ -279,15 +279,16 @@ __global__ __launch_bounds__(256) void k_cc_raster(const ChainDev *__restrict__ 
     uint32_t ue, ve;
     const bool ok = cc_dims(st, m, eps, ue, ve);
     if (blockIdx.x == 0 && threadIdx.x == 0) { st->ue = ue; st->ve = ve; if (!ok) st->err = 1; }
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= m || !ok) return;
+    if (!ok) return;
     const float mnu = ord_f(st->bb[0]), mnv = ord_f(st->bb[1]);
-    int bu = (int)floorf((uv[i].x - mnu) / eps), bv = (int)floorf((uv[i].y - mnv) / eps);
-    bu = min(max(bu, 0), (int)ue - 1);
-    bv = min(max(bv, 0), (int)ve - 1);
-    const uint32_t b = (uint32_t)bu + (uint32_t)bv * ue;
-    bidx[i] = b;
-    bmp[b] = 1;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
+        int bu = (int)floorf((uv[i].x - mnu) / eps), bv = (int)floorf((uv[i].y - mnv) / eps);
+        bu = min(max(bu, 0), (int)ue - 1);
+        bv = min(max(bv, 0), (int)ve - 1);
+        const uint32_t b = (uint32_t)bu + (uint32_t)bv * ue;
+        bidx[i] = b;
+        bmp[b] = 1;
+    }
 }
 
 // closing (DilateCross + ErodeCross, ransac/Bitmap.cpp:154-260, 459-570; no wrapping for planes),
@@ -336,19 +337,29 @@ __global__ __launch_bounds__(1024) void k_cc_label(const ChainDev *__restrict__ 
         }
         __syncthreads();
     }
-    // 8-connected labelling by lock-free union-find: every foreground pixel is united with its W, NW, N,
-    // NE neighbours; the smaller index always becomes the parent, so a component's root is its first
-    // pixel in raster order
-    for (int p = threadIdx.x; p < npx; p += blockDim.x) { label[p] = bmp[p] ? (uint32_t)p : 0xffffffffu; sizes[p] = 0; }
+    // 8-connected labelling: (1) every pixel gets the first pixel of its horizontal run as label (one lane
+    // per row, sequential along the row), (2) runs are united with the runs they touch in the row above
+    // (N, NW, NE) by lock-free union-find on the run heads; the smaller index always becomes the parent, so
+    // a component's root is its first pixel in raster order
+    for (int v = threadIdx.x; v < ve; v += blockDim.x) {
+        uint32_t head = 0xffffffffu;
+        for (int u = 0; u < ue; ++u) {
+            const int p = v * ue + u;
+            if (bmp[p]) { if (head == 0xffffffffu) head = (uint32_t)p; label[p] = head; }
+            else { head = 0xffffffffu; label[p] = 0xffffffffu; }
+            sizes[p] = 0;
+        }
+    }
     __syncthreads();
     for (int p = threadIdx.x; p < npx; p += blockDim.x) {
-        if (!bmp[p]) continue;
-        const int u = p % ue, v = p / ue;
-        const int nb[4] = {u > 0 ? p - 1 : -1, (u > 0 && v > 0) ? p - ue - 1 : -1, v > 0 ? p - ue : -1,
-                           (u < ue - 1 && v > 0) ? p - ue + 1 : -1};
-        for (int e = 0; e < 4; ++e) {
+        if (!bmp[p] || p < ue) continue;
+        const int u = p % ue;
+        const int nb[3] = {u > 0 ? p - ue - 1 : -1, p - ue, u < ue - 1 ? p - ue + 1 : -1};
+        for (int e = 0; e < 3; ++e) {
             if (nb[e] < 0 || !bmp[nb[e]]) continue;
-            uint32_t a = (uint32_t)p, b = (uint32_t)nb[e];
+            // N also covers NW / NE whenever N is set (same run above): skip the redundant unions
+            if (e != 1 && bmp[p - ue]) continue;
+            uint32_t a = label[p], b = label[nb[e]];
             for (;;) {
                 while (label[a] != a) a = label[a];
                 while (label[b] != b) b = label[b];
@@ -418,7 +429,7 @@ __global__ __launch_bounds__(256) void k_cc_select(const ChainDev *__restrict__ 
 // Plane.h:65-74: mean + covariance about the mean + smallest-|eigenvalue| eigenvector).
 // Accumulated in fp64 with a fixed reduction tree (deterministic); the reference accumulates in
 // fp32 sequentially, which is the noisier of the two.
-constexpr int FIT_BLOCKS = 256;
+constexpr int FIT_BLOCKS = 64;
 
 // One pass over slot k's result list: the LS-fit moments (12 sums) and Candidate::WeightedScore
 // (ransac/Candidate.cpp:77-87 with weigh(), ScoreComputer.h:10-16) of the slot's plane.
@@ -494,7 +505,7 @@ __device__ void wscore_final(const ChainDev &C, double *s_ws /* 4, shared */) {
 
 // Sums the per-block partials of the index list `count` belongs to (fixed tree => deterministic);
 // nsum_out receives the sum of the list's point normals (orientation).  mode 0 additionally writes the
-// fitted plane into `st` (the NEXT slot's state) / plane_out.  One workgroup of FIT_BLOCKS lanes.
+// fitted plane into `st` (the NEXT slot's state) / plane_out.  One workgroup of 256 lanes (>= FIT_BLOCKS).
 // `cur` is the state of the slot whose list was just reduced; when the new plane is bitwise equal to
 // cur's plane the chain has converged: every later slot would reproduce cur's results, so they are
 // flagged and their kernels return immediately.
@@ -514,7 +525,7 @@ __device__ void fit_final(const ChainDev &C, int k, double (*s_red)[12]) {
         return;
     }
     double a[12];
-    for (int k = 0; k < 12; ++k) a[k] = part[threadIdx.x * 12 + k];
+    for (int k = 0; k < 12; ++k) a[k] = threadIdx.x < FIT_BLOCKS ? part[threadIdx.x * 12 + k] : 0.0;
     for (int k = 0; k < 12; ++k)
         for (int d = 32; d >= 1; d >>= 1) a[k] += __shfl_xor(a[k], d, 64);
     if ((threadIdx.x & 63) == 0) for (int k = 0; k < 12; ++k) s_red[threadIdx.x >> 6][k] = a[k];
@@ -550,8 +561,8 @@ __device__ void fit_final(const ChainDev &C, int k, double (*s_red)[12]) {
                      st->pos[0] == cur->pos[0] && st->pos[1] == cur->pos[1] && st->pos[2] == cur->pos[2]) ? 1u : 0u;
 }
 
-__global__ __launch_bounds__(FIT_BLOCKS) void k_fit_final(const ChainDev *__restrict__ chains, int k) {
-    __shared__ double s_red[FIT_BLOCKS / 64][12];
+__global__ __launch_bounds__(256) void k_fit_final(const ChainDev *__restrict__ chains, int k) {
+    __shared__ double s_red[4][12];
     __shared__ double s_ws[4];
     const ChainDev &C = chains[blockIdx.x];
     fit_final(C, k, s_red);
@@ -659,12 +670,12 @@ void enqueue_accept(plade_ctx *ctx, RansacWork &W, const CloudView &cv, uint32_t
         score_mark_batch(ctx, c.x(), c.y(), c.z(), c.nx(), c.ny(), c.nz(), W.assigned.p, c.n, W.mark_jobs.p + (size_t)k * B, nc, eps3,
                          cos_t);
         compact_batch(ctx, c.n, W.compact_jobs.p + (size_t)(2 * k) * B, nc, c.x(), c.y(), c.z());
-        hipLaunchKernelGGL(k_cc_raster, dim3(nb, nc), dim3(256), 0, st, tab, k, bitmap_eps);
+        hipLaunchKernelGGL(k_cc_raster, dim3(std::min(nb, 128u), nc), dim3(256), 0, st, tab, k, bitmap_eps);
         hipLaunchKernelGGL(k_cc_label, dim3(nc), dim3(1024), 0, st, tab, k, 1);
         hipLaunchKernelGGL(k_cc_select, dim3(nb4, nc), dim3(256), 0, st, tab, k);
         compact_batch(ctx, c.n, W.compact_jobs.p + (size_t)(2 * k + 1) * B, nc);
         hipLaunchKernelGGL(k_fit_partial, dim3(FIT_BLOCKS, nc), dim3(256), 0, st, cv, tab, k, eps3);
-        hipLaunchKernelGGL(k_fit_final, dim3(nc), dim3(FIT_BLOCKS), 0, st, tab, k);
+        hipLaunchKernelGGL(k_fit_final, dim3(nc), dim3(256), 0, st, tab, k);
     }
 }
 
@@ -829,12 +840,12 @@ void plane_component(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const
     const CompactJob hj{C.cs.masks.p, C.cs.block_counts.p, d_idx.p, D.idxA, D.cntA, nullptr, D.st[0].pos, D.uv, D.st[0].bb};
     HIP_TRY(hipMemcpyAsync(job.p, &hj, sizeof(hj), hipMemcpyHostToDevice, st));
     compact_batch(ctx, n, job.p, 1, cv.x, cv.y, cv.z);
-    hipLaunchKernelGGL(k_cc_raster, dim3(cdiv(n, 256), 1), dim3(256), 0, st, W.chain_tab.p, 0, bitmap_eps);
+    hipLaunchKernelGGL(k_cc_raster, dim3(std::min(cdiv(n, 256), 128u), 1), dim3(256), 0, st, W.chain_tab.p, 0, bitmap_eps);
     hipLaunchKernelGGL(k_cc_label, dim3(1), dim3(1024), 0, st, W.chain_tab.p, 0, closing_filter ? 1 : 0);
     hipLaunchKernelGGL(k_cc_select, dim3(nb4, 1), dim3(256), 0, st, W.chain_tab.p, 0);
     compact_batch(ctx, n, W.compact_jobs.p + (size_t)1 * W.B, 1);
     hipLaunchKernelGGL(k_fit_partial, dim3(FIT_BLOCKS, 1), dim3(256), 0, st, cv, W.chain_tab.p, 0, w_eps);
-    hipLaunchKernelGGL(k_fit_final, dim3(1), dim3(FIT_BLOCKS), 0, st, W.chain_tab.p, 0);
+    hipLaunchKernelGGL(k_fit_final, dim3(1), dim3(256), 0, st, W.chain_tab.p, 0);
     PlaneState hst[2];
     uint32_t nk = 0;
     std::vector<double> ws(FIT_BLOCKS);
