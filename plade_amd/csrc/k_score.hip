@@ -221,6 +221,8 @@ __global__ __launch_bounds__(TPB) void k_compact_batch(const CompactJob *__restr
     __shared__ float s_mm[4][8];
     const CompactJob jb = jobs[blockIdx.y];
     if (jb.skip && *jb.skip) return;
+    // most tiles of a plane's score list are empty: nothing to place (the last tile still reports the total)
+    if (jb.block_counts[blockIdx.x] == 0 && blockIdx.x != nb - 1) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t pre = 0;
     for (uint32_t b = threadIdx.x; b < blockIdx.x; b += TPB) pre += jb.block_counts[b];
