@@ -163,3 +163,25 @@ def test_extract_planes_full_size_partition(ctx, oracle, big_pair):
         dist = np.abs(cloud[ids, :3] @ coef[p, :3] + coef[p, 3])
         assert (dist < eps3 * 1.001).mean() > 0.999
         assert cloud[ids, 3:].mean(0) @ coef[p, :3] > 0
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_registration_full_size_every_intermediate_equals_oracle(oracle, seed):
+    """BASELINE configs[2] size: the oracle run on the planes the GPU extracted reproduces every dumped
+    intermediate (lines, descriptors, matches, transforms, clusters, plane counts, penetration flags,
+    overlap counts, scores) and the final transform bit for bit."""
+    import plade_amd
+    tg, sr, Tgt = make_pair(N, seed=seed)
+    ctx = plade_amd.Context(0, dump=1)
+    ok, T = ctx.registration(tg, sr)
+    d = ctx.dump()
+    ctx.close()
+    tp = (d["tgt_planes"].reshape(-1, 4), d["tgt_plane_offsets"], d["tgt_plane_idx"])
+    sp = (d["src_planes"].reshape(-1, 4), d["src_plane_offsets"], d["src_plane_idx"])
+    ok_o, T_o, do = oracle.registration(tg, sr, tp, sp, voxel_sort_mode=1)
+    assert ok and ok_o and np.array_equal(T, T_o)
+    common = [k for k in do if k in d]
+    assert len(common) >= 30
+    for k in common:
+        assert np.asarray(d[k]).shape == np.asarray(do[k]).shape and np.array_equal(d[k], do[k]), k
+    assert np.linalg.norm(T.astype(np.float64) - Tgt) < 1e-2
