@@ -1,0 +1,132 @@
+"""The reference's user-facing surface on the GPU: the PLADE command line (code/PLADE/main.cpp) and the
+four C++ registration() overloads of plade.h, built from plade_amd/csrc with g++ and run as a user would."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import plade_amd
+from plade_amd.plyio import write_ply
+from plade_amd.synth import make_pair
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "plade_amd", "PLADE")
+
+
+def parse_results(path):
+    """result-file grammar of main.cpp:84-86,136-140"""
+    blocks, cur = [], None
+    for line in open(path).read().split("\n"):
+        if line.startswith("target: "):
+            cur = {"target": line[8:], "rows": [], "failed": False}
+            blocks.append(cur)
+        elif line.startswith("source: "):
+            cur["source"] = line[8:]
+        elif line.startswith("registration failed"):
+            cur["failed"] = True
+        elif line.startswith("transformation:") or not line.strip():
+            continue
+        else:
+            cur["rows"].append([float(x) for x in line.split()])
+    for b in blocks:
+        b["T"] = np.array(b["rows"], np.float64)
+        assert b["T"].shape == (4, 4)
+    return blocks
+
+
+@pytest.fixture(scope="module")
+def ply_pairs(tmp_path_factory):
+    d = tmp_path_factory.mktemp("ply")
+    out = []
+    for s in (3, 4, 5):
+        tg, sr, Tgt = make_pair(80000, seed=s)
+        pt, ps = str(d / f"t{s}.ply"), str(d / f"s{s}.ply")
+        write_ply(pt, tg)
+        write_ply(ps, sr)
+        out.append((pt, ps, tg, sr, Tgt))
+    return d, out
+
+
+def test_cli_single_pair_matches_the_library(ply_pairs, ctx):
+    d, pairs = ply_pairs
+    pt, ps, tg, sr, Tgt = pairs[0]
+    res = str(d / "one.txt")
+    r = subprocess.run([CLI, pt, ps, res], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    (b,) = parse_results(res)
+    assert b["target"] == pt and b["source"] == ps and not b["failed"]
+    ok, T = ctx.registration(tg, sr)
+    assert ok
+    # Eigen's default stream format prints 6 significant digits
+    assert np.allclose(b["T"], T, rtol=2e-5, atol=2e-6)
+    assert np.linalg.norm(b["T"] - Tgt) < 1e-2
+
+
+def test_cli_batch_mode_in_flight_keeps_input_order(ply_pairs, ctx):
+    d, pairs = ply_pairs
+    lst = d / "file_pairs.txt"
+    lst.write_text("".join(f"{pt}\n{ps}\n" for (pt, ps, *_r) in pairs))
+    res = str(d / "batch.txt")
+    env = dict(os.environ, PLADE_INFLIGHT="3", PLADE_GPUS="1")
+    r = subprocess.run([CLI, str(lst), res], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr
+    blocks = parse_results(res)
+    assert [b["target"] for b in blocks] == [p[0] for p in pairs]
+    for b, (pt, ps, tg, sr, Tgt) in zip(blocks, pairs):
+        ok, T = ctx.registration(tg, sr)
+        assert ok and not b["failed"]
+        assert np.allclose(b["T"], T, rtol=2e-5, atol=2e-6)
+
+
+def test_cli_ascii_ply_and_swap_of_a_larger_source(tmp_path, ctx):
+    """ascii PLY input (ply_reader.cpp) and the |source| >= 1.2 |target| swap + inverse of plade.cpp:690-703."""
+    tg, sr, Tgt = make_pair(60000, seed=6)
+    tg2 = make_pair(60000, seed=6)[0].copy()    # the full scene twice (second sample shifted by < 1 mm): 2x the points
+    tg2[:, :3] += np.float32(5e-4)
+    big_src, small_tgt = np.concatenate([tg, tg2]), sr   # register the full scene onto the cropped one
+    T_expected = np.linalg.inv(Tgt)
+    pt, ps = str(tmp_path / "t.ply"), str(tmp_path / "s.ply")
+    with open(pt, "w") as f:                     # ascii target
+        f.write(f"ply\nformat ascii 1.0\nelement vertex {len(small_tgt)}\n" +
+                "".join(f"property float {p}\n" for p in ("x", "y", "z", "nx", "ny", "nz")) + "end_header\n")
+        np.savetxt(f, small_tgt, fmt="%.9g")
+    write_ply(ps, big_src)
+    assert len(big_src) >= 1.2 * len(small_tgt)
+    res = str(tmp_path / "r.txt")
+    r = subprocess.run([CLI, pt, ps, res], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    (b,) = parse_results(res)
+    assert not b["failed"] and np.linalg.norm(b["T"] - T_expected) < 2e-2
+
+
+def test_cxx_api_four_overloads(ply_pairs, tmp_path, ctx):
+    d, pairs = ply_pairs
+    pt, ps, tg, sr, Tgt = pairs[1]
+    exe = str(tmp_path / "api_harness")
+    csrc = os.path.join(ROOT, "plade_amd", "csrc")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-pthread", "-I", os.path.join(ROOT, "include"), "-I", csrc,
+                           os.path.join(ROOT, "tests", "cxx", "api_harness.cpp"), os.path.join(csrc, "plade_host.cpp"),
+                           os.path.join(csrc, "ply_reader.cpp"), "-o", exe, "-L", os.path.join(ROOT, "plade_amd"),
+                           "-lplade_hip", "-Wl,-rpath," + os.path.join(ROOT, "plade_amd")])
+    r = subprocess.run([exe, pt, ps], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    out, cur = {}, None
+    for l in r.stdout.split("\n"):
+        w = l.split()
+        if w and w[0][1:] in ("files", "clouds", "minsupport", "planes", "noplanes") and w[0][0] == "@":
+            cur = w[0][1:]
+            out[cur] = [int(w[1]), []]
+        elif w and w[0] == "@row":
+            out[cur][1].append([float(x) for x in w[1:]])
+    out = {k: (v[0], np.array(v[1])) for k, v in out.items()}
+    ok, T = ctx.registration(tg, sr)
+    assert ok
+    assert out["files"][0] == 1 and np.array_equal(out["files"][1].astype(np.float32), T)
+    assert out["clouds"][0] == 1 and np.array_equal(out["clouds"][1].astype(np.float32), T)
+    ok2, T2 = ctx.registration_minsupport(tg, sr, 1500, 1500)
+    assert out["minsupport"][0] == int(ok2) and np.array_equal(out["minsupport"][1].astype(np.float32), T2)
+    assert out["planes"][0] == 1 and np.linalg.norm(out["planes"][1] - Tgt) < 2e-2
+    assert out["noplanes"][0] == 0 and np.array_equal(out["noplanes"][1], np.eye(4))
