@@ -572,6 +572,25 @@ __global__ __launch_bounds__(256) void k_fit_final(const ChainDev *__restrict__ 
     }
 }
 
+// point removal + output index lists of all accepted candidates of a batch in one launch (job = blockIdx.y)
+struct AssignJobs {
+    const uint32_t *idx[16];
+    uint32_t m[16];
+    int32_t id[16];
+    int32_t *out[16];   // nullptr: support below min_support, points are removed but no plane is reported
+};
+__global__ void k_assign_batch(AssignJobs jobs, const uint32_t *__restrict__ orig, int32_t *__restrict__ assigned) {
+    const uint32_t j = blockIdx.y, m = jobs.m[j];
+    const uint32_t *__restrict__ idx = jobs.idx[j];
+    int32_t *__restrict__ out = jobs.out[j];
+    const int32_t id = jobs.id[j];
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
+        const uint32_t p = idx[i];
+        assigned[p] = id;
+        if (out) out[i] = (int32_t)orig[p];
+    }
+}
+
 __global__ void k_assign(const uint32_t *__restrict__ idx, uint32_t m, int32_t id, int32_t *__restrict__ assigned) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < m) assigned[idx[i]] = id;
@@ -1019,6 +1038,8 @@ void ransac_detect(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const R
             HIP_TRY(hipGetLastError());
             n_full_passes += 4 * (uint32_t)batch.size();
             t_accept += secs_since(t_a0);
+            AssignJobs aj{};
+            uint32_t n_aj = 0, max_m = 0;
             for (size_t b = 0; b < batch.size(); ++b) {
                 Chain &C = *W.chains[b];
                 const Cand &bc = pool[batch[b]];
@@ -1054,7 +1075,8 @@ void ransac_detect(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const R
                 // ---- remove the points (RansacShapeDetector.cpp:666-675) ---------------------------------
                 if (cand_size == 0) continue;
                 const int32_t shape_id = (int32_t)accepted.size();
-                hipLaunchKernelGGL(k_assign, dim3(cdiv(cand_size, 256)), dim3(256), 0, ctx->stream, cand_idx, cand_size, shape_id, W.assigned.p);
+                aj.idx[n_aj] = cand_idx; aj.m[n_aj] = cand_size; aj.id[n_aj] = shape_id; aj.out[n_aj] = nullptr;
+                max_m = std::max(max_m, cand_size);
                 drawn = std::pow(1.f - (cand_size / float(n_remaining)), 3.f) * drawn;
                 n_remaining -= std::min(n_remaining, cand_size);
                 // plane_extraction.cpp:134-149: shapes below min_support are skipped, d = -n.p with n re-normalised
@@ -1074,12 +1096,15 @@ void ransac_detect(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const R
                     }
                     a.coef[0] = nn[0]; a.coef[1] = nn[1]; a.coef[2] = nn[2]; a.coef[3] = d;
                     a.support = cand_size;
-                    hipLaunchKernelGGL(k_map_indices, dim3(cdiv(cand_size, 256)), dim3(256), 0, ctx->stream, cand_idx, cand_size, W.orig.p,
-                                       W.out_idx.p + out_off);
+                    aj.out[n_aj] = W.out_idx.p + out_off;
                     out_off += cand_size;
                 }
+                ++n_aj;
                 accepted.push_back(a);
             }
+            if (n_aj)   // the candidates of a batch have disjoint supports: one launch removes them all
+                hipLaunchKernelGGL(k_assign_batch, dim3(std::min(cdiv(max_m, 256), 256u), n_aj), dim3(256), 0, ctx->stream, aj, W.orig.p,
+                                   W.assigned.p);
             // drop the batch from the pool (indices are ascending)
             for (size_t b = batch.size(); b-- > 0;) pool.erase(pool.begin() + batch[b]);
             if (n_remaining < rp.min_support) { pool.clear(); break; }
