@@ -341,13 +341,26 @@ __global__ __launch_bounds__(1024) void k_cc_label(const ChainDev *__restrict__ 
     // per row, sequential along the row), (2) runs are united with the runs they touch in the row above
     // (N, NW, NE) by lock-free union-find on the run heads; the smaller index always becomes the parent, so
     // a component's root is its first pixel in raster order
-    for (int v = threadIdx.x; v < ve; v += blockDim.x) {
-        uint32_t head = 0xffffffffu;
-        for (int u = 0; u < ue; ++u) {
-            const int p = v * ue + u;
-            if (bmp[p]) { if (head == 0xffffffffu) head = (uint32_t)p; label[p] = head; }
-            else { head = 0xffffffffu; label[p] = 0xffffffffu; }
-            sizes[p] = 0;
+    {   // one wavefront per row, 64 columns at a time: run head = prefix maximum of the run-start columns
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+        for (int v = wave; v < ve; v += nwaves) {
+            int carry = -1;   // head column of the run that reaches the end of the previous 64-column chunk
+            for (int u0 = 0; u0 < ue; u0 += 64) {
+                const int u = u0 + lane;
+                const int p = v * ue + u;
+                const bool fg = u < ue && bmp[p];
+                const bool left_fg = (u > 0 && u < ue) ? (bool)bmp[p - 1] : false;
+                int h = (fg && !left_fg) ? u : -1;   // a run starts here
+                if (lane == 0 && fg && left_fg) h = carry;   // the run continues from the previous chunk
+                for (int d = 1; d < 64; d <<= 1) {
+                    const int o = __shfl_up(h, d, 64);
+                    if (lane >= d) h = max(h, o);
+                }
+                if (u < ue) { label[p] = fg ? (uint32_t)(v * ue + h) : 0xffffffffu; sizes[p] = 0; }
+                const int last_h = __shfl(h, 63, 64);
+                const bool last_fg = __shfl((int)fg, 63, 64) != 0;
+                carry = last_fg ? last_h : -1;
+            }
         }
     }
     __syncthreads();
