@@ -198,6 +198,8 @@ struct RegistrationWork {
     DBuf<float> d_rt12, d_T16, d_centers;
     DBuf<int32_t> d_counts;
     DBuf<uint32_t> d_any;
+    hipEvent_t ev_grid = nullptr;   // target grid of the verification built on the auxiliary stream
+    ~RegistrationWork() { if (ev_grid) (void)hipEventDestroy(ev_grid); }
 };
 
 RegistrationWork *registration_work_create() { return new RegistrationWork; }
@@ -256,6 +258,11 @@ bool run_registration(plade_ctx *ctx, RegistrationWork &W, const CloudDev &tgt, 
         if (main_err.code) throw main_err;
         if (aux_err.code) throw aux_err;
         if (!ok_m || !ok_c) return false;
+        // the verification's target grid (plade.cpp:545-564 builds a kd-tree per candidate) only needs the
+        // downsampled target: built now on the idle auxiliary stream, consumed five stages later
+        if (!W.ev_grid) HIP_TRY(hipEventCreateWithFlags(&W.ev_grid, hipEventDisableTiming));
+        W.grid.build(aux, M.d_ds.p, M.n_ds, 3, downSampleDistance, tgt.bbmin, tgt.bbmax, true);
+        HIP_TRY(hipEventRecord(W.ev_grid, aux->stream));
     }
     {
         StageTimer t(ctx, "t_descriptors");
@@ -417,7 +424,7 @@ bool run_registration(plade_ctx *ctx, RegistrationWork &W, const CloudDev &tgt, 
         W.d_T16.ensure(16 * (size_t)Kv); W.d_centers.ensure(3 * (size_t)Kv); W.d_counts.ensure(Kv); W.d_any.ensure(Kv);
         HIP_TRY(hipMemcpyAsync(W.d_T16.p, T16.data(), 64 * (size_t)Kv, hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(hipMemcpyAsync(W.d_centers.p, centers.data(), 12 * (size_t)Kv, hipMemcpyHostToDevice, ctx->stream));
-        W.grid.build(ctx, M.d_ds.p, M.n_ds, 3, downSampleDistance, nullptr, nullptr, true);
+        HIP_TRY(hipStreamWaitEvent(ctx->stream, W.ev_grid, 0));
         overlap_counts(ctx, C.d_ds_soa.p, C.d_ds_soa.p + C.n_ds, C.d_ds_soa.p + 2 * (size_t)C.n_ds, C.n_ds, W.grid, W.d_T16.p,
                        W.d_centers.p, Kv, (float)C.radius, downSampleDistance, W.d_counts.p, W.d_any.p);
         std::vector<uint32_t> any(Kv);
