@@ -294,8 +294,9 @@ void compact_batch(plade_ctx *ctx, uint32_t n, const CompactJob *jobs_dev, uint3
 
 void score_multi(plade_ctx *ctx, const float *x, const float *y, const float *z, const float *nx, const float *ny,
                  const float *nz, const int32_t *assigned, const uint32_t *sub_index, uint32_t n,
-                 const float4 *planes_dev, uint32_t h, float eps, float cos_thresh, uint32_t *counts_dev) {
-    HIP_TRY(hipMemsetAsync(counts_dev, 0, sizeof(uint32_t) * h, ctx->stream));
+                 const float4 *planes_dev, uint32_t h, float eps, float cos_thresh, uint32_t *counts_dev,
+                 bool counts_are_zero) {
+    if (!counts_are_zero) HIP_TRY(hipMemsetAsync(counts_dev, 0, sizeof(uint32_t) * h, ctx->stream));
     if (n == 0 || h == 0) return;
     dim3 grid(cdiv(n, TILE), cdiv(h, HCHUNK));
     // algorithmic bytes: 12 pos + 12 normal + 4 shapeIndex per point per pass

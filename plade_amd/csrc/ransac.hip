@@ -103,13 +103,16 @@ struct CloudView {
 __global__ __launch_bounds__(256) void k_sample(CloudView c, const uint32_t *__restrict__ codes,
                                                 const int32_t *__restrict__ assigned, uint64_t seed, uint32_t round,
                                                 uint32_t h, int min_level, int max_level, float eps, float cos_t,
-                                                float4 *__restrict__ hyp, float4 *__restrict__ hyp_pos) {
+                                                float4 *__restrict__ hyp, float4 *__restrict__ hyp_pos,
+                                                uint32_t *__restrict__ counts, uint32_t *__restrict__ misc) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= h) return;
     Rng rng{mix64(seed ^ ((uint64_t)round << 32) ^ t)};
     const float nanv = __int_as_float(0x7fc00000);
     hyp[t] = make_float4(0.f, 0.f, 0.f, nanv);
     hyp_pos[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    counts[t] = 0;                 // the scoring pass that follows accumulates with atomics
+    if (t == 0) *misc = 0;         // and so does the unassigned-point count of the subset
     uint32_t i0 = 0;
     bool ok = false;
     for (int tr = 0; tr < 64 && !ok; ++tr) { i0 = rng.next() % c.n; ok = assigned[i0] == -1; }
@@ -648,7 +651,6 @@ struct RansacWork {
     float4 *hyp = nullptr, *hyp_pos = nullptr;
     uint32_t *hyp_counts = nullptr, *misc = nullptr;
     DBuf<float4> top;
-    DBuf<uint32_t> top_counts;
     DBuf<int32_t> out_idx;
     HBuf<char> pinned;
     // acceptance chains
@@ -941,7 +943,7 @@ void ransac_detect(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const R
     W.hyp_pos = W.hyp + H;
     W.hyp_counts = reinterpret_cast<uint32_t *>(W.hyp_pos + H);
     W.misc = W.hyp_counts + H;
-    W.top.ensure(TOP); W.top_counts.ensure(TOP);
+    W.top.ensure(TOP + TOP / 4 + 4);   // TOP planes followed by TOP counts: one upload brings planes + zeroed counts
     char *pin = W.pinned.ensure(round_bytes + 256);
     W.out_idx.ensure((size_t)n + 4);
     // ---- acceptance chains ------------------------------------------------------------------------
@@ -977,9 +979,8 @@ void ransac_detect(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const R
         ++n_rounds;
         Clock::time_point t_s0 = Clock::now();
         hipLaunchKernelGGL(k_sample, dim3(cdiv(H, 256)), dim3(256), 0, ctx->stream, cv, W.codes.p, W.assigned.p, rp.seed, round, H,
-                           min_level, max_level, eps, cos_t, W.hyp, W.hyp_pos);
-        score_multi(ctx, sx, sy, sz, snx, sny, snz, W.assigned.p, W.sub_index.p, W.n_sub, W.hyp, H, eps, cos_t, W.hyp_counts);
-        HIP_TRY(hipMemsetAsync(W.misc, 0, 4, ctx->stream));
+                           min_level, max_level, eps, cos_t, W.hyp, W.hyp_pos, W.hyp_counts, W.misc);
+        score_multi(ctx, sx, sy, sz, snx, sny, snz, W.assigned.p, W.sub_index.p, W.n_sub, W.hyp, H, eps, cos_t, W.hyp_counts, true);
         hipLaunchKernelGGL(k_count_unassigned, dim3(cdiv(W.n_sub, 256)), dim3(256), 0, ctx->stream, W.assigned.p, W.sub_index.p,
                            W.n_sub, W.misc);
         uint32_t sub_un = 0;
@@ -1015,14 +1016,15 @@ void ransac_detect(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const R
         while (!pool.empty()) {
             Clock::time_point t_r0 = Clock::now();
             const uint32_t np = (uint32_t)pool.size();
-            std::vector<float4> pl(np);
+            std::vector<float4> pl(TOP + TOP / 4, make_float4(0.f, 0.f, 0.f, 0.f));
             for (uint32_t i = 0; i < np; ++i) pl[i] = pool[i].pl;
-            HIP_TRY(hipMemcpyAsync(W.top.p, pl.data(), np * 16, hipMemcpyHostToDevice, ctx->stream));
+            uint32_t *top_counts = reinterpret_cast<uint32_t *>(W.top.p + TOP);
+            HIP_TRY(hipMemcpyAsync(W.top.p, pl.data(), pl.size() * 16, hipMemcpyHostToDevice, ctx->stream));
             score_multi(ctx, c.x(), c.y(), c.z(), c.nx(), c.ny(), c.nz(), W.assigned.p, nullptr, n, W.top.p, np, eps, cos_t,
-                        W.top_counts.p);
+                        top_counts, true);
             ++n_full_passes;
             std::vector<uint32_t> cnts(np);
-            HIP_TRY(hipMemcpyAsync(cnts.data(), W.top_counts.p, np * 4, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(hipMemcpyAsync(cnts.data(), top_counts, np * 4, hipMemcpyDeviceToHost, ctx->stream));
             HIP_TRY(hipStreamSynchronize(ctx->stream));
             t_rescore += secs_since(t_r0);
             for (uint32_t i = 0; i < np; ++i) pool[i].count = cnts[i];

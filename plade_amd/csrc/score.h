@@ -10,7 +10,7 @@ namespace plade {
 void score_multi(plade_ctx *ctx, const float *x, const float *y, const float *z, const float *nx,
                  const float *ny, const float *nz, const int32_t *assigned, const uint32_t *sub_index,
                  uint32_t n, const float4 *planes_dev, uint32_t h, float eps, float cos_thresh,
-                 uint32_t *counts_dev /* zeroed by callee */);
+                 uint32_t *counts_dev /* zeroed by callee unless counts_are_zero */, bool counts_are_zero = false);
 
 // Ordered compaction for ONE hypothesis read from device memory (plane_dev[0]):
 // idx_out_dev receives ascending point indices, *count_dev the total.  eps_scale multiplies eps
