@@ -607,15 +607,6 @@ __global__ void k_assign_batch(AssignJobs jobs, const uint32_t *__restrict__ ori
     }
 }
 
-__global__ void k_assign(const uint32_t *__restrict__ idx, uint32_t m, int32_t id, int32_t *__restrict__ assigned) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < m) assigned[idx[i]] = id;
-}
-__global__ void k_map_indices(const uint32_t *__restrict__ idx, uint32_t m, const uint32_t *__restrict__ orig,
-                              int32_t *__restrict__ out) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < m) out[i] = (int32_t)orig[idx[i]];
-}
 __global__ void k_fill_i32(int32_t *p, uint32_t n, int32_t v) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
