@@ -113,9 +113,21 @@ __global__ __launch_bounds__(256) void k_sample(CloudView c, const uint32_t *__r
     hyp_pos[t] = make_float4(0.f, 0.f, 0.f, 0.f);
     counts[t] = 0;                 // the scoring pass that follows accumulates with atomics
     if (t == 0) *misc = 0;         // and so does the unassigned-point count of the subset
+    // draws are made eight at a time so that their shapeIndex look-ups are in flight together (late rounds
+    // have few unassigned points left and most draws miss)
     uint32_t i0 = 0;
     bool ok = false;
-    for (int tr = 0; tr < 64 && !ok; ++tr) { i0 = rng.next() % c.n; ok = assigned[i0] == -1; }
+    for (int tr = 0; tr < 64 && !ok; tr += 8) {
+        uint32_t cand[8];
+        int32_t av[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) cand[u] = rng.next() % c.n;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) av[u] = assigned[cand[u]];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (!ok && av[u] == -1) { i0 = cand[u]; ok = true; }
+    }
     if (!ok) return;
     const int level = min_level + (int)(rng.next() % (uint32_t)(max_level - min_level + 1));
     const uint32_t low_bits = 24 - 3 * level;
@@ -125,19 +137,23 @@ __global__ __launch_bounds__(256) void k_sample(CloudView c, const uint32_t *__r
     uint32_t hi = (hi_key == 0xffffffffu || hi_key >= 0xffffffu) ? c.n : lb_u32(codes, c.n, hi_key + 1u);
     if (hi - lo < 3) return;
     uint32_t s[3] = {i0, 0, 0};
-    for (int k = 1; k < 3; ++k) {
-        bool got = false;
-        for (int tr = 0; tr < 40 && !got; ++tr) {
-            const uint32_t j = lo + rng.next() % (hi - lo);
-            if (assigned[j] != -1) continue;
+    int got = 1;
+    for (int tr = 0; tr < 40 && got < 3; tr += 8) {
+        uint32_t cand[8];
+        int32_t av[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) cand[u] = lo + rng.next() % (hi - lo);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) av[u] = assigned[cand[u]];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (got >= 3 || av[u] != -1) continue;
             bool dup = false;
-            for (int q = 0; q < k; ++q) dup = dup || (s[q] == j);
-            if (dup) continue;
-            s[k] = j;
-            got = true;
+            for (int q = 0; q < got; ++q) dup = dup || (s[q] == cand[u]);
+            if (!dup) s[got++] = cand[u];
         }
-        if (!got) return;
     }
+    if (got < 3) return;
     // three samples drawn: this counts as a generated candidate (genCands, RansacShapeDetector.cpp:122-125)
     // whether or not the plane survives construction / verification below
     hyp_pos[t] = make_float4(0.f, 0.f, 0.f, 2.f);
