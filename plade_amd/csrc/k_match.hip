@@ -99,22 +99,26 @@ __global__ void k_query_offsets(const uint32_t *__restrict__ offs, uint32_t dq, 
 
 // Order inside each query's list: (dist2, target index).  The fill pass already wrote the lists query by
 // query in ascending target order, so each entry's final place is its rank by (dist2, position) inside
-// its own list: one wave per query, O(len^2 / 64) compares (lists are tens to hundreds of entries).
+// its own list: one workgroup per query, the list in LDS, O(len^2 / 256) compares (lists are tens to a few
+// thousand entries).
 constexpr uint32_t RANK_MAX_LIST = 4096;
 __global__ __launch_bounds__(256) void k_rank_lists(const int64_t *__restrict__ offsets, uint32_t dq,
                                                     const uint32_t *__restrict__ t_raw, const double *__restrict__ d2_raw,
                                                     uint32_t *__restrict__ t_out, double *__restrict__ d2_out) {
-    const uint32_t q = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    __shared__ double s_d2[RANK_MAX_LIST];   // one workgroup per query: its list staged in LDS (<= 4096 entries)
+    const uint32_t q = blockIdx.x;
     if (q >= dq) return;
-    const uint32_t b = (uint32_t)offsets[q], e = (uint32_t)offsets[q + 1];
-    for (uint32_t i = b + lane; i < e; i += 64) {
-        const double di = d2_raw[i];
+    const uint32_t b = (uint32_t)offsets[q], e = (uint32_t)offsets[q + 1], len = e - b;
+    for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) s_d2[i] = d2_raw[b + i];
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) {
+        const double di = s_d2[i];
         uint32_t rank = 0;
-        for (uint32_t j = b; j < e; ++j) {
-            const double dj = d2_raw[j];
+        for (uint32_t j = 0; j < len; ++j) {
+            const double dj = s_d2[j];
             rank += (dj < di || (dj == di && j < i)) ? 1u : 0u;
         }
-        t_out[b + rank] = t_raw[i];
+        t_out[b + rank] = t_raw[b + i];
         d2_out[b + rank] = di;
     }
 }
@@ -152,7 +156,7 @@ uint64_t MatchResult::run(plade_ctx *ctx, const float *d_qry, uint32_t dq, const
     t_idx.ensure(m); dist2.ensure(m);
     q_idx_sorted = q_raw.p;   // lists are contiguous per query
     if (max_list <= RANK_MAX_LIST) {
-        hipLaunchKernelGGL(k_rank_lists, dim3(cdiv(dq, 4)), dim3(256), 0, ctx->stream, offsets.p, dq, t_raw.p, d2_raw.p, t_idx.p,
+        hipLaunchKernelGGL(k_rank_lists, dim3(dq), dim3(256), 0, ctx->stream, offsets.p, dq, t_raw.p, d2_raw.p, t_idx.p,
                            dist2.p);
         HIP_TRY(hipGetLastError());
         return total;
