@@ -104,6 +104,8 @@ struct DBuf {
         return p;
     }
     operator T *() const { return p; }
+    // exchange the allocations of two buffers (hand a result over without a device copy)
+    void swap(DBuf &o) { T *tp = p; p = o.p; o.p = tp; size_t tc = cap; cap = o.cap; o.cap = tc; }
 };
 
 // pinned host buffer

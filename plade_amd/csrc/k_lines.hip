@@ -115,18 +115,25 @@ void build_pair_table(plade_ctx *ctx, const LineTableHost &lt, const float *norm
     if (L == 0) return;
     const size_t n = (size_t)L * L;
     PLADE_REQUIRE(n < (1ull << 31), PLADE_ELIMIT, "line-pair table too large");
-    out.d_pt.ensure(3 * (size_t)L); out.d_sp.ensure(2 * (size_t)L); out.d_iter.ensure(lt.iter.size());
-    out.d_it.ensure(4 * (size_t)L); out.d_normals.ensure(3 * (size_t)P);
-    std::vector<int32_t> it(4 * (size_t)L);
-    for (uint32_t l = 0; l < L; ++l) { it[4 * l] = lt.it_off[l]; it[4 * l + 1] = lt.it_len[l]; it[4 * l + 2] = lt.it_start[l]; it[4 * l + 3] = lt.it_period[l]; }
-    HIP_TRY(hipMemcpyAsync(out.d_pt.p, lt.pt.data(), 12 * (size_t)L, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(out.d_sp.p, lt.sp.data(), 8 * (size_t)L, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(out.d_iter.p, lt.iter.data(), lt.iter.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(out.d_it.p, it.data(), 16 * (size_t)L, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(out.d_normals.p, normals, 12 * (size_t)P, hipMemcpyHostToDevice, ctx->stream));
+    // one staging buffer, one upload: pt (3L) | sp (2L) | iterates | it (4L) | normals (3P)
+    const size_t o_pt = 0, o_sp = o_pt + 3 * (size_t)L, o_iter = o_sp + 2 * (size_t)L, o_it = o_iter + lt.iter.size(),
+                 o_nrm = o_it + 4 * (size_t)L, words = o_nrm + 3 * (size_t)P;
+    std::vector<uint32_t> blob(words);
+    memcpy(&blob[o_pt], lt.pt.data(), 12 * (size_t)L);
+    memcpy(&blob[o_sp], lt.sp.data(), 8 * (size_t)L);
+    memcpy(&blob[o_iter], lt.iter.data(), 4 * lt.iter.size());
+    {
+        int32_t *it = reinterpret_cast<int32_t *>(&blob[o_it]);
+        for (uint32_t l = 0; l < L; ++l) { it[4 * l] = lt.it_off[l]; it[4 * l + 1] = lt.it_len[l]; it[4 * l + 2] = lt.it_start[l]; it[4 * l + 3] = lt.it_period[l]; }
+    }
+    memcpy(&blob[o_nrm], normals, 12 * (size_t)P);
+    uint32_t *d = out.d_blob.ensure(words + 4);
+    HIP_TRY(hipMemcpyAsync(d, blob.data(), 4 * words, hipMemcpyHostToDevice, ctx->stream));
     out.all_desc.ensure(n * 8); out.all_lv1.ensure(n * 3); out.all_lv2.ensure(n * 3); out.all_p1.ensure(n * 3);
     out.flags.ensure(n + 1); out.pos.ensure(n + 1);
-    LinesView v{out.d_pt.p, out.d_sp.p, out.d_iter.p, out.d_it.p, out.d_normals.p, L};
+    LinesView v{reinterpret_cast<const float *>(d + o_pt), reinterpret_cast<const int32_t *>(d + o_sp),
+                reinterpret_cast<const float *>(d + o_iter), reinterpret_cast<const int32_t *>(d + o_it),
+                reinterpret_cast<const float *>(d + o_nrm), L};
     const float angle_thresh = (float)cos(10.0 / 180 * M_PI);  // util.cpp:773, plade.cpp:513
     hipLaunchKernelGGL(k_pair_table, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, v, scale, angle_thresh, target ? 1 : 0,
                        out.flags.p, out.all_desc.p, out.all_lv1.p, out.all_lv2.p, out.all_p1.p);
@@ -134,7 +141,7 @@ void build_pair_table(plade_ctx *ctx, const LineTableHost &lt, const float *norm
     exclusive_scan_u32(ctx, out.flags.p, out.pos.p, n + 1);
     uint32_t total = 0;
     HIP_TRY(hipMemcpyAsync(&total, out.pos.p + n, 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));  // also keeps `it` alive until the copies are done
+    HIP_TRY(hipStreamSynchronize(ctx->stream));  // also keeps `blob` alive until the copy is done
     out.count = total;
     out.desc.ensure((size_t)total * 8 + 8); out.lv1.ensure((size_t)total * 3 + 4); out.lv2.ensure((size_t)total * 3 + 4);
     out.p1.ensure((size_t)total * 3 + 4);

@@ -94,17 +94,16 @@ void make_line_table(const float *coef, uint32_t P, f3 bcenter, double radius, L
 }
 
 bool prepare_side(plade_ctx *ctx, const char *tag, const CloudDev &cloud, const PlaneSetView &pl, float leaf, float pen_cell,
-                  Side &S) {
+                  float desc_scale, bool is_target, PairTableDev &pairs, Side &S) {
     const uint32_t P = pl.P;
     Clock::time_point tp0 = Clock::now();
     // whole cloud: DownSamplePointCloud (plade.cpp:77-79 / :292-294)
     S.n_ds = S.vox_all.run(ctx, cloud.aos.p, 6, nullptr, nullptr, cloud.n, 1, leaf, cloud.bbmin, cloud.bbmax);
     if (S.n_ds == 0) return false;
     S.ds.resize(3 * (size_t)S.n_ds);
-    S.d_ds.ensure(3 * (size_t)S.n_ds + 4);
     S.d_ds_soa.ensure(3 * (size_t)S.n_ds + 4);
-    HIP_TRY(hipMemcpyAsync(S.d_ds.p, S.vox_all.out_xyz.p, 12 * (size_t)S.n_ds, hipMemcpyDeviceToDevice, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(S.ds.data(), S.vox_all.out_xyz.p, 12 * (size_t)S.n_ds, hipMemcpyDeviceToHost, ctx->stream));
+    S.d_ds.swap(S.vox_all.out_xyz);   // the result becomes d_ds, the work area takes last call's buffer back
+    HIP_TRY(hipMemcpyAsync(S.ds.data(), S.d_ds.p, 12 * (size_t)S.n_ds, hipMemcpyDeviceToHost, ctx->stream));
     deinterleave3(ctx, S.d_ds.p, S.n_ds, S.d_ds_soa.p, S.d_ds_soa.p + S.n_ds, S.d_ds_soa.p + 2 * (size_t)S.n_ds);
     // per-plane clouds in one pass (plade.cpp:93-105 / :308-319)
     const uint32_t n_items = (uint32_t)pl.offsets[P];
@@ -119,12 +118,10 @@ bool prepare_side(plade_ctx *ctx, const char *tag, const CloudDev &cloud, const 
                                             cloud.bbmax);
     S.plane_ds.resize(3 * (size_t)n_pds);
     S.pcl.off.resize((size_t)P + 1);
-    S.pcl.xyz.ensure(3 * (size_t)n_pds + 4);
-    S.pcl.d_off.ensure((size_t)P + 2);
-    HIP_TRY(hipMemcpyAsync(S.pcl.xyz.p, S.vox_planes.out_xyz.p, 12 * (size_t)n_pds, hipMemcpyDeviceToDevice, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(S.pcl.d_off.p, S.vox_planes.group_offsets.p, 4 * ((size_t)P + 1), hipMemcpyDeviceToDevice, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(S.plane_ds.data(), S.vox_planes.out_xyz.p, 12 * (size_t)n_pds, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(S.pcl.off.data(), S.vox_planes.group_offsets.p, 4 * ((size_t)P + 1), hipMemcpyDeviceToHost, ctx->stream));
+    S.pcl.xyz.swap(S.vox_planes.out_xyz);
+    S.pcl.d_off.swap(S.vox_planes.group_offsets);
+    HIP_TRY(hipMemcpyAsync(S.plane_ds.data(), S.pcl.xyz.p, 12 * (size_t)n_pds, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(S.pcl.off.data(), S.pcl.d_off.p, 4 * ((size_t)P + 1), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     ctx->stats.add(std::string("t_prep_voxel_") + tag, secs_since(tp0));
     tp0 = Clock::now();
@@ -161,6 +158,8 @@ bool prepare_side(plade_ctx *ctx, const char *tag, const CloudDev &cloud, const 
     S.pcl.grid_cell = 0.f;
     build_pen_grid(ctx, S.pcl, S.geom, pen_cell);   // in-plane grids for the penetration walk (A11)
     make_line_table(pl.coef, P, S.bcenter, S.radius, S.lines);
+    // line-pair descriptors of this side (K4); both sides build theirs concurrently
+    build_pair_table(ctx, S.lines, S.normals.data(), P, desc_scale, is_target, pairs);
     ctx->stats.add(std::string("t_prep_lines_") + tag, secs_since(tp0));
     if (ctx->params.dump) {
         const std::string t(tag);
@@ -247,11 +246,11 @@ bool run_registration(plade_ctx *ctx, RegistrationWork &W, const CloudDev &tgt, 
         Err aux_err{0, ""}, main_err{0, ""};
         std::thread th([&]() {
             (void)hipSetDevice(ctx->device);
-            try { ok_c = prepare_side(aux, "src", src, sp, downSampleDistance, pen_grid_cell(lengthThreshold), C); }
+            try { ok_c = prepare_side(aux, "src", src, sp, downSampleDistance, pen_grid_cell(lengthThreshold), scale, false, W.src_pairs, C); }
             catch (const Err &e) { aux_err = e; }
             catch (const std::exception &e) { aux_err = Err{PLADE_EDEVICE, e.what()}; }
         });
-        try { ok_m = prepare_side(ctx, "tgt", tgt, tp, downSampleDistance, pen_grid_cell(lengthThreshold), M); } catch (const Err &e) { main_err = e; }
+        try { ok_m = prepare_side(ctx, "tgt", tgt, tp, downSampleDistance, pen_grid_cell(lengthThreshold), scale, true, W.tgt_pairs, M); } catch (const Err &e) { main_err = e; }
         th.join();
         for (auto &kv : aux->dump) ctx->dump[kv.first] = kv.second;
         ctx->stats.merge(aux->stats);
@@ -265,9 +264,7 @@ bool run_registration(plade_ctx *ctx, RegistrationWork &W, const CloudDev &tgt, 
         HIP_TRY(hipEventRecord(W.ev_grid, aux->stream));
     }
     {
-        StageTimer t(ctx, "t_descriptors");
-        build_pair_table(ctx, M.lines, M.normals.data(), tp.P, scale, true, W.tgt_pairs);
-        build_pair_table(ctx, C.lines, C.normals.data(), sp.P, scale, false, W.src_pairs);
+        StageTimer t(ctx, "t_descriptors");   // built by prepare_side; only the optional dump is left here
         if (ctx->params.dump) {
             ctx->put_dev("tgt_desc", W.tgt_pairs.desc.p, 8 * (size_t)W.tgt_pairs.count);
             ctx->put_dev("src_desc", W.src_pairs.desc.p, 8 * (size_t)W.src_pairs.count);

@@ -27,8 +27,7 @@ struct PairTableDev {
     // scratch
     DBuf<float> all_desc, all_lv1, all_lv2, all_p1;
     DBuf<uint32_t> flags, pos;
-    DBuf<float> d_pt, d_iter, d_normals;
-    DBuf<int32_t> d_sp, d_it;
+    DBuf<uint32_t> d_blob;        // line table in one upload: pt | sp | iterates | it | normals (4-byte words)
 };
 
 // target = true: all ordered pairs i != j (ConstructPairLinesKdTree, util.cpp:774-826);
