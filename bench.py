@@ -117,11 +117,11 @@ def cpu_baseline(n_points, pairs, budget_s=25.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=48)
-    ap.add_argument("--warmup", type=int, default=6)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--points", type=int, default=1000000)
     ap.add_argument("--pairs", type=int, default=2, help="distinct synthetic pairs per rank (cycled)")
-    ap.add_argument("--inflight", type=int, default=6,
+    ap.add_argument("--inflight", type=int, default=8,
                     help="registrations in flight per GPU: independent pairs, one plade_ctx + host thread each "
                          "(a single registration is latency-bound and leaves most of the GPU idle)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

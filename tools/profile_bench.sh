@@ -7,10 +7,10 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out
 mkdir -p $O
 cd $R
-timeout 900 python bench.py --steps 48 --warmup 6 > $O/bench_r1.json 2> $O/bench_r1.err
+timeout 900 python bench.py --steps 64 --warmup 8 > $O/bench_r1.json 2> $O/bench_r1.err
 tail -c 3000 $O/bench_r1.json
 cd /tmp && export TMPDIR=/tmp
-CMD="python $R/bench.py --steps 24 --warmup 6 --no-cpu-baseline"
+CMD="python $R/bench.py --steps 32 --warmup 8 --no-cpu-baseline"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench -o bench -- $CMD > $O/prof_bench.log 2>&1
 timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/prof_pmc_fetch -o pmc -- $CMD > $O/prof_pmc_fetch.log 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/prof_pmc_write -o pmc -- $CMD > $O/prof_pmc_write.log 2>&1
