@@ -148,16 +148,16 @@ bool registration(Eigen::Matrix<float, 4, 4> &transformation, pcl::PointCloud<pc
     return true;
 }
 
-// plade.h:58-61 / plade.cpp:638-662
-bool registration(Eigen::Matrix<float, 4, 4> &transformation, pcl::PointCloud<pcl::PointNormal>::Ptr target_cloud,
-                  pcl::PointCloud<pcl::PointNormal>::Ptr source_cloud) {
+namespace {
+
+// body of registration(T, target, source) (plade.cpp:638-662) on packed x y z nx ny nz arrays
+bool register_packed(Eigen::Matrix<float, 4, 4> &transformation, const float *tg, size_t n_t, const float *sr, size_t n_s) {
     plade_ctx *ctx = context();
     if (!ctx) return false;
     std::cout << "extracting planes for both point clouds...\n";
-    std::vector<float> tg = flatten(*target_cloud), sr = flatten(*source_cloud);
     float T16[16];
     Watch w;
-    int rc = plade_registration(ctx, tg.data(), (uint32_t)target_cloud->size(), sr.data(), (uint32_t)source_cloud->size(), T16);
+    int rc = plade_registration(ctx, tg, (uint32_t)n_t, sr, (uint32_t)n_s, T16);
     if (rc != PLADE_OK) {
         std::cerr << plade_last_error(ctx) << std::endl;
         return false;
@@ -165,6 +165,28 @@ bool registration(Eigen::Matrix<float, 4, 4> &transformation, pcl::PointCloud<pc
     to_matrix(T16, transformation);
     std::cout << "done. time: " << w.str() << std::endl;
     return true;
+}
+
+// a PLY file straight into a packed array (no pcl::PointCloud in between: at GPU speeds the 48 B/point
+// intermediate and its page faults cost several registrations); `buf` is reused from call to call
+bool load_packed(const std::string &file_name, std::vector<float> &buf) {
+    std::string err;
+    std::vector<std::string> warnings;
+    if (!plade::read_ply_pos_nrm(file_name, buf, err, &warnings)) {
+        if (!err.empty()) std::cerr << err << std::endl;
+        return false;
+    }
+    for (auto &w : warnings) std::cout << w << std::endl;
+    return !buf.empty();
+}
+
+}  // namespace
+
+// plade.h:58-61 / plade.cpp:638-662
+bool registration(Eigen::Matrix<float, 4, 4> &transformation, pcl::PointCloud<pcl::PointNormal>::Ptr target_cloud,
+                  pcl::PointCloud<pcl::PointNormal>::Ptr source_cloud) {
+    std::vector<float> tg = flatten(*target_cloud), sr = flatten(*source_cloud);
+    return register_packed(transformation, tg.data(), target_cloud->size(), sr.data(), source_cloud->size());
 }
 
 // plade.h:44-47 / plade.cpp:665-706
@@ -176,24 +198,26 @@ bool registration(Eigen::Matrix<float, 4, 4> &transformation, const std::string 
         std::cerr << "only PLY format is accepted" << std::endl;
         return false;
     }
-    pcl::PointCloud<pcl::PointNormal>::Ptr target_cloud(new pcl::PointCloud<pcl::PointNormal>);
-    if (!load_ply_cloud(target_cloud_file, *target_cloud)) {
+    thread_local std::vector<float> target_buf, source_buf;   // one pair of staging arrays per worker thread
+    if (!load_packed(target_cloud_file, target_buf)) {
         std::cerr << "loading target point cloud failed" << std::endl;
         return false;
     }
-    pcl::PointCloud<pcl::PointNormal>::Ptr source_cloud(new pcl::PointCloud<pcl::PointNormal>);
-    if (!load_ply_cloud(source_cloud_file, *source_cloud)) {
+    if (!load_packed(source_cloud_file, source_buf)) {
         std::cerr << "loading source point cloud failed" << std::endl;
         return false;
     }
+    const float *tg = target_buf.data(), *sr = source_buf.data();
+    size_t n_t = target_buf.size() / 6, n_s = source_buf.size() / 6;
     bool switched = false;
-    if (source_cloud->size() >= target_cloud->size() * 1.2f) {
-        std::swap(target_cloud, source_cloud);
+    if (n_s >= n_t * 1.2f) {
+        std::swap(tg, sr);
+        std::swap(n_t, n_s);
         switched = true;
         std::cout << "---->>> ATTENTION: target and source have been switched for efficiency <<<----" << std::endl;
     }
     transformation.setIdentity();
-    bool status = registration(transformation, target_cloud, source_cloud);
+    bool status = register_packed(transformation, tg, n_t, sr, n_s);
     if (!status) {
         std::cerr << "registration failed" << std::endl;
         return false;

@@ -59,10 +59,10 @@ bool host_is_little_endian() {
 }  // namespace
 
 bool read_ply_pos_nrm(const std::string &path, std::vector<float> &out, std::string &err, std::vector<std::string> *warnings) {
-    out.clear();
+    // `out` may be a reused staging array: it is only resized when the point count differs (no re-zeroing)
     FILE *f = fopen(path.c_str(), "rb");
-    if (!f) { err = "could not open file: " + path; return false; }
-    auto fail = [&](const std::string &m) { err = m; fclose(f); return false; };
+    if (!f) { out.clear(); err = "could not open file: " + path; return false; }
+    auto fail = [&](const std::string &m) { out.clear(); err = m; fclose(f); return false; };
     std::vector<Elem> elems;
     std::string format;
     char linebuf[4096];
@@ -113,7 +113,7 @@ bool read_ply_pos_nrm(const std::string &path, std::vector<float> &out, std::str
             const bool has_pos = col[0] >= 0 && col[1] >= 0 && col[2] >= 0, has_nrm = col[3] >= 0 && col[4] >= 0 && col[5] >= 0;
             if (!has_pos || !has_nrm)
                 return fail("the number of points does not equal to the number of normals in the file");
-            out.resize(6 * e.count);
+            if (out.size() != 6 * e.count) out.resize(6 * e.count);
             got_vertex = true;
         } else if (warnings) warnings->push_back("Warning: unknown element '" + e.name);
         bool fixed = true;
@@ -178,7 +178,7 @@ bool read_ply_pos_nrm(const std::string &path, std::vector<float> &out, std::str
         }
     }
     fclose(f);
-    if (!got_vertex) { err = "no vertex element in " + path; return false; }
+    if (!got_vertex) { out.clear(); err = "no vertex element in " + path; return false; }
     return true;
 }
 
