@@ -80,3 +80,19 @@ def test_g3_connected_component_lsfit_wscore_from_libransac(ctx):
             assert np.abs(fit[3:6] - ref[3:6]).max() < 1e-5
             assert abs(ws - float(g[f"wscore_{i}"])) <= 1e-4 * max(1.0, float(g[f"wscore_{i}"]))
     assert multi >= 6
+
+
+def test_g8_reference_sample_pair_on_the_gpu(ctx, oracle):
+    """End to end on the reference's own sample pair.  With the planes the reference's RANSAC extracted
+    (planes-given overload, plade.h:74) the GPU reproduces the authors' recorded result and the shipped ground
+    truth, bit-identical to the oracle; with its own plane extraction (plade.h:58) it lands on the same pose."""
+    g = load("g8_polyhedron.npz")
+    tp, sp = (g["t_coef"], g["t_off"], g["t_idx"]), (g["s_coef"], g["s_off"], g["s_idx"])
+    ok, T = ctx.registration_planes(g["target"], g["source"], tp, sp)
+    assert ok
+    assert np.abs(T - g["recorded"]).max() < 5e-5      # sample_data/file_pairs_results.txt:3-7
+    assert np.abs(T - g["groundtruth"]).max() < 5e-5   # sample_data/polyhedron_source_groundtruth.txt
+    ok_o, T_o, _ = oracle.registration(g["target"], g["source"], tp, sp, voxel_sort_mode=1)
+    assert ok_o and np.array_equal(T, T_o)
+    ok2, T2 = ctx.registration(g["target"], g["source"])
+    assert ok2 and np.linalg.norm(T2.astype(np.float64) - g["groundtruth"]) < 1e-2

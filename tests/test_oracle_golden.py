@@ -81,6 +81,18 @@ def test_g7_overlap_counts(oracle):
     assert g["counts"][-1] == -1 and g["counts"][:-1].max() > 1000
 
 
+def test_g8_reference_sample_pair_reproduces_the_authors_recorded_result(oracle):
+    """The reference's own sample pair (sample_data/polyhedron_*.ply) with the planes its own RANSAC extracted:
+    the oracle lands on the transform the authors recorded (sample_data/file_pairs_results.txt:3-7) and on the
+    shipped ground truth."""
+    g = load("g8_polyhedron.npz")
+    ok, T, _ = oracle.registration(g["target"], g["source"], (g["t_coef"], g["t_off"], g["t_idx"]),
+                                   (g["s_coef"], g["s_off"], g["s_idx"]))
+    assert ok
+    assert np.abs(T - g["recorded"]).max() < 5e-5
+    assert np.abs(T - g["groundtruth"]).max() < 5e-5
+
+
 def test_average_spacing_bit_exact(oracle):
     g = load("g_spacing.npz")
     assert np.float32(oracle.average_spacing(g["cloud"])) == g["spacing"]

@@ -175,4 +175,30 @@ sets = R.radius_sets(cloud[:5000, :3], qq, 0.3)
 np.savez_compressed(os.path.join(OUT, "g_radius.npz"), cloud=cloud[:5000, :3].copy(), queries=qq, radius=np.float32(0.3),
                     sizes=np.array([len(s) for s in sets], np.int32),
                     members=np.concatenate([np.sort(s) for s in sets]).astype(np.int32))
+# ---- G8: the reference's own sample pair, libransac's planes for it, the authors' recorded result ---------
+# (sample_data/polyhedron_{target,source}.ply are data, not code; the planes come from the reference's RANSAC
+# built from its sources (oracle/_ref) with time() pinned, driven exactly as extract() of plade.cpp:602-635)
+SAMPLE = "/root/reference/sample_data"
+from plade_amd.plyio import read_ply  # noqa: E402
+ptg = read_ply(os.path.join(SAMPLE, "polyhedron_target.ply"))
+psr = read_ply(os.path.join(SAMPLE, "polyhedron_source.ply"))
+
+
+def ref_extract(c, seed):
+    ms, trials = 10000, 1
+    pl = R.ransac_detect(c, ms, fake_time=seed)
+    ms //= 2
+    while len(pl[0]) < 10 and trials < 10 and ms >= 200:
+        pl = R.ransac_detect(c, ms, fake_time=seed)
+        ms //= 2
+        trials += 1
+    return pl
+
+
+tpl, spl = ref_extract(ptg, 1), ref_extract(psr, 2)
+recorded = np.array([[-0.506082, 0.860669, 0.0559446, -0.252576], [0.821345, 0.500721, -0.273261, 0.863337],
+                     [-0.2632, -0.0923425, -0.960312, 0.154749], [0, 0, 0, 1]])   # sample_data/file_pairs_results.txt:3-7
+np.savez_compressed(os.path.join(OUT, "g8_polyhedron.npz"), target=ptg, source=psr,
+                    groundtruth=np.loadtxt(os.path.join(SAMPLE, "polyhedron_source_groundtruth.txt")), recorded=recorded,
+                    t_coef=tpl[0], t_off=tpl[1], t_idx=tpl[2], s_coef=spl[0], s_off=spl[1], s_idx=spl[2])
 print("golden fixtures written to", OUT, [f for f in sorted(os.listdir(OUT))])
