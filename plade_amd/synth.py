@@ -11,13 +11,14 @@ import numpy as np
 ROOM = np.array([10.0, 8.0, 3.0])
 
 
-def _furniture(rng, n_boxes):
+def _furniture(rng, n_boxes, ROOM=ROOM):
     """Non-overlapping boxes standing on the floor; returns (lo, hi) corner arrays."""
     boxes = []
     tries = 0
     while len(boxes) < n_boxes and tries < 20000:
         tries += 1
-        size = np.array([rng.uniform(1.2, 2.0), rng.uniform(1.1, 1.8), rng.uniform(0.8, 2.45)])
+        zmax = 2.45 if ROOM[2] == 3.0 else ROOM[2] - 0.55
+        size = np.array([rng.uniform(1.2, 2.0), rng.uniform(1.1, 1.8), rng.uniform(0.8, zmax)])
         # keep every face >= 0.5 m from the parallel room face and from the other boxes' parallel
         # faces: Schnabel's global scoring uses 3 eps = 15 cm here and would merge closer coplanar-ish
         # faces into one shape (in the reference as much as in this implementation)
@@ -41,7 +42,7 @@ def _furniture(rng, n_boxes):
     return boxes
 
 
-def _faces(scene_seed, n_boxes):
+def _faces(scene_seed, n_boxes, ROOM=ROOM):
     """List of faces: (origin, edge_u, edge_v, normal, weight)."""
     rng = np.random.default_rng(scene_seed)
     h = ROOM / 2
@@ -57,7 +58,7 @@ def _faces(scene_seed, n_boxes):
             nrm = np.zeros(3); nrm[ax] = -sgn
             faces.append((o, eu, ev, nrm, ROOM[u] * ROOM[v]))
     # furniture: top + two sides chosen per box, normals pointing out of the box (into the room)
-    for (lo, hi) in _furniture(rng, n_boxes):
+    for (lo, hi) in _furniture(rng, n_boxes, ROOM):
         size = hi - lo
         sx = rng.choice([-1, 1]); sy = rng.choice([-1, 1])
         # top
@@ -84,9 +85,11 @@ def _faces(scene_seed, n_boxes):
 
 
 def sample_scene(n, scene_seed=0, sample_seed=1, n_boxes=8, noise=0.005, normal_jitter=0.02, outliers=0.03,
-                 return_labels=False):
-    """N x 6 float32 cloud; with return_labels also the generating face id per point (-1 = outlier)."""
-    faces = _faces(scene_seed, n_boxes)
+                 return_labels=False, room=None):
+    """N x 6 float32 cloud; with return_labels also the generating face id per point (-1 = outlier).
+    room: (W, D, H) in metres, default 10 x 8 x 3 (a larger room takes more furniture: BASELINE configs[4])."""
+    ROOM = np.asarray(room, float) if room is not None else globals()["ROOM"]
+    faces = _faces(scene_seed, n_boxes, ROOM)
     rng = np.random.default_rng(sample_seed)
     n_out = int(round(n * outliers))
     n_in = n - n_out
@@ -150,12 +153,13 @@ def planes_from_labels(cloud, labels, min_points=50):
             np.concatenate(idx).astype(np.int32) if idx else np.zeros(0, np.int32))
 
 
-def make_pair(n, seed=0, n_boxes=8, keep=0.6, return_labels=False):
+def make_pair(n, seed=0, n_boxes=8, keep=0.6, return_labels=False, room=None):
     """Returns (target N x 6, source ~N x 6, T_gt 4x4) with T_gt mapping source -> target
     (+ the per-point face labels of both clouds when return_labels)."""
-    target, tl = sample_scene(n, scene_seed=1000 + seed, sample_seed=2 * seed + 1, n_boxes=n_boxes, return_labels=True)
+    target, tl = sample_scene(n, scene_seed=1000 + seed, sample_seed=2 * seed + 1, n_boxes=n_boxes, return_labels=True,
+                              room=room)
     full, fl = sample_scene(int(n / keep), scene_seed=1000 + seed, sample_seed=2 * seed + 2, n_boxes=n_boxes,
-                            return_labels=True)
+                            return_labels=True, room=room)
     rng = np.random.default_rng(5000 + seed)
     d = np.array([1.0, 0.35 * rng.uniform(-1, 1), 0.0]); d /= np.linalg.norm(d)
     proj = full[:, :3] @ d
