@@ -37,7 +37,14 @@ __global__ __launch_bounds__(256) void k_minmax3(const float *__restrict__ xyz, 
     block_minmax_commit<3>(mn, mx, reinterpret_cast<int *>(out6), s_lds);
 }
 
-__global__ void k_cell_ids(const float *__restrict__ xyz, uint32_t n, uint32_t stride, GridParams g,
+// blocked numbering: 4 x 4 x 4 cells per block, blocks x-major (see overlap.h)
+__device__ __forceinline__ uint32_t block_of(int cx, int cy, int cz, int dx, int dy) {
+    const int bdx = (dx + 3) >> 2, bdy = (dy + 3) >> 2;
+    return (uint32_t)((cx >> 2) + bdx * ((cy >> 2) + bdy * (cz >> 2)));
+}
+__device__ __forceinline__ uint32_t local_of(int cx, int cy, int cz) { return (uint32_t)((cx & 3) | ((cy & 3) << 2) | ((cz & 3) << 4)); }
+
+__global__ void k_cell_ids(const float *__restrict__ xyz, uint32_t n, uint32_t stride, GridParams g, int blocked,
                            uint32_t *__restrict__ keys, uint32_t *__restrict__ vals) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -45,7 +52,7 @@ __global__ void k_cell_ids(const float *__restrict__ xyz, uint32_t n, uint32_t s
     int cx = min(max((int)floorf((x - g.mnx) * g.inv), 0), g.dx - 1);
     int cy = min(max((int)floorf((y - g.mny) * g.inv), 0), g.dy - 1);
     int cz = min(max((int)floorf((z - g.mnz) * g.inv), 0), g.dz - 1);
-    keys[i] = (uint32_t)(cx + g.dx * (cy + g.dy * cz));
+    keys[i] = blocked ? (block_of(cx, cy, cz, g.dx, g.dy) << 6) | local_of(cx, cy, cz) : (uint32_t)(cx + g.dx * (cy + g.dy * cz));
     vals[i] = i;
 }
 
@@ -130,11 +137,12 @@ void TargetGrid::build(plade_ctx *ctx, const float *d_xyz, uint32_t n_pts, uint3
     }
     gp.mnx = init[0]; gp.mny = init[1]; gp.mnz = init[2];
     gp.inv = 1.f / cell;
-    ncells = (size_t)gp.dx * gp.dy * gp.dz;
+    ncells = compact ? (size_t)((gp.dx + 3) >> 2) * ((gp.dy + 3) >> 2) * ((gp.dz + 3) >> 2) * 64 : (size_t)gp.dx * gp.dy * gp.dz;
     keys.ensure(n); keys2.ensure(n); vals.ensure(n); vals2.ensure(n);
     sorted.ensure(n);
     GridParams g{gp.mnx, gp.mny, gp.mnz, gp.inv, gp.dx, gp.dy, gp.dz};
-    hipLaunchKernelGGL(k_cell_ids, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, d_xyz, n, stride, g, keys.p, vals.p);
+    hipLaunchKernelGGL(k_cell_ids, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, d_xyz, n, stride, g, compact ? 1 : 0, keys.p,
+                       vals.p);
     int bits = 1;
     while (((size_t)1 << bits) < ncells) ++bits;
     sort_pairs_u32(ctx, keys.p, keys2.p, vals.p, vals2.p, n, bits);
@@ -177,11 +185,21 @@ __global__ __launch_bounds__(OV_TPB) void k_overlap(const float *__restrict__ sx
     for (uint32_t i = threadIdx.x; i < kc * 12; i += OV_TPB) s_T[i / 12][i % 12] = T[(size_t)(k0 + i / 12) * 16 + i % 12];
     for (uint32_t i = threadIdx.x; i < kc * 3; i += OV_TPB) s_c[i / 3][i % 3] = centers[(size_t)(k0 + i / 3) * 3 + i % 3];
     __syncthreads();
-    const uint32_t i = blockIdx.x * OV_TPB + threadIdx.x;
+    // every workgroup walks several tiles of source points and keeps its counts in registers: one atomic per
+    // workgroup and candidate at the end (a counter shared by thousands of wavefronts on eight XCDs
+    // serialises at the memory side -- that, not the probing, bounded this kernel)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t acc[OV_KCH];
+#pragma unroll
+    for (int kk = 0; kk < OV_KCH; ++kk) acc[kk] = 0;
+    const uint32_t ntiles = (n_s + OV_TPB - 1) / OV_TPB;
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const uint32_t i = tile * OV_TPB + threadIdx.x;
     const bool live = i < n_s;
     f3 p = live ? f3(sx[i], sy[i], sz[i]) : f3();
-    const int lane = threadIdx.x & 63;
-    for (uint32_t kk = 0; kk < kc; ++kk) {
+#pragma unroll
+    for (uint32_t kk = 0; kk < (uint32_t)OV_KCH; ++kk) {
+        if (kk >= kc) break;
         bool hit = false;
         if (live) {
             const f3 q = pcl_xform(s_T[kk], p);
@@ -191,26 +209,81 @@ __global__ __launch_bounds__(OV_TPB) void k_overlap(const float *__restrict__ sx
             const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.dx - 1);
             const int y0 = max(cy - 1, 0), y1 = min(cy + 1, g.dy - 1);
             const int z0 = max(cz - 1, 0), z1 = min(cz + 1, g.dz - 1);
-            for (int zz = z0; zz <= z1 && !hit; ++zz)
-                for (int yy = y0; yy <= y1 && !hit; ++yy) {
-                    const int base = g.dx * (yy + g.dy * zz);
-                    for (int xx = x0; xx <= x1 && !hit; ++xx) {
-                        const uint32_t cid = (uint32_t)(base + xx);
-                        const unsigned long long w = occ_bits[cid >> 6], bit = 1ull << (cid & 63);
-                        if (!(w & bit)) continue;
-                        const uint32_t rk = occ_rank[cid >> 6] + (uint32_t)__popcll(w & (bit - 1ull));
-                        const uint32_t b = occ_start[rk], e = occ_start[rk + 1];
-                        for (uint32_t j = b; j < e; ++j) {
-                            const float4 t4 = tgt[j];
-                            const f3 t(t4.x, t4.y, t4.z);
-                            if (flann_d2(q, t) < r2 && flann_d2(c, t) < R2) { hit = true; break; }
+            // the <= 27 cells live in <= 8 blocks of 4 x 4 x 4: one word + one rank per block
+            if (x0 <= x1 && y0 <= y1 && z0 <= z1)
+                for (int bz = z0 >> 2; bz <= (z1 >> 2) && !hit; ++bz)
+                    for (int by = y0 >> 2; by <= (y1 >> 2) && !hit; ++by)
+                        for (int bx = x0 >> 2; bx <= (x1 >> 2) && !hit; ++bx) {
+                            const uint32_t blk = block_of(bx << 2, by << 2, bz << 2, g.dx, g.dy);
+                            const unsigned long long w = occ_bits[blk];
+                            if (!w) continue;
+                            // wanted cells of this block: the part of [x0,x1] x [y0,y1] x [z0,z1] inside it
+                            unsigned long long mx = 0, my = 0, mz = 0;
+                            for (int v = max(x0, bx << 2); v <= min(x1, (bx << 2) + 3); ++v) mx |= 0x1111111111111111ull << (v & 3);
+                            for (int v = max(y0, by << 2); v <= min(y1, (by << 2) + 3); ++v) my |= 0x000f000f000f000full << ((v & 3) << 2);
+                            for (int v = max(z0, bz << 2); v <= min(z1, (bz << 2) + 3); ++v) mz |= 0xffffull << ((v & 3) << 4);
+                            unsigned long long m = w & mx & my & mz;
+                            const uint32_t base = occ_rank[blk];
+                            while (m && !hit) {
+                                const int bit = __ffsll((long long)m) - 1;
+                                m &= m - 1;
+                                const uint32_t rk = base + (uint32_t)__popcll(w & ((1ull << bit) - 1ull));
+                                const uint32_t pb = occ_start[rk], pe = occ_start[rk + 1];
+                                for (uint32_t j = pb; j < pe; ++j) {
+                                    const float4 t4 = tgt[j];
+                                    const f3 t(t4.x, t4.y, t4.z);
+                                    if (flann_d2(q, t) < r2 && flann_d2(c, t) < R2) { hit = true; break; }
+                                }
+                            }
                         }
-                    }
-                }
         }
-        const uint32_t c = (uint32_t)__popcll(__ballot(hit));
-        if (lane == 0 && c) atomicAdd(&counts[k0 + kk], (int32_t)c);
+        acc[kk] += (uint32_t)__popcll(__ballot(hit));
     }
+    }
+    __shared__ uint32_t s_acc[OV_TPB / 64][OV_KCH];
+    if (lane == 0)
+        for (int kk = 0; kk < OV_KCH; ++kk) s_acc[wave][kk] = acc[kk];
+    __syncthreads();
+    if (threadIdx.x < kc) {
+        uint32_t tot = 0;
+        for (int w = 0; w < OV_TPB / 64; ++w) tot += s_acc[w][threadIdx.x];
+        if (tot) atomicAdd(&counts[k0 + threadIdx.x], (int32_t)tot);
+    }
+}
+
+// source points into a spatially blocked order: key = blocked cell id in the source's own frame
+__global__ void k_src_minmax(const float *__restrict__ x, const float *__restrict__ y, const float *__restrict__ z, uint32_t n,
+                             int *__restrict__ out6) {
+    __shared__ float s_lds[6][8];
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float v[3] = {x[i], y[i], z[i]};
+        for (int k = 0; k < 3; ++k) { mn[k] = fminf(mn[k], v[k]); mx[k] = fmaxf(mx[k], v[k]); }
+    }
+    block_minmax_commit<3>(mn, mx, out6, s_lds);
+}
+__global__ void k_src_keys(const float *__restrict__ x, const float *__restrict__ y, const float *__restrict__ z, uint32_t n,
+                           const int *__restrict__ bbox, float inv, uint32_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float mnx = ordered_float(bbox[0]), mny = ordered_float(bbox[1]), mnz = ordered_float(bbox[2]);
+    // 10 bits per axis (coarsened if the extent needs more): 8-bit block coordinates + 2 local bits
+    int cx = (int)((x[i] - mnx) * inv), cy = (int)((y[i] - mny) * inv), cz = (int)((z[i] - mnz) * inv);
+    const float ext = fmaxf(fmaxf(ordered_float(bbox[3]) - mnx, ordered_float(bbox[4]) - mny), ordered_float(bbox[5]) - mnz) * inv;
+    int sh = 0;
+    while ((ext / (float)(1 << sh)) >= 1023.f) ++sh;
+    cx >>= sh; cy >>= sh; cz >>= sh;
+    cx = min(max(cx, 0), 1023); cy = min(max(cy, 0), 1023); cz = min(max(cz, 0), 1023);
+    const uint32_t blk = (uint32_t)(cx >> 2) | ((uint32_t)(cy >> 2) << 8) | ((uint32_t)(cz >> 2) << 16);
+    keys[i] = (blk << 6) | local_of(cx, cy, cz);
+    vals[i] = i;
+}
+__global__ void k_src_gather(const float *__restrict__ x, const float *__restrict__ y, const float *__restrict__ z, uint32_t n,
+                             const uint32_t *__restrict__ perm, float *__restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t p = perm[i];
+    out[i] = x[p]; out[(size_t)n + i] = y[p]; out[2 * (size_t)n + i] = z[p];
 }
 
 // does the coarse sphere of candidate k contain any target point?  (util.h:621-625)
@@ -232,7 +305,30 @@ __global__ __launch_bounds__(256) void k_sphere_any(const float4 *__restrict__ t
     }
 }
 
-void overlap_counts(plade_ctx *ctx, const float *d_sx, const float *d_sy, const float *d_sz, uint32_t n_s,
+void overlap_sort_source(plade_ctx *ctx, OverlapWork &work, const float *d_sx, const float *d_sy, const float *d_sz, uint32_t n_s,
+                         float cell) {
+    if (!n_s) return;
+    // any order gives the same counts; this one makes a wavefront's probes local
+    int init[6];
+    float pinf = INFINITY, ninf = -INFINITY;
+    int a, b;
+    memcpy(&a, &pinf, 4); memcpy(&b, &ninf, 4);
+    for (int k = 0; k < 3; ++k) { init[k] = a; init[3 + k] = b ^ 0x7fffffff; }
+    work.bbox.ensure(8);
+    HIP_TRY(hipMemcpyAsync(work.bbox.p, init, 24, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_src_minmax, dim3(std::min(cdiv(n_s, 256), 512u)), dim3(256), 0, ctx->stream, d_sx, d_sy, d_sz, n_s,
+                       work.bbox.p);
+    work.keys.ensure(n_s); work.keys2.ensure(n_s); work.vals.ensure(n_s); work.vals2.ensure(n_s);
+    work.sorted.ensure(3 * (size_t)n_s + 4);
+    hipLaunchKernelGGL(k_src_keys, dim3(cdiv(n_s, 256)), dim3(256), 0, ctx->stream, d_sx, d_sy, d_sz, n_s, work.bbox.p, 1.f / cell,
+                       work.keys.p, work.vals.p);
+    sort_pairs_u32(ctx, work.keys.p, work.keys2.p, work.vals.p, work.vals2.p, n_s, 30);
+    hipLaunchKernelGGL(k_src_gather, dim3(cdiv(n_s, 256)), dim3(256), 0, ctx->stream, d_sx, d_sy, d_sz, n_s, work.vals2.p,
+                       work.sorted.p);
+    HIP_TRY(hipGetLastError());
+}
+
+void overlap_counts(plade_ctx *ctx, OverlapWork &work, const float *d_sx, const float *d_sy, const float *d_sz, uint32_t n_s,
                     const TargetGrid &grid, const float *d_T, const float *d_centers, uint32_t K, float src_radius,
                     float inlier_dist, int32_t *d_counts, uint32_t *d_any) {
     HIP_TRY(hipMemsetAsync(d_counts, 0, (size_t)K * 4, ctx->stream));
@@ -247,7 +343,7 @@ void overlap_counts(plade_ctx *ctx, const float *d_sx, const float *d_sy, const 
                            d_centers + (size_t)k0 * 3, kc, R2, d_any + k0);
     }
     if (n_s) {
-        dim3 gr(cdiv(n_s, OV_TPB), cdiv(K, OV_KCH));
+        dim3 gr(std::min(cdiv(n_s, OV_TPB), 256u), cdiv(K, OV_KCH));
         // algorithmic bytes: K * n_s * 12 B source stream + n_t * 12 B target
         ctx->ev_begin("overlap", (double)K * n_s * 12.0 + (double)grid.n * 12.0);
         PLADE_REQUIRE(grid.compact, PLADE_EINVAL, "overlap: the target grid needs the compact occupancy index");
@@ -293,7 +389,10 @@ extern "C" int plade_overlap_counts(plade_ctx *ctx, const float *src_ds, uint32_
         deinterleave3(ctx, d_src.p, n_s, d_soa.p, d_soa.p + n_s, d_soa.p + 2 * (size_t)n_s);
         TargetGrid grid;
         grid.build(ctx, d_tgt.p, n_t, 3, inlier_dist, nullptr, nullptr, true);
-        overlap_counts(ctx, d_soa.p, d_soa.p + n_s, d_soa.p + 2 * (size_t)n_s, n_s, grid, d_T.p, d_c.p, k, src_radius,
+        OverlapWork ow;
+        if (n_t && n_s) overlap_sort_source(ctx, ow, d_soa.p, d_soa.p + n_s, d_soa.p + 2 * (size_t)n_s, n_s, 1.f / grid.gp.inv);
+        else ow.sorted.ensure(3 * (size_t)n_s + 4);
+        overlap_counts(ctx, ow, ow.sorted.p, ow.sorted.p + n_s, ow.sorted.p + 2 * (size_t)n_s, n_s, grid, d_T.p, d_c.p, k, src_radius,
                        inlier_dist, d_counts.p, d_any.p);
         std::vector<uint32_t> any(k);
         HIP_TRY(hipMemcpyAsync(counts, d_counts.p, (size_t)k * 4, hipMemcpyDeviceToHost, ctx->stream));

@@ -13,7 +13,9 @@ struct TargetGrid {
     DBuf<float4> sorted;  // target points in cell order: (x, y, z, bitcast original index)
     // compact occupancy index (build(..., compact = true)): surfaces fill a few percent of the cells, so the
     // dense start/end tables (tens of MB, L2 misses on every probe) are replaced by one bit per cell, a
-    // rank per 64-cell word and the start offsets of the occupied cells only -- ~1 MB, L2 resident
+    // rank per 64-cell word and the start offsets of the occupied cells only.  Cells are numbered in blocks
+    // of 4 x 4 x 4: cell id = block id * 64 + (x&3 | (y&3)<<2 | (z&3)<<4), so one 64-bit word is one block,
+    // a 27-cell neighbourhood touches at most 8 words, and the points of a block are contiguous
     DBuf<unsigned long long> occ_bits;   // ncells / 64 words
     DBuf<uint32_t> occ_pop, occ_rank;    // per word: popcount, exclusive prefix (+ total)
     DBuf<uint32_t> occ_start;            // per occupied cell (+ 1): first sorted position
@@ -25,7 +27,18 @@ struct TargetGrid {
 };
 
 // counts[k] (device, int32) and any[k] (device, 1 when the coarse sphere is non-empty)
-void overlap_counts(plade_ctx *ctx, const float *d_sx, const float *d_sy, const float *d_sz, uint32_t n_s,
+// The source points are visited in a spatially blocked order (sorted copy made inside, `work`) so that the
+// lanes of a wavefront probe neighbouring cells.
+struct OverlapWork {
+    DBuf<uint32_t> keys, keys2, vals, vals2;
+    DBuf<float> sorted;   // 3 x n_s SoA in blocked order
+    DBuf<int> bbox;
+};
+// blocked copy of the source (x | y | z in work.sorted); cell = the target grid's cell edge
+void overlap_sort_source(plade_ctx *ctx, OverlapWork &work, const float *d_sx, const float *d_sy, const float *d_sz, uint32_t n_s,
+                         float cell);
+// d_sx/d_sy/d_sz: the source in any order -- pass work.sorted's planes when overlap_sort_source ran before
+void overlap_counts(plade_ctx *ctx, OverlapWork &work, const float *d_sx, const float *d_sy, const float *d_sz, uint32_t n_s,
                     const TargetGrid &grid, const float *d_T, const float *d_centers, uint32_t K, float src_radius,
                     float inlier_dist, int32_t *d_counts, uint32_t *d_any);
 

@@ -197,6 +197,7 @@ struct RegistrationWork {
     DBuf<float> d_rt12, d_T16, d_centers;
     DBuf<int32_t> d_counts;
     DBuf<uint32_t> d_any;
+    OverlapWork ov_work;
     hipEvent_t ev_grid = nullptr;   // target grid of the verification built on the auxiliary stream
     ~RegistrationWork() { if (ev_grid) (void)hipEventDestroy(ev_grid); }
 };
@@ -261,6 +262,9 @@ bool run_registration(plade_ctx *ctx, RegistrationWork &W, const CloudDev &tgt, 
         // downsampled target: built now on the idle auxiliary stream, consumed five stages later
         if (!W.ev_grid) HIP_TRY(hipEventCreateWithFlags(&W.ev_grid, hipEventDisableTiming));
         W.grid.build(aux, M.d_ds.p, M.n_ds, 3, downSampleDistance, tgt.bbmin, tgt.bbmax, true);
+        // ... and the source in a spatially blocked order for the same kernel
+        overlap_sort_source(aux, W.ov_work, C.d_ds_soa.p, C.d_ds_soa.p + C.n_ds, C.d_ds_soa.p + 2 * (size_t)C.n_ds, C.n_ds,
+                            1.f / W.grid.gp.inv);
         HIP_TRY(hipEventRecord(W.ev_grid, aux->stream));
     }
     {
@@ -422,7 +426,8 @@ bool run_registration(plade_ctx *ctx, RegistrationWork &W, const CloudDev &tgt, 
         HIP_TRY(hipMemcpyAsync(W.d_T16.p, T16.data(), 64 * (size_t)Kv, hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(hipMemcpyAsync(W.d_centers.p, centers.data(), 12 * (size_t)Kv, hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(hipStreamWaitEvent(ctx->stream, W.ev_grid, 0));
-        overlap_counts(ctx, C.d_ds_soa.p, C.d_ds_soa.p + C.n_ds, C.d_ds_soa.p + 2 * (size_t)C.n_ds, C.n_ds, W.grid, W.d_T16.p,
+        overlap_counts(ctx, W.ov_work, W.ov_work.sorted.p, W.ov_work.sorted.p + C.n_ds, W.ov_work.sorted.p + 2 * (size_t)C.n_ds, C.n_ds,
+                       W.grid, W.d_T16.p,
                        W.d_centers.p, Kv, (float)C.radius, downSampleDistance, W.d_counts.p, W.d_any.p);
         std::vector<uint32_t> any(Kv);
         HIP_TRY(hipMemcpyAsync(counts.data(), W.d_counts.p, 4 * (size_t)Kv, hipMemcpyDeviceToHost, ctx->stream));
