@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void k_pen_setup(PenTables tb, float len_th, f
     if (0 == (ord[0] / 2 - ord[1] / 2)) return;  // no overlap of the two clipped segments
     const f3 sp = inter[ord[1]], ep = inter[ord[2]];
     const float length = norm_e(ep - sp);
-    atomicAdd(n_items, 1u);
+    (void)n_items;   // (a single counter bumped by every surviving triple serialises at the memory side)
     const uint32_t pair = i1 * tb.pt + j1;
     const uint32_t slot = pair * tb.K + atomicAdd(&pair_count[pair], 1u);
     PenItem it;
@@ -403,11 +403,13 @@ void penetration_filter(plade_ctx *ctx, const float *cand_rt_host, uint32_t K, c
     hipLaunchKernelGGL(k_pen_walk, dim3(n_pairs, cdiv(K, PEN_G)), dim3(PEN_TPB), 0, ctx->stream, d_items, d_pair, d_order, tb, d_steps,
                        sS, sT, cell, search_radius, 10, min_distance, d_flags, d_over);
     ctx->ev_end();
-    std::vector<uint32_t> out((size_t)K + 2);
-    HIP_TRY(hipMemcpyAsync(out.data(), d_ctr, ((size_t)K + 2) * 4, hipMemcpyDeviceToHost, ctx->stream));
+    std::vector<uint32_t> out(n_ctr);   // items, overflow, K candidate flags, per-pair item counts
+    HIP_TRY(hipMemcpyAsync(out.data(), d_ctr, n_ctr * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     HIP_TRY(hipGetLastError());
-    ctx->stats.add("pen_items", (double)out[0]);
+    double items = 0;
+    for (uint32_t pr = 0; pr < n_pairs; ++pr) items += out[(size_t)K + 2 + pr];
+    ctx->stats.add("pen_items", items);
     PLADE_REQUIRE(out[1] == 0, PLADE_ELIMIT, "penetration: intersection segment longer than 1024 search steps");
     for (uint32_t k = 0; k < K; ++k) flags_out[k] = out[k + 2] ? 1 : 0;
 }
