@@ -269,7 +269,20 @@ __global__ __launch_bounds__(TPB) void k_compact_batch(const CompactJob *__restr
             mn[0] = fminf(mn[0], u); mn[1] = fminf(mn[1], v);
             mx[0] = fmaxf(mx[0], u); mx[1] = fmaxf(mx[1], v);
         }
-    block_minmax_commit<2>(mn, mx, jb.bbox, s_mm);
+    // per-tile bounding box, reduced later by the rasteriser (a shared min/max updated with atomics from
+    // hundreds of tiles serialised at the memory side and cost as much as the rest of this kernel)
+    for (int q = 0; q < 2; ++q)
+        for (int d = 32; d >= 1; d >>= 1) {
+            mn[q] = fminf(mn[q], __shfl_xor(mn[q], d, 64));
+            mx[q] = fmaxf(mx[q], __shfl_xor(mx[q], d, 64));
+        }
+    if (lane == 0) { s_mm[0][wave] = mn[0]; s_mm[1][wave] = mn[1]; s_mm[2][wave] = mx[0]; s_mm[3][wave] = mx[1]; }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        float v = s_mm[threadIdx.x][0];
+        for (int w = 1; w < TPB / 64; ++w) v = threadIdx.x < 2 ? fminf(v, s_mm[threadIdx.x][w]) : fmaxf(v, s_mm[threadIdx.x][w]);
+        jb.bbox_part[4 * (size_t)blockIdx.x + threadIdx.x] = v;
+    }
 }
 
 void score_mark_batch(plade_ctx *ctx, const float *x, const float *y, const float *z, const float *nx, const float *ny,

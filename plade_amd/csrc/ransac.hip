@@ -224,6 +224,8 @@ struct ChainDev {
     uint8_t *bmp, *tmp;
     uint8_t *masks2;       // connected-component selection masks
     uint32_t *bc2;
+    const uint32_t *bcA;   // per-tile counts of the score list
+    float *bbpart;         // per-tile (u, v) bounding boxes of the score list
     double *part, *part_ws;
 };
 
@@ -270,10 +272,10 @@ __global__ void k_state_from_hyp(const ChainDev *__restrict__ chains) {
 constexpr uint32_t CC_MAXPIX = 1u << 20;
 
 // BitmapExtent (PlanePrimitiveShape.cpp:185-191)
-__device__ __forceinline__ bool cc_dims(const PlaneState *st, uint32_t count, float eps, uint32_t &ue, uint32_t &ve) {
+__device__ __forceinline__ bool cc_dims(const float bb[4], uint32_t count, float eps, uint32_t &ue, uint32_t &ve) {
     ue = 2; ve = 2;
     if (count) {
-        const float mnu = ord_f(st->bb[0]), mnv = ord_f(st->bb[1]), mxu = ord_f(st->bb[2]), mxv = ord_f(st->bb[3]);
+        const float mnu = bb[0], mnv = bb[1], mxu = bb[2], mxv = bb[3];
         const float fu = ceilf((mxu - mnu) / eps), fv = ceilf((mxv - mnv) / eps);
         ue = (fu < 4.0e6f ? (uint32_t)fu : 4000000u) + 1;
         ve = (fv < 4.0e6f ? (uint32_t)fv : 4000000u) + 1;
@@ -286,7 +288,7 @@ __device__ __forceinline__ bool cc_dims(const PlaneState *st, uint32_t count, fl
 
 // BuildBitmap (BitmapPrimitiveShape.h:139-150) with InBitmap (PlanePrimitiveShape.cpp:193-199).
 // The bitmap is all-zero on entry (k_cc_label clears what it used).
-__global__ __launch_bounds__(256) void k_cc_raster(const ChainDev *__restrict__ chains, int k, float eps) {
+__global__ __launch_bounds__(256) void k_cc_raster(const ChainDev *__restrict__ chains, int k, float eps, uint32_t n_tiles) {
     const ChainDev &C = chains[blockIdx.y];
     PlaneState *st = C.st + k;
     if (st->converged) return;
@@ -295,11 +297,36 @@ __global__ __launch_bounds__(256) void k_cc_raster(const ChainDev *__restrict__ 
     uint32_t *__restrict__ bidx = C.bidx;
     uint8_t *__restrict__ bmp = C.bmp;
     const uint32_t m = *count;
+    // bounding box of the list's (u, v) parameters (BitmapPrimitiveShape.h:113-126): every block reduces the
+    // per-tile boxes the compaction left behind (a few thousand floats from L2)
+    __shared__ float s_bb[4][4];
+    float bbv[4] = {INFINITY, INFINITY, -INFINITY, -INFINITY};
+    for (uint32_t b = threadIdx.x; b < n_tiles; b += blockDim.x)
+        if (C.bcA[b]) {
+            const float4 t = *reinterpret_cast<const float4 *>(C.bbpart + 4 * (size_t)b);
+            bbv[0] = fminf(bbv[0], t.x); bbv[1] = fminf(bbv[1], t.y); bbv[2] = fmaxf(bbv[2], t.z); bbv[3] = fmaxf(bbv[3], t.w);
+        }
+    for (int q = 0; q < 4; ++q)
+        for (int d = 32; d >= 1; d >>= 1) {
+            const float o = __shfl_xor(bbv[q], d, 64);
+            bbv[q] = q < 2 ? fminf(bbv[q], o) : fmaxf(bbv[q], o);
+        }
+    if ((threadIdx.x & 63) == 0) for (int q = 0; q < 4; ++q) s_bb[q][threadIdx.x >> 6] = bbv[q];
+    __syncthreads();
+    for (int q = 0; q < 4; ++q) {
+        float v = s_bb[q][0];
+        for (int w = 1; w < 4; ++w) v = q < 2 ? fminf(v, s_bb[q][w]) : fmaxf(v, s_bb[q][w]);
+        bbv[q] = v;
+    }
     uint32_t ue, ve;
-    const bool ok = cc_dims(st, m, eps, ue, ve);
-    if (blockIdx.x == 0 && threadIdx.x == 0) { st->ue = ue; st->ve = ve; if (!ok) st->err = 1; }
+    const bool ok = cc_dims(bbv, m, eps, ue, ve);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        st->ue = ue; st->ve = ve;
+        if (!ok) st->err = 1;
+        for (int q = 0; q < 4; ++q) st->bb[q] = ord_i(bbv[q]);
+    }
     if (!ok) return;
-    const float mnu = ord_f(st->bb[0]), mnv = ord_f(st->bb[1]);
+    const float mnu = bbv[0], mnv = bbv[1];
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
         int bu = (int)floorf((uv[i].x - mnu) / eps), bv = (int)floorf((uv[i].y - mnv) / eps);
         bu = min(max(bu, 0), (int)ue - 1);
@@ -641,6 +668,7 @@ struct Chain {
     DBuf<uint32_t> bidx, label, sizes;
     DBuf<uint8_t> bmp, tmp;
     DBuf<double> part, part_ws;
+    DBuf<float> bbpart;
 };
 
 constexpr size_t ACCEPT_BYTES = 4 * sizeof(PlaneState) + 16 + 48;   // states, counts, normal sums
@@ -711,7 +739,7 @@ void enqueue_accept(plade_ctx *ctx, RansacWork &W, const CloudView &cv, uint32_t
         score_mark_batch(ctx, c.x(), c.y(), c.z(), c.nx(), c.ny(), c.nz(), W.assigned.p, c.n, W.mark_jobs.p + (size_t)k * B, nc, eps3,
                          cos_t);
         compact_batch(ctx, c.n, W.compact_jobs.p + (size_t)(2 * k) * B, nc, c.x(), c.y(), c.z());
-        hipLaunchKernelGGL(k_cc_raster, dim3(std::min(nb, 128u), nc), dim3(256), 0, st, tab, k, bitmap_eps);
+        hipLaunchKernelGGL(k_cc_raster, dim3(std::min(nb, 128u), nc), dim3(256), 0, st, tab, k, bitmap_eps, nb4);
         hipLaunchKernelGGL(k_cc_label, dim3(nc), dim3(1024), 0, st, tab, k, 1);
         hipLaunchKernelGGL(k_cc_select, dim3(nb4, nc), dim3(256), 0, st, tab, k);
         compact_batch(ctx, c.n, W.compact_jobs.p + (size_t)(2 * k + 1) * B, nc);
@@ -753,6 +781,8 @@ void chains_prepare(plade_ctx *ctx, RansacWork &W, uint32_t B, uint32_t n, float
         D.part = C.part.ensure(FIT_BLOCKS * 12 + 16);
         D.part_ws = C.part_ws.ensure(4 * FIT_BLOCKS + 16);
         C.cs.masks.ensure((size_t)nb4 * 256 + 16); C.cs.block_counts.ensure(nb4 + 4);
+        D.bcA = C.cs.block_counts.p;
+        D.bbpart = C.bbpart.ensure(4 * (size_t)nb4 + 16);
         D.masks2 = C.cs2.masks.ensure((size_t)nb4 * 256 + 16);
         D.bc2 = C.cs2.block_counts.ensure(nb4 + 4);
         for (int k = 0; k < 4; ++k) {
@@ -760,7 +790,7 @@ void chains_prepare(plade_ctx *ctx, RansacWork &W, uint32_t B, uint32_t n, float
             mj[(size_t)k * B + b] = MarkJob{D.plane_cur + k, C.cs.masks.p, C.cs.block_counts.p, skip};
             // score list + its (u, v) parameters in slot k's plane frame (PlaneState: pos, dist, a0, a1, bb)
             cj[(size_t)(2 * k) * B + b] = CompactJob{C.cs.masks.p, C.cs.block_counts.p, nullptr, D.idxA, D.cntA, skip,
-                                                     D.st[k].pos, D.uv, D.st[k].bb};
+                                                     D.st[k].pos, D.uv, D.bbpart};
             cj[(size_t)(2 * k + 1) * B + b] = CompactJob{D.masks2, D.bc2, D.idxA, D.idxS[k], D.cntS + k, skip, nullptr, nullptr, nullptr};
         }
     }
@@ -878,10 +908,10 @@ void plane_component(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const
     hipLaunchKernelGGL(k_list_masks, dim3(cdiv(nb4 * 256, 256)), dim3(256), 0, st, m, nb4, C.cs.masks.p, C.cs.block_counts.p);
     DBuf<CompactJob> job;
     job.ensure(1);
-    const CompactJob hj{C.cs.masks.p, C.cs.block_counts.p, d_idx.p, D.idxA, D.cntA, nullptr, D.st[0].pos, D.uv, D.st[0].bb};
+    const CompactJob hj{C.cs.masks.p, C.cs.block_counts.p, d_idx.p, D.idxA, D.cntA, nullptr, D.st[0].pos, D.uv, D.bbpart};
     HIP_TRY(hipMemcpyAsync(job.p, &hj, sizeof(hj), hipMemcpyHostToDevice, st));
     compact_batch(ctx, n, job.p, 1, cv.x, cv.y, cv.z);
-    hipLaunchKernelGGL(k_cc_raster, dim3(std::min(cdiv(n, 256), 128u), 1), dim3(256), 0, st, W.chain_tab.p, 0, bitmap_eps);
+    hipLaunchKernelGGL(k_cc_raster, dim3(std::min(cdiv(n, 256), 128u), 1), dim3(256), 0, st, W.chain_tab.p, 0, bitmap_eps, nb4);
     hipLaunchKernelGGL(k_cc_label, dim3(1), dim3(1024), 0, st, W.chain_tab.p, 0, closing_filter ? 1 : 0);
     hipLaunchKernelGGL(k_cc_select, dim3(nb4, 1), dim3(256), 0, st, W.chain_tab.p, 0);
     compact_batch(ctx, n, W.compact_jobs.p + (size_t)1 * W.B, 1);

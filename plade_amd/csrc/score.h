@@ -50,7 +50,8 @@ struct CompactJob {
     // ransac/PlanePrimitiveShape.h:97-109): uv[j] of the j-th emitted index and the (u, v) bounding box
     const float *frame;        // nullable: pos(3), unused(1), axis0(3), axis1(3)
     float2 *uv;
-    int *bbox;                 // ordered-int min u, min v, max u, max v
+    float *bbox_part;          // per tile: min u, min v, max u, max v of its emitted points (tiles with a zero
+                               // block count are left untouched): reduced by the consumer, no atomics
 };
 void score_mark_batch(plade_ctx *ctx, const float *x, const float *y, const float *z, const float *nx, const float *ny,
                       const float *nz, const int32_t *assigned, uint32_t n, const MarkJob *jobs_dev, uint32_t nj, float eps,
