@@ -23,7 +23,7 @@ __global__ __launch_bounds__(256) void k_transforms(const float *__restrict__ q_
                                                     const float *__restrict__ q_p1, const float *__restrict__ t_lv1,
                                                     const float *__restrict__ t_lv2, const float *__restrict__ t_p1,
                                                     const uint32_t *__restrict__ q_idx, const uint32_t *__restrict__ t_idx,
-                                                    uint32_t m, float4 *__restrict__ rt, int *__restrict__ t_minmax6) {
+                                                    uint32_t m, float4 *__restrict__ rt, float *__restrict__ t_minmax_part) {
     __shared__ float s_lds[6][8];
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -47,8 +47,21 @@ __global__ __launch_bounds__(256) void k_transforms(const float *__restrict__ q_
     rt[4 * (size_t)i + 3] = make_float4(roll, pitch, yaw, 0.f);
     mn[0] = mx[0] = T.x; mn[1] = mx[1] = T.y; mn[2] = mx[2] = T.z;
     }
-    // bounding box of the translations for the clustering grid (ordered-int atomics)
-    block_minmax_commit<3>(mn, mx, t_minmax6, s_lds);
+    // bounding box of the translations for the clustering grid: one partial per workgroup, reduced by the host
+    // (it needs the box anyway to size the grid), no shared counters
+    for (int q = 0; q < 3; ++q)
+        for (int d = 32; d >= 1; d >>= 1) {
+            mn[q] = fminf(mn[q], __shfl_xor(mn[q], d, 64));
+            mx[q] = fmaxf(mx[q], __shfl_xor(mx[q], d, 64));
+        }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) for (int q = 0; q < 3; ++q) { s_lds[q][wave] = mn[q]; s_lds[3 + q][wave] = mx[q]; }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        float v = s_lds[threadIdx.x][0];
+        for (int w = 1; w < 4; ++w) v = threadIdx.x < 3 ? fminf(v, s_lds[threadIdx.x][w]) : fmaxf(v, s_lds[threadIdx.x][w]);
+        t_minmax_part[6 * (size_t)blockIdx.x + threadIdx.x] = v;
+    }
 }
 
 void build_transforms(plade_ctx *ctx, const PairTableDev &src, const PairTableDev &tgt, const uint32_t *d_q_idx,
@@ -56,15 +69,7 @@ void build_transforms(plade_ctx *ctx, const PairTableDev &src, const PairTableDe
     cs.m = m;
     cs.rt.ensure(4 * (size_t)m + 4);
     if (!m) return;
-    int init[6];
-    {
-        float pinf = INFINITY, ninf = -INFINITY;
-        int a, b;
-        memcpy(&a, &pinf, 4); memcpy(&b, &ninf, 4);
-        for (int k = 0; k < 3; ++k) { init[k] = a; init[3 + k] = b ^ 0x7fffffff; }
-    }
-    cs.t_minmax.ensure(8);
-    HIP_TRY(hipMemcpyAsync(cs.t_minmax.p, init, 24, hipMemcpyHostToDevice, ctx->stream));
+    cs.t_minmax.ensure(6 * (size_t)cdiv(m, 256) + 8);
     hipLaunchKernelGGL(k_transforms, dim3(cdiv(m, 256)), dim3(256), 0, ctx->stream, src.lv1.p, src.lv2.p, src.p1.p,
                        tgt.lv1.p, tgt.lv2.p, tgt.p1.p, d_q_idx, d_t_idx, m, cs.rt.p, cs.t_minmax.p);
     HIP_TRY(hipGetLastError());
@@ -202,17 +207,14 @@ void cluster_transforms(plade_ctx *ctx, CandidateSet &cs, float dist_threshold, 
     const uint32_t m = cs.m;
     cs.n_clusters = 0;
     if (!m) return;
-    // bbox of the translations (reduced inside k_transforms)
-    int out[6];
-    HIP_TRY(hipMemcpyAsync(out, cs.t_minmax.p, 24, hipMemcpyDeviceToHost, ctx->stream));
+    // bbox of the translations (per-workgroup partials left by k_transforms)
+    const uint32_t nbp = cdiv(m, 256);
+    std::vector<float> part(6 * (size_t)nbp);
+    HIP_TRY(hipMemcpyAsync(part.data(), cs.t_minmax.p, 24 * (size_t)nbp, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    float mn[3], mx[3];
-    for (int k = 0; k < 6; ++k) {
-        int v = out[k] >= 0 ? out[k] : out[k] ^ 0x7fffffff;
-        float f;
-        memcpy(&f, &v, 4);
-        if (k < 3) mn[k] = f; else mx[k - 3] = f;
-    }
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (uint32_t b = 0; b < nbp; ++b)
+        for (int k = 0; k < 3; ++k) { mn[k] = std::min(mn[k], part[6 * (size_t)b + k]); mx[k] = std::max(mx[k], part[6 * (size_t)b + 3 + k]); }
     const float r2 = pcl_r2((double)dist_threshold);  // setClusterTolerance -> radiusSearch(double) -> float(r*r)
     float cell = dist_threshold * 1.001f;
     if (!(cell > 0.f)) cell = 1.f;

@@ -89,11 +89,14 @@ __global__ void k_query_offsets(const uint32_t *__restrict__ offs, uint32_t dq, 
                                 uint32_t *__restrict__ info /* [0] total, [1] max list (zeroed) */) {
     uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t total = offs[(size_t)dq * nch];
+    uint32_t len = 0;
     if (q < dq) {
         const uint32_t b = offs[(size_t)q * nch], e = offs[(size_t)(q + 1) * nch];
         out[q] = b;
-        atomicMax(&info[1], e - b);
+        len = e - b;
     }
+    for (int d = 32; d >= 1; d >>= 1) len = max(len, (uint32_t)__shfl_xor((int)len, d, 64));
+    if ((threadIdx.x & 63) == 0 && len > info[1]) atomicMax(&info[1], len);   // one (conditional) atomic per wavefront
     if (q == dq) { out[q] = total; info[0] = total; }
 }
 

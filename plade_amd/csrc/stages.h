@@ -44,7 +44,7 @@ struct CandidateSet {
     DBuf<uint32_t> flags, pos;
     DBuf<uint64_t> ckeys, ckeys2;
     DBuf<uint32_t> cvals, cvals2;
-    DBuf<int> t_minmax;           // ordered-int bbox of the translations (6)
+    DBuf<float> t_minmax;         // per-workgroup bbox partials of the translations (6 each)
     DBuf<float4> st, se;          // nodes in cell order: (T, index bits), Euler angles
     DBuf<uint2> spans;            // per cell head: 9 row spans of its 27-neighbourhood
     DBuf<int32_t> plane_counts;   // per cluster (seed order): matched plane pairs, -1 = centre gate failed
