@@ -247,8 +247,12 @@ __global__ __launch_bounds__(PEN_TPB) void k_pen_walk(const PenItem *__restrict_
                                                       float search_radius, int min_points, float min_distance,
                                                       uint32_t *__restrict__ cand_flags, uint32_t *__restrict__ overflow) {
     __shared__ uint32_t s_cnt_all[PEN_G][PEN_MAXS];
+    __shared__ float s_dist[PEN_MAXS + 1];
     const uint32_t pair = pair_order[blockIdx.x];   // heaviest plane pairs first (longest-processing-time order)
     const uint32_t cnt = pair_count[pair];
+    if (blockIdx.y * PEN_G >= cnt) return;          // whole workgroup idle (uniform)
+    for (int i = threadIdx.x; i <= PEN_MAXS; i += blockDim.x) s_dist[i] = step_dist[i];   // the step table in LDS
+    __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t slot = blockIdx.y * PEN_G + wave;
     if (slot >= cnt) return;
@@ -261,8 +265,8 @@ __global__ __launch_bounds__(PEN_TPB) void k_pen_walk(const PenItem *__restrict_
     int nsteps;
     {
         int lo = 0, hi = PEN_MAXS;
-        while (lo < hi) { const int mid = (lo + hi) >> 1; if (step_dist[mid] < it.length) lo = mid + 1; else hi = mid; }
-        if (lo == PEN_MAXS && step_dist[PEN_MAXS] < it.length && lane == 0) atomicExch(overflow, 1u);
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_dist[mid] < it.length) lo = mid + 1; else hi = mid; }
+        if (lo == PEN_MAXS && s_dist[PEN_MAXS] < it.length && lane == 0) atomicExch(overflow, 1u);
         nsteps = lo;
     }
     if (nsteps == 0) return;  // length <= 0: both walks see nothing -> positive/negative < minPoints
@@ -274,7 +278,7 @@ __global__ __launch_bounds__(PEN_TPB) void k_pen_walk(const PenItem *__restrict_
     const uint32_t i1 = pair / tb.pt, j1 = pair % tb.pt;
     const float *tc = tb.t_coef + 4 * (size_t)j1;
     const float inv_r = 1.f / search_radius;
-    const float L = step_dist[nsteps - 1];   // the last step point
+    const float L = s_dist[nsteps - 1];   // the last step point
     // the segment in the source frame: p_s = R^T (p - T) (cell selection only)
     const f3 ds(start.x - c[9], start.y - c[10], start.z - c[11]);
     const f3 start_s(c[0] * ds.x + c[3] * ds.y + c[6] * ds.z, c[1] * ds.x + c[4] * ds.y + c[7] * ds.z,
@@ -294,7 +298,7 @@ __global__ __launch_bounds__(PEN_TPB) void k_pen_walk(const PenItem *__restrict_
             const float t = d.x * direc.x + d.y * direc.y + d.z * direc.z;
             const int kc = (int)floorf(t * inv_r);
             for (int kk = max(kc - 2, 0); kk <= min(kc + 3, nsteps - 1); ++kk) {
-                const float dist = step_dist[kk];
+                const float dist = s_dist[kk];
                 const f3 spt(start.x + dist * direc.x, start.y + dist * direc.y, start.z + dist * direc.z);
                 if (flann_d2(spt, p) < half_r2) atomicAdd(&s_cnt[kk], 1u);
             }
@@ -313,7 +317,7 @@ __global__ __launch_bounds__(PEN_TPB) void k_pen_walk(const PenItem *__restrict_
             bool hit = false;
             for (int kk = max(kc - 2, 0); kk <= min(kc + 3, nsteps - 1) && !hit; ++kk) {
                 if (s_cnt[kk] < 2u) continue;
-                const float dist = step_dist[kk];
+                const float dist = s_dist[kk];
                 const f3 spt(start.x + dist * direc.x, start.y + dist * direc.y, start.z + dist * direc.z);
                 if (flann_d2(spt, p) < full_r2) hit = true;
             }
