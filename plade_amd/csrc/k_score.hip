@@ -225,7 +225,12 @@ __global__ __launch_bounds__(TPB) void k_compact_batch(const CompactJob *__restr
     if (jb.block_counts[blockIdx.x] == 0 && blockIdx.x != nb - 1) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t pre = 0;
-    for (uint32_t b = threadIdx.x; b < blockIdx.x; b += TPB) pre += jb.block_counts[b];
+    {   // sum of the preceding tiles' counts, four per load (the count arrays are 16-byte aligned)
+        const uint32_t full = blockIdx.x & ~3u;
+        const uint4 *c4 = reinterpret_cast<const uint4 *>(jb.block_counts);
+        for (uint32_t q = threadIdx.x; q < full / 4; q += TPB) { const uint4 v = c4[q]; pre += (v.x + v.y) + (v.z + v.w); }
+        if (threadIdx.x < blockIdx.x - full) pre += jb.block_counts[full + threadIdx.x];
+    }
     for (int d = 32; d >= 1; d >>= 1) pre += __shfl_xor(pre, d, 64);
     if (lane == 0) s_base[wave] = pre;
     const uint32_t m = jb.masks[blockIdx.x * TPB + threadIdx.x];
