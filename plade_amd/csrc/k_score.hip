@@ -150,13 +150,26 @@ __global__ __launch_bounds__(TPB) void k_score_mark_batch(const float *__restric
                                                           const int32_t *__restrict__ assigned, uint32_t n,
                                                           const MarkJob *__restrict__ jobs, uint32_t nj, float eps, float cos_t) {
     __shared__ uint32_t s_w[MARK_MAXJ][TPB / 64];
+    // the jobs' planes / skip flags / output pointers are fetched by nj lanes at once and parked in LDS: read
+    // one after the other inside the hypothesis loop they were a chain of dependent global loads (~1 us each)
+    __shared__ float4 s_pl[MARK_MAXJ];
+    __shared__ uint32_t s_skip[MARK_MAXJ];
+    __shared__ uint8_t *s_masks[MARK_MAXJ];
+    __shared__ uint32_t *s_bc[MARK_MAXJ];
+    if (threadIdx.x < nj) {
+        const MarkJob jb = jobs[threadIdx.x];
+        s_skip[threadIdx.x] = jb.skip ? *jb.skip : 0u;
+        s_pl[threadIdx.x] = jb.plane[0];
+        s_masks[threadIdx.x] = jb.masks;
+        s_bc[threadIdx.x] = jb.block_counts;
+    }
     Tile t;
     load_tile(t, x, y, z, nx, ny, nz, assigned, nullptr, n, blockIdx.x * TILE + threadIdx.x * PPT);
+    __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (uint32_t j = 0; j < nj; ++j) {
-        const MarkJob jb = jobs[j];
-        if (jb.skip && *jb.skip) continue;   // uniform
-        const float4 pl = jb.plane[0];
+        if (s_skip[j]) continue;   // uniform
+        const float4 pl = s_pl[j];
         uint32_t m = 0, c = 0;
 #pragma unroll
         for (int k = 0; k < PPT; ++k) {
@@ -164,15 +177,12 @@ __global__ __launch_bounds__(TPB) void k_score_mark_batch(const float *__restric
             m |= (in ? 1u : 0u) << k;
             c += (uint32_t)__popcll(__ballot(in));
         }
-        jb.masks[blockIdx.x * TPB + threadIdx.x] = (uint8_t)m;
+        s_masks[j][blockIdx.x * TPB + threadIdx.x] = (uint8_t)m;
         if (lane == 0) s_w[j][wave] = c;
     }
     __syncthreads();
-    if (threadIdx.x < nj) {
-        const MarkJob jb = jobs[threadIdx.x];
-        if (!(jb.skip && *jb.skip))
-            jb.block_counts[blockIdx.x] = s_w[threadIdx.x][0] + s_w[threadIdx.x][1] + s_w[threadIdx.x][2] + s_w[threadIdx.x][3];
-    }
+    if (threadIdx.x < nj && !s_skip[threadIdx.x])
+        s_bc[threadIdx.x][blockIdx.x] = s_w[threadIdx.x][0] + s_w[threadIdx.x][1] + s_w[threadIdx.x][2] + s_w[threadIdx.x][3];
 }
 
 // ordered compaction; every block derives its output offset from the preceding blocks' counts itself
