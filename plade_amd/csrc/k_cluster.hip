@@ -218,6 +218,8 @@ void cluster_transforms(plade_ctx *ctx, CandidateSet &cs, float dist_threshold, 
     const float r2 = pcl_r2((double)dist_threshold);  // setClusterTolerance -> radiusSearch(double) -> float(r*r)
     float cell = dist_threshold * 1.001f;
     if (!(cell > 0.f)) cell = 1.f;
+    for (int k = 0; k < 3; ++k)
+        PLADE_REQUIRE(std::isfinite(mn[k]) && std::isfinite(mx[k]), PLADE_EFAIL, "candidate transforms are not finite");
     for (;;) {  // at most 21 bits per axis (+1 offset, +1 probe margin)
         double ext = std::max({(double)mx[0] - mn[0], (double)mx[1] - mn[1], (double)mx[2] - mn[2]});
         if (ext / cell + 4 < (double)(1 << 21)) break;

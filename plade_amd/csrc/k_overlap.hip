@@ -129,6 +129,8 @@ void TargetGrid::build(plade_ctx *ctx, const float *d_xyz, uint32_t n_pts, uint3
     // fp32 rounding of the cell coordinate
     float cell = min_cell * 1.001f;
     if (!(cell > 0.f)) cell = 1.f;
+    PLADE_REQUIRE(std::isfinite(init[0]) && std::isfinite(init[1]) && std::isfinite(init[2]) && std::isfinite(init[3]) &&
+                      std::isfinite(init[4]) && std::isfinite(init[5]), PLADE_EINVAL, "grid: non-finite bounding box");
     for (;;) {
         double ex = std::floor((init[3] - init[0]) / cell) + 1, ey = std::floor((init[4] - init[1]) / cell) + 1,
                ez = std::floor((init[5] - init[2]) / cell) + 1;

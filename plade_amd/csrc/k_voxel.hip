@@ -274,6 +274,7 @@ __global__ __launch_bounds__(256) void k_minmax3_v(const float *__restrict__ xyz
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
         for (int k = 0; k < 3; ++k) {
             float v = xyz[(size_t)i * stride + k];
+            if (!(fabsf(v) <= FLT_MAX)) out6[6] = 1;   // NaN or infinity (fminf / fmaxf would hide a NaN)
             mn[k] = fminf(mn[k], v);
             mx[k] = fmaxf(mx[k], v);
         }
@@ -281,17 +282,21 @@ __global__ __launch_bounds__(256) void k_minmax3_v(const float *__restrict__ xyz
 }
 
 void bbox_host(plade_ctx *ctx, const float *d_xyz, uint32_t n, uint32_t stride, float mn[3], float mx[3]) {
-    int init[6];
+    int init[8];
     float pinf = INFINITY, ninf = -INFINITY;
     int a, b;
     memcpy(&a, &pinf, 4); memcpy(&b, &ninf, 4);
     for (int k = 0; k < 3; ++k) { init[k] = a; init[3 + k] = b ^ 0x7fffffff; }
+    init[6] = init[7] = 0;
     int *d = reinterpret_cast<int *>(ctx->scratch[3].ensure(64));
-    HIP_TRY(hipMemcpyAsync(d, init, 24, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(d, init, 32, hipMemcpyHostToDevice, ctx->stream));
     if (n) hipLaunchKernelGGL(k_minmax3_v, dim3(std::min(cdiv(n, 1024), 1024u)), dim3(256), 0, ctx->stream, d_xyz, n, stride, d);
-    int out[6];
-    HIP_TRY(hipMemcpyAsync(out, d, 24, hipMemcpyDeviceToHost, ctx->stream));
+    int out[8];
+    HIP_TRY(hipMemcpyAsync(out, d, 32, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    // every grid, key and threshold downstream is derived from the coordinates: refuse what the reference's
+    // kd-trees and voxel grids could not digest either, instead of looping on a NaN extent
+    PLADE_REQUIRE(out[6] == 0, PLADE_EINVAL, "the point cloud contains non-finite coordinates (NaN or infinity)");
     for (int k = 0; k < 6; ++k) {
         int v = out[k] >= 0 ? out[k] : out[k] ^ 0x7fffffff;
         float f;

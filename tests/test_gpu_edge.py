@@ -144,3 +144,28 @@ def test_contexts_sharing_a_gpu_are_independent():
         assert ok == want[i][0] and np.array_equal(T, want[i][1]), (w, rep, i)
     for i, (_, _, Tgt) in enumerate(pairs):
         assert want[i][0] and np.linalg.norm(want[i][1] - Tgt) < 1e-2   # 60k points: coarser than the 1M pairs
+
+
+@pytest.mark.timeout(120)
+def test_non_finite_inputs_neither_hang_nor_poison_the_context(ctx):
+    """NaN / infinite coordinates are refused (every grid and threshold derives from them; PCL's kd-trees and
+    voxel grids cannot take them either); NaN or zero normals just never pass the normal test."""
+    tg, sr, Tgt = make_pair(100000, seed=2)
+    for poison in ("nan", "inf"):
+        a, b = tg.copy(), sr.copy()
+        a[::997, :3] = np.nan if poison == "nan" else np.inf
+        with pytest.raises(plade_amd.PladeError) as e:
+            ctx.registration(a, b)
+        assert e.value.code == plade_amd.PLADE_EINVAL and "non-finite" in str(e.value)
+        with pytest.raises(plade_amd.PladeError):
+            ctx.voxel_downsample(a[:, :3].copy(), 0.1)
+    a, b = tg.copy(), sr.copy()
+    a[::991, 3:] = np.nan
+    b[::3, 3:] = 0.0
+    ok, T = ctx.registration(a, b)
+    assert ok and np.linalg.norm(T - Tgt) < 1e-2
+    a[:, 3:] = np.nan                                   # no usable normal at all: no planes, clean failure
+    ok, T = ctx.registration(a, b)
+    assert not ok and np.array_equal(T, np.eye(4, dtype=np.float32))
+    ok, T = ctx.registration(tg, sr)                    # the context is still good
+    assert ok and np.linalg.norm(T - Tgt) < 1e-2
