@@ -221,6 +221,16 @@ __global__ __launch_bounds__(256) void k_knn_grid(const float4 *__restrict__ pts
     }
 }
 
+// occupancy of a grid from its sorted cell keys: flag[0] = some cell holds more than `run` points,
+// flag[1] = number of occupied cells
+__global__ void k_grid_occupancy(const uint32_t *__restrict__ keys, uint32_t n, uint32_t run, uint32_t *__restrict__ flag) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i + run < n && keys[i] == keys[i + run]) flag[0] = 1u;
+    const bool head = i < n && (i == 0 || keys[i] != keys[i - 1]);
+    const uint32_t c = (uint32_t)__popcll(__ballot(head));
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(&flag[1], c);
+}
+
 float average_spacing_dev(plade_ctx *ctx, const float *d_aos, uint32_t stride_f, uint32_t n, const float *bbmin,
                           const float *bbmax, int k, uint32_t samples, TargetGrid &grid) {
     PLADE_REQUIRE(k >= 1 && k <= SP_K, PLADE_ELIMIT, "average_spacing: k must be in [1, 8]");
@@ -234,7 +244,28 @@ float average_spacing_dev(plade_ctx *ctx, const float *d_aos, uint32_t stride_f,
     const double area = 2 * (ex * ey + ey * ez + ex * ez);
     float cell = (float)(2.0 * std::sqrt(area / (double)n));
     if (!(cell > 0.f)) cell = 1.f;
-    grid.build(ctx, d_aos, n, stride_f, cell, bbmin, bbmax);
+    // The estimate assumes a surface-like cloud.  Points on a line, in a thin slab or in tight clumps make it far
+    // too coarse (thousands of points per cell: the exact ring search turns quadratic) or far too fine (every
+    // point alone, hundreds of empty rings per query): adapt the cell until no cell holds more than 256 points
+    // and the occupied cells hold two or more points on average (or the cell budget / duplicates forbid it).
+    int last_dir = 0;
+    for (int attempt = 0; attempt < 12; ++attempt) {
+        grid.build(ctx, d_aos, n, stride_f, cell, bbmin, bbmax);
+        if (n <= 256) break;
+        uint32_t *d_flag = reinterpret_cast<uint32_t *>(ctx->scratch[2].ensure(64));
+        HIP_TRY(hipMemsetAsync(d_flag, 0, 8, ctx->stream));
+        hipLaunchKernelGGL(k_grid_occupancy, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, grid.keys2.p, n, 256u, d_flag);
+        uint32_t occ[2] = {0, 0};
+        HIP_TRY(hipMemcpyAsync(occ, d_flag, 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        const float built = 1.f / grid.gp.inv;          // build() enlarges the cell when the cell budget is hit
+        int dir = 0;
+        if (occ[0] && built <= cell * 1.01f) dir = -1;              // too coarse
+        else if (!occ[0] && (double)occ[1] > 0.5 * (double)n) dir = +1;   // too fine
+        if (dir == 0 || dir == -last_dir) break;
+        cell = dir < 0 ? built * 0.25f : built * 4.f;
+        last_dir = dir;
+    }
     SpGrid g{grid.gp.mnx, grid.gp.mny, grid.gp.mnz, grid.gp.inv, 1.f / grid.gp.inv, grid.gp.dx, grid.gp.dy, grid.gp.dz};
     double *d_avg = reinterpret_cast<double *>(ctx->scratch[1].ensure((size_t)nq * 8 + 8));
     uint32_t *d_nbs = reinterpret_cast<uint32_t *>(ctx->scratch[2].ensure((size_t)nq * 4 + 8));

@@ -169,3 +169,37 @@ def test_non_finite_inputs_neither_hang_nor_poison_the_context(ctx):
     assert not ok and np.array_equal(T, np.eye(4, dtype=np.float32))
     ok, T = ctx.registration(tg, sr)                    # the context is still good
     assert ok and np.linalg.norm(T - Tgt) < 1e-2
+
+
+@pytest.mark.timeout(180)
+@pytest.mark.parametrize("case", ["line", "coplanar", "huge", "tiny", "far_outlier", "disjoint"])
+def test_degenerate_geometry_terminates(ctx, oracle, case):
+    """Inputs no plane-based registration can solve must come back quickly with `false` (or a clean error), not
+    hang: collinear and coplanar clouds, absurd scales, one point a billion metres away, unrelated clouds."""
+    tg, sr, _ = make_pair(60000, seed=2)
+    a, b = tg.copy(), sr.copy()
+    if case == "line":
+        for c in (a, b):
+            c[:, 1:3] = 0.0
+            c[:, 3:] = [0, 0, 1]
+    if case == "coplanar":
+        for c in (a, b):
+            c[:, 2] = 0.0
+            c[:, 3:] = [0, 0, 1]
+    if case == "huge":
+        a[:, :3] *= 1e18
+        b[:, :3] *= 1e18
+    if case == "tiny":
+        a[:, :3] *= 1e-18
+        b[:, :3] *= 1e-18
+    if case == "far_outlier":
+        a[0, :3] = [1e12, 0, 0]
+    if case == "disjoint":
+        b[:, :3] = np.random.default_rng(0).random((len(b), 3)) * 3
+    try:
+        ok, T = ctx.registration(a, b)
+        assert not ok and np.array_equal(T, np.eye(4, dtype=np.float32))
+    except plade_amd.PladeError as e:
+        assert e.code in (plade_amd.PLADE_EINVAL, plade_amd.PLADE_ELIMIT, plade_amd.PLADE_EFAIL)
+    if case == "line":   # the spacing of a collinear cloud is still the exact kNN value
+        assert ctx.average_spacing(a) == np.float32(oracle.average_spacing(a))
