@@ -203,3 +203,15 @@ def test_degenerate_geometry_terminates(ctx, oracle, case):
         assert e.code in (plade_amd.PLADE_EINVAL, plade_amd.PLADE_ELIMIT, plade_amd.PLADE_EFAIL)
     if case == "line":   # the spacing of a collinear cloud is still the exact kNN value
         assert ctx.average_spacing(a) == np.float32(oracle.average_spacing(a))
+
+
+def test_match_lists_longer_than_the_in_lds_ranking(ctx, oracle):
+    """Lists above 4096 entries take the two-radix-sort path of k_match.hip instead of the per-query ranking."""
+    rng = np.random.default_rng(9)
+    t = (rng.random((6000, 8)) * 0.01).astype(np.float32)     # everything within the radius of everything
+    t[1000:1500] = t[0:500]                                     # exact distance ties inside the long lists
+    q = np.concatenate([t[:3], (rng.random((2, 8)) * 0.01).astype(np.float32)])
+    o1, n1, d1 = oracle.match_descriptors(q, t, 0.04)
+    o2, n2, d2 = ctx.match_descriptors(q, t, 0.04)
+    assert (np.diff(o2) > 4096).all()
+    assert np.array_equal(o1, o2) and np.array_equal(n1, n2) and np.array_equal(d1, d2)
