@@ -9,6 +9,18 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    config.addinivalue_line("markers", "timeout: per-test time limit (pytest-timeout)")
+
+
+def pytest_collection_modifyitems(config, items):
+    """No GPU test may sit on the device for ever: 10 minutes each unless the test sets its own limit."""
+    try:
+        import pytest_timeout  # noqa: F401
+    except ImportError:
+        return
+    for item in items:
+        if item.get_closest_marker("gpu") and not item.get_closest_marker("timeout"):
+            item.add_marker(pytest.mark.timeout(600))
 
 
 @pytest.fixture(scope="session")
