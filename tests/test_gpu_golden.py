@@ -96,3 +96,29 @@ def test_g8_reference_sample_pair_on_the_gpu(ctx, oracle):
     assert ok_o and np.array_equal(T, T_o)
     ok2, T2 = ctx.registration(g["target"], g["source"])
     assert ok2 and np.linalg.norm(T2.astype(np.float64) - g["groundtruth"]) < 1e-2
+
+
+def test_g2_plane_sets_against_the_reference_ransac(ctx):
+    """Plane-set level parity of the GPU extraction (seam S1b) with the reference's Schnabel RANSAC on the
+    reference's sample cloud: EVERY plane libransac found is found with the same coefficients (up to the sign
+    the reference leaves arbitrary) and the same points.  The GPU search is more exhaustive (the reference stops
+    on a probability bound) and may report further small faces above min_support."""
+    g = load("g8_polyhedron.npz")
+    for cloud, rc, ro, ri in ((g["target"], g["t_coef"], g["t_off"], g["t_idx"]), (g["source"], g["s_coef"], g["s_off"], g["s_idx"])):
+        coef, off, idx = ctx.extract_planes(cloud, 625)   # extract() of plade.cpp:602-635 ends at 10000 / 16 here
+        assert len(rc) <= len(coef) <= 2 * len(rc)
+        sets = [set(idx[off[p]:off[p + 1]].tolist()) for p in range(len(coef))]
+        exact = 0
+        for p in range(len(rc)):
+            ref_set = set(ri[ro[p]:ro[p + 1]].tolist())
+            cos = coef[:, :3] @ rc[p, :3]
+            best, best_q = 0.0, -1
+            for q in np.nonzero(np.abs(cos) > 0.9999)[0]:
+                if abs(coef[q, 3] - rc[p, 3] * np.sign(cos[q])) > 2e-3:
+                    continue
+                j = len(sets[q] & ref_set) / len(sets[q] | ref_set)
+                if j > best:
+                    best, best_q = j, q
+            assert best > 0.95, (p, len(ref_set), best)
+            exact += len(sets[best_q]) == len(ref_set)
+        assert exact >= len(rc) - 3   # the supports are the same sets for (nearly) all planes
