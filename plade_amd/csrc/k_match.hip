@@ -70,6 +70,15 @@ __global__ void k_d2_keys(const double *__restrict__ d2, uint32_t m, uint64_t *_
     keys[i] = (uint64_t)__double_as_longlong(d2[i]);  // non-negative doubles order as their bit patterns
     vals[i] = i;
 }
+__global__ void k_iota_u32(uint32_t *__restrict__ p, uint32_t m) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) p[i] = i;
+}
+__global__ void k_d2_keys_perm(const double *__restrict__ d2, const uint32_t *__restrict__ perm, uint32_t m,
+                               uint64_t *__restrict__ keys) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) keys[i] = (uint64_t)__double_as_longlong(d2[perm[i]]);
+}
 __global__ void k_gather_u32(const uint32_t *__restrict__ src, const uint32_t *__restrict__ perm, uint32_t m,
                              uint32_t *__restrict__ dst) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -103,7 +112,7 @@ __global__ void k_query_offsets(const uint32_t *__restrict__ offs, uint32_t dq, 
 // Order inside each query's list: (dist2, target index).  The fill pass already wrote the lists query by
 // query in ascending target order, so each entry's final place is its rank by (dist2, position) inside
 // its own list: one workgroup per query, the list in LDS, O(len^2 / 256) compares (lists are tens to a few
-// thousand entries).
+// thousand entries).  Ties are broken on the target index itself, so the fill order inside a list is free.
 constexpr uint32_t RANK_MAX_LIST = 4096;
 __global__ __launch_bounds__(256) void k_rank_lists(const int64_t *__restrict__ offsets, uint32_t dq,
                                                     const uint32_t *__restrict__ t_raw, const double *__restrict__ d2_raw,
@@ -112,18 +121,198 @@ __global__ __launch_bounds__(256) void k_rank_lists(const int64_t *__restrict__ 
     const uint32_t q = blockIdx.x;
     if (q >= dq) return;
     const uint32_t b = (uint32_t)offsets[q], e = (uint32_t)offsets[q + 1], len = e - b;
-    for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) s_d2[i] = d2_raw[b + i];
+    __shared__ uint32_t s_t[RANK_MAX_LIST];
+    for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) { s_d2[i] = d2_raw[b + i]; s_t[i] = t_raw[b + i]; }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) {
         const double di = s_d2[i];
+        const uint32_t ti = s_t[i];
         uint32_t rank = 0;
         for (uint32_t j = 0; j < len; ++j) {
             const double dj = s_d2[j];
-            rank += (dj < di || (dj == di && j < i)) ? 1u : 0u;
+            rank += (dj < di || (dj == di && s_t[j] < ti)) ? 1u : 0u;   // ties: ascending target index
         }
-        t_out[b + rank] = t_raw[b + i];
+        t_out[b + rank] = ti;
         d2_out[b + rank] = di;
     }
+}
+
+// ---- windowed variant for large tables ----------------------------------------------------------------
+// |q - t|^2 <= r^2 needs |q[0] - t[0]| <= r: with both tables sorted by the first component (the
+// closest-point distance of the line pair) a group of 64 neighbouring queries only meets the targets of one
+// contiguous window.  Same exact fp64 test as k_match; only the enumeration differs.
+__device__ __forceinline__ uint32_t ord_u32(float f) { const uint32_t u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+
+__global__ void k_len_keys(const float *__restrict__ desc, uint32_t n, uint32_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { keys[i] = ord_u32(desc[8 * (size_t)i]); vals[i] = i; }
+}
+__global__ void k_gather_desc(const float *__restrict__ desc, const uint32_t *__restrict__ perm, uint32_t n, float *__restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * 2) return;   // two float4 per descriptor
+    const float4 *src = reinterpret_cast<const float4 *>(desc + 8 * (size_t)perm[i >> 1]) + (i & 1);
+    reinterpret_cast<float4 *>(out)[i] = *src;
+}
+// window [lo, lo + cnt) of sorted targets for every group of MT_TPB sorted queries; info[1] = max window
+__global__ void k_windows(const float *__restrict__ q_sorted, uint32_t dq, const uint32_t *__restrict__ t_keys_sorted, uint32_t dt,
+                          float radius, uint32_t *__restrict__ w_lo, uint32_t *__restrict__ w_cnt, uint32_t *__restrict__ info) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x, ng = (dq + MT_TPB - 1) / MT_TPB;
+    if (g >= ng) return;
+    const float qmin = q_sorted[8 * (size_t)(g * MT_TPB)];
+    const float qmax = q_sorted[8 * (size_t)min(dq - 1, g * MT_TPB + MT_TPB - 1)];
+    // conservative float bounds of [qmin - r, qmax + r] (the exact fp64 test decides membership)
+    const float pad = radius * 1.0001f + 1e-30f;
+    const uint32_t klo = ord_u32(qmin - pad - fabsf(qmin) * 1e-6f), khi = ord_u32(qmax + pad + fabsf(qmax) * 1e-6f);
+    uint32_t lo = 0, hi = dt;
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (t_keys_sorted[mid] < klo) lo = mid + 1; else hi = mid; }
+    uint32_t lo2 = lo, hi2 = dt;
+    while (lo2 < hi2) { const uint32_t mid = (lo2 + hi2) >> 1; if (t_keys_sorted[mid] <= khi) lo2 = mid + 1; else hi2 = mid; }
+    w_lo[g] = lo;
+    w_cnt[g] = lo2 - lo;
+    if (lo2 - lo > info[1]) atomicMax(&info[1], lo2 - lo);
+}
+template <bool FILL>
+__global__ __launch_bounds__(MT_TPB) void k_match_win(const float *__restrict__ qry, uint32_t dq, const float *__restrict__ tgt,
+                                                      const uint32_t *__restrict__ w_lo, const uint32_t *__restrict__ w_cnt,
+                                                      double sq_rad, uint32_t nch, uint32_t *__restrict__ cnt,
+                                                      const uint32_t *__restrict__ base /* dq*nch: final positions */,
+                                                      const uint32_t *__restrict__ q_perm, const uint32_t *__restrict__ t_perm,
+                                                      uint32_t *__restrict__ t_idx, double *__restrict__ d2_out,
+                                                      uint32_t *__restrict__ q_idx) {
+    __shared__ float s_t[MT_TILE][8];
+    const uint32_t q = blockIdx.x * MT_TPB + threadIdx.x;
+    const bool live = q < dq;
+    const uint32_t wl = w_lo[blockIdx.x], wc = w_cnt[blockIdx.x];
+    const uint32_t t_begin = wl + blockIdx.y * MT_CHUNK;
+    const uint32_t t_end = min(wl + wc, t_begin + MT_CHUNK);
+    if (blockIdx.y * MT_CHUNK >= wc) {   // chunk beyond this group's window
+        if (!FILL && live) cnt[(size_t)q * nch + blockIdx.y] = 0;
+        return;
+    }
+    double qd[8];
+#pragma unroll
+    for (int d = 0; d < 8; ++d) qd[d] = live ? (double)qry[(size_t)q * 8 + d] : 0.0;
+    uint32_t c = 0;
+    uint32_t wpos = (FILL && live) ? base[(size_t)q * nch + blockIdx.y] : 0u;
+    const uint32_t q_orig = (FILL && live) ? q_perm[q] : 0u;
+    for (uint32_t t0 = t_begin; t0 < t_end; t0 += MT_TILE) {
+        const uint32_t tn = min((uint32_t)MT_TILE, t_end - t0);
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < tn * 8; i += MT_TPB) (&s_t[0][0])[i] = tgt[(size_t)t0 * 8 + i];
+        __syncthreads();
+        if (live)
+            for (uint32_t j = 0; j < tn; ++j) {
+                double dist = 0.0;
+#pragma unroll
+                for (int d = 0; d < 8; ++d) {
+                    double t = qd[d] - (double)s_t[j][d];
+                    dist += t * t;
+                }
+                if (dist <= sq_rad) {
+                    if (FILL) {
+                        t_idx[wpos] = t_perm[t0 + j];
+                        d2_out[wpos] = dist;
+                        q_idx[wpos] = q_orig;
+                        ++wpos;
+                    } else ++c;
+                }
+            }
+    }
+    if (!FILL && live) cnt[(size_t)q * nch + blockIdx.y] = c;
+}
+// per sorted query: its total, scattered to the original query index
+__global__ void k_row_totals(const uint32_t *__restrict__ offs, uint32_t dq, uint32_t nch, const uint32_t *__restrict__ q_perm,
+                             uint32_t *__restrict__ row_tot /* original order, dq + 1 */) {
+    const uint32_t sq = blockIdx.x * blockDim.x + threadIdx.x;
+    if (sq < dq) row_tot[q_perm[sq]] = offs[(size_t)(sq + 1) * nch] - offs[(size_t)sq * nch];
+    if (sq == dq) row_tot[dq] = 0;
+}
+// final position of every (sorted query, chunk) cell; offsets of the original queries; longest list
+__global__ void k_win_bases(const uint32_t *__restrict__ offs, uint32_t dq, uint32_t nch, const uint32_t *__restrict__ q_perm,
+                            const uint32_t *__restrict__ row_off, uint32_t *__restrict__ base, int64_t *__restrict__ out,
+                            uint32_t *__restrict__ info) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < (size_t)dq * nch) {
+        const uint32_t sq = (uint32_t)(i / nch);
+        base[i] = row_off[q_perm[sq]] + (offs[i] - offs[(size_t)sq * nch]);
+    }
+    if (i <= dq) out[i] = row_off[i];
+    uint32_t len = i < dq ? row_off[i + 1] - row_off[i] : 0u;
+    for (int d = 32; d >= 1; d >>= 1) len = max(len, (uint32_t)__shfl_xor((int)len, d, 64));
+    if ((threadIdx.x & 63) == 0 && len > info[1]) atomicMax(&info[1], len);   // one conditional atomic per wavefront
+    if (i == dq) info[0] = row_off[dq];
+}
+
+uint64_t MatchResult::run_windowed(plade_ctx *ctx, const float *d_qry, uint32_t dq, const float *d_tgt, uint32_t dt, float radius) {
+    const float sq_rad_f = radius * radius;
+    const double sq_rad = sq_rad_f;
+    // both tables by ascending first component
+    wk_a.ensure(std::max(dq, dt)); wk_b.ensure(std::max(dq, dt)); wv_a.ensure(std::max(dq, dt));
+    q_perm.ensure(dq); t_perm.ensure(dt); q_sorted.ensure(8 * (size_t)dq + 8); t_sorted.ensure(8 * (size_t)dt + 8);
+    hipLaunchKernelGGL(k_len_keys, dim3(cdiv(dq, 256)), dim3(256), 0, ctx->stream, d_qry, dq, wk_a.p, wv_a.p);
+    sort_pairs_u32(ctx, wk_a.p, wk_b.p, wv_a.p, q_perm.p, dq, 32);
+    hipLaunchKernelGGL(k_gather_desc, dim3(cdiv(2 * (size_t)dq, 256)), dim3(256), 0, ctx->stream, d_qry, q_perm.p, dq, q_sorted.p);
+    hipLaunchKernelGGL(k_len_keys, dim3(cdiv(dt, 256)), dim3(256), 0, ctx->stream, d_tgt, dt, wk_a.p, wv_a.p);
+    sort_pairs_u32(ctx, wk_a.p, wk_b.p, wv_a.p, t_perm.p, dt, 32);   // wk_b = sorted target keys
+    hipLaunchKernelGGL(k_gather_desc, dim3(cdiv(2 * (size_t)dt, 256)), dim3(256), 0, ctx->stream, d_tgt, t_perm.p, dt, t_sorted.p);
+    const uint32_t ng = cdiv(dq, MT_TPB);
+    w_lo.ensure(ng); w_cnt.ensure(ng); info.ensure(2);
+    HIP_TRY(hipMemsetAsync(info.p, 0, 8, ctx->stream));
+    hipLaunchKernelGGL(k_windows, dim3(cdiv(ng, 256)), dim3(256), 0, ctx->stream, q_sorted.p, dq, wk_b.p, dt, radius, w_lo.p, w_cnt.p,
+                       info.p);
+    uint32_t h_info[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(h_info, info.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    const uint32_t nch = std::max(1u, cdiv(h_info[1], MT_CHUNK));
+    const size_t ncnt = (size_t)dq * nch;
+    PLADE_REQUIRE(ncnt < (1ull << 31), PLADE_ELIMIT, "match: too many (query, chunk) cells even inside the length windows");
+    cnt.ensure(ncnt + 1); offs.ensure(ncnt + 1);
+    dim3 grid(ng, nch);
+    hipLaunchKernelGGL(k_match_win<false>, grid, dim3(MT_TPB), 0, ctx->stream, q_sorted.p, dq, t_sorted.p, w_lo.p, w_cnt.p, sq_rad, nch,
+                       cnt.p, (const uint32_t *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr, (uint32_t *)nullptr,
+                       (double *)nullptr, (uint32_t *)nullptr);
+    HIP_TRY(hipMemsetAsync(cnt.p + ncnt, 0, 4, ctx->stream));
+    exclusive_scan_u32(ctx, cnt.p, offs.p, ncnt + 1);
+    row_tot.ensure((size_t)dq + 1); row_off.ensure((size_t)dq + 1);
+    hipLaunchKernelGGL(k_row_totals, dim3(cdiv(dq + 1, 256)), dim3(256), 0, ctx->stream, offs.p, dq, nch, q_perm.p, row_tot.p);
+    exclusive_scan_u32(ctx, row_tot.p, row_off.p, (size_t)dq + 1);
+    HIP_TRY(hipMemsetAsync(info.p, 0, 8, ctx->stream));
+    // `cnt` is free again: it receives the final write positions
+    hipLaunchKernelGGL(k_win_bases, dim3(cdiv(std::max(ncnt, (size_t)dq + 1), 256)), dim3(256), 0, ctx->stream, offs.p, dq, nch, q_perm.p,
+                       row_off.p, cnt.p, offsets.p, info.p);
+    HIP_TRY(hipMemcpyAsync(h_info, info.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    total = h_info[0];
+    const uint32_t max_list = h_info[1];
+    if (total == 0) return 0;
+    const uint32_t m = (uint32_t)total;
+    t_raw.ensure(m); d2_raw.ensure(m); q_raw.ensure(m);
+    hipLaunchKernelGGL(k_match_win<true>, grid, dim3(MT_TPB), 0, ctx->stream, q_sorted.p, dq, t_sorted.p, w_lo.p, w_cnt.p, sq_rad, nch,
+                       (uint32_t *)nullptr, cnt.p, q_perm.p, t_perm.p, t_raw.p, d2_raw.p, q_raw.p);
+    t_idx.ensure(m); dist2.ensure(m);
+    q_idx_sorted = q_raw.p;
+    if (max_list <= RANK_MAX_LIST) {
+        hipLaunchKernelGGL(k_rank_lists, dim3(dq), dim3(256), 0, ctx->stream, offsets.p, dq, t_raw.p, d2_raw.p, t_idx.p, dist2.p);
+        HIP_TRY(hipGetLastError());
+        return total;
+    }
+    // very long lists: stable sorts by target index, then dist2, then query
+    k64a.ensure(m); k64b.ensure(m); v32a.ensure(m); v32b.ensure(m); k32a.ensure(m); k32b.ensure(m);
+    hipLaunchKernelGGL(k_iota_u32, dim3(cdiv(m, 256)), dim3(256), 0, ctx->stream, v32a.p, m);
+    int tbits = 1;
+    while ((1ull << tbits) < dt) ++tbits;
+    sort_pairs_u32(ctx, t_raw.p, k32b.p, v32a.p, v32b.p, m, tbits);                  // v32b: entries by target index
+    hipLaunchKernelGGL(k_d2_keys_perm, dim3(cdiv(m, 256)), dim3(256), 0, ctx->stream, d2_raw.p, v32b.p, m, k64a.p);
+    sort_pairs_u64(ctx, k64a.p, k64b.p, v32b.p, v32a.p, m, 64);                       // v32a: by (dist2, target)
+    hipLaunchKernelGGL(k_gather_u32, dim3(cdiv(m, 256)), dim3(256), 0, ctx->stream, q_raw.p, v32a.p, m, k32a.p);
+    int qbits = 1;
+    while ((1ull << qbits) < dq) ++qbits;
+    sort_pairs_u32(ctx, k32a.p, k32b.p, v32a.p, v32b.p, m, qbits);                    // v32b: by (query, dist2, target)
+    hipLaunchKernelGGL(k_gather_final, dim3(cdiv(m, 256)), dim3(256), 0, ctx->stream, t_raw.p, d2_raw.p, v32b.p, m, t_idx.p,
+                       dist2.p);
+    q_idx_sorted = k32b.p;
+    HIP_TRY(hipGetLastError());
+    return total;
 }
 
 uint64_t MatchResult::run(plade_ctx *ctx, const float *d_qry, uint32_t dq, const float *d_tgt, uint32_t dt,
@@ -134,6 +323,12 @@ uint64_t MatchResult::run(plade_ctx *ctx, const float *d_qry, uint32_t dq, const
     if (radius < 0.f || dt == 0) { HIP_TRY(hipMemsetAsync(offsets.p, 0, ((size_t)dq + 1) * 8, ctx->stream)); return 0; }
     const float sq_rad_f = radius * radius;  // ANN.h:987 `float sqRad = radius*radius`
     const double sq_rad = sq_rad_f;
+    // large tables (or PLADE_MATCH_WINDOW=1): enumerate only inside the length windows
+    {
+        const char *env = getenv("PLADE_MATCH_WINDOW");
+        const bool force = env && atoi(env) > 0, never = env && atoi(env) < 0;
+        if (!never && (force || (double)dq * (double)dt > 2.0e10)) return run_windowed(ctx, d_qry, dq, d_tgt, dt, radius);
+    }
     const uint32_t nch = cdiv(dt, MT_CHUNK);
     const size_t ncnt = (size_t)dq * nch;
     PLADE_REQUIRE(ncnt < (1ull << 31), PLADE_ELIMIT, "match: too many (query, chunk) cells");

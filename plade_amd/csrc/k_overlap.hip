@@ -254,6 +254,10 @@ __global__ __launch_bounds__(OV_TPB) void k_overlap(const float *__restrict__ sx
 }
 
 // source points into a spatially blocked order: key = blocked cell id in the source's own frame
+__global__ void k_init_minmax6(int *__restrict__ out6) {   // (+inf x3, -inf x3) as ordered ints
+    if (threadIdx.x < 3) out6[threadIdx.x] = ordered_int(INFINITY);
+    else if (threadIdx.x < 6) out6[threadIdx.x] = ordered_int(-INFINITY);
+}
 __global__ void k_src_minmax(const float *__restrict__ x, const float *__restrict__ y, const float *__restrict__ z, uint32_t n,
                              int *__restrict__ out6) {
     __shared__ float s_lds[6][8];
@@ -311,13 +315,8 @@ void overlap_sort_source(plade_ctx *ctx, OverlapWork &work, const float *d_sx, c
                          float cell) {
     if (!n_s) return;
     // any order gives the same counts; this one makes a wavefront's probes local
-    int init[6];
-    float pinf = INFINITY, ninf = -INFINITY;
-    int a, b;
-    memcpy(&a, &pinf, 4); memcpy(&b, &ninf, 4);
-    for (int k = 0; k < 3; ++k) { init[k] = a; init[3 + k] = b ^ 0x7fffffff; }
     work.bbox.ensure(8);
-    HIP_TRY(hipMemcpyAsync(work.bbox.p, init, 24, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_init_minmax6, dim3(1), dim3(64), 0, ctx->stream, work.bbox.p);
     hipLaunchKernelGGL(k_src_minmax, dim3(std::min(cdiv(n_s, 256), 512u)), dim3(256), 0, ctx->stream, d_sx, d_sy, d_sz, n_s,
                        work.bbox.p);
     work.keys.ensure(n_s); work.keys2.ensure(n_s); work.vals.ensure(n_s); work.vals2.ensure(n_s);

@@ -160,6 +160,9 @@ bool prepare_side(plade_ctx *ctx, const char *tag, const CloudDev &cloud, const 
     make_line_table(pl.coef, P, S.bcenter, S.radius, S.lines);
     // line-pair descriptors of this side (K4); both sides build theirs concurrently
     build_pair_table(ctx, S.lines, S.normals.data(), P, desc_scale, is_target, pairs);
+    // everything this side produced is consumed on the OTHER stream (match, transforms, penetration run on the
+    // main stream, the source side is prepared on the auxiliary one): finish it before handing over
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
     ctx->stats.add(std::string("t_prep_lines_") + tag, secs_since(tp0));
     if (ctx->params.dump) {
         const std::string t(tag);

@@ -129,7 +129,7 @@ def test_contexts_sharing_a_gpu_are_independent():
 
     def work(w):
         c = plade_amd.Context(0)
-        for rep in range(3):
+        for rep in range(10):   # enough repetitions to expose a missing cross-stream dependency (one was found this way)
             for i, (tg, sr, _) in enumerate(pairs):
                 got[(w, rep, i)] = c.registration(tg, sr)
         c.close()
@@ -139,7 +139,7 @@ def test_contexts_sharing_a_gpu_are_independent():
         t.start()
     for t in ths:
         t.join()
-    assert len(got) == 24
+    assert len(got) == 80
     for (w, rep, i), (ok, T) in got.items():
         assert ok == want[i][0] and np.array_equal(T, want[i][1]), (w, rep, i)
     for i, (_, _, Tgt) in enumerate(pairs):

@@ -124,3 +124,25 @@ def test_voxel_downsample_bit_exact(ctx, oracle, n, leaf):
     assert got.shape == want.shape and np.array_equal(got, want)
     faithful = oracle.voxel_downsample(cloud, leaf, 0)  # PCL's std::sort order: same voxels, <= few ulp apart
     assert faithful.shape == got.shape and np.abs(faithful - got).max() <= 1e-5
+
+
+def test_match_windowed_equals_brute_force(oracle, monkeypatch):
+    """The length-windowed enumeration used for large descriptor tables (k_match.hip) returns exactly what the
+    brute-force kernel returns: same lists, same order, same fp64 distances."""
+    import plade_amd
+    rng = np.random.default_rng(11)
+    t = np.concatenate([(rng.random((30000, 1)) * 60).astype(np.float32), (rng.random((30000, 7)) * 0.2).astype(np.float32)], 1)
+    q = t[rng.integers(0, len(t), 4000)] + rng.normal(0, 0.008, (4000, 8)).astype(np.float32)
+    q[:50] = t[:50]                        # exact hits
+    t[100:150] = t[0:50]                   # duplicated targets: distance ties broken by target index
+    out = {}
+    for mode in ("-1", "1"):
+        monkeypatch.setenv("PLADE_MATCH_WINDOW", mode)
+        c = plade_amd.Context(0)
+        out[mode] = c.match_descriptors(q, t, 0.04)
+        c.close()
+    for a, b in zip(out["-1"], out["1"]):
+        assert np.array_equal(a, b)
+    assert len(out["1"][1]) > 4000
+    o, n, d = oracle.match_descriptors(q[:300], t, 0.04)
+    assert np.array_equal(n, out["1"][1][: len(n)]) and np.array_equal(d, out["1"][2][: len(d)])
