@@ -208,6 +208,8 @@ def main():
     elapsed = float(tmax.item())
     total_ok = int(okt.item())
 
+    # every registration of the same pair, whichever context ran it, must return the same bits
+    identical = all(np.array_equal(results[i], results[i % len(pairs)]) for i in range(len(results)))
     # accuracy of the timed registrations on this rank vs the generator's ground truth
     errs = [float(np.linalg.norm(results[i].astype(np.float64) - pairs[i % len(pairs)][2])) for i in range(len(results))]
 
@@ -283,6 +285,7 @@ def main():
                        "parallelism": f"independent pairs sharded over {world} GPU(s), {M} in flight per GPU"},
             "single_registration_latency_ms": latency_ms,
             "registrations_ok": total_ok,
+            "results_bit_identical_per_pair_rank0": bool(identical),
             "max_frobenius_vs_ground_truth_rank0": max(errs) if errs else None,
             "roofline": roofline,
             "cpu_baseline": cpu,
