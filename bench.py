@@ -165,9 +165,18 @@ def main():
         return ok, T
 
     def run_steps(first, count, out):
-        """Steps first .. first+count-1, step i on worker i % M (each worker runs its steps in order)."""
+        """Steps first .. first+count-1; every worker takes the next free step (a shared counter), so the
+        workers stay busy until the last step has been handed out."""
+        lock = threading.Lock()
+        nxt = [first]
+
         def work(w):
-            for i in range(first + w, first + count, M):
+            while True:
+                with lock:
+                    i = nxt[0]
+                    nxt[0] += 1
+                if i >= first + count:
+                    return
                 out[i - first] = step(i, w)
         if M == 1:
             work(0)
@@ -178,8 +187,18 @@ def main():
         for t in ths:
             t.join()
 
-    warm = [None] * max(args.warmup, M)   # every worker is warmed at least once
-    run_steps(0, len(warm), warm)
+    # warm-up: W steps in total, but every worker (context) at least one, so that no first-use allocation or
+    # graph capture falls into the timed region
+    per_worker = max(len(pairs), -(-args.warmup // M))   # and every distinct pair once per worker (cloud sizes differ)
+
+    def warm_worker(w):
+        for r in range(per_worker):
+            step(r, w)
+    wths = [threading.Thread(target=warm_worker, args=(w,)) for w in range(M)]
+    for t in wths:
+        t.start()
+    for t in wths:
+        t.join()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
