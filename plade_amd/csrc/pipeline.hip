@@ -296,7 +296,9 @@ bool run_registration(plade_ctx *ctx, RegistrationWork &W, const CloudDev &tgt, 
         build_transforms(ctx, W.src_pairs, W.tgt_pairs, W.match.q_idx_sorted, W.match.t_idx.p, (uint32_t)n_match, W.cand);
         if (ctx->params.dump && n_match) {
             std::vector<float4> h(4 * (size_t)n_match);
-            HIP_TRY(hipMemcpy(h.data(), W.cand.rt.p, 64 * (size_t)n_match, hipMemcpyDeviceToHost));
+            // on the context's (non-blocking) stream: a null-stream copy would not wait for build_transforms
+            HIP_TRY(hipMemcpyAsync(h.data(), W.cand.rt.p, 64 * (size_t)n_match, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
             std::vector<float> rt(12 * (size_t)n_match);
             for (size_t i = 0; i < n_match; ++i) {
                 for (int r = 0; r < 3; ++r) {

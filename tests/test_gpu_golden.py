@@ -98,6 +98,37 @@ def test_g8_reference_sample_pair_on_the_gpu(ctx, oracle):
     assert ok2 and np.linalg.norm(T2.astype(np.float64) - g["groundtruth"]) < 1e-2
 
 
+def test_g9_real_room_scan_every_intermediate_equals_oracle(oracle):
+    """A real indoor scan (the reference's sample_data/room_target.ply; surrogate source, tools/make_golden.py) with
+    the planes libransac extracted (two independent draws): all dumped intermediates and the final transform equal
+    the oracle's bit for bit."""
+    import plade_amd
+    g = load("g9_room.npz")
+    ctx = plade_amd.Context(0, dump=1)
+    for pre in ("", "b"):
+        tp = (g[f"t{pre}_coef"], g[f"t{pre}_off"], g[f"t{pre}_idx"])
+        sp = (g[f"s{pre}_coef"], g[f"s{pre}_off"], g[f"s{pre}_idx"])
+        ok, T = ctx.registration_planes(g["target"], g["source"], tp, sp)
+        d = ctx.dump()
+        ok_o, T_o, do = oracle.registration(g["target"], g["source"], tp, sp, voxel_sort_mode=1)
+        assert ok and ok_o and np.array_equal(T, T_o)
+        common = [k for k in do if k in d and not k.startswith("timing")]
+        assert len(common) >= 30 and "initial_RT" in common
+        for k in common:
+            assert np.asarray(d[k]).shape == np.asarray(do[k]).shape and np.array_equal(d[k], do[k]), (pre, k)
+        assert np.linalg.norm(T - g["groundtruth"]) < 0.1
+    ctx.close()
+
+
+def test_g9_real_room_scan_own_plane_extraction(ctx):
+    """Same pair through the full path (plade.h:58): the GPU plane extraction + registration land on the ground truth."""
+    g = load("g9_room.npz")
+    ok, T = ctx.registration(g["target"], g["source"])
+    assert ok and np.linalg.norm(T.astype(np.float64) - g["groundtruth"]) < 1e-2
+    ok2, T2 = ctx.registration(g["target"], g["source"])
+    assert ok2 and np.array_equal(T, T2)
+
+
 def test_g2_plane_sets_against_the_reference_ransac(ctx):
     """Plane-set level parity of the GPU extraction (seam S1b) with the reference's Schnabel RANSAC on the
     reference's sample cloud: EVERY plane libransac found is found with the same coefficients (up to the sign

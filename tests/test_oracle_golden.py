@@ -93,6 +93,19 @@ def test_g8_reference_sample_pair_reproduces_the_authors_recorded_result(oracle)
     assert np.abs(T - g["groundtruth"]).max() < 5e-5
 
 
+def test_g9_real_room_scan_with_the_reference_ransac_planes(oracle):
+    """The reference's real indoor scan (sample_data/room_target.ply) against a surrogate source cut from it (the
+    matching source scan is not shipped, tools/make_golden.py) with two independent draws of libransac's planes:
+    the pipeline recovers the shipped ground truth to the accuracy of a coarse, plane-fit based aligner."""
+    g = load("g9_room.npz")
+    for pre in ("", "b"):
+        tp = (g[f"t{pre}_coef"], g[f"t{pre}_off"], g[f"t{pre}_idx"])
+        sp = (g[f"s{pre}_coef"], g[f"s{pre}_off"], g[f"s{pre}_idx"])
+        ok, T, d = oracle.registration(g["target"], g["source"], tp, sp)
+        assert ok and np.linalg.norm(T - g["groundtruth"]) < 0.1
+        assert len(d["match_nbr"]) > 1000
+
+
 def test_average_spacing_bit_exact(oracle):
     g = load("g_spacing.npz")
     assert np.float32(oracle.average_spacing(g["cloud"])) == g["spacing"]

@@ -201,4 +201,27 @@ recorded = np.array([[-0.506082, 0.860669, 0.0559446, -0.252576], [0.821345, 0.5
 np.savez_compressed(os.path.join(OUT, "g8_polyhedron.npz"), target=ptg, source=psr,
                     groundtruth=np.loadtxt(os.path.join(SAMPLE, "polyhedron_source_groundtruth.txt")), recorded=recorded,
                     t_coef=tpl[0], t_off=tpl[1], t_idx=tpl[2], s_coef=spl[0], s_off=spl[1], s_idx=spl[2])
+# ---- G9: the reference's real indoor scan (sample_data/room_target.ply, 94k points).  The matching source scan is not
+# shipped (only its ground truth, room_source_groundtruth.txt), so the source here is a SURROGATE: a 75 % crop of
+# the target, thinned to 80 %, moved by the inverse of the shipped ground truth (re-orthonormalised: the file is
+# rounded to 5 digits).  Planes of both clouds from the reference's RANSAC as for G8.
+rtg = read_ply(os.path.join(SAMPLE, "room_target.ply"))
+rgt = np.loadtxt(os.path.join(SAMPLE, "room_source_groundtruth.txt")).reshape(4, 4).astype(np.float64)
+U_, _, Vt_ = np.linalg.svd(rgt[:3, :3])
+rgt[:3, :3] = U_ @ Vt_
+rrng = np.random.default_rng(0)
+axis = np.array([1.0, 0.3, 0.1]); axis /= np.linalg.norm(axis)
+proj = rtg[:, :3] @ axis
+crop = proj <= np.quantile(proj, 0.75)
+sub = rtg[crop][rrng.random(int(crop.sum())) < 0.8]
+Ti = np.linalg.inv(rgt)
+rsr = np.concatenate([sub[:, :3].astype(np.float64) @ Ti[:3, :3].T + Ti[:3, 3],
+                      sub[:, 3:].astype(np.float64) @ Ti[:3, :3].T], 1).astype(np.float32)
+# two independent plane-set draws (libransac is seeded by time())
+rtpl, rspl = ref_extract(rtg, 6), ref_extract(rsr, 106)
+rtpl_b, rspl_b = ref_extract(rtg, 1), ref_extract(rsr, 2)
+np.savez_compressed(os.path.join(OUT, "g9_room.npz"), target=rtg, source=rsr, groundtruth=rgt,
+                    t_coef=rtpl[0], t_off=rtpl[1], t_idx=rtpl[2], s_coef=rspl[0], s_off=rspl[1], s_idx=rspl[2],
+                    tb_coef=rtpl_b[0], tb_off=rtpl_b[1], tb_idx=rtpl_b[2], sb_coef=rspl_b[0], sb_off=rspl_b[1],
+                    sb_idx=rspl_b[2])
 print("golden fixtures written to", OUT, [f for f in sorted(os.listdir(OUT))])
