@@ -114,6 +114,15 @@ def cpu_baseline(n_points, pairs, budget_s=25.0):
     }
 
 
+def _cgroup_throttle():
+    """(nr_throttled, throttled_usec) of this container's CPU quota, None where cgroup v2 is not mounted."""
+    try:
+        kv = dict(l.split() for l in open("/sys/fs/cgroup/cpu.stat"))
+        return int(kv["nr_throttled"]), int(kv["throttled_usec"])
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -121,6 +130,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--points", type=int, default=1000000)
     ap.add_argument("--pairs", type=int, default=2, help="distinct synthetic pairs per rank (cycled)")
+    ap.add_argument("--host-wait", choices=["spin", "sleep"], default="spin",
+                    help="how the host threads wait for the GPU (plade_params.host_wait)")
     ap.add_argument("--inflight", type=int, default=8,
                     help="registrations in flight per GPU: independent pairs, one plade_ctx + host thread each "
                          "(a single registration is latency-bound and leaves most of the GPU idle)")
@@ -147,7 +158,8 @@ def main():
 
     import threading
     M = max(1, min(args.inflight, args.steps))
-    ctxs = [plade_amd.Context(local_rank) for _ in range(M)]
+    host_wait = {"spin": 0, "sleep": 1}[args.host_wait]
+    ctxs = [plade_amd.Context(local_rank, host_wait=host_wait) for _ in range(M)]
     ctx = ctxs[0]
     # synthetic pairs: seeds are global pair ids (batch of independent pairs sharded across ranks); every
     # worker holds its own resident copy so the workers share nothing
@@ -203,9 +215,11 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    cpu0, thr0 = time.process_time(), _cgroup_throttle()
     t0 = time.perf_counter()
     timed = [None] * args.steps
     run_steps(0, args.steps, timed)
+    cpu1, thr1 = time.process_time(), _cgroup_throttle()
     oks = [bool(r[0]) for r in timed]
     results = [r[1] for r in timed]
     n_ok = sum(oks)
@@ -300,12 +314,16 @@ def main():
             "config": {"workload": f"Synthetic {args.points}-pt indoor scan pair, ~30 planes (BASELINE configs[2]); "
                                    "full registration(T,target,source) = plane extraction + registration, clouds resident in HBM",
                        "points_per_cloud": args.points, "pairs_per_rank": args.pairs,
-                       "registrations_in_flight_per_gpu": M,
+                       "registrations_in_flight_per_gpu": M, "host_wait": args.host_wait,
                        "parallelism": f"independent pairs sharded over {world} GPU(s), {M} in flight per GPU"},
             "single_registration_latency_ms": latency_ms,
             "registrations_ok": total_ok,
             "results_bit_identical_per_pair_rank0": bool(identical),
             "max_frobenius_vs_ground_truth_rank0": max(errs) if errs else None,
+            "host_rank0": {"cpu_seconds_per_step": (cpu1 - cpu0) / args.steps,
+                           "busy_host_threads_avg": (cpu1 - cpu0) / max(elapsed, 1e-9),
+                           "cgroup_throttled_periods": (thr1[0] - thr0[0]) if thr0 and thr1 else None,
+                           "cgroup_throttled_usec": (thr1[1] - thr0[1]) if thr0 and thr1 else None},
             "roofline": roofline,
             "cpu_baseline": cpu,
             "stage_seconds_profiled_step": stage_times,

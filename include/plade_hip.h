@@ -50,6 +50,11 @@ typedef struct plade_params {
     int32_t orient_normals;
     int32_t dump;
     uint64_t ransac_seed;
+    int32_t host_wait;   /* how the calling thread waits for the GPU: 0 = spin (lowest latency; the HIP runtime keeps
+                          * one CPU busy per waiting thread), 1 = poll + short sleeps (throughput mode: many
+                          * contexts in flight per CPU; adds ~30 us per wait).  Env PLADE_HOST_WAIT=spin|sleep
+                          * overrides the default at context creation. */
+    int32_t reserved0;
 } plade_params;
 void plade_default_params(plade_params *p);
 int plade_set_params(plade_ctx *ctx, const plade_params *p);
@@ -149,6 +154,14 @@ int plade_dump_get(plade_ctx *ctx, const char *name, const void **ptr, int64_t *
 /* Per-stage GPU/host seconds and byte counts of the last registration:
  * names is a ';'-separated list, values has one double per name. */
 int plade_stats_get(plade_ctx *ctx, const char **names, const double **values, int32_t *count);
+/* ---- diagnostic: the device-wide stable radix sort every grid of the path is built with ----------------
+ * (radix_sort.hip; no reference counterpart -- it stands where PCL sorts voxel indices with std::sort,
+ * voxel_grid.hpp:325, and where the kd-trees are built.)  keys: n keys of key_bytes (4 or 8) each, of which the low
+ * `bits` bits are significant; vals: n u32 payloads.  Outputs are host arrays of the same shapes; equal keys keep
+ * their input order. */
+int plade_sort_pairs(plade_ctx *ctx, const void *keys, const uint32_t *vals, uint32_t n, int key_bytes, int bits,
+                     void *keys_out, uint32_t *vals_out);
+
 /* Times `iters` launches of one hot kernel on resident synthetic-shaped data with HIP events on
  * the ctx stream (used by bench.py for the roofline figure): which = "score" | "overlap" | "match". */
 int plade_kernel_time(plade_ctx *ctx, const char *which, int iters, double *avg_seconds,

@@ -21,6 +21,7 @@ ABI_SYMBOLS = [
     "plade_overlap_counts", "plade_average_spacing", "plade_voxel_downsample", "plade_registration_planes",
     "plade_registration", "plade_registration_minsupport", "plade_cloud_upload", "plade_cloud_free",
     "plade_registration_dev", "plade_dump_get", "plade_stats_get", "plade_kernel_time", "plade_plane_component",
+    "plade_sort_pairs",
 ]
 
 
@@ -33,7 +34,7 @@ class PladeError(RuntimeError):
 class Params(C.Structure):
     _fields_ = [("max_planes", C.c_int32), ("min_planes", C.c_int32), ("max_candidates", C.c_int32),
                 ("init_min_support", C.c_int32), ("orient_normals", C.c_int32), ("dump", C.c_int32),
-                ("ransac_seed", C.c_uint64)]
+                ("ransac_seed", C.c_uint64), ("host_wait", C.c_int32), ("reserved0", C.c_int32)]
 
 
 _lib = None
@@ -82,6 +83,7 @@ def load_library(path=LIB_PATH):
     sig("plade_stats_get", argtypes=[p, C.POINTER(C.c_char_p), C.POINTER(C.POINTER(C.c_double)), C.POINTER(i32)])
     sig("plade_kernel_time", argtypes=[p, C.c_char_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)])
     sig("plade_plane_component", argtypes=[p, p, u32, p, p, p, u32, f, C.c_int, f, p, p, p, p])
+    sig("plade_sort_pairs", argtypes=[p, p, p, u32, C.c_int, C.c_int, p, p])
     _lib = L
     return L
 
@@ -170,6 +172,17 @@ class Context:
         for k, v in kw.items():
             setattr(self.params, k, v)
         self._check(self.L.plade_set_params(self.h, C.byref(self.params)))
+
+    def sort_pairs(self, keys, vals, bits=None):
+        """Diagnostic seam: the device-wide stable radix sort (radix_sort.hip).  keys uint32 or uint64."""
+        k = np.ascontiguousarray(keys)
+        assert k.dtype in (np.uint32, np.uint64)
+        v = np.ascontiguousarray(vals, np.uint32)
+        kb = k.dtype.itemsize
+        ko, vo = np.empty_like(k), np.empty_like(v)
+        self._check(self.L.plade_sort_pairs(self.h, k.ctypes.data_as(C.c_void_p), _ptr(v), len(k), kb,
+                                            int(bits if bits is not None else 8 * kb), ko.ctypes.data_as(C.c_void_p), _ptr(vo)))
+        return ko, vo
 
     # ---- seams -----------------------------------------------------------------------------
     def score_planes(self, pos_nrm, shape_index, planes, eps, cos_thresh, want_indices=False):

@@ -14,6 +14,9 @@ extern "C" void plade_default_params(plade_params *p) {
     p->orient_normals = 1;
     p->dump = 0;
     p->ransac_seed = 0x9E3779B97F4A7C15ull;
+    p->host_wait = 0;
+    p->reserved0 = 0;
+    if (const char *w = getenv("PLADE_HOST_WAIT")) p->host_wait = (w[0] == 's' && w[1] == 'l') ? 1 : 0;
 }
 
 extern "C" const char *plade_version(void) { return "plade-hip 0.1 (gfx950)"; }

@@ -2,6 +2,8 @@
 #pragma once
 #include "common.h"
 #include "plade_hip.h"
+#include <ctime>
+#include <sys/prctl.h>
 
 namespace plade {
 
@@ -34,6 +36,14 @@ struct Stats {
     void merge(const Stats &o) { for (size_t i = 0; i < o.names.size(); ++i) add(o.names[i], o.values[i]); }
 };
 
+}  // namespace plade
+
+namespace plade {
+// nanosleep() of a normal thread is rounded up by 50 us of timer slack; ask for 1 us once per thread
+inline void relax_timer_slack() {
+    static thread_local bool done = false;
+    if (!done) { (void)prctl(PR_SET_TIMERSLACK, 1000UL, 0, 0, 0); done = true; }
+}
 }  // namespace plade
 
 struct plade_cloud {
@@ -83,6 +93,29 @@ struct plade_ctx {
         }
         evs.clear();
     }
+    // Wait until everything queued on `s` (default: this ctx's stream) has finished.  Every wait of the HIP runtime
+    // spins (one CPU per waiting thread, whatever the event flags: tools/wait_cost.hip); with several contexts in
+    // flight per GPU that exhausts a container's CPU quota long before the GPU is full, so params.host_wait = 1
+    // polls the stream and sleeps in between.
+    void sync(hipStream_t s = nullptr) {
+        if (!s) s = stream;
+        if (params.host_wait == 0) { HIP_TRY(hipStreamSynchronize(s)); return; }
+        plade::relax_timer_slack();
+        for (int polls = 0;; ++polls) {
+            const hipError_t e = hipStreamQuery(s);
+            if (e == hipSuccess) return;
+            if (e != hipErrorNotReady) throw plade::Err{-2, std::string("hipStreamQuery: ") + hipGetErrorString(e)};
+            timespec ts{0, polls < 8 ? 15000 : 40000};
+            nanosleep(&ts, nullptr);
+        }
+    }
+    // Device -> host readback on this ctx's stream.  A copy into pageable host memory makes the HIP runtime wait
+    // (spinning) for everything queued before it, so in host_wait = 1 mode the stream is drained with sleeping
+    // polls first and only the copy itself is waited for actively.
+    void d2h(void *dst, const void *src, size_t bytes) {
+        if (params.host_wait != 0) sync();
+        HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, stream));
+    }
     // generic scratch
     plade::DBuf<char> scratch[8];
     plade::HBuf<char> pinned[4];
@@ -101,8 +134,8 @@ struct plade_ctx {
     void put_dev(const std::string &name, const T *dptr, size_t count) {
         if (!params.dump) return;
         std::vector<T> h(count);
-        if (count) HIP_TRY(hipMemcpyAsync(h.data(), dptr, count * sizeof(T), hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipStreamSynchronize(stream));
+        if (count) d2h(h.data(), dptr, count * sizeof(T));
+        sync();
         put(name, h.data(), count);
     }
 };

@@ -210,8 +210,8 @@ void cluster_transforms(plade_ctx *ctx, CandidateSet &cs, float dist_threshold, 
     // bbox of the translations (per-workgroup partials left by k_transforms)
     const uint32_t nbp = cdiv(m, 256);
     std::vector<float> part(6 * (size_t)nbp);
-    HIP_TRY(hipMemcpyAsync(part.data(), cs.t_minmax.p, 24 * (size_t)nbp, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->d2h(part.data(), cs.t_minmax.p, 24 * (size_t)nbp);
+    ctx->sync();
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (uint32_t b = 0; b < nbp; ++b)
         for (int k = 0; k < 3; ++k) { mn[k] = std::min(mn[k], part[6 * (size_t)b + k]); mx[k] = std::max(mx[k], part[6 * (size_t)b + 3 + k]); }
@@ -321,7 +321,7 @@ void plane_consistency(plade_ctx *ctx, CandidateSet &cs, const PlaneGeomHost &sr
                        f3(tgt_bcenter[0], tgt_bcenter[1], tgt_bcenter[2]), max_radius, cos_angle_th, length_threshold,
                        cs.plane_counts.p);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(ctx->stream));  // `tab` must outlive the copy
+    ctx->sync();  // `tab` must outlive the copy
 }
 
 }  // namespace plade

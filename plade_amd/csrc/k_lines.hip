@@ -100,8 +100,8 @@ uint32_t compact_flags(plade_ctx *ctx, const uint32_t *d_flags, uint32_t n, DBuf
     // scan n + 1 entries so that pos[n] is the total (the flag array must have n + 1 slots, last = 0)
     exclusive_scan_u32(ctx, d_flags, pos.p, (size_t)n + 1);
     uint32_t total = 0;
-    HIP_TRY(hipMemcpyAsync(&total, pos.p + n, 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->d2h(&total, pos.p + n, 4);
+    ctx->sync();
     out_idx.ensure((size_t)total + 1);
     hipLaunchKernelGGL(k_flag_positions, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, d_flags, pos.p, n, out_idx.p);
     HIP_TRY(hipGetLastError());
@@ -140,8 +140,8 @@ void build_pair_table(plade_ctx *ctx, const LineTableHost &lt, const float *norm
     HIP_TRY(hipMemsetAsync(out.flags.p + n, 0, 4, ctx->stream));
     exclusive_scan_u32(ctx, out.flags.p, out.pos.p, n + 1);
     uint32_t total = 0;
-    HIP_TRY(hipMemcpyAsync(&total, out.pos.p + n, 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));  // also keeps `blob` alive until the copy is done
+    ctx->d2h(&total, out.pos.p + n, 4);
+    ctx->sync();  // also keeps `blob` alive until the copy is done
     out.count = total;
     out.desc.ensure((size_t)total * 8 + 8); out.lv1.ensure((size_t)total * 3 + 4); out.lv2.ensure((size_t)total * 3 + 4);
     out.p1.ensure((size_t)total * 3 + 4);

@@ -261,8 +261,8 @@ uint64_t MatchResult::run_windowed(plade_ctx *ctx, const float *d_qry, uint32_t 
     hipLaunchKernelGGL(k_windows, dim3(cdiv(ng, 256)), dim3(256), 0, ctx->stream, q_sorted.p, dq, wk_b.p, dt, radius, w_lo.p, w_cnt.p,
                        info.p);
     uint32_t h_info[2] = {0, 0};
-    HIP_TRY(hipMemcpyAsync(h_info, info.p, 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->d2h(h_info, info.p, 8);
+    ctx->sync();
     const uint32_t nch = std::max(1u, cdiv(h_info[1], MT_CHUNK));
     const size_t ncnt = (size_t)dq * nch;
     PLADE_REQUIRE(ncnt < (1ull << 31), PLADE_ELIMIT, "match: too many (query, chunk) cells even inside the length windows");
@@ -280,8 +280,8 @@ uint64_t MatchResult::run_windowed(plade_ctx *ctx, const float *d_qry, uint32_t 
     // `cnt` is free again: it receives the final write positions
     hipLaunchKernelGGL(k_win_bases, dim3(cdiv(std::max(ncnt, (size_t)dq + 1), 256)), dim3(256), 0, ctx->stream, offs.p, dq, nch, q_perm.p,
                        row_off.p, cnt.p, offsets.p, info.p);
-    HIP_TRY(hipMemcpyAsync(h_info, info.p, 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->d2h(h_info, info.p, 8);
+    ctx->sync();
     total = h_info[0];
     const uint32_t max_list = h_info[1];
     if (total == 0) return 0;
@@ -342,8 +342,8 @@ uint64_t MatchResult::run(plade_ctx *ctx, const float *d_qry, uint32_t dq, const
     HIP_TRY(hipMemsetAsync(info.p, 0, 8, ctx->stream));
     hipLaunchKernelGGL(k_query_offsets, dim3(cdiv(dq + 1, 256)), dim3(256), 0, ctx->stream, offs.p, dq, nch, offsets.p, info.p);
     uint32_t h_info[2] = {0, 0};
-    HIP_TRY(hipMemcpyAsync(h_info, info.p, 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->d2h(h_info, info.p, 8);
+    ctx->sync();
     const uint32_t tot32 = h_info[0], max_list = h_info[1];
     total = tot32;
     if (total == 0) return 0;
@@ -391,11 +391,11 @@ extern "C" int plade_match_descriptors(plade_ctx *ctx, const float *src, uint32_
         MatchResult r;
         uint64_t total = r.run(ctx, d_q.p, ds, d_t.p, dt, radius);
         *n_pairs = total;
-        HIP_TRY(hipMemcpyAsync(offsets, r.offsets.p, ((size_t)ds + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+        ctx->d2h(offsets, r.offsets.p, ((size_t)ds + 1) * 8);
         uint64_t w = total < cap ? total : cap;
-        if (w && t_idx) HIP_TRY(hipMemcpyAsync(t_idx, r.t_idx.p, w * 4, hipMemcpyDeviceToHost, ctx->stream));
-        if (w && dist2) HIP_TRY(hipMemcpyAsync(dist2, r.dist2.p, w * 8, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (w && t_idx) ctx->d2h(t_idx, r.t_idx.p, w * 4);
+        if (w && dist2) ctx->d2h(dist2, r.dist2.p, w * 8);
+        ctx->sync();
         return (total > cap && (t_idx || dist2) && cap) ? PLADE_ECAP : PLADE_OK;
     });
 }

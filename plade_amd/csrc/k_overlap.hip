@@ -118,8 +118,8 @@ void TargetGrid::build(plade_ctx *ctx, const float *d_xyz, uint32_t n_pts, uint3
     hipLaunchKernelGGL(k_minmax3, dim3(std::min(cdiv(n, 256), 1024u)), dim3(256), 0, ctx->stream, d_xyz, n, stride,
                        bbox.p);
     int ih[6];
-    HIP_TRY(hipMemcpyAsync(ih, bbox.p, 24, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->d2h(ih, bbox.p, 24);
+    ctx->sync();
     for (int k = 0; k < 6; ++k) {
         int v = ih[k] >= 0 ? ih[k] : ih[k] ^ 0x7fffffff;
         memcpy(&init[k], &v, 4);
@@ -396,9 +396,9 @@ extern "C" int plade_overlap_counts(plade_ctx *ctx, const float *src_ds, uint32_
         overlap_counts(ctx, ow, ow.sorted.p, ow.sorted.p + n_s, ow.sorted.p + 2 * (size_t)n_s, n_s, grid, d_T.p, d_c.p, k, src_radius,
                        inlier_dist, d_counts.p, d_any.p);
         std::vector<uint32_t> any(k);
-        HIP_TRY(hipMemcpyAsync(counts, d_counts.p, (size_t)k * 4, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(hipMemcpyAsync(any.data(), d_any.p, (size_t)k * 4, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        ctx->d2h(counts, d_counts.p, (size_t)k * 4);
+        ctx->d2h(any.data(), d_any.p, (size_t)k * 4);
+        ctx->sync();
         for (uint32_t i = 0; i < k; ++i)
             if (!any[i]) counts[i] = -1;
         return PLADE_OK;

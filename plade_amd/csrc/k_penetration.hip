@@ -189,7 +189,7 @@ void build_pen_grid(plade_ctx *ctx, PlaneCloudsDev &pc, const PlaneGeomHost &geo
     sort_pairs_u32(ctx, pc.ckeys.p, pc.ckeys2.p, pc.cvals.p, pc.cvals2.p, n, bits);
     hipLaunchKernelGGL(k_pen_cell_fill, dim3(cdiv(std::max(n, total + 1), 256)), dim3(256), 0, ctx->stream, pc.xyz.p, pc.ckeys2.p,
                        pc.cvals2.p, n, total, pc.cell_pts.p, pc.cell_start.p);
-    HIP_TRY(hipStreamSynchronize(ctx->stream));   // `fr` must outlive the copy
+    ctx->sync();   // `fr` must outlive the copy
 }
 
 // Cells of one plane grid that can hold a point within `rr` of the segment start + t direc, t in [0, L]
@@ -408,8 +408,8 @@ void penetration_filter(plade_ctx *ctx, const float *cand_rt_host, uint32_t K, c
                        sS, sT, cell, search_radius, 10, min_distance, d_flags, d_over);
     ctx->ev_end();
     std::vector<uint32_t> out(n_ctr);   // items, overflow, K candidate flags, per-pair item counts
-    HIP_TRY(hipMemcpyAsync(out.data(), d_ctr, n_ctr * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->d2h(out.data(), d_ctr, n_ctr * 4);
+    ctx->sync();
     HIP_TRY(hipGetLastError());
     double items = 0;
     for (uint32_t pr = 0; pr < n_pairs; ++pr) items += out[(size_t)K + 2 + pr];

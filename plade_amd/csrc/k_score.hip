@@ -410,8 +410,8 @@ extern "C" int plade_score_planes(plade_ctx *ctx, const float *pos_nrm, const in
         d_counts.ensure(h + 1);
         score_multi(ctx, cloud.x(), cloud.y(), cloud.z(), cloud.nx(), cloud.ny(), cloud.nz(),
                     shape_index ? d_assigned.p : nullptr, nullptr, n, d_planes.p, h, eps, cos_thresh, d_counts.p);
-        HIP_TRY(hipMemcpyAsync(counts, d_counts.p, (size_t)h * 4, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        ctx->d2h(counts, d_counts.p, (size_t)h * 4);
+        ctx->sync();
         if (idx_out && cap) {
             CompactScratch cs;
             DBuf<uint32_t> d_idx, d_cnt;
@@ -422,8 +422,8 @@ extern "C" int plade_score_planes(plade_ctx *ctx, const float *pos_nrm, const in
                               shape_index ? d_assigned.p : nullptr, n, d_planes.p + j, eps, cos_thresh, d_idx.p,
                               d_cnt.p);
                 uint32_t c = 0;
-                HIP_TRY(hipMemcpyAsync(&c, d_cnt.p, 4, hipMemcpyDeviceToHost, ctx->stream));
-                HIP_TRY(hipStreamSynchronize(ctx->stream));
+                ctx->d2h(&c, d_cnt.p, 4);
+                ctx->sync();
                 PLADE_REQUIRE(c == counts[j], PLADE_EDEVICE, "plade_score_planes: count/compaction disagreement");
                 uint32_t w = c < cap ? c : cap;
                 if (w) HIP_TRY(hipMemcpy(idx_out + (size_t)j * cap, d_idx.p, (size_t)w * 4, hipMemcpyDeviceToHost));

@@ -124,8 +124,8 @@ uint32_t VoxelWork::run(plade_ctx *ctx, const float *d_xyz, uint32_t stride, con
     HIP_TRY(hipMemsetAsync(flags.p + n_items, 0, 4, ctx->stream));
     exclusive_scan_u32(ctx, flags.p, seg.p, (size_t)n_items + 1);
     uint32_t n_seg = 0;
-    HIP_TRY(hipMemcpyAsync(&n_seg, seg.p + n_items, 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->d2h(&n_seg, seg.p + n_items, 4);
+    ctx->sync();
     heads.ensure((size_t)n_seg + 1);
     hipLaunchKernelGGL(k_heads, dim3(nb), dim3(256), 0, ctx->stream, flags.p, seg.p, n_items, heads.p);
     out_xyz.ensure((size_t)n_seg * 3 + 4);
@@ -139,7 +139,7 @@ uint32_t VoxelWork::run(plade_ctx *ctx, const float *d_xyz, uint32_t stride, con
                        group_offsets.p);
     hipLaunchKernelGGL(k_fix_offsets, dim3(1), dim3(1), 0, ctx->stream, group_offsets.p, n_groups, n_seg);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(ctx->stream));  // `init` must outlive the async copy
+    ctx->sync();  // `init` must outlive the async copy
     n_out = n_seg;
     return n_seg;
 }
@@ -223,12 +223,26 @@ __global__ __launch_bounds__(256) void k_knn_grid(const float4 *__restrict__ pts
 
 // occupancy of a grid from its sorted cell keys: flag[0] = some cell holds more than `run` points,
 // flag[1] = number of occupied cells
-__global__ void k_grid_occupancy(const uint32_t *__restrict__ keys, uint32_t n, uint32_t run, uint32_t *__restrict__ flag) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i + run < n && keys[i] == keys[i + run]) flag[0] = 1u;
-    const bool head = i < n && (i == 0 || keys[i] != keys[i - 1]);
-    const uint32_t c = (uint32_t)__popcll(__ballot(head));
-    if ((threadIdx.x & 63) == 0 && c) atomicAdd(&flag[1], c);
+__global__ __launch_bounds__(256) void k_grid_occupancy(const uint32_t *__restrict__ keys, uint32_t n, uint32_t run,
+                                                        uint32_t *__restrict__ flag) {
+    // grid-stride with per-thread counts and ONE atomic per workgroup: thousands of atomics on one address
+    // serialise at the memory side (this kernel took 180 us at 1M keys with one atomic per wavefront)
+    __shared__ uint32_t s_c[4];
+    uint32_t c = 0;
+    bool dense = false;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t k = keys[i];
+        if (i + run < n && k == keys[i + run]) dense = true;
+        c += (i == 0 || k != keys[i - 1]) ? 1u : 0u;
+    }
+    for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d, 64);
+    if (__ballot(dense) && (threadIdx.x & 63) == 0) flag[0] = 1u;
+    if ((threadIdx.x & 63) == 0) s_c[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t t = s_c[0] + s_c[1] + s_c[2] + s_c[3];
+        if (t) atomicAdd(&flag[1], t);
+    }
 }
 
 float average_spacing_dev(plade_ctx *ctx, const float *d_aos, uint32_t stride_f, uint32_t n, const float *bbmin,
@@ -254,10 +268,10 @@ float average_spacing_dev(plade_ctx *ctx, const float *d_aos, uint32_t stride_f,
         if (n <= 256) break;
         uint32_t *d_flag = reinterpret_cast<uint32_t *>(ctx->scratch[2].ensure(64));
         HIP_TRY(hipMemsetAsync(d_flag, 0, 8, ctx->stream));
-        hipLaunchKernelGGL(k_grid_occupancy, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, grid.keys2.p, n, 256u, d_flag);
+        hipLaunchKernelGGL(k_grid_occupancy, dim3(std::min(cdiv(n, 1024), 512u)), dim3(256), 0, ctx->stream, grid.keys2.p, n, 256u, d_flag);
         uint32_t occ[2] = {0, 0};
-        HIP_TRY(hipMemcpyAsync(occ, d_flag, 8, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        ctx->d2h(occ, d_flag, 8);
+        ctx->sync();
         const float built = 1.f / grid.gp.inv;          // build() enlarges the cell when the cell budget is hit
         int dir = 0;
         if (occ[0] && built <= cell * 1.01f) dir = -1;              // too coarse
@@ -276,9 +290,9 @@ float average_spacing_dev(plade_ctx *ctx, const float *d_aos, uint32_t stride_f,
     HIP_TRY(hipGetLastError());
     std::vector<double> avg(nq);
     std::vector<uint32_t> nbs(nq);
-    HIP_TRY(hipMemcpyAsync(avg.data(), d_avg, (size_t)nq * 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(nbs.data(), d_nbs, (size_t)nq * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->d2h(avg.data(), d_avg, (size_t)nq * 8);
+    ctx->d2h(nbs.data(), d_nbs, (size_t)nq * 4);
+    ctx->sync();
     // util.cpp:1630-1647: sequential double accumulation in sample order
     double total = 0.0;
     size_t total_count = 0;
@@ -323,8 +337,8 @@ void bbox_host(plade_ctx *ctx, const float *d_xyz, uint32_t n, uint32_t stride, 
     HIP_TRY(hipMemcpyAsync(d, init, 32, hipMemcpyHostToDevice, ctx->stream));
     if (n) hipLaunchKernelGGL(k_minmax3_v, dim3(std::min(cdiv(n, 1024), 1024u)), dim3(256), 0, ctx->stream, d_xyz, n, stride, d);
     int out[8];
-    HIP_TRY(hipMemcpyAsync(out, d, 32, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->d2h(out, d, 32);
+    ctx->sync();
     // every grid, key and threshold downstream is derived from the coordinates: refuse what the reference's
     // kd-trees and voxel grids could not digest either, instead of looping on a NaN extent
     PLADE_REQUIRE(out[6] == 0, PLADE_EINVAL, "the point cloud contains non-finite coordinates (NaN or infinity)");
@@ -370,8 +384,8 @@ extern "C" int plade_voxel_downsample(plade_ctx *ctx, const float *xyz, uint32_t
         bbox_host(ctx, d_in.p, n, stride, mn, mx);
         VoxelWork w;
         uint32_t m = w.run(ctx, d_in.p, stride, nullptr, nullptr, n, 1, leaf, mn, mx);
-        HIP_TRY(hipMemcpyAsync(out_xyz, w.out_xyz.p, (size_t)m * 12, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        ctx->d2h(out_xyz, w.out_xyz.p, (size_t)m * 12);
+        ctx->sync();
         *n_out = m;
         return PLADE_OK;
     });

@@ -103,7 +103,7 @@ bool prepare_side(plade_ctx *ctx, const char *tag, const CloudDev &cloud, const 
     S.ds.resize(3 * (size_t)S.n_ds);
     S.d_ds_soa.ensure(3 * (size_t)S.n_ds + 4);
     S.d_ds.swap(S.vox_all.out_xyz);   // the result becomes d_ds, the work area takes last call's buffer back
-    HIP_TRY(hipMemcpyAsync(S.ds.data(), S.d_ds.p, 12 * (size_t)S.n_ds, hipMemcpyDeviceToHost, ctx->stream));
+    ctx->d2h(S.ds.data(), S.d_ds.p, 12 * (size_t)S.n_ds);
     deinterleave3(ctx, S.d_ds.p, S.n_ds, S.d_ds_soa.p, S.d_ds_soa.p + S.n_ds, S.d_ds_soa.p + 2 * (size_t)S.n_ds);
     // per-plane clouds in one pass (plade.cpp:93-105 / :308-319)
     const uint32_t n_items = (uint32_t)pl.offsets[P];
@@ -120,9 +120,9 @@ bool prepare_side(plade_ctx *ctx, const char *tag, const CloudDev &cloud, const 
     S.pcl.off.resize((size_t)P + 1);
     S.pcl.xyz.swap(S.vox_planes.out_xyz);
     S.pcl.d_off.swap(S.vox_planes.group_offsets);
-    HIP_TRY(hipMemcpyAsync(S.plane_ds.data(), S.pcl.xyz.p, 12 * (size_t)n_pds, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(S.pcl.off.data(), S.pcl.d_off.p, 4 * ((size_t)P + 1), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->d2h(S.plane_ds.data(), S.pcl.xyz.p, 12 * (size_t)n_pds);
+    ctx->d2h(S.pcl.off.data(), S.pcl.d_off.p, 4 * ((size_t)P + 1));
+    ctx->sync();
     ctx->stats.add(std::string("t_prep_voxel_") + tag, secs_since(tp0));
     tp0 = Clock::now();
     // ComputeBoundingBox of the whole downsampled cloud (plade.cpp:81-84 / :295-299)
@@ -162,7 +162,7 @@ bool prepare_side(plade_ctx *ctx, const char *tag, const CloudDev &cloud, const 
     build_pair_table(ctx, S.lines, S.normals.data(), P, desc_scale, is_target, pairs);
     // everything this side produced is consumed on the OTHER stream (match, transforms, penetration run on the
     // main stream, the source side is prepared on the auxiliary one): finish it before handing over
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->sync();
     ctx->stats.add(std::string("t_prep_lines_") + tag, secs_since(tp0));
     if (ctx->params.dump) {
         const std::string t(tag);
@@ -297,8 +297,8 @@ bool run_registration(plade_ctx *ctx, RegistrationWork &W, const CloudDev &tgt, 
         if (ctx->params.dump && n_match) {
             std::vector<float4> h(4 * (size_t)n_match);
             // on the context's (non-blocking) stream: a null-stream copy would not wait for build_transforms
-            HIP_TRY(hipMemcpyAsync(h.data(), W.cand.rt.p, 64 * (size_t)n_match, hipMemcpyDeviceToHost, ctx->stream));
-            HIP_TRY(hipStreamSynchronize(ctx->stream));
+            ctx->d2h(h.data(), W.cand.rt.p, 64 * (size_t)n_match);
+            ctx->sync();
             std::vector<float> rt(12 * (size_t)n_match);
             for (size_t i = 0; i < n_match; ++i) {
                 for (int r = 0; r < 3; ++r) {
@@ -329,21 +329,21 @@ bool run_registration(plade_ctx *ctx, RegistrationWork &W, const CloudDev &tgt, 
         StageTimer t(ctx, "t_plane_consistency");
         seeds.resize(nC); sizes.resize(nC); pcounts.resize(nC);
         if (nC) {
-            HIP_TRY(hipMemcpyAsync(sizes.data(), W.cand.sizes.p, 4 * (size_t)nC, hipMemcpyDeviceToHost, ctx->stream));
-            HIP_TRY(hipStreamSynchronize(ctx->stream));
+            ctx->d2h(sizes.data(), W.cand.sizes.p, 4 * (size_t)nC);
+            ctx->sync();
         }
         const float sbc[3] = {C.bcenter.x, C.bcenter.y, C.bcenter.z}, tbc[3] = {M.bcenter.x, M.bcenter.y, M.bcenter.z};
         plane_consistency(ctx, W.cand, C.geom, M.geom, sbc, tbc, (float)M.radius, (float)(double)cosAngleThreshold,
                           lengthThreshold);
         if (nC) {
-            HIP_TRY(hipMemcpyAsync(seeds.data(), W.cand.seeds.p, 4 * (size_t)nC, hipMemcpyDeviceToHost, ctx->stream));
-            HIP_TRY(hipMemcpyAsync(pcounts.data(), W.cand.plane_counts.p, 4 * (size_t)nC, hipMemcpyDeviceToHost, ctx->stream));
+            ctx->d2h(seeds.data(), W.cand.seeds.p, 4 * (size_t)nC);
+            ctx->d2h(pcounts.data(), W.cand.plane_counts.p, 4 * (size_t)nC);
         }
         std::vector<LengthIndex> sortVec(nC);
         for (uint32_t i = 0; i < nC; ++i) { sortVec[i].index = (int)i; sortVec[i].length = (float)sizes[i]; }
         // same comparisons as cmp_greater, as an inlinable functor: std::sort's result is identical
         std::sort(sortVec.begin(), sortVec.end(), [](const LengthIndex &a, const LengthIndex &b) { return a.length > b.length; });
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        ctx->sync();
         cand_cluster.reserve(nC);
         match_counts.reserve(nC);
         for (uint32_t i = 0; i < nC; ++i) {
@@ -397,8 +397,8 @@ bool run_registration(plade_ctx *ctx, RegistrationWork &W, const CloudDev &tgt, 
         W.d_rt12.ensure(12 * (size_t)K);
         HIP_TRY(hipMemcpyAsync(W.d_ids.p, ids.data(), 4 * (size_t)K, hipMemcpyHostToDevice, ctx->stream));
         hipLaunchKernelGGL(k_gather_rt, dim3(cdiv(K, 64)), dim3(64), 0, ctx->stream, W.cand.rt.p, W.d_ids.p, K, W.d_rt12.p);
-        HIP_TRY(hipMemcpyAsync(rt12.data(), W.d_rt12.p, 48 * (size_t)K, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        ctx->d2h(rt12.data(), W.d_rt12.p, 48 * (size_t)K);
+        ctx->sync();
     }
     std::vector<int32_t> penflags;
     {
@@ -435,9 +435,9 @@ bool run_registration(plade_ctx *ctx, RegistrationWork &W, const CloudDev &tgt, 
                        W.grid, W.d_T16.p,
                        W.d_centers.p, Kv, (float)C.radius, downSampleDistance, W.d_counts.p, W.d_any.p);
         std::vector<uint32_t> any(Kv);
-        HIP_TRY(hipMemcpyAsync(counts.data(), W.d_counts.p, 4 * (size_t)Kv, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(hipMemcpyAsync(any.data(), W.d_any.p, 4 * (size_t)Kv, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        ctx->d2h(counts.data(), W.d_counts.p, 4 * (size_t)Kv);
+        ctx->d2h(any.data(), W.d_any.p, 4 * (size_t)Kv);
+        ctx->sync();
         for (uint32_t i = 0; i < Kv; ++i) if (!any[i]) counts[i] = -1;
     }
     std::vector<LengthIndex> ov(Kv);

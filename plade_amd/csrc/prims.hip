@@ -22,14 +22,20 @@ static void sort_pairs(plade_ctx *ctx, const K *ki, K *ko, const uint32_t *vi, u
     HIP_TRY(rocprim::radix_sort_pairs<SortConfig>(t, tb, ki, ko, vi, vo, (unsigned int)n, 0u, (unsigned int)bits, ctx->stream));
 }
 
+// below this size rocPRIM's single-launch block / merge sort is the cheaper choice
+constexpr size_t RS_MIN_ITEMS = 16384;
+static bool use_rocprim() { static const bool v = getenv("PLADE_SORT_ROCPRIM") != nullptr; return v; }
+
 void sort_pairs_u32(plade_ctx *ctx, const uint32_t *ki, uint32_t *ko, const uint32_t *vi, uint32_t *vo, size_t n,
                     int bits) {
-    sort_pairs<uint32_t>(ctx, ki, ko, vi, vo, n, bits);
+    if (n > RS_MIN_ITEMS && !use_rocprim()) radix_sort_pairs_u32(ctx, ki, ko, vi, vo, n, bits);
+    else sort_pairs<uint32_t>(ctx, ki, ko, vi, vo, n, bits);
 }
 
 void sort_pairs_u64(plade_ctx *ctx, const uint64_t *ki, uint64_t *ko, const uint32_t *vi, uint32_t *vo, size_t n,
                     int bits) {
-    sort_pairs<uint64_t>(ctx, ki, ko, vi, vo, n, bits);
+    if (n > RS_MIN_ITEMS && !use_rocprim()) radix_sort_pairs_u64(ctx, ki, ko, vi, vo, n, bits);
+    else sort_pairs<uint64_t>(ctx, ki, ko, vi, vo, n, bits);
 }
 
 void exclusive_scan_u32(plade_ctx *ctx, const uint32_t *in, uint32_t *out, size_t n) {

@@ -1,0 +1,229 @@
+// plade_amd/csrc/radix_sort.hip -- stable LSD radix sort of (key, u32 value) pairs for gfx950, one launch per
+// 8-bit digit plus one histogram launch and NO memsets.
+//
+// Every grid of the path (Morton order, the four voxel grids, the verification / penetration / clustering grids)
+// is built by sorting ~1M packed cell keys whose significant bit count is known.  rocPRIM's onesweep sort costs
+// 12-15 stream commands for such a sort (a fill of the histogram, a fill of the look-back states and a fill of the
+// tile counter per digit, the histogram, its scan, the passes); with ~14 sorts per registration that was a fifth of
+// the GPU time of a registration and an eighth of its commands.  Here:
+//   k_rs_histogram  128 workgroups count all digits of all passes into per-workgroup partial histograms (plain
+//                   stores, so nothing has to be zeroed beforehand) and clear the look-back states and tile
+//                   counters of every pass;
+//   k_rs_pass       "onesweep": a workgroup takes the next tile (atomic ticket, so every predecessor is already
+//                   running), ranks its 4096 keys by digit (wave-level match via 8 ballots per key: stable),
+//                   publishes its digit counts, resolves its exclusive prefix by decoupled look-back over the
+//                   predecessors' states, stages the tile in LDS in digit order and writes runs of equal digits to
+//                   their final place.
+// Algorithmic traffic per pass: read n x (sizeof(K) + 4) B, write the same.
+#include "prims.h"
+
+namespace plade {
+
+namespace {
+
+constexpr int RS_THREADS = 512;
+constexpr int RS_WAVES = RS_THREADS / 64;
+constexpr int RS_IPT = 16;                       // keys per thread
+constexpr int RS_TILE = RS_THREADS * RS_IPT;     // 8192 keys per tile
+constexpr int RS_HBLOCKS = 128;                  // histogram workgroups (= partial histograms per digit place)
+constexpr int RS_MAXP = 8;
+constexpr int RS_LOOK = 8;                      // predecessors fetched per look-back round
+constexpr uint32_t RS_AGG = 1u << 30, RS_PREFIX = 2u << 30, RS_VALUE = (1u << 30) - 1;
+
+template <class K>
+__device__ __forceinline__ uint32_t digit_of(K key, int shift) { return (uint32_t)(key >> shift) & 255u; }
+
+// part[b][p][d]: keys of digit d at place p seen by workgroup b
+template <class K>
+__global__ __launch_bounds__(RS_THREADS) void k_rs_histogram(const K *__restrict__ keys, uint32_t n, int passes,
+                                                             uint32_t *__restrict__ part, uint32_t *__restrict__ tile_ctr,
+                                                             uint32_t *__restrict__ look, size_t look_words) {
+    __shared__ uint32_t s_h[RS_MAXP * 256];
+    for (int i = threadIdx.x; i < passes * 256; i += RS_THREADS) s_h[i] = 0;
+    // clear what the passes will use
+    for (size_t i = (size_t)blockIdx.x * RS_THREADS + threadIdx.x; i < look_words; i += (size_t)RS_HBLOCKS * RS_THREADS) look[i] = 0;
+    if (blockIdx.x == 0 && threadIdx.x < RS_MAXP) tile_ctr[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t per = (n + RS_HBLOCKS - 1) / RS_HBLOCKS;
+    const uint32_t b0 = blockIdx.x * per, b1 = min(n, b0 + per);
+    // 8 independent loads per round: a one-load-per-iteration loop is bound by the load latency (39 us at 1M keys)
+    for (uint32_t i0 = b0; i0 < b1; i0 += 8 * RS_THREADS) {
+        K k[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t i = i0 + j * RS_THREADS + threadIdx.x;
+            k[j] = i < b1 ? keys[i] : (K)0;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (i0 + j * RS_THREADS + threadIdx.x < b1)
+                for (int p = 0; p < passes; ++p) atomicAdd(&s_h[p * 256 + digit_of(k[j], 8 * p)], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < passes * 256; i += RS_THREADS) part[(size_t)blockIdx.x * (RS_MAXP * 256) + i] = s_h[i];
+}
+
+template <class K>
+__global__ __launch_bounds__(RS_THREADS) void k_rs_pass(const K *__restrict__ kin, K *__restrict__ kout,
+                                                        const uint32_t *__restrict__ vin, uint32_t *__restrict__ vout,
+                                                        uint32_t n, int pass, const uint32_t *__restrict__ part,
+                                                        uint32_t *__restrict__ tile_ctr, uint32_t *__restrict__ look) {
+    __shared__ K s_keys[RS_TILE];
+    __shared__ uint32_t s_vals[RS_TILE];
+    __shared__ uint32_t s_cnt[RS_WAVES][256];   // per wave: digit counters, then exclusive offsets inside the digit
+    __shared__ uint32_t s_start[256];           // first tile-local position of digit d
+    __shared__ uint32_t s_dest[256];            // global position of the tile's first key of digit d
+    __shared__ uint32_t s_tile;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int shift = 8 * pass;
+    if (tid == 0) s_tile = atomicAdd(&tile_ctr[pass], 1u);
+    for (int i = tid; i < RS_WAVES * 256; i += RS_THREADS) (&s_cnt[0][0])[i] = 0;
+    // threads 0..255 own one digit each.  Keys of that digit in the whole array = sum of the histogram partials
+    // (independent of the tile: issued first, the latency hides behind the ticket and the key loads)
+    const bool owner = tid < 256;
+    uint32_t total = 0;
+    if (owner)
+        for (int b = 0; b < RS_HBLOCKS; ++b) total += part[(size_t)b * (RS_MAXP * 256) + pass * 256 + tid];
+    __syncthreads();
+    const uint32_t tile = s_tile;
+    const uint32_t base = tile * RS_TILE + wave * (64 * RS_IPT);   // this wave's 1024 consecutive keys
+
+    // ---- load + stable rank inside the wave ------------------------------------------------------
+    K key[RS_IPT];
+    uint32_t val[RS_IPT], rank[RS_IPT];
+#pragma unroll
+    for (int r = 0; r < RS_IPT; ++r) {
+        const uint32_t i = base + r * 64 + lane;
+        const bool ok = i < n;
+        key[r] = ok ? kin[i] : (K)0;
+        val[r] = ok ? vin[i] : 0u;
+    }
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    volatile uint32_t *cnt = s_cnt[wave];
+#pragma unroll
+    for (int r = 0; r < RS_IPT; ++r) {
+        const bool ok = base + r * 64 + lane < n;
+        const uint32_t d = digit_of(key[r], shift);
+        unsigned long long peers = __ballot(ok);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const unsigned long long m = __ballot((d >> b) & 1u);
+            peers &= ((d >> b) & 1u) ? m : ~m;
+        }
+        // all lanes of a digit group read the counter, then its first lane advances it (one wave = in order)
+        const uint32_t c = ok ? cnt[d] : 0u;
+        rank[r] = c + (uint32_t)__popcll(peers & lt);
+        if (ok && (peers & lt) == 0ull) cnt[d] = c + (uint32_t)__popcll(peers);
+    }
+    __syncthreads();
+
+    // ---- per digit (thread d): wave offsets, tile count, global base, look-back -----------------------------
+    const uint32_t d = tid & 255;
+    uint32_t tile_count = 0;
+    if (owner)
+        for (int w = 0; w < RS_WAVES; ++w) { const uint32_t c = s_cnt[w][d]; s_cnt[w][d] = tile_count; tile_count += c; }
+    uint32_t *my_look = look + (size_t)tile * 256 + d;
+    if (owner) __hip_atomic_store(my_look, (tile == 0 ? RS_PREFIX : RS_AGG) | tile_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // block-wide exclusive scans of `total` (global) and `tile_count` (tile-local) over the 256 digits
+    uint32_t inc_g = total, inc_t = tile_count;
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t a = __shfl_up(inc_g, o, 64), b = __shfl_up(inc_t, o, 64);
+        if (lane >= o) { inc_g += a; inc_t += b; }
+    }
+    __shared__ uint32_t s_wg[4], s_wt[4];
+    if (owner && lane == 63) { s_wg[wave] = inc_g; s_wt[wave] = inc_t; }
+    __syncthreads();
+    if (owner) {
+        uint32_t off_g = 0, off_t = 0;
+        for (int w = 0; w < wave; ++w) { off_g += s_wg[w]; off_t += s_wt[w]; }
+        const uint32_t gbase = off_g + inc_g - total;       // exclusive: keys with a smaller digit in the whole array
+        const uint32_t tstart = off_t + inc_t - tile_count; // exclusive
+        // decoupled look-back: exclusive prefix of this digit over the preceding tiles.  Agent-scope loads go past
+        // the per-XCD L2; a window of RS_LOOK predecessors is fetched at once so the walk pays that latency once per
+        // window (wider windows re-read too many rows while every tile is still publishing: slower)
+        uint32_t excl = 0;
+        if (tile > 0) {
+            int t = (int)tile - 1;
+            bool done = false;
+            while (!done) {
+                uint32_t st[RS_LOOK];
+#pragma unroll
+                for (int j = 0; j < RS_LOOK; ++j)
+                    st[j] = (t - j >= 0) ? __hip_atomic_load(look + (size_t)(t - j) * 256 + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : RS_PREFIX;
+                int j = 0;
+#pragma unroll
+                for (; j < RS_LOOK; ++j) {
+                    if ((st[j] & ~RS_VALUE) == 0u) break;          // not published yet: poll again from here
+                    excl += st[j] & RS_VALUE;
+                    if (st[j] & RS_PREFIX) { done = true; break; }
+                }
+                t -= j;
+            }
+            __hip_atomic_store(my_look, RS_PREFIX | (excl + tile_count), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        s_start[d] = tstart;
+        s_dest[d] = gbase + excl;
+    }
+    __syncthreads();
+
+    // ---- stage the tile in digit order, then write runs ------------------------------------------------------
+#pragma unroll
+    for (int r = 0; r < RS_IPT; ++r) {
+        if (base + r * 64 + lane < n) {
+            const uint32_t dg = digit_of(key[r], shift);
+            const uint32_t pos = s_start[dg] + s_cnt[wave][dg] + rank[r];
+            s_keys[pos] = key[r];
+            s_vals[pos] = val[r];
+        }
+    }
+    __syncthreads();
+    const uint32_t in_tile = min((uint32_t)RS_TILE, n - tile * RS_TILE);
+    for (uint32_t pos = tid; pos < in_tile; pos += RS_THREADS) {
+        const K k = s_keys[pos];
+        const uint32_t dg = digit_of(k, shift);
+        const uint32_t out = s_dest[dg] + (pos - s_start[dg]);
+        kout[out] = k;
+        vout[out] = s_vals[pos];
+    }
+}
+
+template <class K>
+void radix_sort_impl(plade_ctx *ctx, const K *ki, K *ko, const uint32_t *vi, uint32_t *vo, size_t n, int bits) {
+    PLADE_REQUIRE(n < (1ull << 30), PLADE_ELIMIT, "sort: too many items");
+    const int passes = std::max(1, (bits + 7) / 8);
+    PLADE_REQUIRE(passes <= RS_MAXP && passes * 8 <= (int)sizeof(K) * 8, PLADE_EINVAL, "sort: bit range");
+    const uint32_t tiles = cdiv(n, RS_TILE);
+    const size_t part_words = (size_t)RS_HBLOCKS * RS_MAXP * 256, look_words = (size_t)passes * tiles * 256;
+    // scratch: partial histograms | tile counters | look-back states | key ping buffer | value ping buffer
+    const size_t off_ctr = part_words, off_look = off_ctr + 64, off_keys = (off_look + look_words + 3) & ~(size_t)3;
+    const size_t key_words = (n * sizeof(K) + 3) / 4, off_vals = (off_keys + key_words + 3) & ~(size_t)3;
+    uint32_t *t = reinterpret_cast<uint32_t *>(ctx->scratch[7].ensure((off_vals + n + 64) * 4 + 256));
+    K *tk = reinterpret_cast<K *>(t + off_keys);
+    uint32_t *tv = t + off_vals;
+    hipStream_t st = ctx->stream;
+    hipLaunchKernelGGL(k_rs_histogram<K>, dim3(RS_HBLOCKS), dim3(RS_THREADS), 0, st, ki, (uint32_t)n, passes, t, t + off_ctr,
+                       t + off_look, look_words);
+    const K *src_k = ki;
+    const uint32_t *src_v = vi;
+    for (int p = 0; p < passes; ++p) {
+        const bool to_out = ((passes - 1 - p) & 1) == 0;    // the last pass lands in the caller's output
+        K *dst_k = to_out ? ko : tk;
+        uint32_t *dst_v = to_out ? vo : tv;
+        hipLaunchKernelGGL(k_rs_pass<K>, dim3(tiles), dim3(RS_THREADS), 0, st, src_k, dst_k, src_v, dst_v, (uint32_t)n, p, t,
+                           t + off_ctr, t + off_look + (size_t)p * tiles * 256);
+        src_k = dst_k;
+        src_v = dst_v;
+    }
+    HIP_TRY(hipGetLastError());
+}
+
+}  // namespace
+
+void radix_sort_pairs_u32(plade_ctx *ctx, const uint32_t *ki, uint32_t *ko, const uint32_t *vi, uint32_t *vo, size_t n, int bits) {
+    radix_sort_impl<uint32_t>(ctx, ki, ko, vi, vo, n, bits);
+}
+void radix_sort_pairs_u64(plade_ctx *ctx, const uint64_t *ki, uint64_t *ko, const uint32_t *vi, uint32_t *vo, size_t n, int bits) {
+    radix_sort_impl<uint64_t>(ctx, ki, ko, vi, vo, n, bits);
+}
+
+}  // namespace plade

@@ -809,7 +809,7 @@ void chains_prepare(plade_ctx *ctx, RansacWork &W, uint32_t B, uint32_t n, float
         HIP_TRY(hipMemcpyAsync(W.chain_tab.p, tab.data(), B * sizeof(ChainDev), hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(hipMemcpyAsync(W.mark_jobs.p, mj.data(), mj.size() * sizeof(MarkJob), hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(hipMemcpyAsync(W.compact_jobs.p, cj.data(), cj.size() * sizeof(CompactJob), hipMemcpyHostToDevice, ctx->stream));
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        ctx->sync();
         W.tab_key = key;
         W.drop_graphs();
     }
@@ -920,10 +920,10 @@ void plane_component(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const
     PlaneState hst[2];
     uint32_t nk = 0;
     std::vector<double> ws(FIT_BLOCKS);
-    HIP_TRY(hipMemcpyAsync(hst, D.st, 2 * sizeof(PlaneState), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(&nk, D.cntS, 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(ws.data(), D.part_ws, 8 * FIT_BLOCKS, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    ctx->d2h(hst, D.st, 2 * sizeof(PlaneState));
+    ctx->d2h(&nk, D.cntS, 4);
+    ctx->d2h(ws.data(), D.part_ws, 8 * FIT_BLOCKS);
+    ctx->sync(st);
     HIP_TRY(hipGetLastError());
     out.err = hst[0].err;
     if (out.err) return;
@@ -988,7 +988,7 @@ void ransac_detect(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const R
     if (const char *e = getenv("PLADE_RANSAC_CHAINS")) B = (uint32_t)std::max(1, std::min(16, atoi(e)));
     chains_prepare(ctx, W, B, n, eps3, cos_t, bitmap_eps);
 
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->sync();
     ctx->stats.add("ransac_t_setup", secs_since(t_setup0));
     const int min_level = 1, max_level = 8;
     const float levels = (float)(max_level - min_level + 1);
@@ -1021,8 +1021,8 @@ void ransac_detect(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const R
         hipLaunchKernelGGL(k_count_unassigned, dim3(cdiv(W.n_sub, 256)), dim3(256), 0, ctx->stream, W.assigned.p, W.sub_index.p,
                            W.n_sub, W.misc);
         uint32_t sub_un = 0;
-        HIP_TRY(hipMemcpyAsync(pin, rb, (size_t)H * 36 + 4, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        ctx->d2h(pin, rb, (size_t)H * 36 + 4);
+        ctx->sync();
         memcpy(h_hyp.data(), pin, (size_t)H * 16);
         memcpy(h_pos.data(), pin + (size_t)H * 16, (size_t)H * 16);
         memcpy(h_counts.data(), pin + (size_t)H * 32, (size_t)H * 4);
@@ -1061,8 +1061,8 @@ void ransac_detect(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const R
                         top_counts, true);
             ++n_full_passes;
             std::vector<uint32_t> cnts(np);
-            HIP_TRY(hipMemcpyAsync(cnts.data(), top_counts, np * 4, hipMemcpyDeviceToHost, ctx->stream));
-            HIP_TRY(hipStreamSynchronize(ctx->stream));
+            ctx->d2h(cnts.data(), top_counts, np * 4);
+            ctx->sync();
             t_rescore += secs_since(t_r0);
             for (uint32_t i = 0; i < np; ++i) pool[i].count = cnts[i];
             // candidates that can no longer reach min_support are dropped (RansacShapeDetector.cpp:826-832)
@@ -1085,8 +1085,8 @@ void ransac_detect(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const R
             HIP_TRY(hipMemcpyAsync(W.cand_in.p, h_in.data(), 32 * nc, hipMemcpyHostToDevice, ctx->stream));
             if (hipGraphExec_t g = accept_graph(ctx, W, cv, nc, eps3, cos_t, bitmap_eps)) HIP_TRY(hipGraphLaunch(g, ctx->stream));
             else enqueue_accept(ctx, W, cv, nc, eps3, cos_t, bitmap_eps);
-            HIP_TRY(hipMemcpyAsync(W.pinned_accept.p, W.accept_block.p, nc * ACCEPT_STRIDE, hipMemcpyDeviceToHost, ctx->stream));
-            HIP_TRY(hipStreamSynchronize(ctx->stream));
+            ctx->d2h(W.pinned_accept.p, W.accept_block.p, nc * ACCEPT_STRIDE);
+            ctx->sync();
             HIP_TRY(hipGetLastError());
             n_full_passes += 4 * (uint32_t)batch.size();
             t_accept += secs_since(t_a0);
@@ -1172,9 +1172,9 @@ void ransac_detect(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const R
     out.idx.clear();
     if (rp.host_indices) {
         out.idx.resize(out_off);
-        if (out_off) HIP_TRY(hipMemcpyAsync(out.idx.data(), W.out_idx.p, 4 * (size_t)out_off, hipMemcpyDeviceToHost, ctx->stream));
+        if (out_off) ctx->d2h(out.idx.data(), W.out_idx.p, 4 * (size_t)out_off);
     }
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->sync();
     for (auto &a : accepted) {
         if (!a.support) continue;
         out.coef.insert(out.coef.end(), a.coef, a.coef + 4);

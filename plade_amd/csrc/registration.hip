@@ -2,6 +2,7 @@
 // C ABI: auto-tuned plane extraction (plade.cpp:602-662) + the planes-given pipeline, device-resident
 // cloud handles, and the S1b seam entry point.
 #include "pipeline.h"
+#include "prims.h"
 #include "ransac.h"
 #include <algorithm>
 #include <numeric>
@@ -185,7 +186,7 @@ extern "C" int plade_cloud_upload(plade_ctx *ctx, const float *pos_nrm, uint32_t
         plade_cloud *c = new plade_cloud;
         try {
             cloud_upload(ctx, pos_nrm, n, c->dev);
-            HIP_TRY(hipStreamSynchronize(ctx->stream));
+            ctx->sync();
         } catch (...) { delete c; throw; }
         *out = c;
         return PLADE_OK;
@@ -264,6 +265,28 @@ extern "C" int plade_plane_component(plade_ctx *ctx, const float *pos_nrm, uint3
         if (!out.kept.empty()) memcpy(kept_out, out.kept.data(), 4 * out.kept.size());
         if (fit_out) memcpy(fit_out, out.fit, sizeof(out.fit));
         if (wscore_out) *wscore_out = out.wscore;
+        return PLADE_OK;
+    });
+}
+
+extern "C" int plade_sort_pairs(plade_ctx *ctx, const void *keys, const uint32_t *vals, uint32_t n, int key_bytes, int bits,
+                                void *keys_out, uint32_t *vals_out) {
+    return guarded(ctx, [&]() -> int {
+        PLADE_REQUIRE((key_bytes == 4 || key_bytes == 8) && bits >= 1 && bits <= 8 * key_bytes, PLADE_EINVAL,
+                      "plade_sort_pairs: key_bytes must be 4 or 8 and 1 <= bits <= 8 * key_bytes");
+        PLADE_REQUIRE(!n || (keys && vals && keys_out && vals_out), PLADE_EINVAL, "plade_sort_pairs: null argument");
+        if (!n) return PLADE_OK;
+        HIP_TRY(hipSetDevice(ctx->device));
+        DBuf<char> ki, ko;
+        DBuf<uint32_t> vi, vo;
+        ki.ensure((size_t)n * key_bytes); ko.ensure((size_t)n * key_bytes); vi.ensure(n); vo.ensure(n);
+        HIP_TRY(hipMemcpyAsync(ki.p, keys, (size_t)n * key_bytes, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(vi.p, vals, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+        if (key_bytes == 4) sort_pairs_u32(ctx, (const uint32_t *)ki.p, (uint32_t *)ko.p, vi.p, vo.p, n, bits);
+        else sort_pairs_u64(ctx, (const uint64_t *)ki.p, (uint64_t *)ko.p, vi.p, vo.p, n, bits);
+        ctx->d2h(keys_out, ko.p, (size_t)n * key_bytes);
+        ctx->d2h(vals_out, vo.p, (size_t)n * 4);
+        ctx->sync();
         return PLADE_OK;
     });
 }

@@ -146,3 +146,31 @@ def test_match_windowed_equals_brute_force(oracle, monkeypatch):
     assert len(out["1"][1]) > 4000
     o, n, d = oracle.match_descriptors(q[:300], t, 0.04)
     assert np.array_equal(n, out["1"][1][: len(n)]) and np.array_equal(d, out["1"][2][: len(d)])
+
+
+@pytest.mark.parametrize("dtype,bits", [(np.uint32, 24), (np.uint32, 32), (np.uint32, 9), (np.uint64, 30), (np.uint64, 47),
+                                        (np.uint64, 64)])
+@pytest.mark.parametrize("n", [16385, 100003, 1 << 20, 3000001])
+def test_radix_sort_is_numpy_stable_argsort(ctx, dtype, bits, n):
+    """The hand-written onesweep sort behind every grid (radix_sort.hip) = numpy's stable sort: sorted keys and, through
+    the payload, the input order of equal keys -- for ragged tile counts, few distinct digits, 32 and 64-bit keys."""
+    rng = np.random.default_rng(n + bits)
+    hi = (1 << bits) - 1
+    keys = rng.integers(0, hi, n, dtype=np.uint64, endpoint=True)
+    keys[: n // 3] &= 0xFF            # many duplicates: stability matters, upper digits all equal
+    keys[n // 3: n // 2] = hi         # one value repeated: a single digit bin takes whole tiles
+    keys = keys.astype(dtype)
+    vals = np.arange(n, dtype=np.uint32)
+    ko, vo = ctx.sort_pairs(keys, vals, bits)
+    order = np.argsort(keys, kind="stable")
+    assert np.array_equal(ko, keys[order]) and np.array_equal(vo, order.astype(np.uint32))
+
+
+def test_radix_sort_sorted_reversed_and_constant_inputs(ctx):
+    n = 250000
+    vals = np.arange(n, dtype=np.uint32)
+    for keys in (np.arange(n, dtype=np.uint32), np.arange(n, dtype=np.uint32)[::-1].copy(), np.full(n, 7, np.uint32),
+                 np.zeros(n, np.uint32)):
+        ko, vo = ctx.sort_pairs(keys, vals, 18)
+        order = np.argsort(keys, kind="stable")
+        assert np.array_equal(ko, keys[order]) and np.array_equal(vo, order.astype(np.uint32))
