@@ -114,6 +114,18 @@ def cpu_baseline(n_points, pairs, budget_s=25.0):
     }
 
 
+def _cpu_budget():
+    """CPUs this process may use: the cgroup v2 quota if one is set, else the affinity mask."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, float(quota) / float(period))
+    except Exception:
+        pass
+    return n
+
+
 def _cgroup_throttle():
     """(nr_throttled, throttled_usec) of this container's CPU quota, None where cgroup v2 is not mounted."""
     try:
@@ -130,8 +142,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--points", type=int, default=1000000)
     ap.add_argument("--pairs", type=int, default=2, help="distinct synthetic pairs per rank (cycled)")
-    ap.add_argument("--host-wait", choices=["spin", "sleep"], default="spin",
-                    help="how the host threads wait for the GPU (plade_params.host_wait)")
+    ap.add_argument("--host-wait", choices=["auto", "spin", "sleep"], default="auto",
+                    help="how the host threads wait for the GPU (plade_params.host_wait): spinning waits are ~3 %% faster "
+                         "but keep ~1.7 CPUs busy per registration in flight; auto = spin when this rank's share of the "
+                         "CPUs (cgroup quota / affinity, divided by the ranks on the node) allows it")
     ap.add_argument("--inflight", type=int, default=8,
                     help="registrations in flight per GPU: independent pairs, one plade_ctx + host thread each "
                          "(a single registration is latency-bound and leaves most of the GPU idle)")
@@ -158,6 +172,9 @@ def main():
 
     import threading
     M = max(1, min(args.inflight, args.steps))
+    if args.host_wait == "auto":
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+        args.host_wait = "spin" if _cpu_budget() / max(1, local_world) >= 1.75 * M + 1 else "sleep"
     host_wait = {"spin": 0, "sleep": 1}[args.host_wait]
     ctxs = [plade_amd.Context(local_rank, host_wait=host_wait) for _ in range(M)]
     ctx = ctxs[0]

@@ -109,6 +109,9 @@ int main(int argc, char **argv) {
     };
     if (n_workers == 1) worker(0);
     else {
+        // several pairs in flight: the worker threads poll + sleep instead of spinning on the GPU (plade_params.host_wait),
+        // so that the workers of all GPUs fit the host's CPUs
+        setenv("PLADE_HOST_WAIT", "sleep", 0);
         std::vector<std::thread> th;
         for (int w = 0; w < n_workers; ++w) th.emplace_back(worker, w % n_gpus);
         for (auto &t : th) t.join();

@@ -226,7 +226,7 @@ struct ChainDev {
     uint32_t *bc2;
     const uint32_t *bcA;   // per-tile counts of the score list
     float *bbpart;         // per-tile (u, v) bounding boxes of the score list
-    double *part, *part_ws;
+    double *part;
 };
 
 __device__ __forceinline__ void hcs_axes(const float *n, float *a0, float *a1) {
@@ -458,29 +458,63 @@ __global__ __launch_bounds__(1024) void k_cc_label(const ChainDev *__restrict__ 
     else { for (int p = threadIdx.x; p < npx; p += blockDim.x) g_bmp[p] = 0; }
 }
 
-// mask layout of k_compact: one byte per lane covering 4 consecutive items, block counts per 1024
-__global__ __launch_bounds__(256) void k_cc_select(const ChainDev *__restrict__ chains, int k) {
+// mask layout of k_compact: one byte per lane covering 4 consecutive items, block counts per 1024.
+// The same pass accumulates, over the kept points, the LS-fit moments (12 sums) and Candidate::WeightedScore
+// (ransac/Candidate.cpp:77-87 with weigh(), ScoreComputer.h:10-16) of the slot's plane: one row of FIT_COLS
+// doubles per 1024 list positions, reduced by k_fit_final in a fixed order.
+constexpr int FIT_COLS = 13;
+
+__global__ __launch_bounds__(256) void k_cc_select(CloudView c, const ChainDev *__restrict__ chains, int k, float eps) {
     __shared__ uint32_t s_w[4];
+    __shared__ double s[4][FIT_COLS];
     const ChainDev &C = chains[blockIdx.y];
     const PlaneState *st = C.st + k;
     if (st->converged) return;
     const uint32_t *__restrict__ bidx = C.bidx, *__restrict__ count = C.cntA, *__restrict__ label = C.label;
+    const uint32_t *__restrict__ idx = C.idxA;
     uint8_t *__restrict__ masks = C.masks2;
     uint32_t *__restrict__ block_counts = C.bc2;
     const uint32_t m = *count, best = st->best_root;
+    if (blockIdx.x * 1024u >= m) {   // past the list: no kept points, no partial row (k_fit_final reads ceil(m / 1024) rows)
+        masks[blockIdx.x * 256 + threadIdx.x] = 0;
+        if (threadIdx.x == 0) block_counts[blockIdx.x] = 0;
+        return;
+    }
+    const float n0 = st->n[0], n1 = st->n[1], n2 = st->n[2], dist = st->dist;
     const uint32_t base = blockIdx.x * 1024 + threadIdx.x * 4;
-    uint32_t mk = 0, c = 0;
+    uint32_t mk = 0, cnt = 0;
+    double a[FIT_COLS] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const uint32_t i = base + k;
+    for (int q = 0; q < 4; ++q) {
+        const uint32_t i = base + q;
         const bool in = i < m && best != 0xffffffffu && label[bidx[i]] == best;
-        mk |= (in ? 1u : 0u) << k;
-        c += (uint32_t)__popcll(__ballot(in));
+        mk |= (in ? 1u : 0u) << q;
+        cnt += (uint32_t)__popcll(__ballot(in));
+        if (in) {
+            const uint32_t p = idx[i];
+            const float fx = c.x[p], fy = c.y[p], fz = c.z[p];
+            const double x = fx, y = fy, z = fz;
+            a[0] += x; a[1] += y; a[2] += z;
+            a[3] += x * x; a[4] += x * y; a[5] += x * z; a[6] += y * y; a[7] += y * z; a[8] += z * z;
+            a[9] += c.nx[p]; a[10] += c.ny[p]; a[11] += c.nz[p];
+            float d = n0 * fx;
+            d += n1 * fy;
+            d += n2 * fz;
+            d = fabsf(dist - d);
+            a[12] += (double)expf(-d * d / (2.f / 9.f * eps * eps));
+        }
     }
     masks[blockIdx.x * 256 + threadIdx.x] = (uint8_t)mk;
-    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = c;
+    for (int q = 0; q < FIT_COLS; ++q)
+        for (int d = 32; d >= 1; d >>= 1) a[q] += __shfl_xor(a[q], d, 64);
+    if ((threadIdx.x & 63) == 0) {
+        s_w[threadIdx.x >> 6] = cnt;
+        for (int q = 0; q < FIT_COLS; ++q) s[threadIdx.x >> 6][q] = a[q];
+    }
     __syncthreads();
     if (threadIdx.x == 0) block_counts[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+    if (threadIdx.x < FIT_COLS)
+        C.part[(size_t)blockIdx.x * FIT_COLS + threadIdx.x] = (s[0][threadIdx.x] + s[1][threadIdx.x]) + (s[2][threadIdx.x] + s[3][threadIdx.x]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -488,42 +522,6 @@ __global__ __launch_bounds__(256) void k_cc_select(const ChainDev *__restrict__ 
 // Plane.h:65-74: mean + covariance about the mean + smallest-|eigenvalue| eigenvector).
 // Accumulated in fp64 with a fixed reduction tree (deterministic); the reference accumulates in
 // fp32 sequentially, which is the noisier of the two.
-constexpr int FIT_BLOCKS = 64;
-
-// One pass over slot k's result list: the LS-fit moments (12 sums) and Candidate::WeightedScore
-// (ransac/Candidate.cpp:77-87 with weigh(), ScoreComputer.h:10-16) of the slot's plane.
-__global__ __launch_bounds__(256) void k_fit_partial(CloudView c, const ChainDev *__restrict__ chains, int k, float eps) {
-    __shared__ double s[4][13];
-    const ChainDev &C = chains[blockIdx.y];
-    const PlaneState *st = C.st + k;
-    if (st->converged) return;
-    const uint32_t *__restrict__ idx = C.idxS[k], *__restrict__ count = C.cntS + k;
-    double *__restrict__ part = C.part;   // FIT_BLOCKS x 12
-    double *__restrict__ part_ws = C.part_ws + (size_t)k * FIT_BLOCKS;
-    const uint32_t m = *count;
-    const float n0 = st->n[0], n1 = st->n[1], n2 = st->n[2], dist = st->dist;
-    double a[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
-        const uint32_t p = idx[i];
-        const float fx = c.x[p], fy = c.y[p], fz = c.z[p];
-        const double x = fx, y = fy, z = fz;
-        a[0] += x; a[1] += y; a[2] += z;
-        a[3] += x * x; a[4] += x * y; a[5] += x * z; a[6] += y * y; a[7] += y * z; a[8] += z * z;
-        a[9] += c.nx[p]; a[10] += c.ny[p]; a[11] += c.nz[p];
-        float d = n0 * fx;
-        d += n1 * fy;
-        d += n2 * fz;
-        d = fabsf(dist - d);
-        a[12] += (double)expf(-d * d / (2.f / 9.f * eps * eps));
-    }
-    for (int q = 0; q < 13; ++q)
-        for (int d = 32; d >= 1; d >>= 1) a[q] += __shfl_xor(a[q], d, 64);
-    if ((threadIdx.x & 63) == 0) for (int q = 0; q < 13; ++q) s[threadIdx.x >> 6][q] = a[q];
-    __syncthreads();
-    if (threadIdx.x < 12) part[blockIdx.x * 12 + threadIdx.x] = (s[0][threadIdx.x] + s[1][threadIdx.x]) + (s[2][threadIdx.x] + s[3][threadIdx.x]);
-    if (threadIdx.x == 12) part_ws[blockIdx.x] = (s[0][12] + s[1][12]) + (s[2][12] + s[3][12]);
-}
-
 __device__ void jacobi3_d(double a[3][3], double d[3], double v[3][3]) {
     for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) v[i][j] = i == j;
     const double scale = fabs(a[0][0]) + fabs(a[1][1]) + fabs(a[2][2]);
@@ -544,31 +542,22 @@ __device__ void jacobi3_d(double a[3][3], double d[3], double v[3][3]) {
     for (int i = 0; i < 3; ++i) d[i] = a[i][i];
 }
 
-// sums the weighted-score partials of all four slots (one wave per slot; called by the last k_fit_final)
-__device__ void wscore_final(const ChainDev &C, double *s_ws /* 4, shared */) {
-    const double *__restrict__ part = C.part_ws;   // 4 x FIT_BLOCKS
+// after the last slot: slots that were skipped because the chain had converged repeat their predecessor's results
+__device__ void wscore_final(const ChainDev &C) {
     PlaneState *st = C.st;
     uint32_t *__restrict__ cnt = C.cntS;
-    const int slot = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    double a = 0;
-    for (int b = lane; b < FIT_BLOCKS; b += 64) a += part[slot * FIT_BLOCKS + b];
-    for (int d = 32; d >= 1; d >>= 1) a += __shfl_xor(a, d, 64);
-    if (lane == 0) s_ws[slot] = a;
-    __syncthreads();
     if (threadIdx.x == 0)
-        for (int k = 0; k < 4; ++k) {
-            if (k > 0 && st[k].converged) { st[k].wscore = st[k - 1].wscore; cnt[k] = cnt[k - 1]; st[k].ue = st[k - 1].ue; st[k].ve = st[k - 1].ve; }
-            else st[k].wscore = s_ws[k];
-        }
+        for (int k = 1; k < 4; ++k)
+            if (st[k].converged) { st[k].wscore = st[k - 1].wscore; cnt[k] = cnt[k - 1]; st[k].ue = st[k - 1].ue; st[k].ve = st[k - 1].ve; }
 }
 
 // Sums the per-block partials of the index list `count` belongs to (fixed tree => deterministic);
 // nsum_out receives the sum of the list's point normals (orientation).  mode 0 additionally writes the
-// fitted plane into `st` (the NEXT slot's state) / plane_out.  One workgroup of 256 lanes (>= FIT_BLOCKS).
+// fitted plane into `st` (the NEXT slot's state) / plane_out.  One workgroup of 256 lanes.
 // `cur` is the state of the slot whose list was just reduced; when the new plane is bitwise equal to
 // cur's plane the chain has converged: every later slot would reproduce cur's results, so they are
 // flagged and their kernels return immediately.
-__device__ void fit_final(const ChainDev &C, int k, double (*s_red)[12]) {
+__device__ void fit_final(const ChainDev &C, int k, double (*s_red)[FIT_COLS]) {
     const int kn = k < 3 ? k + 1 : 3, mode = k < 3 ? 0 : 1;
     const double *__restrict__ part = C.part;
     const uint32_t *__restrict__ count = C.cntS + k;
@@ -583,14 +572,20 @@ __device__ void fit_final(const ChainDev &C, int k, double (*s_red)[12]) {
         }
         return;
     }
-    double a[12];
-    for (int k = 0; k < 12; ++k) a[k] = threadIdx.x < FIT_BLOCKS ? part[threadIdx.x * 12 + k] : 0.0;
-    for (int k = 0; k < 12; ++k)
-        for (int d = 32; d >= 1; d >>= 1) a[k] += __shfl_xor(a[k], d, 64);
-    if ((threadIdx.x & 63) == 0) for (int k = 0; k < 12; ++k) s_red[threadIdx.x >> 6][k] = a[k];
+    // rows written by k_cc_select: one per 1024 positions of the score list; lane t adds rows t, t + 256, ... in
+    // order, then the fixed shuffle / wave tree
+    const uint32_t rows = (*C.cntA + 1023u) / 1024u;
+    double a[FIT_COLS];
+    for (int q = 0; q < FIT_COLS; ++q) a[q] = 0.0;
+    for (uint32_t r = threadIdx.x; r < rows; r += blockDim.x)
+        for (int q = 0; q < FIT_COLS; ++q) a[q] += part[(size_t)r * FIT_COLS + q];
+    for (int q = 0; q < FIT_COLS; ++q)
+        for (int d = 32; d >= 1; d >>= 1) a[q] += __shfl_xor(a[q], d, 64);
+    if ((threadIdx.x & 63) == 0) for (int q = 0; q < FIT_COLS; ++q) s_red[threadIdx.x >> 6][q] = a[q];
     __syncthreads();
     if (threadIdx.x) return;
-    for (int k = 0; k < 12; ++k) a[k] = (s_red[0][k] + s_red[1][k]) + (s_red[2][k] + s_red[3][k]);
+    for (int q = 0; q < FIT_COLS; ++q) a[q] = (s_red[0][q] + s_red[1][q]) + (s_red[2][q] + s_red[3][q]);
+    C.st[k].wscore = a[12];
     nsum_out[0] = (float)a[9]; nsum_out[1] = (float)a[10]; nsum_out[2] = (float)a[11];
     if (mode == 1) return;
     st->err = 0;
@@ -621,13 +616,12 @@ __device__ void fit_final(const ChainDev &C, int k, double (*s_red)[12]) {
 }
 
 __global__ __launch_bounds__(256) void k_fit_final(const ChainDev *__restrict__ chains, int k) {
-    __shared__ double s_red[4][12];
-    __shared__ double s_ws[4];
+    __shared__ double s_red[4][FIT_COLS];
     const ChainDev &C = chains[blockIdx.x];
     fit_final(C, k, s_red);
-    if (k == 3) {   // last slot: also close the four weighted scores
+    if (k == 3) {   // last slot: skipped slots repeat their predecessor
         __syncthreads();
-        wscore_final(C, s_ws);
+        wscore_final(C);
     }
 }
 
@@ -667,7 +661,7 @@ struct Chain {
     DBuf<float2> uv;
     DBuf<uint32_t> bidx, label, sizes;
     DBuf<uint8_t> bmp, tmp;
-    DBuf<double> part, part_ws;
+    DBuf<double> part;
     DBuf<float> bbpart;
 };
 
@@ -741,9 +735,8 @@ void enqueue_accept(plade_ctx *ctx, RansacWork &W, const CloudView &cv, uint32_t
         compact_batch(ctx, c.n, W.compact_jobs.p + (size_t)(2 * k) * B, nc, c.x(), c.y(), c.z());
         hipLaunchKernelGGL(k_cc_raster, dim3(std::min(nb, 128u), nc), dim3(256), 0, st, tab, k, bitmap_eps, nb4);
         hipLaunchKernelGGL(k_cc_label, dim3(nc), dim3(1024), 0, st, tab, k, 1);
-        hipLaunchKernelGGL(k_cc_select, dim3(nb4, nc), dim3(256), 0, st, tab, k);
+        hipLaunchKernelGGL(k_cc_select, dim3(nb4, nc), dim3(256), 0, st, cv, tab, k, eps3);
         compact_batch(ctx, c.n, W.compact_jobs.p + (size_t)(2 * k + 1) * B, nc);
-        hipLaunchKernelGGL(k_fit_partial, dim3(FIT_BLOCKS, nc), dim3(256), 0, st, cv, tab, k, eps3);
         hipLaunchKernelGGL(k_fit_final, dim3(nc), dim3(256), 0, st, tab, k);
     }
 }
@@ -778,8 +771,7 @@ void chains_prepare(plade_ctx *ctx, RansacWork &W, uint32_t B, uint32_t n, float
         D.label = C.label.ensure(CC_MAXPIX); D.sizes = C.sizes.ensure(CC_MAXPIX);
         D.bmp = C.bmp.ensure(CC_MAXPIX); D.tmp = C.tmp.ensure(CC_MAXPIX);
         if (fresh) HIP_TRY(hipMemsetAsync(C.bmp.p, 0, C.bmp.cap, ctx->stream));
-        D.part = C.part.ensure(FIT_BLOCKS * 12 + 16);
-        D.part_ws = C.part_ws.ensure(4 * FIT_BLOCKS + 16);
+        D.part = C.part.ensure((size_t)nb4 * FIT_COLS + 16);
         C.cs.masks.ensure((size_t)nb4 * 256 + 16); C.cs.block_counts.ensure(nb4 + 4);
         D.bcA = C.cs.block_counts.p;
         D.bbpart = C.bbpart.ensure(4 * (size_t)nb4 + 16);
@@ -913,16 +905,13 @@ void plane_component(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const
     compact_batch(ctx, n, job.p, 1, cv.x, cv.y, cv.z);
     hipLaunchKernelGGL(k_cc_raster, dim3(std::min(cdiv(n, 256), 128u), 1), dim3(256), 0, st, W.chain_tab.p, 0, bitmap_eps, nb4);
     hipLaunchKernelGGL(k_cc_label, dim3(1), dim3(1024), 0, st, W.chain_tab.p, 0, closing_filter ? 1 : 0);
-    hipLaunchKernelGGL(k_cc_select, dim3(nb4, 1), dim3(256), 0, st, W.chain_tab.p, 0);
+    hipLaunchKernelGGL(k_cc_select, dim3(nb4, 1), dim3(256), 0, st, cv, W.chain_tab.p, 0, w_eps);
     compact_batch(ctx, n, W.compact_jobs.p + (size_t)1 * W.B, 1);
-    hipLaunchKernelGGL(k_fit_partial, dim3(FIT_BLOCKS, 1), dim3(256), 0, st, cv, W.chain_tab.p, 0, w_eps);
     hipLaunchKernelGGL(k_fit_final, dim3(1), dim3(256), 0, st, W.chain_tab.p, 0);
     PlaneState hst[2];
     uint32_t nk = 0;
-    std::vector<double> ws(FIT_BLOCKS);
     ctx->d2h(hst, D.st, 2 * sizeof(PlaneState));
     ctx->d2h(&nk, D.cntS, 4);
-    ctx->d2h(ws.data(), D.part_ws, 8 * FIT_BLOCKS);
     ctx->sync(st);
     HIP_TRY(hipGetLastError());
     out.err = hst[0].err;
@@ -931,7 +920,7 @@ void plane_component(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const
     if (nk) HIP_TRY(hipMemcpy(out.kept.data(), D.idxS[0], 4 * (size_t)nk, hipMemcpyDeviceToHost));
     for (int k = 0; k < 3; ++k) { out.fit[k] = hst[1].n[k]; out.fit[3 + k] = hst[1].pos[k]; }
     out.fit[6] = hst[1].dist;
-    for (int b = 0; b < FIT_BLOCKS; ++b) out.wscore += ws[b];
+    out.wscore = hst[0].wscore;
 }
 
 void ransac_detect(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const RansacParams &rp, PlaneSetOut &out) {
