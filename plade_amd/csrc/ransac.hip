@@ -343,24 +343,12 @@ __global__ __launch_bounds__(256) void k_cc_raster(const ChainDev *__restrict__ 
 // up to CC_LDS_PIX pixels (every realistic plane at bitmap eps = 2 % of the scene) live in LDS.
 constexpr int CC_LDS_PIX = 8192;
 
-__global__ __launch_bounds__(1024) void k_cc_label(const ChainDev *__restrict__ chains, int k, int do_filter) {
-    const ChainDev &C = chains[blockIdx.x];
-    PlaneState *st = C.st + k;
-    uint8_t *__restrict__ g_bmp = C.bmp, *__restrict__ g_tmp = C.tmp;
-    uint32_t *__restrict__ g_label = C.label, *__restrict__ g_sizes = C.sizes;
-    __shared__ unsigned long long s_best;
-    __shared__ uint32_t s_label[CC_LDS_PIX];
-    __shared__ uint32_t s_sizes[CC_LDS_PIX];
-    __shared__ uint8_t s_bmp[CC_LDS_PIX], s_tmp[CC_LDS_PIX];
-    if (st->converged) return;
-    const int ue = (int)st->ue, ve = (int)st->ve, npx = ue * ve;
-    const bool in_lds = npx <= CC_LDS_PIX;
-    uint8_t *bmp = in_lds ? s_bmp : g_bmp, *tmp = in_lds ? s_tmp : g_tmp;
-    uint32_t *label = in_lds ? s_label : g_label, *sizes = in_lds ? s_sizes : g_sizes;
-    if (in_lds) {
-        for (int p = threadIdx.x; p < npx; p += blockDim.x) { s_bmp[p] = g_bmp[p]; g_bmp[p] = 0; }  // also leaves it clean
-        __syncthreads();
-    }
+// The labelling proper on a bitmap that lives either in LDS or in global memory.  Force-inlined into both branches
+// of k_cc_label so that the LDS instance is compiled to ds_* instructions (a pointer selected at run time would
+// make every access a flat_* one).
+__device__ __forceinline__ void cc_label_body(uint8_t *bmp, uint8_t *tmp, uint32_t *label, uint32_t *sizes, int ue, int ve, int npx,
+                                              int do_filter, unsigned long long *s_best_p, PlaneState *st) {
+    unsigned long long &s_best = *s_best_p;
     if (do_filter) {
         for (int p = threadIdx.x; p < npx; p += blockDim.x) {
             const int u = p % ue, v = p / ue;
@@ -453,9 +441,30 @@ __global__ __launch_bounds__(1024) void k_cc_label(const ChainDev *__restrict__ 
         if (s_best == 0ull) { st->best_root = 0xffffffffu; st->n_fg = 0; }
         else { st->best_root = 0xffffffffu - (uint32_t)(s_best & 0xffffffffu); st->n_fg = (uint32_t)(s_best >> 32); }
     }
-    // k_cc_select reads the labels from global memory; the bitmap is left all-zero for the next raster
-    if (in_lds) { for (int p = threadIdx.x; p < npx; p += blockDim.x) g_label[p] = s_label[p]; }
-    else { for (int p = threadIdx.x; p < npx; p += blockDim.x) g_bmp[p] = 0; }
+}
+
+__global__ __launch_bounds__(1024) void k_cc_label(const ChainDev *__restrict__ chains, int k, int do_filter) {
+    const ChainDev &C = chains[blockIdx.x];
+    PlaneState *st = C.st + k;
+    uint8_t *__restrict__ g_bmp = C.bmp, *__restrict__ g_tmp = C.tmp;
+    uint32_t *__restrict__ g_label = C.label, *__restrict__ g_sizes = C.sizes;
+    __shared__ unsigned long long s_best;
+    __shared__ uint32_t s_label[CC_LDS_PIX];
+    __shared__ uint32_t s_sizes[CC_LDS_PIX];
+    __shared__ uint8_t s_bmp[CC_LDS_PIX], s_tmp[CC_LDS_PIX];
+    if (st->converged) return;
+    const int ue = (int)st->ue, ve = (int)st->ve, npx = ue * ve;
+    if (npx <= CC_LDS_PIX) {
+        for (int p = threadIdx.x; p < npx; p += blockDim.x) { s_bmp[p] = g_bmp[p]; g_bmp[p] = 0; }  // also leaves it clean
+        __syncthreads();
+        cc_label_body(s_bmp, s_tmp, s_label, s_sizes, ue, ve, npx, do_filter, &s_best, st);
+        // k_cc_select reads the labels from global memory; the bitmap is left all-zero for the next raster
+        for (int p = threadIdx.x; p < npx; p += blockDim.x) g_label[p] = s_label[p];
+    } else {
+        cc_label_body(g_bmp, g_tmp, g_label, g_sizes, ue, ve, npx, do_filter, &s_best, st);
+        __syncthreads();
+        for (int p = threadIdx.x; p < npx; p += blockDim.x) g_bmp[p] = 0;
+    }
 }
 
 // mask layout of k_compact: one byte per lane covering 4 consecutive items, block counts per 1024.
