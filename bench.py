@@ -55,8 +55,9 @@ def pmc_traffic(tag):
     return None, None
 
 
-def cpu_baseline(n_points, pairs, budget_s=25.0):
-    """Single-thread CPU registrations/sec on a bounded sample (rank 0, N = 1 only)."""
+def cpu_baseline(n_points, pairs, min_s=10.0, budget_s=25.0):
+    """Single-thread CPU registrations/sec on a bounded sample (rank 0, N = 1 only): the bench pairs are registered
+    in turn (the reference's RANSAC re-seeded every time, as its time() seed would be) until min_s of CPU work."""
     from oracle.oracle import Oracle, Reference, have_reference
     orc = Oracle()
     ref = Reference() if have_reference() else None
@@ -86,10 +87,11 @@ def cpu_baseline(n_points, pairs, budget_s=25.0):
 
     done, t_total, ok_all = 0, 0.0, True
     t_extract = 0.0
-    for (tg, sr, planes) in pairs:
+    while t_total < min_s:
+        tg, sr, planes = pairs[done % len(pairs)]
         t0 = time.perf_counter()
         if ref is not None:
-            tp, sp = extract(tg, 1), extract(sr, 2)
+            tp, sp = extract(tg, 2 * done + 1), extract(sr, 2 * done + 2)
         else:
             tp, sp = planes  # planes handed over from the GPU run: the CPU leg then times the port only
         t1 = time.perf_counter()
@@ -109,7 +111,7 @@ def cpu_baseline(n_points, pairs, budget_s=25.0):
         "unit": "registrations/s",
         "cores": 1,
         "kind": kind,
-        "sample": f"{done} synthetic {n_points}-pt pair(s), {t_total:.1f} s CPU ({t_extract:.1f} s in plane extraction); "
+        "sample": f"{done} registrations of {min(done, len(pairs))} synthetic {n_points}-pt pair(s), {t_total:.1f} s CPU ({t_extract:.1f} s in plane extraction); "
                   + what + "registration stages: oracle restatement; all registrations ok=" + str(ok_all),
     }
 

@@ -143,12 +143,12 @@ __global__ __launch_bounds__(TPB) void k_score_mark(const float *__restrict__ x,
 }
 
 // the same for a batch of hypotheses: the tile is loaded once and tested against every job's plane
-constexpr int MARK_MAXJ = 16;
+constexpr int MARK_MAXJ = BATCH_MAXJ;
 __global__ __launch_bounds__(TPB) void k_score_mark_batch(const float *__restrict__ x, const float *__restrict__ y,
                                                           const float *__restrict__ z, const float *__restrict__ nx,
                                                           const float *__restrict__ ny, const float *__restrict__ nz,
                                                           const int32_t *__restrict__ assigned, uint32_t n,
-                                                          const MarkJob *__restrict__ jobs, uint32_t nj, float eps, float cos_t) {
+                                                          const MarkJobs jobs, uint32_t nj, float eps, float cos_t) {
     __shared__ uint32_t s_w[MARK_MAXJ][TPB / 64];
     // the jobs' planes / skip flags / output pointers are fetched by nj lanes at once and parked in LDS: read
     // one after the other inside the hypothesis loop they were a chain of dependent global loads (~1 us each)
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(TPB) void k_score_mark_batch(const float *__restric
     __shared__ uint8_t *s_masks[MARK_MAXJ];
     __shared__ uint32_t *s_bc[MARK_MAXJ];
     if (threadIdx.x < nj) {
-        const MarkJob jb = jobs[threadIdx.x];
+        const MarkJob jb = jobs.j[threadIdx.x];
         s_skip[threadIdx.x] = jb.skip ? *jb.skip : 0u;
         s_pl[threadIdx.x] = jb.plane[0];
         s_masks[threadIdx.x] = jb.masks;
@@ -223,13 +223,13 @@ __global__ __launch_bounds__(TPB) void k_compact(const uint8_t *__restrict__ mas
 }
 
 // batched form of k_compact: job blockIdx.y
-__global__ __launch_bounds__(TPB) void k_compact_batch(const CompactJob *__restrict__ jobs, uint32_t nb,
+__global__ __launch_bounds__(TPB) void k_compact_batch(const CompactJobs jobs, uint32_t nb,
                                                        const float *__restrict__ px, const float *__restrict__ py,
                                                        const float *__restrict__ pz) {
     __shared__ uint32_t s_w[TPB / 64];
     __shared__ uint32_t s_base[TPB / 64];
     __shared__ float s_mm[4][8];
-    const CompactJob jb = jobs[blockIdx.y];
+    const CompactJob jb = jobs.j[blockIdx.y];
     if (jb.skip && *jb.skip) return;
     // most tiles of a plane's score list are empty: nothing to place (the last tile still reports the total)
     if (jb.block_counts[blockIdx.x] == 0 && blockIdx.x != nb - 1) return;
@@ -301,23 +301,28 @@ __global__ __launch_bounds__(TPB) void k_compact_batch(const CompactJob *__restr
 }
 
 void score_mark_batch(plade_ctx *ctx, const float *x, const float *y, const float *z, const float *nx, const float *ny,
-                      const float *nz, const int32_t *assigned, uint32_t n, const MarkJob *jobs_dev, uint32_t nj, float eps,
+                      const float *nz, const int32_t *assigned, uint32_t n, const MarkJob *jobs_host, uint32_t nj, float eps,
                       float cos_thresh) {
     PLADE_REQUIRE(nj <= (uint32_t)MARK_MAXJ, PLADE_EINVAL, "score_mark_batch: too many jobs");
     const uint32_t nb = cdiv(n, TILE);
     if (nb == 0 || nj == 0) return;
     // algorithmic bytes: the cloud once (28 B/point) + one mask byte per 4 points per hypothesis
     ctx->ev_begin("score_mark", 28.0 * n + 0.25 * n * nj);
-    hipLaunchKernelGGL(k_score_mark_batch, dim3(nb), dim3(TPB), 0, ctx->stream, x, y, z, nx, ny, nz, assigned, n, jobs_dev, nj,
+    MarkJobs jobs;
+    for (uint32_t j = 0; j < (uint32_t)BATCH_MAXJ; ++j) jobs.j[j] = jobs_host[j < nj ? j : 0];
+    hipLaunchKernelGGL(k_score_mark_batch, dim3(nb), dim3(TPB), 0, ctx->stream, x, y, z, nx, ny, nz, assigned, n, jobs, nj,
                        eps, cos_thresh);
     ctx->ev_end();
 }
 
-void compact_batch(plade_ctx *ctx, uint32_t n, const CompactJob *jobs_dev, uint32_t nj, const float *x, const float *y,
+void compact_batch(plade_ctx *ctx, uint32_t n, const CompactJob *jobs_host, uint32_t nj, const float *x, const float *y,
                    const float *z) {
     const uint32_t nb = cdiv(n, TILE);
     if (nb == 0 || nj == 0) return;
-    hipLaunchKernelGGL(k_compact_batch, dim3(nb, nj), dim3(TPB), 0, ctx->stream, jobs_dev, nb, x, y, z);
+    PLADE_REQUIRE(nj <= (uint32_t)BATCH_MAXJ, PLADE_EINVAL, "compact_batch: too many jobs");
+    CompactJobs jobs;
+    for (uint32_t j = 0; j < (uint32_t)BATCH_MAXJ; ++j) jobs.j[j] = jobs_host[j < nj ? j : 0];
+    hipLaunchKernelGGL(k_compact_batch, dim3(nb, nj), dim3(TPB), 0, ctx->stream, jobs, nb, x, y, z);
 }
 
 void score_multi(plade_ctx *ctx, const float *x, const float *y, const float *z, const float *nx, const float *ny,

@@ -208,6 +208,8 @@ struct PlaneState {
     uint32_t converged;              // refit chain: this slot's plane is bitwise the previous slot's
 };
 
+constexpr int CHAIN_MAX = BATCH_MAXJ;   // chains accepted together (table passed by value: 8 x 184 B of kernarg)
+
 // Device-visible buffers of one acceptance chain.  Every kernel of the acceptance sequence takes the
 // table of chains and handles chain blockIdx.y (slot k of it): one launch serves the whole batch of
 // candidates that are accepted together.
@@ -228,6 +230,8 @@ struct ChainDev {
     float *bbpart;         // per-tile (u, v) bounding boxes of the score list
     double *part;
 };
+struct ChainTab { ChainDev c[CHAIN_MAX]; };
+
 
 __device__ __forceinline__ void hcs_axes(const float *n, float *a0, float *a1) {
     float t[3];
@@ -253,9 +257,9 @@ __device__ __forceinline__ int ord_i(float f) { int v = __float_as_int(f); retur
 __device__ __forceinline__ float ord_f(int v) { return __int_as_float(v >= 0 ? v : v ^ 0x7fffffff); }
 
 // initialise the state from a hypothesis (n, dist) + position
-__global__ void k_state_from_hyp(const ChainDev *__restrict__ chains) {
+__global__ void k_state_from_hyp(const ChainTab chains) {
     if (threadIdx.x) return;
-    const ChainDev &C = chains[blockIdx.x];
+    const ChainDev &C = chains.c[blockIdx.x];
     const float4 *hyp = C.top, *pos = C.top + 1;
     PlaneState *st = C.st;
     float4 *plane_out = C.plane_cur;
@@ -288,8 +292,8 @@ __device__ __forceinline__ bool cc_dims(const float bb[4], uint32_t count, float
 
 // BuildBitmap (BitmapPrimitiveShape.h:139-150) with InBitmap (PlanePrimitiveShape.cpp:193-199).
 // The bitmap is all-zero on entry (k_cc_label clears what it used).
-__global__ __launch_bounds__(256) void k_cc_raster(const ChainDev *__restrict__ chains, int k, float eps, uint32_t n_tiles) {
-    const ChainDev &C = chains[blockIdx.y];
+__global__ __launch_bounds__(256) void k_cc_raster(const ChainTab chains, int k, float eps, uint32_t n_tiles) {
+    const ChainDev &C = chains.c[blockIdx.y];
     PlaneState *st = C.st + k;
     if (st->converged) return;
     const float2 *__restrict__ uv = C.uv;
@@ -443,8 +447,8 @@ __device__ __forceinline__ void cc_label_body(uint8_t *bmp, uint8_t *tmp, uint32
     }
 }
 
-__global__ __launch_bounds__(1024) void k_cc_label(const ChainDev *__restrict__ chains, int k, int do_filter) {
-    const ChainDev &C = chains[blockIdx.x];
+__global__ __launch_bounds__(1024) void k_cc_label(const ChainTab chains, int k, int do_filter) {
+    const ChainDev &C = chains.c[blockIdx.x];
     PlaneState *st = C.st + k;
     uint8_t *__restrict__ g_bmp = C.bmp, *__restrict__ g_tmp = C.tmp;
     uint32_t *__restrict__ g_label = C.label, *__restrict__ g_sizes = C.sizes;
@@ -473,10 +477,10 @@ __global__ __launch_bounds__(1024) void k_cc_label(const ChainDev *__restrict__ 
 // doubles per 1024 list positions, reduced by k_fit_final in a fixed order.
 constexpr int FIT_COLS = 13;
 
-__global__ __launch_bounds__(256) void k_cc_select(CloudView c, const ChainDev *__restrict__ chains, int k, float eps) {
+__global__ __launch_bounds__(256) void k_cc_select(CloudView c, const ChainTab chains, int k, float eps) {
     __shared__ uint32_t s_w[4];
     __shared__ double s[4][FIT_COLS];
-    const ChainDev &C = chains[blockIdx.y];
+    const ChainDev &C = chains.c[blockIdx.y];
     const PlaneState *st = C.st + k;
     if (st->converged) return;
     const uint32_t *__restrict__ bidx = C.bidx, *__restrict__ count = C.cntA, *__restrict__ label = C.label;
@@ -624,9 +628,9 @@ __device__ void fit_final(const ChainDev &C, int k, double (*s_red)[FIT_COLS]) {
                      st->pos[0] == cur->pos[0] && st->pos[1] == cur->pos[1] && st->pos[2] == cur->pos[2]) ? 1u : 0u;
 }
 
-__global__ __launch_bounds__(256) void k_fit_final(const ChainDev *__restrict__ chains, int k) {
+__global__ __launch_bounds__(256) void k_fit_final(const ChainTab chains, int k) {
     __shared__ double s_red[4][FIT_COLS];
-    const ChainDev &C = chains[blockIdx.x];
+    const ChainDev &C = chains.c[blockIdx.x];
     fit_final(C, k, s_red);
     if (k == 3) {   // last slot: skipped slots repeat their predecessor
         __syncthreads();
@@ -695,10 +699,10 @@ struct RansacWork {
     std::vector<std::unique_ptr<Chain>> chains;
     DBuf<char> accept_block;         // B x ACCEPT_STRIDE: one D2H copy per batch
     DBuf<float4> cand_in;            // B x (hypothesis, position): one H2D copy per batch
-    DBuf<ChainDev> chain_tab;
+    ChainTab tab;                    // the chains' device pointers, passed by value to every chain kernel
     std::vector<ChainDev> h_tab;
-    DBuf<MarkJob> mark_jobs;         // [slot][chain]
-    DBuf<CompactJob> compact_jobs;   // [slot][A|S][chain]
+    std::vector<MarkJob> mark_jobs;      // [slot][chain]   (host; launches copy one slot's row into the kernargs)
+    std::vector<CompactJob> compact_jobs;   // [slot][A|S][chain]
     HBuf<char> pinned_accept;
     uint32_t B = 0;
     std::vector<uint64_t> tab_key;
@@ -734,23 +738,24 @@ struct Accepted {
 void enqueue_accept(plade_ctx *ctx, RansacWork &W, const CloudView &cv, uint32_t nc, float eps3, float cos_t, float bitmap_eps) {
     const CloudDev &c = W.sorted;
     hipStream_t st = ctx->stream;
-    const ChainDev *tab = W.chain_tab.p;
+    const ChainTab &tab = W.tab;
     const uint32_t B = W.B;
     const uint32_t nb = cdiv(c.n, 256), nb4 = cdiv(c.n, 1024);
     hipLaunchKernelGGL(k_state_from_hyp, dim3(nc), dim3(64), 0, st, tab);
     for (int k = 0; k < 4; ++k) {
-        score_mark_batch(ctx, c.x(), c.y(), c.z(), c.nx(), c.ny(), c.nz(), W.assigned.p, c.n, W.mark_jobs.p + (size_t)k * B, nc, eps3,
+        score_mark_batch(ctx, c.x(), c.y(), c.z(), c.nx(), c.ny(), c.nz(), W.assigned.p, c.n, W.mark_jobs.data() + (size_t)k * B, nc, eps3,
                          cos_t);
-        compact_batch(ctx, c.n, W.compact_jobs.p + (size_t)(2 * k) * B, nc, c.x(), c.y(), c.z());
+        compact_batch(ctx, c.n, W.compact_jobs.data() + (size_t)(2 * k) * B, nc, c.x(), c.y(), c.z());
         hipLaunchKernelGGL(k_cc_raster, dim3(std::min(nb, 128u), nc), dim3(256), 0, st, tab, k, bitmap_eps, nb4);
         hipLaunchKernelGGL(k_cc_label, dim3(nc), dim3(1024), 0, st, tab, k, 1);
         hipLaunchKernelGGL(k_cc_select, dim3(nb4, nc), dim3(256), 0, st, cv, tab, k, eps3);
-        compact_batch(ctx, c.n, W.compact_jobs.p + (size_t)(2 * k + 1) * B, nc);
+        compact_batch(ctx, c.n, W.compact_jobs.data() + (size_t)(2 * k + 1) * B, nc);
         hipLaunchKernelGGL(k_fit_final, dim3(nc), dim3(256), 0, st, tab, k);
     }
 }
 
 void chains_prepare(plade_ctx *ctx, RansacWork &W, uint32_t B, uint32_t n, float eps3, float cos_t, float bitmap_eps) {
+    PLADE_REQUIRE(B >= 1 && B <= (uint32_t)CHAIN_MAX, PLADE_EINVAL, "ransac: batch size");
     W.B = B;
     while (W.chains.size() < B) W.chains.emplace_back(new Chain);
     char *ab = W.accept_block.ensure(B * ACCEPT_STRIDE);
@@ -802,15 +807,17 @@ void chains_prepare(plade_ctx *ctx, RansacWork &W, uint32_t B, uint32_t n, float
         const uint64_t *w = reinterpret_cast<const uint64_t *>(&D);
         key.insert(key.end(), w, w + sizeof(ChainDev) / 8);
     }
-    key.push_back((uint64_t)W.chains[0]->cs.masks.p);
-    W.chain_tab.ensure(B); W.mark_jobs.ensure(4 * (size_t)B); W.compact_jobs.ensure(8 * (size_t)B);
-    key.push_back((uint64_t)W.chain_tab.p); key.push_back((uint64_t)W.mark_jobs.p); key.push_back((uint64_t)W.compact_jobs.p);
+    {   // ... and every pointer of the job tables
+        const uint64_t *w = reinterpret_cast<const uint64_t *>(mj.data());
+        key.insert(key.end(), w, w + mj.size() * sizeof(MarkJob) / 8);
+        w = reinterpret_cast<const uint64_t *>(cj.data());
+        key.insert(key.end(), w, w + cj.size() * sizeof(CompactJob) / 8);
+    }
     W.h_tab = tab;
-    if (key != W.tab_key) {
-        HIP_TRY(hipMemcpyAsync(W.chain_tab.p, tab.data(), B * sizeof(ChainDev), hipMemcpyHostToDevice, ctx->stream));
-        HIP_TRY(hipMemcpyAsync(W.mark_jobs.p, mj.data(), mj.size() * sizeof(MarkJob), hipMemcpyHostToDevice, ctx->stream));
-        HIP_TRY(hipMemcpyAsync(W.compact_jobs.p, cj.data(), cj.size() * sizeof(CompactJob), hipMemcpyHostToDevice, ctx->stream));
-        ctx->sync();
+    if (key != W.tab_key) {   // the tables are baked into the captured launches' arguments
+        for (uint32_t b = 0; b < (uint32_t)CHAIN_MAX; ++b) W.tab.c[b] = tab[b < B ? b : 0];
+        W.mark_jobs = mj;
+        W.compact_jobs = cj;
         W.tab_key = key;
         W.drop_graphs();
     }
@@ -900,23 +907,20 @@ void plane_component(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const
     dist += point[2] * normal[2];
     const float4 two[2] = {make_float4(normal[0], normal[1], normal[2], dist), make_float4(point[0], point[1], point[2], 0.f)};
     HIP_TRY(hipMemcpyAsync(W.cand_in.p, two, 32, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_state_from_hyp, dim3(1), dim3(64), 0, st, W.chain_tab.p);
+    hipLaunchKernelGGL(k_state_from_hyp, dim3(1), dim3(64), 0, st, W.tab);
     // the list as an all-ones mask over list positions, values = the caller's indices
     DBuf<uint32_t> d_idx;
     d_idx.ensure((size_t)n + 4);
     HIP_TRY(hipMemcpyAsync(d_idx.p, idx, 4 * (size_t)m, hipMemcpyHostToDevice, st));
     const uint32_t nb4 = cdiv(n, 1024);
     hipLaunchKernelGGL(k_list_masks, dim3(cdiv(nb4 * 256, 256)), dim3(256), 0, st, m, nb4, C.cs.masks.p, C.cs.block_counts.p);
-    DBuf<CompactJob> job;
-    job.ensure(1);
     const CompactJob hj{C.cs.masks.p, C.cs.block_counts.p, d_idx.p, D.idxA, D.cntA, nullptr, D.st[0].pos, D.uv, D.bbpart};
-    HIP_TRY(hipMemcpyAsync(job.p, &hj, sizeof(hj), hipMemcpyHostToDevice, st));
-    compact_batch(ctx, n, job.p, 1, cv.x, cv.y, cv.z);
-    hipLaunchKernelGGL(k_cc_raster, dim3(std::min(cdiv(n, 256), 128u), 1), dim3(256), 0, st, W.chain_tab.p, 0, bitmap_eps, nb4);
-    hipLaunchKernelGGL(k_cc_label, dim3(1), dim3(1024), 0, st, W.chain_tab.p, 0, closing_filter ? 1 : 0);
-    hipLaunchKernelGGL(k_cc_select, dim3(nb4, 1), dim3(256), 0, st, cv, W.chain_tab.p, 0, w_eps);
-    compact_batch(ctx, n, W.compact_jobs.p + (size_t)1 * W.B, 1);
-    hipLaunchKernelGGL(k_fit_final, dim3(1), dim3(256), 0, st, W.chain_tab.p, 0);
+    compact_batch(ctx, n, &hj, 1, cv.x, cv.y, cv.z);
+    hipLaunchKernelGGL(k_cc_raster, dim3(std::min(cdiv(n, 256), 128u), 1), dim3(256), 0, st, W.tab, 0, bitmap_eps, nb4);
+    hipLaunchKernelGGL(k_cc_label, dim3(1), dim3(1024), 0, st, W.tab, 0, closing_filter ? 1 : 0);
+    hipLaunchKernelGGL(k_cc_select, dim3(nb4, 1), dim3(256), 0, st, cv, W.tab, 0, w_eps);
+    compact_batch(ctx, n, W.compact_jobs.data() + (size_t)1 * W.B, 1);
+    hipLaunchKernelGGL(k_fit_final, dim3(1), dim3(256), 0, st, W.tab, 0);
     PlaneState hst[2];
     uint32_t nk = 0;
     ctx->d2h(hst, D.st, 2 * sizeof(PlaneState));

@@ -53,11 +53,16 @@ struct CompactJob {
     float *bbox_part;          // per tile: min u, min v, max u, max v of its emitted points (tiles with a zero
                                // block count are left untouched): reduced by the consumer, no atomics
 };
+// Job tables travel BY VALUE in the kernel arguments (scalar loads from the kernarg segment): a table in device
+// memory costs every workgroup a dependent global load (~1 us) before it can fetch what the entries point to.
+constexpr int BATCH_MAXJ = 8;
+struct MarkJobs { MarkJob j[BATCH_MAXJ]; };
+struct CompactJobs { CompactJob j[BATCH_MAXJ]; };
 void score_mark_batch(plade_ctx *ctx, const float *x, const float *y, const float *z, const float *nx, const float *ny,
-                      const float *nz, const int32_t *assigned, uint32_t n, const MarkJob *jobs_dev, uint32_t nj, float eps,
+                      const float *nz, const int32_t *assigned, uint32_t n, const MarkJob *jobs_host, uint32_t nj, float eps,
                       float cos_thresh);
 // x, y, z: the cloud the indices refer to (only read by jobs with a frame)
-void compact_batch(plade_ctx *ctx, uint32_t n, const CompactJob *jobs_dev, uint32_t nj, const float *x = nullptr,
+void compact_batch(plade_ctx *ctx, uint32_t n, const CompactJob *jobs_host, uint32_t nj, const float *x = nullptr,
                    const float *y = nullptr, const float *z = nullptr);
 
 }  // namespace plade

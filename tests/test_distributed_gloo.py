@@ -7,7 +7,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from plade_amd.batch import shard, gather_results
+from plade_amd.batch import shard, gather_results, sharded_overlap_counts
 
 
 def _free_port():
@@ -68,3 +68,38 @@ def test_gather_world1():
     T = np.stack([_fake_T(i) for i in range(3)])
     Tg, okg = gather_results(T, np.array([True, False, True]), 3, 0, 1)
     assert np.array_equal(Tg, T) and okg.tolist() == [True, False, True]
+
+
+def _fake_counts(src, tgt, T, centers, radius, dist_):
+    """Stand-in for seam S3 on CPU: a deterministic function of each candidate alone."""
+    return np.array([int(abs(t[0, 3]) * 10) - (1 if c[0] > 50 else 0) for t, c in zip(T, centers)], np.int32)
+
+
+def _overlap_worker(rank, world, port, K, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    T = np.stack([_fake_T(i) for i in range(K)])
+    centers = np.stack([[i, 0, 0] for i in range(K)]).astype(np.float32)
+    got = sharded_overlap_counts(None, None, None, T, centers, 1.0, 0.1, rank, world, counter=_fake_counts)
+    q.put((rank, got))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_candidate_sharding_world2_gloo():
+    """Single-pair axis: candidates split over 2 ranks, counts all-gathered = the unsharded counts, on every rank."""
+    world, K = 2, 101
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_overlap_worker, args=(r, world, port, K, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+    T = np.stack([_fake_T(i) for i in range(K)])
+    centers = np.stack([[i, 0, 0] for i in range(K)]).astype(np.float32)
+    want = _fake_counts(None, None, T, centers, 1.0, 0.1)
+    assert np.array_equal(res[0], want) and np.array_equal(res[1], want)

@@ -215,3 +215,34 @@ def test_match_lists_longer_than_the_in_lds_ranking(ctx, oracle):
     o2, n2, d2 = ctx.match_descriptors(q, t, 0.04)
     assert (np.diff(o2) > 4096).all()
     assert np.array_equal(o1, o2) and np.array_equal(n1, n2) and np.array_equal(d1, d2)
+
+
+def test_host_wait_sleep_mode_returns_the_same_bits(ctx):
+    """plade_params.host_wait = 1 (poll + sleep instead of the HIP runtime's spinning waits) changes how the host
+    waits, not what the GPU computes."""
+    import plade_amd
+    tg, sr, _ = make_pair(120000, seed=5)
+    ok, T = ctx.registration(tg, sr)
+    c2 = plade_amd.Context(0, host_wait=1)
+    ok2, T2 = c2.registration(tg, sr)
+    c2.close()
+    assert ok and ok2 and np.array_equal(T, T2)
+
+
+def test_candidate_shards_of_the_verification_seam_add_up(ctx):
+    """the candidates of one pair split over ranks (round robin) give, shard by shard, the counts of the
+    unsharded call (plade_amd.batch.sharded_overlap_counts does this with an all_gather; gloo test on CPU)."""
+    from plade_amd.batch import shard
+    rng = np.random.default_rng(3)
+    tg = ctx.voxel_downsample(make_pair(200000, seed=2)[0], 0.05)
+    K = 37
+    T = np.tile(np.eye(4, dtype=np.float32), (K, 1, 1))
+    T[:, :3, 3] = rng.normal(0, 0.05, (K, 3)).astype(np.float32)
+    centers = (tg.mean(0)[None, :] + T[:, :3, 3]).astype(np.float32)
+    full = ctx.overlap_counts(tg, tg, T, centers, np.float32(4.0), np.float32(0.05))
+    for world in (2, 3):
+        out = np.zeros(K, np.int32)
+        for r in range(world):
+            idx = shard(K, r, world)
+            out[idx] = ctx.overlap_counts(tg, tg, T[idx], centers[idx], np.float32(4.0), np.float32(0.05))
+        assert np.array_equal(out, full)
