@@ -987,7 +987,7 @@ void ransac_detect(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const R
     W.out_idx.ensure((size_t)n + 4);
     // ---- acceptance chains ------------------------------------------------------------------------
     uint32_t B = 8;
-    if (const char *e = getenv("PLADE_RANSAC_CHAINS")) B = (uint32_t)std::max(1, std::min(16, atoi(e)));
+    if (const char *e = getenv("PLADE_RANSAC_CHAINS")) B = (uint32_t)std::max(1, std::min(CHAIN_MAX, atoi(e)));
     chains_prepare(ctx, W, B, n, eps3, cos_t, bitmap_eps);
 
     ctx->sync();

@@ -32,7 +32,7 @@ lst = os.path.join(d, "pairs.txt")
 with open(lst, "w") as f:
     for i in range(npairs):
         f.write(f"{files[i % 2][0]}\n{files[i % 2][1]}\n")
-for infl in (1, 4, 8):
+for infl in [int(v) for v in os.environ.get("CLI_INFLIGHT", "1,4,8").split(",")]:
     env = dict(os.environ, PLADE_INFLIGHT=str(infl), PLADE_GPUS="1")
     t0 = time.perf_counter()
     r = subprocess.run([CLI, lst, os.path.join(d, "batch.txt")], capture_output=True, text=True, env=env)
