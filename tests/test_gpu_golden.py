@@ -153,3 +153,22 @@ def test_g2_plane_sets_against_the_reference_ransac(ctx):
             assert best > 0.95, (p, len(ref_set), best)
             exact += len(sets[best_q]) == len(ref_set)
         assert exact >= len(rc) - 3   # the supports are the same sets for (nearly) all planes
+
+
+def test_g2_plane_sets_on_the_real_room_scan(ctx):
+    """The same plane-set parity on a real, noisy scan (G9: sample_data/room_target.ply and the surrogate source cut
+    from it): every plane of both libransac draws is found by the GPU extraction with (nearly) the same support."""
+    g = load("g9_room.npz")
+    for cloud, pre in ((g["target"], "t"), (g["source"], "s")):
+        coef, off, idx = ctx.extract_planes(cloud, 625)   # below the smallest support the reference draws ended at
+        sets = [set(idx[off[p]:off[p + 1]].tolist()) for p in range(len(coef))]
+        for draw in ("", "b"):
+            rc, ro, ri = g[f"{pre}{draw}_coef"], g[f"{pre}{draw}_off"], g[f"{pre}{draw}_idx"]
+            assert int(np.diff(ro).min()) > 625
+            best = []
+            for p in range(len(rc)):
+                ref = set(ri[ro[p]:ro[p + 1]].tolist())
+                cand = [q for q in range(len(coef)) if abs(coef[q, :3] @ rc[p, :3]) > 0.99]
+                best.append(max([len(sets[q] & ref) / len(sets[q] | ref) for q in cand], default=0.0))
+            assert min(best) > 0.85, (pre, draw, best)
+            assert sum(b >= 0.97 for b in best) >= len(rc) - 1, (pre, draw, best)
