@@ -44,6 +44,11 @@ extern "C" void plade_ctx_destroy(plade_ctx *ctx) {
     if (ctx->ransac_work) plade::ransac_work_destroy(ctx->ransac_work);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
+    if (getenv("PLADE_DEBUG_ALLOC")) {
+        plade::AllocStats &as = plade::alloc_stats();
+        fprintf(stderr, "[plade] device allocations so far: %llu calls, %.1f MB, %.1f ms in hipMalloc\n", (unsigned long long)as.calls.load(),
+                as.bytes.load() / 1e6, as.nanos.load() / 1e6);
+    }
 }
 
 extern "C" const char *plade_last_error(const plade_ctx *ctx) { return ctx ? ctx->last_error.c_str() : "null ctx"; }

@@ -17,6 +17,7 @@
 #include <vector>
 #include <map>
 #include <chrono>
+#include <atomic>
 
 #define HD __host__ __device__ __forceinline__
 
@@ -84,6 +85,10 @@ struct Err {
         if (!(cond)) throw plade::Err{(code), std::string(text)}; \
     } while (0)
 
+// allocation statistics of this process (PLADE_DEBUG_ALLOC=1 prints them when a context is destroyed)
+struct AllocStats { std::atomic<uint64_t> calls{0}, bytes{0}, nanos{0}; };
+inline AllocStats &alloc_stats() { static AllocStats s; return s; }
+
 // grow-only device buffer
 template <class T>
 struct DBuf {
@@ -98,7 +103,11 @@ struct DBuf {
             if (p) HIP_TRY(hipFree(p));
             p = nullptr;
             size_t want = n + n / 4 + 64;
+            const auto t0 = std::chrono::steady_clock::now();
             HIP_TRY(hipMalloc((void **)&p, want * sizeof(T)));
+            AllocStats &as = alloc_stats();
+            as.calls += 1; as.bytes += want * sizeof(T);
+            as.nanos += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
             cap = want;
         }
         return p;
