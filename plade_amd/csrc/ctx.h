@@ -147,6 +147,9 @@ template <class F>
 int guarded(plade_ctx *ctx, F body) {
     if (!ctx) return PLADE_EINVAL;
     try {
+        // HIP's current device is per host thread (default 0): a context may be driven from any thread, so every
+        // entry point binds the calling thread to the context's GPU first (allocations follow the current device)
+        HIP_TRY(hipSetDevice(ctx->device));
         return body();
     } catch (const Err &e) {
         ctx->last_error = e.msg;

@@ -194,7 +194,7 @@ extern "C" int plade_cloud_upload(plade_ctx *ctx, const float *pos_nrm, uint32_t
 }
 
 extern "C" void plade_cloud_free(plade_ctx *ctx, plade_cloud *c) {
-    if (ctx) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx) { (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->stream); }
     delete c;
 }
 
