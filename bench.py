@@ -145,9 +145,9 @@ def main():
     ap.add_argument("--points", type=int, default=1000000)
     ap.add_argument("--pairs", type=int, default=2, help="distinct synthetic pairs per rank (cycled)")
     ap.add_argument("--host-wait", choices=["auto", "spin", "sleep"], default="auto",
-                    help="how the host threads wait for the GPU (plade_params.host_wait): spinning waits are ~3 %% faster "
-                         "but keep ~1.7 CPUs busy per registration in flight; auto = spin when this rank's share of the "
-                         "CPUs (cgroup quota / affinity, divided by the ranks on the node) allows it")
+                    help="how the host threads wait for the GPU (plade_params.host_wait): spinning waits keep ~1.7 CPUs busy "
+                         "per registration in flight, sleeping ones ~0.5 at the same throughput; auto = sleep when more "
+                         "than one registration is in flight")
     ap.add_argument("--inflight", type=int, default=8,
                     help="registrations in flight per GPU: independent pairs, one plade_ctx + host thread each "
                          "(a single registration is latency-bound and leaves most of the GPU idle)")
@@ -175,8 +175,9 @@ def main():
     import threading
     M = max(1, min(args.inflight, args.steps))
     if args.host_wait == "auto":
-        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
-        args.host_wait = "spin" if _cpu_budget() / max(1, local_world) >= 1.75 * M + 1 else "sleep"
+        # several registrations in flight: sleeping waits (same throughput, a third of the host CPUs, and no way to run
+        # into the container's CPU quota when 8 ranks share a node); one at a time: spin for the lowest latency
+        args.host_wait = "sleep" if M > 1 else "spin"
     host_wait = {"spin": 0, "sleep": 1}[args.host_wait]
     ctxs = [plade_amd.Context(local_rank, host_wait=host_wait) for _ in range(M)]
     ctx = ctxs[0]
@@ -271,6 +272,7 @@ def main():
     latency_ms = None
     if rank == 0:
         lat = []
+        ctx.set_params(host_wait=0)   # alone, a spinning wait is the faster one
         for i in range(4):   # one registration at a time: the latency figure
             t1 = time.perf_counter()
             step(i)
@@ -279,7 +281,7 @@ def main():
         ctx.set_params(dump=2)
         step(0)
         st = ctx.stats()
-        ctx.set_params(dump=0)
+        ctx.set_params(dump=0, host_wait=host_wait)
         kernels = sorted({k[2:-8] for k in st if k.startswith("k_") and k.endswith("_seconds")})
         best = None
         for name in kernels:
@@ -341,6 +343,7 @@ def main():
             "max_frobenius_vs_ground_truth_rank0": max(errs) if errs else None,
             "host_rank0": {"cpu_seconds_per_step": (cpu1 - cpu0) / args.steps,
                            "busy_host_threads_avg": (cpu1 - cpu0) / max(elapsed, 1e-9),
+                           "cpu_budget": _cpu_budget(),
                            "cgroup_throttled_periods": (thr1[0] - thr0[0]) if thr0 and thr1 else None,
                            "cgroup_throttled_usec": (thr1[1] - thr0[1]) if thr0 and thr1 else None},
             "roofline": roofline,

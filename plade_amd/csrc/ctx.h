@@ -99,22 +99,52 @@ struct plade_ctx {
     // polls the stream and sleeps in between.
     void sync(hipStream_t s = nullptr) {
         if (!s) s = stream;
-        if (params.host_wait == 0) { HIP_TRY(hipStreamSynchronize(s)); return; }
-        plade::relax_timer_slack();
-        for (int polls = 0;; ++polls) {
-            const hipError_t e = hipStreamQuery(s);
-            if (e == hipSuccess) return;
-            if (e != hipErrorNotReady) throw plade::Err{-2, std::string("hipStreamQuery: ") + hipGetErrorString(e)};
-            timespec ts{0, polls < 8 ? 15000 : 40000};
-            nanosleep(&ts, nullptr);
+        if (params.host_wait == 0) { HIP_TRY(hipStreamSynchronize(s)); }
+        else {
+            plade::relax_timer_slack();
+            for (int polls = 0;; ++polls) {
+                const hipError_t e = hipStreamQuery(s);
+                if (e == hipSuccess) break;
+                if (e != hipErrorNotReady) throw plade::Err{-2, std::string("hipStreamQuery: ") + hipGetErrorString(e)};
+                timespec ts{0, polls < 8 ? 15000 : 40000};
+                nanosleep(&ts, nullptr);
+            }
         }
+        if (s == stream) finish_reads();
     }
-    // Device -> host readback on this ctx's stream.  A copy into pageable host memory makes the HIP runtime wait
-    // (spinning) for everything queued before it, so in host_wait = 1 mode the stream is drained with sleeping
-    // polls first and only the copy itself is waited for actively.
+    // Device -> host readback on this ctx's stream; `dst` is valid after the next sync().  A copy into pageable host
+    // memory makes the HIP runtime wait (spinning) for everything queued before it and bounce the data through its own
+    // staging buffer; small readbacks (there are ~40 per registration) therefore go to a pinned arena of this context
+    // as truly asynchronous copies and are handed to their destinations by sync().
+    struct PendingRead { void *dst; size_t off, bytes; };
+    std::vector<PendingRead> pending_reads;
+    plade::HBuf<char> read_arena;
+    size_t read_arena_used = 0;
+    static constexpr size_t READ_ARENA_BYTES = 8u << 20, READ_DIRECT_BYTES = 2u << 20;
     void d2h(void *dst, const void *src, size_t bytes) {
-        if (params.host_wait != 0) sync();
-        HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, stream));
+        if (!bytes) return;
+        const size_t need = (bytes + 255) & ~(size_t)255;
+        if (bytes > READ_DIRECT_BYTES || read_arena_used + need > READ_ARENA_BYTES) {
+            if (params.host_wait != 0) sync();   // drain with sleeping polls first: only the copy itself is waited for actively
+            HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, stream));
+            return;
+        }
+        char *a = read_arena.ensure(READ_ARENA_BYTES);
+        HIP_TRY(hipMemcpyAsync(a + read_arena_used, src, bytes, hipMemcpyDeviceToHost, stream));
+        pending_reads.push_back(PendingRead{dst, read_arena_used, bytes});
+        read_arena_used += need;
+    }
+    // forget the queued hand-overs (their destinations may be gone): after an error, and before every call
+    void drop_reads() {
+        if (!pending_reads.empty()) (void)hipStreamSynchronize(stream);   // the copies themselves still target the arena
+        pending_reads.clear();
+        read_arena_used = 0;
+        if (aux) aux->drop_reads();
+    }
+    void finish_reads() {
+        for (const PendingRead &r : pending_reads) memcpy(r.dst, read_arena.p + r.off, r.bytes);
+        pending_reads.clear();
+        read_arena_used = 0;
     }
     // generic scratch
     plade::DBuf<char> scratch[8];
@@ -150,11 +180,14 @@ int guarded(plade_ctx *ctx, F body) {
         // HIP's current device is per host thread (default 0): a context may be driven from any thread, so every
         // entry point binds the calling thread to the context's GPU first (allocations follow the current device)
         HIP_TRY(hipSetDevice(ctx->device));
+        ctx->drop_reads();   // nothing may be pending from a call that ended in an error
         return body();
     } catch (const Err &e) {
+        ctx->drop_reads();
         ctx->last_error = e.msg;
         return e.code;
     } catch (const std::exception &e) {
+        ctx->drop_reads();
         ctx->last_error = e.what();
         return PLADE_EDEVICE;
     }
