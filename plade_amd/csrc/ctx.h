@@ -110,7 +110,7 @@ struct plade_ctx {
                 nanosleep(&ts, nullptr);
             }
         }
-        if (s == stream) finish_reads();
+        if (s == stream) { finish_reads(); write_arena_used = 0; }
     }
     // Device -> host readback on this ctx's stream; `dst` is valid after the next sync().  A copy into pageable host
     // memory makes the HIP runtime wait (spinning) for everything queued before it and bounce the data through its own
@@ -134,11 +134,29 @@ struct plade_ctx {
         pending_reads.push_back(PendingRead{dst, read_arena_used, bytes});
         read_arena_used += need;
     }
+    // Host -> device upload of a small table: staged in the pinned arena so that the copy is asynchronous (a pageable
+    // source makes the runtime copy it to its own staging buffer and, for some sizes, wait for the transfer).
+    plade::HBuf<char> write_arena;
+    size_t write_arena_used = 0;
+    void h2d(void *dst, const void *src, size_t bytes) {
+        if (!bytes) return;
+        const size_t need = (bytes + 255) & ~(size_t)255;
+        if (bytes > READ_DIRECT_BYTES || write_arena_used + need > READ_ARENA_BYTES) {
+            HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream));
+            return;
+        }
+        char *a = write_arena.ensure(READ_ARENA_BYTES) + write_arena_used;
+        memcpy(a, src, bytes);
+        HIP_TRY(hipMemcpyAsync(dst, a, bytes, hipMemcpyHostToDevice, stream));
+        write_arena_used += need;
+    }
     // forget the queued hand-overs (their destinations may be gone): after an error, and before every call
     void drop_reads() {
         if (!pending_reads.empty()) (void)hipStreamSynchronize(stream);   // the copies themselves still target the arena
+        else if (write_arena_used) (void)hipStreamSynchronize(stream);
         pending_reads.clear();
         read_arena_used = 0;
+        write_arena_used = 0;
         if (aux) aux->drop_reads();
     }
     void finish_reads() {

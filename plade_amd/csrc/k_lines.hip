@@ -128,7 +128,7 @@ void build_pair_table(plade_ctx *ctx, const LineTableHost &lt, const float *norm
     }
     memcpy(&blob[o_nrm], normals, 12 * (size_t)P);
     uint32_t *d = out.d_blob.ensure(words + 4);
-    HIP_TRY(hipMemcpyAsync(d, blob.data(), 4 * words, hipMemcpyHostToDevice, ctx->stream));
+    ctx->h2d(d, blob.data(), 4 * words);
     out.all_desc.ensure(n * 8); out.all_lv1.ensure(n * 3); out.all_lv2.ensure(n * 3); out.all_p1.ensure(n * 3);
     out.flags.ensure(n + 1); out.pos.ensure(n + 1);
     LinesView v{reinterpret_cast<const float *>(d + o_pt), reinterpret_cast<const int32_t *>(d + o_sp),

@@ -386,8 +386,8 @@ extern "C" int plade_match_descriptors(plade_ctx *ctx, const float *src, uint32_
         PLADE_REQUIRE(offsets && n_pairs && (src || !ds) && (tgt || !dt), PLADE_EINVAL, "plade_match_descriptors: null argument");
         DBuf<float> d_q, d_t;
         d_q.ensure((size_t)ds * 8 + 8); d_t.ensure((size_t)dt * 8 + 8);
-        if (ds) HIP_TRY(hipMemcpyAsync(d_q.p, src, (size_t)ds * 32, hipMemcpyHostToDevice, ctx->stream));
-        if (dt) HIP_TRY(hipMemcpyAsync(d_t.p, tgt, (size_t)dt * 32, hipMemcpyHostToDevice, ctx->stream));
+        if (ds) ctx->h2d(d_q.p, src, (size_t)ds * 32);
+        if (dt) ctx->h2d(d_t.p, tgt, (size_t)dt * 32);
         MatchResult r;
         uint64_t total = r.run(ctx, d_q.p, ds, d_t.p, dt, radius);
         *n_pairs = total;

@@ -114,7 +114,7 @@ void TargetGrid::build(plade_ctx *ctx, const float *d_xyz, uint32_t n_pts, uint3
         iinit[3 + k] = ib >= 0 ? ib : ib ^ 0x7fffffff;
     }
     bbox.ensure(6);
-    HIP_TRY(hipMemcpyAsync(bbox.p, iinit, 24, hipMemcpyHostToDevice, ctx->stream));
+    ctx->h2d(bbox.p, iinit, 24);
     hipLaunchKernelGGL(k_minmax3, dim3(std::min(cdiv(n, 256), 1024u)), dim3(256), 0, ctx->stream, d_xyz, n, stride,
                        bbox.p);
     int ih[6];
@@ -383,10 +383,10 @@ extern "C" int plade_overlap_counts(plade_ctx *ctx, const float *src_ds, uint32_
         DBuf<uint32_t> d_any;
         d_src.ensure((size_t)n_s * 3 + 4); d_tgt.ensure((size_t)n_t * 3 + 4); d_soa.ensure((size_t)n_s * 3 + 4);
         d_T.ensure((size_t)k * 16 + 4); d_c.ensure((size_t)k * 3 + 4); d_counts.ensure(k + 1); d_any.ensure(k + 1);
-        HIP_TRY(hipMemcpyAsync(d_src.p, src_ds, (size_t)n_s * 12, hipMemcpyHostToDevice, ctx->stream));
-        HIP_TRY(hipMemcpyAsync(d_tgt.p, tgt_ds, (size_t)n_t * 12, hipMemcpyHostToDevice, ctx->stream));
-        HIP_TRY(hipMemcpyAsync(d_T.p, T, (size_t)k * 64, hipMemcpyHostToDevice, ctx->stream));
-        HIP_TRY(hipMemcpyAsync(d_c.p, centers, (size_t)k * 12, hipMemcpyHostToDevice, ctx->stream));
+        ctx->h2d(d_src.p, src_ds, (size_t)n_s * 12);
+        ctx->h2d(d_tgt.p, tgt_ds, (size_t)n_t * 12);
+        ctx->h2d(d_T.p, T, (size_t)k * 64);
+        ctx->h2d(d_c.p, centers, (size_t)k * 12);
         deinterleave3(ctx, d_src.p, n_s, d_soa.p, d_soa.p + n_s, d_soa.p + 2 * (size_t)n_s);
         TargetGrid grid;
         grid.build(ctx, d_tgt.p, n_t, 3, inlier_dist, nullptr, nullptr, true);

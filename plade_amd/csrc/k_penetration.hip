@@ -177,7 +177,7 @@ void build_pen_grid(plade_ctx *ctx, PlaneCloudsDev &pc, const PlaneGeomHost &geo
     pc.n_cells = total;
     pc.grid_cell = cell;
     pc.frames.ensure(P);
-    HIP_TRY(hipMemcpyAsync(pc.frames.p, fr.data(), P * sizeof(PenFrame), hipMemcpyHostToDevice, ctx->stream));
+    ctx->h2d(pc.frames.p, fr.data(), P * sizeof(PenFrame));
     pc.cell_pts.ensure((size_t)n + 1);
     pc.cell_start.ensure((size_t)total + 2);
     pc.ckeys.ensure((size_t)n + 1); pc.ckeys2.ensure((size_t)n + 1); pc.cvals.ensure((size_t)n + 1); pc.cvals2.ensure((size_t)n + 1);
@@ -358,7 +358,7 @@ void penetration_filter(plade_ctx *ctx, const float *cand_rt_host, uint32_t K, c
     float *o_tcen = p; memcpy(p, tgt.center.data(), 12 * (size_t)tgt.P); p += 3 * (size_t)tgt.P;
     float *o_tf = p; memcpy(p, tgt.four.data(), 48 * (size_t)tgt.P); p += 12 * (size_t)tgt.P;
     float *d = reinterpret_cast<float *>(ctx->scratch[4].ensure(nf * 4 + 64));
-    HIP_TRY(hipMemcpyAsync(d, h.data(), nf * 4, hipMemcpyHostToDevice, ctx->stream));
+    ctx->h2d(d, h.data(), nf * 4);
     PenTables tb;
     tb.cand = d + (o_cand - h.data()); tb.s_coef = d + (o_sc - h.data()); tb.s_center = d + (o_scen - h.data());
     tb.s_four = d + (o_sf - h.data()); tb.t_coef = d + (o_tc - h.data()); tb.t_center = d + (o_tcen - h.data());
@@ -388,13 +388,13 @@ void penetration_filter(plade_ctx *ctx, const float *cand_rt_host, uint32_t K, c
         for (uint32_t i = 0; i < n_pairs; ++i) order[i] = i;
         std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return w[a] > w[b]; });
     }
-    HIP_TRY(hipMemcpyAsync(d_order, order.data(), 4 * (size_t)n_pairs, hipMemcpyHostToDevice, ctx->stream));
+    ctx->h2d(d_order, order.data(), 4 * (size_t)n_pairs);
     std::vector<float> steps(PEN_MAXS + 1);
     {
         float dist = 0;
         for (int i = 0; i <= PEN_MAXS; ++i) { steps[i] = dist; dist += search_radius; }  // util.cpp:1383
     }
-    HIP_TRY(hipMemcpyAsync(d_steps, steps.data(), steps.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    ctx->h2d(d_steps, steps.data(), steps.size() * 4);
     hipLaunchKernelGGL(k_pen_setup, dim3(cdiv(total, 256)), dim3(256), 0, ctx->stream, tb, length_threshold,
                        angle_threshold, d_items, d_n, d_pair);
     // in-plane grids of both sides (cell = 2 r)

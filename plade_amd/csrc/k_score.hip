@@ -385,7 +385,7 @@ void cloud_upload(plade_ctx *ctx, const float *pos_nrm, uint32_t n, CloudDev &ou
     out.soa.ensure(6 * out.pitch + 4);
     if (n == 0) return;
     float *stage = out.aos.ensure((size_t)n * 6 + 8);
-    HIP_TRY(hipMemcpyAsync(stage, pos_nrm, (size_t)n * 24, hipMemcpyHostToDevice, ctx->stream));
+    ctx->h2d(stage, pos_nrm, (size_t)n * 24);
     hipLaunchKernelGGL(k_aos_to_soa, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, stage, n, out.pitch, out.soa.p);
     HIP_TRY(hipGetLastError());
     bbox_host(ctx, stage, n, 6, out.bbmin, out.bbmax);
@@ -406,11 +406,11 @@ extern "C" int plade_score_planes(plade_ctx *ctx, const float *pos_nrm, const in
         DBuf<int32_t> d_assigned;
         if (shape_index) {
             d_assigned.ensure((size_t)n + 4);
-            HIP_TRY(hipMemcpyAsync(d_assigned.p, shape_index, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+            ctx->h2d(d_assigned.p, shape_index, (size_t)n * 4);
         }
         DBuf<float4> d_planes;
         d_planes.ensure(h);
-        HIP_TRY(hipMemcpyAsync(d_planes.p, planes, (size_t)h * 16, hipMemcpyHostToDevice, ctx->stream));
+        ctx->h2d(d_planes.p, planes, (size_t)h * 16);
         DBuf<uint32_t> d_counts;
         d_counts.ensure(h + 1);
         score_multi(ctx, cloud.x(), cloud.y(), cloud.z(), cloud.nx(), cloud.ny(), cloud.nz(),

@@ -134,7 +134,7 @@ uint32_t VoxelWork::run(plade_ctx *ctx, const float *d_xyz, uint32_t stride, con
                        keys2.p, vals2.p, heads.p, n_seg, n_items, bx + by + bz, out_xyz.p, seg_group.p);
     group_offsets.ensure((size_t)n_groups + 2);
     std::vector<uint32_t> init(n_groups + 1, n_seg);
-    HIP_TRY(hipMemcpyAsync(group_offsets.p, init.data(), (n_groups + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+    ctx->h2d(group_offsets.p, init.data(), (n_groups + 1) * 4);
     hipLaunchKernelGGL(k_group_offsets, dim3(cdiv(n_seg, 256)), dim3(256), 0, ctx->stream, seg_group.p, n_seg, n_groups,
                        group_offsets.p);
     hipLaunchKernelGGL(k_fix_offsets, dim3(1), dim3(1), 0, ctx->stream, group_offsets.p, n_groups, n_seg);
@@ -334,7 +334,7 @@ void bbox_host(plade_ctx *ctx, const float *d_xyz, uint32_t n, uint32_t stride, 
     for (int k = 0; k < 3; ++k) { init[k] = a; init[3 + k] = b ^ 0x7fffffff; }
     init[6] = init[7] = 0;
     int *d = reinterpret_cast<int *>(ctx->scratch[3].ensure(64));
-    HIP_TRY(hipMemcpyAsync(d, init, 32, hipMemcpyHostToDevice, ctx->stream));
+    ctx->h2d(d, init, 32);
     if (n) hipLaunchKernelGGL(k_minmax3_v, dim3(std::min(cdiv(n, 1024), 1024u)), dim3(256), 0, ctx->stream, d_xyz, n, stride, d);
     int out[8];
     ctx->d2h(out, d, 32);
@@ -362,7 +362,7 @@ extern "C" int plade_average_spacing(plade_ctx *ctx, const float *xyz, uint32_t 
         if (n == 0) return PLADE_OK;
         DBuf<float> d_in;
         d_in.ensure((size_t)n * stride + 4);
-        HIP_TRY(hipMemcpyAsync(d_in.p, xyz, (size_t)n * stride * 4, hipMemcpyHostToDevice, ctx->stream));
+        ctx->h2d(d_in.p, xyz, (size_t)n * stride * 4);
         float mn[3], mx[3];
         bbox_host(ctx, d_in.p, n, stride, mn, mx);
         TargetGrid grid;
@@ -379,7 +379,7 @@ extern "C" int plade_voxel_downsample(plade_ctx *ctx, const float *xyz, uint32_t
         if (n == 0) return PLADE_OK;
         DBuf<float> d_in;
         d_in.ensure((size_t)n * stride + 4);
-        HIP_TRY(hipMemcpyAsync(d_in.p, xyz, (size_t)n * stride * 4, hipMemcpyHostToDevice, ctx->stream));
+        ctx->h2d(d_in.p, xyz, (size_t)n * stride * 4);
         float mn[3], mx[3];
         bbox_host(ctx, d_in.p, n, stride, mn, mx);
         VoxelWork w;

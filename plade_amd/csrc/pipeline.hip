@@ -109,8 +109,8 @@ bool prepare_side(plade_ctx *ctx, const char *tag, const CloudDev &cloud, const 
     const uint32_t n_items = (uint32_t)pl.offsets[P];
     S.d_items.ensure((size_t)n_items + 4); S.d_groups.ensure((size_t)n_items + 4); S.d_offs.ensure((size_t)P + 2);
     if (pl.d_idx) HIP_TRY(hipMemcpyAsync(S.d_items.p, pl.d_idx, 4 * (size_t)n_items, hipMemcpyDeviceToDevice, ctx->stream));
-    else HIP_TRY(hipMemcpyAsync(S.d_items.p, pl.idx, 4 * (size_t)n_items, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(S.d_offs.p, pl.offsets, 4 * ((size_t)P + 1), hipMemcpyHostToDevice, ctx->stream));
+    else ctx->h2d(S.d_items.p, pl.idx, 4 * (size_t)n_items);
+    ctx->h2d(S.d_offs.p, pl.offsets, 4 * ((size_t)P + 1));
     if (n_items)
         hipLaunchKernelGGL(k_expand_groups, dim3(cdiv(n_items, 256)), dim3(256), 0, ctx->stream, S.d_offs.p, P, n_items,
                            S.d_groups.p);
@@ -395,7 +395,7 @@ bool run_registration(plade_ctx *ctx, RegistrationWork &W, const CloudDev &tgt, 
         for (uint32_t i = 0; i < K; ++i) ids[i] = seeds[cand_cluster[tested[i]]];
         W.d_ids.ensure(K);
         W.d_rt12.ensure(12 * (size_t)K);
-        HIP_TRY(hipMemcpyAsync(W.d_ids.p, ids.data(), 4 * (size_t)K, hipMemcpyHostToDevice, ctx->stream));
+        ctx->h2d(W.d_ids.p, ids.data(), 4 * (size_t)K);
         hipLaunchKernelGGL(k_gather_rt, dim3(cdiv(K, 64)), dim3(64), 0, ctx->stream, W.cand.rt.p, W.d_ids.p, K, W.d_rt12.p);
         ctx->d2h(rt12.data(), W.d_rt12.p, 48 * (size_t)K);
         ctx->sync();
@@ -428,8 +428,8 @@ bool run_registration(plade_ctx *ctx, RegistrationWork &W, const CloudDev &tgt, 
     {
         StageTimer t(ctx, "t_verify");
         W.d_T16.ensure(16 * (size_t)Kv); W.d_centers.ensure(3 * (size_t)Kv); W.d_counts.ensure(Kv); W.d_any.ensure(Kv);
-        HIP_TRY(hipMemcpyAsync(W.d_T16.p, T16.data(), 64 * (size_t)Kv, hipMemcpyHostToDevice, ctx->stream));
-        HIP_TRY(hipMemcpyAsync(W.d_centers.p, centers.data(), 12 * (size_t)Kv, hipMemcpyHostToDevice, ctx->stream));
+        ctx->h2d(W.d_T16.p, T16.data(), 64 * (size_t)Kv);
+        ctx->h2d(W.d_centers.p, centers.data(), 12 * (size_t)Kv);
         HIP_TRY(hipStreamWaitEvent(ctx->stream, W.ev_grid, 0));
         overlap_counts(ctx, W.ov_work, W.ov_work.sorted.p, W.ov_work.sorted.p + C.n_ds, W.ov_work.sorted.p + 2 * (size_t)C.n_ds, C.n_ds,
                        W.grid, W.d_T16.p,

@@ -906,12 +906,12 @@ void plane_component(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const
     dist += point[1] * normal[1];
     dist += point[2] * normal[2];
     const float4 two[2] = {make_float4(normal[0], normal[1], normal[2], dist), make_float4(point[0], point[1], point[2], 0.f)};
-    HIP_TRY(hipMemcpyAsync(W.cand_in.p, two, 32, hipMemcpyHostToDevice, st));
+    ctx->h2d(W.cand_in.p, two, 32);
     hipLaunchKernelGGL(k_state_from_hyp, dim3(1), dim3(64), 0, st, W.tab);
     // the list as an all-ones mask over list positions, values = the caller's indices
     DBuf<uint32_t> d_idx;
     d_idx.ensure((size_t)n + 4);
-    HIP_TRY(hipMemcpyAsync(d_idx.p, idx, 4 * (size_t)m, hipMemcpyHostToDevice, st));
+    ctx->h2d(d_idx.p, idx, 4 * (size_t)m);
     const uint32_t nb4 = cdiv(n, 1024);
     hipLaunchKernelGGL(k_list_masks, dim3(cdiv(nb4 * 256, 256)), dim3(256), 0, st, m, nb4, C.cs.masks.p, C.cs.block_counts.p);
     const CompactJob hj{C.cs.masks.p, C.cs.block_counts.p, d_idx.p, D.idxA, D.cntA, nullptr, D.st[0].pos, D.uv, D.bbpart};
@@ -1058,7 +1058,7 @@ void ransac_detect(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const R
             std::vector<float4> pl(TOP + TOP / 4, make_float4(0.f, 0.f, 0.f, 0.f));
             for (uint32_t i = 0; i < np; ++i) pl[i] = pool[i].pl;
             uint32_t *top_counts = reinterpret_cast<uint32_t *>(W.top.p + TOP);
-            HIP_TRY(hipMemcpyAsync(W.top.p, pl.data(), pl.size() * 16, hipMemcpyHostToDevice, ctx->stream));
+            ctx->h2d(W.top.p, pl.data(), pl.size() * 16);
             score_multi(ctx, c.x(), c.y(), c.z(), c.nx(), c.ny(), c.nz(), W.assigned.p, nullptr, n, W.top.p, np, eps, cos_t,
                         top_counts, true);
             ++n_full_passes;
@@ -1084,7 +1084,7 @@ void ransac_detect(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const R
             const uint32_t nc = (uint32_t)batch.size();
             std::vector<float4> h_in(2 * nc);
             for (uint32_t b = 0; b < nc; ++b) { h_in[2 * b] = pool[batch[b]].pl; h_in[2 * b + 1] = pool[batch[b]].pos; }
-            HIP_TRY(hipMemcpyAsync(W.cand_in.p, h_in.data(), 32 * nc, hipMemcpyHostToDevice, ctx->stream));
+            ctx->h2d(W.cand_in.p, h_in.data(), 32 * nc);
             if (hipGraphExec_t g = accept_graph(ctx, W, cv, nc, eps3, cos_t, bitmap_eps)) HIP_TRY(hipGraphLaunch(g, ctx->stream));
             else enqueue_accept(ctx, W, cv, nc, eps3, cos_t, bitmap_eps);
             ctx->d2h(W.pinned_accept.p, W.accept_block.p, nc * ACCEPT_STRIDE);

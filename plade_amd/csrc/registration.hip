@@ -280,8 +280,8 @@ extern "C" int plade_sort_pairs(plade_ctx *ctx, const void *keys, const uint32_t
         DBuf<char> ki, ko;
         DBuf<uint32_t> vi, vo;
         ki.ensure((size_t)n * key_bytes); ko.ensure((size_t)n * key_bytes); vi.ensure(n); vo.ensure(n);
-        HIP_TRY(hipMemcpyAsync(ki.p, keys, (size_t)n * key_bytes, hipMemcpyHostToDevice, ctx->stream));
-        HIP_TRY(hipMemcpyAsync(vi.p, vals, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+        ctx->h2d(ki.p, keys, (size_t)n * key_bytes);
+        ctx->h2d(vi.p, vals, (size_t)n * 4);
         if (key_bytes == 4) sort_pairs_u32(ctx, (const uint32_t *)ki.p, (uint32_t *)ko.p, vi.p, vo.p, n, bits);
         else sort_pairs_u64(ctx, (const uint64_t *)ki.p, (uint64_t *)ko.p, vi.p, vo.p, n, bits);
         ctx->d2h(keys_out, ko.p, (size_t)n * key_bytes);
