@@ -497,22 +497,37 @@ __global__ __launch_bounds__(256) void k_cc_select(CloudView c, const ChainTab c
     const uint32_t base = blockIdx.x * 1024 + threadIdx.x * 4;
     uint32_t mk = 0, cnt = 0;
     double a[FIT_COLS] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    // two rounds of independent loads (list entries, then everything they point to) instead of a chain of four:
+    // nearly every listed point is kept, so the coordinates are fetched before the label test is known
+    uint32_t bi[4], pi[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const uint32_t i = base + q;
-        const bool in = i < m && best != 0xffffffffu && label[bidx[i]] == best;
+        const uint32_t i = min(base + q, m - 1);
+        bi[q] = bidx[i];
+        pi[q] = idx[i];
+    }
+    uint32_t lb[4];
+    float fx[4], fy[4], fz[4], gx[4], gy[4], gz[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        lb[q] = label[bi[q]];
+        const uint32_t p = pi[q];
+        fx[q] = c.x[p]; fy[q] = c.y[p]; fz[q] = c.z[p];
+        gx[q] = c.nx[p]; gy[q] = c.ny[p]; gz[q] = c.nz[p];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const bool in = base + q < m && best != 0xffffffffu && lb[q] == best;
         mk |= (in ? 1u : 0u) << q;
         cnt += (uint32_t)__popcll(__ballot(in));
         if (in) {
-            const uint32_t p = idx[i];
-            const float fx = c.x[p], fy = c.y[p], fz = c.z[p];
-            const double x = fx, y = fy, z = fz;
+            const double x = fx[q], y = fy[q], z = fz[q];
             a[0] += x; a[1] += y; a[2] += z;
             a[3] += x * x; a[4] += x * y; a[5] += x * z; a[6] += y * y; a[7] += y * z; a[8] += z * z;
-            a[9] += c.nx[p]; a[10] += c.ny[p]; a[11] += c.nz[p];
-            float d = n0 * fx;
-            d += n1 * fy;
-            d += n2 * fz;
+            a[9] += gx[q]; a[10] += gy[q]; a[11] += gz[q];
+            float d = n0 * fx[q];
+            d += n1 * fy[q];
+            d += n2 * fz[q];
             d = fabsf(dist - d);
             a[12] += (double)expf(-d * d / (2.f / 9.f * eps * eps));
         }
