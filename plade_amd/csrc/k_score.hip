@@ -230,20 +230,43 @@ __global__ __launch_bounds__(TPB) void k_compact_batch(const CompactJobs jobs, u
     __shared__ uint32_t s_base[TPB / 64];
     __shared__ float s_mm[4][8];
     const CompactJob jb = jobs.j[blockIdx.y];
-    if (jb.skip && *jb.skip) return;
+    // round 1 of loads, all independent: skip flag, this tile's count, its mask bytes, the plane frame (a chain of
+    // early exits, each behind its own global load, used to cost four round trips before the first gather)
+    const uint32_t skip = jb.skip ? *jb.skip : 0u;
+    const uint32_t mine = jb.block_counts[blockIdx.x];
+    const uint32_t m = jb.masks[blockIdx.x * TPB + threadIdx.x];
+    float fr[10];
+    if (jb.frame) {
+#pragma unroll
+        for (int q = 0; q < 10; ++q) fr[q] = jb.frame[q];
+    }
+    if (skip) return;
     // most tiles of a plane's score list are empty: nothing to place (the last tile still reports the total)
-    if (jb.block_counts[blockIdx.x] == 0 && blockIdx.x != nb - 1) return;
+    if (mine == 0 && blockIdx.x != nb - 1) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t first = blockIdx.x * TILE + threadIdx.x * PPT;
+    // round 2: the preceding tiles' counts and what the kept entries point to
     uint32_t pre = 0;
-    {   // sum of the preceding tiles' counts, four per load (the count arrays are 16-byte aligned)
+    {   // four counts per load (the count arrays are 16-byte aligned)
         const uint32_t full = blockIdx.x & ~3u;
         const uint4 *c4 = reinterpret_cast<const uint4 *>(jb.block_counts);
         for (uint32_t q = threadIdx.x; q < full / 4; q += TPB) { const uint4 v = c4[q]; pre += (v.x + v.y) + (v.z + v.w); }
         if (threadIdx.x < blockIdx.x - full) pre += jb.block_counts[full + threadIdx.x];
     }
+    uint32_t pv[PPT];
+    float cx[PPT], cy[PPT], cz[PPT];
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        pv[k] = first + k;
+        if ((m & (1u << k)) && jb.values) pv[k] = jb.values[first + k];
+    }
+    if (jb.frame) {
+#pragma unroll
+        for (int k = 0; k < PPT; ++k)
+            if (m & (1u << k)) { cx[k] = px[pv[k]]; cy[k] = py[pv[k]]; cz[k] = pz[pv[k]]; }
+    }
     for (int d = 32; d >= 1; d >>= 1) pre += __shfl_xor(pre, d, 64);
     if (lane == 0) s_base[wave] = pre;
-    const uint32_t m = jb.masks[blockIdx.x * TPB + threadIdx.x];
     const uint32_t c = __popc(m);
     uint32_t incl = c;
 #pragma unroll
@@ -257,28 +280,22 @@ __global__ __launch_bounds__(TPB) void k_compact_batch(const CompactJobs jobs, u
     uint32_t off = base + incl - c;
     for (int w = 0; w < wave; ++w) off += s_w[w];
     if (blockIdx.x == nb - 1 && threadIdx.x == TPB - 1) *jb.total = off + c;
-    const uint32_t first = blockIdx.x * TILE + threadIdx.x * PPT;
     if (!jb.frame) {
 #pragma unroll
         for (int k = 0; k < PPT; ++k)
-            if (m & (1u << k)) {
-                uint32_t i = first + k;
-                jb.out[off++] = jb.values ? jb.values[i] : i;
-            }
+            if (m & (1u << k)) jb.out[off++] = pv[k];
         return;
     }
-    const float ox = jb.frame[0], oy = jb.frame[1], oz = jb.frame[2];
-    const float a00 = jb.frame[4], a01 = jb.frame[5], a02 = jb.frame[6], a10 = jb.frame[7], a11 = jb.frame[8], a12 = jb.frame[9];
+    const float ox = fr[0], oy = fr[1], oz = fr[2];
+    const float a00 = fr[4], a01 = fr[5], a02 = fr[6], a10 = fr[7], a11 = fr[8], a12 = fr[9];
     float mn[2] = {INFINITY, INFINITY}, mx[2] = {-INFINITY, -INFINITY};
 #pragma unroll
     for (int k = 0; k < PPT; ++k)
         if (m & (1u << k)) {
-            const uint32_t i = first + k;
-            const uint32_t p = jb.values ? jb.values[i] : i;
-            const float pp[3] = {px[p] - ox, py[p] - oy, pz[p] - oz};
+            const float pp[3] = {cx[k] - ox, cy[k] - oy, cz[k] - oz};
             const float u = pp[0] * a00 + pp[1] * a01 + pp[2] * a02;
             const float v = pp[0] * a10 + pp[1] * a11 + pp[2] * a12;
-            jb.out[off] = p;
+            jb.out[off] = pv[k];
             jb.uv[off] = make_float2(u, v);
             ++off;
             mn[0] = fminf(mn[0], u); mn[1] = fminf(mn[1], v);
