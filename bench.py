@@ -140,8 +140,8 @@ def _cgroup_throttle():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=64)
-    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=512)
+    ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--points", type=int, default=1000000)
     ap.add_argument("--pairs", type=int, default=2, help="distinct synthetic pairs per rank (cycled)")
     ap.add_argument("--host-wait", choices=["auto", "spin", "sleep"], default="auto",

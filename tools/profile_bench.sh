@@ -7,7 +7,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out
 mkdir -p $O
 cd $R
-timeout 900 python bench.py --steps 64 --warmup 8 > $O/bench_r1.json 2> $O/bench_r1.err
+timeout 900 python bench.py > $O/bench_r1.json 2> $O/bench_r1.err
 tail -c 3000 $O/bench_r1.json
 cd /tmp && export TMPDIR=/tmp
 CMD="python $R/bench.py --steps 32 --warmup 8 --no-cpu-baseline"
