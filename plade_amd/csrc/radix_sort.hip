@@ -30,16 +30,19 @@ constexpr int RS_MAXP = 8;
 constexpr int RS_LOOK = 8;                      // predecessors fetched per look-back round
 constexpr uint32_t RS_AGG = 1u << 30, RS_PREFIX = 2u << 30, RS_VALUE = (1u << 30) - 1;
 
-template <class K>
-__device__ __forceinline__ uint32_t digit_of(K key, int shift) { return (uint32_t)(key >> shift) & 255u; }
+// Digits are 8 bits wide, or 9 where that saves a pass (25-27, 17-18 significant bits: the voxel and cell grids):
+// 512 bins are one per lane of the 512-lane workgroup.
+template <int DB, class K>
+__device__ __forceinline__ uint32_t digit_of(K key, int shift) { return (uint32_t)(key >> shift) & ((1u << DB) - 1u); }
 
 // part[b][p][d]: keys of digit d at place p seen by workgroup b
-template <class K>
+template <class K, int DB>
 __global__ __launch_bounds__(RS_THREADS) void k_rs_histogram(const K *__restrict__ keys, uint32_t n, int passes,
                                                              uint32_t *__restrict__ part, uint32_t *__restrict__ tile_ctr,
                                                              uint32_t *__restrict__ look, size_t look_words) {
-    __shared__ uint32_t s_h[RS_MAXP * 256];
-    for (int i = threadIdx.x; i < passes * 256; i += RS_THREADS) s_h[i] = 0;
+    constexpr int NB = 1 << DB;
+    __shared__ uint32_t s_h[RS_MAXP * NB];
+    for (int i = threadIdx.x; i < passes * NB; i += RS_THREADS) s_h[i] = 0;
     // clear what the passes will use
     for (size_t i = (size_t)blockIdx.x * RS_THREADS + threadIdx.x; i < look_words; i += (size_t)RS_HBLOCKS * RS_THREADS) look[i] = 0;
     if (blockIdx.x == 0 && threadIdx.x < RS_MAXP) tile_ctr[threadIdx.x] = 0;
@@ -57,33 +60,35 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_histogram(const K *__restrict
 #pragma unroll
         for (int j = 0; j < 8; ++j)
             if (i0 + j * RS_THREADS + threadIdx.x < b1)
-                for (int p = 0; p < passes; ++p) atomicAdd(&s_h[p * 256 + digit_of(k[j], 8 * p)], 1u);
+                for (int p = 0; p < passes; ++p) atomicAdd(&s_h[p * NB + digit_of<DB>(k[j], DB * p)], 1u);
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < passes * 256; i += RS_THREADS) part[(size_t)blockIdx.x * (RS_MAXP * 256) + i] = s_h[i];
+    for (int i = threadIdx.x; i < passes * NB; i += RS_THREADS) part[(size_t)blockIdx.x * (RS_MAXP * NB) + i] = s_h[i];
 }
 
-template <class K>
+template <class K, int DB>
 __global__ __launch_bounds__(RS_THREADS) void k_rs_pass(const K *__restrict__ kin, K *__restrict__ kout,
                                                         const uint32_t *__restrict__ vin, uint32_t *__restrict__ vout,
                                                         uint32_t n, int pass, const uint32_t *__restrict__ part,
                                                         uint32_t *__restrict__ tile_ctr, uint32_t *__restrict__ look) {
+    constexpr int NB = 1 << DB;
+    static_assert(NB <= RS_THREADS, "one lane per digit");
     __shared__ K s_keys[RS_TILE];
     __shared__ uint32_t s_vals[RS_TILE];
-    __shared__ uint32_t s_cnt[RS_WAVES][256];   // per wave: digit counters, then exclusive offsets inside the digit
-    __shared__ uint32_t s_start[256];           // first tile-local position of digit d
-    __shared__ uint32_t s_dest[256];            // global position of the tile's first key of digit d
+    __shared__ uint32_t s_cnt[RS_WAVES][NB];    // per wave: digit counters, then exclusive offsets inside the digit
+    __shared__ uint32_t s_start[NB];            // first tile-local position of digit d
+    __shared__ uint32_t s_dest[NB];             // global position of the tile's first key of digit d
     __shared__ uint32_t s_tile;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int shift = 8 * pass;
+    const int shift = DB * pass;
     if (tid == 0) s_tile = atomicAdd(&tile_ctr[pass], 1u);
-    for (int i = tid; i < RS_WAVES * 256; i += RS_THREADS) (&s_cnt[0][0])[i] = 0;
-    // threads 0..255 own one digit each.  Keys of that digit in the whole array = sum of the histogram partials
+    for (int i = tid; i < RS_WAVES * NB; i += RS_THREADS) (&s_cnt[0][0])[i] = 0;
+    // threads 0..NB-1 own one digit each.  Keys of that digit in the whole array = sum of the histogram partials
     // (independent of the tile: issued first, the latency hides behind the ticket and the key loads)
-    const bool owner = tid < 256;
+    const bool owner = tid < NB;
     uint32_t total = 0;
     if (owner)
-        for (int b = 0; b < RS_HBLOCKS; ++b) total += part[(size_t)b * (RS_MAXP * 256) + pass * 256 + tid];
+        for (int b = 0; b < RS_HBLOCKS; ++b) total += part[(size_t)b * (RS_MAXP * NB) + pass * NB + tid];
     __syncthreads();
     const uint32_t tile = s_tile;
     const uint32_t base = tile * RS_TILE + wave * (64 * RS_IPT);   // this wave's 1024 consecutive keys
@@ -103,10 +108,10 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_pass(const K *__restrict__ ki
 #pragma unroll
     for (int r = 0; r < RS_IPT; ++r) {
         const bool ok = base + r * 64 + lane < n;
-        const uint32_t d = digit_of(key[r], shift);
+        const uint32_t d = digit_of<DB>(key[r], shift);
         unsigned long long peers = __ballot(ok);
 #pragma unroll
-        for (int b = 0; b < 8; ++b) {
+        for (int b = 0; b < DB; ++b) {
             const unsigned long long m = __ballot((d >> b) & 1u);
             peers &= ((d >> b) & 1u) ? m : ~m;
         }
@@ -118,19 +123,19 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_pass(const K *__restrict__ ki
     __syncthreads();
 
     // ---- per digit (thread d): wave offsets, tile count, global base, look-back -----------------------------
-    const uint32_t d = tid & 255;
+    const uint32_t d = tid & (NB - 1);
     uint32_t tile_count = 0;
     if (owner)
         for (int w = 0; w < RS_WAVES; ++w) { const uint32_t c = s_cnt[w][d]; s_cnt[w][d] = tile_count; tile_count += c; }
-    uint32_t *my_look = look + (size_t)tile * 256 + d;
+    uint32_t *my_look = look + (size_t)tile * NB + d;
     if (owner) __hip_atomic_store(my_look, (tile == 0 ? RS_PREFIX : RS_AGG) | tile_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // block-wide exclusive scans of `total` (global) and `tile_count` (tile-local) over the 256 digits
+    // block-wide exclusive scans of `total` (global) and `tile_count` (tile-local) over the NB digits
     uint32_t inc_g = total, inc_t = tile_count;
     for (int o = 1; o < 64; o <<= 1) {
         const uint32_t a = __shfl_up(inc_g, o, 64), b = __shfl_up(inc_t, o, 64);
         if (lane >= o) { inc_g += a; inc_t += b; }
     }
-    __shared__ uint32_t s_wg[4], s_wt[4];
+    __shared__ uint32_t s_wg[NB / 64], s_wt[NB / 64];
     if (owner && lane == 63) { s_wg[wave] = inc_g; s_wt[wave] = inc_t; }
     __syncthreads();
     if (owner) {
@@ -149,7 +154,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_pass(const K *__restrict__ ki
                 uint32_t st[RS_LOOK];
 #pragma unroll
                 for (int j = 0; j < RS_LOOK; ++j)
-                    st[j] = (t - j >= 0) ? __hip_atomic_load(look + (size_t)(t - j) * 256 + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : RS_PREFIX;
+                    st[j] = (t - j >= 0) ? __hip_atomic_load(look + (size_t)(t - j) * NB + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : RS_PREFIX;
                 int j = 0;
 #pragma unroll
                 for (; j < RS_LOOK; ++j) {
@@ -170,7 +175,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_pass(const K *__restrict__ ki
 #pragma unroll
     for (int r = 0; r < RS_IPT; ++r) {
         if (base + r * 64 + lane < n) {
-            const uint32_t dg = digit_of(key[r], shift);
+            const uint32_t dg = digit_of<DB>(key[r], shift);
             const uint32_t pos = s_start[dg] + s_cnt[wave][dg] + rank[r];
             s_keys[pos] = key[r];
             s_vals[pos] = val[r];
@@ -180,20 +185,18 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_pass(const K *__restrict__ ki
     const uint32_t in_tile = min((uint32_t)RS_TILE, n - tile * RS_TILE);
     for (uint32_t pos = tid; pos < in_tile; pos += RS_THREADS) {
         const K k = s_keys[pos];
-        const uint32_t dg = digit_of(k, shift);
+        const uint32_t dg = digit_of<DB>(k, shift);
         const uint32_t out = s_dest[dg] + (pos - s_start[dg]);
         kout[out] = k;
         vout[out] = s_vals[pos];
     }
 }
 
-template <class K>
-void radix_sort_impl(plade_ctx *ctx, const K *ki, K *ko, const uint32_t *vi, uint32_t *vo, size_t n, int bits) {
-    PLADE_REQUIRE(n < (1ull << 30), PLADE_ELIMIT, "sort: too many items");
-    const int passes = std::max(1, (bits + 7) / 8);
-    PLADE_REQUIRE(passes <= RS_MAXP && passes * 8 <= (int)sizeof(K) * 8, PLADE_EINVAL, "sort: bit range");
+template <class K, int DB>
+void radix_sort_run(plade_ctx *ctx, const K *ki, K *ko, const uint32_t *vi, uint32_t *vo, size_t n, int passes) {
+    constexpr int NB = 1 << DB;
     const uint32_t tiles = cdiv(n, RS_TILE);
-    const size_t part_words = (size_t)RS_HBLOCKS * RS_MAXP * 256, look_words = (size_t)passes * tiles * 256;
+    const size_t part_words = (size_t)RS_HBLOCKS * RS_MAXP * NB, look_words = (size_t)passes * tiles * NB;
     // scratch: partial histograms | tile counters | look-back states | key ping buffer | value ping buffer
     const size_t off_ctr = part_words, off_look = off_ctr + 64, off_keys = (off_look + look_words + 3) & ~(size_t)3;
     const size_t key_words = (n * sizeof(K) + 3) / 4, off_vals = (off_keys + key_words + 3) & ~(size_t)3;
@@ -201,7 +204,7 @@ void radix_sort_impl(plade_ctx *ctx, const K *ki, K *ko, const uint32_t *vi, uin
     K *tk = reinterpret_cast<K *>(t + off_keys);
     uint32_t *tv = t + off_vals;
     hipStream_t st = ctx->stream;
-    hipLaunchKernelGGL(k_rs_histogram<K>, dim3(RS_HBLOCKS), dim3(RS_THREADS), 0, st, ki, (uint32_t)n, passes, t, t + off_ctr,
+    hipLaunchKernelGGL((k_rs_histogram<K, DB>), dim3(RS_HBLOCKS), dim3(RS_THREADS), 0, st, ki, (uint32_t)n, passes, t, t + off_ctr,
                        t + off_look, look_words);
     const K *src_k = ki;
     const uint32_t *src_v = vi;
@@ -209,12 +212,26 @@ void radix_sort_impl(plade_ctx *ctx, const K *ki, K *ko, const uint32_t *vi, uin
         const bool to_out = ((passes - 1 - p) & 1) == 0;    // the last pass lands in the caller's output
         K *dst_k = to_out ? ko : tk;
         uint32_t *dst_v = to_out ? vo : tv;
-        hipLaunchKernelGGL(k_rs_pass<K>, dim3(tiles), dim3(RS_THREADS), 0, st, src_k, dst_k, src_v, dst_v, (uint32_t)n, p, t,
-                           t + off_ctr, t + off_look + (size_t)p * tiles * 256);
+        hipLaunchKernelGGL((k_rs_pass<K, DB>), dim3(tiles), dim3(RS_THREADS), 0, st, src_k, dst_k, src_v, dst_v, (uint32_t)n, p, t,
+                           t + off_ctr, t + off_look + (size_t)p * tiles * NB);
         src_k = dst_k;
         src_v = dst_v;
     }
     HIP_TRY(hipGetLastError());
+}
+
+template <class K>
+void radix_sort_impl(plade_ctx *ctx, const K *ki, K *ko, const uint32_t *vi, uint32_t *vo, size_t n, int bits) {
+    PLADE_REQUIRE(n < (1ull << 30), PLADE_ELIMIT, "sort: too many items");
+    PLADE_REQUIRE(bits >= 1 && bits <= (int)sizeof(K) * 8, PLADE_EINVAL, "sort: bit range");
+    const int p8 = (bits + 7) / 8, p9 = (bits + 8) / 9;
+    static const bool no9 = getenv("PLADE_SORT_DIGIT8") != nullptr;
+    // the last 9-bit digit must still lie inside the key: (p9 - 1) * 9 < key bits
+    if (p9 < p8 && !no9 && (p9 - 1) * 9 < (int)sizeof(K) * 8) radix_sort_run<K, 9>(ctx, ki, ko, vi, vo, n, p9);
+    else {
+        PLADE_REQUIRE(p8 <= RS_MAXP, PLADE_EINVAL, "sort: bit range");
+        radix_sort_run<K, 8>(ctx, ki, ko, vi, vo, n, p8);
+    }
 }
 
 }  // namespace

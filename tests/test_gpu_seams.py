@@ -149,7 +149,9 @@ def test_match_windowed_equals_brute_force(oracle, monkeypatch):
 
 
 @pytest.mark.parametrize("dtype,bits", [(np.uint32, 24), (np.uint32, 32), (np.uint32, 9), (np.uint64, 30), (np.uint64, 47),
-                                        (np.uint64, 64)])
+                                        (np.uint64, 64),
+                                        # bit counts where 9-bit digits save a pass (the voxel / cell grids)
+                                        (np.uint32, 18), (np.uint32, 27), (np.uint64, 26), (np.uint64, 35), (np.uint64, 63)])
 @pytest.mark.parametrize("n", [16385, 100003, 1 << 20, 3000001])
 def test_radix_sort_is_numpy_stable_argsort(ctx, dtype, bits, n):
     """The hand-written onesweep sort behind every grid (radix_sort.hip) = numpy's stable sort: sorted keys and, through
