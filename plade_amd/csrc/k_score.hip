@@ -144,11 +144,7 @@ __global__ __launch_bounds__(TPB) void k_score_mark(const float *__restrict__ x,
 
 // the same for a batch of hypotheses: the tile is loaded once and tested against every job's plane
 constexpr int MARK_MAXJ = BATCH_MAXJ;
-__global__ __launch_bounds__(TPB) void k_score_mark_batch(const float *__restrict__ x, const float *__restrict__ y,
-                                                          const float *__restrict__ z, const float *__restrict__ nx,
-                                                          const float *__restrict__ ny, const float *__restrict__ nz,
-                                                          const int32_t *__restrict__ assigned, uint32_t n,
-                                                          const MarkJobs jobs, uint32_t nj, float eps, float cos_t) {
+__global__ __launch_bounds__(TPB) void k_score_mark_batch(const MarkJobs jobs) {
     __shared__ uint32_t s_w[MARK_MAXJ][TPB / 64];
     // the jobs' planes / skip flags / output pointers are fetched by nj lanes at once and parked in LDS: read
     // one after the other inside the hypothesis loop they were a chain of dependent global loads (~1 us each)
@@ -156,16 +152,19 @@ __global__ __launch_bounds__(TPB) void k_score_mark_batch(const float *__restric
     __shared__ uint32_t s_skip[MARK_MAXJ];
     __shared__ uint8_t *s_masks[MARK_MAXJ];
     __shared__ uint32_t *s_bc[MARK_MAXJ];
+    const ScanGroup &G = jobs.g[(jobs.ng > 1 && blockIdx.x >= jobs.g[1].tile0) ? 1 : 0];   // uniform
+    const uint32_t nj = G.nj, tile = blockIdx.x - G.tile0;
     if (threadIdx.x < nj) {
-        const MarkJob jb = jobs.j[threadIdx.x];
+        const MarkJob jb = jobs.j[G.job0 + threadIdx.x];
         s_skip[threadIdx.x] = jb.skip ? *jb.skip : 0u;
         s_pl[threadIdx.x] = jb.plane[0];
         s_masks[threadIdx.x] = jb.masks;
         s_bc[threadIdx.x] = jb.block_counts;
     }
     Tile t;
-    load_tile(t, x, y, z, nx, ny, nz, assigned, nullptr, n, blockIdx.x * TILE + threadIdx.x * PPT);
+    load_tile(t, G.x, G.y, G.z, G.nx, G.ny, G.nz, G.assigned, nullptr, G.n, tile * TILE + threadIdx.x * PPT);
     __syncthreads();
+    const float eps = G.eps, cos_t = G.cos_t;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (uint32_t j = 0; j < nj; ++j) {
         if (s_skip[j]) continue;   // uniform
@@ -177,12 +176,12 @@ __global__ __launch_bounds__(TPB) void k_score_mark_batch(const float *__restric
             m |= (in ? 1u : 0u) << k;
             c += (uint32_t)__popcll(__ballot(in));
         }
-        s_masks[j][blockIdx.x * TPB + threadIdx.x] = (uint8_t)m;
+        s_masks[j][tile * TPB + threadIdx.x] = (uint8_t)m;
         if (lane == 0) s_w[j][wave] = c;
     }
     __syncthreads();
     if (threadIdx.x < nj && !s_skip[threadIdx.x])
-        s_bc[threadIdx.x][blockIdx.x] = s_w[threadIdx.x][0] + s_w[threadIdx.x][1] + s_w[threadIdx.x][2] + s_w[threadIdx.x][3];
+        s_bc[threadIdx.x][tile] = s_w[threadIdx.x][0] + s_w[threadIdx.x][1] + s_w[threadIdx.x][2] + s_w[threadIdx.x][3];
 }
 
 // ordered compaction; every block derives its output offset from the preceding blocks' counts itself
@@ -223,13 +222,14 @@ __global__ __launch_bounds__(TPB) void k_compact(const uint8_t *__restrict__ mas
 }
 
 // batched form of k_compact: job blockIdx.y
-__global__ __launch_bounds__(TPB) void k_compact_batch(const CompactJobs jobs, uint32_t nb,
-                                                       const float *__restrict__ px, const float *__restrict__ py,
-                                                       const float *__restrict__ pz) {
+__global__ __launch_bounds__(TPB) void k_compact_batch(const CompactJobs jobs) {
     __shared__ uint32_t s_w[TPB / 64];
     __shared__ uint32_t s_base[TPB / 64];
     __shared__ float s_mm[4][8];
     const CompactJob jb = jobs.j[blockIdx.y];
+    const uint32_t nb = jb.nb;
+    if (blockIdx.x >= nb) return;   // the grid covers the larger cloud of the batch
+    const float *__restrict__ px = jb.px, *__restrict__ py = jb.py, *__restrict__ pz = jb.pz;
     // round 1 of loads, all independent: skip flag, this tile's count, its mask bytes, the plane frame (a chain of
     // early exits, each behind its own global load, used to cost four round trips before the first gather)
     const uint32_t skip = jb.skip ? *jb.skip : 0u;
@@ -317,29 +317,39 @@ __global__ __launch_bounds__(TPB) void k_compact_batch(const CompactJobs jobs, u
     }
 }
 
-void score_mark_batch(plade_ctx *ctx, const float *x, const float *y, const float *z, const float *nx, const float *ny,
-                      const float *nz, const int32_t *assigned, uint32_t n, const MarkJob *jobs_host, uint32_t nj, float eps,
-                      float cos_thresh) {
-    PLADE_REQUIRE(nj <= (uint32_t)MARK_MAXJ, PLADE_EINVAL, "score_mark_batch: too many jobs");
-    const uint32_t nb = cdiv(n, TILE);
-    if (nb == 0 || nj == 0) return;
-    // algorithmic bytes: the cloud once (28 B/point) + one mask byte per 4 points per hypothesis
-    ctx->ev_begin("score_mark", 28.0 * n + 0.25 * n * nj);
+void score_mark_batch(plade_ctx *ctx, hipStream_t stream, const MarkJob *jobs_host, ScanGroup *groups, uint32_t ng) {
+    PLADE_REQUIRE(ng >= 1 && ng <= 2, PLADE_EINVAL, "score_mark_batch: one or two clouds");
     MarkJobs jobs;
+    uint32_t tiles = 0, nj = 0;
+    double bytes = 0;
+    for (uint32_t g = 0; g < ng; ++g) {
+        groups[g].tile0 = tiles;
+        groups[g].job0 = nj;
+        tiles += cdiv(groups[g].n, TILE);
+        nj += groups[g].nj;
+        // algorithmic bytes: the cloud once (28 B/point) + one mask byte per 4 points per hypothesis
+        bytes += 28.0 * groups[g].n + 0.25 * groups[g].n * groups[g].nj;
+    }
+    PLADE_REQUIRE(nj <= (uint32_t)MARK_MAXJ, PLADE_EINVAL, "score_mark_batch: too many jobs");
+    if (tiles == 0 || nj == 0) return;
     for (uint32_t j = 0; j < (uint32_t)BATCH_MAXJ; ++j) jobs.j[j] = jobs_host[j < nj ? j : 0];
-    hipLaunchKernelGGL(k_score_mark_batch, dim3(nb), dim3(TPB), 0, ctx->stream, x, y, z, nx, ny, nz, assigned, n, jobs, nj,
-                       eps, cos_thresh);
+    jobs.g[0] = groups[0];
+    jobs.g[1] = groups[ng > 1 ? 1 : 0];
+    jobs.ng = ng;
+    ctx->ev_begin("score_mark", bytes);
+    hipLaunchKernelGGL(k_score_mark_batch, dim3(tiles), dim3(TPB), 0, stream, jobs);
     ctx->ev_end();
 }
 
-void compact_batch(plade_ctx *ctx, uint32_t n, const CompactJob *jobs_host, uint32_t nj, const float *x, const float *y,
-                   const float *z) {
-    const uint32_t nb = cdiv(n, TILE);
-    if (nb == 0 || nj == 0) return;
+void compact_batch(plade_ctx *ctx, hipStream_t stream, const CompactJob *jobs_host, uint32_t nj) {
     PLADE_REQUIRE(nj <= (uint32_t)BATCH_MAXJ, PLADE_EINVAL, "compact_batch: too many jobs");
+    uint32_t nb = 0;
+    for (uint32_t j = 0; j < nj; ++j) nb = std::max(nb, jobs_host[j].nb);
+    if (nb == 0 || nj == 0) return;
     CompactJobs jobs;
     for (uint32_t j = 0; j < (uint32_t)BATCH_MAXJ; ++j) jobs.j[j] = jobs_host[j < nj ? j : 0];
-    hipLaunchKernelGGL(k_compact_batch, dim3(nb, nj), dim3(TPB), 0, ctx->stream, jobs, nb, x, y, z);
+    hipLaunchKernelGGL(k_compact_batch, dim3(nb, nj), dim3(TPB), 0, stream, jobs);
+    (void)ctx;
 }
 
 void score_multi(plade_ctx *ctx, const float *x, const float *y, const float *z, const float *nx, const float *ny,

@@ -47,7 +47,14 @@ struct ComponentOut {
 void plane_component(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const float normal[3], const float point[3],
                      const int32_t *idx, uint32_t m, float bitmap_eps, bool closing_filter, float w_eps, ComponentOut &out);
 
+// Coordinator of the acceptance batches of two concurrent detect calls (the two scans of a pair): their batches are
+// launched together, see ransac.hip.  `who` = 0 (target) / 1 (source).
+struct PairAccept;
+PairAccept *pair_accept_create();
+void pair_accept_destroy(PairAccept *p);
+
 // PlaneExtraction::detect (code/PLADE/plane_extraction.cpp:173-200)
-void ransac_detect(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const RansacParams &rp, PlaneSetOut &out);
+void ransac_detect(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const RansacParams &rp, PlaneSetOut &out,
+                   PairAccept *pair = nullptr, int who = 0);
 
 }  // namespace plade

@@ -22,6 +22,8 @@
 //   stopping   : CandidateFailureProbability(minSupport, n_remaining, drawn, levels) <= p
 //                (RansacShapeDetector.h:61-67, .cpp:856-858).
 #include "ransac.h"
+#include <condition_variable>
+#include <mutex>
 #include "score.h"
 #include "prims.h"
 #include "voxel.h"
@@ -208,7 +210,7 @@ struct PlaneState {
     uint32_t converged;              // refit chain: this slot's plane is bitwise the previous slot's
 };
 
-constexpr int CHAIN_MAX = BATCH_MAXJ;   // chains accepted together (table passed by value: 8 x 184 B of kernarg)
+constexpr int CHAIN_MAX = BATCH_MAXJ;   // chains of a launch: 8 per cloud, two clouds (table passed by value in the kernarg)
 
 // Device-visible buffers of one acceptance chain.  Every kernel of the acceptance sequence takes the
 // table of chains and handles chain blockIdx.y (slot k of it): one launch serves the whole batch of
@@ -230,7 +232,10 @@ struct ChainDev {
     float *bbpart;         // per-tile (u, v) bounding boxes of the score list
     double *part;
 };
-struct ChainTab { ChainDev c[CHAIN_MAX]; };
+// A batch may hold the chains of two clouds (the two scans of a pair are extracted in lock-step): chains
+// [0, split) belong to group 0, the rest to group 1.
+struct ChainGroup { CloudView cloud; float eps3, bitmap_eps; uint32_t nb4; };
+struct ChainTab { ChainDev c[CHAIN_MAX]; ChainGroup g[2]; uint32_t split; };
 
 
 __device__ __forceinline__ void hcs_axes(const float *n, float *a0, float *a1) {
@@ -292,8 +297,11 @@ __device__ __forceinline__ bool cc_dims(const float bb[4], uint32_t count, float
 
 // BuildBitmap (BitmapPrimitiveShape.h:139-150) with InBitmap (PlanePrimitiveShape.cpp:193-199).
 // The bitmap is all-zero on entry (k_cc_label clears what it used).
-__global__ __launch_bounds__(256) void k_cc_raster(const ChainTab chains, int k, float eps, uint32_t n_tiles) {
+__global__ __launch_bounds__(256) void k_cc_raster(const ChainTab chains, int k) {
     const ChainDev &C = chains.c[blockIdx.y];
+    const ChainGroup &G = chains.g[blockIdx.y >= chains.split ? 1 : 0];
+    const float eps = G.bitmap_eps;
+    const uint32_t n_tiles = G.nb4;
     PlaneState *st = C.st + k;
     if (st->converged) return;
     const float2 *__restrict__ uv = C.uv;
@@ -477,10 +485,14 @@ __global__ __launch_bounds__(1024) void k_cc_label(const ChainTab chains, int k,
 // doubles per 1024 list positions, reduced by k_fit_final in a fixed order.
 constexpr int FIT_COLS = 13;
 
-__global__ __launch_bounds__(256) void k_cc_select(CloudView c, const ChainTab chains, int k, float eps) {
+__global__ __launch_bounds__(256) void k_cc_select(const ChainTab chains, int k) {
     __shared__ uint32_t s_w[4];
     __shared__ double s[4][FIT_COLS];
     const ChainDev &C = chains.c[blockIdx.y];
+    const ChainGroup &G = chains.g[blockIdx.y >= chains.split ? 1 : 0];
+    if (blockIdx.x >= G.nb4) return;   // the grid covers the larger cloud of the batch
+    const CloudView &c = G.cloud;
+    const float eps = G.eps3;
     const PlaneState *st = C.st + k;
     if (st->converged) return;
     const uint32_t *__restrict__ bidx = C.bidx, *__restrict__ count = C.cntA, *__restrict__ label = C.label;
@@ -696,6 +708,7 @@ struct Chain {
 constexpr size_t ACCEPT_BYTES = 4 * sizeof(PlaneState) + 16 + 48;   // states, counts, normal sums
 constexpr size_t ACCEPT_STRIDE = (ACCEPT_BYTES + 63) & ~(size_t)63;
 
+struct PairAccept;
 struct RansacWork {
     CloudDev sorted;
     DBuf<uint32_t> codes, codes_in, vals_in, orig;
@@ -714,24 +727,16 @@ struct RansacWork {
     std::vector<std::unique_ptr<Chain>> chains;
     DBuf<char> accept_block;         // B x ACCEPT_STRIDE: one D2H copy per batch
     DBuf<float4> cand_in;            // B x (hypothesis, position): one H2D copy per batch
-    ChainTab tab;                    // the chains' device pointers, passed by value to every chain kernel
-    std::vector<ChainDev> h_tab;
+    std::vector<ChainDev> h_tab;     // the chains' device pointers (host copy; batches pass them by value)
     std::vector<MarkJob> mark_jobs;      // [slot][chain]   (host; launches copy one slot's row into the kernargs)
     std::vector<CompactJob> compact_jobs;   // [slot][A|S][chain]
     HBuf<char> pinned_accept;
     uint32_t B = 0;
     std::vector<uint64_t> tab_key;
-    // the acceptance sequence (~33 launches, all arguments in device memory) as hipGraphs, one per
-    // (cloud size / thresholds, batch size): replayed instead of re-issuing the launches from the host
-    std::map<std::vector<uint64_t>, std::vector<hipGraphExec_t>> graphs;
-    std::vector<hipGraphExec_t> *exec = nullptr;   // the entry of the current detect call
-    void drop_graphs() {
-        for (auto &kv : graphs)
-            for (hipGraphExec_t e : kv.second) if (e) (void)hipGraphExecDestroy(e);
-        graphs.clear();
-        exec = nullptr;
-    }
-    ~RansacWork() { drop_graphs(); }
+    uint64_t tab_hash = 0;           // changes whenever a pointer of the tables moves (keys the captured graphs)
+    PairAccept *solo = nullptr;      // runs this work area's batches when no pair coordinator is given
+    hipEvent_t ev_ready = nullptr;
+    ~RansacWork();
 };
 
 RansacWork *ransac_work_create() { return new RansacWork; }
@@ -745,26 +750,63 @@ struct Accepted {
     uint32_t offset;   // into out_idx
 };
 
-// The whole per-candidate sequence of RansacShapeDetector.cpp:618-656 for `nc` chains x four slots, no
-// host round trip: slot 0 = the candidate (GlobalScore(3 eps) + ConnectedComponent; its clone's first
+// One cloud's share of an acceptance batch.
+struct AcceptSide {
+    RansacWork *W = nullptr;
+    uint32_t nc = 0;              // chains of this cloud in the batch
+    CloudView cv{};               // the Morton-ordered cloud
+    const int32_t *assigned = nullptr;
+    float eps3 = 0.f, cos_t = 0.f, bitmap_eps = 0.f;
+    hipEvent_t ready = nullptr;   // recorded on the owner's stream after it queued the batch's inputs
+};
+
+// The whole per-candidate sequence of RansacShapeDetector.cpp:618-656 for the chains of one or two clouds x four
+// slots, no host round trip: slot 0 = the candidate (GlobalScore(3 eps) + ConnectedComponent; its clone's first
 // GlobalWeightedScore is the same computation), slot k = k-th LS refit of slot k-1's points.  Per slot:
 // GlobalWeightedScore (Candidate.h:293-302) = score(3 eps) -> ConnectedComponent -> weighted score,
 // then the LS fit of the result list.
-void enqueue_accept(plade_ctx *ctx, RansacWork &W, const CloudView &cv, uint32_t nc, float eps3, float cos_t, float bitmap_eps) {
-    const CloudDev &c = W.sorted;
+void enqueue_accept(plade_ctx *ctx, const AcceptSide *sides, int ns) {
     hipStream_t st = ctx->stream;
-    const ChainTab &tab = W.tab;
-    const uint32_t B = W.B;
-    const uint32_t nb = cdiv(c.n, 256), nb4 = cdiv(c.n, 1024);
+    ChainTab tab;
+    uint32_t nc = 0, nb4_max = 0;
+    for (int i = 0; i < ns; ++i) {
+        const AcceptSide &S = sides[i];
+        for (uint32_t b = 0; b < S.nc; ++b) tab.c[nc + b] = S.W->h_tab[b];
+        tab.g[i] = ChainGroup{S.cv, S.eps3, S.bitmap_eps, cdiv(S.cv.n, 1024)};
+        nb4_max = std::max(nb4_max, cdiv(S.cv.n, 1024));
+        nc += S.nc;
+    }
+    PLADE_REQUIRE(nc >= 1 && nc <= (uint32_t)CHAIN_MAX, PLADE_EINVAL, "ransac: batch size");
+    for (uint32_t b = nc; b < (uint32_t)CHAIN_MAX; ++b) tab.c[b] = tab.c[0];
+    if (ns == 1) tab.g[1] = tab.g[0];
+    tab.split = sides[0].nc;
     hipLaunchKernelGGL(k_state_from_hyp, dim3(nc), dim3(64), 0, st, tab);
+    std::vector<MarkJob> mj(nc);
+    std::vector<CompactJob> cj(nc);
     for (int k = 0; k < 4; ++k) {
-        score_mark_batch(ctx, c.x(), c.y(), c.z(), c.nx(), c.ny(), c.nz(), W.assigned.p, c.n, W.mark_jobs.data() + (size_t)k * B, nc, eps3,
-                         cos_t);
-        compact_batch(ctx, c.n, W.compact_jobs.data() + (size_t)(2 * k) * B, nc, c.x(), c.y(), c.z());
-        hipLaunchKernelGGL(k_cc_raster, dim3(std::min(nb, 128u), nc), dim3(256), 0, st, tab, k, bitmap_eps, nb4);
-        hipLaunchKernelGGL(k_cc_label, dim3(nc), dim3(1024), 0, st, tab, k, 1);
-        hipLaunchKernelGGL(k_cc_select, dim3(nb4, nc), dim3(256), 0, st, cv, tab, k, eps3);
-        compact_batch(ctx, c.n, W.compact_jobs.data() + (size_t)(2 * k + 1) * B, nc);
+        ScanGroup groups[2];
+        uint32_t o = 0;
+        for (int i = 0; i < ns; ++i) {
+            const AcceptSide &S = sides[i];
+            for (uint32_t b = 0; b < S.nc; ++b) mj[o + b] = S.W->mark_jobs[(size_t)k * S.W->B + b];
+            groups[i] = ScanGroup{S.cv.x, S.cv.y, S.cv.z, S.cv.nx, S.cv.ny, S.cv.nz, S.assigned, S.cv.n, 0, 0, S.nc, S.eps3, S.cos_t};
+            o += S.nc;
+        }
+        score_mark_batch(ctx, st, mj.data(), groups, (uint32_t)ns);
+        for (int ab = 0; ab < 2; ++ab) {
+            if (ab == 1) {
+                hipLaunchKernelGGL(k_cc_raster, dim3(128, nc), dim3(256), 0, st, tab, k);
+                hipLaunchKernelGGL(k_cc_label, dim3(nc), dim3(1024), 0, st, tab, k, 1);
+                hipLaunchKernelGGL(k_cc_select, dim3(nb4_max, nc), dim3(256), 0, st, tab, k);
+            }
+            o = 0;
+            for (int i = 0; i < ns; ++i) {
+                const AcceptSide &S = sides[i];
+                for (uint32_t b = 0; b < S.nc; ++b) cj[o + b] = S.W->compact_jobs[(size_t)(2 * k + ab) * S.W->B + b];
+                o += S.nc;
+            }
+            compact_batch(ctx, st, cj.data(), nc);
+        }
         hipLaunchKernelGGL(k_fit_final, dim3(nc), dim3(256), 0, st, tab, k);
     }
 }
@@ -810,9 +852,11 @@ void chains_prepare(plade_ctx *ctx, RansacWork &W, uint32_t B, uint32_t n, float
             const uint32_t *skip = &D.st[k].converged;
             mj[(size_t)k * B + b] = MarkJob{D.plane_cur + k, C.cs.masks.p, C.cs.block_counts.p, skip};
             // score list + its (u, v) parameters in slot k's plane frame (PlaneState: pos, dist, a0, a1, bb)
+            const CloudDev &sc = W.sorted;
             cj[(size_t)(2 * k) * B + b] = CompactJob{C.cs.masks.p, C.cs.block_counts.p, nullptr, D.idxA, D.cntA, skip,
-                                                     D.st[k].pos, D.uv, D.bbpart};
-            cj[(size_t)(2 * k + 1) * B + b] = CompactJob{D.masks2, D.bc2, D.idxA, D.idxS[k], D.cntS + k, skip, nullptr, nullptr, nullptr};
+                                                     D.st[k].pos, D.uv, D.bbpart, nb4, sc.x(), sc.y(), sc.z()};
+            cj[(size_t)(2 * k + 1) * B + b] = CompactJob{D.masks2, D.bc2, D.idxA, D.idxS[k], D.cntS + k, skip, nullptr, nullptr, nullptr,
+                                                         nb4, nullptr, nullptr, nullptr};
         }
     }
     // (re)upload the tables only when a pointer moved
@@ -829,37 +873,114 @@ void chains_prepare(plade_ctx *ctx, RansacWork &W, uint32_t B, uint32_t n, float
         key.insert(key.end(), w, w + cj.size() * sizeof(CompactJob) / 8);
     }
     W.h_tab = tab;
+    W.mark_jobs = mj;
+    W.compact_jobs = cj;
     if (key != W.tab_key) {   // the tables are baked into the captured launches' arguments
-        for (uint32_t b = 0; b < (uint32_t)CHAIN_MAX; ++b) W.tab.c[b] = tab[b < B ? b : 0];
-        W.mark_jobs = mj;
-        W.compact_jobs = cj;
         W.tab_key = key;
-        W.drop_graphs();
+        uint64_t h = 1469598103934665603ull;
+        for (uint64_t w : key) { h ^= w; h *= 1099511628211ull; }
+        W.tab_hash = h;
     }
-    // graphs are keyed on everything baked into the captured launches
-    auto bits = [](float f) { uint32_t u; memcpy(&u, &f, 4); return (uint64_t)u; };
-    std::vector<uint64_t> gkey = {n, B, bits(eps3), bits(cos_t), bits(bitmap_eps), (uint64_t)W.sorted.soa.p, (uint64_t)W.assigned.p,
-                                  (uint64_t)ctx->stream};
-    if (W.graphs.size() > 16) W.drop_graphs();   // bounded cache (a batch of differently sized clouds)
-    W.exec = &W.graphs[gkey];
-    (void)fresh_bitmap;
+    (void)ctx; (void)eps3; (void)cos_t; (void)bitmap_eps; (void)fresh_bitmap;
 }
 
-// graph for a batch of nc chains (captured lazily)
-hipGraphExec_t accept_graph(plade_ctx *ctx, RansacWork &W, const CloudView &cv, uint32_t nc, float eps3, float cos_t, float bitmap_eps) {
-    if (ctx->profiling() || getenv("PLADE_NO_GRAPH")) return nullptr;
-    std::vector<hipGraphExec_t> &ex = *W.exec;
-    if (ex.size() <= nc) ex.resize(nc + 1, nullptr);
-    if (!ex[nc]) {
-        hipGraph_t graph = nullptr;
-        HIP_TRY(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
-        enqueue_accept(ctx, W, cv, nc, eps3, cos_t, bitmap_eps);
-        HIP_TRY(hipStreamEndCapture(ctx->stream, &graph));
-        HIP_TRY(hipGraphInstantiate(&ex[nc], graph, nullptr, nullptr, 0));
-        (void)hipGraphDestroy(graph);
+}  // namespace
+
+// Runs acceptance batches.  With two participants (the target's and the source's extraction threads of one
+// registration) the two clouds' batches are merged: every kernel of the 29-launch sequence is latency-bound, so
+// one sequence serving the chains of both clouds costs little more than one cloud's and the registration issues
+// half as many of them.  A thread that reaches its next batch waits for the other one (or for it to finish its
+// extraction); whoever arrives last launches for both on its own stream and wakes the other when the GPU is done.
+struct PairAccept {
+    std::mutex m;
+    std::condition_variable cv;
+    int participants = 0, waiting = 0;
+    uint64_t generation = 0;
+    AcceptSide side[2];
+    bool present[2] = {false, false};
+    Err err{0, ""};
+    std::map<uint64_t, hipGraphExec_t> graphs;   // keyed on everything baked into the captured launches
+    ~PairAccept() { for (auto &kv : graphs) if (kv.second) (void)hipGraphExecDestroy(kv.second); }
+
+    void join() { std::lock_guard<std::mutex> lk(m); ++participants; }
+    void leave() { { std::lock_guard<std::mutex> lk(m); --participants; } cv.notify_all(); }
+
+    static uint64_t mix(uint64_t h, uint64_t v) { h ^= v; h *= 1099511628211ull; return h; }
+    static uint64_t fbits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+
+    void run(plade_ctx *ctx, const AcceptSide *sides, int ns) {
+        if (ctx->profiling() || getenv("PLADE_NO_GRAPH")) { enqueue_accept(ctx, sides, ns); return; }
+        uint64_t key = 1469598103934665603ull;
+        for (int i = 0; i < ns; ++i) {
+            const AcceptSide &S = sides[i];
+            key = mix(key, S.W->tab_hash); key = mix(key, S.nc); key = mix(key, S.cv.n); key = mix(key, (uint64_t)S.cv.x);
+            key = mix(key, (uint64_t)S.assigned); key = mix(key, fbits(S.eps3)); key = mix(key, fbits(S.cos_t));
+            key = mix(key, fbits(S.bitmap_eps)); key = mix(key, (uint64_t)S.W);
+        }
+        hipGraphExec_t &g = graphs[key];
+        if (!g) {
+            if (graphs.size() > 96) {   // bounded cache (a batch of differently sized clouds)
+                for (auto &kv : graphs) if (kv.second) (void)hipGraphExecDestroy(kv.second);
+                graphs.clear();
+            }
+            hipGraph_t graph = nullptr;
+            HIP_TRY(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+            try { enqueue_accept(ctx, sides, ns); }
+            catch (...) { (void)hipStreamEndCapture(ctx->stream, &graph); if (graph) (void)hipGraphDestroy(graph); throw; }
+            HIP_TRY(hipStreamEndCapture(ctx->stream, &graph));
+            hipGraphExec_t e = nullptr;
+            HIP_TRY(hipGraphInstantiate(&e, graph, nullptr, nullptr, 0));
+            (void)hipGraphDestroy(graph);
+            graphs[key] = e;
+            HIP_TRY(hipGraphLaunch(e, ctx->stream));
+            return;
+        }
+        HIP_TRY(hipGraphLaunch(g, ctx->stream));
     }
-    return ex[nc];
-}
+
+    // `who`: 0 = target, 1 = source.  Returns when the chains of `s` have run (the launching thread has waited for
+    // the GPU); everything the caller queued for them on its own stream must have completed before the call.
+    void submit(int who, plade_ctx *ctx, const AcceptSide &s) {
+        std::unique_lock<std::mutex> lk(m);
+        side[who] = s;
+        present[who] = true;
+        ++waiting;
+        const uint64_t gen = generation;
+        for (;;) {
+            if (generation != gen) break;
+            if (waiting >= participants) {   // everybody who is still extracting is here: launch for all
+                AcceptSide both[2];
+                int ns = 0;
+                for (int i = 0; i < 2; ++i) if (present[i]) both[ns++] = side[i];
+                err = Err{0, ""};
+                try {
+                    for (int i = 0; i < ns; ++i)
+                        if (both[i].W != s.W && both[i].ready) HIP_TRY(hipStreamWaitEvent(ctx->stream, both[i].ready, 0));
+                    run(ctx, both, ns);
+                    for (int i = 0; i < ns; ++i)   // results of every cloud: one block per chain, into pinned memory
+                        HIP_TRY(hipMemcpyAsync(both[i].W->pinned_accept.p, both[i].W->accept_block.p, both[i].nc * ACCEPT_STRIDE,
+                                               hipMemcpyDeviceToHost, ctx->stream));
+                    ctx->sync();
+                }
+                catch (const Err &e) { err = e; }
+                catch (const std::exception &e) { err = Err{PLADE_EDEVICE, e.what()}; }
+                present[0] = present[1] = false;
+                waiting = 0;
+                ++generation;
+                cv.notify_all();
+                break;
+            }
+            cv.wait(lk);
+        }
+        if (err.code) throw err;
+    }
+};
+
+PairAccept *pair_accept_create() { return new PairAccept; }
+void pair_accept_destroy(PairAccept *p) { delete p; }
+RansacWork::~RansacWork() { delete solo; if (ev_ready) (void)hipEventDestroy(ev_ready); }
+
+namespace {
 
 inline bool same_plane(const float4 &a, const float4 &b, float eps) {
     const float c = a.x * b.x + a.y * b.y + a.z * b.z;
@@ -922,20 +1043,25 @@ void plane_component(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const
     dist += point[2] * normal[2];
     const float4 two[2] = {make_float4(normal[0], normal[1], normal[2], dist), make_float4(point[0], point[1], point[2], 0.f)};
     ctx->h2d(W.cand_in.p, two, 32);
-    hipLaunchKernelGGL(k_state_from_hyp, dim3(1), dim3(64), 0, st, W.tab);
+    const uint32_t nb4 = cdiv(n, 1024);
+    ChainTab tab;
+    for (int b = 0; b < CHAIN_MAX; ++b) tab.c[b] = D;
+    tab.g[0] = tab.g[1] = ChainGroup{cv, w_eps, bitmap_eps, nb4};
+    tab.split = 1;
+    hipLaunchKernelGGL(k_state_from_hyp, dim3(1), dim3(64), 0, st, tab);
     // the list as an all-ones mask over list positions, values = the caller's indices
     DBuf<uint32_t> d_idx;
     d_idx.ensure((size_t)n + 4);
     ctx->h2d(d_idx.p, idx, 4 * (size_t)m);
-    const uint32_t nb4 = cdiv(n, 1024);
     hipLaunchKernelGGL(k_list_masks, dim3(cdiv(nb4 * 256, 256)), dim3(256), 0, st, m, nb4, C.cs.masks.p, C.cs.block_counts.p);
-    const CompactJob hj{C.cs.masks.p, C.cs.block_counts.p, d_idx.p, D.idxA, D.cntA, nullptr, D.st[0].pos, D.uv, D.bbpart};
-    compact_batch(ctx, n, &hj, 1, cv.x, cv.y, cv.z);
-    hipLaunchKernelGGL(k_cc_raster, dim3(std::min(cdiv(n, 256), 128u), 1), dim3(256), 0, st, W.tab, 0, bitmap_eps, nb4);
-    hipLaunchKernelGGL(k_cc_label, dim3(1), dim3(1024), 0, st, W.tab, 0, closing_filter ? 1 : 0);
-    hipLaunchKernelGGL(k_cc_select, dim3(nb4, 1), dim3(256), 0, st, cv, W.tab, 0, w_eps);
-    compact_batch(ctx, n, W.compact_jobs.data() + (size_t)1 * W.B, 1);
-    hipLaunchKernelGGL(k_fit_final, dim3(1), dim3(256), 0, st, W.tab, 0);
+    const CompactJob hj{C.cs.masks.p, C.cs.block_counts.p, d_idx.p, D.idxA, D.cntA, nullptr, D.st[0].pos, D.uv, D.bbpart,
+                        nb4, cv.x, cv.y, cv.z};
+    compact_batch(ctx, st, &hj, 1);
+    hipLaunchKernelGGL(k_cc_raster, dim3(128, 1), dim3(256), 0, st, tab, 0);
+    hipLaunchKernelGGL(k_cc_label, dim3(1), dim3(1024), 0, st, tab, 0, closing_filter ? 1 : 0);
+    hipLaunchKernelGGL(k_cc_select, dim3(nb4, 1), dim3(256), 0, st, tab, 0);
+    compact_batch(ctx, st, W.compact_jobs.data() + (size_t)1 * W.B, 1);
+    hipLaunchKernelGGL(k_fit_final, dim3(1), dim3(256), 0, st, tab, 0);
     PlaneState hst[2];
     uint32_t nk = 0;
     ctx->d2h(hst, D.st, 2 * sizeof(PlaneState));
@@ -951,7 +1077,14 @@ void plane_component(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const
     out.wscore = hst[0].wscore;
 }
 
-void ransac_detect(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const RansacParams &rp, PlaneSetOut &out) {
+void ransac_detect(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const RansacParams &rp, PlaneSetOut &out, PairAccept *pair,
+                   int who) {
+    // a member of a pair takes part in the lock-step batches from here until it returns
+    struct Membership {
+        PairAccept *p;
+        explicit Membership(PairAccept *q) : p(q) { if (p) p->join(); }
+        ~Membership() { if (p) p->leave(); }
+    } membership(pair);
     const uint32_t n = cloud.n;
     Clock::time_point t_setup0 = Clock::now();
     out.coef.clear(); out.offsets.assign(1, 0); out.idx.clear(); out.d_idx = nullptr;
@@ -1002,7 +1135,7 @@ void ransac_detect(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const R
     W.out_idx.ensure((size_t)n + 4);
     // ---- acceptance chains ------------------------------------------------------------------------
     uint32_t B = 8;
-    if (const char *e = getenv("PLADE_RANSAC_CHAINS")) B = (uint32_t)std::max(1, std::min(CHAIN_MAX, atoi(e)));
+    if (const char *e = getenv("PLADE_RANSAC_CHAINS")) B = (uint32_t)std::max(1, std::min(CHAIN_MAX / 2, atoi(e)));
     chains_prepare(ctx, W, B, n, eps3, cos_t, bitmap_eps);
 
     ctx->sync();
@@ -1100,10 +1233,17 @@ void ransac_detect(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const R
             std::vector<float4> h_in(2 * nc);
             for (uint32_t b = 0; b < nc; ++b) { h_in[2 * b] = pool[batch[b]].pl; h_in[2 * b + 1] = pool[batch[b]].pos; }
             ctx->h2d(W.cand_in.p, h_in.data(), 32 * nc);
-            if (hipGraphExec_t g = accept_graph(ctx, W, cv, nc, eps3, cos_t, bitmap_eps)) HIP_TRY(hipGraphLaunch(g, ctx->stream));
-            else enqueue_accept(ctx, W, cv, nc, eps3, cos_t, bitmap_eps);
-            ctx->d2h(W.pinned_accept.p, W.accept_block.p, nc * ACCEPT_STRIDE);
-            ctx->sync();
+            {
+                if (!W.ev_ready) HIP_TRY(hipEventCreateWithFlags(&W.ev_ready, hipEventDisableTiming));
+                HIP_TRY(hipEventRecord(W.ev_ready, ctx->stream));
+                AcceptSide S;
+                S.W = &W; S.nc = nc; S.cv = cv; S.assigned = W.assigned.p;
+                S.eps3 = eps3; S.cos_t = cos_t; S.bitmap_eps = bitmap_eps; S.ready = W.ev_ready;
+                if (!pair && !W.solo) { W.solo = new PairAccept; W.solo->participants = 1; }
+                // launches the batch (merged with the other cloud's when both are ready), reads the accept blocks
+                // back into pinned memory and waits for the GPU
+                (pair ? pair : W.solo)->submit(pair ? who : 0, ctx, S);
+            }
             HIP_TRY(hipGetLastError());
             n_full_passes += 4 * (uint32_t)batch.size();
             t_accept += secs_since(t_a0);

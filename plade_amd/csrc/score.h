@@ -52,17 +52,25 @@ struct CompactJob {
     float2 *uv;
     float *bbox_part;          // per tile: min u, min v, max u, max v of its emitted points (tiles with a zero
                                // block count are left untouched): reduced by the consumer, no atomics
+    uint32_t nb;               // tiles of the cloud the masks cover (filled by compact_batch / the caller)
+    const float *px, *py, *pz; // the cloud the indices refer to (only read by jobs with a frame)
+};
+// One cloud of a batched scoring pass: a launch may serve the jobs of two clouds (the two scans of a pair are
+// extracted in lock-step), workgroups [tile0, tile0 + tiles) scan this cloud for jobs [job0, job0 + nj).
+struct ScanGroup {
+    const float *x, *y, *z, *nx, *ny, *nz;
+    const int32_t *assigned;
+    uint32_t n, tile0, job0, nj;
+    float eps, cos_t;
 };
 // Job tables travel BY VALUE in the kernel arguments (scalar loads from the kernarg segment): a table in device
 // memory costs every workgroup a dependent global load (~1 us) before it can fetch what the entries point to.
-constexpr int BATCH_MAXJ = 8;
-struct MarkJobs { MarkJob j[BATCH_MAXJ]; };
+constexpr int BATCH_MAXJ = 16;     // 8 per cloud
+struct MarkJobs { MarkJob j[BATCH_MAXJ]; ScanGroup g[2]; uint32_t ng; };
 struct CompactJobs { CompactJob j[BATCH_MAXJ]; };
-void score_mark_batch(plade_ctx *ctx, const float *x, const float *y, const float *z, const float *nx, const float *ny,
-                      const float *nz, const int32_t *assigned, uint32_t n, const MarkJob *jobs_host, uint32_t nj, float eps,
-                      float cos_thresh);
-// x, y, z: the cloud the indices refer to (only read by jobs with a frame)
-void compact_batch(plade_ctx *ctx, uint32_t n, const CompactJob *jobs_host, uint32_t nj, const float *x = nullptr,
-                   const float *y = nullptr, const float *z = nullptr);
+// groups: 1 or 2 clouds; tile0 / job0 are filled here (jobs_host holds group 0's jobs, then group 1's)
+void score_mark_batch(plade_ctx *ctx, hipStream_t stream, const MarkJob *jobs_host, ScanGroup *groups, uint32_t ng);
+// every job carries its cloud (nb, px, py, pz)
+void compact_batch(plade_ctx *ctx, hipStream_t stream, const CompactJob *jobs_host, uint32_t nj);
 
 }  // namespace plade
