@@ -51,12 +51,13 @@ struct plade_cloud {
     std::vector<float> host_copy;  // pos_nrm kept for the small host-side gathers
 };
 
-namespace plade { struct RegistrationWork; struct RansacWork; }
+namespace plade { struct RegistrationWork; struct RansacWork; struct PairAccept; }
 
 struct plade_ctx {
     int device = 0;
     plade::RegistrationWork *reg_work = nullptr;
     plade::RansacWork *ransac_work = nullptr;
+    plade::PairAccept *pair_accept = nullptr;   // lock-step acceptance batches of the two clouds of a registration
     plade_ctx *aux = nullptr;   // second stream + work areas: the source cloud's plane extraction runs
                                 // concurrently with the target's (independent until the line stage)
     hipStream_t stream = nullptr;

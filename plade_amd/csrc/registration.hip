@@ -22,11 +22,12 @@ RansacParams ransac_params(plade_ctx *ctx, uint32_t min_support, bool host_indic
 }
 
 // extract() (code/PLADE/plade.cpp:602-635)
-void extract(plade_ctx *ctx, const CloudDev &cloud, int init_min_support, PlaneSetOut &planes, bool host_indices) {
+void extract(plade_ctx *ctx, const CloudDev &cloud, int init_min_support, PlaneSetOut &planes, bool host_indices,
+             PairAccept *pair = nullptr, int who = 0) {
     const uint32_t min_num = (uint32_t)ctx->params.min_planes, max_num = (uint32_t)ctx->params.max_planes;
     const int min_allowed_support = 200;
     if (!ctx->ransac_work) ctx->ransac_work = ransac_work_create();
-    ransac_detect(ctx, *ctx->ransac_work, cloud, ransac_params(ctx, (uint32_t)init_min_support, host_indices), planes);
+    ransac_detect(ctx, *ctx->ransac_work, cloud, ransac_params(ctx, (uint32_t)init_min_support, host_indices), planes, pair, who);
     ctx->stats.add("n_detect_calls", 1);
     ctx->stats.add("n_score_passes", planes.n_score_passes);
     if (planes.P() >= min_num && planes.P() <= max_num) return;
@@ -56,7 +57,7 @@ void extract(plade_ctx *ctx, const CloudDev &cloud, int init_min_support, PlaneS
     int min_support = init_min_support / 2;
     int trials = 1;
     while (planes.P() < min_num && trials < max_trials && min_support >= min_allowed_support) {
-        ransac_detect(ctx, *ctx->ransac_work, cloud, ransac_params(ctx, (uint32_t)min_support, host_indices), planes);
+        ransac_detect(ctx, *ctx->ransac_work, cloud, ransac_params(ctx, (uint32_t)min_support, host_indices), planes, pair, who);
         ctx->stats.add("n_detect_calls", 1);
         ctx->stats.add("n_score_passes", planes.n_score_passes);
         min_support /= 2;
@@ -85,13 +86,18 @@ int register_clouds(plade_ctx *ctx, const CloudDev &tgt, const CloudDev &src, in
         aux->stats.clear();
         Err aux_err{0, ""};
         if (!ctx->reg_work) ctx->reg_work = registration_work_create();
+        // the acceptance batches of the two extractions are launched together (PLADE_PAIR_ACCEPT=0: each on its own)
+        static const bool pair_off = getenv("PLADE_PAIR_ACCEPT") && getenv("PLADE_PAIR_ACCEPT")[0] == '0';
+        if (!pair_off && !ctx->pair_accept) ctx->pair_accept = pair_accept_create();
+        PairAccept *pair = pair_off ? nullptr : ctx->pair_accept;
         auto one = [&](plade_ctx *c, const CloudDev &cloud, int ms, PlaneSetOut &out) {
+            const int who = c == ctx ? 0 : 1;
             // the next stage reads the index lists from the device; the host copy is only for dumps
             const bool host_idx = c->params.dump != 0;
-            if (auto_tune) extract(c, cloud, c->params.init_min_support, out, host_idx);
+            if (auto_tune) extract(c, cloud, c->params.init_min_support, out, host_idx, pair, who);
             else {  // plade.cpp:583-599
                 if (!c->ransac_work) c->ransac_work = ransac_work_create();
-                ransac_detect(c, *c->ransac_work, cloud, ransac_params(c, (uint32_t)ms, host_idx), out);
+                ransac_detect(c, *c->ransac_work, cloud, ransac_params(c, (uint32_t)ms, host_idx), out, pair, who);
             }
         };
         std::thread th([&]() {
