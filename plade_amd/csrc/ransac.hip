@@ -953,6 +953,7 @@ struct PairAccept {
                 int ns = 0;
                 for (int i = 0; i < 2; ++i) if (present[i]) both[ns++] = side[i];
                 err = Err{0, ""};
+                ctx->stats.add(ns == 2 ? "ransac_launches_merged" : "ransac_launches_single", 1);
                 try {
                     for (int i = 0; i < ns; ++i)
                         if (both[i].W != s.W && both[i].ready) HIP_TRY(hipStreamWaitEvent(ctx->stream, both[i].ready, 0));
