@@ -160,14 +160,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # test hook for boxes with one GPU: PLADE_BENCH_ONE_GPU=1 puts every rank on cuda:0 and exchanges over gloo (RCCL
+    # refuses two ranks on one device), so that the N > 1 control flow can be exercised there
+    one_gpu = os.environ.get("PLADE_BENCH_ONE_GPU") == "1"
+    if one_gpu:
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", world_size=world, rank=rank)  # nccl == RCCL on ROCm
+        dist.init_process_group(backend="gloo" if one_gpu else "nccl", world_size=world, rank=rank)  # nccl == RCCL on ROCm
     else:
         torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cpu") if one_gpu else torch.device("cuda", local_rank)
 
     import plade_amd
     from plade_amd.synth import make_pair

@@ -1,0 +1,31 @@
+"""bench.py's N > 1 control flow (rendezvous, barriers, max-over-ranks timing, result gather) on a one-GPU box: two
+ranks share cuda:0 and exchange over gloo (PLADE_BENCH_ONE_GPU=1; RCCL refuses two ranks on one device)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_two_ranks_on_one_gpu():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, PLADE_BENCH_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "4",
+           "--points", "200000", "--inflight", "3"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=540, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1            # rank 0 prints the one JSON line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 12 and d["scaling"] == "weak"
+    assert d["registrations_ok"] == 24 and d["results_bit_identical_per_pair_rank0"]
+    assert d["value"] > 0 and d["cpu_baseline"] is None   # the CPU leg runs at N = 1 only
