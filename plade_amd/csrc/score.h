@@ -31,8 +31,9 @@ void compact_masks(plade_ctx *ctx, CompactScratch &s, uint32_t n, const uint32_t
 // skip_flag (device, nullable): when *skip_flag != 0 the kernels return immediately and leave their
 // outputs untouched (used by the refit chain once it has converged).
 
-// Batched forms (one launch for up to 16 hypotheses; the cloud is read once).  The job tables live in
-// device memory; masks hold cdiv(n,1024)*256 bytes, block_counts cdiv(n,1024) words per job.
+// Batched forms (one launch for up to 16 hypotheses of up to two clouds; each cloud is read once).  The job
+// tables are host arrays copied into the kernel arguments; masks hold cdiv(n,1024)*256 bytes, block_counts
+// cdiv(n,1024) words per job.
 struct MarkJob {
     const float4 *plane;
     uint8_t *masks;
