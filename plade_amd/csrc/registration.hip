@@ -86,10 +86,13 @@ int register_clouds(plade_ctx *ctx, const CloudDev &tgt, const CloudDev &src, in
         aux->stats.clear();
         Err aux_err{0, ""};
         if (!ctx->reg_work) ctx->reg_work = registration_work_create();
-        // the acceptance batches of the two extractions are launched together (PLADE_PAIR_ACCEPT=0: each on its own)
-        static const bool pair_off = getenv("PLADE_PAIR_ACCEPT") && getenv("PLADE_PAIR_ACCEPT")[0] == '0';
-        if (!pair_off && !ctx->pair_accept) ctx->pair_accept = pair_accept_create();
-        PairAccept *pair = pair_off ? nullptr : ctx->pair_accept;
+        // The acceptance batches of the two extractions are launched together in throughput mode (sleeping host waits:
+        // several registrations in flight); a registration that has the GPU to itself (spinning waits) keeps them
+        // apart, because waiting for the other cloud costs it ~0.5 ms.  PLADE_PAIR_ACCEPT=1 / 0 forces either.
+        static const char *pair_env = getenv("PLADE_PAIR_ACCEPT");
+        const bool pair_on = pair_env ? pair_env[0] != '0' : ctx->params.host_wait != 0;
+        if (pair_on && !ctx->pair_accept) ctx->pair_accept = pair_accept_create();
+        PairAccept *pair = pair_on ? ctx->pair_accept : nullptr;
         auto one = [&](plade_ctx *c, const CloudDev &cloud, int ms, PlaneSetOut &out) {
             const int who = c == ctx ? 0 : 1;
             // the next stage reads the index lists from the device; the host copy is only for dumps
