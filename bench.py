@@ -283,7 +283,7 @@ def main():
             step(i)
             lat.append(time.perf_counter() - t1)
         latency_ms = min(lat) * 1e3
-        ctx.set_params(dump=2)
+        ctx.set_params(dump=2, host_wait=host_wait)   # the profiled step runs in the mode of the timed region
         step(0)
         st = ctx.stats()
         ctx.set_params(dump=0, host_wait=host_wait)
