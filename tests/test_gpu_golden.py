@@ -172,3 +172,20 @@ def test_g2_plane_sets_on_the_real_room_scan(ctx):
                 best.append(max([len(sets[q] & ref) / len(sets[q] | ref) for q in cand], default=0.0))
             assert min(best) > 0.85, (pre, draw, best)
             assert sum(b >= 0.97 for b in best) >= len(rc) - 1, (pre, draw, best)
+
+
+def test_g2_plane_sets_on_a_20k_synthetic_scene(ctx):
+    """G2, synthetic part: 20 000 points, libransac at min_support 250 -- every plane it found is found by
+    the GPU extraction with (nearly) the same support."""
+    g = load("g2_synth20k.npz")
+    rc, ro, ri = g["coef"], g["off"], g["idx"]
+    coef, off, idx = ctx.extract_planes(g["cloud"], int(g["min_support"]))
+    sets = [set(idx[off[p]:off[p + 1]].tolist()) for p in range(len(coef))]
+    best = []
+    for p in range(len(rc)):
+        ref = set(ri[ro[p]:ro[p + 1]].tolist())
+        cand = [q for q in range(len(coef)) if abs(coef[q, :3] @ rc[p, :3]) > 0.99]
+        best.append(max([len(sets[q] & ref) / len(sets[q] | ref) for q in cand], default=0.0))
+    assert min(best) > 0.85, best
+    assert sum(b >= 0.97 for b in best) >= len(rc) - 2, best
+    assert len(rc) <= len(coef) <= len(rc) + 6

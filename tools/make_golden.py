@@ -224,4 +224,8 @@ np.savez_compressed(os.path.join(OUT, "g9_room.npz"), target=rtg, source=rsr, gr
                     t_coef=rtpl[0], t_off=rtpl[1], t_idx=rtpl[2], s_coef=rspl[0], s_off=rspl[1], s_idx=rspl[2],
                     tb_coef=rtpl_b[0], tb_off=rtpl_b[1], tb_idx=rtpl_b[2], sb_coef=rspl_b[0], sb_off=rspl_b[1],
                     sb_idx=rspl_b[2])
+# ---- G2 (synthetic part): a 20k-point synthetic scene with libransac's planes at min_support 250 ------
+syn = sample_scene(20000, scene_seed=77, sample_seed=78, n_boxes=4)
+spl20 = R.ransac_detect(syn, 250, fake_time=5)
+np.savez_compressed(os.path.join(OUT, "g2_synth20k.npz"), cloud=syn, coef=spl20[0], off=spl20[1], idx=spl20[2], min_support=np.int32(250))
 print("golden fixtures written to", OUT, [f for f in sorted(os.listdir(OUT))])
