@@ -104,12 +104,19 @@ def cpu_baseline(n_points, pairs, min_s=10.0, budget_s=25.0):
         if t_total > budget_s:
             break
     kind = "port"
+    try:
+        model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")]
+    except Exception:
+        model = []
     what = ("plane extraction: reference Schnabel RANSAC built from /root/reference sources (oracle/_ref); "
             if ref is not None else "plane extraction: not timed (oracle/_ref absent), planes taken from the GPU run; ")
     return {
         "value": done / t_total if t_total > 0 else None,
         "unit": "registrations/s",
         "cores": 1,
+        "host_cpu_model": model[0] if model else None,
+        "host_logical_cpus": len(model) or os.cpu_count(),
+        "host_cpu_budget": _cpu_budget(),
         "kind": kind,
         "sample": f"{done} registrations of {min(done, len(pairs))} synthetic {n_points}-pt pair(s), {t_total:.1f} s CPU ({t_extract:.1f} s in plane extraction); "
                   + what + "registration stages: oracle restatement; all registrations ok=" + str(ok_all),
@@ -151,6 +158,8 @@ def main():
     ap.add_argument("--inflight", type=int, default=8,
                     help="registrations in flight per GPU: independent pairs, one plade_ctx + host thread each "
                          "(a single registration is latency-bound and leaves most of the GPU idle)")
+    ap.add_argument("--host-steps", type=int, default=128,
+                    help="steps of the extra host-buffer leg (plade_registration on page-locked host arrays, H2D inside); 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -184,7 +193,7 @@ def main():
         # into the container's CPU quota when 8 ranks share a node); one at a time: spin for the lowest latency
         args.host_wait = "sleep" if M > 1 else "spin"
     host_wait = {"spin": 0, "sleep": 1}[args.host_wait]
-    ctxs = [plade_amd.Context(local_rank, host_wait=host_wait) for _ in range(M)]
+    ctxs = [plade_amd.Context(local_rank, host_wait=host_wait, orient_normals=1) for _ in range(M)]
     ctx = ctxs[0]
     # synthetic pairs: seeds are global pair ids (batch of independent pairs sharded across ranks); every
     # worker holds its own resident copy so the workers share nothing
@@ -201,6 +210,8 @@ def main():
         ok, T = ctxs[w].registration_dev(ct, cs)
         return ok, T
 
+    step_fn = [step]
+
     def run_steps(first, count, out):
         """Steps first .. first+count-1; every worker takes the next free step (a shared counter), so the
         workers stay busy until the last step has been handed out."""
@@ -214,7 +225,7 @@ def main():
                     nxt[0] += 1
                 if i >= first + count:
                     return
-                out[i - first] = step(i, w)
+                out[i - first] = step_fn[0](i, w)
         if M == 1:
             work(0)
             return
@@ -270,6 +281,38 @@ def main():
     identical = all(np.array_equal(results[i], results[i % len(pairs)]) for i in range(len(results)))
     # accuracy of the timed registrations on this rank vs the generator's ground truth
     errs = [float(np.linalg.norm(results[i].astype(np.float64) - pairs[i % len(pairs)][2])) for i in range(len(results))]
+
+    # ---- host-buffer leg (SURVEY.md 8d's timed region: registration(T, target, source) of plade.h:58 on clouds in HOST
+    #      memory, H2D and D2H inside): plade_registration on the caller's page-locked arrays (plade_host_pin, done once
+    #      outside the timed region like the allocation of any staging buffer), same contexts in flight, so the upload of
+    #      one registration overlaps the kernels of the others.  Reported next to `value`, never as `value`.
+    host_leg = None
+    if args.host_steps > 0:
+        for tg, sr, _ in pairs:
+            ctx.pin(tg); ctx.pin(sr)
+
+        def hstep(i, w=0):
+            tg, sr, _ = pairs[i % len(pairs)]
+            return ctxs[w].registration(tg, sr)
+        step_fn[0] = hstep
+        warm = [None] * (M * len(pairs))
+        run_steps(0, len(warm), warm)          # every context once per pair: its upload buffers exist
+        torch.cuda.synchronize()
+        th0 = time.perf_counter()
+        hres = [None] * args.host_steps
+        run_steps(0, args.host_steps, hres)
+        torch.cuda.synchronize()
+        h_el = time.perf_counter() - th0
+        step_fn[0] = step
+        same = all(np.array_equal(hres[i][1], results[i % len(pairs)]) for i in range(len(hres)))
+        mb = sum(tg.nbytes + sr.nbytes for tg, sr, _ in pairs) / len(pairs) / 1e6
+        host_leg = {"value": args.host_steps / h_el, "unit": "registrations/s (this rank)", "steps": args.host_steps,
+                    "ms_per_step": h_el / args.host_steps * 1e3, "h2d_MB_per_step": mb,
+                    "pcie_GB_per_s": mb * 1e-3 * args.host_steps / h_el,
+                    "identical_to_resident_results": bool(same),
+                    "note": "clouds in page-locked host memory, plade_registration (H2D + SoA conversion + bounding box inside)"}
+        for tg, sr, _ in pairs:
+            ctx.unpin(tg); ctx.unpin(sr)
 
     # ---- roofline leg: one extra profiled step (HIP events on the ctx stream around every launch) ----
     roofline = None
@@ -338,7 +381,9 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"Synthetic {args.points}-pt indoor scan pair, ~30 planes (BASELINE configs[2]); "
-                                   "full registration(T,target,source) = plane extraction + registration, clouds resident in HBM",
+                                   "full registration(T,target,source) = plane extraction + registration, clouds resident in HBM; "
+                                   "plade_params.orient_normals=1 (planes oriented like their inliers' normals: the generator's "
+                                   "Manhattan scenes need it, DESIGN.md section 2); CPU baseline applies the same rule",
                        "points_per_cloud": args.points, "pairs_per_rank": args.pairs,
                        "registrations_in_flight_per_gpu": M, "host_wait": args.host_wait,
                        "parallelism": f"independent pairs sharded over {world} GPU(s), {M} in flight per GPU"},
@@ -351,6 +396,7 @@ def main():
                            "cpu_budget": _cpu_budget(),
                            "cgroup_throttled_periods": (thr1[0] - thr0[0]) if thr0 and thr1 else None,
                            "cgroup_throttled_usec": (thr1[1] - thr0[1]) if thr0 and thr1 else None},
+            "host_buffers_rank0": host_leg,
             "roofline": roofline,
             "cpu_baseline": cpu,
             "stage_seconds_profiled_step": stage_times,

@@ -37,9 +37,14 @@ const char *plade_version(void);
  *   min_planes      10     code/PLADE/plade.cpp:603
  *   max_candidates  200    code/PLADE/plade.cpp:54    (maxCandidateResultNum)
  *   init_min_support 10000 code/PLADE/plade.cpp:602
- *   orient_normals  1      0 = reference behaviour (plane_extraction.cpp:43-58 correct_normal is a
- *                          NaN no-op: plane normal keeps the LS-fit sign); 1 = the evident intent:
- *                          flip the plane normal to agree with the mean inlier point normal.
+ *   orient_normals  0      0 = reference behaviour (plane_extraction.cpp:43-58: correct_normal divides by a
+ *                          counter that stays 0, so its average normal is NaN and the test never flips:
+ *                          the plane normal keeps the sign of the LS-fit eigenvector); 1 = the evident
+ *                          intent: flip (n, d) so that n agrees with the mean normal of the plane's inliers.
+ *                          Env PLADE_ORIENT_NORMALS=1 turns it on for the C++ API / CLI built on this ABI.
+ *   unoriented_normals 0   1 = the "unoriented normals" mode README.md:109-110 describes: every plane takes part
+ *                          with both orientations (2x planes, ~4x line pairs / descriptors), so a pair registers
+ *                          whatever the signs of the extracted plane normals are.  Env PLADE_UNORIENTED_NORMALS=1.
  *   ransac_seed     fixed  the reference seeds from time(NULL) (RansacShapeDetector.cpp:463-464)
  *   dump            0      keep named intermediates for plade_dump_get (tests)            */
 typedef struct plade_params {
@@ -54,7 +59,7 @@ typedef struct plade_params {
                           * one CPU busy per waiting thread), 1 = poll + short sleeps (throughput mode: many
                           * contexts in flight per CPU; adds ~30 us per wait).  Env PLADE_HOST_WAIT=spin|sleep
                           * overrides the default at context creation. */
-    int32_t reserved0;
+    int32_t unoriented_normals;
 } plade_params;
 void plade_default_params(plade_params *p);
 int plade_set_params(plade_ctx *ctx, const plade_params *p);
@@ -141,6 +146,12 @@ int plade_registration(plade_ctx *ctx, const float *tgt_pos_nrm, uint32_t n_t,
 int plade_registration_minsupport(plade_ctx *ctx, const float *tgt_pos_nrm, uint32_t n_t,
                                   const float *src_pos_nrm, uint32_t n_s, int32_t min_support_t,
                                   int32_t min_support_s, float *T16);
+
+/* Optional page-locking of caller-owned cloud buffers (hipHostRegister / hipHostUnregister): the host-pointer overloads
+ * above then upload by asynchronous DMA instead of through the runtime's bounce buffer.  The reference has no counterpart
+ * (its clouds never leave host memory); a host that keeps its PLY staging buffers alive pins them once. */
+int plade_host_pin(plade_ctx *ctx, const void *ptr, size_t bytes);
+int plade_host_unpin(plade_ctx *ctx, const void *ptr);
 
 /* Device-resident clouds: upload once, register many times (bench: inputs resident in HBM). */
 int plade_cloud_upload(plade_ctx *ctx, const float *pos_nrm, uint32_t n, plade_cloud **out);

@@ -58,6 +58,7 @@ class Oracle:
         L.orc_reg_create.restype = _p
         L.orc_reg_destroy.argtypes = [_p]
         L.orc_registration.argtypes = [_p, _p, _i, _p, _i, _p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _p]
+        L.orc_registration_sampled.argtypes = [_p, _p, _i, _p, _i, _p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _p]
         L.orc_dump_get.argtypes = [_p, C.c_char_p, _p, _p]
 
     # -- A3 ------------------------------------------------------------------
@@ -162,8 +163,10 @@ class Oracle:
                                         src_radius, inlier_dist)
 
     # -- whole deterministic stage ---------------------------------------------
-    def registration(self, tgt, src, tgt_planes, src_planes, voxel_sort_mode=0, max_candidates=200):
-        """tgt/src: N x 6 float32. *_planes: (coef P x 4, offsets P+1, idx).  Returns (ok, T, dump dict)."""
+    def registration(self, tgt, src, tgt_planes, src_planes, voxel_sort_mode=0, max_candidates=200, pen_stride=1):
+        """tgt/src: N x 6 float32. *_planes: (coef P x 4, offsets P+1, idx).  Returns (ok, T, dump dict).
+        pen_stride > 1: sampled run for stress configurations (orc_registration_sampled) -- only every pen_stride-th
+        candidate goes through the penetration test (pen_flags -1 elsewhere) and the run ends after that stage."""
         tgt = _f32(tgt)
         src = _f32(src)
         tc, to, ti = _f32(tgt_planes[0]), _i32(tgt_planes[1]), _i32(tgt_planes[2])
@@ -171,9 +174,9 @@ class Oracle:
         T = np.zeros((4, 4), np.float32)
         h = self.L.orc_reg_create()
         try:
-            ok = self.L.orc_registration(h, _ptr(tgt), len(tgt), _ptr(src), len(src), _ptr(tc), _ptr(to), _ptr(ti),
-                                         len(tc), _ptr(sc), _ptr(so), _ptr(si), len(sc), voxel_sort_mode,
-                                         max_candidates, _ptr(T))
+            ok = self.L.orc_registration_sampled(h, _ptr(tgt), len(tgt), _ptr(src), len(src), _ptr(tc), _ptr(to), _ptr(ti),
+                                                 len(tc), _ptr(sc), _ptr(so), _ptr(si), len(sc), voxel_sort_mode,
+                                                 max_candidates, pen_stride, _ptr(T))
             dump = _read_dump(self.L.orc_dump_get, h, ORC_DUMP_FIELDS)
         finally:
             self.L.orc_reg_destroy(h)

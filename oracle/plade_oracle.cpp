@@ -1087,6 +1087,14 @@ int orc_registration(orc_reg *h, const float *tgt_pn, int nt, const float *src_p
                      const int32_t *tgt_off, const int32_t *tgt_idx, int pt, const float *src_planes,
                      const int32_t *src_off, const int32_t *src_idx, int ps, int sort_mode, int max_candidates,
                      float *T16_out) {
+    return orc_registration_sampled(h, tgt_pn, nt, src_pn, ns, tgt_planes, tgt_off, tgt_idx, pt, src_planes, src_off, src_idx, ps,
+                                    sort_mode, max_candidates, 1, T16_out);
+}
+
+int orc_registration_sampled(orc_reg *h, const float *tgt_pn, int nt, const float *src_pn, int ns, const float *tgt_planes,
+                             const int32_t *tgt_off, const int32_t *tgt_idx, int pt, const float *src_planes,
+                             const int32_t *src_off, const int32_t *src_idx, int ps, int sort_mode, int max_candidates,
+                             int pen_stride, float *T16_out) {
     h->blobs.clear();
     std::vector<double> tim;
     std::string tim_names;
@@ -1349,6 +1357,11 @@ int orc_registration(orc_reg *h, const float *tgt_pn, int nt, const float *src_p
             for (size_t i = 0; i < matchedPlanes[m].size(); ++i) {
                 if (count++ > max_candidates) { stop = true; break; }
                 int index = matchedPlanes[m][i];
+                if (pen_stride > 1 && (int)tested.size() % pen_stride != 0) {   // sampled run: candidate not evaluated
+                    tested.push_back(index);
+                    penflag.push_back(-1);
+                    continue;
+                }
                 float T16[16];
                 make_T(Rs[index], Ts[index], T16);
                 bool isPen = false;
@@ -1392,7 +1405,11 @@ int orc_registration(orc_reg *h, const float *tgt_pn, int nt, const float *src_p
     h->put("pen_tested", tested.data(), tested.size());
     h->put("pen_flags", penflag.data(), penflag.size());
     lap("penetration");
-    if (results.empty()) { h->put("timing", tim.data(), tim.size()); h->put("timing_names", tim_names.data(), tim_names.size()); return 0; }
+    if (pen_stride > 1 || results.empty()) {   // a sampled run ends here: the verification needs every flag
+        h->put("timing", tim.data(), tim.size());
+        h->put("timing_names", tim_names.data(), tim_names.size());
+        return 0;
+    }
 
     // plade.cpp:545-575 verification
     GridIndex tg;

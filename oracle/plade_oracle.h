@@ -63,6 +63,14 @@ int orc_registration(orc_reg *h, const float *tgt_pos_nrm, int nt, const float *
                      int pt, const float *src_planes, const int32_t *src_offsets,
                      const int32_t *src_idx, int ps, int voxel_sort_mode, int max_candidates,
                      float *T16_out);
+/* Stress configurations (10^4 candidates): the same run, but only every pen_stride-th candidate of the penetration
+ * filter's list is evaluated (pen_flags = -1 for the others) and the run ends after that stage (returns 0) with
+ * every intermediate up to pen_tested / pen_flags dumped.  pen_stride = 1 is orc_registration. */
+int orc_registration_sampled(orc_reg *h, const float *tgt_pos_nrm, int nt, const float *src_pos_nrm, int ns,
+                             const float *tgt_planes, const int32_t *tgt_offsets, const int32_t *tgt_idx,
+                             int pt, const float *src_planes, const int32_t *src_offsets,
+                             const int32_t *src_idx, int ps, int voxel_sort_mode, int max_candidates,
+                             int pen_stride, float *T16_out);
 /* name -> (ptr, nbytes); returns 0 if found */
 int orc_dump_get(orc_reg *h, const char *name, const void **ptr, int64_t *nbytes);
 /* seconds spent per stage in the last orc_registration: name list via orc_dump "timing_names" */

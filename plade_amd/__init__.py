@@ -21,7 +21,7 @@ ABI_SYMBOLS = [
     "plade_overlap_counts", "plade_average_spacing", "plade_voxel_downsample", "plade_registration_planes",
     "plade_registration", "plade_registration_minsupport", "plade_cloud_upload", "plade_cloud_free",
     "plade_registration_dev", "plade_dump_get", "plade_stats_get", "plade_kernel_time", "plade_plane_component",
-    "plade_sort_pairs",
+    "plade_sort_pairs", "plade_host_pin", "plade_host_unpin",
 ]
 
 
@@ -34,7 +34,7 @@ class PladeError(RuntimeError):
 class Params(C.Structure):
     _fields_ = [("max_planes", C.c_int32), ("min_planes", C.c_int32), ("max_candidates", C.c_int32),
                 ("init_min_support", C.c_int32), ("orient_normals", C.c_int32), ("dump", C.c_int32),
-                ("ransac_seed", C.c_uint64), ("host_wait", C.c_int32), ("reserved0", C.c_int32)]
+                ("ransac_seed", C.c_uint64), ("host_wait", C.c_int32), ("unoriented_normals", C.c_int32)]
 
 
 _lib = None
@@ -84,6 +84,8 @@ def load_library(path=LIB_PATH):
     sig("plade_kernel_time", argtypes=[p, C.c_char_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)])
     sig("plade_plane_component", argtypes=[p, p, u32, p, p, p, u32, f, C.c_int, f, p, p, p, p])
     sig("plade_sort_pairs", argtypes=[p, p, p, u32, C.c_int, C.c_int, p, p])
+    sig("plade_host_pin", argtypes=[p, p, C.c_size_t])
+    sig("plade_host_unpin", argtypes=[p, p])
     _lib = L
     return L
 
@@ -290,6 +292,16 @@ class Context:
 
     def upload(self, pos_nrm):
         return Cloud(self, pos_nrm)
+
+    def pin(self, arr):
+        """Page-lock a C-contiguous float32 array the caller keeps alive (plade_host_pin); registration() calls that are
+        handed this very array then upload it by asynchronous DMA."""
+        assert arr.dtype == np.float32 and arr.flags["C_CONTIGUOUS"]
+        self._check(self.L.plade_host_pin(self.h, _ptr(arr), arr.nbytes))
+        return arr
+
+    def unpin(self, arr):
+        self._check(self.L.plade_host_unpin(self.h, _ptr(arr)))
 
     def registration_dev(self, tgt_cloud, src_cloud):
         T = np.zeros((4, 4), np.float32)

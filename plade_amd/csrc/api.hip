@@ -11,12 +11,15 @@ extern "C" void plade_default_params(plade_params *p) {
     p->min_planes = 10;         // code/PLADE/plade.cpp:603
     p->max_candidates = 200;    // code/PLADE/plade.cpp:54
     p->init_min_support = 10000;  // code/PLADE/plade.cpp:602
-    p->orient_normals = 1;
+    p->orient_normals = 0;      // the reference's behaviour (plane_extraction.cpp:43-58 never flips)
     p->dump = 0;
     p->ransac_seed = 0x9E3779B97F4A7C15ull;
     p->host_wait = 0;
-    p->reserved0 = 0;
+    p->unoriented_normals = 0;
     if (const char *w = getenv("PLADE_HOST_WAIT")) p->host_wait = (w[0] == 's' && w[1] == 'l') ? 1 : 0;
+    // opt-in switches for programs that cannot pass plade_params (the CLI, the C++ registration() overloads)
+    if (const char *w = getenv("PLADE_ORIENT_NORMALS")) p->orient_normals = atoi(w) != 0;
+    if (const char *w = getenv("PLADE_UNORIENTED_NORMALS")) p->unoriented_normals = atoi(w) != 0;
 }
 
 extern "C" const char *plade_version(void) { return "plade-hip 0.1 (gfx950)"; }

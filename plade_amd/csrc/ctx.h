@@ -61,6 +61,9 @@ struct plade_ctx {
     plade_ctx *aux = nullptr;   // second stream + work areas: the source cloud's plane extraction runs
                                 // concurrently with the target's (independent until the line stage)
     hipStream_t stream = nullptr;
+    // device copies of the clouds the host-pointer entry points register (grow-only, reused from call to call: a
+    // hipMalloc / hipFree pair per call costs more than the upload itself, and hipFree synchronises the device)
+    plade::CloudDev up_tgt, up_src;
     plade_params params;
     std::string last_error;
     std::map<std::string, std::vector<char>> dump;

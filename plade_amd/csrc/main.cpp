@@ -1,139 +1,231 @@
-// plade_amd/csrc/main.cpp -- the PLADE command line (code/PLADE/main.cpp:30-159): same positional
-// arguments, same result-file grammar, same exit codes.
+// plade_amd/csrc/main.cpp -- the PLADE command line on the GPU library.
+//
 //   PLADE target.ply source.ply result.txt      register one pair
 //   PLADE file_pairs.txt result.txt             batch mode
-// Batch mode additionally shards the pairs over the GPUs of the node when PLADE_GPUS=N is set, with
-// PLADE_INFLIGHT=M (default 4) worker threads per GPU, each with its own plade_ctx: pairs are independent,
-// one registration alone is latency-bound, and PLY parsing of one pair overlaps the GPU work of the others.
-// Results are written in input order.
+//
+// What is kept from the reference's driver (code/PLADE/main.cpp:30-159) is its *contract*: the positional
+// arguments, every console / result-file string (collected in `text` below, each with the line it comes from),
+// the result-file grammar and the exit codes.  The control flow is this program's own:
+//
+//   * the pair list is read up front and turned into jobs,
+//   * PLADE_GPUS=N x PLADE_INFLIGHT=M worker threads (one plade_ctx each) take jobs from a shared counter
+//     (pairs are independent; PLY parsing of one pair overlaps the GPU work of the others),
+//   * an ordered writer appends every pair's block to the result file as soon as that pair AND all earlier
+//     pairs are done, and flushes it -- like the reference, which writes each block when its registration
+//     returns (main.cpp:134-146), a batch that is interrupted leaves a valid prefix of the results behind,
+//   * each worker's console output is collected per pair and printed in input order with the block, so the
+//     console reads like the reference's sequential run whatever the number of workers.
 #include "plade.h"
 
-#include <atomic>
+#include <algorithm>
+#include <condition_variable>
 #include <cstdlib>
 #include <fstream>
 #include <iostream>
+#include <mutex>
 #include <sstream>
 #include <thread>
 
-static void usage() {
-    std::cerr << "PLADE can register two point clouds dominated by planar structures. It can be used in two ways.\n"
-              << "-------------------------------------------------------------------------------------------------\n"
-              << "Usage 1: register a 'source' point cloud to a 'target' point cloud.\n"
-              << "    ---------------------------------------------------------------------------------------------\n"
-              << "    You can call PLADE with three arguments. The first two are the file names of a target point\n"
-              << "    cloud and a source point cloud (the target point cloud file name always comes first). The\n"
-              << "    third argument specifies the result file name. Below is an example:\n"
-              << "         ./PLADE  room_target.ply  room_source.ply  result.txt\n"
-              << "    The target point cloud file name always comes first, and both point cloud files must be in\n"
-              << "    the 'ply' format. The result file will store the registration result, which is a 4 by 4\n"
-              << "    transformation matrix that aligns the source point cloud to the target point cloud.\n"
-              << "-------------------------------------------------------------------------------------------------\n"
-              << "Usage 2: register a bunch of point cloud pairs.\n"
-              << "    ---------------------------------------------------------------------------------------------\n"
-              << "    You can call PLADE with two arguments: a file (e.g., file_pairs.txt) specifying all pairs\n"
-              << "    of target/source point cloud files and a result file. Below is an example:\n"
-              << "         ./PLADE  file_pairs.txt  result.txt\n"
-              << "    In 'file_pairs.txt', every two consecutive lines store two file names. The first line is the\n"
-              << "    file name of a target point cloud, and the second line is the file name of a source point cloud.\n"
-              << "    Both point cloud files must be in the 'ply' format. The result file will store the registration\n"
-              << "    results, a set of 4 by 4 transformation matrices. Each matrix aligns a source point cloud to\n"
-              << "    its corresponding target point cloud.\n";
+namespace {
+
+// ---- every user-visible string of the reference's driver, by source line ------------------------------------
+namespace text {
+const char *const usage =   // main.cpp:49-74
+    "PLADE can register two point clouds dominated by planar structures. It can be used in two ways.\n"
+    "-------------------------------------------------------------------------------------------------\n"
+    "Usage 1: register a 'source' point cloud to a 'target' point cloud.\n"
+    "    ---------------------------------------------------------------------------------------------\n"
+    "    You can call PLADE with three arguments. The first two are the file names of a target point\n"
+    "    cloud and a source point cloud (the target point cloud file name always comes first). The\n"
+    "    third argument specifies the result file name. Below is an example:\n"
+    "         ./PLADE  room_target.ply  room_source.ply  result.txt\n"
+    "    The target point cloud file name always comes first, and both point cloud files must be in\n"
+    "    the 'ply' format. The result file will store the registration result, which is a 4 by 4\n"
+    "    transformation matrix that aligns the source point cloud to the target point cloud.\n"
+    "-------------------------------------------------------------------------------------------------\n"
+    "Usage 2: register a bunch of point cloud pairs.\n"
+    "    ---------------------------------------------------------------------------------------------\n"
+    "    You can call PLADE with two arguments: a file (e.g., file_pairs.txt) specifying all pairs\n"
+    "    of target/source point cloud files and a result file. Below is an example:\n"
+    "         ./PLADE  file_pairs.txt  result.txt\n"
+    "    In 'file_pairs.txt', every two consecutive lines store two file names. The first line is the\n"
+    "    file name of a target point cloud, and the second line is the file name of a source point cloud.\n"
+    "    Both point cloud files must be in the 'ply' format. The result file will store the registration\n"
+    "    results, a set of 4 by 4 transformation matrices. Each matrix aligns a source point cloud to\n"
+    "    its corresponding target point cloud.\n";
+const char *const cannot_open_result = "failed opening the result file: ";                                      // main.cpp:81,102
+const char *const cannot_open_list = "failed opening the file containing pairs of point cloud names: ";         // main.cpp:96
+const char *const missing_file = "file doesn't exist: ";                                                        // main.cpp:127
+const char *const target_tag = "target: ";                                                                      // main.cpp:86,134
+const char *const source_tag = "source: ";                                                                      // main.cpp:87,135
+const char *const matrix_tag = "transformation:\n";                                                             // main.cpp:88,138
+const char *const failed_block = "registration failed, an identity matrix is recorded:\n";                      // main.cpp:93,142
+const char *const written = "the registration result has been written into file: ";                             // main.cpp:89,154
+const char *const all_failed_a = "registration all failed (", *const all_failed_b = " pairs)";                  // main.cpp:148
+const char *const some_failed_a = "registration of ", *const some_failed_b = " (out of ", *const some_failed_c = ") pairs failed";  // main.cpp:152
+}  // namespace text
+
+using Matrix4 = Eigen::Matrix<float, 4, 4>;
+
+struct Job {
+    std::string target, source;
+};
+
+struct Outcome {
+    bool ok = false;
+    Matrix4 T;
+    std::string console_out, console_err;
+};
+
+// One block of the result file (main.cpp:86-88 / 93 for a single pair, :134-143 in batch mode, where every block
+// is followed by an empty line).
+void write_block(std::ostream &os, const Job &job, const Outcome &r, bool batch) {
+    if (batch || r.ok) os << text::target_tag << job.target << std::endl << text::source_tag << job.source << std::endl;
+    if (r.ok) os << text::matrix_tag << r.T << std::endl;
+    else os << text::failed_block << Matrix4::Identity() << std::endl;
+    if (batch) os << std::endl;
 }
 
-int main(int argc, char **argv) {
-    if (argc != 3 && argc != 4) {
-        usage();
-        return EXIT_FAILURE;
-    }
-    if (argc == 4) {
-        std::ofstream output(argv[3]);
-        if (!output.is_open()) {
-            std::cerr << "failed opening the result file: " << argv[3] << std::endl;
-            return EXIT_FAILURE;
+int env_int(const char *name, int fallback) {
+    const char *v = getenv(name);
+    return std::max(1, v ? atoi(v) : fallback);
+}
+
+// The pair list (main.cpp:117-131): empty lines are skipped, a name that cannot be opened is reported and
+// skipped, and what remains is taken two at a time (a name left over at the end is dropped).
+bool read_jobs(const char *list_path, std::vector<Job> &jobs) {
+    std::ifstream in(list_path);
+    if (!in.is_open()) return false;
+    std::string line, pending;
+    bool have_pending = false;
+    while (std::getline(in, line)) {
+        if (line.empty()) continue;
+        if (!std::ifstream(line).is_open()) {
+            std::cerr << text::missing_file << line << std::endl;
+            continue;
         }
-        Eigen::Matrix<float, 4, 4> transformation;
-        if (registration(transformation, argv[1], argv[2])) {
-            output << "target: " << argv[1] << std::endl;
-            output << "source: " << argv[2] << std::endl;
-            output << "transformation:\n" << transformation << std::endl;
-            std::cout << "the registration result has been written into file: " << argv[3] << std::endl;
-            return EXIT_SUCCESS;
-        } else {
-            output << "registration failed, an identity matrix is recorded:\n" << Eigen::Matrix<float, 4, 4>::Identity() << std::endl;
-            return EXIT_FAILURE;
+        if (!have_pending) { pending = line; have_pending = true; }
+        else { jobs.push_back(Job{pending, line}); have_pending = false; }
+    }
+    return true;
+}
+
+// Appends finished pairs to the result file in input order; pair i is written once pairs 0..i are all done.
+class OrderedWriter {
+public:
+    OrderedWriter(std::ostream &file, const std::vector<Job> &jobs) : file_(file), jobs_(jobs), done_(jobs.size()), have_(jobs.size(), 0) {}
+    void submit(size_t i, Outcome &&r) {
+        std::lock_guard<std::mutex> lk(m_);
+        done_[i] = std::move(r);
+        have_[i] = 1;
+        while (next_ < jobs_.size() && have_[next_]) {
+            Outcome &o = done_[next_];
+            std::cout << o.console_out << std::flush;
+            std::cerr << o.console_err << std::flush;
+            write_block(file_, jobs_[next_], o, true);
+            file_.flush();
+            (o.ok ? n_ok_ : n_failed_) += 1;
+            o = Outcome();   // the text is not needed any more
+            ++next_;
         }
     }
-    // batch mode
-    std::ifstream input(argv[1]);
-    if (!input.is_open()) {
-        std::cerr << "failed opening the file containing pairs of point cloud names: " << argv[1] << std::endl;
-        return EXIT_FAILURE;
+    int n_ok() const { return n_ok_; }
+    int n_failed() const { return n_failed_; }
+
+private:
+    std::mutex m_;
+    std::ostream &file_;
+    const std::vector<Job> &jobs_;
+    std::vector<Outcome> done_;
+    std::vector<char> have_;
+    size_t next_ = 0;
+    int n_ok_ = 0, n_failed_ = 0;
+};
+
+Outcome run_job(const Job &job, bool capture_console) {
+    Outcome r;
+    std::ostringstream out, err;
+    if (capture_console) plade_set_thread_console(&out, &err);
+    try {
+        r.ok = registration(r.T, job.target, job.source);
+    } catch (const std::exception &e) {   // nothing a single malformed pair does may take the batch down
+        err << "registration failed: " << e.what() << std::endl;
+        r.ok = false;
     }
-    std::ofstream output(argv[2]);
+    if (capture_console) {
+        plade_set_thread_console(nullptr, nullptr);
+        r.console_out = out.str();
+        r.console_err = err.str();
+    }
+    return r;
+}
+
+int single_pair(const char *target, const char *source, const char *result_path) {
+    std::ofstream output(result_path);
     if (!output.is_open()) {
-        std::cerr << "failed opening the result file: " << argv[2] << std::endl;
+        std::cerr << text::cannot_open_result << result_path << std::endl;
         return EXIT_FAILURE;
     }
-    auto is_file = [](const std::string &filename) -> bool {
-        std::ifstream fin(filename);
-        return fin.is_open();
-    };
-    std::vector<std::pair<std::string, std::string>> pairs;
-    while (!input.eof()) {
-        std::vector<std::string> file_pair;
-        while (!input.eof() && file_pair.size() < 2) {
-            std::string file_name;
-            getline(input, file_name);
-            if (!file_name.empty()) {
-                if (is_file(file_name)) file_pair.push_back(file_name);
-                else std::cerr << "file doesn't exist: " << file_name << std::endl;
-            }
-        }
-        if (file_pair.size() == 2) pairs.push_back(std::make_pair(file_pair[0], file_pair[1]));
+    const Job job{target, source};
+    const Outcome r = run_job(job, false);
+    write_block(output, job, r, false);
+    if (!r.ok) return EXIT_FAILURE;
+    std::cout << text::written << result_path << std::endl;
+    return EXIT_SUCCESS;
+}
+
+int batch(const char *list_path, const char *result_path) {
+    std::vector<Job> jobs;
+    if (!std::ifstream(list_path).is_open()) {
+        std::cerr << text::cannot_open_list << list_path << std::endl;
+        return EXIT_FAILURE;
     }
-    const char *env = getenv("PLADE_GPUS");
-    const int n_gpus = std::max(1, env ? atoi(env) : 1);
-    const char *env_m = getenv("PLADE_INFLIGHT");
-    const int per_gpu = std::max(1, env_m ? atoi(env_m) : 4);
-    const int n_workers = (int)std::min<size_t>((size_t)n_gpus * per_gpu, std::max<size_t>(pairs.size(), 1));
-    std::vector<Eigen::Matrix<float, 4, 4>> results(pairs.size());
-    std::vector<char> status(pairs.size(), 0);
-    std::atomic<size_t> next(0);
+    std::ofstream output(result_path);
+    if (!output.is_open()) {
+        std::cerr << text::cannot_open_result << result_path << std::endl;
+        return EXIT_FAILURE;
+    }
+    read_jobs(list_path, jobs);
+    const int n_gpus = env_int("PLADE_GPUS", 1), per_gpu = env_int("PLADE_INFLIGHT", 4);
+    const int n_workers = (int)std::min<size_t>((size_t)n_gpus * per_gpu, std::max<size_t>(jobs.size(), 1));
+    OrderedWriter writer(output, jobs);
+    std::mutex take;
+    size_t next = 0;
     auto worker = [&](int gpu) {
         plade_select_device(gpu);
         for (;;) {
-            const size_t i = next.fetch_add(1);
-            if (i >= pairs.size()) break;
-            status[i] = registration(results[i], pairs[i].first, pairs[i].second) ? 1 : 0;
+            size_t i;
+            { std::lock_guard<std::mutex> lk(take); i = next++; }
+            if (i >= jobs.size()) break;
+            writer.submit(i, run_job(jobs[i], true));
         }
+        plade_release_thread_context();   // the worker's plade_ctx (work areas in HBM) goes with the thread
     };
-    if (n_workers == 1) worker(0);
+    if (n_workers <= 1) worker(0);
     else {
-        // several pairs in flight: the worker threads poll + sleep instead of spinning on the GPU (plade_params.host_wait),
+        // several pairs in flight: the workers poll + sleep instead of spinning on the GPU (plade_params.host_wait),
         // so that the workers of all GPUs fit the host's CPUs
         setenv("PLADE_HOST_WAIT", "sleep", 0);
-        std::vector<std::thread> th;
-        for (int w = 0; w < n_workers; ++w) th.emplace_back(worker, w % n_gpus);
-        for (auto &t : th) t.join();
+        std::vector<std::thread> pool;
+        for (int w = 0; w < n_workers; ++w) pool.emplace_back(worker, w % n_gpus);
+        for (std::thread &t : pool) t.join();
     }
-    int count_success = 0, count_failure = 0;
-    for (size_t i = 0; i < pairs.size(); ++i) {
-        output << "target: " << pairs[i].first << std::endl;
-        output << "source: " << pairs[i].second << std::endl;
-        if (status[i]) {
-            output << "transformation:\n" << results[i] << std::endl << std::endl;
-            ++count_success;
-        } else {
-            output << "registration failed, an identity matrix is recorded:\n" << Eigen::Matrix<float, 4, 4>::Identity() << std::endl << std::endl;
-            ++count_failure;
-        }
-    }
-    if (count_success == 0) {
-        std::cerr << "registration all failed (" << count_failure << " pairs)" << std::endl;
+    const int ok = writer.n_ok(), failed = writer.n_failed();
+    if (ok == 0) {
+        std::cerr << text::all_failed_a << failed << text::all_failed_b << std::endl;
         return EXIT_FAILURE;
     }
-    if (count_failure > 0)
-        std::cerr << "registration of " << count_failure << " (out of " << count_failure + count_success << ") pairs failed" << std::endl;
-    std::cout << "the registration result has been written into file: " << argv[2] << std::endl;
+    if (failed > 0) std::cerr << text::some_failed_a << failed << text::some_failed_b << failed + ok << text::some_failed_c << std::endl;
+    std::cout << text::written << result_path << std::endl;
     return EXIT_SUCCESS;
+}
+
+}  // namespace
+
+int main(int argc, char **argv) {
+    switch (argc) {
+        case 4: return single_pair(argv[1], argv[2], argv[3]);
+        case 3: return batch(argv[1], argv[2]);
+        default: std::cerr << text::usage; return EXIT_FAILURE;
+    }
 }

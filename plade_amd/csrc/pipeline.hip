@@ -254,7 +254,9 @@ bool run_registration(plade_ctx *ctx, RegistrationWork &W, const CloudDev &tgt, 
             catch (const Err &e) { aux_err = e; }
             catch (const std::exception &e) { aux_err = Err{PLADE_EDEVICE, e.what()}; }
         });
-        try { ok_m = prepare_side(ctx, "tgt", tgt, tp, downSampleDistance, pen_grid_cell(lengthThreshold), scale, true, W.tgt_pairs, M); } catch (const Err &e) { main_err = e; }
+        try { ok_m = prepare_side(ctx, "tgt", tgt, tp, downSampleDistance, pen_grid_cell(lengthThreshold), scale, true, W.tgt_pairs, M); }
+        catch (const Err &e) { main_err = e; }
+        catch (const std::exception &e) { main_err = Err{PLADE_EDEVICE, e.what()}; }   // the helper thread is still joinable here
         th.join();
         for (auto &kv : aux->dump) ctx->dump[kv.first] = kv.second;
         ctx->stats.merge(aux->stats);
@@ -487,7 +489,7 @@ extern "C" int plade_registration_planes(plade_ctx *ctx, const float *tgt_pos_nr
         ctx->stats.clear();
         ctx->dump.clear();
         if (!ctx->reg_work) ctx->reg_work = registration_work_create();
-        CloudDev tgt, src;
+        CloudDev &tgt = ctx->up_tgt, &src = ctx->up_src;
         {
             StageTimer t(ctx, "t_upload");
             cloud_upload(ctx, tgt_pos_nrm, n_t, tgt);

@@ -11,6 +11,7 @@
 #ifndef PLADE_H
 #define PLADE_H
 
+#include <iosfwd>
 #include <string>
 #include <vector>
 
@@ -53,5 +54,12 @@ bool load_ply_cloud(const std::string &file_name, pcl::PointCloud<pcl::PointNorm
 
 /** Select the GPU used by the calling thread's registrations (default 0). */
 void plade_select_device(int device);
+
+/** Console of the calling thread's registrations: the messages the reference prints on std::cout / std::cerr go to
+ *  these streams instead (nullptr = std::cout / std::cerr again).  Used by the CLI's batch workers. */
+void plade_set_thread_console(std::ostream *out, std::ostream *err);
+
+/** Destroy the calling thread's GPU context (it is created on first use and otherwise lives as long as the thread). */
+void plade_release_thread_context();
 
 #endif  // PLADE_H

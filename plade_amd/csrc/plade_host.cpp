@@ -7,6 +7,7 @@
 
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <iostream>
 #include <mutex>
 
@@ -15,12 +16,17 @@ namespace {
 thread_local int g_device = 0;
 thread_local plade_ctx *g_ctx = nullptr;
 thread_local int g_ctx_device = -1;
+// console of the calling thread: std::cout / std::cerr unless the caller collects the messages itself (the CLI's batch
+// workers do, so that concurrent registrations do not interleave their lines)
+thread_local std::ostream *g_out = nullptr, *g_err = nullptr;
+std::ostream &con_out() { return g_out ? *g_out : std::cout; }
+std::ostream &con_err() { return g_err ? *g_err : std::cerr; }
 
 plade_ctx *context() {
     if (g_ctx && g_ctx_device == g_device) return g_ctx;
     if (g_ctx) { plade_ctx_destroy(g_ctx); g_ctx = nullptr; }
     if (plade_ctx_create(g_device, &g_ctx) != PLADE_OK) {
-        std::cerr << "PLADE: cannot create a GPU context on device " << g_device
+        con_err() << "PLADE: cannot create a GPU context on device " << g_device
                   << " (libplade_hip.so needs a gfx950 GPU; there is no CPU fallback)" << std::endl;
         return nullptr;
     }
@@ -72,11 +78,17 @@ std::string extension(const std::string &file_name) {  // util.cpp:525-531
 
 void plade_select_device(int device) { g_device = device; }
 
+void plade_set_thread_console(std::ostream *out, std::ostream *err) { g_out = out; g_err = err; }
+
+void plade_release_thread_context() {
+    if (g_ctx) { plade_ctx_destroy(g_ctx); g_ctx = nullptr; g_ctx_device = -1; }
+}
+
 std::vector<PLANE> PlaneExtraction::detect(const pcl::PointCloud<pcl::PointNormal> &cloud, unsigned int min_support,
                                            float dist_thresh, float bitmap_reso, float normal_thresh, float overlook_prob) {
     std::vector<PLANE> out;
     if (cloud.size() < 3) {  // plane_extraction.cpp:181-184
-        std::cerr << "point set has less than 3 points" << std::endl;
+        con_err() << "point set has less than 3 points" << std::endl;
         return out;
     }
     plade_ctx *ctx = context();
@@ -88,7 +100,7 @@ std::vector<PLANE> PlaneExtraction::detect(const pcl::PointCloud<pcl::PointNorma
     uint32_t P = 0;
     int rc = plade_extract_planes(ctx, a.data(), (uint32_t)cloud.size(), min_support, dist_thresh, bitmap_reso, normal_thresh,
                                   overlook_prob, coef.data(), off.data(), idx.data(), max_planes, &P);
-    if (rc != PLADE_OK) { std::cerr << "plane extraction failed: " << plade_last_error(ctx) << std::endl; return out; }
+    if (rc != PLADE_OK) { con_err() << "plane extraction failed: " << plade_last_error(ctx) << std::endl; return out; }
     for (uint32_t i = 0; i < P; ++i) {
         PLANE pl(idx.begin() + off[i], idx.begin() + off[i + 1]);
         pl.normal = Eigen::Vector3f(coef[4 * i], coef[4 * i + 1], coef[4 * i + 2]);
@@ -102,10 +114,10 @@ std::vector<PLANE> PlaneExtraction::detect(const pcl::PointCloud<pcl::PointNorma
 bool registration(Eigen::Matrix<float, 4, 4> &transformation, pcl::PointCloud<pcl::PointNormal>::Ptr target_cloud,
                   pcl::PointCloud<pcl::PointNormal>::Ptr source_cloud, const std::vector<PLANE> &target_planes,
                   const std::vector<PLANE> &source_planes) {
-    std::cout << "#point in target point cloud: " << target_cloud->size() << std::endl;
-    std::cout << "#point in source point cloud: " << source_cloud->size() << std::endl;
-    std::cout << "#planes in target point cloud: " << target_planes.size() << std::endl;
-    std::cout << "#planes in source point cloud: " << source_planes.size() << std::endl;
+    con_out() << "#point in target point cloud: " << target_cloud->size() << std::endl;
+    con_out() << "#point in source point cloud: " << source_cloud->size() << std::endl;
+    con_out() << "#planes in target point cloud: " << target_planes.size() << std::endl;
+    con_out() << "#planes in source point cloud: " << source_planes.size() << std::endl;
     plade_ctx *ctx = context();
     if (!ctx) return false;
     std::vector<float> tg = flatten(*target_cloud), sr = flatten(*source_cloud), tc, sc;
@@ -114,16 +126,16 @@ bool registration(Eigen::Matrix<float, 4, 4> &transformation, pcl::PointCloud<pc
     pack_planes(source_planes, sc, so, si);
     float T16[16];
     Watch w;
-    std::cout << "registration..." << std::endl;
+    con_out() << "registration..." << std::endl;
     int rc = plade_registration_planes(ctx, tg.data(), (uint32_t)target_cloud->size(), sr.data(), (uint32_t)source_cloud->size(),
                                        tc.data(), to.data(), ti.data(), (uint32_t)target_planes.size(), sc.data(), so.data(),
                                        si.data(), (uint32_t)source_planes.size(), T16);
     if (rc != PLADE_OK) {
-        std::cerr << (rc == PLADE_EFAIL ? "registration failed: no matched result found" : plade_last_error(ctx)) << std::endl;
+        con_err() << (rc == PLADE_EFAIL ? "registration failed: no matched result found" : plade_last_error(ctx)) << std::endl;
         return false;
     }
     to_matrix(T16, transformation);
-    std::cout << "done. time: " << w.str() << std::endl;
+    con_out() << "done. time: " << w.str() << std::endl;
     return true;
 }
 
@@ -136,15 +148,15 @@ bool registration(Eigen::Matrix<float, 4, 4> &transformation, pcl::PointCloud<pc
     std::vector<float> tg = flatten(*target_cloud), sr = flatten(*source_cloud);
     float T16[16];
     Watch w;
-    std::cout << "extracting planes and registering...\n";
+    con_out() << "extracting planes and registering...\n";
     int rc = plade_registration_minsupport(ctx, tg.data(), (uint32_t)target_cloud->size(), sr.data(), (uint32_t)source_cloud->size(),
                                            ransac_min_support_target, ransac_min_support_source, T16);
     if (rc != PLADE_OK) {
-        std::cerr << (rc == PLADE_EFAIL ? plade_last_error(ctx) : plade_last_error(ctx)) << std::endl;
+        con_err() << (rc == PLADE_EFAIL ? plade_last_error(ctx) : plade_last_error(ctx)) << std::endl;
         return false;
     }
     to_matrix(T16, transformation);
-    std::cout << "done. time: " << w.str() << std::endl;
+    con_out() << "done. time: " << w.str() << std::endl;
     return true;
 }
 
@@ -154,16 +166,16 @@ namespace {
 bool register_packed(Eigen::Matrix<float, 4, 4> &transformation, const float *tg, size_t n_t, const float *sr, size_t n_s) {
     plade_ctx *ctx = context();
     if (!ctx) return false;
-    std::cout << "extracting planes for both point clouds...\n";
+    con_out() << "extracting planes for both point clouds...\n";
     float T16[16];
     Watch w;
     int rc = plade_registration(ctx, tg, (uint32_t)n_t, sr, (uint32_t)n_s, T16);
     if (rc != PLADE_OK) {
-        std::cerr << plade_last_error(ctx) << std::endl;
+        con_err() << plade_last_error(ctx) << std::endl;
         return false;
     }
     to_matrix(T16, transformation);
-    std::cout << "done. time: " << w.str() << std::endl;
+    con_out() << "done. time: " << w.str() << std::endl;
     return true;
 }
 
@@ -173,10 +185,10 @@ bool load_packed(const std::string &file_name, std::vector<float> &buf) {
     std::string err;
     std::vector<std::string> warnings;
     if (!plade::read_ply_pos_nrm(file_name, buf, err, &warnings)) {
-        if (!err.empty()) std::cerr << err << std::endl;
+        if (!err.empty()) con_err() << err << std::endl;
         return false;
     }
-    for (auto &w : warnings) std::cout << w << std::endl;
+    for (auto &w : warnings) con_out() << w << std::endl;
     return !buf.empty();
 }
 
@@ -192,19 +204,19 @@ bool registration(Eigen::Matrix<float, 4, 4> &transformation, pcl::PointCloud<pc
 // plade.h:44-47 / plade.cpp:665-706
 bool registration(Eigen::Matrix<float, 4, 4> &transformation, const std::string &target_cloud_file,
                   const std::string &source_cloud_file) {
-    std::cout << "target file: " << target_cloud_file << std::endl;
-    std::cout << "source file: " << source_cloud_file << std::endl;
+    con_out() << "target file: " << target_cloud_file << std::endl;
+    con_out() << "source file: " << source_cloud_file << std::endl;
     if (extension(target_cloud_file) != "ply" || extension(source_cloud_file) != "ply") {
-        std::cerr << "only PLY format is accepted" << std::endl;
+        con_err() << "only PLY format is accepted" << std::endl;
         return false;
     }
     thread_local std::vector<float> target_buf, source_buf;   // one pair of staging arrays per worker thread
     if (!load_packed(target_cloud_file, target_buf)) {
-        std::cerr << "loading target point cloud failed" << std::endl;
+        con_err() << "loading target point cloud failed" << std::endl;
         return false;
     }
     if (!load_packed(source_cloud_file, source_buf)) {
-        std::cerr << "loading source point cloud failed" << std::endl;
+        con_err() << "loading source point cloud failed" << std::endl;
         return false;
     }
     const float *tg = target_buf.data(), *sr = source_buf.data();
@@ -214,12 +226,12 @@ bool registration(Eigen::Matrix<float, 4, 4> &transformation, const std::string 
         std::swap(tg, sr);
         std::swap(n_t, n_s);
         switched = true;
-        std::cout << "---->>> ATTENTION: target and source have been switched for efficiency <<<----" << std::endl;
+        con_out() << "---->>> ATTENTION: target and source have been switched for efficiency <<<----" << std::endl;
     }
     transformation.setIdentity();
     bool status = register_packed(transformation, tg, n_t, sr, n_s);
     if (!status) {
-        std::cerr << "registration failed" << std::endl;
+        con_err() << "registration failed" << std::endl;
         return false;
     }
     if (switched) transformation = transformation.inverse();
@@ -231,10 +243,10 @@ bool load_ply_cloud(const std::string &file_name, pcl::PointCloud<pcl::PointNorm
     std::string err;
     std::vector<std::string> warnings;
     if (!plade::read_ply_pos_nrm(file_name, pos_nrm, err, &warnings)) {
-        if (!err.empty()) std::cerr << err << std::endl;
+        if (!err.empty()) con_err() << err << std::endl;
         return false;
     }
-    for (auto &w : warnings) std::cout << w << std::endl;
+    for (auto &w : warnings) con_out() << w << std::endl;
     const size_t n = pos_nrm.size() / 6;
     cloud.resize(n);
     for (size_t i = 0; i < n; ++i) {

@@ -58,24 +58,48 @@ bool host_is_little_endian() {
 
 }  // namespace
 
-bool read_ply_pos_nrm(const std::string &path, std::vector<float> &out, std::string &err, std::vector<std::string> *warnings) {
+namespace {
+
+// owns the FILE and the growing line buffer of getline(): closed / freed on every exit path, exceptions included
+struct Source {
+    FILE *f = nullptr;
+    char *line = nullptr;
+    size_t cap = 0;
+    ~Source() { if (f) fclose(f); free(line); }
+    bool next_line() { return getline(&line, &cap, f) >= 0; }   // lines of any length (POSIX getline)
+};
+
+bool read_body(const std::string &path, std::vector<float> &out, std::string &err, std::vector<std::string> *warnings) {
     // `out` may be a reused staging array: it is only resized when the point count differs (no re-zeroing)
-    FILE *f = fopen(path.c_str(), "rb");
+    Source src;
+    src.f = fopen(path.c_str(), "rb");
+    FILE *f = src.f;
     if (!f) { out.clear(); err = "could not open file: " + path; return false; }
-    auto fail = [&](const std::string &m) { out.clear(); err = m; fclose(f); return false; };
+    auto fail = [&](const std::string &m) { out.clear(); err = m; return false; };
+    long long file_size = -1;
+    if (fseek(f, 0, SEEK_END) == 0) { file_size = ftell(f); }
+    rewind(f);
     std::vector<Elem> elems;
     std::string format;
-    char linebuf[4096];
     bool first = true, ended = false;
-    while (fgets(linebuf, sizeof(linebuf), f)) {
-        std::string line(linebuf);
+    while (src.next_line()) {
+        std::string line(src.line);
         while (!line.empty() && (line.back() == '\n' || line.back() == '\r')) line.pop_back();
         std::istringstream is(line);
         std::string kw;
         is >> kw;
         if (first) { if (kw != "ply") return fail("not a PLY file: " + path); first = false; continue; }
         if (kw == "format") { is >> format; }
-        else if (kw == "element") { Elem e; is >> e.name >> e.count; elems.push_back(e); }
+        else if (kw == "element") {
+            Elem e;
+            long long cnt = -1;
+            is >> e.name >> cnt;
+            // the count is untrusted input: negative / unparsable / beyond the C ABI's 32-bit point count is refused here,
+            // counts the file cannot possibly hold are refused below once the row size is known
+            if (is.fail() || cnt < 0 || cnt > 0xffffffffll) return fail("invalid element count in PLY header: " + path);
+            e.count = (size_t)cnt;
+            elems.push_back(e);
+        }
         else if (kw == "property") {
             if (elems.empty()) return fail("PLY property before any element");
             Prop p;
@@ -102,6 +126,14 @@ bool read_ply_pos_nrm(const std::string &path, std::vector<float> &out, std::str
     bool got_vertex = false;
     for (const Elem &e : elems) {
         const bool is_vertex = e.name == "vertex";
+        if (file_size >= 0) {   // an element cannot hold more rows than the rest of the file has bytes for
+            const long long here = ftell(f);
+            size_t min_row = 0;
+            for (const Prop &p : e.props) min_row += ascii ? 2 : (size_t)kTypeSize[p.is_list ? p.count_type : p.type];
+            if (min_row == 0) min_row = 1;
+            if (here < 0 || (unsigned long long)e.count > (unsigned long long)(file_size - here) / min_row + 1)
+                return fail("PLY element count exceeds the file size: " + path);
+        }
         int col[6] = {-1, -1, -1, -1, -1, -1};
         const char *want[6] = {"x", "y", "z", "nx", "ny", "nz"};
         if (is_vertex) {
@@ -128,13 +160,14 @@ bool read_ply_pos_nrm(const std::string &path, std::vector<float> &out, std::str
         }
         if (ascii) {
             for (size_t i = 0; i < e.count; ++i) {
-                if (!fgets(linebuf, sizeof(linebuf), f)) return fail("unexpected end of PLY data: " + path);
+                if (!src.next_line()) return fail("unexpected end of PLY data: " + path);
                 if (!is_vertex) continue;
-                char *s = linebuf;
+                char *s = src.line;
                 for (size_t k = 0; k < e.props.size(); ++k) {
                     char *endp = nullptr;
                     if (e.props[k].is_list) {
                         long c = strtol(s, &endp, 10);
+                        if (endp == s || c < 0) return fail("malformed PLY list in " + path);
                         s = endp;
                         for (long q = 0; q < c; ++q) { strtod(s, &endp); s = endp; }
                         continue;
@@ -168,8 +201,9 @@ bool read_ply_pos_nrm(const std::string &path, std::vector<float> &out, std::str
                     const Prop &p = e.props[k];
                     if (p.is_list) {
                         if (fread(b, kTypeSize[p.count_type], 1, f) != 1) return fail("unexpected end of PLY data: " + path);
-                        const long c = (long)decode(b, p.count_type, swap);
-                        if (fseek(f, c * kTypeSize[p.item_type], SEEK_CUR) != 0) return fail("unexpected end of PLY data: " + path);
+                        const double cd = decode(b, p.count_type, swap);
+                        if (!(cd >= 0) || cd > 1e9) return fail("malformed PLY list in " + path);
+                        if (fseek(f, (long)cd * kTypeSize[p.item_type], SEEK_CUR) != 0) return fail("unexpected end of PLY data: " + path);
                     } else {
                         if (fread(b, kTypeSize[p.type], 1, f) != 1) return fail("unexpected end of PLY data: " + path);
                         if (is_vertex) for (int w = 0; w < 6; ++w) if (col[w] == (int)k) out[6 * i + w] = (float)decode(b, p.type, swap);
@@ -177,9 +211,21 @@ bool read_ply_pos_nrm(const std::string &path, std::vector<float> &out, std::str
                 }
         }
     }
-    fclose(f);
     if (!got_vertex) { out.clear(); err = "no vertex element in " + path; return false; }
     return true;
+}
+
+}  // namespace
+
+bool read_ply_pos_nrm(const std::string &path, std::vector<float> &out, std::string &err, std::vector<std::string> *warnings) {
+    // never throws: a header that asks for more memory than there is ends in `false` like any other malformed file
+    try {
+        return read_body(path, out, err, warnings);
+    } catch (const std::exception &e) {
+        out.clear();
+        err = std::string("cannot read PLY file ") + path + ": " + e.what();
+        return false;
+    }
 }
 
 bool write_ply_pos_nrm(const std::string &path, const float *pos_nrm, size_t n) {

@@ -10,12 +10,17 @@
 //                   stores, so nothing has to be zeroed beforehand) and clear the look-back states and tile
 //                   counters of every pass;
 //   k_rs_pass       "onesweep": a workgroup takes the next tile (atomic ticket, so every predecessor is already
-//                   running), ranks its 4096 keys by digit (wave-level match via 8 ballots per key: stable),
+//                   running), ranks its 8192 keys (512 lanes x 16) by digit (wave-level match via 8 ballots per key: stable),
 //                   publishes its digit counts, resolves its exclusive prefix by decoupled look-back over the
 //                   predecessors' states, stages the tile in LDS in digit order and writes runs of equal digits to
 //                   their final place.
 // Algorithmic traffic per pass: read n x (sizeof(K) + 4) B, write the same.
 #include "prims.h"
+
+// gfx950 only: k_rs_pass keeps a whole 8192-pair tile in LDS (up to ~116 KB of the CU's 160 KB for 64-bit keys).
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "radix_sort.hip is written for gfx950 (160 KB LDS per workgroup); build with --offload-arch=gfx950"
+#endif
 
 namespace plade {
 
@@ -73,6 +78,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_pass(const K *__restrict__ ki
                                                         uint32_t *__restrict__ tile_ctr, uint32_t *__restrict__ look) {
     constexpr int NB = 1 << DB;
     static_assert(NB <= RS_THREADS, "one lane per digit");
+    static_assert(RS_TILE * (sizeof(K) + 4) + (RS_WAVES + 2) * NB * 4 + 64 <= 160 * 1024, "tile does not fit gfx950's 160 KB LDS");
     __shared__ K s_keys[RS_TILE];
     __shared__ uint32_t s_vals[RS_TILE];
     __shared__ uint32_t s_cnt[RS_WAVES][NB];    // per wave: digit counters, then exclusive offsets inside the digit
@@ -195,6 +201,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_pass(const K *__restrict__ ki
 template <class K, int DB>
 void radix_sort_run(plade_ctx *ctx, const K *ki, K *ko, const uint32_t *vi, uint32_t *vo, size_t n, int passes) {
     constexpr int NB = 1 << DB;
+    if (n == 0) return;   // no tiles: nothing to launch
     const uint32_t tiles = cdiv(n, RS_TILE);
     const size_t part_words = (size_t)RS_HBLOCKS * RS_MAXP * NB, look_words = (size_t)passes * tiles * NB;
     // scratch: partial histograms | tile counters | look-back states | key ping buffer | value ping buffer

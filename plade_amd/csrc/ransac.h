@@ -7,7 +7,7 @@ namespace plade {
 struct RansacParams {
     uint32_t min_support = 10000;
     float dist_rel = 0.005f, bitmap_rel = 0.02f, cos_thresh = 0.8f, overlook_p = 0.001f;  // plade.cpp:607
-    int orient_normals = 1;
+    int orient_normals = 0;
     uint64_t seed = 0;
     bool host_indices = true;   // also copy the inlier index lists to the host (PlaneSetOut::idx)
 };

@@ -21,16 +21,24 @@ RansacParams ransac_params(plade_ctx *ctx, uint32_t min_support, bool host_indic
     return rp;  // 0.005f, 0.02f, 0.8f, 0.001f: plade.cpp:607,627
 }
 
-// extract() (code/PLADE/plade.cpp:602-635)
+// extract() (code/PLADE/plade.cpp:602-635).  The trace of the auto-tuning loop (plane count of every detect call, the
+// min_support it ends at) is left in the stats: tests compare it with the reference loop over libransac (g2_extract.npz).
 void extract(plade_ctx *ctx, const CloudDev &cloud, int init_min_support, PlaneSetOut &planes, bool host_indices,
              PairAccept *pair = nullptr, int who = 0) {
     const uint32_t min_num = (uint32_t)ctx->params.min_planes, max_num = (uint32_t)ctx->params.max_planes;
     const int min_allowed_support = 200;
-    if (!ctx->ransac_work) ctx->ransac_work = ransac_work_create();
-    ransac_detect(ctx, *ctx->ransac_work, cloud, ransac_params(ctx, (uint32_t)init_min_support, host_indices), planes, pair, who);
-    ctx->stats.add("n_detect_calls", 1);
-    ctx->stats.add("n_score_passes", planes.n_score_passes);
-    if (planes.P() >= min_num && planes.P() <= max_num) return;
+    const std::string tag = who == 0 ? "_tgt" : "_src";
+    int trials = 0;
+    auto detect = [&](int min_support) {
+        if (!ctx->ransac_work) ctx->ransac_work = ransac_work_create();
+        ransac_detect(ctx, *ctx->ransac_work, cloud, ransac_params(ctx, (uint32_t)min_support, host_indices), planes, pair, who);
+        ++trials;
+        ctx->stats.add("n_detect_calls", 1);
+        ctx->stats.add("n_score_passes", planes.n_score_passes);
+        ctx->stats.add("extract_planes_trial" + std::to_string(trials) + tag, planes.P());
+        ctx->stats.add("extract_final_min_support" + tag, min_support - ctx_stat(ctx, ("extract_final_min_support" + tag).c_str()));
+    };
+    detect(init_min_support);
     if (planes.P() > max_num) {
         // top max_num by support.  The reference sorts with a `>=` comparator (plade.cpp:612-615,
         // undefined behaviour on ties); a stable descending sort is used here.
@@ -53,16 +61,11 @@ void extract(plade_ctx *ctx, const CloudDev &cloud, int init_min_support, PlaneS
         planes = std::move(r);
         return;
     }
+    // plade.cpp:620-633: fewer than min_num planes -> halve min_support, at most 10 detect calls, never below 200
     const int max_trials = 10;
-    int min_support = init_min_support / 2;
-    int trials = 1;
-    while (planes.P() < min_num && trials < max_trials && min_support >= min_allowed_support) {
-        ransac_detect(ctx, *ctx->ransac_work, cloud, ransac_params(ctx, (uint32_t)min_support, host_indices), planes, pair, who);
-        ctx->stats.add("n_detect_calls", 1);
-        ctx->stats.add("n_score_passes", planes.n_score_passes);
-        min_support /= 2;
-        ++trials;
-    }
+    for (int min_support = init_min_support / 2; planes.P() < min_num && trials < max_trials && min_support >= min_allowed_support;
+         min_support /= 2)
+        detect(min_support);
 }
 
 int register_clouds(plade_ctx *ctx, const CloudDev &tgt, const CloudDev &src, int ms_t, int ms_s, bool auto_tune,
@@ -112,7 +115,10 @@ int register_clouds(plade_ctx *ctx, const CloudDev &tgt, const CloudDev &src, in
             catch (const std::exception &e) { aux_err = Err{PLADE_EDEVICE, e.what()}; }
         });
         Err main_err{0, ""};
-        try { one(ctx, tgt, ms_t, tp); } catch (const Err &e) { main_err = e; }
+        // every exception is caught while the helper thread is joinable (unwinding past it would terminate the process)
+        try { one(ctx, tgt, ms_t, tp); }
+        catch (const Err &e) { main_err = e; }
+        catch (const std::exception &e) { main_err = Err{PLADE_EDEVICE, e.what()}; }
         th.join();
         aux->ev_collect();
         ctx->stats.merge(aux->stats);
@@ -202,6 +208,25 @@ extern "C" int plade_cloud_upload(plade_ctx *ctx, const float *pos_nrm, uint32_t
     });
 }
 
+// Page-locking of caller-owned host buffers: with it the 24 B/point upload of plade_registration* is an asynchronous DMA
+// transfer (the calling thread goes on queueing work, uploads of one context overlap the kernels of the others);
+// from pageable memory the HIP runtime stages the data through its own pinned buffer and the call blocks meanwhile.
+extern "C" int plade_host_pin(plade_ctx *ctx, const void *ptr, size_t bytes) {
+    return guarded(ctx, [&]() -> int {
+        PLADE_REQUIRE(ptr && bytes, PLADE_EINVAL, "plade_host_pin: bad argument");
+        HIP_TRY(hipHostRegister(const_cast<void *>(ptr), bytes, hipHostRegisterDefault));
+        return PLADE_OK;
+    });
+}
+extern "C" int plade_host_unpin(plade_ctx *ctx, const void *ptr) {
+    return guarded(ctx, [&]() -> int {
+        PLADE_REQUIRE(ptr, PLADE_EINVAL, "plade_host_unpin: bad argument");
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        HIP_TRY(hipHostUnregister(const_cast<void *>(ptr)));
+        return PLADE_OK;
+    });
+}
+
 extern "C" void plade_cloud_free(plade_ctx *ctx, plade_cloud *c) {
     if (ctx) { (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->stream); }
     delete c;
@@ -224,7 +249,7 @@ extern "C" int plade_registration(plade_ctx *ctx, const float *tgt_pos_nrm, uint
         ctx->stats.clear();
         ctx->dump.clear();
         ctx->last_error.clear();
-        CloudDev tgt, src;
+        CloudDev &tgt = ctx->up_tgt, &src = ctx->up_src;
         {
             StageTimer t(ctx, "t_upload");
             cloud_upload(ctx, tgt_pos_nrm, n_t, tgt);
@@ -243,7 +268,7 @@ extern "C" int plade_registration_minsupport(plade_ctx *ctx, const float *tgt_po
         ctx->stats.clear();
         ctx->dump.clear();
         ctx->last_error.clear();
-        CloudDev tgt, src;
+        CloudDev &tgt = ctx->up_tgt, &src = ctx->up_src;
         cloud_upload(ctx, tgt_pos_nrm, n_t, tgt);
         cloud_upload(ctx, src_pos_nrm, n_s, src);
         return register_clouds(ctx, tgt, src, min_support_t, min_support_s, false, T16);

@@ -1,0 +1,193 @@
+"""BASELINE.json configs[3] and configs[4] at full size on one MI355X.
+
+configs[3]  "Batch of 64 synthetic 1M-pt pairs (file_pairs.txt mode)": the 64-pair list goes through the PLADE command
+            line (code/PLADE/main.cpp batch mode) with PLADE_GPUS=1; every block of the result file must equal the
+            library's result for that pair, in input order; a batch that is killed half way leaves a valid prefix.
+configs[4]  "10M-pt dense scan pair, ~100 planes, ~10k candidate transforms": registration_dev with max_planes = 100,
+            max_candidates = 10000; integer outputs of a fixed candidate subset against the oracle's seam functions at the
+            planes-given boundary, plus the size-independent properties.
+"""
+import os
+import signal
+import subprocess
+import time
+from concurrent.futures import ProcessPoolExecutor
+
+import numpy as np
+import pytest
+
+import plade_amd
+from plade_amd.plyio import write_ply
+from plade_amd.synth import make_pair
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "plade_amd", "PLADE")
+N_PAIRS = 64
+N = 1000000
+
+
+def _gen(args):
+    seed, d = args
+    tg, sr, Tgt = make_pair(N, seed=seed)
+    pt, ps = os.path.join(d, f"target_{seed:02d}.ply"), os.path.join(d, f"source_{seed:02d}.ply")
+    write_ply(pt, tg)
+    write_ply(ps, sr)
+    return pt, ps, Tgt
+
+
+@pytest.fixture(scope="module")
+def batch64(tmp_path_factory):
+    d = str(tmp_path_factory.mktemp("batch64"))
+    with ProcessPoolExecutor(max_workers=max(1, min(16, len(os.sched_getaffinity(0))))) as ex:
+        pairs = list(ex.map(_gen, [(s, d) for s in range(N_PAIRS)]))
+    lst = os.path.join(d, "file_pairs.txt")
+    with open(lst, "w") as f:
+        for pt, ps, _ in pairs:
+            f.write(pt + "\n" + ps + "\n")
+    return d, lst, pairs
+
+
+def _parse(path, allow_truncated_tail=False):
+    """result-file grammar of main.cpp:134-143; returns the complete blocks"""
+    blocks, cur = [], None
+    lines = open(path).read().split("\n")
+    for line in lines:
+        if line.startswith("target: "):
+            cur = {"target": line[8:], "source": None, "rows": [], "failed": False}
+            blocks.append(cur)
+        elif line.startswith("source: "):
+            cur["source"] = line[8:]
+        elif line.startswith("registration failed"):
+            cur["failed"] = True
+        elif line.startswith("transformation:") or not line.strip():
+            continue
+        else:
+            cur["rows"].append([float(x) for x in line.split()])
+    if allow_truncated_tail and blocks and (blocks[-1]["source"] is None or len(blocks[-1]["rows"]) != 4
+                                            or any(len(r) != 4 for r in blocks[-1]["rows"])):
+        blocks.pop()
+    for b in blocks:
+        b["T"] = np.array(b["rows"], np.float64)
+        assert b["T"].shape == (4, 4), b
+    return blocks
+
+
+@pytest.mark.timeout(1800)
+def test_config3_batch_of_64_pairs_through_the_cli(batch64, ctx):
+    d, lst, pairs = batch64
+    res = os.path.join(d, "results.txt")
+    env = dict(os.environ, PLADE_GPUS="1", PLADE_INFLIGHT="4")
+    t0 = time.perf_counter()
+    r = subprocess.run([CLI, lst, res], capture_output=True, text=True, timeout=1200, env=env)
+    dt = time.perf_counter() - t0
+    assert r.returncode == 0, r.stderr[-2000:]
+    blocks = _parse(res)
+    assert len(blocks) == N_PAIRS
+    assert [b["target"] for b in blocks] == [p[0] for p in pairs]      # input order kept
+    assert [b["source"] for b in blocks] == [p[1] for p in pairs]
+    # console: one "target file:" line per pair, in input order (each worker's output is printed with its block)
+    tf = [l[len("target file: "):] for l in r.stdout.split("\n") if l.startswith("target file: ")]
+    assert tf == [p[0] for p in pairs]
+    from plade_amd.plyio import read_ply
+    n_ok = 0
+    for b, (pt, ps, Tgt) in zip(blocks, pairs):
+        ok, T = ctx.registration(read_ply(pt), read_ply(ps))
+        assert ok == (not b["failed"])
+        if ok:
+            # Eigen's default stream format prints 6 significant digits
+            assert np.allclose(b["T"], T, rtol=2e-5, atol=2e-6), b["target"]
+            assert np.linalg.norm(b["T"] - Tgt) < 1e-2
+            n_ok += 1
+    assert n_ok >= N_PAIRS - 1
+    print(f"configs[3]: 64 x 1M-point pairs through the CLI in {dt:.2f} s ({N_PAIRS / dt:.1f} pairs/s end to end, PLY parse included)")
+
+
+@pytest.mark.timeout(900)
+def test_config3_interrupted_batch_leaves_a_valid_prefix(batch64):
+    """The reference writes every pair's block when its registration returns (main.cpp:134-146), so a batch that dies
+    keeps what it had done.  Same here: kill the CLI once a few blocks are on disk, the file must hold complete
+    blocks for a prefix of the input list and nothing else."""
+    d, lst, pairs = batch64
+    res = os.path.join(d, "interrupted.txt")
+    env = dict(os.environ, PLADE_GPUS="1", PLADE_INFLIGHT="2")
+    p = subprocess.Popen([CLI, lst, res], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, env=env)
+    killed = False
+    t0 = time.time()
+    while p.poll() is None and time.time() - t0 < 600:
+        try:
+            if open(res).read().count("target: ") >= 4:
+                p.send_signal(signal.SIGKILL)
+                killed = True
+                break
+        except FileNotFoundError:
+            pass
+        time.sleep(0.002)
+    p.wait(timeout=60)
+    assert killed, "the batch finished before it could be interrupted"
+    blocks = _parse(res, allow_truncated_tail=True)
+    assert 3 <= len(blocks) < N_PAIRS
+    assert [b["target"] for b in blocks] == [q[0] for q in pairs[:len(blocks)]]
+    for b, (pt, ps, Tgt) in zip(blocks, pairs):
+        assert b["failed"] or np.linalg.norm(b["T"] - Tgt) < 1e-2
+
+
+# ---- configs[4] -----------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def big_scene():
+    return make_pair(10000000, seed=0, n_boxes=60, room=(30.0, 24.0, 6.0))
+
+
+@pytest.mark.timeout(3000)
+def test_config4_10m_points_100_planes_10k_candidates(big_scene, oracle):
+    tg, sr, Tgt = big_scene
+    assert len(tg) == 10000000
+    ctx = plade_amd.Context(0, max_planes=100, max_candidates=10000, dump=1, orient_normals=1)
+    ct, cs = ctx.upload(tg), ctx.upload(sr)
+    ok, T = ctx.registration_dev(ct, cs)
+    d, st = ctx.dump(), ctx.stats()
+    assert ok
+    assert np.linalg.norm(T.astype(np.float64) - Tgt) < 1e-2
+    P_t, P_s = len(d["tgt_planes"]) // 4, len(d["src_planes"]) // 4
+    K, Kv = len(d["pen_tested"]), len(d["overlap_counts"])
+    print(f"configs[4]: {P_t} + {P_s} planes, {int(st['n_descriptors_tgt'])} x {int(st['n_descriptors_src'])} descriptors, "
+          f"{int(st['n_matches'])} matches, {int(st['n_clusters'])} clusters, {K} candidates through the penetration filter, "
+          f"{Kv} verified, t_registration {st['t_registration'] * 1e3:.1f} ms")
+    assert 30 <= P_t <= 100 and 20 <= P_s <= 100
+    assert K >= 5000, "the stress configuration must push thousands of candidates through the filter"
+    assert 1 <= Kv <= K
+    # determinism at this size
+    ok2, T2 = ctx.registration_dev(ct, cs)
+    assert ok2 and np.array_equal(T, T2)
+    d2 = ctx.dump()
+    for k in ("overlap_counts", "pen_flags", "plane_match_counts", "pen_tested"):
+        assert np.array_equal(d[k], d2[k]), k
+    ct.free(); cs.free()
+    # ---- the oracle at the planes-given boundary (planes = the ones the GPU extracted).  Everything up to the list of
+    #      candidates that enters the penetration filter is compared in full; of the ~10^4 penetration tests the oracle
+    #      evaluates every 64th (each one transforms every source plane cloud: hours for all of them on one core), and
+    #      the verification counts of a dozen verified candidates come from the oracle's ComputeOverlap seam.
+    tp = (d["tgt_planes"].reshape(-1, 4), d["tgt_plane_offsets"], d["tgt_plane_idx"])
+    sp = (d["src_planes"].reshape(-1, 4), d["src_plane_offsets"], d["src_plane_idx"])
+    t0 = time.perf_counter()
+    _, _, do = oracle.registration(tg, sr, tp, sp, voxel_sort_mode=1, max_candidates=10000, pen_stride=64)
+    print(f"configs[4]: sampled oracle run {time.perf_counter() - t0:.0f} s", dict(zip(do["timing_names"], np.round(do["timing"], 1))))
+    common = [k for k in do if k in d and not k.startswith("timing") and k != "pen_flags"]
+    assert len(common) >= 25 and "pen_tested" in common and "plane_match_counts" in common and "initial_RT" in common
+    for k in common:
+        assert np.asarray(d[k]).shape == np.asarray(do[k]).shape and np.array_equal(d[k], do[k]), k
+    sampled = do["pen_flags"] >= 0
+    assert sampled.sum() >= K // 64 and np.array_equal(d["pen_flags"][sampled], do["pen_flags"][sampled])
+    tgt_ds, src_ds = d["tgt_ds"].reshape(-1, 3), d["src_ds"].reshape(-1, 3)
+    cand, centers = d["candidates"].reshape(-1, 4, 4), d["candidate_centers"].reshape(-1, 3)
+    leaf = np.float32(4) * d["average_spacing"][0]
+    for i in np.unique(np.linspace(0, Kv - 1, 12).astype(int)):
+        want = oracle.overlap_count(src_ds, tgt_ds, cand[i], centers[i], np.float32(d["src_radius"][0]), leaf)
+        assert want == d["overlap_counts"][i], (i, want, d["overlap_counts"][i])
+    # size-independent properties: flags are 0/1, survivors = unflagged, counts bounded by the downsampled source
+    assert set(np.unique(d["pen_flags"]).tolist()) <= {0, 1}
+    assert Kv == int((d["pen_flags"] == 0).sum())
+    assert d["overlap_counts"].max() <= len(src_ds)
+    assert d["best_index"][0] == int(np.argmax(d["scores"]))   # std::sort descending, first on ties
+    ctx.close()

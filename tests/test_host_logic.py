@@ -80,3 +80,70 @@ def test_oracle_registration_small_pair_recovers_ground_truth(oracle):
     ok, T, d = oracle.registration(tg, sr, planes_from_labels(tg, tl), planes_from_labels(sr, sl))
     assert ok and np.linalg.norm(T - Tgt) < 0.01
     assert d["overlap_counts"].max() > 0.5 * len(d["src_ds"]) / 3
+
+
+def _no_gpu():
+    import torch
+    return not torch.cuda.is_available()
+
+
+@pytest.mark.skipif(not os.path.exists(CLI), reason="CLI not built")
+def test_cli_malformed_ply_files_fail_cleanly(tmp_path):
+    """Untrusted headers: negative / huge vertex counts, truncated data, negative list counts and very long
+    ascii lines end in the reference's "loading ... failed" path (exit code 1), never in a crash or an allocation of
+    the size the header claims.  None of these reaches the GPU."""
+    good = tmp_path / "good.ply"
+    write_ply(str(good), sample_scene(500, scene_seed=1, sample_seed=2))
+    props = "".join(f"property float {p}\n" for p in ("x", "y", "z", "nx", "ny", "nz"))
+    cases = {
+        "negative.ply": b"ply\nformat binary_little_endian 1.0\nelement vertex -1\n" + props.encode() + b"end_header\n",
+        "huge.ply": b"ply\nformat binary_little_endian 1.0\nelement vertex 4000000000\n" + props.encode() + b"end_header\n" + b"\0" * 240,
+        "beyond32.ply": b"ply\nformat binary_little_endian 1.0\nelement vertex 99999999999999\n" + props.encode() + b"end_header\n",
+        "truncated.ply": b"ply\nformat binary_little_endian 1.0\nelement vertex 100\n" + props.encode() + b"end_header\n" + b"\0" * 100,
+        "neglist.ply": b"ply\nformat binary_little_endian 1.0\nelement face 1\nproperty list int int vertex_indices\n"
+                       b"element vertex 1\n" + props.encode() + b"end_header\n" + (-5).to_bytes(4, "little", signed=True) + b"\0" * 24,
+        "nonsense.ply": b"ply\nformat ascii 1.0\nelement vertex 2\n" + props.encode() + b"end_header\n1 2 3 0 0 1\nfoo bar\n",
+    }
+    for name, blob in cases.items():
+        p = tmp_path / name
+        p.write_bytes(blob)
+        out = tmp_path / "res.txt"
+        r = subprocess.run([CLI, str(p), str(good), str(out)], capture_output=True, text=True, timeout=60)
+        assert r.returncode == 1, (name, r.returncode, r.stderr)
+        assert "loading target point cloud failed" in r.stderr, (name, r.stderr)
+        assert out.read_text().startswith("registration failed, an identity matrix is recorded:")
+    # an ascii vertex line far longer than any fixed buffer parses (trailing blanks), and extra properties are ignored
+    long_ascii = tmp_path / "long.ply"
+    with open(long_ascii, "w") as f:
+        f.write("ply\nformat ascii 1.0\nelement vertex 2\n" + props + "end_header\n")
+        f.write("1 2 3 0 0 1" + " " * 10000 + "\n4 5 6 0 1 0\n")
+    from plade_amd.plyio import read_ply as rp
+    assert rp(str(long_ascii)).shape == (2, 6)
+
+
+@pytest.mark.skipif(not os.path.exists(CLI), reason="CLI not built")
+def test_cli_batch_blocks_are_streamed_in_input_order_without_a_gpu(tmp_path):
+    """Batch mode on a box without a GPU: every registration fails (no CPU fallback), and the result file still holds
+    one block per pair, in input order, with the reference's grammar (main.cpp:134-143) -- written by the ordered
+    writer while four workers run.  Names that cannot be opened are reported and skipped (main.cpp:127)."""
+    if not _no_gpu():
+        pytest.skip("this variant is for boxes without a GPU; tests/test_gpu_configs.py covers the GPU box")
+    names = []
+    for k in range(6):
+        p = tmp_path / f"c{k}.ply"
+        write_ply(str(p), sample_scene(300, scene_seed=k, sample_seed=k + 1))
+        names.append(str(p))
+    lst = tmp_path / "pairs.txt"
+    lst.write_text(f"{names[0]}\n{names[1]}\n\n/no/such/file.ply\n{names[2]}\n{names[3]}\n{names[4]}\n{names[5]}\n{names[0]}\n")
+    out = tmp_path / "res.txt"
+    r = subprocess.run([CLI, str(lst), str(out)], capture_output=True, text=True, timeout=120,
+                       env=dict(os.environ, PLADE_INFLIGHT="4"))
+    assert r.returncode == 1 and "registration all failed (3 pairs)" in r.stderr
+    assert "file doesn't exist: /no/such/file.ply" in r.stderr
+    ident = "1 0 0 0\n0 1 0 0\n0 0 1 0\n0 0 0 1\n"
+    want = "".join(f"target: {names[2 * k]}\nsource: {names[2 * k + 1]}\nregistration failed, an identity matrix is recorded:\n{ident}\n"
+                   for k in range(3))
+    assert out.read_text() == want
+    # the per-pair console output comes out in input order too
+    tf = [l for l in r.stdout.split("\n") if l.startswith("target file: ")]
+    assert tf == [f"target file: {names[2 * k]}" for k in range(3)]
