@@ -45,7 +45,6 @@ extern "C" void plade_ctx_destroy(plade_ctx *ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->reg_work) plade::registration_work_destroy(ctx->reg_work);
     if (ctx->ransac_work) plade::ransac_work_destroy(ctx->ransac_work);
-    if (ctx->pair_accept) plade::pair_accept_destroy(ctx->pair_accept);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     if (getenv("PLADE_DEBUG_ALLOC")) {

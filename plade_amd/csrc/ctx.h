@@ -51,15 +51,14 @@ struct plade_cloud {
     std::vector<float> host_copy;  // pos_nrm kept for the small host-side gathers
 };
 
-namespace plade { struct RegistrationWork; struct RansacWork; struct PairAccept; }
+namespace plade { struct RegistrationWork; struct RansacWork; }
 
 struct plade_ctx {
     int device = 0;
     plade::RegistrationWork *reg_work = nullptr;
     plade::RansacWork *ransac_work = nullptr;
-    plade::PairAccept *pair_accept = nullptr;   // lock-step acceptance batches of the two clouds of a registration
-    plade_ctx *aux = nullptr;   // second stream + work areas: the source cloud's plane extraction runs
-                                // concurrently with the target's (independent until the line stage)
+    plade_ctx *aux = nullptr;   // second stream + work areas: stages of the source cloud that are independent of the
+                                // target's run concurrently with them
     hipStream_t stream = nullptr;
     // device copies of the clouds the host-pointer entry points register (grow-only, reused from call to call: a
     // hipMalloc / hipFree pair per call costs more than the upload itself, and hipFree synchronises the device)
@@ -90,9 +89,11 @@ struct plade_ctx {
         for (auto &r : evs) {
             float ms = 0.f;
             (void)hipEventElapsedTime(&ms, r.a, r.b);
-            stats.add("k_" + r.tag + "_seconds", ms * 1e-3);
-            stats.add("k_" + r.tag + "_launches", 1.0);
-            stats.add("k_" + r.tag + "_bytes", r.bytes);
+            if (r.bytes >= 0) {   // a negative byte count marks a launch that had nothing to do (device-side early exit)
+                stats.add("k_" + r.tag + "_seconds", ms * 1e-3);
+                stats.add("k_" + r.tag + "_launches", 1.0);
+                stats.add("k_" + r.tag + "_bytes", r.bytes);
+            }
             (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
         }
         evs.clear();

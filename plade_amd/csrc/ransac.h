@@ -1,4 +1,5 @@
-// plade_amd/csrc/ransac.h -- GPU plane extraction (seam S1b).
+// plade_amd/csrc/ransac.h -- GPU plane extraction (seam S1b): a device-driven Efficient-RANSAC that extracts the
+// planes of up to two clouds (the two scans of a pair) in the same launch sequence, see ransac.hip.
 #pragma once
 #include "ctx.h"
 
@@ -7,7 +8,7 @@ namespace plade {
 struct RansacParams {
     uint32_t min_support = 10000;
     float dist_rel = 0.005f, bitmap_rel = 0.02f, cos_thresh = 0.8f, overlook_p = 0.001f;  // plade.cpp:607
-    int orient_normals = 0;
+    int orient_normals = 0;     // 0 = reference behaviour (plane_extraction.cpp:43-58 never flips), see plade_hip.h
     uint64_t seed = 0;
     bool host_indices = true;   // also copy the inlier index lists to the host (PlaneSetOut::idx)
 };
@@ -16,8 +17,9 @@ struct PlaneSetOut {
     std::vector<float> coef;       // P x 4 (unit n, d = -n.p)
     std::vector<int32_t> offsets;  // P + 1
     std::vector<int32_t> idx;      // original point indices
-    const uint32_t *d_idx = nullptr;  // the same list on the device (valid until the next detect on this work area)
-    uint32_t n_score_passes = 0;   // full-array K1 passes issued (roofline bookkeeping)
+    const uint32_t *d_idx = nullptr;  // the same list on the device (valid until the next detect of this cloud slot)
+    uint32_t n_score_passes = 0;   // full-array K1 launches that scanned this cloud (roofline bookkeeping)
+    double score_bytes = 0;        // their algorithmic bytes: 28 B/point per launch + 1 mask byte per 4 points per chain
     uint32_t remaining = 0;
     uint32_t P() const { return (uint32_t)(coef.size() / 4); }
     // make `idx` valid when the detect call skipped the host copy
@@ -47,14 +49,22 @@ struct ComponentOut {
 void plane_component(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const float normal[3], const float point[3],
                      const int32_t *idx, uint32_t m, float bitmap_eps, bool closing_filter, float w_eps, ComponentOut &out);
 
-// Coordinator of the acceptance batches of two concurrent detect calls (the two scans of a pair): their batches are
-// launched together, see ransac.hip.  `who` = 0 (target) / 1 (source).
-struct PairAccept;
-PairAccept *pair_accept_create();
-void pair_accept_destroy(PairAccept *p);
+// Up to two clouds are extracted together ("slots" 0 and 1 of the work area).
+constexpr int RANSAC_SLOTS = 2;
 
-// PlaneExtraction::detect (code/PLADE/plane_extraction.cpp:173-200)
-void ransac_detect(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const RansacParams &rp, PlaneSetOut &out,
-                   PairAccept *pair = nullptr, int who = 0);
+// Morton order + stratified subset of the clouds (once per set of clouds; every detect call on them reuses it).
+void ransac_prepare(plade_ctx *ctx, RansacWork &W, const CloudDev *const clouds[RANSAC_SLOTS], int n_clouds);
+
+// One PlaneExtraction::detect (code/PLADE/plane_extraction.cpp:173-200) per ACTIVE slot, all in one launch sequence:
+// slots with active[s] == false keep the results of their previous detect call untouched.
+struct RansacJob {
+    bool active = false;
+    RansacParams rp;
+    PlaneSetOut *out = nullptr;
+};
+void ransac_detect_prepared(plade_ctx *ctx, RansacWork &W, RansacJob jobs[RANSAC_SLOTS]);
+
+// prepare + detect of a single cloud
+void ransac_detect(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const RansacParams &rp, PlaneSetOut &out);
 
 }  // namespace plade

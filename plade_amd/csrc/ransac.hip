@@ -12,19 +12,27 @@
 //                Morton-sorted once and "the cell at level l" is a contiguous key range.
 //   hypothesis : Plane::Init(p1,p2,p3) (ransac/Plane.cpp:29-38) + the 3-sample verification
 //                (RansacShapeDetector.cpp:143-153).
-//   scoring    : K1 (k_score.hip).  Schnabel scores lazily on nested random subsets to save CPU
-//                time; on the GPU a batch of H hypotheses is scored on a stratified subset in one
-//                launch and the leaders are re-scored on ALL unassigned points in one HBM pass.
+//   scoring    : K1.  Schnabel scores lazily on nested random subsets to save CPU time; on the GPU a
+//                round of 4096 hypotheses is scored on a stratified subset in one launch and the
+//                leaders are re-scored on ALL unassigned points in one HBM pass.
 //   acceptance : exactly the reference's sequence (RansacShapeDetector.cpp:618-675):
 //                GlobalScore(3 eps) -> ConnectedComponent(bitmap eps) -> up to 3 x
 //                { LSFit -> GlobalWeightedScore(3 eps) } keeping a refit only if its weighted score
 //                and size improve -> points marked assigned, drawnCandidates scaled by (1-|S|/n)^3.
 //   stopping   : CandidateFailureProbability(minSupport, n_remaining, drawn, levels) <= p
 //                (RansacShapeDetector.h:61-67, .cpp:856-858).
+//
+// Control is on the DEVICE.  The whole loop state of a cloud (remaining points, drawn candidates, candidate pool,
+// accepted planes) lives in HBM (RState); one iteration is a fixed sequence of 27 launches
+//     sample -> score on the subset -> leaders -> re-score the pool -> select a conflict-free batch ->
+//     4 x { mark, compact + rasterise, label, select + moments, fit } -> decide -> remove points
+// whose kernels read what to do from that state (a cloud that is not sampling, has an empty batch or has finished
+// makes its workgroups return at once).  The sequence is captured once as a hipGraph and replayed; the host never
+// reads anything back in between -- the `decide` kernel reports the iteration count and the final results through a
+// block of host-mapped memory that the host polls while the next (speculative) iteration is already queued.
+// Every kernel serves the clouds of up to two "slots": the two scans of a registration are extracted in lock step by
+// one launch sequence (blockIdx selects the cloud), which halves the number of commands per registration.
 #include "ransac.h"
-#include <condition_variable>
-#include <mutex>
-#include "score.h"
 #include "prims.h"
 #include "voxel.h"
 #include <algorithm>
@@ -33,9 +41,169 @@
 
 namespace plade {
 
+namespace {
+
+constexpr uint32_t R_H = 4096;          // hypotheses per sampling round
+constexpr uint32_t R_TOP = 48;          // candidate pool
+constexpr int R_B = 8;                  // acceptance chains per cloud and iteration
+constexpr int R_G = RANSAC_SLOTS;
+constexpr uint32_t R_MAXP = 4096;       // accepted shapes per detect call
+constexpr uint32_t R_MAX_ROUNDS = 4000;
+constexpr int R_MIN_LEVEL = 1, R_MAX_LEVEL = 8;
+constexpr int TPB = 256, PPT = 4, TILE = TPB * PPT;   // scan kernels: 1024 points per workgroup, 16 B per lane and array
+constexpr int HCHUNK = 64;              // hypotheses per workgroup of the counting kernels (>= R_TOP)
+constexpr int FIT_COLS = 14;            // 12 LS-fit moments, weighted score, kept-point count
+constexpr uint32_t CC_MAXPIX = 1u << 20;
+constexpr int CC_LDS_PIX = 8192;
+
 // ------------------------------------------------------------------------------------------------
-// Morton order
-// 8 bits per axis = the 8 octree levels the sampler draws from (24-bit keys: three radix passes)
+// device-resident state
+struct PlaneState {
+    float n[3], pos[3], dist;        // Plane (ransac/Plane.h: m_normal, m_pos, m_dist)
+    float a0[3], a1[3];              // HyperplaneCoordinateSystem axes (GfxTL/HyperplaneCoordinateSystem.h:81-93)
+    float bb[4];                     // (min u, min v, max u, max v) of the score list
+    uint32_t ue, ve;                 // bitmap extent
+    uint32_t best_root, n_fg;        // largest component: its root pixel, its pixel count
+    uint32_t n_list, n_kept;         // |score list|, |points of the largest component|
+    double wscore;                   // Candidate::WeightedScore of the kept points
+    float nsum[3];                   // sum of the kept points' normals (orientation)
+    uint32_t err;                    // 1: bitmap too large, 2: LS fit impossible
+    uint32_t converged;              // refit chain: this slot's plane is bitwise the previous slot's
+};
+
+struct ChainHdr {
+    PlaneState st[4];                // slot 0 = the candidate, slot k = k-th LS refit
+    float4 cand[2];                  // hypothesis (n, dist), position
+    uint32_t pool_index, pad[3];
+};
+
+// Every chain owns two slabs.  The FIXED one (header, bitmap, labels) has the same layout whatever the cloud, so the
+// bitmap -- which every labelling pass leaves all-zero for the next rasterisation -- stays where it is when a context
+// goes from one cloud size to the next; the VARIABLE one holds the arrays whose size follows the cloud, at the byte
+// offsets below (a function of the cloud size only).
+constexpr uint64_t F_BMP = 4096, F_TMP = F_BMP + CC_MAXPIX, F_LABEL = F_TMP + CC_MAXPIX, F_SIZES = F_LABEL + 4ull * CC_MAXPIX,
+                   F_BYTES = F_SIZES + 4ull * CC_MAXPIX;
+struct ChainLayout {
+    uint32_t nb, pad;                // tiles of the cloud
+    uint64_t masks1, bc1, bbpart, uv, bidx, part, idxA, idxA_stride, masks2, masks2_stride, bc2, bc2_stride, bytes;
+};
+
+struct RResult;
+
+struct RState {
+    // ---- parameters of the running detect call
+    uint32_t n, min_support, orient, active;
+    float eps, eps3, bitmap_eps, cos_t, overlook_p, bbmin[3], bbmax[3];
+    uint64_t seed;
+    // ---- loop state
+    uint32_t done, sampling, round, it;
+    uint32_t n_remaining, sub_unassigned;
+    float drawn;
+    uint32_t npool, nc;
+    uint32_t batch_idx[R_B];
+    uint32_t pool_cnt[R_TOP];
+    float4 pool_pl[R_TOP], pool_pos[R_TOP];
+    uint32_t n_acc, out_off, err;
+    // ---- removal jobs of the current iteration
+    uint32_t aj_n, aj_chain[R_B], aj_slot[R_B], aj_out[R_B];   // aj_out: offset into out_idx, 0xffffffff = none
+    int32_t aj_id[R_B];
+    // ---- counters
+    uint32_t n_rounds, n_rescores, n_batches, n_accepts, n_mark_launches, n_mark_chains;
+};
+
+// Host-mapped, written by single device lanes, read by the host once `flag` says so.
+struct RResult {
+    uint32_t flag;                   // iterations completed, bit 31 = the detect call has finished
+    uint32_t n_acc, out_off, err, remaining;
+    uint32_t n_rounds, n_rescores, n_batches, n_accepts, n_mark_launches, n_mark_chains, pad;
+    float coef[R_MAXP][4];
+    uint32_t support[R_MAXP];        // 0: below min_support (points removed, no plane reported)
+    uint32_t offset[R_MAXP];
+};
+
+struct CloudView {
+    const float *x, *y, *z, *nx, *ny, *nz;
+    uint32_t n;
+};
+
+// Everything static about one cloud slot, passed BY VALUE in the kernel arguments (scalar loads from the kernarg
+// segment; a table in device memory costs every workgroup a dependent global load before it can fetch anything).
+struct RCloudArgs {
+    CloudView cv;                    // the Morton-ordered cloud
+    const uint32_t *codes;           // its Morton codes
+    const uint32_t *orig;            // Morton position -> original point index (nullptr: identity, seam S1c)
+    int32_t *assigned;               // shapeIndex per Morton position (nullptr: all unassigned, seam S1c)
+    const float *sub;                // stratified subset, SoA with pitch sub_pitch
+    const uint32_t *sub_index;
+    uint32_t sub_pitch, n_sub;
+    RState *st;
+    RResult *res;                    // device address of the host-mapped result block
+    float4 *hyp, *hyp_pos;           // R_H hypotheses of the current round
+    uint32_t *hyp_counts;
+    int32_t *out_idx;                // original indices of the accepted planes' supports, plane after plane
+    char *fixed, *var;               // R_B slabs of F_BYTES / L.bytes
+    const uint32_t *list_values;     // seam S1c: the score list is given (list position -> point), else nullptr
+    ChainLayout L;
+};
+struct RArgs {
+    RCloudArgs c[R_G];
+    uint32_t ng, tiles0;             // clouds in this sequence; tiles of cloud 0 (scan grids are the concatenated tiles)
+};
+
+struct ChainPtr {
+    ChainHdr *hdr;
+    uint8_t *masks1; uint32_t *bc1; float4 *bbpart; float2 *uv; uint32_t *bidx; double *part;
+    uint8_t *bmp, *tmp; uint32_t *label, *sizes;
+    char *base; const ChainLayout *L;
+    __device__ __forceinline__ uint32_t *idxA(int k) const { return reinterpret_cast<uint32_t *>(base + L->idxA + k * L->idxA_stride); }
+    __device__ __forceinline__ uint8_t *masks2(int k) const { return reinterpret_cast<uint8_t *>(base + L->masks2 + k * L->masks2_stride); }
+    __device__ __forceinline__ uint32_t *bc2(int k) const { return reinterpret_cast<uint32_t *>(base + L->bc2 + k * L->bc2_stride); }
+};
+__device__ __forceinline__ ChainPtr chain_of(const RCloudArgs &C, uint32_t b) {
+    ChainPtr p;
+    char *base = C.var + (size_t)b * C.L.bytes, *fx = C.fixed + (size_t)b * F_BYTES;
+    p.base = base; p.L = &C.L;
+    p.hdr = reinterpret_cast<ChainHdr *>(fx);
+    p.masks1 = reinterpret_cast<uint8_t *>(base + C.L.masks1);
+    p.bc1 = reinterpret_cast<uint32_t *>(base + C.L.bc1);
+    p.bbpart = reinterpret_cast<float4 *>(base + C.L.bbpart);
+    p.uv = reinterpret_cast<float2 *>(base + C.L.uv);
+    p.bidx = reinterpret_cast<uint32_t *>(base + C.L.bidx);
+    p.part = reinterpret_cast<double *>(base + C.L.part);
+    p.bmp = reinterpret_cast<uint8_t *>(fx + F_BMP);
+    p.tmp = reinterpret_cast<uint8_t *>(fx + F_TMP);
+    p.label = reinterpret_cast<uint32_t *>(fx + F_LABEL);
+    p.sizes = reinterpret_cast<uint32_t *>(fx + F_SIZES);
+    return p;
+}
+
+ChainLayout make_layout(uint32_t n) {
+    ChainLayout L;
+    memset(&L, 0, sizeof(L));
+    const uint64_t nb = cdiv(n, TILE), n4 = ((uint64_t)n + 7) & ~(uint64_t)3;
+    L.nb = (uint32_t)nb;
+    static_assert(sizeof(ChainHdr) <= F_BMP, "chain header must fit in front of the bitmap");
+    uint64_t o = 0;
+    auto take = [&](uint64_t bytes) { const uint64_t at = o; o = (o + bytes + 255) & ~(uint64_t)255; return at; };
+    L.masks1 = take(nb * TPB);
+    L.bc1 = take((nb + 4) * 4);
+    L.bbpart = take((nb + 1) * 16);
+    L.uv = take(n4 * 8);
+    L.bidx = take(n4 * 4);
+    L.part = take((nb + 1) * FIT_COLS * 8);
+    L.idxA_stride = (n4 * 4 + 255) & ~(uint64_t)255;
+    L.idxA = take(4 * L.idxA_stride);
+    L.masks2_stride = (nb * TPB + 255) & ~(uint64_t)255;
+    L.masks2 = take(4 * L.masks2_stride);
+    L.bc2_stride = ((nb + 4) * 4 + 255) & ~(uint64_t)255;
+    L.bc2 = take(4 * L.bc2_stride);
+    L.bytes = o;
+    return L;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Morton order: 8 bits per axis = the 8 octree levels the sampler draws from; the cloud slot is the top bit of the
+// key so that the clouds of a launch sequence are ordered by ONE sort
 __device__ __forceinline__ uint32_t spread3(uint32_t v) {  // up to 10 bits -> every third bit
     v = (v | (v << 16)) & 0x030000FF;
     v = (v | (v << 8)) & 0x0300F00F;
@@ -44,42 +212,68 @@ __device__ __forceinline__ uint32_t spread3(uint32_t v) {  // up to 10 bits -> e
     return v;
 }
 
-__global__ void k_morton(const float *__restrict__ x, const float *__restrict__ y, const float *__restrict__ z,
-                         uint32_t n, float mnx, float mny, float mnz, float inv_cube, uint32_t *__restrict__ keys,
-                         uint32_t *__restrict__ vals) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t qx = min(255u, (uint32_t)max(0.f, (x[i] - mnx) * inv_cube * 256.f));
-    const uint32_t qy = min(255u, (uint32_t)max(0.f, (y[i] - mny) * inv_cube * 256.f));
-    const uint32_t qz = min(255u, (uint32_t)max(0.f, (z[i] - mnz) * inv_cube * 256.f));
-    keys[i] = (spread3(qz) << 2) | (spread3(qy) << 1) | spread3(qx);
-    vals[i] = i;
+struct MortonIn {
+    const float *x, *y, *z;
+    uint32_t n;
+    float mnx, mny, mnz, inv_cube;
+};
+struct MortonArgs { MortonIn c[R_G]; uint32_t ng; };
+
+__global__ void k_morton(const MortonArgs A, uint32_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t n0 = A.c[0].n;
+    const int g = (A.ng > 1 && t >= n0) ? 1 : 0;
+    const MortonIn &C = A.c[g];
+    const uint32_t i = t - (g ? n0 : 0);
+    if (i >= C.n) return;
+    const uint32_t qx = min(255u, (uint32_t)max(0.f, (C.x[i] - C.mnx) * C.inv_cube * 256.f));
+    const uint32_t qy = min(255u, (uint32_t)max(0.f, (C.y[i] - C.mny) * C.inv_cube * 256.f));
+    const uint32_t qz = min(255u, (uint32_t)max(0.f, (C.z[i] - C.mnz) * C.inv_cube * 256.f));
+    keys[t] = ((uint32_t)g << 24) | (spread3(qz) << 2) | (spread3(qy) << 1) | spread3(qx);
+    vals[t] = t;
 }
 
 // Morton-order gather from the AoS copy (24 contiguous bytes per point: one or two 64 B sectors per
-// point instead of six scattered 4 B reads from the SoA planes)
-__global__ void k_gather_cloud(const float *__restrict__ aos, const uint32_t *__restrict__ perm, uint32_t n,
-                               float *__restrict__ dst, size_t dpitch) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float2 *p = reinterpret_cast<const float2 *>(aos + 6 * (size_t)perm[i]);
-    const float2 a = p[0], b = p[1], c = p[2];
-    dst[i] = a.x; dst[dpitch + i] = a.y; dst[2 * dpitch + i] = b.x;
-    dst[3 * dpitch + i] = b.y; dst[4 * dpitch + i] = c.x; dst[5 * dpitch + i] = c.y;
-}
+// point instead of six scattered 4 B reads from the SoA planes) + the stratified subset (every stride-th
+// point of the Morton order)
+struct GatherOut {
+    const float *aos;                // the cloud's N x 6 input layout
+    float *dst; uint32_t pitch;      // Morton-ordered SoA
+    uint32_t *codes, *orig;
+    int32_t *assigned;
+    float *sub; uint32_t sub_pitch, n_sub, stride; uint32_t *sub_index;
+    uint32_t n;
+};
+struct GatherArgs { GatherOut c[R_G]; uint32_t ng; };
 
-__global__ void k_make_subset(const float *__restrict__ src, size_t spitch, uint32_t n, uint32_t stride, uint32_t n_sub,
-                              float *__restrict__ dst, size_t dpitch, uint32_t *__restrict__ sub_index) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_sub) return;
-    const uint32_t p = min(n - 1, i * stride);
-    sub_index[i] = p;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) dst[k * dpitch + i] = src[k * spitch + p];
+__global__ void k_gather_cloud(const GatherArgs A, const uint32_t *__restrict__ keys, const uint32_t *__restrict__ perm) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t n0 = A.c[0].n;
+    const int g = (A.ng > 1 && t >= n0) ? 1 : 0;
+    const GatherOut &C = A.c[g];
+    const uint32_t i = t - (g ? n0 : 0);
+    if (i >= C.n) return;
+    const uint32_t src = perm[t] - (g ? n0 : 0);
+    const float2 *p = reinterpret_cast<const float2 *>(C.aos + 6 * (size_t)src);
+    const float2 a = p[0], b = p[1], c = p[2];
+    const size_t pitch = C.pitch;
+    C.dst[i] = a.x; C.dst[pitch + i] = a.y; C.dst[2 * pitch + i] = b.x;
+    C.dst[3 * pitch + i] = b.y; C.dst[4 * pitch + i] = c.x; C.dst[5 * pitch + i] = c.y;
+    C.codes[i] = keys[t] & 0xffffffu;
+    C.orig[i] = src;
+    if (i % C.stride == 0) {
+        const uint32_t s = i / C.stride;
+        if (s < C.n_sub) {
+            const size_t sp = C.sub_pitch;
+            C.sub_index[s] = i;
+            C.sub[s] = a.x; C.sub[sp + s] = a.y; C.sub[2 * sp + s] = b.x;
+            C.sub[3 * sp + s] = b.y; C.sub[4 * sp + s] = c.x; C.sub[5 * sp + s] = c.y;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
-// hypothesis sampling
+// shared device helpers
 __device__ __forceinline__ uint64_t mix64(uint64_t z) {
     z += 0x9E3779B97F4A7C15ull;
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -97,24 +291,160 @@ __device__ __forceinline__ uint32_t lb_u32(const uint32_t *a, uint32_t n, uint32
     return lo;
 }
 
-struct CloudView {
-    const float *x, *y, *z, *nx, *ny, *nz;
-    uint32_t n;
-};
+__device__ __forceinline__ bool compatible(float4 pl, float px, float py, float pz, float qx, float qy, float qz, float eps,
+                                           float cos_t) {
+    float d = pl.x * px;
+    d += pl.y * py;
+    d += pl.z * pz;
+    const float dist = fabsf(pl.w - d);
+    float nd = pl.x * qx;
+    nd += pl.y * qy;
+    nd += pl.z * qz;
+    return (dist < eps) && (fabsf(nd) >= cos_t);
+}
 
-__global__ __launch_bounds__(256) void k_sample(CloudView c, const uint32_t *__restrict__ codes,
-                                                const int32_t *__restrict__ assigned, uint64_t seed, uint32_t round,
-                                                uint32_t h, int min_level, int max_level, float eps, float cos_t,
-                                                float4 *__restrict__ hyp, float4 *__restrict__ hyp_pos,
-                                                uint32_t *__restrict__ counts, uint32_t *__restrict__ misc) {
+struct Tile {
+    float px[PPT], py[PPT], pz[PPT], qx[PPT], qy[PPT], qz[PPT];
+    bool valid[PPT];
+};
+// 4 consecutive points per lane via 16-byte loads; `assigned` (nullable) is indexed directly or through sub_index
+__device__ __forceinline__ void load_tile(Tile &t, const float *x, const float *y, const float *z, const float *nx, const float *ny,
+                                          const float *nz, const int32_t *assigned, const uint32_t *sub_index, uint32_t n,
+                                          uint32_t base) {
+    if (base + PPT <= n) {
+        const float4 a = *reinterpret_cast<const float4 *>(x + base), b = *reinterpret_cast<const float4 *>(y + base),
+                     c = *reinterpret_cast<const float4 *>(z + base), d = *reinterpret_cast<const float4 *>(nx + base),
+                     e = *reinterpret_cast<const float4 *>(ny + base), f = *reinterpret_cast<const float4 *>(nz + base);
+        t.px[0] = a.x; t.px[1] = a.y; t.px[2] = a.z; t.px[3] = a.w;
+        t.py[0] = b.x; t.py[1] = b.y; t.py[2] = b.z; t.py[3] = b.w;
+        t.pz[0] = c.x; t.pz[1] = c.y; t.pz[2] = c.z; t.pz[3] = c.w;
+        t.qx[0] = d.x; t.qx[1] = d.y; t.qx[2] = d.z; t.qx[3] = d.w;
+        t.qy[0] = e.x; t.qy[1] = e.y; t.qy[2] = e.z; t.qy[3] = e.w;
+        t.qz[0] = f.x; t.qz[1] = f.y; t.qz[2] = f.z; t.qz[3] = f.w;
+        if (assigned && !sub_index) {
+            const int4 s = *reinterpret_cast<const int4 *>(assigned + base);
+            t.valid[0] = s.x == -1; t.valid[1] = s.y == -1; t.valid[2] = s.z == -1; t.valid[3] = s.w == -1;
+        } else if (assigned) {
+            const uint4 si = *reinterpret_cast<const uint4 *>(sub_index + base);
+            t.valid[0] = assigned[si.x] == -1; t.valid[1] = assigned[si.y] == -1;
+            t.valid[2] = assigned[si.z] == -1; t.valid[3] = assigned[si.w] == -1;
+        } else {
+            t.valid[0] = t.valid[1] = t.valid[2] = t.valid[3] = true;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            const uint32_t i = base + k;
+            const bool in = i < n;
+            t.px[k] = in ? x[i] : 0.f; t.py[k] = in ? y[i] : 0.f; t.pz[k] = in ? z[i] : 0.f;
+            t.qx[k] = in ? nx[i] : 0.f; t.qy[k] = in ? ny[i] : 0.f; t.qz[k] = in ? nz[i] : 0.f;
+            bool un = true;
+            if (in && assigned) un = (sub_index ? assigned[sub_index[i]] : assigned[i]) == -1;
+            t.valid[k] = in && un;
+        }
+    }
+}
+
+// which cloud a workgroup of a "concatenated tiles" grid scans
+__device__ __forceinline__ int scan_group(const RArgs &A, uint32_t &tile) {
+    const int g = (A.ng > 1 && blockIdx.x >= A.tiles0) ? 1 : 0;
+    tile = blockIdx.x - (g ? A.tiles0 : 0);
+    return g;
+}
+
+__device__ __forceinline__ void hcs_axes(const float *n, float *a0, float *a1) {
+    float t[3];
+    if (fabsf(n[0]) < 0.015625f && fabsf(n[1]) < 0.015625f) {  // (0,1,0) x n
+        t[0] = 1.f * n[2] - 0.f * n[1]; t[1] = 0.f * n[0] - 0.f * n[2]; t[2] = 0.f * n[1] - 1.f * n[0];
+    } else {                                                      // (0,0,1) x n
+        t[0] = 0.f * n[2] - 1.f * n[1]; t[1] = 1.f * n[0] - 0.f * n[2]; t[2] = 0.f * n[1] - 0.f * n[0];
+    }
+    float l = t[0] * t[0];
+    l += t[1] * t[1];
+    l += t[2] * t[2];
+    l = sqrtf(l);
+    a0[0] = t[0] / l; a0[1] = t[1] / l; a0[2] = t[2] / l;
+    float u[3] = {n[1] * a0[2] - n[2] * a0[1], n[2] * a0[0] - n[0] * a0[2], n[0] * a0[1] - n[1] * a0[0]};
+    l = u[0] * u[0];
+    l += u[1] * u[1];
+    l += u[2] * u[2];
+    l = sqrtf(l);
+    a1[0] = u[0] / l; a1[1] = u[1] / l; a1[2] = u[2] / l;
+}
+
+// plane frame of a slot as the scan kernels keep it in LDS: pos(3), a0(3), a1(3)
+__device__ __forceinline__ void plane_uv(const float *fr, float x, float y, float z, float &u, float &v) {
+    // PlanePrimitiveShape::Parameters (ransac/PlanePrimitiveShape.h:97-109)
+    const float pp[3] = {x - fr[0], y - fr[1], z - fr[2]};
+    u = pp[0] * fr[3] + pp[1] * fr[4] + pp[2] * fr[5];
+    v = pp[0] * fr[6] + pp[1] * fr[7] + pp[2] * fr[8];
+}
+
+// state of slot 0 from a hypothesis (n, dist) + position
+__device__ void state_from_hyp(PlaneState *st, float4 hyp, float4 pos) {
+    st->n[0] = hyp.x; st->n[1] = hyp.y; st->n[2] = hyp.z; st->dist = hyp.w;
+    st->pos[0] = pos.x; st->pos[1] = pos.y; st->pos[2] = pos.z;
+    hcs_axes(st->n, st->a0, st->a1);
+    st->err = 0;
+    st->converged = 0;
+    st->n_list = st->n_kept = 0;
+    st->wscore = 0.0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// init: shapeIndex = -1 for the clouds that take part, loop state from the call's parameters
+struct RInitCloud {
+    uint32_t active, min_support, orient;
+    float eps, eps3, bitmap_eps, cos_t, overlook_p, bbmin[3], bbmax[3];
+    uint64_t seed;
+};
+struct RInit { RInitCloud c[R_G]; };
+
+__global__ __launch_bounds__(TPB) void k_r_init(const RArgs A, const RInit I) {
+    uint32_t tile;
+    const int g = scan_group(A, tile);
+    const RCloudArgs &C = A.c[g];
+    const RInitCloud &P = I.c[g];
+    if (!P.active) {
+        if (tile == 0 && threadIdx.x == 0) { C.st->active = 0; C.st->done = 1; C.st->nc = 0; C.st->aj_n = 0; C.st->npool = 0; C.st->sampling = 0; }
+        return;
+    }
+    const uint32_t base = tile * TILE + threadIdx.x * PPT;
+    if (C.assigned) {
+        if (base + PPT <= ((C.cv.n + 3) & ~3u)) *reinterpret_cast<int4 *>(C.assigned + base) = make_int4(-1, -1, -1, -1);
+    }
+    if (tile == 0 && threadIdx.x == 0) {
+        RState *S = C.st;
+        S->n = C.cv.n; S->min_support = P.min_support; S->orient = P.orient; S->active = 1;
+        S->eps = P.eps; S->eps3 = P.eps3; S->bitmap_eps = P.bitmap_eps; S->cos_t = P.cos_t; S->overlook_p = P.overlook_p;
+        for (int k = 0; k < 3; ++k) { S->bbmin[k] = P.bbmin[k]; S->bbmax[k] = P.bbmax[k]; }
+        S->seed = P.seed;
+        const bool nothing = C.cv.n < 3 || C.cv.n < P.min_support;   // RansacShapeDetector.cpp: no shape can reach minSupport
+        S->done = nothing ? 1u : 0u; S->sampling = nothing ? 0u : 1u; S->round = 0; S->it = 0;
+        S->n_remaining = C.cv.n; S->sub_unassigned = 0; S->drawn = 0.f;
+        S->npool = 0; S->nc = 0; S->n_acc = 0; S->out_off = 0; S->err = 0; S->aj_n = 0;
+        S->n_rounds = S->n_rescores = S->n_batches = S->n_accepts = S->n_mark_launches = S->n_mark_chains = 0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// hypothesis sampling: one lane per hypothesis
+__global__ __launch_bounds__(256) void k_r_sample(const RArgs A) {
+    const RCloudArgs &C = A.c[blockIdx.y];
+    RState *S = C.st;
+    if (S->done || !S->sampling) return;
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= h) return;
-    Rng rng{mix64(seed ^ ((uint64_t)round << 32) ^ t)};
+    if (t >= R_H) return;
+    const CloudView &c = C.cv;
+    const int32_t *__restrict__ assigned = C.assigned;
+    const uint32_t *__restrict__ codes = C.codes;
+    const float eps = S->eps, cos_t = S->cos_t;
+    Rng rng{mix64(S->seed ^ ((uint64_t)S->round << 32) ^ t)};
     const float nanv = __int_as_float(0x7fc00000);
-    hyp[t] = make_float4(0.f, 0.f, 0.f, nanv);
-    hyp_pos[t] = make_float4(0.f, 0.f, 0.f, 0.f);
-    counts[t] = 0;                 // the scoring pass that follows accumulates with atomics
-    if (t == 0) *misc = 0;         // and so does the unassigned-point count of the subset
+    C.hyp[t] = make_float4(0.f, 0.f, 0.f, nanv);
+    C.hyp_pos[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    C.hyp_counts[t] = 0;            // the scoring pass that follows accumulates with atomics
+    if (t == 0) S->sub_unassigned = 0;   // and so does the unassigned-point count of the subset
     // draws are made eight at a time so that their shapeIndex look-ups are in flight together (late rounds
     // have few unassigned points left and most draws miss)
     uint32_t i0 = 0;
@@ -131,7 +461,7 @@ __global__ __launch_bounds__(256) void k_sample(CloudView c, const uint32_t *__r
             if (!ok && av[u] == -1) { i0 = cand[u]; ok = true; }
     }
     if (!ok) return;
-    const int level = min_level + (int)(rng.next() % (uint32_t)(max_level - min_level + 1));
+    const int level = R_MIN_LEVEL + (int)(rng.next() % (uint32_t)(R_MAX_LEVEL - R_MIN_LEVEL + 1));
     const uint32_t low_bits = 24 - 3 * level;
     const uint32_t mask = low_bits >= 32 ? 0u : ~((1u << low_bits) - 1u);
     const uint32_t lo_key = codes[i0] & mask, hi_key = lo_key | ~mask;
@@ -158,7 +488,7 @@ __global__ __launch_bounds__(256) void k_sample(CloudView c, const uint32_t *__r
     if (got < 3) return;
     // three samples drawn: this counts as a generated candidate (genCands, RansacShapeDetector.cpp:122-125)
     // whether or not the plane survives construction / verification below
-    hyp_pos[t] = make_float4(0.f, 0.f, 0.f, 2.f);
+    C.hyp_pos[t] = make_float4(0.f, 0.f, 0.f, 2.f);
     // Plane::Init (ransac/Plane.cpp:29-38)
     const float p1[3] = {c.x[s[0]], c.y[s[0]], c.z[s[0]]}, p2[3] = {c.x[s[1]], c.y[s[1]], c.z[s[1]]},
                 p3[3] = {c.x[s[2]], c.y[s[2]], c.z[s[2]]};
@@ -183,102 +513,371 @@ __global__ __launch_bounds__(256) void k_sample(CloudView c, const uint32_t *__r
         nd += nr[2] * c.nz[s[k]];
         if (!(fabsf(dist - d) < eps && fabsf(nd) >= cos_t)) return;
     }
-    hyp[t] = make_float4(nr[0], nr[1], nr[2], dist);
-    hyp_pos[t] = make_float4(p1[0], p1[1], p1[2], 1.f);
+    C.hyp[t] = make_float4(nr[0], nr[1], nr[2], dist);
+    C.hyp_pos[t] = make_float4(p1[0], p1[1], p1[2], 1.f);
 }
 
-__global__ void k_count_unassigned(const int32_t *__restrict__ assigned, const uint32_t *__restrict__ sub_index,
-                                   uint32_t n, uint32_t *__restrict__ out) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    bool un = false;
-    if (i < n) un = assigned[sub_index ? sub_index[i] : i] == -1;
-    const uint32_t c = (uint32_t)__popcll(__ballot(un));
-    if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+// K1 on the stratified subset: grid (subset tiles, hypothesis chunks, clouds)
+__global__ __launch_bounds__(TPB) void k_r_score_sub(const RArgs A) {
+    __shared__ float4 s_pl[HCHUNK];
+    __shared__ uint32_t s_cnt[TPB / 64][HCHUNK];
+    const RCloudArgs &C = A.c[blockIdx.z];
+    RState *S = C.st;
+    if (S->done || !S->sampling) return;
+    if (blockIdx.x * TILE >= C.n_sub) return;
+    const uint32_t h0 = blockIdx.y * HCHUNK;
+    if (threadIdx.x < HCHUNK) s_pl[threadIdx.x] = C.hyp[h0 + threadIdx.x];
+    const size_t sp = C.sub_pitch;
+    const float eps = S->eps, cos_t = S->cos_t;
+    Tile t;
+    load_tile(t, C.sub, C.sub + sp, C.sub + 2 * sp, C.sub + 3 * sp, C.sub + 4 * sp, C.sub + 5 * sp, C.assigned, C.sub_index, C.n_sub,
+              blockIdx.x * TILE + threadIdx.x * PPT);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (blockIdx.y == 0) {   // unassigned points of the subset (estimates the support on the whole cloud)
+        uint32_t un = 0;
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) un += (uint32_t)__popcll(__ballot(t.valid[k]));
+        if (lane == 0 && un) atomicAdd(&S->sub_unassigned, un);
+    }
+    for (uint32_t hh = 0; hh < HCHUNK; ++hh) {
+        const float4 pl = s_pl[hh];
+        uint32_t c = 0;
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            const bool in = t.valid[k] && compatible(pl, t.px[k], t.py[k], t.pz[k], t.qx[k], t.qy[k], t.qz[k], eps, cos_t);
+            c += (uint32_t)__popcll(__ballot(in));
+        }
+        if (lane == 0) s_cnt[wave][hh] = c;
+    }
+    __syncthreads();
+    if (threadIdx.x < HCHUNK) {
+        const uint32_t tot = s_cnt[0][threadIdx.x] + s_cnt[1][threadIdx.x] + s_cnt[2][threadIdx.x] + s_cnt[3][threadIdx.x];
+        if (tot) atomicAdd(&C.hyp_counts[h0 + threadIdx.x], tot);
+    }
+}
+
+__device__ __forceinline__ bool same_plane(const float4 &a, const float4 &b, float eps) {
+    const float c = a.x * b.x + a.y * b.y + a.z * b.z;
+    if (fabsf(c) < 0.995f) return false;
+    const float db = c >= 0 ? b.w : -b.w;
+    return fabsf(a.w - db) < 2 * eps;
+}
+
+// Leaders of a round: the hypotheses by estimated support, one representative per distinct plane (a greedy pass in
+// descending order that drops what duplicates an earlier pick = repeatedly take the best one alive and strike out
+// its duplicates).  One workgroup of 1024 lanes per cloud, four hypotheses per lane.
+__global__ __launch_bounds__(1024) void k_r_leaders(const RArgs A) {
+    const RCloudArgs &C = A.c[blockIdx.x];
+    RState *S = C.st;
+    if (S->done || !S->sampling) return;
+    __shared__ unsigned long long s_red[16];
+    __shared__ uint32_t s_val[16];
+    __shared__ float4 s_new;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t sub_un = S->sub_unassigned, n_rem = S->n_remaining, ms = S->min_support;
+    const float eps = S->eps;
+    const double ratio = sub_un ? (double)n_rem / sub_un : 0.0;
+    unsigned long long key[4];
+    float4 pl[4];
+    uint32_t valid = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint32_t i = tid + q * 1024;
+        const float4 pos = C.hyp_pos[i];
+        const uint32_t c = C.hyp_counts[i];
+        pl[q] = C.hyp[i];
+        valid += pos.w != 0.f;   // w: 0 no samples, 1 verified plane, 2 drawn but rejected
+        const bool ok = pos.w == 1.f && c * ratio >= 0.5 * ms;
+        key[q] = ok ? (((unsigned long long)c << 32) | (0xffffffffu - i)) : 0ull;   // count descending, index ascending
+    }
+    for (int d = 32; d >= 1; d >>= 1) valid += __shfl_xor(valid, d, 64);
+    if (lane == 0) s_val[wave] = valid;
+    uint32_t npool = 0;
+    for (; npool < R_TOP; ++npool) {
+        unsigned long long m = max(max(key[0], key[1]), max(key[2], key[3]));
+        for (int d = 32; d >= 1; d >>= 1) {
+            const unsigned long long o = __shfl_xor(m, d, 64);
+            m = o > m ? o : m;
+        }
+        if (lane == 0) s_red[wave] = m;
+        __syncthreads();
+        unsigned long long best = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) best = s_red[w] > best ? s_red[w] : best;
+        if (best == 0ull) break;     // uniform
+        const uint32_t idx = 0xffffffffu - (uint32_t)(best & 0xffffffffull);
+        if ((uint32_t)tid == (idx & 1023u)) {
+            const int q = (int)(idx >> 10);
+            float4 v = pl[0];
+            if (q == 1) v = pl[1]; else if (q == 2) v = pl[2]; else if (q == 3) v = pl[3];
+            s_new = v;
+            S->pool_pl[npool] = v;
+            S->pool_pos[npool] = C.hyp_pos[idx];
+        }
+        __syncthreads();
+        const float4 nw = s_new;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (key[q] && same_plane(nw, pl[q], eps)) key[q] = 0ull;   // strikes the pick itself too
+    }
+    __syncthreads();
+    if (tid < (int)R_TOP) S->pool_cnt[tid] = 0;
+    if (tid == 0) {
+        uint32_t v = 0;
+        for (int w = 0; w < 16; ++w) v += s_val[w];
+        S->drawn += (float)v;
+        S->npool = npool;
+        S->round += 1;
+        S->n_rounds += 1;
+        S->sampling = 0;
+    }
+}
+
+// K1: the pool re-scored on ALL unassigned points of its cloud: one HBM pass per cloud, the pool's planes in LDS
+__global__ __launch_bounds__(TPB) void k_r_rescore(const RArgs A) {
+    __shared__ float4 s_pl[HCHUNK];
+    __shared__ uint32_t s_cnt[TPB / 64][HCHUNK];
+    uint32_t tile;
+    const int g = scan_group(A, tile);
+    const RCloudArgs &C = A.c[g];
+    RState *S = C.st;
+    const uint32_t np = S->npool;
+    if (S->done || np == 0) return;
+    if (threadIdx.x < np) s_pl[threadIdx.x] = S->pool_pl[threadIdx.x];
+    const float eps = S->eps, cos_t = S->cos_t;
+    Tile t;
+    load_tile(t, C.cv.x, C.cv.y, C.cv.z, C.cv.nx, C.cv.ny, C.cv.nz, C.assigned, nullptr, C.cv.n, tile * TILE + threadIdx.x * PPT);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (uint32_t hh = 0; hh < np; ++hh) {
+        const float4 pl = s_pl[hh];
+        uint32_t c = 0;
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            const bool in = t.valid[k] && compatible(pl, t.px[k], t.py[k], t.pz[k], t.qx[k], t.qy[k], t.qz[k], eps, cos_t);
+            c += (uint32_t)__popcll(__ballot(in));
+        }
+        if (lane == 0) s_cnt[wave][hh] = c;
+    }
+    __syncthreads();
+    if (threadIdx.x < np) {
+        const uint32_t tot = s_cnt[0][threadIdx.x] + s_cnt[1][threadIdx.x] + s_cnt[2][threadIdx.x] + s_cnt[3][threadIdx.x];
+        if (tot) atomicAdd(&S->pool_cnt[threadIdx.x], tot);
+    }
+    if (tile == 0 && threadIdx.x == 0) S->n_rescores += 1;
+}
+
+// CandidateFailureProbability (RansacShapeDetector.h:61-67, reqSamples = 3)
+__device__ __forceinline__ float fail_prob(float cand_size, float n_pts, float drawn) {
+    const float levels = (float)(R_MAX_LEVEL - R_MIN_LEVEL + 1);
+    return fminf(powf(1.f - cand_size / (n_pts * levels * 4.f), drawn), 1.f);
+}
+
+// the pool is empty: draw another round, or stop (RansacShapeDetector.cpp:856-858 and the loop head)
+__device__ void next_round_or_stop(RState *S) {
+    if (S->n_remaining < S->min_support) S->done = 1;
+    else if (S->round > 0 && fail_prob((float)S->min_support, (float)S->n_remaining, S->drawn) <= S->overlook_p) S->done = 1;
+    else if (S->round >= R_MAX_ROUNDS) S->done = 1;
+    else S->sampling = 1;
+}
+
+// Can a point be an inlier (|dist| < 3 eps AND |n.n_p| >= cos_t) of both planes?  Provably not when
+//  (a) the normals are far apart: n_p within acos(cos_t) of both +-n_a and +-n_b needs
+//      angle(n_a, n_b) <= 2 acos(cos_t) (or its supplement); a 5 degree margin covers the refits; or
+//  (b) the planes are nearly parallel and, everywhere inside the cloud's bounding box, more than
+//      8 eps apart (the two 3 eps bands plus refit drift cannot meet): the difference of the signed
+//      distances is linear in p, so constant sign at the 8 corners + min |.| at a corner decide it.
+// Anything else counts as a conflict and the two candidates are accepted one after the other.
+__device__ bool conflict_free(const float4 &a, const float4 &b, float eps, float cos_t, const float *bbmin, const float *bbmax) {
+    const float c = fabsf(a.x * b.x + a.y * b.y + a.z * b.z);
+    const float two_theta = 2.f * acosf(fminf(1.f, cos_t)) + 0.0873f;
+    if (two_theta < 1.5707f && c < cosf(two_theta)) return true;
+    if (c < 0.97f) return false;
+    const float s = (a.x * b.x + a.y * b.y + a.z * b.z) >= 0 ? 1.f : -1.f;
+    float mn = INFINITY, mx = -INFINITY;
+    for (int k = 0; k < 8; ++k) {
+        const float px = (k & 1) ? bbmax[0] : bbmin[0], py = (k & 2) ? bbmax[1] : bbmin[1], pz = (k & 4) ? bbmax[2] : bbmin[2];
+        const float da = a.x * px + a.y * py + a.z * pz - a.w, db = s * (b.x * px + b.y * py + b.z * pz) - s * b.w;
+        mn = fminf(mn, da - db);
+        mx = fmaxf(mx, da - db);
+    }
+    return (mn > 8 * eps) || (mx < -8 * eps);
+}
+
+// After the re-score: candidates that can no longer reach min_support are dropped (RansacShapeDetector.cpp:826-832),
+// the rest is ordered by support, and the best candidate plus every further one whose support provably cannot touch
+// the supports already in the batch become this iteration's acceptance chains (accepting them concurrently equals
+// accepting them one by one).  One wavefront per cloud.
+__global__ __launch_bounds__(64) void k_r_select(const RArgs A) {
+    const RCloudArgs &C = A.c[blockIdx.x];
+    RState *S = C.st;
+    const int lane = threadIdx.x;
+    if (S->done) { if (lane == 0) { S->nc = 0; S->aj_n = 0; } return; }
+    __shared__ float4 s_pl[R_TOP], s_pos[R_TOP];
+    __shared__ uint32_t s_cnt[R_TOP], s_raw[R_TOP], s_keep[R_TOP];
+    const uint32_t np = S->npool, ms = S->min_support;
+    uint32_t cnt = 0;
+    bool keep = false;
+    float4 pl = make_float4(0, 0, 0, 0), pos = pl;
+    if ((uint32_t)lane < np) { cnt = S->pool_cnt[lane]; keep = cnt >= ms; pl = S->pool_pl[lane]; pos = S->pool_pos[lane]; }
+    if (lane < (int)R_TOP) { s_raw[lane] = cnt; s_keep[lane] = keep ? 1u : 0u; }
+    __syncthreads();
+    // stable descending order of the kept entries
+    uint32_t rank = 0;
+    if (keep)
+        for (uint32_t j = 0; j < np; ++j) rank += s_keep[j] && ((s_raw[j] > cnt) || (s_raw[j] == cnt && j < (uint32_t)lane));
+    const uint32_t np2 = (uint32_t)__popcll(__ballot(keep));
+    if (keep) { s_pl[rank] = pl; s_pos[rank] = pos; s_cnt[rank] = cnt; }
+    __syncthreads();
+    if (np2 == 0) {
+        if (lane == 0) { S->npool = 0; S->nc = 0; S->aj_n = 0; next_round_or_stop(S); }
+        return;
+    }
+    const float eps = S->eps, cos_t = S->cos_t;
+    float bbmin[3], bbmax[3];
+    for (int k = 0; k < 3; ++k) { bbmin[k] = S->bbmin[k]; bbmax[k] = S->bbmax[k]; }
+    __shared__ uint32_t s_batch[R_B];
+    uint32_t nb = 1;
+    if (lane == 0) s_batch[0] = 0;
+    __syncthreads();
+    for (uint32_t i = 1; i < np2 && nb < (uint32_t)R_B; ++i) {
+        bool conflict = false;
+        if ((uint32_t)lane < nb) conflict = !conflict_free(s_pl[i], s_pl[s_batch[lane]], eps, cos_t, bbmin, bbmax);
+        if (__ballot(conflict) == 0ull) {
+            if (lane == 0) s_batch[nb] = i;
+            ++nb;
+        }
+        __syncthreads();
+    }
+    // the ordered pool back to the state, counts cleared for the next re-score
+    if ((uint32_t)lane < np2) { S->pool_pl[lane] = s_pl[lane]; S->pool_pos[lane] = s_pos[lane]; }
+    if (lane < (int)R_TOP) S->pool_cnt[lane] = 0;
+    if ((uint32_t)lane < nb) {
+        const uint32_t bi = s_batch[lane];
+        S->batch_idx[lane] = bi;
+        ChainPtr ch = chain_of(C, lane);
+        ch.hdr->cand[0] = s_pl[bi];
+        ch.hdr->cand[1] = s_pos[bi];
+        ch.hdr->pool_index = bi;
+        state_from_hyp(&ch.hdr->st[0], s_pl[bi], s_pos[bi]);
+    }
+    if (lane == 0) { S->npool = np2; S->nc = nb; S->aj_n = 0; S->n_batches += 1; }
 }
 
 // ------------------------------------------------------------------------------------------------
-// plane state on the device: everything the acceptance sequence needs without a host round trip
-struct PlaneState {
-    float n[3], pos[3], dist;        // Plane (ransac/Plane.h: m_normal, m_pos, m_dist)
-    float a0[3], a1[3];              // HyperplaneCoordinateSystem axes (GfxTL/HyperplaneCoordinateSystem.h:81-93)
-    int bb[4];                       // ordered-int (min u, min v, max u, max v)
-    uint32_t ue, ve;
-    uint32_t best_root, n_fg;
-    double wscore;
-    float nsum[3];                   // sum of inlier point normals (orientation)
-    uint32_t err;
-    uint32_t converged;              // refit chain: this slot's plane is bitwise the previous slot's
-};
-
-constexpr int CHAIN_MAX = BATCH_MAXJ;   // chains of a launch: 8 per cloud, two clouds (table passed by value in the kernarg)
-
-// Device-visible buffers of one acceptance chain.  Every kernel of the acceptance sequence takes the
-// table of chains and handles chain blockIdx.y (slot k of it): one launch serves the whole batch of
-// candidates that are accepted together.
-struct ChainDev {
-    PlaneState *st;        // 4 slots: candidate + 3 refits
-    uint32_t *cntS;        // per-slot result counts
-    float *nsum;           // 4 x 3
-    float4 *top;           // hypothesis (n, dist), position
-    float4 *plane_cur;     // 4
-    uint32_t *idxA, *cntA; // score(3 eps) list before the connected component
-    uint32_t *idxS[4];     // per-slot result lists
-    float2 *uv;
-    uint32_t *bidx, *label, *sizes;
-    uint8_t *bmp, *tmp;
-    uint8_t *masks2;       // connected-component selection masks
-    uint32_t *bc2;
-    const uint32_t *bcA;   // per-tile counts of the score list
-    float *bbpart;         // per-tile (u, v) bounding boxes of the score list
-    double *part;
-};
-// A batch may hold the chains of two clouds (the two scans of a pair are extracted in lock-step): chains
-// [0, split) belong to group 0, the rest to group 1.
-struct ChainGroup { CloudView cloud; float eps3, bitmap_eps; uint32_t nb4; };
-struct ChainTab { ChainDev c[CHAIN_MAX]; ChainGroup g[2]; uint32_t split; };
-
-
-__device__ __forceinline__ void hcs_axes(const float *n, float *a0, float *a1) {
-    float t[3];
-    if (fabsf(n[0]) < 0.015625f && fabsf(n[1]) < 0.015625f) {  // (0,1,0) x n
-        t[0] = 1.f * n[2] - 0.f * n[1]; t[1] = 0.f * n[0] - 0.f * n[2]; t[2] = 0.f * n[1] - 1.f * n[0];
-    } else {                                                      // (0,0,1) x n
-        t[0] = 0.f * n[2] - 1.f * n[1]; t[1] = 1.f * n[0] - 0.f * n[2]; t[2] = 0.f * n[1] - 0.f * n[0];
+// acceptance chain, slot k: GlobalWeightedScore (Candidate.h:293-302) = score(3 eps) -> ConnectedComponent ->
+// weighted score, then the LS fit of the result list.
+//
+// (1) mark: ONE pass over the cloud for all chains of the cloud: 4-bit inlier masks per lane, per-tile counts and
+//     the per-tile bounding boxes of the inliers' (u, v) plane parameters (BitmapPrimitiveShape.h:113-126)
+__global__ __launch_bounds__(TPB) void k_r_mark(const RArgs A, int k) {
+    __shared__ float4 s_pl[R_B];
+    __shared__ float s_fr[R_B][9];
+    __shared__ uint32_t s_skip[R_B];
+    __shared__ uint32_t s_w[R_B][TPB / 64];
+    __shared__ float s_bb[R_B][4][TPB / 64];
+    uint32_t tile;
+    const int g = scan_group(A, tile);
+    const RCloudArgs &C = A.c[g];
+    RState *S = C.st;
+    const uint32_t nc = S->nc;
+    if (nc == 0) return;
+    if (threadIdx.x < nc) {
+        const PlaneState *st = &chain_of(C, threadIdx.x).hdr->st[k];
+        s_skip[threadIdx.x] = st->converged;
+        s_pl[threadIdx.x] = make_float4(st->n[0], st->n[1], st->n[2], st->dist);
+        float *fr = s_fr[threadIdx.x];
+        fr[0] = st->pos[0]; fr[1] = st->pos[1]; fr[2] = st->pos[2];
+        fr[3] = st->a0[0]; fr[4] = st->a0[1]; fr[5] = st->a0[2];
+        fr[6] = st->a1[0]; fr[7] = st->a1[1]; fr[8] = st->a1[2];
     }
-    float l = t[0] * t[0];
-    l += t[1] * t[1];
-    l += t[2] * t[2];
-    l = sqrtf(l);
-    a0[0] = t[0] / l; a0[1] = t[1] / l; a0[2] = t[2] / l;
-    float u[3] = {n[1] * a0[2] - n[2] * a0[1], n[2] * a0[0] - n[0] * a0[2], n[0] * a0[1] - n[1] * a0[0]};
-    l = u[0] * u[0];
-    l += u[1] * u[1];
-    l += u[2] * u[2];
-    l = sqrtf(l);
-    a1[0] = u[0] / l; a1[1] = u[1] / l; a1[2] = u[2] / l;
+    const float eps = S->eps3, cos_t = S->cos_t;
+    Tile t;
+    load_tile(t, C.cv.x, C.cv.y, C.cv.z, C.cv.nx, C.cv.ny, C.cv.nz, C.assigned, nullptr, C.cv.n, tile * TILE + threadIdx.x * PPT);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t active = 0;
+    for (uint32_t j = 0; j < nc; ++j) {
+        if (s_skip[j]) continue;   // uniform
+        ++active;
+        const float4 pl = s_pl[j];
+        uint32_t m = 0, c = 0;
+        float mn0 = INFINITY, mn1 = INFINITY, mx0 = -INFINITY, mx1 = -INFINITY;
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) {
+            const bool in = t.valid[q] && compatible(pl, t.px[q], t.py[q], t.pz[q], t.qx[q], t.qy[q], t.qz[q], eps, cos_t);
+            m |= (in ? 1u : 0u) << q;
+            c += (uint32_t)__popcll(__ballot(in));
+            if (in) {
+                float u, v;
+                plane_uv(s_fr[j], t.px[q], t.py[q], t.pz[q], u, v);
+                mn0 = fminf(mn0, u); mn1 = fminf(mn1, v); mx0 = fmaxf(mx0, u); mx1 = fmaxf(mx1, v);
+            }
+        }
+        chain_of(C, j).masks1[tile * TPB + threadIdx.x] = (uint8_t)m;
+        if (c) {   // wave-uniform
+            for (int d = 32; d >= 1; d >>= 1) {
+                mn0 = fminf(mn0, __shfl_xor(mn0, d, 64)); mn1 = fminf(mn1, __shfl_xor(mn1, d, 64));
+                mx0 = fmaxf(mx0, __shfl_xor(mx0, d, 64)); mx1 = fmaxf(mx1, __shfl_xor(mx1, d, 64));
+            }
+        }
+        if (lane == 0) { s_w[j][wave] = c; s_bb[j][0][wave] = mn0; s_bb[j][1][wave] = mn1; s_bb[j][2][wave] = mx0; s_bb[j][3][wave] = mx1; }
+    }
+    __syncthreads();
+    if (threadIdx.x < nc && !s_skip[threadIdx.x]) {
+        const uint32_t j = threadIdx.x;
+        const ChainPtr ch = chain_of(C, j);
+        const uint32_t tot = s_w[j][0] + s_w[j][1] + s_w[j][2] + s_w[j][3];
+        ch.bc1[tile] = tot;
+        if (tot)
+            ch.bbpart[tile] = make_float4(fminf(fminf(s_bb[j][0][0], s_bb[j][0][1]), fminf(s_bb[j][0][2], s_bb[j][0][3])),
+                                          fminf(fminf(s_bb[j][1][0], s_bb[j][1][1]), fminf(s_bb[j][1][2], s_bb[j][1][3])),
+                                          fmaxf(fmaxf(s_bb[j][2][0], s_bb[j][2][1]), fmaxf(s_bb[j][2][2], s_bb[j][2][3])),
+                                          fmaxf(fmaxf(s_bb[j][3][0], s_bb[j][3][1]), fmaxf(s_bb[j][3][2], s_bb[j][3][3])));
+    }
+    if (tile == 0 && threadIdx.x == 0 && active) { S->n_mark_launches += 1; S->n_mark_chains += active; }
 }
 
-__device__ __forceinline__ int ord_i(float f) { int v = __float_as_int(f); return v >= 0 ? v : v ^ 0x7fffffff; }
-__device__ __forceinline__ float ord_f(int v) { return __int_as_float(v >= 0 ? v : v ^ 0x7fffffff); }
-
-// initialise the state from a hypothesis (n, dist) + position
-__global__ void k_state_from_hyp(const ChainTab chains) {
-    if (threadIdx.x) return;
-    const ChainDev &C = chains.c[blockIdx.x];
-    const float4 *hyp = C.top, *pos = C.top + 1;
-    PlaneState *st = C.st;
-    float4 *plane_out = C.plane_cur;
-    st->n[0] = hyp->x; st->n[1] = hyp->y; st->n[2] = hyp->z; st->dist = hyp->w;
-    st->pos[0] = pos->x; st->pos[1] = pos->y; st->pos[2] = pos->z;
-    hcs_axes(st->n, st->a0, st->a1);
-    st->err = 0;
-    st->converged = 0;
-    st->bb[0] = st->bb[1] = ord_i(INFINITY);
-    st->bb[2] = st->bb[3] = ord_i(-INFINITY);
-    *plane_out = *hyp;
+// seam S1c: the score list is given by the caller.  Same outputs as k_r_mark for chain 0 over LIST POSITIONS
+// (all positions < m are "inliers"); tiles past the list get a zero count.
+__global__ __launch_bounds__(TPB) void k_r_list_mark(const RArgs A, uint32_t m) {
+    __shared__ float s_bb[4][TPB / 64];
+    const RCloudArgs &C = A.c[0];
+    const ChainPtr ch = chain_of(C, 0);
+    const PlaneState *st = &ch.hdr->st[0];
+    const uint32_t tile = blockIdx.x, first = tile * TILE + threadIdx.x * PPT;
+    float fr[9] = {st->pos[0], st->pos[1], st->pos[2], st->a0[0], st->a0[1], st->a0[2], st->a1[0], st->a1[1], st->a1[2]};
+    uint32_t mk = 0;
+    float mn0 = INFINITY, mn1 = INFINITY, mx0 = -INFINITY, mx1 = -INFINITY;
+#pragma unroll
+    for (int q = 0; q < PPT; ++q)
+        if (first + q < m) {
+            mk |= 1u << q;
+            const uint32_t p = C.list_values[first + q];
+            float u, v;
+            plane_uv(fr, C.cv.x[p], C.cv.y[p], C.cv.z[p], u, v);
+            mn0 = fminf(mn0, u); mn1 = fminf(mn1, v); mx0 = fmaxf(mx0, u); mx1 = fmaxf(mx1, v);
+        }
+    ch.masks1[tile * TPB + threadIdx.x] = (uint8_t)mk;
+    for (int d = 32; d >= 1; d >>= 1) {
+        mn0 = fminf(mn0, __shfl_xor(mn0, d, 64)); mn1 = fminf(mn1, __shfl_xor(mn1, d, 64));
+        mx0 = fmaxf(mx0, __shfl_xor(mx0, d, 64)); mx1 = fmaxf(mx1, __shfl_xor(mx1, d, 64));
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { s_bb[0][wave] = mn0; s_bb[1][wave] = mn1; s_bb[2][wave] = mx0; s_bb[3][wave] = mx1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t b0 = tile * TILE;
+        const uint32_t tot = b0 >= m ? 0u : min((uint32_t)TILE, m - b0);
+        ch.bc1[tile] = tot;
+        if (tot)
+            ch.bbpart[tile] = make_float4(fminf(fminf(s_bb[0][0], s_bb[0][1]), fminf(s_bb[0][2], s_bb[0][3])),
+                                          fminf(fminf(s_bb[1][0], s_bb[1][1]), fminf(s_bb[1][2], s_bb[1][3])),
+                                          fmaxf(fmaxf(s_bb[2][0], s_bb[2][1]), fmaxf(s_bb[2][2], s_bb[2][3])),
+                                          fmaxf(fmaxf(s_bb[3][0], s_bb[3][1]), fmaxf(s_bb[3][2], s_bb[3][3])));
+    }
 }
-
-constexpr uint32_t CC_MAXPIX = 1u << 20;
 
 // BitmapExtent (PlanePrimitiveShape.cpp:185-191)
 __device__ __forceinline__ bool cc_dims(const float bb[4], uint32_t count, float eps, uint32_t &ue, uint32_t &ve) {
@@ -295,69 +894,116 @@ __device__ __forceinline__ bool cc_dims(const float bb[4], uint32_t count, float
     return true;
 }
 
-// BuildBitmap (BitmapPrimitiveShape.h:139-150) with InBitmap (PlanePrimitiveShape.cpp:193-199).
-// The bitmap is all-zero on entry (k_cc_label clears what it used).
-__global__ __launch_bounds__(256) void k_cc_raster(const ChainTab chains, int k) {
-    const ChainDev &C = chains.c[blockIdx.y];
-    const ChainGroup &G = chains.g[blockIdx.y >= chains.split ? 1 : 0];
-    const float eps = G.bitmap_eps;
-    const uint32_t n_tiles = G.nb4;
-    PlaneState *st = C.st + k;
-    if (st->converged) return;
-    const float2 *__restrict__ uv = C.uv;
-    const uint32_t *__restrict__ count = C.cntA;
-    uint32_t *__restrict__ bidx = C.bidx;
-    uint8_t *__restrict__ bmp = C.bmp;
-    const uint32_t m = *count;
-    // bounding box of the list's (u, v) parameters (BitmapPrimitiveShape.h:113-126): every block reduces the
-    // per-tile boxes the compaction left behind (a few thousand floats from L2)
-    __shared__ float s_bb[4][4];
+// (2) compact + rasterise: the ordered score list (ascending point position) with its (u, v) parameters, and
+//     BuildBitmap (BitmapPrimitiveShape.h:139-150) with InBitmap (PlanePrimitiveShape.cpp:193-199).  Every workgroup
+//     derives the list's bounding box, its length and its own output offset from the per-tile results of the mark
+//     pass (~1e3 entries, L2 resident): no scan launch, no atomics.  The bitmap is all-zero on entry (the labelling
+//     kernel clears what it used).  grid (tiles, chains of all clouds)
+__global__ __launch_bounds__(TPB) void k_r_compact_raster(const RArgs A, int k) {
+    __shared__ float s_bb[4][TPB / 64];
+    __shared__ uint32_t s_pre[TPB / 64], s_tot[TPB / 64], s_w[TPB / 64];
+    const int g = blockIdx.y / R_B;
+    const uint32_t b = blockIdx.y % R_B;
+    if (g >= (int)A.ng) return;
+    const RCloudArgs &C = A.c[g];
+    const uint32_t nb = C.L.nb;
+    if (blockIdx.x >= nb) return;
+    RState *S = C.st;
+    if (b >= S->nc) return;
+    const ChainPtr ch = chain_of(C, b);
+    PlaneState *st = &ch.hdr->st[k];
+    // round 1 of loads, all independent
+    const uint32_t conv = st->converged;
+    const uint32_t mine = ch.bc1[blockIdx.x];
+    const uint32_t m = ch.masks1[blockIdx.x * TPB + threadIdx.x];
+    const float fr[9] = {st->pos[0], st->pos[1], st->pos[2], st->a0[0], st->a0[1], st->a0[2], st->a1[0], st->a1[1], st->a1[2]};
+    const float eps = S->bitmap_eps;
+    if (conv) return;
+    const bool lead = blockIdx.x == 0;
+    if (mine == 0 && !lead) return;   // most tiles of a plane's score list are empty
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // round 2: all tiles' counts and boxes
+    uint32_t pre = 0, tot = 0;
     float bbv[4] = {INFINITY, INFINITY, -INFINITY, -INFINITY};
-    for (uint32_t b = threadIdx.x; b < n_tiles; b += blockDim.x)
-        if (C.bcA[b]) {
-            const float4 t = *reinterpret_cast<const float4 *>(C.bbpart + 4 * (size_t)b);
+    for (uint32_t q = threadIdx.x; q < nb; q += TPB) {
+        const uint32_t c = ch.bc1[q];
+        tot += c;
+        if (q < blockIdx.x) pre += c;
+        if (c) {
+            const float4 t = ch.bbpart[q];
             bbv[0] = fminf(bbv[0], t.x); bbv[1] = fminf(bbv[1], t.y); bbv[2] = fmaxf(bbv[2], t.z); bbv[3] = fmaxf(bbv[3], t.w);
         }
-    for (int q = 0; q < 4; ++q)
-        for (int d = 32; d >= 1; d >>= 1) {
-            const float o = __shfl_xor(bbv[q], d, 64);
-            bbv[q] = q < 2 ? fminf(bbv[q], o) : fmaxf(bbv[q], o);
-        }
-    if ((threadIdx.x & 63) == 0) for (int q = 0; q < 4; ++q) s_bb[q][threadIdx.x >> 6] = bbv[q];
+    }
+    const uint32_t first = blockIdx.x * TILE + threadIdx.x * PPT;
+    uint32_t pv[PPT];
+    float cx[PPT], cy[PPT], cz[PPT];
+#pragma unroll
+    for (int q = 0; q < PPT; ++q) {
+        pv[q] = first + q;
+        if ((m & (1u << q)) && C.list_values) pv[q] = C.list_values[first + q];
+    }
+#pragma unroll
+    for (int q = 0; q < PPT; ++q)
+        if (m & (1u << q)) { cx[q] = C.cv.x[pv[q]]; cy[q] = C.cv.y[pv[q]]; cz[q] = C.cv.z[pv[q]]; }
+    for (int d = 32; d >= 1; d >>= 1) {
+        pre += __shfl_xor(pre, d, 64);
+        tot += __shfl_xor(tot, d, 64);
+        bbv[0] = fminf(bbv[0], __shfl_xor(bbv[0], d, 64)); bbv[1] = fminf(bbv[1], __shfl_xor(bbv[1], d, 64));
+        bbv[2] = fmaxf(bbv[2], __shfl_xor(bbv[2], d, 64)); bbv[3] = fmaxf(bbv[3], __shfl_xor(bbv[3], d, 64));
+    }
+    const uint32_t c = __popc(m);
+    uint32_t incl = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += o;
+    }
+    if (lane == 0) { s_pre[wave] = pre; s_tot[wave] = tot; for (int q = 0; q < 4; ++q) s_bb[q][wave] = bbv[q]; }
+    if (lane == 63) s_w[wave] = incl;
     __syncthreads();
+    pre = s_pre[0] + s_pre[1] + s_pre[2] + s_pre[3];
+    tot = s_tot[0] + s_tot[1] + s_tot[2] + s_tot[3];
     for (int q = 0; q < 4; ++q) {
         float v = s_bb[q][0];
-        for (int w = 1; w < 4; ++w) v = q < 2 ? fminf(v, s_bb[q][w]) : fmaxf(v, s_bb[q][w]);
+        for (int w = 1; w < TPB / 64; ++w) v = q < 2 ? fminf(v, s_bb[q][w]) : fmaxf(v, s_bb[q][w]);
         bbv[q] = v;
     }
     uint32_t ue, ve;
-    const bool ok = cc_dims(bbv, m, eps, ue, ve);
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        st->ue = ue; st->ve = ve;
+    const bool ok = cc_dims(bbv, tot, eps, ue, ve);
+    if (lead && threadIdx.x == 0) {
+        st->ue = ue; st->ve = ve; st->n_list = tot;
         if (!ok) st->err = 1;
-        for (int q = 0; q < 4; ++q) st->bb[q] = ord_i(bbv[q]);
+        for (int q = 0; q < 4; ++q) st->bb[q] = bbv[q];
     }
-    if (!ok) return;
+    if (!ok || mine == 0) return;
+    uint32_t off = pre + incl - c;
+    for (int w = 0; w < wave; ++w) off += s_w[w];
     const float mnu = bbv[0], mnv = bbv[1];
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
-        int bu = (int)floorf((uv[i].x - mnu) / eps), bv = (int)floorf((uv[i].y - mnv) / eps);
-        bu = min(max(bu, 0), (int)ue - 1);
-        bv = min(max(bv, 0), (int)ve - 1);
-        const uint32_t b = (uint32_t)bu + (uint32_t)bv * ue;
-        bidx[i] = b;
-        bmp[b] = 1;
-    }
+    uint32_t *__restrict__ idxA = ch.idxA(k);
+#pragma unroll
+    for (int q = 0; q < PPT; ++q)
+        if (m & (1u << q)) {
+            float u, v;
+            plane_uv(fr, cx[q], cy[q], cz[q], u, v);
+            int bu = (int)floorf((u - mnu) / eps), bv = (int)floorf((v - mnv) / eps);
+            bu = min(max(bu, 0), (int)ue - 1);
+            bv = min(max(bv, 0), (int)ve - 1);
+            const uint32_t px = (uint32_t)bu + (uint32_t)bv * ue;
+            idxA[off] = pv[q];
+            ch.uv[off] = make_float2(u, v);
+            ch.bidx[off] = px;
+            ch.bmp[px] = 1;
+            ++off;
+        }
 }
 
-// closing (DilateCross + ErodeCross, ransac/Bitmap.cpp:154-260, 459-570; no wrapping for planes),
+// (3) closing (DilateCross + ErodeCross, ransac/Bitmap.cpp:154-260, 459-570; no wrapping for planes),
 // 8-connected labelling (Components, Bitmap.cpp:633-834) and selection of the component with most
-// pixels, first in raster order on ties (BitmapPrimitiveShape.cpp:168-173).  One workgroup; bitmaps of
+// pixels, first in raster order on ties (BitmapPrimitiveShape.cpp:168-173).  One workgroup per chain; bitmaps of
 // up to CC_LDS_PIX pixels (every realistic plane at bitmap eps = 2 % of the scene) live in LDS.
-constexpr int CC_LDS_PIX = 8192;
-
-// The labelling proper on a bitmap that lives either in LDS or in global memory.  Force-inlined into both branches
-// of k_cc_label so that the LDS instance is compiled to ds_* instructions (a pointer selected at run time would
-// make every access a flat_* one).
+// The labelling proper works on a bitmap that lives either in LDS or in global memory; it is force-inlined into both
+// branches of k_r_label so that the LDS instance is compiled to ds_* instructions (a pointer selected at run time
+// would make every access a flat_* one).
 __device__ __forceinline__ void cc_label_body(uint8_t *bmp, uint8_t *tmp, uint32_t *label, uint32_t *sizes, int ue, int ve, int npx,
                                               int do_filter, unsigned long long *s_best_p, PlaneState *st) {
     unsigned long long &s_best = *s_best_p;
@@ -383,11 +1029,11 @@ __device__ __forceinline__ void cc_label_body(uint8_t *bmp, uint8_t *tmp, uint32
         }
         __syncthreads();
     }
-    // 8-connected labelling: (1) every pixel gets the first pixel of its horizontal run as label (one lane
-    // per row, sequential along the row), (2) runs are united with the runs they touch in the row above
-    // (N, NW, NE) by lock-free union-find on the run heads; the smaller index always becomes the parent, so
-    // a component's root is its first pixel in raster order
-    {   // one wavefront per row, 64 columns at a time: run head = prefix maximum of the run-start columns
+    // 8-connected labelling: (1) every pixel gets the first pixel of its horizontal run as label (one wavefront
+    // per row, 64 columns at a time: run head = prefix maximum of the run-start columns), (2) runs are united with
+    // the runs they touch in the row above (N, NW, NE) by lock-free union-find on the run heads; the smaller index
+    // always becomes the parent, so a component's root is its first pixel in raster order
+    {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
         for (int v = wave; v < ve; v += nwaves) {
             int carry = -1;   // head column of the run that reaches the end of the previous 64-column chunk
@@ -455,22 +1101,27 @@ __device__ __forceinline__ void cc_label_body(uint8_t *bmp, uint8_t *tmp, uint32
     }
 }
 
-__global__ __launch_bounds__(1024) void k_cc_label(const ChainTab chains, int k, int do_filter) {
-    const ChainDev &C = chains.c[blockIdx.x];
-    PlaneState *st = C.st + k;
-    uint8_t *__restrict__ g_bmp = C.bmp, *__restrict__ g_tmp = C.tmp;
-    uint32_t *__restrict__ g_label = C.label, *__restrict__ g_sizes = C.sizes;
+__global__ __launch_bounds__(1024) void k_r_label(const RArgs A, int k, int do_filter) {
+    const int g = blockIdx.x / R_B;
+    const uint32_t b = blockIdx.x % R_B;
+    if (g >= (int)A.ng) return;
+    const RCloudArgs &C = A.c[g];
+    if (b >= C.st->nc) return;
+    const ChainPtr ch = chain_of(C, b);
+    PlaneState *st = &ch.hdr->st[k];
+    uint8_t *__restrict__ g_bmp = ch.bmp, *__restrict__ g_tmp = ch.tmp;
+    uint32_t *__restrict__ g_label = ch.label, *__restrict__ g_sizes = ch.sizes;
     __shared__ unsigned long long s_best;
     __shared__ uint32_t s_label[CC_LDS_PIX];
     __shared__ uint32_t s_sizes[CC_LDS_PIX];
     __shared__ uint8_t s_bmp[CC_LDS_PIX], s_tmp[CC_LDS_PIX];
-    if (st->converged) return;
+    if (st->converged || st->err) return;
     const int ue = (int)st->ue, ve = (int)st->ve, npx = ue * ve;
     if (npx <= CC_LDS_PIX) {
         for (int p = threadIdx.x; p < npx; p += blockDim.x) { s_bmp[p] = g_bmp[p]; g_bmp[p] = 0; }  // also leaves it clean
         __syncthreads();
         cc_label_body(s_bmp, s_tmp, s_label, s_sizes, ue, ve, npx, do_filter, &s_best, st);
-        // k_cc_select reads the labels from global memory; the bitmap is left all-zero for the next raster
+        // the selection pass reads the labels from global memory; the bitmap is left all-zero for the next raster
         for (int p = threadIdx.x; p < npx; p += blockDim.x) g_label[p] = s_label[p];
     } else {
         cc_label_body(g_bmp, g_tmp, g_label, g_sizes, ue, ve, npx, do_filter, &s_best, st);
@@ -479,36 +1130,33 @@ __global__ __launch_bounds__(1024) void k_cc_label(const ChainTab chains, int k,
     }
 }
 
-// mask layout of k_compact: one byte per lane covering 4 consecutive items, block counts per 1024.
-// The same pass accumulates, over the kept points, the LS-fit moments (12 sums) and Candidate::WeightedScore
-// (ransac/Candidate.cpp:77-87 with weigh(), ScoreComputer.h:10-16) of the slot's plane: one row of FIT_COLS
-// doubles per 1024 list positions, reduced by k_fit_final in a fixed order.
-constexpr int FIT_COLS = 13;
-
-__global__ __launch_bounds__(256) void k_cc_select(const ChainTab chains, int k) {
+// (4) selection of the list entries whose pixel belongs to the largest component (4-bit masks per lane over list
+// positions + per-tile counts).  The same pass accumulates, over the kept points, the LS-fit moments (12 sums),
+// Candidate::WeightedScore (ransac/Candidate.cpp:77-87 with weigh(), ScoreComputer.h:10-16) of the slot's plane and the
+// kept count: one row of FIT_COLS doubles per 1024 list positions, reduced by k_r_fit in a fixed order.
+__global__ __launch_bounds__(TPB) void k_r_select_cc(const RArgs A, int k) {
     __shared__ uint32_t s_w[4];
     __shared__ double s[4][FIT_COLS];
-    const ChainDev &C = chains.c[blockIdx.y];
-    const ChainGroup &G = chains.g[blockIdx.y >= chains.split ? 1 : 0];
-    if (blockIdx.x >= G.nb4) return;   // the grid covers the larger cloud of the batch
-    const CloudView &c = G.cloud;
-    const float eps = G.eps3;
-    const PlaneState *st = C.st + k;
-    if (st->converged) return;
-    const uint32_t *__restrict__ bidx = C.bidx, *__restrict__ count = C.cntA, *__restrict__ label = C.label;
-    const uint32_t *__restrict__ idx = C.idxA;
-    uint8_t *__restrict__ masks = C.masks2;
-    uint32_t *__restrict__ block_counts = C.bc2;
-    const uint32_t m = *count, best = st->best_root;
-    if (blockIdx.x * 1024u >= m) {   // past the list: no kept points, no partial row (k_fit_final reads ceil(m / 1024) rows)
-        masks[blockIdx.x * 256 + threadIdx.x] = 0;
-        if (threadIdx.x == 0) block_counts[blockIdx.x] = 0;
-        return;
-    }
+    const int g = blockIdx.y / R_B;
+    const uint32_t b = blockIdx.y % R_B;
+    if (g >= (int)A.ng) return;
+    const RCloudArgs &C = A.c[g];
+    if (blockIdx.x >= C.L.nb) return;
+    if (b >= C.st->nc) return;
+    const ChainPtr ch = chain_of(C, b);
+    const PlaneState *st = &ch.hdr->st[k];
+    if (st->converged || st->err) return;
+    const uint32_t m = st->n_list, best = st->best_root;
+    if (blockIdx.x * 1024u >= m) return;   // past the list (k_r_fit reads ceil(m / 1024) rows)
+    const CloudView &c = C.cv;
+    const float eps = C.st->eps3;
+    const uint32_t *__restrict__ bidx = ch.bidx, *__restrict__ label = ch.label, *__restrict__ idx = ch.idxA(k);
     const float n0 = st->n[0], n1 = st->n[1], n2 = st->n[2], dist = st->dist;
     const uint32_t base = blockIdx.x * 1024 + threadIdx.x * 4;
     uint32_t mk = 0, cnt = 0;
-    double a[FIT_COLS] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    double a[FIT_COLS];
+#pragma unroll
+    for (int q = 0; q < FIT_COLS; ++q) a[q] = 0.0;
     // two rounds of independent loads (list entries, then everything they point to) instead of a chain of four:
     // nearly every listed point is kept, so the coordinates are fetched before the label test is known
     uint32_t bi[4], pi[4];
@@ -542,9 +1190,10 @@ __global__ __launch_bounds__(256) void k_cc_select(const ChainTab chains, int k)
             d += n2 * fz[q];
             d = fabsf(dist - d);
             a[12] += (double)expf(-d * d / (2.f / 9.f * eps * eps));
+            a[13] += 1.0;
         }
     }
-    masks[blockIdx.x * 256 + threadIdx.x] = (uint8_t)mk;
+    ch.masks2(k)[blockIdx.x * TPB + threadIdx.x] = (uint8_t)mk;
     for (int q = 0; q < FIT_COLS; ++q)
         for (int d = 32; d >= 1; d >>= 1) a[q] += __shfl_xor(a[q], d, 64);
     if ((threadIdx.x & 63) == 0) {
@@ -552,13 +1201,12 @@ __global__ __launch_bounds__(256) void k_cc_select(const ChainTab chains, int k)
         for (int q = 0; q < FIT_COLS; ++q) s[threadIdx.x >> 6][q] = a[q];
     }
     __syncthreads();
-    if (threadIdx.x == 0) block_counts[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+    if (threadIdx.x == 0) ch.bc2(k)[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
     if (threadIdx.x < FIT_COLS)
-        C.part[(size_t)blockIdx.x * FIT_COLS + threadIdx.x] = (s[0][threadIdx.x] + s[1][threadIdx.x]) + (s[2][threadIdx.x] + s[3][threadIdx.x]);
+        ch.part[(size_t)blockIdx.x * FIT_COLS + threadIdx.x] = (s[0][threadIdx.x] + s[1][threadIdx.x]) + (s[2][threadIdx.x] + s[3][threadIdx.x]);
 }
 
-// ------------------------------------------------------------------------------------------------
-// LS refit (PlanePrimitiveShape::LSFit -> Plane::LeastSquaresFit, ransac/Plane.cpp:169-176,
+// (5) LS refit (PlanePrimitiveShape::LSFit -> Plane::LeastSquaresFit, ransac/Plane.cpp:169-176,
 // Plane.h:65-74: mean + covariance about the mean + smallest-|eigenvalue| eigenvector).
 // Accumulated in fp64 with a fixed reduction tree (deterministic); the reference accumulates in
 // fp32 sequentially, which is the noisier of the two.
@@ -582,39 +1230,35 @@ __device__ void jacobi3_d(double a[3][3], double d[3], double v[3][3]) {
     for (int i = 0; i < 3; ++i) d[i] = a[i][i];
 }
 
-// after the last slot: slots that were skipped because the chain had converged repeat their predecessor's results
-__device__ void wscore_final(const ChainDev &C) {
-    PlaneState *st = C.st;
-    uint32_t *__restrict__ cnt = C.cntS;
-    if (threadIdx.x == 0)
-        for (int k = 1; k < 4; ++k)
-            if (st[k].converged) { st[k].wscore = st[k - 1].wscore; cnt[k] = cnt[k - 1]; st[k].ue = st[k - 1].ue; st[k].ve = st[k - 1].ve; }
-}
-
-// Sums the per-block partials of the index list `count` belongs to (fixed tree => deterministic);
-// nsum_out receives the sum of the list's point normals (orientation).  mode 0 additionally writes the
-// fitted plane into `st` (the NEXT slot's state) / plane_out.  One workgroup of 256 lanes.
-// `cur` is the state of the slot whose list was just reduced; when the new plane is bitwise equal to
-// cur's plane the chain has converged: every later slot would reproduce cur's results, so they are
-// flagged and their kernels return immediately.
-__device__ void fit_final(const ChainDev &C, int k, double (*s_red)[FIT_COLS]) {
-    const int kn = k < 3 ? k + 1 : 3, mode = k < 3 ? 0 : 1;
-    const double *__restrict__ part = C.part;
-    const uint32_t *__restrict__ count = C.cntS + k;
-    const PlaneState *cur = C.st + k;
-    PlaneState *st = C.st + kn;
-    float4 *plane_out = C.plane_cur + kn;
-    float *__restrict__ nsum_out = C.nsum + 3 * k;
-    if (cur->converged) {
+// Sums the per-tile rows of slot k's selection pass (fixed tree => deterministic): weighted score, normal sum and
+// kept count of slot k; for k < 3 additionally the LS plane of the kept points = the NEXT slot's plane.  When that
+// plane is bitwise equal to slot k's the chain has converged: every later slot would reproduce slot k's results, so
+// they are flagged, copy them and their kernels return immediately.  One workgroup of 256 lanes per chain.
+__global__ __launch_bounds__(256) void k_r_fit(const RArgs A, int k) {
+    __shared__ double s_red[4][FIT_COLS];
+    const int g = blockIdx.x / R_B;
+    const uint32_t b = blockIdx.x % R_B;
+    if (g >= (int)A.ng) return;
+    const RCloudArgs &C = A.c[g];
+    if (b >= C.st->nc) return;
+    const ChainPtr ch = chain_of(C, b);
+    PlaneState *cur = &ch.hdr->st[k];
+    PlaneState *nxt = k < 3 ? &ch.hdr->st[k + 1] : nullptr;
+    if (cur->converged) {   // repeat the predecessor
         if (threadIdx.x == 0) {
-            nsum_out[0] = nsum_out[-3]; nsum_out[1] = nsum_out[-2]; nsum_out[2] = nsum_out[-1];
-            if (mode == 0) { st->converged = 1; st->err = 0; *plane_out = plane_out[-1]; }
+            const PlaneState *prev = &ch.hdr->st[k - 1];
+            cur->wscore = prev->wscore; cur->n_kept = prev->n_kept; cur->n_list = prev->n_list; cur->ue = prev->ue; cur->ve = prev->ve;
+            cur->nsum[0] = prev->nsum[0]; cur->nsum[1] = prev->nsum[1]; cur->nsum[2] = prev->nsum[2];
+            if (nxt) { *nxt = *cur; nxt->converged = 1; nxt->err = 0; }
         }
         return;
     }
-    // rows written by k_cc_select: one per 1024 positions of the score list; lane t adds rows t, t + 256, ... in
-    // order, then the fixed shuffle / wave tree
-    const uint32_t rows = (*C.cntA + 1023u) / 1024u;
+    if (cur->err) {   // bitmap too large: nothing was selected
+        if (threadIdx.x == 0) { cur->wscore = 0; cur->n_kept = 0; if (nxt) { *nxt = *cur; nxt->converged = 0; nxt->err = 2; } }
+        return;
+    }
+    const double *__restrict__ part = ch.part;
+    const uint32_t rows = (cur->n_list + 1023u) / 1024u;
     double a[FIT_COLS];
     for (int q = 0; q < FIT_COLS; ++q) a[q] = 0.0;
     for (uint32_t r = threadIdx.x; r < rows; r += blockDim.x)
@@ -625,14 +1269,20 @@ __device__ void fit_final(const ChainDev &C, int k, double (*s_red)[FIT_COLS]) {
     __syncthreads();
     if (threadIdx.x) return;
     for (int q = 0; q < FIT_COLS; ++q) a[q] = (s_red[0][q] + s_red[1][q]) + (s_red[2][q] + s_red[3][q]);
-    C.st[k].wscore = a[12];
-    nsum_out[0] = (float)a[9]; nsum_out[1] = (float)a[10]; nsum_out[2] = (float)a[11];
-    if (mode == 1) return;
-    st->err = 0;
-    st->bb[0] = st->bb[1] = ord_i(INFINITY);
-    st->bb[2] = st->bb[3] = ord_i(-INFINITY);
-    const double m = (double)*count;
-    if (m < 3) { st->err = 2; *plane_out = make_float4(0.f, 0.f, 0.f, __int_as_float(0x7fc00000)); return; }
+    cur->wscore = a[12];
+    cur->nsum[0] = (float)a[9]; cur->nsum[1] = (float)a[10]; cur->nsum[2] = (float)a[11];
+    const double m = a[13];
+    cur->n_kept = (uint32_t)m;
+    if (!nxt) return;
+    nxt->err = 0;
+    nxt->converged = 0;
+    nxt->n_list = nxt->n_kept = 0;
+    nxt->wscore = 0.0;
+    if (m < 3) {   // LSFit impossible: the slot gets a plane nothing is compatible with
+        nxt->err = 2;
+        nxt->n[0] = nxt->n[1] = nxt->n[2] = 0.f; nxt->dist = __int_as_float(0x7fc00000);
+        return;
+    }
     const double mx = a[0] / m, my = a[1] / m, mz = a[2] / m;
     double cv[3][3];
     cv[0][0] = a[3] / m - mx * mx; cv[0][1] = a[4] / m - mx * my; cv[0][2] = a[5] / m - mx * mz;
@@ -643,100 +1293,196 @@ __device__ void fit_final(const ChainDev &C, int k, double (*s_red)[FIT_COLS]) {
     int mi = 0;
     for (int i = 1; i < 3; ++i) if (fabs(ev[i]) < fabs(ev[mi])) mi = i;
     const float n[3] = {(float)vec[0][mi], (float)vec[1][mi], (float)vec[2][mi]};
-    st->n[0] = n[0]; st->n[1] = n[1]; st->n[2] = n[2];
-    st->pos[0] = (float)mx; st->pos[1] = (float)my; st->pos[2] = (float)mz;
-    float dist = st->pos[0] * n[0];   // Plane(p1, normal): m_dist = m_pos.dot(m_normal) (Plane.cpp:21-26)
-    dist += st->pos[1] * n[1];
-    dist += st->pos[2] * n[2];
-    st->dist = dist;
-    hcs_axes(st->n, st->a0, st->a1);
-    *plane_out = make_float4(n[0], n[1], n[2], dist);
-    st->converged = (n[0] == cur->n[0] && n[1] == cur->n[1] && n[2] == cur->n[2] && dist == cur->dist &&
-                     st->pos[0] == cur->pos[0] && st->pos[1] == cur->pos[1] && st->pos[2] == cur->pos[2]) ? 1u : 0u;
-}
-
-__global__ __launch_bounds__(256) void k_fit_final(const ChainTab chains, int k) {
-    __shared__ double s_red[4][FIT_COLS];
-    const ChainDev &C = chains.c[blockIdx.x];
-    fit_final(C, k, s_red);
-    if (k == 3) {   // last slot: skipped slots repeat their predecessor
-        __syncthreads();
-        wscore_final(C);
-    }
-}
-
-// point removal + output index lists of all accepted candidates of a batch in one launch (job = blockIdx.y)
-struct AssignJobs {
-    const uint32_t *idx[16];
-    uint32_t m[16];
-    int32_t id[16];
-    int32_t *out[16];   // nullptr: support below min_support, points are removed but no plane is reported
-};
-__global__ void k_assign_batch(AssignJobs jobs, const uint32_t *__restrict__ orig, int32_t *__restrict__ assigned) {
-    const uint32_t j = blockIdx.y, m = jobs.m[j];
-    const uint32_t *__restrict__ idx = jobs.idx[j];
-    int32_t *__restrict__ out = jobs.out[j];
-    const int32_t id = jobs.id[j];
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
-        const uint32_t p = idx[i];
-        assigned[p] = id;
-        if (out) out[i] = (int32_t)orig[p];
-    }
-}
-
-__global__ void k_fill_i32(int32_t *p, uint32_t n, int32_t v) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = v;
+    nxt->n[0] = n[0]; nxt->n[1] = n[1]; nxt->n[2] = n[2];
+    nxt->pos[0] = (float)mx; nxt->pos[1] = (float)my; nxt->pos[2] = (float)mz;
+    float dist = nxt->pos[0] * n[0];   // Plane(p1, normal): m_dist = m_pos.dot(m_normal) (Plane.cpp:21-26)
+    dist += nxt->pos[1] * n[1];
+    dist += nxt->pos[2] * n[2];
+    nxt->dist = dist;
+    hcs_axes(nxt->n, nxt->a0, nxt->a1);
+    nxt->converged = (n[0] == cur->n[0] && n[1] == cur->n[1] && n[2] == cur->n[2] && dist == cur->dist &&
+                      nxt->pos[0] == cur->pos[0] && nxt->pos[1] == cur->pos[1] && nxt->pos[2] == cur->pos[2]) ? 1u : 0u;
 }
 
 // ------------------------------------------------------------------------------------------------
-// One acceptance chain: everything the reference's per-candidate sequence touches.  Several candidates
-// whose supports provably cannot overlap are accepted together: every kernel of the sequence is
-// launched once for the whole batch (chain = blockIdx.y), the scoring pass reads the cloud once.
-struct Chain {
-    DBuf<float4> plane_cur;
-    CompactScratch cs, cs2;
-    DBuf<uint32_t> idxA, cntA;       // score(3 eps) list before the connected component
-    DBuf<uint32_t> idxS[4];          // per-slot result lists
-    DBuf<float2> uv;
-    DBuf<uint32_t> bidx, label, sizes;
-    DBuf<uint8_t> bmp, tmp;
-    DBuf<double> part;
-    DBuf<float> bbpart;
+// After the four slots: replay of the reference's refit loop on the four results of every chain, removal
+// bookkeeping (RansacShapeDetector.cpp:666-675), output planes (plane_extraction.cpp:134-149), the pool without
+// the batch, and what the next iteration does.  One lane per cloud does the sequential part.
+__global__ __launch_bounds__(64) void k_r_decide(const RArgs A) {
+    const RCloudArgs &C = A.c[blockIdx.x];
+    RState *S = C.st;
+    if (threadIdx.x) return;
+    RResult *R = C.res;
+    if (!S->active) return;
+    const uint32_t nc = S->done ? 0u : S->nc;
+    uint32_t n_aj = 0;
+    for (uint32_t b = 0; b < nc; ++b) {
+        const ChainPtr ch = chain_of(C, b);
+        const PlaneState *st = ch.hdr->st;
+        S->n_accepts += 1;
+        if (st[0].err == 1) { S->err = 1; S->done = 1; break; }   // connected-component bitmap too large
+        int final_slot = 0;
+        {
+            double newScore = st[0].wscore;
+            for (int fittingIter = 1; fittingIter <= 3; ++fittingIter) {
+                const double oldScore = newScore;
+                if (st[fittingIter - 1].n_kept < 3 || st[fittingIter].err) break;   // LSFit impossible
+                newScore = st[fittingIter].wscore;
+                const uint32_t newSize = st[fittingIter].n_kept;
+                if (newScore > oldScore && newSize > S->min_support) final_slot = fittingIter;  // clone.Clone(&candidates.back())
+                if (!(newScore > oldScore)) break;
+            }
+        }
+        const PlaneState &cs = st[final_slot];
+        const uint32_t cand_size = cs.n_kept;
+        if (cand_size == 0) continue;
+        if (S->n_acc >= R_MAXP) { S->err = 3; S->done = 1; break; }
+        const uint32_t id = S->n_acc;
+        S->aj_chain[n_aj] = b; S->aj_slot[n_aj] = (uint32_t)final_slot; S->aj_id[n_aj] = (int32_t)id; S->aj_out[n_aj] = 0xffffffffu;
+        const float frac = 1.f - (cand_size / float(S->n_remaining));
+        S->drawn = frac * frac * frac * S->drawn;    // std::pow(1.f - |S| / n, 3.f) * drawnCandidates
+        S->n_remaining -= min(S->n_remaining, cand_size);
+        // plane_extraction.cpp:134-149: shapes below min_support are skipped, d = -n.p with n re-normalised
+        R->support[id] = 0;
+        R->offset[id] = S->out_off;
+        if (cand_size >= S->min_support) {
+            float nn[3] = {cs.n[0], cs.n[1], cs.n[2]};
+            float l = nn[0] * nn[0];
+            l += nn[1] * nn[1];
+            l += nn[2] * nn[2];
+            l = sqrtf(l);
+            if (l > 0) { nn[0] /= l; nn[1] /= l; nn[2] /= l; }
+            float d = -(nn[0] * cs.pos[0] + nn[1] * cs.pos[1] + nn[2] * cs.pos[2]);
+            if (S->orient) {  // mean inlier normal (the intent of plane_extraction.cpp:43-58)
+                if (cs.nsum[0] * nn[0] + cs.nsum[1] * nn[1] + cs.nsum[2] * nn[2] < 0) { nn[0] = -nn[0]; nn[1] = -nn[1]; nn[2] = -nn[2]; d = -d; }
+            }
+            R->coef[id][0] = nn[0]; R->coef[id][1] = nn[1]; R->coef[id][2] = nn[2]; R->coef[id][3] = d;
+            R->support[id] = cand_size;
+            S->aj_out[n_aj] = S->out_off;
+            S->out_off += cand_size;
+        }
+        S->n_acc = id + 1;
+        ++n_aj;
+    }
+    S->aj_n = n_aj;
+    if (nc) {
+        // drop the batch from the pool (batch indices are ascending), order kept
+        uint32_t w = 0, bq = 0;
+        const uint32_t np = S->npool;
+        for (uint32_t i = 0; i < np; ++i) {
+            if (bq < nc && S->batch_idx[bq] == i) { ++bq; continue; }
+            if (w != i) { S->pool_pl[w] = S->pool_pl[i]; S->pool_pos[w] = S->pool_pos[i]; }
+            ++w;
+        }
+        S->npool = w;
+        S->nc = 0;
+        if (!S->done) {
+            if (S->n_remaining < S->min_support) S->npool = 0;
+            if (S->npool == 0) next_round_or_stop(S);
+        }
+    }
+    S->it += 1;
+    R->n_acc = S->n_acc; R->out_off = S->out_off; R->err = S->err; R->remaining = S->n_remaining;
+    R->n_rounds = S->n_rounds; R->n_rescores = S->n_rescores; R->n_batches = S->n_batches; R->n_accepts = S->n_accepts;
+    R->n_mark_launches = S->n_mark_launches; R->n_mark_chains = S->n_mark_chains;
+    __threadfence_system();
+    *reinterpret_cast<volatile uint32_t *>(&R->flag) = S->it | (S->done ? 0x80000000u : 0u);
+}
+
+// Point removal + output index lists of the accepted candidates: the chosen slot's list entries that belong to the
+// largest component, in list order (ordered compaction of the selection masks; offsets from the per-tile counts as in
+// k_r_compact_raster).  grid (tiles, jobs of all clouds)
+__global__ __launch_bounds__(TPB) void k_r_assign(const RArgs A) {
+    __shared__ uint32_t s_pre[TPB / 64], s_w[TPB / 64];
+    const int g = blockIdx.y / R_B;
+    const uint32_t j = blockIdx.y % R_B;
+    if (g >= (int)A.ng) return;
+    const RCloudArgs &C = A.c[g];
+    if (blockIdx.x >= C.L.nb) return;
+    const RState *S = C.st;
+    if (j >= S->aj_n) return;
+    const int k = (int)S->aj_slot[j];
+    const ChainPtr ch = chain_of(C, S->aj_chain[j]);
+    const uint32_t m = ch.hdr->st[k].n_list;
+    if (blockIdx.x * 1024u >= m) return;
+    const int32_t id = S->aj_id[j];
+    const uint32_t out_off = S->aj_out[j];
+    const uint32_t *__restrict__ bc = ch.bc2(k);
+    const uint32_t mine = bc[blockIdx.x];
+    const uint32_t mk = ch.masks2(k)[blockIdx.x * TPB + threadIdx.x];
+    if (mine == 0) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t pre = 0;
+    for (uint32_t q = threadIdx.x; q < blockIdx.x; q += TPB) pre += bc[q];
+    const uint32_t base = blockIdx.x * 1024 + threadIdx.x * 4;
+    const uint32_t *__restrict__ idx = ch.idxA(k);
+    uint32_t p[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) p[q] = (mk & (1u << q)) ? idx[base + q] : 0u;
+    for (int d = 32; d >= 1; d >>= 1) pre += __shfl_xor(pre, d, 64);
+    const uint32_t c = __popc(mk);
+    uint32_t incl = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += o;
+    }
+    if (lane == 0) s_pre[wave] = pre;
+    if (lane == 63) s_w[wave] = incl;
+    __syncthreads();
+    uint32_t off = s_pre[0] + s_pre[1] + s_pre[2] + s_pre[3] + incl - c;
+    for (int w = 0; w < wave; ++w) off += s_w[w];
+    int32_t *__restrict__ out = out_off == 0xffffffffu ? nullptr : C.out_idx + out_off;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        if (mk & (1u << q)) {
+            if (C.assigned) C.assigned[p[q]] = id;
+            if (out) out[off] = (int32_t)(C.orig ? C.orig[p[q]] : p[q]);
+            ++off;
+        }
+}
+
+// seam S1c: one chain, slot 0, from a caller-given plane
+__global__ void k_r_seam_init(const RArgs A, float4 hyp, float4 pos, float w_eps, float bitmap_eps) {
+    if (threadIdx.x) return;
+    const RCloudArgs &C = A.c[0];
+    RState *S = C.st;
+    S->n = C.cv.n; S->active = 1; S->done = 0; S->sampling = 0; S->nc = 1; S->npool = 0;
+    S->eps3 = w_eps; S->bitmap_eps = bitmap_eps; S->min_support = 0; S->orient = 0; S->err = 0;
+    S->aj_n = 1; S->aj_chain[0] = 0; S->aj_slot[0] = 0; S->aj_id[0] = 0; S->aj_out[0] = 0;
+    S->n_mark_launches = S->n_mark_chains = 0;
+    ChainPtr ch = chain_of(C, 0);
+    ch.hdr->cand[0] = hyp; ch.hdr->cand[1] = pos;
+    state_from_hyp(&ch.hdr->st[0], hyp, pos);
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// host side
+struct RansacSlot {
+    uint32_t n = 0;
+    const CloudDev *cloud = nullptr;
+    CloudDev sorted;
+    DBuf<uint32_t> codes, orig, sub_index;
+    DBuf<int32_t> assigned, out_idx;
+    DBuf<float> sub;
+    uint32_t sub_pitch = 0, n_sub = 0;
+    DBuf<char> round_block;          // hypotheses / positions / counts of the current round
+    DBuf<char> fixed, var;           // the chains' slabs
+    DBuf<RState> state;
+    RResult *res = nullptr, *res_dev = nullptr;   // host-mapped result block
+    ChainLayout L{};
+    DBuf<uint32_t> seam_list;
+    ~RansacSlot() { if (res) (void)hipHostFree(res); }
 };
 
-constexpr size_t ACCEPT_BYTES = 4 * sizeof(PlaneState) + 16 + 48;   // states, counts, normal sums
-constexpr size_t ACCEPT_STRIDE = (ACCEPT_BYTES + 63) & ~(size_t)63;
-
-struct PairAccept;
 struct RansacWork {
-    CloudDev sorted;
-    DBuf<uint32_t> codes, codes_in, vals_in, orig;
-    DBuf<int32_t> assigned;
-    DBuf<float> sub;
-    size_t sub_pitch = 0;
-    DBuf<uint32_t> sub_index;
-    uint32_t n_sub = 0;
-    DBuf<char> round_block;          // contiguous hypotheses / positions / counts: one D2H per round
-    float4 *hyp = nullptr, *hyp_pos = nullptr;
-    uint32_t *hyp_counts = nullptr, *misc = nullptr;
-    DBuf<float4> top;
-    DBuf<int32_t> out_idx;
-    HBuf<char> pinned;
-    // acceptance chains
-    std::vector<std::unique_ptr<Chain>> chains;
-    DBuf<char> accept_block;         // B x ACCEPT_STRIDE: one D2H copy per batch
-    DBuf<float4> cand_in;            // B x (hypothesis, position): one H2D copy per batch
-    std::vector<ChainDev> h_tab;     // the chains' device pointers (host copy; batches pass them by value)
-    std::vector<MarkJob> mark_jobs;      // [slot][chain]   (host; launches copy one slot's row into the kernargs)
-    std::vector<CompactJob> compact_jobs;   // [slot][A|S][chain]
-    HBuf<char> pinned_accept;
-    uint32_t B = 0;
-    std::vector<uint64_t> tab_key;
-    uint64_t tab_hash = 0;           // changes whenever a pointer of the tables moves (keys the captured graphs)
-    PairAccept *solo = nullptr;      // runs this work area's batches when no pair coordinator is given
-    hipEvent_t ev_ready = nullptr;
-    ~RansacWork();
+    RansacSlot slot[R_G];
+    int ng = 0;
+    DBuf<uint32_t> keys_in, vals_in, keys, perm;
+    std::map<uint64_t, hipGraphExec_t> graphs;   // the iteration sequence, keyed on everything baked into its launches
+    ~RansacWork() { for (auto &kv : graphs) if (kv.second) (void)hipGraphExecDestroy(kv.second); }
 };
 
 RansacWork *ransac_work_create() { return new RansacWork; }
@@ -744,284 +1490,302 @@ void ransac_work_destroy(RansacWork *w) { delete w; }
 
 namespace {
 
-struct Accepted {
-    float coef[4];
-    uint32_t support;
-    uint32_t offset;   // into out_idx
-};
+void slot_buffers(plade_ctx *ctx, RansacSlot &s, uint32_t n) {
+    s.n = n;
+    s.L = make_layout(n);
+    if (s.fixed.cap < (size_t)R_B * F_BYTES) {   // fresh bitmaps must be all-zero
+        s.fixed.ensure((size_t)R_B * F_BYTES);
+        HIP_TRY(hipMemsetAsync(s.fixed.p, 0, s.fixed.cap, ctx->stream));
+    }
+    s.var.ensure((size_t)R_B * s.L.bytes);
+    s.state.ensure(1);
+    s.round_block.ensure((size_t)R_H * 36 + 64);
+    s.out_idx.ensure((size_t)n + 4);
+    s.assigned.ensure((size_t)n + 8);
+    if (!s.res) {
+        HIP_TRY(hipHostMalloc((void **)&s.res, sizeof(RResult), hipHostMallocMapped | hipHostMallocCoherent));
+        memset(s.res, 0, sizeof(RResult));
+        HIP_TRY(hipHostGetDevicePointer((void **)&s.res_dev, s.res, 0));
+    }
+}
 
-// One cloud's share of an acceptance batch.
-struct AcceptSide {
-    RansacWork *W = nullptr;
-    uint32_t nc = 0;              // chains of this cloud in the batch
-    CloudView cv{};               // the Morton-ordered cloud
-    const int32_t *assigned = nullptr;
-    float eps3 = 0.f, cos_t = 0.f, bitmap_eps = 0.f;
-    hipEvent_t ready = nullptr;   // recorded on the owner's stream after it queued the batch's inputs
-};
+RArgs make_args(RansacWork &W, int ng) {
+    RArgs A;
+    memset(&A, 0, sizeof(A));
+    A.ng = (uint32_t)ng;
+    for (int g = 0; g < R_G; ++g) {
+        RansacSlot &s = W.slot[g < ng ? g : 0];
+        RCloudArgs &C = A.c[g];
+        const CloudDev &c = s.sorted;
+        // field by field: the bytes of this struct key the captured graphs, padding included (A was zeroed)
+        C.cv.x = c.x(); C.cv.y = c.y(); C.cv.z = c.z(); C.cv.nx = c.nx(); C.cv.ny = c.ny(); C.cv.nz = c.nz(); C.cv.n = s.n;
+        C.codes = s.codes.p; C.orig = s.orig.p; C.assigned = s.assigned.p;
+        C.sub = s.sub.p; C.sub_index = s.sub_index.p; C.sub_pitch = s.sub_pitch; C.n_sub = s.n_sub;
+        C.st = s.state.p; C.res = s.res_dev;
+        C.hyp = reinterpret_cast<float4 *>(s.round_block.p);
+        C.hyp_pos = C.hyp + R_H;
+        C.hyp_counts = reinterpret_cast<uint32_t *>(C.hyp_pos + R_H);
+        C.out_idx = s.out_idx.p;
+        C.fixed = s.fixed.p; C.var = s.var.p;
+        C.list_values = nullptr;
+        memcpy(&C.L, &s.L, sizeof(ChainLayout));
+    }
+    A.tiles0 = A.c[0].L.nb;
+    return A;
+}
 
-// The whole per-candidate sequence of RansacShapeDetector.cpp:618-656 for the chains of one or two clouds x four
-// slots, no host round trip: slot 0 = the candidate (GlobalScore(3 eps) + ConnectedComponent; its clone's first
-// GlobalWeightedScore is the same computation), slot k = k-th LS refit of slot k-1's points.  Per slot:
-// GlobalWeightedScore (Candidate.h:293-302) = score(3 eps) -> ConnectedComponent -> weighted score,
-// then the LS fit of the result list.
-void enqueue_accept(plade_ctx *ctx, const AcceptSide *sides, int ns) {
+uint64_t hash_bytes(const void *p, size_t n) {
+    uint64_t h = 1469598103934665603ull;
+    const unsigned char *b = static_cast<const unsigned char *>(p);
+    for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; }
+    return h;
+}
+
+// one iteration of the detect loop: 27 launches
+void enqueue_iteration(plade_ctx *ctx, const RArgs &A) {
     hipStream_t st = ctx->stream;
-    ChainTab tab;
-    uint32_t nc = 0, nb4_max = 0;
-    for (int i = 0; i < ns; ++i) {
-        const AcceptSide &S = sides[i];
-        for (uint32_t b = 0; b < S.nc; ++b) tab.c[nc + b] = S.W->h_tab[b];
-        tab.g[i] = ChainGroup{S.cv, S.eps3, S.bitmap_eps, cdiv(S.cv.n, 1024)};
-        nb4_max = std::max(nb4_max, cdiv(S.cv.n, 1024));
-        nc += S.nc;
+    const uint32_t ng = A.ng;
+    uint32_t tiles = 0, nb_max = 0, sub_tiles = 0;
+    for (uint32_t g = 0; g < ng; ++g) {
+        tiles += A.c[g].L.nb;
+        nb_max = std::max(nb_max, A.c[g].L.nb);
+        sub_tiles = std::max(sub_tiles, cdiv(A.c[g].n_sub, TILE));
     }
-    PLADE_REQUIRE(nc >= 1 && nc <= (uint32_t)CHAIN_MAX, PLADE_EINVAL, "ransac: batch size");
-    for (uint32_t b = nc; b < (uint32_t)CHAIN_MAX; ++b) tab.c[b] = tab.c[0];
-    if (ns == 1) tab.g[1] = tab.g[0];
-    tab.split = sides[0].nc;
-    hipLaunchKernelGGL(k_state_from_hyp, dim3(nc), dim3(64), 0, st, tab);
-    std::vector<MarkJob> mj(nc);
-    std::vector<CompactJob> cj(nc);
+    hipLaunchKernelGGL(k_r_sample, dim3(cdiv(R_H, 256), ng), dim3(256), 0, st, A);
+    hipLaunchKernelGGL(k_r_score_sub, dim3(sub_tiles, R_H / HCHUNK, ng), dim3(TPB), 0, st, A);
+    hipLaunchKernelGGL(k_r_leaders, dim3(ng), dim3(1024), 0, st, A);
+    ctx->ev_begin("score_multi", 0.0);
+    hipLaunchKernelGGL(k_r_rescore, dim3(tiles), dim3(TPB), 0, st, A);
+    ctx->ev_end();
+    hipLaunchKernelGGL(k_r_select, dim3(ng), dim3(64), 0, st, A);
     for (int k = 0; k < 4; ++k) {
-        ScanGroup groups[2];
-        uint32_t o = 0;
-        for (int i = 0; i < ns; ++i) {
-            const AcceptSide &S = sides[i];
-            for (uint32_t b = 0; b < S.nc; ++b) mj[o + b] = S.W->mark_jobs[(size_t)k * S.W->B + b];
-            groups[i] = ScanGroup{S.cv.x, S.cv.y, S.cv.z, S.cv.nx, S.cv.ny, S.cv.nz, S.assigned, S.cv.n, 0, 0, S.nc, S.eps3, S.cos_t};
-            o += S.nc;
-        }
-        score_mark_batch(ctx, st, mj.data(), groups, (uint32_t)ns);
-        for (int ab = 0; ab < 2; ++ab) {
-            if (ab == 1) {
-                hipLaunchKernelGGL(k_cc_raster, dim3(128, nc), dim3(256), 0, st, tab, k);
-                hipLaunchKernelGGL(k_cc_label, dim3(nc), dim3(1024), 0, st, tab, k, 1);
-                hipLaunchKernelGGL(k_cc_select, dim3(nb4_max, nc), dim3(256), 0, st, tab, k);
-            }
-            o = 0;
-            for (int i = 0; i < ns; ++i) {
-                const AcceptSide &S = sides[i];
-                for (uint32_t b = 0; b < S.nc; ++b) cj[o + b] = S.W->compact_jobs[(size_t)(2 * k + ab) * S.W->B + b];
-                o += S.nc;
-            }
-            compact_batch(ctx, st, cj.data(), nc);
-        }
-        hipLaunchKernelGGL(k_fit_final, dim3(nc), dim3(256), 0, st, tab, k);
+        ctx->ev_begin("score_mark", 0.0);
+        hipLaunchKernelGGL(k_r_mark, dim3(tiles), dim3(TPB), 0, st, A, k);
+        ctx->ev_end();
+        hipLaunchKernelGGL(k_r_compact_raster, dim3(nb_max, R_B * ng), dim3(TPB), 0, st, A, k);
+        hipLaunchKernelGGL(k_r_label, dim3(R_B * ng), dim3(1024), 0, st, A, k, 1);
+        hipLaunchKernelGGL(k_r_select_cc, dim3(nb_max, R_B * ng), dim3(TPB), 0, st, A, k);
+        hipLaunchKernelGGL(k_r_fit, dim3(R_B * ng), dim3(256), 0, st, A, k);
     }
+    hipLaunchKernelGGL(k_r_decide, dim3(ng), dim3(64), 0, st, A);
+    hipLaunchKernelGGL(k_r_assign, dim3(nb_max, R_B * ng), dim3(TPB), 0, st, A);
 }
 
-void chains_prepare(plade_ctx *ctx, RansacWork &W, uint32_t B, uint32_t n, float eps3, float cos_t, float bitmap_eps) {
-    PLADE_REQUIRE(B >= 1 && B <= (uint32_t)CHAIN_MAX, PLADE_EINVAL, "ransac: batch size");
-    W.B = B;
-    while (W.chains.size() < B) W.chains.emplace_back(new Chain);
-    char *ab = W.accept_block.ensure(B * ACCEPT_STRIDE);
-    W.cand_in.ensure(2 * B);
-    W.pinned_accept.ensure(B * ACCEPT_STRIDE + 64);
-    std::vector<ChainDev> tab(B);
-    std::vector<MarkJob> mj(4 * (size_t)B);
-    std::vector<CompactJob> cj(8 * (size_t)B);
-    const uint32_t nb4 = cdiv(n, 1024);
-    bool fresh_bitmap = false;
-    for (uint32_t b = 0; b < B; ++b) {
-        Chain &C = *W.chains[b];
-        ChainDev &D = tab[b];
-        char *base = ab + b * ACCEPT_STRIDE;
-        D.st = reinterpret_cast<PlaneState *>(base);
-        D.cntS = reinterpret_cast<uint32_t *>(base + 4 * sizeof(PlaneState));
-        D.nsum = reinterpret_cast<float *>(base + 4 * sizeof(PlaneState) + 16);
-        D.top = W.cand_in.p + 2 * b;
-        D.plane_cur = C.plane_cur.ensure(4);
-        D.idxA = C.idxA.ensure((size_t)n + 4);
-        D.cntA = C.cntA.ensure(8);
-        for (int k = 0; k < 4; ++k) D.idxS[k] = C.idxS[k].ensure((size_t)n + 4);
-        D.uv = C.uv.ensure((size_t)n + 4);
-        D.bidx = C.bidx.ensure((size_t)n + 4);
-        fresh_bitmap = fresh_bitmap || C.bmp.cap < CC_MAXPIX;
-        const bool fresh = C.bmp.cap < CC_MAXPIX;
-        D.label = C.label.ensure(CC_MAXPIX); D.sizes = C.sizes.ensure(CC_MAXPIX);
-        D.bmp = C.bmp.ensure(CC_MAXPIX); D.tmp = C.tmp.ensure(CC_MAXPIX);
-        if (fresh) HIP_TRY(hipMemsetAsync(C.bmp.p, 0, C.bmp.cap, ctx->stream));
-        D.part = C.part.ensure((size_t)nb4 * FIT_COLS + 16);
-        C.cs.masks.ensure((size_t)nb4 * 256 + 16); C.cs.block_counts.ensure(nb4 + 4);
-        D.bcA = C.cs.block_counts.p;
-        D.bbpart = C.bbpart.ensure(4 * (size_t)nb4 + 16);
-        D.masks2 = C.cs2.masks.ensure((size_t)nb4 * 256 + 16);
-        D.bc2 = C.cs2.block_counts.ensure(nb4 + 4);
-        for (int k = 0; k < 4; ++k) {
-            const uint32_t *skip = &D.st[k].converged;
-            mj[(size_t)k * B + b] = MarkJob{D.plane_cur + k, C.cs.masks.p, C.cs.block_counts.p, skip};
-            // score list + its (u, v) parameters in slot k's plane frame (PlaneState: pos, dist, a0, a1, bb)
-            const CloudDev &sc = W.sorted;
-            cj[(size_t)(2 * k) * B + b] = CompactJob{C.cs.masks.p, C.cs.block_counts.p, nullptr, D.idxA, D.cntA, skip,
-                                                     D.st[k].pos, D.uv, D.bbpart, nb4, sc.x(), sc.y(), sc.z()};
-            cj[(size_t)(2 * k + 1) * B + b] = CompactJob{D.masks2, D.bc2, D.idxA, D.idxS[k], D.cntS + k, skip, nullptr, nullptr, nullptr,
-                                                         nb4, nullptr, nullptr, nullptr};
+void launch_iteration(plade_ctx *ctx, RansacWork &W, const RArgs &A) {
+    if (ctx->profiling() || getenv("PLADE_NO_GRAPH")) { enqueue_iteration(ctx, A); HIP_TRY(hipGetLastError()); return; }
+    const uint64_t key = hash_bytes(&A, sizeof(A));
+    auto it = W.graphs.find(key);
+    if (it == W.graphs.end()) {
+        if (W.graphs.size() > 64) {   // bounded cache (a batch of differently sized clouds)
+            for (auto &kv : W.graphs) if (kv.second) (void)hipGraphExecDestroy(kv.second);
+            W.graphs.clear();
         }
+        hipGraph_t graph = nullptr;
+        HIP_TRY(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+        try { enqueue_iteration(ctx, A); }
+        catch (...) { (void)hipStreamEndCapture(ctx->stream, &graph); if (graph) (void)hipGraphDestroy(graph); throw; }
+        HIP_TRY(hipStreamEndCapture(ctx->stream, &graph));
+        hipGraphExec_t e = nullptr;
+        HIP_TRY(hipGraphInstantiate(&e, graph, nullptr, nullptr, 0));
+        (void)hipGraphDestroy(graph);
+        it = W.graphs.emplace(key, e).first;
     }
-    // (re)upload the tables only when a pointer moved
-    std::vector<uint64_t> key;
-    key.reserve(tab.size() * sizeof(ChainDev) / 8 + 8);
-    for (const ChainDev &D : tab) {
-        const uint64_t *w = reinterpret_cast<const uint64_t *>(&D);
-        key.insert(key.end(), w, w + sizeof(ChainDev) / 8);
+    HIP_TRY(hipGraphLaunch(it->second, ctx->stream));
+}
+
+// Waits until every listed result block reports at least `want` completed iterations (or the end of its detect call).
+// The blocks are host-mapped and written by the device while the stream keeps running; should a flag not become visible
+// (it always has), the stream running dry ends the wait: everything is visible then.
+void wait_iterations(plade_ctx *ctx, RResult *const *res, int nres, uint32_t want) {
+    auto reached = [&]() {
+        for (int i = 0; i < nres; ++i) {
+            const uint32_t f = *reinterpret_cast<volatile uint32_t *>(&res[i]->flag);
+            if (!(f & 0x80000000u) && (f & 0x7fffffffu) < want) return false;
+        }
+        return true;
+    };
+    if (ctx->params.host_wait != 0) relax_timer_slack();
+    for (uint32_t polls = 0;; ++polls) {
+        if (reached()) break;
+        if ((polls & 63u) == 63u || ctx->params.host_wait != 0) {
+            const hipError_t e = hipStreamQuery(ctx->stream);
+            if (e == hipSuccess) { if (reached()) break; throw Err{PLADE_EDEVICE, "plane extraction: the device loop did not report"}; }
+            if (e != hipErrorNotReady) throw Err{PLADE_EDEVICE, std::string("hipStreamQuery: ") + hipGetErrorString(e)};
+        }
+        if (ctx->params.host_wait != 0) { timespec ts{0, polls < 8 ? 15000 : 40000}; nanosleep(&ts, nullptr); }
     }
-    {   // ... and every pointer of the job tables
-        const uint64_t *w = reinterpret_cast<const uint64_t *>(mj.data());
-        key.insert(key.end(), w, w + mj.size() * sizeof(MarkJob) / 8);
-        w = reinterpret_cast<const uint64_t *>(cj.data());
-        key.insert(key.end(), w, w + cj.size() * sizeof(CompactJob) / 8);
-    }
-    W.h_tab = tab;
-    W.mark_jobs = mj;
-    W.compact_jobs = cj;
-    if (key != W.tab_key) {   // the tables are baked into the captured launches' arguments
-        W.tab_key = key;
-        uint64_t h = 1469598103934665603ull;
-        for (uint64_t w : key) { h ^= w; h *= 1099511628211ull; }
-        W.tab_hash = h;
-    }
-    (void)ctx; (void)eps3; (void)cos_t; (void)bitmap_eps; (void)fresh_bitmap;
+    std::atomic_thread_fence(std::memory_order_acquire);
 }
 
 }  // namespace
 
-// Runs acceptance batches.  With two participants (the target's and the source's extraction threads of one
-// registration) the two clouds' batches are merged: every kernel of the 29-launch sequence is latency-bound, so
-// one sequence serving the chains of both clouds costs little more than one cloud's and the registration issues
-// half as many of them.  A thread that reaches its next batch waits for the other one (or for it to finish its
-// extraction); whoever arrives last launches for both on its own stream and wakes the other when the GPU is done.
-struct PairAccept {
-    std::mutex m;
-    std::condition_variable cv;
-    int participants = 0, waiting = 0;
-    uint64_t generation = 0;
-    AcceptSide side[2];
-    bool present[2] = {false, false};
-    Err err{0, ""};
-    std::map<uint64_t, hipGraphExec_t> graphs;   // keyed on everything baked into the captured launches
-    ~PairAccept() { for (auto &kv : graphs) if (kv.second) (void)hipGraphExecDestroy(kv.second); }
-
-    void join() { std::lock_guard<std::mutex> lk(m); ++participants; }
-    void leave() { { std::lock_guard<std::mutex> lk(m); --participants; } cv.notify_all(); }
-
-    static uint64_t mix(uint64_t h, uint64_t v) { h ^= v; h *= 1099511628211ull; return h; }
-    static uint64_t fbits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
-
-    void run(plade_ctx *ctx, const AcceptSide *sides, int ns) {
-        if (ctx->profiling() || getenv("PLADE_NO_GRAPH")) { enqueue_accept(ctx, sides, ns); return; }
-        uint64_t key = 1469598103934665603ull;
-        for (int i = 0; i < ns; ++i) {
-            const AcceptSide &S = sides[i];
-            key = mix(key, S.W->tab_hash); key = mix(key, S.nc); key = mix(key, S.cv.n); key = mix(key, (uint64_t)S.cv.x);
-            key = mix(key, (uint64_t)S.assigned); key = mix(key, fbits(S.eps3)); key = mix(key, fbits(S.cos_t));
-            key = mix(key, fbits(S.bitmap_eps)); key = mix(key, (uint64_t)S.W);
-        }
-        hipGraphExec_t &g = graphs[key];
-        if (!g) {
-            if (graphs.size() > 96) {   // bounded cache (a batch of differently sized clouds)
-                for (auto &kv : graphs) if (kv.second) (void)hipGraphExecDestroy(kv.second);
-                graphs.clear();
-            }
-            hipGraph_t graph = nullptr;
-            HIP_TRY(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
-            try { enqueue_accept(ctx, sides, ns); }
-            catch (...) { (void)hipStreamEndCapture(ctx->stream, &graph); if (graph) (void)hipGraphDestroy(graph); throw; }
-            HIP_TRY(hipStreamEndCapture(ctx->stream, &graph));
-            hipGraphExec_t e = nullptr;
-            HIP_TRY(hipGraphInstantiate(&e, graph, nullptr, nullptr, 0));
-            (void)hipGraphDestroy(graph);
-            graphs[key] = e;
-            HIP_TRY(hipGraphLaunch(e, ctx->stream));
-            return;
-        }
-        HIP_TRY(hipGraphLaunch(g, ctx->stream));
+void ransac_prepare(plade_ctx *ctx, RansacWork &W, const CloudDev *const clouds[RANSAC_SLOTS], int n_clouds) {
+    PLADE_REQUIRE(n_clouds >= 1 && n_clouds <= R_G, PLADE_EINVAL, "ransac: one or two clouds");
+    W.ng = n_clouds;
+    MortonArgs M;
+    GatherArgs G;
+    memset(&M, 0, sizeof(M));
+    memset(&G, 0, sizeof(G));
+    M.ng = G.ng = (uint32_t)n_clouds;
+    uint64_t total = 0;
+    for (int g = 0; g < n_clouds; ++g) {
+        const CloudDev &c = *clouds[g];
+        RansacSlot &s = W.slot[g];
+        s.cloud = clouds[g];
+        slot_buffers(ctx, s, c.n);
+        total += c.n;
+        const float cube = std::max({c.bbmax[0] - c.bbmin[0], c.bbmax[1] - c.bbmin[1], c.bbmax[2] - c.bbmin[2], 1e-30f});
+        M.c[g] = MortonIn{c.x(), c.y(), c.z(), c.n, c.bbmin[0], c.bbmin[1], c.bbmin[2], 1.f / cube};
+        s.sorted.n = c.n;
+        s.sorted.pitch = c.pitch;
+        s.sorted.soa.ensure(6 * c.pitch + 4);
+        for (int k = 0; k < 3; ++k) { s.sorted.bbmin[k] = c.bbmin[k]; s.sorted.bbmax[k] = c.bbmax[k]; }
+        s.codes.ensure((size_t)c.n + 4); s.orig.ensure((size_t)c.n + 4);
+        // stratified subset: every stride-th point of the Morton order
+        const uint32_t stride = std::max(1u, c.n / 16384u);
+        s.n_sub = c.n ? (c.n + stride - 1) / stride : 0;
+        s.sub_pitch = (s.n_sub + 3) & ~3u;
+        s.sub.ensure(6 * (size_t)s.sub_pitch + 4);
+        s.sub_index.ensure((size_t)s.sub_pitch + 4);
+        G.c[g] = GatherOut{c.aos.p, s.sorted.soa.p, (uint32_t)c.pitch, s.codes.p, s.orig.p, s.assigned.p, s.sub.p, s.sub_pitch, s.n_sub,
+                           stride, s.sub_index.p, c.n};
     }
-
-    // `who`: 0 = target, 1 = source.  Returns when the chains of `s` have run (the launching thread has waited for
-    // the GPU); everything the caller queued for them on its own stream must have completed before the call.
-    void submit(int who, plade_ctx *ctx, const AcceptSide &s) {
-        std::unique_lock<std::mutex> lk(m);
-        side[who] = s;
-        present[who] = true;
-        ++waiting;
-        const uint64_t gen = generation;
-        for (;;) {
-            if (generation != gen) break;
-            if (waiting >= participants) {   // everybody who is still extracting is here: launch for all
-                AcceptSide both[2];
-                int ns = 0;
-                for (int i = 0; i < 2; ++i) if (present[i]) both[ns++] = side[i];
-                err = Err{0, ""};
-                ctx->stats.add(ns == 2 ? "ransac_launches_merged" : "ransac_launches_single", 1);
-                try {
-                    for (int i = 0; i < ns; ++i)
-                        if (both[i].W != s.W && both[i].ready) HIP_TRY(hipStreamWaitEvent(ctx->stream, both[i].ready, 0));
-                    run(ctx, both, ns);
-                    for (int i = 0; i < ns; ++i)   // results of every cloud: one block per chain, into pinned memory
-                        HIP_TRY(hipMemcpyAsync(both[i].W->pinned_accept.p, both[i].W->accept_block.p, both[i].nc * ACCEPT_STRIDE,
-                                               hipMemcpyDeviceToHost, ctx->stream));
-                    ctx->sync();
-                }
-                catch (const Err &e) { err = e; }
-                catch (const std::exception &e) { err = Err{PLADE_EDEVICE, e.what()}; }
-                present[0] = present[1] = false;
-                waiting = 0;
-                ++generation;
-                cv.notify_all();
-                break;
-            }
-            cv.wait(lk);
-        }
-        if (err.code) throw err;
-    }
-};
-
-PairAccept *pair_accept_create() { return new PairAccept; }
-void pair_accept_destroy(PairAccept *p) { delete p; }
-RansacWork::~RansacWork() { delete solo; if (ev_ready) (void)hipEventDestroy(ev_ready); }
-
-namespace {
-
-inline bool same_plane(const float4 &a, const float4 &b, float eps) {
-    const float c = a.x * b.x + a.y * b.y + a.z * b.z;
-    if (std::fabs(c) < 0.995f) return false;
-    const float db = c >= 0 ? b.w : -b.w;
-    return std::fabs(a.w - db) < 2 * eps;
+    PLADE_REQUIRE(total < (1ull << 31), PLADE_ELIMIT, "ransac: too many points");
+    if (total == 0) return;
+    if (n_clouds == 1) { M.c[1] = M.c[0]; G.c[1] = G.c[0]; }
+    W.keys_in.ensure(total); W.vals_in.ensure(total); W.keys.ensure(total); W.perm.ensure(total);
+    hipLaunchKernelGGL(k_morton, dim3(cdiv(total, 256)), dim3(256), 0, ctx->stream, M, W.keys_in.p, W.vals_in.p);
+    sort_pairs_u32(ctx, W.keys_in.p, W.keys.p, W.vals_in.p, W.perm.p, total, n_clouds > 1 ? 25 : 24);
+    hipLaunchKernelGGL(k_gather_cloud, dim3(cdiv(total, 256)), dim3(256), 0, ctx->stream, G, W.keys.p, W.perm.p);
+    HIP_TRY(hipGetLastError());
 }
 
-// Can a point be an inlier (|dist| < 3 eps AND |n.n_p| >= cos_t) of both planes?  Provably not when
-//  (a) the normals are far apart: n_p within acos(cos_t) of both +-n_a and +-n_b needs
-//      angle(n_a, n_b) <= 2 acos(cos_t) (or its supplement); a 5 degree margin covers the refits; or
-//  (b) the planes are nearly parallel and, everywhere inside the cloud's bounding box, more than
-//      8 eps apart (the two 3 eps bands plus refit drift cannot meet): the difference of the signed
-//      distances is linear in p, so constant sign at the 8 corners + min |.| at a corner decide it.
-// Anything else counts as a conflict and the two candidates are accepted one after the other.
-inline bool conflict_free(const float4 &a, const float4 &b, float eps, float cos_t, const float *bbmin, const float *bbmax) {
-    const float c = std::fabs(a.x * b.x + a.y * b.y + a.z * b.z);
-    const float two_theta = 2.f * std::acos(std::min(1.f, cos_t)) + 0.0873f;
-    if (two_theta < 1.5707f && c < std::cos(two_theta)) return true;
-    if (c < 0.97f) return false;
-    const float s = (a.x * b.x + a.y * b.y + a.z * b.z) >= 0 ? 1.f : -1.f;
-    float mn = INFINITY, mx = -INFINITY;
-    for (int k = 0; k < 8; ++k) {
-        const float px = (k & 1) ? bbmax[0] : bbmin[0], py = (k & 2) ? bbmax[1] : bbmin[1], pz = (k & 4) ? bbmax[2] : bbmin[2];
-        const float da = a.x * px + a.y * py + a.z * pz - a.w, db = s * (b.x * px + b.y * py + b.z * pz) - s * b.w;
-        mn = std::min(mn, da - db);
-        mx = std::max(mx, da - db);
+void ransac_detect_prepared(plade_ctx *ctx, RansacWork &W, RansacJob jobs[RANSAC_SLOTS]) {
+    const int ng = W.ng;
+    PLADE_REQUIRE(ng >= 1, PLADE_EINVAL, "ransac: not prepared");
+    Clock::time_point t0 = Clock::now();
+    RArgs A = make_args(W, ng);
+    RInit I;
+    memset(&I, 0, sizeof(I));
+    RResult *res[R_G];
+    int nres = 0;
+    for (int g = 0; g < ng; ++g) {
+        RansacJob &J = jobs[g];
+        RansacSlot &s = W.slot[g];
+        if (!J.active || s.n < 3) {
+            if (J.active && J.out) {   // plane_extraction.cpp:181-184: fewer than three points, no planes
+                J.out->coef.clear(); J.out->offsets.assign(1, 0); J.out->idx.clear(); J.out->d_idx = nullptr; J.out->remaining = s.n;
+                J.out->n_score_passes = 0; J.out->score_bytes = 0;
+            }
+            J.active = false;
+            continue;
+        }
+        const CloudDev &c = *s.cloud;
+        // scale exactly as plane_extraction.cpp:71-80 + PointCloud.h:94-98 (Z bug: maxZ stays -FLT_MAX, so the Z extent
+        // never wins the max)
+        const float scale = std::max(c.bbmax[0] - c.bbmin[0], c.bbmax[1] - c.bbmin[1]);
+        const float eps = J.rp.dist_rel * scale, bitmap_eps = J.rp.bitmap_rel * scale;
+        PLADE_REQUIRE(eps > 0.f && bitmap_eps > 0.f, PLADE_EINVAL, "plane extraction: degenerate bounding box");
+        RInitCloud &P = I.c[g];
+        P.active = 1; P.min_support = J.rp.min_support; P.orient = J.rp.orient_normals ? 1u : 0u;
+        P.eps = eps; P.eps3 = 3 * eps;   // RansacShapeDetector.cpp:471-473
+        P.bitmap_eps = bitmap_eps; P.cos_t = J.rp.cos_thresh; P.overlook_p = J.rp.overlook_p;
+        for (int k = 0; k < 3; ++k) { P.bbmin[k] = c.bbmin[k]; P.bbmax[k] = c.bbmax[k]; }
+        P.seed = J.rp.seed;
+        s.res->flag = 0;
+        res[nres++] = s.res;
     }
-    return (mn > 8 * eps) || (mx < -8 * eps);
+    if (nres == 0) return;
+    std::atomic_thread_fence(std::memory_order_seq_cst);
+    uint32_t tiles = 0;
+    for (int g = 0; g < ng; ++g) tiles += A.c[g].L.nb;
+    hipLaunchKernelGGL(k_r_init, dim3(tiles), dim3(TPB), 0, ctx->stream, A, I);
+    HIP_TRY(hipGetLastError());
+    uint32_t iterations = 0;
+    if (ctx->profiling()) {
+        // profiled run (HIP events around the scan kernels): one iteration at a time; the device-side counters say
+        // which clouds each scan launch really served, i.e. its algorithmic bytes (28 B per point and
+        // launch + one mask byte per 4 points and chain)
+        uint32_t seen_rescore[R_G] = {0, 0}, seen_mark[R_G] = {0, 0}, seen_chains[R_G] = {0, 0};
+        for (;; ++iterations) {
+            const size_t ev0 = ctx->evs.size();
+            launch_iteration(ctx, W, A);
+            wait_iterations(ctx, res, nres, iterations + 1);
+            ctx->sync();
+            double rescore_bytes = 0, mark_bytes = 0;
+            uint32_t mark_launches = 0;
+            for (int g = 0; g < ng; ++g) {
+                if (!jobs[g].active) continue;
+                const RResult &R = *W.slot[g].res;
+                const double n = W.slot[g].n;
+                rescore_bytes += 28.0 * n * (R.n_rescores - seen_rescore[g]);
+                mark_bytes += 28.0 * n * (R.n_mark_launches - seen_mark[g]) + 0.25 * n * (R.n_mark_chains - seen_chains[g]);
+                mark_launches = std::max(mark_launches, R.n_mark_launches - seen_mark[g]);
+                seen_rescore[g] = R.n_rescores; seen_mark[g] = R.n_mark_launches; seen_chains[g] = R.n_mark_chains;
+            }
+            uint32_t mk = 0;
+            for (size_t e = ev0; e < ctx->evs.size(); ++e) {
+                plade_ctx::EvRec &r = ctx->evs[e];
+                if (r.tag == "score_multi") r.bytes = rescore_bytes > 0 ? rescore_bytes : -1.0;
+                else if (r.tag == "score_mark") { r.bytes = mk < mark_launches ? mark_bytes / mark_launches : -1.0; ++mk; }
+            }
+            bool all = true;
+            for (int i = 0; i < nres; ++i) all = all && (res[i]->flag & 0x80000000u);
+            if (all) break;
+        }
+    } else {
+        launch_iteration(ctx, W, A);
+        for (;; ++iterations) {
+            launch_iteration(ctx, W, A);   // speculative: returns at once on the device if the loop has ended
+            wait_iterations(ctx, res, nres, iterations + 1);
+            bool all = true;
+            for (int i = 0; i < nres; ++i) all = all && (*reinterpret_cast<volatile uint32_t *>(&res[i]->flag) & 0x80000000u);
+            if (all) break;
+            PLADE_REQUIRE(iterations < 100000, PLADE_EDEVICE, "plane extraction: the device loop does not end");
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    ctx->stats.add("ransac_iterations", iterations + 1);
+    ctx->stats.add("ransac_t_detect", secs_since(t0));
+    for (int g = 0; g < ng; ++g) {
+        RansacJob &J = jobs[g];
+        if (!J.active) continue;
+        RansacSlot &s = W.slot[g];
+        const RResult &R = *s.res;
+        PLADE_REQUIRE(R.err != 1, PLADE_ELIMIT, "plane extraction: connected-component bitmap too large");
+        PLADE_REQUIRE(R.err != 3, PLADE_ELIMIT, "plane extraction: too many shapes");
+        PlaneSetOut &out = *J.out;
+        out.coef.clear(); out.offsets.assign(1, 0); out.idx.clear();
+        for (uint32_t i = 0; i < R.n_acc; ++i) {
+            if (!R.support[i]) continue;
+            out.coef.insert(out.coef.end(), R.coef[i], R.coef[i] + 4);
+            out.offsets.push_back((int32_t)(R.offset[i] + R.support[i]));
+        }
+        out.d_idx = reinterpret_cast<const uint32_t *>(s.out_idx.p);
+        out.remaining = R.remaining;
+        out.n_score_passes = R.n_rescores + R.n_mark_launches;
+        out.score_bytes = 28.0 * s.n * (R.n_rescores + R.n_mark_launches) + 0.25 * s.n * R.n_mark_chains;
+        ctx->stats.add("ransac_rounds", R.n_rounds);
+        ctx->stats.add("ransac_accepts", R.n_accepts);
+        ctx->stats.add("ransac_batches", R.n_batches);
+        ctx->stats.add("ransac_rescore_launches", R.n_rescores);
+        ctx->stats.add("ransac_mark_launches", R.n_mark_launches);
+        if (J.rp.host_indices) {
+            out.idx.resize(R.out_off);
+            if (R.out_off) ctx->d2h(out.idx.data(), s.out_idx.p, 4 * (size_t)R.out_off);
+        }
+    }
+    bool any_host = false;
+    for (int g = 0; g < ng; ++g) any_host = any_host || (jobs[g].active && jobs[g].rp.host_indices);
+    if (any_host) ctx->sync();
 }
 
-}  // namespace
-
-__global__ void k_list_masks(uint32_t m, uint32_t nb, uint8_t *__restrict__ masks, uint32_t *__restrict__ block_counts) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;   // one mask byte per 4 list positions
-    if (t < nb * 256) {
-        const uint32_t first = t * 4;
-        masks[t] = first >= m ? 0 : (m - first >= 4 ? 0xF : (uint8_t)((1u << (m - first)) - 1));
-    }
-    if (t < nb) { const uint32_t b0 = t * 1024; block_counts[t] = b0 >= m ? 0 : min(1024u, m - b0); }
+void ransac_detect(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const RansacParams &rp, PlaneSetOut &out) {
+    const CloudDev *cl[R_G] = {&cloud, nullptr};
+    ransac_prepare(ctx, W, cl, 1);
+    RansacJob jobs[R_G];
+    jobs[0].active = true; jobs[0].rp = rp; jobs[0].out = &out;
+    ransac_detect_prepared(ctx, W, jobs);
 }
 
 void plane_component(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const float normal[3], const float point[3],
@@ -1033,314 +1797,46 @@ void plane_component(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const
     const uint32_t n = cloud.n;
     PLADE_REQUIRE(m <= n && bitmap_eps > 0.f, PLADE_EINVAL, "plane_component: bad argument");
     if (m == 0) return;
-    chains_prepare(ctx, W, 1, n, 0.f, 0.f, 0.f);
-    const ChainDev &D = W.h_tab[0];
-    Chain &C = *W.chains[0];
+    RansacSlot &s = W.slot[0];
+    W.ng = 0;   // the slot no longer holds a prepared cloud
+    slot_buffers(ctx, s, n);
+    s.seam_list.ensure((size_t)n + 4);
     hipStream_t st = ctx->stream;
-    CloudView cv{cloud.x(), cloud.y(), cloud.z(), cloud.nx(), cloud.ny(), cloud.nz(), n};
+    ctx->h2d(s.seam_list.p, idx, 4 * (size_t)m);
+    RArgs A;
+    memset(&A, 0, sizeof(A));
+    A.ng = 1;
+    for (int g = 0; g < R_G; ++g) {
+        RCloudArgs &C = A.c[g];
+        C.cv = CloudView{cloud.x(), cloud.y(), cloud.z(), cloud.nx(), cloud.ny(), cloud.nz(), n};
+        C.st = s.state.p; C.res = s.res_dev; C.out_idx = s.out_idx.p; C.fixed = s.fixed.p; C.var = s.var.p; C.list_values = s.seam_list.p; C.L = s.L;
+    }
+    A.tiles0 = s.L.nb;
     // Plane(point, normal): dist = point . normal with Vec3f::dot's left-to-right sum (Plane.cpp:21-26)
     float dist = point[0] * normal[0];
     dist += point[1] * normal[1];
     dist += point[2] * normal[2];
-    const float4 two[2] = {make_float4(normal[0], normal[1], normal[2], dist), make_float4(point[0], point[1], point[2], 0.f)};
-    ctx->h2d(W.cand_in.p, two, 32);
-    const uint32_t nb4 = cdiv(n, 1024);
-    ChainTab tab;
-    for (int b = 0; b < CHAIN_MAX; ++b) tab.c[b] = D;
-    tab.g[0] = tab.g[1] = ChainGroup{cv, w_eps, bitmap_eps, nb4};
-    tab.split = 1;
-    hipLaunchKernelGGL(k_state_from_hyp, dim3(1), dim3(64), 0, st, tab);
-    // the list as an all-ones mask over list positions, values = the caller's indices
-    DBuf<uint32_t> d_idx;
-    d_idx.ensure((size_t)n + 4);
-    ctx->h2d(d_idx.p, idx, 4 * (size_t)m);
-    hipLaunchKernelGGL(k_list_masks, dim3(cdiv(nb4 * 256, 256)), dim3(256), 0, st, m, nb4, C.cs.masks.p, C.cs.block_counts.p);
-    const CompactJob hj{C.cs.masks.p, C.cs.block_counts.p, d_idx.p, D.idxA, D.cntA, nullptr, D.st[0].pos, D.uv, D.bbpart,
-                        nb4, cv.x, cv.y, cv.z};
-    compact_batch(ctx, st, &hj, 1);
-    hipLaunchKernelGGL(k_cc_raster, dim3(128, 1), dim3(256), 0, st, tab, 0);
-    hipLaunchKernelGGL(k_cc_label, dim3(1), dim3(1024), 0, st, tab, 0, closing_filter ? 1 : 0);
-    hipLaunchKernelGGL(k_cc_select, dim3(nb4, 1), dim3(256), 0, st, tab, 0);
-    compact_batch(ctx, st, W.compact_jobs.data() + (size_t)1 * W.B, 1);
-    hipLaunchKernelGGL(k_fit_final, dim3(1), dim3(256), 0, st, tab, 0);
+    hipLaunchKernelGGL(k_r_seam_init, dim3(1), dim3(64), 0, st, A, make_float4(normal[0], normal[1], normal[2], dist),
+                       make_float4(point[0], point[1], point[2], 0.f), w_eps, bitmap_eps);
+    const uint32_t nb = s.L.nb;
+    hipLaunchKernelGGL(k_r_list_mark, dim3(nb), dim3(TPB), 0, st, A, m);
+    hipLaunchKernelGGL(k_r_compact_raster, dim3(nb, R_B), dim3(TPB), 0, st, A, 0);
+    hipLaunchKernelGGL(k_r_label, dim3(R_B), dim3(1024), 0, st, A, 0, closing_filter ? 1 : 0);
+    hipLaunchKernelGGL(k_r_select_cc, dim3(nb, R_B), dim3(TPB), 0, st, A, 0);
+    hipLaunchKernelGGL(k_r_fit, dim3(R_B), dim3(256), 0, st, A, 0);
+    hipLaunchKernelGGL(k_r_assign, dim3(nb, R_B), dim3(TPB), 0, st, A);
     PlaneState hst[2];
-    uint32_t nk = 0;
-    ctx->d2h(hst, D.st, 2 * sizeof(PlaneState));
-    ctx->d2h(&nk, D.cntS, 4);
+    ctx->d2h(hst, s.fixed.p, 2 * sizeof(PlaneState));   // chain 0's header
     ctx->sync(st);
     HIP_TRY(hipGetLastError());
     out.err = hst[0].err;
     if (out.err) return;
+    const uint32_t nk = hst[0].n_kept;
     out.kept.resize(nk);
-    if (nk) HIP_TRY(hipMemcpy(out.kept.data(), D.idxS[0], 4 * (size_t)nk, hipMemcpyDeviceToHost));
+    if (nk) HIP_TRY(hipMemcpy(out.kept.data(), s.out_idx.p, 4 * (size_t)nk, hipMemcpyDeviceToHost));
     for (int k = 0; k < 3; ++k) { out.fit[k] = hst[1].n[k]; out.fit[3 + k] = hst[1].pos[k]; }
     out.fit[6] = hst[1].dist;
     out.wscore = hst[0].wscore;
-}
-
-void ransac_detect(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const RansacParams &rp, PlaneSetOut &out, PairAccept *pair,
-                   int who) {
-    // a member of a pair takes part in the lock-step batches from here until it returns
-    struct Membership {
-        PairAccept *p;
-        explicit Membership(PairAccept *q) : p(q) { if (p) p->join(); }
-        ~Membership() { if (p) p->leave(); }
-    } membership(pair);
-    const uint32_t n = cloud.n;
-    Clock::time_point t_setup0 = Clock::now();
-    out.coef.clear(); out.offsets.assign(1, 0); out.idx.clear(); out.d_idx = nullptr;
-    out.n_score_passes = 0; out.remaining = n;
-    if (n < 3) return;
-    // ---- scale exactly as plane_extraction.cpp:71-80 + PointCloud.h:94-98 (Z bug: maxZ stays
-    //      -FLT_MAX, so the Z extent never wins the max) ------------------------------------------
-    const float scale = std::max(cloud.bbmax[0] - cloud.bbmin[0], cloud.bbmax[1] - cloud.bbmin[1]);
-    const float eps = rp.dist_rel * scale, bitmap_eps = rp.bitmap_rel * scale, cos_t = rp.cos_thresh;
-    const float eps3 = 3 * eps;   // RansacShapeDetector.cpp:471-473
-    PLADE_REQUIRE(eps > 0.f && bitmap_eps > 0.f, PLADE_EINVAL, "plane extraction: degenerate bounding box");
-
-    // ---- Morton order -------------------------------------------------------------------------
-    W.codes_in.ensure(n); W.vals_in.ensure(n); W.codes.ensure(n); W.orig.ensure(n);
-    const float cube = std::max({cloud.bbmax[0] - cloud.bbmin[0], cloud.bbmax[1] - cloud.bbmin[1], cloud.bbmax[2] - cloud.bbmin[2], 1e-30f});
-    const unsigned nb = cdiv(n, 256);
-    hipLaunchKernelGGL(k_morton, dim3(nb), dim3(256), 0, ctx->stream, cloud.x(), cloud.y(), cloud.z(), n, cloud.bbmin[0],
-                       cloud.bbmin[1], cloud.bbmin[2], 1.f / cube, W.codes_in.p, W.vals_in.p);
-    sort_pairs_u32(ctx, W.codes_in.p, W.codes.p, W.vals_in.p, W.orig.p, n, 24);
-    W.sorted.n = n;
-    W.sorted.pitch = cloud.pitch;
-    W.sorted.soa.ensure(6 * cloud.pitch + 4);
-    hipLaunchKernelGGL(k_gather_cloud, dim3(nb), dim3(256), 0, ctx->stream, cloud.aos.p, W.orig.p, n, W.sorted.soa.p, W.sorted.pitch);
-    const CloudDev &c = W.sorted;
-    CloudView cv{c.x(), c.y(), c.z(), c.nx(), c.ny(), c.nz(), n};
-    W.assigned.ensure((size_t)n + 4);
-    hipLaunchKernelGGL(k_fill_i32, dim3(nb), dim3(256), 0, ctx->stream, W.assigned.p, n, -1);
-    // ---- stratified subset (every stride-th point of the Morton order) --------------------------
-    const uint32_t stride = std::max(1u, n / 16384u);
-    W.n_sub = (n + stride - 1) / stride;
-    W.sub_pitch = ((size_t)W.n_sub + 3) & ~(size_t)3;
-    W.sub.ensure(6 * W.sub_pitch + 4);
-    W.sub_index.ensure(W.sub_pitch + 4);
-    hipLaunchKernelGGL(k_make_subset, dim3(cdiv(W.n_sub, 256)), dim3(256), 0, ctx->stream, c.soa.p, c.pitch, n, stride, W.n_sub,
-                       W.sub.p, W.sub_pitch, W.sub_index.p);
-    const float *sx = W.sub.p, *sy = sx + W.sub_pitch, *sz = sy + W.sub_pitch, *snx = sz + W.sub_pitch, *sny = snx + W.sub_pitch,
-                *snz = sny + W.sub_pitch;
-
-    const uint32_t H = 4096, TOP = 48;
-    const size_t round_bytes = (size_t)H * 36 + 64;
-    char *rb = W.round_block.ensure(round_bytes);
-    W.hyp = reinterpret_cast<float4 *>(rb);
-    W.hyp_pos = W.hyp + H;
-    W.hyp_counts = reinterpret_cast<uint32_t *>(W.hyp_pos + H);
-    W.misc = W.hyp_counts + H;
-    W.top.ensure(TOP + TOP / 4 + 4);   // TOP planes followed by TOP counts: one upload brings planes + zeroed counts
-    char *pin = W.pinned.ensure(round_bytes + 256);
-    W.out_idx.ensure((size_t)n + 4);
-    // ---- acceptance chains ------------------------------------------------------------------------
-    uint32_t B = 8;
-    if (const char *e = getenv("PLADE_RANSAC_CHAINS")) B = (uint32_t)std::max(1, std::min(CHAIN_MAX / 2, atoi(e)));
-    chains_prepare(ctx, W, B, n, eps3, cos_t, bitmap_eps);
-
-    ctx->sync();
-    ctx->stats.add("ransac_t_setup", secs_since(t_setup0));
-    const int min_level = 1, max_level = 8;
-    const float levels = (float)(max_level - min_level + 1);
-    auto fail_prob = [&](float cand_size, float n_pts, float drawn) {  // RansacShapeDetector.h:61-67 (reqSamples = 3)
-        return std::min(std::pow(1.f - cand_size / (n_pts * levels * 4.f), drawn), 1.f);
-    };
-
-    double t_sample = 0, t_rescore = 0, t_accept = 0;
-    uint32_t n_rounds = 0, n_accepts = 0, n_batches = 0;
-    std::vector<Accepted> accepted;
-    std::vector<float4> h_hyp(H), h_pos(H);
-    std::vector<uint32_t> h_counts(H);
-    struct Cand { float4 pl, pos; uint32_t count; };
-    std::vector<Cand> pool;
-    uint32_t n_remaining = n;
-    float drawn = 0.f;
-    uint32_t out_off = 0;
-    uint32_t n_full_passes = 0;
-    const uint32_t max_rounds = 4000;
-    const bool dbg = getenv("PLADE_DEBUG_RANSAC") != nullptr;
-    for (uint32_t round = 0; round < max_rounds; ++round) {
-        if (n_remaining < rp.min_support) break;
-        if (round > 0 && fail_prob((float)rp.min_support, (float)n_remaining, drawn) <= rp.overlook_p && pool.empty()) break;
-        // ---- draw and score a batch ------------------------------------------------------------
-        ++n_rounds;
-        Clock::time_point t_s0 = Clock::now();
-        hipLaunchKernelGGL(k_sample, dim3(cdiv(H, 256)), dim3(256), 0, ctx->stream, cv, W.codes.p, W.assigned.p, rp.seed, round, H,
-                           min_level, max_level, eps, cos_t, W.hyp, W.hyp_pos, W.hyp_counts, W.misc);
-        score_multi(ctx, sx, sy, sz, snx, sny, snz, W.assigned.p, W.sub_index.p, W.n_sub, W.hyp, H, eps, cos_t, W.hyp_counts, true);
-        hipLaunchKernelGGL(k_count_unassigned, dim3(cdiv(W.n_sub, 256)), dim3(256), 0, ctx->stream, W.assigned.p, W.sub_index.p,
-                           W.n_sub, W.misc);
-        uint32_t sub_un = 0;
-        ctx->d2h(pin, rb, (size_t)H * 36 + 4);
-        ctx->sync();
-        memcpy(h_hyp.data(), pin, (size_t)H * 16);
-        memcpy(h_pos.data(), pin + (size_t)H * 16, (size_t)H * 16);
-        memcpy(h_counts.data(), pin + (size_t)H * 32, (size_t)H * 4);
-        memcpy(&sub_un, pin + (size_t)H * 36, 4);
-        t_sample += secs_since(t_s0);
-        uint32_t valid = 0;
-        for (uint32_t i = 0; i < H; ++i) valid += h_pos[i].w != 0.f;   // w: 0 no samples, 1 verified plane, 2 drawn but rejected
-        drawn += (float)valid;
-        if (dbg)
-            fprintf(stderr, "[ransac] round %u valid %u drawn %.0f n_rem %u accepted %zu failprob %.4g\n", round, valid, drawn,
-                    n_remaining, accepted.size(), fail_prob((float)rp.min_support, (float)n_remaining, drawn));
-        // leaders of this batch by estimated support, one representative per distinct plane
-        const double ratio = sub_un ? (double)n_remaining / sub_un : 0.0;
-        std::vector<uint32_t> order;
-        order.reserve(H);
-        for (uint32_t i = 0; i < H; ++i)
-            if (h_pos[i].w == 1.f && h_counts[i] * ratio >= 0.5 * rp.min_support) order.push_back(i);
-        std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
-            return h_counts[a] != h_counts[b] ? h_counts[a] > h_counts[b] : a < b;
-        });
-        for (uint32_t i : order) {
-            if (pool.size() >= TOP) break;
-            bool dup = false;
-            for (const Cand &pc : pool) if (same_plane(pc.pl, h_hyp[i], eps)) { dup = true; break; }
-            if (!dup) pool.push_back(Cand{h_hyp[i], h_pos[i], 0});
-        }
-        // ---- harvest: re-score the pool on all unassigned points, accept the leaders, repeat ----------
-        while (!pool.empty()) {
-            Clock::time_point t_r0 = Clock::now();
-            const uint32_t np = (uint32_t)pool.size();
-            std::vector<float4> pl(TOP + TOP / 4, make_float4(0.f, 0.f, 0.f, 0.f));
-            for (uint32_t i = 0; i < np; ++i) pl[i] = pool[i].pl;
-            uint32_t *top_counts = reinterpret_cast<uint32_t *>(W.top.p + TOP);
-            ctx->h2d(W.top.p, pl.data(), pl.size() * 16);
-            score_multi(ctx, c.x(), c.y(), c.z(), c.nx(), c.ny(), c.nz(), W.assigned.p, nullptr, n, W.top.p, np, eps, cos_t,
-                        top_counts, true);
-            ++n_full_passes;
-            std::vector<uint32_t> cnts(np);
-            ctx->d2h(cnts.data(), top_counts, np * 4);
-            ctx->sync();
-            t_rescore += secs_since(t_r0);
-            for (uint32_t i = 0; i < np; ++i) pool[i].count = cnts[i];
-            // candidates that can no longer reach min_support are dropped (RansacShapeDetector.cpp:826-832)
-            pool.erase(std::remove_if(pool.begin(), pool.end(), [&](const Cand &a) { return a.count < rp.min_support; }), pool.end());
-            if (pool.empty()) break;
-            std::stable_sort(pool.begin(), pool.end(), [](const Cand &a, const Cand &b) { return a.count > b.count; });
-            // the best candidate plus every further one whose support provably cannot touch the supports
-            // already in the batch: accepting them concurrently equals accepting them one by one
-            std::vector<uint32_t> batch{0};
-            for (uint32_t i = 1; i < pool.size() && batch.size() < B; ++i) {
-                bool ok = true;
-                for (uint32_t j : batch) ok = ok && conflict_free(pool[i].pl, pool[j].pl, eps, cos_t, cloud.bbmin, cloud.bbmax);
-                if (ok) batch.push_back(i);
-            }
-            Clock::time_point t_a0 = Clock::now();
-            ++n_batches;
-            const uint32_t nc = (uint32_t)batch.size();
-            std::vector<float4> h_in(2 * nc);
-            for (uint32_t b = 0; b < nc; ++b) { h_in[2 * b] = pool[batch[b]].pl; h_in[2 * b + 1] = pool[batch[b]].pos; }
-            ctx->h2d(W.cand_in.p, h_in.data(), 32 * nc);
-            {
-                if (!W.ev_ready) HIP_TRY(hipEventCreateWithFlags(&W.ev_ready, hipEventDisableTiming));
-                HIP_TRY(hipEventRecord(W.ev_ready, ctx->stream));
-                AcceptSide S;
-                S.W = &W; S.nc = nc; S.cv = cv; S.assigned = W.assigned.p;
-                S.eps3 = eps3; S.cos_t = cos_t; S.bitmap_eps = bitmap_eps; S.ready = W.ev_ready;
-                if (!pair && !W.solo) { W.solo = new PairAccept; W.solo->participants = 1; }
-                // launches the batch (merged with the other cloud's when both are ready), reads the accept blocks
-                // back into pinned memory and waits for the GPU
-                (pair ? pair : W.solo)->submit(pair ? who : 0, ctx, S);
-            }
-            HIP_TRY(hipGetLastError());
-            n_full_passes += 4 * (uint32_t)batch.size();
-            t_accept += secs_since(t_a0);
-            AssignJobs aj{};
-            uint32_t n_aj = 0, max_m = 0;
-            for (size_t b = 0; b < batch.size(); ++b) {
-                Chain &C = *W.chains[b];
-                const Cand &bc = pool[batch[b]];
-                ++n_accepts;
-                PlaneState hst[4];
-                uint32_t hcnt[4];
-                float hns[12];
-                const char *hb = W.pinned_accept.p + b * ACCEPT_STRIDE;
-                memcpy(hst, hb, 4 * sizeof(PlaneState));
-                memcpy(hcnt, hb + 4 * sizeof(PlaneState), 16);
-                memcpy(hns, hb + 4 * sizeof(PlaneState) + 16, 48);
-                PLADE_REQUIRE(hst[0].err != 1, PLADE_ELIMIT, "plane extraction: connected-component bitmap too large");
-                // replay of the reference's refit loop on the four results
-                int final_slot = 0;
-                {
-                    double newScore = hst[0].wscore;
-                    for (int fittingIter = 1; fittingIter <= 3; ++fittingIter) {
-                        const double oldScore = newScore;
-                        if (hcnt[fittingIter - 1] < 3 || hst[fittingIter].err) break;   // LSFit impossible
-                        newScore = hst[fittingIter].wscore;
-                        const uint32_t newSize = hcnt[fittingIter];
-                        if (newScore > oldScore && newSize > rp.min_support) final_slot = fittingIter;  // clone.Clone(&candidates.back())
-                        if (!(newScore > oldScore)) break;
-                    }
-                }
-                const PlaneState &cand_state = hst[final_slot];
-                const uint32_t cand_size = hcnt[final_slot];
-                uint32_t *cand_idx = C.idxS[final_slot].p;
-                if (dbg)
-                    fprintf(stderr, "[ransac]   accept[%zu/%zu]: eps-count %u sizes %u %u %u %u wscore %.1f %.1f %.1f %.1f final slot %d bitmap %ux%u\n",
-                            b, batch.size(), bc.count, hcnt[0], hcnt[1], hcnt[2], hcnt[3], hst[0].wscore, hst[1].wscore, hst[2].wscore,
-                            hst[3].wscore, final_slot, hst[final_slot].ue, hst[final_slot].ve);
-                // ---- remove the points (RansacShapeDetector.cpp:666-675) ---------------------------------
-                if (cand_size == 0) continue;
-                const int32_t shape_id = (int32_t)accepted.size();
-                aj.idx[n_aj] = cand_idx; aj.m[n_aj] = cand_size; aj.id[n_aj] = shape_id; aj.out[n_aj] = nullptr;
-                max_m = std::max(max_m, cand_size);
-                drawn = std::pow(1.f - (cand_size / float(n_remaining)), 3.f) * drawn;
-                n_remaining -= std::min(n_remaining, cand_size);
-                // plane_extraction.cpp:134-149: shapes below min_support are skipped, d = -n.p with n re-normalised
-                Accepted a{};
-                a.support = 0; a.offset = out_off;
-                if (cand_size >= rp.min_support) {
-                    float nn[3] = {cand_state.n[0], cand_state.n[1], cand_state.n[2]};
-                    float l = nn[0] * nn[0];
-                    l += nn[1] * nn[1];
-                    l += nn[2] * nn[2];
-                    l = std::sqrt(l);
-                    if (l > 0) { nn[0] /= l; nn[1] /= l; nn[2] /= l; }
-                    float d = -(nn[0] * cand_state.pos[0] + nn[1] * cand_state.pos[1] + nn[2] * cand_state.pos[2]);
-                    if (rp.orient_normals) {  // mean inlier normal (the intent of plane_extraction.cpp:43-58)
-                        const float *ns = hns + 3 * final_slot;
-                        if (ns[0] * nn[0] + ns[1] * nn[1] + ns[2] * nn[2] < 0) { nn[0] = -nn[0]; nn[1] = -nn[1]; nn[2] = -nn[2]; d = -d; }
-                    }
-                    a.coef[0] = nn[0]; a.coef[1] = nn[1]; a.coef[2] = nn[2]; a.coef[3] = d;
-                    a.support = cand_size;
-                    aj.out[n_aj] = W.out_idx.p + out_off;
-                    out_off += cand_size;
-                }
-                ++n_aj;
-                accepted.push_back(a);
-            }
-            if (n_aj)   // the candidates of a batch have disjoint supports: one launch removes them all
-                hipLaunchKernelGGL(k_assign_batch, dim3(std::min(cdiv(max_m, 256), 256u), n_aj), dim3(256), 0, ctx->stream, aj, W.orig.p,
-                                   W.assigned.p);
-            // drop the batch from the pool (indices are ascending)
-            for (size_t b = batch.size(); b-- > 0;) pool.erase(pool.begin() + batch[b]);
-            if (n_remaining < rp.min_support) { pool.clear(); break; }
-        }
-    }
-    ctx->stats.add("ransac_t_sample", t_sample);
-    ctx->stats.add("ransac_t_rescore", t_rescore);
-    ctx->stats.add("ransac_t_accept", t_accept);
-    ctx->stats.add("ransac_rounds", n_rounds);
-    ctx->stats.add("ransac_accepts", n_accepts);
-    ctx->stats.add("ransac_batches", n_batches);
-    // ---- output ---------------------------------------------------------------------------------
-    out.idx.clear();
-    if (rp.host_indices) {
-        out.idx.resize(out_off);
-        if (out_off) ctx->d2h(out.idx.data(), W.out_idx.p, 4 * (size_t)out_off);
-    }
-    ctx->sync();
-    for (auto &a : accepted) {
-        if (!a.support) continue;
-        out.coef.insert(out.coef.end(), a.coef, a.coef + 4);
-        out.offsets.push_back((int32_t)(a.offset + a.support));
-    }
-    out.d_idx = reinterpret_cast<const uint32_t *>(W.out_idx.p);
-    out.n_score_passes = n_full_passes;
-    out.remaining = n_remaining;
 }
 
 }  // namespace plade

@@ -21,51 +21,72 @@ RansacParams ransac_params(plade_ctx *ctx, uint32_t min_support, bool host_indic
     return rp;  // 0.005f, 0.02f, 0.8f, 0.001f: plade.cpp:607,627
 }
 
-// extract() (code/PLADE/plade.cpp:602-635).  The trace of the auto-tuning loop (plane count of every detect call, the
-// min_support it ends at) is left in the stats: tests compare it with the reference loop over libransac (g2_extract.npz).
-void extract(plade_ctx *ctx, const CloudDev &cloud, int init_min_support, PlaneSetOut &planes, bool host_indices,
-             PairAccept *pair = nullptr, int who = 0) {
+// extract() (code/PLADE/plade.cpp:602-635) of BOTH clouds of a registration: the reference runs it once per cloud; here
+// pass p of the two halving loops is one merged launch sequence (ransac_detect_prepared) in which every cloud that still
+// needs a detect call takes part with its own min_support.  The trace of the auto-tuning loops (plane count of every
+// detect call, the min_support they end at) is left in the stats: tests compare it with the reference loop over
+// libransac (g2_extract.npz).
+void extract_pair(plade_ctx *ctx, const CloudDev *const clouds[2], const int init_min_support[2], bool auto_tune,
+                  PlaneSetOut *const planes[2], bool host_indices) {
     const uint32_t min_num = (uint32_t)ctx->params.min_planes, max_num = (uint32_t)ctx->params.max_planes;
-    const int min_allowed_support = 200;
-    const std::string tag = who == 0 ? "_tgt" : "_src";
-    int trials = 0;
-    auto detect = [&](int min_support) {
-        if (!ctx->ransac_work) ctx->ransac_work = ransac_work_create();
-        ransac_detect(ctx, *ctx->ransac_work, cloud, ransac_params(ctx, (uint32_t)min_support, host_indices), planes, pair, who);
-        ++trials;
-        ctx->stats.add("n_detect_calls", 1);
-        ctx->stats.add("n_score_passes", planes.n_score_passes);
-        ctx->stats.add("extract_planes_trial" + std::to_string(trials) + tag, planes.P());
-        ctx->stats.add("extract_final_min_support" + tag, min_support - ctx_stat(ctx, ("extract_final_min_support" + tag).c_str()));
-    };
-    detect(init_min_support);
-    if (planes.P() > max_num) {
-        // top max_num by support.  The reference sorts with a `>=` comparator (plade.cpp:612-615,
-        // undefined behaviour on ties); a stable descending sort is used here.
-        const uint32_t P = planes.P();
-        planes.fetch_indices(ctx->stream);
-        std::vector<uint32_t> order(P);
-        std::iota(order.begin(), order.end(), 0u);
-        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
-            return planes.offsets[a + 1] - planes.offsets[a] > planes.offsets[b + 1] - planes.offsets[b];
-        });
-        PlaneSetOut r;
-        r.offsets.assign(1, 0);
-        for (uint32_t k = 0; k < max_num; ++k) {
-            const uint32_t i = order[k];
-            r.coef.insert(r.coef.end(), planes.coef.begin() + 4 * i, planes.coef.begin() + 4 * i + 4);
-            r.idx.insert(r.idx.end(), planes.idx.begin() + planes.offsets[i], planes.idx.begin() + planes.offsets[i + 1]);
-            r.offsets.push_back((int32_t)r.idx.size());
+    const int min_allowed_support = 200, max_trials = 10;
+    if (!ctx->ransac_work) ctx->ransac_work = ransac_work_create();
+    RansacWork &W = *ctx->ransac_work;
+    ransac_prepare(ctx, W, clouds, 2);
+    int ms[2] = {init_min_support[0], init_min_support[1]}, trials[2] = {0, 0};
+    bool finished[2] = {false, false};
+    const char *tags[2] = {"_tgt", "_src"};
+    for (;;) {
+        RansacJob jobs[RANSAC_SLOTS];
+        bool any = false;
+        for (int g = 0; g < 2; ++g) {
+            jobs[g].active = !finished[g];
+            jobs[g].rp = ransac_params(ctx, (uint32_t)ms[g], host_indices);
+            jobs[g].out = planes[g];
+            any = any || jobs[g].active;
         }
-        r.n_score_passes = planes.n_score_passes;
-        planes = std::move(r);
-        return;
+        if (!any) break;
+        ransac_detect_prepared(ctx, W, jobs);
+        for (int g = 0; g < 2; ++g) {
+            if (finished[g]) continue;
+            PlaneSetOut &pl = *planes[g];
+            const std::string tag = tags[g];
+            ++trials[g];
+            ctx->stats.add("n_detect_calls", 1);
+            ctx->stats.add("n_score_passes", pl.n_score_passes);
+            ctx->stats.add("bytes_ransac", pl.score_bytes);
+            ctx->stats.add("extract_planes_trial" + std::to_string(trials[g]) + tag, pl.P());
+            ctx->stats.add("extract_final_min_support" + tag, ms[g] - ctx_stat(ctx, ("extract_final_min_support" + tag).c_str()));
+            if (!auto_tune) { finished[g] = true; continue; }   // plade.cpp:583-599: one call with the caller's min_support
+            if (trials[g] == 1 && pl.P() > max_num) {
+                // top max_num by support.  The reference sorts with a `>=` comparator (plade.cpp:612-615,
+                // undefined behaviour on ties); a stable descending sort is used here.
+                const uint32_t P = pl.P();
+                pl.fetch_indices(ctx->stream);
+                std::vector<uint32_t> order(P);
+                std::iota(order.begin(), order.end(), 0u);
+                std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+                    return pl.offsets[a + 1] - pl.offsets[a] > pl.offsets[b + 1] - pl.offsets[b];
+                });
+                PlaneSetOut r;
+                r.offsets.assign(1, 0);
+                for (uint32_t k = 0; k < max_num; ++k) {
+                    const uint32_t i = order[k];
+                    r.coef.insert(r.coef.end(), pl.coef.begin() + 4 * i, pl.coef.begin() + 4 * i + 4);
+                    r.idx.insert(r.idx.end(), pl.idx.begin() + pl.offsets[i], pl.idx.begin() + pl.offsets[i + 1]);
+                    r.offsets.push_back((int32_t)r.idx.size());
+                }
+                r.n_score_passes = pl.n_score_passes;
+                pl = std::move(r);   // d_idx is null now: the next stage uploads the reordered host lists
+                finished[g] = true;
+                continue;
+            }
+            // plade.cpp:620-633: fewer than min_num planes -> halve min_support, at most 10 detect calls, never below 200
+            const int next = ms[g] / 2;
+            if (pl.P() >= min_num || trials[g] >= max_trials || next < min_allowed_support) finished[g] = true;
+            else ms[g] = next;
+        }
     }
-    // plade.cpp:620-633: fewer than min_num planes -> halve min_support, at most 10 detect calls, never below 200
-    const int max_trials = 10;
-    for (int min_support = init_min_support / 2; planes.P() < min_num && trials < max_trials && min_support >= min_allowed_support;
-         min_support /= 2)
-        detect(min_support);
 }
 
 int register_clouds(plade_ctx *ctx, const CloudDev &tgt, const CloudDev &src, int ms_t, int ms_s, bool auto_tune,
@@ -77,8 +98,6 @@ int register_clouds(plade_ctx *ctx, const CloudDev &tgt, const CloudDev &src, in
     Clock::time_point t0 = Clock::now();
     {
         StageTimer t(ctx, "t_extract");
-        // The two clouds' extractions are independent (plade.cpp:645-657 runs them back to back): the
-        // source runs on a second stream / host thread so their many small launches interleave on the GPU.
         if (!ctx->aux) {
             plade_ctx *a = nullptr;
             PLADE_REQUIRE(plade_ctx_create(ctx->device, &a) == PLADE_OK, PLADE_EDEVICE, "cannot create the auxiliary stream");
@@ -89,34 +108,23 @@ int register_clouds(plade_ctx *ctx, const CloudDev &tgt, const CloudDev &src, in
         aux->stats.clear();
         Err aux_err{0, ""};
         if (!ctx->reg_work) ctx->reg_work = registration_work_create();
-        // The acceptance batches of the two extractions are launched together in throughput mode (sleeping host waits:
-        // several registrations in flight); a registration that has the GPU to itself (spinning waits) keeps them
-        // apart, because waiting for the other cloud costs it ~0.5 ms.  PLADE_PAIR_ACCEPT=1 / 0 forces either.
-        static const char *pair_env = getenv("PLADE_PAIR_ACCEPT");
-        const bool pair_on = pair_env ? pair_env[0] != '0' : ctx->params.host_wait != 0;
-        if (pair_on && !ctx->pair_accept) ctx->pair_accept = pair_accept_create();
-        PairAccept *pair = pair_on ? ctx->pair_accept : nullptr;
-        auto one = [&](plade_ctx *c, const CloudDev &cloud, int ms, PlaneSetOut &out) {
-            const int who = c == ctx ? 0 : 1;
-            // the next stage reads the index lists from the device; the host copy is only for dumps
-            const bool host_idx = c->params.dump != 0;
-            if (auto_tune) extract(c, cloud, c->params.init_min_support, out, host_idx, pair, who);
-            else {  // plade.cpp:583-599
-                if (!c->ransac_work) c->ransac_work = ransac_work_create();
-                ransac_detect(c, *c->ransac_work, cloud, ransac_params(c, (uint32_t)ms, host_idx), out, pair, who);
-            }
-        };
+        // the point spacing (plade.cpp:41) only needs the source cloud: it runs on the auxiliary stream, driven by a
+        // helper thread, while this thread extracts the planes of both clouds
         std::thread th([&]() {
             (void)hipSetDevice(ctx->device);
-            // the source side usually finishes first (fewer points / planes): it goes on with the point
-            // spacing (plade.cpp:41), which only needs the source cloud
-            try { one(aux, src, ms_s, sp); spacing = source_spacing(aux, *ctx->reg_work, src); have_spacing = true; }
+            try { spacing = source_spacing(aux, *ctx->reg_work, src); have_spacing = true; }
             catch (const Err &e) { aux_err = e; }
             catch (const std::exception &e) { aux_err = Err{PLADE_EDEVICE, e.what()}; }
         });
         Err main_err{0, ""};
         // every exception is caught while the helper thread is joinable (unwinding past it would terminate the process)
-        try { one(ctx, tgt, ms_t, tp); }
+        try {
+            const CloudDev *clouds[2] = {&tgt, &src};
+            const int init[2] = {auto_tune ? ctx->params.init_min_support : ms_t, auto_tune ? ctx->params.init_min_support : ms_s};
+            PlaneSetOut *outs[2] = {&tp, &sp};
+            // the next stage reads the index lists from the device; the host copy is only for dumps
+            extract_pair(ctx, clouds, init, auto_tune, outs, ctx->params.dump != 0);
+        }
         catch (const Err &e) { main_err = e; }
         catch (const std::exception &e) { main_err = Err{PLADE_EDEVICE, e.what()}; }
         th.join();
@@ -134,7 +142,7 @@ int register_clouds(plade_ctx *ctx, const CloudDev &tgt, const CloudDev &src, in
                 return PLADE_EFAIL;
             }
         }
-        // the device index lists live in the two separate work areas and stay valid for the next stage
+        // the device index lists live in the two slots of the work area and stay valid for the next stage
     }
     if (ctx->params.dump) {
         ctx->put("tgt_planes", tp.coef.data(), tp.coef.size());
@@ -152,8 +160,7 @@ int register_clouds(plade_ctx *ctx, const CloudDev &tgt, const CloudDev &src, in
     tv.d_idx = tp.d_idx;
     const bool ok = run_registration(ctx, *ctx->reg_work, tgt, src, tv, sv, T16, have_spacing ? &spacing : nullptr);
     ctx->stats.add("t_registration", secs_since(t0));
-    // roofline bookkeeping
-    ctx->stats.add("bytes_ransac", 28.0 * ((double)tgt.n + src.n) * 0.5 * ctx_stat(ctx, "n_score_passes"));
+    // roofline bookkeeping; bytes_ransac was summed per scan launch and cloud by extract_pair
     ctx->stats.add("bytes_voxel", 12.0 * ((double)tgt.n + src.n));
     ctx->ev_collect();
     if (!ok) { if (ctx->last_error.empty()) ctx->last_error = "registration failed: no matched result found"; return PLADE_EFAIL; }

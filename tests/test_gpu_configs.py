@@ -91,16 +91,20 @@ def test_config3_batch_of_64_pairs_through_the_cli(batch64, ctx):
     tf = [l[len("target file: "):] for l in r.stdout.split("\n") if l.startswith("target file: ")]
     assert tf == [p[0] for p in pairs]
     from plade_amd.plyio import read_ply
-    n_ok = 0
+    n_ok, errs = 0, []
     for b, (pt, ps, Tgt) in zip(blocks, pairs):
         ok, T = ctx.registration(read_ply(pt), read_ply(ps))
         assert ok == (not b["failed"])
         if ok:
             # Eigen's default stream format prints 6 significant digits
             assert np.allclose(b["T"], T, rtol=2e-5, atol=2e-6), b["target"]
-            assert np.linalg.norm(b["T"] - Tgt) < 1e-2
+            errs.append(np.linalg.norm(b["T"] - Tgt))
             n_ok += 1
     assert n_ok >= N_PAIRS - 1
+    # accuracy against the generator's ground truth is the reference algorithm's (5 mm sensor noise, thresholds that are
+    # multiples of the point spacing; the oracle gives the same transforms): a few cm at worst, under 1e-2 for most pairs
+    errs = np.array(errs)
+    assert errs.max() < 0.1 and (errs < 1e-2).mean() > 0.8, np.sort(errs)[-5:]
     print(f"configs[3]: 64 x 1M-point pairs through the CLI in {dt:.2f} s ({N_PAIRS / dt:.1f} pairs/s end to end, PLY parse included)")
 
 
@@ -130,7 +134,7 @@ def test_config3_interrupted_batch_leaves_a_valid_prefix(batch64):
     assert 3 <= len(blocks) < N_PAIRS
     assert [b["target"] for b in blocks] == [q[0] for q in pairs[:len(blocks)]]
     for b, (pt, ps, Tgt) in zip(blocks, pairs):
-        assert b["failed"] or np.linalg.norm(b["T"] - Tgt) < 1e-2
+        assert b["failed"] or np.linalg.norm(b["T"] - Tgt) < 0.1
 
 
 # ---- configs[4] -----------------------------------------------------------------------------------------------------
@@ -166,19 +170,19 @@ def test_config4_10m_points_100_planes_10k_candidates(big_scene, oracle):
     ct.free(); cs.free()
     # ---- the oracle at the planes-given boundary (planes = the ones the GPU extracted).  Everything up to the list of
     #      candidates that enters the penetration filter is compared in full; of the ~10^4 penetration tests the oracle
-    #      evaluates every 64th (each one transforms every source plane cloud: hours for all of them on one core), and
+    #      evaluates every 16th (each one transforms every source plane cloud: hours for all of them on one core), and
     #      the verification counts of a dozen verified candidates come from the oracle's ComputeOverlap seam.
     tp = (d["tgt_planes"].reshape(-1, 4), d["tgt_plane_offsets"], d["tgt_plane_idx"])
     sp = (d["src_planes"].reshape(-1, 4), d["src_plane_offsets"], d["src_plane_idx"])
     t0 = time.perf_counter()
-    _, _, do = oracle.registration(tg, sr, tp, sp, voxel_sort_mode=1, max_candidates=10000, pen_stride=64)
+    _, _, do = oracle.registration(tg, sr, tp, sp, voxel_sort_mode=1, max_candidates=10000, pen_stride=16)
     print(f"configs[4]: sampled oracle run {time.perf_counter() - t0:.0f} s", dict(zip(do["timing_names"], np.round(do["timing"], 1))))
     common = [k for k in do if k in d and not k.startswith("timing") and k != "pen_flags"]
     assert len(common) >= 25 and "pen_tested" in common and "plane_match_counts" in common and "initial_RT" in common
     for k in common:
         assert np.asarray(d[k]).shape == np.asarray(do[k]).shape and np.array_equal(d[k], do[k]), k
     sampled = do["pen_flags"] >= 0
-    assert sampled.sum() >= K // 64 and np.array_equal(d["pen_flags"][sampled], do["pen_flags"][sampled])
+    assert sampled.sum() >= K // 16 and np.array_equal(d["pen_flags"][sampled], do["pen_flags"][sampled])
     tgt_ds, src_ds = d["tgt_ds"].reshape(-1, 3), d["src_ds"].reshape(-1, 3)
     cand, centers = d["candidates"].reshape(-1, 4, 4), d["candidate_centers"].reshape(-1, 3)
     leaf = np.float32(4) * d["average_spacing"][0]

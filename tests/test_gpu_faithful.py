@@ -115,13 +115,23 @@ def test_faithful_registration_equals_oracle_on_the_same_planes(faithful, oracle
 
 def test_extract_auto_tuning_against_libransac(faithful):
     """extract() level (plade.cpp:602-635): the halving loop over min_support on the reference's sample clouds.  The
-    fixture holds the loop's trace over libransac for eight pinned time() seeds (libransac's plane count at a given
-    min_support varies with the seed, and so does the level its loop ends at: 625 or 1250 for two of the four clouds).
-    The GPU extraction is deterministic and exhaustive: at every level it finds at least as many planes as libransac's
-    weakest draw and at most a few more than its best, and its loop ends at a level libransac's loop ends at."""
+    fixture holds the loop's trace over libransac for eight pinned time() seeds.
+
+    What the data says about libransac itself: at the levels where its count does not depend on the seed (10000, 5000,
+    2500) the GPU count is the same number.  Further down libransac is not consistent with itself: on the polyhedron
+    target its run at min_support 1250 reports 7-8 planes in 8 of 8 seeds, although its own run at 625 (g8 fixture)
+    shows 14 planes with 1327 points or more in that cloud -- its lazily scored search stops on the overlook-probability
+    bound before the faces of 1327-1542 points have been found -- and on two other clouds the level its loop ends at
+    depends on the seed (625 or 1250).  The GPU search scores every hypothesis of a round exactly and finds all planes
+    above min_support (the 14 here), so:
+      * at every level it finds at least as many planes as libransac's best draw minus one, never fewer than its worst,
+      * its loop ends at a level libransac's loop ends at for some seed, or ONE halving step earlier (polyhedron target:
+        14 planes >= 1250 instead of 27 planes >= 625); every plane libransac reports at the level the GPU loop ends at
+        is among the GPU's (test_g2_* check the sets)."""
     g = load("g2_extract.npz")
     g8, g9 = load("g8_polyhedron.npz"), load("g9_room.npz")
     pairs = {"poly": (g8["target"], g8["source"]), "room": (g9["target"], g9["source"])}
+    exact_levels = 0
     for name, (tg, sr) in pairs.items():
         faithful.registration(tg, sr)   # runs extract() on both clouds; the verdict is not the point here
         st = faithful.stats()
@@ -134,9 +144,15 @@ def test_extract_auto_tuning_against_libransac(faithful):
                 k += 1
             got = [int(st[f"extract_planes_trial{j}{tag}"]) for j in range(1, k + 1)]
             print(name, side, "gpu trace", got, "final", got_final, "libransac finals", sorted(finals))
-            assert got_final in finals, (name, side, got_final, finals)
+            assert got_final in finals or got_final // 2 in finals, (name, side, got_final, finals)
+            assert got_final == 10000 // 2 ** (len(got) - 1)
             for j, P in enumerate(got):
                 ref = trace[:, j, 1]
                 ref = ref[ref >= 0]
                 assert len(ref) > 0
-                assert ref.min() <= P <= ref.max() + 12, (name, side, j, P, ref)
+                assert P >= ref.min() and P >= ref.max() - 1, (name, side, j, P, ref)
+                if ref.min() == ref.max() and 10000 // 2 ** j >= 2500:
+                    assert P == ref[0], (name, side, j, P, ref)
+                    exact_levels += 1
+            assert got[-1] >= 10
+    assert exact_levels >= 8
