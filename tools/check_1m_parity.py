@@ -15,7 +15,7 @@ orc = Oracle()
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
 for seed in (0, 1):
     tg, sr, Tgt = make_pair(n, seed=seed)
-    ctx = plade_amd.Context(0, dump=1)
+    ctx = plade_amd.Context(0, dump=1, orient_normals=1)
     ok, T = ctx.registration(tg, sr)
     d = ctx.dump()
     tp = (d["tgt_planes"].reshape(-1, 4), d["tgt_plane_offsets"], d["tgt_plane_idx"])

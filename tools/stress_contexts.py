@@ -14,7 +14,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 60000
 workers = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 8
 pairs = [make_pair(n, seed=s) for s in (3, 4)]
-ref = plade_amd.Context(0, dump=1)
+ref = plade_amd.Context(0, dump=1, orient_normals=1)
 want, want_dump = [], []
 for (tg, sr, _) in pairs:
     want.append(ref.registration(tg, sr))
@@ -25,7 +25,7 @@ lock = threading.Lock()
 
 
 def work(w):
-    c = plade_amd.Context(0, dump=1)
+    c = plade_amd.Context(0, dump=1, orient_normals=1)
     for rep in range(reps):
         for i, (tg, sr, _) in enumerate(pairs):
             ok, T = c.registration(tg, sr)

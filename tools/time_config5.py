@@ -15,7 +15,7 @@ t0 = time.perf_counter()
 room = (30.0, 24.0, 6.0) if boxes > 8 else None      # a larger hall takes the extra furniture
 tg, sr, Tgt = make_pair(n, seed=0, n_boxes=boxes, room=room)
 print(f"generated {len(tg)} + {len(sr)} points in {time.perf_counter() - t0:.1f} s", flush=True)
-ctx = plade_amd.Context(0, max_planes=100, max_candidates=10000, init_min_support=int(os.environ.get("MIN_SUPPORT", "10000")))
+ctx = plade_amd.Context(0, orient_normals=1, max_planes=100, max_candidates=10000, init_min_support=int(os.environ.get("MIN_SUPPORT", "10000")))
 ct, cs = ctx.upload(tg), ctx.upload(sr)
 for it in range(3):
     t0 = time.perf_counter()

@@ -13,7 +13,7 @@ from plade_amd.synth import make_pair
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
 pairs = [make_pair(n, seed=s) for s in range(2)]
 for M in (1, 2, 3, 4, 6):
-    ctxs = [plade_amd.Context(0) for _ in range(M)]
+    ctxs = [plade_amd.Context(0, orient_normals=1) for _ in range(M)]
     clouds = [[(c.upload(tg), c.upload(sr)) for (tg, sr, _) in pairs] for c in ctxs]
     K = 12
     errs = []

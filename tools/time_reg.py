@@ -8,7 +8,7 @@ from plade_amd.synth import make_pair
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
 tg, sr, Tgt = make_pair(n, seed=0)
-ctx = plade_amd.Context(0)
+ctx = plade_amd.Context(0, orient_normals=1)
 ct, cs = ctx.upload(tg), ctx.upload(sr)
 for it in range(4):
     t = time.time()
