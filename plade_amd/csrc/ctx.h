@@ -46,6 +46,11 @@ inline void relax_timer_slack() {
 }
 }  // namespace plade
 
+namespace plade {
+// look-back words and tile ticket of the single-launch scans (prims.hip: never reset, see scan_ticket)
+struct ScanWork { DBuf<uint64_t> state; DBuf<uint32_t> ticket; uint32_t base = 0, gen = 0; };
+}  // namespace plade
+
 struct plade_cloud {
     plade::CloudDev dev;
     std::vector<float> host_copy;  // pos_nrm kept for the small host-side gathers
@@ -169,6 +174,7 @@ struct plade_ctx {
         pending_reads.clear();
         read_arena_used = 0;
     }
+    plade::ScanWork scan;
     // generic scratch
     plade::DBuf<char> scratch[8];
     plade::HBuf<char> pinned[4];

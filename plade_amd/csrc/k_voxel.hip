@@ -20,13 +20,21 @@
 namespace plade {
 
 // ------------------------------------------------------------------------------------------------
-__global__ void k_voxel_keys(const float *__restrict__ xyz, uint32_t stride, const uint32_t *__restrict__ item_point,
-                             const uint32_t *__restrict__ item_group, uint32_t n_items, float inv, int lminx, int lminy,
-                             int lminz, int bx, int by, int bz, uint64_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+// (a) keys: item i -> packed (group | k | j | i-voxel) key.  The whole-cloud call reads the SoA copy of the cloud
+//     (coalesced 4 B/lane streams); item lists (per-plane clouds) gather 12 of the 24 B of an AoS record.
+__global__ void k_voxel_keys(const float *__restrict__ xyz, uint32_t stride, const float *__restrict__ sx,
+                             const float *__restrict__ sy, const float *__restrict__ sz,
+                             const uint32_t *__restrict__ item_point, const uint32_t *__restrict__ item_group,
+                             uint32_t n_items, float inv, int lminx, int lminy, int lminz, int bx, int by, int bz,
+                             uint64_t *__restrict__ keys, uint32_t *__restrict__ vals) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_items) return;
-    const uint32_t p = item_point ? item_point[i] : i;
-    const float x = xyz[(size_t)p * stride], y = xyz[(size_t)p * stride + 1], z = xyz[(size_t)p * stride + 2];
+    float x, y, z;
+    if (!item_point && sx) { x = sx[i]; y = sy[i]; z = sz[i]; }
+    else {
+        const uint32_t p = item_point ? item_point[i] : i;
+        x = xyz[(size_t)p * stride]; y = xyz[(size_t)p * stride + 1]; z = xyz[(size_t)p * stride + 2];
+    }
     // voxel_grid.hpp:330-332: floor(x * inverse_leaf_size) (fp32), then the integer offset
     const uint64_t lx = (uint64_t)((int)floorf(x * inv) - lminx);
     const uint64_t ly = (uint64_t)((int)floorf(y * inv) - lminy);
@@ -36,65 +44,137 @@ __global__ void k_voxel_keys(const float *__restrict__ xyz, uint32_t stride, con
     vals[i] = i;
 }
 
-__global__ void k_head_flags(const uint64_t *__restrict__ keys, uint32_t n, uint32_t *__restrict__ flags) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    flags[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u;
+// (b) after the sort, ONE launch: the runs of equal keys (= voxels) are numbered by a decoupled look-back scan of the
+//     run-head flags (heads[s] = first sorted position of voxel s, seg_group[s] = its group, *n_seg = their number), and
+//     the items' coordinates are gathered into sorted order (coalesced stores), so that the summation kernel streams
+//     contiguous memory.  Tiles of 4096 sorted positions.
+constexpr int VR_T = 256, VR_I = 16, VR_TILE = VR_T * VR_I;
+constexpr uint64_t VR_AGG = 1ull << 32, VR_PREFIX = 2ull << 32, VR_STATUS = 3ull << 32;
+__global__ __launch_bounds__(VR_T) void k_voxel_runs(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals,
+                                                      uint32_t n, const float *__restrict__ xyz, uint32_t stride,
+                                                      const uint32_t *__restrict__ item_point, int group_shift,
+                                                      uint64_t *__restrict__ state, uint32_t *__restrict__ ticket, uint32_t base,
+                                                      uint32_t gen, uint32_t *__restrict__ heads, uint32_t *__restrict__ seg_group,
+                                                      uint32_t *__restrict__ n_seg, float *__restrict__ ox, float *__restrict__ oy,
+                                                      float *__restrict__ oz) {
+    __shared__ uint32_t s_tile, s_w[VR_T / 64], s_excl;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_tile = atomicAdd(ticket, 1u) - base;
+    __syncthreads();
+    const uint32_t tile = s_tile;
+    // the gather first: its loads are in flight while the scan part runs
+    float gx[VR_I], gy[VR_I], gz[VR_I];
+#pragma unroll
+    for (int q = 0; q < VR_I; ++q) {
+        const uint32_t j = tile * VR_TILE + q * VR_T + tid;
+        if (j < n) {
+            const uint32_t it = vals[j];
+            const uint32_t p = item_point ? item_point[it] : it;
+            const float *r = xyz + (size_t)p * stride;
+            gx[q] = r[0]; gy[q] = r[1]; gz[q] = r[2];
+        }
+    }
+    const uint32_t first = tile * VR_TILE + tid * VR_I;
+    uint64_t k[VR_I + 1];
+    k[0] = (first > 0 && first <= n) ? keys[first - 1] : ~0ull;
+#pragma unroll
+    for (int q = 0; q < VR_I; ++q) k[q + 1] = first + q < n ? keys[first + q] : ~0ull;
+    uint32_t fl = 0, sum = 0;
+#pragma unroll
+    for (int q = 0; q < VR_I; ++q) {
+        const bool head = first + q < n && (first + q == 0 || k[q + 1] != k[q]);
+        fl |= (head ? 1u : 0u) << q;
+        sum += head;
+    }
+    uint32_t incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += o;
+    }
+    if (lane == 63) s_w[wave] = incl;
+    __syncthreads();
+    uint32_t agg = 0, woff = 0;
+    for (int w = 0; w < VR_T / 64; ++w) { if (w < wave) woff += s_w[w]; agg += s_w[w]; }
+    const uint64_t tag = (uint64_t)gen << 34;
+    if (wave == 0) {
+        if (lane == 0)
+            __hip_atomic_store(state + tile, tag | (tile == 0 ? VR_PREFIX : VR_AGG) | agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t excl = 0;
+        if (tile > 0) {
+            int t = (int)tile - 1;
+            for (;;) {
+                const int idx = t - lane;
+                uint64_t st = tag | VR_PREFIX;
+                if (idx >= 0) st = __hip_atomic_load(state + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const bool ready = (st >> 34) == gen && (st & VR_STATUS) != 0ull;
+                const unsigned long long not_ready = __ballot(!ready), is_prefix = __ballot(ready && (st & VR_PREFIX));
+                const int first_bad = not_ready ? __ffsll((long long)not_ready) - 1 : 64;
+                const int first_pre = is_prefix ? __ffsll((long long)is_prefix) - 1 : 64;
+                const int take = first_pre < first_bad ? first_pre + 1 : first_bad;
+                uint32_t part = lane < take ? (uint32_t)st : 0u;
+                for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
+                excl += part;
+                if (first_pre < first_bad) break;
+                t -= take;
+            }
+            if (lane == 0)
+                __hip_atomic_store(state + tile, tag | VR_PREFIX | (uint64_t)(excl + agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (lane == 0) s_excl = excl;
+    }
+    __syncthreads();
+    uint32_t rank = s_excl + woff + incl - sum;
+#pragma unroll
+    for (int q = 0; q < VR_I; ++q)
+        if (fl & (1u << q)) {
+            heads[rank] = first + q;
+            seg_group[rank] = (uint32_t)(k[q + 1] >> group_shift);
+            ++rank;
+        }
+    if ((uint64_t)tile * VR_TILE + VR_TILE >= n && tid == VR_T - 1) *n_seg = s_excl + agg;   // the last tile
+#pragma unroll
+    for (int q = 0; q < VR_I; ++q) {
+        const uint32_t j = tile * VR_TILE + q * VR_T + tid;
+        if (j < n) { ox[j] = gx[q]; oy[j] = gy[q]; oz[j] = gz[q]; }
+    }
 }
 
-__global__ void k_heads(const uint32_t *__restrict__ flags, const uint32_t *__restrict__ seg, uint32_t n,
-                        uint32_t *__restrict__ heads) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    if (flags[i]) heads[seg[i]] = i;
-}
-
-__global__ void k_voxel_centroids(const float *__restrict__ xyz, uint32_t stride,
-                                  const uint32_t *__restrict__ item_point, const uint64_t *__restrict__ keys,
-                                  const uint32_t *__restrict__ vals, const uint32_t *__restrict__ heads,
-                                  uint32_t n_seg, uint32_t n_items, int group_shift, float *__restrict__ out_xyz,
-                                  uint32_t *__restrict__ out_group) {
-    uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+// (c) centroids: one lane per voxel adds its points in ascending sorted position (= ascending item order inside the
+//     voxel: the sort is stable) -- the fp32 sum order of the oracle's sort_mode 1 -- from contiguous memory;
+//     centroid = fp32 sum / fp32 count (accumulators.hpp:65-84).  Workgroup 0 also derives the groups' offsets
+//     (first voxel of every group, empty groups included) by binary search in the voxels' group ids.
+__global__ __launch_bounds__(128) void k_voxel_centroids(const float *__restrict__ sx, const float *__restrict__ sy,
+                                                         const float *__restrict__ sz, const uint32_t *__restrict__ heads,
+                                                         const uint32_t *__restrict__ seg_group, const uint32_t *__restrict__ n_seg_p,
+                                                         uint32_t n_items, uint32_t n_groups, float *__restrict__ out_xyz,
+                                                         uint32_t *__restrict__ group_offsets) {
+    const uint32_t n_seg = *n_seg_p;
+    if (blockIdx.x == 0)
+        for (uint32_t g = threadIdx.x; g <= n_groups; g += blockDim.x) {
+            uint32_t lo = 0, hi = n_seg;   // first voxel whose group is >= g
+            while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (seg_group[mid] < g) lo = mid + 1; else hi = mid; }
+            group_offsets[g] = lo;
+        }
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_seg) return;
     const uint32_t b = heads[s], e = (s + 1 < n_seg) ? heads[s + 1] : n_items;
     float ax = 0.f, ay = 0.f, az = 0.f;
-    for (uint32_t j = b; j < e; ++j) {
-        const uint32_t it = vals[j];
-        const uint32_t p = item_point ? item_point[it] : it;
-        ax += xyz[(size_t)p * stride];
-        ay += xyz[(size_t)p * stride + 1];
-        az += xyz[(size_t)p * stride + 2];
-    }
+    for (uint32_t j = b; j < e; ++j) { ax += sx[j]; ay += sy[j]; az += sz[j]; }
     const float cnt = (float)(e - b);
     out_xyz[3 * (size_t)s] = ax / cnt;
     out_xyz[3 * (size_t)s + 1] = ay / cnt;
     out_xyz[3 * (size_t)s + 2] = az / cnt;
-    if (out_group) out_group[s] = (uint32_t)(keys[b] >> group_shift);
 }
 
-__global__ void k_group_offsets(const uint32_t *__restrict__ seg_group, uint32_t n_seg, uint32_t n_groups,
-                                uint32_t *__restrict__ offsets /* n_groups + 1, pre-filled with n_seg */) {
-    uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= n_seg) return;
-    const uint32_t g = seg_group[s];
-    if (s == 0 || seg_group[s - 1] != g) atomicMin(&offsets[g], s);
-}
-
-__global__ void k_fix_offsets(uint32_t *__restrict__ offsets, uint32_t n_groups, uint32_t n_seg) {
-    // empty groups inherit the next group's start (single thread; n_groups is tiny)
-    if (blockIdx.x || threadIdx.x) return;
-    offsets[n_groups] = n_seg;
-    for (int g = (int)n_groups - 1; g >= 0; --g)
-        if (offsets[g] > offsets[g + 1]) offsets[g] = offsets[g + 1];
-}
-
-uint32_t VoxelWork::run(plade_ctx *ctx, const float *d_xyz, uint32_t stride, const uint32_t *d_item_point,
-                        const uint32_t *d_item_group, uint32_t n_items, uint32_t n_groups, float leaf,
-                        const float bbox_min[3], const float bbox_max[3]) {
+void VoxelWork::enqueue(plade_ctx *ctx, const float *d_xyz, uint32_t stride, const float *d_soa_x, const float *d_soa_y,
+                        const float *d_soa_z, const uint32_t *d_item_point, const uint32_t *d_item_group, uint32_t n_items,
+                        uint32_t n_groups, float leaf, const float bbox_min[3], const float bbox_max[3]) {
     n_out = 0;
+    n_pending = 0;
     PLADE_REQUIRE(leaf > 0.f, PLADE_EINVAL, "voxel: leaf must be positive");
     PLADE_REQUIRE(n_groups >= 1 && n_groups <= 1024, PLADE_ELIMIT, "voxel: at most 1024 point groups");
-    if (n_items == 0) return 0;
+    if (n_items == 0) return;
     const float inv = 1.f / leaf;
     const int lmin[3] = {(int)floorf(bbox_min[0] * inv), (int)floorf(bbox_min[1] * inv), (int)floorf(bbox_min[2] * inv)};
     const int lmax[3] = {(int)floorf(bbox_max[0] * inv), (int)floorf(bbox_max[1] * inv), (int)floorf(bbox_max[2] * inv)};
@@ -113,35 +193,42 @@ uint32_t VoxelWork::run(plade_ctx *ctx, const float *d_xyz, uint32_t stride, con
     auto bits_for = [](int64_t range) { int b = 1; while (((int64_t)1 << b) <= range) ++b; return b; };
     const int bx = bits_for((int64_t)lmax[0] - lmin[0]), by = bits_for((int64_t)lmax[1] - lmin[1]), bz = bits_for((int64_t)lmax[2] - lmin[2]);
     keys.ensure(n_items); keys2.ensure(n_items); vals.ensure(n_items); vals2.ensure(n_items);
-    flags.ensure((size_t)n_items + 1); seg.ensure((size_t)n_items + 1);
+    sorted_xyz.ensure(3 * (size_t)n_items + 4);
+    heads.ensure((size_t)n_items + 1);
+    seg_group.ensure((size_t)n_items + 1);
+    out_xyz.ensure((size_t)n_items * 3 + 4);     // upper bound: one voxel per item
+    group_offsets.ensure((size_t)n_groups + 2);
+    count.ensure(4);
     const unsigned nb = cdiv(n_items, 256);
-    hipLaunchKernelGGL(k_voxel_keys, dim3(nb), dim3(256), 0, ctx->stream, d_xyz, stride, d_item_point, d_item_group,
-                       n_items, inv, lmin[0], lmin[1], lmin[2], bx, by, bz, keys.p, vals.p);
+    hipLaunchKernelGGL(k_voxel_keys, dim3(nb), dim3(256), 0, ctx->stream, d_xyz, stride, d_soa_x, d_soa_y, d_soa_z, d_item_point,
+                       d_item_group, n_items, inv, lmin[0], lmin[1], lmin[2], bx, by, bz, keys.p, vals.p);
     int gbits = 0;
     while ((1u << gbits) < n_groups) ++gbits;
     sort_pairs_u64(ctx, keys.p, keys2.p, vals.p, vals2.p, n_items, bx + by + bz + gbits);
-    hipLaunchKernelGGL(k_head_flags, dim3(nb), dim3(256), 0, ctx->stream, keys2.p, n_items, flags.p);
-    HIP_TRY(hipMemsetAsync(flags.p + n_items, 0, 4, ctx->stream));
-    exclusive_scan_u32(ctx, flags.p, seg.p, (size_t)n_items + 1);
-    uint32_t n_seg = 0;
-    ctx->d2h(&n_seg, seg.p + n_items, 4);
-    ctx->sync();
-    heads.ensure((size_t)n_seg + 1);
-    hipLaunchKernelGGL(k_heads, dim3(nb), dim3(256), 0, ctx->stream, flags.p, seg.p, n_items, heads.p);
-    out_xyz.ensure((size_t)n_seg * 3 + 4);
-    seg_group.ensure((size_t)n_seg + 1);
-    hipLaunchKernelGGL(k_voxel_centroids, dim3(cdiv(n_seg, 128)), dim3(128), 0, ctx->stream, d_xyz, stride, d_item_point,
-                       keys2.p, vals2.p, heads.p, n_seg, n_items, bx + by + bz, out_xyz.p, seg_group.p);
-    group_offsets.ensure((size_t)n_groups + 2);
-    std::vector<uint32_t> init(n_groups + 1, n_seg);
-    ctx->h2d(group_offsets.p, init.data(), (n_groups + 1) * 4);
-    hipLaunchKernelGGL(k_group_offsets, dim3(cdiv(n_seg, 256)), dim3(256), 0, ctx->stream, seg_group.p, n_seg, n_groups,
-                       group_offsets.p);
-    hipLaunchKernelGGL(k_fix_offsets, dim3(1), dim3(1), 0, ctx->stream, group_offsets.p, n_groups, n_seg);
+    const ScanTicket t = scan_ticket(ctx, n_items, VR_TILE);
+    float *ox = sorted_xyz.p, *oy = ox + n_items, *oz = oy + n_items;
+    hipLaunchKernelGGL(k_voxel_runs, dim3(t.tiles), dim3(VR_T), 0, ctx->stream, keys2.p, vals2.p, n_items, d_xyz, stride, d_item_point,
+                       bx + by + bz, t.state, t.ticket, t.base, t.gen, heads.p, seg_group.p, count.p, ox, oy, oz);
+    hipLaunchKernelGGL(k_voxel_centroids, dim3(cdiv(n_items, 128)), dim3(128), 0, ctx->stream, ox, oy, oz, heads.p, seg_group.p,
+                       count.p, n_items, n_groups, out_xyz.p, group_offsets.p);
     HIP_TRY(hipGetLastError());
-    ctx->sync();  // `init` must outlive the async copy
-    n_out = n_seg;
-    return n_seg;
+    ctx->d2h(&n_pending_host, count.p, 4);   // valid after the next sync of this stream
+    n_pending = 1;
+}
+
+uint32_t VoxelWork::finish(plade_ctx *ctx) {
+    if (!n_pending) return n_out;
+    ctx->sync();
+    n_pending = 0;
+    n_out = n_pending_host;
+    return n_out;
+}
+
+uint32_t VoxelWork::run(plade_ctx *ctx, const float *d_xyz, uint32_t stride, const uint32_t *d_item_point,
+                        const uint32_t *d_item_group, uint32_t n_items, uint32_t n_groups, float leaf,
+                        const float bbox_min[3], const float bbox_max[3]) {
+    enqueue(ctx, d_xyz, stride, nullptr, nullptr, nullptr, d_item_point, d_item_group, n_items, n_groups, leaf, bbox_min, bbox_max);
+    return finish(ctx);
 }
 
 // ------------------------------------------------------------------------------------------------

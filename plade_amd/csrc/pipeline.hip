@@ -97,15 +97,9 @@ bool prepare_side(plade_ctx *ctx, const char *tag, const CloudDev &cloud, const 
                   float desc_scale, bool is_target, PairTableDev &pairs, Side &S) {
     const uint32_t P = pl.P;
     Clock::time_point tp0 = Clock::now();
-    // whole cloud: DownSamplePointCloud (plade.cpp:77-79 / :292-294)
-    S.n_ds = S.vox_all.run(ctx, cloud.aos.p, 6, nullptr, nullptr, cloud.n, 1, leaf, cloud.bbmin, cloud.bbmax);
-    if (S.n_ds == 0) return false;
-    S.ds.resize(3 * (size_t)S.n_ds);
-    S.d_ds_soa.ensure(3 * (size_t)S.n_ds + 4);
-    S.d_ds.swap(S.vox_all.out_xyz);   // the result becomes d_ds, the work area takes last call's buffer back
-    ctx->d2h(S.ds.data(), S.d_ds.p, 12 * (size_t)S.n_ds);
-    deinterleave3(ctx, S.d_ds.p, S.n_ds, S.d_ds_soa.p, S.d_ds_soa.p + S.n_ds, S.d_ds_soa.p + 2 * (size_t)S.n_ds);
-    // per-plane clouds in one pass (plade.cpp:93-105 / :308-319)
+    // whole cloud: DownSamplePointCloud (plade.cpp:77-79 / :292-294) and the per-plane clouds in one pass
+    // (plade.cpp:93-105 / :308-319): both voxel-grid runs are queued before the host waits for either
+    S.vox_all.enqueue(ctx, cloud.aos.p, 6, cloud.x(), cloud.y(), cloud.z(), nullptr, nullptr, cloud.n, 1, leaf, cloud.bbmin, cloud.bbmax);
     const uint32_t n_items = (uint32_t)pl.offsets[P];
     S.d_items.ensure((size_t)n_items + 4); S.d_groups.ensure((size_t)n_items + 4); S.d_offs.ensure((size_t)P + 2);
     if (pl.d_idx) HIP_TRY(hipMemcpyAsync(S.d_items.p, pl.d_idx, 4 * (size_t)n_items, hipMemcpyDeviceToDevice, ctx->stream));
@@ -114,8 +108,16 @@ bool prepare_side(plade_ctx *ctx, const char *tag, const CloudDev &cloud, const 
     if (n_items)
         hipLaunchKernelGGL(k_expand_groups, dim3(cdiv(n_items, 256)), dim3(256), 0, ctx->stream, S.d_offs.p, P, n_items,
                            S.d_groups.p);
-    const uint32_t n_pds = S.vox_planes.run(ctx, cloud.aos.p, 6, S.d_items.p, S.d_groups.p, n_items, P, leaf, cloud.bbmin,
-                                            cloud.bbmax);
+    S.vox_planes.enqueue(ctx, cloud.aos.p, 6, nullptr, nullptr, nullptr, S.d_items.p, S.d_groups.p, n_items, P, leaf, cloud.bbmin,
+                         cloud.bbmax);
+    S.n_ds = S.vox_all.finish(ctx);
+    const uint32_t n_pds = S.vox_planes.finish(ctx);
+    if (S.n_ds == 0) return false;
+    S.ds.resize(3 * (size_t)S.n_ds);
+    S.d_ds_soa.ensure(3 * (size_t)S.n_ds + 4);
+    S.d_ds.swap(S.vox_all.out_xyz);   // the result becomes d_ds, the work area takes last call's buffer back
+    ctx->d2h(S.ds.data(), S.d_ds.p, 12 * (size_t)S.n_ds);
+    deinterleave3(ctx, S.d_ds.p, S.n_ds, S.d_ds_soa.p, S.d_ds_soa.p + S.n_ds, S.d_ds_soa.p + 2 * (size_t)S.n_ds);
     S.plane_ds.resize(3 * (size_t)n_pds);
     S.pcl.off.resize((size_t)P + 1);
     S.pcl.xyz.swap(S.vox_planes.out_xyz);

@@ -1,5 +1,5 @@
-// plade_amd/csrc/prims.h -- device-wide sort/scan plumbing: radix_sort.hip for the big sorts, rocPRIM (via
-// hipCUB) for scans and small sorts; the only translation unit that includes the heavy templates is prims.hip.
+// plade_amd/csrc/prims.h -- device-wide sort/scan plumbing: radix_sort.hip for the big sorts, a single-launch scan, and
+// rocPRIM's block sort for sorts of a few thousand items; the only translation unit that includes rocPRIM is prims.hip.
 #pragma once
 #include "ctx.h"
 
@@ -15,8 +15,12 @@ void radix_sort_pairs_u32(plade_ctx *ctx, const uint32_t *keys_in, uint32_t *key
                           uint32_t *vals_out, size_t n, int bits);
 void radix_sort_pairs_u64(plade_ctx *ctx, const uint64_t *keys_in, uint64_t *keys_out, const uint32_t *vals_in,
                           uint32_t *vals_out, size_t n, int bits);
-// exclusive prefix sums
+// exclusive prefix sum, one launch (decoupled look-back)
 void exclusive_scan_u32(plade_ctx *ctx, const uint32_t *in, uint32_t *out, size_t n);
-void exclusive_scan_u64(plade_ctx *ctx, const uint64_t *in, uint64_t *out, size_t n);
+// Look-back words + tile ticket for ONE launch of a decoupled look-back kernel over `n` items in tiles of `tile_items`
+// (the scan above, the voxel-run kernel): a tile takes ticket = atomicAdd(ticket, 1) - base, its word is state[tile],
+// tagged with gen in bits 34..63, status in bits 32..33 (1 aggregate, 2 inclusive prefix), value in bits 0..31.
+struct ScanTicket { uint64_t *state; uint32_t *ticket; uint32_t base, gen, tiles; };
+ScanTicket scan_ticket(plade_ctx *ctx, size_t n, uint32_t tile_items);
 
 }  // namespace plade

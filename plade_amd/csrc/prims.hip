@@ -1,6 +1,6 @@
-// plade_amd/csrc/prims.hip -- rocPRIM-backed sort/scan wrappers (plumbing, not a hot op).
+// plade_amd/csrc/prims.hip -- device-wide sort / scan plumbing: the big sorts are radix_sort.hip, the prefix sums the
+// single-launch scan below; rocPRIM's one-launch block sort still serves sorts of a few thousand items.
 #include "prims.h"
-#include <hipcub/hipcub.hpp>
 #include <rocprim/rocprim.hpp>
 
 namespace plade {
@@ -38,20 +38,110 @@ void sort_pairs_u64(plade_ctx *ctx, const uint64_t *ki, uint64_t *ko, const uint
     else sort_pairs<uint64_t>(ctx, ki, ko, vi, vo, n, bits);
 }
 
-void exclusive_scan_u32(plade_ctx *ctx, const uint32_t *in, uint32_t *out, size_t n) {
-    if (!n) return;
-    size_t tb = 0;
-    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, in, out, (int)n, ctx->stream));
-    void *t = temp(ctx, tb);
-    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(t, tb, in, out, (int)n, ctx->stream));
+// ------------------------------------------------------------------------------------------------
+// Exclusive prefix sum of u32 in ONE launch (decoupled look-back).  Tiles of 4096 items; a workgroup takes the next
+// tile by ticket (every predecessor is already running), publishes its aggregate, then its inclusive prefix, as a
+// 64-bit word (call generation | status | value): words of earlier calls never match the generation, so neither the
+// words nor the ticket counter are ever reset (the ticket base of a call is the host's running total).
+namespace {
+constexpr int SC_T = 256, SC_I = 16, SC_TILE = SC_T * SC_I;
+constexpr uint64_t SC_AGG = 1ull << 32, SC_PREFIX = 2ull << 32, SC_STATUS = 3ull << 32;
+
+__global__ __launch_bounds__(SC_T) void k_scan_u32(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, uint32_t n,
+                                                   uint64_t *__restrict__ state, uint32_t *__restrict__ ticket, uint32_t base,
+                                                   uint32_t gen) {
+    __shared__ uint32_t s_tile, s_w[SC_T / 64], s_excl;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_tile = atomicAdd(ticket, 1u) - base;
+    __syncthreads();
+    const uint32_t tile = s_tile;
+    const uint32_t first = tile * SC_TILE + tid * SC_I;
+    uint32_t v[SC_I];
+    if (first + SC_I <= n) {
+#pragma unroll
+        for (int q = 0; q < SC_I / 4; ++q) {
+            const uint4 t = *reinterpret_cast<const uint4 *>(in + first + 4 * q);
+            v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < SC_I; ++q) v[q] = first + q < n ? in[first + q] : 0u;
+    }
+    uint32_t sum = 0;
+#pragma unroll
+    for (int q = 0; q < SC_I; ++q) { const uint32_t t = v[q]; v[q] = sum; sum += t; }
+    uint32_t incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += o;
+    }
+    if (lane == 63) s_w[wave] = incl;
+    __syncthreads();
+    uint32_t agg = 0, woff = 0;
+    for (int w = 0; w < SC_T / 64; ++w) { if (w < wave) woff += s_w[w]; agg += s_w[w]; }
+    const uint64_t tag = (uint64_t)gen << 34;
+    if (wave == 0) {
+        if (lane == 0)
+            __hip_atomic_store(state + tile, tag | (tile == 0 ? SC_PREFIX : SC_AGG) | agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t excl = 0;
+        if (tile > 0) {
+            int t = (int)tile - 1;
+            for (;;) {   // a window of 64 predecessors per round
+                const int idx = t - lane;
+                uint64_t st = tag | SC_PREFIX;   // before the first tile: prefix 0
+                if (idx >= 0) st = __hip_atomic_load(state + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const bool ready = (st >> 34) == gen && (st & SC_STATUS) != 0ull;
+                const unsigned long long not_ready = __ballot(!ready), is_prefix = __ballot(ready && (st & SC_PREFIX));
+                const int first_bad = not_ready ? __ffsll((long long)not_ready) - 1 : 64;
+                const int first_pre = is_prefix ? __ffsll((long long)is_prefix) - 1 : 64;
+                const int take = first_pre < first_bad ? first_pre + 1 : first_bad;   // lanes [0, take) are consumed
+                uint32_t part = lane < take ? (uint32_t)st : 0u;
+                for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
+                excl += part;
+                if (first_pre < first_bad) break;
+                t -= take;
+            }
+            if (lane == 0)
+                __hip_atomic_store(state + tile, tag | SC_PREFIX | (uint64_t)(excl + agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (lane == 0) s_excl = excl;
+    }
+    __syncthreads();
+    const uint32_t off = s_excl + woff + incl - sum;
+    if (first + SC_I <= n) {
+#pragma unroll
+        for (int q = 0; q < SC_I / 4; ++q)
+            *reinterpret_cast<uint4 *>(out + first + 4 * q) = make_uint4(off + v[4 * q], off + v[4 * q + 1], off + v[4 * q + 2], off + v[4 * q + 3]);
+    } else {
+#pragma unroll
+        for (int q = 0; q < SC_I; ++q)
+            if (first + q < n) out[first + q] = off + v[q];
+    }
+}
+}  // namespace
+
+ScanTicket scan_ticket(plade_ctx *ctx, size_t n, uint32_t tile_items) {
+    ScanWork &w = ctx->scan;
+    const uint32_t tiles = cdiv(n, tile_items);
+    if (w.state.cap < tiles + 1 || !w.ticket.p) {   // fresh words must not look like this generation's
+        w.state.ensure((size_t)tiles + 1);
+        w.ticket.ensure(4);
+        HIP_TRY(hipMemsetAsync(w.state.p, 0, w.state.cap * 8, ctx->stream));
+        HIP_TRY(hipMemsetAsync(w.ticket.p, 0, 16, ctx->stream));
+        w.base = 0;
+    }
+    ScanTicket t{w.state.p, w.ticket.p, w.base, ++w.gen & 0x3fffffffu, tiles};
+    if (t.gen == 0) t.gen = w.gen = 1;
+    w.base += tiles;
+    return t;
 }
 
-void exclusive_scan_u64(plade_ctx *ctx, const uint64_t *in, uint64_t *out, size_t n) {
+void exclusive_scan_u32(plade_ctx *ctx, const uint32_t *in, uint32_t *out, size_t n) {
     if (!n) return;
-    size_t tb = 0;
-    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, in, out, (int)n, ctx->stream));
-    void *t = temp(ctx, tb);
-    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(t, tb, in, out, (int)n, ctx->stream));
+    PLADE_REQUIRE(n < (1ull << 32), PLADE_ELIMIT, "scan: too many items");
+    const ScanTicket t = scan_ticket(ctx, n, SC_TILE);
+    hipLaunchKernelGGL(k_scan_u32, dim3(t.tiles), dim3(SC_T), 0, ctx->stream, in, out, (uint32_t)n, t.state, t.ticket, t.base, t.gen);
 }
 
 }  // namespace plade

@@ -45,7 +45,8 @@ namespace {
 
 constexpr uint32_t R_H = 4096;          // hypotheses per sampling round
 constexpr uint32_t R_TOP = 48;          // candidate pool
-constexpr int R_B = 8;                  // acceptance chains per cloud and iteration
+constexpr int R_B = 8;                  // acceptance chains per cloud and iteration (16 gave the same batches: the pool
+                                        // rarely holds more than 8 mutually conflict-free planes)
 constexpr int R_G = RANSAC_SLOTS;
 constexpr uint32_t R_MAXP = 4096;       // accepted shapes per detect call
 constexpr uint32_t R_MAX_ROUNDS = 4000;
@@ -92,11 +93,11 @@ struct RResult;
 
 struct RState {
     // ---- parameters of the running detect call
-    uint32_t n, min_support, orient, active;
+    uint32_t n, min_support, orient, active, gen;   // gen: tag of the call in the result flag
     float eps, eps3, bitmap_eps, cos_t, overlook_p, bbmin[3], bbmax[3];
     uint64_t seed;
     // ---- loop state
-    uint32_t done, sampling, round, it;
+    uint32_t done, sampling, fresh, round, it;   // fresh: the pool holds this iteration's new leaders (not yet re-scored)
     uint32_t n_remaining, sub_unassigned;
     float drawn;
     uint32_t npool, nc;
@@ -108,12 +109,16 @@ struct RState {
     uint32_t aj_n, aj_chain[R_B], aj_slot[R_B], aj_out[R_B];   // aj_out: offset into out_idx, 0xffffffff = none
     int32_t aj_id[R_B];
     // ---- counters
-    uint32_t n_rounds, n_rescores, n_batches, n_accepts, n_mark_launches, n_mark_chains;
+    uint32_t n_rounds, n_rescores[2], n_batches, n_accepts, n_mark_launches, n_mark_chains;
+    // ---- accepted shapes (copied to the host-mapped result block when the call ends)
+    float acc_coef[R_MAXP][4];
+    uint32_t acc_support[R_MAXP], acc_offset[R_MAXP];
 };
 
 // Host-mapped, written by single device lanes, read by the host once `flag` says so.
 struct RResult {
-    uint32_t flag;                   // iterations completed, bit 31 = the detect call has finished
+    uint32_t flag;                   // bits 0-23 iterations completed, 24-30 tag of the detect call (a queued speculative
+                                     // iteration of the PREVIOUS call may still report), 31 = the call has finished
     uint32_t n_acc, out_off, err, remaining;
     uint32_t n_rounds, n_rescores, n_batches, n_accepts, n_mark_launches, n_mark_chains, pad;
     float coef[R_MAXP][4];
@@ -394,7 +399,7 @@ __device__ void state_from_hyp(PlaneState *st, float4 hyp, float4 pos) {
 // ------------------------------------------------------------------------------------------------
 // init: shapeIndex = -1 for the clouds that take part, loop state from the call's parameters
 struct RInitCloud {
-    uint32_t active, min_support, orient;
+    uint32_t active, min_support, orient, gen;
     float eps, eps3, bitmap_eps, cos_t, overlook_p, bbmin[3], bbmax[3];
     uint64_t seed;
 };
@@ -406,7 +411,7 @@ __global__ __launch_bounds__(TPB) void k_r_init(const RArgs A, const RInit I) {
     const RCloudArgs &C = A.c[g];
     const RInitCloud &P = I.c[g];
     if (!P.active) {
-        if (tile == 0 && threadIdx.x == 0) { C.st->active = 0; C.st->done = 1; C.st->nc = 0; C.st->aj_n = 0; C.st->npool = 0; C.st->sampling = 0; }
+        if (tile == 0 && threadIdx.x == 0) { C.st->active = 0; C.st->done = 1; C.st->nc = 0; C.st->aj_n = 0; C.st->npool = 0; C.st->sampling = 0; C.st->fresh = 0; }
         return;
     }
     const uint32_t base = tile * TILE + threadIdx.x * PPT;
@@ -415,15 +420,15 @@ __global__ __launch_bounds__(TPB) void k_r_init(const RArgs A, const RInit I) {
     }
     if (tile == 0 && threadIdx.x == 0) {
         RState *S = C.st;
-        S->n = C.cv.n; S->min_support = P.min_support; S->orient = P.orient; S->active = 1;
+        S->n = C.cv.n; S->min_support = P.min_support; S->orient = P.orient; S->active = 1; S->gen = P.gen;
         S->eps = P.eps; S->eps3 = P.eps3; S->bitmap_eps = P.bitmap_eps; S->cos_t = P.cos_t; S->overlook_p = P.overlook_p;
         for (int k = 0; k < 3; ++k) { S->bbmin[k] = P.bbmin[k]; S->bbmax[k] = P.bbmax[k]; }
         S->seed = P.seed;
         const bool nothing = C.cv.n < 3 || C.cv.n < P.min_support;   // RansacShapeDetector.cpp: no shape can reach minSupport
-        S->done = nothing ? 1u : 0u; S->sampling = nothing ? 0u : 1u; S->round = 0; S->it = 0;
+        S->done = nothing ? 1u : 0u; S->sampling = nothing ? 0u : 1u; S->fresh = 0; S->round = 0; S->it = 0;
         S->n_remaining = C.cv.n; S->sub_unassigned = 0; S->drawn = 0.f;
         S->npool = 0; S->nc = 0; S->n_acc = 0; S->out_off = 0; S->err = 0; S->aj_n = 0;
-        S->n_rounds = S->n_rescores = S->n_batches = S->n_accepts = S->n_mark_launches = S->n_mark_chains = 0;
+        S->n_rounds = S->n_rescores[0] = S->n_rescores[1] = S->n_batches = S->n_accepts = S->n_mark_launches = S->n_mark_chains = 0;
     }
 }
 
@@ -564,23 +569,32 @@ __device__ __forceinline__ bool same_plane(const float4 &a, const float4 &b, flo
     return fabsf(a.w - db) < 2 * eps;
 }
 
-// Leaders of a round: the hypotheses by estimated support, one representative per distinct plane (a greedy pass in
-// descending order that drops what duplicates an earlier pick = repeatedly take the best one alive and strike out
-// its duplicates).  One workgroup of 1024 lanes per cloud, four hypotheses per lane.
+// Leaders of a round: the hypotheses by estimated support, one representative per distinct plane -- a greedy pass in
+// descending order that drops what duplicates an earlier pick (= repeatedly take the best candidate alive and strike
+// out its duplicates).  One workgroup of 1024 lanes per cloud, four hypotheses per lane, two stages:
+//   (1) all lanes: every candidate is hashed by its quantised (orientation-free) plane into an LDS table that keeps
+//       the best key per slot; a candidate that lost its slot to a better candidate OF THE SAME PLANE is a duplicate
+//       the greedy pass would strike anyway and is dropped here (typically 4096 -> a few hundred survivors);
+//   (2) one wavefront runs the exact greedy pass over the survivors (each lane owns the entries lane, lane + 64, ...
+//       of the survivor list, so the only cross-lane traffic is the arg-max and the broadcast of the pick).
+constexpr int LEAD_SLOTS = 4096;
 __global__ __launch_bounds__(1024) void k_r_leaders(const RArgs A) {
     const RCloudArgs &C = A.c[blockIdx.x];
     RState *S = C.st;
     if (S->done || !S->sampling) return;
-    __shared__ unsigned long long s_red[16];
-    __shared__ uint32_t s_val[16];
-    __shared__ float4 s_new;
+    __shared__ unsigned long long s_tab[LEAD_SLOTS];
+    __shared__ unsigned long long s_lkey[R_H];
+    __shared__ float4 s_lpl[R_H];
+    __shared__ uint32_t s_val[16], s_cnt[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t sub_un = S->sub_unassigned, n_rem = S->n_remaining, ms = S->min_support;
     const float eps = S->eps;
     const double ratio = sub_un ? (double)n_rem / sub_un : 0.0;
     unsigned long long key[4];
     float4 pl[4];
+    uint32_t slot[4];
     uint32_t valid = 0;
+    for (int i = tid; i < LEAD_SLOTS; i += 1024) s_tab[i] = 0ull;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const uint32_t i = tid + q * 1024;
@@ -590,40 +604,77 @@ __global__ __launch_bounds__(1024) void k_r_leaders(const RArgs A) {
         valid += pos.w != 0.f;   // w: 0 no samples, 1 verified plane, 2 drawn but rejected
         const bool ok = pos.w == 1.f && c * ratio >= 0.5 * ms;
         key[q] = ok ? (((unsigned long long)c << 32) | (0xffffffffu - i)) : 0ull;   // count descending, index ascending
+        // orientation-free quantised plane: the largest component of the normal made positive
+        float4 cp = pl[q];
+        const float ax = fabsf(cp.x), ay = fabsf(cp.y), az = fabsf(cp.z);
+        const float lead = (ax >= ay && ax >= az) ? cp.x : (ay >= az ? cp.y : cp.z);
+        if (lead < 0.f) { cp.x = -cp.x; cp.y = -cp.y; cp.z = -cp.z; cp.w = -cp.w; }
+        const int qx = (int)floorf(cp.x * 8.f), qy = (int)floorf(cp.y * 8.f), qz = (int)floorf(cp.z * 8.f);
+        const int qd = ok ? (int)floorf(cp.w / (4.f * eps)) : 0;
+        slot[q] = ((uint32_t)qx * 73856093u ^ (uint32_t)qy * 19349663u ^ (uint32_t)qz * 83492791u ^ (uint32_t)qd * 2654435761u) & (LEAD_SLOTS - 1);
     }
     for (int d = 32; d >= 1; d >>= 1) valid += __shfl_xor(valid, d, 64);
     if (lane == 0) s_val[wave] = valid;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        if (key[q]) atomicMax(&s_tab[slot[q]], key[q]);
+    __syncthreads();
+    uint32_t mine = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if (!key[q]) continue;
+        const unsigned long long w = s_tab[slot[q]];
+        if (w != key[q]) {
+            const uint32_t widx = 0xffffffffu - (uint32_t)(w & 0xffffffffull);
+            if (same_plane(C.hyp[widx], pl[q], eps)) key[q] = 0ull;   // duplicate of a better candidate
+        }
+        mine += key[q] != 0ull;
+    }
+    // ordered compaction of the survivors
+    uint32_t incl = mine;
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += o;
+    }
+    if (lane == 63) s_cnt[wave] = incl;
+    __syncthreads();
+    uint32_t off = incl - mine, ns = 0;
+    for (int w = 0; w < 16; ++w) { if (w < wave) off += s_cnt[w]; ns += s_cnt[w]; }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        if (key[q]) { s_lkey[off] = key[q]; s_lpl[off] = pl[q]; ++off; }
+    __syncthreads();
+    if (wave != 0) return;
+    // exact greedy pass, one wavefront
     uint32_t npool = 0;
     for (; npool < R_TOP; ++npool) {
-        unsigned long long m = max(max(key[0], key[1]), max(key[2], key[3]));
-        for (int d = 32; d >= 1; d >>= 1) {
-            const unsigned long long o = __shfl_xor(m, d, 64);
-            m = o > m ? o : m;
+        unsigned long long m = 0ull;
+        uint32_t at = 0;
+        for (uint32_t e = lane; e < ns; e += 64) {
+            const unsigned long long k = s_lkey[e];
+            if (k > m) { m = k; at = e; }
         }
-        if (lane == 0) s_red[wave] = m;
-        __syncthreads();
-        unsigned long long best = 0;
-#pragma unroll
-        for (int w = 0; w < 16; ++w) best = s_red[w] > best ? s_red[w] : best;
+        unsigned long long best = m;
+        for (int d = 32; d >= 1; d >>= 1) {
+            const unsigned long long o = __shfl_xor(best, d, 64);
+            best = o > best ? o : best;
+        }
         if (best == 0ull) break;     // uniform
-        const uint32_t idx = 0xffffffffu - (uint32_t)(best & 0xffffffffull);
-        if ((uint32_t)tid == (idx & 1023u)) {
-            const int q = (int)(idx >> 10);
-            float4 v = pl[0];
-            if (q == 1) v = pl[1]; else if (q == 2) v = pl[2]; else if (q == 3) v = pl[3];
-            s_new = v;
-            S->pool_pl[npool] = v;
+        const int owner = __ffsll((long long)__ballot(m == best)) - 1;   // keys are unique
+        float4 nw = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (lane == owner) nw = s_lpl[at];
+        nw.x = __shfl(nw.x, owner, 64); nw.y = __shfl(nw.y, owner, 64); nw.z = __shfl(nw.z, owner, 64); nw.w = __shfl(nw.w, owner, 64);
+        if (lane == owner) {
+            const uint32_t idx = 0xffffffffu - (uint32_t)(best & 0xffffffffull);
+            S->pool_pl[npool] = nw;
             S->pool_pos[npool] = C.hyp_pos[idx];
         }
-        __syncthreads();
-        const float4 nw = s_new;
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-            if (key[q] && same_plane(nw, pl[q], eps)) key[q] = 0ull;   // strikes the pick itself too
+        for (uint32_t e = lane; e < ns; e += 64)
+            if (s_lkey[e] && same_plane(nw, s_lpl[e], eps)) s_lkey[e] = 0ull;   // strikes the pick itself too
     }
-    __syncthreads();
-    if (tid < (int)R_TOP) S->pool_cnt[tid] = 0;
-    if (tid == 0) {
+    if (lane < (int)R_TOP) S->pool_cnt[lane] = 0;
+    if (lane == 0) {
         uint32_t v = 0;
         for (int w = 0; w < 16; ++w) v += s_val[w];
         S->drawn += (float)v;
@@ -631,11 +682,13 @@ __global__ __launch_bounds__(1024) void k_r_leaders(const RArgs A) {
         S->round += 1;
         S->n_rounds += 1;
         S->sampling = 0;
+        S->fresh = 1;
     }
 }
 
 // K1: the pool re-scored on ALL unassigned points of its cloud: one HBM pass per cloud, the pool's planes in LDS
-__global__ __launch_bounds__(TPB) void k_r_rescore(const RArgs A) {
+// phase 0: what the previous iteration left in the pool; phase 1: the leaders of a round drawn in this iteration
+__global__ __launch_bounds__(TPB) void k_r_rescore(const RArgs A, int phase) {
     __shared__ float4 s_pl[HCHUNK];
     __shared__ uint32_t s_cnt[TPB / 64][HCHUNK];
     uint32_t tile;
@@ -643,7 +696,7 @@ __global__ __launch_bounds__(TPB) void k_r_rescore(const RArgs A) {
     const RCloudArgs &C = A.c[g];
     RState *S = C.st;
     const uint32_t np = S->npool;
-    if (S->done || np == 0) return;
+    if (S->done || np == 0 || (S->fresh != 0u) != (phase != 0)) return;
     if (threadIdx.x < np) s_pl[threadIdx.x] = S->pool_pl[threadIdx.x];
     const float eps = S->eps, cos_t = S->cos_t;
     Tile t;
@@ -665,7 +718,7 @@ __global__ __launch_bounds__(TPB) void k_r_rescore(const RArgs A) {
         const uint32_t tot = s_cnt[0][threadIdx.x] + s_cnt[1][threadIdx.x] + s_cnt[2][threadIdx.x] + s_cnt[3][threadIdx.x];
         if (tot) atomicAdd(&S->pool_cnt[threadIdx.x], tot);
     }
-    if (tile == 0 && threadIdx.x == 0) S->n_rescores += 1;
+    if (tile == 0 && threadIdx.x == 0) S->n_rescores[phase] += 1;
 }
 
 // CandidateFailureProbability (RansacShapeDetector.h:61-67, reqSamples = 3)
@@ -709,11 +762,17 @@ __device__ bool conflict_free(const float4 &a, const float4 &b, float eps, float
 // the rest is ordered by support, and the best candidate plus every further one whose support provably cannot touch
 // the supports already in the batch become this iteration's acceptance chains (accepting them concurrently equals
 // accepting them one by one).  One wavefront per cloud.
-__global__ __launch_bounds__(64) void k_r_select(const RArgs A) {
+__global__ __launch_bounds__(64) void k_r_select(const RArgs A, int phase) {
     const RCloudArgs &C = A.c[blockIdx.x];
     RState *S = C.st;
     const int lane = threadIdx.x;
-    if (S->done) { if (lane == 0) { S->nc = 0; S->aj_n = 0; } return; }
+    if (phase == 0) {
+        // leftovers of the previous iteration: prune + batch; an empty pool asks for a new round, which the kernels that
+        // follow in this same iteration draw
+        if (S->done || S->sampling) { if (lane == 0) { S->nc = 0; S->aj_n = 0; } return; }
+    } else {
+        if (S->done || !S->fresh) return;   // the batch (if any) was chosen in phase 0
+    }
     __shared__ float4 s_pl[R_TOP], s_pos[R_TOP];
     __shared__ uint32_t s_cnt[R_TOP], s_raw[R_TOP], s_keep[R_TOP];
     const uint32_t np = S->npool, ms = S->min_support;
@@ -731,7 +790,7 @@ __global__ __launch_bounds__(64) void k_r_select(const RArgs A) {
     if (keep) { s_pl[rank] = pl; s_pos[rank] = pos; s_cnt[rank] = cnt; }
     __syncthreads();
     if (np2 == 0) {
-        if (lane == 0) { S->npool = 0; S->nc = 0; S->aj_n = 0; next_round_or_stop(S); }
+        if (lane == 0) { S->npool = 0; S->nc = 0; S->aj_n = 0; S->fresh = 0; next_round_or_stop(S); }
         return;
     }
     const float eps = S->eps, cos_t = S->cos_t;
@@ -762,7 +821,7 @@ __global__ __launch_bounds__(64) void k_r_select(const RArgs A) {
         ch.hdr->pool_index = bi;
         state_from_hyp(&ch.hdr->st[0], s_pl[bi], s_pos[bi]);
     }
-    if (lane == 0) { S->npool = np2; S->nc = nb; S->aj_n = 0; S->n_batches += 1; }
+    if (lane == 0) { S->npool = np2; S->nc = nb; S->aj_n = 0; S->fresh = 0; S->n_batches += 1; }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1311,14 +1370,24 @@ __global__ __launch_bounds__(256) void k_r_fit(const RArgs A, int k) {
 __global__ __launch_bounds__(64) void k_r_decide(const RArgs A) {
     const RCloudArgs &C = A.c[blockIdx.x];
     RState *S = C.st;
-    if (threadIdx.x) return;
     RResult *R = C.res;
     if (!S->active) return;
-    const uint32_t nc = S->done ? 0u : S->nc;
+    // the chains' results are fetched by all lanes at once (one lane alone would pay a DRAM/L2 round trip per field)
+    __shared__ PlaneState s_st[R_B][4];
+    const uint32_t nc_all = S->done ? 0u : S->nc;
+    {
+        constexpr int WORDS = sizeof(PlaneState) / 4;
+        for (uint32_t i = threadIdx.x; i < nc_all * 4 * WORDS; i += 64) {
+            const uint32_t b = i / (4 * WORDS), r = i % (4 * WORDS);
+            reinterpret_cast<uint32_t *>(&s_st[b][0])[r] = reinterpret_cast<const uint32_t *>(&chain_of(C, b).hdr->st[0])[r];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+    const uint32_t nc = nc_all;
     uint32_t n_aj = 0;
     for (uint32_t b = 0; b < nc; ++b) {
-        const ChainPtr ch = chain_of(C, b);
-        const PlaneState *st = ch.hdr->st;
+        const PlaneState *st = s_st[b];
         S->n_accepts += 1;
         if (st[0].err == 1) { S->err = 1; S->done = 1; break; }   // connected-component bitmap too large
         int final_slot = 0;
@@ -1343,8 +1412,8 @@ __global__ __launch_bounds__(64) void k_r_decide(const RArgs A) {
         S->drawn = frac * frac * frac * S->drawn;    // std::pow(1.f - |S| / n, 3.f) * drawnCandidates
         S->n_remaining -= min(S->n_remaining, cand_size);
         // plane_extraction.cpp:134-149: shapes below min_support are skipped, d = -n.p with n re-normalised
-        R->support[id] = 0;
-        R->offset[id] = S->out_off;
+        S->acc_support[id] = 0;
+        S->acc_offset[id] = S->out_off;
         if (cand_size >= S->min_support) {
             float nn[3] = {cs.n[0], cs.n[1], cs.n[2]};
             float l = nn[0] * nn[0];
@@ -1356,8 +1425,8 @@ __global__ __launch_bounds__(64) void k_r_decide(const RArgs A) {
             if (S->orient) {  // mean inlier normal (the intent of plane_extraction.cpp:43-58)
                 if (cs.nsum[0] * nn[0] + cs.nsum[1] * nn[1] + cs.nsum[2] * nn[2] < 0) { nn[0] = -nn[0]; nn[1] = -nn[1]; nn[2] = -nn[2]; d = -d; }
             }
-            R->coef[id][0] = nn[0]; R->coef[id][1] = nn[1]; R->coef[id][2] = nn[2]; R->coef[id][3] = d;
-            R->support[id] = cand_size;
+            S->acc_coef[id][0] = nn[0]; S->acc_coef[id][1] = nn[1]; S->acc_coef[id][2] = nn[2]; S->acc_coef[id][3] = d;
+            S->acc_support[id] = cand_size;
             S->aj_out[n_aj] = S->out_off;
             S->out_off += cand_size;
         }
@@ -1382,12 +1451,27 @@ __global__ __launch_bounds__(64) void k_r_decide(const RArgs A) {
         }
     }
     S->it += 1;
-    R->n_acc = S->n_acc; R->out_off = S->out_off; R->err = S->err; R->remaining = S->n_remaining;
-    R->n_rounds = S->n_rounds; R->n_rescores = S->n_rescores; R->n_batches = S->n_batches; R->n_accepts = S->n_accepts;
-    R->n_mark_launches = S->n_mark_launches; R->n_mark_chains = S->n_mark_chains;
+    }
+    __syncthreads();
+    // The host-mapped block is written once, when the call ends (stores over PCIe are slow: all 64 lanes share them);
+    // until then the host only needs the iteration count.
+    const uint32_t done = S->done;
+    if (done) {
+        const uint32_t na = S->n_acc;
+        for (uint32_t i = threadIdx.x; i < 4 * na; i += 64) (&R->coef[0][0])[i] = (&S->acc_coef[0][0])[i];
+        for (uint32_t i = threadIdx.x; i < na; i += 64) { R->support[i] = S->acc_support[i]; R->offset[i] = S->acc_offset[i]; }
+        if (threadIdx.x == 0) {
+            R->n_acc = na; R->out_off = S->out_off; R->err = S->err; R->remaining = S->n_remaining;
+            R->n_rounds = S->n_rounds; R->n_rescores = S->n_rescores[0] + S->n_rescores[1]; R->n_batches = S->n_batches; R->n_accepts = S->n_accepts;
+            R->n_mark_launches = S->n_mark_launches; R->n_mark_chains = S->n_mark_chains;
+        }
+    }
     __threadfence_system();
-    *reinterpret_cast<volatile uint32_t *>(&R->flag) = S->it | (S->done ? 0x80000000u : 0u);
+    __syncthreads();
+    if (threadIdx.x == 0)
+        *reinterpret_cast<volatile uint32_t *>(&R->flag) = (S->it & 0xffffffu) | ((S->gen & 0x7fu) << 24) | (done ? 0x80000000u : 0u);
 }
+
 
 // Point removal + output index lists of the accepted candidates: the chosen slot's list entries that belong to the
 // largest component, in list order (ordered compaction of the selection masks; offsets from the per-tile counts as in
@@ -1480,6 +1564,7 @@ struct RansacSlot {
 struct RansacWork {
     RansacSlot slot[R_G];
     int ng = 0;
+    uint32_t generation = 0;         // detect calls issued on this work area
     DBuf<uint32_t> keys_in, vals_in, keys, perm;
     std::map<uint64_t, hipGraphExec_t> graphs;   // the iteration sequence, keyed on everything baked into its launches
     ~RansacWork() { for (auto &kv : graphs) if (kv.second) (void)hipGraphExecDestroy(kv.second); }
@@ -1541,7 +1626,7 @@ uint64_t hash_bytes(const void *p, size_t n) {
     return h;
 }
 
-// one iteration of the detect loop: 27 launches
+// one iteration of the detect loop: 29 launches
 void enqueue_iteration(plade_ctx *ctx, const RArgs &A) {
     hipStream_t st = ctx->stream;
     const uint32_t ng = A.ng;
@@ -1551,13 +1636,19 @@ void enqueue_iteration(plade_ctx *ctx, const RArgs &A) {
         nb_max = std::max(nb_max, A.c[g].L.nb);
         sub_tiles = std::max(sub_tiles, cdiv(A.c[g].n_sub, TILE));
     }
+    // what the previous iteration left in the pool: re-score, prune, pick a batch ...
+    ctx->ev_begin("score_multi", 0.0);
+    hipLaunchKernelGGL(k_r_rescore, dim3(tiles), dim3(TPB), 0, st, A, 0);
+    ctx->ev_end();
+    hipLaunchKernelGGL(k_r_select, dim3(ng), dim3(64), 0, st, A, 0);
+    // ... and if nothing is left (or at the start), a new round: sample, score on the subset, leaders, re-score, batch
     hipLaunchKernelGGL(k_r_sample, dim3(cdiv(R_H, 256), ng), dim3(256), 0, st, A);
     hipLaunchKernelGGL(k_r_score_sub, dim3(sub_tiles, R_H / HCHUNK, ng), dim3(TPB), 0, st, A);
     hipLaunchKernelGGL(k_r_leaders, dim3(ng), dim3(1024), 0, st, A);
     ctx->ev_begin("score_multi", 0.0);
-    hipLaunchKernelGGL(k_r_rescore, dim3(tiles), dim3(TPB), 0, st, A);
+    hipLaunchKernelGGL(k_r_rescore, dim3(tiles), dim3(TPB), 0, st, A, 1);
     ctx->ev_end();
-    hipLaunchKernelGGL(k_r_select, dim3(ng), dim3(64), 0, st, A);
+    hipLaunchKernelGGL(k_r_select, dim3(ng), dim3(64), 0, st, A, 1);
     for (int k = 0; k < 4; ++k) {
         ctx->ev_begin("score_mark", 0.0);
         hipLaunchKernelGGL(k_r_mark, dim3(tiles), dim3(TPB), 0, st, A, k);
@@ -1596,11 +1687,16 @@ void launch_iteration(plade_ctx *ctx, RansacWork &W, const RArgs &A) {
 // Waits until every listed result block reports at least `want` completed iterations (or the end of its detect call).
 // The blocks are host-mapped and written by the device while the stream keeps running; should a flag not become visible
 // (it always has), the stream running dry ends the wait: everything is visible then.
-void wait_iterations(plade_ctx *ctx, RResult *const *res, int nres, uint32_t want) {
+inline bool flag_done(const RResult *r, uint32_t gen) {
+    const uint32_t f = *reinterpret_cast<const volatile uint32_t *>(&r->flag);
+    return ((f >> 24) & 0x7fu) == (gen & 0x7fu) && (f & 0x80000000u);
+}
+void wait_iterations(plade_ctx *ctx, RResult *const *res, int nres, uint32_t want, uint32_t gen) {
     auto reached = [&]() {
         for (int i = 0; i < nres; ++i) {
             const uint32_t f = *reinterpret_cast<volatile uint32_t *>(&res[i]->flag);
-            if (!(f & 0x80000000u) && (f & 0x7fffffffu) < want) return false;
+            if (((f >> 24) & 0x7fu) != (gen & 0x7fu)) return false;          // still the previous call's reports
+            if (!(f & 0x80000000u) && (f & 0xffffffu) < want) return false;
         }
         return true;
     };
@@ -1669,6 +1765,7 @@ void ransac_detect_prepared(plade_ctx *ctx, RansacWork &W, RansacJob jobs[RANSAC
     memset(&I, 0, sizeof(I));
     RResult *res[R_G];
     int nres = 0;
+    const uint32_t gen = (++W.generation) & 0x7fu;
     for (int g = 0; g < ng; ++g) {
         RansacJob &J = jobs[g];
         RansacSlot &s = W.slot[g];
@@ -1692,11 +1789,10 @@ void ransac_detect_prepared(plade_ctx *ctx, RansacWork &W, RansacJob jobs[RANSAC
         P.bitmap_eps = bitmap_eps; P.cos_t = J.rp.cos_thresh; P.overlook_p = J.rp.overlook_p;
         for (int k = 0; k < 3; ++k) { P.bbmin[k] = c.bbmin[k]; P.bbmax[k] = c.bbmax[k]; }
         P.seed = J.rp.seed;
-        s.res->flag = 0;
+        P.gen = gen;
         res[nres++] = s.res;
     }
     if (nres == 0) return;
-    std::atomic_thread_fence(std::memory_order_seq_cst);
     uint32_t tiles = 0;
     for (int g = 0; g < ng; ++g) tiles += A.c[g].L.nb;
     hipLaunchKernelGGL(k_r_init, dim3(tiles), dim3(TPB), 0, ctx->stream, A, I);
@@ -1706,40 +1802,50 @@ void ransac_detect_prepared(plade_ctx *ctx, RansacWork &W, RansacJob jobs[RANSAC
         // profiled run (HIP events around the scan kernels): one iteration at a time; the device-side counters say
         // which clouds each scan launch really served, i.e. its algorithmic bytes (28 B per point and
         // launch + one mask byte per 4 points and chain)
-        uint32_t seen_rescore[R_G] = {0, 0}, seen_mark[R_G] = {0, 0}, seen_chains[R_G] = {0, 0};
+        uint32_t seen_rescore[R_G][2] = {{0, 0}, {0, 0}}, seen_mark[R_G] = {0, 0}, seen_chains[R_G] = {0, 0};
+        const size_t hdr_bytes = offsetof(RState, acc_coef);
+        std::vector<char> hdr(R_G * hdr_bytes);
         for (;; ++iterations) {
             const size_t ev0 = ctx->evs.size();
             launch_iteration(ctx, W, A);
-            wait_iterations(ctx, res, nres, iterations + 1);
+            for (int g = 0; g < ng; ++g)
+                if (jobs[g].active) ctx->d2h(hdr.data() + g * hdr_bytes, W.slot[g].state.p, hdr_bytes);
             ctx->sync();
-            double rescore_bytes = 0, mark_bytes = 0;
+            double rescore_bytes[2] = {0, 0}, mark_bytes = 0;
             uint32_t mark_launches = 0;
             for (int g = 0; g < ng; ++g) {
                 if (!jobs[g].active) continue;
-                const RResult &R = *W.slot[g].res;
+                const RState &S = *reinterpret_cast<const RState *>(hdr.data() + g * hdr_bytes);
                 const double n = W.slot[g].n;
-                rescore_bytes += 28.0 * n * (R.n_rescores - seen_rescore[g]);
-                mark_bytes += 28.0 * n * (R.n_mark_launches - seen_mark[g]) + 0.25 * n * (R.n_mark_chains - seen_chains[g]);
-                mark_launches = std::max(mark_launches, R.n_mark_launches - seen_mark[g]);
-                seen_rescore[g] = R.n_rescores; seen_mark[g] = R.n_mark_launches; seen_chains[g] = R.n_mark_chains;
+                for (int ph = 0; ph < 2; ++ph) {
+                    rescore_bytes[ph] += 28.0 * n * (S.n_rescores[ph] - seen_rescore[g][ph]);
+                    seen_rescore[g][ph] = S.n_rescores[ph];
+                }
+                mark_bytes += 28.0 * n * (S.n_mark_launches - seen_mark[g]) + 0.25 * n * (S.n_mark_chains - seen_chains[g]);
+                mark_launches = std::max(mark_launches, S.n_mark_launches - seen_mark[g]);
+                seen_mark[g] = S.n_mark_launches; seen_chains[g] = S.n_mark_chains;
             }
-            uint32_t mk = 0;
+            uint32_t mk = 0, rs = 0;
             for (size_t e = ev0; e < ctx->evs.size(); ++e) {
                 plade_ctx::EvRec &r = ctx->evs[e];
-                if (r.tag == "score_multi") r.bytes = rescore_bytes > 0 ? rescore_bytes : -1.0;
+                if (r.tag == "score_multi") { r.bytes = rs < 2 && rescore_bytes[rs] > 0 ? rescore_bytes[rs] : -1.0; ++rs; }
                 else if (r.tag == "score_mark") { r.bytes = mk < mark_launches ? mark_bytes / mark_launches : -1.0; ++mk; }
             }
             bool all = true;
-            for (int i = 0; i < nres; ++i) all = all && (res[i]->flag & 0x80000000u);
+            for (int i = 0; i < nres; ++i) all = all && flag_done(res[i], gen);
             if (all) break;
         }
     } else {
-        launch_iteration(ctx, W, A);
+        // Sleeping host waits (several registrations in flight): the next iteration is queued before the current one has
+        // reported, so the GPU never waits for the host; should the loop have ended, that iteration's kernels return at
+        // once (29 empty launches).  A spinning host reacts within microseconds and queues an iteration only when needed.
+        const bool speculate = ctx->params.host_wait != 0;
+        if (speculate) launch_iteration(ctx, W, A);
         for (;; ++iterations) {
-            launch_iteration(ctx, W, A);   // speculative: returns at once on the device if the loop has ended
-            wait_iterations(ctx, res, nres, iterations + 1);
+            launch_iteration(ctx, W, A);
+            wait_iterations(ctx, res, nres, iterations + 1, gen);
             bool all = true;
-            for (int i = 0; i < nres; ++i) all = all && (*reinterpret_cast<volatile uint32_t *>(&res[i]->flag) & 0x80000000u);
+            for (int i = 0; i < nres; ++i) all = all && flag_done(res[i], gen);
             if (all) break;
             PLADE_REQUIRE(iterations < 100000, PLADE_EDEVICE, "plane extraction: the device loop does not end");
         }

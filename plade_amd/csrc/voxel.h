@@ -7,13 +7,22 @@ namespace plade {
 struct VoxelWork {
     uint32_t n_out = 0;
     DBuf<uint64_t> keys, keys2;
-    DBuf<uint32_t> vals, vals2, flags, seg, heads, seg_group, group_offsets;
+    DBuf<uint32_t> vals, vals2, heads, seg_group, group_offsets, count;
+    DBuf<float> sorted_xyz;   // the items' coordinates in voxel order (x | y | z)
     DBuf<float> out_xyz;  // n_out x 3, ordered by (group, k, j, i)
     // items: item i refers to point item_point[i] (or i when null) of the strided xyz array and
     // belongs to group item_group[i] (or 0).  Items of a voxel are summed in ascending item order.
     uint32_t run(plade_ctx *ctx, const float *d_xyz, uint32_t stride, const uint32_t *d_item_point,
                  const uint32_t *d_item_group, uint32_t n_items, uint32_t n_groups, float leaf,
                  const float bbox_min[3], const float bbox_max[3]);
+    // The same in two steps: enqueue() queues keys, sort, runs and centroids (8 launches, no host round trip; the
+    // optional d_soa_* arrays are the cloud's SoA copy for the whole-cloud call), finish() waits for the stream and
+    // returns the number of voxels.  Several runs can be queued before the first finish().
+    void enqueue(plade_ctx *ctx, const float *d_xyz, uint32_t stride, const float *d_soa_x, const float *d_soa_y,
+                 const float *d_soa_z, const uint32_t *d_item_point, const uint32_t *d_item_group, uint32_t n_items,
+                 uint32_t n_groups, float leaf, const float bbox_min[3], const float bbox_max[3]);
+    uint32_t finish(plade_ctx *ctx);
+    uint32_t n_pending = 0, n_pending_host = 0;
 };
 
 struct TargetGrid;

