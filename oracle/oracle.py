@@ -48,6 +48,7 @@ class Oracle:
         L.orc_ls_fit.argtypes = [_p, _i, _p, _i, _p]
         L.orc_voxel_downsample.argtypes = [_p, _i, _i, _f, _i, _p, _p]
         L.orc_bounding_box.argtypes = [_p, _i, _p, _p, _p]
+        L.orc_bounding_box_mode.argtypes = [_p, _i, _i, _p, _p, _p]
         L.orc_intersection_line.argtypes = [_p, _p, _p, _p]
         L.orc_closest_points.argtypes = [_p, _p, _p, _p, _p, _p, _p]
         L.orc_match_descriptors.restype = C.c_int64
@@ -112,12 +113,12 @@ class Oracle:
         self.L.orc_voxel_downsample(_ptr(a), len(a), a.shape[1], leaf, sort_mode, _ptr(out), C.byref(n))
         return out[: n.value].copy()
 
-    def bounding_box(self, xyz):
+    def bounding_box(self, xyz, sum_mode=0):
         a = _f32(xyz)
         c = np.zeros(3, np.float32)
         whd = np.zeros(3, np.float64)
         corners = np.zeros((8, 3), np.float32)
-        rc = self.L.orc_bounding_box(_ptr(a), len(a), _ptr(c), _ptr(whd), _ptr(corners))
+        rc = self.L.orc_bounding_box_mode(_ptr(a), len(a), sum_mode, _ptr(c), _ptr(whd), _ptr(corners))
         return rc, c, whd, corners
 
     # -- A6/A7/A8 ------------------------------------------------------------

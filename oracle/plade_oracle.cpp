@@ -486,23 +486,48 @@ struct OBB {
     double width, height, depth;
     V3 corners[8];
 };
-int bounding_box(const std::vector<V3> &pts, OBB &o, bool want_corners) {
+// sum_mode 0: PCL's order -- compute3DCentroid / computeCovarianceMatrixNormalized add the points one after the other in
+// fp32 (centroid.hpp:79-121, 250-300).  sum_mode 1: the order of the GPU path (k_obb_units): the points are cut into chunks
+// of 64 consecutive points, every chunk is summed point after point, and the chunk sums are added in chunk order -- a
+// re-association of the same fp32 additions (a 60 000-point serial chain is what a GPU cannot run; the chunks are what
+// its lanes sum in parallel).  The two differ by a few ulp of the sums.
+int bounding_box(const std::vector<V3> &pts, OBB &o, bool want_corners, int sum_mode = 0) {
     if (pts.empty()) return -1;
+    const size_t n = pts.size(), CH = 64;
     float c[3] = {0, 0, 0};
-    for (auto &p : pts) { c[0] += p.x; c[1] += p.y; c[2] += p.z; }
+    if (sum_mode == 0) {
+        for (auto &p : pts) { c[0] += p.x; c[1] += p.y; c[2] += p.z; }
+    } else {
+        for (size_t b = 0; b < n; b += CH) {
+            float s[3] = {0, 0, 0};
+            for (size_t i = b; i < std::min(n, b + CH); ++i) { s[0] += pts[i].x; s[1] += pts[i].y; s[2] += pts[i].z; }
+            c[0] += s[0]; c[1] += s[1]; c[2] += s[2];
+        }
+    }
     float nf = (float)pts.size();
     c[0] /= nf; c[1] /= nf; c[2] /= nf;
     M3 cov;
     memset(&cov, 0, sizeof(cov));
-    for (auto &p : pts) {
+    auto add_point = [&](M3 &acc, const V3 &p) {
         float px = p.x - c[0], py = p.y - c[1], pz = p.z - c[2];
-        cov.m[1][1] += py * py;
-        cov.m[1][2] += py * pz;
-        cov.m[2][2] += pz * pz;
+        acc.m[1][1] += py * py;
+        acc.m[1][2] += py * pz;
+        acc.m[2][2] += pz * pz;
         float qx = px * px, qy = py * px, qz = pz * px;  // pt *= pt.x()
-        cov.m[0][0] += qx;
-        cov.m[0][1] += qy;
-        cov.m[0][2] += qz;
+        acc.m[0][0] += qx;
+        acc.m[0][1] += qy;
+        acc.m[0][2] += qz;
+    };
+    if (sum_mode == 0) {
+        for (auto &p : pts) add_point(cov, p);
+    } else {
+        for (size_t b = 0; b < n; b += CH) {
+            M3 s;
+            memset(&s, 0, sizeof(s));
+            for (size_t i = b; i < std::min(n, b + CH); ++i) add_point(s, pts[i]);
+            cov.m[1][1] += s.m[1][1]; cov.m[1][2] += s.m[1][2]; cov.m[2][2] += s.m[2][2];
+            cov.m[0][0] += s.m[0][0]; cov.m[0][1] += s.m[0][1]; cov.m[0][2] += s.m[0][2];
+        }
     }
     cov.m[1][0] = cov.m[0][1]; cov.m[2][0] = cov.m[0][2]; cov.m[2][1] = cov.m[1][2];
     for (int r = 0; r < 3; ++r) for (int k = 0; k < 3; ++k) cov.m[r][k] /= nf;
@@ -853,7 +878,7 @@ int prepare_side(orc_reg *h, const char *tag, const float *pos_nrm, int n, const
     for (int i = 0; i < n; ++i) all[i] = ld3(pos_nrm + 6 * (size_t)i);
     voxel_downsample(all, leaf, sort_mode, S.ds);
     OBB ob;
-    if (0 != bounding_box(S.ds, ob, false)) return -1;
+    if (0 != bounding_box(S.ds, ob, false, sort_mode)) return -1;
     S.bcenter = ob.center;
     S.radius = std::max(std::max(ob.width, ob.height), ob.depth) / 2;
     h->put(std::string(tag) + "_ds", (const float *)S.ds.data(), S.ds.size() * 3);
@@ -873,7 +898,7 @@ int prepare_side(orc_reg *h, const char *tag, const float *pos_nrm, int n, const
         for (int j = offsets[i]; j < offsets[i + 1]; ++j) tmp.push_back(ld3(pos_nrm + 6 * (size_t)idx[j]));
         voxel_downsample(tmp, leaf, sort_mode, pi.ds);
         OBB pb;
-        bounding_box(pi.ds, pb, true);
+        bounding_box(pi.ds, pb, true, sort_mode);
         for (int k = 0; k < 8; ++k) pi.corners8[k] = pb.corners[k];
         for (int k = 0; k < 4; ++k) pi.four[k] = project_to_plane(pb.corners[k], planes + 4 * (size_t)i);
         pi.center = (pi.four[0] + pi.four[2]) / 2.f;
@@ -1007,10 +1032,13 @@ int orc_voxel_downsample(const float *xyz, int n, int stride, float leaf, int so
 }
 
 int orc_bounding_box(const float *xyz, int n, float *center3, double *whd3, float *corners24) {
+    return orc_bounding_box_mode(xyz, n, 0, center3, whd3, corners24);
+}
+int orc_bounding_box_mode(const float *xyz, int n, int sum_mode, float *center3, double *whd3, float *corners24) {
     std::vector<V3> pts(n);
     for (int i = 0; i < n; ++i) pts[i] = ld3(xyz + 3 * (size_t)i);
     OBB o;
-    if (0 != bounding_box(pts, o, corners24 != nullptr)) return -1;
+    if (0 != bounding_box(pts, o, corners24 != nullptr, sum_mode)) return -1;
     st3(center3, o.center);
     whd3[0] = o.width; whd3[1] = o.height; whd3[2] = o.depth;
     if (corners24) for (int i = 0; i < 8; ++i) st3(corners24 + 3 * i, o.corners[i]);

@@ -29,11 +29,16 @@ float orc_cloud_scale(const float *pos_nrm, int n);
 
 /* A13 */
 float orc_average_spacing(const float *xyz, int n, int stride_floats, int k, int samples);
-/* sort_mode 0: std::sort (PCL-faithful, unstable); 1: stable (ascending point index). */
+/* sort_mode 0: std::sort (PCL-faithful, unstable); 1: stable (ascending point index).  In orc_registration the same
+ * switch also selects the summation order of the bounding-box centroids / covariances (orc_bounding_box_mode): 0 = every
+ * order as PCL has it, 1 = the deterministic orders of the GPU path. */
 int orc_voxel_downsample(const float *xyz, int n, int stride_floats, float leaf, int sort_mode,
                          float *out_xyz, int32_t *n_out);
 /* util.h:186-248: center(3), whd (width,height,depth doubles), corners (8x3, may be NULL) */
 int orc_bounding_box(const float *xyz, int n, float *center3, double *whd3, float *corners24);
+/* sum_mode 0: PCL's point-after-point fp32 sums (= orc_bounding_box); 1: chunks of 64 consecutive points summed point
+ * after point, chunk sums added in chunk order (the GPU path's order, a re-association of the same additions). */
+int orc_bounding_box_mode(const float *xyz, int n, int sum_mode, float *center3, double *whd3, float *corners24);
 
 /* A6 */
 int orc_intersection_line(const float *plane_a4, const float *plane_b4, float *vec3, float *point3);

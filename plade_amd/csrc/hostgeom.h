@@ -1,11 +1,8 @@
-// plade_amd/csrc/hostgeom.h -- the small, strictly sequential fp32 pieces the C++ host keeps
-// (exactly the work the reference's host does per cloud / per plane): PCA oriented bounding boxes
-// of voxel-downsampled clouds.  Sequential accumulation order is part of the result, so these run on
-// the host over the (small) downsampled clouds copied back from the GPU.
+// plade_amd/csrc/hostgeom.h -- PCA oriented bounding boxes of the voxel-downsampled clouds (ComputeBoundingBox,
+// code/PLADE/util.h:186-248): the 3x3 eigen-solver and the box construction as host+device functions (k_obb.hip runs
+// them on the GPU, one workgroup per cloud / per plane).
 #pragma once
 #include "geom.h"
-#include <vector>
-#include <algorithm>
 
 namespace plade {
 
@@ -13,9 +10,9 @@ namespace plade {
 // Eigen/src/Eigenvalues/SelfAdjointEigenSolver.h:420-468 (scaling), Tridiagonalization.h:464-504
 // (3x3 in-place tridiagonalisation), :504-572 + :839-900 (implicit symmetric QR with Wilkinson
 // shift), eigenvalues ascending, eigenvectors in the columns of `vec`.
-inline void symmetric_eigen3(const m3 &cov, float val[3], m3 &vec) {
+HD void symmetric_eigen3(const m3 &cov, float val[3], m3 &vec) {
     float a00 = cov.m[0][0], a10 = cov.m[1][0], a11 = cov.m[1][1], a20 = cov.m[2][0], a21 = cov.m[2][1], a22 = cov.m[2][2];
-    float scale = std::max({std::fabs(a00), std::fabs(a10), std::fabs(a20), std::fabs(a11), std::fabs(a21), std::fabs(a22)});
+    float scale = fmaxf(fmaxf(fmaxf(fabsf(a00), fabsf(a10)), fmaxf(fabsf(a20), fabsf(a11))), fmaxf(fabsf(a21), fabsf(a22)));
     if (scale == 0.f) scale = 1.f;
     a00 /= scale; a10 /= scale; a11 /= scale; a20 /= scale; a21 /= scale; a22 /= scale;
     float diag[3], sub[2], q[3][3];
@@ -25,7 +22,7 @@ inline void symmetric_eigen3(const m3 &cov, float val[3], m3 &vec) {
         diag[1] = a11; diag[2] = a22; sub[0] = a10; sub[1] = a21;
         for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) q[r][c] = r == c ? 1.f : 0.f;
     } else {
-        const float beta = std::sqrt(a10 * a10 + v1norm2);
+        const float beta = sqrtf(a10 * a10 + v1norm2);
         const float invBeta = 1.f / beta;
         const float m01 = a10 * invBeta, m02 = a20 * invBeta;
         const float qq = 2.f * m01 * a21 + m02 * (a22 - a11);
@@ -42,10 +39,10 @@ inline void symmetric_eigen3(const m3 &cov, float val[3], m3 &vec) {
     bool converged = true;
     while (end > 0) {
         for (int i = start; i < end; ++i) {
-            if (std::fabs(sub[i]) < FLT_MIN) sub[i] = 0.f;
+            if (fabsf(sub[i]) < FLT_MIN) sub[i] = 0.f;
             else {
                 const float ss = precision_inv * sub[i];
-                if (ss * ss <= (std::fabs(diag[i]) + std::fabs(diag[i + 1]))) sub[i] = 0.f;
+                if (ss * ss <= (fabsf(diag[i]) + fabsf(diag[i + 1]))) sub[i] = 0.f;
             }
         }
         while (end > 0 && sub[end - 1] == 0.f) end--;
@@ -56,13 +53,13 @@ inline void symmetric_eigen3(const m3 &cov, float val[3], m3 &vec) {
         float td = (diag[end - 1] - diag[end]) * 0.5f;
         const float e = sub[end - 1];
         float mu = diag[end];
-        if (td == 0.f) mu -= std::fabs(e);
+        if (td == 0.f) mu -= fabsf(e);
         else if (e != 0.f) {
             const float e2 = e * e;
-            const float ax = std::fabs(td), ay = std::fabs(e);
-            const float p = std::max(ax, ay);
+            const float ax = fabsf(td), ay = fabsf(e);
+            const float p = fmaxf(ax, ay);
             float h = 0.f;
-            if (p != 0.f) { const float qp = std::min(ay, ax) / p; h = p * std::sqrt(1.f + qp * qp); }
+            if (p != 0.f) { const float qp = fminf(ay, ax) / p; h = p * sqrtf(1.f + qp * qp); }
             if (e2 == 0.f) mu -= e / ((td + (td > 0.f ? h : -h)) / e);
             else mu -= e2 / (td + (td > 0.f ? h : -h));
         }
@@ -87,8 +84,8 @@ inline void symmetric_eigen3(const m3 &cov, float val[3], m3 &vec) {
             float mn = diag[i];
             for (int j = 1; j < 3 - i; ++j) if (diag[i + j] < mn) { mn = diag[i + j]; k = j; }
             if (k > 0) {
-                std::swap(diag[i], diag[k + i]);
-                for (int r = 0; r < 3; ++r) std::swap(q[r][i], q[r][k + i]);
+                { const float t = diag[i]; diag[i] = diag[k + i]; diag[k + i] = t; }
+                for (int r = 0; r < 3; ++r) { const float t = q[r][i]; q[r][i] = q[r][k + i]; q[r][k + i] = t; }
             }
         }
     for (int i = 0; i < 3; ++i) val[i] = diag[i] * scale;
@@ -103,28 +100,29 @@ struct Obb {
 
 // ComputeBoundingBox (code/PLADE/util.h:186-248): pcl::compute3DCentroid + computeCovarianceMatrixNormalized
 // (pcl-1.8.1/common/include/pcl/common/impl/centroid.hpp:79-121, 250-300) -> eigenvectors ->
-// transformPointCloud into the eigen frame -> getMinMax3D -> centre / extents / 8 corners.
-inline bool oriented_bbox(const float *xyz, size_t n, Obb &o, bool corners) {
-    if (n == 0) return false;
-    float c[3] = {0, 0, 0};
-    for (size_t i = 0; i < n; ++i) { c[0] += xyz[3 * i]; c[1] += xyz[3 * i + 1]; c[2] += xyz[3 * i + 2]; }
-    const float nf = (float)n;
-    c[0] /= nf; c[1] /= nf; c[2] /= nf;
+// transformPointCloud into the eigen frame -> getMinMax3D -> centre / extents / 8 corners.  Split at the two places
+// where all points are visited: the caller supplies the sums and the min / max.
+
+// the six covariance terms of one point about the centroid, in PCL's order of operations (centroid.hpp:263-287)
+HD void cov_add_point(float acc[6] /* 11 12 22 00 01 02 */, f3 p, const float c[3]) {
+    const float px = p.x - c[0], py = p.y - c[1], pz = p.z - c[2];
+    acc[0] += py * py;
+    acc[1] += py * pz;
+    acc[2] += pz * pz;
+    acc[3] += px * px;   // pt *= pt.x()
+    acc[4] += py * px;
+    acc[5] += pz * px;
+}
+
+// eigen frame from the summed covariance terms: E (columns = axes, the third one = col0 x col1) and the 3x4 transform
+// P = [E^T | -E^T c] into that frame
+HD void obb_frame(const float cov6[6], float nf, const float c[3], m3 &E, float P[12]) {
     m3 cov;
-    memset(&cov, 0, sizeof(cov));
-    for (size_t i = 0; i < n; ++i) {
-        const float px = xyz[3 * i] - c[0], py = xyz[3 * i + 1] - c[1], pz = xyz[3 * i + 2] - c[2];
-        cov.m[1][1] += py * py;
-        cov.m[1][2] += py * pz;
-        cov.m[2][2] += pz * pz;
-        cov.m[0][0] += px * px;
-        cov.m[0][1] += py * px;
-        cov.m[0][2] += pz * px;
-    }
+    cov.m[1][1] = cov6[0]; cov.m[1][2] = cov6[1]; cov.m[2][2] = cov6[2];
+    cov.m[0][0] = cov6[3]; cov.m[0][1] = cov6[4]; cov.m[0][2] = cov6[5];
     cov.m[1][0] = cov.m[0][1]; cov.m[2][0] = cov.m[0][2]; cov.m[2][1] = cov.m[1][2];
     for (int r = 0; r < 3; ++r) for (int k = 0; k < 3; ++k) cov.m[r][k] /= nf;
     float ev[3];
-    m3 E;
     symmetric_eigen3(cov, ev, E);
     const f3 c0(E.m[0][0], E.m[1][0], E.m[2][0]), c1(E.m[0][1], E.m[1][1], E.m[2][1]);
     const f3 c2 = cross(c0, c1);
@@ -133,35 +131,34 @@ inline bool oriented_bbox(const float *xyz, size_t n, Obb &o, bool corners) {
     for (int r = 0; r < 3; ++r) for (int k = 0; k < 3; ++k) Et.m[r][k] = E.m[k][r];
     const f3 cen(c[0], c[1], c[2]);
     const f3 t = -1.f * mul_e(Et, cen);
-    float P[12] = {Et.m[0][0], Et.m[0][1], Et.m[0][2], t.x, Et.m[1][0], Et.m[1][1], Et.m[1][2], t.y,
-                   Et.m[2][0], Et.m[2][1], Et.m[2][2], t.z};
-    f3 mn(FLT_MAX, FLT_MAX, FLT_MAX), mx(-FLT_MAX, -FLT_MAX, -FLT_MAX);
-    for (size_t i = 0; i < n; ++i) {
-        const f3 q = pcl_xform(P, f3(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]));
-        mn.x = std::min(mn.x, q.x); mn.y = std::min(mn.y, q.y); mn.z = std::min(mn.z, q.z);
-        mx.x = std::max(mx.x, q.x); mx.y = std::max(mx.y, q.y); mx.z = std::max(mx.z, q.z);
-    }
-    const f3 mean_diag = 0.5f * (mx + mn);
-    o.center = mul_e(E, mean_diag) + cen;
-    o.width = mx.x - mn.x;
-    o.depth = mx.y - mn.y;
-    o.height = mx.z - mn.z;
-    if (corners) {
-        const float x = mn.x, y = mn.y, z = mn.z;
-        const double w = o.width, d = o.depth, h = o.height;
-        const f3 cs[8] = {mn,
-                          f3(x, (float)(y + d), z),
-                          f3(x, (float)(y + d), (float)(z + h)),
-                          f3(x, y, (float)(z + h)),
-                          f3((float)(x + w), y, (float)(z + h)),
-                          f3((float)(x + w), (float)(y + d), z),
-                          f3((float)(x + w), y, z),
-                          f3((float)(x + w), (float)(y + d), (float)(z + h))};
-        float Q[12] = {E.m[0][0], E.m[0][1], E.m[0][2], cen.x, E.m[1][0], E.m[1][1], E.m[1][2], cen.y,
-                       E.m[2][0], E.m[2][1], E.m[2][2], cen.z};
-        for (int i = 0; i < 8; ++i) o.corners[i] = pcl_xform(Q, cs[i]);
-    }
-    return true;
+    P[0] = Et.m[0][0]; P[1] = Et.m[0][1]; P[2] = Et.m[0][2]; P[3] = t.x;
+    P[4] = Et.m[1][0]; P[5] = Et.m[1][1]; P[6] = Et.m[1][2]; P[7] = t.y;
+    P[8] = Et.m[2][0]; P[9] = Et.m[2][1]; P[10] = Et.m[2][2]; P[11] = t.z;
 }
+
+// centre, extents and corners from the min / max of the points in the eigen frame
+HD void obb_finish(const m3 &E, const float c[3], f3 mn, f3 mx, f3 &center, double whd[3], f3 corners[8]) {
+    const f3 cen(c[0], c[1], c[2]);
+    const f3 mean_diag = 0.5f * (mx + mn);
+    center = mul_e(E, mean_diag) + cen;
+    whd[0] = mx.x - mn.x;   // width  (float subtraction, widened)
+    whd[2] = mx.y - mn.y;   // depth
+    whd[1] = mx.z - mn.z;   // height
+    const float x = mn.x, y = mn.y, z = mn.z;
+    const double w = whd[0], d = whd[2], h = whd[1];
+    const f3 cs[8] = {mn,
+                      f3(x, (float)(y + d), z),
+                      f3(x, (float)(y + d), (float)(z + h)),
+                      f3(x, y, (float)(z + h)),
+                      f3((float)(x + w), y, (float)(z + h)),
+                      f3((float)(x + w), (float)(y + d), z),
+                      f3((float)(x + w), y, z),
+                      f3((float)(x + w), (float)(y + d), (float)(z + h))};
+    const float Q[12] = {E.m[0][0], E.m[0][1], E.m[0][2], cen.x, E.m[1][0], E.m[1][1], E.m[1][2], cen.y,
+                         E.m[2][0], E.m[2][1], E.m[2][2], cen.z};
+    for (int i = 0; i < 8; ++i) corners[i] = pcl_xform(Q, cs[i]);
+}
+
+constexpr int OBB_CHUNK = 64;   // points per summation chunk (see k_obb.hip)
 
 }  // namespace plade

@@ -1,0 +1,153 @@
+// plade_amd/csrc/k_obb.hip -- PCA oriented bounding boxes on the GPU.
+//
+// ComputeBoundingBox (code/PLADE/util.h:186-248) of the voxel-downsampled cloud (plade.cpp:81-84 / :295-299) and of every
+// per-plane downsampled cloud, followed per plane by the projection of the first four box corners onto the plane, their
+// centre and half diagonal (plade.cpp:106-117 / :320-330, ProjectPoints2Plane util.h:292-340).  One workgroup per
+// "unit" (unit 0 = the whole cloud, unit 1 + i = plane i); nothing but a few dozen floats per unit goes back to the host.
+//
+// PCL adds the points one after the other in fp32 (compute3DCentroid / computeCovarianceMatrixNormalized,
+// centroid.hpp:79-121, 250-300): a 60 000-step dependent chain a GPU lane would spend half a millisecond on.  Here the
+// points of a unit are cut into chunks of OBB_CHUNK = 64 consecutive points; lanes sum one chunk each, point after
+// point, and one lane adds the chunk sums in chunk order: the same additions re-associated, deterministic, and exactly
+// what the oracle's sum mode 1 does (oracle/plade_oracle.cpp bounding_box).  Everything after the sums -- Eigen's 3x3
+// self-adjoint solver, the frame, min / max, corners -- is PCL's arithmetic operation for operation (hostgeom.h).
+#include "stages.h"
+#include "hostgeom.h"
+
+namespace plade {
+
+namespace {
+
+struct ObbArgs {
+    const float *ds; const uint32_t *n_ds_p;   // whole downsampled cloud, n x 3 (its size is still on the device)
+    uint32_t chunk_base_planes;                // first scratch chunk of the per-plane units
+    const float *plane_ds; const uint32_t *plane_off; uint32_t P;   // per-plane clouds, concatenated, P + 1 offsets
+    const float *coef;                         // P x 4 plane coefficients
+    float *chunks;                             // scratch: 9 floats per chunk
+    float *out;                                // OBB_OUT_WHOLE + P * OBB_OUT_PLANE floats
+};
+
+__global__ __launch_bounds__(256) void k_obb_units(const ObbArgs A) {
+    __shared__ float s_c[3], s_P[12], s_E[9];
+    __shared__ float s_mm[6][4];
+    const uint32_t u = blockIdx.x;
+    const float *pts;
+    uint32_t n, chunk0;
+    if (u == 0) { pts = A.ds; n = *A.n_ds_p; chunk0 = 0; }
+    else {
+        const uint32_t b = A.plane_off[u - 1], e = A.plane_off[u];
+        pts = A.plane_ds + 3 * (size_t)b;
+        n = e - b;
+        chunk0 = A.chunk_base_planes + b / OBB_CHUNK + u;   // disjoint chunk ranges for all units
+    }
+    float *out = u == 0 ? A.out : A.out + OBB_OUT_WHOLE + (size_t)(u - 1) * OBB_OUT_PLANE;
+    if (n == 0) {   // empty plane: its boxes stay zero (plade.cpp:106-117 skips it)
+        if (u > 0) for (uint32_t i = threadIdx.x; i < OBB_OUT_PLANE; i += blockDim.x) out[i] = 0.f;
+        else if (threadIdx.x == 0) out[OBB_OUT_WHOLE - 1] = 0.f;
+        return;
+    }
+    float *ch = A.chunks + 9 * (size_t)chunk0;
+    const uint32_t nch = (n + OBB_CHUNK - 1) / OBB_CHUNK;
+    const float nf = (float)n;
+    // ---- centroid: chunk sums, then the chunk sums in order
+    for (uint32_t k = threadIdx.x; k < nch; k += blockDim.x) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+        const uint32_t b = k * OBB_CHUNK, e = min(n, b + OBB_CHUNK);
+        for (uint32_t i = b; i < e; ++i) { s0 += pts[3 * (size_t)i]; s1 += pts[3 * (size_t)i + 1]; s2 += pts[3 * (size_t)i + 2]; }
+        ch[9 * (size_t)k] = s0; ch[9 * (size_t)k + 1] = s1; ch[9 * (size_t)k + 2] = s2;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        float c = 0.f;
+        for (uint32_t k = 0; k < nch; ++k) c += ch[9 * (size_t)k + threadIdx.x];
+        s_c[threadIdx.x] = c / nf;
+    }
+    __syncthreads();
+    const float c[3] = {s_c[0], s_c[1], s_c[2]};
+    // ---- covariance about the centroid, same chunking
+    for (uint32_t k = threadIdx.x; k < nch; k += blockDim.x) {
+        float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const uint32_t b = k * OBB_CHUNK, e = min(n, b + OBB_CHUNK);
+        for (uint32_t i = b; i < e; ++i) cov_add_point(acc, f3(pts[3 * (size_t)i], pts[3 * (size_t)i + 1], pts[3 * (size_t)i + 2]), c);
+        for (int q = 0; q < 6; ++q) ch[9 * (size_t)k + 3 + q] = acc[q];
+    }
+    __syncthreads();
+    __shared__ float s_cov[6];
+    if (threadIdx.x < 6) {
+        float v = 0.f;
+        for (uint32_t k = 0; k < nch; ++k) v += ch[9 * (size_t)k + 3 + threadIdx.x];
+        s_cov[threadIdx.x] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float cov6[6] = {s_cov[0], s_cov[1], s_cov[2], s_cov[3], s_cov[4], s_cov[5]};
+        m3 E;
+        float P[12];
+        obb_frame(cov6, nf, c, E, P);
+        for (int q = 0; q < 12; ++q) s_P[q] = P[q];
+        for (int r = 0; r < 3; ++r) for (int k = 0; k < 3; ++k) s_E[3 * r + k] = E.m[r][k];
+    }
+    __syncthreads();
+    // ---- min / max in the eigen frame (order-free: exact)
+    float P[12];
+    for (int q = 0; q < 12; ++q) P[q] = s_P[q];
+    float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const f3 q = pcl_xform(P, f3(pts[3 * (size_t)i], pts[3 * (size_t)i + 1], pts[3 * (size_t)i + 2]));
+        mn[0] = fminf(mn[0], q.x); mn[1] = fminf(mn[1], q.y); mn[2] = fminf(mn[2], q.z);
+        mx[0] = fmaxf(mx[0], q.x); mx[1] = fmaxf(mx[1], q.y); mx[2] = fmaxf(mx[2], q.z);
+    }
+    for (int q = 0; q < 3; ++q)
+        for (int d = 32; d >= 1; d >>= 1) {
+            mn[q] = fminf(mn[q], __shfl_xor(mn[q], d, 64));
+            mx[q] = fmaxf(mx[q], __shfl_xor(mx[q], d, 64));
+        }
+    if ((threadIdx.x & 63) == 0) for (int q = 0; q < 3; ++q) { s_mm[q][threadIdx.x >> 6] = mn[q]; s_mm[3 + q][threadIdx.x >> 6] = mx[q]; }
+    __syncthreads();
+    if (threadIdx.x) return;
+    for (int q = 0; q < 3; ++q) {
+        mn[q] = fminf(fminf(s_mm[q][0], s_mm[q][1]), fminf(s_mm[q][2], s_mm[q][3]));
+        mx[q] = fmaxf(fmaxf(s_mm[3 + q][0], s_mm[3 + q][1]), fmaxf(s_mm[3 + q][2], s_mm[3 + q][3]));
+    }
+    m3 E;
+    for (int r = 0; r < 3; ++r) for (int k = 0; k < 3; ++k) E.m[r][k] = s_E[3 * r + k];
+    f3 center, corners[8];
+    double whd[3];
+    obb_finish(E, c, f3(mn[0], mn[1], mn[2]), f3(mx[0], mx[1], mx[2]), center, whd, corners);
+    if (u == 0) {
+        // plade.cpp:83-84: centre of the box, radius = max(width, height, depth) / 2 (double)
+        out[0] = center.x; out[1] = center.y; out[2] = center.z;
+        const double r = fmax(fmax(whd[0], whd[1]), whd[2]) / 2;
+        memcpy(out + 4, &r, 8);
+        out[OBB_OUT_WHOLE - 1] = 1.f;
+        return;
+    }
+    const float *pl = A.coef + 4 * (size_t)(u - 1);
+    f3 four[4];
+    for (int k = 0; k < 4; ++k) {
+        four[k] = project_to_plane(corners[k], pl);
+        out[3 * k] = four[k].x; out[3 * k + 1] = four[k].y; out[3 * k + 2] = four[k].z;
+    }
+    const f3 cen = (four[0] + four[2]) / 2.f;
+    out[12] = cen.x; out[13] = cen.y; out[14] = cen.z;
+    out[15] = norm_e(four[0] - four[2]) / 2.f;
+}
+
+}  // namespace
+
+void obb_units(plade_ctx *ctx, ObbWork &W, const float *d_ds, const uint32_t *d_n_ds, uint32_t max_ds, const float *d_plane_ds,
+               const uint32_t *d_plane_off, uint32_t max_plane_pts, uint32_t P, const float *coef_host) {
+    W.d_coef.ensure(4 * (size_t)P + 4);
+    if (P) ctx->h2d(W.d_coef.p, coef_host, 16 * (size_t)P);
+    const uint32_t base_planes = max_ds / OBB_CHUNK + 2;
+    const size_t chunks = (size_t)base_planes + (size_t)max_plane_pts / OBB_CHUNK + P + 4;
+    W.chunks.ensure(9 * chunks + 16);
+    W.out.ensure(OBB_OUT_WHOLE + (size_t)P * OBB_OUT_PLANE + 4);
+    W.host.resize(OBB_OUT_WHOLE + (size_t)P * OBB_OUT_PLANE);
+    ObbArgs A{d_ds, d_n_ds, base_planes, d_plane_ds, d_plane_off, P, W.d_coef.p, W.chunks.p, W.out.p};
+    hipLaunchKernelGGL(k_obb_units, dim3(P + 1), dim3(256), 0, ctx->stream, A);
+    HIP_TRY(hipGetLastError());
+    ctx->d2h(W.host.data(), W.out.p, 4 * W.host.size());   // valid after the next sync of the stream
+}
+
+}  // namespace plade

@@ -174,7 +174,14 @@ void VoxelWork::enqueue(plade_ctx *ctx, const float *d_xyz, uint32_t stride, con
     n_pending = 0;
     PLADE_REQUIRE(leaf > 0.f, PLADE_EINVAL, "voxel: leaf must be positive");
     PLADE_REQUIRE(n_groups >= 1 && n_groups <= 1024, PLADE_ELIMIT, "voxel: at most 1024 point groups");
-    if (n_items == 0) return;
+    if (n_items == 0) {   // no items: zero voxels, every group empty (the consumers still read the device arrays)
+        group_offsets.ensure((size_t)n_groups + 2);
+        count.ensure(4);
+        out_xyz.ensure(4);
+        HIP_TRY(hipMemsetAsync(group_offsets.p, 0, ((size_t)n_groups + 2) * 4, ctx->stream));
+        HIP_TRY(hipMemsetAsync(count.p, 0, 4, ctx->stream));
+        return;
+    }
     const float inv = 1.f / leaf;
     const int lmin[3] = {(int)floorf(bbox_min[0] * inv), (int)floorf(bbox_min[1] * inv), (int)floorf(bbox_min[2] * inv)};
     const int lmax[3] = {(int)floorf(bbox_max[0] * inv), (int)floorf(bbox_max[1] * inv), (int)floorf(bbox_max[2] * inv)};

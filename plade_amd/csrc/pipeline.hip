@@ -55,6 +55,7 @@ struct Side {
     std::vector<float> normals;  // P x 3
     LineTableHost lines;
     VoxelWork vox_all, vox_planes;
+    ObbWork obb;
     DBuf<uint32_t> d_items, d_groups, d_offs;
 };
 
@@ -110,29 +111,28 @@ bool prepare_side(plade_ctx *ctx, const char *tag, const CloudDev &cloud, const 
                            S.d_groups.p);
     S.vox_planes.enqueue(ctx, cloud.aos.p, 6, nullptr, nullptr, nullptr, S.d_items.p, S.d_groups.p, n_items, P, leaf, cloud.bbmin,
                          cloud.bbmax);
+    // ComputeBoundingBox of the whole downsampled cloud (plade.cpp:81-84 / :295-299) and per plane (plade.cpp:106-117 /
+    // :320-330) on the device, reading the voxel grids' results where they lie; ONE wait for the grids' sizes, the
+    // per-plane offsets and the boxes
+    obb_units(ctx, S.obb, S.vox_all.out_xyz.p, S.vox_all.count.p, cloud.n, S.vox_planes.out_xyz.p, S.vox_planes.group_offsets.p, n_items, P,
+              pl.coef);
+    S.pcl.off.resize((size_t)P + 1);
+    ctx->d2h(S.pcl.off.data(), S.vox_planes.group_offsets.p, 4 * ((size_t)P + 1));
     S.n_ds = S.vox_all.finish(ctx);
     const uint32_t n_pds = S.vox_planes.finish(ctx);
-    if (S.n_ds == 0) return false;
-    S.ds.resize(3 * (size_t)S.n_ds);
-    S.d_ds_soa.ensure(3 * (size_t)S.n_ds + 4);
-    S.d_ds.swap(S.vox_all.out_xyz);   // the result becomes d_ds, the work area takes last call's buffer back
-    ctx->d2h(S.ds.data(), S.d_ds.p, 12 * (size_t)S.n_ds);
-    deinterleave3(ctx, S.d_ds.p, S.n_ds, S.d_ds_soa.p, S.d_ds_soa.p + S.n_ds, S.d_ds_soa.p + 2 * (size_t)S.n_ds);
-    S.plane_ds.resize(3 * (size_t)n_pds);
-    S.pcl.off.resize((size_t)P + 1);
-    S.pcl.xyz.swap(S.vox_planes.out_xyz);
-    S.pcl.d_off.swap(S.vox_planes.group_offsets);
-    ctx->d2h(S.plane_ds.data(), S.pcl.xyz.p, 12 * (size_t)n_pds);
-    ctx->d2h(S.pcl.off.data(), S.pcl.d_off.p, 4 * ((size_t)P + 1));
-    ctx->sync();
+    if (n_items == 0) std::fill(S.pcl.off.begin(), S.pcl.off.end(), 0u);
     ctx->stats.add(std::string("t_prep_voxel_") + tag, secs_since(tp0));
     tp0 = Clock::now();
-    // ComputeBoundingBox of the whole downsampled cloud (plade.cpp:81-84 / :295-299)
-    Obb ob;
-    if (!oriented_bbox(S.ds.data(), S.n_ds, ob, false)) return false;
-    S.bcenter = ob.center;
-    S.radius = std::max(std::max(ob.width, ob.height), ob.depth) / 2;
-    // per plane (plade.cpp:106-117 / :320-330)
+    if (S.n_ds == 0) return false;
+    S.d_ds_soa.ensure(3 * (size_t)S.n_ds + 4);
+    S.d_ds.swap(S.vox_all.out_xyz);   // the result becomes d_ds, the work area takes last call's buffer back
+    deinterleave3(ctx, S.d_ds.p, S.n_ds, S.d_ds_soa.p, S.d_ds_soa.p + S.n_ds, S.d_ds_soa.p + 2 * (size_t)S.n_ds);
+    S.pcl.xyz.swap(S.vox_planes.out_xyz);
+    S.pcl.d_off.swap(S.vox_planes.group_offsets);
+    const float *ob = S.obb.host.data();
+    if (ob[OBB_OUT_WHOLE - 1] == 0.f) return false;
+    S.bcenter = f3(ob[0], ob[1], ob[2]);
+    memcpy(&S.radius, ob + 4, 8);
     S.geom.P = P;
     S.geom.coef.assign(pl.coef, pl.coef + 4 * (size_t)P);
     S.geom.center.assign(3 * (size_t)P, 0.f);
@@ -141,19 +141,17 @@ bool prepare_side(plade_ctx *ctx, const char *tag, const CloudDev &cloud, const 
     S.normals.resize(3 * (size_t)P);
     for (uint32_t i = 0; i < P; ++i) {
         for (int k = 0; k < 3; ++k) S.normals[3 * i + k] = pl.coef[4 * (size_t)i + k];
-        const uint32_t b = S.pcl.off[i], e = S.pcl.off[i + 1];
-        Obb pb;
-        if (!oriented_bbox(S.plane_ds.data() + 3 * (size_t)b, e - b, pb, true)) continue;  // empty plane: boxes stay zero
-        f3 four[4];
-        for (int k = 0; k < 4; ++k) {
-            four[k] = project_to_plane(pb.corners[k], pl.coef + 4 * (size_t)i);
-            S.geom.four[12 * (size_t)i + 3 * k] = four[k].x;
-            S.geom.four[12 * (size_t)i + 3 * k + 1] = four[k].y;
-            S.geom.four[12 * (size_t)i + 3 * k + 2] = four[k].z;
-        }
-        const f3 cen = (four[0] + four[2]) / 2.f;
-        S.geom.center[3 * i] = cen.x; S.geom.center[3 * i + 1] = cen.y; S.geom.center[3 * i + 2] = cen.z;
-        S.geom.radius[i] = norm_e(four[0] - four[2]) / 2.f;
+        const float *o = ob + OBB_OUT_WHOLE + (size_t)i * OBB_OUT_PLANE;
+        for (int k = 0; k < 12; ++k) S.geom.four[12 * (size_t)i + k] = o[k];
+        for (int k = 0; k < 3; ++k) S.geom.center[3 * i + k] = o[12 + k];
+        S.geom.radius[i] = o[15];
+    }
+    if (ctx->params.dump) {   // host copies of the downsampled clouds only for the dump
+        S.ds.resize(3 * (size_t)S.n_ds);
+        S.plane_ds.resize(3 * (size_t)n_pds);
+        ctx->d2h(S.ds.data(), S.d_ds.p, 12 * (size_t)S.n_ds);
+        ctx->d2h(S.plane_ds.data(), S.pcl.xyz.p, 12 * (size_t)n_pds);
+        ctx->sync();
     }
     ctx->stats.add(std::string("t_prep_obb_") + tag, secs_since(tp0));
     tp0 = Clock::now();

@@ -571,30 +571,23 @@ __device__ __forceinline__ bool same_plane(const float4 &a, const float4 &b, flo
 
 // Leaders of a round: the hypotheses by estimated support, one representative per distinct plane -- a greedy pass in
 // descending order that drops what duplicates an earlier pick (= repeatedly take the best candidate alive and strike
-// out its duplicates).  One workgroup of 1024 lanes per cloud, four hypotheses per lane, two stages:
-//   (1) all lanes: every candidate is hashed by its quantised (orientation-free) plane into an LDS table that keeps
-//       the best key per slot; a candidate that lost its slot to a better candidate OF THE SAME PLANE is a duplicate
-//       the greedy pass would strike anyway and is dropped here (typically 4096 -> a few hundred survivors);
-//   (2) one wavefront runs the exact greedy pass over the survivors (each lane owns the entries lane, lane + 64, ...
-//       of the survivor list, so the only cross-lane traffic is the arg-max and the broadcast of the pick).
-constexpr int LEAD_SLOTS = 4096;
+// out its duplicates).  One workgroup of 1024 lanes per cloud, four hypotheses per lane; a pick costs one wave-level
+// arg-max of 32-bit keys (count << 12 | 4095 - index: the subset holds fewer than 2^20 points), ONE barrier (the wave
+// winners and their planes go through double-buffered LDS) and four duplicate tests per lane.
 __global__ __launch_bounds__(1024) void k_r_leaders(const RArgs A) {
     const RCloudArgs &C = A.c[blockIdx.x];
     RState *S = C.st;
     if (S->done || !S->sampling) return;
-    __shared__ unsigned long long s_tab[LEAD_SLOTS];
-    __shared__ unsigned long long s_lkey[R_H];
-    __shared__ float4 s_lpl[R_H];
-    __shared__ uint32_t s_val[16], s_cnt[16];
+    __shared__ uint32_t s_key[2][16];
+    __shared__ float4 s_pl[2][16];
+    __shared__ uint32_t s_val[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t sub_un = S->sub_unassigned, n_rem = S->n_remaining, ms = S->min_support;
     const float eps = S->eps;
     const double ratio = sub_un ? (double)n_rem / sub_un : 0.0;
-    unsigned long long key[4];
+    uint32_t key[4];
     float4 pl[4];
-    uint32_t slot[4];
     uint32_t valid = 0;
-    for (int i = tid; i < LEAD_SLOTS; i += 1024) s_tab[i] = 0ull;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const uint32_t i = tid + q * 1024;
@@ -603,78 +596,46 @@ __global__ __launch_bounds__(1024) void k_r_leaders(const RArgs A) {
         pl[q] = C.hyp[i];
         valid += pos.w != 0.f;   // w: 0 no samples, 1 verified plane, 2 drawn but rejected
         const bool ok = pos.w == 1.f && c * ratio >= 0.5 * ms;
-        key[q] = ok ? (((unsigned long long)c << 32) | (0xffffffffu - i)) : 0ull;   // count descending, index ascending
-        // orientation-free quantised plane: the largest component of the normal made positive
-        float4 cp = pl[q];
-        const float ax = fabsf(cp.x), ay = fabsf(cp.y), az = fabsf(cp.z);
-        const float lead = (ax >= ay && ax >= az) ? cp.x : (ay >= az ? cp.y : cp.z);
-        if (lead < 0.f) { cp.x = -cp.x; cp.y = -cp.y; cp.z = -cp.z; cp.w = -cp.w; }
-        const int qx = (int)floorf(cp.x * 8.f), qy = (int)floorf(cp.y * 8.f), qz = (int)floorf(cp.z * 8.f);
-        const int qd = ok ? (int)floorf(cp.w / (4.f * eps)) : 0;
-        slot[q] = ((uint32_t)qx * 73856093u ^ (uint32_t)qy * 19349663u ^ (uint32_t)qz * 83492791u ^ (uint32_t)qd * 2654435761u) & (LEAD_SLOTS - 1);
+        key[q] = ok ? ((min(c, 0xfffffu) << 12) | (0xfffu - i)) : 0u;   // count descending, index ascending; 0 = not a candidate
     }
     for (int d = 32; d >= 1; d >>= 1) valid += __shfl_xor(valid, d, 64);
     if (lane == 0) s_val[wave] = valid;
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-        if (key[q]) atomicMax(&s_tab[slot[q]], key[q]);
-    __syncthreads();
-    uint32_t mine = 0;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        if (!key[q]) continue;
-        const unsigned long long w = s_tab[slot[q]];
-        if (w != key[q]) {
-            const uint32_t widx = 0xffffffffu - (uint32_t)(w & 0xffffffffull);
-            if (same_plane(C.hyp[widx], pl[q], eps)) key[q] = 0ull;   // duplicate of a better candidate
-        }
-        mine += key[q] != 0ull;
-    }
-    // ordered compaction of the survivors
-    uint32_t incl = mine;
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t o = __shfl_up(incl, d, 64);
-        if (lane >= d) incl += o;
-    }
-    if (lane == 63) s_cnt[wave] = incl;
-    __syncthreads();
-    uint32_t off = incl - mine, ns = 0;
-    for (int w = 0; w < 16; ++w) { if (w < wave) off += s_cnt[w]; ns += s_cnt[w]; }
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-        if (key[q]) { s_lkey[off] = key[q]; s_lpl[off] = pl[q]; ++off; }
-    __syncthreads();
-    if (wave != 0) return;
-    // exact greedy pass, one wavefront
     uint32_t npool = 0;
     for (; npool < R_TOP; ++npool) {
-        unsigned long long m = 0ull;
-        uint32_t at = 0;
-        for (uint32_t e = lane; e < ns; e += 64) {
-            const unsigned long long k = s_lkey[e];
-            if (k > m) { m = k; at = e; }
-        }
-        unsigned long long best = m;
-        for (int d = 32; d >= 1; d >>= 1) {
-            const unsigned long long o = __shfl_xor(best, d, 64);
-            best = o > best ? o : best;
-        }
-        if (best == 0ull) break;     // uniform
-        const int owner = __ffsll((long long)__ballot(m == best)) - 1;   // keys are unique
-        float4 nw = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (lane == owner) nw = s_lpl[at];
-        nw.x = __shfl(nw.x, owner, 64); nw.y = __shfl(nw.y, owner, 64); nw.z = __shfl(nw.z, owner, 64); nw.w = __shfl(nw.w, owner, 64);
-        if (lane == owner) {
-            const uint32_t idx = 0xffffffffu - (uint32_t)(best & 0xffffffffull);
+        const int buf = npool & 1;
+        // this lane's best, then the wave's
+        uint32_t m = key[0];
+        int mq = 0;
+        if (key[1] > m) { m = key[1]; mq = 1; }
+        if (key[2] > m) { m = key[2]; mq = 2; }
+        if (key[3] > m) { m = key[3]; mq = 3; }
+        uint32_t wm = m;
+        for (int d = 32; d >= 1; d >>= 1) wm = max(wm, (uint32_t)__shfl_xor((int)wm, d, 64));
+        if (m == wm && wm != 0u) {   // keys are unique: exactly one lane of the wave
+            s_key[buf][wave] = wm;
+            float4 v = pl[0];
+            if (mq == 1) v = pl[1]; else if (mq == 2) v = pl[2]; else if (mq == 3) v = pl[3];
+            s_pl[buf][wave] = v;
+        } else if (lane == 0 && wm == 0u) s_key[buf][wave] = 0u;
+        __syncthreads();
+        uint32_t best = 0;
+        int bw = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) { const uint32_t k = s_key[buf][w]; if (k > best) { best = k; bw = w; } }
+        if (best == 0u) break;     // uniform
+        const float4 nw = s_pl[buf][bw];
+        if (tid == 0) {
+            const uint32_t idx = 0xfffu - (best & 0xfffu);
             S->pool_pl[npool] = nw;
             S->pool_pos[npool] = C.hyp_pos[idx];
         }
-        for (uint32_t e = lane; e < ns; e += 64)
-            if (s_lkey[e] && same_plane(nw, s_lpl[e], eps)) s_lkey[e] = 0ull;   // strikes the pick itself too
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (key[q] && same_plane(nw, pl[q], eps)) key[q] = 0u;   // strikes the pick itself too
     }
-    if (lane < (int)R_TOP) S->pool_cnt[lane] = 0;
-    if (lane == 0) {
+    __syncthreads();
+    if (tid < (int)R_TOP) S->pool_cnt[tid] = 0;
+    if (tid == 0) {
         uint32_t v = 0;
         for (int w = 0; w < 16; ++w) v += s_val[w];
         S->drawn += (float)v;

@@ -99,6 +99,19 @@ void penetration_filter(plade_ctx *ctx, const float *cand_rt_host /*K x 12: R ro
                         PlaneCloudsDev &tgt_pts, float length_threshold, float angle_threshold,
                         std::vector<int32_t> &flags_out);
 
+// ---- oriented bounding boxes (k_obb.hip; ComputeBoundingBox, util.h:186-248) ---------------------------------
+// Result block (floats): whole cloud = centre(3), pad, radius as a double (2 floats), pad, valid flag;
+// per plane = the four projected corners (12), their centre (3), half diagonal (1).
+constexpr uint32_t OBB_OUT_WHOLE = 8, OBB_OUT_PLANE = 16;
+struct ObbWork {
+    DBuf<float> d_coef, chunks, out;
+    std::vector<float> host;     // the result block, valid after the sync that follows obb_units
+};
+// queues the boxes of the whole downsampled cloud and of every per-plane cloud (device arrays whose sizes are still on
+// the device: *d_n_ds <= max_ds points, d_plane_off[P] <= max_plane_pts) + the small read-back
+void obb_units(plade_ctx *ctx, ObbWork &W, const float *d_ds, const uint32_t *d_n_ds, uint32_t max_ds, const float *d_plane_ds,
+               const uint32_t *d_plane_off, uint32_t max_plane_pts, uint32_t P, const float *coef_host);
+
 // generic: positions of set flags (ordered); returns count (sync)
 uint32_t compact_flags(plade_ctx *ctx, const uint32_t *d_flags, uint32_t n, DBuf<uint32_t> &pos_scratch,
                        DBuf<uint32_t> &out_idx);
