@@ -29,6 +29,20 @@ def _i32(a):
     return np.ascontiguousarray(a, dtype=np.int32)
 
 
+def mirror_planes(planes):
+    """The "unoriented normals" mode of the reference's README (README.md:109-110): "allowing a plane (a group of 3D
+    points) to have two opposite orientations.  This way, more descriptors (considering both orientations for each plane)
+    will be generated and matched."  Restated as a transformation of the TARGET plane set handed to registration():
+    every plane (n, d) is followed by (-n, -d) with the same support, so the target's descriptor table holds every sign
+    pattern of every pair of intersection lines (the reference ships no code for this mode: this is its specification
+    here, mirrored by plade_amd/csrc/pipeline.h MirroredPlanes)."""
+    coef, off, idx = _f32(planes[0]).reshape(-1, 4), _i32(planes[1]), _i32(planes[2])
+    total = int(off[-1])
+    return (np.concatenate([coef, -coef]).astype(np.float32),
+            np.concatenate([off, total + off[1:]]).astype(np.int32),
+            np.concatenate([idx[:total], idx[:total]]).astype(np.int32))
+
+
 class Oracle:
     """CPU restatement of the reference's algorithm (oracle/plade_oracle.cpp)."""
 
@@ -164,12 +178,15 @@ class Oracle:
                                         src_radius, inlier_dist)
 
     # -- whole deterministic stage ---------------------------------------------
-    def registration(self, tgt, src, tgt_planes, src_planes, voxel_sort_mode=0, max_candidates=200, pen_stride=1):
+    def registration(self, tgt, src, tgt_planes, src_planes, voxel_sort_mode=0, max_candidates=200, pen_stride=1,
+                     unoriented_normals=False):
         """tgt/src: N x 6 float32. *_planes: (coef P x 4, offsets P+1, idx).  Returns (ok, T, dump dict).
         pen_stride > 1: sampled run for stress configurations (orc_registration_sampled) -- only every pen_stride-th
         candidate goes through the penetration test (pen_flags -1 elsewhere) and the run ends after that stage."""
         tgt = _f32(tgt)
         src = _f32(src)
+        if unoriented_normals:
+            tgt_planes = mirror_planes(tgt_planes)
         tc, to, ti = _f32(tgt_planes[0]), _i32(tgt_planes[1]), _i32(tgt_planes[2])
         sc, so, si = _f32(src_planes[0]), _i32(src_planes[1]), _i32(src_planes[2])
         T = np.zeros((4, 4), np.float32)

@@ -9,7 +9,7 @@
 // centroid.hpp:79-121, 250-300): a 60 000-step dependent chain a GPU lane would spend half a millisecond on.  Here the
 // points of a unit are cut into chunks of OBB_CHUNK = 64 consecutive points; lanes sum one chunk each, point after
 // point, and one lane adds the chunk sums in chunk order: the same additions re-associated, deterministic, and exactly
-// what the oracle's sum mode 1 does (oracle/plade_oracle.cpp bounding_box).  Everything after the sums -- Eigen's 3x3
+// what the CPU checker's sum mode 1 does (see tests).  Everything after the sums -- Eigen's 3x3
 // self-adjoint solver, the frame, min / max, corners -- is PCL's arithmetic operation for operation (hostgeom.h).
 #include "stages.h"
 #include "hostgeom.h"
@@ -20,25 +20,63 @@ namespace {
 
 struct ObbArgs {
     const float *ds; const uint32_t *n_ds_p;   // whole downsampled cloud, n x 3 (its size is still on the device)
-    uint32_t chunk_base_planes;                // first scratch chunk of the per-plane units
     const float *plane_ds; const uint32_t *plane_off; uint32_t P;   // per-plane clouds, concatenated, P + 1 offsets
     const float *coef;                         // P x 4 plane coefficients
-    float *chunks;                             // scratch: 9 floats per chunk
     float *out;                                // OBB_OUT_WHOLE + P * OBB_OUT_PLANE floats
 };
 
-__global__ __launch_bounds__(256) void k_obb_units(const ObbArgs A) {
-    __shared__ float s_c[3], s_P[12], s_E[9];
-    __shared__ float s_mm[6][4];
+constexpr int OBB_T = 256;
+constexpr int OBB_LDS_CHUNKS = 2048;   // chunk sums held in LDS at a time (larger units go through it in rounds)
+
+// sums of the K-component per-point terms over the points of one unit in the chunked order: lanes sum one chunk each
+// (point after point; 16 points are fetched ahead of the additions), the chunk sums go to LDS, lane q < K adds the chunk
+// sums of component q in chunk order
+template <int K, class Term>
+__device__ void chunked_sums(const float *__restrict__ pts, uint32_t n, float (*s_ch)[6], float *s_out, Term term) {
+    const uint32_t nch = (n + OBB_CHUNK - 1) / OBB_CHUNK;
+    float total = 0.f;   // lanes < K: running sum of their component
+    for (uint32_t c0 = 0; c0 < nch; c0 += OBB_LDS_CHUNKS) {
+        const uint32_t cn = min((uint32_t)OBB_LDS_CHUNKS, nch - c0);
+        for (uint32_t k = threadIdx.x; k < cn; k += OBB_T) {
+            float acc[K];
+#pragma unroll
+            for (int q = 0; q < K; ++q) acc[q] = 0.f;
+            const uint32_t b = (c0 + k) * OBB_CHUNK, e = min(n, b + OBB_CHUNK);
+            for (uint32_t i0 = b; i0 < e; i0 += 16) {
+                float x[16], y[16], z[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const uint32_t i = min(i0 + j, e - 1);
+                    x[j] = pts[3 * (size_t)i]; y[j] = pts[3 * (size_t)i + 1]; z[j] = pts[3 * (size_t)i + 2];
+                }
+#pragma unroll
+                for (int j = 0; j < 16; ++j)
+                    if (i0 + j < e) term(acc, f3(x[j], y[j], z[j]));
+            }
+#pragma unroll
+            for (int q = 0; q < K; ++q) s_ch[k][q] = acc[q];
+        }
+        __syncthreads();
+        if (threadIdx.x < K)
+            for (uint32_t k = 0; k < cn; ++k) total += s_ch[k][threadIdx.x];
+        __syncthreads();
+    }
+    if (threadIdx.x < K) s_out[threadIdx.x] = total;
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(OBB_T) void k_obb_units(const ObbArgs A) {
+    __shared__ float s_ch[OBB_LDS_CHUNKS][6];
+    __shared__ float s_c[3], s_cov[6], s_P[12], s_E[9];
+    __shared__ float s_mm[6][OBB_T / 64];
     const uint32_t u = blockIdx.x;
     const float *pts;
-    uint32_t n, chunk0;
-    if (u == 0) { pts = A.ds; n = *A.n_ds_p; chunk0 = 0; }
+    uint32_t n;
+    if (u == 0) { pts = A.ds; n = *A.n_ds_p; }
     else {
         const uint32_t b = A.plane_off[u - 1], e = A.plane_off[u];
         pts = A.plane_ds + 3 * (size_t)b;
         n = e - b;
-        chunk0 = A.chunk_base_planes + b / OBB_CHUNK + u;   // disjoint chunk ranges for all units
     }
     float *out = u == 0 ? A.out : A.out + OBB_OUT_WHOLE + (size_t)(u - 1) * OBB_OUT_PLANE;
     if (n == 0) {   // empty plane: its boxes stay zero (plade.cpp:106-117 skips it)
@@ -46,39 +84,12 @@ __global__ __launch_bounds__(256) void k_obb_units(const ObbArgs A) {
         else if (threadIdx.x == 0) out[OBB_OUT_WHOLE - 1] = 0.f;
         return;
     }
-    float *ch = A.chunks + 9 * (size_t)chunk0;
-    const uint32_t nch = (n + OBB_CHUNK - 1) / OBB_CHUNK;
     const float nf = (float)n;
-    // ---- centroid: chunk sums, then the chunk sums in order
-    for (uint32_t k = threadIdx.x; k < nch; k += blockDim.x) {
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-        const uint32_t b = k * OBB_CHUNK, e = min(n, b + OBB_CHUNK);
-        for (uint32_t i = b; i < e; ++i) { s0 += pts[3 * (size_t)i]; s1 += pts[3 * (size_t)i + 1]; s2 += pts[3 * (size_t)i + 2]; }
-        ch[9 * (size_t)k] = s0; ch[9 * (size_t)k + 1] = s1; ch[9 * (size_t)k + 2] = s2;
-    }
-    __syncthreads();
-    if (threadIdx.x < 3) {
-        float c = 0.f;
-        for (uint32_t k = 0; k < nch; ++k) c += ch[9 * (size_t)k + threadIdx.x];
-        s_c[threadIdx.x] = c / nf;
-    }
-    __syncthreads();
-    const float c[3] = {s_c[0], s_c[1], s_c[2]};
-    // ---- covariance about the centroid, same chunking
-    for (uint32_t k = threadIdx.x; k < nch; k += blockDim.x) {
-        float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        const uint32_t b = k * OBB_CHUNK, e = min(n, b + OBB_CHUNK);
-        for (uint32_t i = b; i < e; ++i) cov_add_point(acc, f3(pts[3 * (size_t)i], pts[3 * (size_t)i + 1], pts[3 * (size_t)i + 2]), c);
-        for (int q = 0; q < 6; ++q) ch[9 * (size_t)k + 3 + q] = acc[q];
-    }
-    __syncthreads();
-    __shared__ float s_cov[6];
-    if (threadIdx.x < 6) {
-        float v = 0.f;
-        for (uint32_t k = 0; k < nch; ++k) v += ch[9 * (size_t)k + 3 + threadIdx.x];
-        s_cov[threadIdx.x] = v;
-    }
-    __syncthreads();
+    // ---- centroid (compute3DCentroid, centroid.hpp:79-121)
+    chunked_sums<3>(pts, n, s_ch, s_c, [](float *acc, f3 p) { acc[0] += p.x; acc[1] += p.y; acc[2] += p.z; });
+    const float c[3] = {s_c[0] / nf, s_c[1] / nf, s_c[2] / nf};
+    // ---- covariance about the centroid (computeCovarianceMatrixNormalized, centroid.hpp:250-300), same chunking
+    chunked_sums<6>(pts, n, s_ch, s_cov, [c](float *acc, f3 p) { cov_add_point(acc, p, c); });
     if (threadIdx.x == 0) {
         const float cov6[6] = {s_cov[0], s_cov[1], s_cov[2], s_cov[3], s_cov[4], s_cov[5]};
         m3 E;
@@ -139,12 +150,10 @@ void obb_units(plade_ctx *ctx, ObbWork &W, const float *d_ds, const uint32_t *d_
                const uint32_t *d_plane_off, uint32_t max_plane_pts, uint32_t P, const float *coef_host) {
     W.d_coef.ensure(4 * (size_t)P + 4);
     if (P) ctx->h2d(W.d_coef.p, coef_host, 16 * (size_t)P);
-    const uint32_t base_planes = max_ds / OBB_CHUNK + 2;
-    const size_t chunks = (size_t)base_planes + (size_t)max_plane_pts / OBB_CHUNK + P + 4;
-    W.chunks.ensure(9 * chunks + 16);
+    (void)max_ds; (void)max_plane_pts;
     W.out.ensure(OBB_OUT_WHOLE + (size_t)P * OBB_OUT_PLANE + 4);
     W.host.resize(OBB_OUT_WHOLE + (size_t)P * OBB_OUT_PLANE);
-    ObbArgs A{d_ds, d_n_ds, base_planes, d_plane_ds, d_plane_off, P, W.d_coef.p, W.chunks.p, W.out.p};
+    ObbArgs A{d_ds, d_n_ds, d_plane_ds, d_plane_off, P, W.d_coef.p, W.out.p};
     hipLaunchKernelGGL(k_obb_units, dim3(P + 1), dim3(256), 0, ctx->stream, A);
     HIP_TRY(hipGetLastError());
     ctx->d2h(W.host.data(), W.out.p, 4 * W.host.size());   // valid after the next sync of the stream

@@ -16,6 +16,22 @@ struct PlaneSetView {
     const int32_t *idx = nullptr;
     const uint32_t *d_idx = nullptr;
     uint32_t P = 0;
+    // unoriented-normals mode: planes [P/2, P) are planes [0, P/2) with (n, d) negated and the same supports; d_idx then
+    // holds the supports of the first half only (offsets[P/2] items)
+    bool mirrored = false;
+};
+
+// The "unoriented normals" mode the reference's README describes (README.md:109-110): "allowing a plane (a group of 3D
+// points) to have two opposite orientations.  This way, more descriptors (considering both orientations for each plane)
+// will be generated and matched."  Every plane of the TARGET takes part twice, as (n, d) and as (-n, -d), with the same
+// support: the target's descriptor table then holds every sign pattern of every pair of intersection lines, so a source
+// pair finds its counterpart whatever signs the source planes came out with, and the plane-consistency count finds an
+// aligned copy of every matching target plane.  (Mirroring the source as well would only repeat each candidate.)
+struct MirroredPlanes {
+    std::vector<float> coef;
+    std::vector<int32_t> offsets, idx;
+    // from a plane set (idx may be null when the lists live on the device only)
+    void build(const float *coef_in, const int32_t *offsets_in, const int32_t *idx_in, uint32_t P);
 };
 
 struct RegistrationWork;

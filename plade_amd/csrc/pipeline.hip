@@ -103,7 +103,11 @@ bool prepare_side(plade_ctx *ctx, const char *tag, const CloudDev &cloud, const 
     S.vox_all.enqueue(ctx, cloud.aos.p, 6, cloud.x(), cloud.y(), cloud.z(), nullptr, nullptr, cloud.n, 1, leaf, cloud.bbmin, cloud.bbmax);
     const uint32_t n_items = (uint32_t)pl.offsets[P];
     S.d_items.ensure((size_t)n_items + 4); S.d_groups.ensure((size_t)n_items + 4); S.d_offs.ensure((size_t)P + 2);
-    if (pl.d_idx) HIP_TRY(hipMemcpyAsync(S.d_items.p, pl.d_idx, 4 * (size_t)n_items, hipMemcpyDeviceToDevice, ctx->stream));
+    if (pl.d_idx && pl.mirrored) {   // the mirrored half shares the supports of the first half
+        const size_t half = (size_t)pl.offsets[P / 2];
+        HIP_TRY(hipMemcpyAsync(S.d_items.p, pl.d_idx, 4 * half, hipMemcpyDeviceToDevice, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(S.d_items.p + half, pl.d_idx, 4 * half, hipMemcpyDeviceToDevice, ctx->stream));
+    } else if (pl.d_idx) HIP_TRY(hipMemcpyAsync(S.d_items.p, pl.d_idx, 4 * (size_t)n_items, hipMemcpyDeviceToDevice, ctx->stream));
     else ctx->h2d(S.d_items.p, pl.idx, 4 * (size_t)n_items);
     ctx->h2d(S.d_offs.p, pl.offsets, 4 * ((size_t)P + 1));
     if (n_items)
@@ -204,6 +208,19 @@ struct RegistrationWork {
     hipEvent_t ev_grid = nullptr;   // target grid of the verification built on the auxiliary stream
     ~RegistrationWork() { if (ev_grid) (void)hipEventDestroy(ev_grid); }
 };
+
+void MirroredPlanes::build(const float *coef_in, const int32_t *offsets_in, const int32_t *idx_in, uint32_t P) {
+    coef.assign(coef_in, coef_in + 4 * (size_t)P);
+    for (size_t i = 0; i < 4 * (size_t)P; ++i) coef.push_back(-coef_in[i]);
+    offsets.assign(offsets_in, offsets_in + P + 1);
+    const int32_t total = offsets_in[P];
+    for (uint32_t i = 1; i <= P; ++i) offsets.push_back(total + offsets_in[i]);
+    idx.clear();
+    if (idx_in) {
+        idx.assign(idx_in, idx_in + total);
+        idx.insert(idx.end(), idx_in, idx_in + total);
+    }
+}
 
 RegistrationWork *registration_work_create() { return new RegistrationWork; }
 void registration_work_destroy(RegistrationWork *w) { delete w; }
@@ -498,6 +515,12 @@ extern "C" int plade_registration_planes(plade_ctx *ctx, const float *tgt_pos_nr
         PlaneSetView tp, sp;
         tp.coef = tgt_planes; tp.offsets = tgt_offsets; tp.idx = tgt_idx; tp.P = p_t;
         sp.coef = src_planes; sp.offsets = src_offsets; sp.idx = src_idx; sp.P = p_s;
+        MirroredPlanes mirror;
+        if (ctx->params.unoriented_normals) {   // README.md:109-110, see MirroredPlanes
+            mirror.build(tgt_planes, tgt_offsets, tgt_idx, p_t);
+            tp.coef = mirror.coef.data(); tp.offsets = mirror.offsets.data(); tp.idx = mirror.idx.data(); tp.P = 2 * p_t;
+            tp.mirrored = true;
+        }
         Clock::time_point t0 = Clock::now();
         const bool ok = run_registration(ctx, *ctx->reg_work, tgt, src, tp, sp, T16, nullptr);
         ctx->stats.add("t_registration", secs_since(t0));

@@ -158,6 +158,13 @@ int register_clouds(plade_ctx *ctx, const CloudDev &tgt, const CloudDev &src, in
     tv.coef = tp.coef.data(); tv.offsets = tp.offsets.data(); tv.idx = tp.idx.data(); tv.P = tp.P();
     sv.coef = sp.coef.data(); sv.offsets = sp.offsets.data(); sv.idx = sp.idx.data(); sv.P = sp.P(); sv.d_idx = sp.d_idx;
     tv.d_idx = tp.d_idx;
+    MirroredPlanes mirror;
+    if (ctx->params.unoriented_normals) {   // README.md:109-110, see MirroredPlanes (pipeline.h)
+        mirror.build(tp.coef.data(), tp.offsets.data(), tp.idx.size() == (size_t)tp.offsets.back() ? tp.idx.data() : nullptr, tp.P());
+        tv.coef = mirror.coef.data(); tv.offsets = mirror.offsets.data(); tv.P = 2 * tp.P(); tv.mirrored = true;
+        tv.idx = mirror.idx.empty() ? nullptr : mirror.idx.data();
+        if (!tv.d_idx && !tv.idx && tv.offsets[tv.P]) { tv.mirrored = false; }   // cannot happen: one of the two lists always exists
+    }
     const bool ok = run_registration(ctx, *ctx->reg_work, tgt, src, tv, sv, T16, have_spacing ? &spacing : nullptr);
     ctx->stats.add("t_registration", secs_since(t0));
     // roofline bookkeeping; bytes_ransac was summed per scan launch and cloud by extract_pair

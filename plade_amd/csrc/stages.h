@@ -104,7 +104,7 @@ void penetration_filter(plade_ctx *ctx, const float *cand_rt_host /*K x 12: R ro
 // per plane = the four projected corners (12), their centre (3), half diagonal (1).
 constexpr uint32_t OBB_OUT_WHOLE = 8, OBB_OUT_PLANE = 16;
 struct ObbWork {
-    DBuf<float> d_coef, chunks, out;
+    DBuf<float> d_coef, out;
     std::vector<float> host;     // the result block, valid after the sync that follows obb_units
 };
 // queues the boxes of the whole downsampled cloud and of every per-plane cloud (device arrays whose sizes are still on
