@@ -34,6 +34,10 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
 
+KERNEL_SYMBOLS = {"score_mark": "k_r_mark(", "score_multi": "k_r_rescore(", "overlap": "k_overlap(", "knn_spacing": "k_knn_grid(",
+                  "pen_walk": "k_pen_walk(", "cluster_edges": "k_cluster_edges("}
+
+
 def pmc_traffic(tag):
     """HBM bytes per launch of the roofline kernel from the committed PMC summary (separate
     `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this same command, FETCH_SIZE doubled as
@@ -43,9 +47,7 @@ def pmc_traffic(tag):
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm.csv")))
     if not files:
         return None, None
-    sym = {"score_mark": "k_score_mark_batch(", "score_multi": "k_score_multi<false>(", "score_subset": "k_score_multi<true>(",
-           "overlap": "k_overlap(", "knn_spacing": "k_knn_grid(", "pen_walk": "k_pen_walk(",
-           "cluster_edges": "k_cluster_edges("}.get(tag, tag + "(")
+    sym = KERNEL_SYMBOLS.get(tag, tag + "(")
     with open(files[-1]) as f:
         for r in csv.DictReader(f):
             if sym in r["kernel"]:
@@ -53,6 +55,29 @@ def pmc_traffic(tag):
                 wr = float(r["hbm_write_bytes(WRITE_SIZE*1024)"])
                 return rd + wr, os.path.relpath(files[-1], ROOT)
     return None, None
+
+
+def rocprof_stats(tag):
+    """(average launch duration in us, share of the GPU time, file) of the roofline kernel in the committed
+    `rocprofv3 --kernel-trace --stats` summary of this command (profiles/*_kernel_stats.csv), plus the three kernels with
+    the most GPU time there: the live HIP-event figure on the line must agree with this average."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_kernel_stats.csv")))
+    if not files:
+        return None
+    sym = KERNEL_SYMBOLS.get(tag, tag + "(")
+    rows = list(csv.DictReader(open(files[-1])))
+    total = sum(float(r["TotalDurationNs"]) for r in rows) or 1.0
+    top = sorted(rows, key=lambda r: -float(r["TotalDurationNs"]))[:3]
+    out = {"file": os.path.relpath(files[-1], ROOT),
+           "top3_by_gpu_time": [{"kernel": r["Name"].split("(")[0][-40:], "share": float(r["TotalDurationNs"]) / total} for r in top]}
+    for r in rows:
+        if sym in r["Name"]:
+            out.update({"avg_launch_us": float(r["AverageNs"]) / 1e3, "calls": int(r["Calls"]),
+                        "share_of_gpu_time": float(r["TotalDurationNs"]) / total})
+            break
+    return out
 
 
 def cpu_baseline(n_points, pairs, min_s=10.0, budget_s=25.0):
@@ -160,6 +185,7 @@ def main():
                          "(a single registration is latency-bound and leaves most of the GPU idle)")
     ap.add_argument("--host-steps", type=int, default=128,
                     help="steps of the extra host-buffer leg (plade_registration on page-locked host arrays, H2D inside); 0 = skip")
+    ap.add_argument("--profiled-steps", type=int, default=8, help="registrations of the roofline leg (HIP events per launch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -326,15 +352,41 @@ def main():
             step(i)
             lat.append(time.perf_counter() - t1)
         latency_ms = min(lat) * 1e3
-        ctx.set_params(dump=2, host_wait=host_wait)   # the profiled step runs in the mode of the timed region
-        step(0)
-        st = ctx.stats()
+        # Profiled steps (HIP events on the launch stream around every launch of the scan kernels) on context 0 WHILE the
+        # other contexts keep registering, i.e. under the load of the timed region: the average launch duration must be
+        # the one `rocprofv3 --kernel-trace --stats` reports for this command (profiles/), not that of an idle GPU.
+        ctx.set_params(dump=2, host_wait=host_wait)
+        stop = threading.Event()
+
+        def background(w):
+            i = w
+            while not stop.is_set():
+                step(i, w)
+                i += 1
+        bths = [threading.Thread(target=background, args=(w,)) for w in range(1, M)]
+        for t in bths:
+            t.start()
+        st = {}
+        for i in range(args.profiled_steps):
+            step(i)
+            for k, v in ctx.stats().items():
+                if k.startswith(("k_", "bytes_")):
+                    st[k] = st.get(k, 0.0) + v
+                else:
+                    st[k] = v
+        stop.set()
+        for t in bths:
+            t.join()
+        for k in list(st):
+            if k.startswith("bytes_"):
+                st[k] /= args.profiled_steps
         ctx.set_params(dump=0, host_wait=host_wait)
         kernels = sorted({k[2:-8] for k in st if k.startswith("k_") and k.endswith("_seconds")})
         best = None
         for name in kernels:
             secs, nl, by = st[f"k_{name}_seconds"], st[f"k_{name}_launches"], st[f"k_{name}_bytes"]
-            stage[name] = {"seconds": secs, "launches": int(nl), "GB/s": (by / secs / 1e9) if secs > 0 else None}
+            stage[name] = {"seconds": secs / args.profiled_steps, "launches": nl / args.profiled_steps,
+                           "GB/s": (by / secs / 1e9) if secs > 0 else None}
             # the roofline kernel is the one with the most GPU time among the HBM-streaming kernels (those
             # with an algorithmic byte count); latency-bound kernels are listed for reference
             if by > 0 and (best is None or secs > st[f"k_{best}_seconds"]):
@@ -343,10 +395,18 @@ def main():
             secs, nl, by = st[f"k_{best}_seconds"], st[f"k_{best}_launches"], st[f"k_{best}_bytes"]
             achieved = by / secs / 1e9
             traffic, traffic_src = pmc_traffic(best)
-            roofline = {"bound": "hbm", "kernel": best, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            roofline = {"bound": "hbm", "kernel": best, "kernel_symbol": KERNEL_SYMBOLS.get(best, best).rstrip("("),
+                        "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                        "launches_per_step": int(nl), "avg_launch_us": secs / nl * 1e6,
-                        "algorithmic_bytes_per_launch": by / nl}
+                        "launches_per_step": nl / args.profiled_steps, "avg_launch_us": secs / nl * 1e6,
+                        "algorithmic_bytes_per_launch": by / nl,
+                        "measured": f"HIP events on the launch stream, {args.profiled_steps} profiled registrations with "
+                                    f"{M - 1} other registrations in flight (the load of the timed region)"}
+            rp = rocprof_stats(best)
+            if rp is not None:
+                roofline["rocprof"] = rp
+                if rp.get("avg_launch_us"):
+                    roofline["rocprof"]["frac_at_rocprof_average"] = (by / nl) / (rp["avg_launch_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS
         stage_times = {k: v for k, v in st.items() if k.startswith("t_")}
         b_total = st.get("bytes_ransac", 0.0) + st.get("bytes_voxel", 0.0) + st.get("bytes_verify", 0.0)
         if roofline is not None:

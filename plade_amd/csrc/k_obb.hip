@@ -25,7 +25,7 @@ struct ObbArgs {
     float *out;                                // OBB_OUT_WHOLE + P * OBB_OUT_PLANE floats
 };
 
-constexpr int OBB_T = 256;
+constexpr int OBB_T = 1024;
 constexpr int OBB_LDS_CHUNKS = 2048;   // chunk sums held in LDS at a time (larger units go through it in rounds)
 
 // sums of the K-component per-point terms over the points of one unit in the chunked order: lanes sum one chunk each
@@ -57,8 +57,17 @@ __device__ void chunked_sums(const float *__restrict__ pts, uint32_t n, float (*
             for (int q = 0; q < K; ++q) s_ch[k][q] = acc[q];
         }
         __syncthreads();
-        if (threadIdx.x < K)
-            for (uint32_t k = 0; k < cn; ++k) total += s_ch[k][threadIdx.x];
+        if (threadIdx.x < K) {   // chunk sums in chunk order; eight LDS reads ahead of the additions
+            uint32_t k = 0;
+            for (; k + 8 <= cn; k += 8) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = s_ch[k + j][threadIdx.x];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) total += v[j];
+            }
+            for (; k < cn; ++k) total += s_ch[k][threadIdx.x];
+        }
         __syncthreads();
     }
     if (threadIdx.x < K) s_out[threadIdx.x] = total;
@@ -103,10 +112,19 @@ __global__ __launch_bounds__(OBB_T) void k_obb_units(const ObbArgs A) {
     float P[12];
     for (int q = 0; q < 12; ++q) P[q] = s_P[q];
     float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
-        const f3 q = pcl_xform(P, f3(pts[3 * (size_t)i], pts[3 * (size_t)i + 1], pts[3 * (size_t)i + 2]));
-        mn[0] = fminf(mn[0], q.x); mn[1] = fminf(mn[1], q.y); mn[2] = fminf(mn[2], q.z);
-        mx[0] = fmaxf(mx[0], q.x); mx[1] = fmaxf(mx[1], q.y); mx[2] = fmaxf(mx[2], q.z);
+    for (uint32_t i0 = threadIdx.x; i0 < n; i0 += 4 * OBB_T) {   // four points in flight per lane
+        float x[4], y[4], z[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t i = min(i0 + j * OBB_T, n - 1);
+            x[j] = pts[3 * (size_t)i]; y[j] = pts[3 * (size_t)i + 1]; z[j] = pts[3 * (size_t)i + 2];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {   // a clamped repeat of the last point changes no minimum / maximum
+            const f3 q = pcl_xform(P, f3(x[j], y[j], z[j]));
+            mn[0] = fminf(mn[0], q.x); mn[1] = fminf(mn[1], q.y); mn[2] = fminf(mn[2], q.z);
+            mx[0] = fmaxf(mx[0], q.x); mx[1] = fmaxf(mx[1], q.y); mx[2] = fmaxf(mx[2], q.z);
+        }
     }
     for (int q = 0; q < 3; ++q)
         for (int d = 32; d >= 1; d >>= 1) {
@@ -116,10 +134,8 @@ __global__ __launch_bounds__(OBB_T) void k_obb_units(const ObbArgs A) {
     if ((threadIdx.x & 63) == 0) for (int q = 0; q < 3; ++q) { s_mm[q][threadIdx.x >> 6] = mn[q]; s_mm[3 + q][threadIdx.x >> 6] = mx[q]; }
     __syncthreads();
     if (threadIdx.x) return;
-    for (int q = 0; q < 3; ++q) {
-        mn[q] = fminf(fminf(s_mm[q][0], s_mm[q][1]), fminf(s_mm[q][2], s_mm[q][3]));
-        mx[q] = fmaxf(fmaxf(s_mm[3 + q][0], s_mm[3 + q][1]), fmaxf(s_mm[3 + q][2], s_mm[3 + q][3]));
-    }
+    for (int q = 0; q < 3; ++q)
+        for (int w = 0; w < OBB_T / 64; ++w) { mn[q] = fminf(mn[q], s_mm[q][w]); mx[q] = fmaxf(mx[q], s_mm[3 + q][w]); }
     m3 E;
     for (int r = 0; r < 3; ++r) for (int k = 0; k < 3; ++k) E.m[r][k] = s_E[3 * r + k];
     f3 center, corners[8];
@@ -154,7 +170,7 @@ void obb_units(plade_ctx *ctx, ObbWork &W, const float *d_ds, const uint32_t *d_
     W.out.ensure(OBB_OUT_WHOLE + (size_t)P * OBB_OUT_PLANE + 4);
     W.host.resize(OBB_OUT_WHOLE + (size_t)P * OBB_OUT_PLANE);
     ObbArgs A{d_ds, d_n_ds, d_plane_ds, d_plane_off, P, W.d_coef.p, W.out.p};
-    hipLaunchKernelGGL(k_obb_units, dim3(P + 1), dim3(256), 0, ctx->stream, A);
+    hipLaunchKernelGGL(k_obb_units, dim3(P + 1), dim3(OBB_T), 0, ctx->stream, A);
     HIP_TRY(hipGetLastError());
     ctx->d2h(W.host.data(), W.out.p, 4 * W.host.size());   // valid after the next sync of the stream
 }

@@ -629,6 +629,10 @@ __global__ __launch_bounds__(1024) void k_r_leaders(const RArgs A) {
             S->pool_pl[npool] = nw;
             S->pool_pos[npool] = C.hyp_pos[idx];
         }
+        // Only near-identical planes are struck out.  (Striking out every tilted version of the pick as well -- candidates
+        // within 25 degrees whose sample point lies in the pick's 3 eps band -- fills the pool with distinct surfaces and
+        // saves a quarter of the iterations, but small planes then enter the early batches; on 1 of 16 synthetic pairs the
+        // registration that followed chose a symmetric alignment of the room.  Measured on the MI355X, DESIGN.md.)
 #pragma unroll
         for (int q = 0; q < 4; ++q)
             if (key[q] && same_plane(nw, pl[q], eps)) key[q] = 0u;   // strikes the pick itself too
@@ -721,8 +725,8 @@ __device__ bool conflict_free(const float4 &a, const float4 &b, float eps, float
 
 // After the re-score: candidates that can no longer reach min_support are dropped (RansacShapeDetector.cpp:826-832),
 // the rest is ordered by support, and the best candidate plus every further one whose support provably cannot touch
-// the supports already in the batch become this iteration's acceptance chains (accepting them concurrently equals
-// accepting them one by one).  One wavefront per cloud.
+// the support of any better candidate become this iteration's acceptance chains (accepting them concurrently equals
+// accepting them one by one, best first).  One wavefront per cloud.
 __global__ __launch_bounds__(64) void k_r_select(const RArgs A, int phase) {
     const RCloudArgs &C = A.c[blockIdx.x];
     RState *S = C.st;
@@ -761,9 +765,12 @@ __global__ __launch_bounds__(64) void k_r_select(const RArgs A, int phase) {
     uint32_t nb = 1;
     if (lane == 0) s_batch[0] = 0;
     __syncthreads();
+    // candidate i joins the batch only if its support cannot touch the support of ANY better candidate of the pool, in
+    // the batch or not: it would then be accepted before a conflicting better one, which the reference, taking the best
+    // candidate first every time (RansacShapeDetector.cpp:548-617), never does
     for (uint32_t i = 1; i < np2 && nb < (uint32_t)R_B; ++i) {
         bool conflict = false;
-        if ((uint32_t)lane < nb) conflict = !conflict_free(s_pl[i], s_pl[s_batch[lane]], eps, cos_t, bbmin, bbmax);
+        if ((uint32_t)lane < i) conflict = !conflict_free(s_pl[i], s_pl[lane], eps, cos_t, bbmin, bbmax);
         if (__ballot(conflict) == 0ull) {
             if (lane == 0) s_batch[nb] = i;
             ++nb;
