@@ -34,6 +34,7 @@ constexpr int OBB_LDS_CHUNKS = 2048;   // chunk sums held in LDS at a time (larg
 template <int K, class Term>
 __device__ void chunked_sums(const float *__restrict__ pts, uint32_t n, float (*s_ch)[6], float *s_out, Term term) {
     const uint32_t nch = (n + OBB_CHUNK - 1) / OBB_CHUNK;
+    const bool aligned = (reinterpret_cast<uintptr_t>(pts) & 15) == 0;   // chunks start at multiples of 768 bytes
     float total = 0.f;   // lanes < K: running sum of their component
     for (uint32_t c0 = 0; c0 < nch; c0 += OBB_LDS_CHUNKS) {
         const uint32_t cn = min((uint32_t)OBB_LDS_CHUNKS, nch - c0);
@@ -43,15 +44,21 @@ __device__ void chunked_sums(const float *__restrict__ pts, uint32_t n, float (*
             for (int q = 0; q < K; ++q) acc[q] = 0.f;
             const uint32_t b = (c0 + k) * OBB_CHUNK, e = min(n, b + OBB_CHUNK);
             for (uint32_t i0 = b; i0 < e; i0 += 16) {
-                float x[16], y[16], z[16];
+                float v[48];   // 16 points, x y z interleaved
+                if (aligned && i0 + 16 <= e) {   // 192 contiguous bytes per lane: twelve 16-byte loads
+                    const float4 *p4 = reinterpret_cast<const float4 *>(pts + 3 * (size_t)i0);
 #pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    const uint32_t i = min(i0 + j, e - 1);
-                    x[j] = pts[3 * (size_t)i]; y[j] = pts[3 * (size_t)i + 1]; z[j] = pts[3 * (size_t)i + 2];
+                    for (int j = 0; j < 12; ++j) { const float4 t = p4[j]; v[4 * j] = t.x; v[4 * j + 1] = t.y; v[4 * j + 2] = t.z; v[4 * j + 3] = t.w; }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        const uint32_t i = min(i0 + j, e - 1);
+                        v[3 * j] = pts[3 * (size_t)i]; v[3 * j + 1] = pts[3 * (size_t)i + 1]; v[3 * j + 2] = pts[3 * (size_t)i + 2];
+                    }
                 }
 #pragma unroll
                 for (int j = 0; j < 16; ++j)
-                    if (i0 + j < e) term(acc, f3(x[j], y[j], z[j]));
+                    if (i0 + j < e) term(acc, f3(v[3 * j], v[3 * j + 1], v[3 * j + 2]));
             }
 #pragma unroll
             for (int q = 0; q < K; ++q) s_ch[k][q] = acc[q];

@@ -925,103 +925,128 @@ __device__ __forceinline__ bool cc_dims(const float bb[4], uint32_t count, float
 //     BuildBitmap (BitmapPrimitiveShape.h:139-150) with InBitmap (PlanePrimitiveShape.cpp:193-199).  Every workgroup
 //     derives the list's bounding box, its length and its own output offset from the per-tile results of the mark
 //     pass (~1e3 entries, L2 resident): no scan launch, no atomics.  The bitmap is all-zero on entry (the labelling
-//     kernel clears what it used).  grid (tiles, chains of all clouds)
+//     kernel clears what it used).  grid (loop_grid(), chains of all clouds): a workgroup takes every gridDim.x-th tile (a grid
+//     of one workgroup per tile and chain was 15 000 workgroups of which a few hundred had anything to do)
+// The looped list kernels run gridDim.x workgroups per chain; a workgroup takes every gridDim.x-th tile / row, OWN_MAX of
+// them per round (the host sizes gridDim.x so that one round usually does: loop_grid()).
+
+// exclusive prefix of `cnt[0..n)` for the items this workgroup owns: pre[j] = sum of cnt[q] for q < item(j), item(j) =
+// blockIdx.x + j * gridDim.x; also the grand total.  One pass over the counts (L2 resident), per-lane partial sums per
+// owned item kept in registers, combined through LDS.  OWN_MAX owned items are handled per call.
+constexpr int OWN_MAX = 8;
+
 __global__ __launch_bounds__(TPB) void k_r_compact_raster(const RArgs A, int k) {
     __shared__ float s_bb[4][TPB / 64];
-    __shared__ uint32_t s_pre[TPB / 64], s_tot[TPB / 64], s_w[TPB / 64];
+    __shared__ uint32_t s_tot[TPB / 64], s_w[TPB / 64];
+    __shared__ uint32_t s_pre[OWN_MAX][TPB / 64];
     const int g = blockIdx.y / R_B;
     const uint32_t b = blockIdx.y % R_B;
     if (g >= (int)A.ng) return;
     const RCloudArgs &C = A.c[g];
     const uint32_t nb = C.L.nb;
-    if (blockIdx.x >= nb) return;
     RState *S = C.st;
     if (b >= S->nc) return;
     const ChainPtr ch = chain_of(C, b);
     PlaneState *st = &ch.hdr->st[k];
-    // round 1 of loads, all independent
     const uint32_t conv = st->converged;
-    const uint32_t mine = ch.bc1[blockIdx.x];
-    const uint32_t m = ch.masks1[blockIdx.x * TPB + threadIdx.x];
     const float fr[9] = {st->pos[0], st->pos[1], st->pos[2], st->a0[0], st->a0[1], st->a0[2], st->a1[0], st->a1[1], st->a1[2]};
     const float eps = S->bitmap_eps;
     if (conv) return;
     const bool lead = blockIdx.x == 0;
-    if (mine == 0 && !lead) return;   // most tiles of a plane's score list are empty
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // round 2: all tiles' counts and boxes
-    uint32_t pre = 0, tot = 0;
-    float bbv[4] = {INFINITY, INFINITY, -INFINITY, -INFINITY};
-    for (uint32_t q = threadIdx.x; q < nb; q += TPB) {
-        const uint32_t c = ch.bc1[q];
-        tot += c;
-        if (q < blockIdx.x) pre += c;
-        if (c) {
-            const float4 t = ch.bbpart[q];
-            bbv[0] = fminf(bbv[0], t.x); bbv[1] = fminf(bbv[1], t.y); bbv[2] = fmaxf(bbv[2], t.z); bbv[3] = fmaxf(bbv[3], t.w);
-        }
-    }
-    const uint32_t first = blockIdx.x * TILE + threadIdx.x * PPT;
-    uint32_t pv[PPT];
-    float cx[PPT], cy[PPT], cz[PPT];
-#pragma unroll
-    for (int q = 0; q < PPT; ++q) {
-        pv[q] = first + q;
-        if ((m & (1u << q)) && C.list_values) pv[q] = C.list_values[first + q];
-    }
-#pragma unroll
-    for (int q = 0; q < PPT; ++q)
-        if (m & (1u << q)) { cx[q] = C.cv.x[pv[q]]; cy[q] = C.cv.y[pv[q]]; cz[q] = C.cv.z[pv[q]]; }
-    for (int d = 32; d >= 1; d >>= 1) {
-        pre += __shfl_xor(pre, d, 64);
-        tot += __shfl_xor(tot, d, 64);
-        bbv[0] = fminf(bbv[0], __shfl_xor(bbv[0], d, 64)); bbv[1] = fminf(bbv[1], __shfl_xor(bbv[1], d, 64));
-        bbv[2] = fmaxf(bbv[2], __shfl_xor(bbv[2], d, 64)); bbv[3] = fmaxf(bbv[3], __shfl_xor(bbv[3], d, 64));
-    }
-    const uint32_t c = __popc(m);
-    uint32_t incl = c;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t o = __shfl_up(incl, d, 64);
-        if (lane >= d) incl += o;
-    }
-    if (lane == 0) { s_pre[wave] = pre; s_tot[wave] = tot; for (int q = 0; q < 4; ++q) s_bb[q][wave] = bbv[q]; }
-    if (lane == 63) s_w[wave] = incl;
-    __syncthreads();
-    pre = s_pre[0] + s_pre[1] + s_pre[2] + s_pre[3];
-    tot = s_tot[0] + s_tot[1] + s_tot[2] + s_tot[3];
-    for (int q = 0; q < 4; ++q) {
-        float v = s_bb[q][0];
-        for (int w = 1; w < TPB / 64; ++w) v = q < 2 ? fminf(v, s_bb[q][w]) : fmaxf(v, s_bb[q][w]);
-        bbv[q] = v;
-    }
-    uint32_t ue, ve;
-    const bool ok = cc_dims(bbv, tot, eps, ue, ve);
-    if (lead && threadIdx.x == 0) {
-        st->ue = ue; st->ve = ve; st->n_list = tot;
-        if (!ok) st->err = 1;
-        for (int q = 0; q < 4; ++q) st->bb[q] = bbv[q];
-    }
-    if (!ok || mine == 0) return;
-    uint32_t off = pre + incl - c;
-    for (int w = 0; w < wave; ++w) off += s_w[w];
-    const float mnu = bbv[0], mnv = bbv[1];
     uint32_t *__restrict__ idxA = ch.idxA(k);
+    // this workgroup owns tiles blockIdx.x, blockIdx.x + gridDim.x, ...: OWN_MAX of them per round
+    for (uint32_t t0 = blockIdx.x; t0 < nb; t0 += gridDim.x * OWN_MAX) {
+        // all tiles' counts and boxes: list length, bounding box, and the offsets of the owned tiles
+        uint32_t tot = 0, pre[OWN_MAX];
 #pragma unroll
-    for (int q = 0; q < PPT; ++q)
-        if (m & (1u << q)) {
-            float u, v;
-            plane_uv(fr, cx[q], cy[q], cz[q], u, v);
-            int bu = (int)floorf((u - mnu) / eps), bv = (int)floorf((v - mnv) / eps);
-            bu = min(max(bu, 0), (int)ue - 1);
-            bv = min(max(bv, 0), (int)ve - 1);
-            const uint32_t px = (uint32_t)bu + (uint32_t)bv * ue;
-            idxA[off] = pv[q];
-            ch.uv[off] = make_float2(u, v);
-            ch.bidx[off] = px;
-            ch.bmp[px] = 1;
-            ++off;
+        for (int j = 0; j < OWN_MAX; ++j) pre[j] = 0;
+        float bbv[4] = {INFINITY, INFINITY, -INFINITY, -INFINITY};
+        for (uint32_t q = threadIdx.x; q < nb; q += TPB) {
+            const uint32_t c = ch.bc1[q];
+            tot += c;
+#pragma unroll
+            for (int j = 0; j < OWN_MAX; ++j) pre[j] += q < t0 + j * gridDim.x ? c : 0u;
+            if (c) {
+                const float4 t = ch.bbpart[q];
+                bbv[0] = fminf(bbv[0], t.x); bbv[1] = fminf(bbv[1], t.y); bbv[2] = fmaxf(bbv[2], t.z); bbv[3] = fmaxf(bbv[3], t.w);
+            }
         }
+        for (int d = 32; d >= 1; d >>= 1) {
+            tot += __shfl_xor(tot, d, 64);
+#pragma unroll
+            for (int j = 0; j < OWN_MAX; ++j) pre[j] += __shfl_xor(pre[j], d, 64);
+            bbv[0] = fminf(bbv[0], __shfl_xor(bbv[0], d, 64)); bbv[1] = fminf(bbv[1], __shfl_xor(bbv[1], d, 64));
+            bbv[2] = fmaxf(bbv[2], __shfl_xor(bbv[2], d, 64)); bbv[3] = fmaxf(bbv[3], __shfl_xor(bbv[3], d, 64));
+        }
+        __syncthreads();   // the previous round's readers of the LDS arrays are done
+        if (lane == 0) {
+            s_tot[wave] = tot;
+            for (int q = 0; q < 4; ++q) s_bb[q][wave] = bbv[q];
+#pragma unroll
+            for (int j = 0; j < OWN_MAX; ++j) s_pre[j][wave] = pre[j];
+        }
+        __syncthreads();
+        tot = s_tot[0] + s_tot[1] + s_tot[2] + s_tot[3];
+        for (int q = 0; q < 4; ++q) {
+            float v = s_bb[q][0];
+            for (int w = 1; w < TPB / 64; ++w) v = q < 2 ? fminf(v, s_bb[q][w]) : fmaxf(v, s_bb[q][w]);
+            bbv[q] = v;
+        }
+        uint32_t ue, ve;
+        const bool ok = cc_dims(bbv, tot, eps, ue, ve);
+        if (lead && t0 == 0 && threadIdx.x == 0) {
+            st->ue = ue; st->ve = ve; st->n_list = tot;
+            if (!ok) st->err = 1;
+            for (int q = 0; q < 4; ++q) st->bb[q] = bbv[q];
+        }
+        if (!ok) return;
+        const float mnu = bbv[0], mnv = bbv[1];
+        for (int j = 0; j < OWN_MAX; ++j) {
+            const uint32_t tile = t0 + j * gridDim.x;
+            if (tile >= nb) break;
+            if (ch.bc1[tile] == 0) continue;   // uniform; most tiles of a plane's score list are empty
+            const uint32_t m = ch.masks1[tile * TPB + threadIdx.x];
+            const uint32_t first = tile * TILE + threadIdx.x * PPT;
+            uint32_t pv[PPT];
+            float cx[PPT], cy[PPT], cz[PPT];
+#pragma unroll
+            for (int q = 0; q < PPT; ++q) {
+                pv[q] = first + q;
+                if ((m & (1u << q)) && C.list_values) pv[q] = C.list_values[first + q];
+            }
+#pragma unroll
+            for (int q = 0; q < PPT; ++q)
+                if (m & (1u << q)) { cx[q] = C.cv.x[pv[q]]; cy[q] = C.cv.y[pv[q]]; cz[q] = C.cv.z[pv[q]]; }
+            const uint32_t c = __popc(m);
+            uint32_t incl = c;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t o = __shfl_up(incl, d, 64);
+                if (lane >= d) incl += o;
+            }
+            __syncthreads();
+            if (lane == 63) s_w[wave] = incl;
+            __syncthreads();
+            uint32_t off = (s_pre[j][0] + s_pre[j][1] + s_pre[j][2] + s_pre[j][3]) + incl - c;
+            for (int w = 0; w < wave; ++w) off += s_w[w];
+#pragma unroll
+            for (int q = 0; q < PPT; ++q)
+                if (m & (1u << q)) {
+                    float u, v;
+                    plane_uv(fr, cx[q], cy[q], cz[q], u, v);
+                    int bu = (int)floorf((u - mnu) / eps), bv = (int)floorf((v - mnv) / eps);
+                    bu = min(max(bu, 0), (int)ue - 1);
+                    bv = min(max(bv, 0), (int)ve - 1);
+                    const uint32_t px = (uint32_t)bu + (uint32_t)bv * ue;
+                    idxA[off] = pv[q];
+                    ch.uv[off] = make_float2(u, v);
+                    ch.bidx[off] = px;
+                    ch.bmp[px] = 1;
+                    ++off;
+                }
+        }
+    }
 }
 
 // (3) closing (DilateCross + ErodeCross, ransac/Bitmap.cpp:154-260, 459-570; no wrapping for planes),
@@ -1168,18 +1193,19 @@ __global__ __launch_bounds__(TPB) void k_r_select_cc(const RArgs A, int k) {
     const uint32_t b = blockIdx.y % R_B;
     if (g >= (int)A.ng) return;
     const RCloudArgs &C = A.c[g];
-    if (blockIdx.x >= C.L.nb) return;
     if (b >= C.st->nc) return;
     const ChainPtr ch = chain_of(C, b);
     const PlaneState *st = &ch.hdr->st[k];
     if (st->converged || st->err) return;
     const uint32_t m = st->n_list, best = st->best_root;
-    if (blockIdx.x * 1024u >= m) return;   // past the list (k_r_fit reads ceil(m / 1024) rows)
     const CloudView &c = C.cv;
     const float eps = C.st->eps3;
     const uint32_t *__restrict__ bidx = ch.bidx, *__restrict__ label = ch.label, *__restrict__ idx = ch.idxA(k);
     const float n0 = st->n[0], n1 = st->n[1], n2 = st->n[2], dist = st->dist;
-    const uint32_t base = blockIdx.x * 1024 + threadIdx.x * 4;
+    // rows of 1024 list positions: this workgroup takes rows blockIdx.x, blockIdx.x + gridDim.x, ... (k_r_fit reads
+    // ceil(m / 1024) rows)
+    for (uint32_t row = blockIdx.x; row * 1024u < m; row += gridDim.x) {
+    const uint32_t base = row * 1024 + threadIdx.x * 4;
     uint32_t mk = 0, cnt = 0;
     double a[FIT_COLS];
 #pragma unroll
@@ -1220,17 +1246,19 @@ __global__ __launch_bounds__(TPB) void k_r_select_cc(const RArgs A, int k) {
             a[13] += 1.0;
         }
     }
-    ch.masks2(k)[blockIdx.x * TPB + threadIdx.x] = (uint8_t)mk;
+    ch.masks2(k)[row * TPB + threadIdx.x] = (uint8_t)mk;
     for (int q = 0; q < FIT_COLS; ++q)
         for (int d = 32; d >= 1; d >>= 1) a[q] += __shfl_xor(a[q], d, 64);
+    __syncthreads();   // the previous row's readers are done
     if ((threadIdx.x & 63) == 0) {
         s_w[threadIdx.x >> 6] = cnt;
         for (int q = 0; q < FIT_COLS; ++q) s[threadIdx.x >> 6][q] = a[q];
     }
     __syncthreads();
-    if (threadIdx.x == 0) ch.bc2(k)[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+    if (threadIdx.x == 0) ch.bc2(k)[row] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
     if (threadIdx.x < FIT_COLS)
-        ch.part[(size_t)blockIdx.x * FIT_COLS + threadIdx.x] = (s[0][threadIdx.x] + s[1][threadIdx.x]) + (s[2][threadIdx.x] + s[3][threadIdx.x]);
+        ch.part[(size_t)row * FIT_COLS + threadIdx.x] = (s[0][threadIdx.x] + s[1][threadIdx.x]) + (s[2][threadIdx.x] + s[3][threadIdx.x]);
+    }
 }
 
 // (5) LS refit (PlanePrimitiveShape::LSFit -> Plane::LeastSquaresFit, ransac/Plane.cpp:169-176,
@@ -1442,56 +1470,76 @@ __global__ __launch_bounds__(64) void k_r_decide(const RArgs A) {
 
 
 // Point removal + output index lists of the accepted candidates: the chosen slot's list entries that belong to the
-// largest component, in list order (ordered compaction of the selection masks; offsets from the per-tile counts as in
-// k_r_compact_raster).  grid (tiles, jobs of all clouds)
+// largest component, in list order (ordered compaction of the selection masks; offsets from the per-row counts as in
+// k_r_compact_raster).  grid (loop_grid(), jobs of all clouds)
 __global__ __launch_bounds__(TPB) void k_r_assign(const RArgs A) {
-    __shared__ uint32_t s_pre[TPB / 64], s_w[TPB / 64];
+    __shared__ uint32_t s_pre[OWN_MAX][TPB / 64], s_w[TPB / 64];
     const int g = blockIdx.y / R_B;
     const uint32_t j = blockIdx.y % R_B;
     if (g >= (int)A.ng) return;
     const RCloudArgs &C = A.c[g];
-    if (blockIdx.x >= C.L.nb) return;
     const RState *S = C.st;
     if (j >= S->aj_n) return;
     const int k = (int)S->aj_slot[j];
     const ChainPtr ch = chain_of(C, S->aj_chain[j]);
     const uint32_t m = ch.hdr->st[k].n_list;
-    if (blockIdx.x * 1024u >= m) return;
+    const uint32_t rows = (m + 1023u) / 1024u;
     const int32_t id = S->aj_id[j];
     const uint32_t out_off = S->aj_out[j];
     const uint32_t *__restrict__ bc = ch.bc2(k);
-    const uint32_t mine = bc[blockIdx.x];
-    const uint32_t mk = ch.masks2(k)[blockIdx.x * TPB + threadIdx.x];
-    if (mine == 0) return;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t pre = 0;
-    for (uint32_t q = threadIdx.x; q < blockIdx.x; q += TPB) pre += bc[q];
-    const uint32_t base = blockIdx.x * 1024 + threadIdx.x * 4;
+    const uint8_t *__restrict__ masks = ch.masks2(k);
     const uint32_t *__restrict__ idx = ch.idxA(k);
-    uint32_t p[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) p[q] = (mk & (1u << q)) ? idx[base + q] : 0u;
-    for (int d = 32; d >= 1; d >>= 1) pre += __shfl_xor(pre, d, 64);
-    const uint32_t c = __popc(mk);
-    uint32_t incl = c;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t o = __shfl_up(incl, d, 64);
-        if (lane >= d) incl += o;
-    }
-    if (lane == 0) s_pre[wave] = pre;
-    if (lane == 63) s_w[wave] = incl;
-    __syncthreads();
-    uint32_t off = s_pre[0] + s_pre[1] + s_pre[2] + s_pre[3] + incl - c;
-    for (int w = 0; w < wave; ++w) off += s_w[w];
     int32_t *__restrict__ out = out_off == 0xffffffffu ? nullptr : C.out_idx + out_off;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (uint32_t r0 = blockIdx.x; r0 < rows; r0 += gridDim.x * OWN_MAX) {
+        uint32_t pre[OWN_MAX];
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-        if (mk & (1u << q)) {
-            if (C.assigned) C.assigned[p[q]] = id;
-            if (out) out[off] = (int32_t)(C.orig ? C.orig[p[q]] : p[q]);
-            ++off;
+        for (int q = 0; q < OWN_MAX; ++q) pre[q] = 0;
+        for (uint32_t q = threadIdx.x; q < rows; q += TPB) {
+            const uint32_t c = bc[q];
+#pragma unroll
+            for (int o = 0; o < OWN_MAX; ++o) pre[o] += q < r0 + o * gridDim.x ? c : 0u;
         }
+        for (int d = 32; d >= 1; d >>= 1) {
+#pragma unroll
+            for (int o = 0; o < OWN_MAX; ++o) pre[o] += __shfl_xor(pre[o], d, 64);
+        }
+        __syncthreads();
+        if (lane == 0) {
+#pragma unroll
+            for (int o = 0; o < OWN_MAX; ++o) s_pre[o][wave] = pre[o];
+        }
+        __syncthreads();
+        for (int o = 0; o < OWN_MAX; ++o) {
+            const uint32_t row = r0 + o * gridDim.x;
+            if (row >= rows) break;
+            if (bc[row] == 0) continue;   // uniform
+            const uint32_t mk = masks[row * TPB + threadIdx.x];
+            const uint32_t base = row * 1024 + threadIdx.x * 4;
+            uint32_t p[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) p[q] = (mk & (1u << q)) ? idx[base + q] : 0u;
+            const uint32_t c = __popc(mk);
+            uint32_t incl = c;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t v = __shfl_up(incl, d, 64);
+                if (lane >= d) incl += v;
+            }
+            __syncthreads();
+            if (lane == 63) s_w[wave] = incl;
+            __syncthreads();
+            uint32_t off = (s_pre[o][0] + s_pre[o][1] + s_pre[o][2] + s_pre[o][3]) + incl - c;
+            for (int w = 0; w < wave; ++w) off += s_w[w];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (mk & (1u << q)) {
+                    if (C.assigned) C.assigned[p[q]] = id;
+                    if (out) out[off] = (int32_t)(C.orig ? C.orig[p[q]] : p[q]);
+                    ++off;
+                }
+        }
+    }
 }
 
 // seam S1c: one chain, slot 0, from a caller-given plane
@@ -1594,6 +1642,8 @@ uint64_t hash_bytes(const void *p, size_t n) {
     return h;
 }
 
+inline uint32_t loop_grid(uint32_t nb) { return std::min(1024u, std::max(32u, cdiv(nb, OWN_MAX))); }
+
 // one iteration of the detect loop: 29 launches
 void enqueue_iteration(plade_ctx *ctx, const RArgs &A) {
     hipStream_t st = ctx->stream;
@@ -1621,13 +1671,13 @@ void enqueue_iteration(plade_ctx *ctx, const RArgs &A) {
         ctx->ev_begin("score_mark", 0.0);
         hipLaunchKernelGGL(k_r_mark, dim3(tiles), dim3(TPB), 0, st, A, k);
         ctx->ev_end();
-        hipLaunchKernelGGL(k_r_compact_raster, dim3(nb_max, R_B * ng), dim3(TPB), 0, st, A, k);
+        hipLaunchKernelGGL(k_r_compact_raster, dim3(loop_grid(nb_max), R_B * ng), dim3(TPB), 0, st, A, k);
         hipLaunchKernelGGL(k_r_label, dim3(R_B * ng), dim3(1024), 0, st, A, k, 1);
-        hipLaunchKernelGGL(k_r_select_cc, dim3(nb_max, R_B * ng), dim3(TPB), 0, st, A, k);
+        hipLaunchKernelGGL(k_r_select_cc, dim3(loop_grid(nb_max), R_B * ng), dim3(TPB), 0, st, A, k);
         hipLaunchKernelGGL(k_r_fit, dim3(R_B * ng), dim3(256), 0, st, A, k);
     }
     hipLaunchKernelGGL(k_r_decide, dim3(ng), dim3(64), 0, st, A);
-    hipLaunchKernelGGL(k_r_assign, dim3(nb_max, R_B * ng), dim3(TPB), 0, st, A);
+    hipLaunchKernelGGL(k_r_assign, dim3(loop_grid(nb_max), R_B * ng), dim3(TPB), 0, st, A);
 }
 
 void launch_iteration(plade_ctx *ctx, RansacWork &W, const RArgs &A) {
@@ -1894,11 +1944,11 @@ void plane_component(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const
                        make_float4(point[0], point[1], point[2], 0.f), w_eps, bitmap_eps);
     const uint32_t nb = s.L.nb;
     hipLaunchKernelGGL(k_r_list_mark, dim3(nb), dim3(TPB), 0, st, A, m);
-    hipLaunchKernelGGL(k_r_compact_raster, dim3(nb, R_B), dim3(TPB), 0, st, A, 0);
+    hipLaunchKernelGGL(k_r_compact_raster, dim3(loop_grid(nb), R_B), dim3(TPB), 0, st, A, 0);
     hipLaunchKernelGGL(k_r_label, dim3(R_B), dim3(1024), 0, st, A, 0, closing_filter ? 1 : 0);
-    hipLaunchKernelGGL(k_r_select_cc, dim3(nb, R_B), dim3(TPB), 0, st, A, 0);
+    hipLaunchKernelGGL(k_r_select_cc, dim3(loop_grid(nb), R_B), dim3(TPB), 0, st, A, 0);
     hipLaunchKernelGGL(k_r_fit, dim3(R_B), dim3(256), 0, st, A, 0);
-    hipLaunchKernelGGL(k_r_assign, dim3(nb, R_B), dim3(TPB), 0, st, A);
+    hipLaunchKernelGGL(k_r_assign, dim3(loop_grid(nb), R_B), dim3(TPB), 0, st, A);
     PlaneState hst[2];
     ctx->d2h(hst, s.fixed.p, 2 * sizeof(PlaneState));   // chain 0's header
     ctx->sync(st);

@@ -5,13 +5,17 @@
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out
+TAG=${1:-r2}
 mkdir -p $O
 cd $R
-timeout 900 python bench.py > $O/bench_r1.json 2> $O/bench_r1.err
-tail -c 3000 $O/bench_r1.json
+timeout 900 python bench.py > $O/bench_$TAG.json 2> $O/bench_$TAG.err
+tail -c 3000 $O/bench_$TAG.json
 cd /tmp && export TMPDIR=/tmp
-CMD="python $R/bench.py --steps 32 --warmup 8 --no-cpu-baseline"
+CMD="python $R/bench.py --steps 96 --warmup 8 --host-steps 0 --no-cpu-baseline --profiled-steps 2"
+rm -rf $O/prof_bench $O/prof_pmc_fetch $O/prof_pmc_write
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench -o bench -- $CMD > $O/prof_bench.log 2>&1
 timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/prof_pmc_fetch -o pmc -- $CMD > $O/prof_pmc_fetch.log 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/prof_pmc_write -o pmc -- $CMD > $O/prof_pmc_write.log 2>&1
+# keep only what the summaries need (the per-dispatch trace is tens of MB)
+find $O/prof_bench -name "*kernel_trace.csv" -delete
 ls -la $O/prof_bench $O/prof_pmc_fetch $O/prof_pmc_write

@@ -2,7 +2,7 @@
 
     python tools/summarize_profiles.py r1
 
-profiles/<round>_kernel_stats.csv : `rocprofv3 --kernel-trace --stats` of `python bench.py --steps 10 --warmup 2 --no-cpu-baseline`
+profiles/<round>_kernel_stats.csv : `rocprofv3 --kernel-trace --stats` of `python bench.py --steps 96 --warmup 8 --host-steps 0 --no-cpu-baseline --profiled-steps 2`
 profiles/<round>_pmc_hbm.csv      : per-kernel average FETCH_SIZE / WRITE_SIZE (separate --pmc passes), with the gfx950
                                     FETCH_SIZE x2 correction of MI355X_MICROARCH.md applied in the `hbm_read_bytes` column
 """
@@ -17,12 +17,15 @@ rnd = sys.argv[1] if len(sys.argv) > 1 else "r1"
 go = os.path.join(ROOT, "gpurun_out")
 out = os.path.join(ROOT, "profiles")
 os.makedirs(out, exist_ok=True)
-shutil.copy(os.path.join(go, "prof_bench", "bench_kernel_stats.csv"), os.path.join(out, f"{rnd}_kernel_stats.csv"))
+import glob
+stats = glob.glob(os.path.join(go, "prof_bench", "**", "*kernel_stats.csv"), recursive=True)
+shutil.copy(stats[0], os.path.join(out, f"{rnd}_kernel_stats.csv"))
 
 
 def pmc(which):
     agg = collections.defaultdict(lambda: [0, 0.0])
-    with open(os.path.join(go, f"prof_pmc_{which}", "pmc_counter_collection.csv")) as f:
+    files = glob.glob(os.path.join(go, f"prof_pmc_{which}", "**", "*counter_collection.csv"), recursive=True)
+    with open(files[0]) as f:
         for r in csv.DictReader(f):
             a = agg[r["Kernel_Name"]]
             a[0] += 1
@@ -38,8 +41,7 @@ with open(os.path.join(out, f"{rnd}_pmc_hbm.csv"), "w", newline="") as f:
         n, v = fe[k]
         wv = wr.get(k, [1, 0.0])
         w.writerow([k, n, f"{v / n:.1f}", f"{wv[1] / max(wv[0], 1):.1f}", f"{v / n * 1024 * 2:.0f}", f"{wv[1] / max(wv[0], 1) * 1024:.0f}"])
-for name in ("bench_r1.json",):
-    src = os.path.join(go, name)
-    if os.path.exists(src):
-        shutil.copy(src, os.path.join(out, f"{rnd}_bench_n1.json"))
+src = os.path.join(go, f"bench_{rnd}.json")
+if os.path.exists(src):
+    shutil.copy(src, os.path.join(out, f"{rnd}_bench_n1.json"))
 print(sorted(os.listdir(out)))
