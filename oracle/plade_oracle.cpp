@@ -487,20 +487,20 @@ struct OBB {
     V3 corners[8];
 };
 // sum_mode 0: PCL's order -- compute3DCentroid / computeCovarianceMatrixNormalized add the points one after the other in
-// fp32 (centroid.hpp:79-121, 250-300).  sum_mode 1: the order of the GPU path (k_obb_units): the points are cut into chunks
-// of 64 consecutive points, every chunk is summed point after point, and the chunk sums are added in chunk order -- a
-// re-association of the same fp32 additions (a 60 000-point serial chain is what a GPU cannot run; the chunks are what
-// its lanes sum in parallel).  The two differ by a few ulp of the sums.
+// fp32 (centroid.hpp:79-121, 250-300).  sum_mode 1: the order of the GPU path (k_obb_units): lane t of 1024 adds the points
+// t, t + 1024, t + 2048, ... one after the other, then the 1024 lane sums are added in lane order -- a re-association of
+// the same fp32 additions (a 150 000-point serial chain is what a GPU cannot run; the strided lanes are what it sums in
+// parallel with coalesced reads).  The two differ by a few ulp of the sums.
 int bounding_box(const std::vector<V3> &pts, OBB &o, bool want_corners, int sum_mode = 0) {
     if (pts.empty()) return -1;
-    const size_t n = pts.size(), CH = 64;
+    const size_t n = pts.size(), LANES = 1024;
     float c[3] = {0, 0, 0};
     if (sum_mode == 0) {
         for (auto &p : pts) { c[0] += p.x; c[1] += p.y; c[2] += p.z; }
     } else {
-        for (size_t b = 0; b < n; b += CH) {
+        for (size_t t = 0; t < LANES; ++t) {
             float s[3] = {0, 0, 0};
-            for (size_t i = b; i < std::min(n, b + CH); ++i) { s[0] += pts[i].x; s[1] += pts[i].y; s[2] += pts[i].z; }
+            for (size_t i = t; i < n; i += LANES) { s[0] += pts[i].x; s[1] += pts[i].y; s[2] += pts[i].z; }
             c[0] += s[0]; c[1] += s[1]; c[2] += s[2];
         }
     }
@@ -521,10 +521,10 @@ int bounding_box(const std::vector<V3> &pts, OBB &o, bool want_corners, int sum_
     if (sum_mode == 0) {
         for (auto &p : pts) add_point(cov, p);
     } else {
-        for (size_t b = 0; b < n; b += CH) {
+        for (size_t t = 0; t < LANES; ++t) {
             M3 s;
             memset(&s, 0, sizeof(s));
-            for (size_t i = b; i < std::min(n, b + CH); ++i) add_point(s, pts[i]);
+            for (size_t i = t; i < n; i += LANES) add_point(s, pts[i]);
             cov.m[1][1] += s.m[1][1]; cov.m[1][2] += s.m[1][2]; cov.m[2][2] += s.m[2][2];
             cov.m[0][0] += s.m[0][0]; cov.m[0][1] += s.m[0][1]; cov.m[0][2] += s.m[0][2];
         }

@@ -36,8 +36,8 @@ int orc_voxel_downsample(const float *xyz, int n, int stride_floats, float leaf,
                          float *out_xyz, int32_t *n_out);
 /* util.h:186-248: center(3), whd (width,height,depth doubles), corners (8x3, may be NULL) */
 int orc_bounding_box(const float *xyz, int n, float *center3, double *whd3, float *corners24);
-/* sum_mode 0: PCL's point-after-point fp32 sums (= orc_bounding_box); 1: chunks of 64 consecutive points summed point
- * after point, chunk sums added in chunk order (the GPU path's order, a re-association of the same additions). */
+/* sum_mode 0: PCL's point-after-point fp32 sums (= orc_bounding_box); 1: lane t of 1024 adds points t, t + 1024, ... one
+ * after the other, the lane sums are added in lane order (the GPU path's order, a re-association of the same additions). */
 int orc_bounding_box_mode(const float *xyz, int n, int sum_mode, float *center3, double *whd3, float *corners24);
 
 /* A6 */

@@ -159,6 +159,6 @@ HD void obb_finish(const m3 &E, const float c[3], f3 mn, f3 mx, f3 &center, doub
     for (int i = 0; i < 8; ++i) corners[i] = pcl_xform(Q, cs[i]);
 }
 
-constexpr int OBB_CHUNK = 64;   // points per summation chunk (see k_obb.hip)
+constexpr int OBB_LANES = 1024;   // lanes of the strided summation order (see k_obb.hip)
 
 }  // namespace plade

@@ -6,11 +6,13 @@
 // "unit" (unit 0 = the whole cloud, unit 1 + i = plane i); nothing but a few dozen floats per unit goes back to the host.
 //
 // PCL adds the points one after the other in fp32 (compute3DCentroid / computeCovarianceMatrixNormalized,
-// centroid.hpp:79-121, 250-300): a 60 000-step dependent chain a GPU lane would spend half a millisecond on.  Here the
-// points of a unit are cut into chunks of OBB_CHUNK = 64 consecutive points; lanes sum one chunk each, point after
-// point, and one lane adds the chunk sums in chunk order: the same additions re-associated, deterministic, and exactly
-// what the CPU checker's sum mode 1 does (see tests).  Everything after the sums -- Eigen's 3x3
-// self-adjoint solver, the frame, min / max, corners -- is PCL's arithmetic operation for operation (hostgeom.h).
+// centroid.hpp:79-121, 250-300): a 150 000-step dependent chain a GPU lane would spend a millisecond on.  Here lane t of
+// the unit's 1024-lane workgroup adds the points t, t + 1024, t + 2048, ... one after the other (coalesced reads: at every
+// step a wavefront touches 64 consecutive points; contiguous 64-point chunks per lane were measured at 220 us per
+// pass for 147 000 points, every lane on its own cache lines), and one lane adds the 1024 lane sums in lane order: the
+// same additions re-associated, deterministic, and exactly what the CPU checker's sum mode 1 does (see tests).
+// Everything after the sums -- Eigen's 3x3 self-adjoint solver, the frame, min / max, corners -- is PCL's arithmetic
+// operation for operation (hostgeom.h).
 #include "stages.h"
 #include "hostgeom.h"
 
@@ -25,64 +27,47 @@ struct ObbArgs {
     float *out;                                // OBB_OUT_WHOLE + P * OBB_OUT_PLANE floats
 };
 
-constexpr int OBB_T = 1024;
-constexpr int OBB_LDS_CHUNKS = 2048;   // chunk sums held in LDS at a time (larger units go through it in rounds)
+constexpr int OBB_T = OBB_LANES;
 
-// sums of the K-component per-point terms over the points of one unit in the chunked order: lanes sum one chunk each
-// (point after point; 16 points are fetched ahead of the additions), the chunk sums go to LDS, lane q < K adds the chunk
-// sums of component q in chunk order
+// sums of the K-component per-point terms over the points of one unit in the lane-strided order: lane t adds the terms
+// of points t, t + 1024, t + 2048, ... one after the other (eight points are fetched ahead of the additions; at every
+// step the lanes of a wavefront read 64 consecutive points), the lane sums go to LDS, lane q < K adds the 1024 lane sums
+// of component q in lane order
 template <int K, class Term>
-__device__ void chunked_sums(const float *__restrict__ pts, uint32_t n, float (*s_ch)[6], float *s_out, Term term) {
-    const uint32_t nch = (n + OBB_CHUNK - 1) / OBB_CHUNK;
-    const bool aligned = (reinterpret_cast<uintptr_t>(pts) & 15) == 0;   // chunks start at multiples of 768 bytes
-    float total = 0.f;   // lanes < K: running sum of their component
-    for (uint32_t c0 = 0; c0 < nch; c0 += OBB_LDS_CHUNKS) {
-        const uint32_t cn = min((uint32_t)OBB_LDS_CHUNKS, nch - c0);
-        for (uint32_t k = threadIdx.x; k < cn; k += OBB_T) {
-            float acc[K];
+__device__ void strided_sums(const float *__restrict__ pts, uint32_t n, float (*s_ch)[6], float *s_out, Term term) {
+    float acc[K];
 #pragma unroll
-            for (int q = 0; q < K; ++q) acc[q] = 0.f;
-            const uint32_t b = (c0 + k) * OBB_CHUNK, e = min(n, b + OBB_CHUNK);
-            for (uint32_t i0 = b; i0 < e; i0 += 16) {
-                float v[48];   // 16 points, x y z interleaved
-                if (aligned && i0 + 16 <= e) {   // 192 contiguous bytes per lane: twelve 16-byte loads
-                    const float4 *p4 = reinterpret_cast<const float4 *>(pts + 3 * (size_t)i0);
+    for (int q = 0; q < K; ++q) acc[q] = 0.f;
+    for (uint32_t i0 = threadIdx.x; i0 < n; i0 += 8 * OBB_T) {
+        float x[8], y[8], z[8];
 #pragma unroll
-                    for (int j = 0; j < 12; ++j) { const float4 t = p4[j]; v[4 * j] = t.x; v[4 * j + 1] = t.y; v[4 * j + 2] = t.z; v[4 * j + 3] = t.w; }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 16; ++j) {
-                        const uint32_t i = min(i0 + j, e - 1);
-                        v[3 * j] = pts[3 * (size_t)i]; v[3 * j + 1] = pts[3 * (size_t)i + 1]; v[3 * j + 2] = pts[3 * (size_t)i + 2];
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < 16; ++j)
-                    if (i0 + j < e) term(acc, f3(v[3 * j], v[3 * j + 1], v[3 * j + 2]));
-            }
-#pragma unroll
-            for (int q = 0; q < K; ++q) s_ch[k][q] = acc[q];
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t i = min(i0 + j * OBB_T, n - 1);
+            x[j] = pts[3 * (size_t)i]; y[j] = pts[3 * (size_t)i + 1]; z[j] = pts[3 * (size_t)i + 2];
         }
-        __syncthreads();
-        if (threadIdx.x < K) {   // chunk sums in chunk order; eight LDS reads ahead of the additions
-            uint32_t k = 0;
-            for (; k + 8 <= cn; k += 8) {
-                float v[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = s_ch[k + j][threadIdx.x];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) total += v[j];
-            }
-            for (; k < cn; ++k) total += s_ch[k][threadIdx.x];
-        }
-        __syncthreads();
+        for (int j = 0; j < 8; ++j)
+            if (i0 + j * OBB_T < n) term(acc, f3(x[j], y[j], z[j]));
     }
-    if (threadIdx.x < K) s_out[threadIdx.x] = total;
+#pragma unroll
+    for (int q = 0; q < K; ++q) s_ch[threadIdx.x][q] = acc[q];
+    __syncthreads();
+    if (threadIdx.x < K) {   // lane sums in lane order; eight LDS reads ahead of the additions
+        float total = 0.f;
+        for (int t = 0; t < OBB_T; t += 8) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = s_ch[t + j][threadIdx.x];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) total += v[j];
+        }
+        s_out[threadIdx.x] = total;
+    }
     __syncthreads();
 }
 
 __global__ __launch_bounds__(OBB_T) void k_obb_units(const ObbArgs A) {
-    __shared__ float s_ch[OBB_LDS_CHUNKS][6];
+    __shared__ float s_ch[OBB_T][6];
     __shared__ float s_c[3], s_cov[6], s_P[12], s_E[9];
     __shared__ float s_mm[6][OBB_T / 64];
     const uint32_t u = blockIdx.x;
@@ -102,10 +87,10 @@ __global__ __launch_bounds__(OBB_T) void k_obb_units(const ObbArgs A) {
     }
     const float nf = (float)n;
     // ---- centroid (compute3DCentroid, centroid.hpp:79-121)
-    chunked_sums<3>(pts, n, s_ch, s_c, [](float *acc, f3 p) { acc[0] += p.x; acc[1] += p.y; acc[2] += p.z; });
+    strided_sums<3>(pts, n, s_ch, s_c, [](float *acc, f3 p) { acc[0] += p.x; acc[1] += p.y; acc[2] += p.z; });
     const float c[3] = {s_c[0] / nf, s_c[1] / nf, s_c[2] / nf};
     // ---- covariance about the centroid (computeCovarianceMatrixNormalized, centroid.hpp:250-300), same chunking
-    chunked_sums<6>(pts, n, s_ch, s_cov, [c](float *acc, f3 p) { cov_add_point(acc, p, c); });
+    strided_sums<6>(pts, n, s_ch, s_cov, [c](float *acc, f3 p) { cov_add_point(acc, p, c); });
     if (threadIdx.x == 0) {
         const float cov6[6] = {s_cov[0], s_cov[1], s_cov[2], s_cov[3], s_cov[4], s_cov[5]};
         m3 E;

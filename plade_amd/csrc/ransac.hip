@@ -110,6 +110,7 @@ struct RState {
     int32_t aj_id[R_B];
     // ---- counters
     uint32_t n_rounds, n_rescores[2], n_batches, n_accepts, n_mark_launches, n_mark_chains;
+    uint32_t n_final[4], n_stop[5];   // chains by the slot they ended with / by the refit at which the reference loop stops
     // ---- accepted shapes (copied to the host-mapped result block when the call ends)
     float acc_coef[R_MAXP][4];
     uint32_t acc_support[R_MAXP], acc_offset[R_MAXP];
@@ -121,6 +122,7 @@ struct RResult {
                                      // iteration of the PREVIOUS call may still report), 31 = the call has finished
     uint32_t n_acc, out_off, err, remaining;
     uint32_t n_rounds, n_rescores, n_batches, n_accepts, n_mark_launches, n_mark_chains, pad;
+    uint32_t n_final[4], n_stop[5], pad2[3];
     float coef[R_MAXP][4];
     uint32_t support[R_MAXP];        // 0: below min_support (points removed, no plane reported)
     uint32_t offset[R_MAXP];
@@ -429,6 +431,8 @@ __global__ __launch_bounds__(TPB) void k_r_init(const RArgs A, const RInit I) {
         S->n_remaining = C.cv.n; S->sub_unassigned = 0; S->drawn = 0.f;
         S->npool = 0; S->nc = 0; S->n_acc = 0; S->out_off = 0; S->err = 0; S->aj_n = 0;
         S->n_rounds = S->n_rescores[0] = S->n_rescores[1] = S->n_batches = S->n_accepts = S->n_mark_launches = S->n_mark_chains = 0;
+        for (int q = 0; q < 4; ++q) S->n_final[q] = 0;
+        for (int q = 0; q < 5; ++q) S->n_stop[q] = 0;
     }
 }
 
@@ -1386,18 +1390,20 @@ __global__ __launch_bounds__(64) void k_r_decide(const RArgs A) {
         const PlaneState *st = s_st[b];
         S->n_accepts += 1;
         if (st[0].err == 1) { S->err = 1; S->done = 1; break; }   // connected-component bitmap too large
-        int final_slot = 0;
+        int final_slot = 0, stop = 4;
         {
             double newScore = st[0].wscore;
             for (int fittingIter = 1; fittingIter <= 3; ++fittingIter) {
                 const double oldScore = newScore;
-                if (st[fittingIter - 1].n_kept < 3 || st[fittingIter].err) break;   // LSFit impossible
+                if (st[fittingIter - 1].n_kept < 3 || st[fittingIter].err) { stop = fittingIter; break; }   // LSFit impossible
                 newScore = st[fittingIter].wscore;
                 const uint32_t newSize = st[fittingIter].n_kept;
                 if (newScore > oldScore && newSize > S->min_support) final_slot = fittingIter;  // clone.Clone(&candidates.back())
-                if (!(newScore > oldScore)) break;
+                if (!(newScore > oldScore)) { stop = fittingIter; break; }
             }
         }
+        S->n_final[final_slot] += 1;
+        S->n_stop[stop] += 1;
         const PlaneState &cs = st[final_slot];
         const uint32_t cand_size = cs.n_kept;
         if (cand_size == 0) continue;
@@ -1460,6 +1466,8 @@ __global__ __launch_bounds__(64) void k_r_decide(const RArgs A) {
             R->n_acc = na; R->out_off = S->out_off; R->err = S->err; R->remaining = S->n_remaining;
             R->n_rounds = S->n_rounds; R->n_rescores = S->n_rescores[0] + S->n_rescores[1]; R->n_batches = S->n_batches; R->n_accepts = S->n_accepts;
             R->n_mark_launches = S->n_mark_launches; R->n_mark_chains = S->n_mark_chains;
+            for (int q = 0; q < 4; ++q) R->n_final[q] = S->n_final[q];
+            for (int q = 0; q < 5; ++q) R->n_stop[q] = S->n_stop[q];
         }
     }
     __threadfence_system();
@@ -1894,6 +1902,8 @@ void ransac_detect_prepared(plade_ctx *ctx, RansacWork &W, RansacJob jobs[RANSAC
         ctx->stats.add("ransac_batches", R.n_batches);
         ctx->stats.add("ransac_rescore_launches", R.n_rescores);
         ctx->stats.add("ransac_mark_launches", R.n_mark_launches);
+        for (int q = 0; q < 4; ++q) ctx->stats.add("ransac_final_slot" + std::to_string(q), R.n_final[q]);
+        for (int q = 1; q < 5; ++q) ctx->stats.add("ransac_loop_stops_at" + std::to_string(q), R.n_stop[q]);
         if (J.rp.host_indices) {
             out.idx.resize(R.out_off);
             if (R.out_off) ctx->d2h(out.idx.data(), s.out_idx.p, 4 * (size_t)R.out_off);
