@@ -62,7 +62,6 @@ struct plade_ctx {
     int device = 0;
     plade::RegistrationWork *reg_work = nullptr;
     plade::RansacWork *ransac_work = nullptr;
-    int ransac_lease = -1;      // first of the two slots held in the device's shared extractor (ransac.h), -1: none
     plade_ctx *aux = nullptr;   // second stream + work areas: stages of the source cloud that are independent of the
                                 // target's run concurrently with them
     hipStream_t stream = nullptr;

@@ -64,15 +64,6 @@ struct RansacJob {
 };
 void ransac_detect_prepared(plade_ctx *ctx, RansacWork &W, RansacJob jobs[RANSAC_SLOTS]);
 
-// The same two calls on a pair of slots of the device's SHARED extractor (ransac.hip, RansacServer): one thread per
-// device runs the launch sequence over the slots of all contexts whose extraction is in progress.  acquire blocks until
-// a pair of slots is free; the index lists of the results live in the slots until release.
-bool ransac_shared_enabled(const plade_ctx *ctx);   // host_wait != 0 (several registrations in flight), PLADE_SHARED_EXTRACTOR=0/1 overrides
-void ransac_shared_acquire(plade_ctx *ctx);
-void ransac_shared_release(plade_ctx *ctx);
-void ransac_shared_prepare(plade_ctx *ctx, const CloudDev *const clouds[RANSAC_SLOTS], int n_clouds);
-void ransac_shared_detect(plade_ctx *ctx, RansacJob jobs[RANSAC_SLOTS]);
-
 // prepare + detect of a single cloud
 void ransac_detect(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const RansacParams &rp, PlaneSetOut &out);
 

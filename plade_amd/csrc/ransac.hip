@@ -38,10 +38,6 @@
 #include <algorithm>
 #include <map>
 #include <memory>
-#include <condition_variable>
-#include <deque>
-#include <mutex>
-#include <thread>
 
 namespace plade {
 
@@ -52,7 +48,7 @@ constexpr uint32_t R_TOP = 48;          // candidate pool
 constexpr int R_B = 8;                  // acceptance chains per cloud and iteration (16 gave the same batches: the pool
                                         // rarely holds more than 8 mutually conflict-free planes)
 constexpr int R_G = RANSAC_SLOTS;        // clouds prepared together (one sort): the two scans of a registration
-constexpr int R_NS = 32;                // slots of a work area: clouds extracted by one launch sequence
+constexpr int R_NS = 16;                // slots of a work area: clouds extracted by one launch sequence
 constexpr uint32_t R_MAXP = 4096;       // accepted shapes per detect call
 constexpr uint32_t R_MAX_ROUNDS = 4000;
 constexpr int R_MIN_LEVEL = 1, R_MAX_LEVEL = 8;
@@ -1596,18 +1592,17 @@ struct RansacSlot {
     DBuf<uint32_t> seam_list;
     DBuf<uint32_t> keys_in, vals_in, keys, perm;   // Morton sort of the clouds prepared with this slot as their first
     uint32_t gen = 0;                // tag of the slot's running / last detect call
-    hipEvent_t prepared = nullptr;   // shared extractor: the preparing stream's hand-over to the extractor's stream
-    bool fresh = false, in_call = false;
-    ~RansacSlot() { if (res) (void)hipHostFree(res); if (prepared) (void)hipEventDestroy(prepared); }
+    ~RansacSlot() { if (res) (void)hipHostFree(res); }
 };
 
 struct RansacWork {
     RansacSlot slot[R_NS];
     DBuf<RState> states;             // R_NS loop states
     DBuf<RCloudArgs> d_tab;          // the slot table the kernels read
-    HBuf<RCloudArgs> h_tab;          // its host mirror (page-locked: uploads are asynchronous copies straight from it)
+    std::vector<RCloudArgs> h_tab;   // its host mirror
     std::vector<uint64_t> tab_hash;  // what of it is on the device
     bool ready = false;
+    uint32_t generation = 0;         // detect calls issued on this work area
     std::map<uint64_t, hipGraphExec_t> graphs;   // the iteration sequence, keyed on everything baked into its launches
     ~RansacWork() { for (auto &kv : graphs) if (kv.second) (void)hipGraphExecDestroy(kv.second); }
 };
@@ -1636,13 +1631,13 @@ void work_ready(plade_ctx *ctx, RansacWork &W) {
     W.d_tab.ensure(R_NS);
     HIP_TRY(hipMemsetAsync(W.states.p, 0, sizeof(RState) * R_NS, ctx->stream));
     hipLaunchKernelGGL(k_r_reset_states, dim3(1), dim3(64), 0, ctx->stream, W.states.p, R_NS);
-    W.h_tab.ensure(R_NS);
-    memset(W.h_tab.p, 0, sizeof(RCloudArgs) * R_NS);
-    for (int g = 0; g < R_NS; ++g) W.h_tab.p[g].st = W.states.p + g;
-    HIP_TRY(hipMemcpyAsync(W.d_tab.p, W.h_tab.p, sizeof(RCloudArgs) * R_NS, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    W.h_tab.resize(R_NS);
+    memset(W.h_tab.data(), 0, sizeof(RCloudArgs) * R_NS);
+    for (int g = 0; g < R_NS; ++g) W.h_tab[g].st = W.states.p + g;
+    HIP_TRY(hipMemcpyAsync(W.d_tab.p, W.h_tab.data(), sizeof(RCloudArgs) * R_NS, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));   // h_tab is pageable: the copy must not outlive this call unobserved
     W.tab_hash.assign(R_NS, 0);
-    for (int g = 0; g < R_NS; ++g) W.tab_hash[g] = hash_bytes(&W.h_tab.p[g], sizeof(RCloudArgs));
+    for (int g = 0; g < R_NS; ++g) W.tab_hash[g] = hash_bytes(&W.h_tab[g], sizeof(RCloudArgs));
     W.ready = true;
 }
 
@@ -1681,17 +1676,16 @@ void slot_entry(RansacWork &W, int g) {
     C.fixed = s.fixed.p; C.var = s.var.p;
     C.list_values = nullptr;
     memcpy(&C.L, &s.L, sizeof(ChainLayout));
-    memcpy(&W.h_tab.p[g], &C, sizeof(C));
+    memcpy(&W.h_tab[g], &C, sizeof(C));
 }
 
-// brings the device table up to date for the listed slots (stream-ordered small copies from the page-locked mirror: an
-// entry is rewritten on the host only after the slot's previous call has been seen to end, i.e. after its last upload)
-void upload_entries(hipStream_t stream, RansacWork &W, const int *slots, int n) {
+// brings the device table up to date for the listed slots (stream-ordered small uploads through the ctx arena)
+void upload_entries(plade_ctx *ctx, RansacWork &W, const int *slots, int n) {
     for (int i = 0; i < n; ++i) {
         const int g = slots[i];
-        const uint64_t h = hash_bytes(&W.h_tab.p[g], sizeof(RCloudArgs));
+        const uint64_t h = hash_bytes(&W.h_tab[g], sizeof(RCloudArgs));
         if (h == W.tab_hash[g]) continue;
-        HIP_TRY(hipMemcpyAsync(W.d_tab.p + g, &W.h_tab.p[g], sizeof(RCloudArgs), hipMemcpyHostToDevice, stream));
+        ctx->h2d(W.d_tab.p + g, &W.h_tab[g], sizeof(RCloudArgs));
         W.tab_hash[g] = h;
     }
 }
@@ -1905,7 +1899,7 @@ void ransac_prepare(plade_ctx *ctx, RansacWork &W, const CloudDev *const clouds[
     work_ready(ctx, W);
     prepare_slots(ctx, W, 0, clouds, n_clouds);
     const int slots[2] = {0, 1};
-    upload_entries(ctx->stream, W, slots, n_clouds);
+    upload_entries(ctx, W, slots, n_clouds);
 }
 
 void ransac_detect_prepared(plade_ctx *ctx, RansacWork &W, RansacJob jobs[RANSAC_SLOTS]) {
@@ -1928,7 +1922,7 @@ void ransac_detect_prepared(plade_ctx *ctx, RansacWork &W, RansacJob jobs[RANSAC
             J.active = false;
             continue;
         }
-        s.gen = (s.gen + 1) & 0x7fu;
+        s.gen = (++W.generation) & 0x7fu;
         I.c[g] = init_of(s, J.rp, s.gen);
         active[g] = true;
         res[nres] = s.res; gens[nres] = s.gen; ++nres;
@@ -2033,9 +2027,9 @@ void plane_component(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const
         C.cv.x = cloud.x(); C.cv.y = cloud.y(); C.cv.z = cloud.z(); C.cv.nx = cloud.nx(); C.cv.ny = cloud.ny(); C.cv.nz = cloud.nz(); C.cv.n = n;
         C.st = W.states.p; C.res = nullptr; C.out_idx = s.out_idx.p; C.fixed = s.fixed.p; C.var = s.var.p; C.list_values = s.seam_list.p;
         memcpy(&C.L, &s.L, sizeof(ChainLayout));
-        memcpy(&W.h_tab.p[0], &C, sizeof(C));
+        memcpy(&W.h_tab[0], &C, sizeof(C));
         const int slot0 = 0;
-        upload_entries(st, W, &slot0, 1);
+        upload_entries(ctx, W, &slot0, 1);
     }
     bool active[R_NS] = {true};
     IterShape sh;
@@ -2066,273 +2060,6 @@ void plane_component(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const
     for (int k = 0; k < 3; ++k) { out.fit[k] = hst[1].n[k]; out.fit[3 + k] = hst[1].pos[k]; }
     out.fit[6] = hst[1].dist;
     out.wscore = hst[0].wscore;
-}
-
-namespace {
-
-// ------------------------------------------------------------------------------------------------
-// Shared extractor of a device.  With several registrations in flight on one GPU (host_wait != 0: bench.py --inflight,
-// the CLI's PLADE_INFLIGHT), every context driving its own seven-iteration loop means 8 x 30 launches per iteration
-// round, most of them a handful of workgroups that last as long for two clouds as for sixteen.  Here one thread per
-// device drives ONE launch sequence over all slots whose extraction is running ("continuous batching": a slot joins at
-// the next iteration after its submission and drops out when its call has ended, the others never wait for it).
-// Slots are independent in every kernel, so a cloud's planes do not depend on which other clouds shared its launches.
-class RansacServer {
-public:
-    static int chains() {
-        static const int k = [] { const char *e = getenv("PLADE_EXTRACTOR_CHAINS"); return e ? std::max(1, std::min(8, atoi(e))) : 2; }();
-        return k;
-    }
-    static RansacServer *of(int device, int chain) { return of(device * 8 + chain); }
-    static RansacServer *of(int device) {
-        static std::mutex reg_mu;
-        static std::map<int, RansacServer *> *reg = new std::map<int, RansacServer *>;   // never destroyed: the threads outlive main()
-        std::lock_guard<std::mutex> lk(reg_mu);
-        auto it = reg->find(device);
-        if (it != reg->end()) return it->second;
-        RansacServer *s = new RansacServer(device / 8);
-        (*reg)[device] = s;
-        return s;
-    }
-    RansacWork W;
-
-    int acquire() {   // a free pair of slots
-        std::unique_lock<std::mutex> lk(mu);
-        for (;;) {
-            check_locked();
-            for (int p = 0; p < R_NS / 2; ++p) if (!busy[p]) { busy[p] = true; return 2 * p; }
-            cv_free.wait(lk);
-        }
-    }
-    void release(int base) {
-        { std::lock_guard<std::mutex> lk(mu); busy[base / 2] = false; }
-        cv_free.notify_one();
-    }
-    void submit(const int *slots, const RInitCloud *inits, int n) {
-        {
-            std::lock_guard<std::mutex> lk(mu);
-            check_locked();
-            for (int i = 0; i < n; ++i) pending.push_back(Submission{slots[i], inits[i]});
-        }
-        cv_work.notify_one();
-    }
-    // sleeps until every listed slot's running call has ended
-    void wait_done(const int *slots, int n) {
-        relax_timer_slack();
-        for (uint32_t polls = 0;; ++polls) {
-            bool all = true;
-            for (int i = 0; i < n; ++i) all = all && flag_done(W.slot[slots[i]].res, W.slot[slots[i]].gen);
-            if (all) break;
-            if ((polls & 15u) == 15u && failed.load(std::memory_order_acquire)) { std::lock_guard<std::mutex> lk(mu); check_locked(); }
-            timespec ts{0, polls < 8 ? 20000 : 50000};
-            nanosleep(&ts, nullptr);
-        }
-        std::atomic_thread_fence(std::memory_order_acquire);
-    }
-    hipStream_t stream() const { return sctx->stream; }
-
-private:
-    struct Submission { int slot; RInitCloud init; };
-    int device;
-    plade_ctx *sctx = nullptr;
-    std::mutex mu;
-    std::condition_variable cv_free, cv_work;
-    bool busy[R_NS / 2] = {};
-    std::deque<Submission> pending;
-    std::atomic<bool> failed{false};
-    Err failure{0, ""};
-    std::thread th;
-
-    explicit RansacServer(int dev) : device(dev) {
-        PLADE_REQUIRE(plade_ctx_create(device, &sctx) == PLADE_OK, PLADE_EDEVICE, "cannot create the shared extractor's stream");
-        sctx->params.host_wait = 1;
-        // The extractor's launch sequence is one long dependent chain that every registration in flight waits for: its
-        // stream gets the highest priority, which also gives it a hardware queue of its own (streams of equal priority
-        // share the device's few queues, and a chain's next kernel would sit behind other streams' long kernels).
-        if (!getenv("PLADE_EXTRACTOR_NO_PRIORITY")) {
-            int least = 0, greatest = 0;
-            HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
-            hipStream_t hp = nullptr;
-            HIP_TRY(hipStreamCreateWithPriority(&hp, hipStreamNonBlocking, greatest));
-            (void)hipStreamDestroy(sctx->stream);
-            sctx->stream = hp;
-        }
-        work_ready(sctx, W);
-        th = std::thread([this]() { run(); });
-        th.detach();
-    }
-    void check_locked() { if (failed.load()) throw failure; }
-
-    void run() {
-        (void)hipSetDevice(device);
-        relax_timer_slack();
-        try {
-            bool running[R_NS] = {};
-            hipEvent_t ring[2];
-            for (hipEvent_t &e : ring) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            uint64_t launched = 0;
-            hipStream_t st = sctx->stream;
-            const bool trace = getenv("PLADE_EXTRACTOR_TRACE") != nullptr;
-            uint64_t sum_slots = 0;
-            Clock::time_point t_trace = Clock::now();
-            for (;;) {
-                std::deque<Submission> fresh;
-                {
-                    std::unique_lock<std::mutex> lk(mu);
-                    bool any = false;
-                    for (bool r : running) any = any || r;
-                    if (!any) cv_work.wait(lk, [&] { return !pending.empty(); });
-                    fresh.swap(pending);
-                }
-                if (!fresh.empty()) {   // admission: hand-over from the preparing streams, table entries, loop states
-                    RInit I;
-                    memset(&I, 0, sizeof(I));
-                    bool mask[R_NS] = {};
-                    int slots[R_NS], n = 0;
-                    for (const Submission &sub : fresh) {
-                        RansacSlot &s = W.slot[sub.slot];
-                        if (s.fresh) { HIP_TRY(hipStreamWaitEvent(st, s.prepared, 0)); s.fresh = false; }
-                        I.c[sub.slot] = sub.init;
-                        mask[sub.slot] = true;
-                        slots[n++] = sub.slot;
-                        running[sub.slot] = true;
-                    }
-                    upload_entries(st, W, slots, n);
-                    IterShape sh;
-                    const RArgs A = make_args(W, mask, R_NS, sh);
-                    hipLaunchKernelGGL(k_r_init, dim3(sh.tiles), dim3(TPB), 0, st, A, I);
-                    HIP_TRY(hipGetLastError());
-                }
-                auto retire = [&]() {
-                    bool any = false;
-                    for (int g = 0; g < R_NS; ++g) {
-                        if (running[g] && flag_done(W.slot[g].res, W.slot[g].gen)) running[g] = false;
-                        any = any || running[g];
-                    }
-                    return any;
-                };
-                if (!retire()) continue;
-                if (launched >= 2) {   // at most two iterations queued: the one that runs and the next
-                    hipEvent_t e = ring[launched & 1];
-                    for (uint32_t polls = 0;; ++polls) {
-                        const hipError_t q = hipEventQuery(e);
-                        if (q == hipSuccess) break;
-                        if (q != hipErrorNotReady) throw Err{PLADE_EDEVICE, std::string("hipEventQuery: ") + hipGetErrorString(q)};
-                        timespec ts{0, polls < 8 ? 15000 : 30000};
-                        nanosleep(&ts, nullptr);
-                    }
-                    if (!retire()) continue;
-                }
-                IterShape sh;
-                const RArgs A = make_args(W, running, R_NS, sh);
-                enqueue_iteration(sctx, st, A, sh);
-                HIP_TRY(hipGetLastError());
-                HIP_TRY(hipEventRecord(ring[launched & 1], st));
-                ++launched;
-                if (trace) {
-                    for (bool r : running) sum_slots += r;
-                    if (launched % 1000 == 0) {
-                        fprintf(stderr, "[extractor %d] %llu iterations, %.2f slots per iteration, %.1f us per iteration\n", device,
-                                (unsigned long long)launched, sum_slots / 1000.0, secs_since(t_trace) * 1e3);
-                        sum_slots = 0; t_trace = Clock::now();
-                    }
-                }
-            }
-        } catch (const Err &e) {
-            std::lock_guard<std::mutex> lk(mu);
-            failure = e;
-            failed.store(true, std::memory_order_release);
-        } catch (const std::exception &e) {
-            std::lock_guard<std::mutex> lk(mu);
-            failure = Err{PLADE_EDEVICE, e.what()};
-            failed.store(true, std::memory_order_release);
-        }
-        cv_free.notify_all();
-    }
-};
-
-}  // namespace
-
-bool ransac_shared_enabled(const plade_ctx *ctx) {
-    if (const char *e = getenv("PLADE_SHARED_EXTRACTOR")) return atoi(e) != 0;
-    return ctx->params.host_wait != 0 && !ctx->profiling();
-}
-
-void ransac_shared_acquire(plade_ctx *ctx) {
-    if (ctx->ransac_lease >= 0) return;
-    static std::atomic<uint32_t> turn{0};
-    const int chain = (int)(turn.fetch_add(1) % (uint32_t)RansacServer::chains());
-    ctx->ransac_lease = chain * R_NS + RansacServer::of(ctx->device, chain)->acquire();
-}
-
-void ransac_shared_release(plade_ctx *ctx) {
-    if (ctx->ransac_lease < 0) return;
-    RansacServer *srv = RansacServer::of(ctx->device, ctx->ransac_lease / R_NS);
-    const int base = ctx->ransac_lease % R_NS;
-    // a call that is still running (the requester gave up on an error) has to end before the slots change hands, and
-    // so does whatever the requester's stream still reads from them
-    int slots[R_G], n = 0;
-    for (int g = 0; g < R_G; ++g) if (srv->W.slot[base + g].in_call) slots[n++] = base + g;
-    try { if (n) srv->wait_done(slots, n); } catch (...) {}
-    for (int g = 0; g < R_G; ++g) srv->W.slot[base + g].in_call = false;
-    (void)hipStreamSynchronize(ctx->stream);
-    ctx->ransac_lease = -1;
-    srv->release(base);
-}
-
-void ransac_shared_prepare(plade_ctx *ctx, const CloudDev *const clouds[RANSAC_SLOTS], int n_clouds) {
-    PLADE_REQUIRE(ctx->ransac_lease >= 0, PLADE_EINVAL, "shared extractor: no slots held");
-    RansacServer *srv = RansacServer::of(ctx->device, ctx->ransac_lease / R_NS);
-    const int base = ctx->ransac_lease % R_NS;
-    prepare_slots(ctx, srv->W, base, clouds, n_clouds);
-    for (int g = 0; g < n_clouds; ++g) {
-        RansacSlot &s = srv->W.slot[base + g];
-        if (!s.prepared) HIP_TRY(hipEventCreateWithFlags(&s.prepared, hipEventDisableTiming));
-    }
-    // one hand-over point for both slots: recorded on the first, waited for by whichever is admitted
-    for (int g = 0; g < n_clouds; ++g) {
-        RansacSlot &s = srv->W.slot[base + g];
-        HIP_TRY(hipEventRecord(s.prepared, ctx->stream));
-        s.fresh = true;
-    }
-}
-
-void ransac_shared_detect(plade_ctx *ctx, RansacJob jobs[RANSAC_SLOTS]) {
-    PLADE_REQUIRE(ctx->ransac_lease >= 0, PLADE_EINVAL, "shared extractor: no slots held");
-    Clock::time_point t0 = Clock::now();
-    RansacServer *srv = RansacServer::of(ctx->device, ctx->ransac_lease / R_NS);
-    const int base = ctx->ransac_lease % R_NS;
-    RInitCloud inits[R_G];
-    int slots[R_G], n = 0;
-    for (int g = 0; g < R_G; ++g) {
-        RansacJob &J = jobs[g];
-        RansacSlot &s = srv->W.slot[base + g];
-        if (!J.active) continue;
-        if (!s.cloud || s.n < 3) {   // plane_extraction.cpp:181-184: fewer than three points, no planes
-            if (J.out) {
-                J.out->coef.clear(); J.out->offsets.assign(1, 0); J.out->idx.clear(); J.out->d_idx = nullptr; J.out->remaining = s.n;
-                J.out->n_score_passes = 0; J.out->score_bytes = 0;
-            }
-            J.active = false;
-            continue;
-        }
-        s.gen = (s.gen + 1) & 0x7fu;
-        inits[n] = init_of(s, J.rp, s.gen);
-        s.in_call = true;
-        slots[n++] = base + g;
-    }
-    if (n == 0) return;
-    srv->submit(slots, inits, n);
-    srv->wait_done(slots, n);
-    for (int i = 0; i < n; ++i) srv->W.slot[slots[i]].in_call = false;
-    ctx->stats.add("ransac_t_detect", secs_since(t0));
-    bool any_host = false;
-    for (int g = 0; g < R_G; ++g) {
-        if (!jobs[g].active) continue;
-        collect(ctx, srv->W.slot[base + g], jobs[g].rp, *jobs[g].out);
-        any_host = any_host || jobs[g].rp.host_indices;
-    }
-    if (any_host) ctx->sync();
 }
 
 }  // namespace plade

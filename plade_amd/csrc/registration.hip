@@ -30,14 +30,9 @@ void extract_pair(plade_ctx *ctx, const CloudDev *const clouds[2], const int ini
                   PlaneSetOut *const planes[2], bool host_indices) {
     const uint32_t min_num = (uint32_t)ctx->params.min_planes, max_num = (uint32_t)ctx->params.max_planes;
     const int min_allowed_support = 200, max_trials = 10;
-    const bool shared = ransac_shared_enabled(ctx);
-    if (shared) {
-        ransac_shared_acquire(ctx);   // released by register_clouds, after the index lists have been consumed
-        ransac_shared_prepare(ctx, clouds, 2);
-    } else {
-        if (!ctx->ransac_work) ctx->ransac_work = ransac_work_create();
-        ransac_prepare(ctx, *ctx->ransac_work, clouds, 2);
-    }
+    if (!ctx->ransac_work) ctx->ransac_work = ransac_work_create();
+    RansacWork &W = *ctx->ransac_work;
+    ransac_prepare(ctx, W, clouds, 2);
     int ms[2] = {init_min_support[0], init_min_support[1]}, trials[2] = {0, 0};
     bool finished[2] = {false, false};
     const char *tags[2] = {"_tgt", "_src"};
@@ -51,8 +46,7 @@ void extract_pair(plade_ctx *ctx, const CloudDev *const clouds[2], const int ini
             any = any || jobs[g].active;
         }
         if (!any) break;
-        if (shared) ransac_shared_detect(ctx, jobs);
-        else ransac_detect_prepared(ctx, *ctx->ransac_work, jobs);
+        ransac_detect_prepared(ctx, W, jobs);
         for (int g = 0; g < 2; ++g) {
             if (finished[g]) continue;
             PlaneSetOut &pl = *planes[g];
@@ -98,7 +92,6 @@ void extract_pair(plade_ctx *ctx, const CloudDev *const clouds[2], const int ini
 int register_clouds(plade_ctx *ctx, const CloudDev &tgt, const CloudDev &src, int ms_t, int ms_s, bool auto_tune,
                     float *T16) {
     for (int i = 0; i < 16; ++i) T16[i] = (i % 5 == 0) ? 1.f : 0.f;
-    struct LeaseGuard { plade_ctx *c; ~LeaseGuard() { ransac_shared_release(c); } } lease_guard{ctx};
     PlaneSetOut tp, sp;
     float spacing = 0.f;
     bool have_spacing = false;

@@ -146,43 +146,6 @@ def test_contexts_sharing_a_gpu_are_independent():
         assert want[i][0] and np.linalg.norm(want[i][1] - Tgt) < 1e-2   # 60k points: coarser than the 1M pairs
 
 
-@pytest.mark.timeout(300)
-def test_shared_extractor_batches_without_changing_a_bit():
-    """host_wait = 1 (several registrations in flight): the plane extraction of all contexts runs on the device's shared
-    extractor, one launch sequence over the slots of whoever is extracting (ransac.hip, RansacServer).  Clouds of
-    different sizes joining and leaving the batch at different iterations get exactly the planes, and the registration
-    exactly the matrix, of a context that runs alone on its own stream."""
-    sizes = (60000, 150000, 90000, 40000)
-    pairs = [make_pair(n, seed=10 + i) for i, n in enumerate(sizes)]
-    ref_ctx = plade_amd.Context(0)          # spinning waits: the per-context loop
-    want = [ref_ctx.registration(tg, sr) for (tg, sr, _) in pairs]
-    ref_ctx.close()
-    got, errs = {}, []
-
-    def work(w):
-        try:
-            c = plade_amd.Context(0, host_wait=1)
-            for rep in range(6):
-                for i in range(len(pairs)):
-                    j = (i + w) % len(pairs)          # the workers walk the pairs out of phase
-                    tg, sr, _ = pairs[j]
-                    got[(w, rep, j)] = c.registration(tg, sr)
-            assert c.stats().get("ransac_iterations", 0) == 0   # the per-context loop did not run
-            c.close()
-        except Exception as e:   # noqa: BLE001 - reported by the main thread
-            errs.append(repr(e))
-
-    ths = [threading.Thread(target=work, args=(w,)) for w in range(10)]   # more workers than slot pairs: some wait for slots
-    for t in ths:
-        t.start()
-    for t in ths:
-        t.join()
-    assert not errs, errs
-    assert len(got) == 10 * 6 * len(pairs)
-    for (w, rep, j), (ok, T) in got.items():
-        assert ok == want[j][0] and np.array_equal(T, want[j][1]), (w, rep, j)
-
-
 @pytest.mark.timeout(120)
 def test_non_finite_inputs_neither_hang_nor_poison_the_context(ctx):
     """NaN / infinite coordinates are refused (every grid and threshold derives from them; PCL's kd-trees and
