@@ -47,8 +47,7 @@ constexpr uint32_t R_H = 4096;          // hypotheses per sampling round
 constexpr uint32_t R_TOP = 48;          // candidate pool
 constexpr int R_B = 8;                  // acceptance chains per cloud and iteration (16 gave the same batches: the pool
                                         // rarely holds more than 8 mutually conflict-free planes)
-constexpr int R_G = RANSAC_SLOTS;        // clouds prepared together (one sort): the two scans of a registration
-constexpr int R_NS = 16;                // slots of a work area: clouds extracted by one launch sequence
+constexpr int R_G = RANSAC_SLOTS;
 constexpr uint32_t R_MAXP = 4096;       // accepted shapes per detect call
 constexpr uint32_t R_MAX_ROUNDS = 4000;
 constexpr int R_MIN_LEVEL = 1, R_MAX_LEVEL = 8;
@@ -134,7 +133,8 @@ struct CloudView {
     uint32_t n;
 };
 
-// Everything static about one cloud slot.
+// Everything static about one cloud slot, passed BY VALUE in the kernel arguments (scalar loads from the kernarg
+// segment; a table in device memory costs every workgroup a dependent global load before it can fetch anything).
 struct RCloudArgs {
     CloudView cv;                    // the Morton-ordered cloud
     const uint32_t *codes;           // its Morton codes
@@ -152,13 +152,9 @@ struct RCloudArgs {
     const uint32_t *list_values;     // seam S1c: the score list is given (list position -> point), else nullptr
     ChainLayout L;
 };
-// The slots' RCloudArgs live in a device-resident table (uniform scalar loads); what travels in the kernel arguments is
-// its address, the number of slots the grids cover and, for the scan kernels whose grid is the concatenation of the
-// slots' tiles, the end of every slot's tile range (a slot that sits out an iteration has an empty range).
 struct RArgs {
-    const RCloudArgs *tab;
-    uint32_t ns, pad;
-    uint32_t tile_end[R_NS];
+    RCloudArgs c[R_G];
+    uint32_t ng, tiles0;             // clouds in this sequence; tiles of cloud 0 (scan grids are the concatenated tiles)
 };
 
 struct ChainPtr {
@@ -358,9 +354,8 @@ __device__ __forceinline__ void load_tile(Tile &t, const float *x, const float *
 
 // which cloud a workgroup of a "concatenated tiles" grid scans
 __device__ __forceinline__ int scan_group(const RArgs &A, uint32_t &tile) {
-    int g = 0;
-    while (g + 1 < (int)A.ns && blockIdx.x >= A.tile_end[g]) ++g;   // uniform, <= 16 steps over kernel arguments
-    tile = blockIdx.x - (g ? A.tile_end[g - 1] : 0u);
+    const int g = (A.ng > 1 && blockIdx.x >= A.tiles0) ? 1 : 0;
+    tile = blockIdx.x - (g ? A.tiles0 : 0);
     return g;
 }
 
@@ -410,14 +405,17 @@ struct RInitCloud {
     float eps, eps3, bitmap_eps, cos_t, overlook_p, bbmin[3], bbmax[3];
     uint64_t seed;
 };
-struct RInit { RInitCloud c[R_NS]; };
+struct RInit { RInitCloud c[R_G]; };
 
 __global__ __launch_bounds__(TPB) void k_r_init(const RArgs A, const RInit I) {
     uint32_t tile;
     const int g = scan_group(A, tile);
-    const RCloudArgs &C = A.tab[g];
+    const RCloudArgs &C = A.c[g];
     const RInitCloud &P = I.c[g];
-    if (!P.active) return;   // this slot is not (re)started by this call: left as it is
+    if (!P.active) {
+        if (tile == 0 && threadIdx.x == 0) { C.st->active = 0; C.st->done = 1; C.st->nc = 0; C.st->aj_n = 0; C.st->npool = 0; C.st->sampling = 0; C.st->fresh = 0; }
+        return;
+    }
     const uint32_t base = tile * TILE + threadIdx.x * PPT;
     if (C.assigned) {
         if (base + PPT <= ((C.cv.n + 3) & ~3u)) *reinterpret_cast<int4 *>(C.assigned + base) = make_int4(-1, -1, -1, -1);
@@ -441,7 +439,7 @@ __global__ __launch_bounds__(TPB) void k_r_init(const RArgs A, const RInit I) {
 // ------------------------------------------------------------------------------------------------
 // hypothesis sampling: one lane per hypothesis
 __global__ __launch_bounds__(256) void k_r_sample(const RArgs A) {
-    const RCloudArgs &C = A.tab[blockIdx.y];
+    const RCloudArgs &C = A.c[blockIdx.y];
     RState *S = C.st;
     if (S->done || !S->sampling) return;
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -532,7 +530,7 @@ __global__ __launch_bounds__(256) void k_r_sample(const RArgs A) {
 __global__ __launch_bounds__(TPB) void k_r_score_sub(const RArgs A) {
     __shared__ float4 s_pl[HCHUNK];
     __shared__ uint32_t s_cnt[TPB / 64][HCHUNK];
-    const RCloudArgs &C = A.tab[blockIdx.z];
+    const RCloudArgs &C = A.c[blockIdx.z];
     RState *S = C.st;
     if (S->done || !S->sampling) return;
     if (blockIdx.x * TILE >= C.n_sub) return;
@@ -581,7 +579,7 @@ __device__ __forceinline__ bool same_plane(const float4 &a, const float4 &b, flo
 // arg-max of 32-bit keys (count << 12 | 4095 - index: the subset holds fewer than 2^20 points), ONE barrier (the wave
 // winners and their planes go through double-buffered LDS) and four duplicate tests per lane.
 __global__ __launch_bounds__(1024) void k_r_leaders(const RArgs A) {
-    const RCloudArgs &C = A.tab[blockIdx.x];
+    const RCloudArgs &C = A.c[blockIdx.x];
     RState *S = C.st;
     if (S->done || !S->sampling) return;
     __shared__ uint32_t s_key[2][16];
@@ -664,7 +662,7 @@ __global__ __launch_bounds__(TPB) void k_r_rescore(const RArgs A, int phase) {
     __shared__ uint32_t s_cnt[TPB / 64][HCHUNK];
     uint32_t tile;
     const int g = scan_group(A, tile);
-    const RCloudArgs &C = A.tab[g];
+    const RCloudArgs &C = A.c[g];
     RState *S = C.st;
     const uint32_t np = S->npool;
     if (S->done || np == 0 || (S->fresh != 0u) != (phase != 0)) return;
@@ -734,7 +732,7 @@ __device__ bool conflict_free(const float4 &a, const float4 &b, float eps, float
 // the support of any better candidate become this iteration's acceptance chains (accepting them concurrently equals
 // accepting them one by one, best first).  One wavefront per cloud.
 __global__ __launch_bounds__(64) void k_r_select(const RArgs A, int phase) {
-    const RCloudArgs &C = A.tab[blockIdx.x];
+    const RCloudArgs &C = A.c[blockIdx.x];
     RState *S = C.st;
     const int lane = threadIdx.x;
     if (phase == 0) {
@@ -812,7 +810,7 @@ __global__ __launch_bounds__(TPB) void k_r_mark(const RArgs A, int k) {
     __shared__ float s_bb[R_B][4][TPB / 64];
     uint32_t tile;
     const int g = scan_group(A, tile);
-    const RCloudArgs &C = A.tab[g];
+    const RCloudArgs &C = A.c[g];
     RState *S = C.st;
     const uint32_t nc = S->nc;
     if (nc == 0) return;
@@ -876,7 +874,7 @@ __global__ __launch_bounds__(TPB) void k_r_mark(const RArgs A, int k) {
 // (all positions < m are "inliers"); tiles past the list get a zero count.
 __global__ __launch_bounds__(TPB) void k_r_list_mark(const RArgs A, uint32_t m) {
     __shared__ float s_bb[4][TPB / 64];
-    const RCloudArgs &C = A.tab[0];
+    const RCloudArgs &C = A.c[0];
     const ChainPtr ch = chain_of(C, 0);
     const PlaneState *st = &ch.hdr->st[0];
     const uint32_t tile = blockIdx.x, first = tile * TILE + threadIdx.x * PPT;
@@ -947,8 +945,8 @@ __global__ __launch_bounds__(TPB) void k_r_compact_raster(const RArgs A, int k) 
     __shared__ uint32_t s_pre[OWN_MAX][TPB / 64];
     const int g = blockIdx.y / R_B;
     const uint32_t b = blockIdx.y % R_B;
-    if (g >= (int)A.ns) return;
-    const RCloudArgs &C = A.tab[g];
+    if (g >= (int)A.ng) return;
+    const RCloudArgs &C = A.c[g];
     const uint32_t nb = C.L.nb;
     RState *S = C.st;
     if (b >= S->nc) return;
@@ -1162,8 +1160,8 @@ __device__ __forceinline__ void cc_label_body(uint8_t *bmp, uint8_t *tmp, uint32
 __global__ __launch_bounds__(1024) void k_r_label(const RArgs A, int k, int do_filter) {
     const int g = blockIdx.x / R_B;
     const uint32_t b = blockIdx.x % R_B;
-    if (g >= (int)A.ns) return;
-    const RCloudArgs &C = A.tab[g];
+    if (g >= (int)A.ng) return;
+    const RCloudArgs &C = A.c[g];
     if (b >= C.st->nc) return;
     const ChainPtr ch = chain_of(C, b);
     PlaneState *st = &ch.hdr->st[k];
@@ -1197,8 +1195,8 @@ __global__ __launch_bounds__(TPB) void k_r_select_cc(const RArgs A, int k) {
     __shared__ double s[4][FIT_COLS];
     const int g = blockIdx.y / R_B;
     const uint32_t b = blockIdx.y % R_B;
-    if (g >= (int)A.ns) return;
-    const RCloudArgs &C = A.tab[g];
+    if (g >= (int)A.ng) return;
+    const RCloudArgs &C = A.c[g];
     if (b >= C.st->nc) return;
     const ChainPtr ch = chain_of(C, b);
     const PlaneState *st = &ch.hdr->st[k];
@@ -1299,8 +1297,8 @@ __global__ __launch_bounds__(256) void k_r_fit(const RArgs A, int k) {
     __shared__ double s_red[4][FIT_COLS];
     const int g = blockIdx.x / R_B;
     const uint32_t b = blockIdx.x % R_B;
-    if (g >= (int)A.ns) return;
-    const RCloudArgs &C = A.tab[g];
+    if (g >= (int)A.ng) return;
+    const RCloudArgs &C = A.c[g];
     if (b >= C.st->nc) return;
     const ChainPtr ch = chain_of(C, b);
     PlaneState *cur = &ch.hdr->st[k];
@@ -1370,8 +1368,9 @@ __global__ __launch_bounds__(256) void k_r_fit(const RArgs A, int k) {
 // bookkeeping (RansacShapeDetector.cpp:666-675), output planes (plane_extraction.cpp:134-149), the pool without
 // the batch, and what the next iteration does.  One lane per cloud does the sequential part.
 __global__ __launch_bounds__(64) void k_r_decide(const RArgs A) {
-    const RCloudArgs &C = A.tab[blockIdx.x];
+    const RCloudArgs &C = A.c[blockIdx.x];
     RState *S = C.st;
+    RResult *R = C.res;
     if (!S->active) return;
     // the chains' results are fetched by all lanes at once (one lane alone would pay a DRAM/L2 round trip per field)
     __shared__ PlaneState s_st[R_B][4];
@@ -1455,16 +1454,9 @@ __global__ __launch_bounds__(64) void k_r_decide(const RArgs A) {
     }
     S->it += 1;
     }
-}
-
-// Last launch of an iteration: what the host reads.  The host-mapped block of a slot is written once, when its call ends
-// (stores over PCIe are slow: all 64 lanes share them); until then the host only needs the iteration count.  Coming
-// after the removal kernel in stream order, a "finished" flag also says that everything the call produced is complete.
-__global__ __launch_bounds__(64) void k_r_report(const RArgs A) {
-    const RCloudArgs &C = A.tab[blockIdx.x];
-    RState *S = C.st;
-    RResult *R = C.res;
-    if (!S->active || !R) return;
+    __syncthreads();
+    // The host-mapped block is written once, when the call ends (stores over PCIe are slow: all 64 lanes share them);
+    // until then the host only needs the iteration count.
     const uint32_t done = S->done;
     if (done) {
         const uint32_t na = S->n_acc;
@@ -1480,11 +1472,10 @@ __global__ __launch_bounds__(64) void k_r_report(const RArgs A) {
     }
     __threadfence_system();
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0)
         *reinterpret_cast<volatile uint32_t *>(&R->flag) = (S->it & 0xffffffu) | ((S->gen & 0x7fu) << 24) | (done ? 0x80000000u : 0u);
-        if (done) S->active = 0;   // reported: the slot sits out until it is started again
-    }
 }
+
 
 // Point removal + output index lists of the accepted candidates: the chosen slot's list entries that belong to the
 // largest component, in list order (ordered compaction of the selection masks; offsets from the per-row counts as in
@@ -1493,8 +1484,8 @@ __global__ __launch_bounds__(TPB) void k_r_assign(const RArgs A) {
     __shared__ uint32_t s_pre[OWN_MAX][TPB / 64], s_w[TPB / 64];
     const int g = blockIdx.y / R_B;
     const uint32_t j = blockIdx.y % R_B;
-    if (g >= (int)A.ns) return;
-    const RCloudArgs &C = A.tab[g];
+    if (g >= (int)A.ng) return;
+    const RCloudArgs &C = A.c[g];
     const RState *S = C.st;
     if (j >= S->aj_n) return;
     const int k = (int)S->aj_slot[j];
@@ -1562,7 +1553,7 @@ __global__ __launch_bounds__(TPB) void k_r_assign(const RArgs A) {
 // seam S1c: one chain, slot 0, from a caller-given plane
 __global__ void k_r_seam_init(const RArgs A, float4 hyp, float4 pos, float w_eps, float bitmap_eps) {
     if (threadIdx.x) return;
-    const RCloudArgs &C = A.tab[0];
+    const RCloudArgs &C = A.c[0];
     RState *S = C.st;
     S->n = C.cv.n; S->active = 1; S->done = 0; S->sampling = 0; S->nc = 1; S->npool = 0;
     S->eps3 = w_eps; S->bitmap_eps = bitmap_eps; S->min_support = 0; S->orient = 0; S->err = 0;
@@ -1587,22 +1578,18 @@ struct RansacSlot {
     uint32_t sub_pitch = 0, n_sub = 0;
     DBuf<char> round_block;          // hypotheses / positions / counts of the current round
     DBuf<char> fixed, var;           // the chains' slabs
+    DBuf<RState> state;
     RResult *res = nullptr, *res_dev = nullptr;   // host-mapped result block
     ChainLayout L{};
     DBuf<uint32_t> seam_list;
-    DBuf<uint32_t> keys_in, vals_in, keys, perm;   // Morton sort of the clouds prepared with this slot as their first
-    uint32_t gen = 0;                // tag of the slot's running / last detect call
     ~RansacSlot() { if (res) (void)hipHostFree(res); }
 };
 
 struct RansacWork {
-    RansacSlot slot[R_NS];
-    DBuf<RState> states;             // R_NS loop states
-    DBuf<RCloudArgs> d_tab;          // the slot table the kernels read
-    std::vector<RCloudArgs> h_tab;   // its host mirror
-    std::vector<uint64_t> tab_hash;  // what of it is on the device
-    bool ready = false;
+    RansacSlot slot[R_G];
+    int ng = 0;
     uint32_t generation = 0;         // detect calls issued on this work area
+    DBuf<uint32_t> keys_in, vals_in, keys, perm;
     std::map<uint64_t, hipGraphExec_t> graphs;   // the iteration sequence, keyed on everything baked into its launches
     ~RansacWork() { for (auto &kv : graphs) if (kv.second) (void)hipGraphExecDestroy(kv.second); }
 };
@@ -1612,35 +1599,6 @@ void ransac_work_destroy(RansacWork *w) { delete w; }
 
 namespace {
 
-__global__ void k_r_reset_states(RState *st, int n) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) { st[i].active = 0; st[i].done = 1; st[i].sampling = 0; st[i].fresh = 0; st[i].npool = 0; st[i].nc = 0; st[i].aj_n = 0; }
-}
-
-uint64_t hash_bytes(const void *p, size_t n) {
-    uint64_t h = 1469598103934665603ull;
-    const unsigned char *b = static_cast<const unsigned char *>(p);
-    for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; }
-    return h;
-}
-
-// first use of a work area: every slot gets a loop state that says "finished" and a table entry that points to it
-void work_ready(plade_ctx *ctx, RansacWork &W) {
-    if (W.ready) return;
-    W.states.ensure(R_NS);
-    W.d_tab.ensure(R_NS);
-    HIP_TRY(hipMemsetAsync(W.states.p, 0, sizeof(RState) * R_NS, ctx->stream));
-    hipLaunchKernelGGL(k_r_reset_states, dim3(1), dim3(64), 0, ctx->stream, W.states.p, R_NS);
-    W.h_tab.resize(R_NS);
-    memset(W.h_tab.data(), 0, sizeof(RCloudArgs) * R_NS);
-    for (int g = 0; g < R_NS; ++g) W.h_tab[g].st = W.states.p + g;
-    HIP_TRY(hipMemcpyAsync(W.d_tab.p, W.h_tab.data(), sizeof(RCloudArgs) * R_NS, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));   // h_tab is pageable: the copy must not outlive this call unobserved
-    W.tab_hash.assign(R_NS, 0);
-    for (int g = 0; g < R_NS; ++g) W.tab_hash[g] = hash_bytes(&W.h_tab[g], sizeof(RCloudArgs));
-    W.ready = true;
-}
-
 void slot_buffers(plade_ctx *ctx, RansacSlot &s, uint32_t n) {
     s.n = n;
     s.L = make_layout(n);
@@ -1649,6 +1607,7 @@ void slot_buffers(plade_ctx *ctx, RansacSlot &s, uint32_t n) {
         HIP_TRY(hipMemsetAsync(s.fixed.p, 0, s.fixed.cap, ctx->stream));
     }
     s.var.ensure((size_t)R_B * s.L.bytes);
+    s.state.ensure(1);
     s.round_block.ensure((size_t)R_H * 36 + 64);
     s.out_idx.ensure((size_t)n + 4);
     s.assigned.ensure((size_t)n + 8);
@@ -1659,98 +1618,79 @@ void slot_buffers(plade_ctx *ctx, RansacSlot &s, uint32_t n) {
     }
 }
 
-// the slot's table entry from its buffers (host mirror only)
-void slot_entry(RansacWork &W, int g) {
-    RansacSlot &s = W.slot[g];
-    RCloudArgs C;
-    memset(&C, 0, sizeof(C));   // field by field below: the bytes are hashed, padding included
-    const CloudDev &c = s.sorted;
-    C.cv.x = c.x(); C.cv.y = c.y(); C.cv.z = c.z(); C.cv.nx = c.nx(); C.cv.ny = c.ny(); C.cv.nz = c.nz(); C.cv.n = s.n;
-    C.codes = s.codes.p; C.orig = s.orig.p; C.assigned = s.assigned.p;
-    C.sub = s.sub.p; C.sub_index = s.sub_index.p; C.sub_pitch = s.sub_pitch; C.n_sub = s.n_sub;
-    C.st = W.states.p + g; C.res = s.res_dev;
-    C.hyp = reinterpret_cast<float4 *>(s.round_block.p);
-    C.hyp_pos = C.hyp + R_H;
-    C.hyp_counts = reinterpret_cast<uint32_t *>(C.hyp_pos + R_H);
-    C.out_idx = s.out_idx.p;
-    C.fixed = s.fixed.p; C.var = s.var.p;
-    C.list_values = nullptr;
-    memcpy(&C.L, &s.L, sizeof(ChainLayout));
-    memcpy(&W.h_tab[g], &C, sizeof(C));
-}
-
-// brings the device table up to date for the listed slots (stream-ordered small uploads through the ctx arena)
-void upload_entries(plade_ctx *ctx, RansacWork &W, const int *slots, int n) {
-    for (int i = 0; i < n; ++i) {
-        const int g = slots[i];
-        const uint64_t h = hash_bytes(&W.h_tab[g], sizeof(RCloudArgs));
-        if (h == W.tab_hash[g]) continue;
-        ctx->h2d(W.d_tab.p + g, &W.h_tab[g], sizeof(RCloudArgs));
-        W.tab_hash[g] = h;
-    }
-}
-
-struct IterShape { uint32_t ns, tiles, nb_max, sub_tiles; };
-
-// kernel arguments of an iteration over the slots with active[g] != 0 (the others contribute no tiles)
-RArgs make_args(RansacWork &W, const bool *active, int ns_in, IterShape &sh) {
+RArgs make_args(RansacWork &W, int ng) {
     RArgs A;
     memset(&A, 0, sizeof(A));
-    A.tab = W.d_tab.p;
-    sh = IterShape{0, 0, 1, 1};
-    uint32_t end = 0;
-    for (int g = 0; g < R_NS; ++g) {
-        if (g < ns_in && active[g]) {
-            end += W.slot[g].L.nb;
-            sh.ns = (uint32_t)g + 1;
-            sh.nb_max = std::max(sh.nb_max, W.slot[g].L.nb);
-            sh.sub_tiles = std::max(sh.sub_tiles, cdiv(W.slot[g].n_sub, TILE));
-        }
-        A.tile_end[g] = end;
+    A.ng = (uint32_t)ng;
+    for (int g = 0; g < R_G; ++g) {
+        RansacSlot &s = W.slot[g < ng ? g : 0];
+        RCloudArgs &C = A.c[g];
+        const CloudDev &c = s.sorted;
+        // field by field: the bytes of this struct key the captured graphs, padding included (A was zeroed)
+        C.cv.x = c.x(); C.cv.y = c.y(); C.cv.z = c.z(); C.cv.nx = c.nx(); C.cv.ny = c.ny(); C.cv.nz = c.nz(); C.cv.n = s.n;
+        C.codes = s.codes.p; C.orig = s.orig.p; C.assigned = s.assigned.p;
+        C.sub = s.sub.p; C.sub_index = s.sub_index.p; C.sub_pitch = s.sub_pitch; C.n_sub = s.n_sub;
+        C.st = s.state.p; C.res = s.res_dev;
+        C.hyp = reinterpret_cast<float4 *>(s.round_block.p);
+        C.hyp_pos = C.hyp + R_H;
+        C.hyp_counts = reinterpret_cast<uint32_t *>(C.hyp_pos + R_H);
+        C.out_idx = s.out_idx.p;
+        C.fixed = s.fixed.p; C.var = s.var.p;
+        C.list_values = nullptr;
+        memcpy(&C.L, &s.L, sizeof(ChainLayout));
     }
-    A.ns = sh.ns;
-    sh.tiles = end;
+    A.tiles0 = A.c[0].L.nb;
     return A;
+}
+
+uint64_t hash_bytes(const void *p, size_t n) {
+    uint64_t h = 1469598103934665603ull;
+    const unsigned char *b = static_cast<const unsigned char *>(p);
+    for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; }
+    return h;
 }
 
 inline uint32_t loop_grid(uint32_t nb) { return std::min(1024u, std::max(32u, cdiv(nb, OWN_MAX))); }
 
-// one iteration of the detect loop: 30 launches
-void enqueue_iteration(plade_ctx *ctx, hipStream_t st, const RArgs &A, const IterShape &sh) {
-    const uint32_t ns = sh.ns, tiles = sh.tiles;
-    if (ns == 0 || tiles == 0) return;
+// one iteration of the detect loop: 29 launches
+void enqueue_iteration(plade_ctx *ctx, const RArgs &A) {
+    hipStream_t st = ctx->stream;
+    const uint32_t ng = A.ng;
+    uint32_t tiles = 0, nb_max = 0, sub_tiles = 0;
+    for (uint32_t g = 0; g < ng; ++g) {
+        tiles += A.c[g].L.nb;
+        nb_max = std::max(nb_max, A.c[g].L.nb);
+        sub_tiles = std::max(sub_tiles, cdiv(A.c[g].n_sub, TILE));
+    }
     // what the previous iteration left in the pool: re-score, prune, pick a batch ...
     ctx->ev_begin("score_multi", 0.0);
     hipLaunchKernelGGL(k_r_rescore, dim3(tiles), dim3(TPB), 0, st, A, 0);
     ctx->ev_end();
-    hipLaunchKernelGGL(k_r_select, dim3(ns), dim3(64), 0, st, A, 0);
+    hipLaunchKernelGGL(k_r_select, dim3(ng), dim3(64), 0, st, A, 0);
     // ... and if nothing is left (or at the start), a new round: sample, score on the subset, leaders, re-score, batch
-    hipLaunchKernelGGL(k_r_sample, dim3(cdiv(R_H, 256), ns), dim3(256), 0, st, A);
-    hipLaunchKernelGGL(k_r_score_sub, dim3(sh.sub_tiles, R_H / HCHUNK, ns), dim3(TPB), 0, st, A);
-    hipLaunchKernelGGL(k_r_leaders, dim3(ns), dim3(1024), 0, st, A);
+    hipLaunchKernelGGL(k_r_sample, dim3(cdiv(R_H, 256), ng), dim3(256), 0, st, A);
+    hipLaunchKernelGGL(k_r_score_sub, dim3(sub_tiles, R_H / HCHUNK, ng), dim3(TPB), 0, st, A);
+    hipLaunchKernelGGL(k_r_leaders, dim3(ng), dim3(1024), 0, st, A);
     ctx->ev_begin("score_multi", 0.0);
     hipLaunchKernelGGL(k_r_rescore, dim3(tiles), dim3(TPB), 0, st, A, 1);
     ctx->ev_end();
-    hipLaunchKernelGGL(k_r_select, dim3(ns), dim3(64), 0, st, A, 1);
-    const uint32_t lg = loop_grid(sh.nb_max);
+    hipLaunchKernelGGL(k_r_select, dim3(ng), dim3(64), 0, st, A, 1);
     for (int k = 0; k < 4; ++k) {
         ctx->ev_begin("score_mark", 0.0);
         hipLaunchKernelGGL(k_r_mark, dim3(tiles), dim3(TPB), 0, st, A, k);
         ctx->ev_end();
-        hipLaunchKernelGGL(k_r_compact_raster, dim3(lg, R_B * ns), dim3(TPB), 0, st, A, k);
-        hipLaunchKernelGGL(k_r_label, dim3(R_B * ns), dim3(1024), 0, st, A, k, 1);
-        hipLaunchKernelGGL(k_r_select_cc, dim3(lg, R_B * ns), dim3(TPB), 0, st, A, k);
-        hipLaunchKernelGGL(k_r_fit, dim3(R_B * ns), dim3(256), 0, st, A, k);
+        hipLaunchKernelGGL(k_r_compact_raster, dim3(loop_grid(nb_max), R_B * ng), dim3(TPB), 0, st, A, k);
+        hipLaunchKernelGGL(k_r_label, dim3(R_B * ng), dim3(1024), 0, st, A, k, 1);
+        hipLaunchKernelGGL(k_r_select_cc, dim3(loop_grid(nb_max), R_B * ng), dim3(TPB), 0, st, A, k);
+        hipLaunchKernelGGL(k_r_fit, dim3(R_B * ng), dim3(256), 0, st, A, k);
     }
-    hipLaunchKernelGGL(k_r_decide, dim3(ns), dim3(64), 0, st, A);
-    hipLaunchKernelGGL(k_r_assign, dim3(lg, R_B * ns), dim3(TPB), 0, st, A);
-    hipLaunchKernelGGL(k_r_report, dim3(ns), dim3(64), 0, st, A);
+    hipLaunchKernelGGL(k_r_decide, dim3(ng), dim3(64), 0, st, A);
+    hipLaunchKernelGGL(k_r_assign, dim3(loop_grid(nb_max), R_B * ng), dim3(TPB), 0, st, A);
 }
 
-void launch_iteration(plade_ctx *ctx, RansacWork &W, const RArgs &A, const IterShape &sh, bool use_graph) {
-    if (!use_graph || ctx->profiling() || getenv("PLADE_NO_GRAPH")) { enqueue_iteration(ctx, ctx->stream, A, sh); HIP_TRY(hipGetLastError()); return; }
-    uint64_t key = hash_bytes(&A, sizeof(A));
-    key ^= hash_bytes(&sh, sizeof(sh)) * 0x9E3779B97F4A7C15ull;
+void launch_iteration(plade_ctx *ctx, RansacWork &W, const RArgs &A) {
+    if (ctx->profiling() || getenv("PLADE_NO_GRAPH")) { enqueue_iteration(ctx, A); HIP_TRY(hipGetLastError()); return; }
+    const uint64_t key = hash_bytes(&A, sizeof(A));
     auto it = W.graphs.find(key);
     if (it == W.graphs.end()) {
         if (W.graphs.size() > 64) {   // bounded cache (a batch of differently sized clouds)
@@ -1759,7 +1699,7 @@ void launch_iteration(plade_ctx *ctx, RansacWork &W, const RArgs &A, const IterS
         }
         hipGraph_t graph = nullptr;
         HIP_TRY(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
-        try { enqueue_iteration(ctx, ctx->stream, A, sh); }
+        try { enqueue_iteration(ctx, A); }
         catch (...) { (void)hipStreamEndCapture(ctx->stream, &graph); if (graph) (void)hipGraphDestroy(graph); throw; }
         HIP_TRY(hipStreamEndCapture(ctx->stream, &graph));
         hipGraphExec_t e = nullptr;
@@ -1770,30 +1710,27 @@ void launch_iteration(plade_ctx *ctx, RansacWork &W, const RArgs &A, const IterS
     HIP_TRY(hipGraphLaunch(it->second, ctx->stream));
 }
 
-inline uint32_t flag_of(const RResult *r) { return *reinterpret_cast<const volatile uint32_t *>(&r->flag); }
-inline bool flag_done(const RResult *r, uint32_t gen) {
-    const uint32_t f = flag_of(r);
-    return ((f >> 24) & 0x7fu) == (gen & 0x7fu) && (f & 0x80000000u);
-}
-inline bool flag_reached(const RResult *r, uint32_t gen, uint32_t want) {
-    const uint32_t f = flag_of(r);
-    if (((f >> 24) & 0x7fu) != (gen & 0x7fu)) return false;          // still the previous call's reports
-    return (f & 0x80000000u) || (f & 0xffffffu) >= want;
-}
-
 // Waits until every listed result block reports at least `want` completed iterations (or the end of its detect call).
 // The blocks are host-mapped and written by the device while the stream keeps running; should a flag not become visible
 // (it always has), the stream running dry ends the wait: everything is visible then.
-void wait_iterations(plade_ctx *ctx, hipStream_t stream, RResult *const *res, const uint32_t *gens, int nres, uint32_t want) {
+inline bool flag_done(const RResult *r, uint32_t gen) {
+    const uint32_t f = *reinterpret_cast<const volatile uint32_t *>(&r->flag);
+    return ((f >> 24) & 0x7fu) == (gen & 0x7fu) && (f & 0x80000000u);
+}
+void wait_iterations(plade_ctx *ctx, RResult *const *res, int nres, uint32_t want, uint32_t gen) {
     auto reached = [&]() {
-        for (int i = 0; i < nres; ++i) if (!flag_reached(res[i], gens[i], want)) return false;
+        for (int i = 0; i < nres; ++i) {
+            const uint32_t f = *reinterpret_cast<volatile uint32_t *>(&res[i]->flag);
+            if (((f >> 24) & 0x7fu) != (gen & 0x7fu)) return false;          // still the previous call's reports
+            if (!(f & 0x80000000u) && (f & 0xffffffu) < want) return false;
+        }
         return true;
     };
     if (ctx->params.host_wait != 0) relax_timer_slack();
     for (uint32_t polls = 0;; ++polls) {
         if (reached()) break;
-        if (stream && ((polls & 63u) == 63u || ctx->params.host_wait != 0)) {
-            const hipError_t e = hipStreamQuery(stream);
+        if ((polls & 63u) == 63u || ctx->params.host_wait != 0) {
+            const hipError_t e = hipStreamQuery(ctx->stream);
             if (e == hipSuccess) { if (reached()) break; throw Err{PLADE_EDEVICE, "plane extraction: the device loop did not report"}; }
             if (e != hipErrorNotReady) throw Err{PLADE_EDEVICE, std::string("hipStreamQuery: ") + hipGetErrorString(e)};
         }
@@ -1802,55 +1739,11 @@ void wait_iterations(plade_ctx *ctx, hipStream_t stream, RResult *const *res, co
     std::atomic_thread_fence(std::memory_order_acquire);
 }
 
-// the per-call parameters of one slot (scale exactly as plane_extraction.cpp:71-80 + PointCloud.h:94-98: maxZ stays
-// -FLT_MAX there, so the Z extent never wins the max)
-RInitCloud init_of(const RansacSlot &s, const RansacParams &rp, uint32_t gen) {
-    const CloudDev &c = *s.cloud;
-    const float scale = std::max(c.bbmax[0] - c.bbmin[0], c.bbmax[1] - c.bbmin[1]);
-    const float eps = rp.dist_rel * scale, bitmap_eps = rp.bitmap_rel * scale;
-    PLADE_REQUIRE(eps > 0.f && bitmap_eps > 0.f, PLADE_EINVAL, "plane extraction: degenerate bounding box");
-    RInitCloud P;
-    memset(&P, 0, sizeof(P));
-    P.active = 1; P.min_support = rp.min_support; P.orient = rp.orient_normals ? 1u : 0u;
-    P.eps = eps; P.eps3 = 3 * eps;   // RansacShapeDetector.cpp:471-473
-    P.bitmap_eps = bitmap_eps; P.cos_t = rp.cos_thresh; P.overlook_p = rp.overlook_p;
-    for (int k = 0; k < 3; ++k) { P.bbmin[k] = c.bbmin[k]; P.bbmax[k] = c.bbmax[k]; }
-    P.seed = rp.seed;
-    P.gen = gen;
-    return P;
-}
+}  // namespace
 
-// the finished call of a slot -> PlaneSetOut (host part; the index lists stay on the device)
-void collect(plade_ctx *ctx, RansacSlot &s, const RansacParams &rp, PlaneSetOut &out) {
-    const RResult &R = *s.res;
-    PLADE_REQUIRE(R.err != 1, PLADE_ELIMIT, "plane extraction: connected-component bitmap too large");
-    PLADE_REQUIRE(R.err != 3, PLADE_ELIMIT, "plane extraction: too many shapes");
-    out.coef.clear(); out.offsets.assign(1, 0); out.idx.clear();
-    for (uint32_t i = 0; i < R.n_acc; ++i) {
-        if (!R.support[i]) continue;
-        out.coef.insert(out.coef.end(), R.coef[i], R.coef[i] + 4);
-        out.offsets.push_back((int32_t)(R.offset[i] + R.support[i]));
-    }
-    out.d_idx = reinterpret_cast<const uint32_t *>(s.out_idx.p);
-    out.remaining = R.remaining;
-    out.n_score_passes = R.n_rescores + R.n_mark_launches;
-    out.score_bytes = 28.0 * s.n * (R.n_rescores + R.n_mark_launches) + 0.25 * s.n * R.n_mark_chains;
-    ctx->stats.add("ransac_rounds", R.n_rounds);
-    ctx->stats.add("ransac_accepts", R.n_accepts);
-    ctx->stats.add("ransac_batches", R.n_batches);
-    ctx->stats.add("ransac_rescore_launches", R.n_rescores);
-    ctx->stats.add("ransac_mark_launches", R.n_mark_launches);
-    for (int q = 0; q < 4; ++q) ctx->stats.add("ransac_final_slot" + std::to_string(q), R.n_final[q]);
-    for (int q = 1; q < 5; ++q) ctx->stats.add("ransac_loop_stops_at" + std::to_string(q), R.n_stop[q]);
-    if (rp.host_indices) {
-        out.idx.resize(R.out_off);
-        if (R.out_off) ctx->d2h(out.idx.data(), s.out_idx.p, 4 * (size_t)R.out_off);   // valid after the caller's sync
-    }
-}
-
-// Morton order + stratified subset of up to two clouds into slots base, base + 1 (queued on ctx's stream)
-void prepare_slots(plade_ctx *ctx, RansacWork &W, int base, const CloudDev *const *clouds, int n_clouds) {
-    PLADE_REQUIRE(n_clouds >= 1 && n_clouds <= R_G && base + n_clouds <= R_NS, PLADE_EINVAL, "ransac: one or two clouds");
+void ransac_prepare(plade_ctx *ctx, RansacWork &W, const CloudDev *const clouds[RANSAC_SLOTS], int n_clouds) {
+    PLADE_REQUIRE(n_clouds >= 1 && n_clouds <= R_G, PLADE_EINVAL, "ransac: one or two clouds");
+    W.ng = n_clouds;
     MortonArgs M;
     GatherArgs G;
     memset(&M, 0, sizeof(M));
@@ -1859,7 +1752,7 @@ void prepare_slots(plade_ctx *ctx, RansacWork &W, int base, const CloudDev *cons
     uint64_t total = 0;
     for (int g = 0; g < n_clouds; ++g) {
         const CloudDev &c = *clouds[g];
-        RansacSlot &s = W.slot[base + g];
+        RansacSlot &s = W.slot[g];
         s.cloud = clouds[g];
         slot_buffers(ctx, s, c.n);
         total += c.n;
@@ -1878,59 +1771,57 @@ void prepare_slots(plade_ctx *ctx, RansacWork &W, int base, const CloudDev *cons
         s.sub_index.ensure((size_t)s.sub_pitch + 4);
         G.c[g] = GatherOut{c.aos.p, s.sorted.soa.p, (uint32_t)c.pitch, s.codes.p, s.orig.p, s.assigned.p, s.sub.p, s.sub_pitch, s.n_sub,
                            stride, s.sub_index.p, c.n};
-        slot_entry(W, base + g);
     }
     PLADE_REQUIRE(total < (1ull << 31), PLADE_ELIMIT, "ransac: too many points");
     if (total == 0) return;
     if (n_clouds == 1) { M.c[1] = M.c[0]; G.c[1] = G.c[0]; }
-    RansacSlot &s0 = W.slot[base];
-    s0.keys_in.ensure(total); s0.vals_in.ensure(total); s0.keys.ensure(total); s0.perm.ensure(total);
-    hipLaunchKernelGGL(k_morton, dim3(cdiv(total, 256)), dim3(256), 0, ctx->stream, M, s0.keys_in.p, s0.vals_in.p);
-    sort_pairs_u32(ctx, s0.keys_in.p, s0.keys.p, s0.vals_in.p, s0.perm.p, total, n_clouds > 1 ? 25 : 24);
-    hipLaunchKernelGGL(k_gather_cloud, dim3(cdiv(total, 256)), dim3(256), 0, ctx->stream, G, s0.keys.p, s0.perm.p);
+    W.keys_in.ensure(total); W.vals_in.ensure(total); W.keys.ensure(total); W.perm.ensure(total);
+    hipLaunchKernelGGL(k_morton, dim3(cdiv(total, 256)), dim3(256), 0, ctx->stream, M, W.keys_in.p, W.vals_in.p);
+    sort_pairs_u32(ctx, W.keys_in.p, W.keys.p, W.vals_in.p, W.perm.p, total, n_clouds > 1 ? 25 : 24);
+    hipLaunchKernelGGL(k_gather_cloud, dim3(cdiv(total, 256)), dim3(256), 0, ctx->stream, G, W.keys.p, W.perm.p);
     HIP_TRY(hipGetLastError());
 }
 
-}  // namespace
-
-// ------------------------------------------------------------------------------------------------
-// per-context path: the calling thread drives its own work area (slots 0 and 1) on its own stream
-void ransac_prepare(plade_ctx *ctx, RansacWork &W, const CloudDev *const clouds[RANSAC_SLOTS], int n_clouds) {
-    work_ready(ctx, W);
-    prepare_slots(ctx, W, 0, clouds, n_clouds);
-    const int slots[2] = {0, 1};
-    upload_entries(ctx, W, slots, n_clouds);
-}
-
 void ransac_detect_prepared(plade_ctx *ctx, RansacWork &W, RansacJob jobs[RANSAC_SLOTS]) {
+    const int ng = W.ng;
+    PLADE_REQUIRE(ng >= 1, PLADE_EINVAL, "ransac: not prepared");
     Clock::time_point t0 = Clock::now();
+    RArgs A = make_args(W, ng);
     RInit I;
     memset(&I, 0, sizeof(I));
     RResult *res[R_G];
-    uint32_t gens[R_G];
-    bool active[R_NS] = {false};
     int nres = 0;
-    for (int g = 0; g < R_G; ++g) {
+    const uint32_t gen = (++W.generation) & 0x7fu;
+    for (int g = 0; g < ng; ++g) {
         RansacJob &J = jobs[g];
         RansacSlot &s = W.slot[g];
-        if (!J.active) continue;
-        if (!s.cloud || s.n < 3) {   // plane_extraction.cpp:181-184: fewer than three points, no planes
-            if (J.out) {
+        if (!J.active || s.n < 3) {
+            if (J.active && J.out) {   // plane_extraction.cpp:181-184: fewer than three points, no planes
                 J.out->coef.clear(); J.out->offsets.assign(1, 0); J.out->idx.clear(); J.out->d_idx = nullptr; J.out->remaining = s.n;
                 J.out->n_score_passes = 0; J.out->score_bytes = 0;
             }
             J.active = false;
             continue;
         }
-        s.gen = (++W.generation) & 0x7fu;
-        I.c[g] = init_of(s, J.rp, s.gen);
-        active[g] = true;
-        res[nres] = s.res; gens[nres] = s.gen; ++nres;
+        const CloudDev &c = *s.cloud;
+        // scale exactly as plane_extraction.cpp:71-80 + PointCloud.h:94-98 (Z bug: maxZ stays -FLT_MAX, so the Z extent
+        // never wins the max)
+        const float scale = std::max(c.bbmax[0] - c.bbmin[0], c.bbmax[1] - c.bbmin[1]);
+        const float eps = J.rp.dist_rel * scale, bitmap_eps = J.rp.bitmap_rel * scale;
+        PLADE_REQUIRE(eps > 0.f && bitmap_eps > 0.f, PLADE_EINVAL, "plane extraction: degenerate bounding box");
+        RInitCloud &P = I.c[g];
+        P.active = 1; P.min_support = J.rp.min_support; P.orient = J.rp.orient_normals ? 1u : 0u;
+        P.eps = eps; P.eps3 = 3 * eps;   // RansacShapeDetector.cpp:471-473
+        P.bitmap_eps = bitmap_eps; P.cos_t = J.rp.cos_thresh; P.overlook_p = J.rp.overlook_p;
+        for (int k = 0; k < 3; ++k) { P.bbmin[k] = c.bbmin[k]; P.bbmax[k] = c.bbmax[k]; }
+        P.seed = J.rp.seed;
+        P.gen = gen;
+        res[nres++] = s.res;
     }
     if (nres == 0) return;
-    IterShape sh;
-    const RArgs A = make_args(W, active, R_G, sh);
-    hipLaunchKernelGGL(k_r_init, dim3(sh.tiles), dim3(TPB), 0, ctx->stream, A, I);
+    uint32_t tiles = 0;
+    for (int g = 0; g < ng; ++g) tiles += A.c[g].L.nb;
+    hipLaunchKernelGGL(k_r_init, dim3(tiles), dim3(TPB), 0, ctx->stream, A, I);
     HIP_TRY(hipGetLastError());
     uint32_t iterations = 0;
     if (ctx->profiling()) {
@@ -1942,14 +1833,14 @@ void ransac_detect_prepared(plade_ctx *ctx, RansacWork &W, RansacJob jobs[RANSAC
         std::vector<char> hdr(R_G * hdr_bytes);
         for (;; ++iterations) {
             const size_t ev0 = ctx->evs.size();
-            launch_iteration(ctx, W, A, sh, false);
-            for (int g = 0; g < R_G; ++g)
-                if (active[g]) ctx->d2h(hdr.data() + g * hdr_bytes, W.states.p + g, hdr_bytes);
+            launch_iteration(ctx, W, A);
+            for (int g = 0; g < ng; ++g)
+                if (jobs[g].active) ctx->d2h(hdr.data() + g * hdr_bytes, W.slot[g].state.p, hdr_bytes);
             ctx->sync();
             double rescore_bytes[2] = {0, 0}, mark_bytes = 0;
             uint32_t mark_launches = 0;
-            for (int g = 0; g < R_G; ++g) {
-                if (!active[g]) continue;
+            for (int g = 0; g < ng; ++g) {
+                if (!jobs[g].active) continue;
                 const RState &S = *reinterpret_cast<const RState *>(hdr.data() + g * hdr_bytes);
                 const double n = W.slot[g].n;
                 for (int ph = 0; ph < 2; ++ph) {
@@ -1967,20 +1858,20 @@ void ransac_detect_prepared(plade_ctx *ctx, RansacWork &W, RansacJob jobs[RANSAC
                 else if (r.tag == "score_mark") { r.bytes = mk < mark_launches ? mark_bytes / mark_launches : -1.0; ++mk; }
             }
             bool all = true;
-            for (int i = 0; i < nres; ++i) all = all && flag_done(res[i], gens[i]);
+            for (int i = 0; i < nres; ++i) all = all && flag_done(res[i], gen);
             if (all) break;
         }
     } else {
         // Sleeping host waits (several registrations in flight): the next iteration is queued before the current one has
         // reported, so the GPU never waits for the host; should the loop have ended, that iteration's kernels return at
-        // once (30 empty launches).  A spinning host reacts within microseconds and queues an iteration only when needed.
+        // once (29 empty launches).  A spinning host reacts within microseconds and queues an iteration only when needed.
         const bool speculate = ctx->params.host_wait != 0;
-        if (speculate) launch_iteration(ctx, W, A, sh, true);
+        if (speculate) launch_iteration(ctx, W, A);
         for (;; ++iterations) {
-            launch_iteration(ctx, W, A, sh, true);
-            wait_iterations(ctx, ctx->stream, res, gens, nres, iterations + 1);
+            launch_iteration(ctx, W, A);
+            wait_iterations(ctx, res, nres, iterations + 1, gen);
             bool all = true;
-            for (int i = 0; i < nres; ++i) all = all && flag_done(res[i], gens[i]);
+            for (int i = 0; i < nres; ++i) all = all && flag_done(res[i], gen);
             if (all) break;
             PLADE_REQUIRE(iterations < 100000, PLADE_EDEVICE, "plane extraction: the device loop does not end");
         }
@@ -1988,12 +1879,38 @@ void ransac_detect_prepared(plade_ctx *ctx, RansacWork &W, RansacJob jobs[RANSAC
     std::atomic_thread_fence(std::memory_order_acquire);
     ctx->stats.add("ransac_iterations", iterations + 1);
     ctx->stats.add("ransac_t_detect", secs_since(t0));
-    bool any_host = false;
-    for (int g = 0; g < R_G; ++g) {
-        if (!jobs[g].active) continue;
-        collect(ctx, W.slot[g], jobs[g].rp, *jobs[g].out);
-        any_host = any_host || jobs[g].rp.host_indices;
+    for (int g = 0; g < ng; ++g) {
+        RansacJob &J = jobs[g];
+        if (!J.active) continue;
+        RansacSlot &s = W.slot[g];
+        const RResult &R = *s.res;
+        PLADE_REQUIRE(R.err != 1, PLADE_ELIMIT, "plane extraction: connected-component bitmap too large");
+        PLADE_REQUIRE(R.err != 3, PLADE_ELIMIT, "plane extraction: too many shapes");
+        PlaneSetOut &out = *J.out;
+        out.coef.clear(); out.offsets.assign(1, 0); out.idx.clear();
+        for (uint32_t i = 0; i < R.n_acc; ++i) {
+            if (!R.support[i]) continue;
+            out.coef.insert(out.coef.end(), R.coef[i], R.coef[i] + 4);
+            out.offsets.push_back((int32_t)(R.offset[i] + R.support[i]));
+        }
+        out.d_idx = reinterpret_cast<const uint32_t *>(s.out_idx.p);
+        out.remaining = R.remaining;
+        out.n_score_passes = R.n_rescores + R.n_mark_launches;
+        out.score_bytes = 28.0 * s.n * (R.n_rescores + R.n_mark_launches) + 0.25 * s.n * R.n_mark_chains;
+        ctx->stats.add("ransac_rounds", R.n_rounds);
+        ctx->stats.add("ransac_accepts", R.n_accepts);
+        ctx->stats.add("ransac_batches", R.n_batches);
+        ctx->stats.add("ransac_rescore_launches", R.n_rescores);
+        ctx->stats.add("ransac_mark_launches", R.n_mark_launches);
+        for (int q = 0; q < 4; ++q) ctx->stats.add("ransac_final_slot" + std::to_string(q), R.n_final[q]);
+        for (int q = 1; q < 5; ++q) ctx->stats.add("ransac_loop_stops_at" + std::to_string(q), R.n_stop[q]);
+        if (J.rp.host_indices) {
+            out.idx.resize(R.out_off);
+            if (R.out_off) ctx->d2h(out.idx.data(), s.out_idx.p, 4 * (size_t)R.out_off);
+        }
     }
+    bool any_host = false;
+    for (int g = 0; g < ng; ++g) any_host = any_host || (jobs[g].active && jobs[g].rp.host_indices);
     if (any_host) ctx->sync();
 }
 
@@ -2014,26 +1931,21 @@ void plane_component(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const
     const uint32_t n = cloud.n;
     PLADE_REQUIRE(m <= n && bitmap_eps > 0.f, PLADE_EINVAL, "plane_component: bad argument");
     if (m == 0) return;
-    work_ready(ctx, W);
     RansacSlot &s = W.slot[0];
-    s.cloud = nullptr;   // the slot no longer holds a prepared cloud
+    W.ng = 0;   // the slot no longer holds a prepared cloud
     slot_buffers(ctx, s, n);
     s.seam_list.ensure((size_t)n + 4);
     hipStream_t st = ctx->stream;
     ctx->h2d(s.seam_list.p, idx, 4 * (size_t)m);
-    {   // table entry of the seam: the caller's cloud as it is, the caller's list
-        RCloudArgs C;
-        memset(&C, 0, sizeof(C));
-        C.cv.x = cloud.x(); C.cv.y = cloud.y(); C.cv.z = cloud.z(); C.cv.nx = cloud.nx(); C.cv.ny = cloud.ny(); C.cv.nz = cloud.nz(); C.cv.n = n;
-        C.st = W.states.p; C.res = nullptr; C.out_idx = s.out_idx.p; C.fixed = s.fixed.p; C.var = s.var.p; C.list_values = s.seam_list.p;
-        memcpy(&C.L, &s.L, sizeof(ChainLayout));
-        memcpy(&W.h_tab[0], &C, sizeof(C));
-        const int slot0 = 0;
-        upload_entries(ctx, W, &slot0, 1);
+    RArgs A;
+    memset(&A, 0, sizeof(A));
+    A.ng = 1;
+    for (int g = 0; g < R_G; ++g) {
+        RCloudArgs &C = A.c[g];
+        C.cv = CloudView{cloud.x(), cloud.y(), cloud.z(), cloud.nx(), cloud.ny(), cloud.nz(), n};
+        C.st = s.state.p; C.res = s.res_dev; C.out_idx = s.out_idx.p; C.fixed = s.fixed.p; C.var = s.var.p; C.list_values = s.seam_list.p; C.L = s.L;
     }
-    bool active[R_NS] = {true};
-    IterShape sh;
-    const RArgs A = make_args(W, active, 1, sh);
+    A.tiles0 = s.L.nb;
     // Plane(point, normal): dist = point . normal with Vec3f::dot's left-to-right sum (Plane.cpp:21-26)
     float dist = point[0] * normal[0];
     dist += point[1] * normal[1];
@@ -2047,7 +1959,6 @@ void plane_component(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const
     hipLaunchKernelGGL(k_r_select_cc, dim3(loop_grid(nb), R_B), dim3(TPB), 0, st, A, 0);
     hipLaunchKernelGGL(k_r_fit, dim3(R_B), dim3(256), 0, st, A, 0);
     hipLaunchKernelGGL(k_r_assign, dim3(loop_grid(nb), R_B), dim3(TPB), 0, st, A);
-    hipLaunchKernelGGL(k_r_reset_states, dim3(1), dim3(64), 0, st, W.states.p, 1);   // the seam's pseudo-call is over
     PlaneState hst[2];
     ctx->d2h(hst, s.fixed.p, 2 * sizeof(PlaneState));   // chain 0's header
     ctx->sync(st);
