@@ -156,29 +156,49 @@ __global__ __launch_bounds__(256) void k_cell_spans(const float4 *__restrict__ r
         }
 }
 
-// one lane per (node in cell order, neighbour row): nine lanes share a node, lanes of a wave share
-// cells, so their span walks read the same addresses (broadcast) and stay short
+// One lane per (node in cell order, neighbour row): nine lanes share a node, lanes of a wave share cells.  The first
+// EDGE_QUICK entries of a span are walked by the lane itself; what is left of the long spans -- the dense cells around
+// the true transformation hold thousands of candidates, and a lane walking 3 x 2000 entries alone set the kernel's
+// duration -- is shared out: the wavefront takes the unfinished (node, span) pairs one after the other, 64 consecutive
+// entries per step (coalesced 16 B reads).  The union-find always hangs the larger root under the smaller one, so the
+// components and their roots (smallest member) do not depend on the order the edges are found in.
+constexpr uint32_t EDGE_QUICK = 16;
+__device__ __forceinline__ void edge_test(const float4 *__restrict__ st, const float4 *__restrict__ se, float4 pa, float4 ea,
+                                          uint32_t j, float r2, float gate, uint32_t *__restrict__ parent) {
+    const float4 pb = st[j];
+    const uint32_t a = __float_as_uint(pa.w), b = __float_as_uint(pb.w);
+    if (b >= a) return;  // every undirected edge once
+    if (!(flann_d2(f3(pa.x, pa.y, pa.z), f3(pb.x, pb.y, pb.z)) < r2)) return;
+    const float4 eb = se[j];
+    const float t0 = ea.x - eb.x, t1 = ea.y - eb.y, t2 = ea.z - eb.z;
+    const float sq = (t0 * t0 + t1 * t1) + t2 * t2;  // Eigen::VectorXf(3).squaredNorm()
+    if (sq < gate) uf_union(parent, a, b);
+}
 __global__ __launch_bounds__(256) void k_cluster_edges(const float4 *__restrict__ st, const float4 *__restrict__ se,
                                                        const uint64_t *__restrict__ skeys, const uint2 *__restrict__ spans,
                                                        uint32_t m, float r2, float gate, uint32_t *__restrict__ parent) {
     const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t si = tid / 9u, r = tid - 9u * si;
-    if (si >= m) return;
-    const float4 pa = st[si];
-    const float4 ea = se[si];
-    const uint32_t a = __float_as_uint(pa.w);
-    const f3 ta(pa.x, pa.y, pa.z);
-    const uint32_t head = lower_bound_u64(skeys, m, skeys[si]);
-    const uint2 sp = spans[(size_t)head * 9 + r];
-    for (uint32_t j = sp.x; j < sp.y; ++j) {
-        const float4 pb = st[j];
-        const uint32_t b = __float_as_uint(pb.w);
-        if (b >= a) continue;  // every undirected edge once
-        if (!(flann_d2(ta, f3(pb.x, pb.y, pb.z)) < r2)) continue;
-        const float4 eb = se[j];
-        const float t0 = ea.x - eb.x, t1 = ea.y - eb.y, t2 = ea.z - eb.z;
-        const float sq = (t0 * t0 + t1 * t1) + t2 * t2;  // Eigen::VectorXf(3).squaredNorm()
-        if (sq < gate) uf_union(parent, a, b);
+    const bool live = si < m;
+    float4 pa = make_float4(0.f, 0.f, 0.f, 0.f), ea = pa;
+    uint32_t j = 0, end = 0;
+    if (live) {
+        pa = st[si];
+        ea = se[si];
+        const uint32_t head = lower_bound_u64(skeys, m, skeys[si]);
+        const uint2 sp = spans[(size_t)head * 9 + r];
+        j = sp.x; end = sp.y;
+    }
+    for (const uint32_t quick_end = min(end, j + EDGE_QUICK); j < quick_end; ++j) edge_test(st, se, pa, ea, j, r2, gate, parent);
+    unsigned long long pend = __ballot(j < end);
+    const uint32_t lane = threadIdx.x & 63u;
+    while (pend) {
+        const int src = __ffsll((long long)pend) - 1;
+        pend &= pend - 1;
+        const float4 pa_s = make_float4(__shfl(pa.x, src, 64), __shfl(pa.y, src, 64), __shfl(pa.z, src, 64), __shfl(pa.w, src, 64));
+        const float4 ea_s = make_float4(__shfl(ea.x, src, 64), __shfl(ea.y, src, 64), __shfl(ea.z, src, 64), __shfl(ea.w, src, 64));
+        const uint32_t j_s = __shfl(j, src, 64), end_s = __shfl(end, src, 64);
+        for (uint32_t jj = j_s + lane; jj < end_s; jj += 64) edge_test(st, se, pa_s, ea_s, jj, r2, gate, parent);
     }
 }
 

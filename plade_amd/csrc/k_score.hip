@@ -142,48 +142,6 @@ __global__ __launch_bounds__(TPB) void k_score_mark(const float *__restrict__ x,
     if (threadIdx.x == 0) block_counts[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
 }
 
-// the same for a batch of hypotheses: the tile is loaded once and tested against every job's plane
-constexpr int MARK_MAXJ = BATCH_MAXJ;
-__global__ __launch_bounds__(TPB) void k_score_mark_batch(const MarkJobs jobs) {
-    __shared__ uint32_t s_w[MARK_MAXJ][TPB / 64];
-    // the jobs' planes / skip flags / output pointers are fetched by nj lanes at once and parked in LDS: read
-    // one after the other inside the hypothesis loop they were a chain of dependent global loads (~1 us each)
-    __shared__ float4 s_pl[MARK_MAXJ];
-    __shared__ uint32_t s_skip[MARK_MAXJ];
-    __shared__ uint8_t *s_masks[MARK_MAXJ];
-    __shared__ uint32_t *s_bc[MARK_MAXJ];
-    const ScanGroup &G = jobs.g[(jobs.ng > 1 && blockIdx.x >= jobs.g[1].tile0) ? 1 : 0];   // uniform
-    const uint32_t nj = G.nj, tile = blockIdx.x - G.tile0;
-    if (threadIdx.x < nj) {
-        const MarkJob jb = jobs.j[G.job0 + threadIdx.x];
-        s_skip[threadIdx.x] = jb.skip ? *jb.skip : 0u;
-        s_pl[threadIdx.x] = jb.plane[0];
-        s_masks[threadIdx.x] = jb.masks;
-        s_bc[threadIdx.x] = jb.block_counts;
-    }
-    Tile t;
-    load_tile(t, G.x, G.y, G.z, G.nx, G.ny, G.nz, G.assigned, nullptr, G.n, tile * TILE + threadIdx.x * PPT);
-    __syncthreads();
-    const float eps = G.eps, cos_t = G.cos_t;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (uint32_t j = 0; j < nj; ++j) {
-        if (s_skip[j]) continue;   // uniform
-        const float4 pl = s_pl[j];
-        uint32_t m = 0, c = 0;
-#pragma unroll
-        for (int k = 0; k < PPT; ++k) {
-            bool in = t.valid[k] && compatible(pl, t.px[k], t.py[k], t.pz[k], t.qx[k], t.qy[k], t.qz[k], eps, cos_t);
-            m |= (in ? 1u : 0u) << k;
-            c += (uint32_t)__popcll(__ballot(in));
-        }
-        s_masks[j][tile * TPB + threadIdx.x] = (uint8_t)m;
-        if (lane == 0) s_w[j][wave] = c;
-    }
-    __syncthreads();
-    if (threadIdx.x < nj && !s_skip[threadIdx.x])
-        s_bc[threadIdx.x][tile] = s_w[threadIdx.x][0] + s_w[threadIdx.x][1] + s_w[threadIdx.x][2] + s_w[threadIdx.x][3];
-}
-
 // ordered compaction; every block derives its output offset from the preceding blocks' counts itself
 // (nb is ~1e3, the count array is L2 resident), which saves a dependent launch per compaction
 __global__ __launch_bounds__(TPB) void k_compact(const uint8_t *__restrict__ masks,
@@ -219,137 +177,6 @@ __global__ __launch_bounds__(TPB) void k_compact(const uint8_t *__restrict__ mas
             uint32_t i = first + k;
             out[off++] = values ? values[i] : i;
         }
-}
-
-// batched form of k_compact: job blockIdx.y
-__global__ __launch_bounds__(TPB) void k_compact_batch(const CompactJobs jobs) {
-    __shared__ uint32_t s_w[TPB / 64];
-    __shared__ uint32_t s_base[TPB / 64];
-    __shared__ float s_mm[4][8];
-    const CompactJob jb = jobs.j[blockIdx.y];
-    const uint32_t nb = jb.nb;
-    if (blockIdx.x >= nb) return;   // the grid covers the larger cloud of the batch
-    const float *__restrict__ px = jb.px, *__restrict__ py = jb.py, *__restrict__ pz = jb.pz;
-    // round 1 of loads, all independent: skip flag, this tile's count, its mask bytes, the plane frame (a chain of
-    // early exits, each behind its own global load, used to cost four round trips before the first gather)
-    const uint32_t skip = jb.skip ? *jb.skip : 0u;
-    const uint32_t mine = jb.block_counts[blockIdx.x];
-    const uint32_t m = jb.masks[blockIdx.x * TPB + threadIdx.x];
-    float fr[10];
-    if (jb.frame) {
-#pragma unroll
-        for (int q = 0; q < 10; ++q) fr[q] = jb.frame[q];
-    }
-    if (skip) return;
-    // most tiles of a plane's score list are empty: nothing to place (the last tile still reports the total)
-    if (mine == 0 && blockIdx.x != nb - 1) return;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t first = blockIdx.x * TILE + threadIdx.x * PPT;
-    // round 2: the preceding tiles' counts and what the kept entries point to
-    uint32_t pre = 0;
-    {   // four counts per load (the count arrays are 16-byte aligned)
-        const uint32_t full = blockIdx.x & ~3u;
-        const uint4 *c4 = reinterpret_cast<const uint4 *>(jb.block_counts);
-        for (uint32_t q = threadIdx.x; q < full / 4; q += TPB) { const uint4 v = c4[q]; pre += (v.x + v.y) + (v.z + v.w); }
-        if (threadIdx.x < blockIdx.x - full) pre += jb.block_counts[full + threadIdx.x];
-    }
-    uint32_t pv[PPT];
-    float cx[PPT], cy[PPT], cz[PPT];
-#pragma unroll
-    for (int k = 0; k < PPT; ++k) {
-        pv[k] = first + k;
-        if ((m & (1u << k)) && jb.values) pv[k] = jb.values[first + k];
-    }
-    if (jb.frame) {
-#pragma unroll
-        for (int k = 0; k < PPT; ++k)
-            if (m & (1u << k)) { cx[k] = px[pv[k]]; cy[k] = py[pv[k]]; cz[k] = pz[pv[k]]; }
-    }
-    for (int d = 32; d >= 1; d >>= 1) pre += __shfl_xor(pre, d, 64);
-    if (lane == 0) s_base[wave] = pre;
-    const uint32_t c = __popc(m);
-    uint32_t incl = c;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t o = __shfl_up(incl, d, 64);
-        if (lane >= d) incl += o;
-    }
-    if (lane == 63) s_w[wave] = incl;
-    __syncthreads();
-    const uint32_t base = s_base[0] + s_base[1] + s_base[2] + s_base[3];
-    uint32_t off = base + incl - c;
-    for (int w = 0; w < wave; ++w) off += s_w[w];
-    if (blockIdx.x == nb - 1 && threadIdx.x == TPB - 1) *jb.total = off + c;
-    if (!jb.frame) {
-#pragma unroll
-        for (int k = 0; k < PPT; ++k)
-            if (m & (1u << k)) jb.out[off++] = pv[k];
-        return;
-    }
-    const float ox = fr[0], oy = fr[1], oz = fr[2];
-    const float a00 = fr[4], a01 = fr[5], a02 = fr[6], a10 = fr[7], a11 = fr[8], a12 = fr[9];
-    float mn[2] = {INFINITY, INFINITY}, mx[2] = {-INFINITY, -INFINITY};
-#pragma unroll
-    for (int k = 0; k < PPT; ++k)
-        if (m & (1u << k)) {
-            const float pp[3] = {cx[k] - ox, cy[k] - oy, cz[k] - oz};
-            const float u = pp[0] * a00 + pp[1] * a01 + pp[2] * a02;
-            const float v = pp[0] * a10 + pp[1] * a11 + pp[2] * a12;
-            jb.out[off] = pv[k];
-            jb.uv[off] = make_float2(u, v);
-            ++off;
-            mn[0] = fminf(mn[0], u); mn[1] = fminf(mn[1], v);
-            mx[0] = fmaxf(mx[0], u); mx[1] = fmaxf(mx[1], v);
-        }
-    // per-tile bounding box, reduced later by the rasteriser (a shared min/max updated with atomics from
-    // hundreds of tiles serialised at the memory side and cost as much as the rest of this kernel)
-    for (int q = 0; q < 2; ++q)
-        for (int d = 32; d >= 1; d >>= 1) {
-            mn[q] = fminf(mn[q], __shfl_xor(mn[q], d, 64));
-            mx[q] = fmaxf(mx[q], __shfl_xor(mx[q], d, 64));
-        }
-    if (lane == 0) { s_mm[0][wave] = mn[0]; s_mm[1][wave] = mn[1]; s_mm[2][wave] = mx[0]; s_mm[3][wave] = mx[1]; }
-    __syncthreads();
-    if (threadIdx.x < 4) {
-        float v = s_mm[threadIdx.x][0];
-        for (int w = 1; w < TPB / 64; ++w) v = threadIdx.x < 2 ? fminf(v, s_mm[threadIdx.x][w]) : fmaxf(v, s_mm[threadIdx.x][w]);
-        jb.bbox_part[4 * (size_t)blockIdx.x + threadIdx.x] = v;
-    }
-}
-
-void score_mark_batch(plade_ctx *ctx, hipStream_t stream, const MarkJob *jobs_host, ScanGroup *groups, uint32_t ng) {
-    PLADE_REQUIRE(ng >= 1 && ng <= 2, PLADE_EINVAL, "score_mark_batch: one or two clouds");
-    MarkJobs jobs;
-    uint32_t tiles = 0, nj = 0;
-    double bytes = 0;
-    for (uint32_t g = 0; g < ng; ++g) {
-        groups[g].tile0 = tiles;
-        groups[g].job0 = nj;
-        tiles += cdiv(groups[g].n, TILE);
-        nj += groups[g].nj;
-        // algorithmic bytes: the cloud once (28 B/point) + one mask byte per 4 points per hypothesis
-        bytes += 28.0 * groups[g].n + 0.25 * groups[g].n * groups[g].nj;
-    }
-    PLADE_REQUIRE(nj <= (uint32_t)MARK_MAXJ, PLADE_EINVAL, "score_mark_batch: too many jobs");
-    if (tiles == 0 || nj == 0) return;
-    for (uint32_t j = 0; j < (uint32_t)BATCH_MAXJ; ++j) jobs.j[j] = jobs_host[j < nj ? j : 0];
-    jobs.g[0] = groups[0];
-    jobs.g[1] = groups[ng > 1 ? 1 : 0];
-    jobs.ng = ng;
-    ctx->ev_begin("score_mark", bytes);
-    hipLaunchKernelGGL(k_score_mark_batch, dim3(tiles), dim3(TPB), 0, stream, jobs);
-    ctx->ev_end();
-}
-
-void compact_batch(plade_ctx *ctx, hipStream_t stream, const CompactJob *jobs_host, uint32_t nj) {
-    PLADE_REQUIRE(nj <= (uint32_t)BATCH_MAXJ, PLADE_EINVAL, "compact_batch: too many jobs");
-    uint32_t nb = 0;
-    for (uint32_t j = 0; j < nj; ++j) nb = std::max(nb, jobs_host[j].nb);
-    if (nb == 0 || nj == 0) return;
-    CompactJobs jobs;
-    for (uint32_t j = 0; j < (uint32_t)BATCH_MAXJ; ++j) jobs.j[j] = jobs_host[j < nj ? j : 0];
-    hipLaunchKernelGGL(k_compact_batch, dim3(nb, nj), dim3(TPB), 0, stream, jobs);
-    (void)ctx;
 }
 
 void score_multi(plade_ctx *ctx, const float *x, const float *y, const float *z, const float *nx, const float *ny,
