@@ -39,7 +39,7 @@ KERNEL_SYMBOLS = {"score_mark": "k_r_mark(", "score_multi": "k_r_rescore(", "ove
 
 
 def pmc_traffic(tag):
-    """HBM bytes per launch of the roofline kernel from the committed PMC summary (separate
+    """HBM bytes per REGISTRATION of the roofline kernel (all its launches) from the committed PMC summary (separate
     `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this same command, FETCH_SIZE doubled as
     MI355X_MICROARCH.md prescribes for gfx950; tools/summarize_profiles.py).  None if no summary exists."""
     import csv
@@ -49,11 +49,14 @@ def pmc_traffic(tag):
         return None, None
     sym = KERNEL_SYMBOLS.get(tag, tag + "(")
     with open(files[-1]) as f:
-        for r in csv.DictReader(f):
-            if sym in r["kernel"]:
-                rd = float(r["hbm_read_bytes(FETCH_SIZE*1024*2)"])
-                wr = float(r["hbm_write_bytes(WRITE_SIZE*1024)"])
-                return rd + wr, os.path.relpath(files[-1], ROOT)
+        rows = list(csv.DictReader(f))
+    regs = next((int(r["launches"]) for r in rows if "k_morton(" in r["kernel"]), 0)   # one launch per registration
+    for r in rows:
+        if sym in r["kernel"]:
+            rd = float(r["hbm_read_bytes(FETCH_SIZE*1024*2)"])
+            wr = float(r["hbm_write_bytes(WRITE_SIZE*1024)"])
+            # counter average over all launches of the kernel x launches per registration = bytes per registration
+            return (rd + wr) * int(r["launches"]) / max(regs, 1), os.path.relpath(files[-1], ROOT)
     return None, None
 
 
@@ -69,12 +72,23 @@ def rocprof_stats(tag):
     sym = KERNEL_SYMBOLS.get(tag, tag + "(")
     rows = list(csv.DictReader(open(files[-1])))
     total = sum(float(r["TotalDurationNs"]) for r in rows) or 1.0
-    top = sorted(rows, key=lambda r: -float(r["TotalDurationNs"]))[:3]
+    def short(name):
+        for junk in ("void ", "plade::", "(anonymous namespace)::"):
+            name = name.replace(junk, "")
+        return name.split("(")[0][:48]
+    top = sorted(rows, key=lambda r: -float(r["TotalDurationNs"]))[:5]
     out = {"file": os.path.relpath(files[-1], ROOT),
-           "top3_by_gpu_time": [{"kernel": r["Name"].split("(")[0][-40:], "share": float(r["TotalDurationNs"]) / total} for r in top]}
+           "top_by_gpu_time": [{"kernel": short(r["Name"]), "share": round(float(r["TotalDurationNs"]) / total, 4),
+                                "avg_us": round(float(r["AverageNs"]) / 1e3, 2)} for r in top]}
+    regs = next((int(r["Calls"]) for r in rows if "k_morton(" in r["Name"]), 0)   # one launch per registration
+    out["registrations_profiled"] = regs
+    out["kernels_per_registration"] = round(sum(int(r["Calls"]) for r in rows if "rocclr" not in r["Name"]) / max(regs, 1), 1)
+    out["copies_and_fills_per_registration"] = round(sum(int(r["Calls"]) for r in rows if "rocclr" in r["Name"]) / max(regs, 1), 1)
+    out["gpu_ms_per_registration"] = round(total / 1e6 / max(regs, 1), 3)
     for r in rows:
         if sym in r["Name"]:
             out.update({"avg_launch_us": float(r["AverageNs"]) / 1e3, "calls": int(r["Calls"]),
+                        "launches_per_registration": int(r["Calls"]) / max(regs, 1),
                         "share_of_gpu_time": float(r["TotalDurationNs"]) / total})
             break
     return out
@@ -381,32 +395,60 @@ def main():
             if k.startswith("bytes_"):
                 st[k] /= args.profiled_steps
         ctx.set_params(dump=0, host_wait=host_wait)
-        kernels = sorted({k[2:-8] for k in st if k.startswith("k_") and k.endswith("_seconds")})
+        kernels = sorted({k[2:-8] for k in st if k.startswith("k_") and k.endswith("_seconds") and not k.endswith("_clock_seconds")})
         best = None
         for name in kernels:
             secs, nl, by = st[f"k_{name}_seconds"], st[f"k_{name}_launches"], st[f"k_{name}_bytes"]
             stage[name] = {"seconds": secs / args.profiled_steps, "launches": nl / args.profiled_steps,
                            "GB/s": (by / secs / 1e9) if secs > 0 else None}
+            if st.get(f"k_{name}_clock_seconds"):   # the kernel's own clock (see roofline.measured)
+                cs, cb = st[f"k_{name}_clock_seconds"], st[f"k_{name}_clock_bytes"]
+                stage[name].update({"clock_seconds": cs / args.profiled_steps, "clock_GB/s": cb / cs / 1e9})
             # the roofline kernel is the one with the most GPU time among the HBM-streaming kernels (those
             # with an algorithmic byte count); latency-bound kernels are listed for reference
             if by > 0 and (best is None or secs > st[f"k_{best}_seconds"]):
                 best = name
         if best is not None:
             secs, nl, by = st[f"k_{best}_seconds"], st[f"k_{best}_launches"], st[f"k_{best}_bytes"]
-            achieved = by / secs / 1e9
-            traffic, traffic_src = pmc_traffic(best)
+            # launch duration: the kernel's own wall-clock stamps (first wavefront in .. last wavefront out, the quantity
+            # rocprofv3's kernel trace reports); the HIP events around the launch are listed next to it -- with other
+            # registrations in flight they also contain the other streams' kernels that ran on the same hardware queue
+            c_secs, c_nl, c_by = st.get(f"k_{best}_clock_seconds"), st.get(f"k_{best}_clock_launches"), st.get(f"k_{best}_clock_bytes")
+            if c_secs and c_nl:
+                achieved, avg_us, how = c_by / c_secs / 1e9, c_secs / c_nl * 1e6, "device wall clock inside the kernel (min start / max end over its wavefronts)"
+            else:
+                achieved, avg_us, how = by / secs / 1e9, secs / nl * 1e6, "HIP events on the launch stream"
+            # rocprofv3 (and the counter passes) average over ALL launches of the kernel, including those of the fixed launch
+            # sequence that find nothing to do and return at once (they move no bytes); the summaries are therefore compared
+            # per registration: counter bytes of all launches of a registration / its working launches = per working launch
+            traffic_reg, traffic_src = pmc_traffic(best)
+            idle = st.get(f"k_{best}_idle_launches", 0.0)
+            work_per_step = nl / args.profiled_steps
+            traffic = traffic_reg / work_per_step if traffic_reg is not None else None
             roofline = {"bound": "hbm", "kernel": best, "kernel_symbol": KERNEL_SYMBOLS.get(best, best).rstrip("("),
                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                        "launches_per_step": nl / args.profiled_steps, "avg_launch_us": secs / nl * 1e6,
+                        "launches_per_step": nl / args.profiled_steps, "avg_launch_us": avg_us,
+                        "avg_launch_us_hip_events": secs / nl * 1e6,
+                        "frac_at_hip_event_average": by / secs / 1e9 / HBM_PEAK_GBS,
                         "algorithmic_bytes_per_launch": by / nl,
-                        "measured": f"HIP events on the launch stream, {args.profiled_steps} profiled registrations with "
-                                    f"{M - 1} other registrations in flight (the load of the timed region)"}
+                        "idle_launches_per_step": idle / args.profiled_steps,
+                        "algorithmic_bytes_per_step": by / args.profiled_steps,
+                        "traffic_per_step": traffic_reg,
+                        "measured": f"{how}; {args.profiled_steps} profiled registrations with "
+                                    f"{M - 1} other registrations in flight (the load of the timed region)",
+                        "why_this_kernel": "largest mover of HBM bytes of the step (the K1 scoring scan, SURVEY.md 8d: 28 B per point and "
+                                           "launch); kernels above it in GPU time (rocprof.top_by_gpu_time) are LDS / latency bound "
+                                           "and have no HBM figure"}
             rp = rocprof_stats(best)
             if rp is not None:
                 roofline["rocprof"] = rp
                 if rp.get("avg_launch_us"):
-                    roofline["rocprof"]["frac_at_rocprof_average"] = (by / nl) / (rp["avg_launch_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS
+                    # same population as the summary: the step's bytes over ALL launches of a registration there (working +
+                    # idle), at the summary's average duration
+                    per_launch = (by / args.profiled_steps) / max(rp.get("launches_per_registration", work_per_step), 1e-9)
+                    roofline["rocprof"]["algorithmic_bytes_per_launch_all"] = per_launch
+                    roofline["rocprof"]["frac_at_rocprof_average"] = per_launch / (rp["avg_launch_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS
         stage_times = {k: v for k, v in st.items() if k.startswith("t_")}
         b_total = st.get("bytes_ransac", 0.0) + st.get("bytes_voxel", 0.0) + st.get("bytes_verify", 0.0)
         if roofline is not None:

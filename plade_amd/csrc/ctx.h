@@ -73,8 +73,29 @@ struct plade_ctx {
     std::map<std::string, std::vector<char>> dump;
     plade::Stats stats;
     // optional per-kernel timing with HIP events on this ctx's stream (params.dump & 2)
-    struct EvRec { hipEvent_t a, b; std::string tag; double bytes; };
+    struct EvRec { hipEvent_t a, b; std::string tag; double bytes; int clk = -1; };
     std::vector<EvRec> evs;
+    // Under load the two events of a record also see whatever other streams run on the same hardware queue in between;
+    // the kernels that matter for the roofline therefore also take the device's wall clock themselves (first wavefront
+    // in, last wavefront out: what rocprofv3's kernel trace reports): one (min start, max end) pair per launch.
+    static constexpr int CLK_SLOTS = 1024, CLK_WAYS = 64;   // launches per collect window, (start, end) pairs per launch
+    plade::DBuf<unsigned long long> clk_dev;
+    int clk_used = 0;
+    double clk_hz = 0;
+    unsigned long long *ev_clock() {   // the clock pair of the record opened last (nullptr outside profiled runs)
+        if (!profiling() || evs.empty() || clk_used >= CLK_SLOTS) return nullptr;
+        if (!clk_dev.p) {
+            clk_dev.ensure(2 * (size_t)CLK_SLOTS * CLK_WAYS);
+            std::vector<unsigned long long> init(2 * (size_t)CLK_SLOTS * CLK_WAYS);
+            for (size_t i = 0; i < init.size() / 2; ++i) { init[2 * i] = ~0ull; init[2 * i + 1] = 0ull; }
+            (void)hipMemcpy(clk_dev.p, init.data(), init.size() * 8, hipMemcpyHostToDevice);
+            int khz = 0;
+            (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device);
+            clk_hz = khz > 0 ? khz * 1e3 : 1e8;
+        }
+        evs.back().clk = clk_used;
+        return clk_dev.p + 2 * (size_t)CLK_WAYS * (clk_used++);
+    }
     bool profiling() const { return (params.dump & 2) != 0; }
     void ev_begin(const char *tag, double bytes) {
         if (!profiling()) return;
@@ -91,6 +112,22 @@ struct plade_ctx {
     void ev_collect() {
         if (evs.empty()) return;
         (void)hipStreamSynchronize(stream);
+        std::vector<unsigned long long> clk(2 * (size_t)clk_used);   // per launch: min start, max end
+        if (clk_used) {
+            std::vector<unsigned long long> raw(2 * (size_t)clk_used * CLK_WAYS);
+            (void)hipMemcpy(raw.data(), clk_dev.p, raw.size() * 8, hipMemcpyDeviceToHost);
+            for (int i = 0; i < clk_used; ++i) {
+                unsigned long long lo = ~0ull, hi = 0ull;
+                for (int w = 0; w < CLK_WAYS; ++w) {
+                    lo = std::min(lo, raw[2 * ((size_t)i * CLK_WAYS + w)]);
+                    hi = std::max(hi, raw[2 * ((size_t)i * CLK_WAYS + w) + 1]);
+                }
+                clk[2 * i] = lo; clk[2 * i + 1] = hi;
+            }
+            for (size_t i = 0; i < raw.size() / 2; ++i) { raw[2 * i] = ~0ull; raw[2 * i + 1] = 0ull; }
+            (void)hipMemcpy(clk_dev.p, raw.data(), raw.size() * 8, hipMemcpyHostToDevice);
+            clk_used = 0;
+        }
         for (auto &r : evs) {
             float ms = 0.f;
             (void)hipEventElapsedTime(&ms, r.a, r.b);
@@ -98,7 +135,12 @@ struct plade_ctx {
                 stats.add("k_" + r.tag + "_seconds", ms * 1e-3);
                 stats.add("k_" + r.tag + "_launches", 1.0);
                 stats.add("k_" + r.tag + "_bytes", r.bytes);
-            }
+                if (r.clk >= 0 && clk[2 * r.clk + 1] > clk[2 * r.clk]) {
+                    stats.add("k_" + r.tag + "_clock_seconds", (double)(clk[2 * r.clk + 1] - clk[2 * r.clk]) / clk_hz);
+                    stats.add("k_" + r.tag + "_clock_launches", 1.0);
+                    stats.add("k_" + r.tag + "_clock_bytes", r.bytes);
+                }
+            } else stats.add("k_" + r.tag + "_idle_launches", 1.0);   // queued, found nothing to do, returned at once
             (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
         }
         evs.clear();

@@ -157,6 +157,17 @@ struct RArgs {
     uint32_t ng, tiles0;             // clouds in this sequence; tiles of cloud 0 (scan grids are the concatenated tiles)
 };
 
+// profiled runs: the launch's own (first wavefront in, last wavefront out) times on the device's wall clock.  A launch owns
+// CLK_WAYS (start, end) pairs, workgroup b uses pair b % CLK_WAYS (thousands of atomics on ONE address would take longer
+// than the kernel); the host takes the minimum / maximum over the pairs.
+struct ClockScope {
+    unsigned long long *p;
+    __device__ explicit ClockScope(unsigned long long *q) : p(q ? q + 2 * (blockIdx.x % plade_ctx::CLK_WAYS) : nullptr) {
+        if (p && threadIdx.x == 0) atomicMin(p, (unsigned long long)wall_clock64());
+    }
+    __device__ ~ClockScope() { if (p && (threadIdx.x & 63) == 0) atomicMax(p + 1, (unsigned long long)wall_clock64()); }
+};
+
 struct ChainPtr {
     ChainHdr *hdr;
     uint8_t *masks1; uint32_t *bc1; float4 *bbpart; float2 *uv; uint32_t *bidx; double *part;
@@ -657,7 +668,8 @@ __global__ __launch_bounds__(1024) void k_r_leaders(const RArgs A) {
 
 // K1: the pool re-scored on ALL unassigned points of its cloud: one HBM pass per cloud, the pool's planes in LDS
 // phase 0: what the previous iteration left in the pool; phase 1: the leaders of a round drawn in this iteration
-__global__ __launch_bounds__(TPB) void k_r_rescore(const RArgs A, int phase) {
+__global__ __launch_bounds__(TPB) void k_r_rescore(const RArgs A, int phase, unsigned long long *clk) {
+    const ClockScope clock_scope(clk);
     __shared__ float4 s_pl[HCHUNK];
     __shared__ uint32_t s_cnt[TPB / 64][HCHUNK];
     uint32_t tile;
@@ -802,7 +814,8 @@ __global__ __launch_bounds__(64) void k_r_select(const RArgs A, int phase) {
 //
 // (1) mark: ONE pass over the cloud for all chains of the cloud: 4-bit inlier masks per lane, per-tile counts and
 //     the per-tile bounding boxes of the inliers' (u, v) plane parameters (BitmapPrimitiveShape.h:113-126)
-__global__ __launch_bounds__(TPB) void k_r_mark(const RArgs A, int k) {
+__global__ __launch_bounds__(TPB) void k_r_mark(const RArgs A, int k, unsigned long long *clk) {
+    const ClockScope clock_scope(clk);
     __shared__ float4 s_pl[R_B];
     __shared__ float s_fr[R_B][9];
     __shared__ uint32_t s_skip[R_B];
@@ -1664,7 +1677,7 @@ void enqueue_iteration(plade_ctx *ctx, const RArgs &A) {
     }
     // what the previous iteration left in the pool: re-score, prune, pick a batch ...
     ctx->ev_begin("score_multi", 0.0);
-    hipLaunchKernelGGL(k_r_rescore, dim3(tiles), dim3(TPB), 0, st, A, 0);
+    hipLaunchKernelGGL(k_r_rescore, dim3(tiles), dim3(TPB), 0, st, A, 0, ctx->ev_clock());
     ctx->ev_end();
     hipLaunchKernelGGL(k_r_select, dim3(ng), dim3(64), 0, st, A, 0);
     // ... and if nothing is left (or at the start), a new round: sample, score on the subset, leaders, re-score, batch
@@ -1672,12 +1685,12 @@ void enqueue_iteration(plade_ctx *ctx, const RArgs &A) {
     hipLaunchKernelGGL(k_r_score_sub, dim3(sub_tiles, R_H / HCHUNK, ng), dim3(TPB), 0, st, A);
     hipLaunchKernelGGL(k_r_leaders, dim3(ng), dim3(1024), 0, st, A);
     ctx->ev_begin("score_multi", 0.0);
-    hipLaunchKernelGGL(k_r_rescore, dim3(tiles), dim3(TPB), 0, st, A, 1);
+    hipLaunchKernelGGL(k_r_rescore, dim3(tiles), dim3(TPB), 0, st, A, 1, ctx->ev_clock());
     ctx->ev_end();
     hipLaunchKernelGGL(k_r_select, dim3(ng), dim3(64), 0, st, A, 1);
     for (int k = 0; k < 4; ++k) {
         ctx->ev_begin("score_mark", 0.0);
-        hipLaunchKernelGGL(k_r_mark, dim3(tiles), dim3(TPB), 0, st, A, k);
+        hipLaunchKernelGGL(k_r_mark, dim3(tiles), dim3(TPB), 0, st, A, k, ctx->ev_clock());
         ctx->ev_end();
         hipLaunchKernelGGL(k_r_compact_raster, dim3(loop_grid(nb_max), R_B * ng), dim3(TPB), 0, st, A, k);
         hipLaunchKernelGGL(k_r_label, dim3(R_B * ng), dim3(1024), 0, st, A, k, 1);
