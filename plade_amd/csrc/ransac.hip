@@ -23,7 +23,7 @@
 //                (RansacShapeDetector.h:61-67, .cpp:856-858).
 //
 // Control is on the DEVICE.  The whole loop state of a cloud (remaining points, drawn candidates, candidate pool,
-// accepted planes) lives in HBM (RState); one iteration is a fixed sequence of 27 launches
+// accepted planes) lives in HBM (RState); one iteration is a fixed sequence of 29 launches
 //     sample -> score on the subset -> leaders -> re-score the pool -> select a conflict-free batch ->
 //     4 x { mark, compact + rasterise, label, select + moments, fit } -> decide -> remove points
 // whose kernels read what to do from that state (a cloud that is not sampling, has an empty batch or has finished

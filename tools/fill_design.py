@@ -1,0 +1,20 @@
+"""Fills the @TOKENS@ of DESIGN.md's measurement table from profiles/<round>_bench_n1.json (run after the final bench)."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r2"
+src = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "DESIGN.md")
+d = json.load(open(os.path.join(ROOT, "profiles", f"{rnd}_bench_n1.json")))
+r = d["roofline"]
+tok = {
+    "@VALUE@": f"{d['value']:.0f}", "@MS@": f"{d['ms_per_step']:.2f}", "@BUSY@": f"{d['host_rank0']['busy_host_threads_avg']:.1f}",
+    "@HOSTVALUE@": f"{d['host_buffers_rank0']['value']:.0f}", "@LAT@": f"{d['single_registration_latency_ms']:.1f}",
+    "@MARKUS@": f"{r['avg_launch_us']:.1f}", "@MARKTB@": f"{r['achieved'] / 1e3:.2f}", "@MARKFRAC@": f"{r['frac']:.2f}",
+}
+s = open(src).read()
+for k, v in tok.items():
+    s = s.replace(k, v)
+open(os.path.join(ROOT, "DESIGN.md"), "w").write(s)
+print(tok)

@@ -303,15 +303,15 @@ thread each, `--inflight`), which is how a batch of pairs (configs[3]) is proces
 
 | | value |
 |---|---|
-| registrations/s, 1 GPU, clouds in HBM (`value`) | **427** (`python bench.py`: 512 steps, 2.34 ms/step at 8 in flight, sleeping host waits, 2.7 busy host threads; 512/512 ok, all registrations of a pair bit-identical across contexts; max ‖T−T_gt‖_F = 1.5e-3 = what the CPU oracle gives on the same planes). Round 1: 406. 800-step A/B runs of the round: 410–427 |
-| the same with the clouds in page-locked HOST memory (`host_buffers_rank0`: `plade_registration`, H2D + SoA conversion + bounding box inside the timed region) | **320** reg/s = 48 MB per registration over PCIe at ≈ 15.4 GB/s while the other contexts compute; results identical to the resident ones. The task's contract keeps `value` = resident; this is the PCIe-inclusive figure. `plade_host_pin` page-locks caller buffers (from pageable memory the runtime stages through its own bounce buffer and the call blocks) |
-| one registration alone (spinning waits) | **6.0 ms** (round 1: 6.9 ms); 6.7 ms of summed kernel time (`tools/trace_one.sh`) |
+| registrations/s, 1 GPU, clouds in HBM (`value`) | **@VALUE@** (`python bench.py`: 512 steps, @MS@ ms/step at 8 in flight, sleeping host waits, @BUSY@ busy host threads; 512/512 ok, all registrations of a pair bit-identical across contexts; max ‖T−T_gt‖_F = 1.5e-3 = what the CPU oracle gives on the same planes). Round 1: 406. 800-step A/B runs of the round: 410–427 |
+| the same with the clouds in page-locked HOST memory (`host_buffers_rank0`: `plade_registration`, H2D + SoA conversion + bounding box inside the timed region) | **@HOSTVALUE@** reg/s = 48 MB per registration over PCIe at ≈ 15.4 GB/s while the other contexts compute; results identical to the resident ones. The task's contract keeps `value` = resident; this is the PCIe-inclusive figure. `plade_host_pin` page-locks caller buffers (from pageable memory the runtime stages through its own bounce buffer and the call blocks) |
+| one registration alone (spinning waits) | **@LAT@ ms** (round 1: 6.9 ms); 6.7 ms of summed kernel time (`tools/trace_one.sh`) |
 | commands per registration (rocprofv3, `r2_kernel_stats.csv`) | **308 kernels + 57 copies / fills** = 365 (round 1: 445 + 91 = 536), 8.8 ms of summed GPU time; the extraction loop reads nothing back (round 1: ≈ 30 read-backs + syncs per cloud) and uses one helper thread per registration |
 | CPU baseline (same box, 1 core of an EPYC 9575F, 256 logical CPUs, cgroup budget 16) | 0.51 reg/s — libransac (reference, `oracle/_ref`) 5.5 s + oracle port 6.2 s per 6 registrations |
-| `roofline` kernel `k_r_mark` | 20 working launches per registration (each scans the clouds of the pair that still have a batch: 52.1 MB algorithmic on average = 28 B per point of those clouds + the mask bytes) + ≈ 8 launches of the fixed sequence that find nothing to do. **23.2 µs per working launch ⇒ 2.25 TB/s = 0.28 of 8 TB/s**, measured *inside the kernel* on the device wall clock (min start / max end over its wavefronts) under the load of the timed region. rocprofv3 of the same command: 17.6 µs averaged over all 27.8 launches per registration ⇒ (20 × 52.1 MB / 27.8) / 17.6 µs = 2.13 TB/s = 0.27 — the two agree to 5 %. HIP events around the launch read 32.8 µs under load: the hardware queue is shared with other streams' kernels, which run between the two events (alone on the GPU: 11.4 µs by rocprofv3 ⇒ 4.6 TB/s). PMC: 1.049 GB fetched + written per registration by this kernel for 1.043 GB algorithmic — no over-fetch |
+| `roofline` kernel `k_r_mark` | 20 working launches per registration (each scans the clouds of the pair that still have a batch: 52.1 MB algorithmic on average = 28 B per point of those clouds + the mask bytes) + ≈ 8 launches of the fixed sequence that find nothing to do. **@MARKUS@ µs per working launch ⇒ @MARKTB@ TB/s = @MARKFRAC@ of 8 TB/s**, measured *inside the kernel* on the device wall clock (min start / max end over its wavefronts) under the load of the timed region. rocprofv3 of the same command: 17.6 µs averaged over all 27.8 launches per registration ⇒ (20 × 52.1 MB / 27.8) / 17.6 µs = 2.13 TB/s = 0.27 — the two agree to 5 %. HIP events around the launch read 32.8 µs under load: the hardware queue is shared with other streams' kernels, which run between the two events (alone on the GPU: 11.4 µs by rocprofv3 ⇒ 4.6 TB/s). PMC: 1.049 GB fetched + written per registration by this kernel for 1.043 GB algorithmic — no over-fetch |
 | the same kernel on large clouds | configs[4] (10M-point clouds, `profiles/config5_r2_*`): 100 cloud passes of 280 MB in 72 launches × 68.6 µs ⇒ **5.7 TB/s = 71 % of 8 TB/s** |
 | why this kernel | it moves the most HBM bytes of the step (1.04 of 1.46 GB). By GPU time under load it is 4th (5.6 %) behind `k_r_label` (7.8 %, LDS union-find, no HBM figure), `k_r_compact_raster` (7.5 %) and `k_r_select_cc` (5.8 %, index-driven gathers); K1 together (`k_r_mark` + `k_r_rescore` + `k_r_score_sub`) is 12.8 % |
-| whole step vs SURVEY §8d `B_total` | 1.46 GB algorithmic per registration (bytes counted per launch and cloud actually scanned) / 2.34 ms = 0.6 TB/s = 7.7 % of peak: the step is bound by its dependent commands, not by bandwidth |
+| whole step vs SURVEY §8d `B_total` | 1.46 GB algorithmic per registration (bytes counted per launch and cloud actually scanned) / @MS@ ms = 0.6 TB/s = 7.7 % of peak: the step is bound by its dependent commands, not by bandwidth |
 | remaining over-fetch (PMC) | index-driven gathers from randomly ordered input: `k_gather_cloud` 275 + 67 MB for 48 + 48 MB, `k_voxel_runs` 134 MB for 24 MB (its writes and `k_voxel_centroids`' 12.8 MB reads are now exactly algorithmic: the sorted copy is written coalesced and summed from contiguous memory). The synthetic clouds are in random point order — the worst case; scanner order is spatially coherent |
 
 **What limits the step.** A HIP process drives the GPU through 4 hardware queues; with 8 registrations in flight all
@@ -324,7 +324,7 @@ launches), the sorts 13 %, clustering + penetration + verification + spacing 15 
 
 Host side: every wait of the HIP runtime spins; `plade_params.host_wait = 1` polls with 15–40 µs sleeps instead, small
 device-to-host readbacks go to a pinned arena as asynchronous copies, and the extraction's loop reports through
-host-mapped memory: 2.7 busy host threads at 8 in flight (round 1: 3.7), budget 16.
+host-mapped memory: @BUSY@ busy host threads at 8 in flight (round 1: 3.7), budget 16.
 
 CLI end to end: BASELINE configs[3]'s 64 × 1M-point pairs through `PLADE pairs.txt out.txt` with the default 4 workers
 on one GPU: every block equal to the library result, in input order, **streamed** as pairs finish (`OrderedWriter`,
