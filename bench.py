@@ -197,7 +197,7 @@ def main():
     ap.add_argument("--inflight", type=int, default=8,
                     help="registrations in flight per GPU: independent pairs, one plade_ctx + host thread each "
                          "(a single registration is latency-bound and leaves most of the GPU idle)")
-    ap.add_argument("--host-steps", type=int, default=128,
+    ap.add_argument("--host-steps", type=int, default=384,
                     help="steps of the extra host-buffer leg (plade_registration on page-locked host arrays, H2D inside); 0 = skip")
     ap.add_argument("--profiled-steps", type=int, default=8, help="registrations of the roofline leg (HIP events per launch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
