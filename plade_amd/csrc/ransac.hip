@@ -1878,7 +1878,7 @@ void ransac_detect_prepared(plade_ctx *ctx, RansacWork &W, RansacJob jobs[RANSAC
         // Sleeping host waits (several registrations in flight): the next iteration is queued before the current one has
         // reported, so the GPU never waits for the host; should the loop have ended, that iteration's kernels return at
         // once (29 empty launches).  A spinning host reacts within microseconds and queues an iteration only when needed.
-        const bool speculate = ctx->params.host_wait != 0;
+        const bool speculate = ctx->params.host_wait != 0 && !getenv("PLADE_NO_SPECULATION");
         if (speculate) launch_iteration(ctx, W, A);
         for (;; ++iterations) {
             launch_iteration(ctx, W, A);

@@ -303,7 +303,7 @@ thread each, `--inflight`), which is how a batch of pairs (configs[3]) is proces
 
 | | value |
 |---|---|
-| registrations/s, 1 GPU, clouds in HBM (`value`) | **@VALUE@** (`python bench.py`: 512 steps, @MS@ ms/step at 8 in flight, sleeping host waits, @BUSY@ busy host threads; 512/512 ok, all registrations of a pair bit-identical across contexts; max ‖T−T_gt‖_F = 1.5e-3 = what the CPU oracle gives on the same planes). Round 1: 406. 800-step A/B runs of the round: 410–427 |
+| registrations/s, 1 GPU, clouds in HBM (`value`) | **@VALUE@** (`python bench.py`: 512 steps, @MS@ ms/step at 8 in flight, sleeping host waits, @BUSY@ busy host threads; 512/512 ok, all registrations of a pair bit-identical across contexts; max ‖T−T_gt‖_F = 1.5e-3 = what the CPU oracle gives on the same planes). Round 1: 406. 800-step A/B runs of the round: 410–427; 30 000-step soak: 428.6 reg/s, 30 000/30 000 ok and bit-identical per pair, 2.6 busy host threads, no cgroup throttling (host-buffer leg of the same run, 2000 steps: 398.5 reg/s, identical results) |
 | the same with the clouds in page-locked HOST memory (`host_buffers_rank0`: `plade_registration`, H2D + SoA conversion + bounding box inside the timed region) | **@HOSTVALUE@** reg/s (384 steps, 8 in flight) = 48 MB per registration over PCIe while the other contexts compute (the 24 MB copies run on the SDMA engines at 43 GB/s, 0.56 ms each: `tools/trace_host.sh`, `tools/h2d_rate.py`); results identical to the resident ones. Each context stalls ≈ 1.3 ms per registration for its own upload, so more contexts hide more of it: 381 / 398 / 404 reg/s at 8 / 10 / 12 in flight (resident: 427 / 426 / 410). The task's contract keeps `value` = resident; this is the PCIe-inclusive figure. `plade_host_pin` page-locks caller buffers (from pageable memory the runtime stages through its own bounce buffer and the call blocks) |
 | one registration alone (spinning waits) | **@LAT@ ms** (round 1: 6.9 ms); 6.7 ms of summed kernel time (`tools/trace_one.sh`) |
 | commands per registration (rocprofv3, `r2_kernel_stats.csv`) | **308 kernels + 57 copies / fills** = 365 (round 1: 445 + 91 = 536), 8.8 ms of summed GPU time; the extraction loop reads nothing back (round 1: ≈ 30 read-backs + syncs per cloud) and uses one helper thread per registration |
@@ -316,8 +316,8 @@ thread each, `--inflight`), which is how a batch of pairs (configs[3]) is proces
 
 **What limits the step.** A HIP process drives the GPU through 4 hardware queues; with 8 registrations in flight all
 four are busy 99.9 % of the time with 3.7 kernels running on average (`tools/trace_load.sh`, `tools/concurrency.py`), so
-throughput ≈ 3.7 / Σ(kernel durations per registration): 9.5 ms under load ⇒ 2.5 ms per step. More queues, more
-processes or more registrations in flight do not help (§4 experiments). Doubling the points (2M per cloud) costs
+throughput ≈ 3.7 / Σ(kernel durations per registration): 9.5 ms under load ⇒ 2.5 ms per step. `GPU_MAX_HW_QUEUES` = 2 / 3 / 4 / 5 / 6 / 8 gives 294 / 362 / 420 / 343 / 323 / 355 reg/s: four concurrently running kernels is what the
+part sustains for this mix; more processes or more registrations in flight do not help either (§4 experiments). Doubling the points (2M per cloud) costs
 +1.0 ms per step: 43 % of the step scales with the bytes, 57 % is the fixed cost of its 365 commands — every one of
 which is also an L2 write-back + invalidate on this 8-XCD part. RANSAC is 48 % of the GPU time (7 iterations × 29
 launches), the sorts 13 %, clustering + penetration + verification + spacing 15 %.
@@ -326,9 +326,14 @@ Host side: every wait of the HIP runtime spins; `plade_params.host_wait = 1` pol
 device-to-host readbacks go to a pinned arena as asynchronous copies, and the extraction's loop reports through
 host-mapped memory: @BUSY@ busy host threads at 8 in flight (round 1: 3.7), budget 16.
 
-CLI end to end: BASELINE configs[3]'s 64 × 1M-point pairs through `PLADE pairs.txt out.txt` with the default 4 workers
-on one GPU: every block equal to the library result, in input order, **streamed** as pairs finish (`OrderedWriter`,
-flushed per block: a batch killed half-way leaves a valid prefix, `tests/test_gpu_configs.py`).
+CLI end to end (`tools/time_cli.py`, binary 1M-point PLY pairs = 24 MB per cloud in the page cache, one GPU): a single
+`PLADE target.ply source.ply result.txt` process takes 0.32–0.39 s, ≈ 0.3 s of it HIP start-up; BASELINE configs[3]'s 64
+pairs through `PLADE pairs.txt out.txt` finish in 0.87 s with the default 4 workers (74 pairs/s), 256 pairs in 1.55 s
+(165 pairs/s; 280 pairs/s marginal: a worker reads 48 MB of PLY per pair, ≈ 10 ms, before it registers). Every block
+equals the library result, blocks are in input order and **streamed** as pairs finish (`OrderedWriter`, flushed per
+block: a batch killed half-way leaves a valid prefix, `tests/test_gpu_configs.py`). Device allocations are not the
+start-up cost (207 `hipMalloc`s of a context's first registration take 3 ms; with 4 workers starting at once they
+contend: 270 ms summed over the threads, `tools/cli_alloc.sh`).
 
 `cpu_baseline.kind` is "port": plane extraction is the *reference's own* RANSAC library, the rest the oracle. It is
 single-threaded because the reference is (`ransac/CMakeLists.txt:222-235`).
