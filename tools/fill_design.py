@@ -11,6 +11,9 @@ r = d["roofline"]
 tok = {
     "@VALUE@": f"{d['value']:.0f}", "@MS@": f"{d['ms_per_step']:.2f}", "@BUSY@": f"{d['host_rank0']['busy_host_threads_avg']:.1f}",
     "@HOSTVALUE@": f"{d['host_buffers_rank0']['value']:.0f}", "@LAT@": f"{d['single_registration_latency_ms']:.1f}",
+    "@RPUS@": f"{r['rocprof']['avg_launch_us']:.1f}", "@RPLAUNCH@": f"{r['rocprof']['launches_per_registration']:.1f}",
+    "@RPFRAC@": f"{r['rocprof']['frac_at_rocprof_average']:.2f}", "@EVUS@": f"{r['avg_launch_us_hip_events']:.1f}",
+    "@TRAFFIC@": f"{r['traffic_per_step'] / 1e9:.3f}", "@ALGO@": f"{r['algorithmic_bytes_per_step'] / 1e9:.3f}",
     "@MARKUS@": f"{r['avg_launch_us']:.1f}", "@MARKTB@": f"{r['achieved'] / 1e3:.2f}", "@MARKFRAC@": f"{r['frac']:.2f}",
 }
 s = open(src).read()
