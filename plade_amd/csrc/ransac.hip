@@ -23,13 +23,17 @@
 //                (RansacShapeDetector.h:61-67, .cpp:856-858).
 //
 // Control is on the DEVICE.  The whole loop state of a cloud (remaining points, drawn candidates, candidate pool,
-// accepted planes) lives in HBM (RState); one iteration is a fixed sequence of 29 launches
+// accepted planes) lives in HBM (RState); one iteration is a fixed sequence of 27 launches
 //     sample -> score on the subset -> leaders -> re-score the pool -> select a conflict-free batch ->
 //     4 x { mark, compact + rasterise, label, select + moments, fit } -> decide -> remove points
-// whose kernels read what to do from that state (a cloud that is not sampling, has an empty batch or has finished
-// makes its workgroups return at once).  The sequence is captured once as a hipGraph and replayed; the host never
-// reads anything back in between -- the `decide` kernel reports the iteration count and the final results through a
-// block of host-mapped memory that the host polls while the next (speculative) iteration is already queued.
+// whose kernels read what to do from that state (a cloud that has an empty batch or has finished makes its workgroups
+// return at once).  Like the reference's loop, which generates new candidates in every pass before it takes the best
+// one (RansacShapeDetector.cpp:548-617), every iteration draws a round of hypotheses; what the previous batch left of
+// the pool competes with them (RState::topup; PLADE_RANSAC_TOPUP=0 brings back round 2's first scheme -- draw only
+// when the pool is empty, two more launches per iteration -- which needed 7 iterations instead of 5 for a 1M-point pair).
+// The sequence is captured once as a hipGraph and replayed; the host never reads anything back in between -- the
+// `decide` kernel reports the iteration count and the final results through a block of host-mapped memory that the
+// host polls while the next (speculative) iteration is already queued.
 // Every kernel serves the clouds of up to two "slots": the two scans of a registration are extracted in lock step by
 // one launch sequence (blockIdx selects the cloud), which halves the number of commands per registration.
 #include "ransac.h"
@@ -94,6 +98,7 @@ struct RResult;
 struct RState {
     // ---- parameters of the running detect call
     uint32_t n, min_support, orient, active, gen;   // gen: tag of the call in the result flag
+    uint32_t topup;                  // every iteration draws a round; what is left of the pool competes with the new hypotheses
     float eps, eps3, bitmap_eps, cos_t, overlook_p, bbmin[3], bbmax[3];
     uint64_t seed;
     // ---- loop state
@@ -155,6 +160,7 @@ struct RCloudArgs {
 struct RArgs {
     RCloudArgs c[R_G];
     uint32_t ng, tiles0;             // clouds in this sequence; tiles of cloud 0 (scan grids are the concatenated tiles)
+    uint32_t topup, pad_;            // host side: the sequence has no separate pass over the old pool (see RState::topup)
 };
 
 // profiled runs: the launch's own (first wavefront in, last wavefront out) times on the device's wall clock.  A launch owns
@@ -412,7 +418,7 @@ __device__ void state_from_hyp(PlaneState *st, float4 hyp, float4 pos) {
 // ------------------------------------------------------------------------------------------------
 // init: shapeIndex = -1 for the clouds that take part, loop state from the call's parameters
 struct RInitCloud {
-    uint32_t active, min_support, orient, gen;
+    uint32_t active, min_support, orient, gen, topup;
     float eps, eps3, bitmap_eps, cos_t, overlook_p, bbmin[3], bbmax[3];
     uint64_t seed;
 };
@@ -433,7 +439,7 @@ __global__ __launch_bounds__(TPB) void k_r_init(const RArgs A, const RInit I) {
     }
     if (tile == 0 && threadIdx.x == 0) {
         RState *S = C.st;
-        S->n = C.cv.n; S->min_support = P.min_support; S->orient = P.orient; S->active = 1; S->gen = P.gen;
+        S->n = C.cv.n; S->min_support = P.min_support; S->orient = P.orient; S->active = 1; S->gen = P.gen; S->topup = P.topup;
         S->eps = P.eps; S->eps3 = P.eps3; S->bitmap_eps = P.bitmap_eps; S->cos_t = P.cos_t; S->overlook_p = P.overlook_p;
         for (int k = 0; k < 3; ++k) { S->bbmin[k] = P.bbmin[k]; S->bbmax[k] = P.bbmax[k]; }
         S->seed = P.seed;
@@ -465,6 +471,15 @@ __global__ __launch_bounds__(256) void k_r_sample(const RArgs A) {
     C.hyp_pos[t] = make_float4(0.f, 0.f, 0.f, 0.f);
     C.hyp_counts[t] = 0;            // the scoring pass that follows accumulates with atomics
     if (t == 0) S->sub_unassigned = 0;   // and so does the unassigned-point count of the subset
+    if (S->topup && t < S->npool) {
+        // what the last batch left of the pool takes the first hypothesis slots and competes with the new draws on the
+        // subset (w = 4: a candidate, but not a draw of this round); versions of planes that have been accepted since
+        // score next to nothing there and drop out
+        const float4 pp = S->pool_pos[t];
+        C.hyp[t] = S->pool_pl[t];
+        C.hyp_pos[t] = make_float4(pp.x, pp.y, pp.z, 4.f);
+        return;
+    }
     // draws are made eight at a time so that their shapeIndex look-ups are in flight together (late rounds
     // have few unassigned points left and most draws miss)
     uint32_t i0 = 0;
@@ -609,8 +624,8 @@ __global__ __launch_bounds__(1024) void k_r_leaders(const RArgs A) {
         const float4 pos = C.hyp_pos[i];
         const uint32_t c = C.hyp_counts[i];
         pl[q] = C.hyp[i];
-        valid += pos.w != 0.f;   // w: 0 no samples, 1 verified plane, 2 drawn but rejected
-        const bool ok = pos.w == 1.f && c * ratio >= 0.5 * ms;
+        valid += pos.w == 1.f || pos.w == 2.f;   // w: 0 no samples, 1 verified plane, 2 drawn but rejected, 4 kept from the pool
+        const bool ok = (pos.w == 1.f || pos.w == 4.f) && c * ratio >= 0.5 * ms;
         key[q] = ok ? ((min(c, 0xfffffu) << 12) | (0xfffu - i)) : 0u;   // count descending, index ascending; 0 = not a candidate
     }
     for (int d = 32; d >= 1; d >>= 1) valid += __shfl_xor(valid, d, 64);
@@ -1463,6 +1478,7 @@ __global__ __launch_bounds__(64) void k_r_decide(const RArgs A) {
         if (!S->done) {
             if (S->n_remaining < S->min_support) S->npool = 0;
             if (S->npool == 0) next_round_or_stop(S);
+            else if (S->topup) { if (S->round >= R_MAX_ROUNDS) S->done = 1; else S->sampling = 1; }
         }
     }
     S->it += 1;
@@ -1653,6 +1669,8 @@ RArgs make_args(RansacWork &W, int ng) {
         memcpy(&C.L, &s.L, sizeof(ChainLayout));
     }
     A.tiles0 = A.c[0].L.nb;
+    static const bool topup = [] { const char *e = getenv("PLADE_RANSAC_TOPUP"); return e ? atoi(e) != 0 : true; }();
+    A.topup = topup ? 1u : 0u;
     return A;
 }
 
@@ -1665,7 +1683,7 @@ uint64_t hash_bytes(const void *p, size_t n) {
 
 inline uint32_t loop_grid(uint32_t nb) { return std::min(1024u, std::max(32u, cdiv(nb, OWN_MAX))); }
 
-// one iteration of the detect loop: 29 launches
+// one iteration of the detect loop: 27 launches (29 without the top-up rule)
 void enqueue_iteration(plade_ctx *ctx, const RArgs &A) {
     hipStream_t st = ctx->stream;
     const uint32_t ng = A.ng;
@@ -1675,11 +1693,14 @@ void enqueue_iteration(plade_ctx *ctx, const RArgs &A) {
         nb_max = std::max(nb_max, A.c[g].L.nb);
         sub_tiles = std::max(sub_tiles, cdiv(A.c[g].n_sub, TILE));
     }
-    // what the previous iteration left in the pool: re-score, prune, pick a batch ...
-    ctx->ev_begin("score_multi", 0.0);
-    hipLaunchKernelGGL(k_r_rescore, dim3(tiles), dim3(TPB), 0, st, A, 0, ctx->ev_clock());
-    ctx->ev_end();
-    hipLaunchKernelGGL(k_r_select, dim3(ng), dim3(64), 0, st, A, 0);
+    // what the previous iteration left in the pool: re-score, prune, pick a batch ...  (with the top-up rule the old pool
+    // goes into the new round instead and these two launches are not part of the sequence)
+    if (!A.topup) {
+        ctx->ev_begin("score_multi", 0.0);
+        hipLaunchKernelGGL(k_r_rescore, dim3(tiles), dim3(TPB), 0, st, A, 0, ctx->ev_clock());
+        ctx->ev_end();
+        hipLaunchKernelGGL(k_r_select, dim3(ng), dim3(64), 0, st, A, 0);
+    }
     // ... and if nothing is left (or at the start), a new round: sample, score on the subset, leaders, re-score, batch
     hipLaunchKernelGGL(k_r_sample, dim3(cdiv(R_H, 256), ng), dim3(256), 0, st, A);
     hipLaunchKernelGGL(k_r_score_sub, dim3(sub_tiles, R_H / HCHUNK, ng), dim3(TPB), 0, st, A);
@@ -1829,6 +1850,7 @@ void ransac_detect_prepared(plade_ctx *ctx, RansacWork &W, RansacJob jobs[RANSAC
         for (int k = 0; k < 3; ++k) { P.bbmin[k] = c.bbmin[k]; P.bbmax[k] = c.bbmax[k]; }
         P.seed = J.rp.seed;
         P.gen = gen;
+        P.topup = A.topup;
         res[nres++] = s.res;
     }
     if (nres == 0) return;
@@ -1862,6 +1884,10 @@ void ransac_detect_prepared(plade_ctx *ctx, RansacWork &W, RansacJob jobs[RANSAC
                 }
                 mark_bytes += 28.0 * n * (S.n_mark_launches - seen_mark[g]) + 0.25 * n * (S.n_mark_chains - seen_chains[g]);
                 mark_launches = std::max(mark_launches, S.n_mark_launches - seen_mark[g]);
+                if (getenv("PLADE_TRACE_RANSAC"))
+                    fprintf(stderr, "[ransac] it %u cloud %d: round %u sampling %u pool %u accepted %u remaining %u batches %u accepts %u (chains this it: %u) done %u\n",
+                            iterations, g, S.round, S.sampling, S.npool, S.n_acc, S.n_remaining, S.n_batches, S.n_accepts,
+                            S.n_mark_chains - seen_chains[g] ? (S.n_mark_chains - seen_chains[g]) : 0u, S.done);
                 seen_mark[g] = S.n_mark_launches; seen_chains[g] = S.n_mark_chains;
             }
             uint32_t mk = 0, rs = 0;
@@ -1877,7 +1903,7 @@ void ransac_detect_prepared(plade_ctx *ctx, RansacWork &W, RansacJob jobs[RANSAC
     } else {
         // Sleeping host waits (several registrations in flight): the next iteration is queued before the current one has
         // reported, so the GPU never waits for the host; should the loop have ended, that iteration's kernels return at
-        // once (29 empty launches).  A spinning host reacts within microseconds and queues an iteration only when needed.
+        // once (27 empty launches).  A spinning host reacts within microseconds and queues an iteration only when needed.
         const bool speculate = ctx->params.host_wait != 0 && !getenv("PLADE_NO_SPECULATION");
         if (speculate) launch_iteration(ctx, W, A);
         for (;; ++iterations) {
