@@ -26,14 +26,18 @@ static void sort_pairs(plade_ctx *ctx, const K *ki, K *ko, const uint32_t *vi, u
 constexpr size_t RS_MIN_ITEMS = 16384;
 static bool use_rocprim() { static const bool v = getenv("PLADE_SORT_ROCPRIM") != nullptr; return v; }
 
+static bool trace_sorts() { static const bool v = getenv("PLADE_TRACE_SORT") != nullptr; return v; }
+
 void sort_pairs_u32(plade_ctx *ctx, const uint32_t *ki, uint32_t *ko, const uint32_t *vi, uint32_t *vo, size_t n,
                     int bits) {
+    if (trace_sorts()) fprintf(stderr, "[sort] u32 n %zu bits %d\n", n, bits);
     if (n > RS_MIN_ITEMS && !use_rocprim()) radix_sort_pairs_u32(ctx, ki, ko, vi, vo, n, bits);
     else sort_pairs<uint32_t>(ctx, ki, ko, vi, vo, n, bits);
 }
 
 void sort_pairs_u64(plade_ctx *ctx, const uint64_t *ki, uint64_t *ko, const uint32_t *vi, uint32_t *vo, size_t n,
                     int bits) {
+    if (trace_sorts()) fprintf(stderr, "[sort] u64 n %zu bits %d\n", n, bits);
     if (n > RS_MIN_ITEMS && !use_rocprim()) radix_sort_pairs_u64(ctx, ki, ko, vi, vo, n, bits);
     else sort_pairs<uint64_t>(ctx, ki, ko, vi, vo, n, bits);
 }

@@ -14,6 +14,11 @@ tok = {
     "@RPUS@": f"{r['rocprof']['avg_launch_us']:.1f}", "@RPLAUNCH@": f"{r['rocprof']['launches_per_registration']:.1f}",
     "@RPFRAC@": f"{r['rocprof']['frac_at_rocprof_average']:.2f}", "@EVUS@": f"{r['avg_launch_us_hip_events']:.1f}",
     "@TRAFFIC@": f"{r['traffic_per_step'] / 1e9:.3f}", "@ALGO@": f"{r['algorithmic_bytes_per_step'] / 1e9:.3f}",
+    "@KERNELS@": f"{r['rocprof']['kernels_per_registration']:.0f}", "@COPIES@": f"{r['rocprof']['copies_and_fills_per_registration']:.0f}",
+    "@GPUMS@": f"{r['rocprof']['gpu_ms_per_registration']:.1f}",
+    "@WORK@": f"{r['launches_per_step']:.0f}", "@ALGOL@": f"{r['algorithmic_bytes_per_launch'] / 1e6:.1f}",
+    "@IDLE@": f"{r['rocprof']['launches_per_registration'] - r['launches_per_step']:.0f}",
+    "@STEPB@": f"{r['step_algorithmic_bytes'] / 1e9:.2f}", "@STEPFRAC@": f"{100 * r['step_frac_of_hbm_peak']:.1f}",
     "@MARKUS@": f"{r['avg_launch_us']:.1f}", "@MARKTB@": f"{r['achieved'] / 1e3:.2f}", "@MARKFRAC@": f"{r['frac']:.2f}",
 }
 s = open(src).read()

@@ -252,21 +252,33 @@ min_support.
 
 **Device-driven loop.** Round 1 decided everything on the host behind ≈ 30 read-backs per cloud. Now the whole loop
 state of a cloud (`RState`: parameters, remaining points, drawn candidates, candidate pool, batch, accepted planes,
-statistics) lives in HBM and one *iteration* is a fixed sequence of 29 launches
+statistics) lives in HBM and one *iteration* is a fixed sequence of 27 launches
 
-    re-score pool → select batch → sample → score on the subset → leaders → re-score → select batch →
+    sample → score on the subset → leaders → re-score the pool → select batch →
     4 × { mark, compact + rasterise, label, select + moments, fit } → decide → remove points
 
-whose kernels read what to do from that state: a cloud that is not sampling, has an empty batch or has finished makes
-its workgroups return at once. The sequence is captured once per cloud-size pair as a hipGraph and replayed. The host
-reads nothing back in between: `k_r_decide` replays the reference's `newScore > oldScore && newSize > minSupport` logic
-over the four slots of every chain, does the removal bookkeeping, the stopping rule
-(`CandidateFailureProbability ≤ p`) and the `(1−|S|/n)³` update, and reports the iteration count — and, when the call
-ends, the planes — through a **host-mapped result block** (`hipHostMallocMapped | Coherent`) whose flag word carries
-(iterations, a 7-bit generation of the call, done). The host polls that word; with sleeping waits it queues the next
-iteration *before* the current one has reported (a stale speculative iteration finds `done` and returns; the
-generation tag keeps its report from being mistaken for the next call's), with spinning waits it queues an iteration
-only when needed. A 1M-point pair needs 7 iterations (3 sampling rounds and 5 batches per cloud, 37 planes).
+whose kernels read what to do from that state: a cloud that has an empty batch or has finished makes its workgroups
+return at once. The sequence is captured once per cloud-size pair as a hipGraph and replayed. The host reads nothing
+back in between: `k_r_decide` replays the reference's `newScore > oldScore && newSize > minSupport` logic over the four
+slots of every chain, does the removal bookkeeping and the `(1−|S|/n)³` update; `k_r_select` applies the stopping rule
+(`CandidateFailureProbability ≤ p`) when a round yields nothing above min_support. The iteration count — and, when the
+call ends, the planes — go to the host through a **host-mapped result block** (`hipHostMallocMapped | Coherent`) whose
+flag word carries (iterations, a 7-bit generation of the call, done). The host polls that word; with sleeping waits it
+queues the next iteration *before* the current one has reported (a stale speculative iteration finds `done` and
+returns; the generation tag keeps its report from being mistaken for the next call's), with spinning waits it queues an
+iteration only when needed.
+
+**A round per iteration ("top-up").** The first device-driven version drew a new round of hypotheses only when the pool
+was empty: after a round's first batch (8 planes) the rest of the pool gave one or two planes per iteration — the
+survivors are mostly faces that conflict with each other — and a 1M-point pair needed 7 iterations. The reference's
+loop generates new candidates in EVERY pass before it takes the best one (`RansacShapeDetector.cpp:548-617`); now every
+iteration draws a round, and what the previous batch left of the pool takes the first hypothesis slots and competes
+with the new draws on the subset (versions of planes accepted since score next to nothing there and drop out): 5
+iterations (3–4 with batches + the confirming round), 27 instead of 29 launches each, 427 → 455 reg/s and 6.0 → 4.8 ms
+for one registration alone. Registration results on 24 synthetic seeds: 24/24 correct in both schemes, same error
+range. Plane sets: touching faces may exchange a few contested points (which face is accepted first), e.g. one of the
+53 planes of the polyhedron fixture gets 777 instead of libransac's 771 points, the other 52 stay exact
+(`PLADE_RANSAC_TOPUP=0` = the first scheme, all 53 exact).
 
 **Batched acceptance.** The reference accepts one candidate at a time (score(3ε) → connected component → weighted
 score → ≤ 3 LS refits, `RansacShapeDetector.cpp:618-656`). Here the best candidate and every further pool candidate
@@ -296,7 +308,7 @@ Seam S1c (`plade_plane_component`) runs the same chain kernels on a caller-given
 ## 5. Measurement (`bench.py`)
 
 Step = full `registration(T, target, source)` of one synthetic 1M-point pair (BASELINE configs[2]; `orient_normals=1`,
-§2 deviation 3), clouds resident in HBM (`plade_registration_dev`). One registration alone is latency-bound (365
+§2 deviation 3), clouds resident in HBM (`plade_registration_dev`). One registration alone is latency-bound (≈ 290
 dependent commands), so `bench.py` keeps **8 independent registrations in flight per GPU** (one `plade_ctx` + host
 thread each, `--inflight`), which is how a batch of pairs (configs[3]) is processed. Round-2 numbers (MI355X,
 `profiles/r2_bench_n1.json`, `profiles/r2_kernel_stats.csv`, `profiles/r2_pmc_hbm.csv`):
@@ -306,21 +318,27 @@ thread each, `--inflight`), which is how a batch of pairs (configs[3]) is proces
 | registrations/s, 1 GPU, clouds in HBM (`value`) | **@VALUE@** (`python bench.py`: 512 steps, @MS@ ms/step at 8 in flight, sleeping host waits, @BUSY@ busy host threads; 512/512 ok, all registrations of a pair bit-identical across contexts; max ‖T−T_gt‖_F = 1.5e-3 = what the CPU oracle gives on the same planes). Round 1: 406. 800-step A/B runs of the round: 410–427; 30 000-step soak: 428.6 reg/s, 30 000/30 000 ok and bit-identical per pair, 2.6 busy host threads, no cgroup throttling (host-buffer leg of the same run, 2000 steps: 398.5 reg/s, identical results) |
 | the same with the clouds in page-locked HOST memory (`host_buffers_rank0`: `plade_registration`, H2D + SoA conversion + bounding box inside the timed region) | **@HOSTVALUE@** reg/s (384 steps, 8 in flight) = 48 MB per registration over PCIe while the other contexts compute (the 24 MB copies run on the SDMA engines at 43 GB/s, 0.56 ms each: `tools/trace_host.sh`, `tools/h2d_rate.py`); results identical to the resident ones. Each context stalls ≈ 1.3 ms per registration for its own upload, so more contexts hide more of it: 381 / 398 / 404 reg/s at 8 / 10 / 12 in flight (resident: 427 / 426 / 410). The task's contract keeps `value` = resident; this is the PCIe-inclusive figure. `plade_host_pin` page-locks caller buffers (from pageable memory the runtime stages through its own bounce buffer and the call blocks) |
 | one registration alone (spinning waits) | **@LAT@ ms** in the committed run (6.0–6.6 ms from run to run; round 1: 6.9 ms); 6.7 ms of summed kernel time (`tools/trace_one.sh`) |
-| commands per registration (rocprofv3, `r2_kernel_stats.csv`) | **308 kernels + 57 copies / fills** = 365 (round 1: 445 + 91 = 536), 8.8 ms of summed GPU time; the extraction loop reads nothing back (round 1: ≈ 30 read-backs + syncs per cloud) and uses one helper thread per registration |
+| commands per registration (rocprofv3, `r2_kernel_stats.csv`) | **@KERNELS@ kernels + @COPIES@ copies / fills** (round 1: 445 + 91 = 536; this round before the top-up rule: 308 + 57), @GPUMS@ ms of summed GPU time; the extraction loop reads nothing back (round 1: ≈ 30 read-backs + syncs per cloud) and uses one helper thread per registration |
 | CPU baseline (same box, 1 core of an EPYC 9575F, 256 logical CPUs, cgroup budget 16) | 0.51 reg/s — libransac (reference, `oracle/_ref`) 5.5 s + oracle port 6.2 s per 6 registrations |
-| `roofline` kernel `k_r_mark` | 20 working launches per registration (each scans the clouds of the pair that still have a batch: 52.1 MB algorithmic on average = 28 B per point of those clouds + the mask bytes) + ≈ 8 launches of the fixed sequence that find nothing to do. **@MARKUS@ µs per working launch ⇒ @MARKTB@ TB/s = @MARKFRAC@ of 8 TB/s**, measured *inside the kernel* on the device wall clock (min start / max end over its wavefronts) under the load of the timed region. rocprofv3 of the same command (`r2_kernel_stats.csv`): @RPUS@ µs averaged over all @RPLAUNCH@ launches per registration ⇒ (20 × 52.1 MB / @RPLAUNCH@) / @RPUS@ µs = @RPFRAC@ of 8 TB/s — the two agree within a few percent. HIP events around the launch read @EVUS@ µs under load: the hardware queue is shared with other streams' kernels, which run between the two events (alone on the GPU: 11.4 µs by rocprofv3 ⇒ 4.6 TB/s). PMC (`r2_pmc_hbm.csv`): @TRAFFIC@ GB fetched + written per registration by this kernel for @ALGO@ GB algorithmic — no over-fetch |
+| `roofline` kernel `k_r_mark` | @WORK@ working launches per registration (each scans the clouds of the pair that still have a batch: @ALGOL@ MB algorithmic on average = 28 B per point of those clouds + the mask bytes) + ≈ @IDLE@ launches of the fixed sequence that find nothing to do. **@MARKUS@ µs per working launch ⇒ @MARKTB@ TB/s = @MARKFRAC@ of 8 TB/s**, measured *inside the kernel* on the device wall clock (min start / max end over its wavefronts) under the load of the timed region. rocprofv3 of the same command (`r2_kernel_stats.csv`): @RPUS@ µs averaged over all @RPLAUNCH@ launches per registration ⇒ (@WORK@ × @ALGOL@ MB / @RPLAUNCH@) / @RPUS@ µs = @RPFRAC@ of 8 TB/s — the two agree within a few percent. HIP events around the launch read @EVUS@ µs under load: the hardware queue is shared with other streams' kernels, which run between the two events (alone on the GPU: 11.4 µs by rocprofv3 ⇒ 4.6 TB/s). PMC (`r2_pmc_hbm.csv`): @TRAFFIC@ GB fetched + written per registration by this kernel for @ALGO@ GB algorithmic — no over-fetch |
 | the same kernel on large clouds | configs[4] (10M-point clouds, `profiles/config5_r2_*`): 100 cloud passes of 280 MB in 72 launches × 68.6 µs ⇒ **5.7 TB/s = 71 % of 8 TB/s** |
-| why this kernel | it moves the most HBM bytes of the step (1.04 of 1.46 GB). By GPU time under load it is 4th (5.6 %) behind `k_r_label` (7.8 %, LDS union-find, no HBM figure), `k_r_compact_raster` (7.5 %) and `k_r_select_cc` (5.8 %, index-driven gathers); K1 together (`k_r_mark` + `k_r_rescore` + `k_r_score_sub`) is 12.8 % |
-| whole step vs SURVEY §8d `B_total` | 1.46 GB algorithmic per registration (bytes counted per launch and cloud actually scanned) / @MS@ ms = 0.6 TB/s = 7.7 % of peak: the step is bound by its dependent commands, not by bandwidth |
+| why this kernel | it moves the most HBM bytes of the step (@ALGO@ of @STEPB@ GB). By GPU time under load it is 4th (5.6 %) behind `k_r_label` (7.8 %, LDS union-find, no HBM figure), `k_r_compact_raster` (7.5 %) and `k_r_select_cc` (5.8 %, index-driven gathers); K1 together (`k_r_mark` + `k_r_rescore` + `k_r_score_sub`) is 12.8 % |
+| whole step vs SURVEY §8d `B_total` | @STEPB@ GB algorithmic per registration (bytes counted per launch and cloud actually scanned) / @MS@ ms = @STEPFRAC@ % of the 8 TB/s peak: the step is bound by its dependent commands, not by bandwidth |
 | remaining over-fetch (PMC) | index-driven gathers from randomly ordered input: `k_gather_cloud` 275 + 67 MB for 48 + 48 MB, `k_voxel_runs` 134 MB for 24 MB (its writes and `k_voxel_centroids`' 12.8 MB reads are now exactly algorithmic: the sorted copy is written coalesced and summed from contiguous memory). The synthetic clouds are in random point order — the worst case; scanner order is spatially coherent |
 
 **What limits the step.** A HIP process drives the GPU through 4 hardware queues; with 8 registrations in flight all
 four are busy 99.9 % of the time with 3.7 kernels running on average (`tools/trace_load.sh`, `tools/concurrency.py`), so
-throughput ≈ 3.7 / Σ(kernel durations per registration): 9.5 ms under load ⇒ 2.5 ms per step. `GPU_MAX_HW_QUEUES` = 2 / 3 / 4 / 5 / 6 / 8 gives 294 / 362 / 420 / 343 / 323 / 355 reg/s: four concurrently running kernels is what the
-part sustains for this mix; more processes or more registrations in flight do not help either (§4 experiments). Doubling the points (2M per cloud) costs
-+1.0 ms per step: 43 % of the step scales with the bytes, 57 % is the fixed cost of its 365 commands — every one of
-which is also an L2 write-back + invalidate on this 8-XCD part. RANSAC is 48 % of the GPU time (7 iterations × 29
-launches), the sorts 13 %, clustering + penetration + verification + spacing 15 %.
+throughput ≈ 3.7 / Σ(kernel durations per registration): @GPUMS@ ms under load ⇒ @MS@ ms per step. `GPU_MAX_HW_QUEUES` =
+2 / 3 / 4 / 5 / 6 / 8 gives 294 / 362 / 420 / 343 / 323 / 355 reg/s (measured before the top-up rule): four concurrently
+running kernels is what the part sustains for this mix; more processes or more registrations in flight do not help
+either (§4 experiments). Every kernel of a 1M-point registration is a single wave of workgroups — its duration is a
+chain of dependent memory accesses, not bandwidth (`k_r_mark`: 11 µs alone for 56 MB, 18 µs under load; 69 µs for
+560 MB at 10M points) — and every kernel boundary is an L2 write-back + invalidate on this 8-XCD part, so what moves the
+number is fewer launches and fewer passes: the top-up rule took 2 of 7 iterations out (427 → 467 reg/s), while halving
+the duration of single kernels (`k_cluster_edges`, the OBB kernel) stays inside the run-to-run noise. Doubling the points
+(2M per cloud) costs +1.0 ms per step. RANSAC is 47 % of the GPU time (≈ 5 iterations × 27 launches; the per-iteration
+sampling trio sample / score-on-subset / leaders is 11 %), the sorts 17 % (32 passes), clustering + penetration +
+verification + spacing 14 %.
 
 Host side: every wait of the HIP runtime spins; `plade_params.host_wait = 1` polls with 15–40 µs sleeps instead, small
 device-to-host readbacks go to a pinned arena as asynchronous copies, and the extraction's loop reports through
