@@ -8,7 +8,15 @@ rnd = sys.argv[1] if len(sys.argv) > 1 else "r2"
 src = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "DESIGN.md")
 d = json.load(open(os.path.join(ROOT, "profiles", f"{rnd}_bench_n1.json")))
 r = d["roofline"]
+import csv
+_rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", f"{rnd}_kernel_stats.csv"))))
+_tot = sum(float(x["TotalDurationNs"]) for x in _rows)
+_k1 = sum(float(x["TotalDurationNs"]) for x in _rows if any(k in x["Name"] for k in ("k_r_mark(", "k_r_rescore(", "k_r_score_sub("))) / _tot
+_rp = r["rocprof"]
+_idle = _rp["launches_per_registration"] - r["launches_per_step"]
 tok = {
+    "@K1SHARE@": f"{100 * _k1:.1f}", "@RPTOTAL@": f"{_rp['launches_per_registration'] * _rp['avg_launch_us']:.0f}",
+    "@IDLEUS@": f"{(_rp['launches_per_registration'] * _rp['avg_launch_us'] - r['launches_per_step'] * r['avg_launch_us']) / max(_idle, 1e-9):.1f}",
     "@VALUE@": f"{d['value']:.0f}", "@MS@": f"{d['ms_per_step']:.2f}", "@BUSY@": f"{d['host_rank0']['busy_host_threads_avg']:.1f}",
     "@HOSTVALUE@": f"{d['host_buffers_rank0']['value']:.0f}", "@LAT@": f"{d['single_registration_latency_ms']:.1f}",
     "@RPUS@": f"{r['rocprof']['avg_launch_us']:.1f}", "@RPLAUNCH@": f"{r['rocprof']['launches_per_registration']:.1f}",
