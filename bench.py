@@ -174,6 +174,16 @@ def _cpu_budget():
     return n
 
 
+def inflight_for_budget(budget, local_world):
+    """Registrations in flight per GPU.  Measured on the MI355X box (sleeping host waits): 5 / 6 / 8 / 10 in flight keep
+    2.2 / 2.3 / 2.6 / 2.7 host threads busy for 435 / 447 / 455-467 / 457 reg/s, i.e. busy = 1.3 + 0.17 per registration in
+    flight.  A container that runs into its CPU quota loses far more than the last few percent of GPU throughput (round 1:
+    287 instead of 400 reg/s under throttling), so the count is lowered until the ranks of the node fit into the quota: 8
+    ranks on 16 CPUs run 4 in flight each."""
+    per_rank = float(budget) / max(local_world, 1)
+    return int(max(2, min(8, (per_rank - 1.3) / 0.17 + 1e-6)))
+
+
 def _cgroup_throttle():
     """(nr_throttled, throttled_usec) of this container's CPU quota, None where cgroup v2 is not mounted."""
     try:
@@ -194,9 +204,10 @@ def main():
                     help="how the host threads wait for the GPU (plade_params.host_wait): spinning waits keep ~1.7 CPUs busy "
                          "per registration in flight, sleeping ones ~0.5 at the same throughput; auto = sleep when more "
                          "than one registration is in flight")
-    ap.add_argument("--inflight", type=int, default=8,
+    ap.add_argument("--inflight", type=int, default=0,
                     help="registrations in flight per GPU: independent pairs, one plade_ctx + host thread each "
-                         "(a single registration is latency-bound and leaves most of the GPU idle)")
+                         "(a single registration is latency-bound and leaves most of the GPU idle).  0 = 8, or fewer when "
+                         "the ranks of this node have to share a small CPU quota (see inflight_for_budget)")
     ap.add_argument("--host-steps", type=int, default=384,
                     help="steps of the extra host-buffer leg (plade_registration on page-locked host arrays, H2D inside); 0 = skip")
     ap.add_argument("--profiled-steps", type=int, default=8, help="registrations of the roofline leg (HIP events per launch)")
@@ -227,6 +238,10 @@ def main():
     from plade_amd.synth import make_pair
 
     import threading
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    inflight_auto = args.inflight <= 0
+    if inflight_auto:
+        args.inflight = inflight_for_budget(_cpu_budget(), local_world)
     M = max(1, min(args.inflight, args.steps))
     if args.host_wait == "auto":
         # several registrations in flight: sleeping waits (same throughput, a third of the host CPUs, and no way to run
@@ -487,7 +502,7 @@ def main():
                                    "plade_params.orient_normals=1 (planes oriented like their inliers' normals: the generator's "
                                    "Manhattan scenes need it, DESIGN.md section 2); CPU baseline applies the same rule",
                        "points_per_cloud": args.points, "pairs_per_rank": args.pairs,
-                       "registrations_in_flight_per_gpu": M, "host_wait": args.host_wait,
+                       "registrations_in_flight_per_gpu": M, "inflight_chosen_from_cpu_quota": inflight_auto, "host_wait": args.host_wait,
                        "parallelism": f"independent pairs sharded over {world} GPU(s), {M} in flight per GPU"},
             "single_registration_latency_ms": latency_ms,
             "registrations_ok": total_ok,

@@ -147,3 +147,16 @@ def test_cli_batch_blocks_are_streamed_in_input_order_without_a_gpu(tmp_path):
     # the per-pair console output comes out in input order too
     tf = [l for l in r.stdout.split("\n") if l.startswith("target file: ")]
     assert tf == [f"target file: {names[2 * k]}" for k in range(3)]
+
+
+def test_bench_lowers_the_in_flight_count_to_fit_a_shared_cpu_quota():
+    """bench.py keeps 8 registrations in flight per GPU unless the ranks of the node share a CPU quota that 8 host-thread
+    pairs per rank would exceed (a throttled container loses far more than the last percent of GPU throughput)."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    assert b.inflight_for_budget(16, 1) == 8 and b.inflight_for_budget(256, 8) == 8 and b.inflight_for_budget(24, 8) == 8
+    assert b.inflight_for_budget(16, 8) == 4          # the GPU boxes of this pool: 16 CPUs for the container
+    assert b.inflight_for_budget(8, 8) == 2 and b.inflight_for_budget(1, 8) == 2

@@ -368,7 +368,11 @@ one pair the RANSAC accept/remove loop is sequential ⇒ replicas only. The seco
 transforms of one pair are independent in the verification step — is available at the seam
 (`plade_amd.batch.sharded_overlap_counts`, gloo + GPU tests); the default pipeline does not use it: with K ≤ 201 the
 verification kernel is 0.2 ms of a 6 ms registration. Host budget per rank: 8 worker threads + 8 helper threads, 2.6 of
-them busy on average; 8 ranks need ≈ 21 busy cores. No 8-GPU run exists (the driver's to launch).
+them busy on average (1.3 + 0.17 per registration in flight): 8 ranks at 8 in flight need ≈ 21 busy cores. `bench.py`
+therefore picks the in-flight count from the CPU quota the ranks of a node share (`inflight_for_budget`: 8 when there
+are ≥ 2.7 CPUs per rank, 4 for 8 ranks on the 16-CPU containers of this pool — ≈ 415 instead of 467 reg/s per GPU, but
+no throttling, which cost a third of the throughput in round 1's experiments); `--inflight N` overrides it. No 8-GPU
+run exists (the driver's to launch).
 
 ## 7. Out of scope / next
 
