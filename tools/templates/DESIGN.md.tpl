@@ -315,7 +315,7 @@ thread each, `--inflight`), which is how a batch of pairs (configs[3]) is proces
 
 | | value |
 |---|---|
-| registrations/s, 1 GPU, clouds in HBM (`value`) | **@VALUE@** (`python bench.py`: 512 steps, @MS@ ms/step at 8 in flight, sleeping host waits, @BUSY@ busy host threads; 512/512 ok, all registrations of a pair bit-identical across contexts; max ‖T−T_gt‖_F = 1.5e-3 = what the CPU oracle gives on the same planes). Round 1: 406; this round before the top-up rule: 427. 30 000-step soak of the final build: 470.5 reg/s, 30 000/30 000 ok and bit-identical per pair, 2.6 busy host threads, no cgroup throttling (host-buffer leg of the same run, 2000 steps: 436.7 reg/s, identical results) |
+| registrations/s, 1 GPU, clouds in HBM (`value`) | **@VALUE@** (`python bench.py`: 512 steps, @MS@ ms/step at 8 in flight, sleeping host waits, @BUSY@ busy host threads; 512/512 ok, all registrations of a pair bit-identical across contexts; max ‖T−T_gt‖_F = 1.5e-3 = what the CPU oracle gives on the same planes). Round 1: 406; this round before the top-up rule: 427. Short runs read lower because the timed region is bracketed by synchronisations, i.e. it contains the fill and the drain of the 8-deep pipeline (≈ 17 ms latency per registration at full load): `--steps 20` 398–431, `--steps 64` 455, `--steps 512` 467. 30 000-step soak of the final build: 470.5 reg/s, 30 000/30 000 ok and bit-identical per pair, 2.6 busy host threads, no cgroup throttling (host-buffer leg of the same run, 2000 steps: 436.7 reg/s, identical results) |
 | the same with the clouds in page-locked HOST memory (`host_buffers_rank0`: `plade_registration`, H2D + SoA conversion + bounding box inside the timed region) | **@HOSTVALUE@** reg/s (384 steps, 8 in flight) = 48 MB per registration over PCIe while the other contexts compute (the 24 MB copies run on the SDMA engines at 43 GB/s, 0.56 ms each: `tools/trace_host.sh`, `tools/h2d_rate.py`); results identical to the resident ones. Each context stalls ≈ 1.3 ms per registration for its own upload, so more contexts hide more of it: 437 / 437 / 445 reg/s at 8 / 10 / 12 in flight over 600–2000 steps (resident: 470 / 453 / 450). The task's contract keeps `value` = resident; this is the PCIe-inclusive figure. `plade_host_pin` page-locks caller buffers (from pageable memory the runtime stages through its own bounce buffer and the call blocks) |
 | one registration alone (spinning waits) | **@LAT@ ms** (before the top-up rule 6.0–6.6 ms, round 1: 6.9 ms) |
 | commands per registration (rocprofv3, `r2_kernel_stats.csv`) | **@KERNELS@ kernels + @COPIES@ copies / fills** (round 1: 445 + 91 = 536; this round before the top-up rule: 308 + 57), @GPUMS@ ms of summed GPU time; the extraction loop reads nothing back (round 1: ≈ 30 read-backs + syncs per cloud); one helper thread at a time per registration (source spacing during the extraction, source side of the preparation afterwards; round 1: two to three) |
