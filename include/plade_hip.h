@@ -41,10 +41,11 @@ const char *plade_version(void);
  *                          counter that stays 0, so its average normal is NaN and the test never flips:
  *                          the plane normal keeps the sign of the LS-fit eigenvector); 1 = the evident
  *                          intent: flip (n, d) so that n agrees with the mean normal of the plane's inliers.
- *                          Env PLADE_ORIENT_NORMALS=1 turns it on for the C++ API / CLI built on this ABI.
+ *                          The C ABI never looks at the environment; the C++ API / CLI (plade_host.cpp) turn it on
+ *                          with env PLADE_ORIENT_NORMALS=1.
  *   unoriented_normals 0   1 = the "unoriented normals" mode README.md:109-110 describes: every plane takes part
  *                          with both orientations (2x planes, ~4x line pairs / descriptors), so a pair registers
- *                          whatever the signs of the extracted plane normals are.  Env PLADE_UNORIENTED_NORMALS=1.
+ *                          whatever the signs of the extracted plane normals are.  C++ API / CLI: env PLADE_UNORIENTED_NORMALS=1.
  *   ransac_seed     fixed  the reference seeds from time(NULL) (RansacShapeDetector.cpp:463-464)
  *   dump            0      keep named intermediates for plade_dump_get (tests)            */
 typedef struct plade_params {
@@ -57,8 +58,8 @@ typedef struct plade_params {
     uint64_t ransac_seed;
     int32_t host_wait;   /* how the calling thread waits for the GPU: 0 = spin (lowest latency; the HIP runtime keeps
                           * one CPU busy per waiting thread), 1 = poll + short sleeps (throughput mode: many
-                          * contexts in flight per CPU; adds ~30 us per wait).  Env PLADE_HOST_WAIT=spin|sleep
-                          * overrides the default at context creation. */
+                          * contexts in flight per CPU; adds ~30 us per wait).  C++ API / CLI: env
+                          * PLADE_HOST_WAIT=spin|sleep. */
     int32_t unoriented_normals;
 } plade_params;
 void plade_default_params(plade_params *p);
@@ -75,6 +76,16 @@ int plade_set_params(plade_ctx *ctx, const plade_params *p);
 int plade_score_planes(plade_ctx *ctx, const float *pos_nrm, const int32_t *shape_index, uint32_t n,
                        const float *planes, uint32_t h, float eps, float cos_thresh,
                        uint32_t *counts, uint32_t *idx_out, uint32_t cap);
+/* The same visitor over a SUBSET of the cloud -- the call shape of candidate generation and bound refinement:
+ * Candidate::ImproveBounds(..., maxSubset = 1) scores H new hypotheses on subset 0 only
+ * (ransac/RansacShapeDetector.cpp:163 -> Candidate.h:154-179, one nested random subset per call); the GPU loop
+ * scores a sampling round on a stratified subset in one launch.  sub_index: m point indices (< n, any order,
+ * repeats allowed); counts[j] = #{ s < m : shape_index[sub_index[s]] == -1 and point sub_index[s] is compatible
+ * with hypothesis j }; *n_unassigned (optional) = #{ s : shape_index[sub_index[s]] == -1 } (the loop's estimate of
+ * the support on the whole cloud scales the counts by remaining / this). */
+int plade_score_planes_subset(plade_ctx *ctx, const float *pos_nrm, const int32_t *shape_index, uint32_t n,
+                              const uint32_t *sub_index, uint32_t m, const float *planes, uint32_t h, float eps,
+                              float cos_thresh, uint32_t *counts, uint32_t *n_unassigned);
 
 /* ---- seam S1c: connected component + LS refit of one plane candidate ---------------------
  * Replaces PlanePrimitiveShape/BitmapPrimitiveShape::ConnectedComponent

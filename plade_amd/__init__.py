@@ -21,7 +21,7 @@ ABI_SYMBOLS = [
     "plade_overlap_counts", "plade_average_spacing", "plade_voxel_downsample", "plade_registration_planes",
     "plade_registration", "plade_registration_minsupport", "plade_cloud_upload", "plade_cloud_free",
     "plade_registration_dev", "plade_dump_get", "plade_stats_get", "plade_kernel_time", "plade_plane_component",
-    "plade_sort_pairs", "plade_host_pin", "plade_host_unpin",
+    "plade_sort_pairs", "plade_host_pin", "plade_host_unpin", "plade_score_planes_subset",
 ]
 
 
@@ -68,6 +68,7 @@ def load_library(path=LIB_PATH):
     sig("plade_default_params", argtypes=[C.POINTER(Params)])
     sig("plade_set_params", argtypes=[p, C.POINTER(Params)])
     sig("plade_score_planes", argtypes=[p, p, p, u32, p, u32, f, f, p, p, u32])
+    sig("plade_score_planes_subset", argtypes=[p, p, p, u32, p, u32, p, u32, f, f, p, p])
     sig("plade_extract_planes", argtypes=[p, p, u32, u32, f, f, f, f, p, p, p, u32, p])
     sig("plade_match_descriptors", argtypes=[p, p, u32, p, u32, f, p, p, p, u64, p])
     sig("plade_overlap_counts", argtypes=[p, p, u32, p, u32, p, u32, p, f, f, p])
@@ -199,6 +200,18 @@ class Context:
         if want_indices:
             return counts, [idx[j, : counts[j]].astype(np.int32) for j in range(h)]
         return counts
+
+    def score_planes_subset(self, pos_nrm, shape_index, sub_index, planes, eps, cos_thresh):
+        """Seam S1a on a subset (k_r_score_sub): (counts per hypothesis, unassigned subset points)."""
+        pn = _f32(pos_nrm)
+        pl = _f32(planes).reshape(-1, 4)
+        si = _i32(shape_index) if shape_index is not None else None
+        sub = np.ascontiguousarray(sub_index, dtype=np.uint32)
+        counts = np.zeros(len(pl), np.uint32)
+        un = C.c_uint32()
+        self._check(self.L.plade_score_planes_subset(self.h, _ptr(pn), _ptr(si), len(pn), _ptr(sub), len(sub), _ptr(pl), len(pl),
+                                                     eps, cos_thresh, _ptr(counts), C.byref(un)))
+        return counts, un.value
 
     def plane_component(self, pos_nrm, normal, point, idx, bitmap_eps, closing_filter, w_eps):
         """Seam S1c: (kept indices, LS fit[7], weighted score) of one plane candidate's score list."""

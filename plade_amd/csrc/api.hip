@@ -16,10 +16,8 @@ extern "C" void plade_default_params(plade_params *p) {
     p->ransac_seed = 0x9E3779B97F4A7C15ull;
     p->host_wait = 0;
     p->unoriented_normals = 0;
-    if (const char *w = getenv("PLADE_HOST_WAIT")) p->host_wait = (w[0] == 's' && w[1] == 'l') ? 1 : 0;
-    // opt-in switches for programs that cannot pass plade_params (the CLI, the C++ registration() overloads)
-    if (const char *w = getenv("PLADE_ORIENT_NORMALS")) p->orient_normals = atoi(w) != 0;
-    if (const char *w = getenv("PLADE_UNORIENTED_NORMALS")) p->unoriented_normals = atoi(w) != 0;
+    // pure: no environment look-ups here -- programs that cannot pass plade_params (the CLI, the C++ registration()
+    // overloads) read their opt-in switches themselves (plade_host.cpp: context())
 }
 
 extern "C" const char *plade_version(void) { return "plade-hip 0.1 (gfx950)"; }

@@ -206,7 +206,8 @@ struct RegistrationWork {
     DBuf<uint32_t> d_any;
     OverlapWork ov_work;
     hipEvent_t ev_grid = nullptr;   // target grid of the verification built on the auxiliary stream
-    ~RegistrationWork() { if (ev_grid) (void)hipEventDestroy(ev_grid); }
+    hipEvent_t ev_main = nullptr;   // everything queued on the main stream before the two sides are prepared
+    ~RegistrationWork() { if (ev_grid) (void)hipEventDestroy(ev_grid); if (ev_main) (void)hipEventDestroy(ev_main); }
 };
 
 void MirroredPlanes::build(const float *coef_in, const int32_t *offsets_in, const int32_t *idx_in, uint32_t P) {
@@ -265,6 +266,13 @@ bool run_registration(plade_ctx *ctx, RegistrationWork &W, const CloudDev &tgt, 
         aux->stats.clear();
         bool ok_c = false, ok_m = false;
         Err aux_err{0, ""}, main_err{0, ""};
+        // The source side reads what the plane extraction left on the device (the support lists in the extraction's work
+        // area), and the extraction ran on the MAIN stream: its host loop returns as soon as the device reports the end
+        // through host-mapped memory, with the last kernels of the iteration possibly still running.  The auxiliary
+        // stream therefore waits for the main one here.
+        if (!W.ev_main) HIP_TRY(hipEventCreateWithFlags(&W.ev_main, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(W.ev_main, ctx->stream));
+        HIP_TRY(hipStreamWaitEvent(aux->stream, W.ev_main, 0));
         std::thread th([&]() {
             (void)hipSetDevice(ctx->device);
             try { ok_c = prepare_side(aux, "src", src, sp, downSampleDistance, pen_grid_cell(lengthThreshold), scale, false, W.src_pairs, C); }

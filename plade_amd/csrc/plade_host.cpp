@@ -31,6 +31,15 @@ plade_ctx *context() {
         return nullptr;
     }
     g_ctx_device = g_device;
+    // opt-in switches of the C++ API / CLI, which have no parameter to carry them (the C ABI's defaults are the
+    // reference's values and do not look at the environment): see include/plade_hip.h, plade_params
+    plade_params prm;
+    plade_default_params(&prm);
+    bool changed = false;
+    if (const char *w = getenv("PLADE_HOST_WAIT")) { prm.host_wait = (w[0] == 's' && w[1] == 'l') ? 1 : 0; changed = true; }
+    if (const char *w = getenv("PLADE_ORIENT_NORMALS")) { prm.orient_normals = atoi(w) != 0; changed = true; }
+    if (const char *w = getenv("PLADE_UNORIENTED_NORMALS")) { prm.unoriented_normals = atoi(w) != 0; changed = true; }
+    if (changed) (void)plade_set_params(g_ctx, &prm);
     return g_ctx;
 }
 

@@ -67,4 +67,12 @@ void ransac_detect_prepared(plade_ctx *ctx, RansacWork &W, RansacJob jobs[RANSAC
 // prepare + detect of a single cloud
 void ransac_detect(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const RansacParams &rp, PlaneSetOut &out);
 
+// Seam S1a (plade_score_planes, plade_score_planes_subset): the caller's hypotheses through the loop's own K1 kernels --
+// counts by k_r_rescore, ordered inlier lists by k_r_mark + k_r_compact_raster, subset counts by k_r_score_sub.
+// The cloud is scanned in the caller's point order (no Morton pass), d_assigned = shapeIndex per point or nullptr.
+void score_planes_seam(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const int32_t *d_assigned, const float *planes,
+                       uint32_t h, float eps, float cos_t, uint32_t *counts, uint32_t *idx_out, uint32_t cap);
+void score_subset_seam(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const int32_t *d_assigned, const uint32_t *sub_index,
+                       uint32_t m, const float *planes, uint32_t h, float eps, float cos_t, uint32_t *counts, uint32_t *n_unassigned);
+
 }  // namespace plade

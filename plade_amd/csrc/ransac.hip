@@ -37,6 +37,7 @@
 // Every kernel serves the clouds of up to two "slots": the two scans of a registration are extracted in lock step by
 // one launch sequence (blockIdx selects the cloud), which halves the number of commands per registration.
 #include "ransac.h"
+#include "k1_point_test.h"
 #include "prims.h"
 #include "voxel.h"
 #include <algorithm>
@@ -55,7 +56,7 @@ constexpr int R_G = RANSAC_SLOTS;
 constexpr uint32_t R_MAXP = 4096;       // accepted shapes per detect call
 constexpr uint32_t R_MAX_ROUNDS = 4000;
 constexpr int R_MIN_LEVEL = 1, R_MAX_LEVEL = 8;
-constexpr int TPB = 256, PPT = 4, TILE = TPB * PPT;   // scan kernels: 1024 points per workgroup, 16 B per lane and array
+constexpr int TPB = K1_TPB, PPT = K1_PPT, TILE = K1_TILE;   // scan kernels: 1024 points per workgroup, 16 B per lane and array (k1_point_test.h)
 constexpr int HCHUNK = 64;              // hypotheses per workgroup of the counting kernels (>= R_TOP)
 constexpr int FIT_COLS = 14;            // 12 LS-fit moments, weighted score, kept-point count
 constexpr uint32_t CC_MAXPIX = 1u << 20;
@@ -315,59 +316,7 @@ __device__ __forceinline__ uint32_t lb_u32(const uint32_t *a, uint32_t n, uint32
     return lo;
 }
 
-__device__ __forceinline__ bool compatible(float4 pl, float px, float py, float pz, float qx, float qy, float qz, float eps,
-                                           float cos_t) {
-    float d = pl.x * px;
-    d += pl.y * py;
-    d += pl.z * pz;
-    const float dist = fabsf(pl.w - d);
-    float nd = pl.x * qx;
-    nd += pl.y * qy;
-    nd += pl.z * qz;
-    return (dist < eps) && (fabsf(nd) >= cos_t);
-}
-
-struct Tile {
-    float px[PPT], py[PPT], pz[PPT], qx[PPT], qy[PPT], qz[PPT];
-    bool valid[PPT];
-};
-// 4 consecutive points per lane via 16-byte loads; `assigned` (nullable) is indexed directly or through sub_index
-__device__ __forceinline__ void load_tile(Tile &t, const float *x, const float *y, const float *z, const float *nx, const float *ny,
-                                          const float *nz, const int32_t *assigned, const uint32_t *sub_index, uint32_t n,
-                                          uint32_t base) {
-    if (base + PPT <= n) {
-        const float4 a = *reinterpret_cast<const float4 *>(x + base), b = *reinterpret_cast<const float4 *>(y + base),
-                     c = *reinterpret_cast<const float4 *>(z + base), d = *reinterpret_cast<const float4 *>(nx + base),
-                     e = *reinterpret_cast<const float4 *>(ny + base), f = *reinterpret_cast<const float4 *>(nz + base);
-        t.px[0] = a.x; t.px[1] = a.y; t.px[2] = a.z; t.px[3] = a.w;
-        t.py[0] = b.x; t.py[1] = b.y; t.py[2] = b.z; t.py[3] = b.w;
-        t.pz[0] = c.x; t.pz[1] = c.y; t.pz[2] = c.z; t.pz[3] = c.w;
-        t.qx[0] = d.x; t.qx[1] = d.y; t.qx[2] = d.z; t.qx[3] = d.w;
-        t.qy[0] = e.x; t.qy[1] = e.y; t.qy[2] = e.z; t.qy[3] = e.w;
-        t.qz[0] = f.x; t.qz[1] = f.y; t.qz[2] = f.z; t.qz[3] = f.w;
-        if (assigned && !sub_index) {
-            const int4 s = *reinterpret_cast<const int4 *>(assigned + base);
-            t.valid[0] = s.x == -1; t.valid[1] = s.y == -1; t.valid[2] = s.z == -1; t.valid[3] = s.w == -1;
-        } else if (assigned) {
-            const uint4 si = *reinterpret_cast<const uint4 *>(sub_index + base);
-            t.valid[0] = assigned[si.x] == -1; t.valid[1] = assigned[si.y] == -1;
-            t.valid[2] = assigned[si.z] == -1; t.valid[3] = assigned[si.w] == -1;
-        } else {
-            t.valid[0] = t.valid[1] = t.valid[2] = t.valid[3] = true;
-        }
-    } else {
-#pragma unroll
-        for (int k = 0; k < PPT; ++k) {
-            const uint32_t i = base + k;
-            const bool in = i < n;
-            t.px[k] = in ? x[i] : 0.f; t.py[k] = in ? y[i] : 0.f; t.pz[k] = in ? z[i] : 0.f;
-            t.qx[k] = in ? nx[i] : 0.f; t.qy[k] = in ? ny[i] : 0.f; t.qz[k] = in ? nz[i] : 0.f;
-            bool un = true;
-            if (in && assigned) un = (sub_index ? assigned[sub_index[i]] : assigned[i]) == -1;
-            t.valid[k] = in && un;
-        }
-    }
-}
+// compatible(), Tile, load_tile(): k1_point_test.h (the one definition of the K1 point test)
 
 // which cloud a workgroup of a "concatenated tiles" grid scans
 __device__ __forceinline__ int scan_group(const RArgs &A, uint32_t &tile) {
@@ -1593,6 +1542,68 @@ __global__ void k_r_seam_init(const RArgs A, float4 hyp, float4 pos, float w_eps
     state_from_hyp(&ch.hdr->st[0], hyp, pos);
 }
 
+// ---- seam S1a (plade_score_planes / plade_score_planes_subset): the caller's hypotheses through the loop's OWN K1
+// kernels -- counts by k_r_rescore (the pool re-score), ordered lists by k_r_mark + k_r_compact_raster (slot 0 of the
+// acceptance chains), subset counts by k_r_score_sub.  These kernels only put the hypotheses where the loop keeps them.
+__global__ void k_r_seam_pool(const RArgs A, const float4 *__restrict__ planes, uint32_t nh, float eps, float cos_t) {
+    const RCloudArgs &C = A.c[0];
+    RState *S = C.st;
+    if (threadIdx.x == 0) {
+        S->n = C.cv.n; S->active = 1; S->done = 0; S->sampling = 0; S->fresh = 1; S->npool = nh; S->nc = 0; S->aj_n = 0;
+        S->eps = eps; S->cos_t = cos_t; S->n_rescores[0] = S->n_rescores[1] = 0;
+    }
+    if (threadIdx.x < R_TOP) {
+        S->pool_cnt[threadIdx.x] = 0;
+        if (threadIdx.x < nh) S->pool_pl[threadIdx.x] = planes[threadIdx.x];
+    }
+}
+
+__global__ void k_r_seam_chains(const RArgs A, const float4 *__restrict__ planes, uint32_t nb, float eps, float cos_t) {
+    const RCloudArgs &C = A.c[0];
+    RState *S = C.st;
+    if (threadIdx.x == 0) {
+        S->n = C.cv.n; S->active = 1; S->done = 0; S->sampling = 0; S->fresh = 0; S->npool = 0; S->nc = nb; S->aj_n = 0;
+        S->eps3 = eps; S->cos_t = cos_t; S->min_support = 0; S->orient = 0; S->err = 0;
+        S->bitmap_eps = INFINITY;   // one-pixel bitmaps: only the ordered list of the compaction is asked for
+        S->n_mark_launches = S->n_mark_chains = 0;
+    }
+    if (threadIdx.x < nb) {
+        ChainPtr ch = chain_of(C, threadIdx.x);
+        const float4 hyp = planes[threadIdx.x], pos = make_float4(0.f, 0.f, 0.f, 0.f);
+        ch.hdr->cand[0] = hyp; ch.hdr->cand[1] = pos;
+        PlaneState *st = &ch.hdr->st[0];
+        state_from_hyp(st, hyp, pos);
+        bool fin = true;
+        for (int q = 0; q < 3; ++q) fin = fin && fabsf(st->a0[q]) <= 2.f && fabsf(st->a1[q]) <= 2.f;
+        if (!fin) {   // a hypothesis without a direction has no in-plane frame: any fixed one serves the list
+            st->a0[0] = 1.f; st->a0[1] = 0.f; st->a0[2] = 0.f; st->a1[0] = 0.f; st->a1[1] = 1.f; st->a1[2] = 0.f;
+        }
+    }
+}
+
+__global__ void k_r_seam_hyps(const RArgs A, const float4 *__restrict__ planes, uint32_t nh, float eps, float cos_t) {
+    const RCloudArgs &C = A.c[0];
+    RState *S = C.st;
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t == 0) {
+        S->n = C.cv.n; S->active = 1; S->done = 0; S->sampling = 1; S->fresh = 0; S->npool = 0; S->nc = 0; S->aj_n = 0;
+        S->eps = eps; S->cos_t = cos_t; S->sub_unassigned = 0;
+    }
+    if (t >= R_H) return;
+    C.hyp[t] = t < nh ? planes[t] : make_float4(0.f, 0.f, 0.f, __int_as_float(0x7fc00000));
+    C.hyp_counts[t] = 0;
+}
+
+__global__ void k_r_seam_subset(const CloudView cv, const uint32_t *__restrict__ sub_index, uint32_t m, float *__restrict__ sub,
+                                uint32_t pitch) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= m) return;
+    const uint32_t i = sub_index[s];
+    const size_t sp = pitch;
+    sub[s] = cv.x[i]; sub[sp + s] = cv.y[i]; sub[2 * sp + s] = cv.z[i];
+    sub[3 * sp + s] = cv.nx[i]; sub[4 * sp + s] = cv.ny[i]; sub[5 * sp + s] = cv.nz[i];
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
@@ -1851,6 +1862,10 @@ void ransac_detect_prepared(plade_ctx *ctx, RansacWork &W, RansacJob jobs[RANSAC
         P.seed = J.rp.seed;
         P.gen = gen;
         P.topup = A.topup;
+        // a slot that sat out earlier calls still shows the flag of its last one; with a 7-bit tag that would look like
+        // THIS call's "done" after 128 calls.  (A speculative iteration of the previous call may still write its own,
+        // older tag over the zero: harmless.)
+        *reinterpret_cast<volatile uint32_t *>(&s.res->flag) = 0u;
         res[nres++] = s.res;
     }
     if (nres == 0) return;
@@ -2010,6 +2025,108 @@ void plane_component(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const
     for (int k = 0; k < 3; ++k) { out.fit[k] = hst[1].n[k]; out.fit[3 + k] = hst[1].pos[k]; }
     out.fit[6] = hst[1].dist;
     out.wscore = hst[0].wscore;
+}
+
+// ---- seam S1a on the loop's kernels ------------------------------------------------------------------------------
+namespace {
+RArgs seam_args(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const int32_t *d_assigned) {
+    RansacSlot &s = W.slot[0];
+    W.ng = 0;   // the slot no longer holds a prepared cloud
+    slot_buffers(ctx, s, cloud.n);
+    RArgs A;
+    memset(&A, 0, sizeof(A));
+    A.ng = 1;
+    for (int g = 0; g < R_G; ++g) {
+        RCloudArgs &C = A.c[g];
+        C.cv = CloudView{cloud.x(), cloud.y(), cloud.z(), cloud.nx(), cloud.ny(), cloud.nz(), cloud.n};
+        C.assigned = const_cast<int32_t *>(d_assigned);
+        C.st = s.state.p; C.res = s.res_dev; C.out_idx = s.out_idx.p; C.fixed = s.fixed.p; C.var = s.var.p; C.L = s.L;
+        C.hyp = reinterpret_cast<float4 *>(s.round_block.p);
+        C.hyp_pos = C.hyp + R_H;
+        C.hyp_counts = reinterpret_cast<uint32_t *>(C.hyp_pos + R_H);
+    }
+    A.tiles0 = s.L.nb;
+    return A;
+}
+}  // namespace
+
+void score_planes_seam(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const int32_t *d_assigned, const float *planes,
+                       uint32_t h, float eps, float cos_t, uint32_t *counts, uint32_t *idx_out, uint32_t cap) {
+    for (uint32_t j = 0; j < h; ++j) counts[j] = 0;
+    if (cloud.n == 0 || h == 0) return;
+    RArgs A = seam_args(ctx, W, cloud, d_assigned);
+    RansacSlot &s = W.slot[0];
+    hipStream_t st = ctx->stream;
+    DBuf<float4> d_planes;
+    d_planes.ensure(h);
+    HIP_TRY(hipMemcpyAsync(d_planes.p, planes, 16 * (size_t)h, hipMemcpyHostToDevice, st));
+    const uint32_t tiles = s.L.nb;
+    // counts: the hypotheses take the place of the candidate pool, R_TOP at a time (k_r_rescore, phase 1 = a fresh pool)
+    for (uint32_t h0 = 0; h0 < h; h0 += R_TOP) {
+        const uint32_t nh = std::min(R_TOP, h - h0);
+        hipLaunchKernelGGL(k_r_seam_pool, dim3(1), dim3(64), 0, st, A, d_planes.p + h0, nh, eps, cos_t);
+        hipLaunchKernelGGL(k_r_rescore, dim3(tiles), dim3(TPB), 0, st, A, 1, (unsigned long long *)nullptr);
+        HIP_TRY(hipMemcpyAsync(counts + h0, reinterpret_cast<const char *>(s.state.p) + offsetof(RState, pool_cnt), 4 * (size_t)nh,
+                               hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    HIP_TRY(hipGetLastError());
+    if (!idx_out || !cap) return;
+    // ordered lists: the hypotheses take the place of the acceptance chains' candidates, R_B at a time: mark (4-bit masks +
+    // per-tile counts) -> ordered compaction (+ a one-pixel bitmap, which the labelling kernel clears again)
+    for (uint32_t h0 = 0; h0 < h; h0 += R_B) {
+        const uint32_t nb = std::min((uint32_t)R_B, h - h0);
+        hipLaunchKernelGGL(k_r_seam_chains, dim3(1), dim3(64), 0, st, A, d_planes.p + h0, nb, eps, cos_t);
+        hipLaunchKernelGGL(k_r_mark, dim3(tiles), dim3(TPB), 0, st, A, 0, (unsigned long long *)nullptr);
+        hipLaunchKernelGGL(k_r_compact_raster, dim3(loop_grid(tiles), R_B), dim3(TPB), 0, st, A, 0);
+        hipLaunchKernelGGL(k_r_label, dim3(R_B), dim3(1024), 0, st, A, 0, 0);
+        PlaneState hst[R_B];
+        for (uint32_t b = 0; b < nb; ++b)
+            HIP_TRY(hipMemcpyAsync(&hst[b], s.fixed.p + (size_t)b * F_BYTES + offsetof(ChainHdr, st), sizeof(PlaneState),
+                                   hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(hipGetLastError());
+        for (uint32_t b = 0; b < nb; ++b) {
+            PLADE_REQUIRE(hst[b].err == 0, PLADE_EDEVICE, "plade_score_planes: compaction failed");
+            PLADE_REQUIRE(hst[b].n_list == counts[h0 + b], PLADE_EDEVICE, "plade_score_planes: count/compaction disagreement");
+            const uint32_t w = std::min(hst[b].n_list, cap);
+            if (w)
+                HIP_TRY(hipMemcpy(idx_out + (size_t)(h0 + b) * cap, s.var.p + (size_t)b * s.L.bytes + s.L.idxA, 4 * (size_t)w,
+                                  hipMemcpyDeviceToHost));
+        }
+    }
+}
+
+void score_subset_seam(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const int32_t *d_assigned, const uint32_t *sub_index,
+                       uint32_t m, const float *planes, uint32_t h, float eps, float cos_t, uint32_t *counts, uint32_t *n_unassigned) {
+    for (uint32_t j = 0; j < h; ++j) counts[j] = 0;
+    if (n_unassigned) *n_unassigned = 0;
+    if (cloud.n == 0 || h == 0 || m == 0) return;
+    RArgs A = seam_args(ctx, W, cloud, d_assigned);
+    RansacSlot &s = W.slot[0];
+    hipStream_t st = ctx->stream;
+    s.n_sub = m;
+    s.sub_pitch = (m + 3) & ~3u;
+    s.sub.ensure(6 * (size_t)s.sub_pitch + 4);
+    s.sub_index.ensure((size_t)s.sub_pitch + 4);
+    HIP_TRY(hipMemcpyAsync(s.sub_index.p, sub_index, 4 * (size_t)m, hipMemcpyHostToDevice, st));
+    for (int g = 0; g < R_G; ++g) { A.c[g].sub = s.sub.p; A.c[g].sub_index = s.sub_index.p; A.c[g].sub_pitch = s.sub_pitch; A.c[g].n_sub = m; }
+    hipLaunchKernelGGL(k_r_seam_subset, dim3(cdiv(m, 256)), dim3(256), 0, st, A.c[0].cv, s.sub_index.p, m, s.sub.p, s.sub_pitch);
+    DBuf<float4> d_planes;
+    d_planes.ensure(h);
+    HIP_TRY(hipMemcpyAsync(d_planes.p, planes, 16 * (size_t)h, hipMemcpyHostToDevice, st));
+    // the hypotheses take the place of a sampling round's, R_H at a time (k_r_score_sub)
+    for (uint32_t h0 = 0; h0 < h; h0 += R_H) {
+        const uint32_t nh = std::min(R_H, h - h0);
+        hipLaunchKernelGGL(k_r_seam_hyps, dim3(cdiv(R_H, 256)), dim3(256), 0, st, A, d_planes.p + h0, nh, eps, cos_t);
+        hipLaunchKernelGGL(k_r_score_sub, dim3(cdiv(m, TILE), R_H / HCHUNK, 1), dim3(TPB), 0, st, A);
+        HIP_TRY(hipMemcpyAsync(counts + h0, A.c[0].hyp_counts, 4 * (size_t)nh, hipMemcpyDeviceToHost, st));
+        if (n_unassigned)
+            HIP_TRY(hipMemcpyAsync(n_unassigned, reinterpret_cast<const char *>(s.state.p) + offsetof(RState, sub_unassigned), 4,
+                                   hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    HIP_TRY(hipGetLastError());
 }
 
 }  // namespace plade

@@ -184,6 +184,52 @@ double ctx_stat(plade_ctx *ctx, const char *name) {
 }  // namespace plade
 
 // ---- C ABI ---------------------------------------------------------------------------------
+// ---- C ABI: seam S1a -------------------------------------------------------------------------
+// Runs on the RANSAC loop's own kernels (ransac.hip: score_planes_seam / score_subset_seam).
+extern "C" int plade_score_planes(plade_ctx *ctx, const float *pos_nrm, const int32_t *shape_index, uint32_t n,
+                                  const float *planes, uint32_t h, float eps, float cos_thresh, uint32_t *counts,
+                                  uint32_t *idx_out, uint32_t cap) {
+    return guarded(ctx, [&]() -> int {
+        PLADE_REQUIRE(planes && counts && (pos_nrm || !n), PLADE_EINVAL, "plade_score_planes: null argument");
+        for (uint32_t j = 0; j < h; ++j) counts[j] = 0;
+        if (n == 0 || h == 0) return PLADE_OK;
+        CloudDev cloud;
+        cloud_upload(ctx, pos_nrm, n, cloud);
+        DBuf<int32_t> d_assigned;
+        if (shape_index) {
+            d_assigned.ensure((size_t)n + 8);
+            ctx->h2d(d_assigned.p, shape_index, (size_t)n * 4);
+        }
+        if (!ctx->ransac_work) ctx->ransac_work = ransac_work_create();
+        score_planes_seam(ctx, *ctx->ransac_work, cloud, shape_index ? d_assigned.p : nullptr, planes, h, eps, cos_thresh, counts,
+                          idx_out, cap);
+        return PLADE_OK;
+    });
+}
+
+extern "C" int plade_score_planes_subset(plade_ctx *ctx, const float *pos_nrm, const int32_t *shape_index, uint32_t n,
+                                         const uint32_t *sub_index, uint32_t m, const float *planes, uint32_t h, float eps,
+                                         float cos_thresh, uint32_t *counts, uint32_t *n_unassigned) {
+    return guarded(ctx, [&]() -> int {
+        PLADE_REQUIRE(planes && counts && (pos_nrm || !n) && (sub_index || !m), PLADE_EINVAL, "plade_score_planes_subset: null argument");
+        for (uint32_t j = 0; j < h; ++j) counts[j] = 0;
+        if (n_unassigned) *n_unassigned = 0;
+        for (uint32_t i = 0; i < m; ++i) PLADE_REQUIRE(sub_index[i] < n, PLADE_EINVAL, "plade_score_planes_subset: subset index outside the cloud");
+        if (n == 0 || h == 0 || m == 0) return PLADE_OK;
+        CloudDev cloud;
+        cloud_upload(ctx, pos_nrm, n, cloud);
+        DBuf<int32_t> d_assigned;
+        if (shape_index) {
+            d_assigned.ensure((size_t)n + 8);
+            ctx->h2d(d_assigned.p, shape_index, (size_t)n * 4);
+        }
+        if (!ctx->ransac_work) ctx->ransac_work = ransac_work_create();
+        score_subset_seam(ctx, *ctx->ransac_work, cloud, shape_index ? d_assigned.p : nullptr, sub_index, m, planes, h, eps, cos_thresh,
+                          counts, n_unassigned);
+        return PLADE_OK;
+    });
+}
+
 extern "C" int plade_extract_planes(plade_ctx *ctx, const float *pos_nrm, uint32_t n, uint32_t min_support, float dist_rel,
                                     float bitmap_rel, float cos_thresh, float overlook_p, float *planes_out,
                                     int32_t *offsets_out, int32_t *idx_out, uint32_t max_planes, uint32_t *n_planes_out) {

@@ -9,10 +9,14 @@ if ROOT not in sys.path:
 # The library's default is the reference's behaviour: plane normals keep the sign of the LS-fit eigenvector
 # (plane_extraction.cpp:43-58 never flips them).  The synthetic scenes of this suite are Manhattan rooms with
 # ORIENTED point normals, where that behaviour registers a pair only when three independent sign bits happen to agree
-# (1 in 8, in the reference as much as here), so the suite runs with params.orient_normals = 1 (planes oriented like
-# their inliers' normals) unless a test passes orient_normals=0 explicitly -- tests/test_gpu_faithful.py does, and
-# pins the reference-faithful mode against libransac's signs and the oracle.  Subprocesses (the CLI) inherit it.
-os.environ.setdefault("PLADE_ORIENT_NORMALS", "1")
+# (1 in 8, in the reference as much as here), so the tests that register synthetic scenes ask for
+# params.orient_normals = 1 explicitly (ORIENTED below; the session context has it), CLI subprocesses get
+# PLADE_ORIENT_NORMALS=1 in their env (ORIENTED_ENV).  The shipped default (orient_normals = 0) is exercised by
+# tests/test_gpu_faithful.py (library, end to end against the oracle) and tests/test_gpu_cli.py (the CLI).
+ORIENTED = {"orient_normals": 1}
+ORIENTED_ENV = {"PLADE_ORIENT_NORMALS": "1"}
+os.environ.pop("PLADE_ORIENT_NORMALS", None)     # nothing is inherited from the caller's shell
+os.environ.pop("PLADE_UNORIENTED_NORMALS", None)
 
 
 def pytest_configure(config):
@@ -40,6 +44,6 @@ def oracle():
 @pytest.fixture(scope="session")
 def ctx():
     import plade_amd
-    c = plade_amd.Context(0)
+    c = plade_amd.Context(0, **ORIENTED)
     yield c
     c.close()

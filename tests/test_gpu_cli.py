@@ -14,6 +14,7 @@ pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CLI = os.path.join(ROOT, "plade_amd", "PLADE")
+ORIENTED_ENV = dict(os.environ, PLADE_ORIENT_NORMALS="1")   # synthetic Manhattan scenes (tests/conftest.py)
 
 
 def parse_results(path):
@@ -54,7 +55,7 @@ def test_cli_single_pair_matches_the_library(ply_pairs, ctx):
     d, pairs = ply_pairs
     pt, ps, tg, sr, Tgt = pairs[0]
     res = str(d / "one.txt")
-    r = subprocess.run([CLI, pt, ps, res], capture_output=True, text=True, timeout=300)
+    r = subprocess.run([CLI, pt, ps, res], capture_output=True, text=True, timeout=300, env=ORIENTED_ENV)
     assert r.returncode == 0, r.stderr
     (b,) = parse_results(res)
     assert b["target"] == pt and b["source"] == ps and not b["failed"]
@@ -70,7 +71,7 @@ def test_cli_batch_mode_in_flight_keeps_input_order(ply_pairs, ctx):
     lst = d / "file_pairs.txt"
     lst.write_text("".join(f"{pt}\n{ps}\n" for (pt, ps, *_r) in pairs))
     res = str(d / "batch.txt")
-    env = dict(os.environ, PLADE_INFLIGHT="3", PLADE_GPUS="1")
+    env = dict(ORIENTED_ENV, PLADE_INFLIGHT="3", PLADE_GPUS="1")
     r = subprocess.run([CLI, str(lst), res], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stderr
     blocks = parse_results(res)
@@ -96,7 +97,7 @@ def test_cli_ascii_ply_and_swap_of_a_larger_source(tmp_path, ctx):
     write_ply(ps, big_src)
     assert len(big_src) >= 1.2 * len(small_tgt)
     res = str(tmp_path / "r.txt")
-    r = subprocess.run([CLI, pt, ps, res], capture_output=True, text=True, timeout=300)
+    r = subprocess.run([CLI, pt, ps, res], capture_output=True, text=True, timeout=300, env=ORIENTED_ENV)
     assert r.returncode == 0, r.stderr
     (b,) = parse_results(res)
     assert not b["failed"] and np.linalg.norm(b["T"] - T_expected) < 2e-2
@@ -111,7 +112,7 @@ def test_cxx_api_four_overloads(ply_pairs, tmp_path, ctx):
                            os.path.join(ROOT, "tests", "cxx", "api_harness.cpp"), os.path.join(csrc, "plade_host.cpp"),
                            os.path.join(csrc, "ply_reader.cpp"), "-o", exe, "-L", os.path.join(ROOT, "plade_amd"),
                            "-lplade_hip", "-Wl,-rpath," + os.path.join(ROOT, "plade_amd")])
-    r = subprocess.run([exe, pt, ps], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([exe, pt, ps], capture_output=True, text=True, timeout=600, env=ORIENTED_ENV)
     assert r.returncode == 0, r.stderr
     out, cur = {}, None
     for l in r.stdout.split("\n"):
@@ -130,3 +131,25 @@ def test_cxx_api_four_overloads(ply_pairs, tmp_path, ctx):
     assert out["minsupport"][0] == int(ok2) and np.array_equal(out["minsupport"][1].astype(np.float32), T2)
     assert out["planes"][0] == 1 and np.linalg.norm(out["planes"][1] - Tgt) < 2e-2
     assert out["noplanes"][0] == 0 and np.array_equal(out["noplanes"][1], np.eye(4))
+
+
+def test_cli_shipped_default_is_the_reference_faithful_mode(tmp_path):
+    """The CLI without any PLADE_* switch runs the library's shipped default (orient_normals = 0: plane normals keep the
+    LS-fit eigenvector's sign, plane_extraction.cpp:43-58) -- on the reference's own sample pair (polyhedron, committed as
+    data in g8_polyhedron.npz) the printed block equals the default-mode library result."""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "g8_polyhedron.npz"), allow_pickle=False)
+    pt, ps, res = str(tmp_path / "t.ply"), str(tmp_path / "s.ply"), str(tmp_path / "r.txt")
+    write_ply(pt, g["target"])
+    write_ply(ps, g["source"])
+    env = {k: v for k, v in os.environ.items() if not k.startswith("PLADE_")}
+    r = subprocess.run([CLI, pt, ps, res], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr
+    (b,) = parse_results(res)
+    c = plade_amd.Context(0)                      # the C ABI's defaults: no parameter set, no environment read
+    assert c.params.orient_normals == 0
+    ok, T = c.registration(g["target"], g["source"])
+    c.close()
+    assert ok == (not b["failed"])
+    assert np.allclose(b["T"], T, rtol=2e-5, atol=2e-6)
+    # (whether the unoriented planes lead to the right alignment depends on their signs, in the reference as much as
+    # here: tests/test_gpu_faithful.py pins that mode against the oracle)

@@ -78,7 +78,7 @@ def _parse(path, allow_truncated_tail=False):
 def test_config3_batch_of_64_pairs_through_the_cli(batch64, ctx):
     d, lst, pairs = batch64
     res = os.path.join(d, "results.txt")
-    env = dict(os.environ, PLADE_GPUS="1", PLADE_INFLIGHT="4")
+    env = dict(os.environ, PLADE_GPUS="1", PLADE_INFLIGHT="4", PLADE_ORIENT_NORMALS="1")
     t0 = time.perf_counter()
     r = subprocess.run([CLI, lst, res], capture_output=True, text=True, timeout=1200, env=env)
     dt = time.perf_counter() - t0
@@ -115,7 +115,7 @@ def test_config3_interrupted_batch_leaves_a_valid_prefix(batch64):
     blocks for a prefix of the input list and nothing else."""
     d, lst, pairs = batch64
     res = os.path.join(d, "interrupted.txt")
-    env = dict(os.environ, PLADE_GPUS="1", PLADE_INFLIGHT="2")
+    env = dict(os.environ, PLADE_GPUS="1", PLADE_INFLIGHT="2", PLADE_ORIENT_NORMALS="1")
     p = subprocess.Popen([CLI, lst, res], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, env=env)
     killed = False
     t0 = time.time()

@@ -122,13 +122,13 @@ def test_contexts_sharing_a_gpu_are_independent():
     """Registrations in flight on one GPU (bench.py --inflight, the CLI's PLADE_INFLIGHT): same results
     as one at a time."""
     pairs = [make_pair(60000, seed=s) for s in (3, 4)]
-    ref_ctx = plade_amd.Context(0)
+    ref_ctx = plade_amd.Context(0, orient_normals=1)
     want = [ref_ctx.registration(tg, sr) for (tg, sr, _) in pairs]
     ref_ctx.close()
     got = {}
 
     def work(w):
-        c = plade_amd.Context(0)
+        c = plade_amd.Context(0, orient_normals=1)
         for rep in range(10):   # enough repetitions to expose a missing cross-stream dependency (one was found this way)
             for i, (tg, sr, _) in enumerate(pairs):
                 got[(w, rep, i)] = c.registration(tg, sr)
@@ -223,7 +223,7 @@ def test_host_wait_sleep_mode_returns_the_same_bits(ctx):
     import plade_amd
     tg, sr, _ = make_pair(120000, seed=5)
     ok, T = ctx.registration(tg, sr)
-    c2 = plade_amd.Context(0, host_wait=1)
+    c2 = plade_amd.Context(0, host_wait=1, orient_normals=1)
     ok2, T2 = c2.registration(tg, sr)
     c2.close()
     assert ok and ok2 and np.array_equal(T, T2)

@@ -30,11 +30,14 @@ def faithful():
 
 
 def test_library_default_is_the_reference_behaviour(monkeypatch):
-    monkeypatch.delenv("PLADE_ORIENT_NORMALS", raising=False)
-    monkeypatch.delenv("PLADE_UNORIENTED_NORMALS", raising=False)
+    """plade_default_params is pure: the reference's literals, whatever the environment says (the opt-in switches are read
+    by the C++ API / CLI only, plade_host.cpp)."""
+    monkeypatch.setenv("PLADE_ORIENT_NORMALS", "1")
+    monkeypatch.setenv("PLADE_UNORIENTED_NORMALS", "1")
+    monkeypatch.setenv("PLADE_HOST_WAIT", "sleep")
     p = plade_amd.Params()
     plade_amd.load_library().plade_default_params(p)
-    assert p.orient_normals == 0 and p.unoriented_normals == 0
+    assert p.orient_normals == 0 and p.unoriented_normals == 0 and p.host_wait == 0
     assert (p.max_planes, p.min_planes, p.max_candidates, p.init_min_support) == (40, 10, 200, 10000)
 
 

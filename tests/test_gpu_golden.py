@@ -129,35 +129,84 @@ def test_g9_real_room_scan_own_plane_extraction(ctx):
     assert ok2 and np.array_equal(T, T2)
 
 
-def test_g2_plane_sets_against_the_reference_ransac(ctx):
-    """Plane-set level parity of the GPU extraction (seam S1b) with the reference's Schnabel RANSAC on the
-    reference's sample cloud: EVERY plane libransac found is found with the same coefficients (up to the sign
-    the reference leaves arbitrary) and the same points.  The GPU search is more exhaustive (the reference stops
-    on a probability bound) and may report further small faces above min_support.
-
-    Measured: 52 of the 53 planes come out with libransac's coefficients and supports exactly (cos = 1, same d, Jaccard
-    1.0); one 771-point face gets six points that libransac gave to a neighbouring face it accepted earlier (777 points,
-    Jaccard 0.992, normal 0.8 degrees off) -- which of two touching faces takes the contested points depends on the order
-    of acceptance, in libransac on its time() seed.  (With PLADE_RANSAC_TOPUP=0 all 53 are exact.)"""
-    g = load("g8_polyhedron.npz")
-    for cloud, rc, ro, ri in ((g["target"], g["t_coef"], g["t_off"], g["t_idx"]), (g["source"], g["s_coef"], g["s_off"], g["s_idx"])):
-        coef, off, idx = ctx.extract_planes(cloud, 625)   # extract() of plade.cpp:602-635 ends at 10000 / 16 here
+def _g2_compare(planes_by_cloud, g):
+    """Per libransac plane: the best GPU plane under the ROUND-1 tolerances (|cos| > 0.9999, |delta d| < 2e-3, sign aside);
+    returns (number of libransac planes, list of (cloud, plane, Jaccard, |S_gpu|, |S_ref|) of the matched planes, list of
+    libransac planes without a match under those tolerances)."""
+    total, matched, unmatched = 0, [], []
+    for c, (rc, ro, ri) in enumerate(((g["t_coef"], g["t_off"], g["t_idx"]), (g["s_coef"], g["s_off"], g["s_idx"]))):
+        coef, off, idx = planes_by_cloud[c]
         assert len(rc) <= len(coef) <= 2 * len(rc)
         sets = [set(idx[off[p]:off[p + 1]].tolist()) for p in range(len(coef))]
-        exact = 0
         for p in range(len(rc)):
+            total += 1
             ref_set = set(ri[ro[p]:ro[p + 1]].tolist())
             cos = coef[:, :3] @ rc[p, :3]
             best, best_q = 0.0, -1
-            for q in np.nonzero(np.abs(cos) > 0.9998)[0]:
-                if abs(coef[q, 3] - rc[p, 3] * np.sign(cos[q])) > 1.5e-2:
+            for q in np.nonzero(np.abs(cos) > 0.9999)[0]:
+                if abs(coef[q, 3] - rc[p, 3] * np.sign(cos[q])) >= 2e-3:
                     continue
                 j = len(sets[q] & ref_set) / len(sets[q] | ref_set)
                 if j > best:
                     best, best_q = j, q
-            assert best > 0.95, (p, len(ref_set), best)
-            exact += len(sets[best_q]) == len(ref_set)
-        assert exact >= len(rc) - 2   # the supports are the same sets for (nearly) all planes
+            if best_q < 0:
+                # which GPU plane is it, under any tolerance?
+                j_any = max((len(sets[q] & ref_set) / len(sets[q] | ref_set), q) for q in range(len(coef)))
+                unmatched.append((c, p, len(ref_set), j_any[0], len(sets[j_any[1]]), float(abs(cos[j_any[1]]))))
+            else:
+                matched.append((c, p, best, len(sets[best_q]), len(ref_set)))
+    return total, matched, unmatched
+
+
+def test_g2_plane_sets_against_the_reference_ransac(ctx):
+    """Plane-set level parity of the GPU extraction (seam S1b, default schedule) with the reference's Schnabel RANSAC on
+    the reference's sample cloud, under the tolerances this test has had since round 1 (|cos| > 0.9999, |delta d| < 2e-3,
+    sign aside): EVERY plane libransac found is found with the same coefficients and the same points, with ONE named
+    exception that is asserted as measured -- a 771-point face gets six points that libransac gave to a neighbouring face
+    it accepted earlier (777 points, Jaccard 0.992, normal 0.8 degrees off).  Which of two touching faces takes the
+    contested points depends on the order of acceptance, in libransac on its time() seed; the best-first order of the
+    first schedule (PLADE_RANSAC_TOPUP=0, next test) reproduces all 53.  The GPU search is more exhaustive (the reference
+    stops on a probability bound) and may report further small faces above min_support."""
+    g = load("g8_polyhedron.npz")
+    # extract() of plade.cpp:602-635 ends at 10000 / 16 here
+    total, matched, unmatched = _g2_compare([ctx.extract_planes(g["target"], 625), ctx.extract_planes(g["source"], 625)], g)
+    assert total == 53
+    assert len(unmatched) <= 1, unmatched
+    for (c, p, j, n_gpu, n_ref) in matched:
+        assert j > 0.95, (c, p, j)
+    assert sum(n_gpu == n_ref and j == 1.0 for (_, _, j, n_gpu, n_ref) in matched) >= total - 1 - len(unmatched), matched
+    for (c, p, n_ref, j, n_gpu, cosv) in unmatched:   # the named exception, as measured
+        assert n_ref == 771 and j >= 0.99 and abs(n_gpu - n_ref) <= 6 and cosv > 0.9998, unmatched
+
+
+def test_g2_plane_sets_best_first_schedule_reproduces_every_plane():
+    """The same comparison with PLADE_RANSAC_TOPUP=0 (hypotheses drawn only when the pool is empty: strict best-first
+    acceptance): all 53 planes under the round-1 tolerances, all with libransac's supports exactly.  The switch is read
+    once per process, hence the child process."""
+    import json
+    import subprocess
+    import sys
+    child = r"""
+import json, os, sys
+import numpy as np
+import plade_amd
+g = np.load(os.path.join("tests", "golden", "g8_polyhedron.npz"), allow_pickle=False)
+ctx = plade_amd.Context(0, orient_normals=1)
+out = []
+for cloud in (g["target"], g["source"]):
+    coef, off, idx = ctx.extract_planes(cloud, 625)
+    out.append([coef.tolist(), off.tolist(), idx.tolist()])
+print(json.dumps(out))
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PLADE_RANSAC_TOPUP="0", PYTHONPATH=root)
+    r = subprocess.run([sys.executable, "-c", child], capture_output=True, text=True, env=env, cwd=root, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    planes = [(np.array(c, np.float32), np.array(o, np.int32), np.array(i, np.int32))
+              for c, o, i in json.loads(r.stdout.strip().splitlines()[-1])]
+    total, matched, unmatched = _g2_compare(planes, load("g8_polyhedron.npz"))
+    assert total == 53 and not unmatched, unmatched
+    assert all(j == 1.0 and n_gpu == n_ref for (_, _, j, n_gpu, n_ref) in matched), matched
 
 
 def test_g2_plane_sets_on_the_real_room_scan(ctx):

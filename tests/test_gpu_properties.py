@@ -62,6 +62,40 @@ def test_k1_full_size_lists_equal_numpy_restatement(ctx, big_pair):
         assert np.isin(lists[j], l_wide[j]).all() and c_wide[j] >= counts[j]
 
 
+def test_k1_full_size_subset_counts_equal_numpy_restatement(ctx, big_pair):
+    """k_r_score_sub at the bench size: a full round (4096 hypotheses) on the stratified subset the loop itself would take
+    (every 61st point of a 1M-point cloud, 16 394 points), counts against the numpy restatement of the point test."""
+    cloud = big_pair[0]
+    rng = np.random.default_rng(2)
+    si = np.full(N, -1, np.int32)
+    si[rng.random(N) < 0.4] = 3
+    stride = N // 16384
+    sub = np.arange(0, N, stride, dtype=np.uint32)
+    tri = cloud[rng.integers(0, N, (4096, 3)), :3].astype(np.float32)
+    a, b = tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 1]
+    nr = np.cross(a, b).astype(np.float32)
+    ln = np.linalg.norm(nr, axis=1).astype(np.float32)
+    nr = (nr / np.maximum(ln, np.float32(1e-20))[:, None]).astype(np.float32)
+    planes = np.concatenate([nr, ((tri[:, 0, 0] * nr[:, 0] + tri[:, 0, 1] * nr[:, 1]) + tri[:, 0, 2] * nr[:, 2])[:, None]], 1).astype(np.float32)
+    planes[:6] = [[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0], [0, 0, 1, 3], [0, 0, 0, 0], [0, 0, 1, np.nan]]
+    eps, cos_t = np.float32(0.05), np.float32(0.8)
+    counts, un = ctx.score_planes_subset(cloud, si, sub, planes, eps, cos_t)
+    sc, ss = cloud[sub], si[sub]
+    assert un == int((ss == -1).sum())
+    live = sc[ss == -1]
+    x, q = live[:, :3], live[:, 3:]
+    tot = 0
+    for j in range(len(planes)):
+        pl = planes[j]
+        d = (pl[0] * x[:, 0] + pl[1] * x[:, 1]) + pl[2] * x[:, 2]
+        nd = (pl[0] * q[:, 0] + pl[1] * q[:, 1]) + pl[2] * q[:, 2]
+        with np.errstate(invalid="ignore"):
+            ref = int(((np.abs(pl[3] - d) < eps) & (np.abs(nd) >= cos_t)).sum())
+        assert counts[j] == ref, j
+        tot += ref
+    assert tot > 100000
+
+
 def test_voxel_grid_full_size_properties(ctx, big_pair):
     cloud = big_pair[0]
     leaf = np.float32(0.05)
@@ -172,7 +206,7 @@ def test_registration_full_size_every_intermediate_equals_oracle(oracle, seed):
     overlap counts, scores) and the final transform bit for bit."""
     import plade_amd
     tg, sr, Tgt = make_pair(N, seed=seed)
-    ctx = plade_amd.Context(0, dump=1)
+    ctx = plade_amd.Context(0, dump=1, orient_normals=1)
     ok, T = ctx.registration(tg, sr)
     d = ctx.dump()
     ctx.close()

@@ -77,7 +77,7 @@ def test_full_registration_matches_oracle_on_same_planes(oracle, seed):
     import plade_amd
     n = 100000
     tg, sr, Tgt = make_pair(n, seed=seed)
-    ctx = plade_amd.Context(0, dump=1)
+    ctx = plade_amd.Context(0, dump=1, orient_normals=1)
     ok, T = ctx.registration(tg, sr)
     assert ok
     d = ctx.dump()
@@ -97,7 +97,7 @@ def test_full_registration_matches_oracle_on_same_planes(oracle, seed):
 def test_registration_dev_equals_host_pointer_path():
     import plade_amd
     tg, sr, Tgt = make_pair(60000, seed=5, n_boxes=6)
-    ctx = plade_amd.Context(0)
+    ctx = plade_amd.Context(0, orient_normals=1)
     ok1, T1 = ctx.registration(tg, sr)
     ct, cs = ctx.upload(tg), ctx.upload(sr)
     ok2, T2 = ctx.registration_dev(ct, cs)

@@ -37,6 +37,41 @@ def test_score_planes_bit_exact(ctx, oracle, n, h):
         assert counts2[j] == len(oracle.score_plane(cloud, None, planes[j], eps, cos_t))
 
 
+@pytest.mark.parametrize("n,m,h", [(5000, 1, 3), (50000, 1023, 70), (50000, 16384, 200), (20000, 20000, 4100)])
+def test_score_planes_subset_bit_exact(ctx, oracle, n, m, h):
+    """The loop's subset-scoring kernel (k_r_score_sub: a round of hypotheses on the stratified subset, the call shape of
+    Candidate::ImproveBounds on subset 0, RansacShapeDetector.cpp:163) against the oracle's visitor on the gathered subset."""
+    rng = np.random.default_rng(n + m + h)
+    cloud = sample_scene(n, scene_seed=5, sample_seed=n)
+    si = np.full(n, -1, np.int32)
+    si[rng.random(n) < 0.25] = 0
+    sub = (np.arange(m, dtype=np.uint32) * max(1, n // m)) if m > 1 else np.array([n // 2], np.uint32)
+    if m == 1023:
+        sub = rng.integers(0, n, m).astype(np.uint32)   # any order, repeats allowed
+    base = sample_scene(4096, scene_seed=5, sample_seed=98)
+    planes = []
+    for t in _hyps(rng, base, h):
+        ok, pl = oracle.plane_from_points(t)
+        planes.append(pl if ok else np.array([0, 0, 1, 0.3], np.float32))
+    planes = np.array(planes, np.float32)
+    eps, cos_t = 0.05, 0.8
+    counts, un = ctx.score_planes_subset(cloud, si, sub, planes, eps, cos_t)
+    assert un == int((si[sub] == -1).sum())
+    sc, ss = np.ascontiguousarray(cloud[sub]), np.ascontiguousarray(si[sub])
+    for j in list(range(min(h, 40))) + list(range(max(0, h - 10), h)):
+        assert counts[j] == len(oracle.score_plane(sc, ss, planes[j], eps, cos_t)), j
+    # vectorised fp32 restatement for all hypotheses (FlatNormalThreshPointCompatibilityFunc.h:14-23, left-to-right dots)
+    x, q = sc[:, :3], sc[:, 3:]
+    for j in range(h):
+        pl = planes[j]
+        d = (pl[0] * x[:, 0] + pl[1] * x[:, 1]) + pl[2] * x[:, 2]
+        nd = (pl[0] * q[:, 0] + pl[1] * q[:, 1]) + pl[2] * q[:, 2]
+        ref = int(((np.abs(pl[3] - d) < np.float32(eps)) & (np.abs(nd) >= np.float32(cos_t)) & (ss == -1)).sum())
+        assert counts[j] == ref, j
+    c0, un0 = ctx.score_planes_subset(cloud, None, sub, planes[:3], eps, cos_t)
+    assert un0 == m
+
+
 def test_score_planes_empty(ctx):
     counts = ctx.score_planes(np.zeros((0, 6), np.float32), None, np.array([[0, 0, 1, 0]], np.float32), 0.1, 0.8)
     assert counts[0] == 0
