@@ -6,10 +6,14 @@
 
 One "step" = one full registration(T, target, source) (code/PLADE/plade.h:58: plane extraction +
 registration) of one synthetic pair of config `Synthetic 1M-pt indoor scan pair, ~30 planes`
-(BASELINE.json configs[2]) with both clouds already resident in HBM.  One process per GPU; scan pairs
+(BASELINE.json configs[2]) with both clouds in page-locked HOST memory: the upload (H2D), the SoA conversion and
+the bounding boxes of every step are inside the timed region.  One process per GPU; scan pairs
 are independent (batch mode, code/PLADE/main.cpp:97-158), so every rank registers its own pairs with no
 data-path collective and the per-pair 4x4 results are gathered to rank 0 over RCCL at the end
-(weak scaling: work per GPU is fixed).  Rank 0 prints ONE JSON line.
+(weak scaling: work per GPU is fixed).  Several registrations are in flight per GPU (one plade_ctx + host thread
+each); `value` is the steady-state rate of that pipeline: the time from the completion of the last lead-in
+(warm-up) step to the completion of the K-th timed step, so `--steps 20` and `--steps 512` read the same.
+Rank 0 prints ONE JSON line.  `resident_rank0` is the same pipeline on clouds already resident in HBM.
 
 Extra objects on the line:
   roofline     -- the dominant kernel of the step, timed live with HIP events on the stream the kernel is
@@ -208,8 +212,10 @@ def main():
                     help="registrations in flight per GPU: independent pairs, one plade_ctx + host thread each "
                          "(a single registration is latency-bound and leaves most of the GPU idle).  0 = 8, or fewer when "
                          "the ranks of this node have to share a small CPU quota (see inflight_for_budget)")
-    ap.add_argument("--host-steps", type=int, default=384,
-                    help="steps of the extra host-buffer leg (plade_registration on page-locked host arrays, H2D inside); 0 = skip")
+    ap.add_argument("--resident-steps", type=int, default=256,
+                    help="steps of the extra resident leg (clouds uploaded once, plade_registration_dev per step); 0 = skip")
+    ap.add_argument("--host-steps", type=int, default=0, help=argparse.SUPPRESS)   # round-2 flag, ignored
+    ap.add_argument("--no-default-mode", action="store_true", help="skip the orient_normals=0 success-rate leg")
     ap.add_argument("--profiled-steps", type=int, default=8, help="registrations of the roofline leg (HIP events per launch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -242,7 +248,7 @@ def main():
     inflight_auto = args.inflight <= 0
     if inflight_auto:
         args.inflight = inflight_for_budget(_cpu_budget(), local_world)
-    M = max(1, min(args.inflight, args.steps))
+    M = max(1, args.inflight)
     if args.host_wait == "auto":
         # several registrations in flight: sleeping waits (same throughput, a third of the host CPUs, and no way to run
         # into the container's CPU quota when 8 ranks share a node); one at a time: spin for the lowest latency
@@ -265,51 +271,66 @@ def main():
         ok, T = ctxs[w].registration_dev(ct, cs)
         return ok, T
 
-    step_fn = [step]
+    # the timed path: registration(T, target, source) of code/PLADE/plade.h:58 on clouds in (page-locked) HOST memory, in
+    # batch mode (main.cpp:97-158 loops over pairs): plade_registration_next = plade_registration + the upload of the pair
+    # the same context registers next, queued on a stream of its own.  H2D, SoA conversion and bounding boxes of every
+    # step are inside the timed region.
+    for tg, sr, _ in pairs:
+        ctx.pin(tg); ctx.pin(sr)
 
-    def run_steps(first, count, out):
-        """Steps first .. first+count-1; every worker takes the next free step (a shared counter), so the
-        workers stay busy until the last step has been handed out."""
-        lock = threading.Lock()
-        nxt = [first]
+    def hstep(i, w, nxt):
+        tg, sr, _ = pairs[i % len(pairs)]
+        ntg, nsr = (pairs[nxt % len(pairs)][0], pairs[nxt % len(pairs)][1]) if nxt is not None else (None, None)
+        return ctxs[w].registration_next(tg, sr, ntg, nsr)
+
+    def rstep(i, w, nxt):
+        return step(i, w)
+
+    def run_pipeline(fn, lead, count):
+        """Steady-state throughput of the M-deep pipeline: worker w takes steps w, w + M, ... of lead + count + M steps
+        (the first `lead` fill the pipeline and are untimed, the last M keep it full until the last timed step completes);
+        the timed window runs from the completion of step number `lead` to the completion of step number lead + count,
+        i.e. EXACTLY `count` completions with the pipeline full on both sides.  Returns (seconds of the window, results of
+        the timed steps in step order, seconds from start to the last completion of all lead + count + M steps)."""
+        total = lead + count + M
+        stamps, out = [0.0] * total, [None] * total
 
         def work(w):
-            while True:
-                with lock:
-                    i = nxt[0]
-                    nxt[0] += 1
-                if i >= first + count:
-                    return
-                out[i - first] = step_fn[0](i, w)
-        if M == 1:
-            work(0)
-            return
+            for i in range(w, total, M):
+                out[i] = fn(i, w, i + M if i + M < total else None)
+                stamps[i] = time.perf_counter()
         ths = [threading.Thread(target=work, args=(w,)) for w in range(M)]
+        ts = time.perf_counter()
         for t in ths:
             t.start()
         for t in ths:
             t.join()
+        done = sorted(stamps)
+        window = done[lead + count - 1] - done[lead - 1]
+        # the timed steps = the `count` steps that completed inside the window
+        order = sorted(range(total), key=lambda i: stamps[i])[lead:lead + count]
+        return window, [out[i] for i in sorted(order)], sorted(order), done[-1] - ts
 
-    # warm-up: W steps in total, but every worker (context) at least one, so that no first-use allocation or
-    # graph capture falls into the timed region
-    per_worker = max(len(pairs), -(-args.warmup // M))   # and every distinct pair once per worker (cloud sizes differ)
-
+    # warm-up: every worker (context) registers every distinct pair once through BOTH entry points, so that no first-use
+    # allocation or graph capture falls into the timed region; the W warm-up steps the driver asks for are the lead-in
+    # of the pipelined run below (at least one per context in flight)
     def warm_worker(w):
-        for r in range(per_worker):
+        for r in range(len(pairs)):
             step(r, w)
+            hstep(r, w, None)
     wths = [threading.Thread(target=warm_worker, args=(w,)) for w in range(M)]
     for t in wths:
         t.start()
     for t in wths:
         t.join()
+    lead = max(args.warmup, M)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     cpu0, thr0 = time.process_time(), _cgroup_throttle()
-    t0 = time.perf_counter()
-    timed = [None] * args.steps
-    run_steps(0, args.steps, timed)
+    t_begin = time.perf_counter()
+    elapsed, timed, timed_ids, span = run_pipeline(hstep, lead, args.steps)
     cpu1, thr1 = time.process_time(), _cgroup_throttle()
     oks = [bool(r[0]) for r in timed]
     results = [r[1] for r in timed]
@@ -323,51 +344,63 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    bracketed = time.perf_counter() - t_begin
+    tmax = torch.tensor([elapsed, bracketed], dtype=torch.float64, device=dev)
     okt = torch.tensor([n_ok], dtype=torch.int64, device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(okt, op=dist.ReduceOp.SUM)
-    elapsed = float(tmax.item())
+    elapsed, bracketed = float(tmax[0].item()), float(tmax[1].item())
     total_ok = int(okt.item())
 
     # every registration of the same pair, whichever context ran it, must return the same bits
-    identical = all(np.array_equal(results[i], results[i % len(pairs)]) for i in range(len(results)))
+    ref_result = {}
+    for k in range(len(results)):
+        ref_result.setdefault(timed_ids[k] % len(pairs), results[k])
+    identical = all(np.array_equal(results[k], ref_result[timed_ids[k] % len(pairs)]) for k in range(len(results)))
     # accuracy of the timed registrations on this rank vs the generator's ground truth
-    errs = [float(np.linalg.norm(results[i].astype(np.float64) - pairs[i % len(pairs)][2])) for i in range(len(results))]
+    errs = [float(np.linalg.norm(results[k].astype(np.float64) - pairs[timed_ids[k] % len(pairs)][2])) for k in range(len(results))]
 
-    # ---- host-buffer leg (SURVEY.md 8d's timed region: registration(T, target, source) of plade.h:58 on clouds in HOST
-    #      memory, H2D and D2H inside): plade_registration on the caller's page-locked arrays (plade_host_pin, done once
-    #      outside the timed region like the allocation of any staging buffer), same contexts in flight, so the upload of
-    #      one registration overlaps the kernels of the others.  Reported next to `value`, never as `value`.
-    host_leg = None
-    if args.host_steps > 0:
-        for tg, sr, _ in pairs:
-            ctx.pin(tg); ctx.pin(sr)
+    # ---- resident leg (clouds already in HBM, plade_registration_dev): the same pipeline without the uploads, reported
+    #      next to `value`
+    resident_leg = None
+    if args.resident_steps > 0:
+        r_el, r_res, r_ids, _ = run_pipeline(rstep, M, args.resident_steps)
+        torch.cuda.synchronize()
+        same = all(np.array_equal(r_res[k][1], ref_result.get(r_ids[k] % len(pairs), r_res[k][1])) for k in range(len(r_res)))
+        resident_leg = {"value": args.resident_steps / r_el, "unit": "registrations/s (this rank)", "steps": args.resident_steps,
+                        "ms_per_step": r_el / args.resident_steps * 1e3, "identical_to_host_cloud_results": bool(same),
+                        "note": "clouds resident in HBM (plade_cloud_upload once, plade_registration_dev per step): no H2D, no SoA "
+                                "conversion, no bounding box in the step"}
+    mb = sum(tg.nbytes + sr.nbytes for tg, sr, _ in pairs) / len(pairs) / 1e6
+    host_leg = {"h2d_MB_per_step": mb, "pcie_GB_per_s": mb * 1e-3 * args.steps / elapsed,
+                "bracketed_value": (lead + args.steps + M) / bracketed if bracketed > 0 else None,
+                "bracketed_note": "all lead-in + timed + tail steps of this rank over the barrier-to-barrier time (fill and drain of "
+                                  "the pipeline and the result gather inside)"}
 
-        def hstep(i, w=0):
-            tg, sr, _ = pairs[i % len(pairs)]
-            return ctxs[w].registration(tg, sr)
-        step_fn[0] = hstep
-        warm = [None] * (M * len(pairs))
-        run_steps(0, len(warm), warm)          # every context once per pair: its upload buffers exist
-        torch.cuda.synchronize()
-        th0 = time.perf_counter()
-        hres = [None] * args.host_steps
-        run_steps(0, args.host_steps, hres)
-        torch.cuda.synchronize()
-        h_el = time.perf_counter() - th0
-        step_fn[0] = step
-        same = all(np.array_equal(hres[i][1], results[i % len(pairs)]) for i in range(len(hres)))
-        mb = sum(tg.nbytes + sr.nbytes for tg, sr, _ in pairs) / len(pairs) / 1e6
-        host_leg = {"value": args.host_steps / h_el, "unit": "registrations/s (this rank)", "steps": args.host_steps,
-                    "ms_per_step": h_el / args.host_steps * 1e3, "h2d_MB_per_step": mb,
-                    "pcie_GB_per_s": mb * 1e-3 * args.host_steps / h_el,
-                    "identical_to_resident_results": bool(same),
-                    "note": "clouds in page-locked host memory, plade_registration (H2D + SoA conversion + bounding box inside)"}
-        for tg, sr, _ in pairs:
-            ctx.unpin(tg); ctx.unpin(sr)
+    # ---- the library's shipped default on the same scenes: orient_normals = 0 (reference behaviour)
+    default_mode = None
+    if rank == 0 and not args.no_default_mode:
+        dctx = plade_amd.Context(local_rank, host_wait=host_wait)          # plade_default_params: orient_normals = 0
+        good, tried = 0, 0
+        for k, (tg, sr, Tgt) in enumerate(pairs):
+            ok, T = dctx.registration(tg, sr)
+            tried += 1
+            good += bool(ok and np.linalg.norm(T.astype(np.float64) - Tgt) < 5e-2)
+        small = 0
+        for sd in range(8):
+            tg, sr, Tgt = make_pair(200000, seed=1000 + sd)
+            ok, T = dctx.registration(tg, sr)
+            small += bool(ok and np.linalg.norm(T.astype(np.float64) - Tgt) < 5e-2)
+        dctx.close()
+        default_mode = {"orient_normals": 0, "bench_pairs_registered": good, "bench_pairs": tried,
+                        "extra_200k_pairs_registered": small, "extra_200k_pairs": 8,
+                        "criterion": "ok and |T - T_ground_truth|_F < 5e-2",
+                        "note": "the reference leaves plane normals unoriented (plane_extraction.cpp:43-58 is a NaN no-op); a "
+                                "Manhattan scene then registers only when three independent sign bits agree (about 1 in 8)"}
+
+    for tg, sr, _ in pairs:
+        ctx.unpin(tg); ctx.unpin(sr)
 
     # ---- roofline leg: one extra profiled step (HIP events on the ctx stream around every launch) ----
     roofline = None
@@ -498,7 +531,10 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"Synthetic {args.points}-pt indoor scan pair, ~30 planes (BASELINE configs[2]); "
-                                   "full registration(T,target,source) = plane extraction + registration, clouds resident in HBM; "
+                                   "full registration(T,target,source) of plade.h:58 = plane extraction + registration on clouds in "
+                                   "page-locked HOST memory, batch mode (plade_registration_next: H2D + SoA conversion + bounding boxes of "
+                                   "every step inside the timed region, the next pair's upload queued under the current pair's kernels); "
+                                   "timed window = EXACTLY `steps` completions of the full pipeline (steady state, SURVEY 8d); "
                                    "plade_params.orient_normals=1 (planes oriented like their inliers' normals: the generator's "
                                    "Manhattan scenes need it, DESIGN.md section 2); CPU baseline applies the same rule",
                        "points_per_cloud": args.points, "pairs_per_rank": args.pairs,
@@ -508,12 +544,17 @@ def main():
             "registrations_ok": total_ok,
             "results_bit_identical_per_pair_rank0": bool(identical),
             "max_frobenius_vs_ground_truth_rank0": max(errs) if errs else None,
-            "host_rank0": {"cpu_seconds_per_step": (cpu1 - cpu0) / args.steps,
-                           "busy_host_threads_avg": (cpu1 - cpu0) / max(elapsed, 1e-9),
+            "host_rank0": {"cpu_seconds_per_step": (cpu1 - cpu0) / (lead + args.steps + M),
+                           "busy_host_threads_avg": (cpu1 - cpu0) / max(span, 1e-9),
                            "cpu_budget": _cpu_budget(),
                            "cgroup_throttled_periods": (thr1[0] - thr0[0]) if thr0 and thr1 else None,
                            "cgroup_throttled_usec": (thr1[1] - thr0[1]) if thr0 and thr1 else None},
             "host_buffers_rank0": host_leg,
+            "resident_rank0": resident_leg,
+            "default_mode_rank0": default_mode,
+            "pipeline": {"lead_in_steps": lead, "timed_steps": args.steps, "tail_steps": M,
+                         "timing": "completion of step #lead_in .. completion of step #(lead_in + steps), per rank, MAX over ranks; "
+                                   "barrier + torch.cuda.synchronize() before the first and after the last step of the run"},
             "roofline": roofline,
             "cpu_baseline": cpu,
             "stage_seconds_profiled_step": stage_times,

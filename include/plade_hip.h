@@ -153,6 +153,16 @@ int plade_registration_planes(plade_ctx *ctx, const float *tgt_pos_nrm, uint32_t
 /* plade.h:58-61  registration(T, target, source): auto-tuned plane extraction (plade.cpp:602-662) */
 int plade_registration(plade_ctx *ctx, const float *tgt_pos_nrm, uint32_t n_t,
                        const float *src_pos_nrm, uint32_t n_s, float *T16);
+/* The same call in BATCH mode (code/PLADE/main.cpp:97-158: a plain loop of registration() over the pairs of
+ * file_pairs.txt).  Registers (tgt, src) exactly like plade_registration and, before it starts computing, queues the
+ * upload of the pair the NEXT call on this ctx will be handed (next_*; NULL / 0 = none) on a stream of its own, so that
+ * the PCIe transfer of pair i+1 runs under the kernels of pair i.  The next call recognises its clouds by pointer and size
+ * and skips its upload; any other pair is uploaded as usual.  The caller must leave the next_* buffers untouched until
+ * that call (page-lock them with plade_host_pin for a truly asynchronous copy).  Results are identical to
+ * plade_registration's. */
+int plade_registration_next(plade_ctx *ctx, const float *tgt_pos_nrm, uint32_t n_t,
+                            const float *src_pos_nrm, uint32_t n_s, const float *next_tgt_pos_nrm,
+                            uint32_t next_n_t, const float *next_src_pos_nrm, uint32_t next_n_s, float *T16);
 /* plade.h:91-96  registration(T, target, source, min_support_target, min_support_source) */
 int plade_registration_minsupport(plade_ctx *ctx, const float *tgt_pos_nrm, uint32_t n_t,
                                   const float *src_pos_nrm, uint32_t n_s, int32_t min_support_t,

@@ -21,7 +21,7 @@ ABI_SYMBOLS = [
     "plade_overlap_counts", "plade_average_spacing", "plade_voxel_downsample", "plade_registration_planes",
     "plade_registration", "plade_registration_minsupport", "plade_cloud_upload", "plade_cloud_free",
     "plade_registration_dev", "plade_dump_get", "plade_stats_get", "plade_kernel_time", "plade_plane_component",
-    "plade_sort_pairs", "plade_host_pin", "plade_host_unpin", "plade_score_planes_subset",
+    "plade_sort_pairs", "plade_host_pin", "plade_host_unpin", "plade_score_planes_subset", "plade_registration_next",
 ]
 
 
@@ -76,6 +76,7 @@ def load_library(path=LIB_PATH):
     sig("plade_voxel_downsample", argtypes=[p, p, u32, u32, f, p, p])
     sig("plade_registration_planes", argtypes=[p, p, u32, p, u32, p, p, p, u32, p, p, p, u32, p])
     sig("plade_registration", argtypes=[p, p, u32, p, u32, p])
+    sig("plade_registration_next", argtypes=[p, p, u32, p, u32, p, u32, p, u32, p])
     sig("plade_registration_minsupport", argtypes=[p, p, u32, p, u32, i32, i32, p])
     sig("plade_cloud_upload", argtypes=[p, p, u32, C.POINTER(p)])
     sig("plade_cloud_free", argtypes=[p, p])
@@ -293,6 +294,18 @@ class Context:
         T = np.zeros((4, 4), np.float32)
         rc = self._check(self.L.plade_registration(self.h, _ptr(tgt), len(tgt), _ptr(src), len(src), _ptr(T)),
                          allow=(PLADE_EFAIL,))
+        return rc == 0, T
+
+    def registration_next(self, tgt, src, next_tgt=None, next_src=None):
+        """plade.h:58 in batch mode: registers (tgt, src) and starts the upload of the pair the next call will be handed.
+        The arrays must be C-contiguous float32 and stay alive and unchanged until that call."""
+        for a in (tgt, src, next_tgt, next_src):
+            assert a is None or (a.dtype == np.float32 and a.flags["C_CONTIGUOUS"])
+        T = np.zeros((4, 4), np.float32)
+        nt, ns = (next_tgt, next_src) if next_tgt is not None and next_src is not None else (None, None)
+        rc = self._check(self.L.plade_registration_next(self.h, _ptr(tgt), len(tgt), _ptr(src), len(src), _ptr(nt),
+                                                        len(nt) if nt is not None else 0, _ptr(ns),
+                                                        len(ns) if ns is not None else 0, _ptr(T)), allow=(PLADE_EFAIL,))
         return rc == 0, T
 
     def registration_minsupport(self, tgt, src, ms_t, ms_s):

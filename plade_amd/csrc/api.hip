@@ -44,6 +44,7 @@ extern "C" void plade_ctx_destroy(plade_ctx *ctx) {
     if (ctx->reg_work) plade::registration_work_destroy(ctx->reg_work);
     if (ctx->ransac_work) plade::ransac_work_destroy(ctx->ransac_work);
     (void)hipStreamDestroy(ctx->stream);
+    if (ctx->pf.stream) { (void)hipStreamSynchronize(ctx->pf.stream); (void)hipStreamDestroy(ctx->pf.stream); }
     delete ctx;
     if (getenv("PLADE_DEBUG_ALLOC")) {
         plade::AllocStats &as = plade::alloc_stats();

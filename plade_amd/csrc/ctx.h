@@ -68,6 +68,17 @@ struct plade_ctx {
     // device copies of the clouds the host-pointer entry points register (grow-only, reused from call to call: a
     // hipMalloc / hipFree pair per call costs more than the upload itself, and hipFree synchronises the device)
     plade::CloudDev up_tgt, up_src;
+    // batch mode (plade_registration_next): the NEXT pair's clouds are uploaded on a stream of their own while the current
+    // pair registers; the next call finds them here and swaps them in
+    struct Prefetch {
+        hipStream_t stream = nullptr;
+        plade::CloudDev tgt, src;
+        const float *ptr_t = nullptr, *ptr_s = nullptr;
+        uint32_t n_t = 0, n_s = 0;
+        bool valid = false;
+        plade::HBuf<int> h;      // page-locked: [0..8) init pattern, then 8 ints per bounding box read back
+        plade::DBuf<int> d;      // 8 ints per box being reduced
+    } pf;
     plade_params params;
     std::string last_error;
     std::map<std::string, std::vector<char>> dump;
@@ -275,5 +286,9 @@ struct StageTimer {
 // ---- kernels / stages implemented across the .hip files ----------------------------------
 // cloud upload: AoS N x 6 (host) -> SoA on device
 void cloud_upload(plade_ctx *ctx, const float *pos_nrm, uint32_t n, CloudDev &out);
+void cloud_upload_pair(plade_ctx *ctx, const float *tgt, uint32_t n_t, CloudDev &out_t, const float *src, uint32_t n_s, CloudDev &out_s);
+// batch mode: queue the upload of the NEXT pair on the context's prefetch stream / take a finished prefetch over
+void cloud_prefetch_pair(plade_ctx *ctx, const float *tgt, uint32_t n_t, const float *src, uint32_t n_s);
+bool cloud_take_prefetched(plade_ctx *ctx, const float *tgt, uint32_t n_t, const float *src, uint32_t n_s);
 
 }  // namespace plade

@@ -420,19 +420,22 @@ __global__ __launch_bounds__(256) void k_minmax3_v(const float *__restrict__ xyz
     block_minmax_commit<3>(mn, mx, out6, s_lds);
 }
 
-void bbox_host(plade_ctx *ctx, const float *d_xyz, uint32_t n, uint32_t stride, float mn[3], float mx[3]) {
-    int init[8];
+// Queues the bounding-box reduction of a strided xyz array on `st`: d_slot (8 ints on the device) is initialised from
+// h_init (8 ints of page-locked memory holding bbox_init_pattern()), reduced into, and copied to h_out (8 ints of
+// page-locked memory), which bbox_decode() reads once `st` has got there.
+void bbox_init_pattern(int init[8]) {
     float pinf = INFINITY, ninf = -INFINITY;
     int a, b;
     memcpy(&a, &pinf, 4); memcpy(&b, &ninf, 4);
     for (int k = 0; k < 3; ++k) { init[k] = a; init[3 + k] = b ^ 0x7fffffff; }
     init[6] = init[7] = 0;
-    int *d = reinterpret_cast<int *>(ctx->scratch[3].ensure(64));
-    ctx->h2d(d, init, 32);
-    if (n) hipLaunchKernelGGL(k_minmax3_v, dim3(std::min(cdiv(n, 1024), 1024u)), dim3(256), 0, ctx->stream, d_xyz, n, stride, d);
-    int out[8];
-    ctx->d2h(out, d, 32);
-    ctx->sync();
+}
+void bbox_async(hipStream_t st, const float *d_xyz, uint32_t n, uint32_t stride, int *d_slot, const int *h_init, int *h_out) {
+    HIP_TRY(hipMemcpyAsync(d_slot, h_init, 32, hipMemcpyHostToDevice, st));
+    if (n) hipLaunchKernelGGL(k_minmax3_v, dim3(std::min(cdiv(n, 1024), 1024u)), dim3(256), 0, st, d_xyz, n, stride, d_slot);
+    HIP_TRY(hipMemcpyAsync(h_out, d_slot, 32, hipMemcpyDeviceToHost, st));
+}
+void bbox_decode(const int out[8], float mn[3], float mx[3]) {
     // every grid, key and threshold downstream is derived from the coordinates: refuse what the reference's
     // kd-trees and voxel grids could not digest either, instead of looping on a NaN extent
     PLADE_REQUIRE(out[6] == 0, PLADE_EINVAL, "the point cloud contains non-finite coordinates (NaN or infinity)");
@@ -442,6 +445,18 @@ void bbox_host(plade_ctx *ctx, const float *d_xyz, uint32_t n, uint32_t stride, 
         memcpy(&f, &v, 4);
         if (k < 3) mn[k] = f; else mx[k - 3] = f;
     }
+}
+
+void bbox_host(plade_ctx *ctx, const float *d_xyz, uint32_t n, uint32_t stride, float mn[3], float mx[3]) {
+    int init[8];
+    bbox_init_pattern(init);
+    int *d = reinterpret_cast<int *>(ctx->scratch[3].ensure(64));
+    ctx->h2d(d, init, 32);
+    if (n) hipLaunchKernelGGL(k_minmax3_v, dim3(std::min(cdiv(n, 1024), 1024u)), dim3(256), 0, ctx->stream, d_xyz, n, stride, d);
+    int out[8];
+    ctx->d2h(out, d, 32);
+    ctx->sync();
+    bbox_decode(out, mn, mx);
 }
 }  // namespace plade
 

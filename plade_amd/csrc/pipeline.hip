@@ -517,8 +517,7 @@ extern "C" int plade_registration_planes(plade_ctx *ctx, const float *tgt_pos_nr
         CloudDev &tgt = ctx->up_tgt, &src = ctx->up_src;
         {
             StageTimer t(ctx, "t_upload");
-            cloud_upload(ctx, tgt_pos_nrm, n_t, tgt);
-            cloud_upload(ctx, src_pos_nrm, n_s, src);
+            cloud_upload_pair(ctx, tgt_pos_nrm, n_t, tgt, src_pos_nrm, n_s, src);
         }
         PlaneSetView tp, sp;
         tp.coef = tgt_planes; tp.offsets = tgt_offsets; tp.idx = tgt_idx; tp.P = p_t;

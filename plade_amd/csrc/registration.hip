@@ -312,8 +312,34 @@ extern "C" int plade_registration(plade_ctx *ctx, const float *tgt_pos_nrm, uint
         CloudDev &tgt = ctx->up_tgt, &src = ctx->up_src;
         {
             StageTimer t(ctx, "t_upload");
-            cloud_upload(ctx, tgt_pos_nrm, n_t, tgt);
-            cloud_upload(ctx, src_pos_nrm, n_s, src);
+            cloud_upload_pair(ctx, tgt_pos_nrm, n_t, tgt, src_pos_nrm, n_s, src);
+        }
+        return register_clouds(ctx, tgt, src, 0, 0, true, T16);
+    });
+}
+
+// Batch mode (code/PLADE/main.cpp:97-158 is a loop over pairs): plade_registration of THIS pair, with the upload of the
+// NEXT pair started first on the prefetch stream, so that its PCIe transfer runs under this pair's kernels.
+extern "C" int plade_registration_next(plade_ctx *ctx, const float *tgt_pos_nrm, uint32_t n_t, const float *src_pos_nrm,
+                                       uint32_t n_s, const float *next_tgt_pos_nrm, uint32_t next_n_t,
+                                       const float *next_src_pos_nrm, uint32_t next_n_s, float *T16) {
+    return guarded(ctx, [&]() -> int {
+        PLADE_REQUIRE(tgt_pos_nrm && src_pos_nrm && T16 && n_t && n_s, PLADE_EINVAL, "plade_registration_next: bad argument");
+        ctx->stats.clear();
+        ctx->dump.clear();
+        ctx->last_error.clear();
+        CloudDev &tgt = ctx->up_tgt, &src = ctx->up_src;
+        {
+            StageTimer t(ctx, "t_upload");
+            Clock::time_point t0 = Clock::now();
+            if (!cloud_take_prefetched(ctx, tgt_pos_nrm, n_t, src_pos_nrm, n_s)) {
+                cloud_upload_pair(ctx, tgt_pos_nrm, n_t, tgt, src_pos_nrm, n_s, src);
+            } else ctx->stats.add("upload_prefetched", 1);
+            ctx->stats.add("t_upload_take", secs_since(t0));
+            t0 = Clock::now();
+            if (next_tgt_pos_nrm && next_src_pos_nrm && next_n_t && next_n_s)
+                cloud_prefetch_pair(ctx, next_tgt_pos_nrm, next_n_t, next_src_pos_nrm, next_n_s);
+            ctx->stats.add("t_upload_submit", secs_since(t0));
         }
         return register_clouds(ctx, tgt, src, 0, 0, true, T16);
     });
@@ -329,8 +355,7 @@ extern "C" int plade_registration_minsupport(plade_ctx *ctx, const float *tgt_po
         ctx->dump.clear();
         ctx->last_error.clear();
         CloudDev &tgt = ctx->up_tgt, &src = ctx->up_src;
-        cloud_upload(ctx, tgt_pos_nrm, n_t, tgt);
-        cloud_upload(ctx, src_pos_nrm, n_s, src);
+        cloud_upload_pair(ctx, tgt_pos_nrm, n_t, tgt, src_pos_nrm, n_s, src);
         return register_clouds(ctx, tgt, src, min_support_t, min_support_s, false, T16);
     });
 }

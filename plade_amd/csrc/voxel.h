@@ -31,5 +31,9 @@ float average_spacing_dev(plade_ctx *ctx, const float *d_aos, uint32_t stride_f,
                           const float *bbmax, int k, uint32_t samples, TargetGrid &grid);
 // min/max of a strided device xyz array, returned on the host
 void bbox_host(plade_ctx *ctx, const float *d_xyz, uint32_t n, uint32_t stride, float mn[3], float mx[3]);
+// the same in two halves for uploads that run ahead on their own stream (cloud.hip): see k_voxel.hip
+void bbox_init_pattern(int init[8]);
+void bbox_async(hipStream_t st, const float *d_xyz, uint32_t n, uint32_t stride, int *d_slot, const int *h_init, int *h_out);
+void bbox_decode(const int out[8], float mn[3], float mx[3]);
 
 }  // namespace plade

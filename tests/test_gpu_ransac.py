@@ -149,3 +149,39 @@ print(json.dumps(out))
             assert abs(x - y) <= 0.01 * max(x, y), (seed, a["supports"][:8], b["supports"][:8])
         assert abs(len(a["supports"]) - len(b["supports"])) <= 4
         assert a["iterations"] <= b["iterations"] + 3   # usually fewer (1M-point pairs: 5 instead of 7), never many more
+
+
+def test_batch_mode_prefetch_returns_the_bits_of_the_plain_call():
+    """plade_registration_next (plade.h:58 in batch mode: the next pair's upload runs under the current pair's kernels):
+    same transforms as plade_registration, the prefetched copy is the one used, and a call that is handed another pair
+    than the one announced falls back to its own upload."""
+    import plade_amd
+    pairs = [make_pair(80000, seed=s)[:2] for s in (3, 4, 5)]
+    pairs = [(np.ascontiguousarray(a), np.ascontiguousarray(b)) for a, b in pairs]
+    ctx = plade_amd.Context(0, orient_normals=1)
+    want = [ctx.registration(tg, sr) for tg, sr in pairs]
+    for hw in (0, 1):
+        ctx.set_params(host_wait=hw)
+        got, used = [], []
+        for k, (tg, sr) in enumerate(pairs):
+            nxt = pairs[k + 1] if k + 1 < len(pairs) else (None, None)
+            got.append(ctx.registration_next(tg, sr, nxt[0], nxt[1]))
+            used.append(ctx.stats().get("upload_prefetched", 0.0))
+        assert used == [0.0, 1.0, 1.0]
+        for (ok, T), (ok2, T2) in zip(want, got):
+            assert ok and ok2 and np.array_equal(T, T2)
+    # announced pair 1, handed pair 2: own upload, right answer; the stale prefetch is dropped
+    ctx.registration_next(pairs[0][0], pairs[0][1], pairs[1][0], pairs[1][1])
+    ok, T = ctx.registration_next(pairs[2][0], pairs[2][1])
+    assert ctx.stats().get("upload_prefetched", 0.0) == 0.0 and ok and np.array_equal(T, want[2][1])
+    ok, T = ctx.registration(pairs[1][0], pairs[1][1])
+    assert ok and np.array_equal(T, want[1][1])
+    # a NaN in an announced cloud is refused when that cloud's turn comes, as the plain call refuses it
+    bad = pairs[1][0].copy()
+    bad[7, 1] = np.nan
+    ctx.registration_next(pairs[0][0], pairs[0][1], bad, pairs[1][1])
+    with pytest.raises(plade_amd.PladeError):
+        ctx.registration_next(bad, pairs[1][1])
+    ok, T = ctx.registration(pairs[0][0], pairs[0][1])
+    assert ok and np.array_equal(T, want[0][1])
+    ctx.close()
