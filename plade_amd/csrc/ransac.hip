@@ -527,10 +527,12 @@ __global__ __launch_bounds__(TPB) void k_r_score_sub(const RArgs A) {
     for (uint32_t hh = 0; hh < HCHUNK; ++hh) {
         const float4 pl = s_pl[hh];
         uint32_t c = 0;
+        if (pl.w == pl.w) {   // uniform; a draw that gave no verified plane carries a NaN distance: nothing is compatible with it
 #pragma unroll
-        for (int k = 0; k < PPT; ++k) {
-            const bool in = t.valid[k] && compatible(pl, t.px[k], t.py[k], t.pz[k], t.qx[k], t.qy[k], t.qz[k], eps, cos_t);
-            c += (uint32_t)__popcll(__ballot(in));
+            for (int k = 0; k < PPT; ++k) {
+                const bool in = t.valid[k] && compatible(pl, t.px[k], t.py[k], t.pz[k], t.qx[k], t.qy[k], t.qz[k], eps, cos_t);
+                c += (uint32_t)__popcll(__ballot(in));
+            }
         }
         if (lane == 0) s_cnt[wave][hh] = c;
     }
@@ -1349,94 +1351,115 @@ __global__ __launch_bounds__(64) void k_r_decide(const RArgs A) {
     RState *S = C.st;
     RResult *R = C.res;
     if (!S->active) return;
-    // the chains' results are fetched by all lanes at once (one lane alone would pay a DRAM/L2 round trip per field)
+    // Everything the sequential part touches is fetched by all lanes at once (one lane alone pays a round trip to L2 per
+    // field, and every store to the state forces the next load to be re-issued): the chains' results, the pool, the scalars.
     __shared__ PlaneState s_st[R_B][4];
-    const uint32_t nc_all = S->done ? 0u : S->nc;
+    __shared__ float4 s_pool_pl[R_TOP], s_pool_pos[R_TOP];
+    __shared__ uint32_t s_batch[R_B], s_keep_pos[R_TOP];
+    const uint32_t done_in = S->done, nc_all = done_in ? 0u : S->nc, np = S->npool;
+    const uint32_t min_support = S->min_support, orient = S->orient;
+    uint32_t n_remaining = S->n_remaining, n_acc = S->n_acc, out_off = S->out_off, n_accepts = S->n_accepts, err = S->err, done = done_in;
+    float drawn = S->drawn;
     {
         constexpr int WORDS = sizeof(PlaneState) / 4;
         for (uint32_t i = threadIdx.x; i < nc_all * 4 * WORDS; i += 64) {
             const uint32_t b = i / (4 * WORDS), r = i % (4 * WORDS);
             reinterpret_cast<uint32_t *>(&s_st[b][0])[r] = reinterpret_cast<const uint32_t *>(&chain_of(C, b).hdr->st[0])[r];
         }
+        if (nc_all) {
+            if (threadIdx.x < np && threadIdx.x < R_TOP) { s_pool_pl[threadIdx.x] = S->pool_pl[threadIdx.x]; s_pool_pos[threadIdx.x] = S->pool_pos[threadIdx.x]; }
+            if (threadIdx.x < nc_all) s_batch[threadIdx.x] = S->batch_idx[threadIdx.x];
+        }
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-    const uint32_t nc = nc_all;
     uint32_t n_aj = 0;
-    for (uint32_t b = 0; b < nc; ++b) {
-        const PlaneState *st = s_st[b];
-        S->n_accepts += 1;
-        if (st[0].err == 1) { S->err = 1; S->done = 1; break; }   // connected-component bitmap too large
-        int final_slot = 0, stop = 4;
-        {
-            double newScore = st[0].wscore;
-            for (int fittingIter = 1; fittingIter <= 3; ++fittingIter) {
-                const double oldScore = newScore;
-                if (st[fittingIter - 1].n_kept < 3 || st[fittingIter].err) { stop = fittingIter; break; }   // LSFit impossible
-                newScore = st[fittingIter].wscore;
-                const uint32_t newSize = st[fittingIter].n_kept;
-                if (newScore > oldScore && newSize > S->min_support) final_slot = fittingIter;  // clone.Clone(&candidates.back())
-                if (!(newScore > oldScore)) { stop = fittingIter; break; }
+    if (threadIdx.x == 0) {
+        uint32_t n_final[4] = {0, 0, 0, 0}, n_stop[5] = {0, 0, 0, 0, 0};
+        for (uint32_t b = 0; b < nc_all; ++b) {
+            const PlaneState *st = s_st[b];
+            n_accepts += 1;
+            if (st[0].err == 1) { err = 1; done = 1; break; }   // connected-component bitmap too large
+            int final_slot = 0, stop = 4;
+            {
+                double newScore = st[0].wscore;
+                for (int fittingIter = 1; fittingIter <= 3; ++fittingIter) {
+                    const double oldScore = newScore;
+                    if (st[fittingIter - 1].n_kept < 3 || st[fittingIter].err) { stop = fittingIter; break; }   // LSFit impossible
+                    newScore = st[fittingIter].wscore;
+                    const uint32_t newSize = st[fittingIter].n_kept;
+                    if (newScore > oldScore && newSize > min_support) final_slot = fittingIter;  // clone.Clone(&candidates.back())
+                    if (!(newScore > oldScore)) { stop = fittingIter; break; }
+                }
             }
-        }
-        S->n_final[final_slot] += 1;
-        S->n_stop[stop] += 1;
-        const PlaneState &cs = st[final_slot];
-        const uint32_t cand_size = cs.n_kept;
-        if (cand_size == 0) continue;
-        if (S->n_acc >= R_MAXP) { S->err = 3; S->done = 1; break; }
-        const uint32_t id = S->n_acc;
-        S->aj_chain[n_aj] = b; S->aj_slot[n_aj] = (uint32_t)final_slot; S->aj_id[n_aj] = (int32_t)id; S->aj_out[n_aj] = 0xffffffffu;
-        const float frac = 1.f - (cand_size / float(S->n_remaining));
-        S->drawn = frac * frac * frac * S->drawn;    // std::pow(1.f - |S| / n, 3.f) * drawnCandidates
-        S->n_remaining -= min(S->n_remaining, cand_size);
-        // plane_extraction.cpp:134-149: shapes below min_support are skipped, d = -n.p with n re-normalised
-        S->acc_support[id] = 0;
-        S->acc_offset[id] = S->out_off;
-        if (cand_size >= S->min_support) {
-            float nn[3] = {cs.n[0], cs.n[1], cs.n[2]};
-            float l = nn[0] * nn[0];
-            l += nn[1] * nn[1];
-            l += nn[2] * nn[2];
-            l = sqrtf(l);
-            if (l > 0) { nn[0] /= l; nn[1] /= l; nn[2] /= l; }
-            float d = -(nn[0] * cs.pos[0] + nn[1] * cs.pos[1] + nn[2] * cs.pos[2]);
-            if (S->orient) {  // mean inlier normal (the intent of plane_extraction.cpp:43-58)
-                if (cs.nsum[0] * nn[0] + cs.nsum[1] * nn[1] + cs.nsum[2] * nn[2] < 0) { nn[0] = -nn[0]; nn[1] = -nn[1]; nn[2] = -nn[2]; d = -d; }
+            n_final[final_slot] += 1;
+            n_stop[stop] += 1;
+            const PlaneState &cs = st[final_slot];
+            const uint32_t cand_size = cs.n_kept;
+            if (cand_size == 0) continue;
+            if (n_acc >= R_MAXP) { err = 3; done = 1; break; }
+            const uint32_t id = n_acc;
+            S->aj_chain[n_aj] = b; S->aj_slot[n_aj] = (uint32_t)final_slot; S->aj_id[n_aj] = (int32_t)id;
+            uint32_t aj_out = 0xffffffffu;
+            const float frac = 1.f - (cand_size / float(n_remaining));
+            drawn = frac * frac * frac * drawn;    // std::pow(1.f - |S| / n, 3.f) * drawnCandidates
+            n_remaining -= min(n_remaining, cand_size);
+            // plane_extraction.cpp:134-149: shapes below min_support are skipped, d = -n.p with n re-normalised
+            uint32_t support = 0;
+            if (cand_size >= min_support) {
+                float nn[3] = {cs.n[0], cs.n[1], cs.n[2]};
+                float l = nn[0] * nn[0];
+                l += nn[1] * nn[1];
+                l += nn[2] * nn[2];
+                l = sqrtf(l);
+                if (l > 0) { nn[0] /= l; nn[1] /= l; nn[2] /= l; }
+                float d = -(nn[0] * cs.pos[0] + nn[1] * cs.pos[1] + nn[2] * cs.pos[2]);
+                if (orient) {  // mean inlier normal (the intent of plane_extraction.cpp:43-58)
+                    if (cs.nsum[0] * nn[0] + cs.nsum[1] * nn[1] + cs.nsum[2] * nn[2] < 0) { nn[0] = -nn[0]; nn[1] = -nn[1]; nn[2] = -nn[2]; d = -d; }
+                }
+                S->acc_coef[id][0] = nn[0]; S->acc_coef[id][1] = nn[1]; S->acc_coef[id][2] = nn[2]; S->acc_coef[id][3] = d;
+                support = cand_size;
+                aj_out = out_off;
             }
-            S->acc_coef[id][0] = nn[0]; S->acc_coef[id][1] = nn[1]; S->acc_coef[id][2] = nn[2]; S->acc_coef[id][3] = d;
-            S->acc_support[id] = cand_size;
-            S->aj_out[n_aj] = S->out_off;
-            S->out_off += cand_size;
+            S->acc_support[id] = support;
+            S->acc_offset[id] = out_off;
+            S->aj_out[n_aj] = aj_out;
+            out_off += support;
+            n_acc = id + 1;
+            ++n_aj;
         }
-        S->n_acc = id + 1;
-        ++n_aj;
+        for (int q = 0; q < 4; ++q) if (n_final[q]) S->n_final[q] += n_final[q];
+        for (int q = 0; q < 5; ++q) if (n_stop[q]) S->n_stop[q] += n_stop[q];
+        S->aj_n = n_aj;
+        S->n_accepts = n_accepts; S->n_remaining = n_remaining; S->n_acc = n_acc; S->out_off = out_off; S->drawn = drawn; S->err = err;
     }
-    S->aj_n = n_aj;
-    if (nc) {
-        // drop the batch from the pool (batch indices are ascending), order kept
-        uint32_t w = 0, bq = 0;
-        const uint32_t np = S->npool;
-        for (uint32_t i = 0; i < np; ++i) {
-            if (bq < nc && S->batch_idx[bq] == i) { ++bq; continue; }
-            if (w != i) { S->pool_pl[w] = S->pool_pl[i]; S->pool_pos[w] = S->pool_pos[i]; }
-            ++w;
+    __syncthreads();
+    // the pool without the batch (batch indices are ascending), order kept: every lane moves its own entry
+    if (nc_all) {
+        bool in_batch = false;
+        uint32_t before = 0;
+        for (uint32_t q = 0; q < nc_all; ++q) { in_batch = in_batch || s_batch[q] == threadIdx.x; before += s_batch[q] < threadIdx.x; }
+        const bool keep = threadIdx.x < np && !in_batch;
+        if (keep) { S->pool_pl[threadIdx.x - before] = s_pool_pl[threadIdx.x]; S->pool_pos[threadIdx.x - before] = s_pool_pos[threadIdx.x]; }
+        if (threadIdx.x == 0) s_keep_pos[0] = 0;
+        const uint32_t w = (uint32_t)__popcll(__ballot(keep));
+        if (threadIdx.x == 0) {
+            // (n_remaining, done, err were updated by this lane above; visible here in its own registers)
+            uint32_t npool = w;
+            S->nc = 0;
+            if (!done) {
+                if (n_remaining < min_support) npool = 0;
+                S->npool = npool;
+                if (npool == 0) next_round_or_stop(S);
+                else if (S->topup) { if (S->round >= R_MAX_ROUNDS) S->done = 1; else S->sampling = 1; }
+            } else { S->npool = npool; S->done = 1; }
         }
-        S->npool = w;
-        S->nc = 0;
-        if (!S->done) {
-            if (S->n_remaining < S->min_support) S->npool = 0;
-            if (S->npool == 0) next_round_or_stop(S);
-            else if (S->topup) { if (S->round >= R_MAX_ROUNDS) S->done = 1; else S->sampling = 1; }
-        }
-    }
-    S->it += 1;
-    }
+    } else if (threadIdx.x == 0 && done && !done_in) S->done = 1;
+    if (threadIdx.x == 0) S->it += 1;
     __syncthreads();
     // The host-mapped block is written once, when the call ends (stores over PCIe are slow: all 64 lanes share them);
     // until then the host only needs the iteration count.
-    const uint32_t done = S->done;
-    if (done) {
+    const uint32_t done_now = S->done;
+    if (done_now) {
         const uint32_t na = S->n_acc;
         for (uint32_t i = threadIdx.x; i < 4 * na; i += 64) (&R->coef[0][0])[i] = (&S->acc_coef[0][0])[i];
         for (uint32_t i = threadIdx.x; i < na; i += 64) { R->support[i] = S->acc_support[i]; R->offset[i] = S->acc_offset[i]; }
@@ -1451,7 +1474,7 @@ __global__ __launch_bounds__(64) void k_r_decide(const RArgs A) {
     __threadfence_system();
     __syncthreads();
     if (threadIdx.x == 0)
-        *reinterpret_cast<volatile uint32_t *>(&R->flag) = (S->it & 0xffffffu) | ((S->gen & 0x7fu) << 24) | (done ? 0x80000000u : 0u);
+        *reinterpret_cast<volatile uint32_t *>(&R->flag) = (S->it & 0xffffffu) | ((S->gen & 0x7fu) << 24) | (done_now ? 0x80000000u : 0u);
 }
 
 
@@ -1919,7 +1942,10 @@ void ransac_detect_prepared(plade_ctx *ctx, RansacWork &W, RansacJob jobs[RANSAC
         // Sleeping host waits (several registrations in flight): the next iteration is queued before the current one has
         // reported, so the GPU never waits for the host; should the loop have ended, that iteration's kernels return at
         // once (27 empty launches).  A spinning host reacts within microseconds and queues an iteration only when needed.
-        const bool speculate = ctx->params.host_wait != 0 && !getenv("PLADE_NO_SPECULATION");
+        // host_wait = 2 only: with many registrations in flight the hardware queues are never idle, and the 27 empty launches
+        // of the one speculative iteration that finds the loop finished cost more (3 % of the throughput at 8 in flight)
+        // than the stream's idle time while the host reacts
+        const bool speculate = ctx->params.host_wait == 2;
         if (speculate) launch_iteration(ctx, W, A);
         for (;; ++iterations) {
             launch_iteration(ctx, W, A);
