@@ -1165,6 +1165,41 @@ __global__ __launch_bounds__(1024) void k_r_label(const RArgs A, int k, int do_f
     }
 }
 
+// Sums of FIT_COLS (= 14) columns over the 64 lanes of a wavefront with 16 exchanges instead of 14 x 6 (a 64-bit exchange is
+// two ds_bpermute; the plain butterflies were most of the selection kernel's tail): at every step a lane hands half of the
+// columns it still holds to its partner and adds the partner's contribution to the half it keeps (7 + 4 + 2 + 1 exchanges),
+// the last two steps add up single values.  Lane l ends with the sum of column 7 b5 + 4 b4 + 2 b3 + b2 (bits of l; the four
+// lanes that differ in b1 b0 hold the same value).  Fixed order: deterministic.
+__device__ __forceinline__ double wave_reduce_cols(const double (&a)[FIT_COLS], int lane, int &col) {
+    static_assert(FIT_COLS == 14, "the exchange pattern is written for 14 columns");
+    const bool h5 = lane & 32, h4 = lane & 16, h3 = lane & 8, h2 = lane & 4;
+    double b[7], c[4], d[2], e;
+#pragma unroll
+    for (int q = 0; q < 7; ++q) {
+        const double send = h5 ? a[q] : a[q + 7], mine = h5 ? a[q + 7] : a[q];
+        b[q] = mine + __shfl_xor(send, 32, 64);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const double hi = q + 4 < 7 ? b[q + 4 < 7 ? q + 4 : 0] : 0.0;
+        const double send = h4 ? b[q] : hi, mine = h4 ? hi : b[q];
+        c[q] = mine + __shfl_xor(send, 16, 64);
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const double send = h3 ? c[q] : c[q + 2], mine = h3 ? c[q + 2] : c[q];
+        d[q] = mine + __shfl_xor(send, 8, 64);
+    }
+    {
+        const double send = h2 ? d[0] : d[1], mine = h2 ? d[1] : d[0];
+        e = mine + __shfl_xor(send, 4, 64);
+    }
+    e += __shfl_xor(e, 2, 64);
+    e += __shfl_xor(e, 1, 64);
+    col = (h5 ? 7 : 0) + (h4 ? 4 : 0) + (h3 ? 2 : 0) + (h2 ? 1 : 0);
+    return e;
+}
+
 // (4) selection of the list entries whose pixel belongs to the largest component (4-bit masks per lane over list
 // positions + per-tile counts).  The same pass accumulates, over the kept points, the LS-fit moments (12 sums),
 // Candidate::WeightedScore (ransac/Candidate.cpp:77-87 with weigh(), ScoreComputer.h:10-16) of the slot's plane and the
@@ -1230,13 +1265,11 @@ __global__ __launch_bounds__(TPB) void k_r_select_cc(const RArgs A, int k) {
         }
     }
     ch.masks2(k)[row * TPB + threadIdx.x] = (uint8_t)mk;
-    for (int q = 0; q < FIT_COLS; ++q)
-        for (int d = 32; d >= 1; d >>= 1) a[q] += __shfl_xor(a[q], d, 64);
+    int col;
+    const double colsum = wave_reduce_cols(a, threadIdx.x & 63, col);
     __syncthreads();   // the previous row's readers are done
-    if ((threadIdx.x & 63) == 0) {
-        s_w[threadIdx.x >> 6] = cnt;
-        for (int q = 0; q < FIT_COLS; ++q) s[threadIdx.x >> 6][q] = a[q];
-    }
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = cnt;
+    if ((threadIdx.x & 3) == 0 && col < FIT_COLS) s[threadIdx.x >> 6][col] = colsum;
     __syncthreads();
     if (threadIdx.x == 0) ch.bc2(k)[row] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
     if (threadIdx.x < FIT_COLS)
@@ -1301,9 +1334,11 @@ __global__ __launch_bounds__(256) void k_r_fit(const RArgs A, int k) {
     for (int q = 0; q < FIT_COLS; ++q) a[q] = 0.0;
     for (uint32_t r = threadIdx.x; r < rows; r += blockDim.x)
         for (int q = 0; q < FIT_COLS; ++q) a[q] += part[(size_t)r * FIT_COLS + q];
-    for (int q = 0; q < FIT_COLS; ++q)
-        for (int d = 32; d >= 1; d >>= 1) a[q] += __shfl_xor(a[q], d, 64);
-    if ((threadIdx.x & 63) == 0) for (int q = 0; q < FIT_COLS; ++q) s_red[threadIdx.x >> 6][q] = a[q];
+    {
+        int col;
+        const double colsum = wave_reduce_cols(a, threadIdx.x & 63, col);
+        if ((threadIdx.x & 3) == 0 && col < FIT_COLS) s_red[threadIdx.x >> 6][col] = colsum;
+    }
     __syncthreads();
     if (threadIdx.x) return;
     for (int q = 0; q < FIT_COLS; ++q) a[q] = (s_red[0][q] + s_red[1][q]) + (s_red[2][q] + s_red[3][q]);

@@ -185,3 +185,36 @@ def test_batch_mode_prefetch_returns_the_bits_of_the_plain_call():
     ok, T = ctx.registration(pairs[0][0], pairs[0][1])
     assert ok and np.array_equal(T, want[0][1])
     ctx.close()
+
+
+def test_tall_scene_takes_the_global_memory_labelling_path():
+    """The bitmap cell is 2 % of max(dx, dy) -- Z is ignored (plane_extraction.cpp:71-80) -- so the walls of a tall, narrow
+    shaft rasterise to far more than the 8192 pixels the labelling kernel keeps in LDS: it labels in global memory instead,
+    and the walls come out whole."""
+    import plade_amd
+    rng = np.random.default_rng(4)
+    n_wall, h = 60000, 40.0
+    walls = []
+    for ax, c, sgn in ((0, 0.0, 1), (0, 2.0, -1), (1, 0.0, 1), (1, 2.0, -1)):
+        p = np.zeros((n_wall, 6), np.float32)
+        p[:, ax] = c + rng.normal(0, 0.002, n_wall)
+        p[:, 1 - ax] = rng.random(n_wall) * 2.0
+        p[:, 2] = rng.random(n_wall) * h
+        p[:, 3 + ax] = sgn
+        walls.append(p)
+    cloud = np.ascontiguousarray(np.concatenate(walls)[rng.permutation(4 * n_wall)])
+    ctx = plade_amd.Context(0, orient_normals=1)
+    coef, off, idx = ctx.extract_planes(cloud, 5000)
+    assert len(coef) == 4
+    sizes = np.diff(off)
+    assert sizes.min() > 0.97 * n_wall          # 2 m / 0.04 m x 40 m / 0.04 m = 50 000 pixels per wall, one component each
+    for p in range(4):
+        ax = int(np.argmax(np.abs(coef[p, :3])))
+        assert ax in (0, 1) and abs(abs(coef[p, ax]) - 1) < 1e-3
+        assert np.all(np.abs(cloud[idx[off[p]:off[p + 1]], 3 + ax]) == 1)
+    # the same cloud squeezed to 4 m: the walls fit the LDS labelling (50 x 100 pixels); same points per wall
+    flat = cloud.copy()
+    flat[:, 2] *= 0.1
+    coef2, off2, idx2 = ctx.extract_planes(flat, 5000)
+    assert len(coef2) == 4 and sorted(np.diff(off2)) == sorted(sizes)
+    ctx.close()

@@ -211,3 +211,35 @@ def test_radix_sort_sorted_reversed_and_constant_inputs(ctx):
         ko, vo = ctx.sort_pairs(keys, vals, 18)
         order = np.argsort(keys, kind="stable")
         assert np.array_equal(ko, keys[order]) and np.array_equal(vo, order.astype(np.uint32))
+
+
+@pytest.mark.parametrize("filt", [True, False])
+def test_plane_component_bitmap_larger_than_the_lds_labelling(ctx, oracle, filt):
+    """Seam S1c on a bitmap of ~360 x 300 pixels (k_r_label keeps bitmaps of up to 8192 pixels in LDS; beyond that it labels
+    in global memory): kept list = the oracle's (BitmapPrimitiveShape.cpp:97-265), LS fit and weighted score as for the
+    small case."""
+    rng = np.random.default_rng(12 + filt)
+    m = 60000
+    uv = rng.random((m, 2)) * [36.0, 30.0]
+    # three islands separated by empty bands (wider than a closing step), the largest one in the middle
+    keep = ((uv[:, 0] < 9) | ((uv[:, 0] > 11) & (uv[:, 0] < 29)) | (uv[:, 0] > 31.5)) & ~((uv[:, 1] > 14) & (uv[:, 1] < 15.5) & (uv[:, 0] > 31.5))
+    uv = uv[keep]
+    n = np.array([0.2, -0.3, 0.93], np.float64); n /= np.linalg.norm(n)
+    a = np.cross(n, [0, 0, 1.0]); a /= np.linalg.norm(a)
+    b = np.cross(n, a)
+    pts = (uv[:, :1] * a + uv[:, 1:] * b + rng.normal(0, 0.01, (len(uv), 1)) * n + [1.0, 2.0, 3.0]).astype(np.float32)
+    cloud = np.concatenate([pts, np.tile(n.astype(np.float32), (len(pts), 1))], 1)
+    extra = sample_scene(5000, 3, 3)
+    cloud = np.ascontiguousarray(np.concatenate([cloud, extra]))
+    idx = rng.permutation(len(pts)).astype(np.int32)
+    nrm, point = n.astype(np.float32), np.array([1.0, 2.0, 3.0], np.float32)
+    kept, fit, ws = ctx.plane_component(cloud, nrm, point, idx, 0.1, filt, 0.15)
+    ref = oracle.connected_component(cloud, nrm, point, idx, 0.1, filt)
+    assert 0.3 * len(idx) < len(ref) < 0.8 * len(idx)          # one island of three
+    assert np.array_equal(kept, ref)
+    rf = oracle.ls_fit(cloud, ref)                        # unit normal, mean, dist
+    sgn = np.sign(fit[:3] @ rf[:3])
+    # the oracle (like the reference) adds 35 000 coordinates of magnitude 20 sequentially in fp32: its own noise is ~5e-5
+    assert np.abs(sgn * fit[:3] - rf[:3]).max() < 5e-5 and np.abs(fit[3:6] - rf[3:6]).max() < 2e-4
+    wref = oracle.weighted_score(cloud, nrm, point, ref, 0.15)
+    assert abs(ws - wref) <= 1e-4 * max(1.0, wref)
