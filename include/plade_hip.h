@@ -134,6 +134,16 @@ int plade_overlap_counts(plade_ctx *ctx, const float *src_ds, uint32_t n_s, cons
                          uint32_t n_t, const float *T, uint32_t k, const float *centers,
                          float src_radius, float inlier_dist, int32_t *counts);
 
+/* ---- seam of the clustering stage (A9) ------------------------------------------------------
+ * Replaces ClusterTransformation (code/PLADE/util.cpp:1245-1277) = pcl::ConditionalEuclideanClustering::segment
+ * (pcl-1.8.1/segmentation/include/pcl/segmentation/impl/conditional_euclidean_clustering.hpp:42-138) with the condition
+ * EnforceSimilarity (util.cpp:1232-1243): candidates a, b are joined when |t_a - t_b|^2 < float(dist_threshold^2) and
+ * |euler_a - euler_b|^2 < angle_gate; clusters = connected components.  t_xyz, euler: m x 3 (translation; roll, pitch,
+ * yaw as pcl::getEulerAngles gives them); cluster_of[i] = index of i's cluster, clusters numbered by their smallest
+ * member (the order PCL creates them in). */
+int plade_cluster_transforms(plade_ctx *ctx, const float *t_xyz, const float *euler, uint32_t m, float dist_threshold,
+                             float angle_gate, int32_t *cluster_of, uint32_t *n_clusters);
+
 /* ---- supporting stage entry points (A13) ------------------------------------------------- */
 /* average_spacing(cloud, k) (code/PLADE/util.cpp:1619-1648); xyz read with `stride` floats. */
 int plade_average_spacing(plade_ctx *ctx, const float *xyz, uint32_t n, uint32_t stride,

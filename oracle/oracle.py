@@ -75,6 +75,38 @@ class Oracle:
         L.orc_registration.argtypes = [_p, _p, _i, _p, _i, _p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _p]
         L.orc_registration_sampled.argtypes = [_p, _p, _i, _p, _i, _p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _p]
         L.orc_dump_get.argtypes = [_p, C.c_char_p, _p, _p]
+        L.orc_set_closest_point_noise.argtypes = [C.c_double, C.c_uint64]
+        L.orc_cluster_transforms.argtypes = [_p, _p, _i, _f, _f, _p]
+        L.orc_euler_angles.argtypes = [_p, _p]
+        L.orc_pen_walk.argtypes = [_p, _i, _p, _i, _p, _p, _p, _f, _f, _f, _p, _p, _p]
+
+    def set_closest_point_noise(self, amp, seed=0):
+        """Tests only: perturb the closest points of every line pair by up to amp per coordinate (0 = off)."""
+        self.L.orc_set_closest_point_noise(float(amp), int(seed))
+
+    # -- A9 / A11 pieces (G10, G11) ---------------------------------------------
+    def euler_angles(self, R):
+        """pcl::getEulerAngles of M rotation matrices (M x 3 x 3) -> M x 3 (roll, pitch, yaw)."""
+        R = _f32(R).reshape(-1, 9)
+        out = np.zeros((len(R), 3), np.float32)
+        for i in range(len(R)):
+            self.L.orc_euler_angles(_ptr(R[i]), _ptr(out[i]))
+        return out
+
+    def cluster_transforms(self, t_xyz, euler, distance_threshold, g_angle):
+        """ClusterTransformation (util.cpp:1245-1277): cluster index per candidate, in creation order."""
+        t, e = _f32(t_xyz).reshape(-1, 3), _f32(euler).reshape(-1, 3)
+        out = np.full(len(t), -1, np.int32)
+        n = self.L.orc_cluster_transforms(_ptr(t), _ptr(e), len(t), distance_threshold, g_angle, _ptr(out))
+        return out, n
+
+    def pen_walk(self, pts_a, pts_b, plane_b, start, direc, length, search_radius, min_distance):
+        """One walk of AreTwoPlanesPenetrable (util.cpp:1379-1405): (positive, negative, skipped steps)."""
+        a, b = _f32(pts_a).reshape(-1, 3), _f32(pts_b).reshape(-1, 3)
+        pos, neg, sk = C.c_int(), C.c_int(), C.c_int()
+        self.L.orc_pen_walk(_ptr(a), len(a), _ptr(b), len(b), _ptr(_f32(plane_b)), _ptr(_f32(start)), _ptr(_f32(direc)),
+                            length, search_radius, min_distance, C.byref(pos), C.byref(neg), C.byref(sk))
+        return pos.value, neg.value, sk.value
 
     # -- A3 ------------------------------------------------------------------
     def score_plane(self, pos_nrm, shape_index, plane4, eps, cos_thresh):
@@ -266,6 +298,24 @@ class Reference:
         L.ref_inverse4.argtypes = [_p, _p]
         L.ref_affine3.argtypes = [_p, _p, _p, _p]
         L.ref_format_matrix4.argtypes = [_p, C.c_char_p, _i]
+        if hasattr(L, "ref_cluster_transforms"):
+            L.ref_cluster_transforms.argtypes = [_p, _p, _i, _f, _f, _p]
+            L.ref_pen_walk.argtypes = [_p, _i, _p, _i, _p, _p, _p, _f, _f, _f, _p, _p, _p]
+
+    def cluster_transforms(self, t_xyz, euler, distance_threshold, g_angle):
+        """pcl::ConditionalEuclideanClustering::segment + EnforceSimilarity over FLANN (ref_shim.cpp, G10)."""
+        t, e = _f32(t_xyz).reshape(-1, 3), _f32(euler).reshape(-1, 3)
+        out = np.full(len(t), -1, np.int32)
+        n = self.L.ref_cluster_transforms(_ptr(t), _ptr(e), len(t), distance_threshold, g_angle, _ptr(out))
+        return out, n
+
+    def pen_walk(self, pts_a, pts_b, plane_b, start, direc, length, search_radius, min_distance):
+        """One walk of AreTwoPlanesPenetrable over FLANN kd-trees (ref_shim.cpp, G11)."""
+        a, b = _f32(pts_a).reshape(-1, 3), _f32(pts_b).reshape(-1, 3)
+        pos, neg, sk = C.c_int(), C.c_int(), C.c_int()
+        self.L.ref_pen_walk(_ptr(a), len(a), _ptr(b), len(b), _ptr(_f32(plane_b)), _ptr(_f32(start)), _ptr(_f32(direc)),
+                            length, search_radius, min_distance, C.byref(pos), C.byref(neg), C.byref(sk))
+        return pos.value, neg.value, sk.value
 
     def cloud_scale(self, pos_nrm):
         pn = _f32(pos_nrm)

@@ -617,6 +617,20 @@ int intersection_line(const float *pl1, const float *pl2, V3 &vec, V3 &pt) {
     return 0;
 }
 
+// Sensitivity switch (tests only, orc_set_closest_point_noise): every closest point is moved by a pseudo-random vector of
+// up to `amp` per coordinate -- the size of the error the reference's fp32 9x9 SVD solve makes against the exact answer
+// (8.8e-5 for coordinates up to 10).  With it the tests bound what the one forced arithmetic deviation
+// of this restatement (closed form instead of cv::solve, which does not build here) can change downstream.
+static double g_cp_noise_amp = 0.0;
+static uint64_t g_cp_noise_seed = 0;
+inline float cp_noise(const V3 &p1, const V3 &p2, uint64_t k) {
+    uint32_t b[6];
+    memcpy(b, &p1, 12); memcpy(b + 3, &p2, 12);
+    uint64_t z = g_cp_noise_seed + 0x9E3779B97F4A7C15ull * (k + 1);
+    for (int i = 0; i < 6; ++i) { z ^= b[i]; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31; }
+    return (float)(g_cp_noise_amp * (2.0 * (double)(z >> 11) / 9007199254740992.0 - 1.0));
+}
+
 // ComputeNearstTwoPointsOfTwo3DLine (code/PLADE/util.cpp:1167-1229).
 // Mutates u1,u2 (normalised in place, exactly like the reference's non-const refs).
 // Closest points: exact closed form in fp64 (DEVIATION from the fp32 9x9 SVD, see header).
@@ -636,6 +650,10 @@ int closest_points(V3 &u1, const V3 &p1, V3 &u2, const V3 &p2, V3 &q1, V3 &q2, d
     double t2 = (a * e - b * d) / den;
     q1 = V3((float)(p1.x + t1 * ax), (float)(p1.y + t1 * ay), (float)(p1.z + t1 * az));
     q2 = V3((float)(p2.x + t2 * bx), (float)(p2.y + t2 * by), (float)(p2.z + t2 * bz));
+    if (g_cp_noise_amp > 0.0) {
+        q1 = q1 + V3(cp_noise(p1, p2, 0), cp_noise(p1, p2, 1), cp_noise(p1, p2, 2));
+        q2 = q2 + V3(cp_noise(p1, p2, 3), cp_noise(p1, p2, 4), cp_noise(p1, p2, 5));
+    }
     len = norm(q1 - q2);  // (point1 - point2).norm() in float, widened
     return 0;
 }
@@ -762,6 +780,45 @@ inline void euler_angles(const M3 &R, float &roll, float &pitch, float &yaw) {
     yaw = (float)std::atan2((double)R.m[1][0], (double)R.m[0][0]);
 }
 
+// ClusterTransformation (util.cpp:1245-1277) = PCL ConditionalEuclideanClustering::segment
+// (pcl-1.8.1/segmentation/.../conditional_euclidean_clustering.hpp:42-138) with EnforceSimilarity (util.cpp:1232-1243) on
+// the Euler angles.  Pinned against the FLANN composition of the same loop (oracle/ref/ref_shim.cpp
+// ref_cluster_transforms, tests/golden/g10_cluster.npz).
+inline void cluster_transforms(const std::vector<V3> &iT, const std::vector<V3> &eul, float distanceThreshold, float g_angle,
+                               std::vector<std::vector<int>> &clusters) {
+    clusters.clear();
+    GridIndex g;
+    g.build(iT.data(), (int)iT.size(), distanceThreshold > 0 ? distanceThreshold : 1.f);
+    float r2 = pcl_r2((double)distanceThreshold);
+    std::vector<char> processed(iT.size(), 0);
+    std::vector<std::pair<float, int>> nn;
+    for (int seed = 0; seed < (int)iT.size(); ++seed) {
+        if (processed[seed]) continue;
+        std::vector<int> cur;
+        cur.push_back(seed);
+        processed[seed] = 1;
+        for (size_t cii = 0; cii < cur.size(); ++cii) {
+            int a = cur[cii];
+            nn.clear();
+            g.radius(iT[a], r2, [&](int i, float d) { nn.push_back(std::make_pair(d, i)); });
+            if (nn.empty()) continue;
+            // sorted results, nn_indices[0] skipped (hpp:101).  The entry at distance 0 with the
+            // smallest index stands in for "first in FLANN order" (the point itself unless an
+            // exact duplicate exists).
+            std::sort(nn.begin(), nn.end());
+            for (size_t nii = 1; nii < nn.size(); ++nii) {
+                int b = nn[nii].second;
+                if (processed[b]) continue;
+                // Eigen::VectorXf(3).squaredNorm(): sequential
+                float t0 = eul[a].x - eul[b].x, t1 = eul[a].y - eul[b].y, t2 = eul[a].z - eul[b].z;
+                float sq = (t0 * t0 + t1 * t1) + t2 * t2;
+                if (sq < g_angle) { cur.push_back(b); processed[b] = 1; }
+            }
+        }
+        clusters.push_back(cur);
+    }
+}
+
 struct LengthIndex { float length; int index; };
 inline bool cmp_greater(const LengthIndex &a, const LengthIndex &b) { return a.length > b.length; }
 inline bool cmp_less(const LengthIndex &a, const LengthIndex &b) { return a.length < b.length; }
@@ -806,6 +863,30 @@ struct orc_reg {
 
 namespace {
 
+// One of the two walks of AreTwoPlanesPenetrable along the common segment (util.cpp:1379-1405 / :1416-1442):
+// A = the cloud whose points are classified against planeB; B = the gate cloud.  Pinned against the FLANN composition of
+// the same loop (oracle/ref/ref_shim.cpp ref_pen_walk, tests/golden/g11_penetration.npz).
+void pen_walk(const std::vector<V3> &ptsA, const GridIndex &gA, const GridIndex &gB, const float *planeB, V3 startPoint, V3 direc,
+              float length, float searchRadius, float minDistance, int &positiveNum, int &negativeNum, int &skipped) {
+    const float half_r2 = pcl_r2((double)(searchRadius / 2)), full_r2 = pcl_r2((double)searchRadius);
+    positiveNum = negativeNum = skipped = 0;
+    std::vector<char> check(ptsA.size(), 1);
+    for (float dist = 0; dist < length; dist += searchRadius) {
+        V3 sp = startPoint + dist * direc;
+        int cnt = 0;
+        gB.radius(sp, half_r2, [&](int, float) { ++cnt; });
+        if (cnt < 2) { ++skipped; continue; }  // radiusSearch(..., max_nn = 2) < 2
+        gA.radius(sp, full_r2, [&](int i, float) {
+            if (check[i]) {
+                check[i] = 0;
+                const V3 &p = ptsA[i];
+                float td = planeB[0] * p.x + planeB[1] * p.y + planeB[2] * p.z + planeB[3];
+                if (std::fabs(td) > minDistance) { if (td >= 0) positiveNum++; else negativeNum++; }
+            }
+        });
+    }
+}
+
 // AreTwoPlanesPenetrable (code/PLADE/util.cpp:1279-1458)
 int planes_penetrable(const float *plane1, const float *plane2, const V3 *corners1, const V3 *corners2,
                       const std::vector<V3> &pts1, const GridIndex &g1, const std::vector<V3> &pts2,
@@ -842,24 +923,10 @@ int planes_penetrable(const float *plane1, const float *plane2, const V3 *corner
     float full_r2 = pcl_r2((double)searchRadius);
     auto walk = [&](const std::vector<V3> &ptsA, const GridIndex &gA, const GridIndex &gB, const float *planeB,
                     int &positiveNum, int &negativeNum) {
-        // A = the cloud whose points are classified against planeB; B = the gate cloud
-        positiveNum = negativeNum = 0;
-        std::vector<char> check(ptsA.size(), 1);
-        for (float dist = 0; dist < length; dist += searchRadius) {
-            V3 sp = startPoint + dist * direc;
-            int cnt = 0;
-            gB.radius(sp, half_r2, [&](int, float) { ++cnt; });
-            if (cnt < 2) continue;  // radiusSearch(..., max_nn = 2) < 2
-            gA.radius(sp, full_r2, [&](int i, float) {
-                if (check[i]) {
-                    check[i] = 0;
-                    const V3 &p = ptsA[i];
-                    float td = planeB[0] * p.x + planeB[1] * p.y + planeB[2] * p.z + planeB[3];
-                    if (std::fabs(td) > minDistance) { if (td >= 0) positiveNum++; else negativeNum++; }
-                }
-            });
-        }
+        int skipped;
+        pen_walk(ptsA, gA, gB, planeB, startPoint, direc, length, searchRadius, minDistance, positiveNum, negativeNum, skipped);
     };
+    (void)half_r2; (void)full_r2;
     int pos, neg;
     walk(pts1, g1, g2, plane2, pos, neg);
     if (pos < minPointsNum || neg < minPointsNum) { pen = false; return 0; }
@@ -1101,6 +1168,36 @@ int orc_overlap_count(const float *src_ds, int ns, const float *tgt_ds, int nt, 
 }
 
 orc_reg *orc_reg_create(void) { return new orc_reg; }
+// G10 / G11 seams of the restatement (see cluster_transforms, pen_walk)
+int orc_cluster_transforms(const float *t_xyz, const float *euler, int m, float distance_threshold, float g_angle, int *cluster_of) {
+    std::vector<V3> T(m), E(m);
+    for (int i = 0; i < m; ++i) { T[i] = ld3(t_xyz + 3 * (size_t)i); E[i] = ld3(euler + 3 * (size_t)i); }
+    std::vector<std::vector<int>> clusters;
+    if (m > 0) cluster_transforms(T, E, distance_threshold, g_angle, clusters);
+    for (size_t c = 0; c < clusters.size(); ++c)
+        for (int i : clusters[c]) cluster_of[i] = (int)c;
+    return (int)clusters.size();
+}
+void orc_euler_angles(const float *R9, float *rpy3) {
+    M3 R;
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) R.m[r][c] = R9[3 * r + c];
+    euler_angles(R, rpy3[0], rpy3[1], rpy3[2]);
+}
+int orc_pen_walk(const float *pts_a, int na, const float *pts_b, int nb, const float *plane_b4, const float *start3,
+                 const float *direc3, float length, float searchRadius, float minDistance, int *positive, int *negative,
+                 int *skipped) {
+    std::vector<V3> A(na), B(nb);
+    for (int i = 0; i < na; ++i) A[i] = ld3(pts_a + 3 * (size_t)i);
+    for (int i = 0; i < nb; ++i) B[i] = ld3(pts_b + 3 * (size_t)i);
+    GridIndex ga, gb;
+    ga.build(A.data(), na, searchRadius > 0 ? searchRadius : 1.f);
+    gb.build(B.data(), nb, searchRadius > 0 ? searchRadius : 1.f);
+    pen_walk(A, ga, gb, plane_b4, ld3(start3), ld3(direc3), length, searchRadius, minDistance, *positive, *negative, *skipped);
+    return 0;
+}
+
+void orc_set_closest_point_noise(double amp, uint64_t seed) { g_cp_noise_amp = amp; g_cp_noise_seed = seed; }
+
 void orc_reg_destroy(orc_reg *h) { delete h; }
 int orc_dump_get(orc_reg *h, const char *name, const void **ptr, int64_t *nbytes) {
     auto it = h->blobs.find(name);
@@ -1277,36 +1374,7 @@ int orc_registration_sampled(orc_reg *h, const float *tgt_pn, int nt, const floa
         const float g_angle = (double)angleThreshold / 2;
         std::vector<V3> eul(iR.size());
         for (size_t i = 0; i < iR.size(); ++i) euler_angles(iR[i], eul[i].x, eul[i].y, eul[i].z);
-        GridIndex g;
-        g.build(iT.data(), (int)iT.size(), distanceThreshold > 0 ? distanceThreshold : 1.f);
-        float r2 = pcl_r2((double)distanceThreshold);
-        std::vector<char> processed(iR.size(), 0);
-        std::vector<std::pair<float, int>> nn;
-        for (int seed = 0; seed < (int)iR.size(); ++seed) {
-            if (processed[seed]) continue;
-            std::vector<int> cur;
-            cur.push_back(seed);
-            processed[seed] = 1;
-            for (size_t cii = 0; cii < cur.size(); ++cii) {
-                int a = cur[cii];
-                nn.clear();
-                g.radius(iT[a], r2, [&](int i, float d) { nn.push_back(std::make_pair(d, i)); });
-                if (nn.empty()) continue;
-                // sorted results, nn_indices[0] skipped (hpp:101).  The entry at distance 0 with the
-                // smallest index stands in for "first in FLANN order" (the point itself unless an
-                // exact duplicate exists).
-                std::sort(nn.begin(), nn.end());
-                for (size_t nii = 1; nii < nn.size(); ++nii) {
-                    int b = nn[nii].second;
-                    if (processed[b]) continue;
-                    // Eigen::VectorXf(3).squaredNorm(): sequential
-                    float t0 = eul[a].x - eul[b].x, t1 = eul[a].y - eul[b].y, t2 = eul[a].z - eul[b].z;
-                    float sq = (t0 * t0 + t1 * t1) + t2 * t2;
-                    if (sq < g_angle) { cur.push_back(b); processed[b] = 1; }
-                }
-            }
-            clusters.push_back(cur);
-        }
+        cluster_transforms(iT, eul, distanceThreshold, g_angle, clusters);
     }
     {
         std::vector<int> cs(clusters.size()), cseed(clusters.size());

@@ -62,6 +62,16 @@ int orc_overlap_count(const float *src_ds, int ns, const float *tgt_ds, int nt, 
  * intermediate arrays for stage-level parity tests (orc_dump_get). */
 typedef struct orc_reg orc_reg;
 orc_reg *orc_reg_create(void);
+/* ClusterTransformation (util.cpp:1245-1277): cluster index (creation order) per candidate; returns the number of clusters.
+ * euler = pcl::getEulerAngles of the rotations (orc_euler_angles). */
+int orc_cluster_transforms(const float *t_xyz, const float *euler, int m, float distance_threshold, float g_angle, int *cluster_of);
+void orc_euler_angles(const float *R9, float *rpy3);
+/* One walk of AreTwoPlanesPenetrable (util.cpp:1379-1405): points of A on either side of plane B along the segment. */
+int orc_pen_walk(const float *pts_a, int na, const float *pts_b, int nb, const float *plane_b4, const float *start3,
+                 const float *direc3, float length, float searchRadius, float minDistance, int *positive, int *negative,
+                 int *skipped);
+/* tests only: perturb every closest point of ComputeNearstTwoPointsOfTwo3DLine by up to amp per coordinate (0 = off) */
+void orc_set_closest_point_noise(double amp, uint64_t seed);
 void orc_reg_destroy(orc_reg *);
 int orc_registration(orc_reg *h, const float *tgt_pos_nrm, int nt, const float *src_pos_nrm, int ns,
                      const float *tgt_planes, const int32_t *tgt_offsets, const int32_t *tgt_idx,

@@ -362,6 +362,96 @@ int ref_overlap_count(const float *query_xyz, int nq, const float *dest_xyz, int
     return count;
 }
 
+// G10: ClusterTransformation (code/PLADE/util.cpp:1245-1277) = pcl::ConditionalEuclideanClustering<PointXYZINormal>::segment
+// (pcl-1.8.1/segmentation/include/pcl/segmentation/impl/conditional_euclidean_clustering.hpp:42-138) with the condition
+// EnforceSimilarity (util.cpp:1232-1243), composed over FLANN the way its pcl::search::KdTree searcher is
+// (KdTreeFLANN::radiusSearch, kdtree_flann.hpp:169-210: sorted results, float(radius * radius), max_nn = 0 -> all).
+// t_xyz = the translations (PointXYZINormal::x/y/z), euler = (normal_x, normal_y, normal_z) = pcl::getEulerAngles of the
+// rotations (computed by the caller: PCL itself does not compile here).  cluster_of[i] = index of i's cluster in the
+// order segment() creates them (min_cluster_size 1, max = all: every cluster is kept, util.cpp:1271-1272).
+int ref_cluster_transforms(const float *t_xyz, const float *euler, int m, float distance_threshold, float g_angle,
+                           int *cluster_of) {
+    if (m <= 0) return 0;
+    RefTree *tree = (RefTree *)ref_flann_build(t_xyz, m);
+    const double cluster_tolerance = distance_threshold;   // setClusterTolerance(float) -> double member (hpp / .h:170)
+    std::vector<bool> processed(m, false);
+    std::vector<int> nn_indices(m);
+    std::vector<float> nn_distances(m);
+    int n_clusters = 0;
+    for (int iii = 0; iii < m; ++iii) {                                             // hpp:76
+        if (processed[iii]) continue;                                               // hpp:79
+        std::vector<int> current_cluster;
+        int cii = 0;
+        current_cluster.push_back(iii);                                             // hpp:87
+        processed[iii] = true;
+        while (cii < (int)current_cluster.size()) {                                 // hpp:91
+            const int a = current_cluster[cii];
+            const int k = ref_flann_radius(tree, t_xyz + 3 * (size_t)a, cluster_tolerance, 0, nn_indices.data(), nn_distances.data(), m);
+            if (k < 1) { cii++; continue; }                                         // hpp:94-98
+            for (int nii = 1; nii < k; ++nii) {                                     // hpp:101: the first neighbour is skipped
+                const int b = nn_indices[nii];
+                if (processed[b]) continue;                                         // hpp:104
+                // EnforceSimilarity(point_a = seed, point_b = neighbour, squared_distance), util.cpp:1232-1243
+                Eigen::VectorXf temp(3);
+                temp[0] = euler[3 * (size_t)a] - euler[3 * (size_t)b];
+                temp[1] = euler[3 * (size_t)a + 1] - euler[3 * (size_t)b + 1];
+                temp[2] = euler[3 * (size_t)a + 2] - euler[3 * (size_t)b + 2];
+                if (temp.squaredNorm() < g_angle) {                                 // util.cpp:1239
+                    current_cluster.push_back(b);                                   // hpp:111
+                    processed[b] = true;
+                }
+            }
+            cii++;
+        }
+        for (size_t q = 0; q < current_cluster.size(); ++q) cluster_of[current_cluster[q]] = n_clusters;
+        ++n_clusters;
+    }
+    ref_flann_free(tree);
+    return n_clusters;
+}
+
+// G11: one of the two walks of AreTwoPlanesPenetrable (code/PLADE/util.cpp:1379-1405 / :1416-1442) along the common
+// segment of two plane rectangles, with KdTree1 / KdTree2 = pcl::search::KdTree<PointXYZ> composed over FLANN as above:
+// A = the cloud whose points are classified against plane B (util.cpp:1393-1402), B = the gate cloud (a step is skipped
+// unless B has two points within searchRadius / 2, radiusSearch(..., max_nn = 2) < 2, util.cpp:1384-1389).  The geometry in
+// front of the walks (rectangle / line intersections through cv::solve) is not part of this: OpenCV does not compile here.
+int ref_pen_walk(const float *pts_a, int na, const float *pts_b, int nb, const float *plane_b4, const float *start3,
+                 const float *direc3, float length, float searchRadius, float minDistance, int *positive, int *negative,
+                 int *skipped) {
+    RefTree *ta = na > 0 ? (RefTree *)ref_flann_build(pts_a, na) : nullptr;
+    RefTree *tb = nb > 0 ? (RefTree *)ref_flann_build(pts_b, nb) : nullptr;
+    const Eigen::Vector3f startPoint(start3[0], start3[1], start3[2]), direc(direc3[0], direc3[1], direc3[2]);
+    Eigen::Vector3f searchPoint;
+    std::vector<int> neighbor(std::max(na, 2));
+    std::vector<float> neighborLength(std::max(na, 2));
+    int negativeNum = 0, positiveNum = 0, count = 0;
+    std::vector<bool> checkIndex1(na, true);
+    for (float dist = 0; dist < length; dist += searchRadius) {                     // util.cpp:1381
+        searchPoint = startPoint + dist * direc;
+        const float sp[3] = {searchPoint(0), searchPoint(1), searchPoint(2)};
+        int two[2];
+        float twod[2];
+        const int kb = tb ? ref_flann_radius(tb, sp, searchRadius / 2, 2, two, twod, 2) : 0;
+        if (kb < 2) { count++; continue; }                                          // util.cpp:1384-1389
+        const int ka = ta ? ref_flann_radius(ta, sp, searchRadius, 0, neighbor.data(), neighborLength.data(), na) : 0;
+        for (int i = 0; i < ka; i++) {
+            if (checkIndex1[neighbor[i]]) {
+                checkIndex1[neighbor[i]] = false;
+                const float *p = pts_a + 3 * (size_t)neighbor[i];
+                float tempDistance = plane_b4[0] * p[0] + plane_b4[1] * p[1] + plane_b4[2] * p[2] + plane_b4[3];
+                if (std::fabs(tempDistance) > minDistance) {
+                    if (tempDistance >= 0) positiveNum++;
+                    else negativeNum++;
+                }
+            }
+        }
+    }
+    if (ta) ref_flann_free(ta);
+    if (tb) ref_flann_free(tb);
+    *positive = positiveNum; *negative = negativeNum; *skipped = count;
+    return 0;
+}
+
 // ---------------------------------------------------------------------------
 // Eigen pieces.
 // G6: pcl::TransformationEstimationSVD -> pcl::umeyama -> Eigen::umeyama(src,dst,false)

@@ -21,7 +21,7 @@ ABI_SYMBOLS = [
     "plade_overlap_counts", "plade_average_spacing", "plade_voxel_downsample", "plade_registration_planes",
     "plade_registration", "plade_registration_minsupport", "plade_cloud_upload", "plade_cloud_free",
     "plade_registration_dev", "plade_dump_get", "plade_stats_get", "plade_kernel_time", "plade_plane_component",
-    "plade_sort_pairs", "plade_host_pin", "plade_host_unpin", "plade_score_planes_subset", "plade_registration_next",
+    "plade_sort_pairs", "plade_host_pin", "plade_host_unpin", "plade_score_planes_subset", "plade_registration_next", "plade_cluster_transforms",
 ]
 
 
@@ -71,6 +71,7 @@ def load_library(path=LIB_PATH):
     sig("plade_score_planes_subset", argtypes=[p, p, p, u32, p, u32, p, u32, f, f, p, p])
     sig("plade_extract_planes", argtypes=[p, p, u32, u32, f, f, f, f, p, p, p, u32, p])
     sig("plade_match_descriptors", argtypes=[p, p, u32, p, u32, f, p, p, p, u64, p])
+    sig("plade_cluster_transforms", argtypes=[p, p, p, u32, f, f, p, p])
     sig("plade_overlap_counts", argtypes=[p, p, u32, p, u32, p, u32, p, f, f, p])
     sig("plade_average_spacing", argtypes=[p, p, u32, u32, u32, u32, p])
     sig("plade_voxel_downsample", argtypes=[p, p, u32, u32, f, p, p])
@@ -253,6 +254,14 @@ class Context:
         self._check(self.L.plade_match_descriptors(self.h, _ptr(q), len(q), _ptr(t), len(t), radius, _ptr(off),
                                                    _ptr(nbr), _ptr(d2), m, C.byref(total)))
         return off, nbr[:m].astype(np.int32), d2[:m]
+
+    def cluster_transforms(self, t_xyz, euler, dist_threshold, angle_gate):
+        """Seam of the clustering stage (util.cpp:1245-1277): (cluster index per candidate, number of clusters)."""
+        t, e = _f32(t_xyz).reshape(-1, 3), _f32(euler).reshape(-1, 3)
+        out = np.full(len(t), -1, np.int32)
+        n = C.c_uint32()
+        self._check(self.L.plade_cluster_transforms(self.h, _ptr(t), _ptr(e), len(t), dist_threshold, angle_gate, _ptr(out), C.byref(n)))
+        return out, n.value
 
     def overlap_counts(self, src_ds, tgt_ds, T, centers, src_radius, inlier_dist):
         s, t = _f32(src_ds), _f32(tgt_ds)

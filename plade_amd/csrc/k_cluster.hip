@@ -345,3 +345,54 @@ void plane_consistency(plade_ctx *ctx, CandidateSet &cs, const PlaneGeomHost &sr
 }
 
 }  // namespace plade
+
+using namespace plade;
+
+// ---- C ABI: seam of the clustering stage ---------------------------------------------------------
+// ClusterTransformation (code/PLADE/util.cpp:1245-1277): the candidates come as translations + Euler angles (what
+// PointXYZINormal carries there); the stage's own kernels (cluster_transforms above) run on them.
+extern "C" int plade_cluster_transforms(plade_ctx *ctx, const float *t_xyz, const float *euler, uint32_t m, float dist_threshold,
+                                        float angle_gate, int32_t *cluster_of, uint32_t *n_clusters) {
+    return guarded(ctx, [&]() -> int {
+        PLADE_REQUIRE(n_clusters && (m == 0 || (t_xyz && euler && cluster_of)), PLADE_EINVAL, "plade_cluster_transforms: null argument");
+        *n_clusters = 0;
+        if (m == 0) return PLADE_OK;
+        CandidateSet cs;
+        cs.m = m;
+        cs.rt.ensure(4 * (size_t)m);
+        std::vector<float4> rt(4 * (size_t)m);
+        const uint32_t nbp = cdiv(m, 256);
+        std::vector<float> part(6 * (size_t)nbp);
+        for (uint32_t b = 0; b < nbp; ++b)
+            for (int k = 0; k < 3; ++k) { part[6 * (size_t)b + k] = INFINITY; part[6 * (size_t)b + 3 + k] = -INFINITY; }
+        for (uint32_t i = 0; i < m; ++i) {
+            const float *t = t_xyz + 3 * (size_t)i, *e = euler + 3 * (size_t)i;
+            rt[4 * (size_t)i] = make_float4(1.f, 0.f, 0.f, t[0]);
+            rt[4 * (size_t)i + 1] = make_float4(0.f, 1.f, 0.f, t[1]);
+            rt[4 * (size_t)i + 2] = make_float4(0.f, 0.f, 1.f, t[2]);
+            rt[4 * (size_t)i + 3] = make_float4(e[0], e[1], e[2], 0.f);
+            for (int k = 0; k < 3; ++k) {
+                part[6 * (size_t)(i / 256) + k] = std::min(part[6 * (size_t)(i / 256) + k], t[k]);
+                part[6 * (size_t)(i / 256) + 3 + k] = std::max(part[6 * (size_t)(i / 256) + 3 + k], t[k]);
+            }
+        }
+        cs.t_minmax.ensure(6 * (size_t)nbp);
+        HIP_TRY(hipMemcpyAsync(cs.rt.p, rt.data(), 64 * (size_t)m, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(cs.t_minmax.p, part.data(), 24 * (size_t)nbp, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        cluster_transforms(ctx, cs, dist_threshold, angle_gate);
+        std::vector<uint32_t> parent(m), seeds(cs.n_clusters);
+        HIP_TRY(hipMemcpyAsync(parent.data(), cs.parent.p, 4 * (size_t)m, hipMemcpyDeviceToHost, ctx->stream));
+        if (cs.n_clusters) HIP_TRY(hipMemcpyAsync(seeds.data(), cs.seeds.p, 4 * (size_t)cs.n_clusters, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        for (uint32_t i = 0; i < m; ++i) {
+            uint32_t r = i;
+            while (parent[r] != r) r = parent[r];
+            // the root of a component is its smallest member = the seed PCL's region growing starts it from
+            cluster_of[i] = (int32_t)(std::lower_bound(seeds.begin(), seeds.end(), r) - seeds.begin());
+        }
+        *n_clusters = cs.n_clusters;
+        return PLADE_OK;
+    });
+}
+

@@ -44,6 +44,17 @@ def test_g5_descriptor_match_from_libann(ctx):
         assert sorted(g["nbr_ann_order"][off[q]:off[q + 1]]) == sorted(nbr[off[q]:off[q + 1]])
 
 
+def test_g10_clusters_from_the_flann_composition(ctx):
+    """The clustering stage's kernels (k_t_keys / k_cell_spans / k_cluster_edges / k_flatten behind the seam
+    plade_cluster_transforms) vs pcl::ConditionalEuclideanClustering::segment composed over FLANN (SURVEY 8c, G10)."""
+    g = load("g10_cluster.npz")
+    for name in str(g["names"]).split(";"):
+        lab, n = ctx.cluster_transforms(g[f"{name}_t"], g[f"{name}_euler"], float(g[f"{name}_dist"]), float(g[f"{name}_angle"]))
+        assert n == int(g[f"{name}_n"]) and np.array_equal(lab, g[f"{name}_cluster_of"]), name
+    lab, n = ctx.cluster_transforms(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32), 0.1, 0.01)
+    assert n == 0 and len(lab) == 0
+
+
 def test_g7_overlap_counts_from_flann(ctx):
     """K8 vs FLANN radius searches composed as util.h:611-647."""
     g = load("g7_overlap.npz")

@@ -62,3 +62,48 @@ def test_registration_planes_failure_is_reported(oracle):
     assert not ok_g and not ok_o
     assert np.array_equal(T_g, np.eye(4, dtype=np.float32))
     ctx.close()
+
+
+def test_obb_stage_against_pcl_summation_order(oracle):
+    """k_obb_units adds the points of a box in a lane-strided order, PCL (compute3DCentroid / computeCovarianceMatrixNormalized,
+    centroid.hpp:79-121,250-259) one after the other in fp32; the every-intermediate tests compare the GPU with the oracle
+    run in the GPU's order (sum_mode 1).  This test bounds the deviation from PCL's own order per unit: the GPU's box centre,
+    radius and projected corners against the oracle in sum_mode 0 on the same downsampled clouds (whole cloud and every
+    plane), relative to the box size."""
+    import plade_amd
+    tg, sr, Tgt, tp, sp = _pair(60000, 2, 5)
+    ctx = plade_amd.Context(0, dump=1)
+    ok, T = ctx.registration_planes(tg, sr, tp, sp)
+    d = ctx.dump()
+    ctx.close()
+    assert ok
+    worst = 0.0
+    for side, planes in (("tgt", tp), ("src", sp)):
+        ds = d[f"{side}_ds"].reshape(-1, 3)
+        _, c0, whd0, _ = oracle.bounding_box(ds, sum_mode=0)
+        size = float(max(whd0))
+        assert np.abs(d[f"{side}_bcenter"] - c0).max() <= 1e-5 * size
+        assert abs(float(d[f"{side}_radius"][0]) - size / 2) <= 1e-5 * size
+        worst = max(worst, float(np.abs(d[f"{side}_bcenter"] - c0).max()) / size)
+        off = d[f"{side}_plane_ds_offsets"]
+        pds = d[f"{side}_plane_ds"].reshape(-1, 3)
+        four = d[f"{side}_plane_four"].reshape(-1, 4, 3)
+        pcr = d[f"{side}_plane_center_radius"].reshape(-1, 4)
+        for i in range(len(off) - 1):
+            pts = pds[off[i]:off[i + 1]]
+            if len(pts) < 3:
+                continue
+            _, c, whd, corners = oracle.bounding_box(pts, sum_mode=0)
+            n4 = planes[0][i].astype(np.float64)
+            cor = corners.reshape(8, 3)[:4].astype(np.float64)
+            proj = cor - (cor @ n4[:3] + n4[3])[:, None] * n4[:3]          # ProjectPoints2Plane (util.h:292-340)
+            sz = float(max(whd))
+            # the principal axes of a near-square face are ill-conditioned (two nearly equal eigenvalues): compare the
+            # rectangle as a whole -- centre and half diagonal -- tightly, the corners only where the axes are well separated
+            assert np.abs(pcr[i, :3] - (proj[0] + proj[2]) / 2).max() <= 2e-5 * sz + 1e-6, (side, i)
+            assert abs(pcr[i, 3] - np.linalg.norm(proj[0] - proj[2]) / 2) <= 2e-5 * sz + 1e-6, (side, i)
+            ev = np.sort(np.asarray(whd))
+            if ev[2] - ev[1] > 0.05 * ev[2] and ev[1] - ev[0] > 0.05 * ev[2]:
+                assert np.abs(four[i] - proj).max() <= 1e-4 * sz, (side, i)
+            worst = max(worst, float(np.abs(pcr[i, :3] - (proj[0] + proj[2]) / 2).max()) / sz)
+    print("largest relative deviation of a box centre from PCL's summation order:", worst)

@@ -59,3 +59,22 @@ def test_g8_polyhedron_pair_reproduces_recorded_result(oracle, ref):
     recorded = np.array([[-0.506082, 0.860669, 0.0559446, -0.252576], [0.821345, 0.500721, -0.273261, 0.863337],
                          [-0.2632, -0.0923425, -0.960312, 0.154749], [0, 0, 0, 1]])
     assert np.abs(T - recorded).max() < 5e-5
+
+
+def test_cluster_and_penetration_walk_live_against_flann(oracle, ref):
+    """G10 / G11 live (fresh random inputs, not the committed vectors)."""
+    rng = np.random.default_rng(77)
+    for trial in range(3):
+        m = 2000
+        t = (rng.uniform(-1, 1, (30, 3))[rng.integers(0, 30, m)] + rng.normal(0, 0.03, (m, 3))).astype(np.float32)
+        e = (rng.integers(0, 2, (m, 1)) * 0.2 + rng.normal(0, 0.03, (m, 3))).astype(np.float32)
+        t[50:80] = t[:30]
+        a, na = oracle.cluster_transforms(t, e, 0.06, 0.004)
+        b, nb = ref.cluster_transforms(t, e, 0.06, 0.004)
+        assert na == nb and np.array_equal(a, b)
+    for trial in range(6):
+        pa = np.concatenate([rng.uniform(-1, 1, (1500, 2)), rng.normal(0, 0.004, (1500, 1))], 1).astype(np.float32)
+        pb = np.concatenate([rng.uniform(-1, 1, (1200, 1)), rng.normal(0, 0.004, (1200, 1)), rng.uniform(-1, 1, (1200, 1))], 1).astype(np.float32)
+        args = (np.array([0, 1, 0, 0], np.float32), np.array([-0.8, 0, 0], np.float32), np.array([1, 0, 0], np.float32),
+                float(rng.uniform(0.4, 1.6)), float(rng.uniform(0.06, 0.2)), 0.01)
+        assert oracle.pen_walk(pa, pb, *args) == ref.pen_walk(pa, pb, *args)
