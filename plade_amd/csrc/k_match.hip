@@ -220,22 +220,24 @@ __global__ __launch_bounds__(MT_TPB) void k_match_win(const float *__restrict__ 
     }
     if (!FILL && live) cnt[(size_t)q * nch + blockIdx.y] = c;
 }
-// per sorted query: its total, scattered to the original query index
+// per sorted query (of a slab): its total, scattered to the original query index
 __global__ void k_row_totals(const uint32_t *__restrict__ offs, uint32_t dq, uint32_t nch, const uint32_t *__restrict__ q_perm,
-                             uint32_t *__restrict__ row_tot /* original order, dq + 1 */) {
+                             uint32_t *__restrict__ row_tot /* original order */) {
     const uint32_t sq = blockIdx.x * blockDim.x + threadIdx.x;
     if (sq < dq) row_tot[q_perm[sq]] = offs[(size_t)(sq + 1) * nch] - offs[(size_t)sq * nch];
-    if (sq == dq) row_tot[dq] = 0;
 }
-// final position of every (sorted query, chunk) cell; offsets of the original queries; longest list
+// final position of every (sorted query, chunk) cell of a slab
 __global__ void k_win_bases(const uint32_t *__restrict__ offs, uint32_t dq, uint32_t nch, const uint32_t *__restrict__ q_perm,
-                            const uint32_t *__restrict__ row_off, uint32_t *__restrict__ base, int64_t *__restrict__ out,
-                            uint32_t *__restrict__ info) {
+                            const uint32_t *__restrict__ row_off, uint32_t *__restrict__ base) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < (size_t)dq * nch) {
         const uint32_t sq = (uint32_t)(i / nch);
         base[i] = row_off[q_perm[sq]] + (offs[i] - offs[(size_t)sq * nch]);
     }
+}
+// offsets of the original queries; total and longest list for the host
+__global__ void k_win_offsets(const uint32_t *__restrict__ row_off, uint32_t dq, int64_t *__restrict__ out, uint32_t *__restrict__ info) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i <= dq) out[i] = row_off[i];
     uint32_t len = i < dq ? row_off[i + 1] - row_off[i] : 0u;
     for (int d = 32; d >= 1; d >>= 1) len = max(len, (uint32_t)__shfl_xor((int)len, d, 64));
@@ -264,22 +266,39 @@ uint64_t MatchResult::run_windowed(plade_ctx *ctx, const float *d_qry, uint32_t 
     ctx->d2h(h_info, info.p, 8);
     ctx->sync();
     const uint32_t nch = std::max(1u, cdiv(h_info[1], MT_CHUNK));
-    const size_t ncnt = (size_t)dq * nch;
-    PLADE_REQUIRE(ncnt < (1ull << 31), PLADE_ELIMIT, "match: too many (query, chunk) cells even inside the length windows");
-    cnt.ensure(ncnt + 1); offs.ensure(ncnt + 1);
-    dim3 grid(ng, nch);
-    hipLaunchKernelGGL(k_match_win<false>, grid, dim3(MT_TPB), 0, ctx->stream, q_sorted.p, dq, t_sorted.p, w_lo.p, w_cnt.p, sq_rad, nch,
-                       cnt.p, (const uint32_t *)nullptr, (const uint32_t *)nullptr, (const uint32_t *)nullptr, (uint32_t *)nullptr,
-                       (double *)nullptr, (uint32_t *)nullptr);
-    HIP_TRY(hipMemsetAsync(cnt.p + ncnt, 0, 4, ctx->stream));
-    exclusive_scan_u32(ctx, cnt.p, offs.p, ncnt + 1);
+    // The (query, chunk) cells of the count / fill passes are laid out per SLAB of consecutive sorted queries, at most
+    // 2^26 cells (two u32 arrays: 512 MB) at a time: BASELINE configs[4] (~90 planes per cloud: 6e6 x 1.2e7 descriptors)
+    // has ~2e9 of them.  With more than one slab the count pass runs twice (totals of all slabs first -- they place the
+    // lists in the order of the ORIGINAL queries -- then again in front of each slab's fill pass).
+    uint64_t cell_budget = 1ull << 26;
+    if (const char *e = getenv("PLADE_MATCH_CELL_BUDGET")) cell_budget = std::max<uint64_t>((uint64_t)MT_TPB * nch, strtoull(e, nullptr, 10));   // tests: small slabs
+    PLADE_REQUIRE((uint64_t)MT_TPB * nch <= cell_budget, PLADE_ELIMIT, "match: a window of more than 5e8 targets");
+    const uint32_t groups_per_slab = (uint32_t)std::min<uint64_t>(ng, cell_budget / ((uint64_t)MT_TPB * nch));
+    const uint32_t n_slabs = cdiv(ng, groups_per_slab);
+    const size_t slab_cells = (size_t)groups_per_slab * MT_TPB * nch;
+    cnt.ensure(slab_cells + 1); offs.ensure(slab_cells + 1);
     row_tot.ensure((size_t)dq + 1); row_off.ensure((size_t)dq + 1);
-    hipLaunchKernelGGL(k_row_totals, dim3(cdiv(dq + 1, 256)), dim3(256), 0, ctx->stream, offs.p, dq, nch, q_perm.p, row_tot.p);
+    auto count_slab = [&](uint32_t s, uint32_t &q0, uint32_t &dqs, uint32_t &g0, uint32_t &ngs) {
+        g0 = s * groups_per_slab;
+        ngs = std::min(groups_per_slab, ng - g0);
+        q0 = g0 * MT_TPB;
+        dqs = std::min(dq - q0, ngs * MT_TPB);
+        const size_t ncnt = (size_t)dqs * nch;
+        hipLaunchKernelGGL(k_match_win<false>, dim3(ngs, nch), dim3(MT_TPB), 0, ctx->stream, q_sorted.p + 8 * (size_t)q0, dqs, t_sorted.p,
+                           w_lo.p + g0, w_cnt.p + g0, sq_rad, nch, cnt.p, (const uint32_t *)nullptr, (const uint32_t *)nullptr,
+                           (const uint32_t *)nullptr, (uint32_t *)nullptr, (double *)nullptr, (uint32_t *)nullptr);
+        HIP_TRY(hipMemsetAsync(cnt.p + ncnt, 0, 4, ctx->stream));
+        exclusive_scan_u32(ctx, cnt.p, offs.p, ncnt + 1);
+    };
+    for (uint32_t s = 0; s < n_slabs; ++s) {
+        uint32_t q0, dqs, g0, ngs;
+        count_slab(s, q0, dqs, g0, ngs);
+        hipLaunchKernelGGL(k_row_totals, dim3(cdiv(dqs, 256)), dim3(256), 0, ctx->stream, offs.p, dqs, nch, q_perm.p + q0, row_tot.p);
+    }
+    HIP_TRY(hipMemsetAsync(row_tot.p + dq, 0, 4, ctx->stream));
     exclusive_scan_u32(ctx, row_tot.p, row_off.p, (size_t)dq + 1);
     HIP_TRY(hipMemsetAsync(info.p, 0, 8, ctx->stream));
-    // `cnt` is free again: it receives the final write positions
-    hipLaunchKernelGGL(k_win_bases, dim3(cdiv(std::max(ncnt, (size_t)dq + 1), 256)), dim3(256), 0, ctx->stream, offs.p, dq, nch, q_perm.p,
-                       row_off.p, cnt.p, offsets.p, info.p);
+    hipLaunchKernelGGL(k_win_offsets, dim3(cdiv((size_t)dq + 1, 256)), dim3(256), 0, ctx->stream, row_off.p, dq, offsets.p, info.p);
     ctx->d2h(h_info, info.p, 8);
     ctx->sync();
     total = h_info[0];
@@ -287,8 +306,17 @@ uint64_t MatchResult::run_windowed(plade_ctx *ctx, const float *d_qry, uint32_t 
     if (total == 0) return 0;
     const uint32_t m = (uint32_t)total;
     t_raw.ensure(m); d2_raw.ensure(m); q_raw.ensure(m);
-    hipLaunchKernelGGL(k_match_win<true>, grid, dim3(MT_TPB), 0, ctx->stream, q_sorted.p, dq, t_sorted.p, w_lo.p, w_cnt.p, sq_rad, nch,
-                       (uint32_t *)nullptr, cnt.p, q_perm.p, t_perm.p, t_raw.p, d2_raw.p, q_raw.p);
+    for (uint32_t s = 0; s < n_slabs; ++s) {
+        uint32_t q0, dqs, g0, ngs;
+        if (n_slabs > 1) count_slab(s, q0, dqs, g0, ngs);   // one slab: its offsets are still in place
+        else { g0 = 0; ngs = ng; q0 = 0; dqs = dq; }
+        const size_t ncnt = (size_t)dqs * nch;
+        // `cnt` is free again: it receives the final write positions
+        hipLaunchKernelGGL(k_win_bases, dim3(cdiv(ncnt, 256)), dim3(256), 0, ctx->stream, offs.p, dqs, nch, q_perm.p + q0, row_off.p, cnt.p);
+        hipLaunchKernelGGL(k_match_win<true>, dim3(ngs, nch), dim3(MT_TPB), 0, ctx->stream, q_sorted.p + 8 * (size_t)q0, dqs, t_sorted.p,
+                           w_lo.p + g0, w_cnt.p + g0, sq_rad, nch, (uint32_t *)nullptr, cnt.p, q_perm.p + q0, t_perm.p, t_raw.p, d2_raw.p,
+                           q_raw.p);
+    }
     t_idx.ensure(m); dist2.ensure(m);
     q_idx_sorted = q_raw.p;
     if (max_list <= RANK_MAX_LIST) {

@@ -115,11 +115,12 @@ struct RState {
     uint32_t aj_n, aj_chain[R_B], aj_slot[R_B], aj_out[R_B];   // aj_out: offset into out_idx, 0xffffffff = none
     int32_t aj_id[R_B];
     // ---- counters
-    uint32_t n_rounds, n_rescores[2], n_batches, n_accepts, n_mark_launches, n_mark_chains;
+    uint32_t n_rounds, n_rescores[2], n_batches, n_accepts, n_mark_launches, n_mark_chains, n_deferred;
     uint32_t n_final[4], n_stop[5];   // chains by the slot they ended with / by the refit at which the reference loop stops
     // ---- accepted shapes (copied to the host-mapped result block when the call ends)
     float acc_coef[R_MAXP][4];
     uint32_t acc_support[R_MAXP], acc_offset[R_MAXP];
+    uint32_t acc_dbg[R_MAXP];        // (iteration << 16) | (chain << 8) | final slot: PLADE_TRACE_RANSAC
 };
 
 // Host-mapped, written by single device lanes, read by the host once `flag` says so.
@@ -128,9 +129,10 @@ struct RResult {
                                      // iteration of the PREVIOUS call may still report), 31 = the call has finished
     uint32_t n_acc, out_off, err, remaining;
     uint32_t n_rounds, n_rescores, n_batches, n_accepts, n_mark_launches, n_mark_chains, pad;
-    uint32_t n_final[4], n_stop[5], pad2[3];
+    uint32_t n_final[4], n_stop[5], n_deferred, pad2[2];
     float coef[R_MAXP][4];
     uint32_t support[R_MAXP];        // 0: below min_support (points removed, no plane reported)
+    uint32_t dbg[R_MAXP];
     uint32_t offset[R_MAXP];
 };
 
@@ -397,6 +399,7 @@ __global__ __launch_bounds__(TPB) void k_r_init(const RArgs A, const RInit I) {
         S->n_remaining = C.cv.n; S->sub_unassigned = 0; S->drawn = 0.f;
         S->npool = 0; S->nc = 0; S->n_acc = 0; S->out_off = 0; S->err = 0; S->aj_n = 0;
         S->n_rounds = S->n_rescores[0] = S->n_rescores[1] = S->n_batches = S->n_accepts = S->n_mark_launches = S->n_mark_chains = 0;
+        S->n_deferred = 0;
         for (int q = 0; q < 4; ++q) S->n_final[q] = 0;
         for (int q = 0; q < 5; ++q) S->n_stop[q] = 0;
     }
@@ -1407,25 +1410,70 @@ __global__ __launch_bounds__(64) void k_r_decide(const RArgs A) {
         }
     }
     __syncthreads();
+    // (1) per chain: the reference's refit loop replayed on the four slots' results (RansacShapeDetector.cpp:633-655)
+    __shared__ int s_final[R_B], s_stop[R_B];
+    __shared__ uint32_t s_defer[R_B];
+    if (threadIdx.x < nc_all) {
+        const PlaneState *st = s_st[threadIdx.x];
+        int final_slot = 0, stop = 4;
+        double newScore = st[0].wscore;
+        for (int fittingIter = 1; fittingIter <= 3; ++fittingIter) {
+            const double oldScore = newScore;
+            if (st[fittingIter - 1].n_kept < 3 || st[fittingIter].err) { stop = fittingIter; break; }   // LSFit impossible
+            newScore = st[fittingIter].wscore;
+            const uint32_t newSize = st[fittingIter].n_kept;
+            if (newScore > oldScore && newSize > min_support) final_slot = fittingIter;  // clone.Clone(&candidates.back())
+            if (!(newScore > oldScore)) { stop = fittingIter; break; }
+        }
+        s_final[threadIdx.x] = final_slot;
+        s_stop[threadIdx.x] = stop;
+        s_defer[threadIdx.x] = 0;
+    }
+    __syncthreads();
+    // (2) Accepting the chains of a batch together equals accepting them one by one, best first, only if no chain's score
+    // lists touch what a better candidate takes.  k_r_select made sure of that for the HYPOTHESES; the LS refits move the
+    // planes, and a refit that starts on a small face can tilt into a large neighbouring surface and end up ON it (seen on
+    // the 100-plane hall of BASELINE configs[4]: a box top 1.5 m under the ceiling, 20 degrees tilted, took the whole
+    // ceiling in its third refit -- together with the ceiling's own chain).  So the same provable-disjointness test is
+    // repeated on the planes the slots really used: chain b is DEFERRED (stays in the pool, nothing of it is removed now;
+    // the next iteration re-scores it without the points accepted in this one) when any plane it scored with conflicts
+    // with any plane a better chain of the batch scored with, or -- beyond its hypothesis -- with a better pool candidate
+    // that is still waiting.  The best chain is never deferred.
+    {
+        const float eps = S->eps, cos_t = S->cos_t;
+        float bbmin[3], bbmax[3];
+        for (int q = 0; q < 3; ++q) { bbmin[q] = S->bbmin[q]; bbmax[q] = S->bbmax[q]; }
+        const uint32_t n_other = 4 * R_B + R_TOP;          // per (chain b, slot sb): 4 slots of every chain, then the pool
+        for (uint32_t t = threadIdx.x; t < nc_all * 4 * n_other; t += 64) {
+            const uint32_t b = t / (4 * n_other), r = t % (4 * n_other), sb = r / n_other, o = r % n_other;
+            if (b == 0 || (int)sb > min(s_stop[b], 3) || s_st[b][sb].err) continue;
+            const float4 pb = make_float4(s_st[b][sb].n[0], s_st[b][sb].n[1], s_st[b][sb].n[2], s_st[b][sb].dist);
+            float4 po;
+            if (o < 4 * R_B) {
+                const uint32_t a = o >> 2, sa = o & 3;
+                if (a >= b || (int)sa > min(s_stop[a], 3) || s_st[a][sa].err) continue;
+                po = make_float4(s_st[a][sa].n[0], s_st[a][sa].n[1], s_st[a][sa].n[2], s_st[a][sa].dist);
+            } else {
+                const uint32_t q = o - 4 * R_B;
+                if (sb == 0 || q >= np || q >= s_batch[b]) continue;     // better candidates only; hypotheses were checked before
+                bool in_batch = false;
+                for (uint32_t x = 0; x < nc_all; ++x) in_batch = in_batch || s_batch[x] == q;
+                if (in_batch) continue;
+                po = s_pool_pl[q];
+            }
+            if (!conflict_free(pb, po, eps, cos_t, bbmin, bbmax)) s_defer[b] = 1;
+        }
+    }
+    __syncthreads();
     uint32_t n_aj = 0;
     if (threadIdx.x == 0) {
         uint32_t n_final[4] = {0, 0, 0, 0}, n_stop[5] = {0, 0, 0, 0, 0};
         for (uint32_t b = 0; b < nc_all; ++b) {
             const PlaneState *st = s_st[b];
-            n_accepts += 1;
             if (st[0].err == 1) { err = 1; done = 1; break; }   // connected-component bitmap too large
-            int final_slot = 0, stop = 4;
-            {
-                double newScore = st[0].wscore;
-                for (int fittingIter = 1; fittingIter <= 3; ++fittingIter) {
-                    const double oldScore = newScore;
-                    if (st[fittingIter - 1].n_kept < 3 || st[fittingIter].err) { stop = fittingIter; break; }   // LSFit impossible
-                    newScore = st[fittingIter].wscore;
-                    const uint32_t newSize = st[fittingIter].n_kept;
-                    if (newScore > oldScore && newSize > min_support) final_slot = fittingIter;  // clone.Clone(&candidates.back())
-                    if (!(newScore > oldScore)) { stop = fittingIter; break; }
-                }
-            }
+            if (s_defer[b]) { S->n_deferred += 1; continue; }
+            n_accepts += 1;
+            const int final_slot = s_final[b], stop = s_stop[b];
             n_final[final_slot] += 1;
             n_stop[stop] += 1;
             const PlaneState &cs = st[final_slot];
@@ -1456,6 +1504,7 @@ __global__ __launch_bounds__(64) void k_r_decide(const RArgs A) {
                 aj_out = out_off;
             }
             S->acc_support[id] = support;
+            S->acc_dbg[id] = (S->it << 16) | (b << 8) | (uint32_t)final_slot;
             S->acc_offset[id] = out_off;
             S->aj_out[n_aj] = aj_out;
             out_off += support;
@@ -1472,7 +1521,11 @@ __global__ __launch_bounds__(64) void k_r_decide(const RArgs A) {
     if (nc_all) {
         bool in_batch = false;
         uint32_t before = 0;
-        for (uint32_t q = 0; q < nc_all; ++q) { in_batch = in_batch || s_batch[q] == threadIdx.x; before += s_batch[q] < threadIdx.x; }
+        for (uint32_t q = 0; q < nc_all; ++q) {   // the batch leaves the pool, except the chains deferred above
+            const bool gone = !s_defer[q];
+            in_batch = in_batch || (gone && s_batch[q] == threadIdx.x);
+            before += (gone && s_batch[q] < threadIdx.x) ? 1u : 0u;
+        }
         const bool keep = threadIdx.x < np && !in_batch;
         if (keep) { S->pool_pl[threadIdx.x - before] = s_pool_pl[threadIdx.x]; S->pool_pos[threadIdx.x - before] = s_pool_pos[threadIdx.x]; }
         if (threadIdx.x == 0) s_keep_pos[0] = 0;
@@ -1497,11 +1550,11 @@ __global__ __launch_bounds__(64) void k_r_decide(const RArgs A) {
     if (done_now) {
         const uint32_t na = S->n_acc;
         for (uint32_t i = threadIdx.x; i < 4 * na; i += 64) (&R->coef[0][0])[i] = (&S->acc_coef[0][0])[i];
-        for (uint32_t i = threadIdx.x; i < na; i += 64) { R->support[i] = S->acc_support[i]; R->offset[i] = S->acc_offset[i]; }
+        for (uint32_t i = threadIdx.x; i < na; i += 64) { R->support[i] = S->acc_support[i]; R->offset[i] = S->acc_offset[i]; R->dbg[i] = S->acc_dbg[i]; }
         if (threadIdx.x == 0) {
             R->n_acc = na; R->out_off = S->out_off; R->err = S->err; R->remaining = S->n_remaining;
             R->n_rounds = S->n_rounds; R->n_rescores = S->n_rescores[0] + S->n_rescores[1]; R->n_batches = S->n_batches; R->n_accepts = S->n_accepts;
-            R->n_mark_launches = S->n_mark_launches; R->n_mark_chains = S->n_mark_chains;
+            R->n_mark_launches = S->n_mark_launches; R->n_mark_chains = S->n_mark_chains; R->n_deferred = S->n_deferred;
             for (int q = 0; q < 4; ++q) R->n_final[q] = S->n_final[q];
             for (int q = 0; q < 5; ++q) R->n_stop[q] = S->n_stop[q];
         }
@@ -2002,6 +2055,10 @@ void ransac_detect_prepared(plade_ctx *ctx, RansacWork &W, RansacJob jobs[RANSAC
         PLADE_REQUIRE(R.err != 1, PLADE_ELIMIT, "plane extraction: connected-component bitmap too large");
         PLADE_REQUIRE(R.err != 3, PLADE_ELIMIT, "plane extraction: too many shapes");
         PlaneSetOut &out = *J.out;
+        if (getenv("PLADE_TRACE_RANSAC"))
+            for (uint32_t i = 0; i < R.n_acc && i < 24; ++i)
+                fprintf(stderr, "[ransac] cloud %d shape %u: iteration %u chain %u slot %u support %u offset %u coef %.4f %.4f %.4f %.4f\n", g, i,
+                        R.dbg[i] >> 16, (R.dbg[i] >> 8) & 255u, R.dbg[i] & 255u, R.support[i], R.offset[i], R.coef[i][0], R.coef[i][1], R.coef[i][2], R.coef[i][3]);
         out.coef.clear(); out.offsets.assign(1, 0); out.idx.clear();
         for (uint32_t i = 0; i < R.n_acc; ++i) {
             if (!R.support[i]) continue;
@@ -2017,6 +2074,7 @@ void ransac_detect_prepared(plade_ctx *ctx, RansacWork &W, RansacJob jobs[RANSAC
         ctx->stats.add("ransac_batches", R.n_batches);
         ctx->stats.add("ransac_rescore_launches", R.n_rescores);
         ctx->stats.add("ransac_mark_launches", R.n_mark_launches);
+        ctx->stats.add("ransac_deferred_chains", R.n_deferred);
         for (int q = 0; q < 4; ++q) ctx->stats.add("ransac_final_slot" + std::to_string(q), R.n_final[q]);
         for (int q = 1; q < 5; ++q) ctx->stats.add("ransac_loop_stops_at" + std::to_string(q), R.n_stop[q]);
         if (J.rp.host_indices) {

@@ -42,9 +42,69 @@ def _furniture(rng, n_boxes, ROOM=ROOM):
     return boxes
 
 
-def _faces(scene_seed, n_boxes, ROOM=ROOM):
+def _tilted_furniture(rng, n_boxes, ROOM):
+    """BASELINE configs[4]: ~100 planes need pieces in general position (random yaw, up to 20 degrees of pitch / roll), so
+    that no two faces are parallel: axis-aligned furniture in a large hall merges into a few dozen planes, because
+    Schnabel's global scoring takes everything within 3 eps = 1.5 % of the hall's width of a plane, and its connected-
+    component step (bitmap pixel = 2 % of the width, closing, 8-connectivity) joins what is less than ~3 pixels apart.
+    The pieces therefore sit on a jittered grid in two layers (standing / suspended), ~10 % of the hall's width in size
+    and >= 7 % of it apart.  Returns a list of (centre, R (3x3, columns = box axes), half sizes)."""
+    W = max(ROOM[0], ROOM[1])
+    per_layer = (n_boxes + 1) // 2
+    nx = max(1, int(round(np.sqrt(per_layer * ROOM[0] / ROOM[1]))))
+    ny = (per_layer + nx - 1) // nx
+    cell = np.array([ROOM[0] / nx, ROOM[1] / ny])
+    boxes = []
+    for k in range(n_boxes):
+        layer, q = k // per_layer, k % per_layer
+        ix, iy = q % nx, q // nx
+        half = np.array([rng.uniform(1.1, 1.4), rng.uniform(0.9, 1.2), rng.uniform(0.8, 1.1)]) * (W / 32.0)
+        yaw, pitch, roll = rng.uniform(0, 2 * np.pi), rng.uniform(-0.35, 0.35), rng.uniform(-0.35, 0.35)
+        cz, sz, cy, sy, cx, sx = np.cos(yaw), np.sin(yaw), np.cos(pitch), np.sin(pitch), np.cos(roll), np.sin(roll)
+        Rm = (np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]]) @ np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+              @ np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]]))
+        jit = (rng.random(2) - 0.5) * 0.08 * cell
+        c = np.array([-ROOM[0] / 2 + (ix + 0.5) * cell[0] + jit[0], -ROOM[1] / 2 + (iy + 0.5) * cell[1] + jit[1],
+                      (-0.25 if layer == 0 else 0.25) * ROOM[2] + rng.uniform(-0.02, 0.02) * ROOM[2]])
+        boxes.append((c, Rm, half))
+    return boxes
+
+
+# BASELINE configs[4] ("10M-pt dense scan pair, ~100 planes"): a 32 x 28 x 12 m hall with 32 pieces in general position,
+# 6 + 3 x 32 = 102 faces.  Outliers 0.05 % instead of 3 %: uniform volumetric outliers at this point count put more than one
+# normal-compatible outlier into every pixel of the connected-component bitmap (pixel = 2 % of the hall's width, slab
+# = 6 eps = 3 % of it), which joins every pair of faces a common plane can be laid through into one shape -- in the
+# reference's RANSAC as much as in this one -- and about 40 shapes are what is left of the 102 faces.
+CONFIG4 = dict(n_boxes=32, room=(32.0, 28.0, 12.0), tilted=True, keep=0.85, outliers=0.0005)
+
+
+def _faces(scene_seed, n_boxes, ROOM=ROOM, tilted=False):
     """List of faces: (origin, edge_u, edge_v, normal, weight)."""
     rng = np.random.default_rng(scene_seed)
+    if tilted:
+        h = ROOM / 2
+        faces = []
+        for ax in range(3):
+            u, v = [a for a in range(3) if a != ax]
+            for sgn in (-1, 1):
+                o = -h.copy()
+                o[ax] = sgn * h[ax]
+                eu = np.zeros(3); eu[u] = ROOM[u]
+                ev = np.zeros(3); ev[v] = ROOM[v]
+                nrm = np.zeros(3); nrm[ax] = -sgn
+                faces.append((o, eu, ev, nrm, ROOM[u] * ROOM[v]))
+        for (c, Rm, half) in _tilted_furniture(rng, n_boxes, ROOM):
+            signs = [rng.choice([-1, 1]) for _ in range(3)]
+            signs[2] = 1                              # the top is always visible
+            for ax in range(3):
+                u, v = [a for a in range(3) if a != ax]
+                nrm = signs[ax] * Rm[:, ax]
+                o = c + signs[ax] * half[ax] * Rm[:, ax] - half[u] * Rm[:, u] - half[v] * Rm[:, v]
+                faces.append((o, 2 * half[u] * Rm[:, u], 2 * half[v] * Rm[:, v], nrm, None))
+        room_area = sum(f[4] for f in faces[:6])
+        n_f = len(faces) - 6
+        # the hall's faces share 40 % of the plane points by area, the furniture faces 60 % equally
+        return [(o, eu, ev, nrm, (0.40 * w / room_area) if i < 6 else 0.60 / max(n_f, 1)) for i, (o, eu, ev, nrm, w) in enumerate(faces)]
     h = ROOM / 2
     faces = []
     # room faces, normals pointing to the interior
@@ -85,11 +145,11 @@ def _faces(scene_seed, n_boxes, ROOM=ROOM):
 
 
 def sample_scene(n, scene_seed=0, sample_seed=1, n_boxes=8, noise=0.005, normal_jitter=0.02, outliers=0.03,
-                 return_labels=False, room=None):
+                 return_labels=False, room=None, tilted=False):
     """N x 6 float32 cloud; with return_labels also the generating face id per point (-1 = outlier).
     room: (W, D, H) in metres, default 10 x 8 x 3 (a larger room takes more furniture: BASELINE configs[4])."""
     ROOM = np.asarray(room, float) if room is not None else globals()["ROOM"]
-    faces = _faces(scene_seed, n_boxes, ROOM)
+    faces = _faces(scene_seed, n_boxes, ROOM, tilted)
     rng = np.random.default_rng(sample_seed)
     n_out = int(round(n * outliers))
     n_in = n - n_out
@@ -153,13 +213,13 @@ def planes_from_labels(cloud, labels, min_points=50):
             np.concatenate(idx).astype(np.int32) if idx else np.zeros(0, np.int32))
 
 
-def make_pair(n, seed=0, n_boxes=8, keep=0.6, return_labels=False, room=None):
+def make_pair(n, seed=0, n_boxes=8, keep=0.6, return_labels=False, room=None, tilted=False, outliers=0.03):
     """Returns (target N x 6, source ~N x 6, T_gt 4x4) with T_gt mapping source -> target
     (+ the per-point face labels of both clouds when return_labels)."""
     target, tl = sample_scene(n, scene_seed=1000 + seed, sample_seed=2 * seed + 1, n_boxes=n_boxes, return_labels=True,
-                              room=room)
+                              room=room, tilted=tilted, outliers=outliers)
     full, fl = sample_scene(int(n / keep), scene_seed=1000 + seed, sample_seed=2 * seed + 2, n_boxes=n_boxes,
-                            return_labels=True, room=room)
+                            return_labels=True, room=room, tilted=tilted, outliers=outliers)
     rng = np.random.default_rng(5000 + seed)
     d = np.array([1.0, 0.35 * rng.uniform(-1, 1), 0.0]); d /= np.linalg.norm(d)
     proj = full[:, :3] @ d

@@ -8,6 +8,7 @@ configs[4]  "10M-pt dense scan pair, ~100 planes, ~10k candidate transforms": re
             planes-given boundary, plus the size-independent properties.
 """
 import os
+import sys
 import signal
 import subprocess
 import time
@@ -138,6 +139,19 @@ def test_config3_interrupted_batch_leaves_a_valid_prefix(batch64):
 
 
 # ---- configs[4] -----------------------------------------------------------------------------------------------------
+# "10M-pt dense scan pair, ~100 planes, ~10k candidate transforms, 1xMI355X (verify-kernel stress)", covered by three tests:
+#  (1) end to end at 10M points with the plane / candidate caps lifted to 100 / 10 000: 10 001 candidates go through the
+#      penetration filter, everything up to there is compared with the oracle (a hall with axis-aligned furniture: 33 + 22
+#      planes -- parallel faces closer than 3 eps = 1.5 % of the hall's width are ONE shape for Schnabel's scoring);
+#  (2) the ~100 planes: the extraction at 10M points on a hall whose 32 pieces stand in general position (102 faces,
+#      plade_amd.synth.CONFIG4) finds every face once;
+#  (3) the verify-kernel stress the config is named after: K = 10^4 transforms on the downsampled clouds of (2) at the seam.
+# The registration of (2) end to end is NOT asserted: with ~100 planes per cloud in general position the reference's own
+# logic gives out -- 1e7 x 5e6 descriptors give 4.4e6 matches, 1.8e6 of them are versions of the true transformation, PCL's
+# single-linkage clustering makes ONE cluster of them and ClusterTransformation hands on its FIRST member
+# (util.cpp:355-357), whose closest-point lever arm of tens of metres puts it ~10 cm off: it matches 33 of 91 planes and
+# every candidate fails the penetration filter ("no matched result found", in the oracle as on the GPU; with ground-truth
+# planes one candidate survives).  tools/dbg_cfg4.py prints these numbers.
 @pytest.fixture(scope="module")
 def big_scene():
     return make_pair(10000000, seed=0, n_boxes=60, room=(30.0, 24.0, 6.0))
@@ -195,3 +209,51 @@ def test_config4_10m_points_100_planes_10k_candidates(big_scene, oracle):
     assert d["overlap_counts"].max() <= len(src_ds)
     assert d["best_index"][0] == int(np.argmax(d["scores"]))   # std::sort descending, first on ties
     ctx.close()
+
+
+@pytest.mark.timeout(3000)
+def test_config4_hundred_planes_are_extracted_at_10m_points():
+    """The ~100 planes of configs[4]: a 32 x 28 x 12 m hall with 32 pieces in general position (6 + 3 x 32 = 102 faces,
+    62 000 points per furniture face at 10M points): the extraction finds every face of the target exactly once -- no point
+    in two planes, no two faces in one plane -- and every face of the cropped source that is larger than min_support."""
+    from plade_amd.synth import CONFIG4
+    tg, sr, Tgt, tl, sl = make_pair(10000000, seed=0, return_labels=True, **CONFIG4)
+    ctx = plade_amd.Context(0, orient_normals=1)
+    for cloud, lab, want_min in ((tg, tl, 95), (sr, sl, 80)):
+        coef, off, idx = ctx.extract_planes(cloud, 10000, max_planes=400)
+        assert len(np.unique(idx)) == len(idx), "a point was handed to two planes"
+        sizes = np.bincount(lab[lab >= 0])
+        faces, mixed = [], 0
+        for p in range(len(coef)):
+            l = lab[idx[off[p]:off[p + 1]]]
+            b = np.bincount(l[l >= 0], minlength=len(sizes))
+            f = int(np.argmax(b))
+            if b[f] >= 0.97 * (off[p + 1] - off[p]) and b[f] >= 0.9 * sizes[f]:
+                faces.append(f)      # one whole face, nothing else
+            else:
+                mixed += 1           # two near-coplanar faces of neighbouring pieces in one shape, or a face in two parts
+        print(f"configs[4] extraction: {len(coef)} planes, {len(faces)} whole single faces, {mixed} others, of {int((sizes >= 12000).sum())} faces")
+        assert len(set(faces)) == len(faces) and len(faces) >= want_min and mixed <= 8, (len(faces), mixed)
+    ctx.close()
+
+
+@pytest.mark.timeout(3000)
+def test_config4_verification_stress_10k_candidates(oracle):
+    """K8 at the size the config is named after: K = 10^4 candidate transforms x ~1e6 downsampled points per cloud
+    (B_verify = K n_s 12 B ~ 1e11 B, T_verify = 27 K n_s cell probes) through the seam plade_overlap_counts,
+    66 candidates checked against the oracle's ComputeOverlap (util.h:611-647); rocprofv3 + PMC of this run:
+    profiles/k8stress_r3_* (tools/prof_k8.sh)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from k8_stress import stress_inputs
+    tds, sds, T, centers, radius, leaf = stress_inputs(10000000, 10000)
+    assert len(sds) >= 500000 and len(tds) >= 500000
+    ctx = plade_amd.Context(0)
+    counts = ctx.overlap_counts(sds, tds, T, centers, radius, leaf)
+    again = ctx.overlap_counts(sds, tds, T, centers, radius, leaf)
+    ctx.close()
+    assert np.array_equal(counts, again)
+    assert counts[0] > 0.5 * min(len(sds), len(tds))        # the true transform overlaps
+    assert (counts > 0.25 * min(len(sds), len(tds))).sum() >= 10 and (counts < 0.05 * len(sds)).sum() >= 1000
+    ids = np.unique(np.concatenate([[0, 1, 2], np.linspace(0, len(T) - 1, 64).astype(int)]))
+    for i in ids:
+        assert oracle.overlap_count(sds, tds, T[i], centers[i], radius, leaf) == counts[i], i

@@ -179,6 +179,15 @@ def test_match_windowed_equals_brute_force(oracle, monkeypatch):
     for a, b in zip(out["-1"], out["1"]):
         assert np.array_equal(a, b)
     assert len(out["1"][1]) > 4000
+    # the same in slabs of a few hundred sorted queries (large tables: the (query, chunk) cells are laid out slab by slab)
+    monkeypatch.setenv("PLADE_MATCH_WINDOW", "1")
+    monkeypatch.setenv("PLADE_MATCH_CELL_BUDGET", "4096")
+    c = plade_amd.Context(0)
+    slabbed = c.match_descriptors(q, t, 0.04)
+    c.close()
+    monkeypatch.delenv("PLADE_MATCH_CELL_BUDGET")
+    for a, b in zip(out["-1"], slabbed):
+        assert np.array_equal(a, b)
     o, n, d = oracle.match_descriptors(q[:300], t, 0.04)
     assert np.array_equal(n, out["1"][1][: len(n)]) and np.array_equal(d, out["1"][2][: len(d)])
 

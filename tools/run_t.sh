@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_gpu_registration.py tests/test_gpu_golden.py "tests/test_gpu_properties.py::test_a6_closed_form_sensitivity_at_full_size" tests/test_oracle_golden.py tests/test_oracle_vs_ref.py -q -x 2>&1 | tail -15
+python -m pytest tests/test_gpu_configs.py -k "config4" -q -s 2>&1 | grep -E "configs\[4\]|passed|failed|^E  " | cut -c1-300 | tail -14

@@ -7,13 +7,13 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import plade_amd
-from plade_amd.synth import make_pair
+from plade_amd.synth import make_pair, CONFIG4
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10000000
-boxes = int(sys.argv[2]) if len(sys.argv) > 2 else 60
+boxes = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 t0 = time.perf_counter()
-room = (30.0, 24.0, 6.0) if boxes > 8 else None      # a larger hall takes the extra furniture
-tg, sr, Tgt = make_pair(n, seed=0, n_boxes=boxes, room=room)
+# a 32 x 28 x 12 m hall with `boxes` pieces of furniture in general position (no two faces parallel): 6 + 3 x 32 = 102 planes
+tg, sr, Tgt = make_pair(n, seed=0, **CONFIG4)
 print(f"generated {len(tg)} + {len(sr)} points in {time.perf_counter() - t0:.1f} s", flush=True)
 ctx = plade_amd.Context(0, orient_normals=1, max_planes=100, max_candidates=10000, init_min_support=int(os.environ.get("MIN_SUPPORT", "10000")))
 ct, cs = ctx.upload(tg), ctx.upload(sr)
