@@ -55,6 +55,12 @@ constexpr int RANSAC_SLOTS = 2;
 // Morton order + stratified subset of the clouds (once per set of clouds; every detect call on them reuses it).
 void ransac_prepare(plade_ctx *ctx, RansacWork &W, const CloudDev *const clouds[RANSAC_SLOTS], int n_clouds);
 
+// average_spacing (code/PLADE/util.cpp:1619-1648) of the cloud in `slot` from its Morton order: two kernels queued on the
+// context's stream behind ransac_prepare; ransac_spacing_finish after any later sync of that stream (false: not available
+// -- nothing queued, or a cloud too clumped for the octree cells -- use average_spacing_dev).
+void ransac_spacing_enqueue(plade_ctx *ctx, RansacWork &W, int slot, int k, uint32_t samples);
+bool ransac_spacing_finish(RansacWork &W, int slot, float *spacing_out);
+
 // One PlaneExtraction::detect (code/PLADE/plane_extraction.cpp:173-200) per ACTIVE slot, all in one launch sequence:
 // slots with active[s] == false keep the results of their previous detect call untouched.
 struct RansacJob {

@@ -1653,6 +1653,110 @@ __global__ void k_r_seam_init(const RArgs A, float4 hyp, float4 pos, float w_eps
     state_from_hyp(&ch.hdr->st[0], hyp, pos);
 }
 
+// ------------------------------------------------------------------------------------------------
+// average_spacing (code/PLADE/util.cpp:1619-1648) from the Morton order the extraction has built anyway: the k = 6 nearest
+// neighbours (FLANN fp32 distances) of <= 10000 strided sample points.  The octree cell of a point at level L is a
+// contiguous range of the sorted cloud; a table of the 8^L range starts (one binary search per cell) turns the exact ring
+// search of k_knn_grid (k_voxel.hip) into look-ups on data that is already in HBM -- no grid build (cell ids, a 1M-key sort,
+// a gather) for 10^4 queries.  The k smallest fp32 distances are the same numbers whatever structure finds them.
+__global__ void k_sp_cells(const uint32_t *__restrict__ codes, uint32_t n, int level, uint32_t *__restrict__ table) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x, ncell = 1u << (3 * level);
+    if (c > ncell) return;
+    table[c] = c == ncell ? n : lb_u32(codes, n, c << (24 - 3 * level));
+}
+
+struct SpArgs {
+    const float *x, *y, *z;          // Morton-ordered SoA
+    const uint32_t *table;           // 8^L + 1 range starts
+    const float *aos;                // the cloud as it came (queries are taken in ORIGINAL order, util.cpp:1626-1633)
+    uint32_t n, step, nq;
+    int level, k;
+    float mnx, mny, mnz, inv_cube, cell;   // Morton quantisation (k_morton), cell edge at `level`
+    uint32_t dense_limit;
+};
+constexpr int SPK = 8;
+__global__ __launch_bounds__(256) void k_sp_knn(const SpArgs A, double *__restrict__ avg_out, uint32_t *__restrict__ nbs_out,
+                                                uint32_t *__restrict__ too_dense) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t qi = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (qi >= A.nq) return;
+    const uint32_t pi = min(A.n - 1, qi * A.step);
+    const f3 q(A.aos[(size_t)pi * 6], A.aos[(size_t)pi * 6 + 1], A.aos[(size_t)pi * 6 + 2]);
+    const int sh = 8 - A.level, dim = 1 << A.level;
+    const int cx = (int)(min(255u, (uint32_t)max(0.f, (q.x - A.mnx) * A.inv_cube * 256.f)) >> sh);
+    const int cy = (int)(min(255u, (uint32_t)max(0.f, (q.y - A.mny) * A.inv_cube * 256.f)) >> sh);
+    const int cz = (int)(min(255u, (uint32_t)max(0.f, (q.z - A.mnz) * A.inv_cube * 256.f)) >> sh);
+    float best[SPK];
+#pragma unroll
+    for (int b = 0; b < SPK; ++b) best[b] = INFINITY;
+    float kth[SPK];
+    int found = 0;
+    bool dense = false;
+    for (int ring = 0; ring <= dim; ++ring) {
+        const int w = 2 * ring + 1;
+        // the cells of the shell, 64 at a time: every lane looks up one cell's range, then the wavefront walks the non-empty
+        // cells one after the other with all lanes striding over the cell's points (coalesced loads from the sorted cloud)
+        for (int t0 = 0; t0 < w * w * w; t0 += 64) {
+            const int t = t0 + lane;
+            uint32_t jb = 0, je = 0;
+            if (t < w * w * w) {
+                const int ddx = t % w - ring, ddy = (t / w) % w - ring, ddz = t / (w * w) - ring;
+                const int x = cx + ddx, y = cy + ddy, z = cz + ddz;
+                if (max(abs(ddx), max(abs(ddy), abs(ddz))) == ring && x >= 0 && y >= 0 && z >= 0 && x < dim && y < dim && z < dim) {
+                    const uint32_t c = (spread3((uint32_t)z) << 2) | (spread3((uint32_t)y) << 1) | spread3((uint32_t)x);
+                    jb = A.table[c]; je = A.table[c + 1];
+                    if (je - jb > A.dense_limit) { dense = true; je = jb; }
+                }
+            }
+            unsigned long long todo = __ballot(je > jb);
+            while (todo) {
+                const int src = __ffsll((long long)todo) - 1;
+                todo &= todo - 1;
+                const uint32_t b = __shfl(jb, src, 64), e = __shfl(je, src, 64);
+                for (uint32_t j = b + lane; j < e; j += 64) {
+                    float d = flann_d2(q, f3(A.x[j], A.y[j], A.z[j]));
+                    if (d < best[SPK - 1]) {
+#pragma unroll
+                        for (int bb = 0; bb < SPK; ++bb)
+                            if (d < best[bb]) { const float tt = best[bb]; best[bb] = d; d = tt; }
+                    }
+                }
+            }
+        }
+        if (__ballot(dense)) break;   // a cell with thousands of points: the caller takes the adaptive grid instead
+        // wave-wide K smallest (lists are ascending: every lane offers its current head)
+        int head = 0;
+        found = 0;
+        for (int r = 0; r < A.k; ++r) {
+            float v = INFINITY;
+#pragma unroll
+            for (int b = 0; b < SPK; ++b) if (b == head) v = best[b];
+            float mv = v;
+            int ml = lane;
+            for (int d = 32; d >= 1; d >>= 1) {
+                const float ov = __shfl_xor(mv, d, 64);
+                const int ol = __shfl_xor(ml, d, 64);
+                if (ov < mv || (ov == mv && ol < ml)) { mv = ov; ml = ol; }
+            }
+            if (mv == INFINITY) break;
+            if (lane == ml) ++head;
+            kth[r] = mv;
+            ++found;
+        }
+        // everything in ring + 1 and beyond is at least ring * cell away from q
+        const float bound = (float)ring * A.cell * 0.999f;
+        if (found == A.k && kth[A.k - 1] < bound * bound) break;
+    }
+    const bool any_dense = __ballot(dense) != 0ull;
+    if (lane == 0) {
+        if (any_dense) *too_dense = 1u;
+        double avg = 0.0;
+        for (int r = 1; r < found; ++r) avg += (double)sqrtf(kth[r]);  // util.cpp:1640-1642: starts from 1 to exclude itself
+        avg_out[qi] = avg;
+        nbs_out[qi] = (uint32_t)found;
+    }
+}
+
 // ---- seam S1a (plade_score_planes / plade_score_planes_subset): the caller's hypotheses through the loop's OWN K1
 // kernels -- counts by k_r_rescore (the pool re-score), ordered lists by k_r_mark + k_r_compact_raster (slot 0 of the
 // acceptance chains), subset counts by k_r_score_sub.  These kernels only put the hypotheses where the loop keeps them.
@@ -1733,7 +1837,12 @@ struct RansacSlot {
     RResult *res = nullptr, *res_dev = nullptr;   // host-mapped result block
     ChainLayout L{};
     DBuf<uint32_t> seam_list;
-    ~RansacSlot() { if (res) (void)hipHostFree(res); }
+    // average spacing from the Morton order (ransac_spacing_*): cell table, results in host-mapped memory
+    DBuf<uint32_t> sp_table;
+    char *sp_host = nullptr, *sp_dev = nullptr;   // nq doubles | nq counts | flag
+    uint32_t sp_nq = 0, sp_cap = 0;
+    float cube_inv = 0.f, cube = 0.f;             // Morton quantisation of this slot (ransac_prepare)
+    ~RansacSlot() { if (res) (void)hipHostFree(res); if (sp_host) (void)hipHostFree(sp_host); }
 };
 
 struct RansacWork {
@@ -1914,6 +2023,7 @@ void ransac_prepare(plade_ctx *ctx, RansacWork &W, const CloudDev *const clouds[
         total += c.n;
         const float cube = std::max({c.bbmax[0] - c.bbmin[0], c.bbmax[1] - c.bbmin[1], c.bbmax[2] - c.bbmin[2], 1e-30f});
         M.c[g] = MortonIn{c.x(), c.y(), c.z(), c.n, c.bbmin[0], c.bbmin[1], c.bbmin[2], 1.f / cube};
+        s.cube = cube; s.cube_inv = 1.f / cube;
         s.sorted.n = c.n;
         s.sorted.pitch = c.pitch;
         s.sorted.soa.ensure(6 * c.pitch + 4);
@@ -2144,6 +2254,71 @@ void plane_component(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const
     for (int k = 0; k < 3; ++k) { out.fit[k] = hst[1].n[k]; out.fit[3 + k] = hst[1].pos[k]; }
     out.fit[6] = hst[1].dist;
     out.wscore = hst[0].wscore;
+}
+
+// ---- average spacing from the Morton order -------------------------------------------------------------------------
+void ransac_spacing_enqueue(plade_ctx *ctx, RansacWork &W, int slot, int k, uint32_t samples) {
+    RansacSlot &s = W.slot[slot];
+    s.sp_nq = 0;
+    PLADE_REQUIRE(k >= 1 && k <= SPK && slot < W.ng, PLADE_EINVAL, "spacing: bad argument");
+    const uint32_t n = s.n;
+    if (n == 0) return;
+    const CloudDev &c = *s.cloud;
+    size_t step = 1;
+    if (n > samples) step = n / samples;                    // util.cpp:1626-1629
+    const uint32_t nq = (uint32_t)((n + step - 1) / step);
+    // level: ~100 points per occupied cell of a surface-like cloud (the wavefront scans a cell with all lanes; measured at 1M
+    // points: level 6 = 15.6 cm cells, k_sp_cells 5 us + k_sp_knn 110 us; level 7: 15 + 128 us)
+    const double ex = std::max(1e-9, (double)c.bbmax[0] - c.bbmin[0]), ey = std::max(1e-9, (double)c.bbmax[1] - c.bbmin[1]),
+                 ez = std::max(1e-9, (double)c.bbmax[2] - c.bbmin[2]);
+    const double area = 2 * (ex * ey + ey * ez + ex * ez);
+    const double want = std::sqrt(128.0 * area / (double)n);
+    int level = 2;
+    static const int max_level = [] { const char *e = getenv("PLADE_SPACING_LEVEL"); return e ? atoi(e) : 7; }();
+    while (level < max_level && (double)s.cube / (double)(1 << (level + 1)) >= 0.7 * want) ++level;
+    const uint32_t ncell = 1u << (3 * level);
+    s.sp_table.ensure((size_t)ncell + 2);
+    const uint32_t need = nq * 12 + 64;
+    if (s.sp_cap < need) {
+        if (s.sp_host) HIP_TRY(hipHostFree(s.sp_host));
+        s.sp_host = nullptr;
+        HIP_TRY(hipHostMalloc((void **)&s.sp_host, need + need / 4, hipHostMallocMapped | hipHostMallocCoherent));
+        HIP_TRY(hipHostGetDevicePointer((void **)&s.sp_dev, s.sp_host, 0));
+        s.sp_cap = need + need / 4;
+    }
+    uint32_t *flag_host = reinterpret_cast<uint32_t *>(s.sp_host + (size_t)nq * 12);
+    *flag_host = 0u;
+    hipLaunchKernelGGL(k_sp_cells, dim3(cdiv((size_t)ncell + 1, 256)), dim3(256), 0, ctx->stream, s.codes.p, n, level, s.sp_table.p);
+    SpArgs A{s.sorted.x(), s.sorted.y(), s.sorted.z(), s.sp_table.p, c.aos.p, n, (uint32_t)step, nq, level, k,
+             c.bbmin[0], c.bbmin[1], c.bbmin[2], s.cube_inv, s.cube / (float)(1 << level), 4096u};
+    hipLaunchKernelGGL(k_sp_knn, dim3(cdiv(nq, 4)), dim3(256), 0, ctx->stream, A, reinterpret_cast<double *>(s.sp_dev),
+                       reinterpret_cast<uint32_t *>(s.sp_dev + (size_t)nq * 8), reinterpret_cast<uint32_t *>(s.sp_dev + (size_t)nq * 12));
+    HIP_TRY(hipGetLastError());
+    s.sp_nq = nq;
+}
+
+// after the stream has passed the kernels above (any later sync of it); false: nothing was queued or the cloud is too
+// clumped for the octree cells (the caller falls back to average_spacing_dev's adaptive grid)
+bool ransac_spacing_finish(RansacWork &W, int slot, float *spacing_out) {
+    RansacSlot &s = W.slot[slot];
+    const uint32_t nq = s.sp_nq;
+    s.sp_nq = 0;
+    if (!nq) return false;
+    std::atomic_thread_fence(std::memory_order_acquire);
+    const double *avg = reinterpret_cast<const double *>(s.sp_host);
+    const uint32_t *nbs = reinterpret_cast<const uint32_t *>(s.sp_host + (size_t)nq * 8);
+    if (*reinterpret_cast<const volatile uint32_t *>(s.sp_host + (size_t)nq * 12)) return false;
+    // util.cpp:1630-1647: sequential double accumulation in sample order
+    double total = 0.0;
+    size_t total_count = 0;
+    for (uint32_t i = 0; i < nq; ++i) {
+        const int nb = (int)nbs[i];
+        if (nb <= 1) continue;
+        total += (avg[i] / nb);
+        ++total_count;
+    }
+    *spacing_out = static_cast<float>(total / total_count);
+    return true;
 }
 
 // ---- seam S1a on the loop's kernels ------------------------------------------------------------------------------

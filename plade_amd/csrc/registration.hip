@@ -33,6 +33,7 @@ void extract_pair(plade_ctx *ctx, const CloudDev *const clouds[2], const int ini
     if (!ctx->ransac_work) ctx->ransac_work = ransac_work_create();
     RansacWork &W = *ctx->ransac_work;
     ransac_prepare(ctx, W, clouds, 2);
+    ransac_spacing_enqueue(ctx, W, 1, 6, 10000);   // average_spacing(source, k = 6) of plade.cpp:41, see ransac.hip
     int ms[2] = {init_min_support[0], init_min_support[1]}, trials[2] = {0, 0};
     bool finished[2] = {false, false};
     const char *tags[2] = {"_tgt", "_src"};
@@ -103,35 +104,19 @@ int register_clouds(plade_ctx *ctx, const CloudDev &tgt, const CloudDev &src, in
             PLADE_REQUIRE(plade_ctx_create(ctx->device, &a) == PLADE_OK, PLADE_EDEVICE, "cannot create the auxiliary stream");
             ctx->aux = a;
         }
-        plade_ctx *aux = ctx->aux;
-        aux->params = ctx->params;
-        aux->stats.clear();
-        Err aux_err{0, ""};
         if (!ctx->reg_work) ctx->reg_work = registration_work_create();
-        // the point spacing (plade.cpp:41) only needs the source cloud: it runs on the auxiliary stream, driven by a
-        // helper thread, while this thread extracts the planes of both clouds
-        std::thread th([&]() {
-            (void)hipSetDevice(ctx->device);
-            try { spacing = source_spacing(aux, *ctx->reg_work, src); have_spacing = true; }
-            catch (const Err &e) { aux_err = e; }
-            catch (const std::exception &e) { aux_err = Err{PLADE_EDEVICE, e.what()}; }
-        });
-        Err main_err{0, ""};
-        // every exception is caught while the helper thread is joinable (unwinding past it would terminate the process)
-        try {
-            const CloudDev *clouds[2] = {&tgt, &src};
-            const int init[2] = {auto_tune ? ctx->params.init_min_support : ms_t, auto_tune ? ctx->params.init_min_support : ms_s};
-            PlaneSetOut *outs[2] = {&tp, &sp};
-            // the next stage reads the index lists from the device; the host copy is only for dumps
-            extract_pair(ctx, clouds, init, auto_tune, outs, ctx->params.dump != 0);
+        const CloudDev *clouds[2] = {&tgt, &src};
+        const int init[2] = {auto_tune ? ctx->params.init_min_support : ms_t, auto_tune ? ctx->params.init_min_support : ms_s};
+        PlaneSetOut *outs[2] = {&tp, &sp};
+        // the next stage reads the index lists from the device; the host copy is only for dumps.  The point spacing
+        // (plade.cpp:41) only needs the source cloud: its two kernels are queued right behind the Morton order of the
+        // extraction (extract_pair) and run ahead of the RANSAC iterations on the same stream -- no helper thread
+        extract_pair(ctx, clouds, init, auto_tune, outs, ctx->params.dump != 0);
+        {
+            StageTimer ts(ctx, "t_spacing");
+            have_spacing = ransac_spacing_finish(*ctx->ransac_work, 1, &spacing);
+            if (!have_spacing) { spacing = source_spacing(ctx, *ctx->reg_work, src); have_spacing = true; }   // clumped cloud
         }
-        catch (const Err &e) { main_err = e; }
-        catch (const std::exception &e) { main_err = Err{PLADE_EDEVICE, e.what()}; }
-        th.join();
-        aux->ev_collect();
-        ctx->stats.merge(aux->stats);
-        if (main_err.code) throw main_err;
-        if (aux_err.code) throw aux_err;
         if (auto_tune) {
             if (tp.P() < (uint32_t)ctx->params.min_planes) {  // plade.cpp:646-650
                 ctx->last_error = "too few planes extracted from the target point cloud";

@@ -1,2 +1,5 @@
 cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_gpu_configs.py -k "config4" -q -s 2>&1 | grep -E "configs\[4\]|passed|failed|^E  " | cut -c1-300 | tail -14
+for L in 6 7; do
+PLADE_SPACING_LEVEL=$L python tools/exp_throughput.py 384 8 2>/dev/null | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); st=d.pop('stats'); print('level $L', round(d['reg_per_s'],1), d['ok'], d['identical'], 'busy', round(d['busy_threads'],2))"
+done
