@@ -14,6 +14,13 @@
 #include <string>
 #include <vector>
 
+// PLADE_USE_REAL_EIGEN: the real Eigen (header only; the reference vendors 3.4.0 under code/3rd_party/eigen-3.4.0) with
+// the PCL stand-ins below -- what a tree without Boost can build, and what tests/test_host_logic.py compiles the host
+// sources against to prove they are source compatible with the real Eigen::Matrix<float,4,4> / Vector3f.
+#ifdef PLADE_USE_REAL_EIGEN
+#include <Eigen/Core>
+#include <Eigen/LU>
+#else
 namespace Eigen {
 
 template <typename Scalar, int Rows, int Cols>
@@ -108,6 +115,7 @@ typedef Matrix<float, 3, 1> Vector3f;
 typedef Matrix<float, 4, 4> Matrix4f;
 
 }  // namespace Eigen
+#endif  // PLADE_USE_REAL_EIGEN
 
 namespace pcl {
 

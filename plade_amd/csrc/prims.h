@@ -1,5 +1,4 @@
-// plade_amd/csrc/prims.h -- device-wide sort/scan plumbing: radix_sort.hip for the big sorts, a single-launch scan, and
-// rocPRIM's block sort for sorts of a few thousand items; the only translation unit that includes rocPRIM is prims.hip.
+// plade_amd/csrc/prims.h -- device-wide sort/scan plumbing: radix_sort.hip for the sorts, a single-launch scan.
 #pragma once
 #include "ctx.h"
 
@@ -10,7 +9,7 @@ void sort_pairs_u32(plade_ctx *ctx, const uint32_t *keys_in, uint32_t *keys_out,
                     uint32_t *vals_out, size_t n, int bits = 32);
 void sort_pairs_u64(plade_ctx *ctx, const uint64_t *keys_in, uint64_t *keys_out, const uint32_t *vals_in,
                     uint32_t *vals_out, size_t n, int bits = 64);
-// radix_sort.hip: the hand-written onesweep sort behind sort_pairs_* for n above a few thousand
+// radix_sort.hip: the hand-written onesweep sort behind sort_pairs_*
 void radix_sort_pairs_u32(plade_ctx *ctx, const uint32_t *keys_in, uint32_t *keys_out, const uint32_t *vals_in,
                           uint32_t *vals_out, size_t n, int bits);
 void radix_sort_pairs_u64(plade_ctx *ctx, const uint64_t *keys_in, uint64_t *keys_out, const uint32_t *vals_in,

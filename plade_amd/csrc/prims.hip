@@ -1,45 +1,22 @@
-// plade_amd/csrc/prims.hip -- device-wide sort / scan plumbing: the big sorts are radix_sort.hip, the prefix sums the
-// single-launch scan below; rocPRIM's one-launch block sort still serves sorts of a few thousand items.
+// plade_amd/csrc/prims.hip -- device-wide sort / scan plumbing: the sorts are radix_sort.hip, the prefix sums the
+// single-launch scan below.  No library device code: everything on the path is hand-written HIP.
 #include "prims.h"
-#include <rocprim/rocprim.hpp>
-
 namespace plade {
-
-static void *temp(plade_ctx *ctx, size_t bytes) { return ctx->scratch[7].ensure(bytes + 256); }
-
-// rocPRIM's default switches from its merge sort to the onesweep radix sort above 1 Mi items; with the
-// bit range known (our keys are packed cell / Morton / index fields) onesweep needs ceil(bits/8)
-// passes and wins far earlier on gfx950, so the switch point is lowered.
-using SortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 16384>;
-
-template <class K>
-static void sort_pairs(plade_ctx *ctx, const K *ki, K *ko, const uint32_t *vi, uint32_t *vo, size_t n, int bits) {
-    if (!n) return;
-    PLADE_REQUIRE(n < (1ull << 31), PLADE_ELIMIT, "sort: too many items");
-    size_t tb = 0;
-    HIP_TRY(rocprim::radix_sort_pairs<SortConfig>(nullptr, tb, ki, ko, vi, vo, (unsigned int)n, 0u, (unsigned int)bits, ctx->stream));
-    void *t = temp(ctx, tb);
-    HIP_TRY(rocprim::radix_sort_pairs<SortConfig>(t, tb, ki, ko, vi, vo, (unsigned int)n, 0u, (unsigned int)bits, ctx->stream));
-}
-
-// below this size rocPRIM's single-launch block / merge sort is the cheaper choice
-constexpr size_t RS_MIN_ITEMS = 16384;
-static bool use_rocprim() { static const bool v = getenv("PLADE_SORT_ROCPRIM") != nullptr; return v; }
 
 static bool trace_sorts() { static const bool v = getenv("PLADE_TRACE_SORT") != nullptr; return v; }
 
+// every sort of the path, whatever its size, is the hand-written onesweep radix sort of radix_sort.hip (a list of a few
+// hundred items is one tile: a histogram launch + one launch per digit)
 void sort_pairs_u32(plade_ctx *ctx, const uint32_t *ki, uint32_t *ko, const uint32_t *vi, uint32_t *vo, size_t n,
                     int bits) {
     if (trace_sorts()) fprintf(stderr, "[sort] u32 n %zu bits %d\n", n, bits);
-    if (n > RS_MIN_ITEMS && !use_rocprim()) radix_sort_pairs_u32(ctx, ki, ko, vi, vo, n, bits);
-    else sort_pairs<uint32_t>(ctx, ki, ko, vi, vo, n, bits);
+    radix_sort_pairs_u32(ctx, ki, ko, vi, vo, n, bits);
 }
 
 void sort_pairs_u64(plade_ctx *ctx, const uint64_t *ki, uint64_t *ko, const uint32_t *vi, uint32_t *vo, size_t n,
                     int bits) {
     if (trace_sorts()) fprintf(stderr, "[sort] u64 n %zu bits %d\n", n, bits);
-    if (n > RS_MIN_ITEMS && !use_rocprim()) radix_sort_pairs_u64(ctx, ki, ko, vi, vo, n, bits);
-    else sort_pairs<uint64_t>(ctx, ki, ko, vi, vo, n, bits);
+    radix_sort_pairs_u64(ctx, ki, ko, vi, vo, n, bits);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -146,6 +146,7 @@ struct CloudView {
 struct RCloudArgs {
     CloudView cv;                    // the Morton-ordered cloud
     const uint32_t *codes;           // its Morton codes
+    const uint32_t *cells6;          // start of every level-6 octree cell in the sorted cloud (8^6 + 1 entries), or nullptr
     const uint32_t *orig;            // Morton position -> original point index (nullptr: identity, seam S1c)
     int32_t *assigned;               // shapeIndex per Morton position (nullptr: all unassigned, seam S1c)
     const float *sub;                // stratified subset, SoA with pitch sub_pitch
@@ -452,8 +453,24 @@ __global__ __launch_bounds__(256) void k_r_sample(const RArgs A) {
     const uint32_t low_bits = 24 - 3 * level;
     const uint32_t mask = low_bits >= 32 ? 0u : ~((1u << low_bits) - 1u);
     const uint32_t lo_key = codes[i0] & mask, hi_key = lo_key | ~mask;
-    const uint32_t lo = lb_u32(codes, c.n, lo_key);
-    uint32_t hi = (hi_key == 0xffffffffu || hi_key >= 0xffffffu) ? c.n : lb_u32(codes, c.n, hi_key + 1u);
+    uint32_t lo, hi;
+    if (C.cells6) {
+        // the cell's range from the level-6 table: two look-ups down to level 6, below that a search inside one level-6 cell
+        // (instead of two 20-step binary searches over the whole cloud: the kernel is a chain of dependent loads)
+        if (level <= 6) {
+            const uint32_t c0 = lo_key >> 6, span = 1u << (3 * (6 - level));
+            lo = C.cells6[c0];
+            hi = C.cells6[c0 + span];
+        } else {
+            const uint32_t c0 = lo_key >> 6;
+            const uint32_t b6 = C.cells6[c0], e6 = C.cells6[c0 + 1];
+            lo = b6 + lb_u32(codes + b6, e6 - b6, lo_key);
+            hi = (hi_key >= 0xffffffu) ? e6 : b6 + lb_u32(codes + b6, e6 - b6, hi_key + 1u);
+        }
+    } else {
+        lo = lb_u32(codes, c.n, lo_key);
+        hi = (hi_key == 0xffffffffu || hi_key >= 0xffffffu) ? c.n : lb_u32(codes, c.n, hi_key + 1u);
+    }
     if (hi - lo < 3) return;
     uint32_t s[3] = {i0, 0, 0};
     int got = 1;
@@ -692,10 +709,14 @@ __device__ void next_round_or_stop(RState *S) {
 //      8 eps apart (the two 3 eps bands plus refit drift cannot meet): the difference of the signed
 //      distances is linear in p, so constant sign at the 8 corners + min |.| at a corner decide it.
 // Anything else counts as a conflict and the two candidates are accepted one after the other.
-__device__ bool conflict_free(const float4 &a, const float4 &b, float eps, float cos_t, const float *bbmin, const float *bbmax) {
-    const float c = fabsf(a.x * b.x + a.y * b.y + a.z * b.z);
+// cos_gate: cosine of 2 acos(cos_t) + 5 degrees when that angle is below 90 degrees, else -1 (criterion (a) never holds)
+__device__ __forceinline__ float conflict_gate(float cos_t) {
     const float two_theta = 2.f * acosf(fminf(1.f, cos_t)) + 0.0873f;
-    if (two_theta < 1.5707f && c < cosf(two_theta)) return true;
+    return two_theta < 1.5707f ? cosf(two_theta) : -1.f;
+}
+__device__ bool conflict_free(const float4 &a, const float4 &b, float eps, float cos_gate, const float *bbmin, const float *bbmax) {
+    const float c = fabsf(a.x * b.x + a.y * b.y + a.z * b.z);
+    if (c < cos_gate) return true;
     if (c < 0.97f) return false;
     const float s = (a.x * b.x + a.y * b.y + a.z * b.z) >= 0 ? 1.f : -1.f;
     float mn = INFINITY, mx = -INFINITY;
@@ -743,7 +764,7 @@ __global__ __launch_bounds__(64) void k_r_select(const RArgs A, int phase) {
         if (lane == 0) { S->npool = 0; S->nc = 0; S->aj_n = 0; S->fresh = 0; next_round_or_stop(S); }
         return;
     }
-    const float eps = S->eps, cos_t = S->cos_t;
+    const float eps = S->eps, cos_t = conflict_gate(S->cos_t);
     float bbmin[3], bbmax[3];
     for (int k = 0; k < 3; ++k) { bbmin[k] = S->bbmin[k]; bbmax[k] = S->bbmax[k]; }
     __shared__ uint32_t s_batch[R_B];
@@ -1440,7 +1461,7 @@ __global__ __launch_bounds__(64) void k_r_decide(const RArgs A) {
     // with any plane a better chain of the batch scored with, or -- beyond its hypothesis -- with a better pool candidate
     // that is still waiting.  The best chain is never deferred.
     {
-        const float eps = S->eps, cos_t = S->cos_t;
+        const float eps = S->eps, cos_t = conflict_gate(S->cos_t);
         float bbmin[3], bbmax[3];
         for (int q = 0; q < 3; ++q) { bbmin[q] = S->bbmin[q]; bbmax[q] = S->bbmax[q]; }
         const uint32_t n_other = 4 * R_B + R_TOP;          // per (chain b, slot sb): 4 slots of every chain, then the pool
@@ -1659,6 +1680,13 @@ __global__ void k_r_seam_init(const RArgs A, float4 hyp, float4 pos, float w_eps
 // contiguous range of the sorted cloud; a table of the 8^L range starts (one binary search per cell) turns the exact ring
 // search of k_knn_grid (k_voxel.hip) into look-ups on data that is already in HBM -- no grid build (cell ids, a 1M-key sort,
 // a gather) for 10^4 queries.  The k smallest fp32 distances are the same numbers whatever structure finds them.
+struct Cells6Args { const uint32_t *codes[R_G]; uint32_t n[R_G]; uint32_t *table[R_G]; };
+__global__ void k_cells6(const Cells6Args A) {   // the sampler's level-6 table of every cloud of the sequence
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x, ncell = 1u << 18;
+    if (c > ncell) return;
+    const int g = blockIdx.y;
+    A.table[g][c] = c == ncell ? A.n[g] : lb_u32(A.codes[g], A.n[g], c << 6);
+}
 __global__ void k_sp_cells(const uint32_t *__restrict__ codes, uint32_t n, int level, uint32_t *__restrict__ table) {
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x, ncell = 1u << (3 * level);
     if (c > ncell) return;
@@ -1838,7 +1866,7 @@ struct RansacSlot {
     ChainLayout L{};
     DBuf<uint32_t> seam_list;
     // average spacing from the Morton order (ransac_spacing_*): cell table, results in host-mapped memory
-    DBuf<uint32_t> sp_table;
+    DBuf<uint32_t> sp_table, cells6;
     char *sp_host = nullptr, *sp_dev = nullptr;   // nq doubles | nq counts | flag
     uint32_t sp_nq = 0, sp_cap = 0;
     float cube_inv = 0.f, cube = 0.f;             // Morton quantisation of this slot (ransac_prepare)
@@ -1888,7 +1916,7 @@ RArgs make_args(RansacWork &W, int ng) {
         const CloudDev &c = s.sorted;
         // field by field: the bytes of this struct key the captured graphs, padding included (A was zeroed)
         C.cv.x = c.x(); C.cv.y = c.y(); C.cv.z = c.z(); C.cv.nx = c.nx(); C.cv.ny = c.ny(); C.cv.nz = c.nz(); C.cv.n = s.n;
-        C.codes = s.codes.p; C.orig = s.orig.p; C.assigned = s.assigned.p;
+        C.codes = s.codes.p; C.cells6 = s.cells6.p; C.orig = s.orig.p; C.assigned = s.assigned.p;
         C.sub = s.sub.p; C.sub_index = s.sub_index.p; C.sub_pitch = s.sub_pitch; C.n_sub = s.n_sub;
         C.st = s.state.p; C.res = s.res_dev;
         C.hyp = reinterpret_cast<float4 *>(s.round_block.p);
@@ -2045,6 +2073,14 @@ void ransac_prepare(plade_ctx *ctx, RansacWork &W, const CloudDev *const clouds[
     hipLaunchKernelGGL(k_morton, dim3(cdiv(total, 256)), dim3(256), 0, ctx->stream, M, W.keys_in.p, W.vals_in.p);
     sort_pairs_u32(ctx, W.keys_in.p, W.keys.p, W.vals_in.p, W.perm.p, total, n_clouds > 1 ? 25 : 24);
     hipLaunchKernelGGL(k_gather_cloud, dim3(cdiv(total, 256)), dim3(256), 0, ctx->stream, G, W.keys.p, W.perm.p);
+    Cells6Args C6;
+    memset(&C6, 0, sizeof(C6));
+    for (int g = 0; g < n_clouds; ++g) {
+        RansacSlot &s = W.slot[g];
+        s.cells6.ensure((1u << 18) + 2);
+        C6.codes[g] = s.codes.p; C6.n[g] = s.n; C6.table[g] = s.cells6.p;
+    }
+    hipLaunchKernelGGL(k_cells6, dim3(cdiv((1u << 18) + 1, 256), n_clouds), dim3(256), 0, ctx->stream, C6);
     HIP_TRY(hipGetLastError());
 }
 

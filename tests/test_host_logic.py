@@ -160,3 +160,20 @@ def test_bench_lowers_the_in_flight_count_to_fit_a_shared_cpu_quota():
     assert b.inflight_for_budget(16, 1) == 8 and b.inflight_for_budget(256, 8) == 8 and b.inflight_for_budget(24, 8) == 8
     assert b.inflight_for_budget(16, 8) == 4          # the GPU boxes of this pool: 16 CPUs for the container
     assert b.inflight_for_budget(8, 8) == 2 and b.inflight_for_budget(1, 8) == 2
+
+
+def test_host_sources_compile_against_the_real_eigen():
+    """plade_host.cpp / main.cpp are written against Eigen::Matrix<float,4,4> and Eigen::Vector3f as the reference's
+    plade.h / plane_extraction.h use them; this image has no Boost (hence no PCL), but Eigen is header-only and vendored by
+    the reference: with -DPLADE_USE_REAL_EIGEN the host sources must compile against it (only the PCL types stay
+    stand-ins).  Runs where /root/reference is mounted (the build container)."""
+    import shutil
+    import subprocess
+    eigen = "/root/reference/code/3rd_party/eigen-3.4.0"
+    if not os.path.isdir(os.path.join(eigen, "Eigen")) or not shutil.which("g++"):
+        pytest.skip("no vendored Eigen here")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "plade_amd", "csrc")
+    r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-DPLADE_USE_REAL_EIGEN", "-I", eigen, "-I", os.path.join(root, "include"),
+                        "-I", csrc, os.path.join(csrc, "plade_host.cpp"), os.path.join(csrc, "main.cpp")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
