@@ -220,9 +220,6 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
-
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -231,17 +228,30 @@ def main():
     one_gpu = os.environ.get("PLADE_BENCH_ONE_GPU") == "1"
     if one_gpu:
         local_rank = 0
+    # torch only where it is needed -- torch.distributed (RCCL) for N > 1.  `import torch` brings the HIP runtime bundled
+    # with the wheel (ROCm 7.0) into the process ahead of the system's (7.2), and the library then runs on that one:
+    # measured 458 instead of 483 registrations/s at N = 1 (tools/exp_throughput.py, EXP_TORCH=import).  A single-GPU run
+    # brackets its timed region with hipDeviceSynchronize through the library instead of device_sync().
+    torch = dist = None
     if world > 1:
+        import torch
+        import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="gloo" if one_gpu else "nccl", world_size=world, rank=rank)  # nccl == RCCL on ROCm
+        dev = torch.device("cpu") if one_gpu else torch.device("cuda", local_rank)
     else:
-        torch.cuda.set_device(local_rank)
-    dev = torch.device("cpu") if one_gpu else torch.device("cuda", local_rank)
+        dev = None
 
     import plade_amd
     from plade_amd.synth import make_pair
+
+    def device_sync():
+        if torch is not None:
+            torch.cuda.synchronize()
+        else:
+            plade_amd.device_synchronize(local_rank)
 
     import threading
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
@@ -324,10 +334,10 @@ def main():
     for t in wths:
         t.join()
     lead = max(args.warmup, M)
-    torch.cuda.synchronize()
+    device_sync()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    device_sync()
     cpu0, thr0 = time.process_time(), _cgroup_throttle()
     t_begin = time.perf_counter()
     elapsed, timed, timed_ids, span = run_pipeline(hstep, lead, args.steps)
@@ -340,18 +350,19 @@ def main():
     from plade_amd.batch import gather_results
     all_T, all_ok = gather_results(np.stack(results), np.array(oks, bool), world * args.steps, rank, world,
                                    device=dev if world > 1 else None)
-    torch.cuda.synchronize()
+    device_sync()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    device_sync()
     bracketed = time.perf_counter() - t_begin
-    tmax = torch.tensor([elapsed, bracketed], dtype=torch.float64, device=dev)
-    okt = torch.tensor([n_ok], dtype=torch.int64, device=dev)
+    total_ok = n_ok
     if world > 1:
+        tmax = torch.tensor([elapsed, bracketed], dtype=torch.float64, device=dev)
+        okt = torch.tensor([n_ok], dtype=torch.int64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(okt, op=dist.ReduceOp.SUM)
-    elapsed, bracketed = float(tmax[0].item()), float(tmax[1].item())
-    total_ok = int(okt.item())
+        elapsed, bracketed = float(tmax[0].item()), float(tmax[1].item())
+        total_ok = int(okt.item())
 
     # every registration of the same pair, whichever context ran it, must return the same bits
     ref_result = {}
@@ -366,7 +377,7 @@ def main():
     resident_leg = None
     if args.resident_steps > 0:
         r_el, r_res, r_ids, _ = run_pipeline(rstep, M, args.resident_steps)
-        torch.cuda.synchronize()
+        device_sync()
         same = all(np.array_equal(r_res[k][1], ref_result.get(r_ids[k] % len(pairs), r_res[k][1])) for k in range(len(r_res)))
         resident_leg = {"value": args.resident_steps / r_el, "unit": "registrations/s (this rank)", "steps": args.resident_steps,
                         "ms_per_step": r_el / args.resident_steps * 1e3, "identical_to_host_cloud_results": bool(same),
@@ -554,7 +565,7 @@ def main():
             "default_mode_rank0": default_mode,
             "pipeline": {"lead_in_steps": lead, "timed_steps": args.steps, "tail_steps": M,
                          "timing": "completion of step #lead_in .. completion of step #(lead_in + steps), per rank, MAX over ranks; "
-                                   "barrier + torch.cuda.synchronize() before the first and after the last step of the run"},
+                                   "barrier + device_sync() before the first and after the last step of the run"},
             "roofline": roofline,
             "cpu_baseline": cpu,
             "stage_seconds_profiled_step": stage_times,

@@ -31,6 +31,8 @@ int plade_ctx_create(int device, plade_ctx **out);
 void plade_ctx_destroy(plade_ctx *ctx);
 const char *plade_last_error(const plade_ctx *ctx);
 const char *plade_version(void);
+/* hipDeviceSynchronize on `device`: everything this process has queued there has finished (benchmark brackets). */
+int plade_device_synchronize(int device);
 
 /* Tunables that are hard-coded literals in the reference (defaults = reference values):
  *   max_planes      40     code/PLADE/plade.cpp:604   (extract(): top-40 cap)

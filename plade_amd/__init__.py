@@ -21,7 +21,7 @@ ABI_SYMBOLS = [
     "plade_overlap_counts", "plade_average_spacing", "plade_voxel_downsample", "plade_registration_planes",
     "plade_registration", "plade_registration_minsupport", "plade_cloud_upload", "plade_cloud_free",
     "plade_registration_dev", "plade_dump_get", "plade_stats_get", "plade_kernel_time", "plade_plane_component",
-    "plade_sort_pairs", "plade_host_pin", "plade_host_unpin", "plade_score_planes_subset", "plade_registration_next", "plade_cluster_transforms",
+    "plade_sort_pairs", "plade_host_pin", "plade_host_unpin", "plade_score_planes_subset", "plade_registration_next", "plade_cluster_transforms", "plade_device_synchronize",
 ]
 
 
@@ -63,6 +63,7 @@ def load_library(path=LIB_PATH):
     sig("plade_version", restype=C.c_char_p)
     sig("plade_last_error", restype=C.c_char_p)
     sig("plade_last_error", argtypes=[p])
+    sig("plade_device_synchronize", argtypes=[C.c_int])
     sig("plade_ctx_create", argtypes=[C.c_int, C.POINTER(p)])
     sig("plade_ctx_destroy", argtypes=[p])
     sig("plade_default_params", argtypes=[C.POINTER(Params)])
@@ -124,6 +125,13 @@ DUMP_FIELDS = {
     "tgt_planes": np.float32, "tgt_plane_offsets": np.int32, "tgt_plane_idx": np.int32,
     "src_planes": np.float32, "src_plane_offsets": np.int32, "src_plane_idx": np.int32,
 }
+
+
+def device_synchronize(device=0):
+    """hipDeviceSynchronize on `device` through the library (no torch needed in a single-GPU process)."""
+    rc = load_library().plade_device_synchronize(int(device))
+    if rc != 0:
+        raise PladeError(rc, "plade_device_synchronize failed")
 
 
 class Cloud:

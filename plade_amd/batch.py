@@ -13,10 +13,12 @@ def shard(n_items, rank, world):
 def gather_results(local_T, local_ok, n_items, rank, world, device=None):
     """local_T: (len(shard), 4, 4) float32, local_ok: (len(shard),) bool.  Returns on rank 0
     (T (n_items,4,4), ok (n_items,)) in input order, on other ranks (None, None)."""
-    import torch
-    import torch.distributed as dist
     mine = shard(n_items, rank, world)
     assert len(mine) == len(local_T) == len(local_ok)
+    if world == 1:   # nothing to exchange (and no torch in a single-GPU process: see bench.py)
+        return np.asarray(local_T, np.float32).reshape(n_items, 4, 4).copy(), np.asarray(local_ok, bool).copy()
+    import torch
+    import torch.distributed as dist
     per = (n_items + world - 1) // world  # pad every shard to the same length for the collective
     buf = np.zeros((per, 17), np.float32)
     if len(mine):

@@ -53,6 +53,12 @@ extern "C" void plade_ctx_destroy(plade_ctx *ctx) {
     }
 }
 
+// waits for everything queued on `device` by this process (the timed region of a benchmark is bracketed with it)
+extern "C" int plade_device_synchronize(int device) {
+    if (hipSetDevice(device) != hipSuccess) return PLADE_EDEVICE;
+    return hipDeviceSynchronize() == hipSuccess ? PLADE_OK : PLADE_EDEVICE;
+}
+
 extern "C" const char *plade_last_error(const plade_ctx *ctx) { return ctx ? ctx->last_error.c_str() : "null ctx"; }
 
 extern "C" int plade_set_params(plade_ctx *ctx, const plade_params *p) {

@@ -8,9 +8,11 @@ import threading
 import time
 
 import numpy as np
-if float(os.environ.get("EXP_BG_COPY", "0")) > 0:
+if float(os.environ.get("EXP_BG_COPY", "0")) > 0 or os.environ.get("EXP_TORCH"):
     import torch
-    torch.cuda.init()
+    if os.environ.get("EXP_TORCH") != "import":
+        torch.cuda.init()
+        torch.cuda.synchronize()
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import plade_amd

@@ -5,13 +5,15 @@
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out
-TAG=${1:-r2}
+TAG=${1:-r3}
 mkdir -p $O
 cd $R
 timeout 900 python bench.py > $O/bench_$TAG.json 2> $O/bench_$TAG.err
-tail -c 3000 $O/bench_$TAG.json
+tail -c 600 $O/bench_$TAG.json
+timeout 900 python bench.py --steps 20 --warmup 5 > $O/bench_${TAG}_driver.json 2> $O/bench_${TAG}_driver.err
+python -c "import json; d=json.load(open('$O/bench_${TAG}_driver.json')); print('driver command:', d['value'], d['ms_per_step'], d['resident_rank0']['value'], d['default_mode_rank0'], d['cpu_baseline']['value'])"
 cd /tmp && export TMPDIR=/tmp
-CMD="python $R/bench.py --steps 96 --warmup 8 --host-steps 0 --no-cpu-baseline --profiled-steps 2"
+CMD="python $R/bench.py --steps 96 --warmup 8 --resident-steps 0 --no-cpu-baseline --no-default-mode --profiled-steps 2"
 rm -rf $O/prof_bench $O/prof_pmc_fetch $O/prof_pmc_write
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench -o bench -- $CMD > $O/prof_bench.log 2>&1
 timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/prof_pmc_fetch -o pmc -- $CMD > $O/prof_pmc_fetch.log 2>&1

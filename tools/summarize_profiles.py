@@ -2,7 +2,7 @@
 
     python tools/summarize_profiles.py r1
 
-profiles/<round>_kernel_stats.csv : `rocprofv3 --kernel-trace --stats` of `python bench.py --steps 96 --warmup 8 --host-steps 0 --no-cpu-baseline --profiled-steps 2`
+profiles/<round>_kernel_stats.csv : `rocprofv3 --kernel-trace --stats` of `python bench.py --steps 96 --warmup 8 --resident-steps 0 --no-cpu-baseline --no-default-mode --profiled-steps 2`
 profiles/<round>_pmc_hbm.csv      : per-kernel average FETCH_SIZE / WRITE_SIZE (separate --pmc passes), with the gfx950
                                     FETCH_SIZE x2 correction of MI355X_MICROARCH.md applied in the `hbm_read_bytes` column
 """
@@ -44,4 +44,7 @@ with open(os.path.join(out, f"{rnd}_pmc_hbm.csv"), "w", newline="") as f:
 src = os.path.join(go, f"bench_{rnd}.json")
 if os.path.exists(src):
     shutil.copy(src, os.path.join(out, f"{rnd}_bench_n1.json"))
+src = os.path.join(go, f"bench_{rnd}_driver.json")
+if os.path.exists(src):
+    shutil.copy(src, os.path.join(out, f"{rnd}_bench_n1_driver_command.json"))
 print(sorted(os.listdir(out)))
