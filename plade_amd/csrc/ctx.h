@@ -39,6 +39,18 @@ struct Stats {
 }  // namespace plade
 
 namespace plade {
+// One sleeping poll of the throughput modes (params.host_wait != 0).  50 us for the first polls, 100 us after: with
+// eight registrations in flight the GPU is never idle while one host thread oversleeps, and against 15 / 40 us the
+// process spends 12 % less CPU at the same throughput (profiles/r3_experiments.md).
+inline void poll_sleep(int polls) {
+    timespec ts{0, polls < 8 ? 50000 : 100000};
+    nanosleep(&ts, nullptr);
+}
+inline double thread_cpu_seconds() {
+    timespec ts;
+    clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
 // nanosleep() of a normal thread is rounded up by 50 us of timer slack; ask for 1 us once per thread
 inline void relax_timer_slack() {
     static thread_local bool done = false;
@@ -165,12 +177,13 @@ struct plade_ctx {
         if (params.host_wait == 0) { HIP_TRY(hipStreamSynchronize(s)); }
         else {
             plade::relax_timer_slack();
+            const double c0 = plade::thread_cpu_seconds();
+            struct Acc { plade::Stats &st; double c0; ~Acc() { st.add("cpu_sync_polls", plade::thread_cpu_seconds() - c0); } } acc{stats, c0};
             for (int polls = 0;; ++polls) {
                 const hipError_t e = hipStreamQuery(s);
                 if (e == hipSuccess) break;
                 if (e != hipErrorNotReady) throw plade::Err{-2, std::string("hipStreamQuery: ") + hipGetErrorString(e)};
-                timespec ts{0, polls < 8 ? 15000 : 40000};
-                nanosleep(&ts, nullptr);
+                plade::poll_sleep(polls);
             }
         }
         if (s == stream) { finish_reads(); write_arena_used = 0; }
@@ -279,8 +292,12 @@ struct StageTimer {
     plade_ctx *ctx;
     const char *name;
     Clock::time_point t0;
-    StageTimer(plade_ctx *c, const char *n) : ctx(c), name(n), t0(Clock::now()) {}
-    ~StageTimer() { ctx->stats.add(name, secs_since(t0)); }
+    double cpu0;      // CPU time of the calling thread (helper threads account for themselves)
+    StageTimer(plade_ctx *c, const char *n) : ctx(c), name(n), t0(Clock::now()), cpu0(plade::thread_cpu_seconds()) {}
+    ~StageTimer() {
+        ctx->stats.add(name, secs_since(t0));
+        ctx->stats.add(std::string("cpu") + (name + 1), plade::thread_cpu_seconds() - cpu0);   // "t_x" -> "cpu_x"
+    }
 };
 
 // ---- kernels / stages implemented across the .hip files ----------------------------------

@@ -274,6 +274,8 @@ bool run_registration(plade_ctx *ctx, RegistrationWork &W, const CloudDev &tgt, 
         HIP_TRY(hipEventRecord(W.ev_main, ctx->stream));
         HIP_TRY(hipStreamWaitEvent(aux->stream, W.ev_main, 0));
         std::thread th([&]() {
+            const double cpu0 = thread_cpu_seconds();
+            struct Acc { Stats &st; double c0; ~Acc() { st.add("cpu_prepare_helper", thread_cpu_seconds() - c0); } } acc{aux->stats, cpu0};
             (void)hipSetDevice(ctx->device);
             try { ok_c = prepare_side(aux, "src", src, sp, downSampleDistance, pen_grid_cell(lengthThreshold), scale, false, W.src_pairs, C); }
             catch (const Err &e) { aux_err = e; }

@@ -2020,14 +2020,19 @@ void wait_iterations(plade_ctx *ctx, RResult *const *res, int nres, uint32_t wan
         return true;
     };
     if (ctx->params.host_wait != 0) relax_timer_slack();
+    const double cpu0 = thread_cpu_seconds();
+    struct Acc { Stats &st; double c0; ~Acc() { st.add("cpu_ransac_wait_polls", thread_cpu_seconds() - c0); } } acc{ctx->stats, cpu0};
+    // the flag is what is waited for; the stream query only catches a device loop that died without reporting (it takes the
+    // runtime's locks, so the sleeping modes ask every 16th poll, the spinning mode every 64th)
+    const uint32_t query_mask = 15u;
     for (uint32_t polls = 0;; ++polls) {
         if (reached()) break;
-        if ((polls & 63u) == 63u || ctx->params.host_wait != 0) {
+        if ((polls & 63u) == 63u || (ctx->params.host_wait != 0 && (polls & query_mask) == query_mask)) {
             const hipError_t e = hipStreamQuery(ctx->stream);
             if (e == hipSuccess) { if (reached()) break; throw Err{PLADE_EDEVICE, "plane extraction: the device loop did not report"}; }
             if (e != hipErrorNotReady) throw Err{PLADE_EDEVICE, std::string("hipStreamQuery: ") + hipGetErrorString(e)};
         }
-        if (ctx->params.host_wait != 0) { timespec ts{0, polls < 8 ? 15000 : 40000}; nanosleep(&ts, nullptr); }
+        if (ctx->params.host_wait != 0) poll_sleep((int)polls);
     }
     std::atomic_thread_fence(std::memory_order_acquire);
 }
