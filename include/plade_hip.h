@@ -59,9 +59,11 @@ typedef struct plade_params {
     int32_t dump;
     uint64_t ransac_seed;
     int32_t host_wait;   /* how the calling thread waits for the GPU: 0 = spin (lowest latency; the HIP runtime keeps
-                          * one CPU busy per waiting thread), 1 = poll + short sleeps (throughput mode: many
-                          * contexts in flight per CPU; adds ~30 us per wait).  C++ API / CLI: env
-                          * PLADE_HOST_WAIT=spin|sleep. */
+                          * one CPU busy per waiting thread), 1 = poll + 50-100 us sleeps (throughput mode: many
+                          * contexts in flight per CPU), 2 = as 1 and the next plane-extraction iteration is
+                          * queued before the current one has reported (a few contexts per GPU whose stream would
+                          * otherwise idle while the host sleeps; with >= 8 in flight the empty speculative
+                          * iteration costs more than it hides).  C++ API / CLI: env PLADE_HOST_WAIT=spin|sleep. */
     int32_t unoriented_normals;
 } plade_params;
 void plade_default_params(plade_params *p);
