@@ -2,7 +2,7 @@
 
     python tools/summarize_profiles.py r1
 
-profiles/<round>_kernel_stats.csv : `rocprofv3 --kernel-trace --stats` of `python bench.py --steps 96 --warmup 8 --resident-steps 0 --no-cpu-baseline --no-default-mode --profiled-steps 2`
+profiles/<round>_kernel_stats.csv : `rocprofv3 --kernel-trace --stats` of `BENCH_LEAD_ROUNDS=1 python bench.py --steps 96 --warmup 8 --resident-steps 0 --no-cpu-baseline --no-default-mode --profiled-steps 2` (tools/profile_bench.sh)
 profiles/<round>_pmc_hbm.csv      : per-kernel average FETCH_SIZE / WRITE_SIZE (separate --pmc passes), with the gfx950
                                     FETCH_SIZE x2 correction of MI355X_MICROARCH.md applied in the `hbm_read_bytes` column
 """
