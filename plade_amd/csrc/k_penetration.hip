@@ -193,9 +193,14 @@ void build_pen_grid(plade_ctx *ctx, PlaneCloudsDev &pc, const PlaneGeomHost &geo
 }
 
 // Cells of one plane grid that can hold a point within `rr` of the segment start + t direc, t in [0, L]
-// (all in the plane cloud's own frame).  The line is walked along its major in-plane axis: lane-strided
-// columns (or rows), in each the cell range the line covers, widened by the radius.  fn(point) is called
-// once for every point of those cells.
+// (all in the plane cloud's own frame).  The line is walked along its major in-plane axis: one lane per column (or row),
+// in each the cell range the line covers, widened by the radius.  fn(point) is called once for every point of those
+// cells.  The POINTS are then shared out over the wavefront: the q-th cell of every column contributes a range of points,
+// the ranges of the 64 columns are laid end to end (wave prefix sum) and lane l takes entries l, l + 64, ... of that
+// list (owner column by binary search over the prefix sums).  A lane per column walking its own cells -- the first
+// version -- is a chain of ~50 dependent loads for the usual 5-column segment with 5 of 64 lanes busy; this way a
+// segment costs two dependent loads per cell row and all lanes load points at once.  Same set of points, every point
+// once; fn only counts, so the order does not matter.
 template <class Fn>
 __device__ __forceinline__ void pen_visit(const PenFrame &f, const float4 *__restrict__ pts, const uint32_t *__restrict__ cell_start,
                                           f3 start, f3 direc, float L, float rr, float cell, int lane, Fn fn) {
@@ -212,20 +217,59 @@ __device__ __forceinline__ void pen_visit(const PenFrame &f, const float4 *__res
     const int ca0 = max((int)floorf(amin * inv) + 1, 0), ca1 = min((int)floorf(amax * inv) + 1, na - 1);
     const float da = a1 - a0;
     const float slope = fabsf(da) > 1e-12f ? (b1 - b0) / da : 0.f;
-    for (int ca = ca0 + lane; ca <= ca1; ca += 64) {
-        // the part of the segment (extended by rr at both ends) inside this column
-        float lo = fmaxf((float)(ca - 1) * cell, amin), hi = fminf((float)ca * cell, amax);
-        if (hi < lo) { const float t = lo; lo = hi; hi = t; }
-        const float bl = b0 + (lo - a0) * slope, bh = b0 + (hi - a0) * slope;
-        const int cb0 = max((int)floorf((fminf(bl, bh) - pad) * inv) + 1, 0);
-        const int cb1 = min((int)floorf((fmaxf(bl, bh) + pad) * inv) + 1, nbm - 1);
-        for (int cb = cb0; cb <= cb1; ++cb) {
-            const uint32_t c = f.base + (major_u ? (uint32_t)cb * (uint32_t)f.nu + (uint32_t)ca
-                                                 : (uint32_t)ca * (uint32_t)f.nu + (uint32_t)cb);
-            const uint32_t pb = cell_start[c], pe = cell_start[c + 1];
-            for (uint32_t j = pb; j < pe; ++j) {
-                const float4 q = pts[j];
-                fn(f3(q.x, q.y, q.z));
+    for (int base = ca0; base <= ca1; base += 64) {          // wave-uniform
+        const int ca = base + lane;
+        int cb0 = 0, ncell = 0;
+        if (ca <= ca1) {
+            // the part of the segment (extended by rr at both ends) inside this column
+            float lo = fmaxf((float)(ca - 1) * cell, amin), hi = fminf((float)ca * cell, amax);
+            if (hi < lo) { const float t = lo; lo = hi; hi = t; }
+            const float bl = b0 + (lo - a0) * slope, bh = b0 + (hi - a0) * slope;
+            cb0 = max((int)floorf((fminf(bl, bh) - pad) * inv) + 1, 0);
+            const int cb1 = min((int)floorf((fmaxf(bl, bh) + pad) * inv) + 1, nbm - 1);
+            ncell = max(cb1 - cb0 + 1, 0);
+        }
+        int most = ncell;
+        for (int d = 32; d >= 1; d >>= 1) most = max(most, __shfl_xor(most, d, 64));
+        constexpr int QN = 4;                                // cells of a column per round (a column spans <= 4: 2 pad + slope)
+        for (int q0 = 0; q0 < most; q0 += QN) {              // wave-uniform
+            uint32_t pb[QN], len[QN], mine = 0;
+#pragma unroll
+            for (int q = 0; q < QN; ++q) {                   // all cell_start loads of the round are in flight together
+                pb[q] = 0; len[q] = 0;
+                if (q0 + q < ncell) {
+                    const int cb = cb0 + q0 + q;
+                    const uint32_t c = f.base + (major_u ? (uint32_t)cb * (uint32_t)f.nu + (uint32_t)ca
+                                                         : (uint32_t)ca * (uint32_t)f.nu + (uint32_t)cb);
+                    pb[q] = cell_start[c];
+                    len[q] = cell_start[c + 1] - pb[q];
+                }
+                mine += len[q];
+            }
+            uint32_t incl = mine;                            // inclusive prefix sum of the columns' point counts
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
+            const uint32_t total = __shfl(incl, 63, 64), excl = incl - mine;
+            for (uint32_t t0 = 0; t0 < total; t0 += 64) {    // wave-uniform
+                const uint32_t t = t0 + (uint32_t)lane;
+                int lo = 0, hi = 63;                         // owner column = first lane whose inclusive sum exceeds t
+                for (int it = 0; it < 6; ++it) {
+                    const int mid = (lo + hi) >> 1;
+                    const bool right = __shfl(incl, mid, 64) <= t;
+                    lo = right ? mid + 1 : lo;
+                    hi = right ? hi : mid;
+                }
+                uint32_t r = t - __shfl(excl, lo, 64), at = 0;   // position inside the owner's cells, then inside one cell
+                bool found = false;
+#pragma unroll
+                for (int q = 0; q < QN; ++q) {
+                    const uint32_t o_pb = __shfl(pb[q], lo, 64), o_len = __shfl(len[q], lo, 64);
+                    if (!found && r < o_len) { at = o_pb + r; found = true; }
+                    if (!found) r -= o_len;
+                }
+                if (t < total && found) {
+                    const float4 p4 = pts[at];
+                    fn(f3(p4.x, p4.y, p4.z));
+                }
             }
         }
     }
@@ -241,7 +285,7 @@ struct PenSide {
 // (util.cpp:1383, fp32 accumulation), PEN_MAXS + 1 entries computed once on the host -- it does not depend
 // on the item.  All distance tests are the reference's arithmetic on the reference's operands (source
 // points moved by the candidate with pcl_xform); the grids only select which points are looked at.
-__global__ __launch_bounds__(PEN_TPB) void k_pen_walk(const PenItem *__restrict__ items, const uint32_t *__restrict__ pair_count,
+__global__ __launch_bounds__(PEN_TPB) __attribute__((amdgpu_waves_per_eu(6))) void k_pen_walk(const PenItem *__restrict__ items, const uint32_t *__restrict__ pair_count,
                                                       const uint32_t *__restrict__ pair_order, PenTables tb,
                                                       const float *__restrict__ step_dist, PenSide S, PenSide T_, float cell,
                                                       float search_radius, int min_points, float min_distance,
@@ -253,7 +297,10 @@ __global__ __launch_bounds__(PEN_TPB) void k_pen_walk(const PenItem *__restrict_
     if (blockIdx.y * PEN_G >= cnt) return;          // whole workgroup idle (uniform)
     for (int i = threadIdx.x; i <= PEN_MAXS; i += blockDim.x) s_dist[i] = step_dist[i];   // the step table in LDS
     __syncthreads();
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // the wave index as a scalar: everything derived from it (the item, its candidate, the two plane frames) is then loaded
+    // with scalar loads into SGPRs instead of being replicated over the lanes' VGPRs: 142 -> 99 VGPRs, and the occupancy
+    // hint above brings the kernel to 80 (6 waves per SIMD instead of 3; the LDS step counters allow 7)
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const uint32_t slot = blockIdx.y * PEN_G + wave;
     if (slot >= cnt) return;
     uint32_t *s_cnt = s_cnt_all[wave];
@@ -306,6 +353,7 @@ __global__ __launch_bounds__(PEN_TPB) void k_pen_walk(const PenItem *__restrict_
         if (pass == 0) pen_visit(ft, T_.pts, T_.cell_start, start, direc, L, search_radius * 0.5f, cell, lane, gate);
         else pen_visit(fs, S.pts, S.cell_start, start_s, direc_s, L, search_radius * 0.5f, cell, lane, gate);
         __syncwarp();
+        if (__atomic_load_n(&cand_flags[it.k], __ATOMIC_RELAXED)) return;   // rejected by another item meanwhile
         const float pl0 = pass == 0 ? tc[0] : it.plane1[0], pl1 = pass == 0 ? tc[1] : it.plane1[1],
                     pl2 = pass == 0 ? tc[2] : it.plane1[2], pl3 = pass == 0 ? tc[3] : it.plane1[3];
         int pos = 0, neg = 0;

@@ -8,7 +8,17 @@ import threading
 import time
 
 import numpy as np
-if float(os.environ.get("EXP_BG_COPY", "0")) > 0 or os.environ.get("EXP_TORCH"):
+if os.environ.get("EXP_TORCH") == "after":      # the library (and with it the SYSTEM HIP runtime) first, torch second
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import plade_amd as _p
+    _p.load_library()
+    import torch
+    torch.cuda.init()
+    _x = torch.arange(8, device="cuda") * 2
+    torch.cuda.synchronize()
+    print("torch after the library: cuda ok", _x.sum().item(), torch.version.hip, flush=True)
+    print([l.split()[-1] for l in open("/proc/self/maps") if "libamdhip64" in l][:2], flush=True)
+elif float(os.environ.get("EXP_BG_COPY", "0")) > 0 or os.environ.get("EXP_TORCH"):
     import torch
     if os.environ.get("EXP_TORCH") != "import":
         torch.cuda.init()
