@@ -24,7 +24,8 @@ constexpr int MT_CHUNK = 512;  // targets per block (grid.y)
 template <bool FILL>
 __global__ __launch_bounds__(MT_TPB) void k_match(const float *__restrict__ qry, uint32_t dq,
                                                   const float *__restrict__ tgt, uint32_t dt, double sq_rad,
-                                                  uint32_t nch, uint32_t *__restrict__ cnt /* dq*nch */,
+                                                  uint32_t nch, uint32_t chunk /* targets per blockIdx.y, multiple of MT_TILE */,
+                                                  uint32_t *__restrict__ cnt /* dq*nch */,
                                                   const uint32_t *__restrict__ offs /* dq*nch */,
                                                   uint32_t *__restrict__ t_idx, double *__restrict__ d2_out,
                                                   uint32_t *__restrict__ q_idx) {
@@ -34,8 +35,8 @@ __global__ __launch_bounds__(MT_TPB) void k_match(const float *__restrict__ qry,
     double qd[8];
 #pragma unroll
     for (int d = 0; d < 8; ++d) qd[d] = live ? (double)qry[(size_t)q * 8 + d] : 0.0;
-    const uint32_t t_begin = blockIdx.y * MT_CHUNK;
-    const uint32_t t_end = min(dt, t_begin + MT_CHUNK);
+    const uint32_t t_begin = blockIdx.y * chunk;
+    const uint32_t t_end = min(dt, t_begin + chunk);
     uint32_t c = 0;
     uint32_t wpos = (FILL && live) ? offs[(size_t)q * nch + blockIdx.y] : 0u;
     for (uint32_t t0 = t_begin; t0 < t_end; t0 += MT_TILE) {
@@ -357,12 +358,17 @@ uint64_t MatchResult::run(plade_ctx *ctx, const float *d_qry, uint32_t dq, const
         const bool force = env && atoi(env) > 0, never = env && atoi(env) < 0;
         if (!never && (force || (double)dq * (double)dt > 2.0e10)) return run_windowed(ctx, d_qry, dq, d_tgt, dt, radius);
     }
-    const uint32_t nch = cdiv(dt, MT_CHUNK);
+    // A workgroup is one wave of 64 queries against one chunk of targets (fp64 distances, ~50 cycles per target): with
+    // 512 targets per chunk the usual table (2 000 x 6 000 descriptors) is 420 waves of 50 us on a part with 1024 SIMDs;
+    // chunks of one LDS tile give four times the waves at a quarter of the length (96 + 82 -> see profiles/r3).  The
+    // (query, chunk) count table grows with it, so large tables keep the long chunks.
+    const uint32_t chunk = (size_t)dq * cdiv(dt, MT_TILE) <= (1u << 22) ? (uint32_t)MT_TILE : (uint32_t)MT_CHUNK;
+    const uint32_t nch = cdiv(dt, chunk);
     const size_t ncnt = (size_t)dq * nch;
     PLADE_REQUIRE(ncnt < (1ull << 31), PLADE_ELIMIT, "match: too many (query, chunk) cells");
     cnt.ensure(ncnt + 1); offs.ensure(ncnt + 1);
     dim3 grid(cdiv(dq, MT_TPB), nch);
-    hipLaunchKernelGGL(k_match<false>, grid, dim3(MT_TPB), 0, ctx->stream, d_qry, dq, d_tgt, dt, sq_rad, nch, cnt.p,
+    hipLaunchKernelGGL(k_match<false>, grid, dim3(MT_TPB), 0, ctx->stream, d_qry, dq, d_tgt, dt, sq_rad, nch, chunk, cnt.p,
                        (const uint32_t *)nullptr, (uint32_t *)nullptr, (double *)nullptr, (uint32_t *)nullptr);
     HIP_TRY(hipMemsetAsync(cnt.p + ncnt, 0, 4, ctx->stream));
     exclusive_scan_u32(ctx, cnt.p, offs.p, ncnt + 1);
@@ -377,7 +383,7 @@ uint64_t MatchResult::run(plade_ctx *ctx, const float *d_qry, uint32_t dq, const
     if (total == 0) return 0;
     const uint32_t m = tot32;
     t_raw.ensure(m); d2_raw.ensure(m); q_raw.ensure(m);
-    hipLaunchKernelGGL(k_match<true>, grid, dim3(MT_TPB), 0, ctx->stream, d_qry, dq, d_tgt, dt, sq_rad, nch, cnt.p, offs.p,
+    hipLaunchKernelGGL(k_match<true>, grid, dim3(MT_TPB), 0, ctx->stream, d_qry, dq, d_tgt, dt, sq_rad, nch, chunk, cnt.p, offs.p,
                        t_raw.p, d2_raw.p, q_raw.p);
     t_idx.ensure(m); dist2.ensure(m);
     q_idx_sorted = q_raw.p;   // lists are contiguous per query

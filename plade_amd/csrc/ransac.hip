@@ -1720,6 +1720,11 @@ __global__ __launch_bounds__(256) void k_sp_knn(const SpArgs A, double *__restri
     float kth[SPK];
     int found = 0;
     bool dense = false;
+    // Cells of the outer rings that cannot hold one of the k nearest are not scanned: once k candidates are known, a cell
+    // whose box is farther from q than the current k-th distance holds nothing closer (a point AT that distance would
+    // not change the sum).  The box is the cell's nominal box widened by 0.1 % of a cell against the rounding of the
+    // Morton quantisation.  After the home cell that leaves 1-4 of the 26 neighbours for a point of a surface.
+    float prune2 = INFINITY;
     for (int ring = 0; ring <= dim; ++ring) {
         const int w = 2 * ring + 1;
         // the cells of the shell, 64 at a time: every lane looks up one cell's range, then the wavefront walks the non-empty
@@ -1731,9 +1736,16 @@ __global__ __launch_bounds__(256) void k_sp_knn(const SpArgs A, double *__restri
                 const int ddx = t % w - ring, ddy = (t / w) % w - ring, ddz = t / (w * w) - ring;
                 const int x = cx + ddx, y = cy + ddy, z = cz + ddz;
                 if (max(abs(ddx), max(abs(ddy), abs(ddz))) == ring && x >= 0 && y >= 0 && z >= 0 && x < dim && y < dim && z < dim) {
-                    const uint32_t c = (spread3((uint32_t)z) << 2) | (spread3((uint32_t)y) << 1) | spread3((uint32_t)x);
-                    jb = A.table[c]; je = A.table[c + 1];
-                    if (je - jb > A.dense_limit) { dense = true; je = jb; }
+                    const float slack = 1e-3f * A.cell;
+                    const float lx = A.mnx + (float)x * A.cell, ly = A.mny + (float)y * A.cell, lz = A.mnz + (float)z * A.cell;
+                    const float gx = fmaxf(0.f, fmaxf(lx - q.x, q.x - (lx + A.cell)) - slack);
+                    const float gy = fmaxf(0.f, fmaxf(ly - q.y, q.y - (ly + A.cell)) - slack);
+                    const float gz = fmaxf(0.f, fmaxf(lz - q.z, q.z - (lz + A.cell)) - slack);
+                    if (!(gx * gx + gy * gy + gz * gz > prune2)) {
+                        const uint32_t c = (spread3((uint32_t)z) << 2) | (spread3((uint32_t)y) << 1) | spread3((uint32_t)x);
+                        jb = A.table[c]; je = A.table[c + 1];
+                        if (je - jb > A.dense_limit) { dense = true; je = jb; }
+                    }
                 }
             }
             unsigned long long todo = __ballot(je > jb);
@@ -1774,6 +1786,7 @@ __global__ __launch_bounds__(256) void k_sp_knn(const SpArgs A, double *__restri
         // everything in ring + 1 and beyond is at least ring * cell away from q
         const float bound = (float)ring * A.cell * 0.999f;
         if (found == A.k && kth[A.k - 1] < bound * bound) break;
+        if (found == A.k) prune2 = kth[A.k - 1];
     }
     const bool any_dense = __ballot(dense) != 0ull;
     if (lane == 0) {
@@ -2308,12 +2321,14 @@ void ransac_spacing_enqueue(plade_ctx *ctx, RansacWork &W, int slot, int k, uint
     size_t step = 1;
     if (n > samples) step = n / samples;                    // util.cpp:1626-1629
     const uint32_t nq = (uint32_t)((n + step - 1) / step);
-    // level: ~100 points per occupied cell of a surface-like cloud (the wavefront scans a cell with all lanes; measured at 1M
-    // points: level 6 = 15.6 cm cells, k_sp_cells 5 us + k_sp_knn 110 us; level 7: 15 + 128 us)
+    // level: ~25 points per occupied cell of a surface-like cloud.  The wavefront scans a cell with all lanes and skips the
+    // neighbour cells that lie beyond the current k-th distance, so smaller cells mean fewer points looked at (measured at
+    // 1M points under load, k_sp_cells + k_sp_knn: ~100 points per cell (level 6) 11 + 124 us, ~25 (level 7) 13 + 66 us;
+    // level 8: 43 + 72 us, the table build takes over)
     const double ex = std::max(1e-9, (double)c.bbmax[0] - c.bbmin[0]), ey = std::max(1e-9, (double)c.bbmax[1] - c.bbmin[1]),
                  ez = std::max(1e-9, (double)c.bbmax[2] - c.bbmin[2]);
     const double area = 2 * (ex * ey + ey * ez + ex * ez);
-    const double want = std::sqrt(128.0 * area / (double)n);
+    const double want = std::sqrt(32.0 * area / (double)n);
     int level = 2;
     static const int max_level = [] { const char *e = getenv("PLADE_SPACING_LEVEL"); return e ? atoi(e) : 7; }();
     while (level < max_level && (double)s.cube / (double)(1 << (level + 1)) >= 0.7 * want) ++level;
