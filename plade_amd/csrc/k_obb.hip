@@ -30,7 +30,7 @@ struct ObbArgs {
 constexpr int OBB_T = OBB_LANES;
 
 // sums of the K-component per-point terms over the points of one unit in the lane-strided order: lane t adds the terms
-// of points t, t + 1024, t + 2048, ... one after the other (eight points are fetched ahead of the additions; at every
+// of points t, t + 1024, t + 2048, ... one after the other (sixteen points are fetched ahead of the additions; at every
 // step the lanes of a wavefront read 64 consecutive points), the lane sums go to LDS, lane q < K adds the 1024 lane sums
 // of component q in lane order
 template <int K, class Term>
@@ -38,15 +38,17 @@ __device__ void strided_sums(const float *__restrict__ pts, uint32_t n, float (*
     float acc[K];
 #pragma unroll
     for (int q = 0; q < K; ++q) acc[q] = 0.f;
-    for (uint32_t i0 = threadIdx.x; i0 < n; i0 += 8 * OBB_T) {
-        float x[8], y[8], z[8];
+    constexpr int AHEAD = 16;   // points in flight per lane: a pass over the 130 000-point unit is 8 load latencies, not 130
+    for (uint32_t i0 = threadIdx.x; i0 < n; i0 += AHEAD * OBB_T) {
+        float x[AHEAD], y[AHEAD], z[AHEAD];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < AHEAD; ++j) {
             const uint32_t i = min(i0 + j * OBB_T, n - 1);
-            x[j] = pts[3 * (size_t)i]; y[j] = pts[3 * (size_t)i + 1]; z[j] = pts[3 * (size_t)i + 2];
+            const float3 p3 = *reinterpret_cast<const float3 *>(pts + 3 * (size_t)i);   // one 12-byte load
+            x[j] = p3.x; y[j] = p3.y; z[j] = p3.z;
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
+        for (int j = 0; j < AHEAD; ++j)
             if (i0 + j * OBB_T < n) term(acc, f3(x[j], y[j], z[j]));
     }
 #pragma unroll
@@ -104,15 +106,16 @@ __global__ __launch_bounds__(OBB_T) void k_obb_units(const ObbArgs A) {
     float P[12];
     for (int q = 0; q < 12; ++q) P[q] = s_P[q];
     float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-    for (uint32_t i0 = threadIdx.x; i0 < n; i0 += 4 * OBB_T) {   // four points in flight per lane
-        float x[4], y[4], z[4];
+    for (uint32_t i0 = threadIdx.x; i0 < n; i0 += 16 * OBB_T) {   // sixteen points in flight per lane
+        float x[16], y[16], z[16];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < 16; ++j) {
             const uint32_t i = min(i0 + j * OBB_T, n - 1);
-            x[j] = pts[3 * (size_t)i]; y[j] = pts[3 * (size_t)i + 1]; z[j] = pts[3 * (size_t)i + 2];
+            const float3 p3 = *reinterpret_cast<const float3 *>(pts + 3 * (size_t)i);   // one 12-byte load
+            x[j] = p3.x; y[j] = p3.y; z[j] = p3.z;
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {   // a clamped repeat of the last point changes no minimum / maximum
+        for (int j = 0; j < 16; ++j) {   // a clamped repeat of the last point changes no minimum / maximum
             const f3 q = pcl_xform(P, f3(x[j], y[j], z[j]));
             mn[0] = fminf(mn[0], q.x); mn[1] = fminf(mn[1], q.y); mn[2] = fminf(mn[2], q.z);
             mx[0] = fmaxf(mx[0], q.x); mx[1] = fmaxf(mx[1], q.y); mx[2] = fmaxf(mx[2], q.z);

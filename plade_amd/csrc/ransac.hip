@@ -521,6 +521,33 @@ __global__ __launch_bounds__(256) void k_r_sample(const RArgs A) {
     C.hyp_pos[t] = make_float4(p1[0], p1[1], p1[2], 1.f);
 }
 
+// Which of the first `np` (<= 64) planes of `s_pl` can have an inlier among the unassigned points this wavefront holds?
+// Bit h is CLEAR only when plane h's eps slab provably misses the bounding box of those points (the interval of n.p over the
+// box, widened far beyond the rounding of the three-term sums); planes with a NaN distance are cleared too (nothing is
+// compatible with them).  The points of a wavefront are neighbours on the Morton curve, i.e. a small box, and most planes
+// of a pool or of a chunk of hypotheses pass nowhere near it.
+__device__ __forceinline__ unsigned long long slab_mask(const Tile &t, const float4 *s_pl, uint32_t np, float eps, int lane) {
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+    for (int k = 0; k < K1_PPT; ++k)
+        if (t.valid[k]) {
+            mn[0] = fminf(mn[0], t.px[k]); mn[1] = fminf(mn[1], t.py[k]); mn[2] = fminf(mn[2], t.pz[k]);
+            mx[0] = fmaxf(mx[0], t.px[k]); mx[1] = fmaxf(mx[1], t.py[k]); mx[2] = fmaxf(mx[2], t.pz[k]);
+        }
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+        for (int d = 32; d >= 1; d >>= 1) { mn[q] = fminf(mn[q], __shfl_xor(mn[q], d, 64)); mx[q] = fmaxf(mx[q], __shfl_xor(mx[q], d, 64)); }
+    bool near = false;
+    if ((uint32_t)lane < np && mn[0] <= mx[0]) {
+        const float4 pl = s_pl[lane];
+        const float lo = fminf(pl.x * mn[0], pl.x * mx[0]) + fminf(pl.y * mn[1], pl.y * mx[1]) + fminf(pl.z * mn[2], pl.z * mx[2]);
+        const float hi = fmaxf(pl.x * mn[0], pl.x * mx[0]) + fmaxf(pl.y * mn[1], pl.y * mx[1]) + fmaxf(pl.z * mn[2], pl.z * mx[2]);
+        const float slack = 1.001f * eps + 1e-5f * (fabsf(lo) + fabsf(hi) + fabsf(pl.w));
+        near = pl.w == pl.w && !(pl.w - hi > slack || lo - pl.w > slack);   // a NaN normal keeps the plane in: the exact test decides
+    }
+    return __ballot(near);
+}
+
 // K1 on the stratified subset: grid (subset tiles, hypothesis chunks, clouds)
 __global__ __launch_bounds__(TPB) void k_r_score_sub(const RArgs A) {
     __shared__ float4 s_pl[HCHUNK];
@@ -544,15 +571,18 @@ __global__ __launch_bounds__(TPB) void k_r_score_sub(const RArgs A) {
         for (int k = 0; k < PPT; ++k) un += (uint32_t)__popcll(__ballot(t.valid[k]));
         if (lane == 0 && un) atomicAdd(&S->sub_unassigned, un);
     }
-    for (uint32_t hh = 0; hh < HCHUNK; ++hh) {
+    // (a draw that gave no verified plane carries a NaN distance: nothing is compatible with it, slab_mask drops it)
+    unsigned long long live = slab_mask(t, s_pl, HCHUNK, eps, lane);
+    s_cnt[wave][lane] = 0u;
+    while (live) {                       // wave-uniform
+        const uint32_t hh = (uint32_t)__ffsll((long long)live) - 1u;
+        live &= live - 1ull;
         const float4 pl = s_pl[hh];
         uint32_t c = 0;
-        if (pl.w == pl.w) {   // uniform; a draw that gave no verified plane carries a NaN distance: nothing is compatible with it
 #pragma unroll
-            for (int k = 0; k < PPT; ++k) {
-                const bool in = t.valid[k] && compatible(pl, t.px[k], t.py[k], t.pz[k], t.qx[k], t.qy[k], t.qz[k], eps, cos_t);
-                c += (uint32_t)__popcll(__ballot(in));
-            }
+        for (int k = 0; k < PPT; ++k) {
+            const bool in = t.valid[k] && compatible(pl, t.px[k], t.py[k], t.pz[k], t.qx[k], t.qy[k], t.qz[k], eps, cos_t);
+            c += (uint32_t)__popcll(__ballot(in));
         }
         if (lane == 0) s_cnt[wave][hh] = c;
     }
@@ -670,7 +700,12 @@ __global__ __launch_bounds__(TPB) void k_r_rescore(const RArgs A, int phase, uns
     load_tile(t, C.cv.x, C.cv.y, C.cv.z, C.cv.nx, C.cv.ny, C.cv.nz, C.assigned, nullptr, C.cv.n, tile * TILE + threadIdx.x * PPT);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (uint32_t hh = 0; hh < np; ++hh) {
+    // only the planes whose slab can reach this wavefront's points get the exact test (slab_mask)
+    unsigned long long live = slab_mask(t, s_pl, np, eps, lane);
+    if ((uint32_t)lane < np) s_cnt[wave][lane] = 0u;
+    while (live) {                       // wave-uniform
+        const uint32_t hh = (uint32_t)__ffsll((long long)live) - 1u;
+        live &= live - 1ull;
         const float4 pl = s_pl[hh];
         uint32_t c = 0;
 #pragma unroll
