@@ -28,8 +28,9 @@ namespace {
 
 constexpr int RS_THREADS = 512;
 constexpr int RS_WAVES = RS_THREADS / 64;
-constexpr int RS_IPT = 16;                       // keys per thread
-constexpr int RS_TILE = RS_THREADS * RS_IPT;     // 8192 keys per tile
+// keys per thread (template parameter IPT of the pass kernel): 8 up to 1.5 M items -- 4096-key tiles, twice the workgroups,
+// 1M items then fill the 256 CUs once (u32 pass 25.7 -> 20.8 us, u64 34.6 -> 31.8 under load) -- and 16 above (the 2M-item
+// Morton sort of a pair is faster with 8192-key tiles: 51 vs 54 us)
 constexpr int RS_HBLOCKS = 128;                  // histogram workgroups (= partial histograms per digit place)
 constexpr int RS_MAXP = 8;
 constexpr int RS_LOOK = 8;                      // predecessors fetched per look-back round
@@ -71,12 +72,13 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_histogram(const K *__restrict
     for (int i = threadIdx.x; i < passes * NB; i += RS_THREADS) part[(size_t)blockIdx.x * (RS_MAXP * NB) + i] = s_h[i];
 }
 
-template <class K, int DB>
+template <class K, int DB, int RS_IPT>
 __global__ __launch_bounds__(RS_THREADS) void k_rs_pass(const K *__restrict__ kin, K *__restrict__ kout,
                                                         const uint32_t *__restrict__ vin, uint32_t *__restrict__ vout,
                                                         uint32_t n, int pass, const uint32_t *__restrict__ part,
                                                         uint32_t *__restrict__ tile_ctr, uint32_t *__restrict__ look) {
     constexpr int NB = 1 << DB;
+    constexpr int RS_TILE = RS_THREADS * RS_IPT;
     static_assert(NB <= RS_THREADS, "one lane per digit");
     static_assert(RS_TILE * (sizeof(K) + 4) + (RS_WAVES + 2) * NB * 4 + 64 <= 160 * 1024, "tile does not fit gfx950's 160 KB LDS");
     __shared__ K s_keys[RS_TILE];
@@ -198,9 +200,10 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_pass(const K *__restrict__ ki
     }
 }
 
-template <class K, int DB>
-void radix_sort_run(plade_ctx *ctx, const K *ki, K *ko, const uint32_t *vi, uint32_t *vo, size_t n, int passes) {
+template <class K, int DB, int RS_IPT>
+void radix_sort_run_ipt(plade_ctx *ctx, const K *ki, K *ko, const uint32_t *vi, uint32_t *vo, size_t n, int passes) {
     constexpr int NB = 1 << DB;
+    constexpr int RS_TILE = RS_THREADS * RS_IPT;
     if (n == 0) return;   // no tiles: nothing to launch
     const uint32_t tiles = cdiv(n, RS_TILE);
     const size_t part_words = (size_t)RS_HBLOCKS * RS_MAXP * NB, look_words = (size_t)passes * tiles * NB;
@@ -219,12 +222,18 @@ void radix_sort_run(plade_ctx *ctx, const K *ki, K *ko, const uint32_t *vi, uint
         const bool to_out = ((passes - 1 - p) & 1) == 0;    // the last pass lands in the caller's output
         K *dst_k = to_out ? ko : tk;
         uint32_t *dst_v = to_out ? vo : tv;
-        hipLaunchKernelGGL((k_rs_pass<K, DB>), dim3(tiles), dim3(RS_THREADS), 0, st, src_k, dst_k, src_v, dst_v, (uint32_t)n, p, t,
+        hipLaunchKernelGGL((k_rs_pass<K, DB, RS_IPT>), dim3(tiles), dim3(RS_THREADS), 0, st, src_k, dst_k, src_v, dst_v, (uint32_t)n, p, t,
                            t + off_ctr, t + off_look + (size_t)p * tiles * NB);
         src_k = dst_k;
         src_v = dst_v;
     }
     HIP_TRY(hipGetLastError());
+}
+
+template <class K, int DB>
+void radix_sort_run(plade_ctx *ctx, const K *ki, K *ko, const uint32_t *vi, uint32_t *vo, size_t n, int passes) {
+    if (n <= 1500000) radix_sort_run_ipt<K, DB, 8>(ctx, ki, ko, vi, vo, n, passes);
+    else radix_sort_run_ipt<K, DB, 16>(ctx, ki, ko, vi, vo, n, passes);
 }
 
 template <class K>
