@@ -332,8 +332,11 @@ void overlap_sort_source(plade_ctx *ctx, OverlapWork &work, const float *d_sx, c
 void overlap_counts(plade_ctx *ctx, OverlapWork &work, const float *d_sx, const float *d_sy, const float *d_sz, uint32_t n_s,
                     const TargetGrid &grid, const float *d_T, const float *d_centers, uint32_t K, float src_radius,
                     float inlier_dist, int32_t *d_counts, uint32_t *d_any) {
-    HIP_TRY(hipMemsetAsync(d_counts, 0, (size_t)K * 4, ctx->stream));
-    HIP_TRY(hipMemsetAsync(d_any, 0, (size_t)K * 4, ctx->stream));
+    if (reinterpret_cast<uint32_t *>(d_counts) + K == d_any) HIP_TRY(hipMemsetAsync(d_counts, 0, (size_t)K * 8, ctx->stream));   // one block
+    else {
+        HIP_TRY(hipMemsetAsync(d_counts, 0, (size_t)K * 4, ctx->stream));
+        HIP_TRY(hipMemsetAsync(d_any, 0, (size_t)K * 4, ctx->stream));
+    }
     if (K == 0 || grid.n == 0) return;
     const float R2 = pcl_r2((double)src_radius), r2 = pcl_r2((double)inlier_dist);
     GridParams g{grid.gp.mnx, grid.gp.mny, grid.gp.mnz, grid.gp.inv, grid.gp.dx, grid.gp.dy, grid.gp.dz};

@@ -394,7 +394,10 @@ void penetration_filter(plade_ctx *ctx, const float *cand_rt_host, uint32_t K, c
     flags_out.assign(K, 0);
     if (!K || !src.P || !tgt.P) return;
     // upload tables
-    const size_t nf = 12 * (size_t)K + (4 + 3 + 12) * ((size_t)src.P + tgt.P);
+    // one upload: candidates | plane tables of both sides | search steps | plane-pair order
+    const uint32_t n_pairs = src.P * tgt.P;
+    const size_t n_tab = 12 * (size_t)K + (4 + 3 + 12) * ((size_t)src.P + tgt.P);
+    const size_t nf = n_tab + (PEN_MAXS + 1) + n_pairs;
     std::vector<float> h(nf);
     float *p = h.data();
     memcpy(p, cand_rt_host, 48 * (size_t)K);
@@ -406,7 +409,6 @@ void penetration_filter(plade_ctx *ctx, const float *cand_rt_host, uint32_t K, c
     float *o_tcen = p; memcpy(p, tgt.center.data(), 12 * (size_t)tgt.P); p += 3 * (size_t)tgt.P;
     float *o_tf = p; memcpy(p, tgt.four.data(), 48 * (size_t)tgt.P); p += 12 * (size_t)tgt.P;
     float *d = reinterpret_cast<float *>(ctx->scratch[4].ensure(nf * 4 + 64));
-    ctx->h2d(d, h.data(), nf * 4);
     PenTables tb;
     tb.cand = d + (o_cand - h.data()); tb.s_coef = d + (o_sc - h.data()); tb.s_center = d + (o_scen - h.data());
     tb.s_four = d + (o_sf - h.data()); tb.t_coef = d + (o_tc - h.data()); tb.t_center = d + (o_tcen - h.data());
@@ -418,14 +420,11 @@ void penetration_filter(plade_ctx *ctx, const float *cand_rt_host, uint32_t K, c
     // AreTwoPlanesPenetrable(..., searchRadius = lengthThreshold, minPointsNum = 10, minDistance = lengthThreshold / 2)
     const float search_radius = (float)(double)length_threshold;
     const float min_distance = (float)((double)length_threshold / 2);
-    const uint32_t n_pairs = src.P * tgt.P;
-    // counters: [0] items, [1] overflow, [2 .. 2+K) candidate flags, then one count per plane pair; then the step table
+    // counters: [0] items, [1] overflow, [2 .. 2+K) candidate flags, then one count per plane pair
     const size_t n_ctr = (size_t)K + 2 + n_pairs;
-    uint32_t *d_ctr = reinterpret_cast<uint32_t *>(ctx->scratch[6].ensure((n_ctr + PEN_MAXS + 8 + n_pairs) * 4));
+    uint32_t *d_ctr = reinterpret_cast<uint32_t *>(ctx->scratch[6].ensure((n_ctr + 8) * 4));
     HIP_TRY(hipMemsetAsync(d_ctr, 0, n_ctr * 4, ctx->stream));
     uint32_t *d_n = d_ctr, *d_over = d_ctr + 1, *d_flags = d_ctr + 2, *d_pair = d_ctr + 2 + K;
-    float *d_steps = reinterpret_cast<float *>(d_ctr + n_ctr);
-    uint32_t *d_order = reinterpret_cast<uint32_t *>(d_steps + PEN_MAXS + 2);
     std::vector<uint32_t> order(n_pairs);
     {
         // an item's cost is proportional to the two plane clouds it streams
@@ -436,13 +435,15 @@ void penetration_filter(plade_ctx *ctx, const float *cand_rt_host, uint32_t K, c
         for (uint32_t i = 0; i < n_pairs; ++i) order[i] = i;
         std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return w[a] > w[b]; });
     }
-    ctx->h2d(d_order, order.data(), 4 * (size_t)n_pairs);
-    std::vector<float> steps(PEN_MAXS + 1);
+    float *h_steps = h.data() + n_tab;
     {
         float dist = 0;
-        for (int i = 0; i <= PEN_MAXS; ++i) { steps[i] = dist; dist += search_radius; }  // util.cpp:1383
+        for (int i = 0; i <= PEN_MAXS; ++i) { h_steps[i] = dist; dist += search_radius; }  // util.cpp:1383
     }
-    ctx->h2d(d_steps, steps.data(), steps.size() * 4);
+    memcpy(h.data() + n_tab + PEN_MAXS + 1, order.data(), 4 * (size_t)n_pairs);
+    ctx->h2d(d, h.data(), nf * 4);
+    const float *d_steps = d + n_tab;
+    const uint32_t *d_order = reinterpret_cast<const uint32_t *>(d + n_tab + PEN_MAXS + 1);
     hipLaunchKernelGGL(k_pen_setup, dim3(cdiv(total, 256)), dim3(256), 0, ctx->stream, tb, length_threshold,
                        angle_threshold, d_items, d_n, d_pair);
     // in-plane grids of both sides (cell = 2 r)

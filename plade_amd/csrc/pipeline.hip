@@ -201,9 +201,8 @@ struct RegistrationWork {
     CandidateSet cand;
     TargetGrid grid, sp_grid;
     DBuf<uint32_t> d_ids;
-    DBuf<float> d_rt12, d_T16, d_centers;
-    DBuf<int32_t> d_counts;
-    DBuf<uint32_t> d_any;
+    DBuf<float> d_rt12, d_T16;      // d_T16: transforms | centres of the verified candidates
+    DBuf<int32_t> d_counts;         // overlap counts | sphere flags
     OverlapWork ov_work;
     hipEvent_t ev_grid = nullptr;   // target grid of the verification built on the auxiliary stream
     hipEvent_t ev_main = nullptr;   // everything queued on the main stream before the two sides are prepared
@@ -456,18 +455,22 @@ bool run_registration(plade_ctx *ctx, RegistrationWork &W, const CloudDev &tgt, 
     std::vector<int32_t> counts(Kv);
     {
         StageTimer t(ctx, "t_verify");
-        W.d_T16.ensure(16 * (size_t)Kv); W.d_centers.ensure(3 * (size_t)Kv); W.d_counts.ensure(Kv); W.d_any.ensure(Kv);
-        ctx->h2d(W.d_T16.p, T16.data(), 64 * (size_t)Kv);
-        ctx->h2d(W.d_centers.p, centers.data(), 12 * (size_t)Kv);
+        // one upload (transforms | centres) and one read-back (counts | sphere flags): every command of a stream costs ~6 us
+        // of queue time and ~10 us of host time, whatever its size
+        W.d_T16.ensure(19 * (size_t)Kv); W.d_counts.ensure(2 * (size_t)Kv);
+        float *d_centers = W.d_T16.p + 16 * (size_t)Kv;
+        uint32_t *d_any = reinterpret_cast<uint32_t *>(W.d_counts.p) + Kv;
+        std::vector<float> up(19 * (size_t)Kv);
+        memcpy(up.data(), T16.data(), 64 * (size_t)Kv);
+        memcpy(up.data() + 16 * (size_t)Kv, centers.data(), 12 * (size_t)Kv);
+        ctx->h2d(W.d_T16.p, up.data(), 76 * (size_t)Kv);
         HIP_TRY(hipStreamWaitEvent(ctx->stream, W.ev_grid, 0));
         overlap_counts(ctx, W.ov_work, W.ov_work.sorted.p, W.ov_work.sorted.p + C.n_ds, W.ov_work.sorted.p + 2 * (size_t)C.n_ds, C.n_ds,
-                       W.grid, W.d_T16.p,
-                       W.d_centers.p, Kv, (float)C.radius, downSampleDistance, W.d_counts.p, W.d_any.p);
-        std::vector<uint32_t> any(Kv);
-        ctx->d2h(counts.data(), W.d_counts.p, 4 * (size_t)Kv);
-        ctx->d2h(any.data(), W.d_any.p, 4 * (size_t)Kv);
+                       W.grid, W.d_T16.p, d_centers, Kv, (float)C.radius, downSampleDistance, W.d_counts.p, d_any);
+        std::vector<int32_t> back(2 * (size_t)Kv);
+        ctx->d2h(back.data(), W.d_counts.p, 8 * (size_t)Kv);
         ctx->sync();
-        for (uint32_t i = 0; i < Kv; ++i) if (!any[i]) counts[i] = -1;
+        for (uint32_t i = 0; i < Kv; ++i) counts[i] = back[Kv + i] ? back[i] : -1;
     }
     std::vector<LengthIndex> ov(Kv);
     std::vector<float> scores(Kv);
