@@ -204,40 +204,52 @@ __global__ __launch_bounds__(OV_TPB) void k_overlap(const float *__restrict__ sx
         if (kk >= kc) break;
         bool hit = false;
         if (live) {
-            const f3 q = pcl_xform(s_T[kk], p);
+            const f3 q_ = pcl_xform(s_T[kk], p);
             const f3 c(s_c[kk][0], s_c[kk][1], s_c[kk][2]);
-            const int cx = (int)floorf((q.x - g.mnx) * g.inv), cy = (int)floorf((q.y - g.mny) * g.inv),
-                      cz = (int)floorf((q.z - g.mnz) * g.inv);
+            const int cx = (int)floorf((q_.x - g.mnx) * g.inv), cy = (int)floorf((q_.y - g.mny) * g.inv),
+                      cz = (int)floorf((q_.z - g.mnz) * g.inv);
             const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.dx - 1);
             const int y0 = max(cy - 1, 0), y1 = min(cy + 1, g.dy - 1);
             const int z0 = max(cz - 1, 0), z1 = min(cz + 1, g.dz - 1);
-            // the <= 27 cells live in <= 8 blocks of 4 x 4 x 4: one word + one rank per block
-            if (x0 <= x1 && y0 <= y1 && z0 <= z1)
-                for (int bz = z0 >> 2; bz <= (z1 >> 2) && !hit; ++bz)
-                    for (int by = y0 >> 2; by <= (y1 >> 2) && !hit; ++by)
-                        for (int bx = x0 >> 2; bx <= (x1 >> 2) && !hit; ++bx) {
-                            const uint32_t blk = block_of(bx << 2, by << 2, bz << 2, g.dx, g.dy);
-                            const unsigned long long w = occ_bits[blk];
-                            if (!w) continue;
-                            // wanted cells of this block: the part of [x0,x1] x [y0,y1] x [z0,z1] inside it
-                            unsigned long long mx = 0, my = 0, mz = 0;
-                            for (int v = max(x0, bx << 2); v <= min(x1, (bx << 2) + 3); ++v) mx |= 0x1111111111111111ull << (v & 3);
-                            for (int v = max(y0, by << 2); v <= min(y1, (by << 2) + 3); ++v) my |= 0x000f000f000f000full << ((v & 3) << 2);
-                            for (int v = max(z0, bz << 2); v <= min(z1, (bz << 2) + 3); ++v) mz |= 0xffffull << ((v & 3) << 4);
-                            unsigned long long m = w & mx & my & mz;
-                            const uint32_t base = occ_rank[blk];
-                            while (m && !hit) {
-                                const int bit = __ffsll((long long)m) - 1;
-                                m &= m - 1;
-                                const uint32_t rk = base + (uint32_t)__popcll(w & ((1ull << bit) - 1ull));
-                                const uint32_t pb = occ_start[rk], pe = occ_start[rk + 1];
-                                for (uint32_t j = pb; j < pe; ++j) {
-                                    const float4 t4 = tgt[j];
-                                    const f3 t(t4.x, t4.y, t4.z);
-                                    if (flann_d2(q, t) < r2 && flann_d2(c, t) < R2) { hit = true; break; }
-                                }
-                            }
+            // the <= 27 cells live in <= 8 blocks of 4 x 4 x 4: one word + one rank per block.  The words of all blocks are
+            // fetched together (most probes of a wrong candidate find nothing: one load latency instead of up to eight
+            // dependent ones), then the occupied blocks are looked at one after the other
+            if (x0 <= x1 && y0 <= y1 && z0 <= z1) {
+                const int bx0 = x0 >> 2, by0 = y0 >> 2, bz0 = z0 >> 2;
+                const int nbx = (x1 >> 2) - bx0 + 1, nby = (y1 >> 2) - by0 + 1, nbz = (z1 >> 2) - bz0 + 1;   // 1 or 2 each
+                unsigned long long w8[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int ix = q & 1, iy = (q >> 1) & 1, iz = q >> 2;
+                    w8[q] = (ix < nbx && iy < nby && iz < nbz) ? occ_bits[block_of((bx0 + ix) << 2, (by0 + iy) << 2, (bz0 + iz) << 2, g.dx, g.dy)] : 0ull;
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const unsigned long long w = w8[q];
+                    if (!w || hit) continue;
+                    const int bx = bx0 + (q & 1), by = by0 + ((q >> 1) & 1), bz = bz0 + (q >> 2);
+                    const uint32_t blk = block_of(bx << 2, by << 2, bz << 2, g.dx, g.dy);
+                    // wanted cells of this block: the part of [x0,x1] x [y0,y1] x [z0,z1] inside it
+                    unsigned long long mx = 0, my = 0, mz = 0;
+                    for (int v = max(x0, bx << 2); v <= min(x1, (bx << 2) + 3); ++v) mx |= 0x1111111111111111ull << (v & 3);
+                    for (int v = max(y0, by << 2); v <= min(y1, (by << 2) + 3); ++v) my |= 0x000f000f000f000full << ((v & 3) << 2);
+                    for (int v = max(z0, bz << 2); v <= min(z1, (bz << 2) + 3); ++v) mz |= 0xffffull << ((v & 3) << 4);
+                    unsigned long long m = w & mx & my & mz;
+                    if (!m) continue;
+                    const uint32_t base = occ_rank[blk];
+                    while (m && !hit) {
+                        const int bit = __ffsll((long long)m) - 1;
+                        m &= m - 1;
+                        const uint32_t rk = base + (uint32_t)__popcll(w & ((1ull << bit) - 1ull));
+                        const uint32_t pb = occ_start[rk], pe = occ_start[rk + 1];
+                        for (uint32_t j = pb; j < pe; ++j) {
+                            const float4 t4 = tgt[j];
+                            const f3 t(t4.x, t4.y, t4.z);
+                            if (flann_d2(q_, t) < r2 && flann_d2(c, t) < R2) { hit = true; break; }
                         }
+                    }
+                }
+            }
         }
         acc[kk] += (uint32_t)__popcll(__ballot(hit));
     }
