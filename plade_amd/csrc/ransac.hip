@@ -1440,7 +1440,8 @@ __global__ __launch_bounds__(256) void k_r_fit(const RArgs A, int k) {
 // After the four slots: replay of the reference's refit loop on the four results of every chain, removal
 // bookkeeping (RansacShapeDetector.cpp:666-675), output planes (plane_extraction.cpp:134-149), the pool without
 // the batch, and what the next iteration does.  One lane per cloud does the sequential part.
-__global__ __launch_bounds__(64) void k_r_decide(const RArgs A) {
+constexpr int DEC_T = 256;   // lanes of k_r_decide: the staging loads and the deferral tests use all of them, the rest wave 0
+__global__ __launch_bounds__(DEC_T) void k_r_decide(const RArgs A) {
     const RCloudArgs &C = A.c[blockIdx.x];
     RState *S = C.st;
     RResult *R = C.res;
@@ -1456,7 +1457,7 @@ __global__ __launch_bounds__(64) void k_r_decide(const RArgs A) {
     float drawn = S->drawn;
     {
         constexpr int WORDS = sizeof(PlaneState) / 4;
-        for (uint32_t i = threadIdx.x; i < nc_all * 4 * WORDS; i += 64) {
+        for (uint32_t i = threadIdx.x; i < nc_all * 4 * WORDS; i += DEC_T) {
             const uint32_t b = i / (4 * WORDS), r = i % (4 * WORDS);
             reinterpret_cast<uint32_t *>(&s_st[b][0])[r] = reinterpret_cast<const uint32_t *>(&chain_of(C, b).hdr->st[0])[r];
         }
@@ -1500,7 +1501,7 @@ __global__ __launch_bounds__(64) void k_r_decide(const RArgs A) {
         float bbmin[3], bbmax[3];
         for (int q = 0; q < 3; ++q) { bbmin[q] = S->bbmin[q]; bbmax[q] = S->bbmax[q]; }
         const uint32_t n_other = 4 * R_B + R_TOP;          // per (chain b, slot sb): 4 slots of every chain, then the pool
-        for (uint32_t t = threadIdx.x; t < nc_all * 4 * n_other; t += 64) {
+        for (uint32_t t = threadIdx.x; t < nc_all * 4 * n_other; t += DEC_T) {
             const uint32_t b = t / (4 * n_other), r = t % (4 * n_other), sb = r / n_other, o = r % n_other;
             if (b == 0 || (int)sb > min(s_stop[b], 3) || s_st[b][sb].err) continue;
             const float4 pb = make_float4(s_st[b][sb].n[0], s_st[b][sb].n[1], s_st[b][sb].n[2], s_st[b][sb].dist);
@@ -1582,10 +1583,10 @@ __global__ __launch_bounds__(64) void k_r_decide(const RArgs A) {
             in_batch = in_batch || (gone && s_batch[q] == threadIdx.x);
             before += (gone && s_batch[q] < threadIdx.x) ? 1u : 0u;
         }
-        const bool keep = threadIdx.x < np && !in_batch;
+        const bool keep = threadIdx.x < np && !in_batch;   // np <= R_TOP < 64: wave 0 holds the whole pool
         if (keep) { S->pool_pl[threadIdx.x - before] = s_pool_pl[threadIdx.x]; S->pool_pos[threadIdx.x - before] = s_pool_pos[threadIdx.x]; }
         if (threadIdx.x == 0) s_keep_pos[0] = 0;
-        const uint32_t w = (uint32_t)__popcll(__ballot(keep));
+        const uint32_t w = (uint32_t)__popcll(__ballot(keep));   // wave 0's ballot is the one lane 0 uses
         if (threadIdx.x == 0) {
             // (n_remaining, done, err were updated by this lane above; visible here in its own registers)
             uint32_t npool = w;
@@ -1605,8 +1606,8 @@ __global__ __launch_bounds__(64) void k_r_decide(const RArgs A) {
     const uint32_t done_now = S->done;
     if (done_now) {
         const uint32_t na = S->n_acc;
-        for (uint32_t i = threadIdx.x; i < 4 * na; i += 64) (&R->coef[0][0])[i] = (&S->acc_coef[0][0])[i];
-        for (uint32_t i = threadIdx.x; i < na; i += 64) { R->support[i] = S->acc_support[i]; R->offset[i] = S->acc_offset[i]; R->dbg[i] = S->acc_dbg[i]; }
+        for (uint32_t i = threadIdx.x; i < 4 * na; i += DEC_T) (&R->coef[0][0])[i] = (&S->acc_coef[0][0])[i];
+        for (uint32_t i = threadIdx.x; i < na; i += DEC_T) { R->support[i] = S->acc_support[i]; R->offset[i] = S->acc_offset[i]; R->dbg[i] = S->acc_dbg[i]; }
         if (threadIdx.x == 0) {
             R->n_acc = na; R->out_off = S->out_off; R->err = S->err; R->remaining = S->n_remaining;
             R->n_rounds = S->n_rounds; R->n_rescores = S->n_rescores[0] + S->n_rescores[1]; R->n_batches = S->n_batches; R->n_accepts = S->n_accepts;
@@ -1615,7 +1616,9 @@ __global__ __launch_bounds__(64) void k_r_decide(const RArgs A) {
             for (int q = 0; q < 5; ++q) R->n_stop[q] = S->n_stop[q];
         }
     }
-    __threadfence_system();
+    // the result block must be visible before the flag says "done"; an iteration count alone orders nothing (the host only
+    // uses it to decide when to queue the next iteration), and a system-scope fence is an L2 write-back on this part
+    if (done_now) __threadfence_system();
     __syncthreads();
     if (threadIdx.x == 0)
         *reinterpret_cast<volatile uint32_t *>(&R->flag) = (S->it & 0xffffffu) | ((S->gen & 0x7fu) << 24) | (done_now ? 0x80000000u : 0u);
@@ -2025,7 +2028,7 @@ void enqueue_iteration(plade_ctx *ctx, const RArgs &A) {
         hipLaunchKernelGGL(k_r_select_cc, dim3(loop_grid(nb_max), R_B * ng), dim3(TPB), 0, st, A, k);
         hipLaunchKernelGGL(k_r_fit, dim3(R_B * ng), dim3(256), 0, st, A, k);
     }
-    hipLaunchKernelGGL(k_r_decide, dim3(ng), dim3(64), 0, st, A);
+    hipLaunchKernelGGL(k_r_decide, dim3(ng), dim3(DEC_T), 0, st, A);
     hipLaunchKernelGGL(k_r_assign, dim3(loop_grid(nb_max), R_B * ng), dim3(TPB), 0, st, A);
 }
 
