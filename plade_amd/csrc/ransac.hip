@@ -803,21 +803,24 @@ __global__ __launch_bounds__(64) void k_r_select(const RArgs A, int phase) {
     float bbmin[3], bbmax[3];
     for (int k = 0; k < 3; ++k) { bbmin[k] = S->bbmin[k]; bbmax[k] = S->bbmax[k]; }
     __shared__ uint32_t s_batch[R_B];
-    uint32_t nb = 1;
-    if (lane == 0) s_batch[0] = 0;
-    __syncthreads();
     // candidate i joins the batch only if its support cannot touch the support of ANY better candidate of the pool, in
     // the batch or not: it would then be accepted before a conflicting better one, which the reference, taking the best
-    // candidate first every time (RansacShapeDetector.cpp:548-617), never does
-    for (uint32_t i = 1; i < np2 && nb < (uint32_t)R_B; ++i) {
+    // candidate first every time (RansacShapeDetector.cpp:548-617), never does.  Whether i qualifies therefore does not
+    // depend on who is in the batch: the rows are tested one after the other without a barrier (lane j holds candidate j),
+    // the batch is the best candidate plus the first R_B - 1 candidates that qualify
+    unsigned long long free_rows = 1ull;
+    for (uint32_t i = 1; i < np2; ++i) {
         bool conflict = false;
         if ((uint32_t)lane < i) conflict = !conflict_free(s_pl[i], s_pl[lane], eps, cos_t, bbmin, bbmax);
-        if (__ballot(conflict) == 0ull) {
-            if (lane == 0) s_batch[nb] = i;
-            ++nb;
-        }
-        __syncthreads();
+        if (__ballot(conflict) == 0ull) free_rows |= 1ull << i;
     }
+    const uint32_t nb = min((uint32_t)__popcll(free_rows), (uint32_t)R_B);
+    if ((uint32_t)lane < nb) {          // lane l: the l-th qualifying candidate
+        unsigned long long m = free_rows;
+        for (int q = 0; q < lane; ++q) m &= m - 1ull;
+        s_batch[lane] = (uint32_t)__ffsll((long long)m) - 1u;
+    }
+    __syncthreads();
     // the ordered pool back to the state, counts cleared for the next re-score
     if ((uint32_t)lane < np2) { S->pool_pl[lane] = s_pl[lane]; S->pool_pos[lane] = s_pos[lane]; }
     if (lane < (int)R_TOP) S->pool_cnt[lane] = 0;
