@@ -23,7 +23,7 @@ namespace plade {
 // (a) keys: item i -> packed (group | k | j | i-voxel) key.  The whole-cloud call reads the SoA copy of the cloud
 //     (coalesced 4 B/lane streams); item lists (per-plane clouds) gather 12 of the 24 B of an AoS record.
 __global__ void k_voxel_keys(const float *__restrict__ xyz, uint32_t stride, const float *__restrict__ sx,
-                             const float *__restrict__ sy, const float *__restrict__ sz,
+                             const float *__restrict__ sy, const float *__restrict__ sz, int soa_indexed,
                              const uint32_t *__restrict__ item_point, const uint32_t *__restrict__ item_group,
                              uint32_t n_items, float inv, int lminx, int lminy, int lminz, int bx, int by, int bz,
                              uint64_t *__restrict__ keys, uint32_t *__restrict__ vals) {
@@ -31,6 +31,7 @@ __global__ void k_voxel_keys(const float *__restrict__ xyz, uint32_t stride, con
     if (i >= n_items) return;
     float x, y, z;
     if (!item_point && sx) { x = sx[i]; y = sy[i]; z = sz[i]; }
+    else if (soa_indexed) { const uint32_t p = item_point[i]; x = sx[p]; y = sy[p]; z = sz[p]; }   // items = positions in an SoA copy
     else {
         const uint32_t p = item_point ? item_point[i] : i;
         x = xyz[(size_t)p * stride]; y = xyz[(size_t)p * stride + 1]; z = xyz[(size_t)p * stride + 2];
@@ -52,6 +53,8 @@ constexpr int VR_T = 256, VR_I = 16, VR_TILE = VR_T * VR_I;
 constexpr uint64_t VR_AGG = 1ull << 32, VR_PREFIX = 2ull << 32, VR_STATUS = 3ull << 32;
 __global__ __launch_bounds__(VR_T) void k_voxel_runs(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals,
                                                       uint32_t n, const float *__restrict__ xyz, uint32_t stride,
+                                                      const float *__restrict__ ix, const float *__restrict__ iy,
+                                                      const float *__restrict__ iz /* SoA planes indexed by item_point, or null */,
                                                       const uint32_t *__restrict__ item_point, int group_shift,
                                                       uint64_t *__restrict__ state, uint32_t *__restrict__ ticket, uint32_t base,
                                                       uint32_t gen, uint32_t *__restrict__ heads, uint32_t *__restrict__ seg_group,
@@ -70,8 +73,11 @@ __global__ __launch_bounds__(VR_T) void k_voxel_runs(const uint64_t *__restrict_
         if (j < n) {
             const uint32_t it = vals[j];
             const uint32_t p = item_point ? item_point[it] : it;
-            const float *r = xyz + (size_t)p * stride;
-            gx[q] = r[0]; gy[q] = r[1]; gz[q] = r[2];
+            if (ix) { gx[q] = ix[p]; gy[q] = iy[p]; gz[q] = iz[p]; }
+            else {
+                const float *r = xyz + (size_t)p * stride;
+                gx[q] = r[0]; gy[q] = r[1]; gz[q] = r[2];
+            }
         }
     }
     const uint32_t first = tile * VR_TILE + tid * VR_I;
@@ -169,7 +175,8 @@ __global__ __launch_bounds__(128) void k_voxel_centroids(const float *__restrict
 
 void VoxelWork::enqueue(plade_ctx *ctx, const float *d_xyz, uint32_t stride, const float *d_soa_x, const float *d_soa_y,
                         const float *d_soa_z, const uint32_t *d_item_point, const uint32_t *d_item_group, uint32_t n_items,
-                        uint32_t n_groups, float leaf, const float bbox_min[3], const float bbox_max[3]) {
+                        uint32_t n_groups, float leaf, const float bbox_min[3], const float bbox_max[3], bool soa_indexed) {
+    PLADE_REQUIRE(!soa_indexed || (d_item_point && d_soa_x), PLADE_EINVAL, "voxel: an indexed SoA source needs items and planes");
     n_out = 0;
     n_pending = 0;
     PLADE_REQUIRE(leaf > 0.f, PLADE_EINVAL, "voxel: leaf must be positive");
@@ -207,14 +214,15 @@ void VoxelWork::enqueue(plade_ctx *ctx, const float *d_xyz, uint32_t stride, con
     group_offsets.ensure((size_t)n_groups + 2);
     count.ensure(4);
     const unsigned nb = cdiv(n_items, 256);
-    hipLaunchKernelGGL(k_voxel_keys, dim3(nb), dim3(256), 0, ctx->stream, d_xyz, stride, d_soa_x, d_soa_y, d_soa_z, d_item_point,
+    hipLaunchKernelGGL(k_voxel_keys, dim3(nb), dim3(256), 0, ctx->stream, d_xyz, stride, d_soa_x, d_soa_y, d_soa_z, soa_indexed ? 1 : 0, d_item_point,
                        d_item_group, n_items, inv, lmin[0], lmin[1], lmin[2], bx, by, bz, keys.p, vals.p);
     int gbits = 0;
     while ((1u << gbits) < n_groups) ++gbits;
     sort_pairs_u64(ctx, keys.p, keys2.p, vals.p, vals2.p, n_items, bx + by + bz + gbits);
     const ScanTicket t = scan_ticket(ctx, n_items, VR_TILE);
     float *ox = sorted_xyz.p, *oy = ox + n_items, *oz = oy + n_items;
-    hipLaunchKernelGGL(k_voxel_runs, dim3(t.tiles), dim3(VR_T), 0, ctx->stream, keys2.p, vals2.p, n_items, d_xyz, stride, d_item_point,
+    hipLaunchKernelGGL(k_voxel_runs, dim3(t.tiles), dim3(VR_T), 0, ctx->stream, keys2.p, vals2.p, n_items, d_xyz, stride,
+                       soa_indexed ? d_soa_x : nullptr, soa_indexed ? d_soa_y : nullptr, soa_indexed ? d_soa_z : nullptr, d_item_point,
                        bx + by + bz, t.state, t.ticket, t.base, t.gen, heads.p, seg_group.p, count.p, ox, oy, oz);
     hipLaunchKernelGGL(k_voxel_centroids, dim3(cdiv(n_items, 128)), dim3(128), 0, ctx->stream, ox, oy, oz, heads.p, seg_group.p,
                        count.p, n_items, n_groups, out_xyz.p, group_offsets.p);

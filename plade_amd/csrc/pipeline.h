@@ -15,6 +15,9 @@ struct PlaneSetView {
     const int32_t *offsets = nullptr;
     const int32_t *idx = nullptr;
     const uint32_t *d_idx = nullptr;
+    // the lists as ascending positions in a Morton-ordered SoA copy of the cloud (PlaneSetOut::d_pos), or null
+    const uint32_t *d_pos = nullptr;
+    const float *m_x = nullptr, *m_y = nullptr, *m_z = nullptr;
     uint32_t P = 0;
     // unoriented-normals mode: planes [P/2, P) are planes [0, P/2) with (n, d) negated and the same supports; d_idx then
     // holds the supports of the first half only (offsets[P/2] items)

@@ -103,18 +103,24 @@ bool prepare_side(plade_ctx *ctx, const char *tag, const CloudDev &cloud, const 
     S.vox_all.enqueue(ctx, cloud.aos.p, 6, cloud.x(), cloud.y(), cloud.z(), nullptr, nullptr, cloud.n, 1, leaf, cloud.bbmin, cloud.bbmax);
     const uint32_t n_items = (uint32_t)pl.offsets[P];
     S.d_items.ensure((size_t)n_items + 4); S.d_groups.ensure((size_t)n_items + 4); S.d_offs.ensure((size_t)P + 2);
-    if (pl.d_idx && pl.mirrored) {   // the mirrored half shares the supports of the first half
+    // Planes that come from the GPU extraction are read through their Morton positions from the extraction's Morton-ordered
+    // copy (the lists are ascending positions: near-sequential reads) instead of through their point indices from the
+    // cloud in input order (random 12-byte reads of 128-byte lines); same coordinates, same order, same sums
+    const bool by_pos = pl.d_pos && pl.m_x;
+    const uint32_t *dev_list = by_pos ? pl.d_pos : pl.d_idx;
+    const uint32_t *items = S.d_items.p;
+    if (dev_list && pl.mirrored) {   // the mirrored half shares the supports of the first half
         const size_t half = (size_t)pl.offsets[P / 2];
-        HIP_TRY(hipMemcpyAsync(S.d_items.p, pl.d_idx, 4 * half, hipMemcpyDeviceToDevice, ctx->stream));
-        HIP_TRY(hipMemcpyAsync(S.d_items.p + half, pl.d_idx, 4 * half, hipMemcpyDeviceToDevice, ctx->stream));
-    } else if (pl.d_idx) HIP_TRY(hipMemcpyAsync(S.d_items.p, pl.d_idx, 4 * (size_t)n_items, hipMemcpyDeviceToDevice, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(S.d_items.p, dev_list, 4 * half, hipMemcpyDeviceToDevice, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(S.d_items.p + half, dev_list, 4 * half, hipMemcpyDeviceToDevice, ctx->stream));
+    } else if (dev_list) items = dev_list;   // read where the extraction left it (valid until this cloud slot's next detect)
     else ctx->h2d(S.d_items.p, pl.idx, 4 * (size_t)n_items);
     ctx->h2d(S.d_offs.p, pl.offsets, 4 * ((size_t)P + 1));
     if (n_items)
         hipLaunchKernelGGL(k_expand_groups, dim3(cdiv(n_items, 256)), dim3(256), 0, ctx->stream, S.d_offs.p, P, n_items,
                            S.d_groups.p);
-    S.vox_planes.enqueue(ctx, cloud.aos.p, 6, nullptr, nullptr, nullptr, S.d_items.p, S.d_groups.p, n_items, P, leaf, cloud.bbmin,
-                         cloud.bbmax);
+    S.vox_planes.enqueue(ctx, cloud.aos.p, 6, by_pos ? pl.m_x : nullptr, by_pos ? pl.m_y : nullptr, by_pos ? pl.m_z : nullptr, items,
+                         S.d_groups.p, n_items, P, leaf, cloud.bbmin, cloud.bbmax, by_pos);
     // ComputeBoundingBox of the whole downsampled cloud (plade.cpp:81-84 / :295-299) and per plane (plade.cpp:106-117 /
     // :320-330) on the device, reading the voxel grids' results where they lie; ONE wait for the grids' sizes, the
     // per-plane offsets and the boxes

@@ -18,6 +18,10 @@ struct PlaneSetOut {
     std::vector<int32_t> offsets;  // P + 1
     std::vector<int32_t> idx;      // original point indices
     const uint32_t *d_idx = nullptr;  // the same list on the device (valid until the next detect of this cloud slot)
+    // ... and as positions in the extraction's Morton-ordered SoA copy of the cloud (x | y | z planes m_x, m_y, m_z): the lists
+    // are ascending positions, so a stage that gathers the planes' points reads that copy almost sequentially
+    const uint32_t *d_pos = nullptr;
+    const float *m_x = nullptr, *m_y = nullptr, *m_z = nullptr;
     uint32_t n_score_passes = 0;   // full-array K1 launches that scanned this cloud (roofline bookkeeping)
     double score_bytes = 0;        // their algorithmic bytes: 28 B/point per launch + 1 mask byte per 4 points per chain
     uint32_t remaining = 0;

@@ -157,6 +157,7 @@ struct RCloudArgs {
     float4 *hyp, *hyp_pos;           // R_H hypotheses of the current round
     uint32_t *hyp_counts;
     int32_t *out_idx;                // original indices of the accepted planes' supports, plane after plane
+    uint32_t *out_pos;               // the same entries as positions in the Morton-ordered copy (nullptr: not wanted)
     char *fixed, *var;               // R_B slabs of F_BYTES / L.bytes
     const uint32_t *list_values;     // seam S1c: the score list is given (list position -> point), else nullptr
     ChainLayout L;
@@ -1694,7 +1695,10 @@ __global__ __launch_bounds__(TPB) void k_r_assign(const RArgs A) {
             for (int q = 0; q < 4; ++q)
                 if (mk & (1u << q)) {
                     if (C.assigned) C.assigned[p[q]] = id;
-                    if (out) out[off] = (int32_t)(C.orig ? C.orig[p[q]] : p[q]);
+                    if (out) {
+                        out[off] = (int32_t)(C.orig ? C.orig[p[q]] : p[q]);
+                        if (C.out_pos) C.out_pos[out_off + off] = p[q];
+                    }
                     ++off;
                 }
         }
@@ -1911,6 +1915,7 @@ struct RansacSlot {
     CloudDev sorted;
     DBuf<uint32_t> codes, orig, sub_index;
     DBuf<int32_t> assigned, out_idx;
+    DBuf<uint32_t> out_pos;
     DBuf<float> sub;
     uint32_t sub_pitch = 0, n_sub = 0;
     DBuf<char> round_block;          // hypotheses / positions / counts of the current round
@@ -1952,6 +1957,7 @@ void slot_buffers(plade_ctx *ctx, RansacSlot &s, uint32_t n) {
     s.state.ensure(1);
     s.round_block.ensure((size_t)R_H * 36 + 64);
     s.out_idx.ensure((size_t)n + 4);
+    s.out_pos.ensure((size_t)n + 4);
     s.assigned.ensure((size_t)n + 8);
     if (!s.res) {
         HIP_TRY(hipHostMalloc((void **)&s.res, sizeof(RResult), hipHostMallocMapped | hipHostMallocCoherent));
@@ -1977,6 +1983,7 @@ RArgs make_args(RansacWork &W, int ng) {
         C.hyp_pos = C.hyp + R_H;
         C.hyp_counts = reinterpret_cast<uint32_t *>(C.hyp_pos + R_H);
         C.out_idx = s.out_idx.p;
+        C.out_pos = s.out_pos.p;
         C.fixed = s.fixed.p; C.var = s.var.p;
         C.list_values = nullptr;
         memcpy(&C.L, &s.L, sizeof(ChainLayout));
@@ -2271,6 +2278,8 @@ void ransac_detect_prepared(plade_ctx *ctx, RansacWork &W, RansacJob jobs[RANSAC
             out.offsets.push_back((int32_t)(R.offset[i] + R.support[i]));
         }
         out.d_idx = reinterpret_cast<const uint32_t *>(s.out_idx.p);
+        out.d_pos = s.out_pos.p;
+        out.m_x = s.sorted.x(); out.m_y = s.sorted.y(); out.m_z = s.sorted.z();
         out.remaining = R.remaining;
         out.n_score_passes = R.n_rescores + R.n_mark_launches;
         out.score_bytes = 28.0 * s.n * (R.n_rescores + R.n_mark_launches) + 0.25 * s.n * R.n_mark_chains;
@@ -2321,7 +2330,7 @@ void plane_component(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const
     for (int g = 0; g < R_G; ++g) {
         RCloudArgs &C = A.c[g];
         C.cv = CloudView{cloud.x(), cloud.y(), cloud.z(), cloud.nx(), cloud.ny(), cloud.nz(), n};
-        C.st = s.state.p; C.res = s.res_dev; C.out_idx = s.out_idx.p; C.fixed = s.fixed.p; C.var = s.var.p; C.list_values = s.seam_list.p; C.L = s.L;
+        C.st = s.state.p; C.res = s.res_dev; C.out_idx = s.out_idx.p; C.out_pos = nullptr; C.fixed = s.fixed.p; C.var = s.var.p; C.list_values = s.seam_list.p; C.L = s.L;
     }
     A.tiles0 = s.L.nb;
     // Plane(point, normal): dist = point . normal with Vec3f::dot's left-to-right sum (Plane.cpp:21-26)
@@ -2431,7 +2440,7 @@ RArgs seam_args(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const int3
         RCloudArgs &C = A.c[g];
         C.cv = CloudView{cloud.x(), cloud.y(), cloud.z(), cloud.nx(), cloud.ny(), cloud.nz(), cloud.n};
         C.assigned = const_cast<int32_t *>(d_assigned);
-        C.st = s.state.p; C.res = s.res_dev; C.out_idx = s.out_idx.p; C.fixed = s.fixed.p; C.var = s.var.p; C.L = s.L;
+        C.st = s.state.p; C.res = s.res_dev; C.out_idx = s.out_idx.p; C.out_pos = nullptr; C.fixed = s.fixed.p; C.var = s.var.p; C.L = s.L;
         C.hyp = reinterpret_cast<float4 *>(s.round_block.p);
         C.hyp_pos = C.hyp + R_H;
         C.hyp_counts = reinterpret_cast<uint32_t *>(C.hyp_pos + R_H);

@@ -143,6 +143,8 @@ int register_clouds(plade_ctx *ctx, const CloudDev &tgt, const CloudDev &src, in
     tv.coef = tp.coef.data(); tv.offsets = tp.offsets.data(); tv.idx = tp.idx.data(); tv.P = tp.P();
     sv.coef = sp.coef.data(); sv.offsets = sp.offsets.data(); sv.idx = sp.idx.data(); sv.P = sp.P(); sv.d_idx = sp.d_idx;
     tv.d_idx = tp.d_idx;
+    if (tp.d_idx) { tv.d_pos = tp.d_pos; tv.m_x = tp.m_x; tv.m_y = tp.m_y; tv.m_z = tp.m_z; }
+    if (sp.d_idx) { sv.d_pos = sp.d_pos; sv.m_x = sp.m_x; sv.m_y = sp.m_y; sv.m_z = sp.m_z; }
     MirroredPlanes mirror;
     if (ctx->params.unoriented_normals) {   // README.md:109-110, see MirroredPlanes (pipeline.h)
         mirror.build(tp.coef.data(), tp.offsets.data(), tp.idx.size() == (size_t)tp.offsets.back() ? tp.idx.data() : nullptr, tp.P());
