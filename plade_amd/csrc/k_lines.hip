@@ -40,6 +40,7 @@ __global__ __launch_bounds__(256) void k_pair_table(LinesView v, float scale, fl
     if (idx >= (size_t)L * L) return;
     const uint32_t i = (uint32_t)(idx / L), j = (uint32_t)(idx % L);
     flags[idx] = 0u;
+    if (idx == 0) flags[(size_t)L * L] = 0u;   // the scan's extra slot (was a memset command of its own)
     if (i == j) return;
     if (!target && i > j) return;
     const f3 pti(v.pt[3 * i], v.pt[3 * i + 1], v.pt[3 * i + 2]), ptj(v.pt[3 * j], v.pt[3 * j + 1], v.pt[3 * j + 2]);
@@ -137,7 +138,6 @@ void build_pair_table(plade_ctx *ctx, const LineTableHost &lt, const float *norm
     const float angle_thresh = (float)cos(10.0 / 180 * M_PI);  // util.cpp:773, plade.cpp:513
     hipLaunchKernelGGL(k_pair_table, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, v, scale, angle_thresh, target ? 1 : 0,
                        out.flags.p, out.all_desc.p, out.all_lv1.p, out.all_lv2.p, out.all_p1.p);
-    HIP_TRY(hipMemsetAsync(out.flags.p + n, 0, 4, ctx->stream));
     exclusive_scan_u32(ctx, out.flags.p, out.pos.p, n + 1);
     uint32_t total = 0;
     ctx->d2h(&total, out.pos.p + n, 4);

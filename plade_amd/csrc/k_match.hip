@@ -28,8 +28,12 @@ __global__ __launch_bounds__(MT_TPB) void k_match(const float *__restrict__ qry,
                                                   uint32_t *__restrict__ cnt /* dq*nch */,
                                                   const uint32_t *__restrict__ offs /* dq*nch */,
                                                   uint32_t *__restrict__ t_idx, double *__restrict__ d2_out,
-                                                  uint32_t *__restrict__ q_idx) {
+                                                  uint32_t *__restrict__ q_idx, uint32_t *__restrict__ info) {
     __shared__ float s_t[MT_TILE][8];
+    if (!FILL && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {   // instead of two memset commands
+        cnt[(size_t)dq * nch] = 0u;       // the scan's extra slot
+        info[0] = 0u; info[1] = 0u;       // k_query_offsets: total, longest list (atomicMax)
+    }
     const uint32_t q = blockIdx.x * MT_TPB + threadIdx.x;
     const bool live = q < dq;
     double qd[8];
@@ -368,12 +372,10 @@ uint64_t MatchResult::run(plade_ctx *ctx, const float *d_qry, uint32_t dq, const
     PLADE_REQUIRE(ncnt < (1ull << 31), PLADE_ELIMIT, "match: too many (query, chunk) cells");
     cnt.ensure(ncnt + 1); offs.ensure(ncnt + 1);
     dim3 grid(cdiv(dq, MT_TPB), nch);
-    hipLaunchKernelGGL(k_match<false>, grid, dim3(MT_TPB), 0, ctx->stream, d_qry, dq, d_tgt, dt, sq_rad, nch, chunk, cnt.p,
-                       (const uint32_t *)nullptr, (uint32_t *)nullptr, (double *)nullptr, (uint32_t *)nullptr);
-    HIP_TRY(hipMemsetAsync(cnt.p + ncnt, 0, 4, ctx->stream));
-    exclusive_scan_u32(ctx, cnt.p, offs.p, ncnt + 1);
     info.ensure(2);
-    HIP_TRY(hipMemsetAsync(info.p, 0, 8, ctx->stream));
+    hipLaunchKernelGGL(k_match<false>, grid, dim3(MT_TPB), 0, ctx->stream, d_qry, dq, d_tgt, dt, sq_rad, nch, chunk, cnt.p,
+                       (const uint32_t *)nullptr, (uint32_t *)nullptr, (double *)nullptr, (uint32_t *)nullptr, info.p);
+    exclusive_scan_u32(ctx, cnt.p, offs.p, ncnt + 1);
     hipLaunchKernelGGL(k_query_offsets, dim3(cdiv(dq + 1, 256)), dim3(256), 0, ctx->stream, offs.p, dq, nch, offsets.p, info.p);
     uint32_t h_info[2] = {0, 0};
     ctx->d2h(h_info, info.p, 8);
@@ -384,7 +386,7 @@ uint64_t MatchResult::run(plade_ctx *ctx, const float *d_qry, uint32_t dq, const
     const uint32_t m = tot32;
     t_raw.ensure(m); d2_raw.ensure(m); q_raw.ensure(m);
     hipLaunchKernelGGL(k_match<true>, grid, dim3(MT_TPB), 0, ctx->stream, d_qry, dq, d_tgt, dt, sq_rad, nch, chunk, cnt.p, offs.p,
-                       t_raw.p, d2_raw.p, q_raw.p);
+                       t_raw.p, d2_raw.p, q_raw.p, (uint32_t *)nullptr);
     t_idx.ensure(m); dist2.ensure(m);
     q_idx_sorted = q_raw.p;   // lists are contiguous per query
     if (max_list <= RANK_MAX_LIST) {

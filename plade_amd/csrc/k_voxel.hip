@@ -26,7 +26,14 @@ __global__ void k_voxel_keys(const float *__restrict__ xyz, uint32_t stride, con
                              const float *__restrict__ sy, const float *__restrict__ sz, int soa_indexed,
                              const uint32_t *__restrict__ item_point, const uint32_t *__restrict__ item_group,
                              uint32_t n_items, float inv, int lminx, int lminy, int lminz, int bx, int by, int bz,
-                             uint64_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+                             uint64_t *__restrict__ keys, uint32_t *__restrict__ vals, uint32_t n_group_offsets) {
+    // n_group_offsets != 0: item_group holds that many ascending item OFFSETS (group g = items [off[g], off[g + 1])) instead
+    // of one group id per item; they are staged in LDS and searched (<= 1025 entries)
+    __shared__ uint32_t s_off[1026];
+    if (n_group_offsets) {
+        for (uint32_t q = threadIdx.x; q < n_group_offsets; q += blockDim.x) s_off[q] = item_group[q];
+        __syncthreads();
+    }
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_items) return;
     float x, y, z;
@@ -40,7 +47,12 @@ __global__ void k_voxel_keys(const float *__restrict__ xyz, uint32_t stride, con
     const uint64_t lx = (uint64_t)((int)floorf(x * inv) - lminx);
     const uint64_t ly = (uint64_t)((int)floorf(y * inv) - lminy);
     const uint64_t lz = (uint64_t)((int)floorf(z * inv) - lminz);
-    const uint64_t g = item_group ? item_group[i] : 0u;
+    uint64_t g = 0u;
+    if (n_group_offsets) {
+        uint32_t lo = 0, hi = n_group_offsets - 1;   // last g with off[g] <= i
+        while (lo < hi) { const uint32_t mid = (lo + hi + 1) >> 1; if (s_off[mid] <= i) lo = mid; else hi = mid - 1; }
+        g = lo;
+    } else if (item_group) g = item_group[i];
     keys[i] = (g << (bx + by + bz)) | (lz << (bx + by)) | (ly << bx) | lx;
     vals[i] = i;
 }
@@ -154,7 +166,7 @@ __global__ __launch_bounds__(128) void k_voxel_centroids(const float *__restrict
                                                          const float *__restrict__ sz, const uint32_t *__restrict__ heads,
                                                          const uint32_t *__restrict__ seg_group, const uint32_t *__restrict__ n_seg_p,
                                                          uint32_t n_items, uint32_t n_groups, float *__restrict__ out_xyz,
-                                                         uint32_t *__restrict__ group_offsets) {
+                                                         uint32_t *__restrict__ group_offsets, float *__restrict__ out_soa) {
     const uint32_t n_seg = *n_seg_p;
     if (blockIdx.x == 0)
         for (uint32_t g = threadIdx.x; g <= n_groups; g += blockDim.x) {
@@ -168,14 +180,17 @@ __global__ __launch_bounds__(128) void k_voxel_centroids(const float *__restrict
     float ax = 0.f, ay = 0.f, az = 0.f;
     for (uint32_t j = b; j < e; ++j) { ax += sx[j]; ay += sy[j]; az += sz[j]; }
     const float cnt = (float)(e - b);
-    out_xyz[3 * (size_t)s] = ax / cnt;
-    out_xyz[3 * (size_t)s + 1] = ay / cnt;
-    out_xyz[3 * (size_t)s + 2] = az / cnt;
+    const float cx = ax / cnt, cy = ay / cnt, cz = az / cnt;
+    out_xyz[3 * (size_t)s] = cx;
+    out_xyz[3 * (size_t)s + 1] = cy;
+    out_xyz[3 * (size_t)s + 2] = cz;
+    if (out_soa) { out_soa[s] = cx; out_soa[(size_t)n_seg + s] = cy; out_soa[2 * (size_t)n_seg + s] = cz; }   // x | y | z, pitch = voxel count
 }
 
 void VoxelWork::enqueue(plade_ctx *ctx, const float *d_xyz, uint32_t stride, const float *d_soa_x, const float *d_soa_y,
                         const float *d_soa_z, const uint32_t *d_item_point, const uint32_t *d_item_group, uint32_t n_items,
-                        uint32_t n_groups, float leaf, const float bbox_min[3], const float bbox_max[3], bool soa_indexed) {
+                        uint32_t n_groups, float leaf, const float bbox_min[3], const float bbox_max[3], bool soa_indexed,
+                        bool groups_are_offsets, float *d_out_soa) {
     PLADE_REQUIRE(!soa_indexed || (d_item_point && d_soa_x), PLADE_EINVAL, "voxel: an indexed SoA source needs items and planes");
     n_out = 0;
     n_pending = 0;
@@ -215,7 +230,8 @@ void VoxelWork::enqueue(plade_ctx *ctx, const float *d_xyz, uint32_t stride, con
     count.ensure(4);
     const unsigned nb = cdiv(n_items, 256);
     hipLaunchKernelGGL(k_voxel_keys, dim3(nb), dim3(256), 0, ctx->stream, d_xyz, stride, d_soa_x, d_soa_y, d_soa_z, soa_indexed ? 1 : 0, d_item_point,
-                       d_item_group, n_items, inv, lmin[0], lmin[1], lmin[2], bx, by, bz, keys.p, vals.p);
+                       d_item_group, n_items, inv, lmin[0], lmin[1], lmin[2], bx, by, bz, keys.p, vals.p,
+                       groups_are_offsets ? n_groups + 1 : 0u);
     int gbits = 0;
     while ((1u << gbits) < n_groups) ++gbits;
     sort_pairs_u64(ctx, keys.p, keys2.p, vals.p, vals2.p, n_items, bx + by + bz + gbits);
@@ -225,7 +241,7 @@ void VoxelWork::enqueue(plade_ctx *ctx, const float *d_xyz, uint32_t stride, con
                        soa_indexed ? d_soa_x : nullptr, soa_indexed ? d_soa_y : nullptr, soa_indexed ? d_soa_z : nullptr, d_item_point,
                        bx + by + bz, t.state, t.ticket, t.base, t.gen, heads.p, seg_group.p, count.p, ox, oy, oz);
     hipLaunchKernelGGL(k_voxel_centroids, dim3(cdiv(n_items, 128)), dim3(128), 0, ctx->stream, ox, oy, oz, heads.p, seg_group.p,
-                       count.p, n_items, n_groups, out_xyz.p, group_offsets.p);
+                       count.p, n_items, n_groups, out_xyz.p, group_offsets.p, d_out_soa);
     HIP_TRY(hipGetLastError());
     ctx->d2h(&n_pending_host, count.p, 4);   // valid after the next sync of this stream
     n_pending = 1;

@@ -29,18 +29,6 @@ __global__ void k_gather_rt(const float4 *__restrict__ rt, const uint32_t *__res
     o[9] = r0.w; o[10] = r1.w; o[11] = r2.w;
 }
 
-__global__ void k_expand_groups(const uint32_t *__restrict__ offsets, uint32_t n_groups, uint32_t n_items,
-                                uint32_t *__restrict__ group_of) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_items) return;
-    uint32_t lo = 0, hi = n_groups;  // last g with offsets[g] <= i
-    while (hi - lo > 1) {
-        uint32_t mid = (lo + hi) >> 1;
-        if (offsets[mid] <= i) lo = mid; else hi = mid;
-    }
-    group_of[i] = lo;
-}
-
 // per-cloud preparation: code/PLADE/plade.cpp:75-172 (target) / :290-381 (source)
 struct Side {
     std::vector<float> ds;       // host copy of the whole-cloud downsample, n_ds x 3
@@ -56,7 +44,7 @@ struct Side {
     LineTableHost lines;
     VoxelWork vox_all, vox_planes;
     ObbWork obb;
-    DBuf<uint32_t> d_items, d_groups, d_offs;
+    DBuf<uint32_t> d_items, d_offs;
 };
 
 void make_line_table(const float *coef, uint32_t P, f3 bcenter, double radius, LineTableHost &lt) {
@@ -100,9 +88,11 @@ bool prepare_side(plade_ctx *ctx, const char *tag, const CloudDev &cloud, const 
     Clock::time_point tp0 = Clock::now();
     // whole cloud: DownSamplePointCloud (plade.cpp:77-79 / :292-294) and the per-plane clouds in one pass
     // (plade.cpp:93-105 / :308-319): both voxel-grid runs are queued before the host waits for either
-    S.vox_all.enqueue(ctx, cloud.aos.p, 6, cloud.x(), cloud.y(), cloud.z(), nullptr, nullptr, cloud.n, 1, leaf, cloud.bbmin, cloud.bbmax);
+    S.d_ds_soa.ensure(3 * (size_t)cloud.n + 4);   // the centroid kernel writes the SoA copy too (pitch = voxel count)
+    S.vox_all.enqueue(ctx, cloud.aos.p, 6, cloud.x(), cloud.y(), cloud.z(), nullptr, nullptr, cloud.n, 1, leaf, cloud.bbmin, cloud.bbmax,
+                      false, false, S.d_ds_soa.p);
     const uint32_t n_items = (uint32_t)pl.offsets[P];
-    S.d_items.ensure((size_t)n_items + 4); S.d_groups.ensure((size_t)n_items + 4); S.d_offs.ensure((size_t)P + 2);
+    S.d_items.ensure((size_t)n_items + 4); S.d_offs.ensure((size_t)P + 2);
     // Planes that come from the GPU extraction are read through their Morton positions from the extraction's Morton-ordered
     // copy (the lists are ascending positions: near-sequential reads) instead of through their point indices from the
     // cloud in input order (random 12-byte reads of 128-byte lines); same coordinates, same order, same sums
@@ -116,11 +106,8 @@ bool prepare_side(plade_ctx *ctx, const char *tag, const CloudDev &cloud, const 
     } else if (dev_list) items = dev_list;   // read where the extraction left it (valid until this cloud slot's next detect)
     else ctx->h2d(S.d_items.p, pl.idx, 4 * (size_t)n_items);
     ctx->h2d(S.d_offs.p, pl.offsets, 4 * ((size_t)P + 1));
-    if (n_items)
-        hipLaunchKernelGGL(k_expand_groups, dim3(cdiv(n_items, 256)), dim3(256), 0, ctx->stream, S.d_offs.p, P, n_items,
-                           S.d_groups.p);
     S.vox_planes.enqueue(ctx, cloud.aos.p, 6, by_pos ? pl.m_x : nullptr, by_pos ? pl.m_y : nullptr, by_pos ? pl.m_z : nullptr, items,
-                         S.d_groups.p, n_items, P, leaf, cloud.bbmin, cloud.bbmax, by_pos);
+                         S.d_offs.p, n_items, P, leaf, cloud.bbmin, cloud.bbmax, by_pos, true);   // groups = the planes' item ranges
     // ComputeBoundingBox of the whole downsampled cloud (plade.cpp:81-84 / :295-299) and per plane (plade.cpp:106-117 /
     // :320-330) on the device, reading the voxel grids' results where they lie; ONE wait for the grids' sizes, the
     // per-plane offsets and the boxes
@@ -134,9 +121,7 @@ bool prepare_side(plade_ctx *ctx, const char *tag, const CloudDev &cloud, const 
     ctx->stats.add(std::string("t_prep_voxel_") + tag, secs_since(tp0));
     tp0 = Clock::now();
     if (S.n_ds == 0) return false;
-    S.d_ds_soa.ensure(3 * (size_t)S.n_ds + 4);
     S.d_ds.swap(S.vox_all.out_xyz);   // the result becomes d_ds, the work area takes last call's buffer back
-    deinterleave3(ctx, S.d_ds.p, S.n_ds, S.d_ds_soa.p, S.d_ds_soa.p + S.n_ds, S.d_ds_soa.p + 2 * (size_t)S.n_ds);
     S.pcl.xyz.swap(S.vox_planes.out_xyz);
     S.pcl.d_off.swap(S.vox_planes.group_offsets);
     const float *ob = S.obb.host.data();

@@ -20,7 +20,11 @@ struct VoxelWork {
     // returns the number of voxels.  Several runs can be queued before the first finish().
     void enqueue(plade_ctx *ctx, const float *d_xyz, uint32_t stride, const float *d_soa_x, const float *d_soa_y,
                  const float *d_soa_z, const uint32_t *d_item_point, const uint32_t *d_item_group, uint32_t n_items,
-                 uint32_t n_groups, float leaf, const float bbox_min[3], const float bbox_max[3], bool soa_indexed = false);
+                 uint32_t n_groups, float leaf, const float bbox_min[3], const float bbox_max[3], bool soa_indexed = false,
+                 bool groups_are_offsets = false, float *d_out_soa = nullptr);
+    // d_out_soa (>= 3 * n_items floats): the centroids also as planes x | y | z with pitch = number of voxels
+    // groups_are_offsets: d_item_group holds n_groups + 1 ascending item offsets (the groups are contiguous item ranges)
+    // instead of one group id per item
     // soa_indexed: the items are POSITIONS in the SoA planes d_soa_* (e.g. the extraction's Morton-ordered copy, whose
     // plane lists are ascending positions: the gathers then walk memory almost in order) instead of rows of d_xyz
     uint32_t finish(plade_ctx *ctx);
