@@ -214,17 +214,20 @@ struct plade_ctx {
     // source makes the runtime copy it to its own staging buffer and, for some sizes, wait for the transfer).
     plade::HBuf<char> write_arena;
     size_t write_arena_used = 0;
-    void h2d(void *dst, const void *src, size_t bytes) {
-        if (!bytes) return;
+    // true: `src` has been copied into the arena and may be released at once; false: the copy reads `src` itself, which
+    // must stay valid until the next sync() of this stream
+    bool h2d(void *dst, const void *src, size_t bytes) {
+        if (!bytes) return true;
         const size_t need = (bytes + 255) & ~(size_t)255;
         if (bytes > READ_DIRECT_BYTES || write_arena_used + need > READ_ARENA_BYTES) {
             HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream));
-            return;
+            return false;
         }
         char *a = write_arena.ensure(READ_ARENA_BYTES) + write_arena_used;
         memcpy(a, src, bytes);
         HIP_TRY(hipMemcpyAsync(dst, a, bytes, hipMemcpyHostToDevice, stream));
         write_arena_used += need;
+        return true;
     }
     // forget the queued hand-overs (their destinations may be gone): after an error, and before every call
     void drop_reads() {

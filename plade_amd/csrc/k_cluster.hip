@@ -334,14 +334,14 @@ void plane_consistency(plade_ctx *ctx, CandidateSet &cs, const PlaneGeomHost &sr
     fill(src, tab.data());
     fill(tgt, tab.data() + 8 * (size_t)src.P);
     float *d_tab = reinterpret_cast<float *>(ctx->scratch[4].ensure(tab.size() * 4 + 16));
-    ctx->h2d(d_tab, tab.data(), tab.size() * 4);
+    const bool staged = ctx->h2d(d_tab, tab.data(), tab.size() * 4);
     const size_t shmem = 32 * ((size_t)src.P + tgt.P);
     hipLaunchKernelGGL(k_plane_consistency, dim3(cdiv(n, 256)), dim3(256), shmem, ctx->stream, cs.rt.p, cs.seeds.p, n, d_tab,
                        src.P, d_tab + 8 * (size_t)src.P, tgt.P, f3(src_bcenter[0], src_bcenter[1], src_bcenter[2]),
                        f3(tgt_bcenter[0], tgt_bcenter[1], tgt_bcenter[2]), max_radius, cos_angle_th, length_threshold,
                        cs.plane_counts.p);
     HIP_TRY(hipGetLastError());
-    ctx->sync();  // `tab` must outlive the copy
+    if (!staged) ctx->sync();  // `tab` must outlive the copy
 }
 
 }  // namespace plade

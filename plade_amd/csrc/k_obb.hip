@@ -158,13 +158,16 @@ __global__ __launch_bounds__(OBB_T) void k_obb_units(const ObbArgs A) {
 }  // namespace
 
 void obb_units(plade_ctx *ctx, ObbWork &W, const float *d_ds, const uint32_t *d_n_ds, uint32_t max_ds, const float *d_plane_ds,
-               const uint32_t *d_plane_off, uint32_t max_plane_pts, uint32_t P, const float *coef_host) {
-    W.d_coef.ensure(4 * (size_t)P + 4);
-    if (P) ctx->h2d(W.d_coef.p, coef_host, 16 * (size_t)P);
+               const uint32_t *d_plane_off, uint32_t max_plane_pts, uint32_t P, const float *coef_host, const float *d_coef) {
+    if (!d_coef) {   // the caller has not uploaded the coefficients with something else
+        W.d_coef.ensure(4 * (size_t)P + 4);
+        if (P) ctx->h2d(W.d_coef.p, coef_host, 16 * (size_t)P);
+        d_coef = W.d_coef.p;
+    }
     (void)max_ds; (void)max_plane_pts;
     W.out.ensure(OBB_OUT_WHOLE + (size_t)P * OBB_OUT_PLANE + 4);
     W.host.resize(OBB_OUT_WHOLE + (size_t)P * OBB_OUT_PLANE);
-    ObbArgs A{d_ds, d_n_ds, d_plane_ds, d_plane_off, P, W.d_coef.p, W.out.p};
+    ObbArgs A{d_ds, d_n_ds, d_plane_ds, d_plane_off, P, d_coef, W.out.p};
     hipLaunchKernelGGL(k_obb_units, dim3(P + 1), dim3(OBB_T), 0, ctx->stream, A);
     HIP_TRY(hipGetLastError());
     ctx->d2h(W.host.data(), W.out.p, 4 * W.host.size());   // valid after the next sync of the stream

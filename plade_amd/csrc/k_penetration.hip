@@ -177,7 +177,7 @@ void build_pen_grid(plade_ctx *ctx, PlaneCloudsDev &pc, const PlaneGeomHost &geo
     pc.n_cells = total;
     pc.grid_cell = cell;
     pc.frames.ensure(P);
-    ctx->h2d(pc.frames.p, fr.data(), P * sizeof(PenFrame));
+    const bool staged = ctx->h2d(pc.frames.p, fr.data(), P * sizeof(PenFrame));
     pc.cell_pts.ensure((size_t)n + 1);
     pc.cell_start.ensure((size_t)total + 2);
     pc.ckeys.ensure((size_t)n + 1); pc.ckeys2.ensure((size_t)n + 1); pc.cvals.ensure((size_t)n + 1); pc.cvals2.ensure((size_t)n + 1);
@@ -189,7 +189,7 @@ void build_pen_grid(plade_ctx *ctx, PlaneCloudsDev &pc, const PlaneGeomHost &geo
     sort_pairs_u32(ctx, pc.ckeys.p, pc.ckeys2.p, pc.cvals.p, pc.cvals2.p, n, bits);
     hipLaunchKernelGGL(k_pen_cell_fill, dim3(cdiv(std::max(n, total + 1), 256)), dim3(256), 0, ctx->stream, pc.xyz.p, pc.ckeys2.p,
                        pc.cvals2.p, n, total, pc.cell_pts.p, pc.cell_start.p);
-    ctx->sync();   // `fr` must outlive the copy
+    if (!staged) ctx->sync();   // `fr` must outlive the copy
 }
 
 // Cells of one plane grid that can hold a point within `rr` of the segment start + t direc, t in [0, L]

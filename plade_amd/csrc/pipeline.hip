@@ -92,7 +92,7 @@ bool prepare_side(plade_ctx *ctx, const char *tag, const CloudDev &cloud, const 
     S.vox_all.enqueue(ctx, cloud.aos.p, 6, cloud.x(), cloud.y(), cloud.z(), nullptr, nullptr, cloud.n, 1, leaf, cloud.bbmin, cloud.bbmax,
                       false, false, S.d_ds_soa.p);
     const uint32_t n_items = (uint32_t)pl.offsets[P];
-    S.d_items.ensure((size_t)n_items + 4); S.d_offs.ensure((size_t)P + 2);
+    S.d_items.ensure((size_t)n_items + 4); S.d_offs.ensure(5 * (size_t)P + 4);
     // Planes that come from the GPU extraction are read through their Morton positions from the extraction's Morton-ordered
     // copy (the lists are ascending positions: near-sequential reads) instead of through their point indices from the
     // cloud in input order (random 12-byte reads of 128-byte lines); same coordinates, same order, same sums
@@ -105,14 +105,19 @@ bool prepare_side(plade_ctx *ctx, const char *tag, const CloudDev &cloud, const 
         HIP_TRY(hipMemcpyAsync(S.d_items.p + half, dev_list, 4 * half, hipMemcpyDeviceToDevice, ctx->stream));
     } else if (dev_list) items = dev_list;   // read where the extraction left it (valid until this cloud slot's next detect)
     else ctx->h2d(S.d_items.p, pl.idx, 4 * (size_t)n_items);
-    ctx->h2d(S.d_offs.p, pl.offsets, 4 * ((size_t)P + 1));
+    {   // one upload: the planes' item offsets | their coefficients (for the per-plane boxes below)
+        std::vector<uint32_t> up(5 * (size_t)P + 1);
+        memcpy(up.data(), pl.offsets, 4 * ((size_t)P + 1));
+        memcpy(up.data() + P + 1, pl.coef, 16 * (size_t)P);
+        ctx->h2d(S.d_offs.p, up.data(), 4 * up.size());
+    }
     S.vox_planes.enqueue(ctx, cloud.aos.p, 6, by_pos ? pl.m_x : nullptr, by_pos ? pl.m_y : nullptr, by_pos ? pl.m_z : nullptr, items,
                          S.d_offs.p, n_items, P, leaf, cloud.bbmin, cloud.bbmax, by_pos, true);   // groups = the planes' item ranges
     // ComputeBoundingBox of the whole downsampled cloud (plade.cpp:81-84 / :295-299) and per plane (plade.cpp:106-117 /
     // :320-330) on the device, reading the voxel grids' results where they lie; ONE wait for the grids' sizes, the
     // per-plane offsets and the boxes
     obb_units(ctx, S.obb, S.vox_all.out_xyz.p, S.vox_all.count.p, cloud.n, S.vox_planes.out_xyz.p, S.vox_planes.group_offsets.p, n_items, P,
-              pl.coef);
+              pl.coef, reinterpret_cast<const float *>(S.d_offs.p + P + 1));
     S.pcl.off.resize((size_t)P + 1);
     ctx->d2h(S.pcl.off.data(), S.vox_planes.group_offsets.p, 4 * ((size_t)P + 1));
     S.n_ds = S.vox_all.finish(ctx);

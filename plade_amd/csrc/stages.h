@@ -110,7 +110,7 @@ struct ObbWork {
 // queues the boxes of the whole downsampled cloud and of every per-plane cloud (device arrays whose sizes are still on
 // the device: *d_n_ds <= max_ds points, d_plane_off[P] <= max_plane_pts) + the small read-back
 void obb_units(plade_ctx *ctx, ObbWork &W, const float *d_ds, const uint32_t *d_n_ds, uint32_t max_ds, const float *d_plane_ds,
-               const uint32_t *d_plane_off, uint32_t max_plane_pts, uint32_t P, const float *coef_host);
+               const uint32_t *d_plane_off, uint32_t max_plane_pts, uint32_t P, const float *coef_host, const float *d_coef = nullptr);
 
 // generic: positions of set flags (ordered); returns count (sync)
 uint32_t compact_flags(plade_ctx *ctx, const uint32_t *d_flags, uint32_t n, DBuf<uint32_t> &pos_scratch,
