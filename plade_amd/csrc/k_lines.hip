@@ -129,7 +129,7 @@ void build_pair_table(plade_ctx *ctx, const LineTableHost &lt, const float *norm
     }
     memcpy(&blob[o_nrm], normals, 12 * (size_t)P);
     uint32_t *d = out.d_blob.ensure(words + 4);
-    ctx->h2d(d, blob.data(), 4 * words);
+    const bool staged = ctx->h2d(d, blob.data(), 4 * words);
     out.all_desc.ensure(n * 8); out.all_lv1.ensure(n * 3); out.all_lv2.ensure(n * 3); out.all_p1.ensure(n * 3);
     out.flags.ensure(n + 1); out.pos.ensure(n + 1);
     LinesView v{reinterpret_cast<const float *>(d + o_pt), reinterpret_cast<const int32_t *>(d + o_sp),
@@ -139,6 +139,17 @@ void build_pair_table(plade_ctx *ctx, const LineTableHost &lt, const float *norm
     hipLaunchKernelGGL(k_pair_table, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, v, scale, angle_thresh, target ? 1 : 0,
                        out.flags.p, out.all_desc.p, out.all_lv1.p, out.all_lv2.p, out.all_p1.p);
     exclusive_scan_u32(ctx, out.flags.p, out.pos.p, n + 1);
+    if (staged && n <= (1u << 20)) {
+        // the usual table (a few hundred lines): the compacted arrays are sized for all n pairs (68 B each) and the count
+        // comes back with the caller's next wait -- no host round trip between the scan and the compaction
+        out.desc.ensure(n * 8 + 8); out.lv1.ensure(n * 3 + 4); out.lv2.ensure(n * 3 + 4); out.p1.ensure(n * 3 + 4);
+        hipLaunchKernelGGL(k_scatter_pairs, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, out.flags.p, out.pos.p, n,
+                           out.all_desc.p, out.all_lv1.p, out.all_lv2.p, out.all_p1.p, out.desc.p, out.lv1.p, out.lv2.p,
+                           out.p1.p);
+        HIP_TRY(hipGetLastError());
+        ctx->d2h(&out.count, out.pos.p + n, 4);   // out.count is valid after the next sync() of this stream
+        return;
+    }
     uint32_t total = 0;
     ctx->d2h(&total, out.pos.p + n, 4);
     ctx->sync();  // also keeps `blob` alive until the copy is done

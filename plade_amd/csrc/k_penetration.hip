@@ -390,18 +390,19 @@ __global__ __launch_bounds__(PEN_TPB) __attribute__((amdgpu_waves_per_eu(6))) vo
 
 void penetration_filter(plade_ctx *ctx, const float *cand_rt_host, uint32_t K, const PlaneGeomHost &src,
                         const PlaneGeomHost &tgt, PlaneCloudsDev &src_pts, PlaneCloudsDev &tgt_pts,
-                        float length_threshold, float angle_threshold, std::vector<int32_t> &flags_out) {
+                        float length_threshold, float angle_threshold, std::vector<int32_t> &flags_out, const float *cand_rt_dev) {
     flags_out.assign(K, 0);
-    if (!K || !src.P || !tgt.P) return;
+    if (!K || !src.P || !tgt.P) { if (cand_rt_dev) ctx->sync(); return; }   // (the caller's read-back of the table rides on our wait)
     // upload tables
     // one upload: candidates | plane tables of both sides | search steps | plane-pair order
     const uint32_t n_pairs = src.P * tgt.P;
-    const size_t n_tab = 12 * (size_t)K + (4 + 3 + 12) * ((size_t)src.P + tgt.P);
+    const size_t n_cand = cand_rt_dev ? 0 : 12 * (size_t)K;   // candidates already on the device: not uploaded again
+    const size_t n_tab = n_cand + (4 + 3 + 12) * ((size_t)src.P + tgt.P);
     const size_t nf = n_tab + (PEN_MAXS + 1) + n_pairs;
     std::vector<float> h(nf);
     float *p = h.data();
-    memcpy(p, cand_rt_host, 48 * (size_t)K);
-    float *o_cand = p; p += 12 * (size_t)K;
+    if (n_cand) memcpy(p, cand_rt_host, 48 * (size_t)K);
+    float *o_cand = p; p += n_cand;
     float *o_sc = p; memcpy(p, src.coef.data(), 16 * (size_t)src.P); p += 4 * (size_t)src.P;
     float *o_scen = p; memcpy(p, src.center.data(), 12 * (size_t)src.P); p += 3 * (size_t)src.P;
     float *o_sf = p; memcpy(p, src.four.data(), 48 * (size_t)src.P); p += 12 * (size_t)src.P;
@@ -410,7 +411,7 @@ void penetration_filter(plade_ctx *ctx, const float *cand_rt_host, uint32_t K, c
     float *o_tf = p; memcpy(p, tgt.four.data(), 48 * (size_t)tgt.P); p += 12 * (size_t)tgt.P;
     float *d = reinterpret_cast<float *>(ctx->scratch[4].ensure(nf * 4 + 64));
     PenTables tb;
-    tb.cand = d + (o_cand - h.data()); tb.s_coef = d + (o_sc - h.data()); tb.s_center = d + (o_scen - h.data());
+    tb.cand = cand_rt_dev ? cand_rt_dev : d + (o_cand - h.data()); tb.s_coef = d + (o_sc - h.data()); tb.s_center = d + (o_scen - h.data());
     tb.s_four = d + (o_sf - h.data()); tb.t_coef = d + (o_tc - h.data()); tb.t_center = d + (o_tcen - h.data());
     tb.t_four = d + (o_tf - h.data());
     tb.K = K; tb.ps = src.P; tb.pt = tgt.P;

@@ -346,28 +346,25 @@ bool run_registration(plade_ctx *ctx, RegistrationWork &W, const CloudDev &tgt, 
     const uint32_t nC = W.cand.n_clusters;
     ctx->stats.add("n_clusters", nC);
     // util.cpp:335-401: clusters by size (std::sort with myCompareGreater), centre gate, plane counts.
-    // The sort only needs the sizes, so it runs on the host while the plane-consistency kernel runs.
     std::vector<int> cand_cluster;   // cluster index per entry of `matches`
     std::vector<int> match_counts;
     {
         StageTimer t(ctx, "t_plane_consistency");
         seeds.resize(nC); sizes.resize(nC); pcounts.resize(nC);
-        if (nC) {
-            ctx->d2h(sizes.data(), W.cand.sizes.p, 4 * (size_t)nC);
-            ctx->sync();
-        }
         const float sbc[3] = {C.bcenter.x, C.bcenter.y, C.bcenter.z}, tbc[3] = {M.bcenter.x, M.bcenter.y, M.bcenter.z};
         plane_consistency(ctx, W.cand, C.geom, M.geom, sbc, tbc, (float)M.radius, (float)(double)cosAngleThreshold,
                           lengthThreshold);
-        if (nC) {
+        if (nC) {   // ONE wait for sizes, seeds and counts (a wait of its own for the sizes, so that the sort could run beside the
+                    // 70 us kernel, cost more than it hid)
+            ctx->d2h(sizes.data(), W.cand.sizes.p, 4 * (size_t)nC);
             ctx->d2h(seeds.data(), W.cand.seeds.p, 4 * (size_t)nC);
             ctx->d2h(pcounts.data(), W.cand.plane_counts.p, 4 * (size_t)nC);
         }
+        ctx->sync();
         std::vector<LengthIndex> sortVec(nC);
         for (uint32_t i = 0; i < nC; ++i) { sortVec[i].index = (int)i; sortVec[i].length = (float)sizes[i]; }
         // same comparisons as cmp_greater, as an inlinable functor: std::sort's result is identical
         std::sort(sortVec.begin(), sortVec.end(), [](const LengthIndex &a, const LengthIndex &b) { return a.length > b.length; });
-        ctx->sync();
         cand_cluster.reserve(nC);
         match_counts.reserve(nC);
         for (uint32_t i = 0; i < nC; ++i) {
@@ -421,13 +418,12 @@ bool run_registration(plade_ctx *ctx, RegistrationWork &W, const CloudDev &tgt, 
         W.d_rt12.ensure(12 * (size_t)K);
         ctx->h2d(W.d_ids.p, ids.data(), 4 * (size_t)K);
         hipLaunchKernelGGL(k_gather_rt, dim3(cdiv(K, 64)), dim3(64), 0, ctx->stream, W.cand.rt.p, W.d_ids.p, K, W.d_rt12.p);
-        ctx->d2h(rt12.data(), W.d_rt12.p, 48 * (size_t)K);
-        ctx->sync();
+        ctx->d2h(rt12.data(), W.d_rt12.p, 48 * (size_t)K);   // valid after the wait at the end of the penetration filter
     }
     std::vector<int32_t> penflags;
     {
         StageTimer t(ctx, "t_penetration");
-        penetration_filter(ctx, rt12.data(), K, C.geom, M.geom, C.pcl, M.pcl, lengthThreshold, angleThreshold, penflags);
+        penetration_filter(ctx, nullptr, K, C.geom, M.geom, C.pcl, M.pcl, lengthThreshold, angleThreshold, penflags, W.d_rt12.p);
     }
     ctx->put("pen_flags", penflags.data(), penflags.size());
     // survivors = MatchedResult list (util.cpp:513-517)

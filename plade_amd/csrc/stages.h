@@ -21,7 +21,7 @@ struct LineTableHost {
 };
 
 struct PairTableDev {
-    uint32_t count = 0;           // D: number of descriptors kept
+    uint32_t count = 0;           // D: number of descriptors kept (valid after the sync() that follows build_pair_table)
     DBuf<float> desc;             // D x 8
     DBuf<float> lv1, lv2, p1;     // D x 3 each: PAIRLINE::lineVec1, lineVec2, linePoints1
     // scratch
@@ -97,7 +97,8 @@ void build_pen_grid(plade_ctx *ctx, PlaneCloudsDev &pc, const PlaneGeomHost &geo
 void penetration_filter(plade_ctx *ctx, const float *cand_rt_host /*K x 12: R row-major, T*/, uint32_t K,
                         const PlaneGeomHost &src, const PlaneGeomHost &tgt, PlaneCloudsDev &src_pts,
                         PlaneCloudsDev &tgt_pts, float length_threshold, float angle_threshold,
-                        std::vector<int32_t> &flags_out);
+                        std::vector<int32_t> &flags_out, const float *cand_rt_dev = nullptr);
+// cand_rt_dev: the same K x 12 table already on the device (cand_rt_host may then be null: nothing is uploaded)
 
 // ---- oriented bounding boxes (k_obb.hip; ComputeBoundingBox, util.h:186-248) ---------------------------------
 // Result block (floats): whole cloud = centre(3), pad, radius as a double (2 floats), pad, valid flag;
