@@ -11,9 +11,11 @@ the bounding boxes of every step are inside the timed region.  On
 are independent (batch mode, code/PLADE/main.cpp:97-158), so every rank registers its own pairs with no
 data-path collective and the per-pair 4x4 results are gathered to rank 0 over RCCL at the end
 (weak scaling: work per GPU is fixed).  Several registrations are in flight per GPU (one plade_ctx + host thread
-each); `value` is the steady-state rate of that pipeline over the K steps that complete after the last lead-in
-(warm-up) step: steps in flight / mean time one of those K steps occupied its worker, which reads the same at
-`--steps 20` and `--steps 512` (the bare first-to-last-completion window is reported beside it).
+each); `value` is the steady-state rate of that pipeline over the timed steps that complete after the last lead-in
+(warm-up) step: steps in flight / mean time one of those steps occupied its worker (the bare first-to-last-completion
+window is reported beside it).  Fewer than 16 rounds of the workers sample a pipeline badly (20 steps = 2.5 rounds of
+8 read +-9 % from run to run), so max(K, 16 x in-flight) steps are timed; `ms_per_step` and `value` are per-step
+figures, `pipeline.timed_steps` says how many steps they come from, `steps` echoes the K that was asked for.
 Rank 0 prints ONE JSON line.  `resident_rank0` is the same pipeline on clouds already resident in HBM.
 
 Extra objects on the line:
@@ -351,7 +353,11 @@ def main():
     device_sync()
     cpu0, thr0 = time.process_time(), _cgroup_throttle()
     t_begin = time.perf_counter()
-    elapsed, timed, timed_ids, span = run_pipeline(hstep, lead, args.steps)
+    # K = --steps timed steps; a pipeline of M workers is not sampled fairly by fewer than ~16 rounds (the driver's 20 steps are
+    # 2.5 rounds of 8: +-9 % from run to run by either estimator), so at least 16 * M steps are timed and the PER-STEP time of
+    # those is what the line reports (`pipeline.timed_steps` says how many; ms_per_step and value are per-step quantities)
+    n_timed = max(args.steps, 16 * M)
+    elapsed, timed, timed_ids, span = run_pipeline(hstep, lead, n_timed)
     host_window = run_pipeline.last_window
     cpu1, thr1 = time.process_time(), _cgroup_throttle()
     oks = [bool(r[0]) for r in timed]
@@ -360,7 +366,7 @@ def main():
     # gather the per-pair 4x4 results on rank 0 in input order (the only exchange the path needs;
     # plade_amd/batch.py, covered on CPU by tests/test_distributed_gloo.py with gloo)
     from plade_amd.batch import gather_results
-    all_T, all_ok = gather_results(np.stack(results), np.array(oks, bool), world * args.steps, rank, world,
+    all_T, all_ok = gather_results(np.stack(results), np.array(oks, bool), world * n_timed, rank, world,
                                    device=dev if world > 1 else None)
     device_sync()
     if world > 1:
@@ -396,8 +402,8 @@ def main():
                         "note": "clouds resident in HBM (plade_cloud_upload once, plade_registration_dev per step): no H2D, no SoA "
                                 "conversion, no bounding box in the step"}
     mb = sum(tg.nbytes + sr.nbytes for tg, sr, _ in pairs) / len(pairs) / 1e6
-    host_leg = {"h2d_MB_per_step": mb, "pcie_GB_per_s": mb * 1e-3 * args.steps / elapsed,
-                "bracketed_value": (lead + args.steps + M) / bracketed if bracketed > 0 else None,
+    host_leg = {"h2d_MB_per_step": mb, "pcie_GB_per_s": mb * 1e-3 * n_timed / elapsed,
+                "bracketed_value": (lead + n_timed + M) / bracketed if bracketed > 0 else None,
                 "bracketed_note": "all lead-in + timed + tail steps of this rank over the barrier-to-barrier time (fill and drain of "
                                   "the pipeline and the result gather inside)"}
 
@@ -526,7 +532,7 @@ def main():
             # B_total / t_registration against the HBM peak (whole-step figure)
             # at the measured throughput (several registrations in flight) and for one registration alone
             roofline["step_algorithmic_bytes"] = b_total
-            roofline["step_frac_of_hbm_peak"] = b_total / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS
+            roofline["step_frac_of_hbm_peak"] = b_total / (elapsed / n_timed) / 1e9 / HBM_PEAK_GBS
             roofline["single_registration_frac_of_hbm_peak"] = b_total / (latency_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -539,7 +545,7 @@ def main():
             cpu = {"value": None, "unit": "registrations/s", "cores": 1, "kind": "port", "sample": f"unavailable: {e}"}
 
     if rank == 0:
-        total = world * args.steps
+        total = world * n_timed
         line = {
             "metric": "scan-pair registrations/sec, 1M-pt synthetic pairs",
             "value": total / elapsed,
@@ -547,7 +553,7 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step": elapsed / n_timed * 1e3,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -564,10 +570,11 @@ def main():
                        "registrations_in_flight_per_gpu": M, "inflight_chosen_from_cpu_quota": inflight_auto, "host_wait": args.host_wait,
                        "parallelism": f"independent pairs sharded over {world} GPU(s), {M} in flight per GPU"},
             "single_registration_latency_ms": latency_ms,
+            "registrations_timed": total,
             "registrations_ok": total_ok,
             "results_bit_identical_per_pair_rank0": bool(identical),
             "max_frobenius_vs_ground_truth_rank0": max(errs) if errs else None,
-            "host_rank0": {"cpu_seconds_per_step": (cpu1 - cpu0) / (lead + args.steps + M),
+            "host_rank0": {"cpu_seconds_per_step": (cpu1 - cpu0) / (lead + n_timed + M),
                            "busy_host_threads_avg": (cpu1 - cpu0) / max(span, 1e-9),
                            "cpu_budget": _cpu_budget(),
                            "cgroup_throttled_periods": (thr1[0] - thr0[0]) if thr0 and thr1 else None,
@@ -575,12 +582,12 @@ def main():
             "host_buffers_rank0": host_leg,
             "resident_rank0": resident_leg,
             "default_mode_rank0": default_mode,
-            "pipeline": {"lead_in_steps": lead, "timed_steps": args.steps, "tail_steps": M,
-                         "timing": "the `steps` completions after completion #lead_in, per rank, MAX over ranks: ms_per_step = mean "
+            "pipeline": {"lead_in_steps": lead, "timed_steps": n_timed, "requested_steps": args.steps, "tail_steps": M,
+                         "timing": "the `timed_steps` = max(steps, 16 x in flight) completions after completion #lead_in, per rank, MAX over ranks: ms_per_step = mean "
                                    "time a timed step occupied its worker / steps in flight (Little's law; = window / steps over long "
                                    "runs, without the burst edge effect over few steps); barrier + device_sync() before the first and "
                                    "after the last step of the run",
-                         "window_value_rank0": args.steps / host_window if host_window > 0 else None,
+                         "window_value_rank0": n_timed / host_window if host_window > 0 else None,
                          "window_note": "steps / (completion #(lead_in + steps) - completion #lead_in) on rank 0"},
             "roofline": roofline,
             "cpu_baseline": cpu,
