@@ -126,12 +126,12 @@ struct HBuf {
     HBuf() = default;
     HBuf(const HBuf &) = delete;
     HBuf &operator=(const HBuf &) = delete;
-    T *ensure(size_t n) {
+    T *ensure(size_t n, unsigned flags = hipHostMallocDefault) {
         if (n > cap) {
             if (p) HIP_TRY(hipHostFree(p));
             p = nullptr;
             size_t want = n + n / 4 + 64;
-            HIP_TRY(hipHostMalloc((void **)&p, want * sizeof(T), hipHostMallocDefault));
+            HIP_TRY(hipHostMalloc((void **)&p, want * sizeof(T), flags));
             cap = want;
         }
         return p;

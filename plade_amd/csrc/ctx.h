@@ -63,6 +63,15 @@ namespace plade {
 struct ScanWork { DBuf<uint64_t> state; DBuf<uint32_t> ticket; uint32_t base = 0, gen = 0; };
 }  // namespace plade
 
+namespace plade {
+// Device -> host hand-over of up to COPY_OUT_RANGES small arrays in ONE kernel (prims.hip): the ranges are written into a
+// page-locked arena of the context, then -- once every workgroup's stores are visible to the host -- the word `flag` (in the
+// same arena) receives `seq`.  The host polls that word in memory; no copy command per array, no question to the runtime.
+constexpr int COPY_OUT_RANGES = 8;
+struct CopyOutArgs { const uint32_t *src[COPY_OUT_RANGES]; uint32_t off_words[COPY_OUT_RANGES], words[COPY_OUT_RANGES], n; };
+void copy_out_launch(hipStream_t st, const CopyOutArgs &a, uint32_t *arena_words, uint32_t *counter, uint32_t *flag, uint32_t seq);
+}  // namespace plade
+
 struct plade_cloud {
     plade::CloudDev dev;
     std::vector<float> host_copy;  // pos_nrm kept for the small host-side gathers
@@ -174,6 +183,7 @@ struct plade_ctx {
     // polls the stream and sleeps in between.
     void sync(hipStream_t s = nullptr) {
         if (!s) s = stream;
+        if (s == stream && !pending_reads.empty()) { sync_with_reads(); return; }
         if (params.host_wait == 0) { HIP_TRY(hipStreamSynchronize(s)); }
         else {
             plade::relax_timer_slack();
@@ -188,27 +198,67 @@ struct plade_ctx {
         }
         if (s == stream) { finish_reads(); write_arena_used = 0; }
     }
-    // Device -> host readback on this ctx's stream; `dst` is valid after the next sync().  A copy into pageable host
-    // memory makes the HIP runtime wait (spinning) for everything queued before it and bounce the data through its own
-    // staging buffer; small readbacks (there are ~40 per registration) therefore go to a pinned arena of this context
-    // as truly asynchronous copies and are handed to their destinations by sync().
-    struct PendingRead { void *dst; size_t off, bytes; };
+    // Device -> host readback on this ctx's stream; `dst` is valid after the next sync(), and `src` must not be overwritten
+    // before it: the small readbacks (there are ~20 per registration) are only NOTED here; sync() hands all of them over
+    // with one kernel that writes them into a page-locked arena and then raises a flag word in the same arena, which the
+    // host polls in memory (plade::copy_out_launch).  Against one copy command per array and a stream query per poll
+    // that is fewer commands in the stream and no work for the runtime's event thread (profiles/r3_experiments.md).
+    // Large arrays, and whatever does not fit the arena, are copied directly.
+    struct PendingRead { void *dst; const void *src; size_t off, bytes; };
     std::vector<PendingRead> pending_reads;
     plade::HBuf<char> read_arena;
+    char *read_arena_dev = nullptr;       // the arena as the device addresses it
+    plade::DBuf<uint32_t> read_counter;
+    uint32_t read_seq = 0;
     size_t read_arena_used = 0;
     static constexpr size_t READ_ARENA_BYTES = 8u << 20, READ_DIRECT_BYTES = 2u << 20;
     void d2h(void *dst, const void *src, size_t bytes) {
         if (!bytes) return;
         const size_t need = (bytes + 255) & ~(size_t)255;
-        if (bytes > READ_DIRECT_BYTES || read_arena_used + need > READ_ARENA_BYTES) {
+        if (bytes > READ_DIRECT_BYTES || (bytes & 3) || (reinterpret_cast<uintptr_t>(src) & 3) || read_arena_used + need > READ_ARENA_BYTES) {
             if (params.host_wait != 0) sync();   // drain with sleeping polls first: only the copy itself is waited for actively
             HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, stream));
             return;
         }
-        char *a = read_arena.ensure(READ_ARENA_BYTES);
-        HIP_TRY(hipMemcpyAsync(a + read_arena_used, src, bytes, hipMemcpyDeviceToHost, stream));
-        pending_reads.push_back(PendingRead{dst, read_arena_used, bytes});
+        pending_reads.push_back(PendingRead{dst, src, read_arena_used, bytes});
         read_arena_used += need;
+    }
+    void sync_with_reads() {
+        // host-mapped and COHERENT: the kernel's stores must reach the host while the stream keeps running
+        char *arena = read_arena.ensure(READ_ARENA_BYTES + 256, hipHostMallocMapped | hipHostMallocCoherent);
+        if (!read_arena_dev) {
+            HIP_TRY(hipHostGetDevicePointer((void **)&read_arena_dev, arena, 0));
+            *reinterpret_cast<volatile uint32_t *>(arena + READ_ARENA_BYTES) = 0u;   // sequence numbers start at 1
+        }
+        if (!read_counter.p) { read_counter.ensure(4); HIP_TRY(hipMemsetAsync(read_counter.p, 0, 16, stream)); }
+        volatile uint32_t *flag = reinterpret_cast<volatile uint32_t *>(arena + READ_ARENA_BYTES);
+        const uint32_t seq = ++read_seq ? read_seq : ++read_seq;   // never 0
+        for (size_t i = 0; i < pending_reads.size(); i += plade::COPY_OUT_RANGES) {
+            plade::CopyOutArgs a;
+            a.n = (uint32_t)std::min<size_t>(plade::COPY_OUT_RANGES, pending_reads.size() - i);
+            for (uint32_t q = 0; q < a.n; ++q) {
+                const PendingRead &r = pending_reads[i + q];
+                a.src[q] = static_cast<const uint32_t *>(r.src); a.off_words[q] = (uint32_t)(r.off / 4); a.words[q] = (uint32_t)(r.bytes / 4);
+            }
+            const bool last = i + plade::COPY_OUT_RANGES >= pending_reads.size();
+            plade::copy_out_launch(stream, a, reinterpret_cast<uint32_t *>(read_arena_dev), read_counter.p,
+                                   last ? reinterpret_cast<uint32_t *>(read_arena_dev + READ_ARENA_BYTES) : nullptr, seq);
+        }
+        const double c0 = plade::thread_cpu_seconds();
+        struct Acc { plade::Stats &st; double c0; ~Acc() { st.add("cpu_sync_polls", plade::thread_cpu_seconds() - c0); } } acc{stats, c0};
+        if (params.host_wait != 0) plade::relax_timer_slack();
+        for (uint32_t polls = 0; *flag != seq; ++polls) {
+            // the stream query only catches a stream that died without raising the flag
+            if ((polls & (params.host_wait != 0 ? 63u : 0xfffffu)) == (params.host_wait != 0 ? 63u : 0xfffffu)) {
+                const hipError_t e = hipStreamQuery(stream);
+                if (e != hipSuccess && e != hipErrorNotReady) throw plade::Err{-2, std::string("hipStreamQuery: ") + hipGetErrorString(e)};
+                if (e == hipSuccess && *flag != seq) throw plade::Err{-2, "device -> host hand-over: the stream finished without the flag"};
+            }
+            if (params.host_wait != 0) plade::poll_sleep((int)polls);
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        finish_reads();
+        write_arena_used = 0;
     }
     // Host -> device upload of a small table: staged in the pinned arena so that the copy is asynchronous (a pageable
     // source makes the runtime copy it to its own staging buffer and, for some sizes, wait for the transfer).

@@ -125,4 +125,40 @@ void exclusive_scan_u32(plade_ctx *ctx, const uint32_t *in, uint32_t *out, size_
     hipLaunchKernelGGL(k_scan_u32, dim3(t.tiles), dim3(SC_T), 0, ctx->stream, in, out, (uint32_t)n, t.state, t.ticket, t.base, t.gen);
 }
 
+
+// ---- device -> host hand-over (ctx.h: plade_ctx::d2h / sync) ----------------------------------------------------------
+// grid (chunks, ranges): workgroup (x, r) copies words x * 1024 .. of range r into the arena; the workgroup that finishes
+// last raises the flag.  Every workgroup makes its stores visible to the host before it takes its ticket, so when the last
+// ticket is drawn all data are out.
+namespace {
+__global__ __launch_bounds__(256) void k_copy_out(const CopyOutArgs a, uint32_t *__restrict__ arena, uint32_t *__restrict__ counter,
+                                                  uint32_t *flag, uint32_t seq) {
+    const uint32_t r = blockIdx.y;
+    const uint32_t n = a.words[r];
+    const uint32_t *__restrict__ src = a.src[r];
+    uint32_t *__restrict__ dst = arena + a.off_words[r];
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) dst[i] = src[i];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t t = atomicAdd(counter, 1u);
+        if (t == gridDim.x * gridDim.y - 1u) {
+            atomicExch(counter, 0u);
+            if (flag) {
+                __threadfence_system();
+                __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    }
+}
+}  // namespace
+
+void copy_out_launch(hipStream_t st, const CopyOutArgs &a, uint32_t *arena_words, uint32_t *counter, uint32_t *flag, uint32_t seq) {
+    uint32_t most = 1;
+    for (uint32_t q = 0; q < a.n; ++q) most = std::max(most, a.words[q]);
+    const uint32_t gx = std::min(64u, cdiv(most, 1024u));   // a workgroup moves 4 KB per round
+    hipLaunchKernelGGL(k_copy_out, dim3(gx, a.n), dim3(256), 0, st, a, arena_words, counter, flag, seq);
+    HIP_TRY(hipGetLastError());
+}
+
 }  // namespace plade
