@@ -208,6 +208,10 @@ int plade_stats_get(plade_ctx *ctx, const char **names, const double **values, i
 int plade_sort_pairs(plade_ctx *ctx, const void *keys, const uint32_t *vals, uint32_t n, int key_bytes, int bits,
                      void *keys_out, uint32_t *vals_out);
 
+/* Test seam: the device -> host hand-over every readback of the library goes through (n_ranges arrays of `words` 32-bit
+ * words read back through one wait; no reference counterpart).  *mismatches = words that arrived wrong (0 expected). */
+int plade_selftest_readback(plade_ctx *ctx, uint32_t n_ranges, uint32_t words, uint32_t *mismatches);
+
 /* Times `iters` launches of one hot kernel on resident synthetic-shaped data with HIP events on
  * the ctx stream (used by bench.py for the roofline figure): which = "score" | "overlap" | "match". */
 int plade_kernel_time(plade_ctx *ctx, const char *which, int iters, double *avg_seconds,

@@ -21,7 +21,7 @@ ABI_SYMBOLS = [
     "plade_overlap_counts", "plade_average_spacing", "plade_voxel_downsample", "plade_registration_planes",
     "plade_registration", "plade_registration_minsupport", "plade_cloud_upload", "plade_cloud_free",
     "plade_registration_dev", "plade_dump_get", "plade_stats_get", "plade_kernel_time", "plade_plane_component",
-    "plade_sort_pairs", "plade_host_pin", "plade_host_unpin", "plade_score_planes_subset", "plade_registration_next", "plade_cluster_transforms", "plade_device_synchronize",
+    "plade_sort_pairs", "plade_host_pin", "plade_host_unpin", "plade_score_planes_subset", "plade_registration_next", "plade_cluster_transforms", "plade_device_synchronize", "plade_selftest_readback",
 ]
 
 
@@ -88,6 +88,7 @@ def load_library(path=LIB_PATH):
     sig("plade_kernel_time", argtypes=[p, C.c_char_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)])
     sig("plade_plane_component", argtypes=[p, p, u32, p, p, p, u32, f, C.c_int, f, p, p, p, p])
     sig("plade_sort_pairs", argtypes=[p, p, p, u32, C.c_int, C.c_int, p, p])
+    sig("plade_selftest_readback", argtypes=[p, u32, u32, C.POINTER(u32)])
     sig("plade_host_pin", argtypes=[p, p, C.c_size_t])
     sig("plade_host_unpin", argtypes=[p, p])
     _lib = L
@@ -196,6 +197,13 @@ class Context:
         self._check(self.L.plade_sort_pairs(self.h, k.ctypes.data_as(C.c_void_p), _ptr(v), len(k), kb,
                                             int(bits if bits is not None else 8 * kb), ko.ctypes.data_as(C.c_void_p), _ptr(vo)))
         return ko, vo
+
+    def selftest_readback(self, n_ranges, words):
+        """Test seam: n_ranges device arrays of `words` words through the library's device -> host hand-over; returns the number
+        of words that arrived wrong."""
+        bad = C.c_uint32(0)
+        self._check(self.L.plade_selftest_readback(self.h, int(n_ranges), int(words), C.byref(bad)))
+        return int(bad.value)
 
     # ---- seams -----------------------------------------------------------------------------
     def score_planes(self, pos_nrm, shape_index, planes, eps, cos_thresh, want_indices=False):

@@ -397,6 +397,34 @@ extern "C" int plade_sort_pairs(plade_ctx *ctx, const void *keys, const uint32_t
     });
 }
 
+// Test seam of the device -> host hand-over (ctx.h: d2h / sync): `n_ranges` device arrays of `words` 32-bit words each,
+// filled with a pattern, are read back through ONE sync(); *mismatches = words that did not arrive as written.
+extern "C" int plade_selftest_readback(plade_ctx *ctx, uint32_t n_ranges, uint32_t words, uint32_t *mismatches) {
+    return guarded(ctx, [&]() -> int {
+        PLADE_REQUIRE(mismatches && n_ranges >= 1 && n_ranges <= 64 && words >= 1 && words <= (1u << 18), PLADE_EINVAL,
+                      "plade_selftest_readback: 1..64 ranges of 1..2^18 words");
+        HIP_TRY(hipSetDevice(ctx->device));
+        std::vector<DBuf<uint32_t>> dev(n_ranges);
+        std::vector<std::vector<uint32_t>> want(n_ranges), got(n_ranges);
+        for (uint32_t r = 0; r < n_ranges; ++r) {
+            const uint32_t w = words - (r % 3);            // ragged sizes
+            want[r].resize(std::max(w, 1u));
+            for (uint32_t i = 0; i < want[r].size(); ++i) want[r][i] = 0x9E3779B9u * (i + 1) + 0x7F4A7C15u * (r + 1);
+            got[r].assign(want[r].size(), 0xdeadbeefu);
+            dev[r].ensure(want[r].size() + 4);
+            HIP_TRY(hipMemcpyAsync(dev[r].p, want[r].data(), 4 * want[r].size(), hipMemcpyHostToDevice, ctx->stream));
+        }
+        HIP_TRY(hipStreamSynchronize(ctx->stream));        // the pageable sources are done with
+        for (uint32_t r = 0; r < n_ranges; ++r) ctx->d2h(got[r].data(), dev[r].p, 4 * got[r].size());
+        ctx->sync();
+        uint32_t bad = 0;
+        for (uint32_t r = 0; r < n_ranges; ++r)
+            for (size_t i = 0; i < want[r].size(); ++i) bad += got[r][i] != want[r][i];
+        *mismatches = bad;
+        return PLADE_OK;
+    });
+}
+
 extern "C" int plade_kernel_time(plade_ctx *ctx, const char *which, int iters, double *avg_seconds,
                                  double *algorithmic_bytes_per_launch) {
     return guarded(ctx, [&]() -> int {

@@ -246,3 +246,18 @@ def test_candidate_shards_of_the_verification_seam_add_up(ctx):
             idx = shard(K, r, world)
             out[idx] = ctx.overlap_counts(tg, tg, T[idx], centers[idx], np.float32(4.0), np.float32(0.05))
         assert np.array_equal(out, full)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("host_wait", [0, 1])
+def test_device_to_host_hand_over_many_and_large_ranges(host_wait):
+    """Every readback of the library is noted by d2h() and handed over by one kernel per wait into a host-mapped arena, with a
+    flag word the host polls (ctx.h, prims.hip k_copy_out).  The registration never has more than a handful pending; this
+    drives the seam with more ranges than one launch takes (8), with ranges of many workgroups, ragged sizes, and both kinds
+    of host wait, repeatedly on one context (the sequence word must keep advancing)."""
+    import plade_amd
+    c = plade_amd.Context(0, host_wait=host_wait)
+    for n_ranges, words in ((1, 1), (3, 7), (8, 1000), (9, 1000), (23, 4099), (5, 200000), (64, 17), (12, 65536)):
+        for _ in range(3):
+            assert c.selftest_readback(n_ranges, words) == 0, (n_ranges, words)
+    c.close()
