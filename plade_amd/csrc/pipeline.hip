@@ -240,6 +240,12 @@ bool run_registration(plade_ctx *ctx, RegistrationWork &W, const CloudDev &tgt, 
     ctx->put1("average_spacing", average_space);
     // plade.cpp:46-56
     const float downSampleDistance = average_space * 4;
+    // The verification kernel probes the target's occupancy index once per (candidate, source point); with the source points
+    // in a spatially blocked order neighbouring lanes probe neighbouring cells.  That order costs a sort of the downsampled
+    // source (4 passes + 5 kernels, ~110 us) and pays from a few hundred candidates on (BASELINE configs[4]: 10^4); for the
+    // default <= 201 candidates, of which ~20 survive the penetration filter, the voxel order the downsampled cloud already
+    // has serves as well (k_overlap 169 / 198 us with the sort, 156 / 226 us without on the two bench pairs; same counts).
+    const bool sort_source = max_candidates > 1000;
     const float lengthThreshold = average_space * 5;
     const float angleThreshold = 5.0 / 180 * M_PI;
     const float cosAngleThreshold = cos(angleThreshold);
@@ -290,6 +296,7 @@ bool run_registration(plade_ctx *ctx, RegistrationWork &W, const CloudDev &tgt, 
         if (!W.ev_grid) HIP_TRY(hipEventCreateWithFlags(&W.ev_grid, hipEventDisableTiming));
         W.grid.build(aux, M.d_ds.p, M.n_ds, 3, downSampleDistance, tgt.bbmin, tgt.bbmax, true);
         // ... and the source in a spatially blocked order for the same kernel
+        if (sort_source)
         overlap_sort_source(aux, W.ov_work, C.d_ds_soa.p, C.d_ds_soa.p + C.n_ds, C.d_ds_soa.p + 2 * (size_t)C.n_ds, C.n_ds,
                             1.f / W.grid.gp.inv);
         HIP_TRY(hipEventRecord(W.ev_grid, aux->stream));
@@ -457,7 +464,8 @@ bool run_registration(plade_ctx *ctx, RegistrationWork &W, const CloudDev &tgt, 
         memcpy(up.data() + 16 * (size_t)Kv, centers.data(), 12 * (size_t)Kv);
         ctx->h2d(W.d_T16.p, up.data(), 76 * (size_t)Kv);
         HIP_TRY(hipStreamWaitEvent(ctx->stream, W.ev_grid, 0));
-        overlap_counts(ctx, W.ov_work, W.ov_work.sorted.p, W.ov_work.sorted.p + C.n_ds, W.ov_work.sorted.p + 2 * (size_t)C.n_ds, C.n_ds,
+        const float *vsx = sort_source ? W.ov_work.sorted.p : C.d_ds_soa.p;
+        overlap_counts(ctx, W.ov_work, vsx, vsx + C.n_ds, vsx + 2 * (size_t)C.n_ds, C.n_ds,
                        W.grid, W.d_T16.p, d_centers, Kv, (float)C.radius, downSampleDistance, W.d_counts.p, d_any);
         std::vector<int32_t> back(2 * (size_t)Kv);
         ctx->d2h(back.data(), W.d_counts.p, 8 * (size_t)Kv);
