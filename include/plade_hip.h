@@ -23,6 +23,8 @@ extern "C" {
 #define PLADE_EFAIL (-4)    /* registration failed (reference returns false) */
 #define PLADE_ELIMIT (-5)   /* internal limit exceeded */
 
+#define PLADE_GROUP_MAX 2   /* pairs per group of plade_registration_pairs */
+
 typedef struct plade_ctx plade_ctx;
 typedef struct plade_cloud plade_cloud; /* device-resident oriented point cloud */
 
@@ -43,13 +45,23 @@ int plade_device_synchronize(int device);
  *                          counter that stays 0, so its average normal is NaN and the test never flips:
  *                          the plane normal keeps the sign of the LS-fit eigenvector); 1 = the evident
  *                          intent: flip (n, d) so that n agrees with the mean normal of the plane's inliers.
- *                          The C ABI never looks at the environment; the C++ API / CLI (plade_host.cpp) turn it on
- *                          with env PLADE_ORIENT_NORMALS=1.
+ *                          The C ABI never looks at the environment for anything that selects a result or an algorithm
+ *                          (only PLADE_TRACE_* / PLADE_DEBUG_* printing and A/B timing hooks); the C++
+ *                          API / CLI (plade_host.cpp) turn it on with env PLADE_ORIENT_NORMALS=1.
  *   unoriented_normals 0   1 = the "unoriented normals" mode README.md:109-110 describes: every plane takes part
  *                          with both orientations (2x planes, ~4x line pairs / descriptors), so a pair registers
  *                          whatever the signs of the extracted plane normals are.  C++ API / CLI: env PLADE_UNORIENTED_NORMALS=1.
  *   ransac_seed     fixed  the reference seeds from time(NULL) (RansacShapeDetector.cpp:463-464)
- *   dump            0      keep named intermediates for plade_dump_get (tests)            */
+ *   dump            0      keep named intermediates for plade_dump_get (tests)
+ *   ransac_topup    1      schedule of the plane extraction's hypothesis rounds.  1 = every iteration draws a round and
+ *                          what the previous batch left of the candidate pool competes with the new draws (the
+ *                          reference's loop generates candidates in every pass, RansacShapeDetector.cpp:548-617);
+ *                          0 = a round is drawn only when the pool is empty: strict best-first acceptance, two more
+ *                          launches per iteration and more iterations.  Same acceptance semantics; which of two touching
+ *                          faces takes contested points can differ (tests/test_gpu_golden.py).
+ *   match_window    0      enumeration of the descriptor match (seam S2): 0 = brute force up to 2e10 descriptor pairs,
+ *                          length-windowed above; 1 = always windowed; -1 = never.  The lists are identical either way.
+ *   match_cell_budget 0    (query, chunk) cells per slab of the windowed enumeration; 0 = 2^26.  Test hook.         */
 typedef struct plade_params {
     int32_t max_planes;
     int32_t min_planes;
@@ -65,6 +77,9 @@ typedef struct plade_params {
                           * otherwise idle while the host sleeps; with >= 8 in flight the empty speculative
                           * iteration costs more than it hides).  C++ API / CLI: env PLADE_HOST_WAIT=spin|sleep. */
     int32_t unoriented_normals;
+    int32_t ransac_topup;
+    int32_t match_window;
+    uint32_t match_cell_budget;
 } plade_params;
 void plade_default_params(plade_params *p);
 int plade_set_params(plade_ctx *ctx, const plade_params *p);
@@ -177,6 +192,24 @@ int plade_registration(plade_ctx *ctx, const float *tgt_pos_nrm, uint32_t n_t,
 int plade_registration_next(plade_ctx *ctx, const float *tgt_pos_nrm, uint32_t n_t,
                             const float *src_pos_nrm, uint32_t n_s, const float *next_tgt_pos_nrm,
                             uint32_t next_n_t, const float *next_src_pos_nrm, uint32_t next_n_s, float *T16);
+/* Batch mode, `count` (1..PLADE_GROUP_MAX) consecutive pairs of the list per call (the loop of code/PLADE/main.cpp:122-148
+ * taken two pairs at a time).  Every pair is registered exactly like plade_registration -- results are bit-identical to
+ * registering it alone -- but the plane extraction of all clouds of the group (PlaneExtraction::detect x 4) is ONE launch
+ * sequence: its ~150 kernels per cloud pair are short and latency-bound, and carrying two pairs per launch halves the
+ * commands, host waits and GPU time per registration; behind the extraction the pairs proceed concurrently, pair 1 on an
+ * internal peer context (plade_pair_ctx).  tgt_pos_nrm / src_pos_nrm: count pointers to N x 6 arrays, n_t / n_s their point
+ * counts; next_*: the clouds the NEXT call on this ctx will be handed (next_count = 0: none), prefetched as
+ * plade_registration_next does.  T16: count x 16 (identity where a pair fails); status[i]: PLADE_OK, PLADE_EFAIL (the
+ * reference returns false) or another PLADE_E* code for pair i.  The return value reports errors that concern the whole
+ * call (bad arguments, upload, plane extraction); plade_last_error(plade_pair_ctx(ctx, i)) has pair i's message. */
+int plade_registration_pairs(plade_ctx *ctx, uint32_t count, const float *const *tgt_pos_nrm, const uint32_t *n_t,
+                             const float *const *src_pos_nrm, const uint32_t *n_s, uint32_t next_count,
+                             const float *const *next_tgt_pos_nrm, const uint32_t *next_n_t,
+                             const float *const *next_src_pos_nrm, const uint32_t *next_n_s, float *T16, int32_t *status);
+/* The context that carried pair `index` of the last plade_registration_pairs* call on ctx (0: ctx itself; 1: its peer, NULL
+ * before the first two-pair call): stats, dump and last error of that pair are read from it with the entry points below.
+ * Borrowed -- it is destroyed with ctx; do not register on it. */
+plade_ctx *plade_pair_ctx(plade_ctx *ctx, uint32_t index);
 /* plade.h:91-96  registration(T, target, source, min_support_target, min_support_source) */
 int plade_registration_minsupport(plade_ctx *ctx, const float *tgt_pos_nrm, uint32_t n_t,
                                   const float *src_pos_nrm, uint32_t n_s, int32_t min_support_t,
@@ -192,6 +225,9 @@ int plade_host_unpin(plade_ctx *ctx, const void *ptr);
 int plade_cloud_upload(plade_ctx *ctx, const float *pos_nrm, uint32_t n, plade_cloud **out);
 void plade_cloud_free(plade_ctx *ctx, plade_cloud *c);
 int plade_registration_dev(plade_ctx *ctx, plade_cloud *tgt, plade_cloud *src, float *T16);
+/* plade_registration_pairs on resident clouds */
+int plade_registration_pairs_dev(plade_ctx *ctx, uint32_t count, plade_cloud *const *tgt, plade_cloud *const *src, float *T16,
+                                 int32_t *status);
 
 /* ---- instrumentation ---------------------------------------------------------------------- */
 /* Named intermediates of the last registration (when params.dump != 0). Returns 0 if found;

@@ -22,6 +22,7 @@ ABI_SYMBOLS = [
     "plade_registration", "plade_registration_minsupport", "plade_cloud_upload", "plade_cloud_free",
     "plade_registration_dev", "plade_dump_get", "plade_stats_get", "plade_kernel_time", "plade_plane_component",
     "plade_sort_pairs", "plade_host_pin", "plade_host_unpin", "plade_score_planes_subset", "plade_registration_next", "plade_cluster_transforms", "plade_device_synchronize", "plade_selftest_readback",
+    "plade_registration_pairs", "plade_registration_pairs_dev", "plade_pair_ctx",
 ]
 
 
@@ -34,7 +35,8 @@ class PladeError(RuntimeError):
 class Params(C.Structure):
     _fields_ = [("max_planes", C.c_int32), ("min_planes", C.c_int32), ("max_candidates", C.c_int32),
                 ("init_min_support", C.c_int32), ("orient_normals", C.c_int32), ("dump", C.c_int32),
-                ("ransac_seed", C.c_uint64), ("host_wait", C.c_int32), ("unoriented_normals", C.c_int32)]
+                ("ransac_seed", C.c_uint64), ("host_wait", C.c_int32), ("unoriented_normals", C.c_int32),
+                ("ransac_topup", C.c_int32), ("match_window", C.c_int32), ("match_cell_budget", C.c_uint32)]
 
 
 _lib = None
@@ -79,6 +81,9 @@ def load_library(path=LIB_PATH):
     sig("plade_registration_planes", argtypes=[p, p, u32, p, u32, p, p, p, u32, p, p, p, u32, p])
     sig("plade_registration", argtypes=[p, p, u32, p, u32, p])
     sig("plade_registration_next", argtypes=[p, p, u32, p, u32, p, u32, p, u32, p])
+    sig("plade_registration_pairs", argtypes=[p, u32, p, p, p, p, u32, p, p, p, p, p, p])
+    sig("plade_registration_pairs_dev", argtypes=[p, u32, p, p, p, p])
+    sig("plade_pair_ctx", argtypes=[p, u32], restype=p)
     sig("plade_registration_minsupport", argtypes=[p, p, u32, p, u32, i32, i32, p])
     sig("plade_cloud_upload", argtypes=[p, p, u32, C.POINTER(p)])
     sig("plade_cloud_free", argtypes=[p, p])
@@ -333,6 +338,58 @@ class Context:
                                                         len(ns) if ns is not None else 0, _ptr(T)), allow=(PLADE_EFAIL,))
         return rc == 0, T
 
+    @staticmethod
+    def _cloud_table(arrs):
+        ptrs = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+        ns = (C.c_uint32 * len(arrs))(*[len(a) for a in arrs])
+        return ptrs, ns
+
+    def registration_pairs(self, pairs, next_pairs=None):
+        """plade.h:58 in batch mode, one GROUP of one or two pairs per call (plade_registration_pairs): pairs = [(tgt, src), ...];
+        next_pairs = the pairs the next call on this context will be handed (their upload is started now).  The arrays must be
+        C-contiguous float32 and stay alive and unchanged until that call.  Returns [(ok, T 4x4), ...]."""
+        for pr in list(pairs) + list(next_pairs or []):
+            for a in pr[:2]:
+                assert a.dtype == np.float32 and a.flags["C_CONTIGUOUS"]
+        k = len(pairs)
+        tp, tn = self._cloud_table([p[0] for p in pairs])
+        sp, sn = self._cloud_table([p[1] for p in pairs])
+        nk = len(next_pairs) if next_pairs else 0
+        if nk:
+            ntp, ntn = self._cloud_table([p[0] for p in next_pairs])
+            nsp, nsn = self._cloud_table([p[1] for p in next_pairs])
+        else:
+            ntp = ntn = nsp = nsn = None
+        T = np.zeros((k, 4, 4), np.float32)
+        st = np.zeros(k, np.int32)
+        self._check(self.L.plade_registration_pairs(self.h, k, tp, tn, sp, sn, nk, ntp, ntn, nsp, nsn, _ptr(T), _ptr(st)))
+        for i in range(k):
+            if st[i] not in (0, PLADE_EFAIL):
+                raise PladeError(int(st[i]), self.pair_error(i))
+        return [(bool(st[i] == 0), T[i].copy()) for i in range(k)]
+
+    def registration_pairs_dev(self, clouds):
+        """The same group call on resident clouds: clouds = [(tgt Cloud, src Cloud), ...]."""
+        k = len(clouds)
+        tp = (C.c_void_p * k)(*[c[0].h.value for c in clouds])
+        sp = (C.c_void_p * k)(*[c[1].h.value for c in clouds])
+        T = np.zeros((k, 4, 4), np.float32)
+        st = np.zeros(k, np.int32)
+        self._check(self.L.plade_registration_pairs_dev(self.h, k, tp, sp, _ptr(T), _ptr(st)))
+        for i in range(k):
+            if st[i] not in (0, PLADE_EFAIL):
+                raise PladeError(int(st[i]), self.pair_error(i))
+        return [(bool(st[i] == 0), T[i].copy()) for i in range(k)]
+
+    def _pair_handle(self, index):
+        h = self.L.plade_pair_ctx(self.h, int(index))
+        if not h:
+            raise PladeError(PLADE_EINVAL, f"no pair {index} on this context")
+        return C.c_void_p(h)
+
+    def pair_error(self, index):
+        return self.L.plade_last_error(self._pair_handle(index)).decode(errors="replace")
+
     def registration_minsupport(self, tgt, src, ms_t, ms_s):
         """plade.h:91."""
         tgt, src = _f32(tgt), _f32(src)
@@ -360,12 +417,13 @@ class Context:
         return rc == 0, T
 
     # ---- instrumentation ---------------------------------------------------------------------
-    def dump(self):
+    def dump(self, pair=0):
         out = {}
+        h = self._pair_handle(pair) if pair else self.h
         for name, dt in DUMP_FIELDS.items():
             ptr = C.c_void_p()
             nb = C.c_int64()
-            if self.L.plade_dump_get(self.h, name.encode(), C.byref(ptr), C.byref(nb)) != 0:
+            if self.L.plade_dump_get(h, name.encode(), C.byref(ptr), C.byref(nb)) != 0:
                 continue
             if nb.value == 0 or not ptr.value:
                 out[name] = np.zeros(0, dt)
@@ -374,11 +432,11 @@ class Context:
             out[name] = np.frombuffer(bytes(buf), dtype=dt).copy()
         return out
 
-    def stats(self):
+    def stats(self, pair=0):
         names = C.c_char_p()
         vals = C.POINTER(C.c_double)()
         cnt = C.c_int32()
-        self._check(self.L.plade_stats_get(self.h, C.byref(names), C.byref(vals), C.byref(cnt)))
+        self._check(self.L.plade_stats_get(self._pair_handle(pair) if pair else self.h, C.byref(names), C.byref(vals), C.byref(cnt)))
         ns = names.value.decode().strip(";").split(";") if cnt.value else []
         return {ns[i]: vals[i] for i in range(cnt.value)}
 

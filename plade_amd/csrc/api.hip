@@ -16,6 +16,9 @@ extern "C" void plade_default_params(plade_params *p) {
     p->ransac_seed = 0x9E3779B97F4A7C15ull;
     p->host_wait = 0;
     p->unoriented_normals = 0;
+    p->ransac_topup = 1;
+    p->match_window = 0;
+    p->match_cell_budget = 0;
     // pure: no environment look-ups here -- programs that cannot pass plade_params (the CLI, the C++ registration()
     // overloads) read their opt-in switches themselves (plade_host.cpp: context())
 }
@@ -39,6 +42,8 @@ extern "C" int plade_ctx_create(int device, plade_ctx **out) {
 extern "C" void plade_ctx_destroy(plade_ctx *ctx) {
     if (!ctx) return;
     if (ctx->aux) { plade_ctx_destroy(ctx->aux); ctx->aux = nullptr; }
+    if (ctx->peer) { plade_ctx_destroy(ctx->peer); ctx->peer = nullptr; }
+    if (ctx->ev_group) { (void)hipEventDestroy(ctx->ev_group); ctx->ev_group = nullptr; }
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->reg_work) plade::registration_work_destroy(ctx->reg_work);
@@ -63,7 +68,7 @@ extern "C" const char *plade_last_error(const plade_ctx *ctx) { return ctx ? ctx
 
 extern "C" int plade_set_params(plade_ctx *ctx, const plade_params *p) {
     if (!ctx || !p) return PLADE_EINVAL;
-    if (p->max_planes < 1 || p->min_planes < 0 || p->max_candidates < 1 || p->init_min_support < 1) return PLADE_EINVAL;
+    if (p->max_planes < 1 || p->min_planes < 0 || p->max_candidates < 1 || p->init_min_support < 1 || p->match_window < -1 || p->match_window > 1) return PLADE_EINVAL;
     ctx->params = *p;
     return PLADE_OK;
 }

@@ -57,14 +57,23 @@ void cloud_upload(plade_ctx *ctx, const float *pos_nrm, uint32_t n, CloudDev &ou
     finish_uploads(ctx, cl, 1);
 }
 
-void cloud_upload_pair(plade_ctx *ctx, const float *tgt, uint32_t n_t, CloudDev &out_t, const float *src, uint32_t n_s, CloudDev &out_s) {
-    shape_cloud(out_t, n_t);
-    shape_cloud(out_s, n_s);
-    if (n_t) HIP_TRY(hipMemcpyAsync(out_t.aos.p, tgt, (size_t)n_t * 24, hipMemcpyHostToDevice, ctx->stream));
-    if (n_s) HIP_TRY(hipMemcpyAsync(out_s.aos.p, src, (size_t)n_s * 24, hipMemcpyHostToDevice, ctx->stream));
+void cloud_upload_many(plade_ctx *ctx, int count, const float *const ptr[], const uint32_t n[], CloudDev *const out[]) {
+    PLADE_REQUIRE(count >= 1 && count <= 4, PLADE_EINVAL, "cloud_upload_many: one to four clouds");
+    for (int i = 0; i < count; ++i) {
+        shape_cloud(*out[i], n[i]);
+        if (n[i]) HIP_TRY(hipMemcpyAsync(out[i]->aos.p, ptr[i], (size_t)n[i] * 24, hipMemcpyHostToDevice, ctx->stream));
+    }
     ctx->sync();
-    CloudDev *cl[2] = {&out_t, &out_s};
-    finish_uploads(ctx, cl, 2);
+    CloudDev *cl[4];
+    for (int i = 0; i < count; ++i) cl[i] = out[i];
+    finish_uploads(ctx, cl, count);
+}
+
+void cloud_upload_pair(plade_ctx *ctx, const float *tgt, uint32_t n_t, CloudDev &out_t, const float *src, uint32_t n_s, CloudDev &out_s) {
+    const float *ptr[2] = {tgt, src};
+    const uint32_t n[2] = {n_t, n_s};
+    CloudDev *out[2] = {&out_t, &out_s};
+    cloud_upload_many(ctx, 2, ptr, n, out);
 }
 
 namespace {
@@ -77,34 +86,43 @@ void swap_clouds(CloudDev &a, CloudDev &b) {
 }
 }  // namespace
 
-// The upload of the pair the NEXT plade_registration_next call will be handed: the two H2D copies (asynchronous DMA when
-// the caller's buffers are page-locked, plade_host_pin) on the prefetch stream and nothing else -- no kernel, no event
-// waits behind them in a hardware queue (see above); the call that takes the pair over converts it.
-void cloud_prefetch_pair(plade_ctx *ctx, const float *tgt, uint32_t n_t, const float *src, uint32_t n_s) {
+void cloud_drop_prefetch(plade_ctx *ctx) {
     plade_ctx::Prefetch &P = ctx->pf;
+    if (!P.valid) return;
     P.valid = false;
-    if (!tgt || !src || !n_t || !n_s) return;
+    if (P.stream) ctx->sync(P.stream);
+}
+
+// The upload of the clouds the NEXT batch-mode call will be handed: the H2D copies (asynchronous DMA when the caller's
+// buffers are page-locked, plade_host_pin) on the prefetch stream and nothing else -- no kernel, no event waits behind them
+// in a hardware queue (see above); the call that takes the clouds over converts them.
+void cloud_prefetch(plade_ctx *ctx, int count, const float *const ptr[], const uint32_t n[]) {
+    plade_ctx::Prefetch &P = ctx->pf;
+    cloud_drop_prefetch(ctx);   // an earlier prefetch nobody took is still writing into the buffers reshaped below
+    if (count != 2 && count != 4) return;
+    for (int i = 0; i < count; ++i) if (!ptr[i] || !n[i]) return;
     if (!P.stream) HIP_TRY(hipStreamCreateWithFlags(&P.stream, hipStreamNonBlocking));
-    shape_cloud(P.tgt, n_t);
-    shape_cloud(P.src, n_s);
-    HIP_TRY(hipMemcpyAsync(P.tgt.aos.p, tgt, (size_t)n_t * 24, hipMemcpyHostToDevice, P.stream));
-    HIP_TRY(hipMemcpyAsync(P.src.aos.p, src, (size_t)n_s * 24, hipMemcpyHostToDevice, P.stream));
-    P.ptr_t = tgt; P.ptr_s = src; P.n_t = n_t; P.n_s = n_s;
+    for (int i = 0; i < count; ++i) {
+        shape_cloud(P.cl[i], n[i]);
+        HIP_TRY(hipMemcpyAsync(P.cl[i].aos.p, ptr[i], (size_t)n[i] * 24, hipMemcpyHostToDevice, P.stream));
+        P.ptr[i] = ptr[i]; P.n[i] = n[i];
+    }
+    P.count = count;
     P.valid = true;
 }
 
-// true: the prefetched clouds are exactly this pair; they are now ctx->up_tgt / ctx->up_src (converted, boxes decoded,
-// non-finite coordinates refused as cloud_upload does).  false: nothing (usable) was prefetched.
-bool cloud_take_prefetched(plade_ctx *ctx, const float *tgt, uint32_t n_t, const float *src, uint32_t n_s) {
+// true: the prefetched clouds are exactly these; they are now out[] (converted, boxes decoded, non-finite coordinates refused as
+// cloud_upload does).  false: nothing (usable) was prefetched.
+bool cloud_take_prefetched(plade_ctx *ctx, int count, const float *const ptr[], const uint32_t n[], CloudDev *const out[]) {
     plade_ctx::Prefetch &P = ctx->pf;
     if (!P.valid) return false;
     P.valid = false;
     ctx->sync(P.stream);   // whatever happens next, the prefetch stream must have finished with the buffers
-    if (P.ptr_t != tgt || P.ptr_s != src || P.n_t != n_t || P.n_s != n_s) return false;
-    swap_clouds(ctx->up_tgt, P.tgt);
-    swap_clouds(ctx->up_src, P.src);
-    CloudDev *cl[2] = {&ctx->up_tgt, &ctx->up_src};
-    finish_uploads(ctx, cl, 2);
+    if (P.count != count) return false;
+    for (int i = 0; i < count; ++i) if (P.ptr[i] != ptr[i] || P.n[i] != n[i]) return false;
+    CloudDev *cl[4];
+    for (int i = 0; i < count; ++i) { swap_clouds(*out[i], P.cl[i]); cl[i] = out[i]; }
+    finish_uploads(ctx, cl, count);
     return true;
 }
 

@@ -83,6 +83,8 @@ struct plade_ctx {
     int device = 0;
     plade::RegistrationWork *reg_work = nullptr;
     plade::RansacWork *ransac_work = nullptr;
+    plade_ctx *peer = nullptr;  // the context of the SECOND pair of a group (plade_registration_pairs): stream, aux, work areas
+    hipEvent_t ev_group = nullptr;   // end of a group's joint plane extraction on `stream` (the peer's stream waits for it)
     plade_ctx *aux = nullptr;   // second stream + work areas: stages of the source cloud that are independent of the
                                 // target's run concurrently with them
     hipStream_t stream = nullptr;
@@ -93,14 +95,18 @@ struct plade_ctx {
     // pair registers; the next call finds them here and swaps them in
     struct Prefetch {
         hipStream_t stream = nullptr;
-        plade::CloudDev tgt, src;
-        const float *ptr_t = nullptr, *ptr_s = nullptr;
-        uint32_t n_t = 0, n_s = 0;
+        plade::CloudDev cl[4];                 // target, source of pair 0; target, source of pair 1
+        const float *ptr[4] = {nullptr, nullptr, nullptr, nullptr};
+        uint32_t n[4] = {0, 0, 0, 0};
+        int count = 0;                         // clouds in flight (2 or 4)
         bool valid = false;
         plade::HBuf<int> h;      // page-locked: [0..8) init pattern, then 8 ints per bounding box read back
         plade::DBuf<int> d;      // 8 ints per box being reduced
     } pf;
     plade_params params;
+    // number of completed host waits on `stream` (sync(), the extraction's flag waits): a stage that left results in host-mapped
+    // memory behind kernels queued earlier remembers the count at enqueue time and knows from it whether anything has waited since
+    uint64_t wait_epoch = 0;
     std::string last_error;
     std::map<std::string, std::vector<char>> dump;
     plade::Stats stats;
@@ -196,7 +202,7 @@ struct plade_ctx {
                 plade::poll_sleep(polls);
             }
         }
-        if (s == stream) { finish_reads(); write_arena_used = 0; }
+        if (s == stream) { finish_reads(); write_arena_used = 0; ++wait_epoch; }
     }
     // Device -> host readback on this ctx's stream; `dst` is valid after the next sync(), and `src` must not be overwritten
     // before it: the small readbacks (there are ~20 per registration) are only NOTED here; sync() hands all of them over
@@ -259,6 +265,7 @@ struct plade_ctx {
         std::atomic_thread_fence(std::memory_order_acquire);
         finish_reads();
         write_arena_used = 0;
+        ++wait_epoch;
     }
     // Host -> device upload of a small table: staged in the pinned arena so that the copy is asynchronous (a pageable
     // source makes the runtime copy it to its own staging buffer and, for some sizes, wait for the transfer).
@@ -287,6 +294,7 @@ struct plade_ctx {
         read_arena_used = 0;
         write_arena_used = 0;
         if (aux) aux->drop_reads();
+        if (peer) peer->drop_reads();
     }
     void finish_reads() {
         for (const PendingRead &r : pending_reads) memcpy(r.dst, read_arena.p + r.off, r.bytes);
@@ -357,8 +365,14 @@ struct StageTimer {
 // cloud upload: AoS N x 6 (host) -> SoA on device
 void cloud_upload(plade_ctx *ctx, const float *pos_nrm, uint32_t n, CloudDev &out);
 void cloud_upload_pair(plade_ctx *ctx, const float *tgt, uint32_t n_t, CloudDev &out_t, const float *src, uint32_t n_s, CloudDev &out_s);
-// batch mode: queue the upload of the NEXT pair on the context's prefetch stream / take a finished prefetch over
-void cloud_prefetch_pair(plade_ctx *ctx, const float *tgt, uint32_t n_t, const float *src, uint32_t n_s);
-bool cloud_take_prefetched(plade_ctx *ctx, const float *tgt, uint32_t n_t, const float *src, uint32_t n_s);
+// `count` (<= 4) clouds in one go: all copies first, one wait, then conversion + bounding boxes of all of them, one wait
+void cloud_upload_many(plade_ctx *ctx, int count, const float *const ptr[], const uint32_t n[], CloudDev *const out[]);
+// batch mode: queue the upload of the NEXT call's clouds (count = 2 or 4: target, source[, target, source]) on the context's
+// prefetch stream / take a finished prefetch over into out[] (false: nothing usable was prefetched)
+void cloud_prefetch(plade_ctx *ctx, int count, const float *const ptr[], const uint32_t n[]);
+bool cloud_take_prefetched(plade_ctx *ctx, int count, const float *const ptr[], const uint32_t n[], CloudDev *const out[]);
+// a pending prefetch is waited for and dropped (every entry point that does not consume it: the caller may release or reuse
+// the buffers after the call that announced them, and a reused address must not be mistaken for the announced pair)
+void cloud_drop_prefetch(plade_ctx *ctx);
 
 }  // namespace plade

@@ -276,7 +276,7 @@ uint64_t MatchResult::run_windowed(plade_ctx *ctx, const float *d_qry, uint32_t 
     // has ~2e9 of them.  With more than one slab the count pass runs twice (totals of all slabs first -- they place the
     // lists in the order of the ORIGINAL queries -- then again in front of each slab's fill pass).
     uint64_t cell_budget = 1ull << 26;
-    if (const char *e = getenv("PLADE_MATCH_CELL_BUDGET")) cell_budget = std::max<uint64_t>((uint64_t)MT_TPB * nch, strtoull(e, nullptr, 10));   // tests: small slabs
+    if (ctx->params.match_cell_budget) cell_budget = std::max<uint64_t>((uint64_t)MT_TPB * nch, ctx->params.match_cell_budget);   // tests: small slabs
     PLADE_REQUIRE((uint64_t)MT_TPB * nch <= cell_budget, PLADE_ELIMIT, "match: a window of more than 5e8 targets");
     const uint32_t groups_per_slab = (uint32_t)std::min<uint64_t>(ng, cell_budget / ((uint64_t)MT_TPB * nch));
     const uint32_t n_slabs = cdiv(ng, groups_per_slab);
@@ -356,10 +356,9 @@ uint64_t MatchResult::run(plade_ctx *ctx, const float *d_qry, uint32_t dq, const
     if (radius < 0.f || dt == 0) { HIP_TRY(hipMemsetAsync(offsets.p, 0, ((size_t)dq + 1) * 8, ctx->stream)); return 0; }
     const float sq_rad_f = radius * radius;  // ANN.h:987 `float sqRad = radius*radius`
     const double sq_rad = sq_rad_f;
-    // large tables (or PLADE_MATCH_WINDOW=1): enumerate only inside the length windows
+    // large tables (or plade_params.match_window = 1): enumerate only inside the length windows
     {
-        const char *env = getenv("PLADE_MATCH_WINDOW");
-        const bool force = env && atoi(env) > 0, never = env && atoi(env) < 0;
+        const bool force = ctx->params.match_window > 0, never = ctx->params.match_window < 0;
         if (!never && (force || (double)dq * (double)dt > 2.0e10)) return run_windowed(ctx, d_qry, dq, d_tgt, dt, radius);
     }
     // A workgroup is one wave of 64 queries against one chunk of targets (fp64 distances, ~50 cycles per target): with

@@ -519,6 +519,7 @@ extern "C" int plade_registration_planes(plade_ctx *ctx, const float *tgt_pos_nr
         ctx->stats.clear();
         ctx->dump.clear();
         if (!ctx->reg_work) ctx->reg_work = registration_work_create();
+        cloud_drop_prefetch(ctx);
         CloudDev &tgt = ctx->up_tgt, &src = ctx->up_src;
         {
             StageTimer t(ctx, "t_upload");

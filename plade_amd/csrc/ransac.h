@@ -1,5 +1,5 @@
 // plade_amd/csrc/ransac.h -- GPU plane extraction (seam S1b): a device-driven Efficient-RANSAC that extracts the
-// planes of up to two clouds (the two scans of a pair) in the same launch sequence, see ransac.hip.
+// planes of up to four clouds (the scans of one or two pairs) in the same launch sequence, see ransac.hip.
 #pragma once
 #include "ctx.h"
 
@@ -53,17 +53,18 @@ struct ComponentOut {
 void plane_component(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const float normal[3], const float point[3],
                      const int32_t *idx, uint32_t m, float bitmap_eps, bool closing_filter, float w_eps, ComponentOut &out);
 
-// Up to two clouds are extracted together ("slots" 0 and 1 of the work area).
-constexpr int RANSAC_SLOTS = 2;
+// Up to four clouds are extracted together ("slots" 0-3 of the work area): the two scans of a registration, or the four of a
+// group of two registrations (plade_registration_pairs), in one launch sequence.
+constexpr int RANSAC_SLOTS = 4;
 
 // Morton order + stratified subset of the clouds (once per set of clouds; every detect call on them reuses it).
 void ransac_prepare(plade_ctx *ctx, RansacWork &W, const CloudDev *const clouds[RANSAC_SLOTS], int n_clouds);
 
 // average_spacing (code/PLADE/util.cpp:1619-1648) of the cloud in `slot` from its Morton order: two kernels queued on the
-// context's stream behind ransac_prepare; ransac_spacing_finish after any later sync of that stream (false: not available
+// context's stream behind ransac_prepare; ransac_spacing_finish waits for them unless a later wait on that stream has completed (false: not available
 // -- nothing queued, or a cloud too clumped for the octree cells -- use average_spacing_dev).
 void ransac_spacing_enqueue(plade_ctx *ctx, RansacWork &W, int slot, int k, uint32_t samples);
-bool ransac_spacing_finish(RansacWork &W, int slot, float *spacing_out);
+bool ransac_spacing_finish(plade_ctx *ctx, RansacWork &W, int slot, float *spacing_out);
 
 // One PlaneExtraction::detect (code/PLADE/plane_extraction.cpp:173-200) per ACTIVE slot, all in one launch sequence:
 // slots with active[s] == false keep the results of their previous detect call untouched.
@@ -71,6 +72,7 @@ struct RansacJob {
     bool active = false;
     RansacParams rp;
     PlaneSetOut *out = nullptr;
+    Stats *stats = nullptr;     // where this cloud's counters go (nullptr: the calling context's)
 };
 void ransac_detect_prepared(plade_ctx *ctx, RansacWork &W, RansacJob jobs[RANSAC_SLOTS]);
 

@@ -29,7 +29,7 @@
 // whose kernels read what to do from that state (a cloud that has an empty batch or has finished makes its workgroups
 // return at once).  Like the reference's loop, which generates new candidates in every pass before it takes the best
 // one (RansacShapeDetector.cpp:548-617), every iteration draws a round of hypotheses; what the previous batch left of
-// the pool competes with them (RState::topup; PLADE_RANSAC_TOPUP=0 brings back round 2's first scheme -- draw only
+// the pool competes with them (RState::topup; plade_params.ransac_topup = 0 brings back round 2's first scheme -- draw only
 // when the pool is empty, two more launches per iteration -- which needed 7 iterations instead of 5 for a 1M-point pair).
 // The sequence is captured once as a hipGraph and replayed; the host never reads anything back in between -- the
 // `decide` kernel reports the iteration count and the final results through a block of host-mapped memory that the
@@ -152,6 +152,12 @@ struct RCloudArgs {
     const float *sub;                // stratified subset, SoA with pitch sub_pitch
     const uint32_t *sub_index;
     uint32_t sub_pitch, n_sub;
+    // shapeIndex of the subset's points, position for position (the subset is every sub_stride-th point of the Morton order):
+    // kept up to date by k_r_assign, so that the subset scorer reads it with the same coalesced loads as the coordinates
+    // instead of gathering assigned[sub_index[i]] -- a 64-byte line per point, per hypothesis chunk (r3: 184 MB of L2
+    // fetches per registration for a 16 k-point subset).  nullptr (seam S1a: an arbitrary subset): gather.
+    int32_t *sub_assigned;
+    uint32_t sub_stride, pad0_;
     RState *st;
     RResult *res;                    // device address of the host-mapped result block
     float4 *hyp, *hyp_pos;           // R_H hypotheses of the current round
@@ -164,8 +170,10 @@ struct RCloudArgs {
 };
 struct RArgs {
     RCloudArgs c[R_G];
-    uint32_t ng, tiles0;             // clouds in this sequence; tiles of cloud 0 (scan grids are the concatenated tiles)
-    uint32_t topup, pad_;            // host side: the sequence has no separate pass over the old pool (see RState::topup)
+    uint32_t ng, topup;              // clouds in this sequence; topup (host side): the sequence has no separate pass over the
+                                     // old pool (see RState::topup)
+    uint32_t tile_start[R_G + 1];    // scan grids are the concatenated tiles of the clouds: first workgroup of every cloud
+    uint32_t pad_;
 };
 
 // profiled runs: the launch's own (first wavefront in, last wavefront out) times on the device's wall clock.  A launch owns
@@ -231,8 +239,8 @@ ChainLayout make_layout(uint32_t n) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Morton order: 8 bits per axis = the 8 octree levels the sampler draws from; the cloud slot is the top bit of the
-// key so that the clouds of a launch sequence are ordered by ONE sort
+// Morton order: 8 bits per axis = the 8 octree levels the sampler draws from; the cloud slot takes the bits above the
+// code (24, 25) so that the clouds of a launch sequence are ordered by ONE sort
 __device__ __forceinline__ uint32_t spread3(uint32_t v) {  // up to 10 bits -> every third bit
     v = (v | (v << 16)) & 0x030000FF;
     v = (v | (v << 8)) & 0x0300F00F;
@@ -246,14 +254,15 @@ struct MortonIn {
     uint32_t n;
     float mnx, mny, mnz, inv_cube;
 };
-struct MortonArgs { MortonIn c[R_G]; uint32_t ng; };
+struct MortonArgs { MortonIn c[R_G]; uint32_t ng; uint32_t start[R_G + 1]; };   // start: first item of every cloud in the joint arrays
 
 __global__ void k_morton(const MortonArgs A, uint32_t *__restrict__ keys, uint32_t *__restrict__ vals) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t n0 = A.c[0].n;
-    const int g = (A.ng > 1 && t >= n0) ? 1 : 0;
+    int g = 0;
+#pragma unroll
+    for (int q = 1; q < R_G; ++q) g += (q < (int)A.ng && t >= A.start[q]) ? 1 : 0;
     const MortonIn &C = A.c[g];
-    const uint32_t i = t - (g ? n0 : 0);
+    const uint32_t i = t - A.start[g];
     if (i >= C.n) return;
     const uint32_t qx = min(255u, (uint32_t)max(0.f, (C.x[i] - C.mnx) * C.inv_cube * 256.f));
     const uint32_t qy = min(255u, (uint32_t)max(0.f, (C.y[i] - C.mny) * C.inv_cube * 256.f));
@@ -273,16 +282,17 @@ struct GatherOut {
     float *sub; uint32_t sub_pitch, n_sub, stride; uint32_t *sub_index;
     uint32_t n;
 };
-struct GatherArgs { GatherOut c[R_G]; uint32_t ng; };
+struct GatherArgs { GatherOut c[R_G]; uint32_t ng; uint32_t start[R_G + 1]; };
 
 __global__ void k_gather_cloud(const GatherArgs A, const uint32_t *__restrict__ keys, const uint32_t *__restrict__ perm) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t n0 = A.c[0].n;
-    const int g = (A.ng > 1 && t >= n0) ? 1 : 0;
+    int g = 0;
+#pragma unroll
+    for (int q = 1; q < R_G; ++q) g += (q < (int)A.ng && t >= A.start[q]) ? 1 : 0;
     const GatherOut &C = A.c[g];
-    const uint32_t i = t - (g ? n0 : 0);
+    const uint32_t i = t - A.start[g];
     if (i >= C.n) return;
-    const uint32_t src = perm[t] - (g ? n0 : 0);
+    const uint32_t src = perm[t] - A.start[g];
     const float2 *p = reinterpret_cast<const float2 *>(C.aos + 6 * (size_t)src);
     const float2 a = p[0], b = p[1], c = p[2];
     const size_t pitch = C.pitch;
@@ -324,8 +334,10 @@ __device__ __forceinline__ uint32_t lb_u32(const uint32_t *a, uint32_t n, uint32
 
 // which cloud a workgroup of a "concatenated tiles" grid scans
 __device__ __forceinline__ int scan_group(const RArgs &A, uint32_t &tile) {
-    const int g = (A.ng > 1 && blockIdx.x >= A.tiles0) ? 1 : 0;
-    tile = blockIdx.x - (g ? A.tiles0 : 0);
+    int g = 0;
+#pragma unroll
+    for (int q = 1; q < R_G; ++q) g += (q < (int)A.ng && blockIdx.x >= A.tile_start[q]) ? 1 : 0;
+    tile = blockIdx.x - A.tile_start[g];
     return g;
 }
 
@@ -390,6 +402,7 @@ __global__ __launch_bounds__(TPB) void k_r_init(const RArgs A, const RInit I) {
     if (C.assigned) {
         if (base + PPT <= ((C.cv.n + 3) & ~3u)) *reinterpret_cast<int4 *>(C.assigned + base) = make_int4(-1, -1, -1, -1);
     }
+    if (C.sub_assigned && base + PPT <= ((C.n_sub + 3) & ~3u)) *reinterpret_cast<int4 *>(C.sub_assigned + base) = make_int4(-1, -1, -1, -1);
     if (tile == 0 && threadIdx.x == 0) {
         RState *S = C.st;
         S->n = C.cv.n; S->min_support = P.min_support; S->orient = P.orient; S->active = 1; S->gen = P.gen; S->topup = P.topup;
@@ -562,7 +575,8 @@ __global__ __launch_bounds__(TPB) void k_r_score_sub(const RArgs A) {
     const size_t sp = C.sub_pitch;
     const float eps = S->eps, cos_t = S->cos_t;
     Tile t;
-    load_tile(t, C.sub, C.sub + sp, C.sub + 2 * sp, C.sub + 3 * sp, C.sub + 4 * sp, C.sub + 5 * sp, C.assigned, C.sub_index, C.n_sub,
+    load_tile(t, C.sub, C.sub + sp, C.sub + 2 * sp, C.sub + 3 * sp, C.sub + 4 * sp, C.sub + 5 * sp,
+              C.sub_assigned ? C.sub_assigned : C.assigned, C.sub_assigned ? nullptr : C.sub_index, C.n_sub,
               blockIdx.x * TILE + threadIdx.x * PPT);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1231,8 +1245,9 @@ __global__ __launch_bounds__(1024) void k_r_label(const RArgs A, int k, int do_f
 // Sums of FIT_COLS (= 14) columns over the 64 lanes of a wavefront with 16 exchanges instead of 14 x 6 (a 64-bit exchange is
 // two ds_bpermute; the plain butterflies were most of the selection kernel's tail): at every step a lane hands half of the
 // columns it still holds to its partner and adds the partner's contribution to the half it keeps (7 + 4 + 2 + 1 exchanges),
-// the last two steps add up single values.  Lane l ends with the sum of column 7 b5 + 4 b4 + 2 b3 + b2 (bits of l; the four
-// lanes that differ in b1 b0 hold the same value).  Fixed order: deterministic.
+// the last two steps add up single values.  Lane l ends with the sum of column 7 b5 + (4 b4 + 2 b3 + b2) (bits of l; the four
+// lanes that differ in b1 b0 hold the same value) when 4 b4 + 2 b3 + b2 < 7; the lanes with b4 b3 b2 = 111 hold the padding of
+// the 7 -> 4 + 4 split and get col = FIT_COLS (callers store only col < FIT_COLS).  Fixed order: deterministic.
 __device__ __forceinline__ double wave_reduce_cols(const double (&a)[FIT_COLS], int lane, int &col) {
     static_assert(FIT_COLS == 14, "the exchange pattern is written for 14 columns");
     const bool h5 = lane & 32, h4 = lane & 16, h3 = lane & 8, h2 = lane & 4;
@@ -1259,7 +1274,10 @@ __device__ __forceinline__ double wave_reduce_cols(const double (&a)[FIT_COLS], 
     }
     e += __shfl_xor(e, 2, 64);
     e += __shfl_xor(e, 1, 64);
-    col = (h5 ? 7 : 0) + (h4 ? 4 : 0) + (h3 ? 2 : 0) + (h2 ? 1 : 0);
+    // column within the half this lane ended up in; 7 = the zero padding of the second step (b4 b3 b2 = 111), which belongs
+    // to no column: those lanes report FIT_COLS so that no caller stores their 0.0 over a real sum
+    const int local = (h4 ? 4 : 0) + (h3 ? 2 : 0) + (h2 ? 1 : 0);
+    col = local < 7 ? (h5 ? 7 : 0) + local : FIT_COLS;
     return e;
 }
 
@@ -1695,6 +1713,7 @@ __global__ __launch_bounds__(TPB) void k_r_assign(const RArgs A) {
             for (int q = 0; q < 4; ++q)
                 if (mk & (1u << q)) {
                     if (C.assigned) C.assigned[p[q]] = id;
+                    if (C.sub_assigned && p[q] % C.sub_stride == 0 && p[q] / C.sub_stride < C.n_sub) C.sub_assigned[p[q] / C.sub_stride] = id;
                     if (out) {
                         out[off] = (int32_t)(C.orig ? C.orig[p[q]] : p[q]);
                         if (C.out_pos) C.out_pos[out_off + off] = p[q];
@@ -1914,7 +1933,8 @@ struct RansacSlot {
     const CloudDev *cloud = nullptr;
     CloudDev sorted;
     DBuf<uint32_t> codes, orig, sub_index;
-    DBuf<int32_t> assigned, out_idx;
+    DBuf<int32_t> assigned, out_idx, sub_assigned;
+    uint32_t sub_stride = 1;
     DBuf<uint32_t> out_pos;
     DBuf<float> sub;
     uint32_t sub_pitch = 0, n_sub = 0;
@@ -1928,6 +1948,7 @@ struct RansacSlot {
     DBuf<uint32_t> sp_table, cells6;
     char *sp_host = nullptr, *sp_dev = nullptr;   // nq doubles | nq counts | flag
     uint32_t sp_nq = 0, sp_cap = 0;
+    uint64_t sp_epoch = 0;                        // plade_ctx::wait_epoch when the query was queued
     float cube_inv = 0.f, cube = 0.f;             // Morton quantisation of this slot (ransac_prepare)
     ~RansacSlot() { if (res) (void)hipHostFree(res); if (sp_host) (void)hipHostFree(sp_host); }
 };
@@ -1966,7 +1987,7 @@ void slot_buffers(plade_ctx *ctx, RansacSlot &s, uint32_t n) {
     }
 }
 
-RArgs make_args(RansacWork &W, int ng) {
+RArgs make_args(RansacWork &W, int ng, bool topup) {
     RArgs A;
     memset(&A, 0, sizeof(A));
     A.ng = (uint32_t)ng;
@@ -1978,6 +1999,7 @@ RArgs make_args(RansacWork &W, int ng) {
         C.cv.x = c.x(); C.cv.y = c.y(); C.cv.z = c.z(); C.cv.nx = c.nx(); C.cv.ny = c.ny(); C.cv.nz = c.nz(); C.cv.n = s.n;
         C.codes = s.codes.p; C.cells6 = s.cells6.p; C.orig = s.orig.p; C.assigned = s.assigned.p;
         C.sub = s.sub.p; C.sub_index = s.sub_index.p; C.sub_pitch = s.sub_pitch; C.n_sub = s.n_sub;
+        C.sub_assigned = s.sub_assigned.p; C.sub_stride = s.sub_stride;
         C.st = s.state.p; C.res = s.res_dev;
         C.hyp = reinterpret_cast<float4 *>(s.round_block.p);
         C.hyp_pos = C.hyp + R_H;
@@ -1988,9 +2010,8 @@ RArgs make_args(RansacWork &W, int ng) {
         C.list_values = nullptr;
         memcpy(&C.L, &s.L, sizeof(ChainLayout));
     }
-    A.tiles0 = A.c[0].L.nb;
-    static const bool topup = [] { const char *e = getenv("PLADE_RANSAC_TOPUP"); return e ? atoi(e) != 0 : true; }();
-    A.topup = topup ? 1u : 0u;
+    for (int g = 0; g < R_G; ++g) A.tile_start[g + 1] = A.tile_start[g] + (g < ng ? A.c[g].L.nb : 0u);
+    A.topup = topup ? 1u : 0u;   // plade_params.ransac_topup
     return A;
 }
 
@@ -2096,12 +2117,13 @@ void wait_iterations(plade_ctx *ctx, RResult *const *res, int nres, uint32_t wan
         if (ctx->params.host_wait != 0) poll_sleep((int)polls);
     }
     std::atomic_thread_fence(std::memory_order_acquire);
+    ++ctx->wait_epoch;   // everything queued before the reported iteration has finished
 }
 
 }  // namespace
 
 void ransac_prepare(plade_ctx *ctx, RansacWork &W, const CloudDev *const clouds[RANSAC_SLOTS], int n_clouds) {
-    PLADE_REQUIRE(n_clouds >= 1 && n_clouds <= R_G, PLADE_EINVAL, "ransac: one or two clouds");
+    PLADE_REQUIRE(n_clouds >= 1 && n_clouds <= R_G, PLADE_EINVAL, "ransac: one to four clouds");
     W.ng = n_clouds;
     MortonArgs M;
     GatherArgs G;
@@ -2114,6 +2136,7 @@ void ransac_prepare(plade_ctx *ctx, RansacWork &W, const CloudDev *const clouds[
         RansacSlot &s = W.slot[g];
         s.cloud = clouds[g];
         slot_buffers(ctx, s, c.n);
+        M.start[g] = G.start[g] = (uint32_t)total;
         total += c.n;
         const float cube = std::max({c.bbmax[0] - c.bbmin[0], c.bbmax[1] - c.bbmin[1], c.bbmax[2] - c.bbmin[2], 1e-30f});
         M.c[g] = MortonIn{c.x(), c.y(), c.z(), c.n, c.bbmin[0], c.bbmin[1], c.bbmin[2], 1.f / cube};
@@ -2129,15 +2152,18 @@ void ransac_prepare(plade_ctx *ctx, RansacWork &W, const CloudDev *const clouds[
         s.sub_pitch = (s.n_sub + 3) & ~3u;
         s.sub.ensure(6 * (size_t)s.sub_pitch + 4);
         s.sub_index.ensure((size_t)s.sub_pitch + 4);
+        s.sub_assigned.ensure((size_t)s.sub_pitch + 8);
+        s.sub_stride = stride;
         G.c[g] = GatherOut{c.aos.p, s.sorted.soa.p, (uint32_t)c.pitch, s.codes.p, s.orig.p, s.assigned.p, s.sub.p, s.sub_pitch, s.n_sub,
                            stride, s.sub_index.p, c.n};
     }
     PLADE_REQUIRE(total < (1ull << 31), PLADE_ELIMIT, "ransac: too many points");
     if (total == 0) return;
-    if (n_clouds == 1) { M.c[1] = M.c[0]; G.c[1] = G.c[0]; }
+    for (int g = n_clouds; g < R_G; ++g) { M.c[g] = M.c[0]; G.c[g] = G.c[0]; }   // never selected (ng), kept valid
+    for (int g = n_clouds; g <= R_G; ++g) M.start[g] = G.start[g] = (uint32_t)total;
     W.keys_in.ensure(total); W.vals_in.ensure(total); W.keys.ensure(total); W.perm.ensure(total);
     hipLaunchKernelGGL(k_morton, dim3(cdiv(total, 256)), dim3(256), 0, ctx->stream, M, W.keys_in.p, W.vals_in.p);
-    sort_pairs_u32(ctx, W.keys_in.p, W.keys.p, W.vals_in.p, W.perm.p, total, n_clouds > 1 ? 25 : 24);
+    sort_pairs_u32(ctx, W.keys_in.p, W.keys.p, W.vals_in.p, W.perm.p, total, n_clouds > 2 ? 26 : n_clouds > 1 ? 25 : 24);
     hipLaunchKernelGGL(k_gather_cloud, dim3(cdiv(total, 256)), dim3(256), 0, ctx->stream, G, W.keys.p, W.perm.p);
     Cells6Args C6;
     memset(&C6, 0, sizeof(C6));
@@ -2154,7 +2180,7 @@ void ransac_detect_prepared(plade_ctx *ctx, RansacWork &W, RansacJob jobs[RANSAC
     const int ng = W.ng;
     PLADE_REQUIRE(ng >= 1, PLADE_EINVAL, "ransac: not prepared");
     Clock::time_point t0 = Clock::now();
-    RArgs A = make_args(W, ng);
+    RArgs A = make_args(W, ng, ctx->params.ransac_topup != 0);
     RInit I;
     memset(&I, 0, sizeof(I));
     RResult *res[R_G];
@@ -2201,7 +2227,7 @@ void ransac_detect_prepared(plade_ctx *ctx, RansacWork &W, RansacJob jobs[RANSAC
         // profiled run (HIP events around the scan kernels): one iteration at a time; the device-side counters say
         // which clouds each scan launch really served, i.e. its algorithmic bytes (28 B per point and
         // launch + one mask byte per 4 points and chain)
-        uint32_t seen_rescore[R_G][2] = {{0, 0}, {0, 0}}, seen_mark[R_G] = {0, 0}, seen_chains[R_G] = {0, 0};
+        uint32_t seen_rescore[R_G][2] = {}, seen_mark[R_G] = {}, seen_chains[R_G] = {};
         const size_t hdr_bytes = offsetof(RState, acc_coef);
         std::vector<char> hdr(R_G * hdr_bytes);
         for (;; ++iterations) {
@@ -2283,14 +2309,15 @@ void ransac_detect_prepared(plade_ctx *ctx, RansacWork &W, RansacJob jobs[RANSAC
         out.remaining = R.remaining;
         out.n_score_passes = R.n_rescores + R.n_mark_launches;
         out.score_bytes = 28.0 * s.n * (R.n_rescores + R.n_mark_launches) + 0.25 * s.n * R.n_mark_chains;
-        ctx->stats.add("ransac_rounds", R.n_rounds);
-        ctx->stats.add("ransac_accepts", R.n_accepts);
-        ctx->stats.add("ransac_batches", R.n_batches);
-        ctx->stats.add("ransac_rescore_launches", R.n_rescores);
-        ctx->stats.add("ransac_mark_launches", R.n_mark_launches);
-        ctx->stats.add("ransac_deferred_chains", R.n_deferred);
-        for (int q = 0; q < 4; ++q) ctx->stats.add("ransac_final_slot" + std::to_string(q), R.n_final[q]);
-        for (int q = 1; q < 5; ++q) ctx->stats.add("ransac_loop_stops_at" + std::to_string(q), R.n_stop[q]);
+        Stats &jst = J.stats ? *J.stats : ctx->stats;
+        jst.add("ransac_rounds", R.n_rounds);
+        jst.add("ransac_accepts", R.n_accepts);
+        jst.add("ransac_batches", R.n_batches);
+        jst.add("ransac_rescore_launches", R.n_rescores);
+        jst.add("ransac_mark_launches", R.n_mark_launches);
+        jst.add("ransac_deferred_chains", R.n_deferred);
+        for (int q = 0; q < 4; ++q) jst.add("ransac_final_slot" + std::to_string(q), R.n_final[q]);
+        for (int q = 1; q < 5; ++q) jst.add("ransac_loop_stops_at" + std::to_string(q), R.n_stop[q]);
         if (J.rp.host_indices) {
             out.idx.resize(R.out_off);
             if (R.out_off) ctx->d2h(out.idx.data(), s.out_idx.p, 4 * (size_t)R.out_off);
@@ -2332,7 +2359,7 @@ void plane_component(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const
         C.cv = CloudView{cloud.x(), cloud.y(), cloud.z(), cloud.nx(), cloud.ny(), cloud.nz(), n};
         C.st = s.state.p; C.res = s.res_dev; C.out_idx = s.out_idx.p; C.out_pos = nullptr; C.fixed = s.fixed.p; C.var = s.var.p; C.list_values = s.seam_list.p; C.L = s.L;
     }
-    A.tiles0 = s.L.nb;
+    for (int g = 0; g < R_G; ++g) A.tile_start[g + 1] = A.tile_start[g] + (g == 0 ? s.L.nb : 0u);
     // Plane(point, normal): dist = point . normal with Vec3f::dot's left-to-right sum (Plane.cpp:21-26)
     float dist = point[0] * normal[0];
     dist += point[1] * normal[1];
@@ -2401,15 +2428,20 @@ void ransac_spacing_enqueue(plade_ctx *ctx, RansacWork &W, int slot, int k, uint
                        reinterpret_cast<uint32_t *>(s.sp_dev + (size_t)nq * 8), reinterpret_cast<uint32_t *>(s.sp_dev + (size_t)nq * 12));
     HIP_TRY(hipGetLastError());
     s.sp_nq = nq;
+    s.sp_epoch = ctx->wait_epoch;
 }
 
 // after the stream has passed the kernels above (any later sync of it); false: nothing was queued or the cloud is too
 // clumped for the octree cells (the caller falls back to average_spacing_dev's adaptive grid)
-bool ransac_spacing_finish(RansacWork &W, int slot, float *spacing_out) {
+bool ransac_spacing_finish(plade_ctx *ctx, RansacWork &W, int slot, float *spacing_out) {
     RansacSlot &s = W.slot[slot];
     const uint32_t nq = s.sp_nq;
     s.sp_nq = 0;
     if (!nq) return false;
+    // the results sit in host-mapped memory behind two kernels of the context's stream: normally an iteration of the
+    // extraction, queued after them, has reported meanwhile; if no wait has completed since they were queued (a detect
+    // call that had nothing to do), wait here
+    if (s.sp_epoch == ctx->wait_epoch) ctx->sync();
     std::atomic_thread_fence(std::memory_order_acquire);
     const double *avg = reinterpret_cast<const double *>(s.sp_host);
     const uint32_t *nbs = reinterpret_cast<const uint32_t *>(s.sp_host + (size_t)nq * 8);
@@ -2445,7 +2477,7 @@ RArgs seam_args(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const int3
         C.hyp_pos = C.hyp + R_H;
         C.hyp_counts = reinterpret_cast<uint32_t *>(C.hyp_pos + R_H);
     }
-    A.tiles0 = s.L.nb;
+    for (int g = 0; g < R_G; ++g) A.tile_start[g + 1] = A.tile_start[g] + (g == 0 ? s.L.nb : 0u);
     return A;
 }
 }  // namespace

@@ -21,43 +21,46 @@ RansacParams ransac_params(plade_ctx *ctx, uint32_t min_support, bool host_indic
     return rp;  // 0.005f, 0.02f, 0.8f, 0.001f: plade.cpp:607,627
 }
 
-// extract() (code/PLADE/plade.cpp:602-635) of BOTH clouds of a registration: the reference runs it once per cloud; here
-// pass p of the two halving loops is one merged launch sequence (ransac_detect_prepared) in which every cloud that still
-// needs a detect call takes part with its own min_support.  The trace of the auto-tuning loops (plane count of every
-// detect call, the min_support they end at) is left in the stats: tests compare it with the reference loop over
-// libransac (g2_extract.npz).
-void extract_pair(plade_ctx *ctx, const CloudDev *const clouds[2], const int init_min_support[2], bool auto_tune,
-                  PlaneSetOut *const planes[2], bool host_indices) {
+// extract() (code/PLADE/plade.cpp:602-635) of ALL clouds of a call -- the two scans of a registration, or the four of a
+// group of two registrations: the reference runs it once per cloud; here pass p of the halving loops is one merged launch
+// sequence (ransac_detect_prepared) in which every cloud that still needs a detect call takes part with its own
+// min_support.  Cloud g's statistics (the trace of its auto-tuning loop: plane count of every detect call, the min_support
+// it ends at; tests compare it with the reference loop over libransac, g2_extract.npz) go to stat_ctx[g], under tags[g].
+void extract_clouds(plade_ctx *ctx, int n_clouds, const CloudDev *const clouds[], const int init_min_support[], bool auto_tune,
+                    PlaneSetOut *const planes[], plade_ctx *const stat_ctx[], const char *const tags[], bool host_indices) {
     const uint32_t min_num = (uint32_t)ctx->params.min_planes, max_num = (uint32_t)ctx->params.max_planes;
     const int min_allowed_support = 200, max_trials = 10;
     if (!ctx->ransac_work) ctx->ransac_work = ransac_work_create();
     RansacWork &W = *ctx->ransac_work;
-    ransac_prepare(ctx, W, clouds, 2);
-    ransac_spacing_enqueue(ctx, W, 1, 6, 10000);   // average_spacing(source, k = 6) of plade.cpp:41, see ransac.hip
-    int ms[2] = {init_min_support[0], init_min_support[1]}, trials[2] = {0, 0};
-    bool finished[2] = {false, false};
-    const char *tags[2] = {"_tgt", "_src"};
+    ransac_prepare(ctx, W, clouds, n_clouds);
+    for (int g = 1; g < n_clouds; g += 2)
+        ransac_spacing_enqueue(ctx, W, g, 6, 10000);   // average_spacing(source, k = 6) of plade.cpp:41, see ransac.hip
+    int ms[RANSAC_SLOTS], trials[RANSAC_SLOTS];
+    bool finished[RANSAC_SLOTS];
+    for (int g = 0; g < RANSAC_SLOTS; ++g) { ms[g] = g < n_clouds ? init_min_support[g] : 0; trials[g] = 0; finished[g] = g >= n_clouds; }
     for (;;) {
         RansacJob jobs[RANSAC_SLOTS];
         bool any = false;
-        for (int g = 0; g < 2; ++g) {
+        for (int g = 0; g < n_clouds; ++g) {
             jobs[g].active = !finished[g];
             jobs[g].rp = ransac_params(ctx, (uint32_t)ms[g], host_indices);
             jobs[g].out = planes[g];
+            jobs[g].stats = &stat_ctx[g]->stats;
             any = any || jobs[g].active;
         }
         if (!any) break;
         ransac_detect_prepared(ctx, W, jobs);
-        for (int g = 0; g < 2; ++g) {
+        for (int g = 0; g < n_clouds; ++g) {
             if (finished[g]) continue;
             PlaneSetOut &pl = *planes[g];
+            Stats &st = stat_ctx[g]->stats;
             const std::string tag = tags[g];
             ++trials[g];
-            ctx->stats.add("n_detect_calls", 1);
-            ctx->stats.add("n_score_passes", pl.n_score_passes);
-            ctx->stats.add("bytes_ransac", pl.score_bytes);
-            ctx->stats.add("extract_planes_trial" + std::to_string(trials[g]) + tag, pl.P());
-            ctx->stats.add("extract_final_min_support" + tag, ms[g] - ctx_stat(ctx, ("extract_final_min_support" + tag).c_str()));
+            st.add("n_detect_calls", 1);
+            st.add("n_score_passes", pl.n_score_passes);
+            st.add("bytes_ransac", pl.score_bytes);
+            st.add("extract_planes_trial" + std::to_string(trials[g]) + tag, pl.P());
+            st.add("extract_final_min_support" + tag, ms[g] - ctx_stat(stat_ctx[g], ("extract_final_min_support" + tag).c_str()));
             if (!auto_tune) { finished[g] = true; continue; }   // plade.cpp:583-599: one call with the caller's min_support
             if (trials[g] == 1 && pl.P() > max_num) {
                 // top max_num by support.  The reference sorts with a `>=` comparator (plade.cpp:612-615,
@@ -90,45 +93,25 @@ void extract_pair(plade_ctx *ctx, const CloudDev *const clouds[2], const int ini
     }
 }
 
-int register_clouds(plade_ctx *ctx, const CloudDev &tgt, const CloudDev &src, int ms_t, int ms_s, bool auto_tune,
-                    float *T16) {
-    for (int i = 0; i < 16; ++i) T16[i] = (i % 5 == 0) ? 1.f : 0.f;
-    PlaneSetOut tp, sp;
-    float spacing = 0.f;
-    bool have_spacing = false;
-    Clock::time_point t0 = Clock::now();
-    {
-        StageTimer t(ctx, "t_extract");
-        if (!ctx->aux) {
-            plade_ctx *a = nullptr;
-            PLADE_REQUIRE(plade_ctx_create(ctx->device, &a) == PLADE_OK, PLADE_EDEVICE, "cannot create the auxiliary stream");
-            ctx->aux = a;
+// Everything of registration(T, target, source) (plade.cpp:638-662) behind the plane extraction, for ONE pair, on the streams
+// and work areas of `pc` (the pair's context: the calling context, or its peer for the second pair of a group); the planes'
+// device lists and the spacing query live in the work area of `owner`, slots `slot_t` and `slot_t + 1`.
+int register_tail(plade_ctx *pc, plade_ctx *owner, int slot_t, const CloudDev &tgt, const CloudDev &src, PlaneSetOut &tp, PlaneSetOut &sp,
+                  bool auto_tune, bool have_spacing, float spacing, float *T16, Clock::time_point t0) {
+    plade_ctx *ctx = pc;
+    (void)slot_t;
+    if (!have_spacing) { spacing = source_spacing(ctx, *ctx->reg_work, src); have_spacing = true; }   // clumped cloud
+    if (auto_tune) {
+        if (tp.P() < (uint32_t)owner->params.min_planes) {  // plade.cpp:646-650
+            ctx->last_error = "too few planes extracted from the target point cloud";
+            return PLADE_EFAIL;
         }
-        if (!ctx->reg_work) ctx->reg_work = registration_work_create();
-        const CloudDev *clouds[2] = {&tgt, &src};
-        const int init[2] = {auto_tune ? ctx->params.init_min_support : ms_t, auto_tune ? ctx->params.init_min_support : ms_s};
-        PlaneSetOut *outs[2] = {&tp, &sp};
-        // the next stage reads the index lists from the device; the host copy is only for dumps.  The point spacing
-        // (plade.cpp:41) only needs the source cloud: its two kernels are queued right behind the Morton order of the
-        // extraction (extract_pair) and run ahead of the RANSAC iterations on the same stream -- no helper thread
-        extract_pair(ctx, clouds, init, auto_tune, outs, ctx->params.dump != 0);
-        {
-            StageTimer ts(ctx, "t_spacing");
-            have_spacing = ransac_spacing_finish(*ctx->ransac_work, 1, &spacing);
-            if (!have_spacing) { spacing = source_spacing(ctx, *ctx->reg_work, src); have_spacing = true; }   // clumped cloud
+        if (sp.P() < (uint32_t)owner->params.min_planes) {  // plade.cpp:653-657
+            ctx->last_error = "too few planes extracted from the source point cloud";
+            return PLADE_EFAIL;
         }
-        if (auto_tune) {
-            if (tp.P() < (uint32_t)ctx->params.min_planes) {  // plade.cpp:646-650
-                ctx->last_error = "too few planes extracted from the target point cloud";
-                return PLADE_EFAIL;
-            }
-            if (sp.P() < (uint32_t)ctx->params.min_planes) {  // plade.cpp:653-657
-                ctx->last_error = "too few planes extracted from the source point cloud";
-                return PLADE_EFAIL;
-            }
-        }
-        // the device index lists live in the two slots of the work area and stay valid for the next stage
     }
+    // the device index lists live in the slots of the owner's work area and stay valid for the next stage
     if (ctx->params.dump) {
         ctx->put("tgt_planes", tp.coef.data(), tp.coef.size());
         ctx->put("tgt_plane_offsets", tp.offsets.data(), tp.offsets.size());
@@ -154,11 +137,108 @@ int register_clouds(plade_ctx *ctx, const CloudDev &tgt, const CloudDev &src, in
     }
     const bool ok = run_registration(ctx, *ctx->reg_work, tgt, src, tv, sv, T16, have_spacing ? &spacing : nullptr);
     ctx->stats.add("t_registration", secs_since(t0));
-    // roofline bookkeeping; bytes_ransac was summed per scan launch and cloud by extract_pair
+    // roofline bookkeeping; bytes_ransac was summed per scan launch and cloud by extract_clouds
     ctx->stats.add("bytes_voxel", 12.0 * ((double)tgt.n + src.n));
     ctx->ev_collect();
     if (!ok) { if (ctx->last_error.empty()) ctx->last_error = "registration failed: no matched result found"; return PLADE_EFAIL; }
     return PLADE_OK;
+}
+
+void ensure_pair_areas(plade_ctx *ctx) {
+    if (!ctx->aux) {
+        plade_ctx *a = nullptr;
+        PLADE_REQUIRE(plade_ctx_create(ctx->device, &a) == PLADE_OK, PLADE_EDEVICE, "cannot create the auxiliary stream");
+        ctx->aux = a;
+    }
+    if (!ctx->reg_work) ctx->reg_work = registration_work_create();
+}
+
+// `count` (1 or 2) registrations as ONE group: the plane extraction of all their clouds is one launch sequence on the calling
+// context's stream (two pairs = four clouds per kernel: the extraction is a chain of ~150 short, latency-bound kernels whose
+// duration hardly grows with twice the workgroups, so a group halves its commands, host waits and GPU time per registration);
+// behind it every pair runs the rest of its registration on its own context (pair 0: the calling one on the calling thread,
+// pair 1: the peer context on a helper thread), concurrently.  status[i]: PLADE_OK / PLADE_EFAIL / an error code.
+void register_group(plade_ctx *ctx, int count, const CloudDev *const tgt[], const CloudDev *const src[], const int ms_t[], const int ms_s[],
+                    bool auto_tune, float *T16, int32_t *status) {
+    PLADE_REQUIRE(count >= 1 && count <= PLADE_GROUP_MAX, PLADE_EINVAL, "a group holds one or two pairs");
+    Clock::time_point t0 = Clock::now();
+    plade_ctx *pcs[PLADE_GROUP_MAX] = {ctx, nullptr};
+    if (count > 1) {
+        if (!ctx->peer) {
+            plade_ctx *a = nullptr;
+            PLADE_REQUIRE(plade_ctx_create(ctx->device, &a) == PLADE_OK, PLADE_EDEVICE, "cannot create the second pair's context");
+            ctx->peer = a;
+        }
+        pcs[1] = ctx->peer;
+        pcs[1]->params = ctx->params;
+        pcs[1]->stats.clear();
+        pcs[1]->dump.clear();
+        pcs[1]->last_error.clear();
+        pcs[1]->drop_reads();
+    }
+    for (int i = 0; i < count; ++i) {
+        ensure_pair_areas(pcs[i]);
+        for (int k = 0; k < 16; ++k) T16[16 * i + k] = (k % 5 == 0) ? 1.f : 0.f;
+        status[i] = PLADE_OK;
+    }
+    PlaneSetOut planes[2 * PLADE_GROUP_MAX];
+    float spacing[PLADE_GROUP_MAX] = {0.f, 0.f};
+    bool have_spacing[PLADE_GROUP_MAX] = {false, false};
+    {
+        StageTimer t(ctx, "t_extract");
+        const CloudDev *clouds[2 * PLADE_GROUP_MAX];
+        int init[2 * PLADE_GROUP_MAX];
+        PlaneSetOut *outs[2 * PLADE_GROUP_MAX];
+        plade_ctx *stat_ctx[2 * PLADE_GROUP_MAX];
+        static const char *const tags[2 * PLADE_GROUP_MAX] = {"_tgt", "_src", "_tgt", "_src"};
+        for (int i = 0; i < count; ++i) {
+            clouds[2 * i] = tgt[i]; clouds[2 * i + 1] = src[i];
+            init[2 * i] = auto_tune ? ctx->params.init_min_support : ms_t[i];
+            init[2 * i + 1] = auto_tune ? ctx->params.init_min_support : ms_s[i];
+            outs[2 * i] = &planes[2 * i]; outs[2 * i + 1] = &planes[2 * i + 1];
+            stat_ctx[2 * i] = stat_ctx[2 * i + 1] = pcs[i];
+        }
+        // the next stage reads the index lists from the device; the host copy is only for dumps.  The point spacing
+        // (plade.cpp:41) only needs the source cloud: its two kernels are queued right behind the Morton order of the
+        // extraction and run ahead of the RANSAC iterations on the same stream -- no helper thread
+        extract_clouds(ctx, 2 * count, clouds, init, auto_tune, outs, stat_ctx, tags, ctx->params.dump != 0);
+        StageTimer ts(ctx, "t_spacing");
+        for (int i = 0; i < count; ++i) have_spacing[i] = ransac_spacing_finish(ctx, *ctx->ransac_work, 2 * i + 1, &spacing[i]);
+    }
+    if (count == 1) {
+        status[0] = register_tail(ctx, ctx, 0, *tgt[0], *src[0], planes[0], planes[1], auto_tune, have_spacing[0], spacing[0], T16, t0);
+        return;
+    }
+    // The second pair's streams read what the extraction wrote on this context's stream (support lists, the Morton-ordered
+    // copy), and the extraction's host loop returns as soon as the device reports through host-mapped memory, with the last
+    // kernels possibly still running: the peer's stream waits for this one.
+    if (!ctx->ev_group) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_group, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(ctx->ev_group, ctx->stream));
+    HIP_TRY(hipStreamWaitEvent(pcs[1]->stream, ctx->ev_group, 0));
+    Err peer_err{0, ""};
+    std::thread th([&]() {
+        const double cpu0 = thread_cpu_seconds();
+        (void)hipSetDevice(ctx->device);
+        try {
+            status[1] = register_tail(pcs[1], ctx, 2, *tgt[1], *src[1], planes[2], planes[3], auto_tune, have_spacing[1], spacing[1], T16 + 16, t0);
+        } catch (const Err &e) { peer_err = e; }
+        catch (const std::exception &e) { peer_err = Err{PLADE_EDEVICE, e.what()}; }
+        pcs[1]->stats.add("cpu_pair_thread", thread_cpu_seconds() - cpu0);
+    });
+    Err main_err{0, ""};
+    try { status[0] = register_tail(ctx, ctx, 0, *tgt[0], *src[0], planes[0], planes[1], auto_tune, have_spacing[0], spacing[0], T16, t0); }
+    catch (const Err &e) { main_err = e; }
+    catch (const std::exception &e) { main_err = Err{PLADE_EDEVICE, e.what()}; }
+    th.join();
+    if (peer_err.code) { pcs[1]->drop_reads(); pcs[1]->last_error = peer_err.msg; status[1] = peer_err.code; }
+    if (main_err.code) { ctx->drop_reads(); ctx->last_error = main_err.msg; status[0] = main_err.code; }
+}
+
+int register_clouds(plade_ctx *ctx, const CloudDev &tgt, const CloudDev &src, int ms_t, int ms_s, bool auto_tune, float *T16) {
+    const CloudDev *t[1] = {&tgt}, *s[1] = {&src};
+    int32_t status[1] = {PLADE_OK};
+    register_group(ctx, 1, t, s, &ms_t, &ms_s, auto_tune, T16, status);
+    return status[0];
 }
 
 }  // namespace
@@ -285,6 +365,7 @@ extern "C" int plade_registration_dev(plade_ctx *ctx, plade_cloud *tgt, plade_cl
         ctx->stats.clear();
         ctx->dump.clear();
         ctx->last_error.clear();
+        cloud_drop_prefetch(ctx);
         return register_clouds(ctx, tgt->dev, src->dev, 0, 0, true, T16);
     });
 }
@@ -296,6 +377,7 @@ extern "C" int plade_registration(plade_ctx *ctx, const float *tgt_pos_nrm, uint
         ctx->stats.clear();
         ctx->dump.clear();
         ctx->last_error.clear();
+        cloud_drop_prefetch(ctx);
         CloudDev &tgt = ctx->up_tgt, &src = ctx->up_src;
         {
             StageTimer t(ctx, "t_upload");
@@ -305,6 +387,43 @@ extern "C" int plade_registration(plade_ctx *ctx, const float *tgt_pos_nrm, uint
     });
 }
 
+namespace {
+// Batch mode: the clouds of THIS call (taken over from the prefetch of the previous call when they are the announced ones),
+// then the upload of the NEXT call's clouds started on the prefetch stream; then the group is registered.
+int registration_batch(plade_ctx *ctx, uint32_t count, const float *const *tgt, const uint32_t *n_t, const float *const *src,
+                       const uint32_t *n_s, uint32_t next_count, const float *const *next_tgt, const uint32_t *next_n_t,
+                       const float *const *next_src, const uint32_t *next_n_s, float *T16, int32_t *status) {
+    ctx->stats.clear();
+    ctx->dump.clear();
+    ctx->last_error.clear();
+    if (count > 1 && !ctx->peer) {
+        plade_ctx *a = nullptr;
+        PLADE_REQUIRE(plade_ctx_create(ctx->device, &a) == PLADE_OK, PLADE_EDEVICE, "cannot create the second pair's context");
+        ctx->peer = a;
+    }
+    const float *ptr[4], *nptr[4];
+    uint32_t n[4], nn[4];
+    CloudDev *out[4] = {&ctx->up_tgt, &ctx->up_src, count > 1 ? &ctx->peer->up_tgt : nullptr, count > 1 ? &ctx->peer->up_src : nullptr};
+    for (uint32_t i = 0; i < count; ++i) { ptr[2 * i] = tgt[i]; ptr[2 * i + 1] = src[i]; n[2 * i] = n_t[i]; n[2 * i + 1] = n_s[i]; }
+    for (uint32_t i = 0; i < next_count; ++i) { nptr[2 * i] = next_tgt[i]; nptr[2 * i + 1] = next_src[i]; nn[2 * i] = next_n_t[i]; nn[2 * i + 1] = next_n_s[i]; }
+    {
+        StageTimer t(ctx, "t_upload");
+        Clock::time_point t0 = Clock::now();
+        if (!cloud_take_prefetched(ctx, 2 * (int)count, ptr, n, out)) cloud_upload_many(ctx, 2 * (int)count, ptr, n, out);
+        else ctx->stats.add("upload_prefetched", 1);
+        ctx->stats.add("t_upload_take", secs_since(t0));
+        t0 = Clock::now();
+        if (next_count) cloud_prefetch(ctx, 2 * (int)next_count, nptr, nn);
+        ctx->stats.add("t_upload_submit", secs_since(t0));
+    }
+    const CloudDev *ct[PLADE_GROUP_MAX] = {&ctx->up_tgt, count > 1 ? &ctx->peer->up_tgt : nullptr};
+    const CloudDev *cs[PLADE_GROUP_MAX] = {&ctx->up_src, count > 1 ? &ctx->peer->up_src : nullptr};
+    const int zero[PLADE_GROUP_MAX] = {0, 0};
+    register_group(ctx, (int)count, ct, cs, zero, zero, true, T16, status);
+    return PLADE_OK;
+}
+}  // namespace
+
 // Batch mode (code/PLADE/main.cpp:97-158 is a loop over pairs): plade_registration of THIS pair, with the upload of the
 // NEXT pair started first on the prefetch stream, so that its PCIe transfer runs under this pair's kernels.
 extern "C" int plade_registration_next(plade_ctx *ctx, const float *tgt_pos_nrm, uint32_t n_t, const float *src_pos_nrm,
@@ -312,24 +431,56 @@ extern "C" int plade_registration_next(plade_ctx *ctx, const float *tgt_pos_nrm,
                                        const float *next_src_pos_nrm, uint32_t next_n_s, float *T16) {
     return guarded(ctx, [&]() -> int {
         PLADE_REQUIRE(tgt_pos_nrm && src_pos_nrm && T16 && n_t && n_s, PLADE_EINVAL, "plade_registration_next: bad argument");
+        const bool have_next = next_tgt_pos_nrm && next_src_pos_nrm && next_n_t && next_n_s;
+        int32_t status = PLADE_OK;
+        registration_batch(ctx, 1, &tgt_pos_nrm, &n_t, &src_pos_nrm, &n_s, have_next ? 1u : 0u, &next_tgt_pos_nrm, &next_n_t,
+                           &next_src_pos_nrm, &next_n_s, T16, &status);
+        return status;
+    });
+}
+
+// Batch mode, `count` (<= PLADE_GROUP_MAX) pairs of the list per call: see include/plade_hip.h.
+extern "C" int plade_registration_pairs(plade_ctx *ctx, uint32_t count, const float *const *tgt_pos_nrm, const uint32_t *n_t,
+                                        const float *const *src_pos_nrm, const uint32_t *n_s, uint32_t next_count,
+                                        const float *const *next_tgt_pos_nrm, const uint32_t *next_n_t,
+                                        const float *const *next_src_pos_nrm, const uint32_t *next_n_s, float *T16, int32_t *status) {
+    return guarded(ctx, [&]() -> int {
+        PLADE_REQUIRE(count >= 1 && count <= PLADE_GROUP_MAX && tgt_pos_nrm && src_pos_nrm && n_t && n_s && T16 && status, PLADE_EINVAL,
+                      "plade_registration_pairs: bad argument");
+        for (uint32_t i = 0; i < count; ++i)
+            PLADE_REQUIRE(tgt_pos_nrm[i] && src_pos_nrm[i] && n_t[i] && n_s[i], PLADE_EINVAL, "plade_registration_pairs: empty cloud");
+        if (next_count > PLADE_GROUP_MAX || !next_tgt_pos_nrm || !next_src_pos_nrm || !next_n_t || !next_n_s) next_count = 0;
+        for (uint32_t i = 0; i < next_count; ++i)
+            if (!next_tgt_pos_nrm[i] || !next_src_pos_nrm[i] || !next_n_t[i] || !next_n_s[i]) next_count = 0;
+        return registration_batch(ctx, count, tgt_pos_nrm, n_t, src_pos_nrm, n_s, next_count, next_tgt_pos_nrm, next_n_t, next_src_pos_nrm,
+                                  next_n_s, T16, status);
+    });
+}
+
+extern "C" int plade_registration_pairs_dev(plade_ctx *ctx, uint32_t count, plade_cloud *const *tgt, plade_cloud *const *src, float *T16,
+                                            int32_t *status) {
+    return guarded(ctx, [&]() -> int {
+        PLADE_REQUIRE(count >= 1 && count <= PLADE_GROUP_MAX && tgt && src && T16 && status, PLADE_EINVAL, "plade_registration_pairs_dev: bad argument");
+        const CloudDev *ct[PLADE_GROUP_MAX] = {nullptr, nullptr}, *cs[PLADE_GROUP_MAX] = {nullptr, nullptr};
+        for (uint32_t i = 0; i < count; ++i) {
+            PLADE_REQUIRE(tgt[i] && src[i], PLADE_EINVAL, "plade_registration_pairs_dev: null cloud");
+            ct[i] = &tgt[i]->dev; cs[i] = &src[i]->dev;
+        }
         ctx->stats.clear();
         ctx->dump.clear();
         ctx->last_error.clear();
-        CloudDev &tgt = ctx->up_tgt, &src = ctx->up_src;
-        {
-            StageTimer t(ctx, "t_upload");
-            Clock::time_point t0 = Clock::now();
-            if (!cloud_take_prefetched(ctx, tgt_pos_nrm, n_t, src_pos_nrm, n_s)) {
-                cloud_upload_pair(ctx, tgt_pos_nrm, n_t, tgt, src_pos_nrm, n_s, src);
-            } else ctx->stats.add("upload_prefetched", 1);
-            ctx->stats.add("t_upload_take", secs_since(t0));
-            t0 = Clock::now();
-            if (next_tgt_pos_nrm && next_src_pos_nrm && next_n_t && next_n_s)
-                cloud_prefetch_pair(ctx, next_tgt_pos_nrm, next_n_t, next_src_pos_nrm, next_n_s);
-            ctx->stats.add("t_upload_submit", secs_since(t0));
-        }
-        return register_clouds(ctx, tgt, src, 0, 0, true, T16);
+        cloud_drop_prefetch(ctx);
+        const int zero[PLADE_GROUP_MAX] = {0, 0};
+        register_group(ctx, (int)count, ct, cs, zero, zero, true, T16, status);
+        return PLADE_OK;
     });
+}
+
+// The context that carried pair `index` of the last group call (0: ctx itself): its stats, dump and last error are read with
+// the ordinary entry points.  Borrowed: it lives and dies with ctx.
+extern "C" plade_ctx *plade_pair_ctx(plade_ctx *ctx, uint32_t index) {
+    if (!ctx) return nullptr;
+    return index == 0 ? ctx : (index == 1 ? ctx->peer : nullptr);
 }
 
 extern "C" int plade_registration_minsupport(plade_ctx *ctx, const float *tgt_pos_nrm, uint32_t n_t,
@@ -341,6 +492,7 @@ extern "C" int plade_registration_minsupport(plade_ctx *ctx, const float *tgt_po
         ctx->stats.clear();
         ctx->dump.clear();
         ctx->last_error.clear();
+        cloud_drop_prefetch(ctx);
         CloudDev &tgt = ctx->up_tgt, &src = ctx->up_src;
         cloud_upload_pair(ctx, tgt_pos_nrm, n_t, tgt, src_pos_nrm, n_s, src);
         return register_clouds(ctx, tgt, src, min_support_t, min_support_s, false, T16);

@@ -1,0 +1,132 @@
+"""Groups of two registrations per launch sequence (plade_registration_pairs / _dev, batch mode of
+code/PLADE/main.cpp:122-148 taken two pairs at a time): every pair of a group must come out bit for bit as the same
+pair registered alone -- extracted planes, every dumped intermediate of the registration, the final transform -- whatever
+its partner is, in either position of the group, through host pointers (with and without the prefetch of the next group)
+and on resident clouds."""
+import numpy as np
+import pytest
+
+import plade_amd
+from plade_amd.synth import make_pair
+
+pytestmark = pytest.mark.gpu
+
+PLANE_KEYS = ["tgt_planes", "tgt_plane_offsets", "tgt_plane_idx", "src_planes", "src_plane_offsets", "src_plane_idx"]
+STAGE_KEYS = ["average_spacing", "tgt_ds", "src_ds", "tgt_plane_ds", "src_plane_ds", "tgt_desc", "src_desc", "match_nbr", "match_dist2",
+              "initial_RT", "cluster_sizes", "cluster_seeds", "plane_match_counts", "pen_tested", "pen_flags", "candidates",
+              "overlap_counts", "scores", "best_index"]
+
+
+@pytest.fixture(scope="module")
+def scenes():
+    out = []
+    for n, seed in ((200000, 3), (120000, 7), (200000, 11)):
+        tg, sr, Tgt = make_pair(n, seed=seed)
+        out.append((np.ascontiguousarray(tg, np.float32), np.ascontiguousarray(sr, np.float32), Tgt))
+    return out
+
+
+@pytest.fixture(scope="module")
+def alone(scenes):
+    """every pair registered alone, with all intermediates"""
+    c = plade_amd.Context(0, orient_normals=1, dump=1)
+    out = []
+    for tg, sr, _ in scenes:
+        ok, T = c.registration(tg, sr)
+        out.append((ok, T, c.dump(), c.stats()))
+    c.close()
+    return out
+
+
+def _same(d, ref, keys):
+    for k in keys:
+        assert k in d and k in ref, k
+        assert d[k].shape == ref[k].shape and np.array_equal(d[k], ref[k]), k
+
+
+@pytest.mark.parametrize("a,b", [(0, 1), (1, 0), (2, 2), (0, 2)])
+def test_group_of_two_equals_the_pairs_alone(scenes, alone, a, b):
+    c = plade_amd.Context(0, orient_normals=1, dump=1)
+    res = c.registration_pairs([(scenes[a][0], scenes[a][1]), (scenes[b][0], scenes[b][1])])
+    for pos, i in enumerate((a, b)):
+        ok, T = res[pos]
+        assert ok == alone[i][0] and ok
+        assert np.array_equal(T, alone[i][1])
+        d = c.dump(pair=pos)
+        _same(d, alone[i][2], PLANE_KEYS + STAGE_KEYS)
+        assert np.linalg.norm(T.astype(np.float64) - scenes[i][2]) < 5e-2
+        st = c.stats(pair=pos)
+        for k in ("n_planes_tgt", "n_planes_src", "n_matches", "n_clusters", "n_candidates_verified", "extract_planes_trial1_tgt",
+                  "extract_planes_trial1_src", "extract_final_min_support_tgt", "extract_final_min_support_src"):
+            assert st[k] == alone[i][3][k], (k, st[k], alone[i][3][k])
+    c.close()
+
+
+def test_group_of_one_is_the_plain_call(scenes, alone):
+    c = plade_amd.Context(0, orient_normals=1)
+    (ok, T), = c.registration_pairs([(scenes[1][0], scenes[1][1])])
+    assert ok and np.array_equal(T, alone[1][1])
+    ct, cs = c.upload(scenes[1][0]), c.upload(scenes[1][1])
+    (ok2, T2), = c.registration_pairs_dev([(ct, cs)])
+    assert ok2 and np.array_equal(T2, alone[1][1])
+    ct.free(); cs.free()
+    c.close()
+
+
+def test_groups_in_batch_mode_with_prefetch_and_on_resident_clouds(scenes, alone):
+    """A list of five pairs taken two at a time, the next group announced to every call (its upload runs under the current
+    group's kernels), the last group a single pair; then the same groups on resident clouds."""
+    order = [0, 1, 2, 1, 0]
+    c = plade_amd.Context(0, orient_normals=1, host_wait=1)
+    for tg, sr, _ in scenes:
+        c.pin(tg); c.pin(sr)
+    groups = [order[i:i + 2] for i in range(0, len(order), 2)]
+    got = []
+    for gi, g in enumerate(groups):
+        nxt = [(scenes[i][0], scenes[i][1]) for i in groups[gi + 1]] if gi + 1 < len(groups) else None
+        got += c.registration_pairs([(scenes[i][0], scenes[i][1]) for i in g], nxt)
+        if gi > 0:
+            assert c.stats().get("upload_prefetched", 0) == 1
+    for (ok, T), i in zip(got, order):
+        assert ok and np.array_equal(T, alone[i][1])
+    # a call that is handed other clouds than the announced ones uploads them itself
+    c.registration_pairs([(scenes[0][0], scenes[0][1])], [(scenes[1][0], scenes[1][1]), (scenes[2][0], scenes[2][1])])
+    (ok, T), = c.registration_pairs([(scenes[2][0], scenes[2][1])])
+    assert ok and np.array_equal(T, alone[2][1]) and c.stats().get("upload_prefetched", 0) == 0
+    for tg, sr, _ in scenes:
+        c.unpin(tg); c.unpin(sr)
+    res = [(c.upload(tg), c.upload(sr)) for tg, sr, _ in scenes]
+    for g in groups:
+        for (ok, T), i in zip(c.registration_pairs_dev([res[i] for i in g]), g):
+            assert ok and np.array_equal(T, alone[i][1])
+    for ct, cs in res:
+        ct.free(); cs.free()
+    c.close()
+
+
+def test_a_failing_pair_does_not_touch_its_partner(scenes, alone):
+    """One pair of the group cannot be registered (a cloud without planes: the reference returns false after its halving
+    loop, plade.cpp:646-657): its status says so, its transform is the identity, its partner's result is untouched --
+    in both positions."""
+    rng = np.random.default_rng(5)
+    blob = np.concatenate([rng.normal(0, 1, (50000, 3)), rng.normal(0, 1, (50000, 3))], 1).astype(np.float32)
+    blob[:, 3:] /= np.linalg.norm(blob[:, 3:], axis=1, keepdims=True)
+    c = plade_amd.Context(0, orient_normals=1)
+    for pos in (0, 1):
+        prs = [(scenes[1][0], scenes[1][1]), (scenes[1][0], scenes[1][1])]
+        prs[pos] = (blob, blob)
+        res = c.registration_pairs(prs)
+        assert not res[pos][0] and np.array_equal(res[pos][1], np.eye(4, dtype=np.float32))
+        assert "too few planes" in c.pair_error(pos)
+        assert res[1 - pos][0] and np.array_equal(res[1 - pos][1], alone[1][1])
+    c.close()
+
+
+def test_bad_group_arguments_are_refused(scenes):
+    c = plade_amd.Context(0, orient_normals=1)
+    pr = (scenes[1][0], scenes[1][1])
+    with pytest.raises(plade_amd.PladeError):
+        c.registration_pairs([pr, pr, pr])
+    with pytest.raises(plade_amd.PladeError):
+        c.registration_pairs([])
+    c.close()

@@ -7,6 +7,7 @@ the planes the GPU extracted must give the same transform."""
 import numpy as np
 import pytest
 
+import plade_amd
 from plade_amd.synth import make_pair, sample_scene, planes_from_labels
 
 pytestmark = pytest.mark.gpu
@@ -110,39 +111,25 @@ def test_registration_dev_equals_host_pointer_path():
 
 def test_both_hypothesis_schedules_register_the_same_pairs():
     """The extraction draws a round of hypotheses in every iteration (what is left of the candidate pool competes with
-    the new draws, as in the reference's loop, RansacShapeDetector.cpp:548-617); PLADE_RANSAC_TOPUP=0 draws only when the
-    pool is empty (two more launches per iteration, more iterations).  Both are the same search with the same
+    the new draws, as in the reference's loop, RansacShapeDetector.cpp:548-617); plade_params.ransac_topup = 0 draws only
+    when the pool is empty (two more launches per iteration, more iterations).  Both are the same search with the same
     acceptance semantics: the same large planes with (nearly) the same supports, and the same registration up to the
-    noise of which small faces were found.  The switch is read once per process, hence the child processes."""
-    import json
-    import os
-    import subprocess
-    import sys
-    child = r"""
-import json, sys
-import numpy as np
-import plade_amd
-from plade_amd.synth import make_pair
-out = {}
-ctx = plade_amd.Context(0, orient_normals=1)
-for seed in (3, 7):
-    tg, sr, Tgt = make_pair(200000, seed=seed)
-    co, off, idx = ctx.extract_planes(tg, 2000)
-    ok, T = ctx.registration(tg, sr)
-    st = ctx.stats()
-    out[str(seed)] = {"supports": sorted((int(b - a) for a, b in zip(off[:-1], off[1:])), reverse=True), "ok": bool(ok),
-                      "err": float(np.linalg.norm(T - Tgt)), "iterations": int(st["ransac_iterations"])}
-print(json.dumps(out))
-"""
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    noise of which small faces were found.  The switch is a parameter of the context: both schedules run in this process."""
     res = {}
-    for mode in ("1", "0"):
-        env = dict(os.environ, PLADE_RANSAC_TOPUP=mode, PYTHONPATH=root)
-        r = subprocess.run([sys.executable, "-c", child], capture_output=True, text=True, env=env, cwd=root, timeout=300)
-        assert r.returncode == 0, r.stderr[-2000:]
-        res[mode] = json.loads(r.stdout.strip().splitlines()[-1])
-    for seed in res["1"]:
-        a, b = res["1"][seed], res["0"][seed]
+    for mode in (1, 0):
+        ctx = plade_amd.Context(0, orient_normals=1, ransac_topup=mode)
+        out = {}
+        for seed in (3, 7):
+            tg, sr, Tgt = make_pair(200000, seed=seed)
+            co, off, idx = ctx.extract_planes(tg, 2000)
+            ok, T = ctx.registration(tg, sr)
+            st = ctx.stats()
+            out[seed] = {"supports": sorted((int(b - a) for a, b in zip(off[:-1], off[1:])), reverse=True), "ok": bool(ok),
+                         "err": float(np.linalg.norm(T - Tgt)), "iterations": int(st["ransac_iterations"])}
+        ctx.close()
+        res[mode] = out
+    for seed in res[1]:
+        a, b = res[1][seed], res[0][seed]
         assert a["ok"] and b["ok"] and a["err"] < 5e-2 and b["err"] < 5e-2, (seed, a["err"], b["err"])
         # the six largest planes (walls, floor, ceiling) are the same surfaces with the same supports to a fraction of a percent
         for x, y in zip(a["supports"][:6], b["supports"][:6]):

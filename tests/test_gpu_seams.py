@@ -161,7 +161,7 @@ def test_voxel_downsample_bit_exact(ctx, oracle, n, leaf):
     assert faithful.shape == got.shape and np.abs(faithful - got).max() <= 1e-5
 
 
-def test_match_windowed_equals_brute_force(oracle, monkeypatch):
+def test_match_windowed_equals_brute_force(oracle):
     """The length-windowed enumeration used for large descriptor tables (k_match.hip) returns exactly what the
     brute-force kernel returns: same lists, same order, same fp64 distances."""
     import plade_amd
@@ -171,25 +171,21 @@ def test_match_windowed_equals_brute_force(oracle, monkeypatch):
     q[:50] = t[:50]                        # exact hits
     t[100:150] = t[0:50]                   # duplicated targets: distance ties broken by target index
     out = {}
-    for mode in ("-1", "1"):
-        monkeypatch.setenv("PLADE_MATCH_WINDOW", mode)
-        c = plade_amd.Context(0)
+    for mode in (-1, 1):
+        c = plade_amd.Context(0, match_window=mode)
         out[mode] = c.match_descriptors(q, t, 0.04)
         c.close()
-    for a, b in zip(out["-1"], out["1"]):
+    for a, b in zip(out[-1], out[1]):
         assert np.array_equal(a, b)
-    assert len(out["1"][1]) > 4000
+    assert len(out[1][1]) > 4000
     # the same in slabs of a few hundred sorted queries (large tables: the (query, chunk) cells are laid out slab by slab)
-    monkeypatch.setenv("PLADE_MATCH_WINDOW", "1")
-    monkeypatch.setenv("PLADE_MATCH_CELL_BUDGET", "4096")
-    c = plade_amd.Context(0)
+    c = plade_amd.Context(0, match_window=1, match_cell_budget=4096)
     slabbed = c.match_descriptors(q, t, 0.04)
     c.close()
-    monkeypatch.delenv("PLADE_MATCH_CELL_BUDGET")
-    for a, b in zip(out["-1"], slabbed):
+    for a, b in zip(out[-1], slabbed):
         assert np.array_equal(a, b)
     o, n, d = oracle.match_descriptors(q[:300], t, 0.04)
-    assert np.array_equal(n, out["1"][1][: len(n)]) and np.array_equal(d, out["1"][2][: len(d)])
+    assert np.array_equal(n, out[1][1][: len(n)]) and np.array_equal(d, out[1][2][: len(d)])
 
 
 @pytest.mark.parametrize("dtype,bits", [(np.uint32, 24), (np.uint32, 32), (np.uint32, 9), (np.uint64, 30), (np.uint64, 47),
