@@ -23,7 +23,7 @@ extern "C" {
 #define PLADE_EFAIL (-4)    /* registration failed (reference returns false) */
 #define PLADE_ELIMIT (-5)   /* internal limit exceeded */
 
-#define PLADE_GROUP_MAX 2   /* pairs per group of plade_registration_pairs */
+#define PLADE_GROUP_MAX 4   /* pairs per group of plade_registration_pairs */
 
 typedef struct plade_ctx plade_ctx;
 typedef struct plade_cloud plade_cloud; /* device-resident oriented point cloud */
@@ -195,9 +195,9 @@ int plade_registration_next(plade_ctx *ctx, const float *tgt_pos_nrm, uint32_t n
 /* Batch mode, `count` (1..PLADE_GROUP_MAX) consecutive pairs of the list per call (the loop of code/PLADE/main.cpp:122-148
  * taken two pairs at a time).  Every pair is registered exactly like plade_registration -- results are bit-identical to
  * registering it alone -- but the plane extraction of all clouds of the group (PlaneExtraction::detect x 4) is ONE launch
- * sequence: its ~150 kernels per cloud pair are short and latency-bound, and carrying two pairs per launch halves the
- * commands, host waits and GPU time per registration; behind the extraction the pairs proceed concurrently, pair 1 on an
- * internal peer context (plade_pair_ctx).  tgt_pos_nrm / src_pos_nrm: count pointers to N x 6 arrays, n_t / n_s their point
+ * sequence: its ~150 kernels per cloud pair are short and mostly latency-bound, and carrying the clouds of 2-4 pairs per launch
+ * divides the commands, host waits and much of the GPU time per registration; behind the extraction the pairs proceed
+ * concurrently, pairs 1.. on internal peer contexts (plade_pair_ctx).  tgt_pos_nrm / src_pos_nrm: count pointers to N x 6 arrays, n_t / n_s their point
  * counts; next_*: the clouds the NEXT call on this ctx will be handed (next_count = 0: none), prefetched as
  * plade_registration_next does.  T16: count x 16 (identity where a pair fails); status[i]: PLADE_OK, PLADE_EFAIL (the
  * reference returns false) or another PLADE_E* code for pair i.  The return value reports errors that concern the whole
@@ -206,8 +206,8 @@ int plade_registration_pairs(plade_ctx *ctx, uint32_t count, const float *const 
                              const float *const *src_pos_nrm, const uint32_t *n_s, uint32_t next_count,
                              const float *const *next_tgt_pos_nrm, const uint32_t *next_n_t,
                              const float *const *next_src_pos_nrm, const uint32_t *next_n_s, float *T16, int32_t *status);
-/* The context that carried pair `index` of the last plade_registration_pairs* call on ctx (0: ctx itself; 1: its peer, NULL
- * before the first two-pair call): stats, dump and last error of that pair are read from it with the entry points below.
+/* The context that carried pair `index` of the last plade_registration_pairs* call on ctx (0: ctx itself; 1..: its peers, NULL
+ * before the first call with that many pairs): stats, dump and last error of that pair are read from it with the entry points below.
  * Borrowed -- it is destroyed with ctx; do not register on it. */
 plade_ctx *plade_pair_ctx(plade_ctx *ctx, uint32_t index);
 /* plade.h:91-96  registration(T, target, source, min_support_target, min_support_source) */

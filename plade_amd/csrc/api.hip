@@ -42,7 +42,7 @@ extern "C" int plade_ctx_create(int device, plade_ctx **out) {
 extern "C" void plade_ctx_destroy(plade_ctx *ctx) {
     if (!ctx) return;
     if (ctx->aux) { plade_ctx_destroy(ctx->aux); ctx->aux = nullptr; }
-    if (ctx->peer) { plade_ctx_destroy(ctx->peer); ctx->peer = nullptr; }
+    for (plade_ctx *&p : ctx->peers) if (p) { plade_ctx_destroy(p); p = nullptr; }
     if (ctx->ev_group) { (void)hipEventDestroy(ctx->ev_group); ctx->ev_group = nullptr; }
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);

@@ -36,8 +36,9 @@ void convert_on(hipStream_t st, CloudDev &c) {
 // SoA conversion + bounding boxes of clouds whose AoS copy is complete: ONE wait for all of them
 void finish_uploads(plade_ctx *ctx, CloudDev *const clouds[], int count) {
     plade_ctx::Prefetch &P = ctx->pf;
-    if (!P.h.p) { bbox_init_pattern(P.h.ensure(8 + 8 * 4)); P.d.ensure(8 * 4); }
-    PLADE_REQUIRE(count <= 4, PLADE_EINVAL, "finish_uploads: at most four clouds");
+    constexpr int MAXC = 2 * PLADE_GROUP_MAX;
+    if (!P.h.p) { bbox_init_pattern(P.h.ensure(8 + 8 * MAXC)); P.d.ensure(8 * MAXC); }
+    PLADE_REQUIRE(count <= MAXC, PLADE_EINVAL, "finish_uploads: too many clouds");
     for (int i = 0; i < count; ++i) {
         convert_on(ctx->stream, *clouds[i]);
         bbox_async(ctx->stream, clouds[i]->aos.p, clouds[i]->n, 6, P.d.p + 8 * i, P.h.p, P.h.p + 8 + 8 * i);
@@ -58,13 +59,13 @@ void cloud_upload(plade_ctx *ctx, const float *pos_nrm, uint32_t n, CloudDev &ou
 }
 
 void cloud_upload_many(plade_ctx *ctx, int count, const float *const ptr[], const uint32_t n[], CloudDev *const out[]) {
-    PLADE_REQUIRE(count >= 1 && count <= 4, PLADE_EINVAL, "cloud_upload_many: one to four clouds");
+    PLADE_REQUIRE(count >= 1 && count <= 2 * PLADE_GROUP_MAX, PLADE_EINVAL, "cloud_upload_many: too many clouds");
     for (int i = 0; i < count; ++i) {
         shape_cloud(*out[i], n[i]);
         if (n[i]) HIP_TRY(hipMemcpyAsync(out[i]->aos.p, ptr[i], (size_t)n[i] * 24, hipMemcpyHostToDevice, ctx->stream));
     }
     ctx->sync();
-    CloudDev *cl[4];
+    CloudDev *cl[2 * PLADE_GROUP_MAX];
     for (int i = 0; i < count; ++i) cl[i] = out[i];
     finish_uploads(ctx, cl, count);
 }
@@ -99,7 +100,7 @@ void cloud_drop_prefetch(plade_ctx *ctx) {
 void cloud_prefetch(plade_ctx *ctx, int count, const float *const ptr[], const uint32_t n[]) {
     plade_ctx::Prefetch &P = ctx->pf;
     cloud_drop_prefetch(ctx);   // an earlier prefetch nobody took is still writing into the buffers reshaped below
-    if (count != 2 && count != 4) return;
+    if (count < 2 || count > 2 * PLADE_GROUP_MAX || (count & 1)) return;
     for (int i = 0; i < count; ++i) if (!ptr[i] || !n[i]) return;
     if (!P.stream) HIP_TRY(hipStreamCreateWithFlags(&P.stream, hipStreamNonBlocking));
     for (int i = 0; i < count; ++i) {
@@ -120,7 +121,7 @@ bool cloud_take_prefetched(plade_ctx *ctx, int count, const float *const ptr[], 
     ctx->sync(P.stream);   // whatever happens next, the prefetch stream must have finished with the buffers
     if (P.count != count) return false;
     for (int i = 0; i < count; ++i) if (P.ptr[i] != ptr[i] || P.n[i] != n[i]) return false;
-    CloudDev *cl[4];
+    CloudDev *cl[2 * PLADE_GROUP_MAX];
     for (int i = 0; i < count; ++i) { swap_clouds(*out[i], P.cl[i]); cl[i] = out[i]; }
     finish_uploads(ctx, cl, count);
     return true;

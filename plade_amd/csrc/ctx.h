@@ -83,8 +83,8 @@ struct plade_ctx {
     int device = 0;
     plade::RegistrationWork *reg_work = nullptr;
     plade::RansacWork *ransac_work = nullptr;
-    plade_ctx *peer = nullptr;  // the context of the SECOND pair of a group (plade_registration_pairs): stream, aux, work areas
-    hipEvent_t ev_group = nullptr;   // end of a group's joint plane extraction on `stream` (the peer's stream waits for it)
+    plade_ctx *peers[PLADE_GROUP_MAX - 1] = {};   // the contexts of pairs 1.. of a group (plade_registration_pairs): stream, aux, work areas
+    hipEvent_t ev_group = nullptr;   // end of a group's joint plane extraction on `stream` (the peers' streams wait for it)
     plade_ctx *aux = nullptr;   // second stream + work areas: stages of the source cloud that are independent of the
                                 // target's run concurrently with them
     hipStream_t stream = nullptr;
@@ -95,10 +95,10 @@ struct plade_ctx {
     // pair registers; the next call finds them here and swaps them in
     struct Prefetch {
         hipStream_t stream = nullptr;
-        plade::CloudDev cl[4];                 // target, source of pair 0; target, source of pair 1
-        const float *ptr[4] = {nullptr, nullptr, nullptr, nullptr};
-        uint32_t n[4] = {0, 0, 0, 0};
-        int count = 0;                         // clouds in flight (2 or 4)
+        plade::CloudDev cl[2 * PLADE_GROUP_MAX];   // target, source of pair 0; target, source of pair 1; ...
+        const float *ptr[2 * PLADE_GROUP_MAX] = {};
+        uint32_t n[2 * PLADE_GROUP_MAX] = {};
+        int count = 0;                         // clouds in flight (2 per pair)
         bool valid = false;
         plade::HBuf<int> h;      // page-locked: [0..8) init pattern, then 8 ints per bounding box read back
         plade::DBuf<int> d;      // 8 ints per box being reduced
@@ -294,7 +294,7 @@ struct plade_ctx {
         read_arena_used = 0;
         write_arena_used = 0;
         if (aux) aux->drop_reads();
-        if (peer) peer->drop_reads();
+        for (plade_ctx *p : peers) if (p) p->drop_reads();
     }
     void finish_reads() {
         for (const PendingRead &r : pending_reads) memcpy(r.dst, read_arena.p + r.off, r.bytes);
@@ -365,9 +365,9 @@ struct StageTimer {
 // cloud upload: AoS N x 6 (host) -> SoA on device
 void cloud_upload(plade_ctx *ctx, const float *pos_nrm, uint32_t n, CloudDev &out);
 void cloud_upload_pair(plade_ctx *ctx, const float *tgt, uint32_t n_t, CloudDev &out_t, const float *src, uint32_t n_s, CloudDev &out_s);
-// `count` (<= 4) clouds in one go: all copies first, one wait, then conversion + bounding boxes of all of them, one wait
+// `count` (<= 2 * PLADE_GROUP_MAX) clouds in one go: all copies first, one wait, then conversion + bounding boxes of all of them, one wait
 void cloud_upload_many(plade_ctx *ctx, int count, const float *const ptr[], const uint32_t n[], CloudDev *const out[]);
-// batch mode: queue the upload of the NEXT call's clouds (count = 2 or 4: target, source[, target, source]) on the context's
+// batch mode: queue the upload of the NEXT call's clouds (count = 2 per pair: target, source[, target, source ...]) on the context's
 // prefetch stream / take a finished prefetch over into out[] (false: nothing usable was prefetched)
 void cloud_prefetch(plade_ctx *ctx, int count, const float *const ptr[], const uint32_t n[]);
 bool cloud_take_prefetched(plade_ctx *ctx, int count, const float *const ptr[], const uint32_t n[], CloudDev *const out[]);

@@ -1,5 +1,5 @@
 // plade_amd/csrc/ransac.h -- GPU plane extraction (seam S1b): a device-driven Efficient-RANSAC that extracts the
-// planes of up to four clouds (the scans of one or two pairs) in the same launch sequence, see ransac.hip.
+// planes of up to eight clouds (the scans of one to four pairs) in the same launch sequence, see ransac.hip.
 #pragma once
 #include "ctx.h"
 
@@ -53,9 +53,9 @@ struct ComponentOut {
 void plane_component(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const float normal[3], const float point[3],
                      const int32_t *idx, uint32_t m, float bitmap_eps, bool closing_filter, float w_eps, ComponentOut &out);
 
-// Up to four clouds are extracted together ("slots" 0-3 of the work area): the two scans of a registration, or the four of a
-// group of two registrations (plade_registration_pairs), in one launch sequence.
-constexpr int RANSAC_SLOTS = 4;
+// Up to eight clouds are extracted together ("slots" 0-7 of the work area): the two scans of a registration, or the 2 x count
+// scans of a group of registrations (plade_registration_pairs), in one launch sequence.
+constexpr int RANSAC_SLOTS = 2 * PLADE_GROUP_MAX;
 
 // Morton order + stratified subset of the clouds (once per set of clouds; every detect call on them reuses it).
 void ransac_prepare(plade_ctx *ctx, RansacWork &W, const CloudDev *const clouds[RANSAC_SLOTS], int n_clouds);

@@ -34,8 +34,10 @@
 // The sequence is captured once as a hipGraph and replayed; the host never reads anything back in between -- the
 // `decide` kernel reports the iteration count and the final results through a block of host-mapped memory that the
 // host polls while the next (speculative) iteration is already queued.
-// Every kernel serves the clouds of up to two "slots": the two scans of a registration are extracted in lock step by
-// one launch sequence (blockIdx selects the cloud), which halves the number of commands per registration.
+// Every kernel serves the clouds of up to RANSAC_SLOTS "slots": the two scans of a registration -- or all scans of a group of
+// registrations (plade_registration_pairs) -- are extracted in lock step by one launch sequence (blockIdx selects the cloud):
+// most kernels of the loop are latency chains whose duration hardly grows with more workgroups, so every cloud added to a
+// sequence divides their cost per registration.
 #include "ransac.h"
 #include "k1_point_test.h"
 #include "prims.h"
@@ -240,7 +242,7 @@ ChainLayout make_layout(uint32_t n) {
 
 // ------------------------------------------------------------------------------------------------
 // Morton order: 8 bits per axis = the 8 octree levels the sampler draws from; the cloud slot takes the bits above the
-// code (24, 25) so that the clouds of a launch sequence are ordered by ONE sort
+// code (24-26) so that the clouds of a launch sequence are ordered by ONE sort
 __device__ __forceinline__ uint32_t spread3(uint32_t v) {  // up to 10 bits -> every third bit
     v = (v | (v << 16)) & 0x030000FF;
     v = (v | (v << 8)) & 0x0300F00F;
@@ -2123,7 +2125,7 @@ void wait_iterations(plade_ctx *ctx, RResult *const *res, int nres, uint32_t wan
 }  // namespace
 
 void ransac_prepare(plade_ctx *ctx, RansacWork &W, const CloudDev *const clouds[RANSAC_SLOTS], int n_clouds) {
-    PLADE_REQUIRE(n_clouds >= 1 && n_clouds <= R_G, PLADE_EINVAL, "ransac: one to four clouds");
+    PLADE_REQUIRE(n_clouds >= 1 && n_clouds <= R_G, PLADE_EINVAL, "ransac: too many clouds");
     W.ng = n_clouds;
     MortonArgs M;
     GatherArgs G;
@@ -2163,7 +2165,7 @@ void ransac_prepare(plade_ctx *ctx, RansacWork &W, const CloudDev *const clouds[
     for (int g = n_clouds; g <= R_G; ++g) M.start[g] = G.start[g] = (uint32_t)total;
     W.keys_in.ensure(total); W.vals_in.ensure(total); W.keys.ensure(total); W.perm.ensure(total);
     hipLaunchKernelGGL(k_morton, dim3(cdiv(total, 256)), dim3(256), 0, ctx->stream, M, W.keys_in.p, W.vals_in.p);
-    sort_pairs_u32(ctx, W.keys_in.p, W.keys.p, W.vals_in.p, W.perm.p, total, n_clouds > 2 ? 26 : n_clouds > 1 ? 25 : 24);
+    sort_pairs_u32(ctx, W.keys_in.p, W.keys.p, W.vals_in.p, W.perm.p, total, n_clouds > 4 ? 27 : n_clouds > 2 ? 26 : n_clouds > 1 ? 25 : 24);
     hipLaunchKernelGGL(k_gather_cloud, dim3(cdiv(total, 256)), dim3(256), 0, ctx->stream, G, W.keys.p, W.perm.p);
     Cells6Args C6;
     memset(&C6, 0, sizeof(C6));
@@ -2329,7 +2331,7 @@ void ransac_detect_prepared(plade_ctx *ctx, RansacWork &W, RansacJob jobs[RANSAC
 }
 
 void ransac_detect(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const RansacParams &rp, PlaneSetOut &out) {
-    const CloudDev *cl[R_G] = {&cloud, nullptr};
+    const CloudDev *cl[R_G] = {&cloud};
     ransac_prepare(ctx, W, cl, 1);
     RansacJob jobs[R_G];
     jobs[0].active = true; jobs[0].rp = rp; jobs[0].out = &out;

@@ -153,28 +153,34 @@ void ensure_pair_areas(plade_ctx *ctx) {
     if (!ctx->reg_work) ctx->reg_work = registration_work_create();
 }
 
-// `count` (1 or 2) registrations as ONE group: the plane extraction of all their clouds is one launch sequence on the calling
-// context's stream (two pairs = four clouds per kernel: the extraction is a chain of ~150 short, latency-bound kernels whose
-// duration hardly grows with twice the workgroups, so a group halves its commands, host waits and GPU time per registration);
-// behind it every pair runs the rest of its registration on its own context (pair 0: the calling one on the calling thread,
-// pair 1: the peer context on a helper thread), concurrently.  status[i]: PLADE_OK / PLADE_EFAIL / an error code.
+plade_ctx *peer_ctx(plade_ctx *ctx, int i) {   // the context of pair i >= 1 of a group
+    plade_ctx *&p = ctx->peers[i - 1];
+    if (!p) {
+        plade_ctx *a = nullptr;
+        PLADE_REQUIRE(plade_ctx_create(ctx->device, &a) == PLADE_OK, PLADE_EDEVICE, "cannot create the context of a further pair of the group");
+        p = a;
+    }
+    return p;
+}
+
+// `count` (1 .. PLADE_GROUP_MAX) registrations as ONE group: the plane extraction of all their clouds is one launch sequence on
+// the calling context's stream (count pairs = 2 x count clouds per kernel: the extraction is a chain of ~150 short, mostly
+// latency-bound kernels whose duration grows slowly with more workgroups, so a group divides its commands, host waits and
+// GPU time per registration); behind it every pair runs the rest of its registration on its own context (pair 0: the calling
+// one on the calling thread, pair i: peer context i on a helper thread), concurrently.  status[i]: PLADE_OK / PLADE_EFAIL /
+// an error code.
 void register_group(plade_ctx *ctx, int count, const CloudDev *const tgt[], const CloudDev *const src[], const int ms_t[], const int ms_s[],
                     bool auto_tune, float *T16, int32_t *status) {
-    PLADE_REQUIRE(count >= 1 && count <= PLADE_GROUP_MAX, PLADE_EINVAL, "a group holds one or two pairs");
+    PLADE_REQUIRE(count >= 1 && count <= PLADE_GROUP_MAX, PLADE_EINVAL, "a group holds one to PLADE_GROUP_MAX pairs");
     Clock::time_point t0 = Clock::now();
-    plade_ctx *pcs[PLADE_GROUP_MAX] = {ctx, nullptr};
-    if (count > 1) {
-        if (!ctx->peer) {
-            plade_ctx *a = nullptr;
-            PLADE_REQUIRE(plade_ctx_create(ctx->device, &a) == PLADE_OK, PLADE_EDEVICE, "cannot create the second pair's context");
-            ctx->peer = a;
-        }
-        pcs[1] = ctx->peer;
-        pcs[1]->params = ctx->params;
-        pcs[1]->stats.clear();
-        pcs[1]->dump.clear();
-        pcs[1]->last_error.clear();
-        pcs[1]->drop_reads();
+    plade_ctx *pcs[PLADE_GROUP_MAX] = {ctx};
+    for (int i = 1; i < count; ++i) {
+        pcs[i] = peer_ctx(ctx, i);
+        pcs[i]->params = ctx->params;
+        pcs[i]->stats.clear();
+        pcs[i]->dump.clear();
+        pcs[i]->last_error.clear();
+        pcs[i]->drop_reads();
     }
     for (int i = 0; i < count; ++i) {
         ensure_pair_areas(pcs[i]);
@@ -182,21 +188,22 @@ void register_group(plade_ctx *ctx, int count, const CloudDev *const tgt[], cons
         status[i] = PLADE_OK;
     }
     PlaneSetOut planes[2 * PLADE_GROUP_MAX];
-    float spacing[PLADE_GROUP_MAX] = {0.f, 0.f};
-    bool have_spacing[PLADE_GROUP_MAX] = {false, false};
+    float spacing[PLADE_GROUP_MAX] = {};
+    bool have_spacing[PLADE_GROUP_MAX] = {};
     {
         StageTimer t(ctx, "t_extract");
         const CloudDev *clouds[2 * PLADE_GROUP_MAX];
         int init[2 * PLADE_GROUP_MAX];
         PlaneSetOut *outs[2 * PLADE_GROUP_MAX];
         plade_ctx *stat_ctx[2 * PLADE_GROUP_MAX];
-        static const char *const tags[2 * PLADE_GROUP_MAX] = {"_tgt", "_src", "_tgt", "_src"};
+        const char *tags[2 * PLADE_GROUP_MAX];
         for (int i = 0; i < count; ++i) {
             clouds[2 * i] = tgt[i]; clouds[2 * i + 1] = src[i];
             init[2 * i] = auto_tune ? ctx->params.init_min_support : ms_t[i];
             init[2 * i + 1] = auto_tune ? ctx->params.init_min_support : ms_s[i];
             outs[2 * i] = &planes[2 * i]; outs[2 * i + 1] = &planes[2 * i + 1];
             stat_ctx[2 * i] = stat_ctx[2 * i + 1] = pcs[i];
+            tags[2 * i] = "_tgt"; tags[2 * i + 1] = "_src";
         }
         // the next stage reads the index lists from the device; the host copy is only for dumps.  The point spacing
         // (plade.cpp:41) only needs the source cloud: its two kernels are queued right behind the Morton order of the
@@ -209,29 +216,34 @@ void register_group(plade_ctx *ctx, int count, const CloudDev *const tgt[], cons
         status[0] = register_tail(ctx, ctx, 0, *tgt[0], *src[0], planes[0], planes[1], auto_tune, have_spacing[0], spacing[0], T16, t0);
         return;
     }
-    // The second pair's streams read what the extraction wrote on this context's stream (support lists, the Morton-ordered
+    // The other pairs' streams read what the extraction wrote on this context's stream (support lists, the Morton-ordered
     // copy), and the extraction's host loop returns as soon as the device reports through host-mapped memory, with the last
-    // kernels possibly still running: the peer's stream waits for this one.
+    // kernels possibly still running: the peers' streams wait for this one.
     if (!ctx->ev_group) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_group, hipEventDisableTiming));
     HIP_TRY(hipEventRecord(ctx->ev_group, ctx->stream));
-    HIP_TRY(hipStreamWaitEvent(pcs[1]->stream, ctx->ev_group, 0));
-    Err peer_err{0, ""};
-    std::thread th([&]() {
-        const double cpu0 = thread_cpu_seconds();
-        (void)hipSetDevice(ctx->device);
+    Err errs[PLADE_GROUP_MAX];
+    for (Err &e : errs) e = Err{0, ""};
+    auto tail = [&](int i) {
         try {
-            status[1] = register_tail(pcs[1], ctx, 2, *tgt[1], *src[1], planes[2], planes[3], auto_tune, have_spacing[1], spacing[1], T16 + 16, t0);
-        } catch (const Err &e) { peer_err = e; }
-        catch (const std::exception &e) { peer_err = Err{PLADE_EDEVICE, e.what()}; }
-        pcs[1]->stats.add("cpu_pair_thread", thread_cpu_seconds() - cpu0);
-    });
-    Err main_err{0, ""};
-    try { status[0] = register_tail(ctx, ctx, 0, *tgt[0], *src[0], planes[0], planes[1], auto_tune, have_spacing[0], spacing[0], T16, t0); }
-    catch (const Err &e) { main_err = e; }
-    catch (const std::exception &e) { main_err = Err{PLADE_EDEVICE, e.what()}; }
-    th.join();
-    if (peer_err.code) { pcs[1]->drop_reads(); pcs[1]->last_error = peer_err.msg; status[1] = peer_err.code; }
-    if (main_err.code) { ctx->drop_reads(); ctx->last_error = main_err.msg; status[0] = main_err.code; }
+            status[i] = register_tail(pcs[i], ctx, 2 * i, *tgt[i], *src[i], planes[2 * i], planes[2 * i + 1], auto_tune, have_spacing[i], spacing[i],
+                                      T16 + 16 * i, t0);
+        } catch (const Err &e) { errs[i] = e; }
+        catch (const std::exception &e) { errs[i] = Err{PLADE_EDEVICE, e.what()}; }
+    };
+    std::thread ths[PLADE_GROUP_MAX];
+    for (int i = 1; i < count; ++i) {
+        HIP_TRY(hipStreamWaitEvent(pcs[i]->stream, ctx->ev_group, 0));
+        ths[i] = std::thread([&, i]() {
+            const double cpu0 = thread_cpu_seconds();
+            (void)hipSetDevice(ctx->device);
+            tail(i);
+            pcs[i]->stats.add("cpu_pair_thread", thread_cpu_seconds() - cpu0);
+        });
+    }
+    tail(0);
+    for (int i = 1; i < count; ++i) ths[i].join();
+    for (int i = 0; i < count; ++i)
+        if (errs[i].code) { pcs[i]->drop_reads(); pcs[i]->last_error = errs[i].msg; status[i] = errs[i].code; }
 }
 
 int register_clouds(plade_ctx *ctx, const CloudDev &tgt, const CloudDev &src, int ms_t, int ms_s, bool auto_tune, float *T16) {
@@ -396,14 +408,15 @@ int registration_batch(plade_ctx *ctx, uint32_t count, const float *const *tgt, 
     ctx->stats.clear();
     ctx->dump.clear();
     ctx->last_error.clear();
-    if (count > 1 && !ctx->peer) {
-        plade_ctx *a = nullptr;
-        PLADE_REQUIRE(plade_ctx_create(ctx->device, &a) == PLADE_OK, PLADE_EDEVICE, "cannot create the second pair's context");
-        ctx->peer = a;
+    const float *ptr[2 * PLADE_GROUP_MAX], *nptr[2 * PLADE_GROUP_MAX];
+    uint32_t n[2 * PLADE_GROUP_MAX], nn[2 * PLADE_GROUP_MAX];
+    CloudDev *out[2 * PLADE_GROUP_MAX];
+    const CloudDev *ct[PLADE_GROUP_MAX], *cs[PLADE_GROUP_MAX];
+    for (uint32_t i = 0; i < count; ++i) {
+        plade_ctx *pc = i ? peer_ctx(ctx, (int)i) : ctx;
+        out[2 * i] = &pc->up_tgt; out[2 * i + 1] = &pc->up_src;
+        ct[i] = &pc->up_tgt; cs[i] = &pc->up_src;
     }
-    const float *ptr[4], *nptr[4];
-    uint32_t n[4], nn[4];
-    CloudDev *out[4] = {&ctx->up_tgt, &ctx->up_src, count > 1 ? &ctx->peer->up_tgt : nullptr, count > 1 ? &ctx->peer->up_src : nullptr};
     for (uint32_t i = 0; i < count; ++i) { ptr[2 * i] = tgt[i]; ptr[2 * i + 1] = src[i]; n[2 * i] = n_t[i]; n[2 * i + 1] = n_s[i]; }
     for (uint32_t i = 0; i < next_count; ++i) { nptr[2 * i] = next_tgt[i]; nptr[2 * i + 1] = next_src[i]; nn[2 * i] = next_n_t[i]; nn[2 * i + 1] = next_n_s[i]; }
     {
@@ -416,9 +429,7 @@ int registration_batch(plade_ctx *ctx, uint32_t count, const float *const *tgt, 
         if (next_count) cloud_prefetch(ctx, 2 * (int)next_count, nptr, nn);
         ctx->stats.add("t_upload_submit", secs_since(t0));
     }
-    const CloudDev *ct[PLADE_GROUP_MAX] = {&ctx->up_tgt, count > 1 ? &ctx->peer->up_tgt : nullptr};
-    const CloudDev *cs[PLADE_GROUP_MAX] = {&ctx->up_src, count > 1 ? &ctx->peer->up_src : nullptr};
-    const int zero[PLADE_GROUP_MAX] = {0, 0};
+    const int zero[PLADE_GROUP_MAX] = {};
     register_group(ctx, (int)count, ct, cs, zero, zero, true, T16, status);
     return PLADE_OK;
 }
@@ -461,7 +472,7 @@ extern "C" int plade_registration_pairs_dev(plade_ctx *ctx, uint32_t count, plad
                                             int32_t *status) {
     return guarded(ctx, [&]() -> int {
         PLADE_REQUIRE(count >= 1 && count <= PLADE_GROUP_MAX && tgt && src && T16 && status, PLADE_EINVAL, "plade_registration_pairs_dev: bad argument");
-        const CloudDev *ct[PLADE_GROUP_MAX] = {nullptr, nullptr}, *cs[PLADE_GROUP_MAX] = {nullptr, nullptr};
+        const CloudDev *ct[PLADE_GROUP_MAX] = {}, *cs[PLADE_GROUP_MAX] = {};
         for (uint32_t i = 0; i < count; ++i) {
             PLADE_REQUIRE(tgt[i] && src[i], PLADE_EINVAL, "plade_registration_pairs_dev: null cloud");
             ct[i] = &tgt[i]->dev; cs[i] = &src[i]->dev;
@@ -470,7 +481,7 @@ extern "C" int plade_registration_pairs_dev(plade_ctx *ctx, uint32_t count, plad
         ctx->dump.clear();
         ctx->last_error.clear();
         cloud_drop_prefetch(ctx);
-        const int zero[PLADE_GROUP_MAX] = {0, 0};
+        const int zero[PLADE_GROUP_MAX] = {};
         register_group(ctx, (int)count, ct, cs, zero, zero, true, T16, status);
         return PLADE_OK;
     });
@@ -480,7 +491,7 @@ extern "C" int plade_registration_pairs_dev(plade_ctx *ctx, uint32_t count, plad
 // the ordinary entry points.  Borrowed: it lives and dies with ctx.
 extern "C" plade_ctx *plade_pair_ctx(plade_ctx *ctx, uint32_t index) {
     if (!ctx) return nullptr;
-    return index == 0 ? ctx : (index == 1 ? ctx->peer : nullptr);
+    return index == 0 ? ctx : (index < PLADE_GROUP_MAX ? ctx->peers[index - 1] : nullptr);
 }
 
 extern "C" int plade_registration_minsupport(plade_ctx *ctx, const float *tgt_pos_nrm, uint32_t n_t,

@@ -62,6 +62,18 @@ def test_group_of_two_equals_the_pairs_alone(scenes, alone, a, b):
     c.close()
 
 
+@pytest.mark.parametrize("members", [(0, 1, 2), (2, 1, 0, 1), (1, 1, 1, 1)])
+def test_groups_of_three_and_four(scenes, alone, members):
+    """PLADE_GROUP_MAX = 4 pairs (eight clouds) per extraction sequence: same bits as the pairs alone, the planes included."""
+    c = plade_amd.Context(0, orient_normals=1, dump=1)
+    res = c.registration_pairs([(scenes[i][0], scenes[i][1]) for i in members])
+    for pos, i in enumerate(members):
+        ok, T = res[pos]
+        assert ok and np.array_equal(T, alone[i][1])
+        _same(c.dump(pair=pos), alone[i][2], PLANE_KEYS + ["overlap_counts", "scores", "match_nbr"])
+    c.close()
+
+
 def test_group_of_one_is_the_plain_call(scenes, alone):
     c = plade_amd.Context(0, orient_normals=1)
     (ok, T), = c.registration_pairs([(scenes[1][0], scenes[1][1])])
@@ -126,7 +138,7 @@ def test_bad_group_arguments_are_refused(scenes):
     c = plade_amd.Context(0, orient_normals=1)
     pr = (scenes[1][0], scenes[1][1])
     with pytest.raises(plade_amd.PladeError):
-        c.registration_pairs([pr, pr, pr])
+        c.registration_pairs([pr, pr, pr, pr, pr])
     with pytest.raises(plade_amd.PladeError):
         c.registration_pairs([])
     c.close()

@@ -72,11 +72,12 @@ t0, t1 = done_t[W - 1], done_t[W + K - 1]
 ok = sum(bool(r[0]) for r in res.values())
 same = all(np.array_equal(res[i][1], ref[i % NP][1]) and res[i][0] == ref[i % NP][0] for i in res)
 st = ctxs[0].stats()
-keys = [k for k in st if k.startswith(("ransac_", "n_", "cpu_"))]
+keys = [k for k in st if k.startswith(("ransac_", "n_", "cpu_", "t_"))]
+st1 = ctxs[0].stats(pair=1) if S > 1 else {}
 total = n_groups * S
 print(json.dumps({"reg_per_s": K / (t1 - t0), "ms_per_step": (t1 - t0) / K * 1e3, "groups_in_flight": G, "pairs_per_group": S, "steps": K,
                   "host_clouds": host, "bracketed_reg_per_s": total / (done_t[-1] - t_start), "ok": ok, "of": total,
                   "identical_to_single": bool(same), "busy_threads": (cpu1 - cpu0) / (done_t[-1] - t_start),
                   "cpu_ms_per_registration": (cpu1 - cpu0) / total * 1e3,
                   "env": {k: v for k, v in os.environ.items() if k.startswith(("PLADE_", "GPU_MAX", "EXP_"))},
-                  "stats": {k: st[k] for k in keys}}))
+                  "stats": {k: st[k] for k in keys}, "stats_pair1": {k: v for k, v in st1.items() if k.startswith(("cpu_", "t_"))}}))
