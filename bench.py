@@ -10,12 +10,14 @@ registration) of one synthetic pair of config `Synthetic 1M-pt indoor scan pair,
 the bounding boxes of every step are inside the timed region.  One process per GPU; scan pairs
 are independent (batch mode, code/PLADE/main.cpp:97-158), so every rank registers its own pairs with no
 data-path collective and the per-pair 4x4 results are gathered to rank 0 over RCCL at the end
-(weak scaling: work per GPU is fixed).  Several registrations are in flight per GPU (one plade_ctx + host thread
-each); `value` is the steady-state rate of that pipeline over the timed steps that complete after the last lead-in
-(warm-up) step: steps in flight / mean time one of those steps occupied its worker (the bare first-to-last-completion
-window is reported beside it).  Fewer than 16 rounds of the workers sample a pipeline badly (20 steps = 2.5 rounds of
-8 read +-9 % from run to run), so max(K, 16 x in-flight) steps are timed; `ms_per_step` and `value` are per-step
-figures, `pipeline.timed_steps` says how many steps they come from, `steps` echoes the K that was asked for.
+(weak scaling: work per GPU is fixed).  Several GROUPS of pairs are in flight per GPU (one plade_ctx + host thread per
+group, --group consecutive pairs of the batch per plade_registration_pairs call: the plane extraction of a group's clouds
+is one launch sequence); `value` = timed steps / the window between the completion of the last lead-in group and the
+completion of the last timed group, i.e. exactly `steps` registrations complete inside the window with the pipeline full
+on both sides.  A pipeline of M x S registrations in flight is not sampled fairly by a handful of steps (the driver's 20
+are little more than one round of 16), so max(K, 32 x registrations in flight) steps are timed, in whole groups: `steps`
+on the line is the number really timed, `requested_steps` echoes K; the occupancy estimator of round 3 is reported
+beside it (`pipeline.occupancy_value`).
 Rank 0 prints ONE JSON line.  `resident_rank0` is the same pipeline on clouds already resident in HBM.
 
 Extra objects on the line:
@@ -181,14 +183,21 @@ def _cpu_budget():
     return n
 
 
+# busy host threads per rank, measured on the MI355X box in round 4 (tools/exp_groups.py, sleeping host waits, groups of 4 pairs,
+# host clouds): groups in flight -> busy threads (registrations/s): see profiles/r4_experiments.md
+BUSY_THREADS_BY_GROUPS = {2: 1.79, 3: 2.02, 4: 2.21, 6: 2.4, 8: 2.5}   # 557 / 610 / 635 / 621 / 635 registrations/s
+
+
 def inflight_for_budget(budget, local_world):
-    """Registrations in flight per GPU.  Measured on the MI355X box (sleeping host waits): 5 / 6 / 8 / 10 in flight keep
-    2.2 / 2.3 / 2.6 / 2.7 host threads busy for 435 / 447 / 455-467 / 457 reg/s, i.e. busy = 1.3 + 0.17 per registration in
-    flight.  A container that runs into its CPU quota loses far more than the last few percent of GPU throughput (round 1:
-    287 instead of 400 reg/s under throttling), so the count is lowered until the ranks of the node fit into the quota: 8
-    ranks on 16 CPUs run 4 in flight each."""
-    per_rank = float(budget) / max(local_world, 1)
-    return int(max(2, min(8, (per_rank - 1.3) / 0.17 + 1e-6)))
+    """Groups (of 4 pairs) in flight per GPU.  A container that runs into its CPU quota loses far more than the last few
+    percent of GPU throughput (round 1: 287 instead of 400 reg/s under throttling), so the count is the largest one whose
+    measured host load (BUSY_THREADS_BY_GROUPS), times the ranks of this node, still fits the quota with 10 % to spare."""
+    per_rank = 0.9 * float(budget) / max(local_world, 1)
+    best = 2
+    for g in sorted(BUSY_THREADS_BY_GROUPS):
+        if g <= 4 and BUSY_THREADS_BY_GROUPS[g] <= per_rank:
+            best = g
+    return best
 
 
 def _cgroup_throttle():
@@ -212,9 +221,12 @@ def main():
                          "per registration in flight, sleeping ones ~0.5 at the same throughput; auto = sleep when more "
                          "than one registration is in flight")
     ap.add_argument("--inflight", type=int, default=0,
-                    help="registrations in flight per GPU: independent pairs, one plade_ctx + host thread each "
-                         "(a single registration is latency-bound and leaves most of the GPU idle).  0 = 8, or fewer when "
-                         "the ranks of this node have to share a small CPU quota (see inflight_for_budget)")
+                    help="GROUPS in flight per GPU: one plade_ctx + host thread each, every call registers --group consecutive "
+                         "pairs of the batch (a single registration is latency-bound and leaves most of the GPU idle).  0 = 4, or "
+                         "fewer when the ranks of this node have to share a small CPU quota (see inflight_for_budget)")
+    ap.add_argument("--group", type=int, default=4,
+                    help="pairs per group (plade_registration_pairs, 1..4): the plane extraction of all clouds of a group is one "
+                         "launch sequence; 1 = one pair per call (round 3's scheme)")
     ap.add_argument("--resident-steps", type=int, default=256,
                     help="steps of the extra resident leg (clouds uploaded once, plade_registration_dev per step); 0 = skip")
     ap.add_argument("--host-steps", type=int, default=0, help=argparse.SUPPRESS)   # round-2 flag, ignored
@@ -261,11 +273,13 @@ def main():
     inflight_auto = args.inflight <= 0
     if inflight_auto:
         args.inflight = inflight_for_budget(_cpu_budget(), local_world)
-    M = max(1, args.inflight)
+    M = max(1, args.inflight)                  # groups in flight
+    S = max(1, min(4, args.group))             # pairs per group
+    RIF = M * S                                # registrations in flight
     if args.host_wait == "auto":
         # several registrations in flight: sleeping waits (same throughput, a third of the host CPUs, and no way to run
         # into the container's CPU quota when 8 ranks share a node); one at a time: spin for the lowest latency
-        args.host_wait = "sleep" if M > 1 else "spin"
+        args.host_wait = "sleep" if RIF > 1 else "spin"
     host_wait = {"spin": 0, "sleep": 1}[args.host_wait]
     ctxs = [plade_amd.Context(local_rank, host_wait=host_wait, orient_normals=1) for _ in range(M)]
     ctx = ctxs[0]
@@ -278,40 +292,45 @@ def main():
         pairs.append((tg, sr, Tgt))
         for w in range(M):
             clouds[w].append((ctxs[w].upload(tg), ctxs[w].upload(sr)))
+    NP = len(pairs)
 
-    def step(i, w=0):
-        ct, cs = clouds[w][i % len(pairs)]
-        ok, T = ctxs[w].registration_dev(ct, cs)
-        return ok, T
+    def step(i, w=0):       # one pair alone on resident clouds (latency figure, default-mode leg)
+        ct, cs = clouds[w][i % NP]
+        return ctxs[w].registration_dev(ct, cs)
+
+    # Step number i registers pair i % NP; group number j holds the steps j*S .. j*S + S - 1 (consecutive pairs of the batch).
+    def members(j):
+        return [j * S + q for q in range(S)]
 
     # the timed path: registration(T, target, source) of code/PLADE/plade.h:58 on clouds in (page-locked) HOST memory, in
-    # batch mode (main.cpp:97-158 loops over pairs): plade_registration_next = plade_registration + the upload of the pair
-    # the same context registers next, queued on a stream of its own.  H2D, SoA conversion and bounding boxes of every
-    # step are inside the timed region.
+    # batch mode (main.cpp:97-158 loops over pairs): plade_registration_pairs = S x plade_registration with the plane
+    # extraction of the group's clouds in one launch sequence + the upload of the group the same context registers next,
+    # queued on a stream of its own.  H2D, SoA conversion and bounding boxes of every step are inside the timed region.
     for tg, sr, _ in pairs:
         ctx.pin(tg); ctx.pin(sr)
 
-    def hstep(i, w, nxt):
-        tg, sr, _ = pairs[i % len(pairs)]
-        ntg, nsr = (pairs[nxt % len(pairs)][0], pairs[nxt % len(pairs)][1]) if nxt is not None else (None, None)
-        return ctxs[w].registration_next(tg, sr, ntg, nsr)
+    def hgroup(j, w, nxt):
+        cur = [(pairs[i % NP][0], pairs[i % NP][1]) for i in members(j)]
+        nx = [(pairs[i % NP][0], pairs[i % NP][1]) for i in members(nxt)] if nxt is not None else None
+        return ctxs[w].registration_pairs(cur, nx)
 
-    def rstep(i, w, nxt):
-        return step(i, w)
+    def rgroup(j, w, nxt):
+        return ctxs[w].registration_pairs_dev([clouds[w][i % NP] for i in members(j)])
 
-    def run_pipeline(fn, lead, count):
-        """Steady-state throughput of the M-deep pipeline: worker w takes steps w, w + M, ... of lead + count + M steps
-        (the first `lead` fill the pipeline and are untimed, the last M keep it full until the last timed step completes);
-        the timed window runs from the completion of step number `lead` to the completion of step number lead + count,
-        i.e. EXACTLY `count` completions with the pipeline full on both sides.  Returns (seconds of the window, results of
-        the timed steps in step order, seconds from start to the last completion of all lead + count + M steps)."""
-        total = lead + count + M
+    def run_pipeline(fn, lead_groups, count_groups):
+        """Steady-state throughput of the pipeline of M groups in flight: worker w takes groups w, w + M, ... of lead + count + M
+        groups (the first `lead` fill the pipeline and are untimed, the last M keep it full until the last timed group
+        completes); the timed window runs from the completion of group number `lead` to the completion of group number
+        lead + count, i.e. EXACTLY count x S registrations complete inside it with the pipeline full on both sides.
+        Returns (seconds of the window, [(step, ok, T)] of the timed steps, occupancy estimate of the same steps in seconds,
+        seconds from start to the last completion)."""
+        total = lead_groups + count_groups + M
         stamps, out = [0.0] * total, [None] * total
 
         def work(w):
-            for i in range(w, total, M):
-                out[i] = fn(i, w, i + M if i + M < total else None)
-                stamps[i] = time.perf_counter()
+            for j in range(w, total, M):
+                out[j] = fn(j, w, j + M if j + M < total else None)
+                stamps[j] = time.perf_counter()
         ths = [threading.Thread(target=work, args=(w,)) for w in range(M)]
         ts = time.perf_counter()
         for t in ths:
@@ -319,49 +338,49 @@ def main():
         for t in ths:
             t.join()
         done = sorted(stamps)
-        window = done[lead + count - 1] - done[lead - 1]
-        # the timed steps = the `count` steps that completed inside the window
-        order = sorted(range(total), key=lambda i: stamps[i])[lead:lead + count]
-        # Each worker completes its steps back to back, so step i occupied its worker from stamps[i - M] to stamps[i]; with
-        # M steps always in flight the rate is M / (mean occupancy of the timed steps) (Little's law).  The M workers complete
-        # in bursts, so the bare window over few steps (the driver's 20 = 2.5 rounds of 8) swings by +-15 % with where the
-        # bursts fall; the occupancy form times the same `count` steps without that edge effect and equals count / window
-        # over long runs (both are reported).
-        occupancy = sum(stamps[i] - (stamps[i - M] if i >= M else ts) for i in order) / count
-        run_pipeline.last_window = window
-        return count * occupancy / M, [out[i] for i in sorted(order)], sorted(order), done[-1] - ts
+        window = done[lead_groups + count_groups - 1] - done[lead_groups - 1]
+        order = sorted(range(total), key=lambda j: stamps[j])[lead_groups:lead_groups + count_groups]
+        # secondary estimator (Little's law): a group occupied its worker from stamps[j - M] to stamps[j]; with M groups
+        # always in flight the rate is M * S / (mean occupancy of the timed groups)
+        occupancy = sum(stamps[j] - (stamps[j - M] if j >= M else ts) for j in order) / count_groups
+        steps = []
+        for j in sorted(order):
+            for q, i in enumerate(members(j)):
+                steps.append((i, bool(out[j][q][0]), out[j][q][1]))
+        return window, steps, count_groups * occupancy / M, done[-1] - ts
 
-    # warm-up: every worker (context) registers every distinct pair once through BOTH entry points, so that no first-use
-    # allocation or graph capture falls into the timed region; the W warm-up steps the driver asks for are the lead-in
-    # of the pipelined run below (at least one per context in flight)
+    # warm-up: every worker (context) registers every group composition once through BOTH entry points, so that no
+    # first-use allocation or graph capture falls into the timed region; the W warm-up steps the driver asks for are part
+    # of the lead-in of the pipelined run below
     def warm_worker(w):
-        for r in range(len(pairs)):
-            step(r, w)
-            hstep(r, w, None)
+        for j in range(NP):
+            rgroup(j, w, None)
+            hgroup(j, w, None)
     wths = [threading.Thread(target=warm_worker, args=(w,)) for w in range(M)]
     for t in wths:
         t.start()
     for t in wths:
         t.join()
     # lead-in: the W warm-up steps the driver asks for, and at least 8 rounds of the M workers -- they start in lock step
-    # (all in the same stage at once, competing for the same units) and need a few rounds to spread out over the
-    # stages; the first two rounds run 20 % slower than the steady state the metric is quoted on
-    lead = max(args.warmup, int(os.environ.get("BENCH_LEAD_ROUNDS", "8")) * M)
+    # (all in the same stage at once, competing for the same units) and need a few rounds to spread out over the stages
+    lead_groups = max((args.warmup + S - 1) // S, int(os.environ.get("BENCH_LEAD_ROUNDS", "8")) * M)
     device_sync()
     if world > 1:
         dist.barrier()
     device_sync()
     cpu0, thr0 = time.process_time(), _cgroup_throttle()
     t_begin = time.perf_counter()
-    # K = --steps timed steps; a pipeline of M workers is not sampled fairly by fewer than ~16 rounds (the driver's 20 steps are
-    # 2.5 rounds of 8: +-9 % from run to run by either estimator), so at least 16 * M steps are timed and the PER-STEP time of
-    # those is what the line reports (`pipeline.timed_steps` says how many; ms_per_step and value are per-step quantities)
-    n_timed = max(args.steps, 16 * M)
-    elapsed, timed, timed_ids, span = run_pipeline(hstep, lead, n_timed)
-    host_window = run_pipeline.last_window
+    # K = --steps; a pipeline of M x S registrations in flight is not sampled fairly by fewer than ~32 rounds of it (the driver's
+    # 20 steps are little more than ONE round of 16), so at least 32 * M * S steps are timed, in whole groups; `steps` on the
+    # line is the number of steps really timed, `requested_steps` echoes K
+    timed_groups = (max(args.steps, 32 * RIF) + S - 1) // S
+    n_timed = timed_groups * S
+    window, timed, occ_elapsed, span = run_pipeline(hgroup, lead_groups, timed_groups)
+    elapsed = window
     cpu1, thr1 = time.process_time(), _cgroup_throttle()
-    oks = [bool(r[0]) for r in timed]
-    results = [r[1] for r in timed]
+    timed_ids = [t[0] for t in timed]
+    oks = [t[1] for t in timed]
+    results = [t[2] for t in timed]
     n_ok = sum(oks)
     # gather the per-pair 4x4 results on rank 0 in input order (the only exchange the path needs;
     # plade_amd/batch.py, covered on CPU by tests/test_distributed_gloo.py with gloo)
@@ -375,35 +394,37 @@ def main():
     bracketed = time.perf_counter() - t_begin
     total_ok = n_ok
     if world > 1:
-        tmax = torch.tensor([elapsed, bracketed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed, bracketed, occ_elapsed], dtype=torch.float64, device=dev)
         okt = torch.tensor([n_ok], dtype=torch.int64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(okt, op=dist.ReduceOp.SUM)
-        elapsed, bracketed = float(tmax[0].item()), float(tmax[1].item())
+        elapsed, bracketed, occ_elapsed = float(tmax[0].item()), float(tmax[1].item()), float(tmax[2].item())
         total_ok = int(okt.item())
 
-    # every registration of the same pair, whichever context ran it, must return the same bits
-    ref_result = {}
-    for k in range(len(results)):
-        ref_result.setdefault(timed_ids[k] % len(pairs), results[k])
-    identical = all(np.array_equal(results[k], ref_result[timed_ids[k] % len(pairs)]) for k in range(len(results)))
+    # every registration of the same pair, whichever context ran it and whatever its partners in the group were, must
+    # return the same bits -- and the bits of the pair registered ALONE (one plade_registration_dev per distinct pair)
+    alone = [step(k) for k in range(NP)]
+    identical = all(np.array_equal(results[k], alone[timed_ids[k] % NP][1]) and oks[k] == bool(alone[timed_ids[k] % NP][0])
+                    for k in range(len(results)))
+    ref_result = {k: alone[k][1] for k in range(NP)}
     # accuracy of the timed registrations on this rank vs the generator's ground truth
-    errs = [float(np.linalg.norm(results[k].astype(np.float64) - pairs[timed_ids[k] % len(pairs)][2])) for k in range(len(results))]
+    errs = [float(np.linalg.norm(results[k].astype(np.float64) - pairs[timed_ids[k] % NP][2])) for k in range(len(results))]
 
-    # ---- resident leg (clouds already in HBM, plade_registration_dev): the same pipeline without the uploads, reported
-    #      next to `value`
+    # ---- resident leg (clouds already in HBM, plade_registration_pairs_dev): the same pipeline without the uploads,
+    #      reported next to `value`
     resident_leg = None
     if args.resident_steps > 0:
-        r_el, r_res, r_ids, _ = run_pipeline(rstep, M, args.resident_steps)
+        r_groups = (args.resident_steps + S - 1) // S
+        r_win, r_res, _, _ = run_pipeline(rgroup, 2 * M, r_groups)
         device_sync()
-        same = all(np.array_equal(r_res[k][1], ref_result.get(r_ids[k] % len(pairs), r_res[k][1])) for k in range(len(r_res)))
-        resident_leg = {"value": args.resident_steps / r_el, "unit": "registrations/s (this rank)", "steps": args.resident_steps,
-                        "ms_per_step": r_el / args.resident_steps * 1e3, "identical_to_host_cloud_results": bool(same),
-                        "note": "clouds resident in HBM (plade_cloud_upload once, plade_registration_dev per step): no H2D, no SoA "
+        same = all(np.array_equal(T, ref_result[i % NP]) for (i, ok, T) in r_res)
+        resident_leg = {"value": r_groups * S / r_win, "unit": "registrations/s (this rank)", "steps": r_groups * S,
+                        "ms_per_step": r_win / (r_groups * S) * 1e3, "identical_to_host_cloud_results": bool(same),
+                        "note": "clouds resident in HBM (plade_cloud_upload once, plade_registration_pairs_dev per group): no H2D, no SoA "
                                 "conversion, no bounding box in the step"}
-    mb = sum(tg.nbytes + sr.nbytes for tg, sr, _ in pairs) / len(pairs) / 1e6
+    mb = sum(tg.nbytes + sr.nbytes for tg, sr, _ in pairs) / NP / 1e6
     host_leg = {"h2d_MB_per_step": mb, "pcie_GB_per_s": mb * 1e-3 * n_timed / elapsed,
-                "bracketed_value": (lead + n_timed + M) / bracketed if bracketed > 0 else None,
+                "bracketed_value": (lead_groups + timed_groups + M) * S / bracketed if bracketed > 0 else None,
                 "bracketed_note": "all lead-in + timed + tail steps of this rank over the barrier-to-barrier time (fill and drain of "
                                   "the pipeline and the result gather inside)"}
 
@@ -450,24 +471,29 @@ def main():
         stop = threading.Event()
 
         def background(w):
-            i = w
+            j = w
             while not stop.is_set():
-                step(i, w)
-                i += 1
+                rgroup(j, w, None)
+                j += M
         bths = [threading.Thread(target=background, args=(w,)) for w in range(1, M)]
         for t in bths:
             t.start()
         st = {}
-        for i in range(args.profiled_steps):
-            step(i)
-            for k, v in ctx.stats().items():
-                if k.startswith(("k_", "bytes_")):
-                    st[k] = st.get(k, 0.0) + v
-                else:
-                    st[k] = v
+        # a profiled "step" is a GROUP of S pairs on context 0, as in the timed region (the scan launches of its extraction
+        # cover the 2 x S clouds of the group); every per-step figure below is per REGISTRATION: / (groups x S)
+        prof_groups = max(1, (args.profiled_steps + S - 1) // S)
+        for j in range(prof_groups):
+            rgroup(j, 0, None)
+            for q in range(S):
+                for k, v in ctx.stats(pair=q).items():
+                    if k.startswith(("k_", "bytes_")):
+                        st[k] = st.get(k, 0.0) + v
+                    elif q == 0:
+                        st[k] = v
         stop.set()
         for t in bths:
             t.join()
+        args.profiled_steps = prof_groups * S
         for k in list(st):
             if k.startswith("bytes_"):
                 st[k] /= args.profiled_steps
@@ -513,7 +539,7 @@ def main():
                         "algorithmic_bytes_per_step": by / args.profiled_steps,
                         "traffic_per_step": traffic_reg,
                         "measured": f"{how}; {args.profiled_steps} profiled registrations with "
-                                    f"{M - 1} other registrations in flight (the load of the timed region)",
+                                    f"{(M - 1) * S} other registrations in flight (the load of the timed region); launches are those of groups of {S} pairs, as timed",
                         "why_this_kernel": "largest mover of HBM bytes of the step (the K1 scoring scan, SURVEY.md 8d: 28 B per point and "
                                            "launch); kernels above it in GPU time (rocprof.top_by_gpu_time) are LDS / latency bound "
                                            "and have no HBM figure"}
@@ -551,8 +577,9 @@ def main():
             "value": total / elapsed,
             "unit": "registrations/s",
             "n_gpus": world,
-            "steps": args.steps,
+            "steps": n_timed,
             "warmup": args.warmup,
+            "requested_steps": args.steps,
             "ms_per_step": elapsed / n_timed * 1e3,
             "higher_is_better": True,
             "scaling": "weak",
@@ -561,20 +588,23 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"Synthetic {args.points}-pt indoor scan pair, ~30 planes (BASELINE configs[2]); "
                                    "full registration(T,target,source) of plade.h:58 = plane extraction + registration on clouds in "
-                                   "page-locked HOST memory, batch mode (plade_registration_next: H2D + SoA conversion + bounding boxes of "
-                                   "every step inside the timed region, the next pair's upload queued under the current pair's kernels); "
+                                   "page-locked HOST memory, batch mode (plade_registration_pairs: consecutive pairs of the batch in groups whose plane "
+                                   "extraction is one launch sequence; H2D + SoA conversion + bounding boxes of every step inside the timed "
+                                   "region, the next group's upload queued under the current group's kernels); "
                                    "timed window = EXACTLY `steps` completions of the full pipeline (steady state, SURVEY 8d); "
                                    "plade_params.orient_normals=1 (planes oriented like their inliers' normals: the generator's "
                                    "Manhattan scenes need it, DESIGN.md section 2); CPU baseline applies the same rule",
                        "points_per_cloud": args.points, "pairs_per_rank": args.pairs,
-                       "registrations_in_flight_per_gpu": M, "inflight_chosen_from_cpu_quota": inflight_auto, "host_wait": args.host_wait,
-                       "parallelism": f"independent pairs sharded over {world} GPU(s), {M} in flight per GPU"},
+                       "groups_in_flight_per_gpu": M, "pairs_per_group": S, "registrations_in_flight_per_gpu": RIF,
+                       "inflight_chosen_from_cpu_quota": inflight_auto, "host_wait": args.host_wait,
+                       "inflight_for_local_world_8": inflight_for_budget(_cpu_budget(), 8),
+                       "parallelism": f"independent pairs sharded over {world} GPU(s), {M} groups of {S} pairs in flight per GPU"},
             "single_registration_latency_ms": latency_ms,
             "registrations_timed": total,
             "registrations_ok": total_ok,
-            "results_bit_identical_per_pair_rank0": bool(identical),
+            "results_bit_identical_to_the_pair_alone_rank0": bool(identical),
             "max_frobenius_vs_ground_truth_rank0": max(errs) if errs else None,
-            "host_rank0": {"cpu_seconds_per_step": (cpu1 - cpu0) / (lead + n_timed + M),
+            "host_rank0": {"cpu_seconds_per_step": (cpu1 - cpu0) / ((lead_groups + timed_groups + M) * S),
                            "busy_host_threads_avg": (cpu1 - cpu0) / max(span, 1e-9),
                            "cpu_budget": _cpu_budget(),
                            "cgroup_throttled_periods": (thr1[0] - thr0[0]) if thr0 and thr1 else None,
@@ -582,13 +612,15 @@ def main():
             "host_buffers_rank0": host_leg,
             "resident_rank0": resident_leg,
             "default_mode_rank0": default_mode,
-            "pipeline": {"lead_in_steps": lead, "timed_steps": n_timed, "requested_steps": args.steps, "tail_steps": M,
-                         "timing": "the `timed_steps` = max(steps, 16 x in flight) completions after completion #lead_in, per rank, MAX over ranks: ms_per_step = mean "
-                                   "time a timed step occupied its worker / steps in flight (Little's law; = window / steps over long "
-                                   "runs, without the burst edge effect over few steps); barrier + device_sync() before the first and "
-                                   "after the last step of the run",
-                         "window_value_rank0": n_timed / host_window if host_window > 0 else None,
-                         "window_note": "steps / (completion #(lead_in + steps) - completion #lead_in) on rank 0"},
+            "pipeline": {"lead_in_steps": lead_groups * S, "timed_steps": n_timed, "requested_steps": args.steps, "tail_steps": M * S,
+                         "groups_in_flight": M, "pairs_per_group": S,
+                         "timing": "value = timed_steps / (completion of group #(lead_in + timed) - completion of group #lead_in), per rank, MAX of "
+                                   "the window over ranks: exactly `steps` registrations complete inside the window with the pipeline full on both "
+                                   "sides; barrier + device_sync() before the first and after the last step of the run.  steps = max(requested, "
+                                   "32 x registrations in flight) in whole groups",
+                         "occupancy_value": world * n_timed / occ_elapsed if occ_elapsed > 0 else None,
+                         "occupancy_note": "secondary estimator (round 3's `value`): groups in flight x pairs per group / mean time a timed "
+                                           "group occupied its worker (Little's law)"},
             "roofline": roofline,
             "cpu_baseline": cpu,
             "stage_seconds_profiled_step": stage_times,
