@@ -302,6 +302,9 @@ struct plade_ctx {
         read_arena_used = 0;
     }
     plade::ScanWork scan;
+    // the radix sort's two global digit histograms (radix_sort.hip) and the number of sorts issued on this context
+    plade::DBuf<uint32_t> sort_ghist;
+    uint32_t sort_seq = 0;
     // generic scratch
     plade::DBuf<char> scratch[8];
     plade::HBuf<char> pinned[4];

@@ -6,9 +6,12 @@
 // 12-15 stream commands for such a sort (a fill of the histogram, a fill of the look-back states and a fill of the
 // tile counter per digit, the histogram, its scan, the passes); with ~14 sorts per registration that was a fifth of
 // the GPU time of a registration and an eighth of its commands.  Here:
-//   k_rs_histogram  128 workgroups count all digits of all passes into per-workgroup partial histograms (plain
-//                   stores, so nothing has to be zeroed beforehand) and clear the look-back states and tile
-//                   counters of every pass;
+//   k_rs_histogram  128 workgroups count all digits of all passes in LDS and add their counts to ONE global histogram
+//                   (integer atomics: order-independent), and clear the look-back states and tile counters of every
+//                   pass.  The histogram lives in one of two buffers of the context that take turns from sort to sort:
+//                   the passes of a sort zero the buffer of the NEXT one, so nothing has to be zeroed by a command.
+//                   (r3 wrote per-workgroup partial histograms and every tile of every pass summed all 128 of them per
+//                   digit: 256 KB of loads per tile, twice the traffic of the keys themselves.)
 //   k_rs_pass       "onesweep": a workgroup takes the next tile (atomic ticket, so every predecessor is already
 //                   running), ranks its 8192 keys (512 lanes x 16) by digit (wave-level match via 8 ballots per key: stable),
 //                   publishes its digit counts, resolves its exclusive prefix by decoupled look-back over the
@@ -41,10 +44,10 @@ constexpr uint32_t RS_AGG = 1u << 30, RS_PREFIX = 2u << 30, RS_VALUE = (1u << 30
 template <int DB, class K>
 __device__ __forceinline__ uint32_t digit_of(K key, int shift) { return (uint32_t)(key >> shift) & ((1u << DB) - 1u); }
 
-// part[b][p][d]: keys of digit d at place p seen by workgroup b
+// ghist[p][d]: keys of digit d at place p (all-zero on entry)
 template <class K, int DB>
 __global__ __launch_bounds__(RS_THREADS) void k_rs_histogram(const K *__restrict__ keys, uint32_t n, int passes,
-                                                             uint32_t *__restrict__ part, uint32_t *__restrict__ tile_ctr,
+                                                             uint32_t *__restrict__ ghist, uint32_t *__restrict__ tile_ctr,
                                                              uint32_t *__restrict__ look, size_t look_words) {
     constexpr int NB = 1 << DB;
     __shared__ uint32_t s_h[RS_MAXP * NB];
@@ -69,14 +72,15 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_histogram(const K *__restrict
                 for (int p = 0; p < passes; ++p) atomicAdd(&s_h[p * NB + digit_of<DB>(k[j], DB * p)], 1u);
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < passes * NB; i += RS_THREADS) part[(size_t)blockIdx.x * (RS_MAXP * NB) + i] = s_h[i];
+    for (int i = threadIdx.x; i < passes * NB; i += RS_THREADS) { const uint32_t c = s_h[i]; if (c) atomicAdd(&ghist[i], c); }
 }
 
 template <class K, int DB, int RS_IPT>
 __global__ __launch_bounds__(RS_THREADS) void k_rs_pass(const K *__restrict__ kin, K *__restrict__ kout,
                                                         const uint32_t *__restrict__ vin, uint32_t *__restrict__ vout,
-                                                        uint32_t n, int pass, const uint32_t *__restrict__ part,
-                                                        uint32_t *__restrict__ tile_ctr, uint32_t *__restrict__ look) {
+                                                        uint32_t n, int pass, const uint32_t *__restrict__ ghist,
+                                                        uint32_t *__restrict__ ghist_next, uint32_t *__restrict__ tile_ctr,
+                                                        uint32_t *__restrict__ look) {
     constexpr int NB = 1 << DB;
     constexpr int RS_TILE = RS_THREADS * RS_IPT;
     static_assert(NB <= RS_THREADS, "one lane per digit");
@@ -91,14 +95,16 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_pass(const K *__restrict__ ki
     const int shift = DB * pass;
     if (tid == 0) s_tile = atomicAdd(&tile_ctr[pass], 1u);
     for (int i = tid; i < RS_WAVES * NB; i += RS_THREADS) (&s_cnt[0][0])[i] = 0;
-    // threads 0..NB-1 own one digit each.  Keys of that digit in the whole array = sum of the histogram partials
-    // (independent of the tile: issued first, the latency hides behind the ticket and the key loads)
+    // threads 0..NB-1 own one digit each.  Keys of that digit in the whole array: the global histogram (independent of the
+    // tile: issued first, the latency hides behind the ticket and the key loads)
     const bool owner = tid < NB;
-    uint32_t total = 0;
-    if (owner)
-        for (int b = 0; b < RS_HBLOCKS; ++b) total += part[(size_t)b * (RS_MAXP * NB) + pass * NB + tid];
+    const uint32_t total = owner ? ghist[pass * NB + tid] : 0u;
     __syncthreads();
     const uint32_t tile = s_tile;
+    // the first tile of the first pass leaves the OTHER histogram buffer all-zero for the next sort of this context (its last
+    // user, the previous sort on this stream, has finished)
+    if (pass == 0 && tile == 0)
+        for (int i = tid; i < RS_MAXP * 512; i += RS_THREADS) ghist_next[i] = 0u;
     const uint32_t base = tile * RS_TILE + wave * (64 * RS_IPT);   // this wave's 1024 consecutive keys
 
     // ---- load + stable rank inside the wave ------------------------------------------------------
@@ -206,15 +212,23 @@ void radix_sort_run_ipt(plade_ctx *ctx, const K *ki, K *ko, const uint32_t *vi, 
     constexpr int RS_TILE = RS_THREADS * RS_IPT;
     if (n == 0) return;   // no tiles: nothing to launch
     const uint32_t tiles = cdiv(n, RS_TILE);
-    const size_t part_words = (size_t)RS_HBLOCKS * RS_MAXP * NB, look_words = (size_t)passes * tiles * NB;
-    // scratch: partial histograms | tile counters | look-back states | key ping buffer | value ping buffer
-    const size_t off_ctr = part_words, off_look = off_ctr + 64, off_keys = (off_look + look_words + 3) & ~(size_t)3;
+    const size_t look_words = (size_t)passes * tiles * NB;
+    // scratch: tile counters | look-back states | key ping buffer | value ping buffer
+    const size_t off_ctr = 0, off_look = off_ctr + 64, off_keys = (off_look + look_words + 3) & ~(size_t)3;
     const size_t key_words = (n * sizeof(K) + 3) / 4, off_vals = (off_keys + key_words + 3) & ~(size_t)3;
     uint32_t *t = reinterpret_cast<uint32_t *>(ctx->scratch[7].ensure((off_vals + n + 64) * 4 + 256));
     K *tk = reinterpret_cast<K *>(t + off_keys);
     uint32_t *tv = t + off_vals;
     hipStream_t st = ctx->stream;
-    hipLaunchKernelGGL((k_rs_histogram<K, DB>), dim3(RS_HBLOCKS), dim3(RS_THREADS), 0, st, ki, (uint32_t)n, passes, t, t + off_ctr,
+    // the two global histograms of this context (see the header): zeroed once, then by the sorts themselves
+    constexpr size_t GH = (size_t)RS_MAXP * 512;
+    if (!ctx->sort_ghist.p) {
+        ctx->sort_ghist.ensure(2 * GH);
+        HIP_TRY(hipMemsetAsync(ctx->sort_ghist.p, 0, 2 * GH * 4, st));
+    }
+    uint32_t *gh = ctx->sort_ghist.p + (ctx->sort_seq & 1u) * GH, *gh_next = ctx->sort_ghist.p + ((ctx->sort_seq + 1u) & 1u) * GH;
+    ctx->sort_seq += 1;
+    hipLaunchKernelGGL((k_rs_histogram<K, DB>), dim3(RS_HBLOCKS), dim3(RS_THREADS), 0, st, ki, (uint32_t)n, passes, gh, t + off_ctr,
                        t + off_look, look_words);
     const K *src_k = ki;
     const uint32_t *src_v = vi;
@@ -222,8 +236,8 @@ void radix_sort_run_ipt(plade_ctx *ctx, const K *ki, K *ko, const uint32_t *vi, 
         const bool to_out = ((passes - 1 - p) & 1) == 0;    // the last pass lands in the caller's output
         K *dst_k = to_out ? ko : tk;
         uint32_t *dst_v = to_out ? vo : tv;
-        hipLaunchKernelGGL((k_rs_pass<K, DB, RS_IPT>), dim3(tiles), dim3(RS_THREADS), 0, st, src_k, dst_k, src_v, dst_v, (uint32_t)n, p, t,
-                           t + off_ctr, t + off_look + (size_t)p * tiles * NB);
+        hipLaunchKernelGGL((k_rs_pass<K, DB, RS_IPT>), dim3(tiles), dim3(RS_THREADS), 0, st, src_k, dst_k, src_v, dst_v, (uint32_t)n, p, gh,
+                           gh_next, t + off_ctr, t + off_look + (size_t)p * tiles * NB);
         src_k = dst_k;
         src_v = dst_v;
     }

@@ -90,10 +90,40 @@ struct ChainHdr {
 // goes from one cloud size to the next; the VARIABLE one holds the arrays whose size follows the cloud, at the byte
 // offsets below (a function of the cloud size only).
 constexpr uint64_t F_BMP = 4096, F_TMP = F_BMP + CC_MAXPIX, F_LABEL = F_TMP + CC_MAXPIX, F_SIZES = F_LABEL + 4ull * CC_MAXPIX,
-                   F_BYTES = F_SIZES + 4ull * CC_MAXPIX;
+                   F_AGG = F_SIZES + 4ull * CC_MAXPIX;
+// Aggregates of a chain's score list, accumulated by the mark pass with integer / order-independent atomics (so that the
+// result does not depend on the order the tiles finish in) and consumed by the compaction pass that follows: list length,
+// bounding box of the (u, v) parameters, and the list's entries per SUPERTILE of 32 tiles.  With them a compaction workgroup
+// finds the offset of a tile from <= nb / 32 + 31 numbers instead of re-reading the counts and boxes of all nb tiles (r3:
+// every one of ~2000 workgroups per launch read ~1000 counts and up to ~300 boxes: more traffic than the compaction itself).
+// All-zero = empty; the labelling kernel of the slot zeroes what the mark pass added (as it does for the bitmap).
+constexpr int SUP_SHIFT = 5;
+constexpr uint32_t AGG_MAX_SUP = 1u << 16;       // supertiles (2^16 x 32 tiles x 1024 points: any cloud below 2^31 points)
+struct ChainAgg {
+    uint32_t tot;                    // list length
+    uint32_t bb[4];                  // ~enc(min u), ~enc(min v), enc(max u), enc(max v): enc = order-preserving float -> u32, 0 = none
+    uint32_t pad[3];
+    uint32_t sup[AGG_MAX_SUP];
+};
+constexpr uint64_t F_BYTES = F_AGG + ((sizeof(ChainAgg) + 255) & ~255ull);
+__device__ __forceinline__ uint32_t enc_f(float x) { const uint32_t u = __float_as_uint(x); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+__device__ __forceinline__ float dec_f(uint32_t e) { return __uint_as_float((e & 0x80000000u) ? (e & 0x7fffffffu) : ~e); }
+__device__ __forceinline__ void agg_add(ChainAgg *agg, uint32_t tile, uint32_t tot, float mnu, float mnv, float mxu, float mxv) {
+    atomicAdd(&agg->tot, tot);
+    atomicAdd(&agg->sup[tile >> SUP_SHIFT], tot);
+    atomicMax(&agg->bb[0], ~enc_f(mnu));
+    atomicMax(&agg->bb[1], ~enc_f(mnv));
+    atomicMax(&agg->bb[2], enc_f(mxu));
+    atomicMax(&agg->bb[3], enc_f(mxv));
+}
+__device__ __forceinline__ void agg_clear(ChainAgg *agg, uint32_t nb, uint32_t tid, uint32_t nthreads) {
+    const uint32_t nsup = (nb >> SUP_SHIFT) + 1;
+    for (uint32_t q = tid; q < nsup; q += nthreads) agg->sup[q] = 0u;
+    if (tid < 8) (&agg->tot)[tid] = 0u;
+}
 struct ChainLayout {
     uint32_t nb, pad;                // tiles of the cloud
-    uint64_t masks1, bc1, bbpart, uv, bidx, part, idxA, idxA_stride, masks2, masks2_stride, bc2, bc2_stride, bytes;
+    uint64_t masks1, bc1, uv, bidx, part, idxA, idxA_stride, masks2, masks2_stride, bc2, bc2_stride, bytes;
 };
 
 struct RResult;
@@ -191,7 +221,7 @@ struct ClockScope {
 
 struct ChainPtr {
     ChainHdr *hdr;
-    uint8_t *masks1; uint32_t *bc1; float4 *bbpart; float2 *uv; uint32_t *bidx; double *part;
+    uint8_t *masks1; uint32_t *bc1; float2 *uv; uint32_t *bidx; double *part; ChainAgg *agg;
     uint8_t *bmp, *tmp; uint32_t *label, *sizes;
     char *base; const ChainLayout *L;
     __device__ __forceinline__ uint32_t *idxA(int k) const { return reinterpret_cast<uint32_t *>(base + L->idxA + k * L->idxA_stride); }
@@ -205,7 +235,7 @@ __device__ __forceinline__ ChainPtr chain_of(const RCloudArgs &C, uint32_t b) {
     p.hdr = reinterpret_cast<ChainHdr *>(fx);
     p.masks1 = reinterpret_cast<uint8_t *>(base + C.L.masks1);
     p.bc1 = reinterpret_cast<uint32_t *>(base + C.L.bc1);
-    p.bbpart = reinterpret_cast<float4 *>(base + C.L.bbpart);
+    p.agg = reinterpret_cast<ChainAgg *>(fx + F_AGG);
     p.uv = reinterpret_cast<float2 *>(base + C.L.uv);
     p.bidx = reinterpret_cast<uint32_t *>(base + C.L.bidx);
     p.part = reinterpret_cast<double *>(base + C.L.part);
@@ -226,7 +256,6 @@ ChainLayout make_layout(uint32_t n) {
     auto take = [&](uint64_t bytes) { const uint64_t at = o; o = (o + bytes + 255) & ~(uint64_t)255; return at; };
     L.masks1 = take(nb * TPB);
     L.bc1 = take((nb + 4) * 4);
-    L.bbpart = take((nb + 1) * 16);
     L.uv = take(n4 * 8);
     L.bidx = take(n4 * 4);
     L.part = take((nb + 1) * FIT_COLS * 8);
@@ -405,6 +434,8 @@ __global__ __launch_bounds__(TPB) void k_r_init(const RArgs A, const RInit I) {
         if (base + PPT <= ((C.cv.n + 3) & ~3u)) *reinterpret_cast<int4 *>(C.assigned + base) = make_int4(-1, -1, -1, -1);
     }
     if (C.sub_assigned && base + PPT <= ((C.n_sub + 3) & ~3u)) *reinterpret_cast<int4 *>(C.sub_assigned + base) = make_int4(-1, -1, -1, -1);
+    if (tile < (uint32_t)R_B) agg_clear(chain_of(C, tile).agg, C.L.nb, threadIdx.x, blockDim.x);   // (a call that died half-way left some)
+    else if (C.L.nb < (uint32_t)R_B && tile == 0) for (uint32_t b2 = C.L.nb; b2 < (uint32_t)R_B; ++b2) agg_clear(chain_of(C, b2).agg, C.L.nb, threadIdx.x, blockDim.x);
     if (tile == 0 && threadIdx.x == 0) {
         RState *S = C.st;
         S->n = C.cv.n; S->min_support = P.min_support; S->orient = P.orient; S->active = 1; S->gen = P.gen; S->topup = P.topup;
@@ -857,8 +888,9 @@ __global__ __launch_bounds__(64) void k_r_select(const RArgs A, int phase) {
 // acceptance chain, slot k: GlobalWeightedScore (Candidate.h:293-302) = score(3 eps) -> ConnectedComponent ->
 // weighted score, then the LS fit of the result list.
 //
-// (1) mark: ONE pass over the cloud for all chains of the cloud: 4-bit inlier masks per lane, per-tile counts and
-//     the per-tile bounding boxes of the inliers' (u, v) plane parameters (BitmapPrimitiveShape.h:113-126)
+// (1) mark: ONE pass over the cloud for all chains of the cloud: 4-bit inlier masks per lane, per-tile counts, and the
+//     aggregates of every chain's list (ChainAgg: length, bounding box of the inliers' (u, v) plane parameters,
+//     BitmapPrimitiveShape.h:113-126, entries per supertile)
 __global__ __launch_bounds__(TPB) void k_r_mark(const RArgs A, int k, unsigned long long *clk) {
     const ClockScope clock_scope(clk);
     __shared__ float4 s_pl[R_B];
@@ -920,10 +952,10 @@ __global__ __launch_bounds__(TPB) void k_r_mark(const RArgs A, int k, unsigned l
         const uint32_t tot = s_w[j][0] + s_w[j][1] + s_w[j][2] + s_w[j][3];
         ch.bc1[tile] = tot;
         if (tot)
-            ch.bbpart[tile] = make_float4(fminf(fminf(s_bb[j][0][0], s_bb[j][0][1]), fminf(s_bb[j][0][2], s_bb[j][0][3])),
-                                          fminf(fminf(s_bb[j][1][0], s_bb[j][1][1]), fminf(s_bb[j][1][2], s_bb[j][1][3])),
-                                          fmaxf(fmaxf(s_bb[j][2][0], s_bb[j][2][1]), fmaxf(s_bb[j][2][2], s_bb[j][2][3])),
-                                          fmaxf(fmaxf(s_bb[j][3][0], s_bb[j][3][1]), fmaxf(s_bb[j][3][2], s_bb[j][3][3])));
+            agg_add(ch.agg, tile, tot, fminf(fminf(s_bb[j][0][0], s_bb[j][0][1]), fminf(s_bb[j][0][2], s_bb[j][0][3])),
+                    fminf(fminf(s_bb[j][1][0], s_bb[j][1][1]), fminf(s_bb[j][1][2], s_bb[j][1][3])),
+                    fmaxf(fmaxf(s_bb[j][2][0], s_bb[j][2][1]), fmaxf(s_bb[j][2][2], s_bb[j][2][3])),
+                    fmaxf(fmaxf(s_bb[j][3][0], s_bb[j][3][1]), fmaxf(s_bb[j][3][2], s_bb[j][3][3])));
     }
     if (tile == 0 && threadIdx.x == 0 && active) { S->n_mark_launches += 1; S->n_mark_chains += active; }
 }
@@ -961,10 +993,10 @@ __global__ __launch_bounds__(TPB) void k_r_list_mark(const RArgs A, uint32_t m) 
         const uint32_t tot = b0 >= m ? 0u : min((uint32_t)TILE, m - b0);
         ch.bc1[tile] = tot;
         if (tot)
-            ch.bbpart[tile] = make_float4(fminf(fminf(s_bb[0][0], s_bb[0][1]), fminf(s_bb[0][2], s_bb[0][3])),
-                                          fminf(fminf(s_bb[1][0], s_bb[1][1]), fminf(s_bb[1][2], s_bb[1][3])),
-                                          fmaxf(fmaxf(s_bb[2][0], s_bb[2][1]), fmaxf(s_bb[2][2], s_bb[2][3])),
-                                          fmaxf(fmaxf(s_bb[3][0], s_bb[3][1]), fmaxf(s_bb[3][2], s_bb[3][3])));
+            agg_add(ch.agg, tile, tot, fminf(fminf(s_bb[0][0], s_bb[0][1]), fminf(s_bb[0][2], s_bb[0][3])),
+                    fminf(fminf(s_bb[1][0], s_bb[1][1]), fminf(s_bb[1][2], s_bb[1][3])),
+                    fmaxf(fmaxf(s_bb[2][0], s_bb[2][1]), fmaxf(s_bb[2][2], s_bb[2][3])),
+                    fmaxf(fmaxf(s_bb[3][0], s_bb[3][1]), fmaxf(s_bb[3][2], s_bb[3][3])));
     }
 }
 
@@ -984,23 +1016,18 @@ __device__ __forceinline__ bool cc_dims(const float bb[4], uint32_t count, float
 }
 
 // (2) compact + rasterise: the ordered score list (ascending point position) with its (u, v) parameters, and
-//     BuildBitmap (BitmapPrimitiveShape.h:139-150) with InBitmap (PlanePrimitiveShape.cpp:193-199).  Every workgroup
-//     derives the list's bounding box, its length and its own output offset from the per-tile results of the mark
-//     pass (~1e3 entries, L2 resident): no scan launch, no atomics.  The bitmap is all-zero on entry (the labelling
-//     kernel clears what it used).  grid (loop_grid(), chains of all clouds): a workgroup takes every gridDim.x-th tile (a grid
-//     of one workgroup per tile and chain was 15 000 workgroups of which a few hundred had anything to do)
-// The looped list kernels run gridDim.x workgroups per chain; a workgroup takes every gridDim.x-th tile / row, OWN_MAX of
-// them per round (the host sizes gridDim.x so that one round usually does: loop_grid()).
-
-// exclusive prefix of `cnt[0..n)` for the items this workgroup owns: pre[j] = sum of cnt[q] for q < item(j), item(j) =
-// blockIdx.x + j * gridDim.x; also the grand total.  One pass over the counts (L2 resident), per-lane partial sums per
-// owned item kept in registers, combined through LDS.  OWN_MAX owned items are handled per call.
+//     BuildBitmap (BitmapPrimitiveShape.h:139-150) with InBitmap (PlanePrimitiveShape.cpp:193-199).  The list's length and
+//     bounding box come from the aggregates of the mark pass (ChainAgg), the output offset of a tile from the supertile
+//     sums + the counts of the tiles of its own supertile: no scan launch, a few dozen loads per workgroup.  The bitmap is
+//     all-zero on entry (the labelling kernel clears what it used).  grid (loop_grid(), chains of all clouds): a workgroup
+//     owns tiles blockIdx.x, blockIdx.x + gridDim.x, ... OWN_MAX of them per round (the host sizes gridDim.x so that one
+//     round usually does: loop_grid()); a workgroup whose tiles hold nothing of the list returns after one round of loads.
 constexpr int OWN_MAX = 8;
+static_assert(OWN_MAX * 32 == TPB, "32 lanes per owned tile");
 
 __global__ __launch_bounds__(TPB) void k_r_compact_raster(const RArgs A, int k) {
-    __shared__ float s_bb[4][TPB / 64];
-    __shared__ uint32_t s_tot[TPB / 64], s_w[TPB / 64];
-    __shared__ uint32_t s_pre[OWN_MAX][TPB / 64];
+    __shared__ uint32_t s_w[TPB / 64];
+    __shared__ uint32_t s_pre[OWN_MAX], s_cnt[OWN_MAX];
     const int g = blockIdx.y / R_B;
     const uint32_t b = blockIdx.y % R_B;
     if (g >= (int)A.ng) return;
@@ -1016,58 +1043,40 @@ __global__ __launch_bounds__(TPB) void k_r_compact_raster(const RArgs A, int k) 
     if (conv) return;
     const bool lead = blockIdx.x == 0;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int oj = threadIdx.x >> 5, ol = threadIdx.x & 31;     // 32 lanes look after owned tile number oj
     uint32_t *__restrict__ idxA = ch.idxA(k);
-    // this workgroup owns tiles blockIdx.x, blockIdx.x + gridDim.x, ...: OWN_MAX of them per round
+    // the whole list: length and bounding box
+    const uint32_t tot = ch.agg->tot;
+    float bbv[4] = {INFINITY, INFINITY, -INFINITY, -INFINITY};
+    if (tot) { bbv[0] = dec_f(~ch.agg->bb[0]); bbv[1] = dec_f(~ch.agg->bb[1]); bbv[2] = dec_f(ch.agg->bb[2]); bbv[3] = dec_f(ch.agg->bb[3]); }
+    uint32_t ue, ve;
+    const bool ok = cc_dims(bbv, tot, eps, ue, ve);
+    if (lead && threadIdx.x == 0) {
+        st->ue = ue; st->ve = ve; st->n_list = tot;
+        if (!ok) st->err = 1;
+        for (int q = 0; q < 4; ++q) st->bb[q] = bbv[q];
+    }
+    if (!ok || tot == 0) return;
+    const float mnu = bbv[0], mnv = bbv[1];
     for (uint32_t t0 = blockIdx.x; t0 < nb; t0 += gridDim.x * OWN_MAX) {
-        // all tiles' counts and boxes: list length, bounding box, and the offsets of the owned tiles
-        uint32_t tot = 0, pre[OWN_MAX];
-#pragma unroll
-        for (int j = 0; j < OWN_MAX; ++j) pre[j] = 0;
-        float bbv[4] = {INFINITY, INFINITY, -INFINITY, -INFINITY};
-        for (uint32_t q = threadIdx.x; q < nb; q += TPB) {
-            const uint32_t c = ch.bc1[q];
-            tot += c;
-#pragma unroll
-            for (int j = 0; j < OWN_MAX; ++j) pre[j] += q < t0 + j * gridDim.x ? c : 0u;
-            if (c) {
-                const float4 t = ch.bbpart[q];
-                bbv[0] = fminf(bbv[0], t.x); bbv[1] = fminf(bbv[1], t.y); bbv[2] = fmaxf(bbv[2], t.z); bbv[3] = fmaxf(bbv[3], t.w);
-            }
+        // the owned tiles' counts, and for the non-empty ones the number of list entries in front of them
+        const uint32_t my_tile = t0 + (uint32_t)oj * gridDim.x;
+        const uint32_t my_cnt = my_tile < nb ? ch.bc1[my_tile] : 0u;
+        uint32_t part = 0;
+        if (my_cnt) {
+            const uint32_t ns = my_tile >> SUP_SHIFT;
+            for (uint32_t q = ol; q < ns; q += 32) part += ch.agg->sup[q];
+            for (uint32_t q = (ns << SUP_SHIFT) + ol; q < my_tile; q += 32) part += ch.bc1[q];
         }
-        for (int d = 32; d >= 1; d >>= 1) {
-            tot += __shfl_xor(tot, d, 64);
 #pragma unroll
-            for (int j = 0; j < OWN_MAX; ++j) pre[j] += __shfl_xor(pre[j], d, 64);
-            bbv[0] = fminf(bbv[0], __shfl_xor(bbv[0], d, 64)); bbv[1] = fminf(bbv[1], __shfl_xor(bbv[1], d, 64));
-            bbv[2] = fmaxf(bbv[2], __shfl_xor(bbv[2], d, 64)); bbv[3] = fmaxf(bbv[3], __shfl_xor(bbv[3], d, 64));
-        }
+        for (int d = 16; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);   // stays inside the 32-lane half
         __syncthreads();   // the previous round's readers of the LDS arrays are done
-        if (lane == 0) {
-            s_tot[wave] = tot;
-            for (int q = 0; q < 4; ++q) s_bb[q][wave] = bbv[q];
-#pragma unroll
-            for (int j = 0; j < OWN_MAX; ++j) s_pre[j][wave] = pre[j];
-        }
+        if (ol == 0) { s_pre[oj] = part; s_cnt[oj] = my_cnt; }
         __syncthreads();
-        tot = s_tot[0] + s_tot[1] + s_tot[2] + s_tot[3];
-        for (int q = 0; q < 4; ++q) {
-            float v = s_bb[q][0];
-            for (int w = 1; w < TPB / 64; ++w) v = q < 2 ? fminf(v, s_bb[q][w]) : fmaxf(v, s_bb[q][w]);
-            bbv[q] = v;
-        }
-        uint32_t ue, ve;
-        const bool ok = cc_dims(bbv, tot, eps, ue, ve);
-        if (lead && t0 == 0 && threadIdx.x == 0) {
-            st->ue = ue; st->ve = ve; st->n_list = tot;
-            if (!ok) st->err = 1;
-            for (int q = 0; q < 4; ++q) st->bb[q] = bbv[q];
-        }
-        if (!ok) return;
-        const float mnu = bbv[0], mnv = bbv[1];
         for (int j = 0; j < OWN_MAX; ++j) {
             const uint32_t tile = t0 + j * gridDim.x;
             if (tile >= nb) break;
-            if (ch.bc1[tile] == 0) continue;   // uniform; most tiles of a plane's score list are empty
+            if (s_cnt[j] == 0) continue;   // uniform; most tiles of a plane's score list are empty
             const uint32_t m = ch.masks1[tile * TPB + threadIdx.x];
             const uint32_t first = tile * TILE + threadIdx.x * PPT;
             uint32_t pv[PPT];
@@ -1090,7 +1099,7 @@ __global__ __launch_bounds__(TPB) void k_r_compact_raster(const RArgs A, int k) 
             __syncthreads();
             if (lane == 63) s_w[wave] = incl;
             __syncthreads();
-            uint32_t off = (s_pre[j][0] + s_pre[j][1] + s_pre[j][2] + s_pre[j][3]) + incl - c;
+            uint32_t off = s_pre[j] + incl - c;
             for (int w = 0; w < wave; ++w) off += s_w[w];
 #pragma unroll
             for (int q = 0; q < PPT; ++q)
@@ -1229,7 +1238,9 @@ __global__ __launch_bounds__(1024) void k_r_label(const RArgs A, int k, int do_f
     __shared__ uint32_t s_label[CC_LDS_PIX];
     __shared__ uint32_t s_sizes[CC_LDS_PIX];
     __shared__ uint8_t s_bmp[CC_LDS_PIX], s_tmp[CC_LDS_PIX];
-    if (st->converged || st->err) return;
+    if (st->converged) return;                      // the mark pass skipped this chain: nothing was added
+    agg_clear(ch.agg, C.L.nb, threadIdx.x, blockDim.x);   // the compaction pass has consumed the mark pass's aggregates
+    if (st->err) return;
     const int ue = (int)st->ue, ve = (int)st->ve, npx = ue * ve;
     if (npx <= CC_LDS_PIX) {
         for (int p = threadIdx.x; p < npx; p += blockDim.x) { s_bmp[p] = g_bmp[p]; g_bmp[p] = 0; }  // also leaves it clean
@@ -1728,6 +1739,7 @@ __global__ __launch_bounds__(TPB) void k_r_assign(const RArgs A) {
 
 // seam S1c: one chain, slot 0, from a caller-given plane
 __global__ void k_r_seam_init(const RArgs A, float4 hyp, float4 pos, float w_eps, float bitmap_eps) {
+    agg_clear(chain_of(A.c[0], 0).agg, A.c[0].L.nb, threadIdx.x, blockDim.x);
     if (threadIdx.x) return;
     const RCloudArgs &C = A.c[0];
     RState *S = C.st;
@@ -1889,6 +1901,7 @@ __global__ void k_r_seam_chains(const RArgs A, const float4 *__restrict__ planes
         S->bitmap_eps = INFINITY;   // one-pixel bitmaps: only the ordered list of the compaction is asked for
         S->n_mark_launches = S->n_mark_chains = 0;
     }
+    for (uint32_t b2 = 0; b2 < nb; ++b2) agg_clear(chain_of(C, b2).agg, C.L.nb, threadIdx.x, blockDim.x);
     if (threadIdx.x < nb) {
         ChainPtr ch = chain_of(C, threadIdx.x);
         const float4 hyp = planes[threadIdx.x], pos = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -2165,7 +2178,13 @@ void ransac_prepare(plade_ctx *ctx, RansacWork &W, const CloudDev *const clouds[
     for (int g = n_clouds; g <= R_G; ++g) M.start[g] = G.start[g] = (uint32_t)total;
     W.keys_in.ensure(total); W.vals_in.ensure(total); W.keys.ensure(total); W.perm.ensure(total);
     hipLaunchKernelGGL(k_morton, dim3(cdiv(total, 256)), dim3(256), 0, ctx->stream, M, W.keys_in.p, W.vals_in.p);
-    sort_pairs_u32(ctx, W.keys_in.p, W.keys.p, W.vals_in.p, W.perm.p, total, n_clouds > 4 ? 27 : n_clouds > 2 ? 26 : n_clouds > 1 ? 25 : 24);
+    // One sort per PAIR of clouds (the slot bits above bit 24 are equal inside a pair's range): a radix pass over the ~2M keys of
+    // a pair takes 58 us, one over the 8M keys of a group of four pairs 426 us (its look-back chain runs over four times the
+    // tiles) -- 4 x 3 short passes beat 3 long ones by 0.5 ms per group
+    for (int g = 0; g < n_clouds; g += 2) {
+        const uint32_t b = M.start[g], e = M.start[std::min(g + 2, n_clouds)];
+        if (e > b) sort_pairs_u32(ctx, W.keys_in.p + b, W.keys.p + b, W.vals_in.p + b, W.perm.p + b, e - b, g + 1 < n_clouds ? 25 : 24);
+    }
     hipLaunchKernelGGL(k_gather_cloud, dim3(cdiv(total, 256)), dim3(256), 0, ctx->stream, G, W.keys.p, W.perm.p);
     Cells6Args C6;
     memset(&C6, 0, sizeof(C6));
