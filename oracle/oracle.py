@@ -75,14 +75,28 @@ class Oracle:
         L.orc_registration.argtypes = [_p, _p, _i, _p, _i, _p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _p]
         L.orc_registration_sampled.argtypes = [_p, _p, _i, _p, _i, _p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _p]
         L.orc_dump_get.argtypes = [_p, C.c_char_p, _p, _p]
-        L.orc_set_closest_point_noise.argtypes = [C.c_double, C.c_uint64]
+        L.orc_set_closest_point_mode.argtypes = [_i]
+        L.orc_intersection_point.argtypes = [_p, _p, _p, _p, _p]
+        L.orc_solve_svd_f32.argtypes = [_p, _p, _p, _i, _i]
         L.orc_cluster_transforms.argtypes = [_p, _p, _i, _f, _f, _p]
         L.orc_euler_angles.argtypes = [_p, _p]
         L.orc_pen_walk.argtypes = [_p, _i, _p, _i, _p, _p, _p, _f, _f, _f, _p, _p, _p]
 
-    def set_closest_point_noise(self, amp, seed=0):
-        """Tests only: perturb the closest points of every line pair by up to amp per coordinate (0 = off)."""
-        self.L.orc_set_closest_point_noise(float(amp), int(seed))
+    def set_closest_point_mode(self, mode):
+        """0 / "closed_form": exact fp64 closed form (default, = the HIP path); 1 / "svd_fp32": the reference's fp32 cv::solve
+        (DECOMP_SVD) restated from OpenCV 2.4 (util.cpp:1183-1226, 1467-1497)."""
+        self.L.orc_set_closest_point_mode(1 if mode in (1, "svd_fp32") else 0)
+
+    def intersection_point(self, v1, p1, v2, p2):
+        out = np.zeros(3, np.float32)
+        rc = self.L.orc_intersection_point(_ptr(_f32(v1)), _ptr(_f32(p1)), _ptr(_f32(v2)), _ptr(_f32(p2)), _ptr(out))
+        return rc, out
+
+    def solve_svd_f32(self, A, B):
+        A = _f32(A); B = _f32(B).reshape(-1)
+        X = np.zeros(A.shape[1], np.float32)
+        self.L.orc_solve_svd_f32(_ptr(A), _ptr(B), _ptr(X), A.shape[0], A.shape[1])
+        return X
 
     # -- A9 / A11 pieces (G10, G11) ---------------------------------------------
     def euler_angles(self, R):

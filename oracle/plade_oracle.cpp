@@ -17,10 +17,13 @@
 //   "parity unpinned" (PCL / PLADE glue cannot be compiled here: no Boost):
 //     VoxelGrid ordering, clustering, plane-consistency, penetration filter and
 //     the driver plade.cpp:31-580 are restated from source reading only.
-//   deliberate deviation: closest points of two lines use the exact closed form
-//     in fp64 instead of OpenCV's fp32 9x9 / 6x5 SVD solves (util.cpp:1183-1226,
-//     1467-1497; OpenCV 2.4 core needs cmake-generated headers => unbuildable
-//     here).  Survey probe: |delta| <= 8.8e-5 at 10 m scale.
+//   closest points of two lines (util.cpp:1183-1226, 1467-1497): two modes (orc_set_closest_point_mode).
+//     mode 0 (default, what the HIP path computes): the exact closed form in fp64;
+//     mode 1 "svd_fp32": cv::solve(A, B, X, DECOMP_SVD) restated operation for operation --
+//     JacobiSVDImpl_<float> + SVBkSbImpl_ of OpenCV 2.4 (3rd_party/opencv/modules/core/src/lapack.cpp:
+//     533-710, 751-812, 1335-1460), driven exactly like the reference.  OpenCV itself cannot be
+//     built here (cmake-generated headers), so mode 1 is "restated, unpinned by a build"; it measures
+//     what the closed form changes downstream (tests/test_oracle_golden.py::test_a6_*).
 #include "plade_oracle.h"
 #include "orc_math.h"
 
@@ -617,18 +620,152 @@ int intersection_line(const float *pl1, const float *pl2, V3 &vec, V3 &pt) {
     return 0;
 }
 
-// Sensitivity switch (tests only, orc_set_closest_point_noise): every closest point is moved by a pseudo-random vector of
-// up to `amp` per coordinate -- the size of the error the reference's fp32 9x9 SVD solve makes against the exact answer
-// (8.8e-5 for coordinates up to 10).  With it the tests bound what the one forced arithmetic deviation
-// of this restatement (closed form instead of cv::solve, which does not build here) can change downstream.
-static double g_cp_noise_amp = 0.0;
-static uint64_t g_cp_noise_seed = 0;
-inline float cp_noise(const V3 &p1, const V3 &p2, uint64_t k) {
-    uint32_t b[6];
-    memcpy(b, &p1, 12); memcpy(b + 3, &p2, 12);
-    uint64_t z = g_cp_noise_seed + 0x9E3779B97F4A7C15ull * (k + 1);
-    for (int i = 0; i < 6; ++i) { z ^= b[i]; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31; }
-    return (float)(g_cp_noise_amp * (2.0 * (double)(z >> 11) / 9007199254740992.0 - 1.0));
+// ---------------------------------------------------------------------------------------------------------------
+// cv::solve(A, B, X, cv::DECOMP_SVD) for CV_32F and one right-hand side, restated from OpenCV 2.4
+// (code/3rd_party/opencv/modules/core/src/lapack.cpp): cv::solve :1335-1460 transposes A into `At` (n rows of m),
+// runs JacobiSVD(At, w, Vt, m, n) (:533-699, the one-sided Jacobi of Hestenes on the rows of At; float data, double
+// accumulators, eps = FLT_EPSILON * 2, minval = FLT_MIN, at most max(m, 30) sweeps) and back-substitutes with
+// SVBkSb(m, n, w, u = At (uT), v = Vt (vT), b, nb = 1) (:751-812, eps = (float)(DBL_EPSILON * 2)).
+// The SSE2 paths of VBLAS<float>::givens (:421-437) perform the same fp32 operations as the scalar tail, lane by lane.
+static int g_cp_mode = 0;            // 0 closed form (fp64), 1 svd_fp32
+
+struct CvRng {                       // cv::RNG (core/operations.hpp: MWC, state * 4164903690 + carry)
+    uint64_t state;
+    unsigned next() { state = (uint64_t)(unsigned)state * 4164903690U + (unsigned)(state >> 32); return (unsigned)state; }
+};
+
+// At: n rows of m floats (row stride m); W: n; Vt: n x n
+void cv_jacobi_svd_f32(float *At, float *_W, float *Vt, int m, int n) {
+    const double minval = FLT_MIN;
+    const float eps = FLT_EPSILON * 2;
+    const int n1 = n;
+    std::vector<double> W(n);
+    int i, j, k, iter, max_iter = std::max(m, 30);
+    float c, s;
+    double sd;
+    for (i = 0; i < n; i++) {
+        for (k = 0, sd = 0; k < m; k++) { float t = At[i * m + k]; sd += (double)t * t; }
+        W[i] = sd;
+        for (k = 0; k < n; k++) Vt[i * n + k] = 0;
+        Vt[i * n + i] = 1;
+    }
+    for (iter = 0; iter < max_iter; iter++) {
+        bool changed = false;
+        for (i = 0; i < n - 1; i++)
+            for (j = i + 1; j < n; j++) {
+                float *Ai = At + i * m, *Aj = At + j * m;
+                double a = W[i], p = 0, b = W[j];
+                for (k = 0; k < m; k++) p += (double)Ai[k] * Aj[k];
+                if (std::abs(p) <= eps * std::sqrt((double)a * b)) continue;
+                p *= 2;
+                double beta = a - b, gamma = hypot((double)p, beta);
+                if (beta < 0) {
+                    double delta = (gamma - beta) * 0.5;
+                    s = (float)std::sqrt(delta / gamma);
+                    c = (float)(p / (gamma * s * 2));
+                } else {
+                    c = (float)std::sqrt((gamma + beta) / (gamma * 2));
+                    s = (float)(p / (gamma * c * 2));
+                }
+                a = b = 0;
+                for (k = 0; k < m; k++) {
+                    float t0 = c * Ai[k] + s * Aj[k];
+                    float t1 = -s * Ai[k] + c * Aj[k];
+                    Ai[k] = t0; Aj[k] = t1;
+                    a += (double)t0 * t0; b += (double)t1 * t1;
+                }
+                W[i] = a; W[j] = b;
+                changed = true;
+                float *Vi = Vt + i * n, *Vj = Vt + j * n;
+                for (k = 0; k < n; k++) {
+                    float t0 = c * Vi[k] + s * Vj[k];
+                    float t1 = -s * Vi[k] + c * Vj[k];
+                    Vi[k] = t0; Vj[k] = t1;
+                }
+            }
+        if (!changed) break;
+    }
+    for (i = 0; i < n; i++) {
+        for (k = 0, sd = 0; k < m; k++) { float t = At[i * m + k]; sd += (double)t * t; }
+        W[i] = std::sqrt(sd);
+    }
+    for (i = 0; i < n - 1; i++) {
+        j = i;
+        for (k = i + 1; k < n; k++) if (W[j] < W[k]) j = k;
+        if (i != j) {
+            std::swap(W[i], W[j]);
+            for (k = 0; k < m; k++) std::swap(At[i * m + k], At[j * m + k]);
+            for (k = 0; k < n; k++) std::swap(Vt[i * n + k], Vt[j * n + k]);
+        }
+    }
+    for (i = 0; i < n; i++) _W[i] = (float)W[i];
+    CvRng rng{0x12345678};
+    for (i = 0; i < n1; i++) {
+        sd = i < n ? W[i] : 0;
+        while (sd <= minval) {
+            // a zero singular value: a random vector, orthogonalised against the left singular vectors found so far
+            const float val0 = (float)(1. / m);
+            for (k = 0; k < m; k++) { float val = (rng.next() & 256) != 0 ? val0 : -val0; At[i * m + k] = val; }
+            for (iter = 0; iter < 2; iter++)
+                for (j = 0; j < i; j++) {
+                    sd = 0;
+                    for (k = 0; k < m; k++) sd += At[i * m + k] * At[j * m + k];
+                    float asum = 0;
+                    for (k = 0; k < m; k++) {
+                        float t = (float)(At[i * m + k] - sd * At[j * m + k]);
+                        At[i * m + k] = t;
+                        asum += std::abs(t);
+                    }
+                    asum = asum > eps * 100 ? 1 / asum : 0;
+                    for (k = 0; k < m; k++) At[i * m + k] *= asum;
+                }
+            sd = 0;
+            for (k = 0; k < m; k++) { float t = At[i * m + k]; sd += (double)t * t; }
+            sd = std::sqrt(sd);
+        }
+        s = (float)(1 / sd);
+        for (k = 0; k < m; k++) At[i * m + k] *= s;
+    }
+}
+
+// x (n) = V * inv(W) * U^T * b for one right-hand side; u = At rows (uT), v = Vt rows (vT)
+void cv_svbksb_f32(int m, int n, const float *w, const float *u, const float *v, const float *b, float *x) {
+    const float eps = (float)(DBL_EPSILON * 2);
+    double threshold = 0;
+    const int nm = std::min(m, n);
+    for (int i = 0; i < n; i++) x[i] = 0;
+    for (int i = 0; i < nm; i++) threshold += w[i];
+    threshold *= eps;
+    for (int i = 0; i < nm; i++, u += m, v += n) {
+        double wi = w[i];
+        if ((double)std::abs(wi) <= threshold) continue;
+        wi = 1 / wi;
+        double s = 0;
+        for (int j = 0; j < m; j++) s += u[j] * b[j];     // float product, double accumulator (lapack.cpp:791-793)
+        s *= wi;
+        for (int j = 0; j < n; j++) x[j] = (float)(x[j] + s * v[j]);
+    }
+}
+
+// A: m x n row-major, B: m, X: n
+void cv_solve_svd_f32(const float *A, const float *B, float *X, int m, int n) {
+    std::vector<float> At((size_t)n * m), W(n), Vt((size_t)n * n);
+    for (int r = 0; r < m; ++r) for (int c = 0; c < n; ++c) At[(size_t)c * m + r] = A[(size_t)r * n + c];   // transpose(src, a)
+    cv_jacobi_svd_f32(At.data(), W.data(), Vt.data(), m, n);
+    cv_svbksb_f32(m, n, W.data(), At.data(), Vt.data(), B, X);
+}
+
+// the 9 x 9 system of util.cpp:1183-1220 and its solution (point1 = X[0..2], point2 = X[4..6])
+void closest_points_svd(const V3 &u1, const V3 &p1, const V3 &u2, const V3 &p2, const V3 &dir, V3 &q1, V3 &q2) {
+    float A[81] = {0}, B[9] = {0}, X[9];
+    auto a = [&](int r, int c) -> float & { return A[r * 9 + c]; };
+    a(0, 0) = 1; a(0, 3) = -u1.x; a(1, 1) = 1; a(1, 3) = -u1.y; a(2, 2) = 1; a(2, 3) = -u1.z;
+    a(3, 4) = 1; a(3, 7) = -u2.x; a(4, 5) = 1; a(4, 7) = -u2.y; a(5, 6) = 1; a(5, 7) = -u2.z;
+    a(6, 0) = -1; a(6, 4) = 1; a(6, 8) = -dir.x; a(7, 1) = -1; a(7, 5) = 1; a(7, 8) = -dir.y; a(8, 2) = -1; a(8, 6) = 1; a(8, 8) = -dir.z;
+    B[0] = p1.x; B[1] = p1.y; B[2] = p1.z; B[3] = p2.x; B[4] = p2.y; B[5] = p2.z;
+    cv_solve_svd_f32(A, B, X, 9, 9);
+    q1 = V3(X[0], X[1], X[2]);
+    q2 = V3(X[4], X[5], X[6]);
 }
 
 // ComputeNearstTwoPointsOfTwo3DLine (code/PLADE/util.cpp:1167-1229).
@@ -638,6 +775,13 @@ int closest_points(V3 &u1, const V3 &p1, V3 &u2, const V3 &p2, V3 &q1, V3 &q2, d
     normalize(u1);
     normalize(u2);
     if (u1.x == u2.x && u1.y == u2.y && u1.z == u2.z) return -1;
+    if (g_cp_mode == 1) {   // util.cpp:1176-1226 with the real solver's arithmetic
+        V3 dir = cross(u1, u2);
+        normalize(dir);
+        closest_points_svd(u1, p1, u2, p2, dir, q1, q2);
+        len = norm(q1 - q2);
+        return 0;
+    }
     double ax = u1.x, ay = u1.y, az = u1.z, bx = u2.x, by = u2.y, bz = u2.z;
     double wx = (double)p1.x - p2.x, wy = (double)p1.y - p2.y, wz = (double)p1.z - p2.z;
     double a = ax * ax + ay * ay + az * az;
@@ -650,10 +794,6 @@ int closest_points(V3 &u1, const V3 &p1, V3 &u2, const V3 &p2, V3 &q1, V3 &q2, d
     double t2 = (a * e - b * d) / den;
     q1 = V3((float)(p1.x + t1 * ax), (float)(p1.y + t1 * ay), (float)(p1.z + t1 * az));
     q2 = V3((float)(p2.x + t2 * bx), (float)(p2.y + t2 * by), (float)(p2.z + t2 * bz));
-    if (g_cp_noise_amp > 0.0) {
-        q1 = q1 + V3(cp_noise(p1, p2, 0), cp_noise(p1, p2, 1), cp_noise(p1, p2, 2));
-        q2 = q2 + V3(cp_noise(p1, p2, 3), cp_noise(p1, p2, 4), cp_noise(p1, p2, 5));
-    }
     len = norm(q1 - q2);  // (point1 - point2).norm() in float, widened
     return 0;
 }
@@ -663,6 +803,15 @@ int closest_points(V3 &u1, const V3 &p1, V3 &u2, const V3 &p2, V3 &q1, V3 &q2, d
 // DEVIATION from the fp32 6x5 SVD solve).
 int intersection_point_2lines(const V3 &v1, const V3 &p1, const V3 &v2, const V3 &p2, V3 &out) {
     if (std::fabs(dot(v1, v2)) > 0.9999) return -1;
+    if (g_cp_mode == 1) {   // the 6 x 5 system of util.cpp:1467-1497
+        float A[30] = {0}, B[6], X[5];
+        A[0 * 5 + 0] = 1; A[0 * 5 + 3] = -v1.x; A[1 * 5 + 1] = 1; A[1 * 5 + 3] = -v1.y; A[2 * 5 + 2] = 1; A[2 * 5 + 3] = -v1.z;
+        A[3 * 5 + 0] = 1; A[3 * 5 + 4] = -v2.x; A[4 * 5 + 1] = 1; A[4 * 5 + 4] = -v2.y; A[5 * 5 + 2] = 1; A[5 * 5 + 4] = -v2.z;
+        B[0] = p1.x; B[1] = p1.y; B[2] = p1.z; B[3] = p2.x; B[4] = p2.y; B[5] = p2.z;
+        cv_solve_svd_f32(A, B, X, 6, 5);
+        out = V3(X[0], X[1], X[2]);
+        return 0;
+    }
     double ax = v1.x, ay = v1.y, az = v1.z, bx = v2.x, by = v2.y, bz = v2.z;
     double wx = (double)p1.x - p2.x, wy = (double)p1.y - p2.y, wz = (double)p1.z - p2.z;
     double a = ax * ax + ay * ay + az * az, b = ax * bx + ay * by + az * bz, c = bx * bx + by * by + bz * bz;
@@ -1196,7 +1345,14 @@ int orc_pen_walk(const float *pts_a, int na, const float *pts_b, int nb, const f
     return 0;
 }
 
-void orc_set_closest_point_noise(double amp, uint64_t seed) { g_cp_noise_amp = amp; g_cp_noise_seed = seed; }
+void orc_set_closest_point_mode(int mode) { g_cp_mode = mode == 1 ? 1 : 0; }
+int orc_intersection_point(const float *v1, const float *p1, const float *v2, const float *p2, float *out) {
+    V3 o;
+    const int rc = intersection_point_2lines(ld3(v1), ld3(p1), ld3(v2), ld3(p2), o);
+    if (rc == 0) st3(out, o);
+    return rc;
+}
+void orc_solve_svd_f32(const float *A, const float *B, float *X, int m, int n) { cv_solve_svd_f32(A, B, X, m, n); }
 
 void orc_reg_destroy(orc_reg *h) { delete h; }
 int orc_dump_get(orc_reg *h, const char *name, const void **ptr, int64_t *nbytes) {

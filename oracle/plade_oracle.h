@@ -70,8 +70,13 @@ void orc_euler_angles(const float *R9, float *rpy3);
 int orc_pen_walk(const float *pts_a, int na, const float *pts_b, int nb, const float *plane_b4, const float *start3,
                  const float *direc3, float length, float searchRadius, float minDistance, int *positive, int *negative,
                  int *skipped);
-/* tests only: perturb every closest point of ComputeNearstTwoPointsOfTwo3DLine by up to amp per coordinate (0 = off) */
-void orc_set_closest_point_noise(double amp, uint64_t seed);
+/* closest points of two lines / least-squares point of two lines (util.cpp:1167-1229, 1461-1500): 0 = exact closed form in fp64
+ * (default; what the HIP path computes), 1 = "svd_fp32": the reference's cv::solve(DECOMP_SVD) in float, restated from OpenCV 2.4's
+ * JacobiSVDImpl_ / SVBkSbImpl_ (lapack.cpp:533-710, 751-812) */
+void orc_set_closest_point_mode(int mode);
+int orc_intersection_point(const float *v1, const float *p1, const float *v2, const float *p2, float *out);
+/* cv::solve(A (m x n, row-major), B (m), X (n), DECOMP_SVD) for CV_32F, the restated solver itself */
+void orc_solve_svd_f32(const float *A, const float *B, float *X, int m, int n);
 void orc_reg_destroy(orc_reg *);
 int orc_registration(orc_reg *h, const float *tgt_pos_nrm, int nt, const float *src_pos_nrm, int ns,
                      const float *tgt_planes, const int32_t *tgt_offsets, const int32_t *tgt_idx,

@@ -225,10 +225,12 @@ def test_registration_full_size_every_intermediate_equals_oracle(oracle, seed):
     assert ok_f and np.linalg.norm(T.astype(np.float64) - T_f.astype(np.float64)) <= 1e-4
 
 
-def test_a6_closed_form_sensitivity_at_full_size(ctx, oracle, big_pair):
-    """The A6 sensitivity test (tests/test_oracle_golden.py::test_a6_closed_form_deviation_is_bounded) at the bench size: a
-    1M-point pair with the planes the GPU extracted, closest points perturbed by the reference solver's own error at this
-    scene size: the final transform moves by less than 1e-4."""
+def test_a6_closed_form_against_the_reference_solver_at_full_size(ctx, oracle, big_pair):
+    """tests/test_oracle_golden.py::test_a6_closed_form_against_the_reference_solver_end_to_end at the bench size: the 1M-point
+    pair with the planes the GPU extracted, registered by the GPU (closed form, = oracle mode 0 bit for bit) and by the
+    oracle with the reference's fp32 SVD solves (mode 1, restated from OpenCV's lapack.cpp:533-812): a handful of the
+    ~1.4e5 descriptor matches change sides of the radius, the same candidate wins and the final transform moves by far less
+    than 1e-4."""
     import plade_amd
     tg, sr, Tgt = big_pair
     c = plade_amd.Context(0, dump=1, orient_normals=1)
@@ -238,13 +240,19 @@ def test_a6_closed_form_sensitivity_at_full_size(ctx, oracle, big_pair):
     tp = (d["tgt_planes"].reshape(-1, 4), d["tgt_plane_offsets"], d["tgt_plane_idx"])
     sp = (d["src_planes"].reshape(-1, 4), d["src_plane_offsets"], d["src_plane_idx"])
     try:
-        oracle.set_closest_point_noise(0)
+        oracle.set_closest_point_mode(0)
         ok0, T0, d0 = oracle.registration(tg, sr, tp, sp, voxel_sort_mode=1)
         assert ok and ok0 and np.array_equal(T, T0)
-        oracle.set_closest_point_noise(8.8e-5 * float(np.abs(tg[:, :3]).max()) / 10, 5)
+        oracle.set_closest_point_mode("svd_fp32")
         ok1, T1, d1 = oracle.registration(tg, sr, tp, sp, voxel_sort_mode=1)
-        assert ok1 and np.linalg.norm(T1.astype(np.float64) - T0.astype(np.float64)) <= 1e-4
-        nm = len(d0["match_nbr"])
-        assert abs(len(d1["match_nbr"]) - nm) <= max(4, 1e-3 * nm)
     finally:
-        oracle.set_closest_point_noise(0)
+        oracle.set_closest_point_mode(0)
+    assert ok1
+    dT = float(np.linalg.norm(T1.astype(np.float64) - T0.astype(np.float64)))
+    nm = len(d0["match_nbr"])
+    q0 = set(zip(np.repeat(np.arange(len(d0["match_offsets"]) - 1), np.diff(d0["match_offsets"])).tolist(), d0["match_nbr"].tolist()))
+    q1 = set(zip(np.repeat(np.arange(len(d1["match_offsets"]) - 1), np.diff(d1["match_offsets"])).tolist(), d1["match_nbr"].tolist()))
+    print(f"A6 at 1M points: {len(q0 ^ q1)} of {nm} matches flip, |dT|_F = {dT:.3g}")
+    assert len(q0 ^ q1) <= max(8, 2e-4 * nm), (len(q0 ^ q1), nm)
+    assert dT <= 1e-4
+    assert np.array_equal(d["overlap_counts"], d0["overlap_counts"])
