@@ -171,6 +171,112 @@ def cpu_baseline(n_points, pairs, min_s=10.0, budget_s=25.0):
     }
 
 
+def _cpu_batch_worker(wid, files, n_regs, barrier, q):
+    """One single-threaded CPU worker of cpu_baseline_batch (a process of its own, like one CLI process of the reference)."""
+    import numpy as np
+    from oracle.oracle import Oracle, Reference, have_reference
+    orc = Oracle()
+    ref = Reference() if have_reference() else None
+    clouds = [(np.load(t), np.load(s_)) for t, s_ in files]
+    barrier.wait()
+    t0 = time.perf_counter()
+    ok_all = True
+    for r in range(n_regs):
+        tg, sr = clouds[(wid + r) % len(clouds)]
+        planes = []
+        for cloud, seed in ((tg, 2 * (wid * n_regs + r) + 1), (sr, 2 * (wid * n_regs + r) + 2)):
+            pl = ref.ransac_detect(cloud, 10000, fake_time=seed)
+            co = pl[0].copy()
+            for i in range(len(co)):      # params.orient_normals = 1 (the rule the GPU path applies)
+                ids = pl[2][pl[1][i]:pl[1][i + 1]]
+                if cloud[ids, 3:].astype(np.float64).mean(0) @ co[i, :3] < 0:
+                    co[i] = -co[i]
+            planes.append((co, pl[1], pl[2]))
+        ok, T, _ = orc.registration(tg, sr, planes[0], planes[1], voxel_sort_mode=0)
+        ok_all = ok_all and bool(ok)
+    q.put((wid, t0, time.perf_counter(), ok_all))
+
+
+def cpu_baseline_batch(pairs, n_pairs_batch=64):
+    """for the batch config the CPU analogue of sharding pairs over GPUs is min(#cores, #pairs) independent
+    single-threaded worker PROCESSES.  Every worker registers one pair (reference RANSAC from oracle/_ref + the oracle's
+    restatement); rate = registrations / (last finish - first start).  Skipped where oracle/_ref is absent."""
+    import multiprocessing as mp
+    import tempfile
+    from oracle.oracle import have_reference
+    if not have_reference():
+        return {"value": None, "sample": "unavailable: oracle/_ref absent"}
+    workers = int(max(1, min(_cpu_budget(), n_pairs_batch)))
+    ctx = mp.get_context("spawn")
+    d = tempfile.mkdtemp(prefix="plade_cpu_batch_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    files = []
+    try:
+        for k, (tg, sr, _) in enumerate(pairs):
+            ft, fs = os.path.join(d, f"t{k}.npy"), os.path.join(d, f"s{k}.npy")
+            np.save(ft, tg); np.save(fs, sr)
+            files.append((ft, fs))
+        barrier, q = ctx.Barrier(workers), ctx.Queue()
+        procs = [ctx.Process(target=_cpu_batch_worker, args=(w, files, 1, barrier, q)) for w in range(workers)]
+        for p_ in procs:
+            p_.start()
+        res = [q.get(timeout=300) for _ in procs]
+        for p_ in procs:
+            p_.join(timeout=60)
+    finally:
+        import shutil
+        shutil.rmtree(d, ignore_errors=True)
+    t_first, t_last = min(r[1] for r in res), max(r[2] for r in res)
+    return {"value": workers / (t_last - t_first), "unit": "registrations/s", "processes": workers, "cores": workers,
+            "registrations": workers, "all_ok": all(r[3] for r in res), "seconds": t_last - t_first,
+            "sample": f"{workers} single-threaded worker processes (min(CPU budget, 64 pairs)), one 1M-pt registration each, started "
+                      "together: reference Schnabel RANSAC (oracle/_ref) + oracle restatement; rate = registrations / (last finish - "
+                      "first start)"}
+
+
+def cli_end_to_end(pairs, n_pairs=64, inflight=4, group=4):
+    """the CLI end to end (code/PLADE/main.cpp:97-158 batch mode), PLY parse and process start-up included: a
+    file_pairs.txt of n_pairs lines pairs over the bench pairs' PLY files (binary little endian, float x y z nx ny nz),
+    `PLADE file_pairs.txt result.txt` as a user would run it."""
+    import subprocess
+    import tempfile
+    from plade_amd.plyio import write_ply
+    cli = os.path.join(ROOT, "plade_amd", "PLADE")
+    if not os.path.exists(cli):
+        return {"value": None, "note": "plade_amd/PLADE not built"}
+    d = tempfile.mkdtemp(prefix="plade_cli_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        names = []
+        for k, (tg, sr, _) in enumerate(pairs):
+            ft, fs = os.path.join(d, f"t{k}.ply"), os.path.join(d, f"s{k}.ply")
+            write_ply(ft, tg); write_ply(fs, sr)
+            names.append((ft, fs))
+        lst, out = os.path.join(d, "file_pairs.txt"), os.path.join(d, "result.txt")
+        with open(lst, "w") as f:
+            for i in range(n_pairs):
+                f.write(f"{names[i % len(names)][0]}\n{names[i % len(names)][1]}\n")
+        env = dict(os.environ, PLADE_ORIENT_NORMALS="1", PLADE_INFLIGHT=str(inflight), PLADE_GROUP=str(group), PLADE_GPUS="1")
+        runs = []
+        for _ in range(2):
+            t0 = time.perf_counter()
+            r = subprocess.run([cli, lst, out], capture_output=True, text=True, timeout=600, env=env)
+            runs.append(time.perf_counter() - t0)
+            if r.returncode != 0:
+                return {"value": None, "note": "CLI failed: " + r.stderr[-300:]}
+        blocks = open(out).read().count("transformation:")
+        t1 = subprocess.run([cli, names[0][0], names[0][1], out], capture_output=True, text=True, timeout=600, env=env)
+        ts = time.perf_counter()
+        subprocess.run([cli, names[0][0], names[0][1], out], capture_output=True, text=True, timeout=600, env=env)
+        single = time.perf_counter() - ts
+    finally:
+        import shutil
+        shutil.rmtree(d, ignore_errors=True)
+    best = min(runs)
+    return {"value": n_pairs / best, "unit": "registrations/s", "pairs": n_pairs, "registered": blocks, "seconds": best,
+            "seconds_all_runs": runs, "single_pair_process_seconds": single, "workers": inflight, "pairs_per_group": group,
+            "note": "wall time of the whole `PLADE file_pairs.txt result.txt` process: HIP start-up (~0.3 s), PLY parse of 2 x 24 MB "
+                    "per pair (files in the page cache), registration, ordered result file"}
+
+
 def _cpu_budget():
     """CPUs this process may use: the cgroup v2 quota if one is set, else the affinity mask."""
     n = len(os.sched_getaffinity(0))
@@ -233,6 +339,7 @@ def main():
     ap.add_argument("--no-default-mode", action="store_true", help="skip the orient_normals=0 success-rate leg")
     ap.add_argument("--profiled-steps", type=int, default=8, help="registrations of the roofline leg (HIP events per launch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cli", action="store_true", help="skip the CLI end-to-end leg (64-pair file_pairs.txt through plade_amd/PLADE)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -570,6 +677,18 @@ def main():
         except Exception as e:  # the oracle is test infrastructure: its absence must not hide the GPU number
             cpu = {"value": None, "unit": "registrations/s", "cores": 1, "kind": "port", "sample": f"unavailable: {e}"}
 
+    cpu_batch = cli_e2e = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            cpu_batch = cpu_baseline_batch(pairs)
+        except Exception as e:
+            cpu_batch = {"value": None, "sample": f"unavailable: {e}"}
+    if rank == 0 and world == 1 and not args.no_cli:
+        try:
+            cli_e2e = cli_end_to_end(pairs)
+        except Exception as e:
+            cli_e2e = {"value": None, "note": f"unavailable: {e}"}
+
     if rank == 0:
         total = world * n_timed
         line = {
@@ -623,6 +742,8 @@ def main():
                                            "group occupied its worker (Little's law)"},
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "cpu_baseline_batch": cpu_batch,
+            "cli_end_to_end": cli_e2e,
             "stage_seconds_profiled_step": stage_times,
             "kernels_profiled_step": stage,
         }

@@ -215,6 +215,18 @@ int plade_registration_minsupport(plade_ctx *ctx, const float *tgt_pos_nrm, uint
                                   const float *src_pos_nrm, uint32_t n_s, int32_t min_support_t,
                                   int32_t min_support_s, float *T16);
 
+/* ---- second sharding axis: the candidates of ONE pair over several GPUs -------------------------------------
+ * The K candidate transforms of the verification loop (code/PLADE/plade.cpp:547-564) are independent.  With a shard set, a
+ * registration whose verification holds at least `min_candidates` candidates scores only candidates k with k % world == rank
+ * on this context's GPU (every rank runs the same registration on its own copy of the pair, so all ranks hold the same
+ * candidate list) and then calls `exchange`: values holds `count` int32 words of which this rank has filled those at indices
+ * i with (i % (count / 2)) % world == rank (first half: counts, second half: sphere flags); on return ALL words must be
+ * valid on every rank (an all-gather: RCCL / MPI / torch.distributed, the caller's choice -- the library itself links no
+ * communication library).  exchange returns 0 on success.  world <= 1 or exchange == NULL switches the axis off. */
+typedef int (*plade_exchange_fn)(void *user, int32_t *values, uint32_t count, uint32_t rank, uint32_t world);
+int plade_set_candidate_shard(plade_ctx *ctx, uint32_t rank, uint32_t world, uint32_t min_candidates, plade_exchange_fn exchange,
+                              void *user);
+
 /* Optional page-locking of caller-owned cloud buffers (hipHostRegister / hipHostUnregister): the host-pointer overloads
  * above then upload by asynchronous DMA instead of through the runtime's bounce buffer.  The reference has no counterpart
  * (its clouds never leave host memory); a host that keeps its PLY staging buffers alive pins them once. */

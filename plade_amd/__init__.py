@@ -22,7 +22,7 @@ ABI_SYMBOLS = [
     "plade_registration", "plade_registration_minsupport", "plade_cloud_upload", "plade_cloud_free",
     "plade_registration_dev", "plade_dump_get", "plade_stats_get", "plade_kernel_time", "plade_plane_component",
     "plade_sort_pairs", "plade_host_pin", "plade_host_unpin", "plade_score_planes_subset", "plade_registration_next", "plade_cluster_transforms", "plade_device_synchronize", "plade_selftest_readback",
-    "plade_registration_pairs", "plade_registration_pairs_dev", "plade_pair_ctx",
+    "plade_registration_pairs", "plade_registration_pairs_dev", "plade_pair_ctx", "plade_set_candidate_shard",
 ]
 
 
@@ -38,6 +38,8 @@ class Params(C.Structure):
                 ("ransac_seed", C.c_uint64), ("host_wait", C.c_int32), ("unoriented_normals", C.c_int32),
                 ("ransac_topup", C.c_int32), ("match_window", C.c_int32), ("match_cell_budget", C.c_uint32)]
 
+
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int32), C.c_uint32, C.c_uint32, C.c_uint32)
 
 _lib = None
 
@@ -84,6 +86,7 @@ def load_library(path=LIB_PATH):
     sig("plade_registration_pairs", argtypes=[p, u32, p, p, p, p, u32, p, p, p, p, p, p])
     sig("plade_registration_pairs_dev", argtypes=[p, u32, p, p, p, p])
     sig("plade_pair_ctx", argtypes=[p, u32], restype=p)
+    sig("plade_set_candidate_shard", argtypes=[p, u32, u32, u32, EXCHANGE_FN, p])
     sig("plade_registration_minsupport", argtypes=[p, p, u32, p, u32, i32, i32, p])
     sig("plade_cloud_upload", argtypes=[p, p, u32, C.POINTER(p)])
     sig("plade_cloud_free", argtypes=[p, p])
@@ -380,6 +383,26 @@ class Context:
             if st[i] not in (0, PLADE_EFAIL):
                 raise PladeError(int(st[i]), self.pair_error(i))
         return [(bool(st[i] == 0), T[i].copy()) for i in range(k)]
+
+    def set_candidate_shard(self, rank, world, exchange=None, min_candidates=0):
+        """Second sharding axis (plade_set_candidate_shard): with world > 1 this context scores only candidates k % world == rank
+        of a registration's verification and calls exchange(values: int32 numpy view of all words, rank, world), which must fill
+        in the other ranks' words (an all-gather).  world <= 1 switches it off."""
+        if world <= 1 or exchange is None:
+            self._shard_cb = None
+            self._check(self.L.plade_set_candidate_shard(self.h, 0, 1, 0, EXCHANGE_FN(0), None))
+            return
+
+        def cb(user, values, count, r, w):
+            try:
+                exchange(np.ctypeslib.as_array(values, shape=(count,)), int(r), int(w))
+                return 0
+            except Exception:      # never let an exception cross the C boundary
+                import traceback
+                traceback.print_exc()
+                return -1
+        self._shard_cb = EXCHANGE_FN(cb)      # keep the trampoline alive
+        self._check(self.L.plade_set_candidate_shard(self.h, int(rank), int(world), int(min_candidates), self._shard_cb, None))
 
     def _pair_handle(self, index):
         h = self.L.plade_pair_ctx(self.h, int(index))

@@ -73,6 +73,14 @@ extern "C" int plade_set_params(plade_ctx *ctx, const plade_params *p) {
     return PLADE_OK;
 }
 
+extern "C" int plade_set_candidate_shard(plade_ctx *ctx, uint32_t rank, uint32_t world, uint32_t min_candidates, plade_exchange_fn exchange,
+                                         void *user) {
+    if (!ctx || (world > 1 && (rank >= world || !exchange))) return PLADE_EINVAL;
+    ctx->shard.rank = world > 1 ? rank : 0; ctx->shard.world = world > 1 ? world : 1; ctx->shard.min_candidates = min_candidates;
+    ctx->shard.exchange = world > 1 ? exchange : nullptr; ctx->shard.user = user;
+    return PLADE_OK;
+}
+
 extern "C" int plade_dump_get(plade_ctx *ctx, const char *name, const void **ptr, int64_t *nbytes) {
     if (!ctx || !name || !ptr || !nbytes) return PLADE_EINVAL;
     auto it = ctx->dump.find(name);

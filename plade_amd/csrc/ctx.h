@@ -104,6 +104,7 @@ struct plade_ctx {
         plade::DBuf<int> d;      // 8 ints per box being reduced
     } pf;
     plade_params params;
+    struct CandidateShard { uint32_t rank = 0, world = 1, min_candidates = 0; plade_exchange_fn exchange = nullptr; void *user = nullptr; } shard;
     // number of completed host waits on `stream` (sync(), the extraction's flag waits): a stage that left results in host-mapped
     // memory behind kernels queued earlier remembers the count at enqueue time and knows from it whether anything has waited since
     uint64_t wait_epoch = 0;

@@ -8,8 +8,9 @@
 // the result-file grammar and the exit codes.  The control flow is this program's own:
 //
 //   * the pair list is read up front and turned into jobs,
-//   * PLADE_GPUS=N x PLADE_INFLIGHT=M worker threads (one plade_ctx each) take jobs from a shared counter
-//     (pairs are independent; PLY parsing of one pair overlaps the GPU work of the others),
+//   * PLADE_GPUS=N x PLADE_INFLIGHT=M worker threads (one plade_ctx each) take PLADE_GROUP (default 4) consecutive jobs at a
+//     time from a shared counter and register them as one group (pairs are independent; the plane extraction of a group's
+//     clouds is one GPU launch sequence; PLY parsing of one group overlaps the GPU work of the others),
 //   * an ordered writer appends every pair's block to the result file as soon as that pair AND all earlier
 //     pairs are done, and flushes it -- like the reference, which writes each block when its registration
 //     returns (main.cpp:134-146), a batch that is interrupted leaves a valid prefix of the results behind,
@@ -186,22 +187,51 @@ int batch(const char *list_path, const char *result_path) {
         return EXIT_FAILURE;
     }
     read_jobs(list_path, jobs);
+    // PLADE_GPUS x PLADE_INFLIGHT workers, each taking PLADE_GROUP (1..4) consecutive pairs of the list per call (one GROUP:
+    // the plane extraction of its clouds is one launch sequence, plade.h registration_group).  PLADE_GPU_MAP ("0,0,1,1", a test
+    // hook for boxes with fewer GPUs than PLADE_GPUS) maps worker-side device numbers to physical ones.
     const int n_gpus = env_int("PLADE_GPUS", 1), per_gpu = env_int("PLADE_INFLIGHT", 4);
-    const int n_workers = (int)std::min<size_t>((size_t)n_gpus * per_gpu, std::max<size_t>(jobs.size(), 1));
+    const size_t group = (size_t)std::min(env_int("PLADE_GROUP", 4), 4);
+    std::vector<int> gpu_map(n_gpus);
+    for (int g = 0; g < n_gpus; ++g) gpu_map[g] = g;
+    if (const char *m = getenv("PLADE_GPU_MAP")) {
+        std::stringstream ss(m);
+        std::string tok;
+        for (int g = 0; g < n_gpus && std::getline(ss, tok, ','); ++g) gpu_map[g] = atoi(tok.c_str());
+    }
+    const size_t n_groups = (jobs.size() + group - 1) / group;
+    const int n_workers = (int)std::min<size_t>((size_t)n_gpus * per_gpu, std::max<size_t>(n_groups, 1));
     OrderedWriter writer(output, jobs);
     std::mutex take;
     size_t next = 0;
     auto worker = [&](int gpu) {
-        plade_select_device(gpu);
+        plade_select_device(gpu_map[gpu]);
         for (;;) {
-            size_t i;
-            { std::lock_guard<std::mutex> lk(take); i = next++; }
-            if (i >= jobs.size()) break;
-            writer.submit(i, run_job(jobs[i], true));
+            size_t i0;
+            { std::lock_guard<std::mutex> lk(take); i0 = next; next += group; }
+            if (i0 >= jobs.size()) break;
+            const size_t k = std::min(group, jobs.size() - i0);
+            if (k == 1) { writer.submit(i0, run_job(jobs[i0], true)); continue; }
+            Outcome res[4];
+            std::ostringstream outs[4], errs[4];
+            std::ostream *op[4], *ep[4];
+            std::string tg[4], sr[4];
+            Matrix4 T[4];
+            bool ok[4];
+            for (size_t q = 0; q < k; ++q) { op[q] = &outs[q]; ep[q] = &errs[q]; tg[q] = jobs[i0 + q].target; sr[q] = jobs[i0 + q].source; }
+            try {
+                registration_group(k, T, tg, sr, ok, op, ep);
+            } catch (const std::exception &e) {   // nothing a malformed pair does may take the batch down
+                for (size_t q = 0; q < k; ++q) { errs[q] << "registration failed: " << e.what() << std::endl; ok[q] = false; }
+            }
+            for (size_t q = 0; q < k; ++q) {
+                res[q].ok = ok[q]; res[q].T = T[q]; res[q].console_out = outs[q].str(); res[q].console_err = errs[q].str();
+                writer.submit(i0 + q, std::move(res[q]));
+            }
         }
         plade_release_thread_context();   // the worker's plade_ctx (work areas in HBM) goes with the thread
     };
-    if (n_workers <= 1) worker(0);
+    if (n_workers <= 1 && group <= 1) worker(0);
     else {
         // several pairs in flight: the workers poll + sleep instead of spinning on the GPU (plade_params.host_wait),
         // so that the workers of all GPUs fit the host's CPUs

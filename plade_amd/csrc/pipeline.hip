@@ -455,21 +455,38 @@ bool run_registration(plade_ctx *ctx, RegistrationWork &W, const CloudDev &tgt, 
     {
         StageTimer t(ctx, "t_verify");
         // one upload (transforms | centres) and one read-back (counts | sphere flags): every command of a stream costs ~6 us
-        // of queue time and ~10 us of host time, whatever its size
-        W.d_T16.ensure(19 * (size_t)Kv); W.d_counts.ensure(2 * (size_t)Kv);
-        float *d_centers = W.d_T16.p + 16 * (size_t)Kv;
-        uint32_t *d_any = reinterpret_cast<uint32_t *>(W.d_counts.p) + Kv;
-        std::vector<float> up(19 * (size_t)Kv);
-        memcpy(up.data(), T16.data(), 64 * (size_t)Kv);
-        memcpy(up.data() + 16 * (size_t)Kv, centers.data(), 12 * (size_t)Kv);
-        ctx->h2d(W.d_T16.p, up.data(), 76 * (size_t)Kv);
-        HIP_TRY(hipStreamWaitEvent(ctx->stream, W.ev_grid, 0));
-        const float *vsx = sort_source ? W.ov_work.sorted.p : C.d_ds_soa.p;
-        overlap_counts(ctx, W.ov_work, vsx, vsx + C.n_ds, vsx + 2 * (size_t)C.n_ds, C.n_ds,
-                       W.grid, W.d_T16.p, d_centers, Kv, (float)C.radius, downSampleDistance, W.d_counts.p, d_any);
-        std::vector<int32_t> back(2 * (size_t)Kv);
-        ctx->d2h(back.data(), W.d_counts.p, 8 * (size_t)Kv);
-        ctx->sync();
+        // of queue time and ~10 us of host time, whatever its size.  With a candidate shard set (plade_set_candidate_shard)
+        // only this rank's candidates k % world == rank are scored here and the counts of the others arrive through the
+        // caller's exchange.
+        const plade_ctx::CandidateShard &sh = ctx->shard;
+        const bool sharded = sh.world > 1 && sh.exchange && Kv >= sh.min_candidates;
+        std::vector<uint32_t> mine;
+        for (uint32_t i = 0; i < Kv; ++i) if (!sharded || i % sh.world == sh.rank) mine.push_back(i);
+        const uint32_t Km = (uint32_t)mine.size();
+        W.d_T16.ensure(19 * (size_t)Km + 4); W.d_counts.ensure(2 * (size_t)Km + 4);
+        float *d_centers = W.d_T16.p + 16 * (size_t)Km;
+        uint32_t *d_any = reinterpret_cast<uint32_t *>(W.d_counts.p) + Km;
+        std::vector<float> up(19 * (size_t)Km);
+        for (uint32_t q = 0; q < Km; ++q) {
+            memcpy(up.data() + 16 * (size_t)q, T16.data() + 16 * (size_t)mine[q], 64);
+            memcpy(up.data() + 16 * (size_t)Km + 3 * (size_t)q, centers.data() + 3 * (size_t)mine[q], 12);
+        }
+        std::vector<int32_t> back(2 * (size_t)Kv, 0);
+        if (Km) {
+            ctx->h2d(W.d_T16.p, up.data(), 76 * (size_t)Km);
+            HIP_TRY(hipStreamWaitEvent(ctx->stream, W.ev_grid, 0));
+            const float *vsx = sort_source ? W.ov_work.sorted.p : C.d_ds_soa.p;
+            overlap_counts(ctx, W.ov_work, vsx, vsx + C.n_ds, vsx + 2 * (size_t)C.n_ds, C.n_ds,
+                           W.grid, W.d_T16.p, d_centers, Km, (float)C.radius, downSampleDistance, W.d_counts.p, d_any);
+            std::vector<int32_t> part(2 * (size_t)Km);
+            ctx->d2h(part.data(), W.d_counts.p, 8 * (size_t)Km);
+            ctx->sync();
+            for (uint32_t q = 0; q < Km; ++q) { back[mine[q]] = part[q]; back[Kv + mine[q]] = part[Km + q]; }
+        }
+        if (sharded) {
+            ctx->stats.add("n_candidates_scored_here", Km);
+            PLADE_REQUIRE(sh.exchange(sh.user, back.data(), 2 * Kv, sh.rank, sh.world) == 0, PLADE_EDEVICE, "candidate shard: the exchange failed");
+        }
         for (uint32_t i = 0; i < Kv; ++i) counts[i] = back[Kv + i] ? back[i] : -1;
     }
     std::vector<LengthIndex> ov(Kv);

@@ -248,6 +248,65 @@ bool registration(Eigen::Matrix<float, 4, 4> &transformation, const std::string 
     return true;
 }
 
+// Batch extension: see plade.h.  The per-pair part of the file overload above (messages, extension check, loading, the
+// target/source switch, plade.cpp:665-706) runs pair by pair; the pairs that got that far are registered as one group.
+void registration_group(size_t count, Eigen::Matrix<float, 4, 4> *transformations, const std::string *target_cloud_files,
+                        const std::string *source_cloud_files, bool *ok, std::ostream *const *out, std::ostream *const *err) {
+    constexpr size_t GMAX = PLADE_GROUP_MAX;
+    if (count > GMAX) count = GMAX;
+    thread_local std::vector<float> bufs[2 * GMAX];   // staging arrays of this worker thread, reused from group to group
+    struct Item { size_t pair; const float *tg, *sr; size_t n_t, n_s; bool switched; };
+    std::vector<Item> items;
+    for (size_t i = 0; i < count; ++i) {
+        ok[i] = false;
+        transformations[i].setIdentity();
+        plade_set_thread_console(out ? out[i] : nullptr, err ? err[i] : nullptr);
+        con_out() << "target file: " << target_cloud_files[i] << std::endl;
+        con_out() << "source file: " << source_cloud_files[i] << std::endl;
+        if (extension(target_cloud_files[i]) != "ply" || extension(source_cloud_files[i]) != "ply") {
+            con_err() << "only PLY format is accepted" << std::endl;
+            continue;
+        }
+        if (!load_packed(target_cloud_files[i], bufs[2 * i])) { con_err() << "loading target point cloud failed" << std::endl; continue; }
+        if (!load_packed(source_cloud_files[i], bufs[2 * i + 1])) { con_err() << "loading source point cloud failed" << std::endl; continue; }
+        Item it{i, bufs[2 * i].data(), bufs[2 * i + 1].data(), bufs[2 * i].size() / 6, bufs[2 * i + 1].size() / 6, false};
+        if (it.n_s >= it.n_t * 1.2f) {
+            std::swap(it.tg, it.sr);
+            std::swap(it.n_t, it.n_s);
+            it.switched = true;
+            con_out() << "---->>> ATTENTION: target and source have been switched for efficiency <<<----" << std::endl;
+        }
+        con_out() << "extracting planes for both point clouds...\n";
+        items.push_back(it);
+    }
+    plade_set_thread_console(nullptr, nullptr);
+    if (items.empty()) return;
+    plade_ctx *ctx = context();
+    const uint32_t k = (uint32_t)items.size();
+    const float *tg[GMAX], *sr[GMAX];
+    uint32_t n_t[GMAX], n_s[GMAX];
+    float T16[16 * GMAX];
+    int32_t status[GMAX];
+    for (uint32_t q = 0; q < k; ++q) { tg[q] = items[q].tg; sr[q] = items[q].sr; n_t[q] = (uint32_t)items[q].n_t; n_s[q] = (uint32_t)items[q].n_s; status[q] = PLADE_EDEVICE; }
+    Watch w;
+    int rc = ctx ? plade_registration_pairs(ctx, k, tg, n_t, sr, n_s, 0, nullptr, nullptr, nullptr, nullptr, T16, status) : PLADE_EDEVICE;
+    for (uint32_t q = 0; q < k; ++q) {
+        const Item &it = items[q];
+        plade_set_thread_console(out ? out[it.pair] : nullptr, err ? err[it.pair] : nullptr);
+        if (rc != PLADE_OK || status[q] != PLADE_OK) {
+            const plade_ctx *pc = ctx ? (rc != PLADE_OK ? ctx : plade_pair_ctx(ctx, q)) : nullptr;
+            if (pc) con_err() << plade_last_error(pc) << std::endl;
+            con_err() << "registration failed" << std::endl;
+            continue;
+        }
+        to_matrix(T16 + 16 * q, transformations[it.pair]);
+        con_out() << "done. time: " << w.str() << std::endl;
+        if (it.switched) transformations[it.pair] = transformations[it.pair].inverse();
+        ok[it.pair] = true;
+    }
+    plade_set_thread_console(nullptr, nullptr);
+}
+
 bool load_ply_cloud(const std::string &file_name, pcl::PointCloud<pcl::PointNormal> &cloud) {
     std::vector<float> pos_nrm;
     std::string err;

@@ -177,6 +177,7 @@ void register_group(plade_ctx *ctx, int count, const CloudDev *const tgt[], cons
     for (int i = 1; i < count; ++i) {
         pcs[i] = peer_ctx(ctx, i);
         pcs[i]->params = ctx->params;
+        pcs[i]->shard = ctx->shard;
         pcs[i]->stats.clear();
         pcs[i]->dump.clear();
         pcs[i]->last_error.clear();

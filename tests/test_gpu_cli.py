@@ -82,6 +82,56 @@ def test_cli_batch_mode_in_flight_keeps_input_order(ply_pairs, ctx):
         assert np.allclose(b["T"], T, rtol=2e-5, atol=2e-6)
 
 
+def test_cli_batch_in_groups_and_on_two_logical_gpus(ply_pairs, ctx):
+    """Batch mode takes PLADE_GROUP consecutive pairs of the list per call (one group: registration_group, plade.h); every
+    block must be what the single-pair path writes, whatever the grouping -- groups of 1, 2, 3 (a ragged last group) and 4 --
+    and with PLADE_GPUS=2 worker sets, here both mapped onto the one GPU of the box (PLADE_GPU_MAP=0,0: the per-device
+    branch of main.cpp runs with two device numbers)."""
+    d, pairs = ply_pairs
+    order = [0, 1, 2, 1, 0, 2, 2]
+    lst = d / "file_pairs_groups.txt"
+    lst.write_text("".join(f"{pairs[i][0]}\n{pairs[i][1]}\n" for i in order))
+    want = {}
+    for i in set(order):
+        ok, T = ctx.registration(pairs[i][2], pairs[i][3])
+        assert ok
+        want[i] = T
+    texts = {}
+    for tag, extra in (("g1", {"PLADE_GROUP": "1", "PLADE_INFLIGHT": "2"}), ("g2", {"PLADE_GROUP": "2", "PLADE_INFLIGHT": "2"}),
+                       ("g3", {"PLADE_GROUP": "3", "PLADE_INFLIGHT": "1"}), ("g4", {"PLADE_INFLIGHT": "2"}),
+                       ("two_gpus", {"PLADE_GPUS": "2", "PLADE_GPU_MAP": "0,0", "PLADE_INFLIGHT": "1", "PLADE_GROUP": "2"})):
+        res = str(d / f"batch_{tag}.txt")
+        r = subprocess.run([CLI, str(lst), res], capture_output=True, text=True, timeout=600, env=dict(ORIENTED_ENV, **extra))
+        assert r.returncode == 0, (tag, r.stderr)
+        blocks = parse_results(res)
+        assert [b["target"] for b in blocks] == [pairs[i][0] for i in order], tag
+        for b, i in zip(blocks, order):
+            assert not b["failed"] and np.allclose(b["T"], want[i], rtol=2e-5, atol=2e-6), (tag, i)
+        texts[tag] = open(res).read()
+        # the console reads like the sequential run: every pair's messages, in input order
+        tf = [l for l in r.stdout.split("\n") if l.startswith("target file: ")]
+        assert tf == [f"target file: {pairs[i][0]}" for i in order], tag
+        assert r.stdout.count("done. time: ") == len(order)
+    assert len(set(texts.values())) == 1          # the same file, byte for byte
+
+
+def test_cli_group_with_a_broken_pair(ply_pairs, tmp_path):
+    """A pair of a group that cannot be loaded (not a PLY) or registered fails alone: its block records the identity, its
+    partners' blocks are untouched (main.cpp:141-146 per pair)."""
+    d, pairs = ply_pairs
+    bad = tmp_path / "broken.ply"
+    bad.write_text("ply\nformat ascii 1.0\nelement vertex 3\nproperty float x\nend_header\n0\n1\n2\n")
+    lst = tmp_path / "pairs.txt"
+    lst.write_text(f"{pairs[0][0]}\n{pairs[0][1]}\n{bad}\n{pairs[1][1]}\n{pairs[1][0]}\n{pairs[1][1]}\n")
+    res = str(tmp_path / "r.txt")
+    r = subprocess.run([CLI, str(lst), res], capture_output=True, text=True, timeout=600, env=dict(ORIENTED_ENV, PLADE_GROUP="3"))
+    assert r.returncode == 0, r.stderr
+    blocks = parse_results(res)
+    assert [b["failed"] for b in blocks] == [False, True, False]
+    assert np.array_equal(blocks[1]["T"], np.eye(4))
+    assert "registration of 1 (out of 3) pairs failed" in r.stderr
+
+
 def test_cli_ascii_ply_and_swap_of_a_larger_source(tmp_path, ctx):
     """ascii PLY input (ply_reader.cpp) and the |source| >= 1.2 |target| swap + inverse of plade.cpp:690-703."""
     tg, sr, Tgt = make_pair(60000, seed=6)

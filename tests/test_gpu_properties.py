@@ -225,34 +225,71 @@ def test_registration_full_size_every_intermediate_equals_oracle(oracle, seed):
     assert ok_f and np.linalg.norm(T.astype(np.float64) - T_f.astype(np.float64)) <= 1e-4
 
 
+def _match_set(d):
+    q = np.repeat(np.arange(len(d["match_offsets"]) - 1), np.diff(d["match_offsets"]))
+    return set(zip(q.tolist(), d["match_nbr"].tolist()))
+
+
 def test_a6_closed_form_against_the_reference_solver_at_full_size(ctx, oracle, big_pair):
-    """tests/test_oracle_golden.py::test_a6_closed_form_against_the_reference_solver_end_to_end at the bench size: the 1M-point
-    pair with the planes the GPU extracted, registered by the GPU (closed form, = oracle mode 0 bit for bit) and by the
-    oracle with the reference's fp32 SVD solves (mode 1, restated from OpenCV's lapack.cpp:533-812): a handful of the
-    ~1.4e5 descriptor matches change sides of the radius, the same candidate wins and the final transform moves by far less
-    than 1e-4."""
+    """tests/test_oracle_golden.py::test_a6_closed_form_against_the_reference_solver_end_to_end at the bench size, on the
+    planes the GPU extracts: the GPU (closed form = oracle mode 0, bit for bit) against the oracle with the reference's fp32
+    SVD solves (mode 1, restated from OpenCV's lapack.cpp:533-812).
+
+    (a) the 1M-point pair in a GENERIC orientation (both clouds turned by one random rotation): a handful of the ~1e6
+        descriptor matches change sides of the radius, the same candidate wins, |dT|_F <= 1e-4 (measured 4e-6 ... 7e-6).
+    (b) the bench pair as generated -- an axis-aligned Manhattan room.  There the REFERENCE's arithmetic is ill-conditioned:
+        ComputeIntersectionLine (util.cpp:639-675) takes the first 2 x 2 minor with |det| > 1e-6 and sets the free coordinate
+        to 0, which puts the base point of more than half of the lines of an axis-aligned scene 1e3 ... 2e6 m away; the fp32
+        9 x 9 solve of ComputeNearstTwoPointsOfTwo3DLine then cancels 5-6 digits and its closest points are off by
+        centimetres to decimetres (any fp32 evaluation order would be; the values depend on the last bits of libm's hypot).
+        The closed form evaluates the same inputs exactly.  As measured: thousands of matches differ, both modes register
+        the pair, and the closed form is the one closer to the ground truth."""
     import plade_amd
     tg, sr, Tgt = big_pair
-    c = plade_amd.Context(0, dump=1, orient_normals=1)
-    ok, T = c.registration(tg, sr)
-    d = c.dump()
-    c.close()
-    tp = (d["tgt_planes"].reshape(-1, 4), d["tgt_plane_offsets"], d["tgt_plane_idx"])
-    sp = (d["src_planes"].reshape(-1, 4), d["src_plane_offsets"], d["src_plane_idx"])
-    try:
-        oracle.set_closest_point_mode(0)
-        ok0, T0, d0 = oracle.registration(tg, sr, tp, sp, voxel_sort_mode=1)
-        assert ok and ok0 and np.array_equal(T, T0)
-        oracle.set_closest_point_mode("svd_fp32")
-        ok1, T1, d1 = oracle.registration(tg, sr, tp, sp, voxel_sort_mode=1)
-    finally:
-        oracle.set_closest_point_mode(0)
-    assert ok1
+    rng = np.random.default_rng(4)
+    q = rng.normal(size=4)
+    q /= np.linalg.norm(q)
+    w, x, y, z = q
+    R0 = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                   [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                   [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+    def turned(c):
+        o = np.empty_like(c)
+        o[:, :3] = (c[:, :3].astype(np.float64) @ R0.T).astype(np.float32)
+        o[:, 3:] = (c[:, 3:].astype(np.float64) @ R0.T).astype(np.float32)
+        return o
+
+    def both_modes(a, b):
+        c = plade_amd.Context(0, dump=1, orient_normals=1)
+        ok, T = c.registration(a, b)
+        d = c.dump()
+        c.close()
+        tp = (d["tgt_planes"].reshape(-1, 4), d["tgt_plane_offsets"], d["tgt_plane_idx"])
+        sp = (d["src_planes"].reshape(-1, 4), d["src_plane_offsets"], d["src_plane_idx"])
+        try:
+            oracle.set_closest_point_mode(0)
+            ok0, T0, d0 = oracle.registration(a, b, tp, sp, voxel_sort_mode=1)
+            assert ok and ok0 and np.array_equal(T, T0) and np.array_equal(d["overlap_counts"], d0["overlap_counts"])
+            oracle.set_closest_point_mode("svd_fp32")
+            ok1, T1, d1 = oracle.registration(a, b, tp, sp, voxel_sort_mode=1)
+        finally:
+            oracle.set_closest_point_mode(0)
+        assert ok1
+        lines = np.concatenate([d0["tgt_lines"].reshape(-1, 8), d0["src_lines"].reshape(-1, 8)])
+        far = float((np.abs(lines[:, 3:6]).max(1) > 1e3).mean())
+        return T0, T1, len(_match_set(d0) ^ _match_set(d1)), len(d0["match_nbr"]), far
+
+    # (a) generic orientation
+    T0, T1, flips, nm, far = both_modes(turned(tg), turned(sr))
     dT = float(np.linalg.norm(T1.astype(np.float64) - T0.astype(np.float64)))
-    nm = len(d0["match_nbr"])
-    q0 = set(zip(np.repeat(np.arange(len(d0["match_offsets"]) - 1), np.diff(d0["match_offsets"])).tolist(), d0["match_nbr"].tolist()))
-    q1 = set(zip(np.repeat(np.arange(len(d1["match_offsets"]) - 1), np.diff(d1["match_offsets"])).tolist(), d1["match_nbr"].tolist()))
-    print(f"A6 at 1M points: {len(q0 ^ q1)} of {nm} matches flip, |dT|_F = {dT:.3g}")
-    assert len(q0 ^ q1) <= max(8, 2e-4 * nm), (len(q0 ^ q1), nm)
-    assert dT <= 1e-4
-    assert np.array_equal(d["overlap_counts"], d0["overlap_counts"])
+    print(f"A6 at 1M points, generic orientation: {flips} of {nm} matches flip, |dT|_F = {dT:.3g}, lines with a far base point: {far:.2f}")
+    assert far == 0.0 and flips <= max(32, 5e-5 * nm) and dT <= 1e-4
+    # (b) the axis-aligned bench pair
+    T0, T1, flips, nm, far = both_modes(tg, sr)
+    e0, e1 = float(np.linalg.norm(T0.astype(np.float64) - Tgt)), float(np.linalg.norm(T1.astype(np.float64) - Tgt))
+    print(f"A6 at 1M points, axis-aligned: {flips} of {nm} matches flip, |T - T_gt|_F closed form {e0:.3g} / reference solver {e1:.3g}, "
+          f"lines with a far base point: {far:.2f}")
+    assert far > 0.3                         # the ill-conditioned inputs are there
+    assert e0 < 2e-2 and e1 < 1e-1           # both register the pair
+    assert e0 <= e1 + 1e-3                   # and the exact evaluation is the one nearer the truth

@@ -18,7 +18,7 @@ cd /tmp && export TMPDIR=/tmp
 # (lead-in of one round instead of eight: with ~170 registrations in one traced process rocprofv3 7.2 segfaults inside the
 #  profiled process, below hipGraphLaunch; ~110 are fine)
 export BENCH_LEAD_ROUNDS=1
-CMD="python $R/bench.py --steps 96 --warmup 8 --resident-steps 0 --no-cpu-baseline --no-default-mode --profiled-steps 2"
+CMD="python $R/bench.py --steps 96 --warmup 8 --resident-steps 0 --no-cpu-baseline --no-cli --no-default-mode --profiled-steps 2"
 rm -rf $O/prof_bench $O/prof_pmc_fetch $O/prof_pmc_write
 # every pass is tried up to three times
 prof() {   # prof <dir> <output name> <rocprofv3 options...>
