@@ -239,11 +239,12 @@ def test_a6_closed_form_against_the_reference_solver_at_full_size(ctx, oracle, b
         descriptor matches change sides of the radius, the same candidate wins, |dT|_F <= 1e-4 (measured 4e-6 ... 7e-6).
     (b) the bench pair as generated -- an axis-aligned Manhattan room.  There the REFERENCE's arithmetic is ill-conditioned:
         ComputeIntersectionLine (util.cpp:639-675) takes the first 2 x 2 minor with |det| > 1e-6 and sets the free coordinate
-        to 0, which puts the base point of more than half of the lines of an axis-aligned scene 1e3 ... 2e6 m away; the fp32
+        to 0, which puts the base point of many lines of an axis-aligned scene (9 % with the extracted planes of this pair, more
+        than half with exact ones) 1e3 ... 2e6 m away; the fp32
         9 x 9 solve of ComputeNearstTwoPointsOfTwo3DLine then cancels 5-6 digits and its closest points are off by
         centimetres to decimetres (any fp32 evaluation order would be; the values depend on the last bits of libm's hypot).
-        The closed form evaluates the same inputs exactly.  As measured: thousands of matches differ, both modes register
-        the pair, and the closed form is the one closer to the ground truth."""
+        The closed form evaluates the same inputs exactly.  As measured: 15 000 of 75 000 matches differ, both modes register
+        the pair, and the closed form is the one closer to the ground truth (4e-5 against 4e-2)."""
     import plade_amd
     tg, sr, Tgt = big_pair
     rng = np.random.default_rng(4)
@@ -290,6 +291,6 @@ def test_a6_closed_form_against_the_reference_solver_at_full_size(ctx, oracle, b
     e0, e1 = float(np.linalg.norm(T0.astype(np.float64) - Tgt)), float(np.linalg.norm(T1.astype(np.float64) - Tgt))
     print(f"A6 at 1M points, axis-aligned: {flips} of {nm} matches flip, |T - T_gt|_F closed form {e0:.3g} / reference solver {e1:.3g}, "
           f"lines with a far base point: {far:.2f}")
-    assert far > 0.3                         # the ill-conditioned inputs are there
+    assert far > 0.02                        # the ill-conditioned inputs are there (measured: 9 % of the lines)
     assert e0 < 2e-2 and e1 < 1e-1           # both register the pair
     assert e0 <= e1 + 1e-3                   # and the exact evaluation is the one nearer the truth
