@@ -13,10 +13,17 @@
 //                   (r3 wrote per-workgroup partial histograms and every tile of every pass summed all 128 of them per
 //                   digit: 256 KB of loads per tile, twice the traffic of the keys themselves.)
 //   k_rs_pass       "onesweep": a workgroup takes the next tile (atomic ticket, so every predecessor is already
-//                   running), ranks its 8192 keys (512 lanes x 16) by digit (wave-level match via 8 ballots per key: stable),
-//                   publishes its digit counts, resolves its exclusive prefix by decoupled look-back over the
-//                   predecessors' states, stages the tile in LDS in digit order and writes runs of equal digits to
-//                   their final place.
+//                   running), ranks its keys (512 lanes x 8 or 16) by digit (wave-level match via 8 ballots per key: stable),
+//                   publishes its digit counts, resolves its exclusive prefix over the preceding tiles (below), stages the
+//                   tile in LDS in digit order and writes runs of equal digits to their final place.
+//   prefix          TWO levels instead of a chained look-back.  The tiles form supertiles of ST ~ sqrt(#tiles) tiles; a tile
+//                   publishes its counts (one word per digit) and adds them to its supertile's word (a 64-bit atomic add of
+//                   count | 1 << 40: the high part counts the tiles that have contributed).  Its exclusive prefix is the sum
+//                   of the COMPLETE supertiles before its own plus the counts of the tiles before it inside its own:
+//                   <= #tiles / ST + ST independent loads, issued together and polled until valid.  r3's chained look-back
+//                   (windows of 8 predecessors, aggregate or inclusive prefix) needed ~#tiles / 16 dependent round trips
+//                   for the last tiles when all tiles of a sort run at once -- 15 trips of 1-2 us past the L2s for the 244
+//                   tiles of a 1M-key sort, i.e. most of a 30 us pass.
 // Algorithmic traffic per pass: read n x (sizeof(K) + 4) B, write the same.
 #include "prims.h"
 
@@ -36,8 +43,9 @@ constexpr int RS_WAVES = RS_THREADS / 64;
 // Morton sort of a pair is faster with 8192-key tiles: 51 vs 54 us)
 constexpr int RS_HBLOCKS = 128;                  // histogram workgroups (= partial histograms per digit place)
 constexpr int RS_MAXP = 8;
-constexpr int RS_LOOK = 8;                      // predecessors fetched per look-back round
-constexpr uint32_t RS_AGG = 1u << 30, RS_PREFIX = 2u << 30, RS_VALUE = (1u << 30) - 1;
+constexpr int RS_LOOK = 8;                      // states fetched per round of the prefix loads
+constexpr uint32_t RS_VALID = 1u << 31, RS_VALUE = RS_VALID - 1;
+constexpr unsigned long long RS_SUP_ONE = 1ull << 40, RS_SUP_VALUE = RS_SUP_ONE - 1ull;
 
 // Digits are 8 bits wide, or 9 where that saves a pass (25-27, 17-18 significant bits: the voxel and cell grids):
 // 512 bins are one per lane of the 512-lane workgroup.
@@ -80,7 +88,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_pass(const K *__restrict__ ki
                                                         const uint32_t *__restrict__ vin, uint32_t *__restrict__ vout,
                                                         uint32_t n, int pass, const uint32_t *__restrict__ ghist,
                                                         uint32_t *__restrict__ ghist_next, uint32_t *__restrict__ tile_ctr,
-                                                        uint32_t *__restrict__ look) {
+                                                        uint32_t *__restrict__ look, unsigned long long *__restrict__ sup, uint32_t st_shift) {
     constexpr int NB = 1 << DB;
     constexpr int RS_TILE = RS_THREADS * RS_IPT;
     static_assert(NB <= RS_THREADS, "one lane per digit");
@@ -141,8 +149,12 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_pass(const K *__restrict__ ki
     uint32_t tile_count = 0;
     if (owner)
         for (int w = 0; w < RS_WAVES; ++w) { const uint32_t c = s_cnt[w][d]; s_cnt[w][d] = tile_count; tile_count += c; }
-    uint32_t *my_look = look + (size_t)tile * NB + d;
-    if (owner) __hip_atomic_store(my_look, (tile == 0 ? RS_PREFIX : RS_AGG) | tile_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // publish: this tile's counts, and their share in the supertile's sum
+    if (owner) {
+        __hip_atomic_store(look + (size_t)tile * NB + d, RS_VALID | tile_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(sup + (size_t)(tile >> st_shift) * NB + d, RS_SUP_ONE | (unsigned long long)tile_count, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+    }
     // block-wide exclusive scans of `total` (global) and `tile_count` (tile-local) over the NB digits
     uint32_t inc_g = total, inc_t = tile_count;
     for (int o = 1; o < 64; o <<= 1) {
@@ -157,28 +169,33 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_pass(const K *__restrict__ ki
         for (int w = 0; w < wave; ++w) { off_g += s_wg[w]; off_t += s_wt[w]; }
         const uint32_t gbase = off_g + inc_g - total;       // exclusive: keys with a smaller digit in the whole array
         const uint32_t tstart = off_t + inc_t - tile_count; // exclusive
-        // decoupled look-back: exclusive prefix of this digit over the preceding tiles.  Agent-scope loads go past
-        // the per-XCD L2; a window of RS_LOOK predecessors is fetched at once so the walk pays that latency once per
-        // window (wider windows re-read too many rows while every tile is still publishing: slower)
+        // exclusive prefix of this digit over the preceding tiles: complete supertiles, then the tiles of the own one.
+        // Agent-scope loads go past the per-XCD L2; RS_LOOK of them are in flight together, a word that is not there yet
+        // (its tiles hold earlier tickets, so they are running) is polled.
         uint32_t excl = 0;
-        if (tile > 0) {
-            int t = (int)tile - 1;
-            bool done = false;
-            while (!done) {
-                uint32_t st[RS_LOOK];
+        const uint32_t my_sup = tile >> st_shift, st_tiles = 1u << st_shift;
+        for (uint32_t s0 = 0; s0 < my_sup; s0 += RS_LOOK) {
+            unsigned long long w[RS_LOOK];
 #pragma unroll
-                for (int j = 0; j < RS_LOOK; ++j)
-                    st[j] = (t - j >= 0) ? __hip_atomic_load(look + (size_t)(t - j) * NB + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : RS_PREFIX;
-                int j = 0;
+            for (int j = 0; j < RS_LOOK; ++j)
+                w[j] = (s0 + j < my_sup) ? __hip_atomic_load(sup + (size_t)(s0 + j) * NB + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                         : ((unsigned long long)st_tiles << 40);
 #pragma unroll
-                for (; j < RS_LOOK; ++j) {
-                    if ((st[j] & ~RS_VALUE) == 0u) break;          // not published yet: poll again from here
-                    excl += st[j] & RS_VALUE;
-                    if (st[j] & RS_PREFIX) { done = true; break; }
-                }
-                t -= j;
+            for (int j = 0; j < RS_LOOK; ++j) {
+                while ((w[j] >> 40) != st_tiles) w[j] = __hip_atomic_load(sup + (size_t)(s0 + j) * NB + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                excl += (uint32_t)(w[j] & RS_SUP_VALUE);
             }
-            __hip_atomic_store(my_look, RS_PREFIX | (excl + tile_count), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        for (uint32_t t0 = my_sup << st_shift; t0 < tile; t0 += RS_LOOK) {
+            uint32_t w[RS_LOOK];
+#pragma unroll
+            for (int j = 0; j < RS_LOOK; ++j)
+                w[j] = (t0 + j < tile) ? __hip_atomic_load(look + (size_t)(t0 + j) * NB + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : RS_VALID;
+#pragma unroll
+            for (int j = 0; j < RS_LOOK; ++j) {
+                while (!(w[j] & RS_VALID)) w[j] = __hip_atomic_load(look + (size_t)(t0 + j) * NB + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                excl += w[j] & RS_VALUE;
+            }
         }
         s_start[d] = tstart;
         s_dest[d] = gbase + excl;
@@ -212,7 +229,11 @@ void radix_sort_run_ipt(plade_ctx *ctx, const K *ki, K *ko, const uint32_t *vi, 
     constexpr int RS_TILE = RS_THREADS * RS_IPT;
     if (n == 0) return;   // no tiles: nothing to launch
     const uint32_t tiles = cdiv(n, RS_TILE);
-    const size_t look_words = (size_t)passes * tiles * NB;
+    // supertiles of 2^st_shift ~ sqrt(tiles) tiles; per pass: one u32 per (tile, digit), then one u64 per (supertile, digit)
+    uint32_t st_shift = 2;
+    while ((1u << (2 * st_shift)) < tiles && st_shift < 8) ++st_shift;
+    const uint32_t nsup = (tiles >> st_shift) + 1;
+    const size_t pass_words = (size_t)tiles * NB + 2 * (size_t)nsup * NB, look_words = (size_t)passes * pass_words;
     // scratch: tile counters | look-back states | key ping buffer | value ping buffer
     const size_t off_ctr = 0, off_look = off_ctr + 64, off_keys = (off_look + look_words + 3) & ~(size_t)3;
     const size_t key_words = (n * sizeof(K) + 3) / 4, off_vals = (off_keys + key_words + 3) & ~(size_t)3;
@@ -236,8 +257,9 @@ void radix_sort_run_ipt(plade_ctx *ctx, const K *ki, K *ko, const uint32_t *vi, 
         const bool to_out = ((passes - 1 - p) & 1) == 0;    // the last pass lands in the caller's output
         K *dst_k = to_out ? ko : tk;
         uint32_t *dst_v = to_out ? vo : tv;
+        uint32_t *pass_look = t + off_look + (size_t)p * pass_words;
         hipLaunchKernelGGL((k_rs_pass<K, DB, RS_IPT>), dim3(tiles), dim3(RS_THREADS), 0, st, src_k, dst_k, src_v, dst_v, (uint32_t)n, p, gh,
-                           gh_next, t + off_ctr, t + off_look + (size_t)p * tiles * NB);
+                           gh_next, t + off_ctr, pass_look, reinterpret_cast<unsigned long long *>(pass_look + (size_t)tiles * NB), st_shift);
         src_k = dst_k;
         src_v = dst_v;
     }
