@@ -47,7 +47,7 @@ KERNEL_SYMBOLS = {"score_mark": "k_r_mark(", "score_multi": "k_r_rescore(", "ove
                   "pen_walk": "k_pen_walk(", "cluster_edges": "k_cluster_edges("}
 
 
-def pmc_traffic(tag):
+def pmc_traffic(tag, group=4):
     """HBM bytes per REGISTRATION of the roofline kernel (all its launches) from the committed PMC summary (separate
     `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this same command, FETCH_SIZE doubled as
     MI355X_MICROARCH.md prescribes for gfx950; tools/summarize_profiles.py).  None if no summary exists."""
@@ -59,7 +59,7 @@ def pmc_traffic(tag):
     sym = KERNEL_SYMBOLS.get(tag, tag + "(")
     with open(files[-1]) as f:
         rows = list(csv.DictReader(f))
-    regs = next((int(r["launches"]) for r in rows if "k_morton(" in r["kernel"]), 0)   # one launch per registration
+    regs = group * next((int(r["launches"]) for r in rows if "k_morton(" in r["kernel"]), 0)   # one launch per GROUP of `group` registrations
     for r in rows:
         if sym in r["kernel"]:
             rd = float(r["hbm_read_bytes(FETCH_SIZE*1024*2)"])
@@ -69,7 +69,7 @@ def pmc_traffic(tag):
     return None, None
 
 
-def rocprof_stats(tag):
+def rocprof_stats(tag, group=4):
     """(average launch duration in us, share of the GPU time, file) of the roofline kernel in the committed
     `rocprofv3 --kernel-trace --stats` summary of this command (profiles/*_kernel_stats.csv), plus the three kernels with
     the most GPU time there: the live HIP-event figure on the line must agree with this average."""
@@ -89,7 +89,7 @@ def rocprof_stats(tag):
     out = {"file": os.path.relpath(files[-1], ROOT),
            "top_by_gpu_time": [{"kernel": short(r["Name"]), "share": round(float(r["TotalDurationNs"]) / total, 4),
                                 "avg_us": round(float(r["AverageNs"]) / 1e3, 2)} for r in top]}
-    regs = next((int(r["Calls"]) for r in rows if "k_morton(" in r["Name"]), 0)   # one launch per registration
+    regs = group * next((int(r["Calls"]) for r in rows if "k_morton(" in r["Name"]), 0)   # one launch per GROUP of `group` registrations
     out["registrations_profiled"] = regs
     out["kernels_per_registration"] = round(sum(int(r["Calls"]) for r in rows if "rocclr" not in r["Name"]) / max(regs, 1), 1)
     out["copies_and_fills_per_registration"] = round(sum(int(r["Calls"]) for r in rows if "rocclr" in r["Name"]) / max(regs, 1), 1)
@@ -480,7 +480,7 @@ def main():
     # K = --steps; a pipeline of M x S registrations in flight is not sampled fairly by fewer than ~32 rounds of it (the driver's
     # 20 steps are little more than ONE round of 16), so at least 32 * M * S steps are timed, in whole groups; `steps` on the
     # line is the number of steps really timed, `requested_steps` echoes K
-    timed_groups = (max(args.steps, 32 * RIF) + S - 1) // S
+    timed_groups = (max(args.steps, int(os.environ.get("BENCH_MIN_ROUNDS", "32")) * RIF) + S - 1) // S   # (BENCH_MIN_ROUNDS: profiling runs)
     n_timed = timed_groups * S
     window, timed, occ_elapsed, span = run_pipeline(hgroup, lead_groups, timed_groups)
     elapsed = window
@@ -631,7 +631,7 @@ def main():
             # rocprofv3 (and the counter passes) average over ALL launches of the kernel, including those of the fixed launch
             # sequence that find nothing to do and return at once (they move no bytes); the summaries are therefore compared
             # per registration: counter bytes of all launches of a registration / its working launches = per working launch
-            traffic_reg, traffic_src = pmc_traffic(best)
+            traffic_reg, traffic_src = pmc_traffic(best, S)
             idle = st.get(f"k_{best}_idle_launches", 0.0)
             work_per_step = nl / args.profiled_steps
             traffic = traffic_reg / work_per_step if traffic_reg is not None else None
@@ -650,7 +650,7 @@ def main():
                         "why_this_kernel": "largest mover of HBM bytes of the step (the K1 scoring scan, SURVEY.md 8d: 28 B per point and "
                                            "launch); kernels above it in GPU time (rocprof.top_by_gpu_time) are LDS / latency bound "
                                            "and have no HBM figure"}
-            rp = rocprof_stats(best)
+            rp = rocprof_stats(best, S)
             if rp is not None:
                 roofline["rocprof"] = rp
                 if rp.get("avg_launch_us"):

@@ -260,6 +260,10 @@ int plade_sort_pairs(plade_ctx *ctx, const void *keys, const uint32_t *vals, uin
  * words read back through one wait; no reference counterpart).  *mismatches = words that arrived wrong (0 expected). */
 int plade_selftest_readback(plade_ctx *ctx, uint32_t n_ranges, uint32_t words, uint32_t *mismatches);
 
+/* Diagnostic: `count` launches, on this context's stream, of a kernel of `blocks` workgroups that returns at once (mbytes = 0) or
+ * streams `mbytes` MB of scratch memory; returns when they have finished.  tools/exp_interference.py runs it beside the
+ * registrations to measure what foreign kernel boundaries, workgroup dispatches and memory traffic cost them. */
+int plade_diag_launches(plade_ctx *ctx, uint32_t count, uint32_t blocks, uint32_t mbytes);
 /* Times `iters` launches of one hot kernel on resident synthetic-shaped data with HIP events on
  * the ctx stream (used by bench.py for the roofline figure): which = "score" | "overlap" | "match". */
 int plade_kernel_time(plade_ctx *ctx, const char *which, int iters, double *avg_seconds,

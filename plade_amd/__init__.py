@@ -22,7 +22,7 @@ ABI_SYMBOLS = [
     "plade_registration", "plade_registration_minsupport", "plade_cloud_upload", "plade_cloud_free",
     "plade_registration_dev", "plade_dump_get", "plade_stats_get", "plade_kernel_time", "plade_plane_component",
     "plade_sort_pairs", "plade_host_pin", "plade_host_unpin", "plade_score_planes_subset", "plade_registration_next", "plade_cluster_transforms", "plade_device_synchronize", "plade_selftest_readback",
-    "plade_registration_pairs", "plade_registration_pairs_dev", "plade_pair_ctx", "plade_set_candidate_shard",
+    "plade_registration_pairs", "plade_registration_pairs_dev", "plade_pair_ctx", "plade_set_candidate_shard", "plade_diag_launches",
 ]
 
 
@@ -86,6 +86,7 @@ def load_library(path=LIB_PATH):
     sig("plade_registration_pairs", argtypes=[p, u32, p, p, p, p, u32, p, p, p, p, p, p])
     sig("plade_registration_pairs_dev", argtypes=[p, u32, p, p, p, p])
     sig("plade_pair_ctx", argtypes=[p, u32], restype=p)
+    sig("plade_diag_launches", argtypes=[p, u32, u32, u32])
     sig("plade_set_candidate_shard", argtypes=[p, u32, u32, u32, EXCHANGE_FN, p])
     sig("plade_registration_minsupport", argtypes=[p, p, u32, p, u32, i32, i32, p])
     sig("plade_cloud_upload", argtypes=[p, p, u32, C.POINTER(p)])
@@ -403,6 +404,10 @@ class Context:
                 return -1
         self._shard_cb = EXCHANGE_FN(cb)      # keep the trampoline alive
         self._check(self.L.plade_set_candidate_shard(self.h, int(rank), int(world), int(min_candidates), self._shard_cb, None))
+
+    def diag_launches(self, count, blocks=1, mbytes=0):
+        """Diagnostic: `count` launches of an empty (or memory-streaming) kernel on this context's stream, then a wait."""
+        self._check(self.L.plade_diag_launches(self.h, int(count), int(blocks), int(mbytes)))
 
     def _pair_handle(self, index):
         h = self.L.plade_pair_ctx(self.h, int(index))

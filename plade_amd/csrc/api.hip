@@ -81,6 +81,29 @@ extern "C" int plade_set_candidate_shard(plade_ctx *ctx, uint32_t rank, uint32_t
     return PLADE_OK;
 }
 
+// Diagnostic (tools/exp_interference.py): `count` launches on this context's stream of a kernel with `blocks` workgroups of 256
+// lanes that either return at once (mbytes = 0) or read `mbytes` MB of scratch memory, then a wait.  Used to measure what
+// foreign kernel boundaries / workgroup dispatches / memory traffic cost the registrations running beside them.
+namespace plade {
+__global__ void k_diag_load(const float4 *__restrict__ buf, size_t n16, float *__restrict__ sink) {
+    float acc = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) { const float4 v = buf[i]; acc += v.x + v.y + v.z + v.w; }
+    if (acc == 12345.678f) *sink = acc;   // never true: keeps the loads
+}
+}  // namespace plade
+extern "C" int plade_diag_launches(plade_ctx *ctx, uint32_t count, uint32_t blocks, uint32_t mbytes) {
+    return guarded(ctx, [&]() -> int {
+        PLADE_REQUIRE(blocks >= 1 && blocks <= (1u << 20) && mbytes <= 4096, PLADE_EINVAL, "plade_diag_launches: bad argument");
+        const size_t n16 = (size_t)mbytes << 16;
+        float4 *buf = reinterpret_cast<float4 *>(ctx->scratch[0].ensure(n16 * 16 + 256));
+        for (uint32_t i = 0; i < count; ++i)
+            hipLaunchKernelGGL(plade::k_diag_load, dim3(blocks), dim3(256), 0, ctx->stream, buf, n16, reinterpret_cast<float *>(buf));
+        HIP_TRY(hipGetLastError());
+        ctx->sync();
+        return PLADE_OK;
+    });
+}
+
 extern "C" int plade_dump_get(plade_ctx *ctx, const char *name, const void **ptr, int64_t *nbytes) {
     if (!ctx || !name || !ptr || !nbytes) return PLADE_EINVAL;
     auto it = ctx->dump.find(name);
