@@ -22,11 +22,14 @@ namespace plade {
 // ------------------------------------------------------------------------------------------------
 // (a) keys: item i -> packed (group | k | j | i-voxel) key.  The whole-cloud call reads the SoA copy of the cloud
 //     (coalesced 4 B/lane streams); item lists (per-plane clouds) gather 12 of the 24 B of an AoS record.
+// (K = uint32_t when the packed key fits 32 bits -- the usual case: a 10 m room at a 5 cm leaf takes 22 bits + 5 group bits --
+//  so that the sort moves 8 instead of 12 bytes per item and pass; uint64_t otherwise)
+template <class K>
 __global__ void k_voxel_keys(const float *__restrict__ xyz, uint32_t stride, const float *__restrict__ sx,
                              const float *__restrict__ sy, const float *__restrict__ sz, int soa_indexed,
                              const uint32_t *__restrict__ item_point, const uint32_t *__restrict__ item_group,
                              uint32_t n_items, float inv, int lminx, int lminy, int lminz, int bx, int by, int bz,
-                             uint64_t *__restrict__ keys, uint32_t *__restrict__ vals, uint32_t n_group_offsets) {
+                             K *__restrict__ keys, uint32_t *__restrict__ vals, uint32_t n_group_offsets) {
     // n_group_offsets != 0: item_group holds that many ascending item OFFSETS (group g = items [off[g], off[g + 1])) instead
     // of one group id per item; they are staged in LDS and searched (<= 1025 entries)
     __shared__ uint32_t s_off[1026];
@@ -53,7 +56,7 @@ __global__ void k_voxel_keys(const float *__restrict__ xyz, uint32_t stride, con
         while (lo < hi) { const uint32_t mid = (lo + hi + 1) >> 1; if (s_off[mid] <= i) lo = mid; else hi = mid - 1; }
         g = lo;
     } else if (item_group) g = item_group[i];
-    keys[i] = (g << (bx + by + bz)) | (lz << (bx + by)) | (ly << bx) | lx;
+    keys[i] = (K)((g << (bx + by + bz)) | (lz << (bx + by)) | (ly << bx) | lx);
     vals[i] = i;
 }
 
@@ -63,7 +66,8 @@ __global__ void k_voxel_keys(const float *__restrict__ xyz, uint32_t stride, con
 //     contiguous memory.  Tiles of 4096 sorted positions.
 constexpr int VR_T = 256, VR_I = 16, VR_TILE = VR_T * VR_I;
 constexpr uint64_t VR_AGG = 1ull << 32, VR_PREFIX = 2ull << 32, VR_STATUS = 3ull << 32;
-__global__ __launch_bounds__(VR_T) void k_voxel_runs(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals,
+template <class K>
+__global__ __launch_bounds__(VR_T) void k_voxel_runs(const K *__restrict__ keys, const uint32_t *__restrict__ vals,
                                                       uint32_t n, const float *__restrict__ xyz, uint32_t stride,
                                                       const float *__restrict__ ix, const float *__restrict__ iy,
                                                       const float *__restrict__ iz /* SoA planes indexed by item_point, or null */,
@@ -93,10 +97,10 @@ __global__ __launch_bounds__(VR_T) void k_voxel_runs(const uint64_t *__restrict_
         }
     }
     const uint32_t first = tile * VR_TILE + tid * VR_I;
-    uint64_t k[VR_I + 1];
-    k[0] = (first > 0 && first <= n) ? keys[first - 1] : ~0ull;
+    K k[VR_I + 1];
+    k[0] = (first > 0 && first <= n) ? keys[first - 1] : (K)~(K)0;
 #pragma unroll
-    for (int q = 0; q < VR_I; ++q) k[q + 1] = first + q < n ? keys[first + q] : ~0ull;
+    for (int q = 0; q < VR_I; ++q) k[q + 1] = first + q < n ? keys[first + q] : (K)~(K)0;
     uint32_t fl = 0, sum = 0;
 #pragma unroll
     for (int q = 0; q < VR_I; ++q) {
@@ -229,17 +233,31 @@ void VoxelWork::enqueue(plade_ctx *ctx, const float *d_xyz, uint32_t stride, con
     group_offsets.ensure((size_t)n_groups + 2);
     count.ensure(4);
     const unsigned nb = cdiv(n_items, 256);
-    hipLaunchKernelGGL(k_voxel_keys, dim3(nb), dim3(256), 0, ctx->stream, d_xyz, stride, d_soa_x, d_soa_y, d_soa_z, soa_indexed ? 1 : 0, d_item_point,
-                       d_item_group, n_items, inv, lmin[0], lmin[1], lmin[2], bx, by, bz, keys.p, vals.p,
-                       groups_are_offsets ? n_groups + 1 : 0u);
     int gbits = 0;
     while ((1u << gbits) < n_groups) ++gbits;
-    sort_pairs_u64(ctx, keys.p, keys2.p, vals.p, vals2.p, n_items, bx + by + bz + gbits);
+    const int key_bits = bx + by + bz + gbits;
+    const bool narrow = key_bits <= 31;   // (31: the all-ones padding key of k_voxel_runs must not be a real key)
+    uint32_t *k32 = reinterpret_cast<uint32_t *>(keys.p), *k32b = reinterpret_cast<uint32_t *>(keys2.p);
+    if (narrow)
+        hipLaunchKernelGGL(k_voxel_keys<uint32_t>, dim3(nb), dim3(256), 0, ctx->stream, d_xyz, stride, d_soa_x, d_soa_y, d_soa_z, soa_indexed ? 1 : 0,
+                           d_item_point, d_item_group, n_items, inv, lmin[0], lmin[1], lmin[2], bx, by, bz, k32, vals.p,
+                           groups_are_offsets ? n_groups + 1 : 0u);
+    else
+        hipLaunchKernelGGL(k_voxel_keys<uint64_t>, dim3(nb), dim3(256), 0, ctx->stream, d_xyz, stride, d_soa_x, d_soa_y, d_soa_z, soa_indexed ? 1 : 0,
+                           d_item_point, d_item_group, n_items, inv, lmin[0], lmin[1], lmin[2], bx, by, bz, keys.p, vals.p,
+                           groups_are_offsets ? n_groups + 1 : 0u);
+    if (narrow) sort_pairs_u32(ctx, k32, k32b, vals.p, vals2.p, n_items, key_bits);
+    else sort_pairs_u64(ctx, keys.p, keys2.p, vals.p, vals2.p, n_items, key_bits);
     const ScanTicket t = scan_ticket(ctx, n_items, VR_TILE);
     float *ox = sorted_xyz.p, *oy = ox + n_items, *oz = oy + n_items;
-    hipLaunchKernelGGL(k_voxel_runs, dim3(t.tiles), dim3(VR_T), 0, ctx->stream, keys2.p, vals2.p, n_items, d_xyz, stride,
-                       soa_indexed ? d_soa_x : nullptr, soa_indexed ? d_soa_y : nullptr, soa_indexed ? d_soa_z : nullptr, d_item_point,
-                       bx + by + bz, t.state, t.ticket, t.base, t.gen, heads.p, seg_group.p, count.p, ox, oy, oz);
+    if (narrow)
+        hipLaunchKernelGGL(k_voxel_runs<uint32_t>, dim3(t.tiles), dim3(VR_T), 0, ctx->stream, k32b, vals2.p, n_items, d_xyz, stride,
+                           soa_indexed ? d_soa_x : nullptr, soa_indexed ? d_soa_y : nullptr, soa_indexed ? d_soa_z : nullptr, d_item_point,
+                           bx + by + bz, t.state, t.ticket, t.base, t.gen, heads.p, seg_group.p, count.p, ox, oy, oz);
+    else
+        hipLaunchKernelGGL(k_voxel_runs<uint64_t>, dim3(t.tiles), dim3(VR_T), 0, ctx->stream, keys2.p, vals2.p, n_items, d_xyz, stride,
+                           soa_indexed ? d_soa_x : nullptr, soa_indexed ? d_soa_y : nullptr, soa_indexed ? d_soa_z : nullptr, d_item_point,
+                           bx + by + bz, t.state, t.ticket, t.base, t.gen, heads.p, seg_group.p, count.p, ox, oy, oz);
     hipLaunchKernelGGL(k_voxel_centroids, dim3(cdiv(n_items, 128)), dim3(128), 0, ctx->stream, ox, oy, oz, heads.p, seg_group.p,
                        count.p, n_items, n_groups, out_xyz.p, group_offsets.p, d_out_soa);
     HIP_TRY(hipGetLastError());

@@ -180,7 +180,8 @@ struct RCloudArgs {
     const uint32_t *codes;           // its Morton codes
     const uint32_t *cells6;          // start of every level-6 octree cell in the sorted cloud (8^6 + 1 entries), or nullptr
     const uint32_t *orig;            // Morton position -> original point index (nullptr: identity, seam S1c)
-    int32_t *assigned;               // shapeIndex per Morton position (nullptr: all unassigned, seam S1c)
+    int32_t *assigned;               // seams only: the caller's shapeIndex per point (nullptr: all unassigned)
+    uint32_t *abits;                 // the loop's own form: one bit per Morton position, 1 = taken by a shape (nullptr in the seams)
     const float *sub;                // stratified subset, SoA with pitch sub_pitch
     const uint32_t *sub_index;
     uint32_t sub_pitch, n_sub;
@@ -430,9 +431,7 @@ __global__ __launch_bounds__(TPB) void k_r_init(const RArgs A, const RInit I) {
         return;
     }
     const uint32_t base = tile * TILE + threadIdx.x * PPT;
-    if (C.assigned) {
-        if (base + PPT <= ((C.cv.n + 3) & ~3u)) *reinterpret_cast<int4 *>(C.assigned + base) = make_int4(-1, -1, -1, -1);
-    }
+    if (C.abits && (threadIdx.x & 7) == 0 && base < C.cv.n) C.abits[base >> 5] = 0u;   // 8 lanes x 4 points per word
     if (C.sub_assigned && base + PPT <= ((C.n_sub + 3) & ~3u)) *reinterpret_cast<int4 *>(C.sub_assigned + base) = make_int4(-1, -1, -1, -1);
     if (tile < (uint32_t)R_B) agg_clear(chain_of(C, tile).agg, C.L.nb, threadIdx.x, blockDim.x);   // (a call that died half-way left some)
     else if (C.L.nb < (uint32_t)R_B && tile == 0) for (uint32_t b2 = C.L.nb; b2 < (uint32_t)R_B; ++b2) agg_clear(chain_of(C, b2).agg, C.L.nb, threadIdx.x, blockDim.x);
@@ -462,7 +461,7 @@ __global__ __launch_bounds__(256) void k_r_sample(const RArgs A) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= R_H) return;
     const CloudView &c = C.cv;
-    const int32_t *__restrict__ assigned = C.assigned;
+    const uint32_t *__restrict__ abits = C.abits;
     const uint32_t *__restrict__ codes = C.codes;
     const float eps = S->eps, cos_t = S->cos_t;
     Rng rng{mix64(S->seed ^ ((uint64_t)S->round << 32) ^ t)};
@@ -490,7 +489,7 @@ __global__ __launch_bounds__(256) void k_r_sample(const RArgs A) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) cand[u] = rng.next() % c.n;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) av[u] = assigned[cand[u]];
+        for (int u = 0; u < 8; ++u) av[u] = ((abits[cand[u] >> 5] >> (cand[u] & 31u)) & 1u) ? 0 : -1;
 #pragma unroll
         for (int u = 0; u < 8; ++u)
             if (!ok && av[u] == -1) { i0 = cand[u]; ok = true; }
@@ -527,7 +526,7 @@ __global__ __launch_bounds__(256) void k_r_sample(const RArgs A) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) cand[u] = lo + rng.next() % (hi - lo);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) av[u] = assigned[cand[u]];
+        for (int u = 0; u < 8; ++u) av[u] = ((abits[cand[u] >> 5] >> (cand[u] & 31u)) & 1u) ? 0 : -1;
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             if (got >= 3 || av[u] != -1) continue;
@@ -745,7 +744,7 @@ __global__ __launch_bounds__(TPB) void k_r_rescore(const RArgs A, int phase, uns
     if (threadIdx.x < np) s_pl[threadIdx.x] = S->pool_pl[threadIdx.x];
     const float eps = S->eps, cos_t = S->cos_t;
     Tile t;
-    load_tile(t, C.cv.x, C.cv.y, C.cv.z, C.cv.nx, C.cv.ny, C.cv.nz, C.assigned, nullptr, C.cv.n, tile * TILE + threadIdx.x * PPT);
+    load_tile(t, C.cv.x, C.cv.y, C.cv.z, C.cv.nx, C.cv.ny, C.cv.nz, C.assigned, nullptr, C.cv.n, tile * TILE + threadIdx.x * PPT, C.abits);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // only the planes whose slab can reach this wavefront's points get the exact test (slab_mask)
@@ -915,7 +914,7 @@ __global__ __launch_bounds__(TPB) void k_r_mark(const RArgs A, int k, unsigned l
     }
     const float eps = S->eps3, cos_t = S->cos_t;
     Tile t;
-    load_tile(t, C.cv.x, C.cv.y, C.cv.z, C.cv.nx, C.cv.ny, C.cv.nz, C.assigned, nullptr, C.cv.n, tile * TILE + threadIdx.x * PPT);
+    load_tile(t, C.cv.x, C.cv.y, C.cv.z, C.cv.nx, C.cv.ny, C.cv.nz, C.assigned, nullptr, C.cv.n, tile * TILE + threadIdx.x * PPT, C.abits);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t active = 0;
@@ -1725,7 +1724,7 @@ __global__ __launch_bounds__(TPB) void k_r_assign(const RArgs A) {
 #pragma unroll
             for (int q = 0; q < 4; ++q)
                 if (mk & (1u << q)) {
-                    if (C.assigned) C.assigned[p[q]] = id;
+                    if (C.abits) atomicOr(&C.abits[p[q] >> 5], 1u << (p[q] & 31u));
                     if (C.sub_assigned && p[q] % C.sub_stride == 0 && p[q] / C.sub_stride < C.n_sub) C.sub_assigned[p[q] / C.sub_stride] = id;
                     if (out) {
                         out[off] = (int32_t)(C.orig ? C.orig[p[q]] : p[q]);
@@ -1948,7 +1947,8 @@ struct RansacSlot {
     const CloudDev *cloud = nullptr;
     CloudDev sorted;
     DBuf<uint32_t> codes, orig, sub_index;
-    DBuf<int32_t> assigned, out_idx, sub_assigned;
+    DBuf<int32_t> out_idx, sub_assigned;
+    DBuf<uint32_t> abits;
     uint32_t sub_stride = 1;
     DBuf<uint32_t> out_pos;
     DBuf<float> sub;
@@ -1994,7 +1994,7 @@ void slot_buffers(plade_ctx *ctx, RansacSlot &s, uint32_t n) {
     s.round_block.ensure((size_t)R_H * 36 + 64);
     s.out_idx.ensure((size_t)n + 4);
     s.out_pos.ensure((size_t)n + 4);
-    s.assigned.ensure((size_t)n + 8);
+    s.abits.ensure(((size_t)n >> 5) + 8);
     if (!s.res) {
         HIP_TRY(hipHostMalloc((void **)&s.res, sizeof(RResult), hipHostMallocMapped | hipHostMallocCoherent));
         memset(s.res, 0, sizeof(RResult));
@@ -2012,7 +2012,7 @@ RArgs make_args(RansacWork &W, int ng, bool topup) {
         const CloudDev &c = s.sorted;
         // field by field: the bytes of this struct key the captured graphs, padding included (A was zeroed)
         C.cv.x = c.x(); C.cv.y = c.y(); C.cv.z = c.z(); C.cv.nx = c.nx(); C.cv.ny = c.ny(); C.cv.nz = c.nz(); C.cv.n = s.n;
-        C.codes = s.codes.p; C.cells6 = s.cells6.p; C.orig = s.orig.p; C.assigned = s.assigned.p;
+        C.codes = s.codes.p; C.cells6 = s.cells6.p; C.orig = s.orig.p; C.assigned = nullptr; C.abits = s.abits.p;
         C.sub = s.sub.p; C.sub_index = s.sub_index.p; C.sub_pitch = s.sub_pitch; C.n_sub = s.n_sub;
         C.sub_assigned = s.sub_assigned.p; C.sub_stride = s.sub_stride;
         C.st = s.state.p; C.res = s.res_dev;
@@ -2169,7 +2169,7 @@ void ransac_prepare(plade_ctx *ctx, RansacWork &W, const CloudDev *const clouds[
         s.sub_index.ensure((size_t)s.sub_pitch + 4);
         s.sub_assigned.ensure((size_t)s.sub_pitch + 8);
         s.sub_stride = stride;
-        G.c[g] = GatherOut{c.aos.p, s.sorted.soa.p, (uint32_t)c.pitch, s.codes.p, s.orig.p, s.assigned.p, s.sub.p, s.sub_pitch, s.n_sub,
+        G.c[g] = GatherOut{c.aos.p, s.sorted.soa.p, (uint32_t)c.pitch, s.codes.p, s.orig.p, nullptr, s.sub.p, s.sub_pitch, s.n_sub,
                            stride, s.sub_index.p, c.n};
     }
     PLADE_REQUIRE(total < (1ull << 31), PLADE_ELIMIT, "ransac: too many points");
