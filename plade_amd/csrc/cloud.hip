@@ -8,15 +8,6 @@
 
 namespace plade {
 
-__global__ void k_aos_to_soa(const float *__restrict__ aos, uint32_t n, size_t pitch, float *__restrict__ soa) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float2 *p = reinterpret_cast<const float2 *>(aos + 6 * (size_t)i);
-    float2 a = p[0], b = p[1], c = p[2];
-    soa[i] = a.x; soa[pitch + i] = a.y; soa[2 * pitch + i] = b.x;
-    soa[3 * pitch + i] = b.y; soa[4 * pitch + i] = c.x; soa[5 * pitch + i] = c.y;
-}
-
 // A large H2D copy runs on an SDMA engine; a kernel queued BEHIND it on the same stream waits in its hardware queue
 // behind a barrier packet until the engine signals -- and with it every other stream that shares that hardware queue
 // (the runtime maps all streams of a process onto four of them).  Measured: two 24 MB uploads per registration with
@@ -30,22 +21,66 @@ void shape_cloud(CloudDev &out, uint32_t n) {
     out.soa.ensure(6 * out.pitch + 4);
     out.aos.ensure((size_t)n * 6 + 8);
 }
-void convert_on(hipStream_t st, CloudDev &c) {
-    if (c.n) hipLaunchKernelGGL(k_aos_to_soa, dim3(cdiv(c.n, 256)), dim3(256), 0, st, c.aos.p, c.n, c.pitch, c.soa.p);
+// SoA conversion AND bounding box (+ the refusal of non-finite coordinates) of up to 2 * PLADE_GROUP_MAX uploaded clouds in
+// ONE launch: every point is read once (r3: a conversion kernel and a min/max kernel per cloud, each reading the 24 B/point,
+// with an 32-byte copy in front of and behind every min/max kernel: 4 commands per cloud).  grid (workgroups, clouds).
+struct FinishArgs {
+    const float *aos[2 * PLADE_GROUP_MAX];
+    float *soa[2 * PLADE_GROUP_MAX];
+    uint32_t n[2 * PLADE_GROUP_MAX];
+    uint32_t pitch[2 * PLADE_GROUP_MAX];
+};
+__global__ __launch_bounds__(256) void k_finish_uploads(const FinishArgs A, int *__restrict__ slots /* 8 ints per cloud, initialised */) {
+    __shared__ float s_lds[6][8];
+    const int c = blockIdx.y;
+    const uint32_t n = A.n[c];
+    const float *__restrict__ aos = A.aos[c];
+    float *__restrict__ soa = A.soa[c];
+    const size_t pitch = A.pitch[c];
+    int *out = slots + 8 * c;
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    bool bad = false;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float2 *p = reinterpret_cast<const float2 *>(aos + 6 * (size_t)i);
+        const float2 a = p[0], b = p[1], d = p[2];
+        soa[i] = a.x; soa[pitch + i] = a.y; soa[2 * pitch + i] = b.x;
+        soa[3 * pitch + i] = b.y; soa[4 * pitch + i] = d.x; soa[5 * pitch + i] = d.y;
+        const float v[3] = {a.x, a.y, b.x};
+        for (int k = 0; k < 3; ++k) {
+            bad = bad || !(fabsf(v[k]) <= FLT_MAX);   // NaN or infinity (fminf / fmaxf would hide a NaN)
+            mn[k] = fminf(mn[k], v[k]);
+            mx[k] = fmaxf(mx[k], v[k]);
+        }
+    }
+    if (bad) out[6] = 1;
+    block_minmax_commit<3>(mn, mx, out, s_lds);
 }
-// SoA conversion + bounding boxes of clouds whose AoS copy is complete: ONE wait for all of them
+
+// SoA conversion + bounding boxes of clouds whose AoS copy is complete: one small upload (the slots' initial pattern), one
+// kernel, one read-back, ONE wait for all of them
 void finish_uploads(plade_ctx *ctx, CloudDev *const clouds[], int count) {
     plade_ctx::Prefetch &P = ctx->pf;
     constexpr int MAXC = 2 * PLADE_GROUP_MAX;
-    if (!P.h.p) { bbox_init_pattern(P.h.ensure(8 + 8 * MAXC)); P.d.ensure(8 * MAXC); }
-    PLADE_REQUIRE(count <= MAXC, PLADE_EINVAL, "finish_uploads: too many clouds");
-    for (int i = 0; i < count; ++i) {
-        convert_on(ctx->stream, *clouds[i]);
-        bbox_async(ctx->stream, clouds[i]->aos.p, clouds[i]->n, 6, P.d.p + 8 * i, P.h.p, P.h.p + 8 + 8 * i);
+    if (!P.h.p) {
+        int *h = P.h.ensure(8 * MAXC + 8 * MAXC);   // [0, 8 MAXC): the init pattern of every slot; then the slots read back
+        for (int i = 0; i < MAXC; ++i) bbox_init_pattern(h + 8 * i);
+        P.d.ensure(8 * MAXC);
     }
+    PLADE_REQUIRE(count >= 1 && count <= MAXC, PLADE_EINVAL, "finish_uploads: too many clouds");
+    FinishArgs A;
+    memset(&A, 0, sizeof(A));
+    uint32_t n_max = 0;
+    for (int i = 0; i < count; ++i) {
+        A.aos[i] = clouds[i]->aos.p; A.soa[i] = clouds[i]->soa.p; A.n[i] = clouds[i]->n; A.pitch[i] = (uint32_t)clouds[i]->pitch;
+        n_max = std::max(n_max, clouds[i]->n);
+    }
+    int *h_out = P.h.p + 8 * MAXC;
+    HIP_TRY(hipMemcpyAsync(P.d.p, P.h.p, 32 * (size_t)count, hipMemcpyHostToDevice, ctx->stream));
+    if (n_max) hipLaunchKernelGGL(k_finish_uploads, dim3(std::min(cdiv(n_max, 1024), 1024u), count), dim3(256), 0, ctx->stream, A, P.d.p);
+    HIP_TRY(hipMemcpyAsync(h_out, P.d.p, 32 * (size_t)count, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipGetLastError());
     ctx->sync();
-    for (int i = 0; i < count; ++i) bbox_decode(P.h.p + 8 + 8 * i, clouds[i]->bbmin, clouds[i]->bbmax);
+    for (int i = 0; i < count; ++i) bbox_decode(h_out + 8 * i, clouds[i]->bbmin, clouds[i]->bbmax);
 }
 }  // namespace
 

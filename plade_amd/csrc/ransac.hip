@@ -182,6 +182,7 @@ struct RCloudArgs {
     const uint32_t *orig;            // Morton position -> original point index (nullptr: identity, seam S1c)
     int32_t *assigned;               // seams only: the caller's shapeIndex per point (nullptr: all unassigned)
     uint32_t *abits;                 // the loop's own form: one bit per Morton position, 1 = taken by a shape (nullptr in the seams)
+    const float *tile_box;           // per tile of 1024 Morton-neighbouring points: min x, y, z, max x, y, z, 2 pad (nullptr: no culling)
     const float *sub;                // stratified subset, SoA with pitch sub_pitch
     const uint32_t *sub_index;
     uint32_t sub_pitch, n_sub;
@@ -340,6 +341,34 @@ __global__ void k_gather_cloud(const GatherArgs A, const uint32_t *__restrict__ 
             C.sub[s] = a.x; C.sub[sp + s] = a.y; C.sub[2 * sp + s] = b.x;
             C.sub[3 * sp + s] = b.y; C.sub[4 * sp + s] = c.x; C.sub[5 * sp + s] = c.y;
         }
+    }
+}
+
+// Bounding box of every tile (1024 consecutive points of the Morton order = a patch of ~0.5 m): the mark pass skips the tiles
+// none of its planes' slabs can reach without loading them.  grid: the concatenated tiles of the clouds.
+struct TileBoxArgs { const float *x[R_G], *y[R_G], *z[R_G]; float *box[R_G]; uint32_t n[R_G]; uint32_t ng; uint32_t tile_start[R_G + 1]; };
+__global__ __launch_bounds__(K1_TPB) void k_tile_boxes(const TileBoxArgs A) {
+    __shared__ float s_v[6][K1_TPB / 64];
+    int g = 0;
+#pragma unroll
+    for (int q = 1; q < R_G; ++q) g += (q < (int)A.ng && blockIdx.x >= A.tile_start[q]) ? 1 : 0;
+    const uint32_t tile = blockIdx.x - A.tile_start[g], n = A.n[g];
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    const uint32_t base = tile * K1_TILE + threadIdx.x * K1_PPT;
+    for (int q = 0; q < K1_PPT; ++q)
+        if (base + q < n) {
+            const float v[3] = {A.x[g][base + q], A.y[g][base + q], A.z[g][base + q]};
+            for (int k = 0; k < 3; ++k) { mn[k] = fminf(mn[k], v[k]); mx[k] = fmaxf(mx[k], v[k]); }
+        }
+    for (int k = 0; k < 3; ++k)
+        for (int d = 32; d >= 1; d >>= 1) { mn[k] = fminf(mn[k], __shfl_xor(mn[k], d, 64)); mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], d, 64)); }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) for (int k = 0; k < 3; ++k) { s_v[k][wave] = mn[k]; s_v[3 + k][wave] = mx[k]; }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        float v = s_v[threadIdx.x][0];
+        for (int w = 1; w < K1_TPB / 64; ++w) v = threadIdx.x < 3 ? fminf(v, s_v[threadIdx.x][w]) : fmaxf(v, s_v[threadIdx.x][w]);
+        A.box[g][8 * (size_t)tile + threadIdx.x] = v;
     }
 }
 
@@ -894,7 +923,7 @@ __global__ __launch_bounds__(TPB) void k_r_mark(const RArgs A, int k, unsigned l
     const ClockScope clock_scope(clk);
     __shared__ float4 s_pl[R_B];
     __shared__ float s_fr[R_B][9];
-    __shared__ uint32_t s_skip[R_B];
+    __shared__ uint32_t s_skip[R_B], s_need[R_B];
     __shared__ uint32_t s_w[R_B][TPB / 64];
     __shared__ float s_bb[R_B][4][TPB / 64];
     uint32_t tile;
@@ -906,6 +935,20 @@ __global__ __launch_bounds__(TPB) void k_r_mark(const RArgs A, int k, unsigned l
     if (threadIdx.x < nc) {
         const PlaneState *st = &chain_of(C, threadIdx.x).hdr->st[k];
         s_skip[threadIdx.x] = st->converged;
+        // Can this plane's 3 eps slab reach the tile at all?  The interval of n.p over the tile's bounding box, widened far beyond
+        // the rounding of the three-term sums (as slab_mask does per wavefront); a plane that cannot gets a zero count for the
+        // tile without a point being loaded.  (A NaN distance -- a slot whose LS fit was impossible -- reaches nothing.)
+        uint32_t need = 1u;
+        if (C.tile_box) {
+            const float *bx = C.tile_box + 8 * (size_t)tile;
+            const float e3 = S->eps3;
+            const float lo = fminf(st->n[0] * bx[0], st->n[0] * bx[3]) + fminf(st->n[1] * bx[1], st->n[1] * bx[4]) + fminf(st->n[2] * bx[2], st->n[2] * bx[5]);
+            const float hi = fmaxf(st->n[0] * bx[0], st->n[0] * bx[3]) + fmaxf(st->n[1] * bx[1], st->n[1] * bx[4]) + fmaxf(st->n[2] * bx[2], st->n[2] * bx[5]);
+            const float slack = 1.001f * e3 + 1e-5f * (fabsf(lo) + fabsf(hi) + fabsf(st->dist));
+            need = (st->dist == st->dist && !(st->dist - hi > slack || lo - st->dist > slack)) ? 1u : 0u;
+            if (!(lo == lo && hi == hi)) need = st->dist == st->dist ? 1u : 0u;   // a NaN normal: let the exact test decide
+        }
+        s_need[threadIdx.x] = need;
         s_pl[threadIdx.x] = make_float4(st->n[0], st->n[1], st->n[2], st->dist);
         float *fr = s_fr[threadIdx.x];
         fr[0] = st->pos[0]; fr[1] = st->pos[1]; fr[2] = st->pos[2];
@@ -913,14 +956,20 @@ __global__ __launch_bounds__(TPB) void k_r_mark(const RArgs A, int k, unsigned l
         fr[6] = st->a1[0]; fr[7] = st->a1[1]; fr[8] = st->a1[2];
     }
     const float eps = S->eps3, cos_t = S->cos_t;
+    __syncthreads();
+    uint32_t active = 0, needed = 0;
+    for (uint32_t j = 0; j < nc; ++j) { active += s_skip[j] ? 0u : 1u; needed += (!s_skip[j] && s_need[j]) ? 1u : 0u; }
+    if (needed == 0) {   // uniform: no slab reaches this tile (about half of all (tile, launch) pairs): nothing is loaded
+        if (threadIdx.x < nc && !s_skip[threadIdx.x]) chain_of(C, threadIdx.x).bc1[tile] = 0u;
+        if (tile == 0 && threadIdx.x == 0 && active) { S->n_mark_launches += 1; S->n_mark_chains += active; }
+        return;
+    }
     Tile t;
     load_tile(t, C.cv.x, C.cv.y, C.cv.z, C.cv.nx, C.cv.ny, C.cv.nz, C.assigned, nullptr, C.cv.n, tile * TILE + threadIdx.x * PPT, C.abits);
-    __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t active = 0;
     for (uint32_t j = 0; j < nc; ++j) {
         if (s_skip[j]) continue;   // uniform
-        ++active;
+        if (!s_need[j]) { if (lane == 0) s_w[j][wave] = 0u; continue; }   // uniform: provably no inlier here
         const float4 pl = s_pl[j];
         uint32_t m = 0, c = 0;
         float mn0 = INFINITY, mn1 = INFINITY, mx0 = -INFINITY, mx1 = -INFINITY;
@@ -1949,6 +1998,7 @@ struct RansacSlot {
     DBuf<uint32_t> codes, orig, sub_index;
     DBuf<int32_t> out_idx, sub_assigned;
     DBuf<uint32_t> abits;
+    DBuf<float> tile_box;
     uint32_t sub_stride = 1;
     DBuf<uint32_t> out_pos;
     DBuf<float> sub;
@@ -2012,7 +2062,7 @@ RArgs make_args(RansacWork &W, int ng, bool topup) {
         const CloudDev &c = s.sorted;
         // field by field: the bytes of this struct key the captured graphs, padding included (A was zeroed)
         C.cv.x = c.x(); C.cv.y = c.y(); C.cv.z = c.z(); C.cv.nx = c.nx(); C.cv.ny = c.ny(); C.cv.nz = c.nz(); C.cv.n = s.n;
-        C.codes = s.codes.p; C.cells6 = s.cells6.p; C.orig = s.orig.p; C.assigned = nullptr; C.abits = s.abits.p;
+        C.codes = s.codes.p; C.cells6 = s.cells6.p; C.orig = s.orig.p; C.assigned = nullptr; C.abits = s.abits.p; C.tile_box = s.tile_box.p;
         C.sub = s.sub.p; C.sub_index = s.sub_index.p; C.sub_pitch = s.sub_pitch; C.n_sub = s.n_sub;
         C.sub_assigned = s.sub_assigned.p; C.sub_stride = s.sub_stride;
         C.st = s.state.p; C.res = s.res_dev;
@@ -2194,6 +2244,16 @@ void ransac_prepare(plade_ctx *ctx, RansacWork &W, const CloudDev *const clouds[
         C6.codes[g] = s.codes.p; C6.n[g] = s.n; C6.table[g] = s.cells6.p;
     }
     hipLaunchKernelGGL(k_cells6, dim3(cdiv((1u << 18) + 1, 256), n_clouds), dim3(256), 0, ctx->stream, C6);
+    TileBoxArgs TB;
+    memset(&TB, 0, sizeof(TB));
+    TB.ng = (uint32_t)n_clouds;
+    for (int g = 0; g < R_G; ++g) {
+        RansacSlot &s = W.slot[g < n_clouds ? g : 0];
+        if (g < n_clouds) s.tile_box.ensure(8 * (size_t)s.L.nb + 8);
+        TB.x[g] = s.sorted.x(); TB.y[g] = s.sorted.y(); TB.z[g] = s.sorted.z(); TB.box[g] = s.tile_box.p; TB.n[g] = s.n;
+        TB.tile_start[g + 1] = TB.tile_start[g] + (g < n_clouds ? s.L.nb : 0u);
+    }
+    if (TB.tile_start[R_G]) hipLaunchKernelGGL(k_tile_boxes, dim3(TB.tile_start[R_G]), dim3(K1_TPB), 0, ctx->stream, TB);
     HIP_TRY(hipGetLastError());
 }
 
