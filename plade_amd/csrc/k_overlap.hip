@@ -76,23 +76,35 @@ __global__ void k_occ_bits(const uint32_t *__restrict__ keys, uint32_t n, unsign
     const uint32_t k = keys[i];
     if (i == 0 || keys[i - 1] != k) atomicOr(&bits[k >> 6], 1ull << (k & 63));
 }
-__global__ void k_occ_pop(const unsigned long long *__restrict__ bits, uint32_t nw, uint32_t *__restrict__ pop) {
+// ... and the BLOCK mask: one bit per 4 x 4 x 4-cell block, set when the block holds any occupied cell (bit b of blk[b >> 6]; the
+// 64 lanes of a wavefront look at 64 consecutive blocks, one ballot is one word).  The verification kernel keeps it in LDS.
+__global__ void k_occ_pop(const unsigned long long *__restrict__ bits, uint32_t nw, uint32_t *__restrict__ pop,
+                          unsigned long long *__restrict__ blk) {
     const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
-    if (w < nw) pop[w] = (uint32_t)__popcll(bits[w]);
+    const unsigned long long b = w < nw ? bits[w] : 0ull;
+    if (w < nw) pop[w] = (uint32_t)__popcll(b);
     if (w == nw) pop[w] = 0;
+    const unsigned long long any = __ballot(b != 0ull);
+    if ((threadIdx.x & 63) == 0 && w <= nw) blk[w >> 6] = any;
 }
 __global__ void k_occ_start(const float *__restrict__ xyz, uint32_t stride, const uint32_t *__restrict__ keys,
                             const uint32_t *__restrict__ vals, uint32_t n, const unsigned long long *__restrict__ bits,
                             const uint32_t *__restrict__ rank, uint32_t nw, float4 *__restrict__ sorted,
-                            uint32_t *__restrict__ occ_start) {
+                            uint32_t *__restrict__ occ_start, float4 *__restrict__ cell_first) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t v = vals[i];
-    sorted[i] = make_float4(xyz[(size_t)v * stride], xyz[(size_t)v * stride + 1], xyz[(size_t)v * stride + 2],
-                            __uint_as_float(v));
+    const float4 pt = make_float4(xyz[(size_t)v * stride], xyz[(size_t)v * stride + 1], xyz[(size_t)v * stride + 2], __uint_as_float(v));
+    sorted[i] = pt;
     const uint32_t k = keys[i];
-    if (i == 0 || keys[i - 1] != k)
-        occ_start[rank[k >> 6] + (uint32_t)__popcll(bits[k >> 6] & ((1ull << (k & 63)) - 1ull))] = i;
+    if (i == 0 || keys[i - 1] != k) {
+        const uint32_t rk = rank[k >> 6] + (uint32_t)__popcll(bits[k >> 6] & ((1ull << (k & 63)) - 1ull));
+        occ_start[rk] = i;
+        // the cell's first point next to its position in the sorted array, bit 31 set when it is the cell's ONLY point (nearly
+        // every cell of a voxel-downsampled cloud): the verification kernel then needs one load per occupied cell
+        const bool single = i == n - 1 || keys[i + 1] != k;
+        cell_first[rk] = make_float4(pt.x, pt.y, pt.z, __uint_as_float(i | (single ? 0x80000000u : 0u)));
+    }
     if (i == n - 1) occ_start[rank[nw]] = n;
 }
 
@@ -151,12 +163,14 @@ void TargetGrid::build(plade_ctx *ctx, const float *d_xyz, uint32_t n_pts, uint3
     if (compact) {
         const uint32_t nw = (uint32_t)((ncells + 63) / 64);
         occ_bits.ensure(nw + 1); occ_pop.ensure(nw + 2); occ_rank.ensure(nw + 2); occ_start.ensure((size_t)n + 2);
+        occ_blk.ensure(nw / 64 + 2);
+        cell_first.ensure((size_t)n + 2);
         HIP_TRY(hipMemsetAsync(occ_bits.p, 0, ((size_t)nw + 1) * 8, ctx->stream));
         hipLaunchKernelGGL(k_occ_bits, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, keys2.p, n, occ_bits.p);
-        hipLaunchKernelGGL(k_occ_pop, dim3(cdiv(nw + 1, 256)), dim3(256), 0, ctx->stream, occ_bits.p, nw, occ_pop.p);
+        hipLaunchKernelGGL(k_occ_pop, dim3(cdiv(nw + 1, 256)), dim3(256), 0, ctx->stream, occ_bits.p, nw, occ_pop.p, occ_blk.p);
         exclusive_scan_u32(ctx, occ_pop.p, occ_rank.p, (size_t)nw + 1);
         hipLaunchKernelGGL(k_occ_start, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, d_xyz, stride, keys2.p, vals2.p, n,
-                           occ_bits.p, occ_rank.p, nw, sorted.p, occ_start.p);
+                           occ_bits.p, occ_rank.p, nw, sorted.p, occ_start.p, cell_first.p);
         HIP_TRY(hipGetLastError());
         return;
     }
@@ -169,100 +183,142 @@ void TargetGrid::build(plade_ctx *ctx, const float *d_xyz, uint32_t n_pts, uint3
 }
 
 constexpr int OV_TPB = 256;
-constexpr int OV_KCH = 2;   // candidates per workgroup: few, so that even ~10 candidates fill the GPU
+constexpr int OV_KCH = 16;             // candidates per chunk at most (few candidates: chunks of 2, so that ~10 candidates fill the GPU)
+constexpr uint32_t OV_MASK_MAX = 48u << 10;   // bytes of LDS the block mask may take (3.9e5 blocks = 2.5e7 cells); above: no mask
 
+// One work item = one tile of 256 source points x one chunk of `ch` candidates.  A workgroup takes a contiguous range of items
+// (chunk-major, so that it changes chunk at most once or twice), keeps the chunk's transforms and its hit counters in LDS and
+// adds the counters to the global counts when the chunk changes: the source tile is read once per chunk instead of once per
+// pair of candidates (r3), and a counter shared by thousands of wavefronts on eight XCDs is touched once per workgroup and
+// candidate.  With `mask_words` != 0 the workgroup first copies the target grid's BLOCK mask (k_occ_pop) into LDS: a probe whose
+// <= 8 blocks are all empty -- nearly every probe of a wrong candidate, and everything outside the target -- ends without a
+// global load; only the words of non-empty blocks are fetched.
 __global__ __launch_bounds__(OV_TPB) void k_overlap(const float *__restrict__ sx, const float *__restrict__ sy,
                                                     const float *__restrict__ sz, uint32_t n_s,
                                                     const float4 *__restrict__ tgt,
                                                     const unsigned long long *__restrict__ occ_bits,
                                                     const uint32_t *__restrict__ occ_rank,
-                                                    const uint32_t *__restrict__ occ_start, GridParams g,
+                                                    const uint32_t *__restrict__ occ_start,
+                                                    const float4 *__restrict__ cell_first,
+                                                    const uint32_t *__restrict__ blk_mask, uint32_t mask_words, GridParams g,
                                                     const float *__restrict__ T /*K x 16*/,
                                                     const float *__restrict__ centers /*K x 3*/, uint32_t K, float R2,
-                                                    float r2, int32_t *__restrict__ counts) {
+                                                    float r2, int32_t *__restrict__ counts, uint32_t ch, uint32_t items_per_wg) {
     __shared__ float s_T[OV_KCH][12];
     __shared__ float s_c[OV_KCH][3];
-    const uint32_t k0 = blockIdx.y * OV_KCH;
-    const uint32_t kc = min((uint32_t)OV_KCH, K - k0);
-    for (uint32_t i = threadIdx.x; i < kc * 12; i += OV_TPB) s_T[i / 12][i % 12] = T[(size_t)(k0 + i / 12) * 16 + i % 12];
-    for (uint32_t i = threadIdx.x; i < kc * 3; i += OV_TPB) s_c[i / 3][i % 3] = centers[(size_t)(k0 + i / 3) * 3 + i % 3];
-    __syncthreads();
-    // every workgroup walks several tiles of source points and keeps its counts in registers: one atomic per
-    // workgroup and candidate at the end (a counter shared by thousands of wavefronts on eight XCDs
-    // serialises at the memory side -- that, not the probing, bounded this kernel)
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t acc[OV_KCH];
+    __shared__ uint32_t s_cnt[OV_KCH];
+    extern __shared__ uint32_t s_mask[];
+    for (uint32_t i = threadIdx.x; i < mask_words; i += OV_TPB) s_mask[i] = blk_mask[i];
+    const int lane = threadIdx.x & 63;
+    const uint32_t ntiles = (n_s + OV_TPB - 1) / OV_TPB, nchunks = (K + ch - 1) / ch;
+    const uint64_t nitems = (uint64_t)ntiles * nchunks;
+    const uint64_t it0 = (uint64_t)blockIdx.x * items_per_wg, it1 = min(nitems, it0 + items_per_wg);
+    uint32_t cur = 0xffffffffu, k0 = 0, kc = 0;
+    for (uint64_t item = it0; item < it1; ++item) {
+        const uint32_t chunk = (uint32_t)(item / ntiles), tile = (uint32_t)(item % ntiles);
+        if (chunk != cur) {   // uniform
+            __syncthreads();
+            if (cur != 0xffffffffu && threadIdx.x < kc && s_cnt[threadIdx.x]) atomicAdd(&counts[k0 + threadIdx.x], (int32_t)s_cnt[threadIdx.x]);
+            __syncthreads();
+            cur = chunk; k0 = chunk * ch; kc = min(ch, K - k0);
+            for (uint32_t i = threadIdx.x; i < kc * 12; i += OV_TPB) s_T[i / 12][i % 12] = T[(size_t)(k0 + i / 12) * 16 + i % 12];
+            for (uint32_t i = threadIdx.x; i < kc * 3; i += OV_TPB) s_c[i / 3][i % 3] = centers[(size_t)(k0 + i / 3) * 3 + i % 3];
+            if (threadIdx.x < OV_KCH) s_cnt[threadIdx.x] = 0u;
+            __syncthreads();
+        }
+        const uint32_t i = tile * OV_TPB + threadIdx.x;
+        const bool live = i < n_s;
+        const f3 p = live ? f3(sx[i], sy[i], sz[i]) : f3();
+        for (uint32_t kk = 0; kk < kc; ++kk) {
+            bool hit = false;
+            if (live) {
+                const f3 q_ = pcl_xform(s_T[kk], p);
+                const f3 c(s_c[kk][0], s_c[kk][1], s_c[kk][2]);
+                const int cx = (int)floorf((q_.x - g.mnx) * g.inv), cy = (int)floorf((q_.y - g.mny) * g.inv),
+                          cz = (int)floorf((q_.z - g.mnz) * g.inv);
+                const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.dx - 1);
+                const int y0 = max(cy - 1, 0), y1 = min(cy + 1, g.dy - 1);
+                const int z0 = max(cz - 1, 0), z1 = min(cz + 1, g.dz - 1);
+                // the <= 27 cells live in <= 8 blocks of 4 x 4 x 4: one word + one rank per block.  The words of all non-empty blocks
+                // are fetched together (one load latency instead of up to eight dependent ones), then looked at one after the other
+                if (x0 <= x1 && y0 <= y1 && z0 <= z1) {
+                    const int bx0 = x0 >> 2, by0 = y0 >> 2, bz0 = z0 >> 2;
+                    const int nbx = (x1 >> 2) - bx0 + 1, nby = (y1 >> 2) - by0 + 1, nbz = (z1 >> 2) - bz0 + 1;   // 1 or 2 each
+                    // Three rounds of INDEPENDENT loads instead of a chain of ~20 dependent ones (r3: block word -> rank -> start ->
+                    // point, cell after cell: ~20 round trips to L2 per probe of a point near a surface): (1) the words of the
+                    // non-empty blocks, (2) the ranks of the blocks that hold wanted cells, (3) the first points of up to four
+                    // wanted cells at a time (cell_first: point + "only point of its cell").
+                    unsigned long long w8[8], m8[8];
 #pragma unroll
-    for (int kk = 0; kk < OV_KCH; ++kk) acc[kk] = 0;
-    const uint32_t ntiles = (n_s + OV_TPB - 1) / OV_TPB;
-    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const uint32_t i = tile * OV_TPB + threadIdx.x;
-    const bool live = i < n_s;
-    f3 p = live ? f3(sx[i], sy[i], sz[i]) : f3();
+                    for (int q = 0; q < 8; ++q) {
+                        const int ix = q & 1, iy = (q >> 1) & 1, iz = q >> 2;
+                        w8[q] = 0ull;
+                        if (ix < nbx && iy < nby && iz < nbz) {
+                            const uint32_t blk = block_of((bx0 + ix) << 2, (by0 + iy) << 2, (bz0 + iz) << 2, g.dx, g.dy);
+                            if (!mask_words || ((s_mask[blk >> 5] >> (blk & 31u)) & 1u)) w8[q] = occ_bits[blk];
+                        }
+                    }
+                    uint32_t r8[8];
+                    bool any = false;
 #pragma unroll
-    for (uint32_t kk = 0; kk < (uint32_t)OV_KCH; ++kk) {
-        if (kk >= kc) break;
-        bool hit = false;
-        if (live) {
-            const f3 q_ = pcl_xform(s_T[kk], p);
-            const f3 c(s_c[kk][0], s_c[kk][1], s_c[kk][2]);
-            const int cx = (int)floorf((q_.x - g.mnx) * g.inv), cy = (int)floorf((q_.y - g.mny) * g.inv),
-                      cz = (int)floorf((q_.z - g.mnz) * g.inv);
-            const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.dx - 1);
-            const int y0 = max(cy - 1, 0), y1 = min(cy + 1, g.dy - 1);
-            const int z0 = max(cz - 1, 0), z1 = min(cz + 1, g.dz - 1);
-            // the <= 27 cells live in <= 8 blocks of 4 x 4 x 4: one word + one rank per block.  The words of all blocks are
-            // fetched together (most probes of a wrong candidate find nothing: one load latency instead of up to eight
-            // dependent ones), then the occupied blocks are looked at one after the other
-            if (x0 <= x1 && y0 <= y1 && z0 <= z1) {
-                const int bx0 = x0 >> 2, by0 = y0 >> 2, bz0 = z0 >> 2;
-                const int nbx = (x1 >> 2) - bx0 + 1, nby = (y1 >> 2) - by0 + 1, nbz = (z1 >> 2) - bz0 + 1;   // 1 or 2 each
-                unsigned long long w8[8];
+                    for (int q = 0; q < 8; ++q) {
+                        m8[q] = 0ull;
+                        r8[q] = 0u;
+                        if (!w8[q]) continue;
+                        const int bx = bx0 + (q & 1), by = by0 + ((q >> 1) & 1), bz = bz0 + (q >> 2);
+                        // wanted cells of this block: the part of [x0,x1] x [y0,y1] x [z0,z1] inside it
+                        unsigned long long mx = 0, my = 0, mz = 0;
+                        for (int v = max(x0, bx << 2); v <= min(x1, (bx << 2) + 3); ++v) mx |= 0x1111111111111111ull << (v & 3);
+                        for (int v = max(y0, by << 2); v <= min(y1, (by << 2) + 3); ++v) my |= 0x000f000f000f000full << ((v & 3) << 2);
+                        for (int v = max(z0, bz << 2); v <= min(z1, (bz << 2) + 3); ++v) mz |= 0xffffull << ((v & 3) << 4);
+                        m8[q] = w8[q] & mx & my & mz;
+                        if (m8[q]) { r8[q] = occ_rank[block_of(bx << 2, by << 2, bz << 2, g.dx, g.dy)]; any = true; }
+                    }
+                    while (any && !hit) {
+                        uint32_t rk0 = 0xffffffffu, rk1 = 0xffffffffu, rk2 = 0xffffffffu, rk3 = 0xffffffffu;
+                        int cnt = 0;
+                        any = false;
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const int ix = q & 1, iy = (q >> 1) & 1, iz = q >> 2;
-                    w8[q] = (ix < nbx && iy < nby && iz < nbz) ? occ_bits[block_of((bx0 + ix) << 2, (by0 + iy) << 2, (bz0 + iz) << 2, g.dx, g.dy)] : 0ull;
-                }
+                        for (int q = 0; q < 8; ++q) {
+                            while (m8[q] && cnt < 4) {
+                                const int bit = __ffsll((long long)m8[q]) - 1;
+                                m8[q] &= m8[q] - 1;
+                                const uint32_t rk = r8[q] + (uint32_t)__popcll(w8[q] & ((1ull << bit) - 1ull));
+                                if (cnt == 0) rk0 = rk; else if (cnt == 1) rk1 = rk; else if (cnt == 2) rk2 = rk; else rk3 = rk;
+                                ++cnt;
+                            }
+                            any = any || m8[q] != 0ull;
+                        }
+                        float4 c0, c1, c2, c3;
+                        if (rk0 != 0xffffffffu) c0 = cell_first[rk0];
+                        if (rk1 != 0xffffffffu) c1 = cell_first[rk1];
+                        if (rk2 != 0xffffffffu) c2 = cell_first[rk2];
+                        if (rk3 != 0xffffffffu) c3 = cell_first[rk3];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const unsigned long long w = w8[q];
-                    if (!w || hit) continue;
-                    const int bx = bx0 + (q & 1), by = by0 + ((q >> 1) & 1), bz = bz0 + (q >> 2);
-                    const uint32_t blk = block_of(bx << 2, by << 2, bz << 2, g.dx, g.dy);
-                    // wanted cells of this block: the part of [x0,x1] x [y0,y1] x [z0,z1] inside it
-                    unsigned long long mx = 0, my = 0, mz = 0;
-                    for (int v = max(x0, bx << 2); v <= min(x1, (bx << 2) + 3); ++v) mx |= 0x1111111111111111ull << (v & 3);
-                    for (int v = max(y0, by << 2); v <= min(y1, (by << 2) + 3); ++v) my |= 0x000f000f000f000full << ((v & 3) << 2);
-                    for (int v = max(z0, bz << 2); v <= min(z1, (bz << 2) + 3); ++v) mz |= 0xffffull << ((v & 3) << 4);
-                    unsigned long long m = w & mx & my & mz;
-                    if (!m) continue;
-                    const uint32_t base = occ_rank[blk];
-                    while (m && !hit) {
-                        const int bit = __ffsll((long long)m) - 1;
-                        m &= m - 1;
-                        const uint32_t rk = base + (uint32_t)__popcll(w & ((1ull << bit) - 1ull));
-                        const uint32_t pb = occ_start[rk], pe = occ_start[rk + 1];
-                        for (uint32_t j = pb; j < pe; ++j) {
-                            const float4 t4 = tgt[j];
-                            const f3 t(t4.x, t4.y, t4.z);
-                            if (flann_d2(q_, t) < r2 && flann_d2(c, t) < R2) { hit = true; break; }
+                        for (int e = 0; e < 4; ++e) {
+                            const uint32_t rk = e == 0 ? rk0 : e == 1 ? rk1 : e == 2 ? rk2 : rk3;
+                            if (rk == 0xffffffffu || hit) continue;
+                            const float4 cf = e == 0 ? c0 : e == 1 ? c1 : e == 2 ? c2 : c3;
+                            const f3 t(cf.x, cf.y, cf.z);
+                            if (flann_d2(q_, t) < r2 && flann_d2(c, t) < R2) { hit = true; continue; }
+                            const uint32_t tag = __float_as_uint(cf.w);
+                            if (tag & 0x80000000u) continue;              // that was the cell's only point
+                            const uint32_t pe = occ_start[rk + 1];
+                            for (uint32_t j2 = (tag & 0x7fffffffu) + 1; j2 < pe; ++j2) {
+                                const float4 t4 = tgt[j2];
+                                const f3 t2(t4.x, t4.y, t4.z);
+                                if (flann_d2(q_, t2) < r2 && flann_d2(c, t2) < R2) { hit = true; break; }
+                            }
                         }
                     }
                 }
             }
+            const uint32_t h = (uint32_t)__popcll(__ballot(hit));
+            if (lane == 0 && h) atomicAdd(&s_cnt[kk], h);
         }
-        acc[kk] += (uint32_t)__popcll(__ballot(hit));
     }
-    }
-    __shared__ uint32_t s_acc[OV_TPB / 64][OV_KCH];
-    if (lane == 0)
-        for (int kk = 0; kk < OV_KCH; ++kk) s_acc[wave][kk] = acc[kk];
     __syncthreads();
-    if (threadIdx.x < kc) {
-        uint32_t tot = 0;
-        for (int w = 0; w < OV_TPB / 64; ++w) tot += s_acc[w][threadIdx.x];
-        if (tot) atomicAdd(&counts[k0 + threadIdx.x], (int32_t)tot);
-    }
+    if (cur != 0xffffffffu && threadIdx.x < kc && s_cnt[threadIdx.x]) atomicAdd(&counts[k0 + threadIdx.x], (int32_t)s_cnt[threadIdx.x]);
 }
 
 // source points into a spatially blocked order: key = blocked cell id in the source's own frame
@@ -359,12 +415,20 @@ void overlap_counts(plade_ctx *ctx, OverlapWork &work, const float *d_sx, const 
                            d_centers + (size_t)k0 * 3, kc, R2, d_any + k0);
     }
     if (n_s) {
-        dim3 gr(std::min(cdiv(n_s, OV_TPB), 256u), cdiv(K, OV_KCH));
+        // chunks of 2 candidates while there are few (the default <= 201, of which ~20 reach this stage: the items must fill the
+        // GPU), of OV_KCH from a few hundred candidates on (BASELINE configs[4]: 10^4)
+        const uint32_t ch = K <= 64 ? 2u : (K <= 512 ? 4u : (uint32_t)OV_KCH);
+        const uint64_t nitems = (uint64_t)cdiv(n_s, OV_TPB) * cdiv(K, ch);
+        const uint32_t wgs = (uint32_t)std::min<uint64_t>(nitems, 2048);
+        const uint32_t per = (uint32_t)((nitems + wgs - 1) / wgs);
+        const uint32_t nw = (uint32_t)((grid.ncells + 63) / 64);
+        const uint32_t mask_words = (nw + 31) / 32 * 4 <= OV_MASK_MAX ? (nw + 63) / 64 * 2 : 0u;   // whole 64-bit words of occ_blk
         // algorithmic bytes: K * n_s * 12 B source stream + n_t * 12 B target
         ctx->ev_begin("overlap", (double)K * n_s * 12.0 + (double)grid.n * 12.0);
         PLADE_REQUIRE(grid.compact, PLADE_EINVAL, "overlap: the target grid needs the compact occupancy index");
-        hipLaunchKernelGGL(k_overlap, gr, dim3(OV_TPB), 0, ctx->stream, d_sx, d_sy, d_sz, n_s, grid.sorted.p,
-                           grid.occ_bits.p, grid.occ_rank.p, grid.occ_start.p, g, d_T, d_centers, K, R2, r2, d_counts);
+        hipLaunchKernelGGL(k_overlap, dim3(cdiv(nitems, per)), dim3(OV_TPB), mask_words * 4, ctx->stream, d_sx, d_sy, d_sz, n_s, grid.sorted.p,
+                           grid.occ_bits.p, grid.occ_rank.p, grid.occ_start.p, grid.cell_first.p, reinterpret_cast<const uint32_t *>(grid.occ_blk.p), mask_words, g,
+                           d_T, d_centers, K, R2, r2, d_counts, ch, per);
         ctx->ev_end();
     }
     HIP_TRY(hipGetLastError());

@@ -17,8 +17,10 @@ struct TargetGrid {
     // of 4 x 4 x 4: cell id = block id * 64 + (x&3 | (y&3)<<2 | (z&3)<<4), so one 64-bit word is one block,
     // a 27-cell neighbourhood touches at most 8 words, and the points of a block are contiguous
     DBuf<unsigned long long> occ_bits;   // ncells / 64 words
+    DBuf<unsigned long long> occ_blk;    // one bit per block (word of occ_bits): non-empty; staged in LDS by the verification kernel
     DBuf<uint32_t> occ_pop, occ_rank;    // per word: popcount, exclusive prefix (+ total)
     DBuf<uint32_t> occ_start;            // per occupied cell (+ 1): first sorted position
+    DBuf<float4> cell_first;             // per occupied cell: its first point, w = that position | 1 << 31 when it is the cell's only point
     bool compact = false;
     // d_xyz: device pointer, `stride` floats between points; min_cell = largest probe radius used.
     void build(plade_ctx *ctx, const float *d_xyz, uint32_t n_pts, uint32_t stride, float min_cell,
