@@ -35,13 +35,12 @@ struct Tile {
     bool valid[K1_PPT];
 };
 
-// 4 consecutive points per lane via 16-byte loads; `assigned` (nullable) is indexed directly or through sub_index.
-// abits (nullable, takes precedence): the same information as ONE BIT per point (1 = taken by a shape), the form the
-// extraction loop keeps it in -- the scan kernels then move 24.1 instead of 28 bytes per point, and the sampler's random
-// probes hit a 125 KB array instead of a 4 MB one.  (The seams hand over the caller's int32 shapeIndex array.)
+// 4 consecutive points per lane via 16-byte loads; `assigned` (nullable: every point counts) is indexed directly or through
+// sub_index.  The extraction loop passes nullptr: its full passes read a view that holds exactly the unassigned points
+// (ransac.hip, scan view), 24 bytes per point; the seams hand over the caller's int32 shapeIndex array (28 bytes per point).
 __device__ __forceinline__ void load_tile(Tile &t, const float *x, const float *y, const float *z, const float *nx, const float *ny,
                                           const float *nz, const int32_t *assigned, const uint32_t *sub_index, uint32_t n,
-                                          uint32_t base, const uint32_t *abits = nullptr) {
+                                          uint32_t base) {
     constexpr int PPT = K1_PPT;
     if (base + PPT <= n) {
         const float4 a = *reinterpret_cast<const float4 *>(x + base), b = *reinterpret_cast<const float4 *>(y + base),
@@ -53,10 +52,7 @@ __device__ __forceinline__ void load_tile(Tile &t, const float *x, const float *
         t.qx[0] = d.x; t.qx[1] = d.y; t.qx[2] = d.z; t.qx[3] = d.w;
         t.qy[0] = e.x; t.qy[1] = e.y; t.qy[2] = e.z; t.qy[3] = e.w;
         t.qz[0] = f.x; t.qz[1] = f.y; t.qz[2] = f.z; t.qz[3] = f.w;
-        if (abits) {
-            const uint32_t nib = (abits[base >> 5] >> (base & 31u)) & 0xfu;   // base is a multiple of 4
-            t.valid[0] = !(nib & 1u); t.valid[1] = !(nib & 2u); t.valid[2] = !(nib & 4u); t.valid[3] = !(nib & 8u);
-        } else if (assigned && !sub_index) {
+        if (assigned && !sub_index) {
             const int4 s = *reinterpret_cast<const int4 *>(assigned + base);
             t.valid[0] = s.x == -1; t.valid[1] = s.y == -1; t.valid[2] = s.z == -1; t.valid[3] = s.w == -1;
         } else if (assigned) {
@@ -74,8 +70,7 @@ __device__ __forceinline__ void load_tile(Tile &t, const float *x, const float *
             t.px[k] = in ? x[i] : 0.f; t.py[k] = in ? y[i] : 0.f; t.pz[k] = in ? z[i] : 0.f;
             t.qx[k] = in ? nx[i] : 0.f; t.qy[k] = in ? ny[i] : 0.f; t.qz[k] = in ? nz[i] : 0.f;
             bool un = true;
-            if (in && abits) un = !((abits[i >> 5] >> (i & 31u)) & 1u);
-            else if (in && assigned) un = (sub_index ? assigned[sub_index[i]] : assigned[i]) == -1;
+            if (in && assigned) un = (sub_index ? assigned[sub_index[i]] : assigned[i]) == -1;
             t.valid[k] = in && un;
         }
     }

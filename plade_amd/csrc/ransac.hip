@@ -137,6 +137,10 @@ struct RState {
     // ---- loop state
     uint32_t done, sampling, fresh, round, it;   // fresh: the pool holds this iteration's new leaders (not yet re-scored)
     uint32_t n_remaining, sub_unassigned;
+    // the SCAN VIEW: what the full passes (mark, re-score) read.  0: the Morton-ordered cloud itself (nothing has been taken yet);
+    // 1 / 2: compacted copy A / B = exactly the points no shape has taken, in Morton order, with their Morton positions
+    // (rebuilt behind every iteration that took points, k_view_*)
+    uint32_t view_sel, view_n, view_dirty, view_next_n;
     float drawn;
     uint32_t npool, nc;
     uint32_t batch_idx[R_B];
@@ -181,8 +185,14 @@ struct RCloudArgs {
     const uint32_t *cells6;          // start of every level-6 octree cell in the sorted cloud (8^6 + 1 entries), or nullptr
     const uint32_t *orig;            // Morton position -> original point index (nullptr: identity, seam S1c)
     int32_t *assigned;               // seams only: the caller's shapeIndex per point (nullptr: all unassigned)
-    uint32_t *abits;                 // the loop's own form: one bit per Morton position, 1 = taken by a shape (nullptr in the seams)
+    uint8_t *taken;                  // the loop's own form: one BYTE per Morton position, 1 = taken by a shape (nullptr in the seams).
+                                     // Plain byte stores from the assign kernel (a bit per point needed an atomic per taken point:
+                                     // 76 -> 122 us per launch); read by the sampler's random probes and by the rebuild of the scan
+                                     // view -- the full passes never look at it (they read the view)
     const float *tile_box;           // per tile of 1024 Morton-neighbouring points: min x, y, z, max x, y, z, 2 pad (nullptr: no culling)
+    float *view[2];                  // scan views A / B: SoA x | y | z | nx | ny | nz with the cloud's pitch (nullptr: seams)
+    uint32_t *view_map[2];           // view position -> Morton position
+    uint32_t *view_cnt, *view_sup;   // rebuild: surviving points per view tile / per supertile of 32 tiles (all-zero between rebuilds)
     const float *sub;                // stratified subset, SoA with pitch sub_pitch
     const uint32_t *sub_index;
     uint32_t sub_pitch, n_sub;
@@ -393,6 +403,21 @@ __device__ __forceinline__ uint32_t lb_u32(const uint32_t *a, uint32_t n, uint32
 
 // compatible(), Tile, load_tile(): k1_point_test.h (the one definition of the K1 point test)
 
+// what a full pass reads: the cloud itself or its current compacted view (RState::view_sel)
+struct ScanSrc { const float *x, *y, *z, *nx, *ny, *nz; const uint32_t *map; uint32_t n; };
+__device__ __forceinline__ ScanSrc scan_src(const RCloudArgs &C, const RState *S) {
+    ScanSrc v;
+    const uint32_t sel = C.view[0] ? S->view_sel : 0u;
+    if (sel == 0u) { v.x = C.cv.x; v.y = C.cv.y; v.z = C.cv.z; v.nx = C.cv.nx; v.ny = C.cv.ny; v.nz = C.cv.nz; v.map = nullptr; v.n = C.cv.n; }
+    else {
+        const float *b = C.view[sel - 1];
+        const size_t pitch = ((size_t)C.cv.n + 3) & ~(size_t)3;
+        v.x = b; v.y = b + pitch; v.z = b + 2 * pitch; v.nx = b + 3 * pitch; v.ny = b + 4 * pitch; v.nz = b + 5 * pitch;
+        v.map = C.view_map[sel - 1]; v.n = S->view_n;
+    }
+    return v;
+}
+
 // which cloud a workgroup of a "concatenated tiles" grid scans
 __device__ __forceinline__ int scan_group(const RArgs &A, uint32_t &tile) {
     int g = 0;
@@ -460,8 +485,9 @@ __global__ __launch_bounds__(TPB) void k_r_init(const RArgs A, const RInit I) {
         return;
     }
     const uint32_t base = tile * TILE + threadIdx.x * PPT;
-    if (C.abits && (threadIdx.x & 7) == 0 && base < C.cv.n) C.abits[base >> 5] = 0u;   // 8 lanes x 4 points per word
+    if (C.taken && base < ((C.cv.n + 3) & ~3u)) *reinterpret_cast<uint32_t *>(C.taken + base) = 0u;   // 4 points per lane
     if (C.sub_assigned && base + PPT <= ((C.n_sub + 3) & ~3u)) *reinterpret_cast<int4 *>(C.sub_assigned + base) = make_int4(-1, -1, -1, -1);
+    if (C.view_sup && tile == 0) for (uint32_t q = threadIdx.x; q < (C.L.nb >> SUP_SHIFT) + 2; q += blockDim.x) C.view_sup[q] = 0u;
     if (tile < (uint32_t)R_B) agg_clear(chain_of(C, tile).agg, C.L.nb, threadIdx.x, blockDim.x);   // (a call that died half-way left some)
     else if (C.L.nb < (uint32_t)R_B && tile == 0) for (uint32_t b2 = C.L.nb; b2 < (uint32_t)R_B; ++b2) agg_clear(chain_of(C, b2).agg, C.L.nb, threadIdx.x, blockDim.x);
     if (tile == 0 && threadIdx.x == 0) {
@@ -473,6 +499,7 @@ __global__ __launch_bounds__(TPB) void k_r_init(const RArgs A, const RInit I) {
         const bool nothing = C.cv.n < 3 || C.cv.n < P.min_support;   // RansacShapeDetector.cpp: no shape can reach minSupport
         S->done = nothing ? 1u : 0u; S->sampling = nothing ? 0u : 1u; S->fresh = 0; S->round = 0; S->it = 0;
         S->n_remaining = C.cv.n; S->sub_unassigned = 0; S->drawn = 0.f;
+        S->view_sel = 0; S->view_n = C.cv.n; S->view_dirty = 0; S->view_next_n = 0;
         S->npool = 0; S->nc = 0; S->n_acc = 0; S->out_off = 0; S->err = 0; S->aj_n = 0;
         S->n_rounds = S->n_rescores[0] = S->n_rescores[1] = S->n_batches = S->n_accepts = S->n_mark_launches = S->n_mark_chains = 0;
         S->n_deferred = 0;
@@ -490,7 +517,7 @@ __global__ __launch_bounds__(256) void k_r_sample(const RArgs A) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= R_H) return;
     const CloudView &c = C.cv;
-    const uint32_t *__restrict__ abits = C.abits;
+    const uint8_t *__restrict__ taken = C.taken;
     const uint32_t *__restrict__ codes = C.codes;
     const float eps = S->eps, cos_t = S->cos_t;
     Rng rng{mix64(S->seed ^ ((uint64_t)S->round << 32) ^ t)};
@@ -518,7 +545,7 @@ __global__ __launch_bounds__(256) void k_r_sample(const RArgs A) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) cand[u] = rng.next() % c.n;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) av[u] = ((abits[cand[u] >> 5] >> (cand[u] & 31u)) & 1u) ? 0 : -1;
+        for (int u = 0; u < 8; ++u) av[u] = taken[cand[u]] ? 0 : -1;
 #pragma unroll
         for (int u = 0; u < 8; ++u)
             if (!ok && av[u] == -1) { i0 = cand[u]; ok = true; }
@@ -555,7 +582,7 @@ __global__ __launch_bounds__(256) void k_r_sample(const RArgs A) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) cand[u] = lo + rng.next() % (hi - lo);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) av[u] = ((abits[cand[u] >> 5] >> (cand[u] & 31u)) & 1u) ? 0 : -1;
+        for (int u = 0; u < 8; ++u) av[u] = taken[cand[u]] ? 0 : -1;
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             if (got >= 3 || av[u] != -1) continue;
@@ -770,10 +797,14 @@ __global__ __launch_bounds__(TPB) void k_r_rescore(const RArgs A, int phase, uns
     RState *S = C.st;
     const uint32_t np = S->npool;
     if (S->done || np == 0 || (S->fresh != 0u) != (phase != 0)) return;
+    const ScanSrc V = scan_src(C, S);
+    if (tile * TILE >= V.n && tile != 0) return;      // beyond the (compacted) view (tile 0 keeps the launch counter)
     if (threadIdx.x < np) s_pl[threadIdx.x] = S->pool_pl[threadIdx.x];
     const float eps = S->eps, cos_t = S->cos_t;
     Tile t;
-    load_tile(t, C.cv.x, C.cv.y, C.cv.z, C.cv.nx, C.cv.ny, C.cv.nz, C.assigned, nullptr, C.cv.n, tile * TILE + threadIdx.x * PPT, C.abits);
+    // A view holds exactly the points no shape has taken (the cloud itself while nothing has been taken: the view is rebuilt behind
+    // every iteration that takes points): no shapeIndex to look at.  (The seams scan the caller's cloud with its shapeIndex array.)
+    load_tile(t, V.x, V.y, V.z, V.nx, V.ny, V.nz, V.map ? nullptr : C.assigned, nullptr, V.n, tile * TILE + threadIdx.x * PPT);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // only the planes whose slab can reach this wavefront's points get the exact test (slab_mask)
@@ -939,7 +970,7 @@ __global__ __launch_bounds__(TPB) void k_r_mark(const RArgs A, int k, unsigned l
         // the rounding of the three-term sums (as slab_mask does per wavefront); a plane that cannot gets a zero count for the
         // tile without a point being loaded.  (A NaN distance -- a slot whose LS fit was impossible -- reaches nothing.)
         uint32_t need = 1u;
-        if (C.tile_box) {
+        if (C.tile_box && !(C.view[0] && S->view_sel)) {   // (the boxes are those of the cloud's own tiles)
             const float *bx = C.tile_box + 8 * (size_t)tile;
             const float e3 = S->eps3;
             const float lo = fminf(st->n[0] * bx[0], st->n[0] * bx[3]) + fminf(st->n[1] * bx[1], st->n[1] * bx[4]) + fminf(st->n[2] * bx[2], st->n[2] * bx[5]);
@@ -956,16 +987,18 @@ __global__ __launch_bounds__(TPB) void k_r_mark(const RArgs A, int k, unsigned l
         fr[6] = st->a1[0]; fr[7] = st->a1[1]; fr[8] = st->a1[2];
     }
     const float eps = S->eps3, cos_t = S->cos_t;
+    const ScanSrc V = scan_src(C, S);
     __syncthreads();
     uint32_t active = 0, needed = 0;
     for (uint32_t j = 0; j < nc; ++j) { active += s_skip[j] ? 0u : 1u; needed += (!s_skip[j] && s_need[j]) ? 1u : 0u; }
+    if (tile * TILE >= V.n) needed = 0;      // beyond the (compacted) view: an empty tile
     if (needed == 0) {   // uniform: no slab reaches this tile (about half of all (tile, launch) pairs): nothing is loaded
         if (threadIdx.x < nc && !s_skip[threadIdx.x]) chain_of(C, threadIdx.x).bc1[tile] = 0u;
         if (tile == 0 && threadIdx.x == 0 && active) { S->n_mark_launches += 1; S->n_mark_chains += active; }
         return;
     }
     Tile t;
-    load_tile(t, C.cv.x, C.cv.y, C.cv.z, C.cv.nx, C.cv.ny, C.cv.nz, C.assigned, nullptr, C.cv.n, tile * TILE + threadIdx.x * PPT, C.abits);
+    load_tile(t, V.x, V.y, V.z, V.nx, V.ny, V.nz, V.map ? nullptr : C.assigned, nullptr, V.n, tile * TILE + threadIdx.x * PPT);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (uint32_t j = 0; j < nc; ++j) {
         if (s_skip[j]) continue;   // uniform
@@ -1094,6 +1127,7 @@ __global__ __launch_bounds__(TPB) void k_r_compact_raster(const RArgs A, int k) 
     const int oj = threadIdx.x >> 5, ol = threadIdx.x & 31;     // 32 lanes look after owned tile number oj
     uint32_t *__restrict__ idxA = ch.idxA(k);
     // the whole list: length and bounding box
+    const ScanSrc V = scan_src(C, S);
     const uint32_t tot = ch.agg->tot;
     float bbv[4] = {INFINITY, INFINITY, -INFINITY, -INFINITY};
     if (tot) { bbv[0] = dec_f(~ch.agg->bb[0]); bbv[1] = dec_f(~ch.agg->bb[1]); bbv[2] = dec_f(ch.agg->bb[2]); bbv[3] = dec_f(ch.agg->bb[3]); }
@@ -1129,14 +1163,20 @@ __global__ __launch_bounds__(TPB) void k_r_compact_raster(const RArgs A, int k) 
             const uint32_t first = tile * TILE + threadIdx.x * PPT;
             uint32_t pv[PPT];
             float cx[PPT], cy[PPT], cz[PPT];
+            // the masks are over positions of what the mark pass scanned: the cloud (position = point), a caller's list (seam S1c)
+            // or the compacted view, whose coordinates lie at the same positions and whose map gives the points
 #pragma unroll
             for (int q = 0; q < PPT; ++q) {
                 pv[q] = first + q;
                 if ((m & (1u << q)) && C.list_values) pv[q] = C.list_values[first + q];
+                else if ((m & (1u << q)) && V.map) pv[q] = V.map[first + q];
             }
 #pragma unroll
             for (int q = 0; q < PPT; ++q)
-                if (m & (1u << q)) { cx[q] = C.cv.x[pv[q]]; cy[q] = C.cv.y[pv[q]]; cz[q] = C.cv.z[pv[q]]; }
+                if (m & (1u << q)) {
+                    const uint32_t at = V.map ? first + q : pv[q];
+                    cx[q] = V.x[at]; cy[q] = V.y[at]; cz[q] = V.z[at];
+                }
             const uint32_t c = __popc(m);
             uint32_t incl = c;
 #pragma unroll
@@ -1654,6 +1694,7 @@ __global__ __launch_bounds__(DEC_T) void k_r_decide(const RArgs A) {
         for (int q = 0; q < 4; ++q) if (n_final[q]) S->n_final[q] += n_final[q];
         for (int q = 0; q < 5; ++q) if (n_stop[q]) S->n_stop[q] += n_stop[q];
         S->aj_n = n_aj;
+        S->view_dirty = (n_aj && C.view[0]) ? 1u : 0u;   // points will be taken: the scan view is rebuilt behind k_r_assign
         S->n_accepts = n_accepts; S->n_remaining = n_remaining; S->n_acc = n_acc; S->out_off = out_off; S->drawn = drawn; S->err = err;
     }
     __syncthreads();
@@ -1773,7 +1814,7 @@ __global__ __launch_bounds__(TPB) void k_r_assign(const RArgs A) {
 #pragma unroll
             for (int q = 0; q < 4; ++q)
                 if (mk & (1u << q)) {
-                    if (C.abits) atomicOr(&C.abits[p[q] >> 5], 1u << (p[q] & 31u));
+                    if (C.taken) C.taken[p[q]] = 1;
                     if (C.sub_assigned && p[q] % C.sub_stride == 0 && p[q] / C.sub_stride < C.n_sub) C.sub_assigned[p[q] / C.sub_stride] = id;
                     if (out) {
                         out[off] = (int32_t)(C.orig ? C.orig[p[q]] : p[q]);
@@ -1782,6 +1823,112 @@ __global__ __launch_bounds__(TPB) void k_r_assign(const RArgs A) {
                     ++off;
                 }
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The scan view (RState::view_sel): behind an iteration that took points, the points nobody has taken are copied, in order,
+// into the other view buffer -- coordinates, normals and Morton positions -- so that the next iteration's five full passes (four
+// mark passes, one re-score) read ~30 %, then ~15 %, ... of the cloud instead of all of it with most points masked out
+// (r3 / verdict: 13.5 of 18 mark launches per registration re-scanned 2 x 28 MB).  Same points in the same order: the masks,
+// lists and counts of every pass are unchanged, bit for bit.  Three launches: count the survivors per view tile (+ supertile
+// sums by atomics), compact (a tile's offset from the supertile sums + the counts of its own supertile, as the chains'
+// compaction does), commit (flip the view, clear the sums).  Nothing to do (view_dirty = 0): the workgroups return at once.
+__global__ __launch_bounds__(TPB) void k_view_count(const RArgs A) {
+    __shared__ uint32_t s_w[TPB / 64];
+    uint32_t tile;
+    const int g = scan_group(A, tile);
+    const RCloudArgs &C = A.c[g];
+    RState *S = C.st;
+    if (!C.view[0] || !S->view_dirty || S->done) return;
+    const ScanSrc V = scan_src(C, S);
+    if (tile * TILE >= V.n) return;
+    const uint32_t first = tile * TILE + threadIdx.x * PPT;
+    uint32_t c = 0;
+#pragma unroll
+    for (int q = 0; q < PPT; ++q)
+        if (first + q < V.n) {
+            const uint32_t p = V.map ? V.map[first + q] : first + q;
+            c += C.taken[p] ? 0u : 1u;
+        }
+    for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d, 64);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t tot = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        C.view_cnt[tile] = tot;
+        if (tot) { atomicAdd(&C.view_sup[tile >> SUP_SHIFT], tot); atomicAdd(&S->view_next_n, tot); }
+    }
+}
+
+__global__ __launch_bounds__(TPB) void k_view_compact(const RArgs A) {
+    __shared__ uint32_t s_w[TPB / 64], s_pre;
+    uint32_t tile;
+    const int g = scan_group(A, tile);
+    const RCloudArgs &C = A.c[g];
+    const RState *S = C.st;
+    if (!C.view[0] || !S->view_dirty || S->done) return;
+    const ScanSrc V = scan_src(C, S);
+    if (tile * TILE >= V.n) return;
+    if (C.view_cnt[tile] == 0) return;   // uniform
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // entries in front of this tile: complete supertiles + the tiles of its own supertile before it
+    uint32_t part = 0;
+    if (wave == 0) {
+        const uint32_t ns = tile >> SUP_SHIFT;
+        for (uint32_t q = lane; q < ns; q += 64) part += C.view_sup[q];
+        for (uint32_t q = (ns << SUP_SHIFT) + lane; q < tile; q += 64) part += C.view_cnt[q];
+        for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
+        if (lane == 0) s_pre = part;
+    }
+    const uint32_t first = tile * TILE + threadIdx.x * PPT;
+    uint32_t pos[PPT], m = 0;
+#pragma unroll
+    for (int q = 0; q < PPT; ++q) {
+        pos[q] = 0;
+        if (first + q < V.n) {
+            pos[q] = V.map ? V.map[first + q] : first + q;
+            m |= (C.taken[pos[q]] ? 0u : 1u) << q;
+        }
+    }
+    const uint32_t c = __popc(m);
+    uint32_t incl = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += o;
+    }
+    if (lane == 63) s_w[wave] = incl;
+    __syncthreads();
+    uint32_t off = s_pre + incl - c;
+    for (int w = 0; w < wave; ++w) off += s_w[w];
+    const uint32_t dst_sel = S->view_sel == 1u ? 1u : 0u;     // from the cloud or from A into ... A (0) unless A is the source
+    float *b = C.view[dst_sel];
+    uint32_t *dmap = C.view_map[dst_sel];
+    const size_t pitch = ((size_t)C.cv.n + 3) & ~(size_t)3;
+#pragma unroll
+    for (int q = 0; q < PPT; ++q)
+        if (m & (1u << q)) {
+            const uint32_t at = first + q;
+            b[off] = V.x[at]; b[pitch + off] = V.y[at]; b[2 * pitch + off] = V.z[at];
+            b[3 * pitch + off] = V.nx[at]; b[4 * pitch + off] = V.ny[at]; b[5 * pitch + off] = V.nz[at];
+            dmap[off] = pos[q];
+            ++off;
+        }
+}
+
+__global__ __launch_bounds__(256) void k_view_commit(const RArgs A) {
+    const RCloudArgs &C = A.c[blockIdx.x];
+    RState *S = C.st;
+    if (!C.view[0] || !S->view_dirty || S->done) { if (C.view[0] && threadIdx.x == 0 && S->view_dirty) S->view_dirty = 0; return; }
+    const uint32_t ntiles = (S->view_n + TILE - 1) / TILE;
+    for (uint32_t q = threadIdx.x; q < (ntiles >> SUP_SHIFT) + 1; q += blockDim.x) C.view_sup[q] = 0u;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        S->view_sel = S->view_sel == 1u ? 2u : 1u;
+        S->view_n = S->view_next_n;
+        S->view_next_n = 0;
+        S->view_dirty = 0;
     }
 }
 
@@ -1997,8 +2144,9 @@ struct RansacSlot {
     CloudDev sorted;
     DBuf<uint32_t> codes, orig, sub_index;
     DBuf<int32_t> out_idx, sub_assigned;
-    DBuf<uint32_t> abits;
-    DBuf<float> tile_box;
+    DBuf<uint8_t> taken;
+    DBuf<float> tile_box, view_a, view_b;
+    DBuf<uint32_t> view_map_a, view_map_b, view_cnt, view_sup;
     uint32_t sub_stride = 1;
     DBuf<uint32_t> out_pos;
     DBuf<float> sub;
@@ -2044,7 +2192,13 @@ void slot_buffers(plade_ctx *ctx, RansacSlot &s, uint32_t n) {
     s.round_block.ensure((size_t)R_H * 36 + 64);
     s.out_idx.ensure((size_t)n + 4);
     s.out_pos.ensure((size_t)n + 4);
-    s.abits.ensure(((size_t)n >> 5) + 8);
+    s.taken.ensure((size_t)n + 16);
+    {   // the two scan views (compacted copies of the points not yet taken) and the tables of their rebuild
+        const size_t pitch = ((size_t)n + 3) & ~(size_t)3;
+        s.view_a.ensure(6 * pitch + 4); s.view_b.ensure(6 * pitch + 4);
+        s.view_map_a.ensure((size_t)n + 4); s.view_map_b.ensure((size_t)n + 4);
+        s.view_cnt.ensure(s.L.nb + 4); s.view_sup.ensure((s.L.nb >> SUP_SHIFT) + 4);
+    }
     if (!s.res) {
         HIP_TRY(hipHostMalloc((void **)&s.res, sizeof(RResult), hipHostMallocMapped | hipHostMallocCoherent));
         memset(s.res, 0, sizeof(RResult));
@@ -2062,7 +2216,9 @@ RArgs make_args(RansacWork &W, int ng, bool topup) {
         const CloudDev &c = s.sorted;
         // field by field: the bytes of this struct key the captured graphs, padding included (A was zeroed)
         C.cv.x = c.x(); C.cv.y = c.y(); C.cv.z = c.z(); C.cv.nx = c.nx(); C.cv.ny = c.ny(); C.cv.nz = c.nz(); C.cv.n = s.n;
-        C.codes = s.codes.p; C.cells6 = s.cells6.p; C.orig = s.orig.p; C.assigned = nullptr; C.abits = s.abits.p; C.tile_box = s.tile_box.p;
+        C.codes = s.codes.p; C.cells6 = s.cells6.p; C.orig = s.orig.p; C.assigned = nullptr; C.taken = s.taken.p; C.tile_box = s.tile_box.p;
+        C.view[0] = s.view_a.p; C.view[1] = s.view_b.p; C.view_map[0] = s.view_map_a.p; C.view_map[1] = s.view_map_b.p;
+        C.view_cnt = s.view_cnt.p; C.view_sup = s.view_sup.p;
         C.sub = s.sub.p; C.sub_index = s.sub_index.p; C.sub_pitch = s.sub_pitch; C.n_sub = s.n_sub;
         C.sub_assigned = s.sub_assigned.p; C.sub_stride = s.sub_stride;
         C.st = s.state.p; C.res = s.res_dev;
@@ -2089,7 +2245,7 @@ uint64_t hash_bytes(const void *p, size_t n) {
 
 inline uint32_t loop_grid(uint32_t nb) { return std::min(1024u, std::max(32u, cdiv(nb, OWN_MAX))); }
 
-// one iteration of the detect loop: 27 launches (29 without the top-up rule)
+// one iteration of the detect loop: 30 launches (32 without the top-up rule)
 void enqueue_iteration(plade_ctx *ctx, const RArgs &A) {
     hipStream_t st = ctx->stream;
     const uint32_t ng = A.ng;
@@ -2126,6 +2282,10 @@ void enqueue_iteration(plade_ctx *ctx, const RArgs &A) {
     }
     hipLaunchKernelGGL(k_r_decide, dim3(ng), dim3(DEC_T), 0, st, A);
     hipLaunchKernelGGL(k_r_assign, dim3(loop_grid(nb_max), R_B * ng), dim3(TPB), 0, st, A);
+    // the scan view of the next iteration: the points this one left
+    hipLaunchKernelGGL(k_view_count, dim3(tiles), dim3(TPB), 0, st, A);
+    hipLaunchKernelGGL(k_view_compact, dim3(tiles), dim3(TPB), 0, st, A);
+    hipLaunchKernelGGL(k_view_commit, dim3(ng), dim3(256), 0, st, A);
 }
 
 void launch_iteration(plade_ctx *ctx, RansacWork &W, const RArgs &A) {
