@@ -268,7 +268,7 @@ void radix_sort_run_ipt(plade_ctx *ctx, const K *ki, K *ko, const uint32_t *vi, 
 
 template <class K, int DB>
 void radix_sort_run(plade_ctx *ctx, const K *ki, K *ko, const uint32_t *vi, uint32_t *vo, size_t n, int passes) {
-    if (n <= 1500000) radix_sort_run_ipt<K, DB, 8>(ctx, ki, ko, vi, vo, n, passes);
+    if (n <= 3000000) radix_sort_run_ipt<K, DB, 8>(ctx, ki, ko, vi, vo, n, passes);
     else radix_sort_run_ipt<K, DB, 16>(ctx, ki, ko, vi, vo, n, passes);
 }
 

@@ -1115,20 +1115,20 @@ __global__ __launch_bounds__(TPB) void k_r_compact_raster(const RArgs A, int k) 
     const RCloudArgs &C = A.c[g];
     const uint32_t nb = C.L.nb;
     RState *S = C.st;
-    if (b >= S->nc) return;
     const ChainPtr ch = chain_of(C, b);
     PlaneState *st = &ch.hdr->st[k];
-    const uint32_t conv = st->converged;
+    // (fetched together: one round trip for the workgroups that have nothing to do)
+    const uint32_t nc = S->nc, conv = st->converged, tot_early = ch.agg->tot;
+    const bool lead = blockIdx.x == 0;
+    if ((b >= nc) | (conv != 0u) | (!lead && tot_early == 0u)) return;
     const float fr[9] = {st->pos[0], st->pos[1], st->pos[2], st->a0[0], st->a0[1], st->a0[2], st->a1[0], st->a1[1], st->a1[2]};
     const float eps = S->bitmap_eps;
-    if (conv) return;
-    const bool lead = blockIdx.x == 0;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int oj = threadIdx.x >> 5, ol = threadIdx.x & 31;     // 32 lanes look after owned tile number oj
     uint32_t *__restrict__ idxA = ch.idxA(k);
     // the whole list: length and bounding box
     const ScanSrc V = scan_src(C, S);
-    const uint32_t tot = ch.agg->tot;
+    const uint32_t tot = tot_early;
     float bbv[4] = {INFINITY, INFINITY, -INFINITY, -INFINITY};
     if (tot) { bbv[0] = dec_f(~ch.agg->bb[0]); bbv[1] = dec_f(~ch.agg->bb[1]); bbv[2] = dec_f(ch.agg->bb[2]); bbv[3] = dec_f(ch.agg->bb[3]); }
     uint32_t ue, ve;
@@ -1393,11 +1393,12 @@ __global__ __launch_bounds__(TPB) void k_r_select_cc(const RArgs A, int k) {
     const uint32_t b = blockIdx.y % R_B;
     if (g >= (int)A.ng) return;
     const RCloudArgs &C = A.c[g];
-    if (b >= C.st->nc) return;
     const ChainPtr ch = chain_of(C, b);
     const PlaneState *st = &ch.hdr->st[k];
-    if (st->converged || st->err) return;
-    const uint32_t m = st->n_list, best = st->best_root;
+    // everything the decision to leave needs is fetched together (the addresses come from the kernel arguments): one round trip
+    // for the many workgroups that have nothing to do instead of three dependent ones
+    const uint32_t nc = C.st->nc, conv = st->converged, serr = st->err, m = st->n_list, best = st->best_root;
+    if ((b >= nc) | (conv != 0u) | (serr != 0u) | ((uint64_t)blockIdx.x * 1024u >= m)) return;
     const CloudView &c = C.cv;
     const float eps = C.st->eps3;
     const uint32_t *__restrict__ bidx = ch.bidx, *__restrict__ label = ch.label, *__restrict__ idx = ch.idxA(k);
