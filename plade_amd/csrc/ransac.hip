@@ -1159,20 +1159,17 @@ __global__ __launch_bounds__(TPB) void k_r_compact_raster(const RArgs A, int k) 
             const uint32_t first = tile * TILE + threadIdx.x * PPT;
             uint32_t pv[PPT];
             float cx[PPT], cy[PPT], cz[PPT];
-            // the masks are over positions of what the mark pass scanned: the cloud (position = point), a caller's list (seam S1c)
-            // or the compacted view, whose coordinates lie at the same positions and whose map gives the points
+            // the masks are over positions of what the mark pass scanned: the cloud, the compacted view (the list then holds VIEW
+            // positions: the selection pass reads the view's contiguous coordinates, the assign kernel translates the accepted
+            // slot's entries into Morton positions through the view's map) or a caller's list (seam S1c: the list gives the points)
 #pragma unroll
             for (int q = 0; q < PPT; ++q) {
                 pv[q] = first + q;
                 if ((m & (1u << q)) && C.list_values) pv[q] = C.list_values[first + q];
-                else if ((m & (1u << q)) && V.map) pv[q] = V.map[first + q];
             }
 #pragma unroll
             for (int q = 0; q < PPT; ++q)
-                if (m & (1u << q)) {
-                    const uint32_t at = V.map ? first + q : pv[q];
-                    cx[q] = V.x[at]; cy[q] = V.y[at]; cz[q] = V.z[at];
-                }
+                if (m & (1u << q)) { cx[q] = V.x[pv[q]]; cy[q] = V.y[pv[q]]; cz[q] = V.z[pv[q]]; }
             const uint32_t c = __popc(m);
             uint32_t incl = c;
 #pragma unroll
@@ -1393,7 +1390,7 @@ __global__ __launch_bounds__(TPB) void k_r_select_cc(const RArgs A, int k) {
     // for the many workgroups that have nothing to do instead of three dependent ones
     const uint32_t nc = C.st->nc, conv = st->converged, serr = st->err, m = st->n_list, best = st->best_root;
     if ((b >= nc) | (conv != 0u) | (serr != 0u) | ((uint64_t)blockIdx.x * 1024u >= m)) return;
-    const CloudView &c = C.cv;
+    const ScanSrc c = scan_src(C, C.st);       // the list entries are positions in what the mark pass scanned
     const float eps = C.st->eps3;
     const uint32_t *__restrict__ label = ch.label, *__restrict__ idx = ch.idxA(k);
     const float n0 = st->n[0], n1 = st->n[1], n2 = st->n[2], dist = st->dist;
@@ -1774,6 +1771,7 @@ __global__ __launch_bounds__(TPB) void k_r_assign(const RArgs A) {
     const uint8_t *__restrict__ masks = ch.masks2(k);
     const uint32_t *__restrict__ idx = ch.idxA(k);
     int32_t *__restrict__ out = out_off == 0xffffffffu ? nullptr : C.out_idx + out_off;
+    const uint32_t *__restrict__ vmap = scan_src(C, S).map;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (uint32_t r0 = blockIdx.x; r0 < rows; r0 += gridDim.x * OWN_MAX) {
         uint32_t pre[OWN_MAX];
@@ -1803,6 +1801,8 @@ __global__ __launch_bounds__(TPB) void k_r_assign(const RArgs A) {
             uint32_t p[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) p[q] = (mk & (1u << q)) ? idx[base + q] : 0u;
+            if (vmap)   // the lists hold positions of the scan view: here they become Morton positions
+                for (int q = 0; q < 4; ++q) if (mk & (1u << q)) p[q] = vmap[p[q]];
             const uint32_t c = __popc(mk);
             uint32_t incl = c;
 #pragma unroll
