@@ -60,10 +60,10 @@ constexpr int RANSAC_SLOTS = 2 * PLADE_GROUP_MAX;
 // Morton order + stratified subset of the clouds (once per set of clouds; every detect call on them reuses it).
 void ransac_prepare(plade_ctx *ctx, RansacWork &W, const CloudDev *const clouds[RANSAC_SLOTS], int n_clouds);
 
-// average_spacing (code/PLADE/util.cpp:1619-1648) of the cloud in `slot` from its Morton order: two kernels queued on the
+// average_spacing (code/PLADE/util.cpp:1619-1648) of the clouds in `slots` from their Morton order: two kernels (for all of them) queued on the
 // context's stream behind ransac_prepare; ransac_spacing_finish waits for them unless a later wait on that stream has completed (false: not available
 // -- nothing queued, or a cloud too clumped for the octree cells -- use average_spacing_dev).
-void ransac_spacing_enqueue(plade_ctx *ctx, RansacWork &W, int slot, int k, uint32_t samples);
+void ransac_spacing_enqueue(plade_ctx *ctx, RansacWork &W, const int *slots, int count, int k, uint32_t samples);
 bool ransac_spacing_finish(plade_ctx *ctx, RansacWork &W, int slot, float *spacing_out);
 
 // One PlaneExtraction::detect (code/PLADE/plane_extraction.cpp:173-200) per ACTIVE slot, all in one launch sequence:

@@ -1964,10 +1964,14 @@ __global__ void k_cells6(const Cells6Args A) {   // the sampler's level-6 table 
     const int g = blockIdx.y;
     A.table[g][c] = c == ncell ? A.n[g] : lb_u32(A.codes[g], A.n[g], c << 6);
 }
-__global__ void k_sp_cells(const uint32_t *__restrict__ codes, uint32_t n, int level, uint32_t *__restrict__ table) {
+// (both spacing kernels serve the source clouds of all pairs of a group in one launch: blockIdx.y selects the cloud)
+struct SpCellsArgs { const uint32_t *codes[PLADE_GROUP_MAX]; uint32_t n[PLADE_GROUP_MAX]; int level[PLADE_GROUP_MAX]; uint32_t *table[PLADE_GROUP_MAX]; };
+__global__ void k_sp_cells(const SpCellsArgs A) {
+    const int q = blockIdx.y;
+    const int level = A.level[q];
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x, ncell = 1u << (3 * level);
     if (c > ncell) return;
-    table[c] = c == ncell ? n : lb_u32(codes, n, c << (24 - 3 * level));
+    A.table[q][c] = c == ncell ? A.n[q] : lb_u32(A.codes[q], A.n[q], c << (24 - 3 * level));
 }
 
 struct SpArgs {
@@ -1980,8 +1984,11 @@ struct SpArgs {
     uint32_t dense_limit;
 };
 constexpr int SPK = 8;
-__global__ __launch_bounds__(256) void k_sp_knn(const SpArgs A, double *__restrict__ avg_out, uint32_t *__restrict__ nbs_out,
-                                                uint32_t *__restrict__ too_dense) {
+struct SpBatch { SpArgs a[PLADE_GROUP_MAX]; double *avg[PLADE_GROUP_MAX]; uint32_t *nbs[PLADE_GROUP_MAX], *dense[PLADE_GROUP_MAX]; };
+__global__ __launch_bounds__(256) void k_sp_knn(const SpBatch B) {
+    const SpArgs &A = B.a[blockIdx.y];
+    double *__restrict__ avg_out = B.avg[blockIdx.y];
+    uint32_t *__restrict__ nbs_out = B.nbs[blockIdx.y], *__restrict__ too_dense = B.dense[blockIdx.y];
     const int lane = threadIdx.x & 63;
     const uint32_t qi = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (qi >= A.nq) return;
@@ -2633,47 +2640,64 @@ void plane_component(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const
 }
 
 // ---- average spacing from the Morton order -------------------------------------------------------------------------
-void ransac_spacing_enqueue(plade_ctx *ctx, RansacWork &W, int slot, int k, uint32_t samples) {
-    RansacSlot &s = W.slot[slot];
-    s.sp_nq = 0;
-    PLADE_REQUIRE(k >= 1 && k <= SPK && slot < W.ng, PLADE_EINVAL, "spacing: bad argument");
-    const uint32_t n = s.n;
-    if (n == 0) return;
-    const CloudDev &c = *s.cloud;
-    size_t step = 1;
-    if (n > samples) step = n / samples;                    // util.cpp:1626-1629
-    const uint32_t nq = (uint32_t)((n + step - 1) / step);
-    // level: ~25 points per occupied cell of a surface-like cloud.  The wavefront scans a cell with all lanes and skips the
-    // neighbour cells that lie beyond the current k-th distance, so smaller cells mean fewer points looked at (measured at
-    // 1M points under load, k_sp_cells + k_sp_knn: ~100 points per cell (level 6) 11 + 124 us, ~25 (level 7) 13 + 66 us;
-    // level 8: 43 + 72 us, the table build takes over)
-    const double ex = std::max(1e-9, (double)c.bbmax[0] - c.bbmin[0]), ey = std::max(1e-9, (double)c.bbmax[1] - c.bbmin[1]),
-                 ez = std::max(1e-9, (double)c.bbmax[2] - c.bbmin[2]);
-    const double area = 2 * (ex * ey + ey * ez + ex * ez);
-    const double want = std::sqrt(32.0 * area / (double)n);
-    int level = 2;
-    static const int max_level = [] { const char *e = getenv("PLADE_SPACING_LEVEL"); return e ? atoi(e) : 7; }();
-    while (level < max_level && (double)s.cube / (double)(1 << (level + 1)) >= 0.7 * want) ++level;
-    const uint32_t ncell = 1u << (3 * level);
-    s.sp_table.ensure((size_t)ncell + 2);
-    const uint32_t need = nq * 12 + 64;
-    if (s.sp_cap < need) {
-        if (s.sp_host) HIP_TRY(hipHostFree(s.sp_host));
-        s.sp_host = nullptr;
-        HIP_TRY(hipHostMalloc((void **)&s.sp_host, need + need / 4, hipHostMallocMapped | hipHostMallocCoherent));
-        HIP_TRY(hipHostGetDevicePointer((void **)&s.sp_dev, s.sp_host, 0));
-        s.sp_cap = need + need / 4;
+void ransac_spacing_enqueue(plade_ctx *ctx, RansacWork &W, const int *slots, int count, int k, uint32_t samples) {
+    PLADE_REQUIRE(count >= 1 && count <= PLADE_GROUP_MAX, PLADE_EINVAL, "spacing: bad argument");
+    SpCellsArgs CA;
+    SpBatch B;
+    memset(&CA, 0, sizeof(CA));
+    memset(&B, 0, sizeof(B));
+    uint32_t max_cells = 0, max_nq = 0;
+    int used = 0;
+    for (int qi = 0; qi < count; ++qi) {
+        const int slot = slots[qi];
+        PLADE_REQUIRE(k >= 1 && k <= SPK && slot < W.ng, PLADE_EINVAL, "spacing: bad argument");
+        RansacSlot &s = W.slot[slot];
+        s.sp_nq = 0;
+        const uint32_t n = s.n;
+        if (n == 0) continue;
+        const CloudDev &c = *s.cloud;
+        size_t step = 1;
+        if (n > samples) step = n / samples;                    // util.cpp:1626-1629
+        const uint32_t nq = (uint32_t)((n + step - 1) / step);
+        // level: ~25 points per occupied cell of a surface-like cloud.  The wavefront scans a cell with all lanes and skips the
+        // neighbour cells that lie beyond the current k-th distance, so smaller cells mean fewer points looked at (measured at
+        // 1M points under load, k_sp_cells + k_sp_knn: ~100 points per cell (level 6) 11 + 124 us, ~25 (level 7) 13 + 66 us;
+        // level 8: 43 + 72 us, the table build takes over)
+        const double ex = std::max(1e-9, (double)c.bbmax[0] - c.bbmin[0]), ey = std::max(1e-9, (double)c.bbmax[1] - c.bbmin[1]),
+                     ez = std::max(1e-9, (double)c.bbmax[2] - c.bbmin[2]);
+        const double area = 2 * (ex * ey + ey * ez + ex * ez);
+        const double want = std::sqrt(32.0 * area / (double)n);
+        int level = 2;
+        static const int max_level = [] { const char *e = getenv("PLADE_SPACING_LEVEL"); return e ? atoi(e) : 7; }();
+        while (level < max_level && (double)s.cube / (double)(1 << (level + 1)) >= 0.7 * want) ++level;
+        const uint32_t ncell = 1u << (3 * level);
+        s.sp_table.ensure((size_t)ncell + 2);
+        const uint32_t need = nq * 12 + 64;
+        if (s.sp_cap < need) {
+            if (s.sp_host) HIP_TRY(hipHostFree(s.sp_host));
+            s.sp_host = nullptr;
+            HIP_TRY(hipHostMalloc((void **)&s.sp_host, need + need / 4, hipHostMallocMapped | hipHostMallocCoherent));
+            HIP_TRY(hipHostGetDevicePointer((void **)&s.sp_dev, s.sp_host, 0));
+            s.sp_cap = need + need / 4;
+        }
+        uint32_t *flag_host = reinterpret_cast<uint32_t *>(s.sp_host + (size_t)nq * 12);
+        *flag_host = 0u;
+        CA.codes[used] = s.codes.p; CA.n[used] = n; CA.level[used] = level; CA.table[used] = s.sp_table.p;
+        B.a[used] = SpArgs{s.sorted.x(), s.sorted.y(), s.sorted.z(), s.sp_table.p, c.aos.p, n, (uint32_t)step, nq, level, k,
+                           c.bbmin[0], c.bbmin[1], c.bbmin[2], s.cube_inv, s.cube / (float)(1 << level), 4096u};
+        B.avg[used] = reinterpret_cast<double *>(s.sp_dev);
+        B.nbs[used] = reinterpret_cast<uint32_t *>(s.sp_dev + (size_t)nq * 8);
+        B.dense[used] = reinterpret_cast<uint32_t *>(s.sp_dev + (size_t)nq * 12);
+        max_cells = std::max(max_cells, ncell + 1);
+        max_nq = std::max(max_nq, nq);
+        s.sp_nq = nq;
+        s.sp_epoch = ctx->wait_epoch;
+        ++used;
     }
-    uint32_t *flag_host = reinterpret_cast<uint32_t *>(s.sp_host + (size_t)nq * 12);
-    *flag_host = 0u;
-    hipLaunchKernelGGL(k_sp_cells, dim3(cdiv((size_t)ncell + 1, 256)), dim3(256), 0, ctx->stream, s.codes.p, n, level, s.sp_table.p);
-    SpArgs A{s.sorted.x(), s.sorted.y(), s.sorted.z(), s.sp_table.p, c.aos.p, n, (uint32_t)step, nq, level, k,
-             c.bbmin[0], c.bbmin[1], c.bbmin[2], s.cube_inv, s.cube / (float)(1 << level), 4096u};
-    hipLaunchKernelGGL(k_sp_knn, dim3(cdiv(nq, 4)), dim3(256), 0, ctx->stream, A, reinterpret_cast<double *>(s.sp_dev),
-                       reinterpret_cast<uint32_t *>(s.sp_dev + (size_t)nq * 8), reinterpret_cast<uint32_t *>(s.sp_dev + (size_t)nq * 12));
+    if (!used) return;
+    hipLaunchKernelGGL(k_sp_cells, dim3(cdiv(max_cells, 256), used), dim3(256), 0, ctx->stream, CA);
+    hipLaunchKernelGGL(k_sp_knn, dim3(cdiv(max_nq, 4), used), dim3(256), 0, ctx->stream, B);
     HIP_TRY(hipGetLastError());
-    s.sp_nq = nq;
-    s.sp_epoch = ctx->wait_epoch;
 }
 
 // after the stream has passed the kernels above (any later sync of it); false: nothing was queued or the cloud is too

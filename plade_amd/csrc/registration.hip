@@ -33,8 +33,11 @@ void extract_clouds(plade_ctx *ctx, int n_clouds, const CloudDev *const clouds[]
     if (!ctx->ransac_work) ctx->ransac_work = ransac_work_create();
     RansacWork &W = *ctx->ransac_work;
     ransac_prepare(ctx, W, clouds, n_clouds);
-    for (int g = 1; g < n_clouds; g += 2)
-        ransac_spacing_enqueue(ctx, W, g, 6, 10000);   // average_spacing(source, k = 6) of plade.cpp:41, see ransac.hip
+    {   // average_spacing(source, k = 6) of plade.cpp:41 for every pair's source cloud, see ransac.hip
+        int src_slots[PLADE_GROUP_MAX], ns = 0;
+        for (int g = 1; g < n_clouds; g += 2) src_slots[ns++] = g;
+        if (ns) ransac_spacing_enqueue(ctx, W, src_slots, ns, 6, 10000);
+    }
     int ms[RANSAC_SLOTS], trials[RANSAC_SLOTS];
     bool finished[RANSAC_SLOTS];
     for (int g = 0; g < RANSAC_SLOTS; ++g) { ms[g] = g < n_clouds ? init_min_support[g] : 0; trials[g] = 0; finished[g] = g >= n_clouds; }
