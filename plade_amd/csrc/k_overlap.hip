@@ -267,10 +267,14 @@ __global__ __launch_bounds__(OV_TPB) void k_overlap(const float *__restrict__ sx
                         if (!w8[q]) continue;
                         const int bx = bx0 + (q & 1), by = by0 + ((q >> 1) & 1), bz = bz0 + (q >> 2);
                         // wanted cells of this block: the part of [x0,x1] x [y0,y1] x [z0,z1] inside it
-                        unsigned long long mx = 0, my = 0, mz = 0;
-                        for (int v = max(x0, bx << 2); v <= min(x1, (bx << 2) + 3); ++v) mx |= 0x1111111111111111ull << (v & 3);
-                        for (int v = max(y0, by << 2); v <= min(y1, (by << 2) + 3); ++v) my |= 0x000f000f000f000full << ((v & 3) << 2);
-                        for (int v = max(z0, bz << 2); v <= min(z1, (bz << 2) + 3); ++v) mz |= 0xffffull << ((v & 3) << 4);
+                        // (ranges lo .. hi of local coordinates 0 .. 3 per axis as bit patterns: bits lo .. hi of every nibble / nibbles
+                        //  lo .. hi of every 16-bit group / groups lo .. hi -- three multiplications instead of three loops)
+                        const int lx = max(x0, bx << 2) & 3, hx = min(x1, (bx << 2) + 3) & 3;
+                        const int ly = max(y0, by << 2) & 3, hy = min(y1, (by << 2) + 3) & 3;
+                        const int lz = max(z0, bz << 2) & 3, hz = min(z1, (bz << 2) + 3) & 3;
+                        const unsigned long long mx = 0x1111111111111111ull * (unsigned long long)((2u << hx) - (1u << lx));
+                        const unsigned long long my = 0x0001000100010001ull * (unsigned long long)((16u << (hy << 2)) - (1u << (ly << 2)));
+                        const unsigned long long mz = ((hz == 3 ? 0ull : (1ull << ((hz + 1) << 4))) - 1ull) & ~((1ull << (lz << 4)) - 1ull);
                         m8[q] = w8[q] & mx & my & mz;
                         if (m8[q]) { r8[q] = occ_rank[block_of(bx << 2, by << 2, bz << 2, g.dx, g.dy)]; any = true; }
                     }
