@@ -2399,12 +2399,13 @@ void ransac_prepare(plade_ctx *ctx, RansacWork &W, const CloudDev *const clouds[
     for (int g = n_clouds; g <= R_G; ++g) M.start[g] = G.start[g] = (uint32_t)total;
     W.keys_in.ensure(total); W.vals_in.ensure(total); W.keys.ensure(total); W.perm.ensure(total);
     hipLaunchKernelGGL(k_morton, dim3(cdiv(total, 256)), dim3(256), 0, ctx->stream, M, W.keys_in.p, W.vals_in.p);
-    // One sort per PAIR of clouds (the slot bits above bit 24 are equal inside a pair's range): a radix pass over the ~2M keys of
-    // a pair takes 58 us, one over the 8M keys of a group of four pairs 426 us (its look-back chain runs over four times the
-    // tiles) -- 4 x 3 short passes beat 3 long ones by 0.5 ms per group
-    for (int g = 0; g < n_clouds; g += 2) {
-        const uint32_t b = M.start[g], e = M.start[std::min(g + 2, n_clouds)];
-        if (e > b) sort_pairs_u32(ctx, W.keys_in.p + b, W.keys.p + b, W.vals_in.p + b, W.perm.p + b, e - b, g + 1 < n_clouds ? 25 : 24);
+    // One sort per CLOUD (the slot bits above bit 23 are equal inside a cloud's range): under the load of the pipeline a radix
+    // pass over the ~1M keys of a cloud takes ~20 us, one over the 2M keys of a pair 95-110 us, one over the 8M keys of a group
+    // of four pairs 426 us -- the passes are chains of dependent round trips whose tiles wait for each other, and the more
+    // tiles a pass has the longer each of them is kept waiting by foreign workgroups
+    for (int g = 0; g < n_clouds; ++g) {
+        const uint32_t b = M.start[g], e = M.start[g + 1];
+        if (e > b) sort_pairs_u32(ctx, W.keys_in.p + b, W.keys.p + b, W.vals_in.p + b, W.perm.p + b, e - b, 24);
     }
     hipLaunchKernelGGL(k_gather_cloud, dim3(cdiv(total, 256)), dim3(256), 0, ctx->stream, G, W.keys.p, W.perm.p);
     Cells6Args C6;
