@@ -21,9 +21,11 @@ beside it (`pipeline.occupancy_value`).
 Rank 0 prints ONE JSON line.  `resident_rank0` is the same pipeline on clouds already resident in HBM.
 
 Extra objects on the line:
-  roofline     -- the dominant kernel of the step, timed live with HIP events on the stream the kernel is
-                  launched on (one extra profiled step after the timed region), achieved = algorithmic
-                  bytes per launch / average launch duration, peak = 8 TB/s HBM3E.
+  roofline     -- the dominant kernel of the step, timed live after the timed region under the same load, in two legs:
+                  HIP events on the launch stream around every launch (the loop launched kernel by kernel), and
+                  the kernel's own device clock with the loop launched as in the timed region (one hipGraph per
+                  iteration; `launch_path`): achieved = algorithmic bytes per launch / average
+                  launch duration of the graph leg, peak = 8 TB/s HBM3E.
   cpu_baseline -- the CPU path on this box's host cores, single thread like the reference: plane
                   extraction by the reference's own Schnabel RANSAC compiled from its sources
                   (oracle/_ref) when that library is present, everything after it by the oracle's
@@ -574,7 +576,6 @@ def main():
         # Profiled steps (HIP events on the launch stream around every launch of the scan kernels) on context 0 WHILE the
         # other contexts keep registering, i.e. under the load of the timed region: the average launch duration must be
         # the one `rocprofv3 --kernel-trace --stats` reports for this command (profiles/), not that of an idle GPU.
-        ctx.set_params(dump=2, host_wait=host_wait)
         stop = threading.Event()
 
         def background(w):
@@ -585,25 +586,35 @@ def main():
         bths = [threading.Thread(target=background, args=(w,)) for w in range(1, M)]
         for t in bths:
             t.start()
-        st = {}
         # a profiled "step" is a GROUP of S pairs on context 0, as in the timed region (the scan launches of its extraction
         # cover the 2 x S clouds of the group); every per-step figure below is per REGISTRATION: / (groups x S)
         prof_groups = max(1, (args.profiled_steps + S - 1) // S)
-        for j in range(prof_groups):
-            rgroup(j, 0, None)
-            for q in range(S):
-                for k, v in ctx.stats(pair=q).items():
-                    if k.startswith(("k_", "bytes_")):
-                        st[k] = st.get(k, 0.0) + v
-                    elif q == 0:
-                        st[k] = v
+
+        def profiled(mode):
+            acc = {}
+            ctx.set_params(dump=mode, host_wait=host_wait)
+            for j in range(prof_groups):
+                rgroup(j, 0, None)
+                for q in range(S):
+                    for k, v in ctx.stats(pair=q).items():
+                        if k.startswith(("k_", "bytes_")):
+                            acc[k] = acc.get(k, 0.0) + v
+                        elif q == 0:
+                            acc[k] = v
+            for k in list(acc):
+                if k.startswith("bytes_"):
+                    acc[k] /= prof_groups * S
+            return acc
+        # leg 1: HIP events on the launch stream around every profiled launch (every stage; the extraction loop is launched
+        # kernel by kernel for it); leg 2: the extraction loop as the timed region launches it -- one captured hipGraph per
+        # iteration -- with the scan kernels stamping the device's wall clock themselves (events cannot sit between the
+        # nodes of a graph launch).  The roofline figure is leg 2's.
+        st = profiled(2)
+        st_graph = profiled(6)
         stop.set()
         for t in bths:
             t.join()
         args.profiled_steps = prof_groups * S
-        for k in list(st):
-            if k.startswith("bytes_"):
-                st[k] /= args.profiled_steps
         ctx.set_params(dump=0, host_wait=host_wait)
         kernels = sorted({k[2:-8] for k in st if k.startswith("k_") and k.endswith("_seconds") and not k.endswith("_clock_seconds")})
         best = None
@@ -624,7 +635,15 @@ def main():
             # rocprofv3's kernel trace reports); the HIP events around the launch are listed next to it -- with other
             # registrations in flight they also contain the other streams' kernels that ran on the same hardware queue
             c_secs, c_nl, c_by = st.get(f"k_{best}_clock_seconds"), st.get(f"k_{best}_clock_launches"), st.get(f"k_{best}_clock_bytes")
-            if c_secs and c_nl:
+            g_secs, g_nl, g_by = (st_graph.get(f"k_{best}_clock_seconds"), st_graph.get(f"k_{best}_clock_launches"),
+                                  st_graph.get(f"k_{best}_clock_bytes"))
+            direct = ({"achieved": c_by / c_secs / 1e9, "avg_launch_us": c_secs / c_nl * 1e6, "frac": c_by / c_secs / 1e9 / HBM_PEAK_GBS,
+                       "launches_per_step": c_nl / args.profiled_steps} if c_secs and c_nl else None)
+            if g_secs and g_nl:
+                achieved, avg_us, how = (g_by / g_secs / 1e9, g_secs / g_nl * 1e6,
+                                         "device wall clock inside the kernel (min start / max end over its wavefronts), launched as "
+                                         "a node of the iteration's hipGraph exactly as in the timed region")
+            elif c_secs and c_nl:
                 achieved, avg_us, how = c_by / c_secs / 1e9, c_secs / c_nl * 1e6, "device wall clock inside the kernel (min start / max end over its wavefronts)"
             else:
                 achieved, avg_us, how = by / secs / 1e9, secs / nl * 1e6, "HIP events on the launch stream"
@@ -639,6 +658,8 @@ def main():
                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                         "launches_per_step": nl / args.profiled_steps, "avg_launch_us": avg_us,
+                        "launch_path": "hipGraph" if (g_secs and g_nl) else "direct",
+                        "direct_launch_leg": direct,
                         "avg_launch_us_hip_events": secs / nl * 1e6,
                         "frac_at_hip_event_average": by / secs / 1e9 / HBM_PEAK_GBS,
                         "algorithmic_bytes_per_launch": by / nl,

@@ -52,7 +52,10 @@ int plade_device_synchronize(int device);
  *                          with both orientations (2x planes, ~4x line pairs / descriptors), so a pair registers
  *                          whatever the signs of the extracted plane normals are.  C++ API / CLI: env PLADE_UNORIENTED_NORMALS=1.
  *   ransac_seed     fixed  the reference seeds from time(NULL) (RansacShapeDetector.cpp:463-464)
- *   dump            0      keep named intermediates for plade_dump_get (tests)
+ *   dump            0      bit 0: keep named intermediates for plade_dump_get (tests); bit 1 (2): time the scan kernels
+ *                          (HIP events on the launch stream + the kernel's own clock; the extraction loop is then
+ *                          launched kernel by kernel); bits 1 + 2 (6): the kernel's own clock only, inside the captured
+ *                          graph of the iteration as the unprofiled path launches it (bench.py's roofline leg)
  *   ransac_topup    1      schedule of the plane extraction's hypothesis rounds.  1 = every iteration draws a round and
  *                          what the previous batch left of the candidate pool competes with the new draws (the
  *                          reference's loop generates candidates in every pass, RansacShapeDetector.cpp:548-617);

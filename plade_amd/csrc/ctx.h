@@ -112,7 +112,7 @@ struct plade_ctx {
     std::map<std::string, std::vector<char>> dump;
     plade::Stats stats;
     // optional per-kernel timing with HIP events on this ctx's stream (params.dump & 2)
-    struct EvRec { hipEvent_t a, b; std::string tag; double bytes; int clk = -1; };
+    struct EvRec { hipEvent_t a = nullptr, b = nullptr; std::string tag; double bytes = 0; int clk = -1; double clk_secs = -1.0; };
     std::vector<EvRec> evs;
     // Under load the two events of a record also see whatever other streams run on the same hardware queue in between;
     // the kernels that matter for the roofline therefore also take the device's wall clock themselves (first wavefront
@@ -121,9 +121,19 @@ struct plade_ctx {
     plade::DBuf<unsigned long long> clk_dev;
     int clk_used = 0;
     double clk_hz = 0;
-    unsigned long long *ev_clock() {   // the clock pair of the record opened last (nullptr outside profiled runs)
-        if (!profiling() || evs.empty() || clk_used >= CLK_SLOTS) return nullptr;
-        if (!clk_dev.p) {
+    // params.dump & 4 (with & 2): the profiled launches stay inside the captured graph of the plane extraction's iteration,
+    // as in the timed path.  Kernel arguments of a graph are fixed, so launch j of an iteration always stamps clock pair j
+    // (the graph is captured with these pointers; the plain graph has nullptr there), the pairs are read and reset behind
+    // every iteration (ev_graph_clocks), and there are no HIP events -- they cannot be placed between the nodes of a
+    // graph launch: a record's `seconds` is then the kernel's own clock too.
+    bool graph_clocks() const { return (params.dump & 6) == 6; }
+    bool capturing = false;                 // between hipStreamBeginCapture and EndCapture of such a graph
+    int cap_slot = 0;
+    std::vector<std::string> cap_tags;      // tags of the stamped launches of the graph being captured, in launch order
+    std::vector<unsigned long long> clk_host, clk_init;
+    void ensure_clk() {
+        if (clk_dev.p) return;
+        {
             clk_dev.ensure(2 * (size_t)CLK_SLOTS * CLK_WAYS);
             std::vector<unsigned long long> init(2 * (size_t)CLK_SLOTS * CLK_WAYS);
             for (size_t i = 0; i < init.size() / 2; ++i) { init[2 * i] = ~0ull; init[2 * i + 1] = 0ull; }
@@ -132,12 +142,51 @@ struct plade_ctx {
             (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device);
             clk_hz = khz > 0 ? khz * 1e3 : 1e8;
         }
+    }
+    unsigned long long *ev_clock() {   // the clock pair of the record opened last (nullptr outside profiled runs)
+        if (graph_clocks()) {
+            if (!capturing || cap_slot >= CLK_SLOTS) return nullptr;
+            ensure_clk();
+            return clk_dev.p + 2 * (size_t)CLK_WAYS * (cap_slot++);
+        }
+        if (!profiling() || evs.empty() || clk_used >= CLK_SLOTS) return nullptr;
+        ensure_clk();
         evs.back().clk = clk_used;
         return clk_dev.p + 2 * (size_t)CLK_WAYS * (clk_used++);
+    }
+    // graph path: one record per stamped launch of the graph just queued ...
+    void ev_graph_launched(const std::vector<std::string> &tags) {
+        for (size_t j = 0; j < tags.size(); ++j) { EvRec r; r.tag = tags[j]; r.clk = (int)j; evs.push_back(r); }
+    }
+    // ... and, with the iteration finished (the caller has waited for the stream), their clock pairs: read, reset
+    void ev_graph_clocks(size_t ev0) {
+        size_t used = 0;
+        for (size_t e = ev0; e < evs.size(); ++e) if (!evs[e].a && evs[e].clk >= 0) used = std::max(used, (size_t)evs[e].clk + 1);
+        if (!used) return;
+        clk_host.resize(2 * used * CLK_WAYS);
+        if (clk_init.size() < clk_host.size()) {
+            clk_init.resize(clk_host.size());
+            for (size_t i = 0; i < clk_init.size() / 2; ++i) { clk_init[2 * i] = ~0ull; clk_init[2 * i + 1] = 0ull; }
+        }
+        HIP_TRY(hipMemcpyAsync(clk_host.data(), clk_dev.p, clk_host.size() * 8, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(clk_dev.p, clk_init.data(), clk_host.size() * 8, hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        for (size_t e = ev0; e < evs.size(); ++e) {
+            EvRec &r = evs[e];
+            if (r.a || r.clk < 0) continue;
+            unsigned long long lo = ~0ull, hi = 0ull;
+            for (int w = 0; w < CLK_WAYS; ++w) {
+                lo = std::min(lo, clk_host[2 * ((size_t)r.clk * CLK_WAYS + w)]);
+                hi = std::max(hi, clk_host[2 * ((size_t)r.clk * CLK_WAYS + w) + 1]);
+            }
+            r.clk_secs = hi > lo ? (double)(hi - lo) / clk_hz : -1.0;
+            r.clk = -1;
+        }
     }
     bool profiling() const { return (params.dump & 2) != 0; }
     void ev_begin(const char *tag, double bytes) {
         if (!profiling()) return;
+        if (graph_clocks()) { if (capturing) cap_tags.push_back(tag); return; }
         EvRec r;
         r.tag = tag; r.bytes = bytes;
         (void)hipEventCreate(&r.a); (void)hipEventCreate(&r.b);
@@ -145,7 +194,7 @@ struct plade_ctx {
         evs.push_back(r);
     }
     void ev_end() {
-        if (!profiling() || evs.empty()) return;
+        if (!profiling() || graph_clocks() || evs.empty()) return;
         (void)hipEventRecord(evs.back().b, stream);
     }
     void ev_collect() {
@@ -169,6 +218,17 @@ struct plade_ctx {
         }
         for (auto &r : evs) {
             float ms = 0.f;
+            if (!r.a) {   // a launch inside a graph: its own clock is all there is
+                if (r.bytes >= 0 && r.clk_secs >= 0) {
+                    stats.add("k_" + r.tag + "_seconds", r.clk_secs);
+                    stats.add("k_" + r.tag + "_launches", 1.0);
+                    stats.add("k_" + r.tag + "_bytes", r.bytes);
+                    stats.add("k_" + r.tag + "_clock_seconds", r.clk_secs);
+                    stats.add("k_" + r.tag + "_clock_launches", 1.0);
+                    stats.add("k_" + r.tag + "_clock_bytes", r.bytes);
+                } else stats.add("k_" + r.tag + "_idle_launches", 1.0);
+                continue;
+            }
             (void)hipEventElapsedTime(&ms, r.a, r.b);
             if (r.bytes >= 0) {   // a negative byte count marks a launch that had nothing to do (device-side early exit)
                 stats.add("k_" + r.tag + "_seconds", ms * 1e-3);

@@ -2183,6 +2183,7 @@ struct RansacWork {
     uint32_t generation = 0;         // detect calls issued on this work area
     DBuf<uint32_t> keys_in, vals_in, keys, perm;
     std::map<uint64_t, hipGraphExec_t> graphs;   // the iteration sequence, keyed on everything baked into its launches
+    std::map<uint64_t, std::vector<std::string>> graph_tags;   // of the graphs captured with clock stamps (plade_ctx::graph_clocks)
     ~RansacWork() { for (auto &kv : graphs) if (kv.second) (void)hipGraphExecDestroy(kv.second); }
 };
 
@@ -2300,25 +2301,31 @@ void enqueue_iteration(plade_ctx *ctx, const RArgs &A) {
 }
 
 void launch_iteration(plade_ctx *ctx, RansacWork &W, const RArgs &A) {
-    if (ctx->profiling() || getenv("PLADE_NO_GRAPH")) { enqueue_iteration(ctx, A); HIP_TRY(hipGetLastError()); return; }
-    const uint64_t key = hash_bytes(&A, sizeof(A));
+    const bool stamped = ctx->graph_clocks();   // profiled on the graph path: its own graph, with clock pointers in the scan launches
+    if ((ctx->profiling() && !stamped) || getenv("PLADE_NO_GRAPH")) { enqueue_iteration(ctx, A); HIP_TRY(hipGetLastError()); return; }
+    const uint64_t key = hash_bytes(&A, sizeof(A)) ^ (stamped ? 0x9e3779b97f4a7c15ull : 0ull);
     auto it = W.graphs.find(key);
     if (it == W.graphs.end()) {
         if (W.graphs.size() > 64) {   // bounded cache (a batch of differently sized clouds)
             for (auto &kv : W.graphs) if (kv.second) (void)hipGraphExecDestroy(kv.second);
             W.graphs.clear();
+            W.graph_tags.clear();
         }
         hipGraph_t graph = nullptr;
+        if (stamped) { ctx->ensure_clk(); ctx->capturing = true; ctx->cap_slot = 0; ctx->cap_tags.clear(); }
         HIP_TRY(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
         try { enqueue_iteration(ctx, A); }
-        catch (...) { (void)hipStreamEndCapture(ctx->stream, &graph); if (graph) (void)hipGraphDestroy(graph); throw; }
+        catch (...) { ctx->capturing = false; (void)hipStreamEndCapture(ctx->stream, &graph); if (graph) (void)hipGraphDestroy(graph); throw; }
+        ctx->capturing = false;
         HIP_TRY(hipStreamEndCapture(ctx->stream, &graph));
+        if (stamped) W.graph_tags[key] = ctx->cap_tags;
         hipGraphExec_t e = nullptr;
         HIP_TRY(hipGraphInstantiate(&e, graph, nullptr, nullptr, 0));
         (void)hipGraphDestroy(graph);
         it = W.graphs.emplace(key, e).first;
     }
     HIP_TRY(hipGraphLaunch(it->second, ctx->stream));
+    if (stamped) ctx->ev_graph_launched(W.graph_tags[key]);
 }
 
 // Waits until every listed result block reports at least `want` completed iterations (or the end of its detect call).
@@ -2489,6 +2496,7 @@ void ransac_detect_prepared(plade_ctx *ctx, RansacWork &W, RansacJob jobs[RANSAC
             for (int g = 0; g < ng; ++g)
                 if (jobs[g].active) ctx->d2h(hdr.data() + g * hdr_bytes, W.slot[g].state.p, hdr_bytes);
             ctx->sync();
+            if (ctx->graph_clocks()) ctx->ev_graph_clocks(ev0);
             double rescore_bytes[2] = {0, 0}, mark_bytes = 0;
             uint32_t mark_launches = 0;
             for (int g = 0; g < ng; ++g) {

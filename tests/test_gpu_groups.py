@@ -142,3 +142,29 @@ def test_bad_group_arguments_are_refused(scenes):
     with pytest.raises(plade_amd.PladeError):
         c.registration_pairs([])
     c.close()
+
+
+@pytest.mark.parametrize("mode", [2, 6])
+def test_profiled_modes_time_the_scan_kernels_and_change_nothing(scenes, alone, mode):
+    """params.dump & 2 times the scan kernels of the extraction loop (bench.py's roofline leg): mode 2 launches the loop
+    kernel by kernel with HIP events around the scans, mode 6 keeps the iteration's captured graph and has the kernels
+    stamp the device clock themselves.  Both report one record per working launch with the same algorithmic bytes
+    (28 B per point and launch + the mask bytes), and the registration is the unprofiled one bit for bit."""
+    c = plade_amd.Context(0, orient_normals=1, dump=mode)
+    res = c.registration_pairs([(scenes[0][0], scenes[0][1]), (scenes[1][0], scenes[1][1])])
+    st = c.stats()
+    for pos, i in enumerate((0, 1)):
+        assert res[pos][0] and np.array_equal(res[pos][1], alone[i][1])
+    launches, secs, byts = st["k_score_mark_clock_launches"], st["k_score_mark_clock_seconds"], st["k_score_mark_clock_bytes"]
+    assert launches >= 4 and launches == st["k_score_mark_launches"] and byts == st["k_score_mark_bytes"]
+    # every working launch reads at least one cloud and at most the four of the group
+    n_min, n_max = 120000, 2 * 200000 + 2 * 120000
+    assert 28.0 * n_min * launches <= byts <= 28.5 * n_max * launches
+    assert 1e-6 * launches < secs < 5e-3 * launches
+    c.close()
+    # the same byte count in both modes: it is a property of the extraction, not of how it was launched
+    key = "_profiled_bytes"
+    seen = globals().setdefault(key, {})
+    seen[mode] = (launches, byts)
+    if len(seen) == 2:
+        assert seen[2] == seen[6]
