@@ -352,12 +352,15 @@ def main():
     one_gpu = os.environ.get("PLADE_BENCH_ONE_GPU") == "1"
     if one_gpu:
         local_rank = 0
-    # torch only where it is needed -- torch.distributed (RCCL) for N > 1.  `import torch` brings the HIP runtime bundled
-    # with the wheel (ROCm 7.0) into the process ahead of the system's (7.2), and the library then runs on that one:
-    # measured 458 instead of 483 registrations/s at N = 1 (tools/exp_throughput.py, EXP_TORCH=import).  A single-GPU run
-    # brackets its timed region with hipDeviceSynchronize through the library instead of device_sync().
-    torch = dist = None
-    if world > 1:
+    # No torch in the ranks.  `import torch` brings the HIP runtime bundled with the wheel (ROCm 7.0) into the process ahead
+    # of the system's (7.2), and the library then runs on that one: measured 458 instead of 483 registrations/s at N = 1
+    # (tools/exp_throughput.py, EXP_TORCH=import) -- a penalty every rank would pay.  The path shards whole pairs and has
+    # no data-path collective; what the ranks exchange -- the barriers around the timed region, three numbers to reduce and
+    # 68 bytes of result per pair -- goes over their loopback rendezvous (plade_amd/rendezvous.py; the ranks of
+    # `torch.distributed.run --nnodes=1` share one host).  The timed region is bracketed with hipDeviceSynchronize through
+    # the library.  PLADE_BENCH_TORCH=1 restores the torch.distributed exchange (RCCL; gloo with PLADE_BENCH_ONE_GPU).
+    torch = dist = comm = dev = None
+    if world > 1 and os.environ.get("PLADE_BENCH_TORCH") == "1":
         import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -365,8 +368,9 @@ def main():
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="gloo" if one_gpu else "nccl", world_size=world, rank=rank)  # nccl == RCCL on ROCm
         dev = torch.device("cpu") if one_gpu else torch.device("cuda", local_rank)
-    else:
-        dev = None
+    elif world > 1:
+        from plade_amd.rendezvous import Rendezvous
+        comm = Rendezvous.from_env()
 
     import plade_amd
     from plade_amd.synth import make_pair
@@ -376,6 +380,12 @@ def main():
             torch.cuda.synchronize()
         else:
             plade_amd.device_synchronize(local_rank)
+
+    def barrier():
+        if comm is not None:
+            comm.barrier()
+        elif dist is not None:
+            dist.barrier()
 
     import threading
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
@@ -474,8 +484,7 @@ def main():
     # (all in the same stage at once, competing for the same units) and need a few rounds to spread out over the stages
     lead_groups = max((args.warmup + S - 1) // S, int(os.environ.get("BENCH_LEAD_ROUNDS", "8")) * M)
     device_sync()
-    if world > 1:
-        dist.barrier()
+    barrier()
     device_sync()
     cpu0, thr0 = time.process_time(), _cgroup_throttle()
     t_begin = time.perf_counter()
@@ -495,14 +504,16 @@ def main():
     # plade_amd/batch.py, covered on CPU by tests/test_distributed_gloo.py with gloo)
     from plade_amd.batch import gather_results
     all_T, all_ok = gather_results(np.stack(results), np.array(oks, bool), world * n_timed, rank, world,
-                                   device=dev if world > 1 else None)
+                                   device=dev, comm=comm)
     device_sync()
-    if world > 1:
-        dist.barrier()
+    barrier()
     device_sync()
     bracketed = time.perf_counter() - t_begin
     total_ok = n_ok
-    if world > 1:
+    if comm is not None:
+        elapsed, bracketed, occ_elapsed = comm.all_reduce_max([elapsed, bracketed, occ_elapsed])
+        total_ok = int(comm.all_reduce_sum([n_ok])[0])
+    elif world > 1:
         tmax = torch.tensor([elapsed, bracketed, occ_elapsed], dtype=torch.float64, device=dev)
         okt = torch.tensor([n_ok], dtype=torch.int64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -723,6 +734,9 @@ def main():
             "ms_per_step": elapsed / n_timed * 1e3,
             "higher_is_better": True,
             "scaling": "weak",
+            "rank_exchange": ("single process" if world == 1 else "loopback rendezvous (plade_amd/rendezvous.py)" if comm is not None
+                              else "torch.distributed"),
+            "torch_in_process": "torch" in sys.modules,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
@@ -775,7 +789,9 @@ def main():
         for ct, cs in clouds[w]:
             ct.free(); cs.free()
         ctxs[w].close()
-    if world > 1:
+    if comm is not None:
+        comm.close()
+    elif dist is not None:
         dist.destroy_process_group()
 
 

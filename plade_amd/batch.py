@@ -1,7 +1,8 @@
 """Multi-GPU batch mode: scan pairs are independent (code/PLADE/main.cpp:97-158 is a plain loop), so
 pair i goes to rank i % world, each rank registers its shard on its own GPU with no data-path
-collective, and the 4x4 results (+ status) are gathered (one all_gather) and assembled on rank 0 in input
-order over torch.distributed (RCCL on GPUs, gloo in the CPU tests)."""
+collective, and the 4x4 results (+ status) are gathered and assembled on rank 0 in input order -- 68 bytes per pair, over
+the ranks' loopback rendezvous (`comm`, plade_amd/rendezvous.py: no torch in the process) or, for callers that live in a
+torch.distributed job anyway, with one all_gather (RCCL on GPUs, gloo in the CPU tests)."""
 import numpy as np
 
 
@@ -10,13 +11,32 @@ def shard(n_items, rank, world):
     return list(range(rank, n_items, world))
 
 
-def gather_results(local_T, local_ok, n_items, rank, world, device=None):
+def _assemble(parts, n_items, world):
+    T = np.zeros((n_items, 4, 4), np.float32)
+    ok = np.zeros(n_items, bool)
+    for r in range(world):
+        a = parts[r]
+        for k, i in enumerate(shard(n_items, r, world)):
+            T[i] = a[k, :16].reshape(4, 4)
+            ok[i] = a[k, 16] > 0.5
+    return T, ok
+
+
+def gather_results(local_T, local_ok, n_items, rank, world, device=None, comm=None):
     """local_T: (len(shard), 4, 4) float32, local_ok: (len(shard),) bool.  Returns on rank 0
-    (T (n_items,4,4), ok (n_items,)) in input order, on other ranks (None, None)."""
+    (T (n_items,4,4), ok (n_items,)) in input order, on other ranks (None, None).  `comm`: a plade_amd.rendezvous.Rendezvous
+    of the ranks (then nothing here touches torch); without it the exchange is torch.distributed's."""
     mine = shard(n_items, rank, world)
     assert len(mine) == len(local_T) == len(local_ok)
     if world == 1:   # nothing to exchange (and no torch in a single-GPU process: see bench.py)
         return np.asarray(local_T, np.float32).reshape(n_items, 4, 4).copy(), np.asarray(local_ok, bool).copy()
+    if comm is not None:
+        buf = np.zeros((len(mine), 17), np.float32)
+        if len(mine):
+            buf[:, :16] = np.asarray(local_T, np.float32).reshape(len(mine), 16)
+            buf[:, 16] = np.asarray(local_ok, np.float32)
+        parts = comm.gather(buf)
+        return _assemble(parts, n_items, world) if rank == 0 else (None, None)
     import torch
     import torch.distributed as dist
     per = (n_items + world - 1) // world  # pad every shard to the same length for the collective
@@ -36,17 +56,10 @@ def gather_results(local_T, local_ok, n_items, rank, world, device=None):
         dist.all_gather(parts, t)
     if rank != 0:
         return None, None
-    T = np.zeros((n_items, 4, 4), np.float32)
-    ok = np.zeros(n_items, bool)
-    for r in range(world):
-        a = parts[r].cpu().numpy()
-        for k, i in enumerate(shard(n_items, r, world)):
-            T[i] = a[k, :16].reshape(4, 4)
-            ok[i] = a[k, 16] > 0.5
-    return T, ok
+    return _assemble([p.cpu().numpy() for p in parts], n_items, world)
 
 
-def sharded_overlap_counts(ctx, src_ds, tgt_ds, T, centers, src_radius, inlier_dist, rank, world, device=None, counter=None):
+def sharded_overlap_counts(ctx, src_ds, tgt_ds, T, centers, src_radius, inlier_dist, rank, world, device=None, counter=None, comm=None):
     """Second sharding axis: the K candidate transforms of ONE pair are independent in the verification
     step (code/PLADE/plade.cpp:547-564), so rank r scores candidates r, r + world, ... on its own GPU against its
     own copy of the two downsampled clouds (seam S3, plade_overlap_counts) and the K int32 counts are all-gathered
@@ -54,8 +67,6 @@ def sharded_overlap_counts(ctx, src_ds, tgt_ds, T, centers, src_radius, inlier_d
     candidate order on every rank.  `counter(src, tgt, T, centers, radius, dist)` defaults to ctx.overlap_counts (the
     CPU tests pass a stand-in).  The default pipeline does not use this: with the reference's K <= 201 the
     verification kernel takes ~0.2 ms of a 7 ms registration; it pays when the candidate cap is lifted."""
-    import torch
-    import torch.distributed as dist
     T = np.ascontiguousarray(T, np.float32).reshape(-1, 4, 4)
     centers = np.ascontiguousarray(centers, np.float32).reshape(-1, 3)
     K = len(T)
@@ -65,6 +76,13 @@ def sharded_overlap_counts(ctx, src_ds, tgt_ds, T, centers, src_radius, inlier_d
              if mine else np.zeros(0, np.int32))
     if world == 1:
         return local
+    if comm is not None:
+        out = np.zeros(K, np.int32)
+        for r, a in enumerate(comm.all_gather(local)):
+            out[shard(K, r, world)] = a
+        return out
+    import torch
+    import torch.distributed as dist
     per = (K + world - 1) // world
     buf = np.full(per, -2, np.int32)
     buf[: len(mine)] = local

@@ -1,5 +1,6 @@
 """bench.py's N > 1 control flow (rendezvous, barriers, max-over-ranks timing, result gather) on a one-GPU box: two
-ranks share cuda:0 and exchange over gloo (PLADE_BENCH_ONE_GPU=1; RCCL refuses two ranks on one device)."""
+ranks share cuda:0 (PLADE_BENCH_ONE_GPU=1) and exchange over their loopback rendezvous, without torch in the ranks; and
+with PLADE_BENCH_TORCH=1 over torch.distributed (gloo here: RCCL refuses two ranks on one device)."""
 import json
 import os
 import socket
@@ -12,12 +13,16 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_bench_two_ranks_on_one_gpu():
+@pytest.mark.parametrize("with_torch", [False, True])
+def test_bench_two_ranks_on_one_gpu(with_torch):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     env = dict(os.environ, PLADE_BENCH_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("PLADE_BENCH_TORCH", None)
+    if with_torch:
+        env["PLADE_BENCH_TORCH"] = "1"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "4",
            "--points", "200000", "--inflight", "2", "--group", "2"]
@@ -27,6 +32,7 @@ def test_bench_two_ranks_on_one_gpu():
     assert len(lines) == 1            # rank 0 prints the one JSON line
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak"
+    assert d["torch_in_process"] == with_torch and ("torch" in d["rank_exchange"]) == with_torch
     # at least 32 rounds of the registrations in flight are timed whatever --steps says (bench.py: a short window samples a
     # pipeline badly); `steps` is the number really timed
     timed = 32 * 2 * 2
