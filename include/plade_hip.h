@@ -267,6 +267,13 @@ int plade_selftest_readback(plade_ctx *ctx, uint32_t n_ranges, uint32_t words, u
  * streams `mbytes` MB of scratch memory; returns when they have finished.  tools/exp_interference.py runs it beside the
  * registrations to measure what foreign kernel boundaries, workgroup dispatches and memory traffic cost them. */
 int plade_diag_launches(plade_ctx *ctx, uint32_t count, uint32_t blocks, uint32_t mbytes);
+/* Seam of the one host-side stage whose tie-breaking shapes the result: the order in which
+ * std::sort(sortVec.begin(), sortVec.end(), myCompareGreater) (code/PLADE/util.cpp:335-345, util.h:347-365) leaves clusters
+ * of the given sizes -- order[i] = index of the cluster at sorted position i.  mode 0: the library's implementation
+ * (exact_sort.h: libstdc++'s introsort with a block-wise partition), 1: std::sort itself, 2 / 3: the block-wise / the
+ * sequential partition with the recursion depth limited to `depth_limit` (< 0: the library's 2 lg n).  Host code only: no
+ * context, no GPU. */
+int plade_diag_cluster_order(const float *sizes, uint32_t n, int32_t mode, int32_t depth_limit, int32_t *order);
 /* Times `iters` launches of one hot kernel on resident synthetic-shaped data with HIP events on
  * the ctx stream (used by bench.py for the roofline figure): which = "score" | "overlap" | "match". */
 int plade_kernel_time(plade_ctx *ctx, const char *which, int iters, double *avg_seconds,

@@ -22,7 +22,7 @@ ABI_SYMBOLS = [
     "plade_registration", "plade_registration_minsupport", "plade_cloud_upload", "plade_cloud_free",
     "plade_registration_dev", "plade_dump_get", "plade_stats_get", "plade_kernel_time", "plade_plane_component",
     "plade_sort_pairs", "plade_host_pin", "plade_host_unpin", "plade_score_planes_subset", "plade_registration_next", "plade_cluster_transforms", "plade_device_synchronize", "plade_selftest_readback",
-    "plade_registration_pairs", "plade_registration_pairs_dev", "plade_pair_ctx", "plade_set_candidate_shard", "plade_diag_launches",
+    "plade_registration_pairs", "plade_registration_pairs_dev", "plade_pair_ctx", "plade_set_candidate_shard", "plade_diag_launches", "plade_diag_cluster_order",
 ]
 
 
@@ -87,6 +87,7 @@ def load_library(path=LIB_PATH):
     sig("plade_registration_pairs_dev", argtypes=[p, u32, p, p, p, p])
     sig("plade_pair_ctx", argtypes=[p, u32], restype=p)
     sig("plade_diag_launches", argtypes=[p, u32, u32, u32])
+    sig("plade_diag_cluster_order", argtypes=[p, u32, i32, i32, p])
     sig("plade_set_candidate_shard", argtypes=[p, u32, u32, u32, EXCHANGE_FN, p])
     sig("plade_registration_minsupport", argtypes=[p, p, u32, p, u32, i32, i32, p])
     sig("plade_cloud_upload", argtypes=[p, p, u32, C.POINTER(p)])
@@ -142,6 +143,18 @@ def device_synchronize(device=0):
     rc = load_library().plade_device_synchronize(int(device))
     if rc != 0:
         raise PladeError(rc, "plade_device_synchronize failed")
+
+
+def cluster_order(sizes, mode=0, depth_limit=-1):
+    """Host seam: the order std::sort(..., myCompareGreater) (util.cpp:335-345) gives clusters of these sizes -- mode 0: the
+    library's implementation, 1: std::sort, 2 / 3: block-wise / sequential partition at a given recursion depth limit."""
+    a = _f32(sizes).reshape(-1)
+    out = np.zeros(len(a), np.int32)
+    rc = load_library().plade_diag_cluster_order(a.ctypes.data_as(C.c_void_p), len(a), int(mode), int(depth_limit),
+                                                 out.ctypes.data_as(C.c_void_p))
+    if rc != 0:
+        raise PladeError(rc, "plade_diag_cluster_order failed")
+    return out
 
 
 class Cloud:

@@ -1,5 +1,6 @@
 // plade_amd/csrc/api.hip -- context management and instrumentation entry points of the C ABI.
 #include "ctx.h"
+#include "exact_sort.h"
 #include "pipeline.h"
 #include "ransac.h"
 
@@ -102,6 +103,20 @@ extern "C" int plade_diag_launches(plade_ctx *ctx, uint32_t count, uint32_t bloc
         ctx->sync();
         return PLADE_OK;
     });
+}
+
+extern "C" int plade_diag_cluster_order(const float *sizes, uint32_t n, int32_t mode, int32_t depth_limit, int32_t *order) {
+    if ((n && (!sizes || !order)) || mode < 0 || mode > 3) return PLADE_EINVAL;
+    try {
+        std::vector<plade::exact_sort::Item> v(n);
+        for (uint32_t i = 0; i < n; ++i) { v[i].index = (int)i; v[i].length = sizes[i]; }
+        if (mode == 0) plade::exact_sort::sort_descending(v.data(), v.data() + n);
+        else if (mode == 1) std::sort(v.begin(), v.end(), plade::exact_sort::greater);
+        else if (mode == 2) plade::exact_sort::sort_descending<true>(v.data(), v.data() + n, depth_limit);
+        else plade::exact_sort::sort_descending<false>(v.data(), v.data() + n, depth_limit);
+        for (uint32_t i = 0; i < n; ++i) order[i] = v[i].index;
+    } catch (...) { return PLADE_ELIMIT; }
+    return PLADE_OK;
 }
 
 extern "C" int plade_dump_get(plade_ctx *ctx, const char *name, const void **ptr, int64_t *nbytes) {

@@ -7,6 +7,7 @@
 #include "pipeline.h"
 #include "hostgeom.h"
 #include "prims.h"
+#include "exact_sort.h"
 #include <algorithm>
 #include <numeric>
 #include <thread>
@@ -200,6 +201,14 @@ struct RegistrationWork {
     DBuf<float> d_rt12, d_T16;      // d_T16: transforms | centres of the verified candidates
     DBuf<int32_t> d_counts;         // overlap counts | sphere flags
     OverlapWork ov_work;
+    // host side of the cluster stage: ~30 000 clusters per registration, five arrays of them -- kept from call to call (a fresh
+    // std::vector of 100-200 KB per call is an mmap, a page fault per 4 KB and an munmap: ~0.3 ms of system time per registration)
+    struct ClusterHost {
+        std::vector<uint32_t> seeds, sizes;
+        std::vector<int32_t> pcounts;
+        std::vector<int> cand_cluster, match_counts;
+        std::vector<exact_sort::Item> sort_vec;
+    } ch;
     hipEvent_t ev_grid = nullptr;   // target grid of the verification built on the auxiliary stream
     hipEvent_t ev_main = nullptr;   // everything queued on the main stream before the two sides are prepared
     ~RegistrationWork() { if (ev_grid) (void)hipEventDestroy(ev_grid); if (ev_main) (void)hipEventDestroy(ev_main); }
@@ -340,8 +349,8 @@ bool run_registration(plade_ctx *ctx, RegistrationWork &W, const CloudDev &tgt, 
             ctx->put("initial_RT", rt.data(), rt.size());
         }
     }
-    std::vector<uint32_t> seeds, sizes;
-    std::vector<int32_t> pcounts;
+    std::vector<uint32_t> &seeds = W.ch.seeds, &sizes = W.ch.sizes;
+    std::vector<int32_t> &pcounts = W.ch.pcounts;
     {
         StageTimer t(ctx, "t_cluster");
         // util.cpp:331: ClusterTransformation(Rs, Ts, lengthThreshold / 2, angleThreshold / 2) with the
@@ -353,8 +362,9 @@ bool run_registration(plade_ctx *ctx, RegistrationWork &W, const CloudDev &tgt, 
     const uint32_t nC = W.cand.n_clusters;
     ctx->stats.add("n_clusters", nC);
     // util.cpp:335-401: clusters by size (std::sort with myCompareGreater), centre gate, plane counts.
-    std::vector<int> cand_cluster;   // cluster index per entry of `matches`
-    std::vector<int> match_counts;
+    std::vector<int> &cand_cluster = W.ch.cand_cluster;   // cluster index per entry of `matches`
+    std::vector<int> &match_counts = W.ch.match_counts;
+    cand_cluster.clear(); match_counts.clear();
     {
         StageTimer t(ctx, "t_plane_consistency");
         seeds.resize(nC); sizes.resize(nC); pcounts.resize(nC);
@@ -368,10 +378,15 @@ bool run_registration(plade_ctx *ctx, RegistrationWork &W, const CloudDev &tgt, 
             ctx->d2h(pcounts.data(), W.cand.plane_counts.p, 4 * (size_t)nC);
         }
         ctx->sync();
-        std::vector<LengthIndex> sortVec(nC);
+        const double c_c = thread_cpu_seconds();
+        std::vector<exact_sort::Item> &sortVec = W.ch.sort_vec;
+        sortVec.resize(nC);
         for (uint32_t i = 0; i < nC; ++i) { sortVec[i].index = (int)i; sortVec[i].length = (float)sizes[i]; }
-        // same comparisons as cmp_greater, as an inlinable functor: std::sort's result is identical
-        std::sort(sortVec.begin(), sortVec.end(), [](const LengthIndex &a, const LengthIndex &b) { return a.length > b.length; });
+        // std::sort(sortVec.begin(), sortVec.end(), myCompareGreater) -- its permutation exactly, ties included, at a third
+        // of the host time (exact_sort.h)
+        exact_sort::sort_descending(sortVec.data(), sortVec.data() + nC);
+        const double c_d = thread_cpu_seconds();
+        ctx->stats.add("cpu_cluster_order", c_d - c_c);
         cand_cluster.reserve(nC);
         match_counts.reserve(nC);
         for (uint32_t i = 0; i < nC; ++i) {

@@ -180,3 +180,53 @@ def test_host_sources_compile_against_the_real_eigen():
     r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-DPLADE_USE_REAL_EIGEN", "-I", eigen, "-I", os.path.join(root, "include"),
                         "-I", csrc, os.path.join(csrc, "plade_host.cpp"), os.path.join(csrc, "main.cpp")], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-3000:]
+
+
+def _cluster_size_cases():
+    rng = np.random.default_rng(11)
+    for rep in range(400):
+        n = int(rng.integers(0, 700)) if rep < 250 else int(rng.integers(700, 70000))
+        mode = rep % 7
+        if mode == 0:     # what a registration produces: mostly clusters of one or two candidates, a few large ones
+            u = rng.random(n)
+            s = np.where(u < 0.6, 1, np.where(u < 0.8, 2, np.where(u < 0.9, 3, rng.integers(1, 41, n))))
+        elif mode == 1:
+            s = rng.integers(0, 3, n)
+        elif mode == 2:
+            s = rng.integers(0, 100000, n)
+        elif mode == 3:
+            s = np.arange(n, 0, -1)            # already in order
+        elif mode == 4:
+            s = np.arange(n)                   # reversed
+        elif mode == 5:
+            s = np.ones(n)                     # all tied
+        else:                                  # organ pipe
+            s = np.minimum(np.arange(n), np.arange(n)[::-1])
+        yield np.asarray(s, np.float32)
+
+
+def test_cluster_order_is_std_sorts_permutation_ties_included():
+    """util.cpp:335-345 orders the clusters of candidate transforms with an unstable std::sort on their sizes; most sizes
+    are tied, so the permutation is a property of libstdc++'s introsort.  The library's block-wise restatement
+    (exact_sort.h) must reproduce it cell for cell."""
+    import plade_amd
+    for s in _cluster_size_cases():
+        ref = plade_amd.cluster_order(s, mode=1)
+        got = plade_amd.cluster_order(s, mode=0)
+        assert np.array_equal(got, ref), (len(s), s[:8])
+        assert np.all(np.diff(s[got]) <= 0)
+
+
+def test_cluster_order_heap_sort_branch():
+    """Below a recursion depth of 2 lg n introsort finishes a range with heap sort; real inputs never get there, so the
+    branch is forced with small depth limits: the block-wise partition must hand the heap sort the same cells in the same
+    state as the sequential one (which IS the library's loop: at the library's own limit it equals std::sort above)."""
+    import plade_amd
+    for k, s in enumerate(_cluster_size_cases()):
+        if k % 4:
+            continue
+        for depth in (0, 1, 3, 6):
+            a = plade_amd.cluster_order(s, mode=2, depth_limit=depth)
+            b = plade_amd.cluster_order(s, mode=3, depth_limit=depth)
+            assert np.array_equal(a, b), (len(s), depth)
+        assert np.array_equal(plade_amd.cluster_order(s, mode=3), plade_amd.cluster_order(s, mode=1))
