@@ -178,11 +178,32 @@ __global__ __launch_bounds__(128) void k_voxel_centroids(const float *__restrict
             while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (seg_group[mid] < g) lo = mid + 1; else hi = mid; }
             group_offsets[g] = lo;
         }
-    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= n_seg) return;
-    const uint32_t b = heads[s], e = (s + 1 < n_seg) ? heads[s + 1] : n_items;
+    // The 128 voxels of a workgroup own one contiguous span of the sorted points.  A lane that walked its run in global memory
+    // touched a different line than its neighbours with every load (64 lines per wavefront load for 64 x 4 useful bytes); the
+    // span is staged through LDS in chunks instead -- coalesced loads -- and every lane adds, in ascending position as before,
+    // the part of its run that lies in the chunk.
+    constexpr uint32_t CH = 2048;
+    __shared__ float s_x[CH], s_y[CH], s_z[CH];
+    __shared__ uint32_t s_span[2];
+    const uint32_t s0 = blockIdx.x * blockDim.x;
+    if (s0 >= n_seg) return;
+    const uint32_t s = s0 + threadIdx.x;
+    const bool live = s < n_seg;
+    const uint32_t b = live ? heads[s] : 0u, e = live ? ((s + 1 < n_seg) ? heads[s + 1] : n_items) : 0u;
+    if (threadIdx.x == 0) s_span[0] = b;
+    if (s == min(n_seg, s0 + (uint32_t)blockDim.x) - 1) s_span[1] = e;
+    __syncthreads();
+    const uint32_t span_b = s_span[0], span_e = s_span[1];
     float ax = 0.f, ay = 0.f, az = 0.f;
-    for (uint32_t j = b; j < e; ++j) { ax += sx[j]; ay += sy[j]; az += sz[j]; }
+    for (uint32_t c0 = span_b; c0 < span_e; c0 += CH) {
+        const uint32_t c1 = min(span_e, c0 + CH);
+        for (uint32_t j = c0 + threadIdx.x; j < c1; j += blockDim.x) { s_x[j - c0] = sx[j]; s_y[j - c0] = sy[j]; s_z[j - c0] = sz[j]; }
+        __syncthreads();
+        const uint32_t jb = max(b, c0), je = min(e, c1);
+        for (uint32_t j = jb; j < je; ++j) { ax += s_x[j - c0]; ay += s_y[j - c0]; az += s_z[j - c0]; }
+        __syncthreads();
+    }
+    if (!live) return;
     const float cnt = (float)(e - b);
     const float cx = ax / cnt, cy = ay / cnt, cz = az / cnt;
     out_xyz[3 * (size_t)s] = cx;
