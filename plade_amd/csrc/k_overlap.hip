@@ -162,10 +162,11 @@ void TargetGrid::build(plade_ctx *ctx, const float *d_xyz, uint32_t n_pts, uint3
     sort_pairs_u32(ctx, keys.p, keys2.p, vals.p, vals2.p, n, bits);
     if (compact) {
         const uint32_t nw = (uint32_t)((ncells + 63) / 64);
-        occ_bits.ensure(nw + 1); occ_pop.ensure(nw + 2); occ_rank.ensure(nw + 2); occ_start.ensure((size_t)n + 2);
+        occ_bits.ensure(nw + 8); occ_pop.ensure(nw + 2); occ_rank.ensure(nw + 2); occ_start.ensure((size_t)n + 2);
         occ_blk.ensure(nw / 64 + 2);
         cell_first.ensure((size_t)n + 2);
-        HIP_TRY(hipMemsetAsync(occ_bits.p, 0, ((size_t)nw + 1) * 8, ctx->stream));
+        // (a multiple of 64 bytes: the runtime splits any other size into an aligned fill and a second command for the tail)
+        HIP_TRY(hipMemsetAsync(occ_bits.p, 0, (((size_t)nw + 1 + 7) & ~(size_t)7) * 8, ctx->stream));
         hipLaunchKernelGGL(k_occ_bits, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, keys2.p, n, occ_bits.p);
         hipLaunchKernelGGL(k_occ_pop, dim3(cdiv(nw + 1, 256)), dim3(256), 0, ctx->stream, occ_bits.p, nw, occ_pop.p, occ_blk.p);
         exclusive_scan_u32(ctx, occ_pop.p, occ_rank.p, (size_t)nw + 1);
@@ -403,8 +404,9 @@ void overlap_sort_source(plade_ctx *ctx, OverlapWork &work, const float *d_sx, c
 
 void overlap_counts(plade_ctx *ctx, OverlapWork &work, const float *d_sx, const float *d_sy, const float *d_sz, uint32_t n_s,
                     const TargetGrid &grid, const float *d_T, const float *d_centers, uint32_t K, float src_radius,
-                    float inlier_dist, int32_t *d_counts, uint32_t *d_any) {
-    if (reinterpret_cast<uint32_t *>(d_counts) + K == d_any) HIP_TRY(hipMemsetAsync(d_counts, 0, (size_t)K * 8, ctx->stream));   // one block
+                    float inlier_dist, int32_t *d_counts, uint32_t *d_any, bool counts_are_zero) {
+    if (counts_are_zero) {}
+    else if (reinterpret_cast<uint32_t *>(d_counts) + K == d_any) HIP_TRY(hipMemsetAsync(d_counts, 0, (size_t)K * 8, ctx->stream));   // one block
     else {
         HIP_TRY(hipMemsetAsync(d_counts, 0, (size_t)K * 4, ctx->stream));
         HIP_TRY(hipMemsetAsync(d_any, 0, (size_t)K * 4, ctx->stream));

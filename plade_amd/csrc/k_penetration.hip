@@ -390,16 +390,29 @@ __global__ __launch_bounds__(PEN_TPB) __attribute__((amdgpu_waves_per_eu(6))) vo
 
 void penetration_filter(plade_ctx *ctx, const float *cand_rt_host, uint32_t K, const PlaneGeomHost &src,
                         const PlaneGeomHost &tgt, PlaneCloudsDev &src_pts, PlaneCloudsDev &tgt_pts,
-                        float length_threshold, float angle_threshold, std::vector<int32_t> &flags_out, const float *cand_rt_dev) {
+                        float length_threshold, float angle_threshold, std::vector<int32_t> &flags_out, const float *cand_rt_dev,
+                        const PenGather *gather) {
     flags_out.assign(K, 0);
-    if (!K || !src.P || !tgt.P) { if (cand_rt_dev) ctx->sync(); return; }   // (the caller's read-back of the table rides on our wait)
+    if (!K || !src.P || !tgt.P) {   // (the caller's read-back of the table rides on our wait)
+        if (gather && K) {
+            uint32_t *d_ids = reinterpret_cast<uint32_t *>(ctx->scratch[4].ensure(4 * (size_t)K + 64));
+            ctx->h2d(d_ids, gather->ids, 4 * (size_t)K);
+            gather->launch(d_ids);
+        }
+        if (cand_rt_dev) ctx->sync();
+        return;
+    }
     // upload tables
-    // one upload: candidates | plane tables of both sides | search steps | plane-pair order
+    // one upload: candidates | plane tables of both sides | search steps | plane-pair order | the caller's candidate ids |
+    // the zeroed counters (a memset of their own would be one or two more commands)
     const uint32_t n_pairs = src.P * tgt.P;
     const size_t n_cand = cand_rt_dev ? 0 : 12 * (size_t)K;   // candidates already on the device: not uploaded again
     const size_t n_tab = n_cand + (4 + 3 + 12) * ((size_t)src.P + tgt.P);
-    const size_t nf = n_tab + (PEN_MAXS + 1) + n_pairs;
-    std::vector<float> h(nf);
+    const size_t n_ids = gather ? K : 0;
+    // counters: [0] items, [1] overflow, [2 .. 2+K) candidate flags, then one count per plane pair
+    const size_t n_ctr = (size_t)K + 2 + n_pairs;
+    const size_t nf = n_tab + (PEN_MAXS + 1) + n_pairs + n_ids + n_ctr;
+    std::vector<float> h(nf, 0.f);
     float *p = h.data();
     if (n_cand) memcpy(p, cand_rt_host, 48 * (size_t)K);
     float *o_cand = p; p += n_cand;
@@ -421,10 +434,7 @@ void penetration_filter(plade_ctx *ctx, const float *cand_rt_host, uint32_t K, c
     // AreTwoPlanesPenetrable(..., searchRadius = lengthThreshold, minPointsNum = 10, minDistance = lengthThreshold / 2)
     const float search_radius = (float)(double)length_threshold;
     const float min_distance = (float)((double)length_threshold / 2);
-    // counters: [0] items, [1] overflow, [2 .. 2+K) candidate flags, then one count per plane pair
-    const size_t n_ctr = (size_t)K + 2 + n_pairs;
-    uint32_t *d_ctr = reinterpret_cast<uint32_t *>(ctx->scratch[6].ensure((n_ctr + 8) * 4));
-    HIP_TRY(hipMemsetAsync(d_ctr, 0, n_ctr * 4, ctx->stream));
+    uint32_t *d_ctr = reinterpret_cast<uint32_t *>(d + n_tab + PEN_MAXS + 1 + n_pairs + n_ids);
     uint32_t *d_n = d_ctr, *d_over = d_ctr + 1, *d_flags = d_ctr + 2, *d_pair = d_ctr + 2 + K;
     std::vector<uint32_t> order(n_pairs);
     {
@@ -442,7 +452,9 @@ void penetration_filter(plade_ctx *ctx, const float *cand_rt_host, uint32_t K, c
         for (int i = 0; i <= PEN_MAXS; ++i) { h_steps[i] = dist; dist += search_radius; }  // util.cpp:1383
     }
     memcpy(h.data() + n_tab + PEN_MAXS + 1, order.data(), 4 * (size_t)n_pairs);
+    if (n_ids) memcpy(h.data() + n_tab + PEN_MAXS + 1 + n_pairs, gather->ids, 4 * n_ids);
     ctx->h2d(d, h.data(), nf * 4);
+    if (gather) gather->launch(reinterpret_cast<const uint32_t *>(d + n_tab + PEN_MAXS + 1 + n_pairs));
     const float *d_steps = d + n_tab;
     const uint32_t *d_order = reinterpret_cast<const uint32_t *>(d + n_tab + PEN_MAXS + 1);
     hipLaunchKernelGGL(k_pen_setup, dim3(cdiv(total, 256)), dim3(256), 0, ctx->stream, tb, length_threshold,

@@ -42,7 +42,8 @@ void overlap_sort_source(plade_ctx *ctx, OverlapWork &work, const float *d_sx, c
 // d_sx/d_sy/d_sz: the source in any order -- pass work.sorted's planes when overlap_sort_source ran before
 void overlap_counts(plade_ctx *ctx, OverlapWork &work, const float *d_sx, const float *d_sy, const float *d_sz, uint32_t n_s,
                     const TargetGrid &grid, const float *d_T, const float *d_centers, uint32_t K, float src_radius,
-                    float inlier_dist, int32_t *d_counts, uint32_t *d_any);
+                    float inlier_dist, int32_t *d_counts, uint32_t *d_any, bool counts_are_zero = false);
+// counts_are_zero: d_counts / d_any arrived zeroed with the caller's upload (no memset commands)
 
 void deinterleave3(plade_ctx *ctx, const float *d_xyz, uint32_t n, float *d_x, float *d_y, float *d_z);
 

@@ -197,9 +197,7 @@ struct RegistrationWork {
     MatchResult match;
     CandidateSet cand;
     TargetGrid grid, sp_grid;
-    DBuf<uint32_t> d_ids;
-    DBuf<float> d_rt12, d_T16;      // d_T16: transforms | centres of the verified candidates
-    DBuf<int32_t> d_counts;         // overlap counts | sphere flags
+    DBuf<float> d_rt12, d_T16;      // d_T16: transforms | centres | overlap counts | sphere flags of the verified candidates
     OverlapWork ov_work;
     // host side of the cluster stage: ~30 000 clusters per registration, five arrays of them -- kept from call to call (a fresh
     // std::vector of 100-200 KB per call is an mmap, a page fault per 4 KB and an munmap: ~0.3 ms of system time per registration)
@@ -434,18 +432,19 @@ bool run_registration(plade_ctx *ctx, RegistrationWork &W, const CloudDev &tgt, 
     // fetch the (R, T) of the tested candidates
     std::vector<float> rt12(12 * (size_t)K);
     {
-        std::vector<uint32_t> ids(K);
-        for (uint32_t i = 0; i < K; ++i) ids[i] = seeds[cand_cluster[tested[i]]];
-        W.d_ids.ensure(K);
         W.d_rt12.ensure(12 * (size_t)K);
-        ctx->h2d(W.d_ids.p, ids.data(), 4 * (size_t)K);
-        hipLaunchKernelGGL(k_gather_rt, dim3(cdiv(K, 64)), dim3(64), 0, ctx->stream, W.cand.rt.p, W.d_ids.p, K, W.d_rt12.p);
-        ctx->d2h(rt12.data(), W.d_rt12.p, 48 * (size_t)K);   // valid after the wait at the end of the penetration filter
     }
     std::vector<int32_t> penflags;
     {
         StageTimer t(ctx, "t_penetration");
-        penetration_filter(ctx, nullptr, K, C.geom, M.geom, C.pcl, M.pcl, lengthThreshold, angleThreshold, penflags, W.d_rt12.p);
+        // the ids of the tested candidates travel with the filter's table upload; the gather of their (R, T) is queued behind it
+        std::vector<uint32_t> ids(K);
+        for (uint32_t i = 0; i < K; ++i) ids[i] = seeds[cand_cluster[tested[i]]];
+        PenGather pg{ids.data(), [&](const uint32_t *d_ids) {
+            hipLaunchKernelGGL(k_gather_rt, dim3(cdiv(K, 64)), dim3(64), 0, ctx->stream, W.cand.rt.p, d_ids, K, W.d_rt12.p);
+            ctx->d2h(rt12.data(), W.d_rt12.p, 48 * (size_t)K);   // valid after the wait at the end of the penetration filter
+        }};
+        penetration_filter(ctx, nullptr, K, C.geom, M.geom, C.pcl, M.pcl, lengthThreshold, angleThreshold, penflags, W.d_rt12.p, &pg);
     }
     ctx->put("pen_flags", penflags.data(), penflags.size());
     // survivors = MatchedResult list (util.cpp:513-517)
@@ -478,23 +477,26 @@ bool run_registration(plade_ctx *ctx, RegistrationWork &W, const CloudDev &tgt, 
         std::vector<uint32_t> mine;
         for (uint32_t i = 0; i < Kv; ++i) if (!sharded || i % sh.world == sh.rank) mine.push_back(i);
         const uint32_t Km = (uint32_t)mine.size();
-        W.d_T16.ensure(19 * (size_t)Km + 4); W.d_counts.ensure(2 * (size_t)Km + 4);
+        // transforms | centres | counts | sphere flags in one block: the zeros of the last two travel with the upload (a memset of
+        // a few hundred bytes is one or two fill commands of its own)
+        W.d_T16.ensure(21 * (size_t)Km + 4);
         float *d_centers = W.d_T16.p + 16 * (size_t)Km;
-        uint32_t *d_any = reinterpret_cast<uint32_t *>(W.d_counts.p) + Km;
-        std::vector<float> up(19 * (size_t)Km);
+        int32_t *d_counts = reinterpret_cast<int32_t *>(W.d_T16.p + 19 * (size_t)Km);
+        uint32_t *d_any = reinterpret_cast<uint32_t *>(d_counts) + Km;
+        std::vector<float> up(21 * (size_t)Km, 0.f);
         for (uint32_t q = 0; q < Km; ++q) {
             memcpy(up.data() + 16 * (size_t)q, T16.data() + 16 * (size_t)mine[q], 64);
             memcpy(up.data() + 16 * (size_t)Km + 3 * (size_t)q, centers.data() + 3 * (size_t)mine[q], 12);
         }
         std::vector<int32_t> back(2 * (size_t)Kv, 0);
         if (Km) {
-            ctx->h2d(W.d_T16.p, up.data(), 76 * (size_t)Km);
+            ctx->h2d(W.d_T16.p, up.data(), 84 * (size_t)Km);
             HIP_TRY(hipStreamWaitEvent(ctx->stream, W.ev_grid, 0));
             const float *vsx = sort_source ? W.ov_work.sorted.p : C.d_ds_soa.p;
             overlap_counts(ctx, W.ov_work, vsx, vsx + C.n_ds, vsx + 2 * (size_t)C.n_ds, C.n_ds,
-                           W.grid, W.d_T16.p, d_centers, Km, (float)C.radius, downSampleDistance, W.d_counts.p, d_any);
+                           W.grid, W.d_T16.p, d_centers, Km, (float)C.radius, downSampleDistance, d_counts, d_any, true);
             std::vector<int32_t> part(2 * (size_t)Km);
-            ctx->d2h(part.data(), W.d_counts.p, 8 * (size_t)Km);
+            ctx->d2h(part.data(), d_counts, 8 * (size_t)Km);
             ctx->sync();
             for (uint32_t q = 0; q < Km; ++q) { back[mine[q]] = part[q]; back[Kv + mine[q]] = part[Km + q]; }
         }

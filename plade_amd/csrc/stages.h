@@ -3,6 +3,7 @@
 #pragma once
 #include "ctx.h"
 #include "geom.h"
+#include <functional>
 
 namespace plade {
 
@@ -93,11 +94,14 @@ struct PlaneCloudsDev {           // per-plane voxel-downsampled points, concate
 inline float pen_grid_cell(float length_threshold) { return 2.f * (float)(double)length_threshold; }
 struct PlaneGeomHost;
 void build_pen_grid(plade_ctx *ctx, PlaneCloudsDev &pc, const PlaneGeomHost &geom, float cell);
+// (pipeline) the candidates' table is gathered on the device from `ids` (K words): the ids are uploaded together with the
+// filter's own tables and `launch` queues the gather, given their device address, in front of the filter's kernels
+struct PenGather { const uint32_t *ids; std::function<void(const uint32_t *d_ids)> launch; };
 // flags_out[k] = 1 when candidate k has a penetrating plane pair
 void penetration_filter(plade_ctx *ctx, const float *cand_rt_host /*K x 12: R row-major, T*/, uint32_t K,
                         const PlaneGeomHost &src, const PlaneGeomHost &tgt, PlaneCloudsDev &src_pts,
                         PlaneCloudsDev &tgt_pts, float length_threshold, float angle_threshold,
-                        std::vector<int32_t> &flags_out, const float *cand_rt_dev = nullptr);
+                        std::vector<int32_t> &flags_out, const float *cand_rt_dev = nullptr, const PenGather *gather = nullptr);
 // cand_rt_dev: the same K x 12 table already on the device (cand_rt_host may then be null: nothing is uploaded)
 
 // ---- oriented bounding boxes (k_obb.hip; ComputeBoundingBox, util.h:186-248) ---------------------------------
