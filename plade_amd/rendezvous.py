@@ -3,8 +3,8 @@ data-path collective (code/PLADE/main.cpp:97-158 is a plain loop over independen
 barrier around the timed region, a few numbers to reduce, and 68 bytes of result per pair for rank 0 to write out.  That
 does not need a collective library in the process -- and `import torch` costs the registration ~5 % (it brings the HIP
 runtime bundled with the wheel into the process ahead of the system's, bench.py) -- so the ranks meet on a TCP socket of
-the loopback interface instead: rank 0 listens on an ephemeral port and publishes it in a file named after the launcher
-(the ranks' common parent process) and MASTER_PORT; ranks 1.. connect; every operation is a gather to rank 0 followed by
+the loopback interface instead: rank 0 listens on an ephemeral port and publishes it (with a random token) in a file named
+after MASTER_PORT; ranks 1.. connect and present the token; every operation is a gather to rank 0 followed by
 a broadcast of the result.
 
     comm = Rendezvous.from_env()           # RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT as torch.distributed.run sets them
@@ -70,8 +70,12 @@ class Rendezvous:
                     continue
                 c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
                 c.settimeout(timeout)
-                hello = _recv(c)
-                if hello.get("token") != token or hello.get("rank") in got or not 0 < hello.get("rank", 0) < self.world:
+                try:
+                    hello = _recv(c)
+                    ok = hello.get("token") == token and hello.get("rank") not in got and 0 < hello.get("rank", 0) < self.world
+                except Exception:                # noqa: BLE001 -- not one of ours: whatever it sent, it is turned away
+                    ok = False
+                if not ok:
                     c.close()                    # a straggler of another launch that read a stale file
                     continue
                 got[hello["rank"]] = c
@@ -92,8 +96,8 @@ class Rendezvous:
                         self.sock = s
                         break
                     s.close()
-                except (OSError, ValueError, ConnectionError, EOFError):
-                    pass                          # no file yet, a stale one, or rank 0 not listening yet
+                except Exception:                 # noqa: BLE001 -- no file yet, a stale one (nobody, or somebody else, listens
+                    pass                          # there), or rank 0 not listening yet: read the file again
                 time.sleep(0.02)
 
     @classmethod
@@ -101,7 +105,10 @@ class Rendezvous:
         """The ranks `python -m torch.distributed.run` (or anything that sets the same variables) started on this host."""
         world = int(os.environ.get("WORLD_SIZE", "1"))
         rank = int(os.environ.get("RANK", "0"))
-        key = os.environ.get("PLADE_RENDEZVOUS_KEY") or f"{os.getppid()}_{os.environ.get('MASTER_PORT', '0')}"
+        # MASTER_PORT identifies the launch among those running on this host at the same time (two cannot share it); a file
+        # left by an earlier launch on the same port is harmless: nobody listens there (or its token is refused) and the
+        # ranks keep reading until the new rank 0 has replaced it
+        key = os.environ.get("PLADE_RENDEZVOUS_KEY") or f"{os.getuid()}_{os.environ.get('MASTER_PORT', '0')}"
         return cls(rank, world, key, os.environ.get("PLADE_RENDEZVOUS_ADDR", "127.0.0.1"), timeout)
 
     def all_gather(self, obj):
