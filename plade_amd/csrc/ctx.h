@@ -271,7 +271,11 @@ struct plade_ctx {
     // host polls in memory (plade::copy_out_launch).  Against one copy command per array and a stream query per poll
     // that is fewer commands in the stream and no work for the runtime's event thread (profiles/r3_experiments.md).
     // Large arrays, and whatever does not fit the arena, are copied directly.
-    struct PendingRead { void *dst; const void *src; size_t off, bytes; };
+    struct PendingRead { void *dst; const void *src; size_t off, bytes; std::vector<char> eager; };
+    // The contract of d2h() -- `src` must keep its contents until the next sync() -- is checked, not just stated, under
+    // PLADE_DEBUG_READS=1: the range is also copied at once (a stream wait + a blocking copy: debug only) and compared with what
+    // the deferred hand-over delivers; a difference fails the call (the GPU test-suite passes in this mode).
+    bool debug_reads = getenv("PLADE_DEBUG_READS") != nullptr;
     std::vector<PendingRead> pending_reads;
     plade::HBuf<char> read_arena;
     char *read_arena_dev = nullptr;       // the arena as the device addresses it
@@ -287,7 +291,12 @@ struct plade_ctx {
             HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, stream));
             return;
         }
-        pending_reads.push_back(PendingRead{dst, src, read_arena_used, bytes});
+        pending_reads.push_back(PendingRead{dst, src, read_arena_used, bytes, {}});
+        if (debug_reads) {
+            HIP_TRY(hipStreamSynchronize(stream));
+            pending_reads.back().eager.resize(bytes);
+            HIP_TRY(hipMemcpy(pending_reads.back().eager.data(), src, bytes, hipMemcpyDeviceToHost));
+        }
         read_arena_used += need;
     }
     void sync_with_reads() {
@@ -358,9 +367,14 @@ struct plade_ctx {
         for (plade_ctx *p : peers) if (p) p->drop_reads();
     }
     void finish_reads() {
-        for (const PendingRead &r : pending_reads) memcpy(r.dst, read_arena.p + r.off, r.bytes);
+        bool changed = false;
+        for (const PendingRead &r : pending_reads) {
+            memcpy(r.dst, read_arena.p + r.off, r.bytes);
+            if (!r.eager.empty() && memcmp(r.eager.data(), read_arena.p + r.off, r.bytes) != 0) changed = true;
+        }
         pending_reads.clear();
         read_arena_used = 0;
+        if (changed) throw plade::Err{-2, "PLADE_DEBUG_READS: a range noted by d2h() changed before the wait that delivers it"};
     }
     plade::ScanWork scan;
     // the radix sort's two global digit histograms (radix_sort.hip) and the number of sorts issued on this context

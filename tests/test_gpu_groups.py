@@ -168,3 +168,17 @@ def test_profiled_modes_time_the_scan_kernels_and_change_nothing(scenes, alone, 
     seen[mode] = (launches, byts)
     if len(seen) == 2:
         assert seen[2] == seen[6]
+
+
+def test_deferred_readbacks_keep_their_contract(scenes, alone, monkeypatch):
+    """ctx.d2h() only notes a range; the next wait delivers it, so the range must not change in between.  Under
+    PLADE_DEBUG_READS=1 every noted range is also copied at once and compared with what the wait delivers: a group of
+    registrations (every stage's read-backs, both host paths) must pass the check and return the usual bits."""
+    monkeypatch.setenv("PLADE_DEBUG_READS", "1")
+    c = plade_amd.Context(0, orient_normals=1, dump=1)
+    res = c.registration_pairs([(scenes[0][0], scenes[0][1]), (scenes[2][0], scenes[2][1])])
+    for pos, i in enumerate((0, 2)):
+        assert res[pos][0] and np.array_equal(res[pos][1], alone[i][1])
+    ok, T = c.registration(scenes[1][0], scenes[1][1])
+    assert ok and np.array_equal(T, alone[1][1])
+    c.close()
