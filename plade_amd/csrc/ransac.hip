@@ -212,12 +212,33 @@ struct RCloudArgs {
     const uint32_t *list_values;     // seam S1c: the score list is given (list position -> point), else nullptr
     ChainLayout L;
 };
-struct RArgs {
-    RCloudArgs c[R_G];
+// What the kernels take by value: the per-cloud table lives in device memory (16 clouds x 360 bytes do not fit the 4 KB of
+// kernel arguments; the kernels index it exactly as they indexed the array), the rest is small.
+struct RKArgs {
+    const RCloudArgs *c;             // R_G entries
     uint32_t ng, topup;              // clouds in this sequence; topup (host side): the sequence has no separate pass over the
                                      // old pool (see RState::topup)
     uint32_t tile_start[R_G + 1];    // scan grids are the concatenated tiles of the clouds: first workgroup of every cloud
     uint32_t pad_;
+};
+// The kernels read the table through the CONSTANT address space: its loads are then known to be invariant and, the index being
+// uniform, become scalar loads wherever they stand in the kernel -- as the loads of by-value kernel arguments were.  (Through a
+// plain global pointer every field read after the kernel's first store was a per-lane vector load: -2.5 % on the whole step.)
+typedef const RCloudArgs __attribute__((address_space(4))) RCloudArgsK;
+__device__ __forceinline__ RCloudArgsK &cloud_args(const RKArgs &A, uint32_t g) { return *(RCloudArgsK *)(A.c + g); }
+// The host's form: the table as the host fills it.  args_commit() uploads it and sets `dev`; a launch converts to RKArgs.
+struct RArgs {
+    RCloudArgs c[R_G];
+    uint32_t ng, topup;
+    uint32_t tile_start[R_G + 1];
+    uint32_t pad_;
+    const RCloudArgs *dev;           // the committed device copy of c (nullptr: not committed)
+    operator RKArgs() const {
+        RKArgs k;
+        k.c = dev; k.ng = ng; k.topup = topup; k.pad_ = 0;
+        for (int g = 0; g <= R_G; ++g) k.tile_start[g] = tile_start[g];
+        return k;
+    }
 };
 
 // profiled runs: the launch's own (first wavefront in, last wavefront out) times on the device's wall clock.  A launch owns
@@ -235,12 +256,13 @@ struct ChainPtr {
     ChainHdr *hdr;
     uint8_t *masks1; uint32_t *bc1; double *part; ChainAgg *agg;
     uint8_t *bmp, *tmp; uint32_t *label, *sizes;
-    char *base; const ChainLayout *L;
+    char *base; const ChainLayout __attribute__((address_space(4))) *L;   // inside the constant-space argument table
     __device__ __forceinline__ uint32_t *idxA(int k) const { return reinterpret_cast<uint32_t *>(base + L->idxA + k * L->idxA_stride); }
     __device__ __forceinline__ uint8_t *masks2(int k) const { return reinterpret_cast<uint8_t *>(base + L->masks2 + k * L->masks2_stride); }
     __device__ __forceinline__ uint32_t *bc2(int k) const { return reinterpret_cast<uint32_t *>(base + L->bc2 + k * L->bc2_stride); }
 };
-__device__ __forceinline__ ChainPtr chain_of(const RCloudArgs &C, uint32_t b) {
+template <class CA>
+__device__ __forceinline__ ChainPtr chain_of(const CA &C, uint32_t b) {
     ChainPtr p;
     char *base = C.var + (size_t)b * C.L.bytes, *fx = C.fixed + (size_t)b * F_BYTES;
     p.base = base; p.L = &C.L;
@@ -401,7 +423,8 @@ __device__ __forceinline__ uint32_t lb_u32(const uint32_t *a, uint32_t n, uint32
 
 // what a full pass reads: the cloud itself or its current compacted view (RState::view_sel)
 struct ScanSrc { const float *x, *y, *z, *nx, *ny, *nz; const uint32_t *map; uint32_t n; };
-__device__ __forceinline__ ScanSrc scan_src(const RCloudArgs &C, const RState *S) {
+template <class CA>
+__device__ __forceinline__ ScanSrc scan_src(const CA &C, const RState *S) {
     ScanSrc v;
     const uint32_t sel = C.view[0] ? S->view_sel : 0u;
     if (sel == 0u) { v.x = C.cv.x; v.y = C.cv.y; v.z = C.cv.z; v.nx = C.cv.nx; v.ny = C.cv.ny; v.nz = C.cv.nz; v.map = nullptr; v.n = C.cv.n; }
@@ -415,7 +438,7 @@ __device__ __forceinline__ ScanSrc scan_src(const RCloudArgs &C, const RState *S
 }
 
 // which cloud a workgroup of a "concatenated tiles" grid scans
-__device__ __forceinline__ int scan_group(const RArgs &A, uint32_t &tile) {
+__device__ __forceinline__ int scan_group(const RKArgs &A, uint32_t &tile) {
     int g = 0;
 #pragma unroll
     for (int q = 1; q < R_G; ++q) g += (q < (int)A.ng && blockIdx.x >= A.tile_start[q]) ? 1 : 0;
@@ -471,10 +494,10 @@ struct RInitCloud {
 };
 struct RInit { RInitCloud c[R_G]; };
 
-__global__ __launch_bounds__(TPB) void k_r_init(const RArgs A, const RInit I) {
+__global__ __launch_bounds__(TPB) void k_r_init(const RKArgs A, const RInit I) {
     uint32_t tile;
     const int g = scan_group(A, tile);
-    const RCloudArgs &C = A.c[g];
+    const RCloudArgsK &C = cloud_args(A, g);
     const RInitCloud &P = I.c[g];
     if (!P.active) {
         if (tile == 0 && threadIdx.x == 0) { C.st->active = 0; C.st->done = 1; C.st->nc = 0; C.st->aj_n = 0; C.st->npool = 0; C.st->sampling = 0; C.st->fresh = 0; }
@@ -506,13 +529,13 @@ __global__ __launch_bounds__(TPB) void k_r_init(const RArgs A, const RInit I) {
 
 // ------------------------------------------------------------------------------------------------
 // hypothesis sampling: one lane per hypothesis
-__global__ __launch_bounds__(256) void k_r_sample(const RArgs A) {
-    const RCloudArgs &C = A.c[blockIdx.y];
+__global__ __launch_bounds__(256) void k_r_sample(const RKArgs A) {
+    const RCloudArgsK &C = cloud_args(A, blockIdx.y);
     RState *S = C.st;
     if (S->done || !S->sampling) return;
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= R_H) return;
-    const CloudView &c = C.cv;
+    const auto &c = C.cv;
     const uint8_t *__restrict__ taken = C.taken;
     const uint32_t *__restrict__ codes = C.codes;
     const float eps = S->eps, cos_t = S->cos_t;
@@ -647,10 +670,10 @@ __device__ __forceinline__ unsigned long long slab_mask(const Tile &t, const flo
 }
 
 // K1 on the stratified subset: grid (subset tiles, hypothesis chunks, clouds)
-__global__ __launch_bounds__(TPB) void k_r_score_sub(const RArgs A) {
+__global__ __launch_bounds__(TPB) void k_r_score_sub(const RKArgs A) {
     __shared__ float4 s_pl[HCHUNK];
     __shared__ uint32_t s_cnt[TPB / 64][HCHUNK];
-    const RCloudArgs &C = A.c[blockIdx.z];
+    const RCloudArgsK &C = cloud_args(A, blockIdx.z);
     RState *S = C.st;
     if (S->done || !S->sampling) return;
     if (blockIdx.x * TILE >= C.n_sub) return;
@@ -704,8 +727,8 @@ __device__ __forceinline__ bool same_plane(const float4 &a, const float4 &b, flo
 // out its duplicates).  One workgroup of 1024 lanes per cloud, four hypotheses per lane; a pick costs one wave-level
 // arg-max of 32-bit keys (count << 12 | 4095 - index: the subset holds fewer than 2^20 points), ONE barrier (the wave
 // winners and their planes go through double-buffered LDS) and four duplicate tests per lane.
-__global__ __launch_bounds__(1024) void k_r_leaders(const RArgs A) {
-    const RCloudArgs &C = A.c[blockIdx.x];
+__global__ __launch_bounds__(1024) void k_r_leaders(const RKArgs A) {
+    const RCloudArgsK &C = cloud_args(A, blockIdx.x);
     RState *S = C.st;
     if (S->done || !S->sampling) return;
     __shared__ uint32_t s_key[2][16];
@@ -783,13 +806,13 @@ __global__ __launch_bounds__(1024) void k_r_leaders(const RArgs A) {
 
 // K1: the pool re-scored on ALL unassigned points of its cloud: one HBM pass per cloud, the pool's planes in LDS
 // phase 0: what the previous iteration left in the pool; phase 1: the leaders of a round drawn in this iteration
-__global__ __launch_bounds__(TPB) void k_r_rescore(const RArgs A, int phase, unsigned long long *clk) {
+__global__ __launch_bounds__(TPB) void k_r_rescore(const RKArgs A, int phase, unsigned long long *clk) {
     const ClockScope clock_scope(clk);
     __shared__ float4 s_pl[HCHUNK];
     __shared__ uint32_t s_cnt[TPB / 64][HCHUNK];
     uint32_t tile;
     const int g = scan_group(A, tile);
-    const RCloudArgs &C = A.c[g];
+    const RCloudArgsK &C = cloud_args(A, g);
     RState *S = C.st;
     const uint32_t np = S->npool;
     if (S->done || np == 0 || (S->fresh != 0u) != (phase != 0)) return;
@@ -871,8 +894,8 @@ __device__ bool conflict_free(const float4 &a, const float4 &b, float eps, float
 // the rest is ordered by support, and the best candidate plus every further one whose support provably cannot touch
 // the support of any better candidate become this iteration's acceptance chains (accepting them concurrently equals
 // accepting them one by one, best first).  One wavefront per cloud.
-__global__ __launch_bounds__(64) void k_r_select(const RArgs A, int phase) {
-    const RCloudArgs &C = A.c[blockIdx.x];
+__global__ __launch_bounds__(64) void k_r_select(const RKArgs A, int phase) {
+    const RCloudArgsK &C = cloud_args(A, blockIdx.x);
     RState *S = C.st;
     const int lane = threadIdx.x;
     if (phase == 0) {
@@ -946,7 +969,7 @@ __global__ __launch_bounds__(64) void k_r_select(const RArgs A, int phase) {
 // (1) mark: ONE pass over the cloud for all chains of the cloud: 4-bit inlier masks per lane, per-tile counts, and the
 //     aggregates of every chain's list (ChainAgg: length, bounding box of the inliers' (u, v) plane parameters,
 //     BitmapPrimitiveShape.h:113-126, entries per supertile)
-__global__ __launch_bounds__(TPB) void k_r_mark(const RArgs A, int k, unsigned long long *clk) {
+__global__ __launch_bounds__(TPB) void k_r_mark(const RKArgs A, int k, unsigned long long *clk) {
     const ClockScope clock_scope(clk);
     __shared__ float4 s_pl[R_B];
     __shared__ float s_fr[R_B][9];
@@ -955,7 +978,7 @@ __global__ __launch_bounds__(TPB) void k_r_mark(const RArgs A, int k, unsigned l
     __shared__ float s_bb[R_B][4][TPB / 64];
     uint32_t tile;
     const int g = scan_group(A, tile);
-    const RCloudArgs &C = A.c[g];
+    const RCloudArgsK &C = cloud_args(A, g);
     RState *S = C.st;
     const uint32_t nc = S->nc;
     if (nc == 0) return;
@@ -1039,9 +1062,9 @@ __global__ __launch_bounds__(TPB) void k_r_mark(const RArgs A, int k, unsigned l
 
 // seam S1c: the score list is given by the caller.  Same outputs as k_r_mark for chain 0 over LIST POSITIONS
 // (all positions < m are "inliers"); tiles past the list get a zero count.
-__global__ __launch_bounds__(TPB) void k_r_list_mark(const RArgs A, uint32_t m) {
+__global__ __launch_bounds__(TPB) void k_r_list_mark(const RKArgs A, uint32_t m) {
     __shared__ float s_bb[4][TPB / 64];
-    const RCloudArgs &C = A.c[0];
+    const RCloudArgsK &C = cloud_args(A, 0);
     const ChainPtr ch = chain_of(C, 0);
     const PlaneState *st = &ch.hdr->st[0];
     const uint32_t tile = blockIdx.x, first = tile * TILE + threadIdx.x * PPT;
@@ -1102,13 +1125,13 @@ __device__ __forceinline__ bool cc_dims(const float bb[4], uint32_t count, float
 constexpr int OWN_MAX = 8;
 static_assert(OWN_MAX * 32 == TPB, "32 lanes per owned tile");
 
-__global__ __launch_bounds__(TPB) void k_r_compact_raster(const RArgs A, int k) {
+__global__ __launch_bounds__(TPB) void k_r_compact_raster(const RKArgs A, int k) {
     __shared__ uint32_t s_w[TPB / 64];
     __shared__ uint32_t s_pre[OWN_MAX], s_cnt[OWN_MAX];
     const int g = blockIdx.y / R_B;
     const uint32_t b = blockIdx.y % R_B;
     if (g >= (int)A.ng) return;
-    const RCloudArgs &C = A.c[g];
+    const RCloudArgsK &C = cloud_args(A, g);
     const uint32_t nb = C.L.nb;
     RState *S = C.st;
     const ChainPtr ch = chain_of(C, b);
@@ -1303,11 +1326,11 @@ __device__ __forceinline__ void cc_label_body(uint8_t *bmp, uint8_t *tmp, uint32
     }
 }
 
-__global__ __launch_bounds__(1024) void k_r_label(const RArgs A, int k, int do_filter) {
+__global__ __launch_bounds__(1024) void k_r_label(const RKArgs A, int k, int do_filter) {
     const int g = blockIdx.x / R_B;
     const uint32_t b = blockIdx.x % R_B;
     if (g >= (int)A.ng) return;
-    const RCloudArgs &C = A.c[g];
+    const RCloudArgsK &C = cloud_args(A, g);
     if (b >= C.st->nc) return;
     const ChainPtr ch = chain_of(C, b);
     PlaneState *st = &ch.hdr->st[k];
@@ -1377,13 +1400,13 @@ __device__ __forceinline__ double wave_reduce_cols(const double (&a)[FIT_COLS], 
 // positions + per-tile counts).  The same pass accumulates, over the kept points, the LS-fit moments (12 sums),
 // Candidate::WeightedScore (ransac/Candidate.cpp:77-87 with weigh(), ScoreComputer.h:10-16) of the slot's plane and the
 // kept count: one row of FIT_COLS doubles per 1024 list positions, reduced by k_r_fit in a fixed order.
-__global__ __launch_bounds__(TPB) void k_r_select_cc(const RArgs A, int k) {
+__global__ __launch_bounds__(TPB) void k_r_select_cc(const RKArgs A, int k) {
     __shared__ uint32_t s_w[4];
     __shared__ double s[4][FIT_COLS];
     const int g = blockIdx.y / R_B;
     const uint32_t b = blockIdx.y % R_B;
     if (g >= (int)A.ng) return;
-    const RCloudArgs &C = A.c[g];
+    const RCloudArgsK &C = cloud_args(A, g);
     const ChainPtr ch = chain_of(C, b);
     const PlaneState *st = &ch.hdr->st[k];
     // everything the decision to leave needs is fetched together (the addresses come from the kernel arguments): one round trip
@@ -1488,12 +1511,12 @@ __device__ void jacobi3_d(double a[3][3], double d[3], double v[3][3]) {
 // kept count of slot k; for k < 3 additionally the LS plane of the kept points = the NEXT slot's plane.  When that
 // plane is bitwise equal to slot k's the chain has converged: every later slot would reproduce slot k's results, so
 // they are flagged, copy them and their kernels return immediately.  One workgroup of 256 lanes per chain.
-__global__ __launch_bounds__(256) void k_r_fit(const RArgs A, int k) {
+__global__ __launch_bounds__(256) void k_r_fit(const RKArgs A, int k) {
     __shared__ double s_red[4][FIT_COLS];
     const int g = blockIdx.x / R_B;
     const uint32_t b = blockIdx.x % R_B;
     if (g >= (int)A.ng) return;
-    const RCloudArgs &C = A.c[g];
+    const RCloudArgsK &C = cloud_args(A, g);
     if (b >= C.st->nc) return;
     const ChainPtr ch = chain_of(C, b);
     PlaneState *cur = &ch.hdr->st[k];
@@ -1565,8 +1588,8 @@ __global__ __launch_bounds__(256) void k_r_fit(const RArgs A, int k) {
 // bookkeeping (RansacShapeDetector.cpp:666-675), output planes (plane_extraction.cpp:134-149), the pool without
 // the batch, and what the next iteration does.  One lane per cloud does the sequential part.
 constexpr int DEC_T = 256;   // lanes of k_r_decide: the staging loads and the deferral tests use all of them, the rest wave 0
-__global__ __launch_bounds__(DEC_T) void k_r_decide(const RArgs A) {
-    const RCloudArgs &C = A.c[blockIdx.x];
+__global__ __launch_bounds__(DEC_T) void k_r_decide(const RKArgs A) {
+    const RCloudArgsK &C = cloud_args(A, blockIdx.x);
     RState *S = C.st;
     RResult *R = C.res;
     if (!S->active) return;
@@ -1753,12 +1776,12 @@ __global__ __launch_bounds__(DEC_T) void k_r_decide(const RArgs A) {
 // Point removal + output index lists of the accepted candidates: the chosen slot's list entries that belong to the
 // largest component, in list order (ordered compaction of the selection masks; offsets from the per-row counts as in
 // k_r_compact_raster).  grid (loop_grid(), jobs of all clouds)
-__global__ __launch_bounds__(TPB) void k_r_assign(const RArgs A) {
+__global__ __launch_bounds__(TPB) void k_r_assign(const RKArgs A) {
     __shared__ uint32_t s_pre[OWN_MAX][TPB / 64], s_w[TPB / 64];
     const int g = blockIdx.y / R_B;
     const uint32_t j = blockIdx.y % R_B;
     if (g >= (int)A.ng) return;
-    const RCloudArgs &C = A.c[g];
+    const RCloudArgsK &C = cloud_args(A, g);
     const RState *S = C.st;
     if (j >= S->aj_n) return;
     const int k = (int)S->aj_slot[j];
@@ -1838,11 +1861,11 @@ __global__ __launch_bounds__(TPB) void k_r_assign(const RArgs A) {
 // lists and counts of every pass are unchanged, bit for bit.  Three launches: count the survivors per view tile (+ supertile
 // sums by atomics), compact (a tile's offset from the supertile sums + the counts of its own supertile, as the chains'
 // compaction does), commit (flip the view, clear the sums).  Nothing to do (view_dirty = 0): the workgroups return at once.
-__global__ __launch_bounds__(TPB) void k_view_count(const RArgs A) {
+__global__ __launch_bounds__(TPB) void k_view_count(const RKArgs A) {
     __shared__ uint32_t s_w[TPB / 64];
     uint32_t tile;
     const int g = scan_group(A, tile);
-    const RCloudArgs &C = A.c[g];
+    const RCloudArgsK &C = cloud_args(A, g);
     RState *S = C.st;
     if (!C.view[0] || !S->view_dirty || S->done) return;
     const ScanSrc V = scan_src(C, S);
@@ -1865,11 +1888,11 @@ __global__ __launch_bounds__(TPB) void k_view_count(const RArgs A) {
     }
 }
 
-__global__ __launch_bounds__(TPB) void k_view_compact(const RArgs A) {
+__global__ __launch_bounds__(TPB) void k_view_compact(const RKArgs A) {
     __shared__ uint32_t s_w[TPB / 64], s_pre;
     uint32_t tile;
     const int g = scan_group(A, tile);
-    const RCloudArgs &C = A.c[g];
+    const RCloudArgsK &C = cloud_args(A, g);
     const RState *S = C.st;
     if (!C.view[0] || !S->view_dirty || S->done) return;
     const ScanSrc V = scan_src(C, S);
@@ -1921,8 +1944,8 @@ __global__ __launch_bounds__(TPB) void k_view_compact(const RArgs A) {
         }
 }
 
-__global__ __launch_bounds__(256) void k_view_commit(const RArgs A) {
-    const RCloudArgs &C = A.c[blockIdx.x];
+__global__ __launch_bounds__(256) void k_view_commit(const RKArgs A) {
+    const RCloudArgsK &C = cloud_args(A, blockIdx.x);
     RState *S = C.st;
     if (!C.view[0] || !S->view_dirty || S->done) { if (C.view[0] && threadIdx.x == 0 && S->view_dirty) S->view_dirty = 0; return; }
     const uint32_t ntiles = (S->view_n + TILE - 1) / TILE;
@@ -1937,10 +1960,10 @@ __global__ __launch_bounds__(256) void k_view_commit(const RArgs A) {
 }
 
 // seam S1c: one chain, slot 0, from a caller-given plane
-__global__ void k_r_seam_init(const RArgs A, float4 hyp, float4 pos, float w_eps, float bitmap_eps) {
-    agg_clear(chain_of(A.c[0], 0).agg, A.c[0].L.nb, threadIdx.x, blockDim.x);
+__global__ void k_r_seam_init(const RKArgs A, float4 hyp, float4 pos, float w_eps, float bitmap_eps) {
+    agg_clear(chain_of(cloud_args(A, 0), 0).agg, cloud_args(A, 0).L.nb, threadIdx.x, blockDim.x);
     if (threadIdx.x) return;
-    const RCloudArgs &C = A.c[0];
+    const RCloudArgsK &C = cloud_args(A, 0);
     RState *S = C.st;
     S->n = C.cv.n; S->active = 1; S->done = 0; S->sampling = 0; S->nc = 1; S->npool = 0;
     S->eps3 = w_eps; S->bitmap_eps = bitmap_eps; S->min_support = 0; S->orient = 0; S->err = 0;
@@ -2085,8 +2108,8 @@ __global__ __launch_bounds__(256) void k_sp_knn(const SpBatch B) {
 // ---- seam S1a (plade_score_planes / plade_score_planes_subset): the caller's hypotheses through the loop's OWN K1
 // kernels -- counts by k_r_rescore (the pool re-score), ordered lists by k_r_mark + k_r_compact_raster (slot 0 of the
 // acceptance chains), subset counts by k_r_score_sub.  These kernels only put the hypotheses where the loop keeps them.
-__global__ void k_r_seam_pool(const RArgs A, const float4 *__restrict__ planes, uint32_t nh, float eps, float cos_t) {
-    const RCloudArgs &C = A.c[0];
+__global__ void k_r_seam_pool(const RKArgs A, const float4 *__restrict__ planes, uint32_t nh, float eps, float cos_t) {
+    const RCloudArgsK &C = cloud_args(A, 0);
     RState *S = C.st;
     if (threadIdx.x == 0) {
         S->n = C.cv.n; S->active = 1; S->done = 0; S->sampling = 0; S->fresh = 1; S->npool = nh; S->nc = 0; S->aj_n = 0;
@@ -2098,8 +2121,8 @@ __global__ void k_r_seam_pool(const RArgs A, const float4 *__restrict__ planes, 
     }
 }
 
-__global__ void k_r_seam_chains(const RArgs A, const float4 *__restrict__ planes, uint32_t nb, float eps, float cos_t) {
-    const RCloudArgs &C = A.c[0];
+__global__ void k_r_seam_chains(const RKArgs A, const float4 *__restrict__ planes, uint32_t nb, float eps, float cos_t) {
+    const RCloudArgsK &C = cloud_args(A, 0);
     RState *S = C.st;
     if (threadIdx.x == 0) {
         S->n = C.cv.n; S->active = 1; S->done = 0; S->sampling = 0; S->fresh = 0; S->npool = 0; S->nc = nb; S->aj_n = 0;
@@ -2122,8 +2145,8 @@ __global__ void k_r_seam_chains(const RArgs A, const float4 *__restrict__ planes
     }
 }
 
-__global__ void k_r_seam_hyps(const RArgs A, const float4 *__restrict__ planes, uint32_t nh, float eps, float cos_t) {
-    const RCloudArgs &C = A.c[0];
+__global__ void k_r_seam_hyps(const RKArgs A, const float4 *__restrict__ planes, uint32_t nh, float eps, float cos_t) {
+    const RCloudArgsK &C = cloud_args(A, 0);
     RState *S = C.st;
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t == 0) {
@@ -2182,6 +2205,8 @@ struct RansacWork {
     int ng = 0;
     uint32_t generation = 0;         // detect calls issued on this work area
     DBuf<uint32_t> keys_in, vals_in, keys, perm;
+    DBuf<RCloudArgs> args_dev;       // the per-cloud argument table the kernels read (args_commit)
+    uint64_t args_hash = 0;          // of the table uploaded last
     std::map<uint64_t, hipGraphExec_t> graphs;   // the iteration sequence, keyed on everything baked into its launches
     std::map<uint64_t, std::vector<std::string>> graph_tags;   // of the graphs captured with clock stamps (plade_ctx::graph_clocks)
     ~RansacWork() { for (auto &kv : graphs) if (kv.second) (void)hipGraphExecDestroy(kv.second); }
@@ -2253,6 +2278,19 @@ uint64_t hash_bytes(const void *p, size_t n) {
     const unsigned char *b = static_cast<const unsigned char *>(p);
     for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; }
     return h;
+}
+
+// The table of per-cloud arguments goes to the device (once per change: every launch that reads it is queued on ctx->stream behind
+// the upload, and a call with the same buffers as the last one -- the steady state of a batch -- uploads nothing).
+void args_commit(plade_ctx *ctx, RansacWork &W, RArgs &A) {
+    W.args_dev.ensure(R_G);
+    A.dev = W.args_dev.p;
+    const uint64_t h = hash_bytes(A.c, sizeof(A.c)) | 1ull;
+    if (h != W.args_hash) {
+        const bool staged = ctx->h2d(W.args_dev.p, A.c, sizeof(A.c));
+        if (!staged) ctx->sync();
+        W.args_hash = h;
+    }
 }
 
 inline uint32_t loop_grid(uint32_t nb) { return std::min(1024u, std::max(32u, cdiv(nb, OWN_MAX))); }
@@ -2441,6 +2479,7 @@ void ransac_detect_prepared(plade_ctx *ctx, RansacWork &W, RansacJob jobs[RANSAC
     PLADE_REQUIRE(ng >= 1, PLADE_EINVAL, "ransac: not prepared");
     Clock::time_point t0 = Clock::now();
     RArgs A = make_args(W, ng, ctx->params.ransac_topup != 0);
+    args_commit(ctx, W, A);
     RInit I;
     memset(&I, 0, sizeof(I));
     RResult *res[R_G];
@@ -2621,6 +2660,7 @@ void plane_component(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const
         C.st = s.state.p; C.res = s.res_dev; C.out_idx = s.out_idx.p; C.out_pos = nullptr; C.fixed = s.fixed.p; C.var = s.var.p; C.list_values = s.seam_list.p; C.L = s.L;
     }
     for (int g = 0; g < R_G; ++g) A.tile_start[g + 1] = A.tile_start[g] + (g == 0 ? s.L.nb : 0u);
+    args_commit(ctx, W, A);
     // Plane(point, normal): dist = point . normal with Vec3f::dot's left-to-right sum (Plane.cpp:21-26)
     float dist = point[0] * normal[0];
     dist += point[1] * normal[1];
@@ -2756,6 +2796,7 @@ RArgs seam_args(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const int3
         C.hyp_counts = reinterpret_cast<uint32_t *>(C.hyp_pos + R_H);
     }
     for (int g = 0; g < R_G; ++g) A.tile_start[g + 1] = A.tile_start[g] + (g == 0 ? s.L.nb : 0u);
+    args_commit(ctx, W, A);
     return A;
 }
 }  // namespace
@@ -2821,6 +2862,7 @@ void score_subset_seam(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, con
     s.sub_index.ensure((size_t)s.sub_pitch + 4);
     HIP_TRY(hipMemcpyAsync(s.sub_index.p, sub_index, 4 * (size_t)m, hipMemcpyHostToDevice, st));
     for (int g = 0; g < R_G; ++g) { A.c[g].sub = s.sub.p; A.c[g].sub_index = s.sub_index.p; A.c[g].sub_pitch = s.sub_pitch; A.c[g].n_sub = m; }
+    args_commit(ctx, W, A);
     hipLaunchKernelGGL(k_r_seam_subset, dim3(cdiv(m, 256)), dim3(256), 0, st, A.c[0].cv, s.sub_index.p, m, s.sub.p, s.sub_pitch);
     DBuf<float4> d_planes;
     d_planes.ensure(h);
