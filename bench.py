@@ -9,13 +9,13 @@ registration) of one synthetic pair of config `Synthetic 1M-pt indoor scan pair,
 (BASELINE.json configs[2]) with both clouds in page-locked HOST memory: the upload (H2D), the SoA conversion and
 the bounding boxes of every step are inside the timed region.  One process per GPU; scan pairs
 are independent (batch mode, code/PLADE/main.cpp:97-158), so every rank registers its own pairs with no
-data-path collective and the per-pair 4x4 results are gathered to rank 0 over RCCL at the end
+data-path collective and the per-pair 4x4 results are gathered to rank 0 over the ranks' loopback rendezvous at the end
 (weak scaling: work per GPU is fixed).  Several GROUPS of pairs are in flight per GPU (one plade_ctx + host thread per
 group, --group consecutive pairs of the batch per plade_registration_pairs call: the plane extraction of a group's clouds
 is one launch sequence); `value` = timed steps / the window between the completion of the last lead-in group and the
 completion of the last timed group, i.e. exactly `steps` registrations complete inside the window with the pipeline full
 on both sides.  A pipeline of M x S registrations in flight is not sampled fairly by a handful of steps (the driver's 20
-are little more than one round of 16), so max(K, 32 x registrations in flight) steps are timed, in whole groups: `steps`
+are less than one round of 32), so max(K, 32 x registrations in flight) steps are timed, in whole groups: `steps`
 on the line is the number really timed, `requested_steps` echoes K; the occupancy estimator of round 3 is reported
 beside it (`pipeline.occupancy_value`).
 Rank 0 prints ONE JSON line.  `resident_rank0` is the same pipeline on clouds already resident in HBM.
@@ -49,7 +49,7 @@ KERNEL_SYMBOLS = {"score_mark": "k_r_mark(", "score_multi": "k_r_rescore(", "ove
                   "pen_walk": "k_pen_walk(", "cluster_edges": "k_cluster_edges("}
 
 
-def pmc_traffic(tag, group=4):
+def pmc_traffic(tag, group=8):
     """HBM bytes per REGISTRATION of the roofline kernel (all its launches) from the committed PMC summary (separate
     `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this same command, FETCH_SIZE doubled as
     MI355X_MICROARCH.md prescribes for gfx950; tools/summarize_profiles.py).  None if no summary exists."""
@@ -71,7 +71,7 @@ def pmc_traffic(tag, group=4):
     return None, None
 
 
-def rocprof_stats(tag, group=4):
+def rocprof_stats(tag, group=8):
     """(average launch duration in us, share of the GPU time, file) of the roofline kernel in the committed
     `rocprofv3 --kernel-trace --stats` summary of this command (profiles/*_kernel_stats.csv), plus the three kernels with
     the most GPU time there: the live HIP-event figure on the line must agree with this average."""
@@ -235,7 +235,7 @@ def cpu_baseline_batch(pairs, n_pairs_batch=64):
                       "first start)"}
 
 
-def cli_end_to_end(pairs, n_pairs=64, inflight=4, group=4):
+def cli_end_to_end(pairs, n_pairs=64, inflight=None, group=None):
     """the CLI end to end (code/PLADE/main.cpp:97-158 batch mode), PLY parse and process start-up included: a
     file_pairs.txt of n_pairs lines pairs over the bench pairs' PLY files (binary little endian, float x y z nx ny nz),
     `PLADE file_pairs.txt result.txt` as a user would run it."""
@@ -256,7 +256,11 @@ def cli_end_to_end(pairs, n_pairs=64, inflight=4, group=4):
         with open(lst, "w") as f:
             for i in range(n_pairs):
                 f.write(f"{names[i % len(names)][0]}\n{names[i % len(names)][1]}\n")
-        env = dict(os.environ, PLADE_ORIENT_NORMALS="1", PLADE_INFLIGHT=str(inflight), PLADE_GROUP=str(group), PLADE_GPUS="1")
+        env = dict(os.environ, PLADE_ORIENT_NORMALS="1", PLADE_GPUS="1")   # workers and group size: the CLI's own defaults
+        if inflight:
+            env["PLADE_INFLIGHT"] = str(inflight)
+        if group:
+            env["PLADE_GROUP"] = str(group)
         runs = []
         for _ in range(2):
             t0 = time.perf_counter()
@@ -274,7 +278,7 @@ def cli_end_to_end(pairs, n_pairs=64, inflight=4, group=4):
         shutil.rmtree(d, ignore_errors=True)
     best = min(runs)
     return {"value": n_pairs / best, "unit": "registrations/s", "pairs": n_pairs, "registered": blocks, "seconds": best,
-            "seconds_all_runs": runs, "single_pair_process_seconds": single, "workers": inflight, "pairs_per_group": group,
+            "seconds_all_runs": runs, "single_pair_process_seconds": single, "workers": inflight or "CLI default (2 below 512 pairs, else 4)", "pairs_per_group": group or "CLI default (4 below 512 pairs, else 8)",
             "note": "wall time of the whole `PLADE file_pairs.txt result.txt` process: HIP start-up (~0.3 s), PLY parse of 2 x 24 MB "
                     "per pair (files in the page cache), registration, ordered result file"}
 
@@ -291,13 +295,13 @@ def _cpu_budget():
     return n
 
 
-# busy host threads per rank, measured on the MI355X box in round 4 (tools/exp_groups.py, sleeping host waits, groups of 4 pairs,
+# busy host threads per rank, measured on the MI355X box in round 4 (tools/exp_groups.py, sleeping host waits, groups of 8 pairs,
 # host clouds): groups in flight -> busy threads (registrations/s): see profiles/r4_experiments.md
-BUSY_THREADS_BY_GROUPS = {2: 1.79, 3: 2.02, 4: 2.21, 6: 2.4, 8: 2.5}   # 557 / 610 / 635 / 621 / 635 registrations/s
+BUSY_THREADS_BY_GROUPS = {2: 2.02, 3: 2.19, 4: 2.34}   # 663 / 725 / 749 registrations/s
 
 
 def inflight_for_budget(budget, local_world):
-    """Groups (of 4 pairs) in flight per GPU.  A container that runs into its CPU quota loses far more than the last few
+    """Groups (of 8 pairs) in flight per GPU.  A container that runs into its CPU quota loses far more than the last few
     percent of GPU throughput (round 1: 287 instead of 400 reg/s under throttling), so the count is the largest one whose
     measured host load (BUSY_THREADS_BY_GROUPS), times the ranks of this node, still fits the quota with 10 % to spare."""
     per_rank = 0.9 * float(budget) / max(local_world, 1)
@@ -332,14 +336,14 @@ def main():
                     help="GROUPS in flight per GPU: one plade_ctx + host thread each, every call registers --group consecutive "
                          "pairs of the batch (a single registration is latency-bound and leaves most of the GPU idle).  0 = 4, or "
                          "fewer when the ranks of this node have to share a small CPU quota (see inflight_for_budget)")
-    ap.add_argument("--group", type=int, default=4,
-                    help="pairs per group (plade_registration_pairs, 1..4): the plane extraction of all clouds of a group is one "
+    ap.add_argument("--group", type=int, default=8,
+                    help="pairs per group (plade_registration_pairs, 1..8): the plane extraction of all clouds of a group is one "
                          "launch sequence; 1 = one pair per call (round 3's scheme)")
     ap.add_argument("--resident-steps", type=int, default=256,
                     help="steps of the extra resident leg (clouds uploaded once, plade_registration_dev per step); 0 = skip")
     ap.add_argument("--host-steps", type=int, default=0, help=argparse.SUPPRESS)   # round-2 flag, ignored
     ap.add_argument("--no-default-mode", action="store_true", help="skip the orient_normals=0 success-rate leg")
-    ap.add_argument("--profiled-steps", type=int, default=8, help="registrations of the roofline leg (HIP events per launch)")
+    ap.add_argument("--profiled-steps", type=int, default=16, help="registrations of the roofline leg (HIP events per launch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cli", action="store_true", help="skip the CLI end-to-end leg (64-pair file_pairs.txt through plade_amd/PLADE)")
     args = ap.parse_args()
@@ -393,7 +397,7 @@ def main():
     if inflight_auto:
         args.inflight = inflight_for_budget(_cpu_budget(), local_world)
     M = max(1, args.inflight)                  # groups in flight
-    S = max(1, min(4, args.group))             # pairs per group
+    S = max(1, min(8, args.group))             # pairs per group (PLADE_GROUP_MAX)
     RIF = M * S                                # registrations in flight
     if args.host_wait == "auto":
         # several registrations in flight: sleeping waits (same throughput, a third of the host CPUs, and no way to run
@@ -636,9 +640,10 @@ def main():
             if st.get(f"k_{name}_clock_seconds"):   # the kernel's own clock (see roofline.measured)
                 cs, cb = st[f"k_{name}_clock_seconds"], st[f"k_{name}_clock_bytes"]
                 stage[name].update({"clock_seconds": cs / args.profiled_steps, "clock_GB/s": cb / cs / 1e9})
-            # the roofline kernel is the one with the most GPU time among the HBM-streaming kernels (those
-            # with an algorithmic byte count); latency-bound kernels are listed for reference
-            if by > 0 and (best is None or secs > st[f"k_{best}_seconds"]):
+            # the roofline kernel is the largest mover of algorithmic HBM bytes of the step: the K1 scan of the
+            # plane extraction (0.76 GB per registration; the verification kernel, next, moves ~15 MB); latency-bound kernels
+            # are listed for reference
+            if by > 0 and (best is None or by > st[f"k_{best}_bytes"]):
                 best = name
         if best is not None:
             secs, nl, by = st[f"k_{best}_seconds"], st[f"k_{best}_launches"], st[f"k_{best}_bytes"]

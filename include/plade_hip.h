@@ -23,7 +23,7 @@ extern "C" {
 #define PLADE_EFAIL (-4)    /* registration failed (reference returns false) */
 #define PLADE_ELIMIT (-5)   /* internal limit exceeded */
 
-#define PLADE_GROUP_MAX 4   /* pairs per group of plade_registration_pairs */
+#define PLADE_GROUP_MAX 8   /* pairs per group of plade_registration_pairs */
 
 typedef struct plade_ctx plade_ctx;
 typedef struct plade_cloud plade_cloud; /* device-resident oriented point cloud */

@@ -187,11 +187,16 @@ int batch(const char *list_path, const char *result_path) {
         return EXIT_FAILURE;
     }
     read_jobs(list_path, jobs);
-    // PLADE_GPUS x PLADE_INFLIGHT workers, each taking PLADE_GROUP (1..4) consecutive pairs of the list per call (one GROUP:
+    // Defaults by the length of the list: a worker's context and work areas cost ~0.3 s to set up (more for larger groups) and
+    // the set-ups of one process run one after the other, so a short list is done sooner with two workers taking four pairs at
+    // a time (64 pairs: 1.0 s against 1.4 s with four workers and 2.5 s with four workers x eight pairs), while a long one is
+    // worth the full pipeline of the library's batch mode (bench.py: 4 groups of 8 pairs in flight per GPU).
+    // PLADE_GPUS x PLADE_INFLIGHT workers, each taking PLADE_GROUP (1..8) consecutive pairs of the list per call (one GROUP:
     // the plane extraction of its clouds is one launch sequence, plade.h registration_group).  PLADE_GPU_MAP ("0,0,1,1", a test
     // hook for boxes with fewer GPUs than PLADE_GPUS) maps worker-side device numbers to physical ones.
-    const int n_gpus = env_int("PLADE_GPUS", 1), per_gpu = env_int("PLADE_INFLIGHT", 4);
-    const size_t group = (size_t)std::min(env_int("PLADE_GROUP", 4), 4);
+    const bool long_list = jobs.size() >= 512;
+    const int n_gpus = env_int("PLADE_GPUS", 1), per_gpu = env_int("PLADE_INFLIGHT", long_list ? 4 : 2);
+    const size_t group = (size_t)std::min(env_int("PLADE_GROUP", long_list ? 8 : 4), (int)registration_group_max);
     std::vector<int> gpu_map(n_gpus);
     for (int g = 0; g < n_gpus; ++g) gpu_map[g] = g;
     if (const char *m = getenv("PLADE_GPU_MAP")) {
@@ -212,12 +217,12 @@ int batch(const char *list_path, const char *result_path) {
             if (i0 >= jobs.size()) break;
             const size_t k = std::min(group, jobs.size() - i0);
             if (k == 1) { writer.submit(i0, run_job(jobs[i0], true)); continue; }
-            Outcome res[4];
-            std::ostringstream outs[4], errs[4];
-            std::ostream *op[4], *ep[4];
-            std::string tg[4], sr[4];
-            Matrix4 T[4];
-            bool ok[4];
+            Outcome res[registration_group_max];
+            std::ostringstream outs[registration_group_max], errs[registration_group_max];
+            std::ostream *op[registration_group_max], *ep[registration_group_max];
+            std::string tg[registration_group_max], sr[registration_group_max];
+            Matrix4 T[registration_group_max];
+            bool ok[registration_group_max];
             for (size_t q = 0; q < k; ++q) { op[q] = &outs[q]; ep[q] = &errs[q]; tg[q] = jobs[i0 + q].target; sr[q] = jobs[i0 + q].source; }
             try {
                 registration_group(k, T, tg, sr, ok, op, ep);

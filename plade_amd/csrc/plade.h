@@ -50,10 +50,11 @@ bool registration(Eigen::Matrix<float, 4, 4> &transformation,
                   int ransac_min_support_source);
 
 /** Batch extension (no counterpart in the reference, whose batch mode is a plain loop of the file overload above,
- *  code/PLADE/main.cpp:122-148): `count` (1..4) consecutive pairs of the list as ONE group.  Every pair gets the result,
+ *  code/PLADE/main.cpp:122-148): `count` (1..registration_group_max = PLADE_GROUP_MAX) consecutive pairs of the list as ONE group.  Every pair gets the result,
  *  the messages and the identity-on-failure of the file overload -- its transformation is bit for bit the one the file overload
  *  returns -- but the plane extraction of all clouds of the group is one GPU launch sequence (plade_registration_pairs,
  *  include/plade_hip.h).  out[i] / err[i]: where pair i's console messages go (nullptr: std::cout / std::cerr). */
+constexpr size_t registration_group_max = 8;
 void registration_group(size_t count, Eigen::Matrix<float, 4, 4> *transformations, const std::string *target_cloud_files,
                         const std::string *source_cloud_files, bool *ok, std::ostream *const *out, std::ostream *const *err);
 

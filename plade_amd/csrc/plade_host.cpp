@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <iostream>
 #include <mutex>
+#include <thread>
 
 namespace {
 
@@ -253,10 +254,36 @@ bool registration(Eigen::Matrix<float, 4, 4> &transformation, const std::string 
 void registration_group(size_t count, Eigen::Matrix<float, 4, 4> *transformations, const std::string *target_cloud_files,
                         const std::string *source_cloud_files, bool *ok, std::ostream *const *out, std::ostream *const *err) {
     constexpr size_t GMAX = PLADE_GROUP_MAX;
+    static_assert(GMAX == registration_group_max, "plade.h states the group limit of include/plade_hip.h");
     if (count > GMAX) count = GMAX;
     thread_local std::vector<float> bufs[2 * GMAX];   // staging arrays of this worker thread, reused from group to group
     struct Item { size_t pair; const float *tg, *sr; size_t n_t, n_s; bool switched; };
     std::vector<Item> items;
+    // The files of the group are read side by side (a 1M-point binary PLY is ~10 ms of parsing and copying; sixteen of them one
+    // after the other would take longer than the group's registration); what the loads have to say is kept and printed below,
+    // pair by pair, where the sequential run prints it.
+    struct Loaded { bool tried = false, ok = false; std::string err; std::vector<std::string> warnings; };
+    Loaded loaded[2 * GMAX];
+    {
+        std::vector<float> *const b = bufs;
+        std::vector<std::thread> readers;
+        for (size_t i = 0; i < count; ++i) {
+            if (extension(target_cloud_files[i]) != "ply" || extension(source_cloud_files[i]) != "ply") continue;
+            for (int side = 0; side < 2; ++side) {
+                const std::string *file = side ? &source_cloud_files[i] : &target_cloud_files[i];
+                Loaded *l = &loaded[2 * i + side];
+                std::vector<float> *buf = &b[2 * i + side];
+                l->tried = true;
+                readers.emplace_back([file, l, buf]() { l->ok = plade::read_ply_pos_nrm(*file, *buf, l->err, &l->warnings) && !buf->empty(); });
+            }
+        }
+        for (auto &t : readers) t.join();
+    }
+    auto report = [&](const Loaded &l) {   // load_packed's messages
+        if (!l.ok && !l.err.empty()) con_err() << l.err << std::endl;
+        if (l.ok || l.err.empty()) for (auto &w : l.warnings) con_out() << w << std::endl;
+        return l.ok;
+    };
     for (size_t i = 0; i < count; ++i) {
         ok[i] = false;
         transformations[i].setIdentity();
@@ -267,8 +294,8 @@ void registration_group(size_t count, Eigen::Matrix<float, 4, 4> *transformation
             con_err() << "only PLY format is accepted" << std::endl;
             continue;
         }
-        if (!load_packed(target_cloud_files[i], bufs[2 * i])) { con_err() << "loading target point cloud failed" << std::endl; continue; }
-        if (!load_packed(source_cloud_files[i], bufs[2 * i + 1])) { con_err() << "loading source point cloud failed" << std::endl; continue; }
+        if (!report(loaded[2 * i])) { con_err() << "loading target point cloud failed" << std::endl; continue; }
+        if (!report(loaded[2 * i + 1])) { con_err() << "loading source point cloud failed" << std::endl; continue; }
         Item it{i, bufs[2 * i].data(), bufs[2 * i + 1].data(), bufs[2 * i].size() / 6, bufs[2 * i + 1].size() / 6, false};
         if (it.n_s >= it.n_t * 1.2f) {
             std::swap(it.tg, it.sr);

@@ -84,7 +84,7 @@ def test_cli_batch_mode_in_flight_keeps_input_order(ply_pairs, ctx):
 
 def test_cli_batch_in_groups_and_on_two_logical_gpus(ply_pairs, ctx):
     """Batch mode takes PLADE_GROUP consecutive pairs of the list per call (one group: registration_group, plade.h); every
-    block must be what the single-pair path writes, whatever the grouping -- groups of 1, 2, 3 (a ragged last group) and 4 --
+    block must be what the single-pair path writes, whatever the grouping -- groups of 1, 2, 3 (a ragged last group), 4 and the default 8 (here one group of all seven pairs) --
     and with PLADE_GPUS=2 worker sets, here both mapped onto the one GPU of the box (PLADE_GPU_MAP=0,0: the per-device
     branch of main.cpp runs with two device numbers)."""
     d, pairs = ply_pairs
@@ -98,7 +98,8 @@ def test_cli_batch_in_groups_and_on_two_logical_gpus(ply_pairs, ctx):
         want[i] = T
     texts = {}
     for tag, extra in (("g1", {"PLADE_GROUP": "1", "PLADE_INFLIGHT": "2"}), ("g2", {"PLADE_GROUP": "2", "PLADE_INFLIGHT": "2"}),
-                       ("g3", {"PLADE_GROUP": "3", "PLADE_INFLIGHT": "1"}), ("g4", {"PLADE_INFLIGHT": "2"}),
+                       ("g3", {"PLADE_GROUP": "3", "PLADE_INFLIGHT": "1"}), ("g4", {"PLADE_GROUP": "4", "PLADE_INFLIGHT": "2"}),
+                       ("g8", {"PLADE_INFLIGHT": "2"}),
                        ("two_gpus", {"PLADE_GPUS": "2", "PLADE_GPU_MAP": "0,0", "PLADE_INFLIGHT": "1", "PLADE_GROUP": "2"})):
         res = str(d / f"batch_{tag}.txt")
         r = subprocess.run([CLI, str(lst), res], capture_output=True, text=True, timeout=600, env=dict(ORIENTED_ENV, **extra))

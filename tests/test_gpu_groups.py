@@ -1,5 +1,5 @@
-"""Groups of two registrations per launch sequence (plade_registration_pairs / _dev, batch mode of
-code/PLADE/main.cpp:122-148 taken two pairs at a time): every pair of a group must come out bit for bit as the same
+"""Groups of up to eight registrations per launch sequence (plade_registration_pairs / _dev, batch mode of
+code/PLADE/main.cpp:122-148 taken several pairs at a time): every pair of a group must come out bit for bit as the same
 pair registered alone -- extracted planes, every dumped intermediate of the registration, the final transform -- whatever
 its partner is, in either position of the group, through host pointers (with and without the prefetch of the next group)
 and on resident clouds."""
@@ -62,9 +62,9 @@ def test_group_of_two_equals_the_pairs_alone(scenes, alone, a, b):
     c.close()
 
 
-@pytest.mark.parametrize("members", [(0, 1, 2), (2, 1, 0, 1), (1, 1, 1, 1)])
-def test_groups_of_three_and_four(scenes, alone, members):
-    """PLADE_GROUP_MAX = 4 pairs (eight clouds) per extraction sequence: same bits as the pairs alone, the planes included."""
+@pytest.mark.parametrize("members", [(0, 1, 2), (2, 1, 0, 1), (1, 1, 1, 1), (0, 1, 2, 1, 0), (2, 0, 1, 1, 2, 0, 1), (0, 1, 2, 2, 1, 0, 0, 1)])
+def test_groups_of_three_to_eight(scenes, alone, members):
+    """PLADE_GROUP_MAX = 8 pairs (sixteen clouds) per extraction sequence: same bits as the pairs alone, the planes included."""
     c = plade_amd.Context(0, orient_normals=1, dump=1)
     res = c.registration_pairs([(scenes[i][0], scenes[i][1]) for i in members])
     for pos, i in enumerate(members):
@@ -138,7 +138,7 @@ def test_bad_group_arguments_are_refused(scenes):
     c = plade_amd.Context(0, orient_normals=1)
     pr = (scenes[1][0], scenes[1][1])
     with pytest.raises(plade_amd.PladeError):
-        c.registration_pairs([pr, pr, pr, pr, pr])
+        c.registration_pairs([pr] * 9)
     with pytest.raises(plade_amd.PladeError):
         c.registration_pairs([])
     c.close()
