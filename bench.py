@@ -61,7 +61,9 @@ def pmc_traffic(tag, group=8):
     sym = KERNEL_SYMBOLS.get(tag, tag + "(")
     with open(files[-1]) as f:
         rows = list(csv.DictReader(f))
-    regs = group * next((int(r["launches"]) for r in rows if "k_morton(" in r["kernel"]), 0)   # one launch per GROUP of `group` registrations
+    # registrations in the profile = launches of the verification kernel (one per registration, whatever the size of its group:
+    # the profiled command also registers a few pairs alone)
+    regs = next((int(r["launches"]) for r in rows if "k_overlap(" in r["kernel"]), 0) or group * next((int(r["launches"]) for r in rows if "k_morton(" in r["kernel"]), 0)
     for r in rows:
         if sym in r["kernel"]:
             rd = float(r["hbm_read_bytes(FETCH_SIZE*1024*2)"])
@@ -91,7 +93,7 @@ def rocprof_stats(tag, group=8):
     out = {"file": os.path.relpath(files[-1], ROOT),
            "top_by_gpu_time": [{"kernel": short(r["Name"]), "share": round(float(r["TotalDurationNs"]) / total, 4),
                                 "avg_us": round(float(r["AverageNs"]) / 1e3, 2)} for r in top]}
-    regs = group * next((int(r["Calls"]) for r in rows if "k_morton(" in r["Name"]), 0)   # one launch per GROUP of `group` registrations
+    regs = next((int(r["Calls"]) for r in rows if "k_overlap(" in r["Name"]), 0) or group * next((int(r["Calls"]) for r in rows if "k_morton(" in r["Name"]), 0)
     out["registrations_profiled"] = regs
     out["kernels_per_registration"] = round(sum(int(r["Calls"]) for r in rows if "rocclr" not in r["Name"]) / max(regs, 1), 1)
     out["copies_and_fills_per_registration"] = round(sum(int(r["Calls"]) for r in rows if "rocclr" in r["Name"]) / max(regs, 1), 1)

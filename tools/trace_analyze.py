@@ -41,7 +41,7 @@ for t, d in ev:
     cur += d
 hist[cur] += hi - last
 total_busy = sum(e - s for s, e, *_ in win)
-regs = sum(1 for r in win if "k_morton" in r[4])
+regs = sum(1 for r in win if "k_overlap" in r[4])   # one launch of the verification kernel per registration
 per_q = collections.defaultdict(lambda: [0, 0])
 for s, e, q, st, n in win:
     per_q[q][0] += e - s
