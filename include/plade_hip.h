@@ -196,10 +196,10 @@ int plade_registration_next(plade_ctx *ctx, const float *tgt_pos_nrm, uint32_t n
                             const float *src_pos_nrm, uint32_t n_s, const float *next_tgt_pos_nrm,
                             uint32_t next_n_t, const float *next_src_pos_nrm, uint32_t next_n_s, float *T16);
 /* Batch mode, `count` (1..PLADE_GROUP_MAX) consecutive pairs of the list per call (the loop of code/PLADE/main.cpp:122-148
- * taken two pairs at a time).  Every pair is registered exactly like plade_registration -- results are bit-identical to
- * registering it alone -- but the plane extraction of all clouds of the group (PlaneExtraction::detect x 4) is ONE launch
- * sequence: its ~150 kernels per cloud pair are short and mostly latency-bound, and carrying the clouds of 2-4 pairs per launch
- * divides the commands, host waits and much of the GPU time per registration; behind the extraction the pairs proceed
+ * taken up to PLADE_GROUP_MAX pairs at a time).  Every pair is registered exactly like plade_registration -- results are bit-identical to
+ * registering it alone -- but the plane extraction of all clouds of the group (PlaneExtraction::detect x 2 count) is ONE launch
+ * sequence: its ~150 kernels per cloud pair are short and mostly latency-bound, and carrying the clouds of up to 8 pairs per
+ * launch divides the commands, host waits and much of the GPU time per registration (~0.9 GB of HBM per cloud of the group); behind the extraction the pairs proceed
  * concurrently, pairs 1.. on internal peer contexts (plade_pair_ctx).  tgt_pos_nrm / src_pos_nrm: count pointers to N x 6 arrays, n_t / n_s their point
  * counts; next_*: the clouds the NEXT call on this ctx will be handed (next_count = 0: none), prefetched as
  * plade_registration_next does.  T16: count x 16 (identity where a pair fails); status[i]: PLADE_OK, PLADE_EFAIL (the

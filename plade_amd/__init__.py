@@ -362,7 +362,7 @@ class Context:
         return ptrs, ns
 
     def registration_pairs(self, pairs, next_pairs=None):
-        """plade.h:58 in batch mode, one GROUP of one or two pairs per call (plade_registration_pairs): pairs = [(tgt, src), ...];
+        """plade.h:58 in batch mode, one GROUP of 1..8 pairs per call (plade_registration_pairs): pairs = [(tgt, src), ...];
         next_pairs = the pairs the next call on this context will be handed (their upload is started now).  The arrays must be
         C-contiguous float32 and stay alive and unchanged until that call.  Returns [(ok, T 4x4), ...]."""
         for pr in list(pairs) + list(next_pairs or []):

@@ -1,5 +1,5 @@
 // plade_amd/csrc/ransac.h -- GPU plane extraction (seam S1b): a device-driven Efficient-RANSAC that extracts the
-// planes of up to eight clouds (the scans of one to four pairs) in the same launch sequence, see ransac.hip.
+// planes of up to sixteen clouds (the scans of one to eight pairs) in the same launch sequence, see ransac.hip.
 #pragma once
 #include "ctx.h"
 
@@ -53,7 +53,7 @@ struct ComponentOut {
 void plane_component(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const float normal[3], const float point[3],
                      const int32_t *idx, uint32_t m, float bitmap_eps, bool closing_filter, float w_eps, ComponentOut &out);
 
-// Up to eight clouds are extracted together ("slots" 0-7 of the work area): the two scans of a registration, or the 2 x count
+// Up to sixteen clouds are extracted together ("slots" 0-15 of the work area): the two scans of a registration, or the 2 x count
 // scans of a group of registrations (plade_registration_pairs), in one launch sequence.
 constexpr int RANSAC_SLOTS = 2 * PLADE_GROUP_MAX;
 

@@ -22,7 +22,7 @@ RansacParams ransac_params(plade_ctx *ctx, uint32_t min_support, bool host_indic
 }
 
 // extract() (code/PLADE/plade.cpp:602-635) of ALL clouds of a call -- the two scans of a registration, or the four of a
-// group of two registrations: the reference runs it once per cloud; here pass p of the halving loops is one merged launch
+// group of registrations: the reference runs it once per cloud; here pass p of the halving loops is one merged launch
 // sequence (ransac_detect_prepared) in which every cloud that still needs a detect call takes part with its own
 // min_support.  Cloud g's statistics (the trace of its auto-tuning loop: plane count of every detect call, the min_support
 // it ends at; tests compare it with the reference loop over libransac, g2_extract.npz) go to stat_ctx[g], under tags[g].
