@@ -64,7 +64,10 @@ int plade_device_synchronize(int device);
  *                          faces takes contested points can differ (tests/test_gpu_golden.py).
  *   match_window    0      enumeration of the descriptor match (seam S2): 0 = brute force up to 2e10 descriptor pairs,
  *                          length-windowed above; 1 = always windowed; -1 = never.  The lists are identical either way.
- *   match_cell_budget 0    (query, chunk) cells per slab of the windowed enumeration; 0 = 2^26.  Test hook.         */
+ *   match_cell_budget 0    (query, chunk) cells per slab of the windowed enumeration; 0 = 2^26.  Test hook.
+ *   group_max_points 48e6  points of all clouds that go through ONE extraction sequence of plade_registration_pairs*: a group
+ *                          that holds more is registered in consecutive parts within this budget (the extraction's work area
+ *                          takes ~0.9 KB of HBM per point it serves at once); results do not depend on it.  0 = default. */
 typedef struct plade_params {
     int32_t max_planes;
     int32_t min_planes;
@@ -83,6 +86,7 @@ typedef struct plade_params {
     int32_t ransac_topup;
     int32_t match_window;
     uint32_t match_cell_budget;
+    uint32_t group_max_points;
 } plade_params;
 void plade_default_params(plade_params *p);
 int plade_set_params(plade_ctx *ctx, const plade_params *p);

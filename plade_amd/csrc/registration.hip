@@ -172,13 +172,16 @@ plade_ctx *peer_ctx(plade_ctx *ctx, int i) {   // the context of pair i >= 1 of 
 // GPU time per registration); behind it every pair runs the rest of its registration on its own context (pair 0: the calling
 // one on the calling thread, pair i: peer context i on a helper thread), concurrently.  status[i]: PLADE_OK / PLADE_EFAIL /
 // an error code.
-void register_group(plade_ctx *ctx, int count, const CloudDev *const tgt[], const CloudDev *const src[], const int ms_t[], const int ms_s[],
-                    bool auto_tune, float *T16, int32_t *status) {
-    PLADE_REQUIRE(count >= 1 && count <= PLADE_GROUP_MAX, PLADE_EINVAL, "a group holds one to PLADE_GROUP_MAX pairs");
+// `first`: the pairs are numbers first .. first + count - 1 of the caller's group (register_group_parts): pair number j runs on
+// peer context j (number 0 on ctx itself), whichever part of the group it is registered with.
+void register_group(plade_ctx *ctx, int first, int count, const CloudDev *const tgt[], const CloudDev *const src[], const int ms_t[],
+                    const int ms_s[], bool auto_tune, float *T16, int32_t *status) {
+    PLADE_REQUIRE(count >= 1 && first >= 0 && first + count <= PLADE_GROUP_MAX, PLADE_EINVAL, "a group holds one to PLADE_GROUP_MAX pairs");
     Clock::time_point t0 = Clock::now();
-    plade_ctx *pcs[PLADE_GROUP_MAX] = {ctx};
-    for (int i = 1; i < count; ++i) {
-        pcs[i] = peer_ctx(ctx, i);
+    plade_ctx *pcs[PLADE_GROUP_MAX] = {};
+    for (int i = 0; i < count; ++i) {
+        if (first + i == 0) { pcs[i] = ctx; continue; }
+        pcs[i] = peer_ctx(ctx, first + i);
         pcs[i]->params = ctx->params;
         pcs[i]->shard = ctx->shard;
         pcs[i]->stats.clear();
@@ -216,7 +219,7 @@ void register_group(plade_ctx *ctx, int count, const CloudDev *const tgt[], cons
         StageTimer ts(ctx, "t_spacing");
         for (int i = 0; i < count; ++i) have_spacing[i] = ransac_spacing_finish(ctx, *ctx->ransac_work, 2 * i + 1, &spacing[i]);
     }
-    if (count == 1) {
+    if (count == 1 && pcs[0] == ctx) {
         status[0] = register_tail(ctx, ctx, 0, *tgt[0], *src[0], planes[0], planes[1], auto_tune, have_spacing[0], spacing[0], T16, t0);
         return;
     }
@@ -235,8 +238,9 @@ void register_group(plade_ctx *ctx, int count, const CloudDev *const tgt[], cons
         catch (const std::exception &e) { errs[i] = Err{PLADE_EDEVICE, e.what()}; }
     };
     std::thread ths[PLADE_GROUP_MAX];
-    for (int i = 1; i < count; ++i) {
-        HIP_TRY(hipStreamWaitEvent(pcs[i]->stream, ctx->ev_group, 0));
+    for (int i = 0; i < count; ++i) {
+        if (pcs[i] != ctx) HIP_TRY(hipStreamWaitEvent(pcs[i]->stream, ctx->ev_group, 0));
+        if (i == 0) continue;   // the first pair of the part runs on the calling thread
         ths[i] = std::thread([&, i]() {
             const double cpu0 = thread_cpu_seconds();
             (void)hipSetDevice(ctx->device);
@@ -250,10 +254,30 @@ void register_group(plade_ctx *ctx, int count, const CloudDev *const tgt[], cons
         if (errs[i].code) { pcs[i]->drop_reads(); pcs[i]->last_error = errs[i].msg; status[i] = errs[i].code; }
 }
 
+// A group whose clouds together hold more than plade_params.group_max_points points is registered in consecutive PARTS, each
+// within that budget (or a single pair): the extraction's work area takes ~0.9 KB of HBM per point of the clouds it serves at
+// once -- sixteen 1M-point clouds are 14 GB, sixteen 10M-point clouds would be 144 GB per context -- and is reused from part to
+// part.  Results do not depend on the partition (every pair is the pair alone, bit for bit).
+void register_group_parts(plade_ctx *ctx, int count, const CloudDev *const tgt[], const CloudDev *const src[], const int ms_t[],
+                          const int ms_s[], bool auto_tune, float *T16, int32_t *status) {
+    PLADE_REQUIRE(count >= 1 && count <= PLADE_GROUP_MAX, PLADE_EINVAL, "a group holds one to PLADE_GROUP_MAX pairs");
+    const uint64_t budget = ctx->params.group_max_points ? ctx->params.group_max_points : 48000000u;
+    int parts = 0;
+    for (int b = 0; b < count;) {
+        int e = b + 1;
+        uint64_t pts = (uint64_t)tgt[b]->n + src[b]->n;
+        while (e < count && pts + tgt[e]->n + src[e]->n <= budget) { pts += (uint64_t)tgt[e]->n + src[e]->n; ++e; }
+        register_group(ctx, b, e - b, tgt + b, src + b, ms_t + b, ms_s + b, auto_tune, T16 + 16 * b, status + b);
+        b = e;
+        ++parts;
+    }
+    ctx->stats.add("group_parts", parts);
+}
+
 int register_clouds(plade_ctx *ctx, const CloudDev &tgt, const CloudDev &src, int ms_t, int ms_s, bool auto_tune, float *T16) {
     const CloudDev *t[1] = {&tgt}, *s[1] = {&src};
     int32_t status[1] = {PLADE_OK};
-    register_group(ctx, 1, t, s, &ms_t, &ms_s, auto_tune, T16, status);
+    register_group(ctx, 0, 1, t, s, &ms_t, &ms_s, auto_tune, T16, status);
     return status[0];
 }
 
@@ -434,7 +458,7 @@ int registration_batch(plade_ctx *ctx, uint32_t count, const float *const *tgt, 
         ctx->stats.add("t_upload_submit", secs_since(t0));
     }
     const int zero[PLADE_GROUP_MAX] = {};
-    register_group(ctx, (int)count, ct, cs, zero, zero, true, T16, status);
+    register_group_parts(ctx, (int)count, ct, cs, zero, zero, true, T16, status);
     return PLADE_OK;
 }
 }  // namespace
@@ -486,7 +510,7 @@ extern "C" int plade_registration_pairs_dev(plade_ctx *ctx, uint32_t count, plad
         ctx->last_error.clear();
         cloud_drop_prefetch(ctx);
         const int zero[PLADE_GROUP_MAX] = {};
-        register_group(ctx, (int)count, ct, cs, zero, zero, true, T16, status);
+        register_group_parts(ctx, (int)count, ct, cs, zero, zero, true, T16, status);
         return PLADE_OK;
     });
 }

@@ -182,3 +182,19 @@ def test_deferred_readbacks_keep_their_contract(scenes, alone, monkeypatch):
     ok, T = c.registration(scenes[1][0], scenes[1][1])
     assert ok and np.array_equal(T, alone[1][1])
     c.close()
+
+
+@pytest.mark.parametrize("budget,parts", [(900000, 3), (500000, 5), (0, 1)])
+def test_a_group_over_the_point_budget_is_registered_in_parts(scenes, alone, budget, parts):
+    """plade_params.group_max_points bounds what one extraction sequence serves at once (its work area takes ~0.9 KB of HBM per
+    point): a group that holds more is registered in consecutive parts -- pair j still on peer context j -- and every pair
+    comes out as the pair alone, bit for bit, whatever the partition."""
+    members = (0, 1, 2, 1, 0)           # 400k / 240k / 400k / 240k / 400k points per pair
+    c = plade_amd.Context(0, orient_normals=1, dump=1, group_max_points=budget)
+    res = c.registration_pairs([(scenes[i][0], scenes[i][1]) for i in members])
+    assert c.stats()["group_parts"] == parts
+    for pos, i in enumerate(members):
+        ok, T = res[pos]
+        assert ok and np.array_equal(T, alone[i][1])
+        _same(c.dump(pair=pos), alone[i][2], PLANE_KEYS + ["overlap_counts", "scores", "match_nbr"])
+    c.close()
