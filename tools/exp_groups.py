@@ -21,6 +21,14 @@ host = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 n = int(sys.argv[5]) if len(sys.argv) > 5 else 1000000
 NP = 2
 pairs = [make_pair(n, seed=s) for s in range(NP)]
+if os.environ.get("EXP_ORDER") == "scan":
+    # the same points in the order a spinning scanner at the centre of the cloud would deliver them (256 elevation rings,
+    # azimuth within a ring) instead of the generator's random order: what the index-driven gathers cost depends on it
+    def scan_order(c):
+        d = c[:, :3] - c[:, :3].mean(0)
+        ring = np.floor((np.arctan2(d[:, 2], np.hypot(d[:, 0], d[:, 1])) / np.pi + 0.5) * 256).astype(np.int64)
+        return np.ascontiguousarray(c[np.lexsort((np.arctan2(d[:, 1], d[:, 0]), ring))])
+    pairs = [(scan_order(tg), scan_order(sr), T) for tg, sr, T in pairs]
 ctxs = [plade_amd.Context(0, orient_normals=1, host_wait=1) for _ in range(G)]
 clouds = [[(c.upload(tg), c.upload(sr)) for (tg, sr, _) in pairs] for c in ctxs]
 if host:
