@@ -38,7 +38,7 @@ __device__ void strided_sums(const float *__restrict__ pts, uint32_t n, float (*
     float acc[K];
 #pragma unroll
     for (int q = 0; q < K; ++q) acc[q] = 0.f;
-    constexpr int AHEAD = 16;   // points in flight per lane: a pass over the 130 000-point unit is 8 load latencies, not 130
+    constexpr int AHEAD = 24;   // points in flight per lane (what 128 registers hold without spilling): a pass over a 130 000-point unit is 6 load latencies, not 130
     for (uint32_t i0 = threadIdx.x; i0 < n; i0 += AHEAD * OBB_T) {
         float x[AHEAD], y[AHEAD], z[AHEAD];
 #pragma unroll
@@ -106,16 +106,17 @@ __global__ __launch_bounds__(OBB_T) void k_obb_units(const ObbArgs A) {
     float P[12];
     for (int q = 0; q < 12; ++q) P[q] = s_P[q];
     float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-    for (uint32_t i0 = threadIdx.x; i0 < n; i0 += 16 * OBB_T) {   // sixteen points in flight per lane
-        float x[16], y[16], z[16];
+    constexpr int MM_AHEAD = 24;
+    for (uint32_t i0 = threadIdx.x; i0 < n; i0 += MM_AHEAD * OBB_T) {   // twenty-four points in flight per lane
+        float x[MM_AHEAD], y[MM_AHEAD], z[MM_AHEAD];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
+        for (int j = 0; j < MM_AHEAD; ++j) {
             const uint32_t i = min(i0 + j * OBB_T, n - 1);
             const float3 p3 = *reinterpret_cast<const float3 *>(pts + 3 * (size_t)i);   // one 12-byte load
             x[j] = p3.x; y[j] = p3.y; z[j] = p3.z;
         }
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {   // a clamped repeat of the last point changes no minimum / maximum
+        for (int j = 0; j < MM_AHEAD; ++j) {   // a clamped repeat of the last point changes no minimum / maximum
             const f3 q = pcl_xform(P, f3(x[j], y[j], z[j]));
             mn[0] = fminf(mn[0], q.x); mn[1] = fminf(mn[1], q.y); mn[2] = fminf(mn[2], q.z);
             mx[0] = fmaxf(mx[0], q.x); mx[1] = fmaxf(mx[1], q.y); mx[2] = fmaxf(mx[2], q.z);
