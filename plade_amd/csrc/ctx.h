@@ -380,6 +380,7 @@ struct plade_ctx {
     // the radix sort's two global digit histograms (radix_sort.hip) and the number of sorts issued on this context
     plade::DBuf<uint32_t> sort_ghist;
     uint32_t sort_seq = 0;
+    uint32_t sort_segs[2] = {0, 0};   // segments whose histogram words the last sort on each buffer left non-zero
     // generic scratch
     plade::DBuf<char> scratch[8];
     plade::HBuf<char> pinned[4];

@@ -14,6 +14,10 @@ void radix_sort_pairs_u32(plade_ctx *ctx, const uint32_t *keys_in, uint32_t *key
                           uint32_t *vals_out, size_t n, int bits);
 void radix_sort_pairs_u64(plade_ctx *ctx, const uint64_t *keys_in, uint64_t *keys_out, const uint32_t *vals_in,
                           uint32_t *vals_out, size_t n, int bits);
+// up to 16 arrays in ONE launch sequence: segment s = items [seg_off[s], seg_off[s + 1]) of the same buffers, each sorted on
+// its own (stable) and left in its own range
+void radix_sort_segments_u32(plade_ctx *ctx, const uint32_t *keys_in, uint32_t *keys_out, const uint32_t *vals_in,
+                             uint32_t *vals_out, const uint32_t *seg_off, int nseg, int bits);
 // exclusive prefix sum, one launch (decoupled look-back)
 void exclusive_scan_u32(plade_ctx *ctx, const uint32_t *in, uint32_t *out, size_t n);
 // Look-back words + tile ticket for ONE launch of a decoupled look-back kernel over `n` items in tiles of `tile_items`

@@ -45,6 +45,25 @@ constexpr int RS_HBLOCKS = 128;                  // histogram workgroups (= part
 constexpr int RS_MAXP = 8;
 constexpr int RS_LOOK = 8;                      // states fetched per round of the prefix loads
 constexpr uint32_t RS_VALID = 1u << 31, RS_VALUE = RS_VALID - 1;
+// One launch sequence can sort up to RS_MAXSEG independent ARRAYS ("segments": consecutive ranges of the same key / value
+// buffers, each sorted on its own and left in its own range): the Morton order of the sixteen clouds of a group is 4 launches
+// instead of 64.  A segment has its own global histogram, tiles, look-back words and supertile sums -- sixteen independent prefix
+// chains in one grid, not one chain sixteen times as long (a single sort over the keys of all clouds was measured at 426 us per
+// pass under load against ~25 per 1M-key cloud: the more tiles one chain has, the longer each of them waits).
+constexpr int RS_MAXSEG = 16;
+constexpr uint32_t RS_GH_SEG = RS_MAXP * 512;   // words of global histogram per segment
+struct RSSegs {
+    uint32_t nseg;
+    uint32_t off[RS_MAXSEG + 1];          // segment s = items [off[s], off[s + 1])
+    uint32_t tile_start[RS_MAXSEG + 1];   // first tile of segment s in the pass grid
+    uint32_t sup_start[RS_MAXSEG + 1];    // first supertile word group of segment s
+};
+__device__ __forceinline__ uint32_t seg_of_tile(const RSSegs &S, uint32_t tile) {
+    uint32_t s = 0;
+#pragma unroll
+    for (int q = 1; q < RS_MAXSEG; ++q) s += (q < (int)S.nseg && tile >= S.tile_start[q]) ? 1u : 0u;
+    return s;
+}
 constexpr unsigned long long RS_SUP_ONE = 1ull << 40, RS_SUP_VALUE = RS_SUP_ONE - 1ull;
 
 // Digits are 8 bits wide, or 9 where that saves a pass (25-27, 17-18 significant bits: the voxel and cell grids):
@@ -54,18 +73,23 @@ __device__ __forceinline__ uint32_t digit_of(K key, int shift) { return (uint32_
 
 // ghist[p][d]: keys of digit d at place p (all-zero on entry)
 template <class K, int DB>
-__global__ __launch_bounds__(RS_THREADS) void k_rs_histogram(const K *__restrict__ keys, uint32_t n, int passes,
-                                                             uint32_t *__restrict__ ghist, uint32_t *__restrict__ tile_ctr,
+__global__ __launch_bounds__(RS_THREADS) void k_rs_histogram(const K *__restrict__ keys_all, const RSSegs S, int passes,
+                                                             uint32_t *__restrict__ ghist_all, uint32_t *__restrict__ tile_ctr,
                                                              uint32_t *__restrict__ look, size_t look_words) {
     constexpr int NB = 1 << DB;
     __shared__ uint32_t s_h[RS_MAXP * NB];
     for (int i = threadIdx.x; i < passes * NB; i += RS_THREADS) s_h[i] = 0;
     // clear what the passes will use
-    for (size_t i = (size_t)blockIdx.x * RS_THREADS + threadIdx.x; i < look_words; i += (size_t)RS_HBLOCKS * RS_THREADS) look[i] = 0;
+    for (size_t i = (size_t)blockIdx.x * RS_THREADS + threadIdx.x; i < look_words; i += (size_t)gridDim.x * RS_THREADS) look[i] = 0;
     if (blockIdx.x == 0 && threadIdx.x < RS_MAXP) tile_ctr[threadIdx.x] = 0;
     __syncthreads();
+    // RS_HBLOCKS workgroups per segment
+    const uint32_t seg = blockIdx.x / RS_HBLOCKS, hb = blockIdx.x % RS_HBLOCKS;
+    const K *__restrict__ keys = keys_all + S.off[seg];
+    uint32_t *__restrict__ ghist = ghist_all + (size_t)seg * RS_GH_SEG;
+    const uint32_t n = S.off[seg + 1] - S.off[seg];
     const uint32_t per = (n + RS_HBLOCKS - 1) / RS_HBLOCKS;
-    const uint32_t b0 = blockIdx.x * per, b1 = min(n, b0 + per);
+    const uint32_t b0 = hb * per, b1 = min(n, b0 + per);
     // 8 independent loads per round: a one-load-per-iteration loop is bound by the load latency (39 us at 1M keys)
     for (uint32_t i0 = b0; i0 < b1; i0 += 8 * RS_THREADS) {
         K k[8];
@@ -84,11 +108,11 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_histogram(const K *__restrict
 }
 
 template <class K, int DB, int RS_IPT>
-__global__ __launch_bounds__(RS_THREADS) void k_rs_pass(const K *__restrict__ kin, K *__restrict__ kout,
-                                                        const uint32_t *__restrict__ vin, uint32_t *__restrict__ vout,
-                                                        uint32_t n, int pass, const uint32_t *__restrict__ ghist,
-                                                        uint32_t *__restrict__ ghist_next, uint32_t *__restrict__ tile_ctr,
-                                                        uint32_t *__restrict__ look, unsigned long long *__restrict__ sup, uint32_t st_shift) {
+__global__ __launch_bounds__(RS_THREADS) void k_rs_pass(const K *__restrict__ kin_all, K *__restrict__ kout_all,
+                                                        const uint32_t *__restrict__ vin_all, uint32_t *__restrict__ vout_all,
+                                                        const RSSegs S, int pass, const uint32_t *__restrict__ ghist_all,
+                                                        uint32_t *__restrict__ ghist_next, uint32_t zero_words, uint32_t *__restrict__ tile_ctr,
+                                                        uint32_t *__restrict__ look_all, unsigned long long *__restrict__ sup_all, uint32_t st_shift) {
     constexpr int NB = 1 << DB;
     constexpr int RS_TILE = RS_THREADS * RS_IPT;
     static_assert(NB <= RS_THREADS, "one lane per digit");
@@ -106,13 +130,25 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_pass(const K *__restrict__ ki
     // threads 0..NB-1 own one digit each.  Keys of that digit in the whole array: the global histogram (independent of the
     // tile: issued first, the latency hides behind the ticket and the key loads)
     const bool owner = tid < NB;
-    const uint32_t total = owner ? ghist[pass * NB + tid] : 0u;
     __syncthreads();
-    const uint32_t tile = s_tile;
+    // ticket -> (segment, tile inside the segment): tickets are handed out in grid order, so every tile of a segment that
+    // precedes this one holds an earlier ticket and is running
+    const uint32_t gtile = s_tile;
+    const uint32_t seg = seg_of_tile(S, gtile), tile = gtile - S.tile_start[seg];
+    const uint32_t n = S.off[seg + 1] - S.off[seg];
+    const K *__restrict__ kin = kin_all + S.off[seg];
+    K *__restrict__ kout = kout_all + S.off[seg];
+    const uint32_t *__restrict__ vin = vin_all + S.off[seg];
+    uint32_t *__restrict__ vout = vout_all + S.off[seg];
+    const uint32_t *__restrict__ ghist = ghist_all + (size_t)seg * RS_GH_SEG;
+    uint32_t *__restrict__ look = look_all + (size_t)S.tile_start[seg] * NB;
+    unsigned long long *__restrict__ sup = sup_all + (size_t)S.sup_start[seg] * NB;
+    // keys of this thread's digit in the whole segment: the global histogram
+    const uint32_t total = owner ? ghist[pass * NB + tid] : 0u;
     // the first tile of the first pass leaves the OTHER histogram buffer all-zero for the next sort of this context (its last
-    // user, the previous sort on this stream, has finished)
-    if (pass == 0 && tile == 0)
-        for (int i = tid; i < RS_MAXP * 512; i += RS_THREADS) ghist_next[i] = 0u;
+    // user, the previous sort on this stream, has finished): as many words as that sort's segments touched
+    if (pass == 0 && gtile == 0)
+        for (uint32_t i = tid; i < zero_words; i += RS_THREADS) ghist_next[i] = 0u;
     const uint32_t base = tile * RS_TILE + wave * (64 * RS_IPT);   // this wave's 1024 consecutive keys
 
     // ---- load + stable rank inside the wave ------------------------------------------------------
@@ -224,15 +260,29 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_pass(const K *__restrict__ ki
 }
 
 template <class K, int DB, int RS_IPT>
-void radix_sort_run_ipt(plade_ctx *ctx, const K *ki, K *ko, const uint32_t *vi, uint32_t *vo, size_t n, int passes) {
+void radix_sort_run_ipt(plade_ctx *ctx, const K *ki, K *ko, const uint32_t *vi, uint32_t *vo, const uint32_t *seg_off, int nseg, int passes) {
     constexpr int NB = 1 << DB;
     constexpr int RS_TILE = RS_THREADS * RS_IPT;
+    const size_t n = seg_off[nseg] - seg_off[0];
     if (n == 0) return;   // no tiles: nothing to launch
-    const uint32_t tiles = cdiv(n, RS_TILE);
-    // supertiles of 2^st_shift ~ sqrt(tiles) tiles; per pass: one u32 per (tile, digit), then one u64 per (supertile, digit)
+    RSSegs S;
+    memset(&S, 0, sizeof(S));
+    S.nseg = (uint32_t)nseg;
+    uint32_t max_tiles = 1;
+    for (int q = 0; q <= RS_MAXSEG; ++q) S.off[q] = seg_off[std::min(q, nseg)] - seg_off[0];
+    for (int q = 0; q < nseg; ++q) {
+        const uint32_t t = cdiv(S.off[q + 1] - S.off[q], RS_TILE);
+        S.tile_start[q + 1] = S.tile_start[q] + t;
+        max_tiles = std::max(max_tiles, t);
+    }
+    for (int q = nseg; q < RS_MAXSEG; ++q) S.tile_start[q + 1] = S.tile_start[q];
+    const uint32_t tiles = S.tile_start[nseg];
+    // supertiles of 2^st_shift ~ sqrt(tiles of a segment) tiles; per pass: one u32 per (tile, digit), then one u64 per (supertile, digit)
     uint32_t st_shift = 2;
-    while ((1u << (2 * st_shift)) < tiles && st_shift < 8) ++st_shift;
-    const uint32_t nsup = (tiles >> st_shift) + 1;
+    while ((1u << (2 * st_shift)) < max_tiles && st_shift < 8) ++st_shift;
+    for (int q = 0; q < RS_MAXSEG; ++q)
+        S.sup_start[q + 1] = S.sup_start[q] + (q < nseg ? ((S.tile_start[q + 1] - S.tile_start[q]) >> st_shift) + 1 : 0u);
+    const uint32_t nsup = S.sup_start[nseg];
     const size_t pass_words = (size_t)tiles * NB + 2 * (size_t)nsup * NB, look_words = (size_t)passes * pass_words;
     // scratch: tile counters | look-back states | key ping buffer | value ping buffer
     const size_t off_ctr = 0, off_look = off_ctr + 64, off_keys = (off_look + look_words + 3) & ~(size_t)3;
@@ -241,15 +291,22 @@ void radix_sort_run_ipt(plade_ctx *ctx, const K *ki, K *ko, const uint32_t *vi, 
     K *tk = reinterpret_cast<K *>(t + off_keys);
     uint32_t *tv = t + off_vals;
     hipStream_t st = ctx->stream;
-    // the two global histograms of this context (see the header): zeroed once, then by the sorts themselves
-    constexpr size_t GH = (size_t)RS_MAXP * 512;
+    // the two global histograms of this context (see the header): zeroed once, then by the sorts themselves -- every sort
+    // zeroes, in the buffer of the NEXT sort, what the sort before it left there
+    constexpr size_t GH = (size_t)RS_MAXSEG * RS_GH_SEG;
     if (!ctx->sort_ghist.p) {
         ctx->sort_ghist.ensure(2 * GH);
         HIP_TRY(hipMemsetAsync(ctx->sort_ghist.p, 0, 2 * GH * 4, st));
+        ctx->sort_segs[0] = ctx->sort_segs[1] = 0;
     }
-    uint32_t *gh = ctx->sort_ghist.p + (ctx->sort_seq & 1u) * GH, *gh_next = ctx->sort_ghist.p + ((ctx->sort_seq + 1u) & 1u) * GH;
+    const uint32_t cur = ctx->sort_seq & 1u, nxt = cur ^ 1u;
+    uint32_t *gh = ctx->sort_ghist.p + cur * GH, *gh_next = ctx->sort_ghist.p + nxt * GH;
+    const uint32_t zero_words = ctx->sort_segs[nxt] * RS_GH_SEG;   // what the previous sort dirtied in the other buffer
+    ctx->sort_segs[nxt] = 0;
+    ctx->sort_segs[cur] = (uint32_t)nseg;
     ctx->sort_seq += 1;
-    hipLaunchKernelGGL((k_rs_histogram<K, DB>), dim3(RS_HBLOCKS), dim3(RS_THREADS), 0, st, ki, (uint32_t)n, passes, gh, t + off_ctr,
+    ki += seg_off[0]; ko += seg_off[0]; vi += seg_off[0]; vo += seg_off[0];
+    hipLaunchKernelGGL((k_rs_histogram<K, DB>), dim3(RS_HBLOCKS * nseg), dim3(RS_THREADS), 0, st, ki, S, passes, gh, t + off_ctr,
                        t + off_look, look_words);
     const K *src_k = ki;
     const uint32_t *src_v = vi;
@@ -258,8 +315,8 @@ void radix_sort_run_ipt(plade_ctx *ctx, const K *ki, K *ko, const uint32_t *vi, 
         K *dst_k = to_out ? ko : tk;
         uint32_t *dst_v = to_out ? vo : tv;
         uint32_t *pass_look = t + off_look + (size_t)p * pass_words;
-        hipLaunchKernelGGL((k_rs_pass<K, DB, RS_IPT>), dim3(tiles), dim3(RS_THREADS), 0, st, src_k, dst_k, src_v, dst_v, (uint32_t)n, p, gh,
-                           gh_next, t + off_ctr, pass_look, reinterpret_cast<unsigned long long *>(pass_look + (size_t)tiles * NB), st_shift);
+        hipLaunchKernelGGL((k_rs_pass<K, DB, RS_IPT>), dim3(tiles), dim3(RS_THREADS), 0, st, src_k, dst_k, src_v, dst_v, S, p, gh,
+                           gh_next, zero_words, t + off_ctr, pass_look, reinterpret_cast<unsigned long long *>(pass_look + (size_t)tiles * NB), st_shift);
         src_k = dst_k;
         src_v = dst_v;
     }
@@ -267,32 +324,44 @@ void radix_sort_run_ipt(plade_ctx *ctx, const K *ki, K *ko, const uint32_t *vi, 
 }
 
 template <class K, int DB>
-void radix_sort_run(plade_ctx *ctx, const K *ki, K *ko, const uint32_t *vi, uint32_t *vo, size_t n, int passes) {
-    if (n <= 3000000) radix_sort_run_ipt<K, DB, 8>(ctx, ki, ko, vi, vo, n, passes);
-    else radix_sort_run_ipt<K, DB, 16>(ctx, ki, ko, vi, vo, n, passes);
+void radix_sort_run(plade_ctx *ctx, const K *ki, K *ko, const uint32_t *vi, uint32_t *vo, const uint32_t *seg_off, int nseg, int passes) {
+    uint32_t largest = 0;
+    for (int q = 0; q < nseg; ++q) largest = std::max(largest, seg_off[q + 1] - seg_off[q]);
+    if (largest <= 3000000) radix_sort_run_ipt<K, DB, 8>(ctx, ki, ko, vi, vo, seg_off, nseg, passes);
+    else radix_sort_run_ipt<K, DB, 16>(ctx, ki, ko, vi, vo, seg_off, nseg, passes);
 }
 
 template <class K>
-void radix_sort_impl(plade_ctx *ctx, const K *ki, K *ko, const uint32_t *vi, uint32_t *vo, size_t n, int bits) {
-    PLADE_REQUIRE(n < (1ull << 30), PLADE_ELIMIT, "sort: too many items");
+void radix_sort_impl(plade_ctx *ctx, const K *ki, K *ko, const uint32_t *vi, uint32_t *vo, const uint32_t *seg_off, int nseg, int bits) {
+    PLADE_REQUIRE(nseg >= 1 && nseg <= RS_MAXSEG, PLADE_EINVAL, "sort: one to sixteen segments");
+    for (int q = 0; q < nseg; ++q) PLADE_REQUIRE(seg_off[q] <= seg_off[q + 1], PLADE_EINVAL, "sort: segment offsets must ascend");
+    PLADE_REQUIRE((uint64_t)seg_off[nseg] - seg_off[0] < (1ull << 30), PLADE_ELIMIT, "sort: too many items");
     PLADE_REQUIRE(bits >= 1 && bits <= (int)sizeof(K) * 8, PLADE_EINVAL, "sort: bit range");
     const int p8 = (bits + 7) / 8, p9 = (bits + 8) / 9;
     static const bool no9 = getenv("PLADE_SORT_DIGIT8") != nullptr;
     // the last 9-bit digit must still lie inside the key: (p9 - 1) * 9 < key bits
-    if (p9 < p8 && !no9 && (p9 - 1) * 9 < (int)sizeof(K) * 8) radix_sort_run<K, 9>(ctx, ki, ko, vi, vo, n, p9);
+    if (p9 < p8 && !no9 && (p9 - 1) * 9 < (int)sizeof(K) * 8) radix_sort_run<K, 9>(ctx, ki, ko, vi, vo, seg_off, nseg, p9);
     else {
         PLADE_REQUIRE(p8 <= RS_MAXP, PLADE_EINVAL, "sort: bit range");
-        radix_sort_run<K, 8>(ctx, ki, ko, vi, vo, n, p8);
+        radix_sort_run<K, 8>(ctx, ki, ko, vi, vo, seg_off, nseg, p8);
     }
 }
 
 }  // namespace
 
 void radix_sort_pairs_u32(plade_ctx *ctx, const uint32_t *ki, uint32_t *ko, const uint32_t *vi, uint32_t *vo, size_t n, int bits) {
-    radix_sort_impl<uint32_t>(ctx, ki, ko, vi, vo, n, bits);
+    PLADE_REQUIRE(n < (1ull << 30), PLADE_ELIMIT, "sort: too many items");
+    const uint32_t off[2] = {0u, (uint32_t)n};
+    radix_sort_impl<uint32_t>(ctx, ki, ko, vi, vo, off, 1, bits);
 }
 void radix_sort_pairs_u64(plade_ctx *ctx, const uint64_t *ki, uint64_t *ko, const uint32_t *vi, uint32_t *vo, size_t n, int bits) {
-    radix_sort_impl<uint64_t>(ctx, ki, ko, vi, vo, n, bits);
+    PLADE_REQUIRE(n < (1ull << 30), PLADE_ELIMIT, "sort: too many items");
+    const uint32_t off[2] = {0u, (uint32_t)n};
+    radix_sort_impl<uint64_t>(ctx, ki, ko, vi, vo, off, 1, bits);
+}
+void radix_sort_segments_u32(plade_ctx *ctx, const uint32_t *ki, uint32_t *ko, const uint32_t *vi, uint32_t *vo, const uint32_t *seg_off,
+                             int nseg, int bits) {
+    radix_sort_impl<uint32_t>(ctx, ki, ko, vi, vo, seg_off, nseg, bits);
 }
 
 }  // namespace plade

@@ -2444,13 +2444,18 @@ void ransac_prepare(plade_ctx *ctx, RansacWork &W, const CloudDev *const clouds[
     for (int g = n_clouds; g <= R_G; ++g) M.start[g] = G.start[g] = (uint32_t)total;
     W.keys_in.ensure(total); W.vals_in.ensure(total); W.keys.ensure(total); W.perm.ensure(total);
     hipLaunchKernelGGL(k_morton, dim3(cdiv(total, 256)), dim3(256), 0, ctx->stream, M, W.keys_in.p, W.vals_in.p);
-    // One sort per CLOUD (the slot bits above bit 23 are equal inside a cloud's range): under the load of the pipeline a radix
-    // pass over the ~1M keys of a cloud takes ~20 us, one over the 2M keys of a pair 95-110 us, one over the 8M keys of a group
-    // of four pairs 426 us -- the passes are chains of dependent round trips whose tiles wait for each other, and the more
-    // tiles a pass has the longer each of them is kept waiting by foreign workgroups
-    for (int g = 0; g < n_clouds; ++g) {
-        const uint32_t b = M.start[g], e = M.start[g + 1];
-        if (e > b) sort_pairs_u32(ctx, W.keys_in.p + b, W.keys.p + b, W.vals_in.p + b, W.perm.p + b, e - b, 24);
+    // One sort per CLOUD (the slot bits above bit 23 are equal inside a cloud's range) -- as SEGMENTS of one launch sequence
+    // (radix_sort.hip: every cloud keeps its own histogram and prefix chain; one chain over the keys of all clouds of a group
+    // was measured at 426 us per pass under load against ~25 per 1M-key cloud, sixteen sorts one after the other are 64 launches)
+    {
+        uint32_t seg_off[R_G + 1];
+        int nseg = 0;
+        for (int g = 0; g < n_clouds; ++g) {
+            if (M.start[g + 1] == M.start[g]) continue;   // an empty cloud has nothing to sort
+            seg_off[nseg] = M.start[g];
+            seg_off[++nseg] = M.start[g + 1];
+        }
+        if (nseg) radix_sort_segments_u32(ctx, W.keys_in.p, W.keys.p, W.vals_in.p, W.perm.p, seg_off, nseg, 24);
     }
     hipLaunchKernelGGL(k_gather_cloud, dim3(cdiv(total, 256)), dim3(256), 0, ctx->stream, G, W.keys.p, W.perm.p);
     Cells6Args C6;
