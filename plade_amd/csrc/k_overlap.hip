@@ -353,8 +353,9 @@ __global__ void k_src_keys(const float *__restrict__ x, const float *__restrict_
     while ((ext / (float)(1 << sh)) >= 1023.f) ++sh;
     cx >>= sh; cy >>= sh; cz >>= sh;
     cx = min(max(cx, 0), 1023); cy = min(max(cy, 0), 1023); cz = min(max(cz, 0), 1023);
-    const uint32_t blk = (uint32_t)(cx >> 2) | ((uint32_t)(cy >> 2) << 8) | ((uint32_t)(cz >> 2) << 16);
-    keys[i] = (blk << 6) | local_of(cx, cy, cz);
+    // the block alone is the key (24 bits = three radix passes instead of the four that 30 bits took): inside a block of 4 x 4 x 4
+    // cells the points keep their order -- any order gives the same counts, the sort only makes a wavefront's probes local
+    keys[i] = (uint32_t)(cx >> 2) | ((uint32_t)(cy >> 2) << 8) | ((uint32_t)(cz >> 2) << 16);
     vals[i] = i;
 }
 __global__ void k_src_gather(const float *__restrict__ x, const float *__restrict__ y, const float *__restrict__ z, uint32_t n,
@@ -396,7 +397,7 @@ void overlap_sort_source(plade_ctx *ctx, OverlapWork &work, const float *d_sx, c
     work.sorted.ensure(3 * (size_t)n_s + 4);
     hipLaunchKernelGGL(k_src_keys, dim3(cdiv(n_s, 256)), dim3(256), 0, ctx->stream, d_sx, d_sy, d_sz, n_s, work.bbox.p, 1.f / cell,
                        work.keys.p, work.vals.p);
-    sort_pairs_u32(ctx, work.keys.p, work.keys2.p, work.vals.p, work.vals2.p, n_s, 30);
+    sort_pairs_u32(ctx, work.keys.p, work.keys2.p, work.vals.p, work.vals2.p, n_s, 24);
     hipLaunchKernelGGL(k_src_gather, dim3(cdiv(n_s, 256)), dim3(256), 0, ctx->stream, d_sx, d_sy, d_sz, n_s, work.vals2.p,
                        work.sorted.p);
     HIP_TRY(hipGetLastError());
