@@ -262,6 +262,11 @@ int plade_stats_get(plade_ctx *ctx, const char **names, const double **values, i
  * their input order. */
 int plade_sort_pairs(plade_ctx *ctx, const void *keys, const uint32_t *vals, uint32_t n, int key_bytes, int bits,
                      void *keys_out, uint32_t *vals_out);
+/* The same sort over up to 16 independent arrays in ONE launch sequence (how the Morton order of the clouds of a group is
+ * built): segment s = items [seg_off[s], seg_off[s + 1]) of the u32 keys / values, seg_off ascending with seg_off[0] = 0 and
+ * seg_off[nseg] = n; every segment is sorted on its own (stable) and left in its own range. */
+int plade_sort_segments(plade_ctx *ctx, const uint32_t *keys, const uint32_t *vals, const uint32_t *seg_off, uint32_t nseg, int bits,
+                        uint32_t *keys_out, uint32_t *vals_out);
 
 /* Test seam: the device -> host hand-over every readback of the library goes through (n_ranges arrays of `words` 32-bit
  * words read back through one wait; no reference counterpart).  *mismatches = words that arrived wrong (0 expected). */

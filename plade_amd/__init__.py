@@ -22,7 +22,7 @@ ABI_SYMBOLS = [
     "plade_registration", "plade_registration_minsupport", "plade_cloud_upload", "plade_cloud_free",
     "plade_registration_dev", "plade_dump_get", "plade_stats_get", "plade_kernel_time", "plade_plane_component",
     "plade_sort_pairs", "plade_host_pin", "plade_host_unpin", "plade_score_planes_subset", "plade_registration_next", "plade_cluster_transforms", "plade_device_synchronize", "plade_selftest_readback",
-    "plade_registration_pairs", "plade_registration_pairs_dev", "plade_pair_ctx", "plade_set_candidate_shard", "plade_diag_launches", "plade_diag_cluster_order",
+    "plade_registration_pairs", "plade_registration_pairs_dev", "plade_pair_ctx", "plade_set_candidate_shard", "plade_diag_launches", "plade_diag_cluster_order", "plade_sort_segments",
 ]
 
 
@@ -89,6 +89,7 @@ def load_library(path=LIB_PATH):
     sig("plade_pair_ctx", argtypes=[p, u32], restype=p)
     sig("plade_diag_launches", argtypes=[p, u32, u32, u32])
     sig("plade_diag_cluster_order", argtypes=[p, u32, i32, i32, p])
+    sig("plade_sort_segments", argtypes=[p, p, p, p, u32, C.c_int, p, p])
     sig("plade_set_candidate_shard", argtypes=[p, u32, u32, u32, EXCHANGE_FN, p])
     sig("plade_registration_minsupport", argtypes=[p, p, u32, p, u32, i32, i32, p])
     sig("plade_cloud_upload", argtypes=[p, p, u32, C.POINTER(p)])
@@ -219,6 +220,15 @@ class Context:
         ko, vo = np.empty_like(k), np.empty_like(v)
         self._check(self.L.plade_sort_pairs(self.h, k.ctypes.data_as(C.c_void_p), _ptr(v), len(k), kb,
                                             int(bits if bits is not None else 8 * kb), ko.ctypes.data_as(C.c_void_p), _ptr(vo)))
+        return ko, vo
+
+    def sort_segments(self, keys, vals, seg_off, bits=32):
+        """The radix sort over up to 16 independent arrays in one launch sequence: segment s = [seg_off[s], seg_off[s + 1])."""
+        k = np.ascontiguousarray(keys, np.uint32)
+        v = np.ascontiguousarray(vals, np.uint32)
+        so = np.ascontiguousarray(seg_off, np.uint32)
+        ko, vo = np.empty_like(k), np.empty_like(v)
+        self._check(self.L.plade_sort_segments(self.h, _ptr(k), _ptr(v), _ptr(so), len(so) - 1, int(bits), _ptr(ko), _ptr(vo)))
         return ko, vo
 
     def selftest_readback(self, n_ranges, words):

@@ -515,6 +515,28 @@ extern "C" int plade_registration_pairs_dev(plade_ctx *ctx, uint32_t count, plad
     });
 }
 
+extern "C" int plade_sort_segments(plade_ctx *ctx, const uint32_t *keys, const uint32_t *vals, const uint32_t *seg_off, uint32_t nseg, int bits,
+                                   uint32_t *keys_out, uint32_t *vals_out) {
+    return guarded(ctx, [&]() -> int {
+        PLADE_REQUIRE(seg_off && nseg >= 1 && nseg <= 16 && bits >= 1 && bits <= 32 && seg_off[0] == 0, PLADE_EINVAL,
+                      "plade_sort_segments: 1..16 segments starting at 0, 1 <= bits <= 32");
+        for (uint32_t q = 0; q < nseg; ++q) PLADE_REQUIRE(seg_off[q] <= seg_off[q + 1], PLADE_EINVAL, "plade_sort_segments: offsets must ascend");
+        const uint32_t n = seg_off[nseg];
+        PLADE_REQUIRE(!n || (keys && vals && keys_out && vals_out), PLADE_EINVAL, "plade_sort_segments: null argument");
+        if (!n) return PLADE_OK;
+        HIP_TRY(hipSetDevice(ctx->device));
+        DBuf<uint32_t> ki, ko, vi, vo;
+        ki.ensure(n); ko.ensure(n); vi.ensure(n); vo.ensure(n);
+        ctx->h2d(ki.p, keys, (size_t)n * 4);
+        ctx->h2d(vi.p, vals, (size_t)n * 4);
+        radix_sort_segments_u32(ctx, ki.p, ko.p, vi.p, vo.p, seg_off, (int)nseg, bits);
+        ctx->d2h(keys_out, ko.p, (size_t)n * 4);
+        ctx->d2h(vals_out, vo.p, (size_t)n * 4);
+        ctx->sync();
+        return PLADE_OK;
+    });
+}
+
 // The context that carried pair `index` of the last group call (0: ctx itself): its stats, dump and last error are read with
 // the ordinary entry points.  Borrowed: it lives and dies with ctx.
 extern "C" plade_ctx *plade_pair_ctx(plade_ctx *ctx, uint32_t index) {

@@ -218,6 +218,32 @@ def test_radix_sort_sorted_reversed_and_constant_inputs(ctx):
         assert np.array_equal(ko, keys[order]) and np.array_equal(vo, order.astype(np.uint32))
 
 
+@pytest.mark.parametrize("sizes,bits", [((1000000, 1000000, 300000), 24), ((5000, 0, 70000, 1, 4097, 4096, 123457, 9), 24),
+                                        (tuple([60000] * 16), 27), ((3000001, 17), 20), ((0, 0, 5), 9)])
+def test_radix_sort_over_segments_sorts_every_array_on_its_own(ctx, sizes, bits):
+    """Up to 16 independent arrays in one launch sequence (the Morton order of the clouds of a group, ransac.hip): every
+    segment must come out as numpy's stable argsort of that segment alone -- own histogram, own prefix chain, empty and
+    single-item segments, segments that end inside a tile, the 16-key-per-lane tiles above 3M keys; and an ordinary sort
+    right behind it must find the histogram words of all sixteen segments zeroed."""
+    rng = np.random.default_rng(len(sizes) * 1000 + bits)
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.uint32)
+    n = int(off[-1])
+    keys = rng.integers(0, 1 << bits, n, dtype=np.uint64).astype(np.uint32)
+    keys[: n // 3] &= np.uint32(0xff)          # many ties in front: stability matters
+    vals = rng.permutation(n).astype(np.uint32)
+    ko, vo = ctx.sort_segments(keys, vals, off, bits)
+    for s in range(len(sizes)):
+        b, e = int(off[s]), int(off[s + 1])
+        order = np.argsort(keys[b:e], kind="stable")
+        assert np.array_equal(ko[b:e], keys[b:e][order]) and np.array_equal(vo[b:e], vals[b:e][order]), s
+    k2 = rng.integers(0, 1 << 20, 200000, dtype=np.uint64).astype(np.uint32)
+    v2 = np.arange(len(k2), dtype=np.uint32)
+    for _ in range(2):                          # both histogram buffers
+        ko2, vo2 = ctx.sort_pairs(k2, v2, 20)
+        order = np.argsort(k2, kind="stable")
+        assert np.array_equal(ko2, k2[order]) and np.array_equal(vo2, order.astype(np.uint32))
+
+
 @pytest.mark.parametrize("filt", [True, False])
 def test_plane_component_bitmap_larger_than_the_lds_labelling(ctx, oracle, filt):
     """Seam S1c on a bitmap of ~360 x 300 pixels (k_r_label keeps bitmaps of up to 8192 pixels in LDS; beyond that it labels
