@@ -65,6 +65,11 @@ int plade_device_synchronize(int device);
  *   match_window    0      enumeration of the descriptor match (seam S2): 0 = brute force up to 2e10 descriptor pairs,
  *                          length-windowed above; 1 = always windowed; -1 = never.  The lists are identical either way.
  *   match_cell_budget 0    (query, chunk) cells per slab of the windowed enumeration; 0 = 2^26.  Test hook.
+ *   prepare_sides   0      what the two clouds of a pair go through between plane extraction and descriptor match (downsampling,
+ *                          boxes, grids, line pairs): 1 = side by side (source on an auxiliary stream + host thread: the shortest
+ *                          single registration), 2 = one after the other on the context's stream (fewer streams and threads: the
+ *                          higher batch throughput), 0 = 2 inside a group of several pairs or with host_wait != 0, else 1.
+ *                          Results do not depend on it.
  *   group_max_points 48e6  points of all clouds that go through ONE extraction sequence of plade_registration_pairs*: a group
  *                          that holds more is registered in consecutive parts within this budget (the extraction's work area
  *                          takes ~0.9 KB of HBM per point it serves at once); results do not depend on it.  0 = default. */
@@ -87,6 +92,7 @@ typedef struct plade_params {
     int32_t match_window;
     uint32_t match_cell_budget;
     uint32_t group_max_points;
+    int32_t prepare_sides;
 } plade_params;
 void plade_default_params(plade_params *p);
 int plade_set_params(plade_ctx *ctx, const plade_params *p);

@@ -37,7 +37,7 @@ class Params(C.Structure):
                 ("init_min_support", C.c_int32), ("orient_normals", C.c_int32), ("dump", C.c_int32),
                 ("ransac_seed", C.c_uint64), ("host_wait", C.c_int32), ("unoriented_normals", C.c_int32),
                 ("ransac_topup", C.c_int32), ("match_window", C.c_int32), ("match_cell_budget", C.c_uint32),
-                ("group_max_points", C.c_uint32)]
+                ("group_max_points", C.c_uint32), ("prepare_sides", C.c_int32)]
 
 
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int32), C.c_uint32, C.c_uint32, C.c_uint32)

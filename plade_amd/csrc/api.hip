@@ -21,6 +21,7 @@ extern "C" void plade_default_params(plade_params *p) {
     p->match_window = 0;
     p->match_cell_budget = 0;
     p->group_max_points = 48000000u;
+    p->prepare_sides = 0;
     // pure: no environment look-ups here -- programs that cannot pass plade_params (the CLI, the C++ registration()
     // overloads) read their opt-in switches themselves (plade_host.cpp: context())
 }

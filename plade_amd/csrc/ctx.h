@@ -85,6 +85,7 @@ struct plade_ctx {
     plade::RansacWork *ransac_work = nullptr;
     plade_ctx *peers[PLADE_GROUP_MAX - 1] = {};   // the contexts of pairs 1.. of a group (plade_registration_pairs): stream, aux, work areas
     hipEvent_t ev_group = nullptr;   // end of a group's joint plane extraction on `stream` (the peers' streams wait for it)
+    bool in_group = false;      // this context carries one pair of a group of several (register_group)
     plade_ctx *aux = nullptr;   // second stream + work areas: stages of the source cloud that are independent of the
                                 // target's run concurrently with them
     hipStream_t stream = nullptr;

@@ -281,7 +281,18 @@ bool run_registration(plade_ctx *ctx, RegistrationWork &W, const CloudDev &tgt, 
         if (!W.ev_main) HIP_TRY(hipEventCreateWithFlags(&W.ev_main, hipEventDisableTiming));
         HIP_TRY(hipEventRecord(W.ev_main, ctx->stream));
         HIP_TRY(hipStreamWaitEvent(aux->stream, W.ev_main, 0));
+        // Alone on the GPU the two sides run side by side (the source on the auxiliary stream and a second host thread: a
+        // single registration is 0.5 ms shorter); with other registrations in flight that only doubles the streams that share
+        // the four hardware queues and adds a host thread per pair -- one side after the other on this stream: +1.5 % of the
+        // batch throughput, 0.6 ms less host CPU per registration (profiles/r4_experiments.md 2c).  plade_params.prepare_sides.
+        const int ps = ctx->params.prepare_sides;
+        const bool serial_sides = ps == 2 || (ps == 0 && (ctx->in_group || ctx->params.host_wait != 0));
+        if (serial_sides) {
+            ok_m = prepare_side(ctx, "tgt", tgt, tp, downSampleDistance, pen_grid_cell(lengthThreshold), scale, true, W.tgt_pairs, M);
+            ok_c = prepare_side(ctx, "src", src, sp, downSampleDistance, pen_grid_cell(lengthThreshold), scale, false, W.src_pairs, C);
+        }
         std::thread th([&]() {
+            if (serial_sides) return;
             const double cpu0 = thread_cpu_seconds();
             struct Acc { Stats &st; double c0; ~Acc() { st.add("cpu_prepare_helper", thread_cpu_seconds() - c0); } } acc{aux->stats, cpu0};
             (void)hipSetDevice(ctx->device);
@@ -289,7 +300,7 @@ bool run_registration(plade_ctx *ctx, RegistrationWork &W, const CloudDev &tgt, 
             catch (const Err &e) { aux_err = e; }
             catch (const std::exception &e) { aux_err = Err{PLADE_EDEVICE, e.what()}; }
         });
-        try { ok_m = prepare_side(ctx, "tgt", tgt, tp, downSampleDistance, pen_grid_cell(lengthThreshold), scale, true, W.tgt_pairs, M); }
+        try { if (!serial_sides) ok_m = prepare_side(ctx, "tgt", tgt, tp, downSampleDistance, pen_grid_cell(lengthThreshold), scale, true, W.tgt_pairs, M); }
         catch (const Err &e) { main_err = e; }
         catch (const std::exception &e) { main_err = Err{PLADE_EDEVICE, e.what()}; }   // the helper thread is still joinable here
         th.join();

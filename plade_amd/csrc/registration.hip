@@ -190,6 +190,7 @@ void register_group(plade_ctx *ctx, int first, int count, const CloudDev *const 
         pcs[i]->drop_reads();
     }
     for (int i = 0; i < count; ++i) {
+        pcs[i]->in_group = count > 1;
         ensure_pair_areas(pcs[i]);
         for (int k = 0; k < 16; ++k) T16[16 * i + k] = (k % 5 == 0) ? 1.f : 0.f;
         status[i] = PLADE_OK;

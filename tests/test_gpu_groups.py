@@ -198,3 +198,19 @@ def test_a_group_over_the_point_budget_is_registered_in_parts(scenes, alone, bud
         assert ok and np.array_equal(T, alone[i][1])
         _same(c.dump(pair=pos), alone[i][2], PLANE_KEYS + ["overlap_counts", "scores", "match_nbr"])
     c.close()
+
+
+@pytest.mark.parametrize("sides", [1, 2])
+def test_sides_of_a_pair_side_by_side_or_one_after_the_other(scenes, alone, sides):
+    """plade_params.prepare_sides: the two clouds of a pair are prepared side by side (source on the auxiliary stream and a
+    helper thread) or one after the other on the context's stream; alone and inside a group, every intermediate and the
+    transform are the same bits (`alone` was registered with the default: side by side for a single pair)."""
+    c = plade_amd.Context(0, orient_normals=1, dump=1, prepare_sides=sides)
+    ok, T = c.registration(scenes[0][0], scenes[0][1])
+    assert ok and np.array_equal(T, alone[0][1])
+    _same(c.dump(), alone[0][2], PLANE_KEYS + STAGE_KEYS)
+    res = c.registration_pairs([(scenes[1][0], scenes[1][1]), (scenes[2][0], scenes[2][1])])
+    for pos, i in enumerate((1, 2)):
+        assert res[pos][0] and np.array_equal(res[pos][1], alone[i][1])
+        _same(c.dump(pair=pos), alone[i][2], PLANE_KEYS + STAGE_KEYS)
+    c.close()
