@@ -299,7 +299,7 @@ def _cpu_budget():
 
 # busy host threads per rank, measured on the MI355X box in round 4 (tools/exp_groups.py, sleeping host waits, groups of 8 pairs,
 # host clouds): groups in flight -> busy threads (registrations/s): see profiles/r4_experiments.md
-BUSY_THREADS_BY_GROUPS = {2: 2.02, 3: 2.19, 4: 2.34}   # 663 / 725 / 749 registrations/s
+BUSY_THREADS_BY_GROUPS = {1: 1.46, 2: 1.8, 3: 2.12, 4: 2.3}   # 544 / 667 / 709-725 / 736-750 registrations/s
 
 
 def inflight_for_budget(budget, local_world):
@@ -307,7 +307,7 @@ def inflight_for_budget(budget, local_world):
     percent of GPU throughput (round 1: 287 instead of 400 reg/s under throttling), so the count is the largest one whose
     measured host load (BUSY_THREADS_BY_GROUPS), times the ranks of this node, still fits the quota with 10 % to spare."""
     per_rank = 0.9 * float(budget) / max(local_world, 1)
-    best = 2
+    best = 1
     for g in sorted(BUSY_THREADS_BY_GROUPS):
         if g <= 4 and BUSY_THREADS_BY_GROUPS[g] <= per_rank:
             best = g

@@ -312,12 +312,14 @@ bool run_registration(plade_ctx *ctx, RegistrationWork &W, const CloudDev &tgt, 
         // the verification's target grid (plade.cpp:545-564 builds a kd-tree per candidate) only needs the
         // downsampled target: built now on the idle auxiliary stream, consumed five stages later
         if (!W.ev_grid) HIP_TRY(hipEventCreateWithFlags(&W.ev_grid, hipEventDisableTiming));
-        W.grid.build(aux, M.d_ds.p, M.n_ds, 3, downSampleDistance, tgt.bbmin, tgt.bbmax, true);
+        // (in a crowd -- serial_sides -- on this stream too: no second stream per pair at all)
+        plade_ctx *gctx = serial_sides ? ctx : aux;
+        W.grid.build(gctx, M.d_ds.p, M.n_ds, 3, downSampleDistance, tgt.bbmin, tgt.bbmax, true);
         // ... and the source in a spatially blocked order for the same kernel
         if (sort_source)
-        overlap_sort_source(aux, W.ov_work, C.d_ds_soa.p, C.d_ds_soa.p + C.n_ds, C.d_ds_soa.p + 2 * (size_t)C.n_ds, C.n_ds,
+        overlap_sort_source(gctx, W.ov_work, C.d_ds_soa.p, C.d_ds_soa.p + C.n_ds, C.d_ds_soa.p + 2 * (size_t)C.n_ds, C.n_ds,
                             1.f / W.grid.gp.inv);
-        HIP_TRY(hipEventRecord(W.ev_grid, aux->stream));
+        HIP_TRY(hipEventRecord(W.ev_grid, gctx->stream));
     }
     {
         StageTimer t(ctx, "t_descriptors");   // built by prepare_side; only the optional dump is left here
