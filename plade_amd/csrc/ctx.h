@@ -41,9 +41,12 @@ struct Stats {
 namespace plade {
 // One sleeping poll of the throughput modes (params.host_wait != 0).  50 us for the first polls, 100 us after: with
 // eight registrations in flight the GPU is never idle while one host thread oversleeps, and against 15 / 40 us the
-// process spends 12 % less CPU at the same throughput (profiles/r3_experiments.md).
-inline void poll_sleep(int polls) {
-    timespec ts{0, polls < 8 ? 50000 : 100000};
+// process spends 12 % less CPU at the same throughput (profiles/r3_experiments.md).  `crowd` (the pairs of a group: 32
+// registrations in flight in batch mode): 100 / 200 us -- the same throughput for another 0.25 ms less CPU per registration
+// (10 / 20 / 50 / 100 us first polls: 762 / 763 / 761 / 762 registrations/s at 3.4 / 3.0 / 2.4 / 2.2 busy threads, r4).
+inline void poll_sleep(int polls, bool crowd = false) {
+    const long base_ns = crowd ? 100000L : 50000L;
+    timespec ts{0, polls < 8 ? base_ns : 2 * base_ns};
     nanosleep(&ts, nullptr);
 }
 inline double thread_cpu_seconds() {
@@ -261,7 +264,7 @@ struct plade_ctx {
                 const hipError_t e = hipStreamQuery(s);
                 if (e == hipSuccess) break;
                 if (e != hipErrorNotReady) throw plade::Err{-2, std::string("hipStreamQuery: ") + hipGetErrorString(e)};
-                plade::poll_sleep(polls);
+                plade::poll_sleep(polls, in_group);
             }
         }
         if (s == stream) { finish_reads(); write_arena_used = 0; ++wait_epoch; }
@@ -331,7 +334,7 @@ struct plade_ctx {
                 if (e != hipSuccess && e != hipErrorNotReady) throw plade::Err{-2, std::string("hipStreamQuery: ") + hipGetErrorString(e)};
                 if (e == hipSuccess && *flag != seq) throw plade::Err{-2, "device -> host hand-over: the stream finished without the flag"};
             }
-            if (params.host_wait != 0) plade::poll_sleep((int)polls);
+            if (params.host_wait != 0) plade::poll_sleep((int)polls, in_group);
         }
         std::atomic_thread_fence(std::memory_order_acquire);
         finish_reads();

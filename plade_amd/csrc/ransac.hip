@@ -2395,7 +2395,7 @@ void wait_iterations(plade_ctx *ctx, RResult *const *res, int nres, uint32_t wan
             if (e == hipSuccess) { if (reached()) break; throw Err{PLADE_EDEVICE, "plane extraction: the device loop did not report"}; }
             if (e != hipErrorNotReady) throw Err{PLADE_EDEVICE, std::string("hipStreamQuery: ") + hipGetErrorString(e)};
         }
-        if (ctx->params.host_wait != 0) poll_sleep((int)polls);
+        if (ctx->params.host_wait != 0) poll_sleep((int)polls, ctx->in_group);
     }
     std::atomic_thread_fence(std::memory_order_acquire);
     ++ctx->wait_epoch;   // everything queued before the reported iteration has finished
