@@ -194,7 +194,9 @@ constexpr uint32_t OV_MASK_MAX = 48u << 10;   // bytes of LDS the block mask may
 // candidate.  With `mask_words` != 0 the workgroup first copies the target grid's BLOCK mask (k_occ_pop) into LDS: a probe whose
 // <= 8 blocks are all empty -- nearly every probe of a wrong candidate, and everything outside the target -- ends without a
 // global load; only the words of non-empty blocks are fetched.
-__global__ __launch_bounds__(OV_TPB) void k_overlap(const float *__restrict__ sx, const float *__restrict__ sy,
+// (five wavefronts per SIMD: 96 registers; the probe is a chain of three load rounds, latency hidden by occupancy -- 4 waves / 100
+//  registers: 186 us at the bench's shape, 0.62 s at the stress shape; 5: 178 us, 0.575 s; 6 and 8 spill and are slower)
+__global__ __launch_bounds__(OV_TPB, 5) void k_overlap(const float *__restrict__ sx, const float *__restrict__ sy,
                                                     const float *__restrict__ sz, uint32_t n_s,
                                                     const float4 *__restrict__ tgt,
                                                     const unsigned long long *__restrict__ occ_bits,
