@@ -121,12 +121,15 @@ __global__ void k_query_offsets(const uint32_t *__restrict__ offs, uint32_t dq, 
 constexpr uint32_t RANK_MAX_LIST = 4096;
 __global__ __launch_bounds__(256) void k_rank_lists(const int64_t *__restrict__ offsets, uint32_t dq,
                                                     const uint32_t *__restrict__ t_raw, const double *__restrict__ d2_raw,
-                                                    uint32_t *__restrict__ t_out, double *__restrict__ d2_out) {
-    __shared__ double s_d2[RANK_MAX_LIST];   // one workgroup per query: its list staged in LDS (<= 4096 entries)
+                                                    uint32_t *__restrict__ t_out, double *__restrict__ d2_out, uint32_t cap) {
+    // one workgroup per query: its list staged in LDS -- as much of it as the LONGEST list of the call needs (`cap` entries of
+    // 12 bytes, dynamic: with room for 4096 entries reserved per workgroup only three fitted a CU, for lists of a few dozen)
+    extern __shared__ double s_rank[];
+    double *s_d2 = s_rank;
+    uint32_t *s_t = reinterpret_cast<uint32_t *>(s_rank + cap);
     const uint32_t q = blockIdx.x;
     if (q >= dq) return;
     const uint32_t b = (uint32_t)offsets[q], e = (uint32_t)offsets[q + 1], len = e - b;
-    __shared__ uint32_t s_t[RANK_MAX_LIST];
     for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) { s_d2[i] = d2_raw[b + i]; s_t[i] = t_raw[b + i]; }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) {
@@ -325,7 +328,8 @@ uint64_t MatchResult::run_windowed(plade_ctx *ctx, const float *d_qry, uint32_t 
     t_idx.ensure(m); dist2.ensure(m);
     q_idx_sorted = q_raw.p;
     if (max_list <= RANK_MAX_LIST) {
-        hipLaunchKernelGGL(k_rank_lists, dim3(dq), dim3(256), 0, ctx->stream, offsets.p, dq, t_raw.p, d2_raw.p, t_idx.p, dist2.p);
+        const uint32_t cap = std::max(64u, (max_list + 63u) & ~63u);   // entries of LDS per workgroup
+        hipLaunchKernelGGL(k_rank_lists, dim3(dq), dim3(256), cap * 12, ctx->stream, offsets.p, dq, t_raw.p, d2_raw.p, t_idx.p, dist2.p, cap);
         HIP_TRY(hipGetLastError());
         return total;
     }
@@ -389,8 +393,9 @@ uint64_t MatchResult::run(plade_ctx *ctx, const float *d_qry, uint32_t dq, const
     t_idx.ensure(m); dist2.ensure(m);
     q_idx_sorted = q_raw.p;   // lists are contiguous per query
     if (max_list <= RANK_MAX_LIST) {
-        hipLaunchKernelGGL(k_rank_lists, dim3(dq), dim3(256), 0, ctx->stream, offsets.p, dq, t_raw.p, d2_raw.p, t_idx.p,
-                           dist2.p);
+        const uint32_t cap = std::max(64u, (max_list + 63u) & ~63u);   // entries of LDS per workgroup
+        hipLaunchKernelGGL(k_rank_lists, dim3(dq), dim3(256), cap * 12, ctx->stream, offsets.p, dq, t_raw.p, d2_raw.p, t_idx.p,
+                           dist2.p, cap);
         HIP_TRY(hipGetLastError());
         return total;
     }
