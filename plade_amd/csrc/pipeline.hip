@@ -84,7 +84,7 @@ void make_line_table(const float *coef, uint32_t P, f3 bcenter, double radius, L
 }
 
 bool prepare_side(plade_ctx *ctx, const char *tag, const CloudDev &cloud, const PlaneSetView &pl, float leaf, float pen_cell,
-                  float desc_scale, bool is_target, PairTableDev &pairs, Side &S) {
+                  float desc_scale, bool is_target, PairTableDev &pairs, Side &S, bool finish = true) {
     const uint32_t P = pl.P;
     Clock::time_point tp0 = Clock::now();
     // whole cloud: DownSamplePointCloud (plade.cpp:77-79 / :292-294) and the per-plane clouds in one pass
@@ -162,8 +162,9 @@ bool prepare_side(plade_ctx *ctx, const char *tag, const CloudDev &cloud, const 
     // line-pair descriptors of this side (K4); both sides build theirs concurrently
     build_pair_table(ctx, S.lines, S.normals.data(), P, desc_scale, is_target, pairs);
     // everything this side produced is consumed on the OTHER stream (match, transforms, penetration run on the
-    // main stream, the source side is prepared on the auxiliary one): finish it before handing over
-    ctx->sync();
+    // main stream, the source side is prepared on the auxiliary one): finish it before handing over.  (One side after the other
+    // on ONE stream: the first side's last read-back -- the size of its descriptor table -- rides on the second side's waits.)
+    if (finish || ctx->params.dump) ctx->sync();
     ctx->stats.add(std::string("t_prep_lines_") + tag, secs_since(tp0));
     if (ctx->params.dump) {
         const std::string t(tag);
@@ -288,8 +289,9 @@ bool run_registration(plade_ctx *ctx, RegistrationWork &W, const CloudDev &tgt, 
         const int ps = ctx->params.prepare_sides;
         const bool serial_sides = ps == 2 || (ps == 0 && (ctx->in_group || ctx->params.host_wait != 0));
         if (serial_sides) {
-            ok_m = prepare_side(ctx, "tgt", tgt, tp, downSampleDistance, pen_grid_cell(lengthThreshold), scale, true, W.tgt_pairs, M);
+            ok_m = prepare_side(ctx, "tgt", tgt, tp, downSampleDistance, pen_grid_cell(lengthThreshold), scale, true, W.tgt_pairs, M, false);
             ok_c = prepare_side(ctx, "src", src, sp, downSampleDistance, pen_grid_cell(lengthThreshold), scale, false, W.src_pairs, C);
+            if (!ok_c) ctx->sync();   // the source side gave up before its last wait: the target side's read-back is still out
         }
         std::thread th([&]() {
             if (serial_sides) return;
