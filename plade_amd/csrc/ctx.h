@@ -64,6 +64,8 @@ inline void relax_timer_slack() {
 namespace plade {
 // look-back words and tile ticket of the single-launch scans (prims.hip: never reset, see scan_ticket)
 struct ScanWork { DBuf<uint64_t> state; DBuf<uint32_t> ticket; uint32_t base = 0, gen = 0; };
+// scratch of voxel_whole_batch (voxel.h): keys / values of the concatenated clouds, run heads, coordinates in voxel order
+struct VoxBatchWork { DBuf<uint32_t> keys, keys2, vals, vals2, heads; DBuf<float> sorted_xyz; };
 }  // namespace plade
 
 namespace plade {
@@ -381,6 +383,7 @@ struct plade_ctx {
         if (changed) throw plade::Err{-2, "PLADE_DEBUG_READS: a range noted by d2h() changed before the wait that delivers it"};
     }
     plade::ScanWork scan;
+    plade::VoxBatchWork vox_batch;   // the whole-cloud voxel grids of a group's clouds (voxel_whole_batch)
     // the radix sort's two global digit histograms (radix_sort.hip) and the number of sorts issued on this context
     plade::DBuf<uint32_t> sort_ghist;
     uint32_t sort_seq = 0;

@@ -286,6 +286,231 @@ void VoxelWork::enqueue(plade_ctx *ctx, const float *d_xyz, uint32_t stride, con
     n_pending = 1;
 }
 
+void VoxelWork::adopt_batch(plade_ctx *ctx) {
+    n_out = 0;
+    ctx->d2h(&n_pending_host, count.p, 4);   // valid after the next sync of this stream
+    n_pending = 1;
+}
+
+// ---- the whole-cloud grids of several clouds in one launch sequence (voxel.h) ------------------------------------------------
+constexpr int VB_MAX = 16;
+struct VBCloud {
+    const float *sx, *sy, *sz, *aos;
+    uint32_t n;
+    float inv;
+    int lminx, lminy, lminz, bx, by;
+    float *out_xyz, *out_soa;
+    uint32_t *count, *group_offsets;
+};
+struct VBArgs {
+    VBCloud c[VB_MAX];
+    uint32_t ncl;
+    uint32_t start[VB_MAX + 1];        // first item of cloud g in the concatenated arrays
+    uint32_t tile_start[VB_MAX + 1];   // first tile of VR_TILE sorted positions
+    uint32_t cblk_start[VB_MAX + 1];   // first workgroup of the centroid kernel
+    uint32_t total;
+};
+__device__ __forceinline__ uint32_t vb_find(const uint32_t *start, uint32_t ncl, uint32_t v) {
+    uint32_t g = 0;
+#pragma unroll
+    for (int q = 1; q < VB_MAX; ++q) g += (q < (int)ncl && v >= start[q]) ? 1u : 0u;
+    return g;
+}
+
+__global__ void k_vb_keys(const VBArgs A, uint32_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= A.total) return;
+    const uint32_t g = vb_find(A.start, A.ncl, t);
+    const VBCloud &C = A.c[g];
+    const uint32_t i = t - A.start[g];
+    const float x = C.sx[i], y = C.sy[i], z = C.sz[i];
+    // voxel_grid.hpp:330-332, as k_voxel_keys
+    const uint32_t lx = (uint32_t)((int)floorf(x * C.inv) - C.lminx);
+    const uint32_t ly = (uint32_t)((int)floorf(y * C.inv) - C.lminy);
+    const uint32_t lz = (uint32_t)((int)floorf(z * C.inv) - C.lminz);
+    keys[t] = (lz << (C.bx + C.by)) | (ly << C.bx) | lx;
+    vals[t] = i;
+}
+
+// k_voxel_runs for the concatenated clouds: a tile belongs to one cloud, the look-back stops at the cloud's first tile
+__global__ __launch_bounds__(VR_T) void k_vb_runs(const VBArgs A, const uint32_t *__restrict__ keys_all, const uint32_t *__restrict__ vals_all,
+                                                  uint64_t *__restrict__ state_all, uint32_t *__restrict__ ticket, uint32_t base, uint32_t gen,
+                                                  uint32_t *__restrict__ heads_all, float *__restrict__ sorted_all) {
+    __shared__ uint32_t s_tile, s_w[VR_T / 64], s_excl;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_tile = atomicAdd(ticket, 1u) - base;
+    __syncthreads();
+    const uint32_t gtile = s_tile;
+    const uint32_t g = vb_find(A.tile_start, A.ncl, gtile);
+    const VBCloud &C = A.c[g];
+    const uint32_t tile = gtile - A.tile_start[g], n = C.n;
+    const uint32_t *__restrict__ keys = keys_all + A.start[g];
+    const uint32_t *__restrict__ vals = vals_all + A.start[g];
+    uint64_t *__restrict__ state = state_all + A.tile_start[g];
+    uint32_t *__restrict__ heads = heads_all + A.start[g] + g;   // n + 1 slots per cloud
+    float *__restrict__ ox = sorted_all + A.start[g], *__restrict__ oy = ox + A.total, *__restrict__ oz = oy + A.total;
+    float gx[VR_I], gy[VR_I], gz[VR_I];
+#pragma unroll
+    for (int q = 0; q < VR_I; ++q) {
+        const uint32_t j = tile * VR_TILE + q * VR_T + tid;
+        if (j < n) {
+            const float *r = C.aos + (size_t)vals[j] * 6;
+            gx[q] = r[0]; gy[q] = r[1]; gz[q] = r[2];
+        }
+    }
+    const uint32_t first = tile * VR_TILE + tid * VR_I;
+    uint32_t k[VR_I + 1];
+    k[0] = (first > 0 && first <= n) ? keys[first - 1] : 0xffffffffu;
+#pragma unroll
+    for (int q = 0; q < VR_I; ++q) k[q + 1] = first + q < n ? keys[first + q] : 0xffffffffu;
+    uint32_t fl = 0, sum = 0;
+#pragma unroll
+    for (int q = 0; q < VR_I; ++q) {
+        const bool head = first + q < n && (first + q == 0 || k[q + 1] != k[q]);
+        fl |= (head ? 1u : 0u) << q;
+        sum += head;
+    }
+    uint32_t incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += o;
+    }
+    if (lane == 63) s_w[wave] = incl;
+    __syncthreads();
+    uint32_t agg = 0, woff = 0;
+    for (int w = 0; w < VR_T / 64; ++w) { if (w < wave) woff += s_w[w]; agg += s_w[w]; }
+    const uint64_t tag = (uint64_t)gen << 34;
+    if (wave == 0) {
+        if (lane == 0)
+            __hip_atomic_store(state + tile, tag | (tile == 0 ? VR_PREFIX : VR_AGG) | agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t excl = 0;
+        if (tile > 0) {
+            int t = (int)tile - 1;
+            for (;;) {
+                const int idx = t - lane;
+                uint64_t st = tag | VR_PREFIX;
+                if (idx >= 0) st = __hip_atomic_load(state + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const bool ready = (st >> 34) == gen && (st & VR_STATUS) != 0ull;
+                const unsigned long long not_ready = __ballot(!ready), is_prefix = __ballot(ready && (st & VR_PREFIX));
+                const int first_bad = not_ready ? __ffsll((long long)not_ready) - 1 : 64;
+                const int first_pre = is_prefix ? __ffsll((long long)is_prefix) - 1 : 64;
+                const int take = first_pre < first_bad ? first_pre + 1 : first_bad;
+                uint32_t part = lane < take ? (uint32_t)st : 0u;
+                for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
+                excl += part;
+                if (first_pre < first_bad) break;
+                t -= take;
+            }
+            if (lane == 0)
+                __hip_atomic_store(state + tile, tag | VR_PREFIX | (uint64_t)(excl + agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (lane == 0) s_excl = excl;
+    }
+    __syncthreads();
+    uint32_t rank = s_excl + woff + incl - sum;
+#pragma unroll
+    for (int q = 0; q < VR_I; ++q)
+        if (fl & (1u << q)) { heads[rank] = first + q; ++rank; }
+    if ((uint64_t)tile * VR_TILE + VR_TILE >= n && tid == VR_T - 1) *C.count = s_excl + agg;   // the cloud's last tile
+#pragma unroll
+    for (int q = 0; q < VR_I; ++q) {
+        const uint32_t j = tile * VR_TILE + q * VR_T + tid;
+        if (j < n) { ox[j] = gx[q]; oy[j] = gy[q]; oz[j] = gz[q]; }
+    }
+}
+
+// k_voxel_centroids for the concatenated clouds (one group per cloud: group_offsets = {0, voxels})
+__global__ __launch_bounds__(128) void k_vb_centroids(const VBArgs A, const uint32_t *__restrict__ heads_all, const float *__restrict__ sorted_all) {
+    constexpr uint32_t CH = 2048;
+    __shared__ float s_x[CH], s_y[CH], s_z[CH];
+    __shared__ uint32_t s_span[2];
+    const uint32_t g = vb_find(A.cblk_start, A.ncl, blockIdx.x);
+    const VBCloud &C = A.c[g];
+    const uint32_t blk = blockIdx.x - A.cblk_start[g];
+    const uint32_t n_seg = *C.count, n_items = C.n;
+    if (blk == 0 && threadIdx.x == 0) { C.group_offsets[0] = 0u; C.group_offsets[1] = n_seg; }
+    const uint32_t *__restrict__ heads = heads_all + A.start[g] + g;
+    const float *__restrict__ sx = sorted_all + A.start[g], *__restrict__ sy = sx + A.total, *__restrict__ sz = sy + A.total;
+    const uint32_t s0 = blk * blockDim.x;
+    if (s0 >= n_seg) return;
+    const uint32_t s = s0 + threadIdx.x;
+    const bool live = s < n_seg;
+    const uint32_t b = live ? heads[s] : 0u, e = live ? ((s + 1 < n_seg) ? heads[s + 1] : n_items) : 0u;
+    if (threadIdx.x == 0) s_span[0] = b;
+    if (s == min(n_seg, s0 + (uint32_t)blockDim.x) - 1) s_span[1] = e;
+    __syncthreads();
+    const uint32_t span_b = s_span[0], span_e = s_span[1];
+    float ax = 0.f, ay = 0.f, az = 0.f;
+    for (uint32_t c0 = span_b; c0 < span_e; c0 += CH) {
+        const uint32_t c1 = min(span_e, c0 + CH);
+        for (uint32_t j = c0 + threadIdx.x; j < c1; j += blockDim.x) { s_x[j - c0] = sx[j]; s_y[j - c0] = sy[j]; s_z[j - c0] = sz[j]; }
+        __syncthreads();
+        const uint32_t jb = max(b, c0), je = min(e, c1);
+        for (uint32_t j = jb; j < je; ++j) { ax += s_x[j - c0]; ay += s_y[j - c0]; az += s_z[j - c0]; }
+        __syncthreads();
+    }
+    if (!live) return;
+    const float cnt = (float)(e - b);
+    const float cx = ax / cnt, cy = ay / cnt, cz = az / cnt;
+    C.out_xyz[3 * (size_t)s] = cx; C.out_xyz[3 * (size_t)s + 1] = cy; C.out_xyz[3 * (size_t)s + 2] = cz;
+    C.out_soa[s] = cx; C.out_soa[(size_t)n_seg + s] = cy; C.out_soa[2 * (size_t)n_seg + s] = cz;
+}
+
+bool voxel_whole_batch(plade_ctx *ctx, VoxBatchWork &B, int count, const VoxBatchItem *items) {
+    if (count < 1 || count > VB_MAX) return false;
+    VBArgs A;
+    memset(&A, 0, sizeof(A));
+    A.ncl = (uint32_t)count;
+    auto bits_for = [](int64_t range) { int b = 1; while (((int64_t)1 << b) <= range) ++b; return b; };
+    int max_bits = 1;
+    uint64_t total = 0;
+    for (int g = 0; g < count; ++g) {
+        const VoxBatchItem &it = items[g];
+        if (it.n == 0 || !(it.leaf > 0.f) || !it.work || !it.out_soa) return false;
+        const float inv = 1.f / it.leaf;
+        const int lmin[3] = {(int)floorf(it.bbmin[0] * inv), (int)floorf(it.bbmin[1] * inv), (int)floorf(it.bbmin[2] * inv)};
+        const int lmax[3] = {(int)floorf(it.bbmax[0] * inv), (int)floorf(it.bbmax[1] * inv), (int)floorf(it.bbmax[2] * inv)};
+        for (int k = 0; k < 3; ++k)
+            if ((int64_t)lmax[k] - lmin[k] >= (1 << 18)) return false;
+        const int64_t dx = (int64_t)((it.bbmax[0] - it.bbmin[0]) * inv) + 1, dy = (int64_t)((it.bbmax[1] - it.bbmin[1]) * inv) + 1,
+                      dz = (int64_t)((it.bbmax[2] - it.bbmin[2]) * inv) + 1;
+        if (dx * dy * dz > (int64_t)INT32_MAX) return false;
+        const int bx = bits_for((int64_t)lmax[0] - lmin[0]), by = bits_for((int64_t)lmax[1] - lmin[1]), bz = bits_for((int64_t)lmax[2] - lmin[2]);
+        if (bx + by + bz > 31) return false;
+        max_bits = std::max(max_bits, bx + by + bz);
+        VBCloud &C = A.c[g];
+        C.sx = it.sx; C.sy = it.sy; C.sz = it.sz; C.aos = it.aos; C.n = it.n; C.inv = inv;
+        C.lminx = lmin[0]; C.lminy = lmin[1]; C.lminz = lmin[2]; C.bx = bx; C.by = by;
+        VoxelWork &w = *it.work;
+        w.out_xyz.ensure((size_t)it.n * 3 + 4);
+        w.group_offsets.ensure(4);
+        w.count.ensure(4);
+        w.n_out = 0; w.n_pending = 0;
+        C.out_xyz = w.out_xyz.p; C.out_soa = it.out_soa; C.count = w.count.p; C.group_offsets = w.group_offsets.p;
+        A.start[g + 1] = A.start[g] + it.n;
+        A.tile_start[g + 1] = A.tile_start[g] + cdiv(it.n, VR_TILE);
+        A.cblk_start[g + 1] = A.cblk_start[g] + cdiv(it.n, 128);
+        total += it.n;
+    }
+    if (total >= (1ull << 30)) return false;
+    for (int g = count; g < VB_MAX; ++g) { A.c[g] = A.c[0]; A.start[g + 1] = A.start[g]; A.tile_start[g + 1] = A.tile_start[g]; A.cblk_start[g + 1] = A.cblk_start[g]; }
+    A.total = (uint32_t)total;
+    B.keys.ensure(total); B.keys2.ensure(total); B.vals.ensure(total); B.vals2.ensure(total);
+    B.heads.ensure(total + VB_MAX + 1);
+    B.sorted_xyz.ensure(3 * total + 4);
+    hipStream_t st = ctx->stream;
+    hipLaunchKernelGGL(k_vb_keys, dim3(cdiv(total, 256)), dim3(256), 0, st, A, B.keys.p, B.vals.p);
+    radix_sort_segments_u32(ctx, B.keys.p, B.keys2.p, B.vals.p, B.vals2.p, A.start, count, max_bits);
+    const uint32_t tiles = A.tile_start[count];
+    const ScanTicket t = scan_ticket(ctx, (size_t)tiles * VR_TILE, VR_TILE);
+    hipLaunchKernelGGL(k_vb_runs, dim3(tiles), dim3(VR_T), 0, st, A, B.keys2.p, B.vals2.p, t.state, t.ticket, t.base, t.gen, B.heads.p,
+                       B.sorted_xyz.p);
+    hipLaunchKernelGGL(k_vb_centroids, dim3(A.cblk_start[count]), dim3(128), 0, st, A, B.heads.p, B.sorted_xyz.p);
+    HIP_TRY(hipGetLastError());
+    return true;
+}
+
 uint32_t VoxelWork::finish(plade_ctx *ctx) {
     if (!n_pending) return n_out;
     ctx->sync();

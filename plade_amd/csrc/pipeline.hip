@@ -44,6 +44,7 @@ struct Side {
     std::vector<float> normals;  // P x 3
     LineTableHost lines;
     VoxelWork vox_all, vox_planes;
+    bool vox_all_ready = false;  // the whole-cloud grid of the coming registration was queued with the group's (voxel_whole_batch)
     ObbWork obb;
     DBuf<uint32_t> d_items, d_offs;
 };
@@ -90,6 +91,8 @@ bool prepare_side(plade_ctx *ctx, const char *tag, const CloudDev &cloud, const 
     // whole cloud: DownSamplePointCloud (plade.cpp:77-79 / :292-294) and the per-plane clouds in one pass
     // (plade.cpp:93-105 / :308-319): both voxel-grid runs are queued before the host waits for either
     S.d_ds_soa.ensure(3 * (size_t)cloud.n + 4);   // the centroid kernel writes the SoA copy too (pitch = voxel count)
+    if (S.vox_all_ready) { S.vox_all_ready = false; S.vox_all.adopt_batch(ctx); }   // queued with the group's grids (registration.hip)
+    else
     S.vox_all.enqueue(ctx, cloud.aos.p, 6, cloud.x(), cloud.y(), cloud.z(), nullptr, nullptr, cloud.n, 1, leaf, cloud.bbmin, cloud.bbmax,
                       false, false, S.d_ds_soa.p);
     const uint32_t n_items = (uint32_t)pl.offsets[P];
@@ -227,6 +230,11 @@ void MirroredPlanes::build(const float *coef_in, const int32_t *offsets_in, cons
 }
 
 RegistrationWork *registration_work_create() { return new RegistrationWork; }
+WholeVoxelSlot whole_voxel_slot(RegistrationWork &W, bool target, uint32_t n) {
+    Side &S = target ? W.M : W.C;
+    S.d_ds_soa.ensure(3 * (size_t)n + 4);
+    return WholeVoxelSlot{&S.vox_all, S.d_ds_soa.p, &S.vox_all_ready};
+}
 void registration_work_destroy(RegistrationWork *w) { delete w; }
 
 float source_spacing(plade_ctx *ctx, RegistrationWork &W, const CloudDev &src) {

@@ -191,6 +191,7 @@ void register_group(plade_ctx *ctx, int first, int count, const CloudDev *const 
     }
     for (int i = 0; i < count; ++i) {
         pcs[i]->in_group = count > 1;
+        if (pcs[i]->reg_work) { *whole_voxel_slot(*pcs[i]->reg_work, true, 0).ready = false; *whole_voxel_slot(*pcs[i]->reg_work, false, 0).ready = false; }
         ensure_pair_areas(pcs[i]);
         for (int k = 0; k < 16; ++k) T16[16 * i + k] = (k % 5 == 0) ? 1.f : 0.f;
         status[i] = PLADE_OK;
@@ -219,6 +220,31 @@ void register_group(plade_ctx *ctx, int first, int count, const CloudDev *const 
         extract_clouds(ctx, 2 * count, clouds, init, auto_tune, outs, stat_ctx, tags, ctx->params.dump != 0);
         StageTimer ts(ctx, "t_spacing");
         for (int i = 0; i < count; ++i) have_spacing[i] = ransac_spacing_finish(ctx, *ctx->ransac_work, 2 * i + 1, &spacing[i]);
+    }
+    // The whole-cloud voxel grids of all clouds of the group (DownSamplePointCloud, plade.cpp:77-79 / :292-294: leaf = 4 x the
+    // pair's point spacing) in ONE launch sequence on this stream -- 7 launches instead of 7 per cloud; doubling the per-cloud grids
+    // was measured to cost the batch 8 % -- written where every pair's preparation expects its own (pipeline.hip: prepare_side).
+    if (count > 1 && ctx->params.prepare_sides != 1) {
+        bool all = true;
+        for (int i = 0; i < count; ++i) all = all && have_spacing[i] && planes[2 * i].P() && planes[2 * i + 1].P();
+        if (all) {
+            StageTimer tv(ctx, "t_group_voxel");
+            VoxBatchItem items[2 * PLADE_GROUP_MAX];
+            bool *ready[2 * PLADE_GROUP_MAX];
+            for (int i = 0; i < count; ++i)
+                for (int side = 0; side < 2; ++side) {
+                    const CloudDev &c = side ? *src[i] : *tgt[i];
+                    const WholeVoxelSlot slot = whole_voxel_slot(*pcs[i]->reg_work, side == 0, c.n);
+                    VoxBatchItem &it = items[2 * i + side];
+                    it.aos = c.aos.p; it.sx = c.x(); it.sy = c.y(); it.sz = c.z(); it.n = c.n;
+                    it.leaf = spacing[i] * 4;   // pipeline.hip: downSampleDistance
+                    for (int k = 0; k < 3; ++k) { it.bbmin[k] = c.bbmin[k]; it.bbmax[k] = c.bbmax[k]; }
+                    it.work = slot.work; it.out_soa = slot.out_soa;
+                    ready[2 * i + side] = slot.ready;
+                }
+            if (voxel_whole_batch(ctx, ctx->vox_batch, 2 * count, items))
+                for (int q = 0; q < 2 * count; ++q) *ready[q] = true;
+        }
     }
     if (count == 1 && pcs[0] == ctx) {
         status[0] = register_tail(ctx, ctx, 0, *tgt[0], *src[0], planes[0], planes[1], auto_tune, have_spacing[0], spacing[0], T16, t0);
@@ -251,6 +277,10 @@ void register_group(plade_ctx *ctx, int first, int count, const CloudDev *const 
     }
     tail(0);
     for (int i = 1; i < count; ++i) ths[i].join();
+    for (int i = 0; i < count; ++i) {   // a pair that gave up before its preparation must not leave its grid marked as queued
+        *whole_voxel_slot(*pcs[i]->reg_work, true, 0).ready = false;
+        *whole_voxel_slot(*pcs[i]->reg_work, false, 0).ready = false;
+    }
     for (int i = 0; i < count; ++i)
         if (errs[i].code) { pcs[i]->drop_reads(); pcs[i]->last_error = errs[i].msg; status[i] = errs[i].code; }
 }

@@ -28,8 +28,27 @@ struct VoxelWork {
     // soa_indexed: the items are POSITIONS in the SoA planes d_soa_* (e.g. the extraction's Morton-ordered copy, whose
     // plane lists are ascending positions: the gathers then walk memory almost in order) instead of rows of d_xyz
     uint32_t finish(plade_ctx *ctx);
+    // The grid has been queued by voxel_whole_batch (below) on another stream that `ctx`'s stream already waits for: note the
+    // read-back of its size here; finish(ctx) delivers it.
+    void adopt_batch(plade_ctx *ctx);
     uint32_t n_pending = 0, n_pending_host = 0;
 };
+
+// The whole-cloud grids (n_groups = 1, items = all points in input order) of up to 16 clouds in ONE launch sequence: keys of all
+// clouds, one segmented sort, runs and centroids of all clouds -- 7 launches instead of 7 per cloud (the clouds of a group of
+// pairs, registration.hip).  Every cloud's result lands in ITS VoxelWork (out_xyz, count, group_offsets) and out_soa exactly as
+// VoxelWork::enqueue would leave it: same keys, same stable order inside a voxel, same sums.
+struct VoxBatchItem {
+    const float *aos, *sx, *sy, *sz;   // the cloud: N x 6 rows and its SoA planes
+    uint32_t n;
+    float leaf, bbmin[3], bbmax[3];
+    VoxelWork *work;
+    float *out_soa;                    // >= 3 n floats
+};
+// (VoxBatchWork, the batch's scratch arrays, lives in ctx.h: every context owns one)
+// false (nothing queued): the batch does not fit this path (an empty cloud, keys wider than 31 bits, a grid PCL would refuse)
+// -- the caller lets every pair build its own grid, which reports what is wrong where it belongs
+bool voxel_whole_batch(plade_ctx *ctx, VoxBatchWork &B, int count, const VoxBatchItem *items);
 
 struct TargetGrid;
 // average_spacing (code/PLADE/util.cpp:1619-1648) of a strided device xyz array with known bbox
