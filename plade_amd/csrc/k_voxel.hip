@@ -295,11 +295,13 @@ void VoxelWork::adopt_batch(plade_ctx *ctx) {
 // ---- the whole-cloud grids of several clouds in one launch sequence (voxel.h) ------------------------------------------------
 constexpr int VB_MAX = 16;
 struct VBCloud {
-    const float *sx, *sy, *sz, *aos;
-    uint32_t n;
+    const float *sx, *sy, *sz, *aos;   // whole cloud: its SoA planes (keys) and N x 6 rows (gather); item lists: the SoA planes the items index
+    const uint32_t *items;             // item i = position items[i] in sx / sy / sz (nullptr: item i = point i)
+    const uint32_t *offs;              // P + 1 ascending item offsets: group g = items [offs[g], offs[g + 1]) (nullptr: one group)
+    uint32_t n, P;
     float inv;
-    int lminx, lminy, lminz, bx, by;
-    float *out_xyz, *out_soa;
+    int lminx, lminy, lminz, bx, by, gshift;   // gshift = bx + by + bz: the group id sits above the voxel index
+    float *out_xyz, *out_soa;          // out_soa may be nullptr
     uint32_t *count, *group_offsets;
 };
 struct VBArgs {
@@ -323,19 +325,27 @@ __global__ void k_vb_keys(const VBArgs A, uint32_t *__restrict__ keys, uint32_t 
     const uint32_t g = vb_find(A.start, A.ncl, t);
     const VBCloud &C = A.c[g];
     const uint32_t i = t - A.start[g];
-    const float x = C.sx[i], y = C.sy[i], z = C.sz[i];
+    const uint32_t p = C.items ? C.items[i] : i;
+    const float x = C.sx[p], y = C.sy[p], z = C.sz[p];
     // voxel_grid.hpp:330-332, as k_voxel_keys
     const uint32_t lx = (uint32_t)((int)floorf(x * C.inv) - C.lminx);
     const uint32_t ly = (uint32_t)((int)floorf(y * C.inv) - C.lminy);
     const uint32_t lz = (uint32_t)((int)floorf(z * C.inv) - C.lminz);
-    keys[t] = (lz << (C.bx + C.by)) | (ly << C.bx) | lx;
+    uint32_t grp = 0;
+    if (C.offs) {   // last group whose first item is <= i
+        uint32_t lo = 0, hi = C.P;
+        while (lo < hi) { const uint32_t mid = (lo + hi + 1) >> 1; if (C.offs[mid] <= i) lo = mid; else hi = mid - 1; }
+        grp = lo;
+    }
+    keys[t] = (grp << C.gshift) | (lz << (C.bx + C.by)) | (ly << C.bx) | lx;
     vals[t] = i;
 }
 
 // k_voxel_runs for the concatenated clouds: a tile belongs to one cloud, the look-back stops at the cloud's first tile
 __global__ __launch_bounds__(VR_T) void k_vb_runs(const VBArgs A, const uint32_t *__restrict__ keys_all, const uint32_t *__restrict__ vals_all,
                                                   uint64_t *__restrict__ state_all, uint32_t *__restrict__ ticket, uint32_t base, uint32_t gen,
-                                                  uint32_t *__restrict__ heads_all, float *__restrict__ sorted_all) {
+                                                  uint32_t *__restrict__ heads_all, uint32_t *__restrict__ seg_group_all,
+                                                  float *__restrict__ sorted_all) {
     __shared__ uint32_t s_tile, s_w[VR_T / 64], s_excl;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) s_tile = atomicAdd(ticket, 1u) - base;
@@ -348,14 +358,15 @@ __global__ __launch_bounds__(VR_T) void k_vb_runs(const VBArgs A, const uint32_t
     const uint32_t *__restrict__ vals = vals_all + A.start[g];
     uint64_t *__restrict__ state = state_all + A.tile_start[g];
     uint32_t *__restrict__ heads = heads_all + A.start[g] + g;   // n + 1 slots per cloud
+    uint32_t *__restrict__ seg_group = seg_group_all + A.start[g] + g;
     float *__restrict__ ox = sorted_all + A.start[g], *__restrict__ oy = ox + A.total, *__restrict__ oz = oy + A.total;
     float gx[VR_I], gy[VR_I], gz[VR_I];
 #pragma unroll
     for (int q = 0; q < VR_I; ++q) {
         const uint32_t j = tile * VR_TILE + q * VR_T + tid;
         if (j < n) {
-            const float *r = C.aos + (size_t)vals[j] * 6;
-            gx[q] = r[0]; gy[q] = r[1]; gz[q] = r[2];
+            if (C.items) { const uint32_t p = C.items[vals[j]]; gx[q] = C.sx[p]; gy[q] = C.sy[p]; gz[q] = C.sz[p]; }
+            else { const float *r = C.aos + (size_t)vals[j] * 6; gx[q] = r[0]; gy[q] = r[1]; gz[q] = r[2]; }
         }
     }
     const uint32_t first = tile * VR_TILE + tid * VR_I;
@@ -411,7 +422,7 @@ __global__ __launch_bounds__(VR_T) void k_vb_runs(const VBArgs A, const uint32_t
     uint32_t rank = s_excl + woff + incl - sum;
 #pragma unroll
     for (int q = 0; q < VR_I; ++q)
-        if (fl & (1u << q)) { heads[rank] = first + q; ++rank; }
+        if (fl & (1u << q)) { heads[rank] = first + q; seg_group[rank] = k[q + 1] >> C.gshift; ++rank; }
     if ((uint64_t)tile * VR_TILE + VR_TILE >= n && tid == VR_T - 1) *C.count = s_excl + agg;   // the cloud's last tile
 #pragma unroll
     for (int q = 0; q < VR_I; ++q) {
@@ -421,7 +432,8 @@ __global__ __launch_bounds__(VR_T) void k_vb_runs(const VBArgs A, const uint32_t
 }
 
 // k_voxel_centroids for the concatenated clouds (one group per cloud: group_offsets = {0, voxels})
-__global__ __launch_bounds__(128) void k_vb_centroids(const VBArgs A, const uint32_t *__restrict__ heads_all, const float *__restrict__ sorted_all) {
+__global__ __launch_bounds__(128) void k_vb_centroids(const VBArgs A, const uint32_t *__restrict__ heads_all,
+                                                      const uint32_t *__restrict__ seg_group_all, const float *__restrict__ sorted_all) {
     constexpr uint32_t CH = 2048;
     __shared__ float s_x[CH], s_y[CH], s_z[CH];
     __shared__ uint32_t s_span[2];
@@ -429,8 +441,15 @@ __global__ __launch_bounds__(128) void k_vb_centroids(const VBArgs A, const uint
     const VBCloud &C = A.c[g];
     const uint32_t blk = blockIdx.x - A.cblk_start[g];
     const uint32_t n_seg = *C.count, n_items = C.n;
-    if (blk == 0 && threadIdx.x == 0) { C.group_offsets[0] = 0u; C.group_offsets[1] = n_seg; }
     const uint32_t *__restrict__ heads = heads_all + A.start[g] + g;
+    if (blk == 0) {   // first voxel of every group, empty groups included (as k_voxel_centroids)
+        const uint32_t *__restrict__ seg_group = seg_group_all + A.start[g] + g;
+        for (uint32_t q = threadIdx.x; q <= C.P; q += blockDim.x) {
+            uint32_t lo = 0, hi = n_seg;
+            while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (seg_group[mid] < q) lo = mid + 1; else hi = mid; }
+            C.group_offsets[q] = lo;
+        }
+    }
     const float *__restrict__ sx = sorted_all + A.start[g], *__restrict__ sy = sx + A.total, *__restrict__ sz = sy + A.total;
     const uint32_t s0 = blk * blockDim.x;
     if (s0 >= n_seg) return;
@@ -454,7 +473,7 @@ __global__ __launch_bounds__(128) void k_vb_centroids(const VBArgs A, const uint
     const float cnt = (float)(e - b);
     const float cx = ax / cnt, cy = ay / cnt, cz = az / cnt;
     C.out_xyz[3 * (size_t)s] = cx; C.out_xyz[3 * (size_t)s + 1] = cy; C.out_xyz[3 * (size_t)s + 2] = cz;
-    C.out_soa[s] = cx; C.out_soa[(size_t)n_seg + s] = cy; C.out_soa[2 * (size_t)n_seg + s] = cz;
+    if (C.out_soa) { C.out_soa[s] = cx; C.out_soa[(size_t)n_seg + s] = cy; C.out_soa[2 * (size_t)n_seg + s] = cz; }
 }
 
 bool voxel_whole_batch(plade_ctx *ctx, VoxBatchWork &B, int count, const VoxBatchItem *items) {
@@ -465,9 +484,11 @@ bool voxel_whole_batch(plade_ctx *ctx, VoxBatchWork &B, int count, const VoxBatc
     auto bits_for = [](int64_t range) { int b = 1; while (((int64_t)1 << b) <= range) ++b; return b; };
     int max_bits = 1;
     uint64_t total = 0;
+    size_t n_offs = 0;
     for (int g = 0; g < count; ++g) {
         const VoxBatchItem &it = items[g];
-        if (it.n == 0 || !(it.leaf > 0.f) || !it.work || !it.out_soa) return false;
+        if (it.n == 0 || !(it.leaf > 0.f) || !it.work || (!it.items && !it.out_soa)) return false;
+        if (it.items && (!it.offsets_host || it.P < 1 || it.P > 1024)) return false;
         const float inv = 1.f / it.leaf;
         const int lmin[3] = {(int)floorf(it.bbmin[0] * inv), (int)floorf(it.bbmin[1] * inv), (int)floorf(it.bbmin[2] * inv)};
         const int lmax[3] = {(int)floorf(it.bbmax[0] * inv), (int)floorf(it.bbmax[1] * inv), (int)floorf(it.bbmax[2] * inv)};
@@ -477,14 +498,18 @@ bool voxel_whole_batch(plade_ctx *ctx, VoxBatchWork &B, int count, const VoxBatc
                       dz = (int64_t)((it.bbmax[2] - it.bbmin[2]) * inv) + 1;
         if (dx * dy * dz > (int64_t)INT32_MAX) return false;
         const int bx = bits_for((int64_t)lmax[0] - lmin[0]), by = bits_for((int64_t)lmax[1] - lmin[1]), bz = bits_for((int64_t)lmax[2] - lmin[2]);
-        if (bx + by + bz > 31) return false;
-        max_bits = std::max(max_bits, bx + by + bz);
+        int gbits = 0;
+        if (it.items) while ((1u << gbits) < it.P) ++gbits;
+        if (bx + by + bz + gbits > 31) return false;
+        max_bits = std::max(max_bits, bx + by + bz + gbits);
+        n_offs += it.items ? it.P + 1 : 0;
         VBCloud &C = A.c[g];
         C.sx = it.sx; C.sy = it.sy; C.sz = it.sz; C.aos = it.aos; C.n = it.n; C.inv = inv;
+        C.items = it.items; C.P = it.items ? it.P : 1u; C.gshift = bx + by + bz;
         C.lminx = lmin[0]; C.lminy = lmin[1]; C.lminz = lmin[2]; C.bx = bx; C.by = by;
         VoxelWork &w = *it.work;
         w.out_xyz.ensure((size_t)it.n * 3 + 4);
-        w.group_offsets.ensure(4);
+        w.group_offsets.ensure((size_t)C.P + 2);
         w.count.ensure(4);
         w.n_out = 0; w.n_pending = 0;
         C.out_xyz = w.out_xyz.p; C.out_soa = it.out_soa; C.count = w.count.p; C.group_offsets = w.group_offsets.p;
@@ -498,15 +523,29 @@ bool voxel_whole_batch(plade_ctx *ctx, VoxBatchWork &B, int count, const VoxBatc
     A.total = (uint32_t)total;
     B.keys.ensure(total); B.keys2.ensure(total); B.vals.ensure(total); B.vals2.ensure(total);
     B.heads.ensure(total + VB_MAX + 1);
+    B.seg_group.ensure(total + VB_MAX + 1);
     B.sorted_xyz.ensure(3 * total + 4);
     hipStream_t st = ctx->stream;
+    if (n_offs) {   // the item offsets of all item-list clouds: one upload
+        B.offs.ensure(n_offs + 4);
+        std::vector<uint32_t> h(n_offs);
+        size_t o = 0;
+        for (int g = 0; g < count; ++g) {
+            if (!items[g].items) continue;
+            for (uint32_t q = 0; q <= items[g].P; ++q) h[o + q] = (uint32_t)items[g].offsets_host[q];
+            A.c[g].offs = B.offs.p + o;
+            o += items[g].P + 1;
+        }
+        const bool staged = ctx->h2d(B.offs.p, h.data(), 4 * n_offs);
+        if (!staged) ctx->sync();
+    }
     hipLaunchKernelGGL(k_vb_keys, dim3(cdiv(total, 256)), dim3(256), 0, st, A, B.keys.p, B.vals.p);
     radix_sort_segments_u32(ctx, B.keys.p, B.keys2.p, B.vals.p, B.vals2.p, A.start, count, max_bits);
     const uint32_t tiles = A.tile_start[count];
     const ScanTicket t = scan_ticket(ctx, (size_t)tiles * VR_TILE, VR_TILE);
     hipLaunchKernelGGL(k_vb_runs, dim3(tiles), dim3(VR_T), 0, st, A, B.keys2.p, B.vals2.p, t.state, t.ticket, t.base, t.gen, B.heads.p,
-                       B.sorted_xyz.p);
-    hipLaunchKernelGGL(k_vb_centroids, dim3(A.cblk_start[count]), dim3(128), 0, st, A, B.heads.p, B.sorted_xyz.p);
+                       B.seg_group.p, B.sorted_xyz.p);
+    hipLaunchKernelGGL(k_vb_centroids, dim3(A.cblk_start[count]), dim3(128), 0, st, A, B.heads.p, B.seg_group.p, B.sorted_xyz.p);
     HIP_TRY(hipGetLastError());
     return true;
 }

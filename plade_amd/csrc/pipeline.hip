@@ -45,6 +45,7 @@ struct Side {
     LineTableHost lines;
     VoxelWork vox_all, vox_planes;
     bool vox_all_ready = false;  // the whole-cloud grid of the coming registration was queued with the group's (voxel_whole_batch)
+    bool vox_planes_ready = false;   // ... and the per-plane grids
     ObbWork obb;
     DBuf<uint32_t> d_items, d_offs;
 };
@@ -115,6 +116,8 @@ bool prepare_side(plade_ctx *ctx, const char *tag, const CloudDev &cloud, const 
         memcpy(up.data() + P + 1, pl.coef, 16 * (size_t)P);
         ctx->h2d(S.d_offs.p, up.data(), 4 * up.size());
     }
+    if (S.vox_planes_ready && by_pos && !pl.mirrored) { S.vox_planes_ready = false; S.vox_planes.adopt_batch(ctx); }
+    else
     S.vox_planes.enqueue(ctx, cloud.aos.p, 6, by_pos ? pl.m_x : nullptr, by_pos ? pl.m_y : nullptr, by_pos ? pl.m_z : nullptr, items,
                          S.d_offs.p, n_items, P, leaf, cloud.bbmin, cloud.bbmax, by_pos, true);   // groups = the planes' item ranges
     // ComputeBoundingBox of the whole downsampled cloud (plade.cpp:81-84 / :295-299) and per plane (plade.cpp:106-117 /
@@ -233,7 +236,7 @@ RegistrationWork *registration_work_create() { return new RegistrationWork; }
 WholeVoxelSlot whole_voxel_slot(RegistrationWork &W, bool target, uint32_t n) {
     Side &S = target ? W.M : W.C;
     S.d_ds_soa.ensure(3 * (size_t)n + 4);
-    return WholeVoxelSlot{&S.vox_all, S.d_ds_soa.p, &S.vox_all_ready};
+    return WholeVoxelSlot{&S.vox_all, S.d_ds_soa.p, &S.vox_all_ready, &S.vox_planes, &S.vox_planes_ready};
 }
 void registration_work_destroy(RegistrationWork *w) { delete w; }
 

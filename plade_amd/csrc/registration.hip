@@ -191,7 +191,11 @@ void register_group(plade_ctx *ctx, int first, int count, const CloudDev *const 
     }
     for (int i = 0; i < count; ++i) {
         pcs[i]->in_group = count > 1;
-        if (pcs[i]->reg_work) { *whole_voxel_slot(*pcs[i]->reg_work, true, 0).ready = false; *whole_voxel_slot(*pcs[i]->reg_work, false, 0).ready = false; }
+        if (pcs[i]->reg_work)
+            for (int side = 0; side < 2; ++side) {
+                const WholeVoxelSlot sl = whole_voxel_slot(*pcs[i]->reg_work, side == 0, 0);
+                *sl.ready = false; *sl.planes_ready = false;
+            }
         ensure_pair_areas(pcs[i]);
         for (int k = 0; k < 16; ++k) T16[16 * i + k] = (k % 5 == 0) ? 1.f : 0.f;
         status[i] = PLADE_OK;
@@ -244,6 +248,25 @@ void register_group(plade_ctx *ctx, int first, int count, const CloudDev *const 
                 }
             if (voxel_whole_batch(ctx, ctx->vox_batch, 2 * count, items))
                 for (int q = 0; q < 2 * count; ++q) *ready[q] = true;
+            // ... and the per-plane grids (plade.cpp:93-105 / :308-319): the planes' supports as the extraction left them on the
+            // device (positions in its Morton-ordered copy), one group per plane
+            bool lists = !ctx->params.unoriented_normals;
+            for (int q = 0; q < 2 * count; ++q) lists = lists && planes[q].d_pos && planes[q].m_x && planes[q].P() <= 1024;
+            if (lists) {
+                for (int i = 0; i < count; ++i)
+                    for (int side = 0; side < 2; ++side) {
+                        const PlaneSetOut &pl = planes[2 * i + side];
+                        const WholeVoxelSlot slot = whole_voxel_slot(*pcs[i]->reg_work, side == 0, 0);
+                        VoxBatchItem &it = items[2 * i + side];
+                        it.aos = nullptr; it.sx = pl.m_x; it.sy = pl.m_y; it.sz = pl.m_z;
+                        it.items = pl.d_pos; it.offsets_host = pl.offsets.data(); it.P = pl.P();
+                        it.n = (uint32_t)pl.offsets[pl.P()];
+                        it.work = slot.planes; it.out_soa = nullptr;
+                        ready[2 * i + side] = slot.planes_ready;
+                    }
+                if (voxel_whole_batch(ctx, ctx->vox_batch, 2 * count, items))
+                    for (int q = 0; q < 2 * count; ++q) *ready[q] = true;
+            }
         }
     }
     if (count == 1 && pcs[0] == ctx) {
@@ -278,8 +301,10 @@ void register_group(plade_ctx *ctx, int first, int count, const CloudDev *const 
     tail(0);
     for (int i = 1; i < count; ++i) ths[i].join();
     for (int i = 0; i < count; ++i) {   // a pair that gave up before its preparation must not leave its grid marked as queued
-        *whole_voxel_slot(*pcs[i]->reg_work, true, 0).ready = false;
-        *whole_voxel_slot(*pcs[i]->reg_work, false, 0).ready = false;
+        for (int side = 0; side < 2; ++side) {
+            const WholeVoxelSlot sl = whole_voxel_slot(*pcs[i]->reg_work, side == 0, 0);
+            *sl.ready = false; *sl.planes_ready = false;
+        }
     }
     for (int i = 0; i < count; ++i)
         if (errs[i].code) { pcs[i]->drop_reads(); pcs[i]->last_error = errs[i].msg; status[i] = errs[i].code; }

@@ -39,11 +39,14 @@ struct VoxelWork {
 // pairs, registration.hip).  Every cloud's result lands in ITS VoxelWork (out_xyz, count, group_offsets) and out_soa exactly as
 // VoxelWork::enqueue would leave it: same keys, same stable order inside a voxel, same sums.
 struct VoxBatchItem {
-    const float *aos, *sx, *sy, *sz;   // the cloud: N x 6 rows and its SoA planes
-    uint32_t n;
+    const float *aos, *sx, *sy, *sz;   // the cloud: N x 6 rows and its SoA planes (item lists: the SoA planes the items index; aos unused)
+    const uint32_t *items = nullptr;   // device: item i = position items[i] of sx / sy / sz; nullptr: the whole cloud, item i = point i
+    const int32_t *offsets_host = nullptr;   // with items: P + 1 ascending item offsets, group g = items [off[g], off[g + 1]) (the planes)
+    uint32_t P = 0;
+    uint32_t n;                        // points (whole cloud) or items
     float leaf, bbmin[3], bbmax[3];
     VoxelWork *work;
-    float *out_soa;                    // >= 3 n floats
+    float *out_soa;                    // >= 3 n floats (whole cloud; may be nullptr for item lists)
 };
 // (VoxBatchWork, the batch's scratch arrays, lives in ctx.h: every context owns one)
 // false (nothing queued): the batch does not fit this path (an empty cloud, keys wider than 31 bits, a grid PCL would refuse)
