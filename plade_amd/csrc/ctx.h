@@ -65,7 +65,7 @@ namespace plade {
 // look-back words and tile ticket of the single-launch scans (prims.hip: never reset, see scan_ticket)
 struct ScanWork { DBuf<uint64_t> state; DBuf<uint32_t> ticket; uint32_t base = 0, gen = 0; };
 // scratch of voxel_whole_batch (voxel.h): keys / values of the concatenated clouds, run heads, coordinates in voxel order
-struct VoxBatchWork { DBuf<uint32_t> keys, keys2, vals, vals2, heads, seg_group, offs; DBuf<float> sorted_xyz; };
+struct VoxBatchWork { DBuf<uint32_t> keys, keys2, vals, vals2, heads, seg_group, offs; DBuf<float> sorted_xyz, obb_coef; };
 }  // namespace plade
 
 namespace plade {

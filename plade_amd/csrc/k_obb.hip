@@ -68,11 +68,10 @@ __device__ void strided_sums(const float *__restrict__ pts, uint32_t n, float (*
     __syncthreads();
 }
 
-__global__ __launch_bounds__(OBB_T) void k_obb_units(const ObbArgs A) {
+__device__ __forceinline__ void obb_unit(const ObbArgs &A, const uint32_t u) {
     __shared__ float s_ch[OBB_T][6];
     __shared__ float s_c[3], s_cov[6], s_P[12], s_E[9];
     __shared__ float s_mm[6][OBB_T / 64];
-    const uint32_t u = blockIdx.x;
     const float *pts;
     uint32_t n;
     if (u == 0) { pts = A.ds; n = *A.n_ds_p; }
@@ -156,7 +155,52 @@ __global__ __launch_bounds__(OBB_T) void k_obb_units(const ObbArgs A) {
     out[15] = norm_e(four[0] - four[2]) / 2.f;
 }
 
+__global__ __launch_bounds__(OBB_T) void k_obb_units(const ObbArgs A) { obb_unit(A, blockIdx.x); }
+
+// the units of up to 16 clouds in one launch: these workgroups are latency chains (three dependent passes over their points
+// by ONE workgroup each), so sixteen clouds take as long as one -- and a millisecond of such queue time per registration costs
+// the batch 14 % (profiles/r4_experiments.md 2c)
+constexpr int OBB_BATCH = 16;
+struct ObbBatchArgs { ObbArgs c[OBB_BATCH]; uint32_t ncl; uint32_t unit_start[OBB_BATCH + 1]; };
+__global__ __launch_bounds__(OBB_T) void k_obb_units_batch(const ObbBatchArgs B) {
+    uint32_t g = 0;
+#pragma unroll
+    for (int q = 1; q < OBB_BATCH; ++q) g += (q < (int)B.ncl && blockIdx.x >= B.unit_start[q]) ? 1u : 0u;
+    obb_unit(B.c[g], blockIdx.x - B.unit_start[g]);
+}
+
 }  // namespace
+
+bool obb_units_batch(plade_ctx *ctx, int count, const ObbBatchItem *items, DBuf<float> &coef_scratch) {
+    if (count < 1 || count > OBB_BATCH) return false;
+    ObbBatchArgs B;
+    memset(&B, 0, sizeof(B));
+    B.ncl = (uint32_t)count;
+    size_t n_coef = 0;
+    for (int g = 0; g < count; ++g) n_coef += 4 * (size_t)items[g].P;
+    coef_scratch.ensure(n_coef + 4);
+    std::vector<float> h(n_coef);
+    size_t o = 0;
+    for (int g = 0; g < count; ++g) {
+        const ObbBatchItem &it = items[g];
+        ObbWork &W = *it.work;
+        W.out.ensure(OBB_OUT_WHOLE + (size_t)it.P * OBB_OUT_PLANE + 4);
+        memcpy(h.data() + o, it.coef_host, 16 * (size_t)it.P);
+        B.c[g] = ObbArgs{it.d_ds, it.d_n_ds, it.d_plane_ds, it.d_plane_off, it.P, coef_scratch.p + o, W.out.p};
+        o += 4 * (size_t)it.P;
+        B.unit_start[g + 1] = B.unit_start[g] + it.P + 1;
+    }
+    for (int g = count; g < OBB_BATCH; ++g) { B.c[g] = B.c[0]; B.unit_start[g + 1] = B.unit_start[g]; }
+    if (n_coef) { const bool staged = ctx->h2d(coef_scratch.p, h.data(), 4 * n_coef); if (!staged) ctx->sync(); }
+    hipLaunchKernelGGL(k_obb_units_batch, dim3(B.unit_start[count]), dim3(OBB_T), 0, ctx->stream, B);
+    HIP_TRY(hipGetLastError());
+    return true;
+}
+
+void obb_adopt_batch(plade_ctx *ctx, ObbWork &W, uint32_t P) {
+    W.host.resize(OBB_OUT_WHOLE + (size_t)P * OBB_OUT_PLANE);
+    ctx->d2h(W.host.data(), W.out.p, 4 * W.host.size());   // valid after the next sync of the stream
+}
 
 void obb_units(plade_ctx *ctx, ObbWork &W, const float *d_ds, const uint32_t *d_n_ds, uint32_t max_ds, const float *d_plane_ds,
                const uint32_t *d_plane_off, uint32_t max_plane_pts, uint32_t P, const float *coef_host, const float *d_coef) {

@@ -42,7 +42,8 @@ RegistrationWork *registration_work_create();
 // where the whole-cloud voxel grid of the pair's next registration goes when the caller builds it for several pairs at once
 // (voxel_whole_batch): the side's VoxelWork, its SoA output (>= 3 n floats) and the flag prepare_side consumes
 struct VoxelWork;
-struct WholeVoxelSlot { VoxelWork *work; float *out_soa; bool *ready; VoxelWork *planes; bool *planes_ready; };
+struct ObbWork;
+struct WholeVoxelSlot { VoxelWork *work; float *out_soa; bool *ready; VoxelWork *planes; bool *planes_ready; ObbWork *obb; bool *obb_ready; };
 WholeVoxelSlot whole_voxel_slot(RegistrationWork &W, bool target, uint32_t n);
 void registration_work_destroy(RegistrationWork *w);
 

@@ -46,6 +46,7 @@ struct Side {
     VoxelWork vox_all, vox_planes;
     bool vox_all_ready = false;  // the whole-cloud grid of the coming registration was queued with the group's (voxel_whole_batch)
     bool vox_planes_ready = false;   // ... and the per-plane grids
+    bool obb_ready = false;          // ... and the boxes (obb_units_batch)
     ObbWork obb;
     DBuf<uint32_t> d_items, d_offs;
 };
@@ -123,6 +124,8 @@ bool prepare_side(plade_ctx *ctx, const char *tag, const CloudDev &cloud, const 
     // ComputeBoundingBox of the whole downsampled cloud (plade.cpp:81-84 / :295-299) and per plane (plade.cpp:106-117 /
     // :320-330) on the device, reading the voxel grids' results where they lie; ONE wait for the grids' sizes, the
     // per-plane offsets and the boxes
+    if (S.obb_ready && !pl.mirrored) { S.obb_ready = false; obb_adopt_batch(ctx, S.obb, P); }   // queued with the group's boxes
+    else
     obb_units(ctx, S.obb, S.vox_all.out_xyz.p, S.vox_all.count.p, cloud.n, S.vox_planes.out_xyz.p, S.vox_planes.group_offsets.p, n_items, P,
               pl.coef, reinterpret_cast<const float *>(S.d_offs.p + P + 1));
     S.pcl.off.resize((size_t)P + 1);
@@ -236,7 +239,7 @@ RegistrationWork *registration_work_create() { return new RegistrationWork; }
 WholeVoxelSlot whole_voxel_slot(RegistrationWork &W, bool target, uint32_t n) {
     Side &S = target ? W.M : W.C;
     S.d_ds_soa.ensure(3 * (size_t)n + 4);
-    return WholeVoxelSlot{&S.vox_all, S.d_ds_soa.p, &S.vox_all_ready, &S.vox_planes, &S.vox_planes_ready};
+    return WholeVoxelSlot{&S.vox_all, S.d_ds_soa.p, &S.vox_all_ready, &S.vox_planes, &S.vox_planes_ready, &S.obb, &S.obb_ready};
 }
 void registration_work_destroy(RegistrationWork *w) { delete w; }
 

@@ -194,7 +194,7 @@ void register_group(plade_ctx *ctx, int first, int count, const CloudDev *const 
         if (pcs[i]->reg_work)
             for (int side = 0; side < 2; ++side) {
                 const WholeVoxelSlot sl = whole_voxel_slot(*pcs[i]->reg_work, side == 0, 0);
-                *sl.ready = false; *sl.planes_ready = false;
+                *sl.ready = false; *sl.planes_ready = false; *sl.obb_ready = false;
             }
         ensure_pair_areas(pcs[i]);
         for (int k = 0; k < 16; ++k) T16[16 * i + k] = (k % 5 == 0) ? 1.f : 0.f;
@@ -264,8 +264,22 @@ void register_group(plade_ctx *ctx, int first, int count, const CloudDev *const 
                         it.work = slot.planes; it.out_soa = nullptr;
                         ready[2 * i + side] = slot.planes_ready;
                     }
-                if (voxel_whole_batch(ctx, ctx->vox_batch, 2 * count, items))
+                if (voxel_whole_batch(ctx, ctx->vox_batch, 2 * count, items)) {
                     for (int q = 0; q < 2 * count; ++q) *ready[q] = true;
+                    // ... and, both grids of every cloud being queued, the boxes of all of them (ComputeBoundingBox, plade.cpp:81-84,
+                    // :106-117): one launch of latency-chain workgroups instead of one per cloud
+                    ObbBatchItem ob[2 * PLADE_GROUP_MAX];
+                    for (int i = 0; i < count; ++i)
+                        for (int side = 0; side < 2; ++side) {
+                            const PlaneSetOut &pl = planes[2 * i + side];
+                            const WholeVoxelSlot slot = whole_voxel_slot(*pcs[i]->reg_work, side == 0, 0);
+                            ob[2 * i + side] = ObbBatchItem{slot.work->out_xyz.p, slot.work->count.p, slot.planes->out_xyz.p, slot.planes->group_offsets.p,
+                                                            pl.P(), pl.coef.data(), slot.obb};
+                            ready[2 * i + side] = slot.obb_ready;
+                        }
+                    if (obb_units_batch(ctx, 2 * count, ob, ctx->vox_batch.obb_coef))
+                        for (int q = 0; q < 2 * count; ++q) *ready[q] = true;
+                }
             }
         }
     }
@@ -303,7 +317,7 @@ void register_group(plade_ctx *ctx, int first, int count, const CloudDev *const 
     for (int i = 0; i < count; ++i) {   // a pair that gave up before its preparation must not leave its grid marked as queued
         for (int side = 0; side < 2; ++side) {
             const WholeVoxelSlot sl = whole_voxel_slot(*pcs[i]->reg_work, side == 0, 0);
-            *sl.ready = false; *sl.planes_ready = false;
+            *sl.ready = false; *sl.planes_ready = false; *sl.obb_ready = false;
         }
     }
     for (int i = 0; i < count; ++i)

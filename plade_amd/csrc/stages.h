@@ -116,6 +116,12 @@ struct ObbWork {
 // the device: *d_n_ds <= max_ds points, d_plane_off[P] <= max_plane_pts) + the small read-back
 void obb_units(plade_ctx *ctx, ObbWork &W, const float *d_ds, const uint32_t *d_n_ds, uint32_t max_ds, const float *d_plane_ds,
                const uint32_t *d_plane_off, uint32_t max_plane_pts, uint32_t P, const float *coef_host, const float *d_coef = nullptr);
+// the same for up to 16 clouds in ONE launch (the clouds of a group of pairs): every cloud's result block lands in ITS
+// ObbWork::out; obb_adopt_batch(ctx, W, P) notes the read-back on the stream that goes on with that cloud
+struct ObbBatchItem { const float *d_ds; const uint32_t *d_n_ds; const float *d_plane_ds; const uint32_t *d_plane_off; uint32_t P;
+                      const float *coef_host; ObbWork *work; };
+bool obb_units_batch(plade_ctx *ctx, int count, const ObbBatchItem *items, DBuf<float> &coef_scratch);
+void obb_adopt_batch(plade_ctx *ctx, ObbWork &W, uint32_t P);
 
 // generic: positions of set flags (ordered); returns count (sync)
 uint32_t compact_flags(plade_ctx *ctx, const uint32_t *d_flags, uint32_t n, DBuf<uint32_t> &pos_scratch,
