@@ -299,7 +299,7 @@ def _cpu_budget():
 
 # busy host threads per rank, measured on the MI355X box in round 4 (tools/exp_groups.py, sleeping host waits, groups of 8 pairs,
 # host clouds): groups in flight -> busy threads (registrations/s): see profiles/r4_experiments.md
-BUSY_THREADS_BY_GROUPS = {1: 1.56, 2: 1.72, 3: 1.89, 4: 2.02}   # 555 / 676 / 719 / 742 registrations/s
+BUSY_THREADS_BY_GROUPS = {1: 1.38, 2: 1.66, 3: 1.8, 4: 1.91}   # 578 / 700 / 741 / 766 registrations/s
 
 
 def inflight_for_budget(budget, local_world):
