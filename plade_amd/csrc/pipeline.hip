@@ -111,7 +111,8 @@ bool prepare_side(plade_ctx *ctx, const char *tag, const CloudDev &cloud, const 
         HIP_TRY(hipMemcpyAsync(S.d_items.p + half, dev_list, 4 * half, hipMemcpyDeviceToDevice, ctx->stream));
     } else if (dev_list) items = dev_list;   // read where the extraction left it (valid until this cloud slot's next detect)
     else ctx->h2d(S.d_items.p, pl.idx, 4 * (size_t)n_items);
-    {   // one upload: the planes' item offsets | their coefficients (for the per-plane boxes below)
+    const bool batched = S.vox_planes_ready && S.obb_ready && by_pos && !pl.mirrored;   // grids and boxes came with the group's
+    if (!batched) {   // one upload: the planes' item offsets | their coefficients (for the per-plane boxes below)
         std::vector<uint32_t> up(5 * (size_t)P + 1);
         memcpy(up.data(), pl.offsets, 4 * ((size_t)P + 1));
         memcpy(up.data() + P + 1, pl.coef, 16 * (size_t)P);
