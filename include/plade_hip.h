@@ -93,6 +93,14 @@ typedef struct plade_params {
     uint32_t match_cell_budget;
     uint32_t group_max_points;
     int32_t prepare_sides;
+    int32_t closest_point_mode;   /* arithmetic of ComputeNearstTwoPointsOfTwo3DLine (code/PLADE/util.cpp:1167-1229) and
+                          * ComputeIntersectionPointOf23DLine (util.cpp:1461-1500): 0 = exact closed form in fp64 (default; the
+                          * better-conditioned evaluation of the same inputs), 1 = "svd_fp32": the reference's own
+                          * cv::solve(A, B, X, DECOMP_SVD) on the 9 x 9 / 6 x 5 float systems, rounding for rounding
+                          * (opencv/modules/core/src/lapack.cpp:533-710, 751-812, 1335-1460; one system per lane,
+                          * plade_amd/csrc/k_svd.h) -- for hosts that must reproduce the reference's transform on scenes
+                          * where those solves are ill-conditioned (axis-aligned planes).
+                          * C++ API / CLI: env PLADE_CLOSEST_POINT_MODE=svd_fp32. */
 } plade_params;
 void plade_default_params(plade_params *p);
 int plade_set_params(plade_ctx *ctx, const plade_params *p);
@@ -175,6 +183,19 @@ int plade_overlap_counts(plade_ctx *ctx, const float *src_ds, uint32_t n_s, cons
  * member (the order PCL creates them in). */
 int plade_cluster_transforms(plade_ctx *ctx, const float *t_xyz, const float *euler, uint32_t m, float dist_threshold,
                              float angle_gate, int32_t *cluster_of, uint32_t *n_clusters);
+
+/* ---- seams of the line geometry (A6 / A11) ------------------------------------------------------
+ * plade_closest_points replaces ComputeNearstTwoPointsOfTwo3DLine (code/PLADE/util.cpp:1167-1229) for n line pairs:
+ * u1, u2 (n x 3, directions: normalised first, as the reference does in place), p1, p2 (n x 3, a point of each line) ->
+ * q1, q2 (n x 3, the closest points), len (n doubles: (q1 - q2).norm() in float, widened), ok (n: 0 where the two
+ * normalised directions are bitwise equal -- the reference returns -1 there -- else 1).
+ * plade_lines_meet replaces ComputeIntersectionPointOf23DLine (util.cpp:1461-1500): v1, v2 are used as given;
+ * ok = 0 where |v1 . v2| > 0.9999.
+ * mode: 0 = closed form (fp64), 1 = the reference's cv::solve(DECOMP_SVD) in float (plade_params.closest_point_mode). */
+int plade_closest_points(plade_ctx *ctx, int32_t mode, const float *u1, const float *p1, const float *u2, const float *p2,
+                         uint32_t n, float *q1, float *q2, double *len, int32_t *ok);
+int plade_lines_meet(plade_ctx *ctx, int32_t mode, const float *v1, const float *p1, const float *v2, const float *p2,
+                     uint32_t n, float *out, int32_t *ok);
 
 /* ---- supporting stage entry points (A13) ------------------------------------------------- */
 /* average_spacing(cloud, k) (code/PLADE/util.cpp:1619-1648); xyz read with `stride` floats. */

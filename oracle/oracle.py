@@ -78,6 +78,10 @@ class Oracle:
         L.orc_set_closest_point_mode.argtypes = [_i]
         L.orc_intersection_point.argtypes = [_p, _p, _p, _p, _p]
         L.orc_solve_svd_f32.argtypes = [_p, _p, _p, _i, _i]
+        L.orc_hypot.restype = C.c_double
+        L.orc_hypot.argtypes = [C.c_double, C.c_double]
+        L.orc_libm_hypot.restype = C.c_double
+        L.orc_libm_hypot.argtypes = [C.c_double, C.c_double]
         L.orc_cluster_transforms.argtypes = [_p, _p, _i, _f, _f, _p]
         L.orc_euler_angles.argtypes = [_p, _p]
         L.orc_pen_walk.argtypes = [_p, _i, _p, _i, _p, _p, _p, _f, _f, _f, _p, _p, _p]

@@ -123,6 +123,28 @@ inline Rot rot_transpose(Rot j) { return Rot{j.c, -j.s}; }
 // JacobiRotation operator*: c = c1 c2 - s1 s2 ; s = c1 s2 + s1 c2  (real case)
 inline Rot rot_mul(Rot a, Rot b) { return Rot{a.c * b.c - a.s * b.s, a.c * b.s + a.s * b.c}; }
 
+// hypot() as the reference's OpenCV calls it (lapack.cpp:579: the C library's).  The GPU cannot call glibc, so oracle
+// and kernel (plade_amd/csrc/k_svd.h) evaluate the SAME explicit formula: the kernel of glibc 2.35's dbl-64 hypot without
+// FMA (sqrt of the plain sum, then one correction step with the residual h^2 - x^2 - y^2 split into two nearly exact
+// terms); glibc rescales only above 2^511 / below 2^-459, far outside what the 9 x 9 systems produce.
+// tests/test_host_logic.py::test_hypot_formula_is_glibc_s compares it with this machine's libm bit for bit.
+inline double hypot_glibc235(double x, double y) {
+    double ax = std::fabs(x), ay = std::fabs(y);
+    if (ax < ay) std::swap(ax, ay);
+    double h = std::sqrt(ax * ax + ay * ay), t1, t2;
+    if (h <= 2.0 * ay) {
+        double delta = h - ay;
+        t1 = ax * (2.0 * delta - ax);
+        t2 = (delta - 2.0 * (ax - ay)) * delta;
+    } else {
+        double delta = h - ax;
+        t1 = 2.0 * delta * (ax - 2.0 * ay);
+        t2 = (4.0 * delta - ay) * ay + delta * delta;
+    }
+    h -= (t1 + t2) / (2.0 * h);
+    return h;
+}
+
 // positive_real_hypot (Eigen/src/Core/MathFunctionsImpl.h:80-94) on |x|,|y|
 inline float eig_hypot(float x, float y) {
     x = std::fabs(x); y = std::fabs(y);

@@ -658,7 +658,7 @@ void cv_jacobi_svd_f32(float *At, float *_W, float *Vt, int m, int n) {
                 for (k = 0; k < m; k++) p += (double)Ai[k] * Aj[k];
                 if (std::abs(p) <= eps * std::sqrt((double)a * b)) continue;
                 p *= 2;
-                double beta = a - b, gamma = hypot((double)p, beta);
+                double beta = a - b, gamma = hypot_glibc235((double)p, beta);   // hypot(): see orc_math.h
                 if (beta < 0) {
                     double delta = (gamma - beta) * 0.5;
                     s = (float)std::sqrt(delta / gamma);
@@ -1353,6 +1353,8 @@ int orc_intersection_point(const float *v1, const float *p1, const float *v2, co
     return rc;
 }
 void orc_solve_svd_f32(const float *A, const float *B, float *X, int m, int n) { cv_solve_svd_f32(A, B, X, m, n); }
+double orc_hypot(double x, double y) { return hypot_glibc235(x, y); }
+double orc_libm_hypot(double x, double y) { return hypot(x, y); }
 
 void orc_reg_destroy(orc_reg *h) { delete h; }
 int orc_dump_get(orc_reg *h, const char *name, const void **ptr, int64_t *nbytes) {

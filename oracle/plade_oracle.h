@@ -77,6 +77,10 @@ void orc_set_closest_point_mode(int mode);
 int orc_intersection_point(const float *v1, const float *p1, const float *v2, const float *p2, float *out);
 /* cv::solve(A (m x n, row-major), B (m), X (n), DECOMP_SVD) for CV_32F, the restated solver itself */
 void orc_solve_svd_f32(const float *A, const float *B, float *X, int m, int n);
+/* the hypot() of that solver (orc_math.h: the explicit formula kernel and oracle share) and this machine's libm hypot, for the test
+ * that pins the one against the other */
+double orc_hypot(double x, double y);
+double orc_libm_hypot(double x, double y);
 void orc_reg_destroy(orc_reg *);
 int orc_registration(orc_reg *h, const float *tgt_pos_nrm, int nt, const float *src_pos_nrm, int ns,
                      const float *tgt_planes, const int32_t *tgt_offsets, const int32_t *tgt_idx,

@@ -23,6 +23,7 @@ ABI_SYMBOLS = [
     "plade_registration_dev", "plade_dump_get", "plade_stats_get", "plade_kernel_time", "plade_plane_component",
     "plade_sort_pairs", "plade_host_pin", "plade_host_unpin", "plade_score_planes_subset", "plade_registration_next", "plade_cluster_transforms", "plade_device_synchronize", "plade_selftest_readback",
     "plade_registration_pairs", "plade_registration_pairs_dev", "plade_pair_ctx", "plade_set_candidate_shard", "plade_diag_launches", "plade_diag_cluster_order", "plade_sort_segments",
+    "plade_closest_points", "plade_lines_meet",
 ]
 
 
@@ -37,7 +38,7 @@ class Params(C.Structure):
                 ("init_min_support", C.c_int32), ("orient_normals", C.c_int32), ("dump", C.c_int32),
                 ("ransac_seed", C.c_uint64), ("host_wait", C.c_int32), ("unoriented_normals", C.c_int32),
                 ("ransac_topup", C.c_int32), ("match_window", C.c_int32), ("match_cell_budget", C.c_uint32),
-                ("group_max_points", C.c_uint32), ("prepare_sides", C.c_int32)]
+                ("group_max_points", C.c_uint32), ("prepare_sides", C.c_int32), ("closest_point_mode", C.c_int32)]
 
 
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int32), C.c_uint32, C.c_uint32, C.c_uint32)
@@ -87,6 +88,8 @@ def load_library(path=LIB_PATH):
     sig("plade_registration_pairs", argtypes=[p, u32, p, p, p, p, u32, p, p, p, p, p, p])
     sig("plade_registration_pairs_dev", argtypes=[p, u32, p, p, p, p])
     sig("plade_pair_ctx", argtypes=[p, u32], restype=p)
+    sig("plade_closest_points", argtypes=[p, i32, p, p, p, p, u32, p, p, p, p])
+    sig("plade_lines_meet", argtypes=[p, i32, p, p, p, p, u32, p, p])
     sig("plade_diag_launches", argtypes=[p, u32, u32, u32])
     sig("plade_diag_cluster_order", argtypes=[p, u32, i32, i32, p])
     sig("plade_sort_segments", argtypes=[p, p, p, p, u32, C.c_int, p, p])
@@ -210,6 +213,29 @@ class Context:
         for k, v in kw.items():
             setattr(self.params, k, v)
         self._check(self.L.plade_set_params(self.h, C.byref(self.params)))
+
+    def closest_points(self, u1, p1, u2, p2, mode=0):
+        """Seam of ComputeNearstTwoPointsOfTwo3DLine (util.cpp:1167-1229) for n line pairs; mode 0 closed form, 1 / "svd_fp32"
+        the reference's 9 x 9 float SVD solve.  Returns q1, q2 (n x 3), len (n, float64), ok (n, int32)."""
+        u1, p1, u2, p2 = (_f32(a).reshape(-1, 3) for a in (u1, p1, u2, p2))
+        n = len(u1)
+        if not (len(p1) == len(u2) == len(p2) == n):
+            raise ValueError("closest_points: the four arrays must hold the same number of rows")
+        q1, q2 = np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32)
+        ln, ok = np.zeros(n, np.float64), np.zeros(n, np.int32)
+        self._check(self.L.plade_closest_points(self.h, 1 if mode in (1, "svd_fp32") else 0, _ptr(u1), _ptr(p1), _ptr(u2), _ptr(p2), n,
+                                                _ptr(q1), _ptr(q2), _ptr(ln), _ptr(ok)))
+        return q1, q2, ln, ok
+
+    def lines_meet(self, v1, p1, v2, p2, mode=0):
+        """Seam of ComputeIntersectionPointOf23DLine (util.cpp:1461-1500); returns points (n x 3), ok (n)."""
+        v1, p1, v2, p2 = (_f32(a).reshape(-1, 3) for a in (v1, p1, v2, p2))
+        n = len(v1)
+        if not (len(p1) == len(v2) == len(p2) == n):
+            raise ValueError("lines_meet: the four arrays must hold the same number of rows")
+        out, ok = np.zeros((n, 3), np.float32), np.zeros(n, np.int32)
+        self._check(self.L.plade_lines_meet(self.h, 1 if mode in (1, "svd_fp32") else 0, _ptr(v1), _ptr(p1), _ptr(v2), _ptr(p2), n, _ptr(out), _ptr(ok)))
+        return out, ok
 
     def sort_pairs(self, keys, vals, bits=None):
         """Diagnostic seam: the device-wide stable radix sort (radix_sort.hip).  keys uint32 or uint64."""

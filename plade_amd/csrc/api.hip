@@ -22,6 +22,7 @@ extern "C" void plade_default_params(plade_params *p) {
     p->match_cell_budget = 0;
     p->group_max_points = 48000000u;
     p->prepare_sides = 0;
+    p->closest_point_mode = 0;  // closed form; 1 = the reference's fp32 SVD solves (k_svd.h)
     // pure: no environment look-ups here -- programs that cannot pass plade_params (the CLI, the C++ registration()
     // overloads) read their opt-in switches themselves (plade_host.cpp: context())
 }
@@ -71,7 +72,8 @@ extern "C" const char *plade_last_error(const plade_ctx *ctx) { return ctx ? ctx
 
 extern "C" int plade_set_params(plade_ctx *ctx, const plade_params *p) {
     if (!ctx || !p) return PLADE_EINVAL;
-    if (p->max_planes < 1 || p->min_planes < 0 || p->max_candidates < 1 || p->init_min_support < 1 || p->match_window < -1 || p->match_window > 1) return PLADE_EINVAL;
+    if (p->max_planes < 1 || p->min_planes < 0 || p->max_candidates < 1 || p->init_min_support < 1 || p->match_window < -1 || p->match_window > 1 ||
+        p->closest_point_mode < 0 || p->closest_point_mode > 1) return PLADE_EINVAL;
     ctx->params = *p;
     return PLADE_OK;
 }

@@ -11,6 +11,7 @@
 // per-line iterate table (see stages.h).
 #include "stages.h"
 #include "prims.h"
+#include "k_svd.h"
 
 namespace plade {
 
@@ -31,7 +32,53 @@ __device__ __forceinline__ f3 line_iter(const LinesView &v, uint32_t line, int k
     return f3(p[0], p[1], p[2]);
 }
 
+// ---- closest_point_mode = 1: the closest points of every line pair i < j by the reference's 9 x 9 solve (k_svd.h) -------
+// One system per lane, 64 lanes per workgroup (46 KB of LDS hold their matrices); lane t serves the t-th pair of the
+// row-major enumeration of i < j and leaves (q1, q2) in slot i * L + j of `cp`; k_pair_table picks them up for (i, j) and,
+// mirrored, for (j, i) (util.cpp:784-788 copies the entry).  The direction vectors are the iterates the pair would see in
+// the reference's call order, exactly as in the closed-form path.
+constexpr int CP_TPB = 64;
+__device__ __forceinline__ void unordered_pair(uint32_t t, uint32_t L, uint32_t &i, uint32_t &j) {
+    // pairs before row i: f(i) = i (2L - i - 1) / 2
+    const double b = 2.0 * L - 1.0;
+    long r = (long)floor((b - sqrt(b * b - 8.0 * (double)t)) * 0.5);
+    if (r < 0) r = 0;
+    auto f = [&](long q) { return (unsigned long long)q * (2ull * L - (unsigned long long)q - 1ull) / 2ull; };
+    while (r + 1 < (long)L && f(r + 1) <= t) ++r;
+    while (r > 0 && f(r) > t) --r;
+    i = (uint32_t)r;
+    j = (uint32_t)(t - f(r)) + i + 1u;
+}
+
+__global__ __launch_bounds__(CP_TPB) void k_closest_svd(LinesView v, uint32_t n_pairs, float *__restrict__ cp) {
+    __shared__ float lds[LaneSolver<9, 9, CP_TPB>::WORDS_PER_LANE * CP_TPB];
+    const uint32_t t = blockIdx.x * CP_TPB + threadIdx.x;
+    if (t >= n_pairs) return;
+    uint32_t i, j;
+    unordered_pair(t, v.L, i, j);
+    const f3 ci = line_iter(v, i, 3 + (int)j), cj = line_iter(v, j, 4 + (int)i);
+    if (ci.x == cj.x && ci.y == cj.y && ci.z == cj.z) return;     // util.cpp:1173: the caller sees "-1"
+    const f3 pti(v.pt[3 * i], v.pt[3 * i + 1], v.pt[3 * i + 2]), ptj(v.pt[3 * j], v.pt[3 * j + 1], v.pt[3 * j + 2]);
+    LaneSolver<9, 9, CP_TPB> solver(lds, threadIdx.x);
+    f3 q1, q2;
+    closest_points_solver(solver, ci, pti, cj, ptj, q1, q2);
+    float *o = cp + 6 * ((size_t)i * v.L + j);
+    o[0] = q1.x; o[1] = q1.y; o[2] = q1.z; o[3] = q2.x; o[4] = q2.y; o[5] = q2.z;
+}
+
+// closest points of pair (a, b), a < b: from the solver's table when there is one, else the closed form
+__device__ __forceinline__ bool pair_closest(const float *__restrict__ cp, uint32_t L, uint32_t a, uint32_t b, f3 ua, f3 pa, f3 ub, f3 pb,
+                                             f3 &q1, f3 &q2, double &len) {
+    if (!cp) return closest_points(ua, pa, ub, pb, q1, q2, len);
+    if (ua.x == ub.x && ua.y == ub.y && ua.z == ub.z) return false;
+    const float *o = cp + 6 * ((size_t)a * L + b);
+    q1 = f3(o[0], o[1], o[2]); q2 = f3(o[3], o[4], o[5]);
+    len = norm_e(q1 - q2);     // (point1 - point2).norm(), util.cpp:1227
+    return true;
+}
+
 __global__ __launch_bounds__(256) void k_pair_table(LinesView v, float scale, float angle_thresh, int target,
+                                                    const float *__restrict__ cp,
                                                     uint32_t *__restrict__ flags, float *__restrict__ desc,
                                                     float *__restrict__ lv1, float *__restrict__ lv2,
                                                     float *__restrict__ p1out) {
@@ -49,13 +96,13 @@ __global__ __launch_bounds__(256) void k_pair_table(LinesView v, float scale, fl
     bool ok;
     if (i < j) {
         const f3 ci = line_iter(v, i, 3 + (int)j), cj = line_iter(v, j, 4 + (int)i);
-        ok = closest_points(ci, pti, cj, ptj, p1, p2, len);
+        ok = pair_closest(cp, L, i, j, ci, pti, cj, ptj, p1, p2, len);
         if (target) { vi = ci; vj = cj; }
         else { vi = line_iter(v, i, 2 + (int)L); vj = line_iter(v, j, 2 + (int)L); }
     } else {
         // copied from entry (j, i) (util.cpp:784-788)
         f3 q1, q2;
-        ok = closest_points(line_iter(v, j, 3 + (int)i), ptj, line_iter(v, i, 4 + (int)j), pti, q1, q2, len);
+        ok = pair_closest(cp, L, j, i, line_iter(v, j, 3 + (int)i), ptj, line_iter(v, i, 4 + (int)j), pti, q1, q2, len);
         p1 = q2; p2 = q1;
         vi = line_iter(v, i, 3 + (int)i);
         vj = line_iter(v, j, 2 + (int)L);
@@ -136,7 +183,13 @@ void build_pair_table(plade_ctx *ctx, const LineTableHost &lt, const float *norm
                 reinterpret_cast<const float *>(d + o_iter), reinterpret_cast<const int32_t *>(d + o_it),
                 reinterpret_cast<const float *>(d + o_nrm), L};
     const float angle_thresh = (float)cos(10.0 / 180 * M_PI);  // util.cpp:773, plade.cpp:513
-    hipLaunchKernelGGL(k_pair_table, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, v, scale, angle_thresh, target ? 1 : 0,
+    const float *cp = nullptr;
+    if (ctx->params.closest_point_mode == 1 && L > 1) {
+        const uint32_t n_pairs = (uint32_t)((size_t)L * (L - 1) / 2);
+        cp = out.cp.ensure(n * 6);
+        hipLaunchKernelGGL(k_closest_svd, dim3(cdiv(n_pairs, CP_TPB)), dim3(CP_TPB), 0, ctx->stream, v, n_pairs, out.cp.p);
+    }
+    hipLaunchKernelGGL(k_pair_table, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, v, scale, angle_thresh, target ? 1 : 0, cp,
                        out.flags.p, out.all_desc.p, out.all_lv1.p, out.all_lv2.p, out.all_p1.p);
     exclusive_scan_u32(ctx, out.flags.p, out.pos.p, n + 1);
     if (staged && n <= (1u << 20)) {
@@ -163,4 +216,90 @@ void build_pair_table(plade_ctx *ctx, const LineTableHost &lt, const float *norm
     HIP_TRY(hipGetLastError());
 }
 
+// ---- seams: n independent line pairs through the same device functions ----------------------------------------------------
+// in: u1 | p1 | u2 | p2 (each n x 3); out: q1 | q2 (n x 3 each)
+template <int SVD>
+__global__ __launch_bounds__(CP_TPB) void k_closest_seam(const float *__restrict__ in, uint32_t n, float *__restrict__ q, double *__restrict__ len,
+                                                         int32_t *__restrict__ ok) {
+    __shared__ float lds[SVD ? LaneSolver<9, 9, CP_TPB>::WORDS_PER_LANE * CP_TPB : 1];
+    const uint32_t t = blockIdx.x * CP_TPB + threadIdx.x;
+    if (t >= n) return;
+    auto ld = [&](int a) { const float *p = in + 3 * ((size_t)a * n + t); return f3(p[0], p[1], p[2]); };
+    const f3 u1 = normalized_e(ld(0)), p1 = ld(1), u2 = normalized_e(ld(2)), p2 = ld(3);
+    f3 q1, q2;
+    double l = -1;
+    bool good;
+    if (SVD) {
+        good = !(u1.x == u2.x && u1.y == u2.y && u1.z == u2.z);
+        if (good) {
+            LaneSolver<9, 9, CP_TPB> solver(lds, threadIdx.x);
+            closest_points_solver(solver, u1, p1, u2, p2, q1, q2);
+            l = norm_e(q1 - q2);
+        }
+    } else good = closest_points(u1, p1, u2, p2, q1, q2, l);
+    ok[t] = good ? 1 : 0;
+    len[t] = good ? l : -1.0;
+    float *a = q + 3 * (size_t)t, *b = q + 3 * ((size_t)n + t);
+    a[0] = q1.x; a[1] = q1.y; a[2] = q1.z; b[0] = q2.x; b[1] = q2.y; b[2] = q2.z;
+}
+
+template <int SVD>
+__global__ __launch_bounds__(128) void k_meet_seam(const float *__restrict__ in, uint32_t n, float *__restrict__ out, int32_t *__restrict__ ok) {
+    __shared__ float lds[SVD ? LaneSolver<6, 5, 128>::WORDS_PER_LANE * 128 : 1];
+    const uint32_t t = blockIdx.x * 128 + threadIdx.x;
+    if (t >= n) return;
+    auto ld = [&](int a) { const float *p = in + 3 * ((size_t)a * n + t); return f3(p[0], p[1], p[2]); };
+    const f3 v1 = ld(0), p1 = ld(1), v2 = ld(2), p2 = ld(3);
+    f3 o;
+    bool good;
+    if (SVD) {
+        good = !(fabsf(dot_e(v1, v2)) > 0.9999);
+        if (good) { LaneSolver<6, 5, 128> solver(lds, threadIdx.x); o = lines_meet_solver(solver, v1, p1, v2, p2); }
+    } else good = lines_meet(v1, p1, v2, p2, o);
+    ok[t] = good ? 1 : 0;
+    out[3 * (size_t)t] = o.x; out[3 * (size_t)t + 1] = o.y; out[3 * (size_t)t + 2] = o.z;
+}
+
 }  // namespace plade
+
+using namespace plade;
+
+static int line_seam(plade_ctx *ctx, int kind, int32_t mode, const float *a, const float *b, const float *c, const float *d, uint32_t n,
+                     float *o1, float *o2, double *len, int32_t *ok) {
+    return guarded(ctx, [&]() -> int {
+        PLADE_REQUIRE(mode == 0 || mode == 1, PLADE_EINVAL, "line seam: mode must be 0 (closed form) or 1 (svd_fp32)");
+        PLADE_REQUIRE(n == 0 || (a && b && c && d && o1 && ok && (kind == 1 || (o2 && len))), PLADE_EINVAL, "line seam: null argument");
+        if (!n) return PLADE_OK;
+        float *d_in = reinterpret_cast<float *>(ctx->scratch[0].ensure(48 * (size_t)n + 64));
+        float *d_q = reinterpret_cast<float *>(ctx->scratch[1].ensure(24 * (size_t)n + 64));
+        double *d_len = reinterpret_cast<double *>(ctx->scratch[2].ensure(8 * (size_t)n + 64));
+        int32_t *d_ok = reinterpret_cast<int32_t *>(ctx->scratch[3].ensure(4 * (size_t)n + 64));
+        const float *src[4] = {a, b, c, d};
+        for (int k = 0; k < 4; ++k) HIP_TRY(hipMemcpyAsync(d_in + 3 * (size_t)k * n, src[k], 12 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+        if (kind == 0) {
+            if (mode) hipLaunchKernelGGL(k_closest_seam<1>, dim3(cdiv(n, CP_TPB)), dim3(CP_TPB), 0, ctx->stream, d_in, n, d_q, d_len, d_ok);
+            else hipLaunchKernelGGL(k_closest_seam<0>, dim3(cdiv(n, CP_TPB)), dim3(CP_TPB), 0, ctx->stream, d_in, n, d_q, d_len, d_ok);
+        } else {
+            if (mode) hipLaunchKernelGGL(k_meet_seam<1>, dim3(cdiv(n, 128)), dim3(128), 0, ctx->stream, d_in, n, d_q, d_ok);
+            else hipLaunchKernelGGL(k_meet_seam<0>, dim3(cdiv(n, 128)), dim3(128), 0, ctx->stream, d_in, n, d_q, d_ok);
+        }
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(o1, d_q, 12 * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+        if (kind == 0) {
+            HIP_TRY(hipMemcpyAsync(o2, d_q + 3 * (size_t)n, 12 * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(hipMemcpyAsync(len, d_len, 8 * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+        }
+        HIP_TRY(hipMemcpyAsync(ok, d_ok, 4 * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        return PLADE_OK;
+    });
+}
+
+extern "C" int plade_closest_points(plade_ctx *ctx, int32_t mode, const float *u1, const float *p1, const float *u2, const float *p2, uint32_t n,
+                                    float *q1, float *q2, double *len, int32_t *ok) {
+    return line_seam(ctx, 0, mode, u1, p1, u2, p2, n, q1, q2, len, ok);
+}
+extern "C" int plade_lines_meet(plade_ctx *ctx, int32_t mode, const float *v1, const float *p1, const float *v2, const float *p2, uint32_t n,
+                                float *out, int32_t *ok) {
+    return line_seam(ctx, 1, mode, v1, p1, v2, p2, n, out, nullptr, nullptr, ok);
+}

@@ -14,6 +14,7 @@
 //                 so brute-force fp32 distance tests (FLANN L2_Simple, strict <) reproduce the counts.
 #include "stages.h"
 #include "prims.h"
+#include "k_svd.h"
 #include <algorithm>
 
 namespace plade {
@@ -35,23 +36,35 @@ struct PenTables {
     uint32_t K, ps, pt;
 };
 
-__device__ __forceinline__ int edge_hits(f3 lineVec, f3 linePoint, const f3 *c, f3 *out) {
+// `meet(v1, p1, v2, p2, out)`: ComputeIntersectionPointOf23DLine (util.cpp:1461-1500) in the arithmetic the context asked for
+template <class Meet>
+__device__ __forceinline__ void edge_hit(f3 lineVec, f3 linePoint, f3 a, f3 b, f3 *out, int &n, Meet meet) {
+    const f3 tl = normalized_e(b - a);
+    f3 ip;
+    if (!meet(lineVec, linePoint, tl, a, ip)) return;
+    if (dot_e(a - ip, b - ip) > 0) return;
+    if (n < 4) out[n] = ip;
+    ++n;
+}
+template <bool ROLLED, class Meet>
+__device__ __forceinline__ int edge_hits(f3 lineVec, f3 linePoint, const f3 *c, f3 *out, Meet meet) {
     int n = 0;
-    for (int i = 1; i <= 4; ++i) {
-        const f3 a = c[(i - 1) % 4], b = c[i % 4];
-        const f3 tl = normalized_e(b - a);
-        f3 ip;
-        if (!lines_meet(lineVec, linePoint, tl, a, ip)) continue;
-        if (dot_e(a - ip, b - ip) > 0) continue;
-        if (n < 4) out[n] = ip;
-        ++n;
+    if (ROLLED) {     // the solver's body once, not four times, in the instruction stream
+#pragma unroll 1
+        for (int i = 1; i <= 4; ++i) edge_hit(lineVec, linePoint, c[(i - 1) % 4], c[i % 4], out, n, meet);
+    } else {
+        for (int i = 1; i <= 4; ++i) edge_hit(lineVec, linePoint, c[(i - 1) % 4], c[i % 4], out, n, meet);
     }
     return n;
 }
 
 // items are grouped by plane pair: pair (i1, j1) owns slots [pair * K, pair * K + pair_count[pair])
-__global__ __launch_bounds__(256) void k_pen_setup(PenTables tb, float len_th, float ang_th, PenItem *__restrict__ items,
+// SVD = 1 (plade_params.closest_point_mode = 1): the eight line / rectangle-edge meetings of a triple are the reference's
+// 6 x 5 float solves (k_svd.h), one lane's matrices in LDS (260 B per lane, hence 128 lanes per workgroup)
+template <int SVD, int TPB>
+__global__ __launch_bounds__(TPB) void k_pen_setup(PenTables tb, float len_th, float ang_th, PenItem *__restrict__ items,
                                                    uint32_t *__restrict__ n_items, uint32_t *__restrict__ pair_count) {
+    __shared__ float lds[SVD ? LaneSolver<6, 5, TPB>::WORDS_PER_LANE * TPB : 1];
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t total = (size_t)tb.K * tb.ps * tb.pt;
     if (idx >= total) return;
@@ -81,8 +94,15 @@ __global__ __launch_bounds__(256) void k_pen_setup(PenTables tb, float len_th, f
         c2[q] = f3(g[0], g[1], g[2]);
     }
     f3 ip1[4], ip2[4];
-    const int n1 = edge_hits(lineVec, linePoint, c1, ip1);
-    const int n2 = edge_hits(lineVec, linePoint, c2, ip2);
+    auto meet = [&](f3 v1, f3 p1, f3 v2, f3 p2, f3 &out) -> bool {
+        if (!SVD) return lines_meet(v1, p1, v2, p2, out);
+        if (fabsf(dot_e(v1, v2)) > 0.9999) return false;    // util.cpp:1463
+        LaneSolver<6, 5, TPB> solver(lds, threadIdx.x);
+        out = lines_meet_solver(solver, v1, p1, v2, p2);
+        return true;
+    };
+    const int n1 = edge_hits<SVD != 0>(lineVec, linePoint, c1, ip1, meet);
+    const int n2 = edge_hits<SVD != 0>(lineVec, linePoint, c2, ip2, meet);
     if (n1 != 2 || n2 != 2) return;  // empty -> not penetrable; any other count -> "-1, continue"
     const f3 direc = normalized_e(ip1[1] - ip1[0]);
     const f3 inter[4] = {ip1[0], ip1[1], ip2[0], ip2[1]};
@@ -457,8 +477,12 @@ void penetration_filter(plade_ctx *ctx, const float *cand_rt_host, uint32_t K, c
     if (gather) gather->launch(reinterpret_cast<const uint32_t *>(d + n_tab + PEN_MAXS + 1 + n_pairs));
     const float *d_steps = d + n_tab;
     const uint32_t *d_order = reinterpret_cast<const uint32_t *>(d + n_tab + PEN_MAXS + 1);
-    hipLaunchKernelGGL(k_pen_setup, dim3(cdiv(total, 256)), dim3(256), 0, ctx->stream, tb, length_threshold,
-                       angle_threshold, d_items, d_n, d_pair);
+    if (ctx->params.closest_point_mode == 1)
+        hipLaunchKernelGGL((k_pen_setup<1, 128>), dim3(cdiv(total, 128)), dim3(128), 0, ctx->stream, tb, length_threshold,
+                           angle_threshold, d_items, d_n, d_pair);
+    else
+        hipLaunchKernelGGL((k_pen_setup<0, 256>), dim3(cdiv(total, 256)), dim3(256), 0, ctx->stream, tb, length_threshold,
+                           angle_threshold, d_items, d_n, d_pair);
     // in-plane grids of both sides (cell = 2 r)
     const float cell = pen_grid_cell(length_threshold);
     if (src_pts.grid_cell != cell) build_pen_grid(ctx, src_pts, src, cell);   // normally built by prepare_side

@@ -28,6 +28,7 @@ struct PairTableDev {
     // scratch
     DBuf<float> all_desc, all_lv1, all_lv2, all_p1;
     DBuf<uint32_t> flags, pos;
+    DBuf<float> cp;               // closest_point_mode = 1: (q1, q2) of every pair i < j from the 9 x 9 solver, slot i * L + j
     DBuf<uint32_t> d_blob;        // line table in one upload: pt | sp | iterates | it | normals (4-byte words)
 };
 

@@ -1,0 +1,204 @@
+"""plade_params.closest_point_mode = 1 ("svd_fp32"): the reference's OWN arithmetic for the closest points of two lines
+(ComputeNearstTwoPointsOfTwo3DLine, code/PLADE/util.cpp:1167-1229: a 9 x 9 float system through cv::solve(DECOMP_SVD)) and
+for the meeting point of two lines (ComputeIntersectionPointOf23DLine, util.cpp:1461-1500: 6 x 5) on the GPU
+(plade_amd/csrc/k_svd.h, one system per lane), against the oracle's restatement of OpenCV's solver
+(oracle/plade_oracle.cpp, opencv/modules/core/src/lapack.cpp:533-812, 1335-1460).  Everything here is BIT-EXACT: the seams
+system by system, the registration in every dumped intermediate -- on the reference's sample pair (G8), the real room scan
+(G9, both libransac draws) and the 1M-point bench pair in generic orientation AND as generated (axis-aligned, where the
+reference's solves are ill-conditioned and the closed-form default lands 4e-2 away from them)."""
+import os
+import numpy as np
+import pytest
+
+from plade_amd.synth import make_pair
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(GOLD, name))
+
+
+def _same_bits(a, b):
+    """bit-equal, NaNs (whose payload differs between x86 and the GPU) matching NaNs"""
+    a, b = np.asarray(a, np.float32), np.asarray(b, np.float32)
+    na, nb = np.isnan(a), np.isnan(b)
+    return np.array_equal(na, nb) and np.array_equal(a[~na].view(np.uint32), b[~nb].view(np.uint32))
+
+
+def _line_cases(seed):
+    """Line pairs of every kind the registration meets: generic; axis-aligned with base points 1e3 ... 2e6 m away (what
+    ComputeIntersectionLine, util.cpp:639-675, produces for Manhattan planes); nearly parallel; identical directions (the
+    reference returns -1); unnormalised directions; lines that really meet."""
+    rng = np.random.default_rng(seed)
+    n = 600
+    u1, u2 = rng.normal(size=(n, 3)), rng.normal(size=(n, 3))
+    p1, p2 = rng.uniform(-10, 10, (n, 3)), rng.uniform(-10, 10, (n, 3))
+    # axis-aligned directions with last-bit noise, far base points
+    ax = np.eye(3)[rng.integers(0, 3, 200)] * rng.choice([-1, 1], 200)[:, None] + rng.normal(scale=1e-5, size=(200, 3))
+    bx = np.eye(3)[rng.integers(0, 3, 200)] * rng.choice([-1, 1], 200)[:, None] + rng.normal(scale=1e-5, size=(200, 3))
+    far1 = rng.uniform(-5, 5, (200, 3)) + ax * (10.0 ** rng.uniform(3, 6.3, 200))[:, None]
+    far2 = rng.uniform(-5, 5, (200, 3)) + bx * (10.0 ** rng.uniform(3, 6.3, 200))[:, None]
+    # nearly parallel
+    base = rng.normal(size=(100, 3))
+    near = base + rng.normal(scale=1e-3, size=(100, 3)) * np.linalg.norm(base, axis=1, keepdims=True)
+    # identical
+    same = rng.normal(size=(20, 3))
+    # meeting lines: both through one point
+    hub = rng.uniform(-5, 5, (80, 3))
+    m1, m2 = rng.normal(size=(80, 3)), rng.normal(size=(80, 3))
+    U1 = np.concatenate([u1, ax, base, same, m1, np.zeros((1, 3))])
+    U2 = np.concatenate([u2, bx, near, same, m2, np.zeros((1, 3))])
+    P1 = np.concatenate([p1, far1, rng.uniform(-10, 10, (100, 3)), rng.uniform(-1, 1, (20, 3)), hub + 3.0 * m1, np.ones((1, 3))])
+    P2 = np.concatenate([p2, far2, rng.uniform(-10, 10, (100, 3)), rng.uniform(-1, 1, (20, 3)), hub - 2.0 * m2, np.zeros((1, 3))])
+    return tuple(a.astype(np.float32) for a in (U1, P1, U2, P2))
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_closest_points_seam_bit_exact(ctx, oracle, mode):
+    U1, P1, U2, P2 = _line_cases(11)
+    q1, q2, ln, ok = ctx.closest_points(U1, P1, U2, P2, mode=mode)
+    try:
+        oracle.set_closest_point_mode(mode)
+        n_fail = 0
+        for i in range(len(U1)):
+            rc, o1, o2, ol = oracle.closest_points(U1[i], P1[i], U2[i], P2[i])
+            assert (rc == 0) == bool(ok[i]), i
+            if rc != 0:
+                n_fail += 1
+                assert ln[i] == -1.0
+                continue
+            assert _same_bits(q1[i], o1) and _same_bits(q2[i], o2), (mode, i, q1[i], o1, q2[i], o2)
+            assert ln[i] == ol or (np.isnan(ln[i]) and np.isnan(ol)), (mode, i)
+        assert n_fail >= 21      # the identical-direction pairs and the zero vectors
+    finally:
+        oracle.set_closest_point_mode(0)
+    if mode == 1:
+        # the solver really is another arithmetic: on the far-base-point pairs it differs from the closed form by centimetres
+        c1, _, _, _ = ctx.closest_points(U1, P1, U2, P2, mode=0)
+        far = slice(600, 800)
+        assert np.abs(q1[far] - c1[far]).max() > 1e-3
+        assert np.abs(q1[:600] - c1[:600]).max() < 1e-3
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_lines_meet_seam_bit_exact(ctx, oracle, mode):
+    U1, P1, U2, P2 = _line_cases(12)
+    V1 = U1 / np.maximum(np.linalg.norm(U1, axis=1, keepdims=True), 1e-30).astype(np.float32)
+    V2 = U2 / np.maximum(np.linalg.norm(U2, axis=1, keepdims=True), 1e-30).astype(np.float32)
+    out, ok = ctx.lines_meet(V1, P1, V2, P2, mode=mode)
+    try:
+        oracle.set_closest_point_mode(mode)
+        skipped = 0
+        for i in range(len(V1)):
+            rc, o = oracle.intersection_point(V1[i], P1[i], V2[i], P2[i])
+            assert (rc == 0) == bool(ok[i]), i
+            if rc != 0:
+                skipped += 1
+                continue
+            assert _same_bits(out[i], o), (mode, i, out[i], o)
+        assert skipped >= 20
+    finally:
+        oracle.set_closest_point_mode(0)
+
+
+def _every_intermediate(d, do, tag):
+    common = [k for k in do if k in d and not k.startswith("timing")]
+    assert len(common) >= 30 and "initial_RT" in common and "pen_flags" in common
+    for k in common:
+        assert np.asarray(d[k]).shape == np.asarray(do[k]).shape and np.array_equal(d[k], do[k]), (tag, k)
+
+
+def _match_set(d):
+    q = np.repeat(np.arange(len(d["match_offsets"]) - 1), np.diff(d["match_offsets"]))
+    return set(zip(q.tolist(), d["match_nbr"].tolist()))
+
+
+@pytest.mark.parametrize("fix,pre", [("g8_polyhedron.npz", ""), ("g9_room.npz", ""), ("g9_room.npz", "b")])
+def test_registration_with_the_reference_solver_equals_oracle_on_the_reference_data(oracle, fix, pre):
+    """G8 (the reference's sample pair, the planes its RANSAC extracted) and G9 (real room scan, two libransac draws) with
+    closest_point_mode = 1: every dumped intermediate and the transform equal the oracle in mode svd_fp32, bit for bit; the
+    match sets are identical to the closed form's and the transform moves by <= 1e-5 (measured 5e-7 ... 3.2e-6)."""
+    import plade_amd
+    g = load(fix)
+    tp = (g[f"t{pre}_coef"], g[f"t{pre}_off"], g[f"t{pre}_idx"])
+    sp = (g[f"s{pre}_coef"], g[f"s{pre}_off"], g[f"s{pre}_idx"])
+    c = plade_amd.Context(0, dump=1, closest_point_mode=1)
+    ok, T = c.registration_planes(g["target"], g["source"], tp, sp)
+    d = c.dump()
+    c.set_params(closest_point_mode=0)
+    ok0, T0 = c.registration_planes(g["target"], g["source"], tp, sp)
+    d0 = c.dump()
+    c.close()
+    try:
+        oracle.set_closest_point_mode("svd_fp32")
+        ok_o, T_o, do = oracle.registration(g["target"], g["source"], tp, sp, voxel_sort_mode=1)
+    finally:
+        oracle.set_closest_point_mode(0)
+    assert ok and ok_o and ok0 and np.array_equal(T, T_o)
+    _every_intermediate(d, do, (fix, pre))
+    assert _match_set(d) == _match_set(d0)
+    assert np.linalg.norm(T.astype(np.float64) - T0.astype(np.float64)) <= 1e-5
+    if fix.startswith("g8"):
+        assert np.abs(T - g["recorded"]).max() < 5e-5      # sample_data/file_pairs_results.txt:3-7, with the reference's arithmetic
+
+
+def _turn(c, R0):
+    o = np.empty_like(c)
+    o[:, :3] = (c[:, :3].astype(np.float64) @ R0.T).astype(np.float32)
+    o[:, 3:] = (c[:, 3:].astype(np.float64) @ R0.T).astype(np.float32)
+    return o
+
+
+@pytest.mark.parametrize("orientation", ["generic", "as_generated"])
+def test_full_size_pair_with_the_reference_solver_equals_oracle(oracle, orientation):
+    """BASELINE configs[2] (1M-point pair), full registration() with the GPU's own plane extraction and closest_point_mode = 1:
+    the oracle in mode svd_fp32 on the planes the GPU extracted gives the same match set, every dumped intermediate and the
+    same transform, bit for bit -- in a generic orientation and on the axis-aligned pair as generated, where the closed form
+    (the default) differs from the reference's arithmetic by thousands of matches."""
+    import plade_amd
+    tg, sr, Tgt = make_pair(1000000, seed=0)
+    if orientation == "generic":
+        q = np.random.default_rng(4).normal(size=4)
+        q /= np.linalg.norm(q)
+        w, x, y, z = q
+        R0 = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                       [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                       [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+        tg, sr = _turn(tg, R0), _turn(sr, R0)
+    c = plade_amd.Context(0, dump=1, orient_normals=1, closest_point_mode=1)
+    ok, T = c.registration(tg, sr)
+    d = c.dump()
+    c.set_params(closest_point_mode=0)
+    ok0, T0 = c.registration(tg, sr)
+    d0 = c.dump()
+    c.close()
+    tp = (d["tgt_planes"].reshape(-1, 4), d["tgt_plane_offsets"], d["tgt_plane_idx"])
+    sp = (d["src_planes"].reshape(-1, 4), d["src_plane_offsets"], d["src_plane_idx"])
+    try:
+        oracle.set_closest_point_mode("svd_fp32")
+        ok_o, T_o, do = oracle.registration(tg, sr, tp, sp, voxel_sort_mode=1)
+    finally:
+        oracle.set_closest_point_mode(0)
+    assert ok and ok_o and ok0
+    flips_vs_oracle = len(_match_set(d) ^ _match_set(do))
+    flips_vs_closed = len(_match_set(d) ^ _match_set(d0))
+    dT = float(np.linalg.norm(T.astype(np.float64) - T_o.astype(np.float64)))
+    dT_closed = float(np.linalg.norm(T.astype(np.float64) - T0.astype(np.float64)))
+    print(f"svd_fp32 on the GPU, 1M points, {orientation}: {flips_vs_oracle} match flips and |dT|_F = {dT:.3g} against the oracle's "
+          f"solver; against the closed form {flips_vs_closed} of {len(d['match_nbr'])} flips, |dT|_F = {dT_closed:.3g}")
+    assert flips_vs_oracle == 0 and dT <= 1e-6 and np.array_equal(T, T_o)
+    _every_intermediate(d, do, orientation)
+    if orientation == "generic":
+        assert flips_vs_closed <= 32 and dT_closed <= 1e-4
+    else:
+        assert flips_vs_closed > 1000       # the ill-conditioned inputs are there: the default and the reference's arithmetic part
+
+
+def test_mode_is_validated(ctx):
+    import plade_amd
+    with pytest.raises(plade_amd.PladeError):
+        ctx.set_params(closest_point_mode=2)
+    ctx.params.closest_point_mode = 0
+    ctx.set_params(closest_point_mode=0)

@@ -230,3 +230,21 @@ def test_cluster_order_heap_sort_branch():
             b = plade_amd.cluster_order(s, mode=3, depth_limit=depth)
             assert np.array_equal(a, b), (len(s), depth)
         assert np.array_equal(plade_amd.cluster_order(s, mode=3), plade_amd.cluster_order(s, mode=1))
+
+
+def test_hypot_formula_is_glibc_s(oracle):
+    """closest_point_mode = svd_fp32: OpenCV's Jacobi rotation calls the C library's hypot() (lapack.cpp:579).  The GPU cannot,
+    so kernel (plade_amd/csrc/k_svd.h: hypot_corrected) and oracle (orc_math.h: hypot_glibc235) evaluate one explicit formula --
+    the kernel of glibc 2.35's hypot without FMA.  Here: that formula against THIS machine's libm, bit for bit, on arguments
+    spread over 40 binades (the solver's are squared norms and inner products of columns of magnitude 1 ... 1e13)."""
+    rng = np.random.default_rng(7)
+    n = 200000
+    x = (rng.random(n) - 0.5) * np.exp2(rng.uniform(-20, 45, n))
+    y = (rng.random(n) - 0.5) * np.exp2(rng.uniform(-20, 45, n))
+    x[:100] = 0.0
+    y[100:200] = 0.0
+    y[200:300] = x[200:300]
+    bad = 0
+    for a, b in zip(x.tolist(), y.tolist()):
+        bad += oracle.L.orc_hypot(a, b) != oracle.L.orc_libm_hypot(a, b)
+    assert bad == 0
