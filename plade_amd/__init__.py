@@ -168,7 +168,8 @@ class Cloud:
     def __init__(self, ctx, pos_nrm):
         self.ctx = ctx
         a = _f32(pos_nrm)
-        assert a.ndim == 2 and a.shape[1] == 6
+        if a.ndim != 2 or a.shape[1] != 6:
+            raise ValueError(f"Cloud: an (N, 6) array x y z nx ny nz is required, got shape {a.shape}")
         self.n = len(a)
         self.h = C.c_void_p()
         ctx._check(ctx.L.plade_cloud_upload(ctx.h, _ptr(a), self.n, C.byref(self.h)))
@@ -375,6 +376,7 @@ class Context:
     def registration(self, tgt, src):
         """plade.h:58.  Returns (ok, T 4x4)."""
         tgt, src = _f32(tgt), _f32(src)
+        self._check_cloud(tgt, "registration"); self._check_cloud(src, "registration")
         T = np.zeros((4, 4), np.float32)
         rc = self._check(self.L.plade_registration(self.h, _ptr(tgt), len(tgt), _ptr(src), len(src), _ptr(T)),
                          allow=(PLADE_EFAIL,))
@@ -384,9 +386,11 @@ class Context:
         """plade.h:58 in batch mode: registers (tgt, src) and starts the upload of the pair the next call will be handed.
         The arrays must be C-contiguous float32 and stay alive and unchanged until that call."""
         for a in (tgt, src, next_tgt, next_src):
-            assert a is None or (a.dtype == np.float32 and a.flags["C_CONTIGUOUS"])
+            if a is not None:
+                self._check_cloud(a, "registration_next")
         T = np.zeros((4, 4), np.float32)
         nt, ns = (next_tgt, next_src) if next_tgt is not None and next_src is not None else (None, None)
+        self._announced = [(nt, ns)] if nt is not None else None      # alive until the next call consumes or drops them
         rc = self._check(self.L.plade_registration_next(self.h, _ptr(tgt), len(tgt), _ptr(src), len(src), _ptr(nt),
                                                         len(nt) if nt is not None else 0, _ptr(ns),
                                                         len(ns) if ns is not None else 0, _ptr(T)), allow=(PLADE_EFAIL,))
@@ -398,13 +402,28 @@ class Context:
         ns = (C.c_uint32 * len(arrs))(*[len(a) for a in arrs])
         return ptrs, ns
 
-    def registration_pairs(self, pairs, next_pairs=None):
+    @staticmethod
+    def _check_cloud(a, what):
+        """The library reads len(a) x 6 floats behind the pointer: anything else than a C-contiguous (N, 6) float32 array would
+        make it read past the buffer (python -O strips asserts, so this raises)."""
+        if not isinstance(a, np.ndarray) or a.dtype != np.float32 or a.ndim != 2 or a.shape[1] != 6 or not a.flags["C_CONTIGUOUS"]:
+            raise ValueError(f"{what}: a C-contiguous float32 array of shape (N, 6) is required, got "
+                             f"{getattr(a, 'dtype', type(a))} {getattr(a, 'shape', '')}")
+        if len(a) == 0:
+            raise ValueError(f"{what}: empty cloud")
+
+    def registration_pairs(self, pairs, next_pairs=None, raise_on_error=True):
         """plade.h:58 in batch mode, one GROUP of 1..8 pairs per call (plade_registration_pairs): pairs = [(tgt, src), ...];
         next_pairs = the pairs the next call on this context will be handed (their upload is started now).  The arrays must be
-        C-contiguous float32 and stay alive and unchanged until that call.  Returns [(ok, T 4x4), ...]."""
+        C-contiguous (N, 6) float32 and stay alive and UNCHANGED until that call (the context keeps a reference to them until
+        then; changing their contents meanwhile is the caller's race).  Returns [(ok, T 4x4), ...]; with raise_on_error=False a
+        pair the library refused (status other than OK / EFAIL) does not raise: [(status, T), ...] with the PLADE_E* codes."""
+        if not 1 <= len(pairs) <= 8 or (next_pairs and len(next_pairs) > 8):
+            raise ValueError("registration_pairs: a group holds 1..8 pairs")
         for pr in list(pairs) + list(next_pairs or []):
             for a in pr[:2]:
-                assert a.dtype == np.float32 and a.flags["C_CONTIGUOUS"]
+                self._check_cloud(a, "registration_pairs")
+        self._announced = [(p[0], p[1]) for p in next_pairs] if next_pairs else None   # alive until the next call consumes or drops them
         k = len(pairs)
         tp, tn = self._cloud_table([p[0] for p in pairs])
         sp, sn = self._cloud_table([p[1] for p in pairs])
@@ -417,19 +436,25 @@ class Context:
         T = np.zeros((k, 4, 4), np.float32)
         st = np.zeros(k, np.int32)
         self._check(self.L.plade_registration_pairs(self.h, k, tp, tn, sp, sn, nk, ntp, ntn, nsp, nsn, _ptr(T), _ptr(st)))
+        if not raise_on_error:
+            return [(int(st[i]), T[i].copy()) for i in range(k)]
         for i in range(k):
             if st[i] not in (0, PLADE_EFAIL):
                 raise PladeError(int(st[i]), self.pair_error(i))
         return [(bool(st[i] == 0), T[i].copy()) for i in range(k)]
 
-    def registration_pairs_dev(self, clouds):
+    def registration_pairs_dev(self, clouds, raise_on_error=True):
         """The same group call on resident clouds: clouds = [(tgt Cloud, src Cloud), ...]."""
         k = len(clouds)
+        if not 1 <= k <= 8:
+            raise ValueError("registration_pairs_dev: a group holds 1..8 pairs")
         tp = (C.c_void_p * k)(*[c[0].h.value for c in clouds])
         sp = (C.c_void_p * k)(*[c[1].h.value for c in clouds])
         T = np.zeros((k, 4, 4), np.float32)
         st = np.zeros(k, np.int32)
         self._check(self.L.plade_registration_pairs_dev(self.h, k, tp, sp, _ptr(T), _ptr(st)))
+        if not raise_on_error:
+            return [(int(st[i]), T[i].copy()) for i in range(k)]
         for i in range(k):
             if st[i] not in (0, PLADE_EFAIL):
                 raise PladeError(int(st[i]), self.pair_error(i))

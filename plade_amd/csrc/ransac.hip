@@ -2340,7 +2340,8 @@ void enqueue_iteration(plade_ctx *ctx, const RArgs &A) {
 
 void launch_iteration(plade_ctx *ctx, RansacWork &W, const RArgs &A) {
     const bool stamped = ctx->graph_clocks();   // profiled on the graph path: its own graph, with clock pointers in the scan launches
-    if ((ctx->profiling() && !stamped) || getenv("PLADE_NO_GRAPH")) { enqueue_iteration(ctx, A); HIP_TRY(hipGetLastError()); return; }
+    static const bool no_graph = getenv("PLADE_NO_GRAPH") != nullptr;   // A/B timing hook, looked up once
+    if ((ctx->profiling() && !stamped) || no_graph) { enqueue_iteration(ctx, A); HIP_TRY(hipGetLastError()); return; }
     const uint64_t key = hash_bytes(&A, sizeof(A)) ^ (stamped ? 0x9e3779b97f4a7c15ull : 0ull);
     auto it = W.graphs.find(key);
     if (it == W.graphs.end()) {

@@ -179,11 +179,33 @@ void register_group(plade_ctx *ctx, int first, int count, const CloudDev *const 
     PLADE_REQUIRE(count >= 1 && first >= 0 && first + count <= PLADE_GROUP_MAX, PLADE_EINVAL, "a group holds one to PLADE_GROUP_MAX pairs");
     Clock::time_point t0 = Clock::now();
     plade_ctx *pcs[PLADE_GROUP_MAX] = {};
+    struct ShardOff {      // pair 0 of a group of several runs on ctx itself: its shard is set aside for the call
+        plade_ctx *c; plade_ctx::CandidateShard saved; bool off;
+        ShardOff(plade_ctx *c_, bool off_) : c(c_), saved(c_->shard), off(off_) { if (off) c->shard = plade_ctx::CandidateShard{}; }
+        ~ShardOff() { if (off) c->shard = saved; }
+    } shard_off(ctx, count > 1);
+    // whatever way this call ends, no pair context keeps a grid marked "queued by the group" (a later single-pair call on it
+    // would adopt a stale one)
+    struct ReadyGuard {
+        plade_ctx **pcs; int count;
+        ~ReadyGuard() {
+            for (int i = 0; i < count; ++i) {
+                if (!pcs[i] || !pcs[i]->reg_work) continue;
+                for (int side = 0; side < 2; ++side) {
+                    const WholeVoxelSlot sl = whole_voxel_slot(*pcs[i]->reg_work, side == 0, 0);
+                    *sl.ready = false; *sl.planes_ready = false; *sl.obb_ready = false;
+                }
+            }
+        }
+    } ready_guard{pcs, count};
     for (int i = 0; i < count; ++i) {
         if (first + i == 0) { pcs[i] = ctx; continue; }
         pcs[i] = peer_ctx(ctx, first + i);
         pcs[i]->params = ctx->params;
-        pcs[i]->shard = ctx->shard;
+        // the candidate shard is an axis of ONE pair (include/plade_hip.h): the pairs of a group run their tails on concurrent
+        // threads, and a collective entered from several threads in an order that differs between the ranks would mismatch
+        // or hang (advisor r4) -- a batch shards whole pairs over the ranks instead
+        pcs[i]->shard = count > 1 ? plade_ctx::CandidateShard{} : ctx->shard;
         pcs[i]->stats.clear();
         pcs[i]->dump.clear();
         pcs[i]->last_error.clear();
@@ -301,9 +323,14 @@ void register_group(plade_ctx *ctx, int first, int count, const CloudDev *const 
         } catch (const Err &e) { errs[i] = e; }
         catch (const std::exception &e) { errs[i] = Err{PLADE_EDEVICE, e.what()}; }
     };
-    std::thread ths[PLADE_GROUP_MAX];
-    for (int i = 0; i < count; ++i) {
+    struct Joiner {       // an exception between the first helper's start and the joins must not destroy a joinable thread
+        std::thread t[PLADE_GROUP_MAX];
+        ~Joiner() { for (std::thread &x : t) if (x.joinable()) x.join(); }
+    } joiner;
+    std::thread *ths = joiner.t;
+    for (int i = 0; i < count; ++i)
         if (pcs[i] != ctx) HIP_TRY(hipStreamWaitEvent(pcs[i]->stream, ctx->ev_group, 0));
+    for (int i = 0; i < count; ++i) {
         if (i == 0) continue;   // the first pair of the part runs on the calling thread
         ths[i] = std::thread([&, i]() {
             const double cpu0 = thread_cpu_seconds();
@@ -314,12 +341,6 @@ void register_group(plade_ctx *ctx, int first, int count, const CloudDev *const 
     }
     tail(0);
     for (int i = 1; i < count; ++i) ths[i].join();
-    for (int i = 0; i < count; ++i) {   // a pair that gave up before its preparation must not leave its grid marked as queued
-        for (int side = 0; side < 2; ++side) {
-            const WholeVoxelSlot sl = whole_voxel_slot(*pcs[i]->reg_work, side == 0, 0);
-            *sl.ready = false; *sl.planes_ready = false; *sl.obb_ready = false;
-        }
-    }
     for (int i = 0; i < count; ++i)
         if (errs[i].code) { pcs[i]->drop_reads(); pcs[i]->last_error = errs[i].msg; status[i] = errs[i].code; }
 }
@@ -498,6 +519,31 @@ extern "C" int plade_registration(plade_ctx *ctx, const float *tgt_pos_nrm, uint
 }
 
 namespace {
+// The fallback of a group that raised as a whole: pair i alone (on peer context i, as in the group), `prepare(i)` first (the
+// host-pointer path uploads the pair's clouds again: the failed group upload stopped at the first refused cloud).
+template <class Prepare>
+void register_pairs_one_by_one(plade_ctx *ctx, int count, const CloudDev *const ct[], const CloudDev *const cs[], float *T16, int32_t *status,
+                               Prepare prepare) {
+    ctx->stats.add("group_fallback_pair_by_pair", 1);
+    for (int i = 0; i < count; ++i) {
+        plade_ctx *pc = i ? peer_ctx(ctx, i) : ctx;
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipStreamSynchronize(pc->stream);
+        ctx->drop_reads();
+        for (int k = 0; k < 16; ++k) T16[16 * i + k] = (k % 5 == 0) ? 1.f : 0.f;
+        const int zero = 0;
+        try {
+            prepare(i);
+            register_group(ctx, i, 1, ct + i, cs + i, &zero, &zero, true, T16 + 16 * i, status + i);
+        } catch (const Err &e) {
+            ctx->drop_reads();
+            if (i) { pc->stats.clear(); pc->dump.clear(); }
+            pc->last_error = e.msg;
+            status[i] = e.code;
+        }
+    }
+}
+
 // Batch mode: the clouds of THIS call (taken over from the prefetch of the previous call when they are the announced ones),
 // then the upload of the NEXT call's clouds started on the prefetch stream; then the group is registered.
 int registration_batch(plade_ctx *ctx, uint32_t count, const float *const *tgt, const uint32_t *n_t, const float *const *src,
@@ -517,18 +563,32 @@ int registration_batch(plade_ctx *ctx, uint32_t count, const float *const *tgt, 
     }
     for (uint32_t i = 0; i < count; ++i) { ptr[2 * i] = tgt[i]; ptr[2 * i + 1] = src[i]; n[2 * i] = n_t[i]; n[2 * i + 1] = n_s[i]; }
     for (uint32_t i = 0; i < next_count; ++i) { nptr[2 * i] = next_tgt[i]; nptr[2 * i + 1] = next_src[i]; nn[2 * i] = next_n_t[i]; nn[2 * i + 1] = next_n_s[i]; }
+    // A cloud the path cannot digest (non-finite coordinates, a bounding box without extent, ...) fails the upload or the
+    // extraction of the WHOLE launch sequence; the reference's loop (main.cpp:122-148) fails that pair only.  So a group that
+    // raises is registered again pair by pair, each under its own guard: the healthy pairs return what they return alone,
+    // the offending one its error code in status[i] and its message in plade_last_error(plade_pair_ctx(ctx, i)).
+    bool group_ok = true;
     {
         StageTimer t(ctx, "t_upload");
         Clock::time_point t0 = Clock::now();
-        if (!cloud_take_prefetched(ctx, 2 * (int)count, ptr, n, out)) cloud_upload_many(ctx, 2 * (int)count, ptr, n, out);
-        else ctx->stats.add("upload_prefetched", 1);
+        try {
+            if (!cloud_take_prefetched(ctx, 2 * (int)count, ptr, n, out)) cloud_upload_many(ctx, 2 * (int)count, ptr, n, out);
+            else ctx->stats.add("upload_prefetched", 1);
+        } catch (const Err &) { if (count == 1) throw; group_ok = false; }
         ctx->stats.add("t_upload_take", secs_since(t0));
         t0 = Clock::now();
         if (next_count) cloud_prefetch(ctx, 2 * (int)next_count, nptr, nn);
         ctx->stats.add("t_upload_submit", secs_since(t0));
     }
     const int zero[PLADE_GROUP_MAX] = {};
-    register_group_parts(ctx, (int)count, ct, cs, zero, zero, true, T16, status);
+    if (group_ok) {
+        try { register_group_parts(ctx, (int)count, ct, cs, zero, zero, true, T16, status); return PLADE_OK; }
+        catch (const Err &) { if (count == 1) throw; }
+    }
+    register_pairs_one_by_one(ctx, (int)count, ct, cs, T16, status, [&](int i) {
+        CloudDev *o[2] = {out[2 * i], out[2 * i + 1]};
+        cloud_upload_many(ctx, 2, ptr + 2 * i, n + 2 * i, o);
+    });
     return PLADE_OK;
 }
 }  // namespace
@@ -580,7 +640,11 @@ extern "C" int plade_registration_pairs_dev(plade_ctx *ctx, uint32_t count, plad
         ctx->last_error.clear();
         cloud_drop_prefetch(ctx);
         const int zero[PLADE_GROUP_MAX] = {};
-        register_group_parts(ctx, (int)count, ct, cs, zero, zero, true, T16, status);
+        try { register_group_parts(ctx, (int)count, ct, cs, zero, zero, true, T16, status); }
+        catch (const Err &) {
+            if (count == 1) throw;
+            register_pairs_one_by_one(ctx, (int)count, ct, cs, T16, status, [](int) {});   // see registration_batch
+        }
         return PLADE_OK;
     });
 }

@@ -137,10 +137,62 @@ def test_a_failing_pair_does_not_touch_its_partner(scenes, alone):
 def test_bad_group_arguments_are_refused(scenes):
     c = plade_amd.Context(0, orient_normals=1)
     pr = (scenes[1][0], scenes[1][1])
-    with pytest.raises(plade_amd.PladeError):
+    with pytest.raises((plade_amd.PladeError, ValueError)):
         c.registration_pairs([pr] * 9)
-    with pytest.raises(plade_amd.PladeError):
+    with pytest.raises((plade_amd.PladeError, ValueError)):
         c.registration_pairs([])
+    # the library reads N x 6 floats behind every pointer: anything else is refused before the call (python -O strips asserts)
+    for bad in (pr[0][:, :3].copy(), pr[0].reshape(-1), pr[0].astype(np.float64), pr[0][::2]):
+        with pytest.raises(ValueError):
+            c.registration_pairs([(bad, pr[1])])
+        with pytest.raises(ValueError):
+            c.registration_pairs([pr], [(pr[0], bad)])
+    c.close()
+
+
+@pytest.mark.parametrize("kind", ["nan", "inf", "no_extent"])
+@pytest.mark.parametrize("pos", [0, 2, 3])
+def test_a_malformed_cloud_fails_its_pair_only(scenes, alone, kind, pos):
+    """A cloud the path refuses -- a non-finite coordinate (the upload's validation) or a bounding box without extent (the
+    extraction's) -- raises inside the launch sequence the whole group shares.  The reference's loop (main.cpp:122-148) fails
+    that pair only; so does the group call: the pair's status carries the error code and its context the message, its
+    transform is the identity, and the three healthy neighbours return the bits of the pairs alone (advisor r4) -- through
+    host pointers with a prefetch announced, and on resident clouds."""
+    bad = scenes[1][1].copy()
+    if kind == "nan":
+        bad[1234, 1] = np.nan
+    elif kind == "inf":
+        bad[77, 0] = np.inf
+    else:
+        bad[:, :3] = bad[0, :3]          # every point in one place
+    order = [0, 1, 2, 1]
+    prs = [(scenes[k][0], scenes[k][1]) for k in order]
+    prs[pos] = (prs[pos][0], bad)
+    c = plade_amd.Context(0, orient_normals=1)
+    for rep in range(2):                 # the second call takes the prefetched clouds of the first
+        res = c.registration_pairs(prs, prs if rep == 0 else None, raise_on_error=False)
+        for q, (st, T) in enumerate(res):
+            if q == pos:
+                assert st not in (plade_amd.PLADE_OK,), (kind, st)
+                assert np.array_equal(T, np.eye(4, dtype=np.float32))
+                if kind != "no_extent":
+                    assert st == plade_amd.PLADE_EINVAL and "finite" in c.pair_error(q), c.pair_error(q)
+            else:
+                assert st == plade_amd.PLADE_OK and np.array_equal(T, alone[order[q]][1]), (kind, pos, q)
+        assert c.stats().get("group_fallback_pair_by_pair", 0) == 1
+    if kind == "no_extent":              # resident clouds: the upload accepts it, the extraction refuses it
+        cl = [(c.upload(a), c.upload(b)) for a, b in prs]
+        res = c.registration_pairs_dev(cl, raise_on_error=False)
+        for q, (st, T) in enumerate(res):
+            if q == pos:
+                assert st != plade_amd.PLADE_OK
+            else:
+                assert st == plade_amd.PLADE_OK and np.array_equal(T, alone[order[q]][1])
+        for a, b in cl:
+            a.free(); b.free()
+    # the context is as good as new
+    ok, T = c.registration_pairs(prs[:1] if pos else prs[1:2])[0]
+    assert ok
     c.close()
 
 
