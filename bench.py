@@ -483,8 +483,10 @@ def main():
     # 68 bytes of result per pair -- goes over their loopback rendezvous (plade_amd/rendezvous.py; the ranks of
     # `torch.distributed.run --nnodes=1` share one host).  The timed region is bracketed with hipDeviceSynchronize through
     # the library.  PLADE_BENCH_TORCH=1 restores the torch.distributed exchange (RCCL; gloo with PLADE_BENCH_ONE_GPU).
-    torch = dist = comm = dev = None
+    torch = dist = comm = dev = boot = None
+    exchange_note = "single process"
     if world > 1 and os.environ.get("PLADE_BENCH_TORCH") == "1":
+        exchange_note = "torch.distributed"
         import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -493,8 +495,19 @@ def main():
         dist.init_process_group(backend="gloo" if one_gpu else "nccl", world_size=world, rank=rank)  # nccl == RCCL on ROCm
         dev = torch.device("cpu") if one_gpu else torch.device("cuda", local_rank)
     elif world > 1:
+        # Default: RCCL over xGMI, bound by the library itself (dlopen, no torch in the process): plade_amd/rccl_comm.py.  The
+        # loopback rendezvous carries the 128-byte unique id and is the fallback where RCCL cannot serve (two ranks on one
+        # device -- the one-GPU test hook --, no librccl, an initialisation that does not finish): the ranks agree on it.
         from plade_amd.rendezvous import Rendezvous
-        comm = Rendezvous.from_env()
+        boot = Rendezvous.from_env()
+        comm, exchange_note = boot, "loopback rendezvous (plade_amd/rendezvous.py)"
+        if os.environ.get("PLADE_BENCH_NO_RCCL") != "1":
+            from plade_amd import rccl_comm
+            rc_comm, why = rccl_comm.connect(rank, world, local_rank, boot)
+            if rc_comm is not None:
+                comm, exchange_note = rc_comm, "rccl (ncclAllGather over xGMI, librccl opened by libplade_hip.so; bootstrap: loopback rendezvous)"
+            else:
+                exchange_note += f"; rccl not used: {why}"
 
     import plade_amd
     from plade_amd.synth import make_pair
@@ -928,8 +941,7 @@ def main():
             "ms_per_step": elapsed / n_timed * 1e3,
             "higher_is_better": True,
             "scaling": "weak",
-            "rank_exchange": ("single process" if world == 1 else "loopback rendezvous (plade_amd/rendezvous.py)" if comm is not None
-                              else "torch.distributed"),
+            "rank_exchange": exchange_note,
             "torch_in_process": "torch" in sys.modules,
             "vs_baseline": None,
             "dtype": "f32",
@@ -989,7 +1001,9 @@ def main():
         ctxs[w].close()
     if comm is not None:
         comm.close()
-    elif dist is not None:
+    if boot is not None and boot is not comm:
+        boot.close()
+    if dist is not None:
         dist.destroy_process_group()
 
 

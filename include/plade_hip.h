@@ -27,6 +27,7 @@ extern "C" {
 
 typedef struct plade_ctx plade_ctx;
 typedef struct plade_cloud plade_cloud; /* device-resident oriented point cloud */
+typedef struct plade_comm plade_comm;   /* RCCL communicator of this rank (multi-GPU), see below */
 
 /* Context: owns the HIP stream, scratch pools and the debug dump. */
 int plade_ctx_create(int device, plade_ctx **out);
@@ -35,6 +36,9 @@ const char *plade_last_error(const plade_ctx *ctx);
 const char *plade_version(void);
 /* hipDeviceSynchronize on `device`: everything this process has queued there has finished (benchmark brackets). */
 int plade_device_synchronize(int device);
+/* GPUs this process sees (hipGetDeviceCount; 0 without a GPU or a HIP runtime): the CLI's batch mode spreads the pairs of the
+ * list (the loop code/PLADE/main.cpp:122-148) over all of them by default. */
+int plade_device_count(void);
 
 /* Tunables that are hard-coded literals in the reference (defaults = reference values):
  *   max_planes      40     code/PLADE/plade.cpp:604   (extract(): top-40 cap)
@@ -260,6 +264,33 @@ int plade_registration_minsupport(plade_ctx *ctx, const float *tgt_pos_nrm, uint
 typedef int (*plade_exchange_fn)(void *user, int32_t *values, uint32_t count, uint32_t rank, uint32_t world);
 int plade_set_candidate_shard(plade_ctx *ctx, uint32_t rank, uint32_t world, uint32_t min_candidates, plade_exchange_fn exchange,
                               void *user);
+/* The shard applies to calls that register ONE pair (plade_registration, _next, _dev, _planes, _minsupport and groups of
+ * one); inside a group of several pairs (plade_registration_pairs* with count > 1) it is switched off for the call: the pairs'
+ * tails run on concurrent threads, and collectives entered from several threads in an order that may differ between the
+ * ranks would mismatch -- a batch shards whole pairs over the ranks instead. */
+
+/* ---- RCCL communicator (multi-GPU): one process per GPU, ranks of one node over xGMI ---------------------------
+ * The two exchange steps of the path -- the 68 bytes of result per pair that batch mode gathers once per batch (the loop
+ * code/PLADE/main.cpp:122-148 sharded pair i -> rank i % world) and the 8 bytes per candidate of the candidate shard above --
+ * are each ONE ncclAllGather.  librccl is opened with dlopen() on first use: a single-GPU host never loads it and the library
+ * keeps no link dependency on it.
+ *   plade_comm_unique_id   rank 0: 128 bytes (ncclGetUniqueId) that the host hands to every rank of the job by its own means
+ *                          (bench.py / plade_amd.rccl_comm: the ranks' rendezvous file; MPI_Bcast; a pipe)
+ *   plade_comm_create      every rank, collectively: ncclCommInitRank on `device`
+ *   plade_comm_all_gather  send: `bytes` bytes of this rank (host memory), recv: world x bytes in rank order (host memory);
+ *                          staged through device memory, one ncclAllGather, blocking.  A barrier is an all-gather of one word.
+ *   plade_set_candidate_shard_comm   the candidate shard with the library doing the exchange itself: the counts the
+ *                          verification kernel wrote stay in device memory, one ncclAllGather on the context's stream behind that
+ *                          kernel, one read-back of all ranks' counts -- no host callback.  comm == NULL switches the axis off (a
+ *                          communicator of one rank still runs the exchange: that is how a one-GPU box tests it).  The communicator must outlive its use by the context and serve one call at a time.
+ * Errors: PLADE_EDEVICE (no librccl, RCCL error; plade_comm_last_error(comm or NULL) has the text). */
+#define PLADE_COMM_ID_BYTES 128
+int plade_comm_unique_id(void *id128);
+int plade_comm_create(int device, uint32_t rank, uint32_t world, const void *id128, plade_comm **out);
+int plade_comm_all_gather(plade_comm *comm, const void *send, void *recv, uint64_t bytes);
+void plade_comm_destroy(plade_comm *comm);
+const char *plade_comm_last_error(const plade_comm *comm);
+int plade_set_candidate_shard_comm(plade_ctx *ctx, plade_comm *comm, uint32_t min_candidates);
 
 /* Optional page-locking of caller-owned cloud buffers (hipHostRegister / hipHostUnregister): the host-pointer overloads
  * above then upload by asynchronous DMA instead of through the runtime's bounce buffer.  The reference has no counterpart

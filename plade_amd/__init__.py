@@ -24,6 +24,8 @@ ABI_SYMBOLS = [
     "plade_sort_pairs", "plade_host_pin", "plade_host_unpin", "plade_score_planes_subset", "plade_registration_next", "plade_cluster_transforms", "plade_device_synchronize", "plade_selftest_readback",
     "plade_registration_pairs", "plade_registration_pairs_dev", "plade_pair_ctx", "plade_set_candidate_shard", "plade_diag_launches", "plade_diag_cluster_order", "plade_sort_segments",
     "plade_closest_points", "plade_lines_meet",
+    "plade_device_count", "plade_comm_unique_id", "plade_comm_create", "plade_comm_all_gather", "plade_comm_destroy", "plade_comm_last_error",
+    "plade_set_candidate_shard_comm",
 ]
 
 

@@ -30,6 +30,15 @@ def gather_results(local_T, local_ok, n_items, rank, world, device=None, comm=No
     assert len(mine) == len(local_T) == len(local_ok)
     if world == 1:   # nothing to exchange (and no torch in a single-GPU process: see bench.py)
         return np.asarray(local_T, np.float32).reshape(n_items, 4, 4).copy(), np.asarray(local_ok, bool).copy()
+    if comm is not None and hasattr(comm, "all_gather_array"):
+        # RCCL (plade_amd/rccl_comm.py): ONE ncclAllGather of equally sized blocks, 68 bytes per pair, shards padded to the same length
+        per = (n_items + world - 1) // world
+        buf = np.zeros((per, 17), np.float32)
+        if len(mine):
+            buf[: len(mine), :16] = np.asarray(local_T, np.float32).reshape(len(mine), 16)
+            buf[: len(mine), 16] = np.asarray(local_ok, np.float32)
+        parts = comm.all_gather_array(buf)
+        return _assemble(parts, n_items, world) if rank == 0 else (None, None)
     if comm is not None:
         buf = np.zeros((len(mine), 17), np.float32)
         if len(mine):
@@ -76,6 +85,15 @@ def sharded_overlap_counts(ctx, src_ds, tgt_ds, T, centers, src_radius, inlier_d
              if mine else np.zeros(0, np.int32))
     if world == 1:
         return local
+    if comm is not None and hasattr(comm, "all_gather_array"):
+        per = (K + world - 1) // world
+        buf = np.full(per, -2, np.int32)
+        buf[: len(mine)] = local
+        out = np.zeros(K, np.int32)
+        for r, a in enumerate(comm.all_gather_array(buf)):
+            idx = shard(K, r, world)
+            out[idx] = a[: len(idx)]
+        return out
     if comm is not None:
         out = np.zeros(K, np.int32)
         for r, a in enumerate(comm.all_gather(local)):

@@ -68,6 +68,11 @@ extern "C" int plade_device_synchronize(int device) {
     return hipDeviceSynchronize() == hipSuccess ? PLADE_OK : PLADE_EDEVICE;
 }
 
+extern "C" int plade_device_count(void) {
+    int count = 0;
+    return hipGetDeviceCount(&count) == hipSuccess && count > 0 ? count : 0;
+}
+
 extern "C" const char *plade_last_error(const plade_ctx *ctx) { return ctx ? ctx->last_error.c_str() : "null ctx"; }
 
 extern "C" int plade_set_params(plade_ctx *ctx, const plade_params *p) {

@@ -83,6 +83,7 @@ struct plade_cloud {
 };
 
 namespace plade { struct RegistrationWork; struct RansacWork; }
+namespace plade { void comm_all_gather_dev(plade_comm *c, const void *d_send, void *d_recv, size_t bytes, hipStream_t stream); }
 
 struct plade_ctx {
     int device = 0;
@@ -110,7 +111,8 @@ struct plade_ctx {
         plade::DBuf<int> d;      // 8 ints per box being reduced
     } pf;
     plade_params params;
-    struct CandidateShard { uint32_t rank = 0, world = 1, min_candidates = 0; plade_exchange_fn exchange = nullptr; void *user = nullptr; } shard;
+    struct CandidateShard { uint32_t rank = 0, world = 1, min_candidates = 0; plade_exchange_fn exchange = nullptr; void *user = nullptr;
+                            plade_comm *comm = nullptr; /* RCCL form (comm.hip): the counts never leave the device before the all-gather */ } shard;
     // number of completed host waits on `stream` (sync(), the extraction's flag waits): a stage that left results in host-mapped
     // memory behind kernels queued earlier remembers the count at enqueue time and knows from it whether anything has waited since
     uint64_t wait_epoch = 0;

@@ -192,10 +192,13 @@ int batch(const char *list_path, const char *result_path) {
     // a time (64 pairs: 1.0 s against 1.4 s with four workers and 2.5 s with four workers x eight pairs), while a long one is
     // worth the full pipeline of the library's batch mode (bench.py: 4 groups of 8 pairs in flight per GPU).
     // PLADE_GPUS x PLADE_INFLIGHT workers, each taking PLADE_GROUP (1..8) consecutive pairs of the list per call (one GROUP:
-    // the plane extraction of its clouds is one launch sequence, plade.h registration_group).  PLADE_GPU_MAP ("0,0,1,1", a test
-    // hook for boxes with fewer GPUs than PLADE_GPUS) maps worker-side device numbers to physical ones.
+    // the plane extraction of its clouds is one launch sequence, plade.h registration_group).  PLADE_GPUS defaults to EVERY GPU
+    // the process sees: the pairs of a list are independent (main.cpp:122-148 is a plain loop) and `PLADE pairs.txt out.txt`
+    // carries no other switch, so batch mode shards over the node's GPUs unasked (worker w runs on GPU w % PLADE_GPUS; the
+    // result file is written in input order whatever finishes first).  PLADE_GPU_MAP ("0,0,1,1", a test hook for boxes with
+    // fewer GPUs than PLADE_GPUS) maps worker-side device numbers to physical ones.
     const bool long_list = jobs.size() >= 512;
-    const int n_gpus = env_int("PLADE_GPUS", 1), per_gpu = env_int("PLADE_INFLIGHT", long_list ? 4 : 2);
+    const int n_gpus = env_int("PLADE_GPUS", std::max(1, plade_gpu_count())), per_gpu = env_int("PLADE_INFLIGHT", long_list ? 4 : 2);
     const size_t group = (size_t)std::min(env_int("PLADE_GROUP", long_list ? 8 : 4), (int)registration_group_max);
     std::vector<int> gpu_map(n_gpus);
     for (int g = 0; g < n_gpus; ++g) gpu_map[g] = g;

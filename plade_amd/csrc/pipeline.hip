@@ -209,6 +209,7 @@ struct RegistrationWork {
     CandidateSet cand;
     TargetGrid grid, sp_grid;
     DBuf<float> d_rt12, d_T16;      // d_T16: transforms | centres | overlap counts | sphere flags of the verified candidates
+    DBuf<int32_t> d_shard_all;      // candidate shard over RCCL: every rank's (counts | flags) block after the all-gather
     OverlapWork ov_work;
     // host side of the cluster stage: ~30 000 clusters per registration, five arrays of them -- kept from call to call (a fresh
     // std::vector of 100-200 KB per call is an mmap, a page fault per 4 KB and an munmap: ~0.3 ms of system time per registration)
@@ -503,37 +504,56 @@ bool run_registration(plade_ctx *ctx, RegistrationWork &W, const CloudDev &tgt, 
         // only this rank's candidates k % world == rank are scored here and the counts of the others arrive through the
         // caller's exchange.
         const plade_ctx::CandidateShard &sh = ctx->shard;
-        const bool sharded = sh.world > 1 && sh.exchange && Kv >= sh.min_candidates;
+        const bool sharded = ((sh.world > 1 && sh.exchange) || sh.comm) && Kv >= sh.min_candidates;   // a communicator of ONE rank still exchanges (the one-GPU test of this path)
+        const bool by_rccl = sharded && sh.comm;
         std::vector<uint32_t> mine;
         for (uint32_t i = 0; i < Kv; ++i) if (!sharded || i % sh.world == sh.rank) mine.push_back(i);
         const uint32_t Km = (uint32_t)mine.size();
+        // slots per rank: the RCCL form all-gathers equally sized blocks (counts | sphere flags of ceil(Kv / world) candidates)
+        const uint32_t per = by_rccl ? cdiv(Kv, sh.world) : Km;
         // transforms | centres | counts | sphere flags in one block: the zeros of the last two travel with the upload (a memset of
         // a few hundred bytes is one or two fill commands of its own)
-        W.d_T16.ensure(21 * (size_t)Km + 4);
+        W.d_T16.ensure(19 * (size_t)Km + 2 * (size_t)per + 4);
         float *d_centers = W.d_T16.p + 16 * (size_t)Km;
         int32_t *d_counts = reinterpret_cast<int32_t *>(W.d_T16.p + 19 * (size_t)Km);
-        uint32_t *d_any = reinterpret_cast<uint32_t *>(d_counts) + Km;
-        std::vector<float> up(21 * (size_t)Km, 0.f);
+        uint32_t *d_any = reinterpret_cast<uint32_t *>(d_counts) + per;
+        std::vector<float> up(19 * (size_t)Km + 2 * (size_t)per, 0.f);
         for (uint32_t q = 0; q < Km; ++q) {
             memcpy(up.data() + 16 * (size_t)q, T16.data() + 16 * (size_t)mine[q], 64);
             memcpy(up.data() + 16 * (size_t)Km + 3 * (size_t)q, centers.data() + 3 * (size_t)mine[q], 12);
         }
         std::vector<int32_t> back(2 * (size_t)Kv, 0);
-        if (Km) {
-            ctx->h2d(W.d_T16.p, up.data(), 84 * (size_t)Km);
-            HIP_TRY(hipStreamWaitEvent(ctx->stream, W.ev_grid, 0));
-            const float *vsx = sort_source ? W.ov_work.sorted.p : C.d_ds_soa.p;
-            overlap_counts(ctx, W.ov_work, vsx, vsx + C.n_ds, vsx + 2 * (size_t)C.n_ds, C.n_ds,
-                           W.grid, W.d_T16.p, d_centers, Km, (float)C.radius, downSampleDistance, d_counts, d_any, true);
-            std::vector<int32_t> part(2 * (size_t)Km);
-            ctx->d2h(part.data(), d_counts, 8 * (size_t)Km);
-            ctx->sync();
-            for (uint32_t q = 0; q < Km; ++q) { back[mine[q]] = part[q]; back[Kv + mine[q]] = part[Km + q]; }
+        if (Km || by_rccl) {
+            ctx->h2d(W.d_T16.p, up.data(), 4 * up.size());
+            if (Km) {
+                HIP_TRY(hipStreamWaitEvent(ctx->stream, W.ev_grid, 0));
+                const float *vsx = sort_source ? W.ov_work.sorted.p : C.d_ds_soa.p;
+                overlap_counts(ctx, W.ov_work, vsx, vsx + C.n_ds, vsx + 2 * (size_t)C.n_ds, C.n_ds,
+                               W.grid, W.d_T16.p, d_centers, Km, (float)C.radius, downSampleDistance, d_counts, d_any, true);
+            }
+            if (by_rccl) {
+                // ONE ncclAllGather on this stream, behind the kernel that wrote the counts: they never visit the host before
+                // every rank holds all of them (rank r's slot q is candidate q * world + r)
+                int32_t *d_all = W.d_shard_all.ensure(2 * (size_t)per * sh.world + 4);
+                comm_all_gather_dev(sh.comm, d_counts, d_all, 8 * (size_t)per, ctx->stream);
+                std::vector<int32_t> all(2 * (size_t)per * sh.world);
+                ctx->d2h(all.data(), d_all, 4 * all.size());
+                ctx->sync();
+                for (uint32_t r = 0; r < sh.world; ++r)
+                    for (uint32_t q = 0; q < per; ++q) {
+                        const uint32_t i = q * sh.world + r;
+                        if (i < Kv) { back[i] = all[2 * (size_t)per * r + q]; back[Kv + i] = all[2 * (size_t)per * r + per + q]; }
+                    }
+            } else {
+                std::vector<int32_t> part(2 * (size_t)Km);
+                ctx->d2h(part.data(), d_counts, 8 * (size_t)Km);
+                ctx->sync();
+                for (uint32_t q = 0; q < Km; ++q) { back[mine[q]] = part[q]; back[Kv + mine[q]] = part[Km + q]; }
+            }
         }
-        if (sharded) {
-            ctx->stats.add("n_candidates_scored_here", Km);
+        if (sharded) ctx->stats.add("n_candidates_scored_here", Km);
+        if (sharded && !by_rccl)
             PLADE_REQUIRE(sh.exchange(sh.user, back.data(), 2 * Kv, sh.rank, sh.world) == 0, PLADE_EDEVICE, "candidate shard: the exchange failed");
-        }
         for (uint32_t i = 0; i < Kv; ++i) counts[i] = back[Kv + i] ? back[i] : -1;
     }
     std::vector<LengthIndex> ov(Kv);

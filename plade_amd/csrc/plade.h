@@ -63,6 +63,8 @@ bool load_ply_cloud(const std::string &file_name, pcl::PointCloud<pcl::PointNorm
 
 /** Select the GPU used by the calling thread's registrations (default 0). */
 void plade_select_device(int device);
+/** GPUs this process sees (0 without one): the CLI's batch mode spreads the list over all of them by default. */
+int plade_gpu_count();
 
 /** Console of the calling thread's registrations: the messages the reference prints on std::cout / std::cerr go to
  *  these streams instead (nullptr = std::cout / std::cerr again).  Used by the CLI's batch workers. */

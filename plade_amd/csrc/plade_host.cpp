@@ -89,6 +89,7 @@ std::string extension(const std::string &file_name) {  // util.cpp:525-531
 }  // namespace
 
 void plade_select_device(int device) { g_device = device; }
+int plade_gpu_count() { return plade_device_count(); }
 
 void plade_set_thread_console(std::ostream *out, std::ostream *err) { g_out = out; g_err = err; }
 

@@ -82,9 +82,9 @@ def test_world_of_one_needs_no_peer():
 def test_a_stale_port_file_is_ignored(tmp_path):
     """A port file left by a launch that died (nobody listens there, or somebody else does) must not wedge the next one:
     rank 1 keeps retrying until the rank 0 of ITS launch has replaced the file."""
-    import tempfile
+    from plade_amd.rendezvous import _private_dir
     key = f"stale_{os.getpid()}"
-    path = os.path.join(tempfile.gettempdir(), f"plade_rendezvous_{key}")
+    path = os.path.join(_private_dir(), f"plade_rendezvous_{key}")
     with open(path, "w") as f:
         f.write("1 deadbeef\n")                  # port 1: connection refused
     ctx = mp.get_context("spawn")
@@ -98,3 +98,78 @@ def test_a_stale_port_file_is_ignored(tmp_path):
     p0.join(30); p1.join(30)
     assert all(r[1] is False for r in res), res
     assert not os.path.exists(path)
+
+
+def test_the_port_file_is_private_and_nothing_is_unpickled():
+    """Advisor r4: the port file lives in a directory only this user can enter (mode 0700, owner checked, no symlink) with mode
+    0600; the handshake is a fixed-format HMAC proof checked before anything else is read; payloads are JSON + raw numeric
+    arrays -- the module does not import pickle, refuses object arrays and arbitrary objects, and bounds every length."""
+    import socket
+    import stat
+    import struct
+    import threading
+    import plade_amd.rendezvous as rz
+    src = open(rz.__file__).read()
+    assert "import pickle" not in src and "pickle.loads" not in src
+    d = rz._private_dir()
+    st = os.lstat(d)
+    assert stat.S_ISDIR(st.st_mode) and st.st_uid == os.getuid() and (st.st_mode & 0o077) == 0
+    # round trip of what the ranks exchange
+    a, b = socket.socketpair()
+    obj = {"rank": 3, "a": np.arange(5, dtype=np.int32), "l": [1.5, None, "x", [np.float32(2.0)]], "ok": True}
+    th = threading.Thread(target=rz._send, args=(a, obj))
+    th.start()
+    got = rz._recv(b)
+    th.join()
+    assert got["rank"] == 3 and np.array_equal(got["a"], obj["a"]) and got["l"][:3] == [1.5, None, "x"] and got["ok"] is True
+    with pytest.raises(TypeError):
+        rz._encode(np.array([object()], dtype=object))
+    with pytest.raises(TypeError):
+        rz._encode(object())
+    # malformed / oversized headers are refused before anything is allocated
+    a.sendall(struct.pack("<IIQ", 0x12345678, 0, 4))
+    with pytest.raises(ConnectionError):
+        rz._recv(b)
+    a.sendall(struct.pack("<IIQ", rz._MAGIC, 0, 1 << 40))
+    with pytest.raises(ConnectionError):
+        rz._recv(b)
+    a.close(); b.close()
+
+
+def _rank_with_a_stranger(rank, world, key, q):
+    try:
+        comm = Rendezvous(rank, world, key, timeout=60.0)
+        comm.barrier()
+        comm.close()
+        q.put((rank, "ok"))
+    except Exception as e:   # noqa: BLE001
+        q.put((rank, repr(e)))
+
+
+def test_a_stranger_without_the_token_is_turned_away():
+    """Somebody who finds the port (but cannot read the 0600 port file) and connects with garbage or a wrong proof does not
+    become a rank, does not crash rank 0, and does not keep the real rank 1 out."""
+    import socket
+    import struct
+    from plade_amd.rendezvous import _private_dir, _MAGIC
+    key = f"stranger_{os.getpid()}"
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p0 = ctx.Process(target=_rank_with_a_stranger, args=(0, 2, key, q))
+    p0.start()
+    path = os.path.join(_private_dir(), f"plade_rendezvous_{key}")
+    t0 = time.time()
+    while not os.path.exists(path) and time.time() - t0 < 30:
+        time.sleep(0.02)
+    port = int(open(path).read().split()[0])
+    for payload in (b"\x80\x04\x95" + b"A" * 200,                                    # a pickle, for a listener that would unpickle
+                    struct.pack("<II", _MAGIC, 1) + b"\0" * 32):                      # right format, wrong proof
+        s = socket.create_connection(("127.0.0.1", port), timeout=5)
+        s.sendall(payload)
+        time.sleep(0.1)
+        s.close()
+    p1 = ctx.Process(target=_rank_with_a_stranger, args=(1, 2, key, q))
+    p1.start()
+    res = sorted(q.get(timeout=60) for _ in range(2))
+    p0.join(30); p1.join(30)
+    assert res == [(0, "ok"), (1, "ok")], res
