@@ -89,6 +89,11 @@ struct Err {
 struct AllocStats { std::atomic<uint64_t> calls{0}, bytes{0}, nanos{0}; };
 inline AllocStats &alloc_stats() { static AllocStats s; return s; }
 
+// While the pairs of a group run in lock step (launch.h) what a pair launches is queued, not issued: an allocation that is
+// replaced by a larger one meanwhile may still be named by queued launches, so it is kept until the pair's next wait has
+// returned (hipFree on a stream-ordered path waits for the device; here the work has not even been queued).
+inline thread_local std::vector<void *> *tl_deferred_free = nullptr;
+
 // grow-only device buffer
 template <class T>
 struct DBuf {
@@ -100,7 +105,7 @@ struct DBuf {
     DBuf &operator=(const DBuf &) = delete;
     T *ensure(size_t n) {
         if (n > cap) {
-            if (p) HIP_TRY(hipFree(p));
+            if (p) { if (tl_deferred_free) tl_deferred_free->push_back(p); else HIP_TRY(hipFree(p)); }
             p = nullptr;
             size_t want = n + n / 4 + 64;
             const auto t0 = std::chrono::steady_clock::now();

@@ -2,6 +2,7 @@
 #pragma once
 #include "common.h"
 #include "plade_hip.h"
+#include "launch.h"
 #include <ctime>
 #include <sys/prctl.h>
 
@@ -92,6 +93,8 @@ struct plade_ctx {
     plade_ctx *peers[PLADE_GROUP_MAX - 1] = {};   // the contexts of pairs 1.. of a group (plade_registration_pairs): stream, aux, work areas
     hipEvent_t ev_group = nullptr;   // end of a group's joint plane extraction on `stream` (the peers' streams wait for it)
     bool in_group = false;      // this context carries one pair of a group of several (register_group)
+    plade::Combiner *comb = nullptr;   // ... whose launches, small copies and waits are merged with those of the other pairs (launch.h)
+    int comb_slot = -1;
     plade_ctx *aux = nullptr;   // second stream + work areas: stages of the source cloud that are independent of the
                                 // target's run concurrently with them
     hipStream_t stream = nullptr;
@@ -258,6 +261,7 @@ struct plade_ctx {
     // polls the stream and sleeps in between.
     void sync(hipStream_t s = nullptr) {
         if (!s) s = stream;
+        if (comb && s == stream) { comb->wait(this); return; }
         if (s == stream && !pending_reads.empty()) { sync_with_reads(); return; }
         if (params.host_wait == 0) { HIP_TRY(hipStreamSynchronize(s)); }
         else {
@@ -295,6 +299,12 @@ struct plade_ctx {
         if (!bytes) return;
         const size_t need = (bytes + 255) & ~(size_t)255;
         if (bytes > READ_DIRECT_BYTES || (bytes & 3) || (reinterpret_cast<uintptr_t>(src) & 3) || read_arena_used + need > READ_ARENA_BYTES) {
+            if (comb) {    // at its place in the pair's order, on the group's stream
+                plade::QEntry &e = comb->push(this);
+                e.kind = plade::QEntry::FUNC;
+                e.fn = [dst, src, bytes](hipStream_t st) { HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st)); };
+                return;
+            }
             if (params.host_wait != 0) sync();   // drain with sleeping polls first: only the copy itself is waited for actively
             HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, stream));
             return;
@@ -307,7 +317,7 @@ struct plade_ctx {
         }
         read_arena_used += need;
     }
-    void sync_with_reads() {
+    char *ensure_read_arena() {
         // host-mapped and COHERENT: the kernel's stores must reach the host while the stream keeps running
         char *arena = read_arena.ensure(READ_ARENA_BYTES + 256, hipHostMallocMapped | hipHostMallocCoherent);
         if (!read_arena_dev) {
@@ -315,6 +325,10 @@ struct plade_ctx {
             *reinterpret_cast<volatile uint32_t *>(arena + READ_ARENA_BYTES) = 0u;   // sequence numbers start at 1
         }
         if (!read_counter.p) { read_counter.ensure(4); HIP_TRY(hipMemsetAsync(read_counter.p, 0, 16, stream)); }
+        return arena;
+    }
+    void sync_with_reads() {
+        char *arena = ensure_read_arena();
         volatile uint32_t *flag = reinterpret_cast<volatile uint32_t *>(arena + READ_ARENA_BYTES);
         const uint32_t seq = ++read_seq ? read_seq : ++read_seq;   // never 0
         for (size_t i = 0; i < pending_reads.size(); i += plade::COPY_OUT_RANGES) {
@@ -351,18 +365,62 @@ struct plade_ctx {
     size_t write_arena_used = 0;
     // true: `src` has been copied into the arena and may be released at once; false: the copy reads `src` itself, which
     // must stay valid until the next sync() of this stream
+    char *write_arena_dev = nullptr;      // the staging arena as the device addresses it (the group's copy kernel reads it there)
     bool h2d(void *dst, const void *src, size_t bytes) {
         if (!bytes) return true;
         const size_t need = (bytes + 255) & ~(size_t)255;
         if (bytes > READ_DIRECT_BYTES || write_arena_used + need > READ_ARENA_BYTES) {
+            if (comb) {
+                plade::QEntry &e = comb->push(this);
+                e.kind = plade::QEntry::FUNC;
+                e.fn = [dst, src, bytes](hipStream_t st) { HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st)); };
+                return false;
+            }
             HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream));
             return false;
         }
-        char *a = write_arena.ensure(READ_ARENA_BYTES) + write_arena_used;
+        char *a = write_arena.ensure(READ_ARENA_BYTES, hipHostMallocMapped) + write_arena_used;
         memcpy(a, src, bytes);
-        HIP_TRY(hipMemcpyAsync(dst, a, bytes, hipMemcpyHostToDevice, stream));
+        if (comb && !(bytes & 3) && !(reinterpret_cast<uintptr_t>(dst) & 3)) {
+            // merged with the other pairs' uploads into one copy kernel that reads the staging arenas over PCIe
+            if (!write_arena_dev) HIP_TRY(hipHostGetDevicePointer((void **)&write_arena_dev, write_arena.p, 0));
+            plade::QEntry &e = comb->push(this);
+            e.kind = plade::QEntry::COPY_IN;
+            e.dst = dst; e.src = write_arena_dev + write_arena_used; e.words = (uint32_t)(bytes / 4);
+        } else if (comb) {
+            plade::QEntry &e = comb->push(this);
+            e.kind = plade::QEntry::FUNC;
+            e.fn = [dst, a, bytes](hipStream_t st) { HIP_TRY(hipMemcpyAsync(dst, a, bytes, hipMemcpyHostToDevice, st)); };
+        } else HIP_TRY(hipMemcpyAsync(dst, a, bytes, hipMemcpyHostToDevice, stream));
         write_arena_used += need;
         return true;
+    }
+    // fill / device-to-device copy on this context's stream (in a group: at their place in the pair's order on the group's)
+    void fill_async(void *dst, int byte_value, size_t bytes) {
+        if (!bytes) return;
+        if (comb && bytes <= (1u << 20) && !(bytes & 3) && !(reinterpret_cast<uintptr_t>(dst) & 3)) {
+            plade::QEntry &e = comb->push(this);
+            e.kind = plade::QEntry::FILL;
+            const uint32_t b = (uint32_t)(byte_value & 0xff);
+            e.dst = dst; e.words = (uint32_t)(bytes / 4); e.value = b | (b << 8) | (b << 16) | (b << 24);
+        } else if (comb) {
+            plade::QEntry &e = comb->push(this);
+            e.kind = plade::QEntry::FUNC;
+            e.fn = [dst, byte_value, bytes](hipStream_t st) { HIP_TRY(hipMemsetAsync(dst, byte_value, bytes, st)); };
+        } else HIP_TRY(hipMemsetAsync(dst, byte_value, bytes, stream));
+    }
+    void copy_dd_async(void *dst, const void *src, size_t bytes) {
+        if (!bytes) return;
+        if (comb) {
+            plade::QEntry &e = comb->push(this);
+            e.kind = plade::QEntry::FUNC;
+            e.fn = [dst, src, bytes](hipStream_t st) { HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st)); };
+        } else HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, stream));
+    }
+    // a kernel that has not been given its launch.h form: at its place in the pair's order, on its own
+    template <class F> void raw_launch(F f) {
+        if (comb) { plade::QEntry &e = comb->push(this); e.kind = plade::QEntry::FUNC; e.fn = f; }
+        else f(stream);
     }
     // forget the queued hand-overs (their destinations may be gone): after an error, and before every call
     void drop_reads() {
@@ -413,6 +471,22 @@ struct plade_ctx {
         put(name, h.data(), count);
     }
 };
+
+#ifdef __HIPCC__
+#include <tuple>
+namespace plade {
+// An ordinary __global__ kernel on the context's stream; in a group (launch.h) at its place in the pair's order on the group's
+// stream, on its own.  The arguments are evaluated NOW, as a launch would.
+template <class... KArgs, class... Args>
+void launch_raw(plade_ctx *ctx, void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t smem, Args... args) {
+    if (!ctx->comb) { hipLaunchKernelGGL(kernel, grid, block, smem, ctx->stream, static_cast<KArgs>(args)...); return; }
+    std::tuple<KArgs...> t(static_cast<KArgs>(args)...);
+    ctx->raw_launch([kernel, grid, block, smem, t](hipStream_t st) {
+        std::apply([&](auto... a) { hipLaunchKernelGGL(kernel, grid, block, smem, st, a...); }, t);
+    });
+}
+}  // namespace plade
+#endif
 
 namespace plade {
 

@@ -70,7 +70,7 @@ void build_transforms(plade_ctx *ctx, const PairTableDev &src, const PairTableDe
     cs.rt.ensure(4 * (size_t)m + 4);
     if (!m) return;
     cs.t_minmax.ensure(6 * (size_t)cdiv(m, 256) + 8);
-    hipLaunchKernelGGL(k_transforms, dim3(cdiv(m, 256)), dim3(256), 0, ctx->stream, src.lv1.p, src.lv2.p, src.p1.p,
+    launch_raw(ctx, k_transforms, dim3(cdiv(m, 256)), dim3(256), 0, src.lv1.p, src.lv2.p, src.p1.p,
                        tgt.lv1.p, tgt.lv2.p, tgt.p1.p, d_q_idx, d_t_idx, m, cs.rt.p, cs.t_minmax.p);
     HIP_TRY(hipGetLastError());
 }
@@ -252,20 +252,20 @@ void cluster_transforms(plade_ctx *ctx, CandidateSet &cs, float dist_threshold, 
     cs.parent.ensure(m); cs.sizes_all.ensure(m); cs.flags.ensure((size_t)m + 1);
     cs.st.ensure(m); cs.se.ensure(m); cs.spans.ensure((size_t)m * 9);
     const unsigned nb = cdiv(m, 256);
-    hipLaunchKernelGGL(k_t_keys, dim3(nb), dim3(256), 0, ctx->stream, cs.rt.p, m, g, cs.ckeys.p, cs.cvals.p, cs.parent.p,
+    launch_raw(ctx, k_t_keys, dim3(nb), dim3(256), 0, cs.rt.p, m, g, cs.ckeys.p, cs.cvals.p, cs.parent.p,
                        cs.sizes_all.p);
     sort_pairs_u64(ctx, cs.ckeys.p, cs.ckeys2.p, cs.cvals.p, cs.cvals2.p, m, bx + by + bz);
-    hipLaunchKernelGGL(k_cell_spans, dim3(nb), dim3(256), 0, ctx->stream, cs.rt.p, cs.cvals2.p, cs.ckeys2.p, m, g, cs.st.p,
+    launch_raw(ctx, k_cell_spans, dim3(nb), dim3(256), 0, cs.rt.p, cs.cvals2.p, cs.ckeys2.p, m, g, cs.st.p,
                        cs.se.p, cs.spans.p);
     ctx->ev_begin("cluster_edges", 0.0);   // latency / atomics bound, no HBM figure
-    hipLaunchKernelGGL(k_cluster_edges, dim3(cdiv((size_t)m * 9, 256)), dim3(256), 0, ctx->stream, cs.st.p, cs.se.p, cs.ckeys2.p,
+    launch_raw(ctx, k_cluster_edges, dim3(cdiv((size_t)m * 9, 256)), dim3(256), 0, cs.st.p, cs.se.p, cs.ckeys2.p,
                        cs.spans.p, m, r2, angle_gate, cs.parent.p);
     ctx->ev_end();
-    hipLaunchKernelGGL(k_flatten, dim3(cdiv(m + 1, 256)), dim3(256), 0, ctx->stream, cs.parent.p, m, cs.sizes_all.p, cs.flags.p);
+    launch_raw(ctx, k_flatten, dim3(cdiv(m + 1, 256)), dim3(256), 0, cs.parent.p, m, cs.sizes_all.p, cs.flags.p);
     cs.n_clusters = compact_flags(ctx, cs.flags.p, m, cs.pos, cs.seeds);
     cs.sizes.ensure((size_t)cs.n_clusters + 1);
     if (cs.n_clusters)
-        hipLaunchKernelGGL(k_gather_sizes, dim3(cdiv(cs.n_clusters, 256)), dim3(256), 0, ctx->stream, cs.seeds.p,
+        launch_raw(ctx, k_gather_sizes, dim3(cdiv(cs.n_clusters, 256)), dim3(256), 0, cs.seeds.p,
                            cs.n_clusters, cs.sizes_all.p, cs.sizes.p);
     HIP_TRY(hipGetLastError());
 }
@@ -336,7 +336,7 @@ void plane_consistency(plade_ctx *ctx, CandidateSet &cs, const PlaneGeomHost &sr
     float *d_tab = reinterpret_cast<float *>(ctx->scratch[4].ensure(tab.size() * 4 + 16));
     const bool staged = ctx->h2d(d_tab, tab.data(), tab.size() * 4);
     const size_t shmem = 32 * ((size_t)src.P + tgt.P);
-    hipLaunchKernelGGL(k_plane_consistency, dim3(cdiv(n, 256)), dim3(256), shmem, ctx->stream, cs.rt.p, cs.seeds.p, n, d_tab,
+    launch_raw(ctx, k_plane_consistency, dim3(cdiv(n, 256)), dim3(256), shmem, cs.rt.p, cs.seeds.p, n, d_tab,
                        src.P, d_tab + 8 * (size_t)src.P, tgt.P, f3(src_bcenter[0], src_bcenter[1], src_bcenter[2]),
                        f3(tgt_bcenter[0], tgt_bcenter[1], tgt_bcenter[2]), max_radius, cos_angle_th, length_threshold,
                        cs.plane_counts.p);

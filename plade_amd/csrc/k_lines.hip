@@ -151,7 +151,7 @@ uint32_t compact_flags(plade_ctx *ctx, const uint32_t *d_flags, uint32_t n, DBuf
     ctx->d2h(&total, pos.p + n, 4);
     ctx->sync();
     out_idx.ensure((size_t)total + 1);
-    hipLaunchKernelGGL(k_flag_positions, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, d_flags, pos.p, n, out_idx.p);
+    launch_raw(ctx, k_flag_positions, dim3(cdiv(n, 256)), dim3(256), 0, d_flags, pos.p, n, out_idx.p);
     HIP_TRY(hipGetLastError());
     return total;
 }
@@ -187,16 +187,16 @@ void build_pair_table(plade_ctx *ctx, const LineTableHost &lt, const float *norm
     if (ctx->params.closest_point_mode == 1 && L > 1) {
         const uint32_t n_pairs = (uint32_t)((size_t)L * (L - 1) / 2);
         cp = out.cp.ensure(n * 6);
-        hipLaunchKernelGGL(k_closest_svd, dim3(cdiv(n_pairs, CP_TPB)), dim3(CP_TPB), 0, ctx->stream, v, n_pairs, out.cp.p);
+        launch_raw(ctx, k_closest_svd, dim3(cdiv(n_pairs, CP_TPB)), dim3(CP_TPB), 0, v, n_pairs, out.cp.p);
     }
-    hipLaunchKernelGGL(k_pair_table, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, v, scale, angle_thresh, target ? 1 : 0, cp,
+    launch_raw(ctx, k_pair_table, dim3(cdiv(n, 256)), dim3(256), 0, v, scale, angle_thresh, target ? 1 : 0, cp,
                        out.flags.p, out.all_desc.p, out.all_lv1.p, out.all_lv2.p, out.all_p1.p);
     exclusive_scan_u32(ctx, out.flags.p, out.pos.p, n + 1);
     if (staged && n <= (1u << 20)) {
         // the usual table (a few hundred lines): the compacted arrays are sized for all n pairs (68 B each) and the count
         // comes back with the caller's next wait -- no host round trip between the scan and the compaction
         out.desc.ensure(n * 8 + 8); out.lv1.ensure(n * 3 + 4); out.lv2.ensure(n * 3 + 4); out.p1.ensure(n * 3 + 4);
-        hipLaunchKernelGGL(k_scatter_pairs, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, out.flags.p, out.pos.p, n,
+        launch_raw(ctx, k_scatter_pairs, dim3(cdiv(n, 256)), dim3(256), 0, out.flags.p, out.pos.p, n,
                            out.all_desc.p, out.all_lv1.p, out.all_lv2.p, out.all_p1.p, out.desc.p, out.lv1.p, out.lv2.p,
                            out.p1.p);
         HIP_TRY(hipGetLastError());
@@ -210,7 +210,7 @@ void build_pair_table(plade_ctx *ctx, const LineTableHost &lt, const float *norm
     out.desc.ensure((size_t)total * 8 + 8); out.lv1.ensure((size_t)total * 3 + 4); out.lv2.ensure((size_t)total * 3 + 4);
     out.p1.ensure((size_t)total * 3 + 4);
     if (total)
-        hipLaunchKernelGGL(k_scatter_pairs, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, out.flags.p, out.pos.p, n,
+        launch_raw(ctx, k_scatter_pairs, dim3(cdiv(n, 256)), dim3(256), 0, out.flags.p, out.pos.p, n,
                            out.all_desc.p, out.all_lv1.p, out.all_lv2.p, out.all_p1.p, out.desc.p, out.lv1.p, out.lv2.p,
                            out.p1.p);
     HIP_TRY(hipGetLastError());
@@ -277,11 +277,11 @@ static int line_seam(plade_ctx *ctx, int kind, int32_t mode, const float *a, con
         const float *src[4] = {a, b, c, d};
         for (int k = 0; k < 4; ++k) HIP_TRY(hipMemcpyAsync(d_in + 3 * (size_t)k * n, src[k], 12 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
         if (kind == 0) {
-            if (mode) hipLaunchKernelGGL(k_closest_seam<1>, dim3(cdiv(n, CP_TPB)), dim3(CP_TPB), 0, ctx->stream, d_in, n, d_q, d_len, d_ok);
-            else hipLaunchKernelGGL(k_closest_seam<0>, dim3(cdiv(n, CP_TPB)), dim3(CP_TPB), 0, ctx->stream, d_in, n, d_q, d_len, d_ok);
+            if (mode) launch_raw(ctx, k_closest_seam<1>, dim3(cdiv(n, CP_TPB)), dim3(CP_TPB), 0, d_in, n, d_q, d_len, d_ok);
+            else launch_raw(ctx, k_closest_seam<0>, dim3(cdiv(n, CP_TPB)), dim3(CP_TPB), 0, d_in, n, d_q, d_len, d_ok);
         } else {
-            if (mode) hipLaunchKernelGGL(k_meet_seam<1>, dim3(cdiv(n, 128)), dim3(128), 0, ctx->stream, d_in, n, d_q, d_ok);
-            else hipLaunchKernelGGL(k_meet_seam<0>, dim3(cdiv(n, 128)), dim3(128), 0, ctx->stream, d_in, n, d_q, d_ok);
+            if (mode) launch_raw(ctx, k_meet_seam<1>, dim3(cdiv(n, 128)), dim3(128), 0, d_in, n, d_q, d_ok);
+            else launch_raw(ctx, k_meet_seam<0>, dim3(cdiv(n, 128)), dim3(128), 0, d_in, n, d_q, d_ok);
         }
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(o1, d_q, 12 * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));

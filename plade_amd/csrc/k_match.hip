@@ -259,16 +259,16 @@ uint64_t MatchResult::run_windowed(plade_ctx *ctx, const float *d_qry, uint32_t 
     // both tables by ascending first component
     wk_a.ensure(std::max(dq, dt)); wk_b.ensure(std::max(dq, dt)); wv_a.ensure(std::max(dq, dt));
     q_perm.ensure(dq); t_perm.ensure(dt); q_sorted.ensure(8 * (size_t)dq + 8); t_sorted.ensure(8 * (size_t)dt + 8);
-    hipLaunchKernelGGL(k_len_keys, dim3(cdiv(dq, 256)), dim3(256), 0, ctx->stream, d_qry, dq, wk_a.p, wv_a.p);
+    launch_raw(ctx, k_len_keys, dim3(cdiv(dq, 256)), dim3(256), 0, d_qry, dq, wk_a.p, wv_a.p);
     sort_pairs_u32(ctx, wk_a.p, wk_b.p, wv_a.p, q_perm.p, dq, 32);
-    hipLaunchKernelGGL(k_gather_desc, dim3(cdiv(2 * (size_t)dq, 256)), dim3(256), 0, ctx->stream, d_qry, q_perm.p, dq, q_sorted.p);
-    hipLaunchKernelGGL(k_len_keys, dim3(cdiv(dt, 256)), dim3(256), 0, ctx->stream, d_tgt, dt, wk_a.p, wv_a.p);
+    launch_raw(ctx, k_gather_desc, dim3(cdiv(2 * (size_t)dq, 256)), dim3(256), 0, d_qry, q_perm.p, dq, q_sorted.p);
+    launch_raw(ctx, k_len_keys, dim3(cdiv(dt, 256)), dim3(256), 0, d_tgt, dt, wk_a.p, wv_a.p);
     sort_pairs_u32(ctx, wk_a.p, wk_b.p, wv_a.p, t_perm.p, dt, 32);   // wk_b = sorted target keys
-    hipLaunchKernelGGL(k_gather_desc, dim3(cdiv(2 * (size_t)dt, 256)), dim3(256), 0, ctx->stream, d_tgt, t_perm.p, dt, t_sorted.p);
+    launch_raw(ctx, k_gather_desc, dim3(cdiv(2 * (size_t)dt, 256)), dim3(256), 0, d_tgt, t_perm.p, dt, t_sorted.p);
     const uint32_t ng = cdiv(dq, MT_TPB);
     w_lo.ensure(ng); w_cnt.ensure(ng); info.ensure(2);
-    HIP_TRY(hipMemsetAsync(info.p, 0, 8, ctx->stream));
-    hipLaunchKernelGGL(k_windows, dim3(cdiv(ng, 256)), dim3(256), 0, ctx->stream, q_sorted.p, dq, wk_b.p, dt, radius, w_lo.p, w_cnt.p,
+    ctx->fill_async(info.p, 0, 8);
+    launch_raw(ctx, k_windows, dim3(cdiv(ng, 256)), dim3(256), 0, q_sorted.p, dq, wk_b.p, dt, radius, w_lo.p, w_cnt.p,
                        info.p);
     uint32_t h_info[2] = {0, 0};
     ctx->d2h(h_info, info.p, 8);
@@ -292,21 +292,21 @@ uint64_t MatchResult::run_windowed(plade_ctx *ctx, const float *d_qry, uint32_t 
         q0 = g0 * MT_TPB;
         dqs = std::min(dq - q0, ngs * MT_TPB);
         const size_t ncnt = (size_t)dqs * nch;
-        hipLaunchKernelGGL(k_match_win<false>, dim3(ngs, nch), dim3(MT_TPB), 0, ctx->stream, q_sorted.p + 8 * (size_t)q0, dqs, t_sorted.p,
+        launch_raw(ctx, k_match_win<false>, dim3(ngs, nch), dim3(MT_TPB), 0, q_sorted.p + 8 * (size_t)q0, dqs, t_sorted.p,
                            w_lo.p + g0, w_cnt.p + g0, sq_rad, nch, cnt.p, (const uint32_t *)nullptr, (const uint32_t *)nullptr,
                            (const uint32_t *)nullptr, (uint32_t *)nullptr, (double *)nullptr, (uint32_t *)nullptr);
-        HIP_TRY(hipMemsetAsync(cnt.p + ncnt, 0, 4, ctx->stream));
+        ctx->fill_async(cnt.p + ncnt, 0, 4);
         exclusive_scan_u32(ctx, cnt.p, offs.p, ncnt + 1);
     };
     for (uint32_t s = 0; s < n_slabs; ++s) {
         uint32_t q0, dqs, g0, ngs;
         count_slab(s, q0, dqs, g0, ngs);
-        hipLaunchKernelGGL(k_row_totals, dim3(cdiv(dqs, 256)), dim3(256), 0, ctx->stream, offs.p, dqs, nch, q_perm.p + q0, row_tot.p);
+        launch_raw(ctx, k_row_totals, dim3(cdiv(dqs, 256)), dim3(256), 0, offs.p, dqs, nch, q_perm.p + q0, row_tot.p);
     }
-    HIP_TRY(hipMemsetAsync(row_tot.p + dq, 0, 4, ctx->stream));
+    ctx->fill_async(row_tot.p + dq, 0, 4);
     exclusive_scan_u32(ctx, row_tot.p, row_off.p, (size_t)dq + 1);
-    HIP_TRY(hipMemsetAsync(info.p, 0, 8, ctx->stream));
-    hipLaunchKernelGGL(k_win_offsets, dim3(cdiv((size_t)dq + 1, 256)), dim3(256), 0, ctx->stream, row_off.p, dq, offsets.p, info.p);
+    ctx->fill_async(info.p, 0, 8);
+    launch_raw(ctx, k_win_offsets, dim3(cdiv((size_t)dq + 1, 256)), dim3(256), 0, row_off.p, dq, offsets.p, info.p);
     ctx->d2h(h_info, info.p, 8);
     ctx->sync();
     total = h_info[0];
@@ -320,8 +320,8 @@ uint64_t MatchResult::run_windowed(plade_ctx *ctx, const float *d_qry, uint32_t 
         else { g0 = 0; ngs = ng; q0 = 0; dqs = dq; }
         const size_t ncnt = (size_t)dqs * nch;
         // `cnt` is free again: it receives the final write positions
-        hipLaunchKernelGGL(k_win_bases, dim3(cdiv(ncnt, 256)), dim3(256), 0, ctx->stream, offs.p, dqs, nch, q_perm.p + q0, row_off.p, cnt.p);
-        hipLaunchKernelGGL(k_match_win<true>, dim3(ngs, nch), dim3(MT_TPB), 0, ctx->stream, q_sorted.p + 8 * (size_t)q0, dqs, t_sorted.p,
+        launch_raw(ctx, k_win_bases, dim3(cdiv(ncnt, 256)), dim3(256), 0, offs.p, dqs, nch, q_perm.p + q0, row_off.p, cnt.p);
+        launch_raw(ctx, k_match_win<true>, dim3(ngs, nch), dim3(MT_TPB), 0, q_sorted.p + 8 * (size_t)q0, dqs, t_sorted.p,
                            w_lo.p + g0, w_cnt.p + g0, sq_rad, nch, (uint32_t *)nullptr, cnt.p, q_perm.p + q0, t_perm.p, t_raw.p, d2_raw.p,
                            q_raw.p);
     }
@@ -329,23 +329,23 @@ uint64_t MatchResult::run_windowed(plade_ctx *ctx, const float *d_qry, uint32_t 
     q_idx_sorted = q_raw.p;
     if (max_list <= RANK_MAX_LIST) {
         const uint32_t cap = std::max(64u, (max_list + 63u) & ~63u);   // entries of LDS per workgroup
-        hipLaunchKernelGGL(k_rank_lists, dim3(dq), dim3(256), cap * 12, ctx->stream, offsets.p, dq, t_raw.p, d2_raw.p, t_idx.p, dist2.p, cap);
+        launch_raw(ctx, k_rank_lists, dim3(dq), dim3(256), cap * 12, offsets.p, dq, t_raw.p, d2_raw.p, t_idx.p, dist2.p, cap);
         HIP_TRY(hipGetLastError());
         return total;
     }
     // very long lists: stable sorts by target index, then dist2, then query
     k64a.ensure(m); k64b.ensure(m); v32a.ensure(m); v32b.ensure(m); k32a.ensure(m); k32b.ensure(m);
-    hipLaunchKernelGGL(k_iota_u32, dim3(cdiv(m, 256)), dim3(256), 0, ctx->stream, v32a.p, m);
+    launch_raw(ctx, k_iota_u32, dim3(cdiv(m, 256)), dim3(256), 0, v32a.p, m);
     int tbits = 1;
     while ((1ull << tbits) < dt) ++tbits;
     sort_pairs_u32(ctx, t_raw.p, k32b.p, v32a.p, v32b.p, m, tbits);                  // v32b: entries by target index
-    hipLaunchKernelGGL(k_d2_keys_perm, dim3(cdiv(m, 256)), dim3(256), 0, ctx->stream, d2_raw.p, v32b.p, m, k64a.p);
+    launch_raw(ctx, k_d2_keys_perm, dim3(cdiv(m, 256)), dim3(256), 0, d2_raw.p, v32b.p, m, k64a.p);
     sort_pairs_u64(ctx, k64a.p, k64b.p, v32b.p, v32a.p, m, 64);                       // v32a: by (dist2, target)
-    hipLaunchKernelGGL(k_gather_u32, dim3(cdiv(m, 256)), dim3(256), 0, ctx->stream, q_raw.p, v32a.p, m, k32a.p);
+    launch_raw(ctx, k_gather_u32, dim3(cdiv(m, 256)), dim3(256), 0, q_raw.p, v32a.p, m, k32a.p);
     int qbits = 1;
     while ((1ull << qbits) < dq) ++qbits;
     sort_pairs_u32(ctx, k32a.p, k32b.p, v32a.p, v32b.p, m, qbits);                    // v32b: by (query, dist2, target)
-    hipLaunchKernelGGL(k_gather_final, dim3(cdiv(m, 256)), dim3(256), 0, ctx->stream, t_raw.p, d2_raw.p, v32b.p, m, t_idx.p,
+    launch_raw(ctx, k_gather_final, dim3(cdiv(m, 256)), dim3(256), 0, t_raw.p, d2_raw.p, v32b.p, m, t_idx.p,
                        dist2.p);
     q_idx_sorted = k32b.p;
     HIP_TRY(hipGetLastError());
@@ -356,8 +356,8 @@ uint64_t MatchResult::run(plade_ctx *ctx, const float *d_qry, uint32_t dq, const
                           float radius) {
     total = 0;
     offsets.ensure((size_t)dq + 1);
-    if (dq == 0) { HIP_TRY(hipMemsetAsync(offsets.p, 0, 8, ctx->stream)); return 0; }
-    if (radius < 0.f || dt == 0) { HIP_TRY(hipMemsetAsync(offsets.p, 0, ((size_t)dq + 1) * 8, ctx->stream)); return 0; }
+    if (dq == 0) { ctx->fill_async(offsets.p, 0, 8); return 0; }
+    if (radius < 0.f || dt == 0) { ctx->fill_async(offsets.p, 0, ((size_t)dq + 1) * 8); return 0; }
     const float sq_rad_f = radius * radius;  // ANN.h:987 `float sqRad = radius*radius`
     const double sq_rad = sq_rad_f;
     // large tables (or plade_params.match_window = 1): enumerate only inside the length windows
@@ -376,10 +376,10 @@ uint64_t MatchResult::run(plade_ctx *ctx, const float *d_qry, uint32_t dq, const
     cnt.ensure(ncnt + 1); offs.ensure(ncnt + 1);
     dim3 grid(cdiv(dq, MT_TPB), nch);
     info.ensure(2);
-    hipLaunchKernelGGL(k_match<false>, grid, dim3(MT_TPB), 0, ctx->stream, d_qry, dq, d_tgt, dt, sq_rad, nch, chunk, cnt.p,
+    launch_raw(ctx, k_match<false>, grid, dim3(MT_TPB), 0, d_qry, dq, d_tgt, dt, sq_rad, nch, chunk, cnt.p,
                        (const uint32_t *)nullptr, (uint32_t *)nullptr, (double *)nullptr, (uint32_t *)nullptr, info.p);
     exclusive_scan_u32(ctx, cnt.p, offs.p, ncnt + 1);
-    hipLaunchKernelGGL(k_query_offsets, dim3(cdiv(dq + 1, 256)), dim3(256), 0, ctx->stream, offs.p, dq, nch, offsets.p, info.p);
+    launch_raw(ctx, k_query_offsets, dim3(cdiv(dq + 1, 256)), dim3(256), 0, offs.p, dq, nch, offsets.p, info.p);
     uint32_t h_info[2] = {0, 0};
     ctx->d2h(h_info, info.p, 8);
     ctx->sync();
@@ -388,26 +388,26 @@ uint64_t MatchResult::run(plade_ctx *ctx, const float *d_qry, uint32_t dq, const
     if (total == 0) return 0;
     const uint32_t m = tot32;
     t_raw.ensure(m); d2_raw.ensure(m); q_raw.ensure(m);
-    hipLaunchKernelGGL(k_match<true>, grid, dim3(MT_TPB), 0, ctx->stream, d_qry, dq, d_tgt, dt, sq_rad, nch, chunk, cnt.p, offs.p,
+    launch_raw(ctx, k_match<true>, grid, dim3(MT_TPB), 0, d_qry, dq, d_tgt, dt, sq_rad, nch, chunk, cnt.p, offs.p,
                        t_raw.p, d2_raw.p, q_raw.p, (uint32_t *)nullptr);
     t_idx.ensure(m); dist2.ensure(m);
     q_idx_sorted = q_raw.p;   // lists are contiguous per query
     if (max_list <= RANK_MAX_LIST) {
         const uint32_t cap = std::max(64u, (max_list + 63u) & ~63u);   // entries of LDS per workgroup
-        hipLaunchKernelGGL(k_rank_lists, dim3(dq), dim3(256), cap * 12, ctx->stream, offsets.p, dq, t_raw.p, d2_raw.p, t_idx.p,
+        launch_raw(ctx, k_rank_lists, dim3(dq), dim3(256), cap * 12, offsets.p, dq, t_raw.p, d2_raw.p, t_idx.p,
                            dist2.p, cap);
         HIP_TRY(hipGetLastError());
         return total;
     }
     // very long lists: a stable sort by dist2 followed by a stable sort by query
     k64a.ensure(m); k64b.ensure(m); v32a.ensure(m); v32b.ensure(m); k32a.ensure(m); k32b.ensure(m);
-    hipLaunchKernelGGL(k_d2_keys, dim3(cdiv(m, 256)), dim3(256), 0, ctx->stream, d2_raw.p, m, k64a.p, v32a.p);
+    launch_raw(ctx, k_d2_keys, dim3(cdiv(m, 256)), dim3(256), 0, d2_raw.p, m, k64a.p, v32a.p);
     sort_pairs_u64(ctx, k64a.p, k64b.p, v32a.p, v32b.p, m, 64);
-    hipLaunchKernelGGL(k_gather_u32, dim3(cdiv(m, 256)), dim3(256), 0, ctx->stream, q_raw.p, v32b.p, m, k32a.p);
+    launch_raw(ctx, k_gather_u32, dim3(cdiv(m, 256)), dim3(256), 0, q_raw.p, v32b.p, m, k32a.p);
     int qbits = 1;
     while ((1ull << qbits) < dq) ++qbits;
     sort_pairs_u32(ctx, k32a.p, k32b.p, v32b.p, v32a.p, m, qbits);
-    hipLaunchKernelGGL(k_gather_final, dim3(cdiv(m, 256)), dim3(256), 0, ctx->stream, t_raw.p, d2_raw.p, v32a.p, m,
+    launch_raw(ctx, k_gather_final, dim3(cdiv(m, 256)), dim3(256), 0, t_raw.p, d2_raw.p, v32a.p, m,
                        t_idx.p, dist2.p);
     q_idx_sorted = k32b.p;
     HIP_TRY(hipGetLastError());

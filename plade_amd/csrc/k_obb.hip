@@ -192,7 +192,7 @@ bool obb_units_batch(plade_ctx *ctx, int count, const ObbBatchItem *items, DBuf<
     }
     for (int g = count; g < OBB_BATCH; ++g) { B.c[g] = B.c[0]; B.unit_start[g + 1] = B.unit_start[g]; }
     if (n_coef) { const bool staged = ctx->h2d(coef_scratch.p, h.data(), 4 * n_coef); if (!staged) ctx->sync(); }
-    hipLaunchKernelGGL(k_obb_units_batch, dim3(B.unit_start[count]), dim3(OBB_T), 0, ctx->stream, B);
+    launch_raw(ctx, k_obb_units_batch, dim3(B.unit_start[count]), dim3(OBB_T), 0, B);
     HIP_TRY(hipGetLastError());
     return true;
 }
@@ -213,7 +213,7 @@ void obb_units(plade_ctx *ctx, ObbWork &W, const float *d_ds, const uint32_t *d_
     W.out.ensure(OBB_OUT_WHOLE + (size_t)P * OBB_OUT_PLANE + 4);
     W.host.resize(OBB_OUT_WHOLE + (size_t)P * OBB_OUT_PLANE);
     ObbArgs A{d_ds, d_n_ds, d_plane_ds, d_plane_off, P, d_coef, W.out.p};
-    hipLaunchKernelGGL(k_obb_units, dim3(P + 1), dim3(OBB_T), 0, ctx->stream, A);
+    launch_raw(ctx, k_obb_units, dim3(P + 1), dim3(OBB_T), 0, A);
     HIP_TRY(hipGetLastError());
     ctx->d2h(W.host.data(), W.out.p, 4 * W.host.size());   // valid after the next sync of the stream
 }

@@ -127,7 +127,7 @@ void TargetGrid::build(plade_ctx *ctx, const float *d_xyz, uint32_t n_pts, uint3
     }
     bbox.ensure(6);
     ctx->h2d(bbox.p, iinit, 24);
-    hipLaunchKernelGGL(k_minmax3, dim3(std::min(cdiv(n, 256), 1024u)), dim3(256), 0, ctx->stream, d_xyz, n, stride,
+    launch_raw(ctx, k_minmax3, dim3(std::min(cdiv(n, 256), 1024u)), dim3(256), 0, d_xyz, n, stride,
                        bbox.p);
     int ih[6];
     ctx->d2h(ih, bbox.p, 24);
@@ -155,7 +155,7 @@ void TargetGrid::build(plade_ctx *ctx, const float *d_xyz, uint32_t n_pts, uint3
     keys.ensure(n); keys2.ensure(n); vals.ensure(n); vals2.ensure(n);
     sorted.ensure(n);
     GridParams g{gp.mnx, gp.mny, gp.mnz, gp.inv, gp.dx, gp.dy, gp.dz};
-    hipLaunchKernelGGL(k_cell_ids, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, d_xyz, n, stride, g, compact ? 1 : 0, keys.p,
+    launch_raw(ctx, k_cell_ids, dim3(cdiv(n, 256)), dim3(256), 0, d_xyz, n, stride, g, compact ? 1 : 0, keys.p,
                        vals.p);
     int bits = 1;
     while (((size_t)1 << bits) < ncells) ++bits;
@@ -166,19 +166,19 @@ void TargetGrid::build(plade_ctx *ctx, const float *d_xyz, uint32_t n_pts, uint3
         occ_blk.ensure(nw / 64 + 2);
         cell_first.ensure((size_t)n + 2);
         // (a multiple of 64 bytes: the runtime splits any other size into an aligned fill and a second command for the tail)
-        HIP_TRY(hipMemsetAsync(occ_bits.p, 0, (((size_t)nw + 1 + 7) & ~(size_t)7) * 8, ctx->stream));
-        hipLaunchKernelGGL(k_occ_bits, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, keys2.p, n, occ_bits.p);
-        hipLaunchKernelGGL(k_occ_pop, dim3(cdiv(nw + 1, 256)), dim3(256), 0, ctx->stream, occ_bits.p, nw, occ_pop.p, occ_blk.p);
+        ctx->fill_async(occ_bits.p, 0, (((size_t)nw + 1 + 7) & ~(size_t)7) * 8);
+        launch_raw(ctx, k_occ_bits, dim3(cdiv(n, 256)), dim3(256), 0, keys2.p, n, occ_bits.p);
+        launch_raw(ctx, k_occ_pop, dim3(cdiv(nw + 1, 256)), dim3(256), 0, occ_bits.p, nw, occ_pop.p, occ_blk.p);
         exclusive_scan_u32(ctx, occ_pop.p, occ_rank.p, (size_t)nw + 1);
-        hipLaunchKernelGGL(k_occ_start, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, d_xyz, stride, keys2.p, vals2.p, n,
+        launch_raw(ctx, k_occ_start, dim3(cdiv(n, 256)), dim3(256), 0, d_xyz, stride, keys2.p, vals2.p, n,
                            occ_bits.p, occ_rank.p, nw, sorted.p, occ_start.p, cell_first.p);
         HIP_TRY(hipGetLastError());
         return;
     }
     cell_start.ensure(ncells); cell_end.ensure(ncells);
-    HIP_TRY(hipMemsetAsync(cell_start.p, 0, ncells * 4, ctx->stream));
-    HIP_TRY(hipMemsetAsync(cell_end.p, 0, ncells * 4, ctx->stream));
-    hipLaunchKernelGGL(k_gather_cells, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, d_xyz, stride, keys2.p, vals2.p, n,
+    ctx->fill_async(cell_start.p, 0, ncells * 4);
+    ctx->fill_async(cell_end.p, 0, ncells * 4);
+    launch_raw(ctx, k_gather_cells, dim3(cdiv(n, 256)), dim3(256), 0, d_xyz, stride, keys2.p, vals2.p, n,
                        sorted.p, cell_start.p, cell_end.p);
     HIP_TRY(hipGetLastError());
 }
@@ -392,15 +392,15 @@ void overlap_sort_source(plade_ctx *ctx, OverlapWork &work, const float *d_sx, c
     if (!n_s) return;
     // any order gives the same counts; this one makes a wavefront's probes local
     work.bbox.ensure(8);
-    hipLaunchKernelGGL(k_init_minmax6, dim3(1), dim3(64), 0, ctx->stream, work.bbox.p);
-    hipLaunchKernelGGL(k_src_minmax, dim3(std::min(cdiv(n_s, 256), 512u)), dim3(256), 0, ctx->stream, d_sx, d_sy, d_sz, n_s,
+    launch_raw(ctx, k_init_minmax6, dim3(1), dim3(64), 0, work.bbox.p);
+    launch_raw(ctx, k_src_minmax, dim3(std::min(cdiv(n_s, 256), 512u)), dim3(256), 0, d_sx, d_sy, d_sz, n_s,
                        work.bbox.p);
     work.keys.ensure(n_s); work.keys2.ensure(n_s); work.vals.ensure(n_s); work.vals2.ensure(n_s);
     work.sorted.ensure(3 * (size_t)n_s + 4);
-    hipLaunchKernelGGL(k_src_keys, dim3(cdiv(n_s, 256)), dim3(256), 0, ctx->stream, d_sx, d_sy, d_sz, n_s, work.bbox.p, 1.f / cell,
+    launch_raw(ctx, k_src_keys, dim3(cdiv(n_s, 256)), dim3(256), 0, d_sx, d_sy, d_sz, n_s, work.bbox.p, 1.f / cell,
                        work.keys.p, work.vals.p);
     sort_pairs_u32(ctx, work.keys.p, work.keys2.p, work.vals.p, work.vals2.p, n_s, 24);
-    hipLaunchKernelGGL(k_src_gather, dim3(cdiv(n_s, 256)), dim3(256), 0, ctx->stream, d_sx, d_sy, d_sz, n_s, work.vals2.p,
+    launch_raw(ctx, k_src_gather, dim3(cdiv(n_s, 256)), dim3(256), 0, d_sx, d_sy, d_sz, n_s, work.vals2.p,
                        work.sorted.p);
     HIP_TRY(hipGetLastError());
 }
@@ -409,10 +409,10 @@ void overlap_counts(plade_ctx *ctx, OverlapWork &work, const float *d_sx, const 
                     const TargetGrid &grid, const float *d_T, const float *d_centers, uint32_t K, float src_radius,
                     float inlier_dist, int32_t *d_counts, uint32_t *d_any, bool counts_are_zero) {
     if (counts_are_zero) {}
-    else if (reinterpret_cast<uint32_t *>(d_counts) + K == d_any) HIP_TRY(hipMemsetAsync(d_counts, 0, (size_t)K * 8, ctx->stream));   // one block
+    else if (reinterpret_cast<uint32_t *>(d_counts) + K == d_any) ctx->fill_async(d_counts, 0, (size_t)K * 8);   // one block
     else {
-        HIP_TRY(hipMemsetAsync(d_counts, 0, (size_t)K * 4, ctx->stream));
-        HIP_TRY(hipMemsetAsync(d_any, 0, (size_t)K * 4, ctx->stream));
+        ctx->fill_async(d_counts, 0, (size_t)K * 4);
+        ctx->fill_async(d_any, 0, (size_t)K * 4);
     }
     if (K == 0 || grid.n == 0) return;
     const float R2 = pcl_r2((double)src_radius), r2 = pcl_r2((double)inlier_dist);
@@ -420,7 +420,7 @@ void overlap_counts(plade_ctx *ctx, OverlapWork &work, const float *d_sx, const 
     // sphere test in chunks of <= 2048 candidates (LDS)
     for (uint32_t k0 = 0; k0 < K; k0 += 2048) {
         uint32_t kc = std::min(2048u, K - k0);
-        hipLaunchKernelGGL(k_sphere_any, dim3(cdiv(grid.n, 256)), dim3(256), kc * 12, ctx->stream, grid.sorted.p, grid.n,
+        launch_raw(ctx, k_sphere_any, dim3(cdiv(grid.n, 256)), dim3(256), kc * 12, grid.sorted.p, grid.n,
                            d_centers + (size_t)k0 * 3, kc, R2, d_any + k0);
     }
     if (n_s) {
@@ -435,7 +435,7 @@ void overlap_counts(plade_ctx *ctx, OverlapWork &work, const float *d_sx, const 
         // algorithmic bytes: K * n_s * 12 B source stream + n_t * 12 B target
         ctx->ev_begin("overlap", (double)K * n_s * 12.0 + (double)grid.n * 12.0);
         PLADE_REQUIRE(grid.compact, PLADE_EINVAL, "overlap: the target grid needs the compact occupancy index");
-        hipLaunchKernelGGL(k_overlap, dim3(cdiv(nitems, per)), dim3(OV_TPB), mask_words * 4, ctx->stream, d_sx, d_sy, d_sz, n_s, grid.sorted.p,
+        launch_raw(ctx, k_overlap, dim3(cdiv(nitems, per)), dim3(OV_TPB), mask_words * 4, d_sx, d_sy, d_sz, n_s, grid.sorted.p,
                            grid.occ_bits.p, grid.occ_rank.p, grid.occ_start.p, grid.cell_first.p, reinterpret_cast<const uint32_t *>(grid.occ_blk.p), mask_words, g,
                            d_T, d_centers, K, R2, r2, d_counts, ch, per);
         ctx->ev_end();
@@ -452,7 +452,7 @@ __global__ void k_deinterleave3(const float *__restrict__ xyz, uint32_t n, float
 
 void deinterleave3(plade_ctx *ctx, const float *d_xyz, uint32_t n, float *d_x, float *d_y, float *d_z) {
     if (!n) return;
-    hipLaunchKernelGGL(k_deinterleave3, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, d_xyz, n, d_x, d_y, d_z);
+    launch_raw(ctx, k_deinterleave3, dim3(cdiv(n, 256)), dim3(256), 0, d_xyz, n, d_x, d_y, d_z);
     HIP_TRY(hipGetLastError());
 }
 

@@ -202,12 +202,12 @@ void build_pen_grid(plade_ctx *ctx, PlaneCloudsDev &pc, const PlaneGeomHost &geo
     pc.cell_start.ensure((size_t)total + 2);
     pc.ckeys.ensure((size_t)n + 1); pc.ckeys2.ensure((size_t)n + 1); pc.cvals.ensure((size_t)n + 1); pc.cvals2.ensure((size_t)n + 1);
     if (n)
-        hipLaunchKernelGGL(k_pen_cell_keys, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, pc.xyz.p, n, pc.d_off.p, P, pc.frames.p,
+        launch_raw(ctx, k_pen_cell_keys, dim3(cdiv(n, 256)), dim3(256), 0, pc.xyz.p, n, pc.d_off.p, P, pc.frames.p,
                            1.f / cell, pc.ckeys.p, pc.cvals.p);
     int bits = 1;
     while ((1ull << bits) < total) ++bits;
     sort_pairs_u32(ctx, pc.ckeys.p, pc.ckeys2.p, pc.cvals.p, pc.cvals2.p, n, bits);
-    hipLaunchKernelGGL(k_pen_cell_fill, dim3(cdiv(std::max(n, total + 1), 256)), dim3(256), 0, ctx->stream, pc.xyz.p, pc.ckeys2.p,
+    launch_raw(ctx, k_pen_cell_fill, dim3(cdiv(std::max(n, total + 1), 256)), dim3(256), 0, pc.xyz.p, pc.ckeys2.p,
                        pc.cvals2.p, n, total, pc.cell_pts.p, pc.cell_start.p);
     if (!staged) ctx->sync();   // `fr` must outlive the copy
 }
@@ -478,10 +478,10 @@ void penetration_filter(plade_ctx *ctx, const float *cand_rt_host, uint32_t K, c
     const float *d_steps = d + n_tab;
     const uint32_t *d_order = reinterpret_cast<const uint32_t *>(d + n_tab + PEN_MAXS + 1);
     if (ctx->params.closest_point_mode == 1)
-        hipLaunchKernelGGL((k_pen_setup<1, 128>), dim3(cdiv(total, 128)), dim3(128), 0, ctx->stream, tb, length_threshold,
+        launch_raw(ctx, (k_pen_setup<1, 128>), dim3(cdiv(total, 128)), dim3(128), 0, tb, length_threshold,
                            angle_threshold, d_items, d_n, d_pair);
     else
-        hipLaunchKernelGGL((k_pen_setup<0, 256>), dim3(cdiv(total, 256)), dim3(256), 0, ctx->stream, tb, length_threshold,
+        launch_raw(ctx, (k_pen_setup<0, 256>), dim3(cdiv(total, 256)), dim3(256), 0, tb, length_threshold,
                            angle_threshold, d_items, d_n, d_pair);
     // in-plane grids of both sides (cell = 2 r)
     const float cell = pen_grid_cell(length_threshold);
@@ -490,7 +490,7 @@ void penetration_filter(plade_ctx *ctx, const float *cand_rt_host, uint32_t K, c
     const PenSide sS{src_pts.frames.p, src_pts.cell_pts.p, src_pts.cell_start.p}, sT{tgt_pts.frames.p, tgt_pts.cell_pts.p, tgt_pts.cell_start.p};
     // a plane pair holds at most K items: grid.y covers the worst case, empty groups exit at once
     ctx->ev_begin("pen_walk", 0.0);
-    hipLaunchKernelGGL(k_pen_walk, dim3(n_pairs, cdiv(K, PEN_G)), dim3(PEN_TPB), 0, ctx->stream, d_items, d_pair, d_order, tb, d_steps,
+    launch_raw(ctx, k_pen_walk, dim3(n_pairs, cdiv(K, PEN_G)), dim3(PEN_TPB), 0, d_items, d_pair, d_order, tb, d_steps,
                        sS, sT, cell, search_radius, 10, min_distance, d_flags, d_over);
     ctx->ev_end();
     std::vector<uint32_t> out(n_ctr);   // items, overflow, K candidate flags, per-pair item counts

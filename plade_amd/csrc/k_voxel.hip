@@ -225,8 +225,8 @@ void VoxelWork::enqueue(plade_ctx *ctx, const float *d_xyz, uint32_t stride, con
         group_offsets.ensure((size_t)n_groups + 2);
         count.ensure(4);
         out_xyz.ensure(4);
-        HIP_TRY(hipMemsetAsync(group_offsets.p, 0, ((size_t)n_groups + 2) * 4, ctx->stream));
-        HIP_TRY(hipMemsetAsync(count.p, 0, 4, ctx->stream));
+        ctx->fill_async(group_offsets.p, 0, ((size_t)n_groups + 2) * 4);
+        ctx->fill_async(count.p, 0, 4);
         return;
     }
     const float inv = 1.f / leaf;
@@ -260,11 +260,11 @@ void VoxelWork::enqueue(plade_ctx *ctx, const float *d_xyz, uint32_t stride, con
     const bool narrow = key_bits <= 31;   // (31: the all-ones padding key of k_voxel_runs must not be a real key)
     uint32_t *k32 = reinterpret_cast<uint32_t *>(keys.p), *k32b = reinterpret_cast<uint32_t *>(keys2.p);
     if (narrow)
-        hipLaunchKernelGGL(k_voxel_keys<uint32_t>, dim3(nb), dim3(256), 0, ctx->stream, d_xyz, stride, d_soa_x, d_soa_y, d_soa_z, soa_indexed ? 1 : 0,
+        launch_raw(ctx, k_voxel_keys<uint32_t>, dim3(nb), dim3(256), 0, d_xyz, stride, d_soa_x, d_soa_y, d_soa_z, soa_indexed ? 1 : 0,
                            d_item_point, d_item_group, n_items, inv, lmin[0], lmin[1], lmin[2], bx, by, bz, k32, vals.p,
                            groups_are_offsets ? n_groups + 1 : 0u);
     else
-        hipLaunchKernelGGL(k_voxel_keys<uint64_t>, dim3(nb), dim3(256), 0, ctx->stream, d_xyz, stride, d_soa_x, d_soa_y, d_soa_z, soa_indexed ? 1 : 0,
+        launch_raw(ctx, k_voxel_keys<uint64_t>, dim3(nb), dim3(256), 0, d_xyz, stride, d_soa_x, d_soa_y, d_soa_z, soa_indexed ? 1 : 0,
                            d_item_point, d_item_group, n_items, inv, lmin[0], lmin[1], lmin[2], bx, by, bz, keys.p, vals.p,
                            groups_are_offsets ? n_groups + 1 : 0u);
     if (narrow) sort_pairs_u32(ctx, k32, k32b, vals.p, vals2.p, n_items, key_bits);
@@ -272,14 +272,14 @@ void VoxelWork::enqueue(plade_ctx *ctx, const float *d_xyz, uint32_t stride, con
     const ScanTicket t = scan_ticket(ctx, n_items, VR_TILE);
     float *ox = sorted_xyz.p, *oy = ox + n_items, *oz = oy + n_items;
     if (narrow)
-        hipLaunchKernelGGL(k_voxel_runs<uint32_t>, dim3(t.tiles), dim3(VR_T), 0, ctx->stream, k32b, vals2.p, n_items, d_xyz, stride,
+        launch_raw(ctx, k_voxel_runs<uint32_t>, dim3(t.tiles), dim3(VR_T), 0, k32b, vals2.p, n_items, d_xyz, stride,
                            soa_indexed ? d_soa_x : nullptr, soa_indexed ? d_soa_y : nullptr, soa_indexed ? d_soa_z : nullptr, d_item_point,
                            bx + by + bz, t.state, t.ticket, t.base, t.gen, heads.p, seg_group.p, count.p, ox, oy, oz);
     else
-        hipLaunchKernelGGL(k_voxel_runs<uint64_t>, dim3(t.tiles), dim3(VR_T), 0, ctx->stream, keys2.p, vals2.p, n_items, d_xyz, stride,
+        launch_raw(ctx, k_voxel_runs<uint64_t>, dim3(t.tiles), dim3(VR_T), 0, keys2.p, vals2.p, n_items, d_xyz, stride,
                            soa_indexed ? d_soa_x : nullptr, soa_indexed ? d_soa_y : nullptr, soa_indexed ? d_soa_z : nullptr, d_item_point,
                            bx + by + bz, t.state, t.ticket, t.base, t.gen, heads.p, seg_group.p, count.p, ox, oy, oz);
-    hipLaunchKernelGGL(k_voxel_centroids, dim3(cdiv(n_items, 128)), dim3(128), 0, ctx->stream, ox, oy, oz, heads.p, seg_group.p,
+    launch_raw(ctx, k_voxel_centroids, dim3(cdiv(n_items, 128)), dim3(128), 0, ox, oy, oz, heads.p, seg_group.p,
                        count.p, n_items, n_groups, out_xyz.p, group_offsets.p, d_out_soa);
     HIP_TRY(hipGetLastError());
     ctx->d2h(&n_pending_host, count.p, 4);   // valid after the next sync of this stream
@@ -688,8 +688,8 @@ float average_spacing_dev(plade_ctx *ctx, const float *d_aos, uint32_t stride_f,
         grid.build(ctx, d_aos, n, stride_f, cell, bbmin, bbmax);
         if (n <= 256) break;
         uint32_t *d_flag = reinterpret_cast<uint32_t *>(ctx->scratch[2].ensure(64));
-        HIP_TRY(hipMemsetAsync(d_flag, 0, 8, ctx->stream));
-        hipLaunchKernelGGL(k_grid_occupancy, dim3(std::min(cdiv(n, 1024), 512u)), dim3(256), 0, ctx->stream, grid.keys2.p, n, 256u, d_flag);
+        ctx->fill_async(d_flag, 0, 8);
+        launch_raw(ctx, k_grid_occupancy, dim3(std::min(cdiv(n, 1024), 512u)), dim3(256), 0, grid.keys2.p, n, 256u, d_flag);
         uint32_t occ[2] = {0, 0};
         ctx->d2h(occ, d_flag, 8);
         ctx->sync();
@@ -705,7 +705,7 @@ float average_spacing_dev(plade_ctx *ctx, const float *d_aos, uint32_t stride_f,
     double *d_avg = reinterpret_cast<double *>(ctx->scratch[1].ensure((size_t)nq * 8 + 8));
     uint32_t *d_nbs = reinterpret_cast<uint32_t *>(ctx->scratch[2].ensure((size_t)nq * 4 + 8));
     ctx->ev_begin("knn_spacing", 12.0 * n);
-    hipLaunchKernelGGL(k_knn_grid, dim3(cdiv(nq, 4)), dim3(256), 0, ctx->stream, grid.sorted.p, grid.cell_start.p,
+    launch_raw(ctx, k_knn_grid, dim3(cdiv(nq, 4)), dim3(256), 0, grid.sorted.p, grid.cell_start.p,
                        grid.cell_end.p, g, d_aos, stride_f, n, (uint32_t)step, nq, k, d_avg, d_nbs);
     ctx->ev_end();
     HIP_TRY(hipGetLastError());
@@ -779,7 +779,7 @@ void bbox_host(plade_ctx *ctx, const float *d_xyz, uint32_t n, uint32_t stride, 
     bbox_init_pattern(init);
     int *d = reinterpret_cast<int *>(ctx->scratch[3].ensure(64));
     ctx->h2d(d, init, 32);
-    if (n) hipLaunchKernelGGL(k_minmax3_v, dim3(std::min(cdiv(n, 1024), 1024u)), dim3(256), 0, ctx->stream, d_xyz, n, stride, d);
+    if (n) launch_raw(ctx, k_minmax3_v, dim3(std::min(cdiv(n, 1024), 1024u)), dim3(256), 0, d_xyz, n, stride, d);
     int out[8];
     ctx->d2h(out, d, 32);
     ctx->sync();

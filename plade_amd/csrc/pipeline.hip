@@ -107,8 +107,8 @@ bool prepare_side(plade_ctx *ctx, const char *tag, const CloudDev &cloud, const 
     const uint32_t *items = S.d_items.p;
     if (dev_list && pl.mirrored) {   // the mirrored half shares the supports of the first half
         const size_t half = (size_t)pl.offsets[P / 2];
-        HIP_TRY(hipMemcpyAsync(S.d_items.p, dev_list, 4 * half, hipMemcpyDeviceToDevice, ctx->stream));
-        HIP_TRY(hipMemcpyAsync(S.d_items.p + half, dev_list, 4 * half, hipMemcpyDeviceToDevice, ctx->stream));
+        ctx->copy_dd_async(S.d_items.p, dev_list, 4 * half);
+        ctx->copy_dd_async(S.d_items.p + half, dev_list, 4 * half);
     } else if (dev_list) items = dev_list;   // read where the extraction left it (valid until this cloud slot's next detect)
     else ctx->h2d(S.d_items.p, pl.idx, 4 * (size_t)n_items);
     const bool batched = S.vox_planes_ready && S.obb_ready && by_pos && !pl.mirrored;   // grids and boxes came with the group's
@@ -472,7 +472,7 @@ bool run_registration(plade_ctx *ctx, RegistrationWork &W, const CloudDev &tgt, 
         std::vector<uint32_t> ids(K);
         for (uint32_t i = 0; i < K; ++i) ids[i] = seeds[cand_cluster[tested[i]]];
         PenGather pg{ids.data(), [&](const uint32_t *d_ids) {
-            hipLaunchKernelGGL(k_gather_rt, dim3(cdiv(K, 64)), dim3(64), 0, ctx->stream, W.cand.rt.p, d_ids, K, W.d_rt12.p);
+            launch_raw(ctx, k_gather_rt, dim3(cdiv(K, 64)), dim3(64), 0, W.cand.rt.p, d_ids, K, W.d_rt12.p);
             ctx->d2h(rt12.data(), W.d_rt12.p, 48 * (size_t)K);   // valid after the wait at the end of the penetration filter
         }};
         penetration_filter(ctx, nullptr, K, C.geom, M.geom, C.pcl, M.pcl, lengthThreshold, angleThreshold, penflags, W.d_rt12.p, &pg);

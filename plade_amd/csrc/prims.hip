@@ -108,8 +108,8 @@ ScanTicket scan_ticket(plade_ctx *ctx, size_t n, uint32_t tile_items) {
     if (w.state.cap < tiles + 1 || !w.ticket.p) {   // fresh words must not look like this generation's
         w.state.ensure((size_t)tiles + 1);
         w.ticket.ensure(4);
-        HIP_TRY(hipMemsetAsync(w.state.p, 0, w.state.cap * 8, ctx->stream));
-        HIP_TRY(hipMemsetAsync(w.ticket.p, 0, 16, ctx->stream));
+        ctx->fill_async(w.state.p, 0, w.state.cap * 8);
+        ctx->fill_async(w.ticket.p, 0, 16);
         w.base = 0;
     }
     ScanTicket t{w.state.p, w.ticket.p, w.base, ++w.gen & 0x3fffffffu, tiles};
@@ -122,7 +122,7 @@ void exclusive_scan_u32(plade_ctx *ctx, const uint32_t *in, uint32_t *out, size_
     if (!n) return;
     PLADE_REQUIRE(n < (1ull << 32), PLADE_ELIMIT, "scan: too many items");
     const ScanTicket t = scan_ticket(ctx, n, SC_TILE);
-    hipLaunchKernelGGL(k_scan_u32, dim3(t.tiles), dim3(SC_T), 0, ctx->stream, in, out, (uint32_t)n, t.state, t.ticket, t.base, t.gen);
+    launch_raw(ctx, k_scan_u32, dim3(t.tiles), dim3(SC_T), 0, in, out, (uint32_t)n, t.state, t.ticket, t.base, t.gen);
 }
 
 

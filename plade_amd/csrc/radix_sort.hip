@@ -296,7 +296,7 @@ void radix_sort_run_ipt(plade_ctx *ctx, const K *ki, K *ko, const uint32_t *vi, 
     constexpr size_t GH = (size_t)RS_MAXSEG * RS_GH_SEG;
     if (!ctx->sort_ghist.p) {
         ctx->sort_ghist.ensure(2 * GH);
-        HIP_TRY(hipMemsetAsync(ctx->sort_ghist.p, 0, 2 * GH * 4, st));
+        ctx->fill_async(ctx->sort_ghist.p, 0, 2 * GH * 4);
         ctx->sort_segs[0] = ctx->sort_segs[1] = 0;
     }
     const uint32_t cur = ctx->sort_seq & 1u, nxt = cur ^ 1u;
@@ -306,7 +306,7 @@ void radix_sort_run_ipt(plade_ctx *ctx, const K *ki, K *ko, const uint32_t *vi, 
     ctx->sort_segs[cur] = (uint32_t)nseg;
     ctx->sort_seq += 1;
     ki += seg_off[0]; ko += seg_off[0]; vi += seg_off[0]; vo += seg_off[0];
-    hipLaunchKernelGGL((k_rs_histogram<K, DB>), dim3(RS_HBLOCKS * nseg), dim3(RS_THREADS), 0, st, ki, S, passes, gh, t + off_ctr,
+    launch_raw(ctx, (k_rs_histogram<K, DB>), dim3(RS_HBLOCKS * nseg), dim3(RS_THREADS), 0, ki, S, passes, gh, t + off_ctr,
                        t + off_look, look_words);
     const K *src_k = ki;
     const uint32_t *src_v = vi;
@@ -315,7 +315,7 @@ void radix_sort_run_ipt(plade_ctx *ctx, const K *ki, K *ko, const uint32_t *vi, 
         K *dst_k = to_out ? ko : tk;
         uint32_t *dst_v = to_out ? vo : tv;
         uint32_t *pass_look = t + off_look + (size_t)p * pass_words;
-        hipLaunchKernelGGL((k_rs_pass<K, DB, RS_IPT>), dim3(tiles), dim3(RS_THREADS), 0, st, src_k, dst_k, src_v, dst_v, S, p, gh,
+        launch_raw(ctx, (k_rs_pass<K, DB, RS_IPT>), dim3(tiles), dim3(RS_THREADS), 0, src_k, dst_k, src_v, dst_v, S, p, gh,
                            gh_next, zero_words, t + off_ctr, pass_look, reinterpret_cast<unsigned long long *>(pass_look + (size_t)tiles * NB), st_shift);
         src_k = dst_k;
         src_v = dst_v;

@@ -316,7 +316,29 @@ void register_group(plade_ctx *ctx, int first, int count, const CloudDev *const 
     HIP_TRY(hipEventRecord(ctx->ev_group, ctx->stream));
     Err errs[PLADE_GROUP_MAX];
     for (Err &e : errs) e = Err{0, ""};
+    // Lock step (launch.h): what the pairs launch behind this point is collected per pair and issued, merged, on THIS context's
+    // stream whenever all of them have reached their next host wait.  Not with the profiled modes (HIP events around single
+    // launches), nor under PLADE_DEBUG_READS (eager copies on the pair's own stream); PLADE_NO_LOCKSTEP=1 is the A/B switch.
+    static const bool no_lockstep = getenv("PLADE_NO_LOCKSTEP") != nullptr;
+    Combiner comb;
+    comb.lead = ctx;
+    const bool lockstep = !no_lockstep && !ctx->profiling() && !ctx->debug_reads;
+    struct CombGuard {      // no context keeps a pointer to the combiner of a call that has ended
+        plade_ctx **pcs; int count;
+        ~CombGuard() { for (int i = 0; i < count; ++i) if (pcs[i]) { pcs[i]->comb = nullptr; pcs[i]->comb_slot = -1; } }
+    } comb_guard{pcs, count};
+    if (lockstep) for (int i = 0; i < count; ++i) comb.join(pcs[i]);
     auto tail = [&](int i) {
+        std::vector<void *> graveyard;     // allocations replaced while launches that may name them were still queued (common.h)
+        struct Leave {
+            Combiner &cb; plade_ctx *pc; bool on; std::vector<void *> &gy;
+            ~Leave() {
+                tl_deferred_free = nullptr;
+                if (on) { try { cb.leave(pc); } catch (...) {} }
+                for (void *p : gy) (void)hipFree(p);
+            }
+        } leave{comb, pcs[i], lockstep, graveyard};
+        if (lockstep) tl_deferred_free = &graveyard;
         try {
             status[i] = register_tail(pcs[i], ctx, 2 * i, *tgt[i], *src[i], planes[2 * i], planes[2 * i + 1], auto_tune, have_spacing[i], spacing[i],
                                       T16 + 16 * i, t0);
@@ -341,6 +363,13 @@ void register_group(plade_ctx *ctx, int first, int count, const CloudDev *const 
     }
     tail(0);
     for (int i = 1; i < count; ++i) ths[i].join();
+    if (lockstep) {
+        uint64_t asked = 0;
+        for (int i = 0; i < count; ++i) asked += comb.asked[i];
+        ctx->stats.add("lockstep_operations_asked", (double)asked);
+        ctx->stats.add("lockstep_commands_issued", (double)comb.launches_issued);
+        ctx->stats.add("lockstep_group_waits", (double)comb.waits);
+    }
     for (int i = 0; i < count; ++i)
         if (errs[i].code) { pcs[i]->drop_reads(); pcs[i]->last_error = errs[i].msg; status[i] = errs[i].code; }
 }
