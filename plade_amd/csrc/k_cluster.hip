@@ -19,13 +19,13 @@
 
 namespace plade {
 
-__global__ __launch_bounds__(256) void k_transforms(const float *__restrict__ q_lv1, const float *__restrict__ q_lv2,
+__device__ void k_transforms(const VB &vb, const float *__restrict__ q_lv1, const float *__restrict__ q_lv2,
                                                     const float *__restrict__ q_p1, const float *__restrict__ t_lv1,
                                                     const float *__restrict__ t_lv2, const float *__restrict__ t_p1,
                                                     const uint32_t *__restrict__ q_idx, const uint32_t *__restrict__ t_idx,
                                                     uint32_t m, float4 *__restrict__ rt, float *__restrict__ t_minmax_part) {
     __shared__ float s_lds[6][8];
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = vb.bx * blockDim.x + threadIdx.x;
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     if (i < m) {
     const uint32_t q = q_idx[i], t = t_idx[i];
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void k_transforms(const float *__restrict__ q_
     if (threadIdx.x < 6) {
         float v = s_lds[threadIdx.x][0];
         for (int w = 1; w < 4; ++w) v = threadIdx.x < 3 ? fminf(v, s_lds[threadIdx.x][w]) : fmaxf(v, s_lds[threadIdx.x][w]);
-        t_minmax_part[6 * (size_t)blockIdx.x + threadIdx.x] = v;
+        t_minmax_part[6 * (size_t)vb.bx + threadIdx.x] = v;
     }
 }
 
@@ -70,7 +70,7 @@ void build_transforms(plade_ctx *ctx, const PairTableDev &src, const PairTableDe
     cs.rt.ensure(4 * (size_t)m + 4);
     if (!m) return;
     cs.t_minmax.ensure(6 * (size_t)cdiv(m, 256) + 8);
-    launch_raw(ctx, k_transforms, dim3(cdiv(m, 256)), dim3(256), 0, src.lv1.p, src.lv2.p, src.p1.p,
+    launch<k_transforms, 256>(ctx, dim3(cdiv(m, 256)), 0, src.lv1.p, src.lv2.p, src.p1.p,
                        tgt.lv1.p, tgt.lv2.p, tgt.p1.p, d_q_idx, d_t_idx, m, cs.rt.p, cs.t_minmax.p);
     HIP_TRY(hipGetLastError());
 }
@@ -88,9 +88,9 @@ __device__ __forceinline__ uint64_t cell_key(const HashGrid &g, int cx, int cy, 
 }
 
 // keys + union-find / size initialisation
-__global__ void k_t_keys(const float4 *__restrict__ rt, uint32_t m, HashGrid g, uint64_t *__restrict__ keys,
+__device__ void k_t_keys(const VB &vb, const float4 *__restrict__ rt, uint32_t m, HashGrid g, uint64_t *__restrict__ keys,
                          uint32_t *__restrict__ vals, uint32_t *__restrict__ parent, uint32_t *__restrict__ sizes) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = vb.bx * blockDim.x + threadIdx.x;
     if (i >= m) return;
     const int cx = (int)floorf((rt[4 * (size_t)i].w - g.mnx) * g.inv) + 1;
     const int cy = (int)floorf((rt[4 * (size_t)i + 1].w - g.mny) * g.inv) + 1;
@@ -132,11 +132,11 @@ __device__ __forceinline__ uint32_t lower_bound_u64(const uint64_t *a, uint32_t 
 
 // After the sort: nodes gathered into cell order (translation + original index, Euler angles), and for the
 // first node of every cell the nine spans [lo, hi) of sorted positions covering its 27-neighbourhood.
-__global__ __launch_bounds__(256) void k_cell_spans(const float4 *__restrict__ rt, const uint32_t *__restrict__ order,
+__device__ void k_cell_spans(const VB &vb, const float4 *__restrict__ rt, const uint32_t *__restrict__ order,
                                                     const uint64_t *__restrict__ skeys, uint32_t m, HashGrid g,
                                                     float4 *__restrict__ st, float4 *__restrict__ se,
                                                     uint2 *__restrict__ spans /* m x 9, rows of cell heads only */) {
-    const uint32_t si = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t si = vb.bx * blockDim.x + threadIdx.x;
     if (si >= m) return;
     const uint32_t a = order[si];
     st[si] = make_float4(rt[4 * (size_t)a].w, rt[4 * (size_t)a + 1].w, rt[4 * (size_t)a + 2].w, __uint_as_float(a));
@@ -174,10 +174,10 @@ __device__ __forceinline__ void edge_test(const float4 *__restrict__ st, const f
     const float sq = (t0 * t0 + t1 * t1) + t2 * t2;  // Eigen::VectorXf(3).squaredNorm()
     if (sq < gate) uf_union(parent, a, b);
 }
-__global__ __launch_bounds__(256) void k_cluster_edges(const float4 *__restrict__ st, const float4 *__restrict__ se,
+__device__ void k_cluster_edges(const VB &vb, const float4 *__restrict__ st, const float4 *__restrict__ se,
                                                        const uint64_t *__restrict__ skeys, const uint2 *__restrict__ spans,
                                                        uint32_t m, float r2, float gate, uint32_t *__restrict__ parent) {
-    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t tid = vb.bx * blockDim.x + threadIdx.x;
     const uint32_t si = tid / 9u, r = tid - 9u * si;
     const bool live = si < m;
     float4 pa = make_float4(0.f, 0.f, 0.f, 0.f), ea = pa;
@@ -202,18 +202,18 @@ __global__ __launch_bounds__(256) void k_cluster_edges(const float4 *__restrict_
     }
 }
 
-__global__ void k_flatten(uint32_t *__restrict__ parent, uint32_t n, uint32_t *__restrict__ sizes,
+__device__ void k_flatten(const VB &vb, uint32_t *__restrict__ parent, uint32_t n, uint32_t *__restrict__ sizes,
                           uint32_t *__restrict__ root_flags) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = vb.bx * blockDim.x + threadIdx.x;
     if (i >= n) { if (i == n) root_flags[n] = 0; return; }
     uint32_t r = i;
     while (parent[r] != r) r = parent[r];
     atomicAdd(&sizes[r], 1u);
     root_flags[i] = (r == i) ? 1u : 0u;
 }
-__global__ void k_gather_sizes(const uint32_t *__restrict__ seeds, uint32_t n, const uint32_t *__restrict__ sizes_all,
+__device__ void k_gather_sizes(const VB &vb, const uint32_t *__restrict__ seeds, uint32_t n, const uint32_t *__restrict__ sizes_all,
                                uint32_t *__restrict__ out) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = vb.bx * blockDim.x + threadIdx.x;
     if (i < n) out[i] = sizes_all[seeds[i]];
 }
 
@@ -252,26 +252,26 @@ void cluster_transforms(plade_ctx *ctx, CandidateSet &cs, float dist_threshold, 
     cs.parent.ensure(m); cs.sizes_all.ensure(m); cs.flags.ensure((size_t)m + 1);
     cs.st.ensure(m); cs.se.ensure(m); cs.spans.ensure((size_t)m * 9);
     const unsigned nb = cdiv(m, 256);
-    launch_raw(ctx, k_t_keys, dim3(nb), dim3(256), 0, cs.rt.p, m, g, cs.ckeys.p, cs.cvals.p, cs.parent.p,
+    launch<k_t_keys, 256>(ctx, dim3(nb), 0, cs.rt.p, m, g, cs.ckeys.p, cs.cvals.p, cs.parent.p,
                        cs.sizes_all.p);
     sort_pairs_u64(ctx, cs.ckeys.p, cs.ckeys2.p, cs.cvals.p, cs.cvals2.p, m, bx + by + bz);
-    launch_raw(ctx, k_cell_spans, dim3(nb), dim3(256), 0, cs.rt.p, cs.cvals2.p, cs.ckeys2.p, m, g, cs.st.p,
+    launch<k_cell_spans, 256>(ctx, dim3(nb), 0, cs.rt.p, cs.cvals2.p, cs.ckeys2.p, m, g, cs.st.p,
                        cs.se.p, cs.spans.p);
     ctx->ev_begin("cluster_edges", 0.0);   // latency / atomics bound, no HBM figure
-    launch_raw(ctx, k_cluster_edges, dim3(cdiv((size_t)m * 9, 256)), dim3(256), 0, cs.st.p, cs.se.p, cs.ckeys2.p,
+    launch<k_cluster_edges, 256>(ctx, dim3(cdiv((size_t)m * 9, 256)), 0, cs.st.p, cs.se.p, cs.ckeys2.p,
                        cs.spans.p, m, r2, angle_gate, cs.parent.p);
     ctx->ev_end();
-    launch_raw(ctx, k_flatten, dim3(cdiv(m + 1, 256)), dim3(256), 0, cs.parent.p, m, cs.sizes_all.p, cs.flags.p);
+    launch<k_flatten, 256>(ctx, dim3(cdiv(m + 1, 256)), 0, cs.parent.p, m, cs.sizes_all.p, cs.flags.p);
     cs.n_clusters = compact_flags(ctx, cs.flags.p, m, cs.pos, cs.seeds);
     cs.sizes.ensure((size_t)cs.n_clusters + 1);
     if (cs.n_clusters)
-        launch_raw(ctx, k_gather_sizes, dim3(cdiv(cs.n_clusters, 256)), dim3(256), 0, cs.seeds.p,
+        launch<k_gather_sizes, 256>(ctx, dim3(cdiv(cs.n_clusters, 256)), 0, cs.seeds.p,
                            cs.n_clusters, cs.sizes_all.p, cs.sizes.p);
     HIP_TRY(hipGetLastError());
 }
 
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_plane_consistency(const float4 *__restrict__ rt, const uint32_t *__restrict__ seeds,
+__device__ void k_plane_consistency(const VB &vb, const float4 *__restrict__ rt, const uint32_t *__restrict__ seeds,
                                                            uint32_t n_clusters, const float *__restrict__ s_tab,
                                                            uint32_t ps, const float *__restrict__ t_tab, uint32_t pt,
                                                            f3 src_bc, f3 tgt_bc, float max_radius, float cos_th,
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(256) void k_plane_consistency(const float4 *__restr
     for (uint32_t i = threadIdx.x; i < 8 * ps; i += blockDim.x) S[i] = s_tab[i];
     for (uint32_t i = threadIdx.x; i < 8 * pt; i += blockDim.x) Tt[i] = t_tab[i];
     __syncthreads();
-    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t c = vb.bx * blockDim.x + threadIdx.x;
     if (c >= n_clusters) return;
     const uint32_t k = seeds[c];
     const float4 r0 = rt[4 * (size_t)k], r1 = rt[4 * (size_t)k + 1], r2v = rt[4 * (size_t)k + 2];
@@ -336,7 +336,7 @@ void plane_consistency(plade_ctx *ctx, CandidateSet &cs, const PlaneGeomHost &sr
     float *d_tab = reinterpret_cast<float *>(ctx->scratch[4].ensure(tab.size() * 4 + 16));
     const bool staged = ctx->h2d(d_tab, tab.data(), tab.size() * 4);
     const size_t shmem = 32 * ((size_t)src.P + tgt.P);
-    launch_raw(ctx, k_plane_consistency, dim3(cdiv(n, 256)), dim3(256), shmem, cs.rt.p, cs.seeds.p, n, d_tab,
+    launch<k_plane_consistency, 256>(ctx, dim3(cdiv(n, 256)), shmem, cs.rt.p, cs.seeds.p, n, d_tab,
                        src.P, d_tab + 8 * (size_t)src.P, tgt.P, f3(src_bcenter[0], src_bcenter[1], src_bcenter[2]),
                        f3(tgt_bcenter[0], tgt_bcenter[1], tgt_bcenter[2]), max_radius, cos_angle_th, length_threshold,
                        cs.plane_counts.p);

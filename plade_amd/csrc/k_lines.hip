@@ -50,9 +50,9 @@ __device__ __forceinline__ void unordered_pair(uint32_t t, uint32_t L, uint32_t 
     j = (uint32_t)(t - f(r)) + i + 1u;
 }
 
-__global__ __launch_bounds__(CP_TPB) void k_closest_svd(LinesView v, uint32_t n_pairs, float *__restrict__ cp) {
+__device__ void k_closest_svd(const VB &vb, LinesView v, uint32_t n_pairs, float *__restrict__ cp) {
     __shared__ float lds[LaneSolver<9, 9, CP_TPB>::WORDS_PER_LANE * CP_TPB];
-    const uint32_t t = blockIdx.x * CP_TPB + threadIdx.x;
+    const uint32_t t = vb.bx * CP_TPB + threadIdx.x;
     if (t >= n_pairs) return;
     uint32_t i, j;
     unordered_pair(t, v.L, i, j);
@@ -77,13 +77,13 @@ __device__ __forceinline__ bool pair_closest(const float *__restrict__ cp, uint3
     return true;
 }
 
-__global__ __launch_bounds__(256) void k_pair_table(LinesView v, float scale, float angle_thresh, int target,
+__device__ void k_pair_table(const VB &vb, LinesView v, float scale, float angle_thresh, int target,
                                                     const float *__restrict__ cp,
                                                     uint32_t *__restrict__ flags, float *__restrict__ desc,
                                                     float *__restrict__ lv1, float *__restrict__ lv2,
                                                     float *__restrict__ p1out) {
     const uint32_t L = v.L;
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t idx = (size_t)vb.bx * blockDim.x + threadIdx.x;
     if (idx >= (size_t)L * L) return;
     const uint32_t i = (uint32_t)(idx / L), j = (uint32_t)(idx % L);
     flags[idx] = 0u;
@@ -125,20 +125,20 @@ __global__ __launch_bounds__(256) void k_pair_table(LinesView v, float scale, fl
     (void)p2;
 }
 
-__global__ void k_scatter_pairs(const uint32_t *__restrict__ flags, const uint32_t *__restrict__ pos, size_t n,
+__device__ void k_scatter_pairs(const VB &vb, const uint32_t *__restrict__ flags, const uint32_t *__restrict__ pos, size_t n,
                                 const float *__restrict__ desc, const float *__restrict__ lv1,
                                 const float *__restrict__ lv2, const float *__restrict__ p1, float *__restrict__ o_desc,
                                 float *__restrict__ o_lv1, float *__restrict__ o_lv2, float *__restrict__ o_p1) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t i = (size_t)vb.bx * blockDim.x + threadIdx.x;
     if (i >= n || !flags[i]) return;
     const size_t o = pos[i];
     for (int k = 0; k < 8; ++k) o_desc[o * 8 + k] = desc[i * 8 + k];
     for (int k = 0; k < 3; ++k) { o_lv1[o * 3 + k] = lv1[i * 3 + k]; o_lv2[o * 3 + k] = lv2[i * 3 + k]; o_p1[o * 3 + k] = p1[i * 3 + k]; }
 }
 
-__global__ void k_flag_positions(const uint32_t *__restrict__ flags, const uint32_t *__restrict__ pos, uint32_t n,
+__device__ void k_flag_positions(const VB &vb, const uint32_t *__restrict__ flags, const uint32_t *__restrict__ pos, uint32_t n,
                                  uint32_t *__restrict__ out) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t i = vb.bx * blockDim.x + threadIdx.x;
     if (i < n && flags[i]) out[pos[i]] = i;
 }
 
@@ -151,7 +151,7 @@ uint32_t compact_flags(plade_ctx *ctx, const uint32_t *d_flags, uint32_t n, DBuf
     ctx->d2h(&total, pos.p + n, 4);
     ctx->sync();
     out_idx.ensure((size_t)total + 1);
-    launch_raw(ctx, k_flag_positions, dim3(cdiv(n, 256)), dim3(256), 0, d_flags, pos.p, n, out_idx.p);
+    launch<k_flag_positions, 256>(ctx, dim3(cdiv(n, 256)), 0, d_flags, pos.p, n, out_idx.p);
     HIP_TRY(hipGetLastError());
     return total;
 }
@@ -187,16 +187,16 @@ void build_pair_table(plade_ctx *ctx, const LineTableHost &lt, const float *norm
     if (ctx->params.closest_point_mode == 1 && L > 1) {
         const uint32_t n_pairs = (uint32_t)((size_t)L * (L - 1) / 2);
         cp = out.cp.ensure(n * 6);
-        launch_raw(ctx, k_closest_svd, dim3(cdiv(n_pairs, CP_TPB)), dim3(CP_TPB), 0, v, n_pairs, out.cp.p);
+        launch<k_closest_svd, CP_TPB>(ctx, dim3(cdiv(n_pairs, CP_TPB)), 0, v, n_pairs, out.cp.p);
     }
-    launch_raw(ctx, k_pair_table, dim3(cdiv(n, 256)), dim3(256), 0, v, scale, angle_thresh, target ? 1 : 0, cp,
+    launch<k_pair_table, 256>(ctx, dim3(cdiv(n, 256)), 0, v, scale, angle_thresh, target ? 1 : 0, cp,
                        out.flags.p, out.all_desc.p, out.all_lv1.p, out.all_lv2.p, out.all_p1.p);
     exclusive_scan_u32(ctx, out.flags.p, out.pos.p, n + 1);
     if (staged && n <= (1u << 20)) {
         // the usual table (a few hundred lines): the compacted arrays are sized for all n pairs (68 B each) and the count
         // comes back with the caller's next wait -- no host round trip between the scan and the compaction
         out.desc.ensure(n * 8 + 8); out.lv1.ensure(n * 3 + 4); out.lv2.ensure(n * 3 + 4); out.p1.ensure(n * 3 + 4);
-        launch_raw(ctx, k_scatter_pairs, dim3(cdiv(n, 256)), dim3(256), 0, out.flags.p, out.pos.p, n,
+        launch<k_scatter_pairs, 256>(ctx, dim3(cdiv(n, 256)), 0, out.flags.p, out.pos.p, n,
                            out.all_desc.p, out.all_lv1.p, out.all_lv2.p, out.all_p1.p, out.desc.p, out.lv1.p, out.lv2.p,
                            out.p1.p);
         HIP_TRY(hipGetLastError());
@@ -210,7 +210,7 @@ void build_pair_table(plade_ctx *ctx, const LineTableHost &lt, const float *norm
     out.desc.ensure((size_t)total * 8 + 8); out.lv1.ensure((size_t)total * 3 + 4); out.lv2.ensure((size_t)total * 3 + 4);
     out.p1.ensure((size_t)total * 3 + 4);
     if (total)
-        launch_raw(ctx, k_scatter_pairs, dim3(cdiv(n, 256)), dim3(256), 0, out.flags.p, out.pos.p, n,
+        launch<k_scatter_pairs, 256>(ctx, dim3(cdiv(n, 256)), 0, out.flags.p, out.pos.p, n,
                            out.all_desc.p, out.all_lv1.p, out.all_lv2.p, out.all_p1.p, out.desc.p, out.lv1.p, out.lv2.p,
                            out.p1.p);
     HIP_TRY(hipGetLastError());

@@ -22,7 +22,7 @@ constexpr int MT_TILE = 128;   // targets per LDS tile
 constexpr int MT_CHUNK = 512;  // targets per block (grid.y)
 
 template <bool FILL>
-__global__ __launch_bounds__(MT_TPB) void k_match(const float *__restrict__ qry, uint32_t dq,
+__device__ void k_match(const VB &vb, const float *__restrict__ qry, uint32_t dq,
                                                   const float *__restrict__ tgt, uint32_t dt, double sq_rad,
                                                   uint32_t nch, uint32_t chunk /* targets per blockIdx.y, multiple of MT_TILE */,
                                                   uint32_t *__restrict__ cnt /* dq*nch */,
@@ -30,19 +30,19 @@ __global__ __launch_bounds__(MT_TPB) void k_match(const float *__restrict__ qry,
                                                   uint32_t *__restrict__ t_idx, double *__restrict__ d2_out,
                                                   uint32_t *__restrict__ q_idx, uint32_t *__restrict__ info) {
     __shared__ float s_t[MT_TILE][8];
-    if (!FILL && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {   // instead of two memset commands
+    if (!FILL && vb.bx == 0 && vb.by == 0 && threadIdx.x == 0) {   // instead of two memset commands
         cnt[(size_t)dq * nch] = 0u;       // the scan's extra slot
         info[0] = 0u; info[1] = 0u;       // k_query_offsets: total, longest list (atomicMax)
     }
-    const uint32_t q = blockIdx.x * MT_TPB + threadIdx.x;
+    const uint32_t q = vb.bx * MT_TPB + threadIdx.x;
     const bool live = q < dq;
     double qd[8];
 #pragma unroll
     for (int d = 0; d < 8; ++d) qd[d] = live ? (double)qry[(size_t)q * 8 + d] : 0.0;
-    const uint32_t t_begin = blockIdx.y * chunk;
+    const uint32_t t_begin = vb.by * chunk;
     const uint32_t t_end = min(dt, t_begin + chunk);
     uint32_t c = 0;
-    uint32_t wpos = (FILL && live) ? offs[(size_t)q * nch + blockIdx.y] : 0u;
+    uint32_t wpos = (FILL && live) ? offs[(size_t)q * nch + vb.by] : 0u;
     for (uint32_t t0 = t_begin; t0 < t_end; t0 += MT_TILE) {
         const uint32_t tn = min((uint32_t)MT_TILE, t_end - t0);
         __syncthreads();
@@ -66,11 +66,11 @@ __global__ __launch_bounds__(MT_TPB) void k_match(const float *__restrict__ qry,
                 }
             }
     }
-    if (!FILL && live) cnt[(size_t)q * nch + blockIdx.y] = c;
+    if (!FILL && live) cnt[(size_t)q * nch + vb.by] = c;
 }
 
-__global__ void k_d2_keys(const double *__restrict__ d2, uint32_t m, uint64_t *__restrict__ keys, uint32_t *__restrict__ vals) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ void k_d2_keys(const VB &vb, const double *__restrict__ d2, uint32_t m, uint64_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+    uint32_t i = vb.bx * blockDim.x + threadIdx.x;
     if (i >= m) return;
     keys[i] = (uint64_t)__double_as_longlong(d2[i]);  // non-negative doubles order as their bit patterns
     vals[i] = i;
@@ -84,24 +84,24 @@ __global__ void k_d2_keys_perm(const double *__restrict__ d2, const uint32_t *__
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < m) keys[i] = (uint64_t)__double_as_longlong(d2[perm[i]]);
 }
-__global__ void k_gather_u32(const uint32_t *__restrict__ src, const uint32_t *__restrict__ perm, uint32_t m,
+__device__ void k_gather_u32(const VB &vb, const uint32_t *__restrict__ src, const uint32_t *__restrict__ perm, uint32_t m,
                              uint32_t *__restrict__ dst) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t i = vb.bx * blockDim.x + threadIdx.x;
     if (i < m) dst[i] = src[perm[i]];
 }
-__global__ void k_gather_final(const uint32_t *__restrict__ t_idx, const double *__restrict__ d2,
+__device__ void k_gather_final(const VB &vb, const uint32_t *__restrict__ t_idx, const double *__restrict__ d2,
                                const uint32_t *__restrict__ perm, uint32_t m, uint32_t *__restrict__ t_out,
                                double *__restrict__ d2_out) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t i = vb.bx * blockDim.x + threadIdx.x;
     if (i >= m) return;
     uint32_t p = perm[i];
     t_out[i] = t_idx[p];
     d2_out[i] = d2[p];
 }
 // per-query offsets + {total, longest per-query list} for the host
-__global__ void k_query_offsets(const uint32_t *__restrict__ offs, uint32_t dq, uint32_t nch, int64_t *__restrict__ out,
+__device__ void k_query_offsets(const VB &vb, const uint32_t *__restrict__ offs, uint32_t dq, uint32_t nch, int64_t *__restrict__ out,
                                 uint32_t *__restrict__ info /* [0] total, [1] max list (zeroed) */) {
-    uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t q = vb.bx * blockDim.x + threadIdx.x;
     const uint32_t total = offs[(size_t)dq * nch];
     uint32_t len = 0;
     if (q < dq) {
@@ -119,7 +119,7 @@ __global__ void k_query_offsets(const uint32_t *__restrict__ offs, uint32_t dq, 
 // its own list: one workgroup per query, the list in LDS, O(len^2 / 256) compares (lists are tens to a few
 // thousand entries).  Ties are broken on the target index itself, so the fill order inside a list is free.
 constexpr uint32_t RANK_MAX_LIST = 4096;
-__global__ __launch_bounds__(256) void k_rank_lists(const int64_t *__restrict__ offsets, uint32_t dq,
+__device__ void k_rank_lists(const VB &vb, const int64_t *__restrict__ offsets, uint32_t dq,
                                                     const uint32_t *__restrict__ t_raw, const double *__restrict__ d2_raw,
                                                     uint32_t *__restrict__ t_out, double *__restrict__ d2_out, uint32_t cap) {
     // one workgroup per query: its list staged in LDS -- as much of it as the LONGEST list of the call needs (`cap` entries of
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256) void k_rank_lists(const int64_t *__restrict__ 
     extern __shared__ double s_rank[];
     double *s_d2 = s_rank;
     uint32_t *s_t = reinterpret_cast<uint32_t *>(s_rank + cap);
-    const uint32_t q = blockIdx.x;
+    const uint32_t q = vb.bx;
     if (q >= dq) return;
     const uint32_t b = (uint32_t)offsets[q], e = (uint32_t)offsets[q + 1], len = e - b;
     for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) { s_d2[i] = d2_raw[b + i]; s_t[i] = t_raw[b + i]; }
@@ -329,7 +329,7 @@ uint64_t MatchResult::run_windowed(plade_ctx *ctx, const float *d_qry, uint32_t 
     q_idx_sorted = q_raw.p;
     if (max_list <= RANK_MAX_LIST) {
         const uint32_t cap = std::max(64u, (max_list + 63u) & ~63u);   // entries of LDS per workgroup
-        launch_raw(ctx, k_rank_lists, dim3(dq), dim3(256), cap * 12, offsets.p, dq, t_raw.p, d2_raw.p, t_idx.p, dist2.p, cap);
+        launch<k_rank_lists, 256>(ctx, dim3(dq), cap * 12, offsets.p, dq, t_raw.p, d2_raw.p, t_idx.p, dist2.p, cap);
         HIP_TRY(hipGetLastError());
         return total;
     }
@@ -341,11 +341,11 @@ uint64_t MatchResult::run_windowed(plade_ctx *ctx, const float *d_qry, uint32_t 
     sort_pairs_u32(ctx, t_raw.p, k32b.p, v32a.p, v32b.p, m, tbits);                  // v32b: entries by target index
     launch_raw(ctx, k_d2_keys_perm, dim3(cdiv(m, 256)), dim3(256), 0, d2_raw.p, v32b.p, m, k64a.p);
     sort_pairs_u64(ctx, k64a.p, k64b.p, v32b.p, v32a.p, m, 64);                       // v32a: by (dist2, target)
-    launch_raw(ctx, k_gather_u32, dim3(cdiv(m, 256)), dim3(256), 0, q_raw.p, v32a.p, m, k32a.p);
+    launch<k_gather_u32, 256>(ctx, dim3(cdiv(m, 256)), 0, q_raw.p, v32a.p, m, k32a.p);
     int qbits = 1;
     while ((1ull << qbits) < dq) ++qbits;
     sort_pairs_u32(ctx, k32a.p, k32b.p, v32a.p, v32b.p, m, qbits);                    // v32b: by (query, dist2, target)
-    launch_raw(ctx, k_gather_final, dim3(cdiv(m, 256)), dim3(256), 0, t_raw.p, d2_raw.p, v32b.p, m, t_idx.p,
+    launch<k_gather_final, 256>(ctx, dim3(cdiv(m, 256)), 0, t_raw.p, d2_raw.p, v32b.p, m, t_idx.p,
                        dist2.p);
     q_idx_sorted = k32b.p;
     HIP_TRY(hipGetLastError());
@@ -376,10 +376,10 @@ uint64_t MatchResult::run(plade_ctx *ctx, const float *d_qry, uint32_t dq, const
     cnt.ensure(ncnt + 1); offs.ensure(ncnt + 1);
     dim3 grid(cdiv(dq, MT_TPB), nch);
     info.ensure(2);
-    launch_raw(ctx, k_match<false>, grid, dim3(MT_TPB), 0, d_qry, dq, d_tgt, dt, sq_rad, nch, chunk, cnt.p,
+    launch<k_match<false>, MT_TPB>(ctx, grid, 0, d_qry, dq, d_tgt, dt, sq_rad, nch, chunk, cnt.p,
                        (const uint32_t *)nullptr, (uint32_t *)nullptr, (double *)nullptr, (uint32_t *)nullptr, info.p);
     exclusive_scan_u32(ctx, cnt.p, offs.p, ncnt + 1);
-    launch_raw(ctx, k_query_offsets, dim3(cdiv(dq + 1, 256)), dim3(256), 0, offs.p, dq, nch, offsets.p, info.p);
+    launch<k_query_offsets, 256>(ctx, dim3(cdiv(dq + 1, 256)), 0, offs.p, dq, nch, offsets.p, info.p);
     uint32_t h_info[2] = {0, 0};
     ctx->d2h(h_info, info.p, 8);
     ctx->sync();
@@ -388,26 +388,26 @@ uint64_t MatchResult::run(plade_ctx *ctx, const float *d_qry, uint32_t dq, const
     if (total == 0) return 0;
     const uint32_t m = tot32;
     t_raw.ensure(m); d2_raw.ensure(m); q_raw.ensure(m);
-    launch_raw(ctx, k_match<true>, grid, dim3(MT_TPB), 0, d_qry, dq, d_tgt, dt, sq_rad, nch, chunk, cnt.p, offs.p,
+    launch<k_match<true>, MT_TPB>(ctx, grid, 0, d_qry, dq, d_tgt, dt, sq_rad, nch, chunk, cnt.p, offs.p,
                        t_raw.p, d2_raw.p, q_raw.p, (uint32_t *)nullptr);
     t_idx.ensure(m); dist2.ensure(m);
     q_idx_sorted = q_raw.p;   // lists are contiguous per query
     if (max_list <= RANK_MAX_LIST) {
         const uint32_t cap = std::max(64u, (max_list + 63u) & ~63u);   // entries of LDS per workgroup
-        launch_raw(ctx, k_rank_lists, dim3(dq), dim3(256), cap * 12, offsets.p, dq, t_raw.p, d2_raw.p, t_idx.p,
+        launch<k_rank_lists, 256>(ctx, dim3(dq), cap * 12, offsets.p, dq, t_raw.p, d2_raw.p, t_idx.p,
                            dist2.p, cap);
         HIP_TRY(hipGetLastError());
         return total;
     }
     // very long lists: a stable sort by dist2 followed by a stable sort by query
     k64a.ensure(m); k64b.ensure(m); v32a.ensure(m); v32b.ensure(m); k32a.ensure(m); k32b.ensure(m);
-    launch_raw(ctx, k_d2_keys, dim3(cdiv(m, 256)), dim3(256), 0, d2_raw.p, m, k64a.p, v32a.p);
+    launch<k_d2_keys, 256>(ctx, dim3(cdiv(m, 256)), 0, d2_raw.p, m, k64a.p, v32a.p);
     sort_pairs_u64(ctx, k64a.p, k64b.p, v32a.p, v32b.p, m, 64);
-    launch_raw(ctx, k_gather_u32, dim3(cdiv(m, 256)), dim3(256), 0, q_raw.p, v32b.p, m, k32a.p);
+    launch<k_gather_u32, 256>(ctx, dim3(cdiv(m, 256)), 0, q_raw.p, v32b.p, m, k32a.p);
     int qbits = 1;
     while ((1ull << qbits) < dq) ++qbits;
     sort_pairs_u32(ctx, k32a.p, k32b.p, v32b.p, v32a.p, m, qbits);
-    launch_raw(ctx, k_gather_final, dim3(cdiv(m, 256)), dim3(256), 0, t_raw.p, d2_raw.p, v32a.p, m,
+    launch<k_gather_final, 256>(ctx, dim3(cdiv(m, 256)), 0, t_raw.p, d2_raw.p, v32a.p, m,
                        t_idx.p, dist2.p);
     q_idx_sorted = k32b.p;
     HIP_TRY(hipGetLastError());

@@ -24,11 +24,11 @@ struct GridParams {
     int dx, dy, dz;
 };
 
-__global__ __launch_bounds__(256) void k_minmax3(const float *__restrict__ xyz, uint32_t n, uint32_t stride, float *__restrict__ out6) {
+__device__ void k_minmax3(const VB &vb, const float *__restrict__ xyz, uint32_t n, uint32_t stride, float *__restrict__ out6) {
     // out6 initialised to (+inf x3, -inf x3) as ordered ints by the host
     __shared__ float s_lds[6][8];
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    for (uint32_t i = vb.bx * blockDim.x + threadIdx.x; i < n; i += vb.gx * blockDim.x)
         for (int k = 0; k < 3; ++k) {
             float v = xyz[(size_t)i * stride + k];
             mn[k] = fminf(mn[k], v);
@@ -44,9 +44,9 @@ __device__ __forceinline__ uint32_t block_of(int cx, int cy, int cz, int dx, int
 }
 __device__ __forceinline__ uint32_t local_of(int cx, int cy, int cz) { return (uint32_t)((cx & 3) | ((cy & 3) << 2) | ((cz & 3) << 4)); }
 
-__global__ void k_cell_ids(const float *__restrict__ xyz, uint32_t n, uint32_t stride, GridParams g, int blocked,
+__device__ void k_cell_ids(const VB &vb, const float *__restrict__ xyz, uint32_t n, uint32_t stride, GridParams g, int blocked,
                            uint32_t *__restrict__ keys, uint32_t *__restrict__ vals) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t i = vb.bx * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float x = xyz[(size_t)i * stride], y = xyz[(size_t)i * stride + 1], z = xyz[(size_t)i * stride + 2];
     int cx = min(max((int)floorf((x - g.mnx) * g.inv), 0), g.dx - 1);
@@ -56,10 +56,10 @@ __global__ void k_cell_ids(const float *__restrict__ xyz, uint32_t n, uint32_t s
     vals[i] = i;
 }
 
-__global__ void k_gather_cells(const float *__restrict__ xyz, uint32_t stride, const uint32_t *__restrict__ keys,
+__device__ void k_gather_cells(const VB &vb, const float *__restrict__ xyz, uint32_t stride, const uint32_t *__restrict__ keys,
                                const uint32_t *__restrict__ vals, uint32_t n, float4 *__restrict__ sorted,
                                uint32_t *__restrict__ cell_start, uint32_t *__restrict__ cell_end) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t i = vb.bx * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint32_t v = vals[i];
     sorted[i] = make_float4(xyz[(size_t)v * stride], xyz[(size_t)v * stride + 1], xyz[(size_t)v * stride + 2],
@@ -70,28 +70,28 @@ __global__ void k_gather_cells(const float *__restrict__ xyz, uint32_t stride, c
 }
 
 // compact occupancy index over the sorted cell keys
-__global__ void k_occ_bits(const uint32_t *__restrict__ keys, uint32_t n, unsigned long long *__restrict__ bits) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ void k_occ_bits(const VB &vb, const uint32_t *__restrict__ keys, uint32_t n, unsigned long long *__restrict__ bits) {
+    const uint32_t i = vb.bx * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t k = keys[i];
     if (i == 0 || keys[i - 1] != k) atomicOr(&bits[k >> 6], 1ull << (k & 63));
 }
 // ... and the BLOCK mask: one bit per 4 x 4 x 4-cell block, set when the block holds any occupied cell (bit b of blk[b >> 6]; the
 // 64 lanes of a wavefront look at 64 consecutive blocks, one ballot is one word).  The verification kernel keeps it in LDS.
-__global__ void k_occ_pop(const unsigned long long *__restrict__ bits, uint32_t nw, uint32_t *__restrict__ pop,
+__device__ void k_occ_pop(const VB &vb, const unsigned long long *__restrict__ bits, uint32_t nw, uint32_t *__restrict__ pop,
                           unsigned long long *__restrict__ blk) {
-    const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t w = vb.bx * blockDim.x + threadIdx.x;
     const unsigned long long b = w < nw ? bits[w] : 0ull;
     if (w < nw) pop[w] = (uint32_t)__popcll(b);
     if (w == nw) pop[w] = 0;
     const unsigned long long any = __ballot(b != 0ull);
     if ((threadIdx.x & 63) == 0 && w <= nw) blk[w >> 6] = any;
 }
-__global__ void k_occ_start(const float *__restrict__ xyz, uint32_t stride, const uint32_t *__restrict__ keys,
+__device__ void k_occ_start(const VB &vb, const float *__restrict__ xyz, uint32_t stride, const uint32_t *__restrict__ keys,
                             const uint32_t *__restrict__ vals, uint32_t n, const unsigned long long *__restrict__ bits,
                             const uint32_t *__restrict__ rank, uint32_t nw, float4 *__restrict__ sorted,
                             uint32_t *__restrict__ occ_start, float4 *__restrict__ cell_first) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = vb.bx * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t v = vals[i];
     const float4 pt = make_float4(xyz[(size_t)v * stride], xyz[(size_t)v * stride + 1], xyz[(size_t)v * stride + 2], __uint_as_float(v));
@@ -127,7 +127,7 @@ void TargetGrid::build(plade_ctx *ctx, const float *d_xyz, uint32_t n_pts, uint3
     }
     bbox.ensure(6);
     ctx->h2d(bbox.p, iinit, 24);
-    launch_raw(ctx, k_minmax3, dim3(std::min(cdiv(n, 256), 1024u)), dim3(256), 0, d_xyz, n, stride,
+    launch<k_minmax3, 256>(ctx, dim3(std::min(cdiv(n, 256), 1024u)), 0, d_xyz, n, stride,
                        bbox.p);
     int ih[6];
     ctx->d2h(ih, bbox.p, 24);
@@ -155,7 +155,7 @@ void TargetGrid::build(plade_ctx *ctx, const float *d_xyz, uint32_t n_pts, uint3
     keys.ensure(n); keys2.ensure(n); vals.ensure(n); vals2.ensure(n);
     sorted.ensure(n);
     GridParams g{gp.mnx, gp.mny, gp.mnz, gp.inv, gp.dx, gp.dy, gp.dz};
-    launch_raw(ctx, k_cell_ids, dim3(cdiv(n, 256)), dim3(256), 0, d_xyz, n, stride, g, compact ? 1 : 0, keys.p,
+    launch<k_cell_ids, 256>(ctx, dim3(cdiv(n, 256)), 0, d_xyz, n, stride, g, compact ? 1 : 0, keys.p,
                        vals.p);
     int bits = 1;
     while (((size_t)1 << bits) < ncells) ++bits;
@@ -167,10 +167,10 @@ void TargetGrid::build(plade_ctx *ctx, const float *d_xyz, uint32_t n_pts, uint3
         cell_first.ensure((size_t)n + 2);
         // (a multiple of 64 bytes: the runtime splits any other size into an aligned fill and a second command for the tail)
         ctx->fill_async(occ_bits.p, 0, (((size_t)nw + 1 + 7) & ~(size_t)7) * 8);
-        launch_raw(ctx, k_occ_bits, dim3(cdiv(n, 256)), dim3(256), 0, keys2.p, n, occ_bits.p);
-        launch_raw(ctx, k_occ_pop, dim3(cdiv(nw + 1, 256)), dim3(256), 0, occ_bits.p, nw, occ_pop.p, occ_blk.p);
+        launch<k_occ_bits, 256>(ctx, dim3(cdiv(n, 256)), 0, keys2.p, n, occ_bits.p);
+        launch<k_occ_pop, 256>(ctx, dim3(cdiv(nw + 1, 256)), 0, occ_bits.p, nw, occ_pop.p, occ_blk.p);
         exclusive_scan_u32(ctx, occ_pop.p, occ_rank.p, (size_t)nw + 1);
-        launch_raw(ctx, k_occ_start, dim3(cdiv(n, 256)), dim3(256), 0, d_xyz, stride, keys2.p, vals2.p, n,
+        launch<k_occ_start, 256>(ctx, dim3(cdiv(n, 256)), 0, d_xyz, stride, keys2.p, vals2.p, n,
                            occ_bits.p, occ_rank.p, nw, sorted.p, occ_start.p, cell_first.p);
         HIP_TRY(hipGetLastError());
         return;
@@ -178,7 +178,7 @@ void TargetGrid::build(plade_ctx *ctx, const float *d_xyz, uint32_t n_pts, uint3
     cell_start.ensure(ncells); cell_end.ensure(ncells);
     ctx->fill_async(cell_start.p, 0, ncells * 4);
     ctx->fill_async(cell_end.p, 0, ncells * 4);
-    launch_raw(ctx, k_gather_cells, dim3(cdiv(n, 256)), dim3(256), 0, d_xyz, stride, keys2.p, vals2.p, n,
+    launch<k_gather_cells, 256>(ctx, dim3(cdiv(n, 256)), 0, d_xyz, stride, keys2.p, vals2.p, n,
                        sorted.p, cell_start.p, cell_end.p);
     HIP_TRY(hipGetLastError());
 }
@@ -196,7 +196,7 @@ constexpr uint32_t OV_MASK_MAX = 48u << 10;   // bytes of LDS the block mask may
 // global load; only the words of non-empty blocks are fetched.
 // (five wavefronts per SIMD: 96 registers; the probe is a chain of three load rounds, latency hidden by occupancy -- 4 waves / 100
 //  registers: 186 us at the bench's shape, 0.62 s at the stress shape; 5: 178 us, 0.575 s; 6 and 8 spill and are slower)
-__global__ __launch_bounds__(OV_TPB, 5) void k_overlap(const float *__restrict__ sx, const float *__restrict__ sy,
+__device__ void k_overlap(const VB &vb, const float *__restrict__ sx, const float *__restrict__ sy,
                                                     const float *__restrict__ sz, uint32_t n_s,
                                                     const float4 *__restrict__ tgt,
                                                     const unsigned long long *__restrict__ occ_bits,
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(OV_TPB, 5) void k_overlap(const float *__restrict__
     const int lane = threadIdx.x & 63;
     const uint32_t ntiles = (n_s + OV_TPB - 1) / OV_TPB, nchunks = (K + ch - 1) / ch;
     const uint64_t nitems = (uint64_t)ntiles * nchunks;
-    const uint64_t it0 = (uint64_t)blockIdx.x * items_per_wg, it1 = min(nitems, it0 + items_per_wg);
+    const uint64_t it0 = (uint64_t)vb.bx * items_per_wg, it1 = min(nitems, it0 + items_per_wg);
     uint32_t cur = 0xffffffffu, k0 = 0, kc = 0;
     for (uint64_t item = it0; item < it1; ++item) {
         const uint32_t chunk = (uint32_t)(item / ntiles), tile = (uint32_t)(item % ntiles);
@@ -329,23 +329,23 @@ __global__ __launch_bounds__(OV_TPB, 5) void k_overlap(const float *__restrict__
 }
 
 // source points into a spatially blocked order: key = blocked cell id in the source's own frame
-__global__ void k_init_minmax6(int *__restrict__ out6) {   // (+inf x3, -inf x3) as ordered ints
+__device__ void k_init_minmax6(const VB &, int *__restrict__ out6) {   // (+inf x3, -inf x3) as ordered ints
     if (threadIdx.x < 3) out6[threadIdx.x] = ordered_int(INFINITY);
     else if (threadIdx.x < 6) out6[threadIdx.x] = ordered_int(-INFINITY);
 }
-__global__ void k_src_minmax(const float *__restrict__ x, const float *__restrict__ y, const float *__restrict__ z, uint32_t n,
+__device__ void k_src_minmax(const VB &vb, const float *__restrict__ x, const float *__restrict__ y, const float *__restrict__ z, uint32_t n,
                              int *__restrict__ out6) {
     __shared__ float s_lds[6][8];
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    for (uint32_t i = vb.bx * blockDim.x + threadIdx.x; i < n; i += vb.gx * blockDim.x) {
         const float v[3] = {x[i], y[i], z[i]};
         for (int k = 0; k < 3; ++k) { mn[k] = fminf(mn[k], v[k]); mx[k] = fmaxf(mx[k], v[k]); }
     }
     block_minmax_commit<3>(mn, mx, out6, s_lds);
 }
-__global__ void k_src_keys(const float *__restrict__ x, const float *__restrict__ y, const float *__restrict__ z, uint32_t n,
+__device__ void k_src_keys(const VB &vb, const float *__restrict__ x, const float *__restrict__ y, const float *__restrict__ z, uint32_t n,
                            const int *__restrict__ bbox, float inv, uint32_t *__restrict__ keys, uint32_t *__restrict__ vals) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = vb.bx * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float mnx = ordered_float(bbox[0]), mny = ordered_float(bbox[1]), mnz = ordered_float(bbox[2]);
     // 10 bits per axis (coarsened if the extent needs more): 8-bit block coordinates + 2 local bits
@@ -360,22 +360,22 @@ __global__ void k_src_keys(const float *__restrict__ x, const float *__restrict_
     keys[i] = (uint32_t)(cx >> 2) | ((uint32_t)(cy >> 2) << 8) | ((uint32_t)(cz >> 2) << 16);
     vals[i] = i;
 }
-__global__ void k_src_gather(const float *__restrict__ x, const float *__restrict__ y, const float *__restrict__ z, uint32_t n,
+__device__ void k_src_gather(const VB &vb, const float *__restrict__ x, const float *__restrict__ y, const float *__restrict__ z, uint32_t n,
                              const uint32_t *__restrict__ perm, float *__restrict__ out) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = vb.bx * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t p = perm[i];
     out[i] = x[p]; out[(size_t)n + i] = y[p]; out[2 * (size_t)n + i] = z[p];
 }
 
 // does the coarse sphere of candidate k contain any target point?  (util.h:621-625)
-__global__ __launch_bounds__(256) void k_sphere_any(const float4 *__restrict__ tgt, uint32_t n_t,
+__device__ void k_sphere_any(const VB &vb, const float4 *__restrict__ tgt, uint32_t n_t,
                                                     const float *__restrict__ centers, uint32_t K, float R2,
                                                     uint32_t *__restrict__ any) {
     extern __shared__ float s_cc[];
     for (uint32_t i = threadIdx.x; i < K * 3; i += blockDim.x) s_cc[i] = centers[i];
     __syncthreads();
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = vb.bx * blockDim.x + threadIdx.x;
     const bool live = i < n_t;
     const float4 t4 = live ? tgt[i] : make_float4(0, 0, 0, 0);
     const f3 t(t4.x, t4.y, t4.z);
@@ -392,15 +392,15 @@ void overlap_sort_source(plade_ctx *ctx, OverlapWork &work, const float *d_sx, c
     if (!n_s) return;
     // any order gives the same counts; this one makes a wavefront's probes local
     work.bbox.ensure(8);
-    launch_raw(ctx, k_init_minmax6, dim3(1), dim3(64), 0, work.bbox.p);
-    launch_raw(ctx, k_src_minmax, dim3(std::min(cdiv(n_s, 256), 512u)), dim3(256), 0, d_sx, d_sy, d_sz, n_s,
+    launch<k_init_minmax6, 64>(ctx, dim3(1), 0, work.bbox.p);
+    launch<k_src_minmax, 256>(ctx, dim3(std::min(cdiv(n_s, 256), 512u)), 0, d_sx, d_sy, d_sz, n_s,
                        work.bbox.p);
     work.keys.ensure(n_s); work.keys2.ensure(n_s); work.vals.ensure(n_s); work.vals2.ensure(n_s);
     work.sorted.ensure(3 * (size_t)n_s + 4);
-    launch_raw(ctx, k_src_keys, dim3(cdiv(n_s, 256)), dim3(256), 0, d_sx, d_sy, d_sz, n_s, work.bbox.p, 1.f / cell,
+    launch<k_src_keys, 256>(ctx, dim3(cdiv(n_s, 256)), 0, d_sx, d_sy, d_sz, n_s, work.bbox.p, 1.f / cell,
                        work.keys.p, work.vals.p);
     sort_pairs_u32(ctx, work.keys.p, work.keys2.p, work.vals.p, work.vals2.p, n_s, 24);
-    launch_raw(ctx, k_src_gather, dim3(cdiv(n_s, 256)), dim3(256), 0, d_sx, d_sy, d_sz, n_s, work.vals2.p,
+    launch<k_src_gather, 256>(ctx, dim3(cdiv(n_s, 256)), 0, d_sx, d_sy, d_sz, n_s, work.vals2.p,
                        work.sorted.p);
     HIP_TRY(hipGetLastError());
 }
@@ -420,7 +420,7 @@ void overlap_counts(plade_ctx *ctx, OverlapWork &work, const float *d_sx, const 
     // sphere test in chunks of <= 2048 candidates (LDS)
     for (uint32_t k0 = 0; k0 < K; k0 += 2048) {
         uint32_t kc = std::min(2048u, K - k0);
-        launch_raw(ctx, k_sphere_any, dim3(cdiv(grid.n, 256)), dim3(256), kc * 12, grid.sorted.p, grid.n,
+        launch<k_sphere_any, 256>(ctx, dim3(cdiv(grid.n, 256)), kc * 12, grid.sorted.p, grid.n,
                            d_centers + (size_t)k0 * 3, kc, R2, d_any + k0);
     }
     if (n_s) {
@@ -435,7 +435,7 @@ void overlap_counts(plade_ctx *ctx, OverlapWork &work, const float *d_sx, const 
         // algorithmic bytes: K * n_s * 12 B source stream + n_t * 12 B target
         ctx->ev_begin("overlap", (double)K * n_s * 12.0 + (double)grid.n * 12.0);
         PLADE_REQUIRE(grid.compact, PLADE_EINVAL, "overlap: the target grid needs the compact occupancy index");
-        launch_raw(ctx, k_overlap, dim3(cdiv(nitems, per)), dim3(OV_TPB), mask_words * 4, d_sx, d_sy, d_sz, n_s, grid.sorted.p,
+        launch<k_overlap, OV_TPB, 5>(ctx, dim3(cdiv(nitems, per)), mask_words * 4, d_sx, d_sy, d_sz, n_s, grid.sorted.p,
                            grid.occ_bits.p, grid.occ_rank.p, grid.occ_start.p, grid.cell_first.p, reinterpret_cast<const uint32_t *>(grid.occ_blk.p), mask_words, g,
                            d_T, d_centers, K, R2, r2, d_counts, ch, per);
         ctx->ev_end();

@@ -62,10 +62,10 @@ __device__ __forceinline__ int edge_hits(f3 lineVec, f3 linePoint, const f3 *c, 
 // SVD = 1 (plade_params.closest_point_mode = 1): the eight line / rectangle-edge meetings of a triple are the reference's
 // 6 x 5 float solves (k_svd.h), one lane's matrices in LDS (260 B per lane, hence 128 lanes per workgroup)
 template <int SVD, int TPB>
-__global__ __launch_bounds__(TPB) void k_pen_setup(PenTables tb, float len_th, float ang_th, PenItem *__restrict__ items,
+__device__ void k_pen_setup(const VB &vb, PenTables tb, float len_th, float ang_th, PenItem *__restrict__ items,
                                                    uint32_t *__restrict__ n_items, uint32_t *__restrict__ pair_count) {
     __shared__ float lds[SVD ? LaneSolver<6, 5, TPB>::WORDS_PER_LANE * TPB : 1];
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t idx = (size_t)vb.bx * blockDim.x + threadIdx.x;
     const size_t total = (size_t)tb.K * tb.ps * tb.pt;
     if (idx >= total) return;
     const uint32_t j1 = (uint32_t)(idx % tb.pt), i1 = (uint32_t)((idx / tb.pt) % tb.ps), k = (uint32_t)(idx / ((size_t)tb.pt * tb.ps));
@@ -143,10 +143,10 @@ __device__ __forceinline__ void pen_uv(const PenFrame &f, f3 p, float &u, float 
     v = dx * f.ev[0] + dy * f.ev[1] + dz * f.ev[2];
 }
 
-__global__ void k_pen_cell_keys(const float *__restrict__ xyz, uint32_t n, const uint32_t *__restrict__ off, uint32_t P,
+__device__ void k_pen_cell_keys(const VB &vb, const float *__restrict__ xyz, uint32_t n, const uint32_t *__restrict__ off, uint32_t P,
                                 const PenFrame *__restrict__ frames, float inv_cell, uint32_t *__restrict__ keys,
                                 uint32_t *__restrict__ vals) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = vb.bx * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint32_t lo = 0, hi = P;   // plane of point i: last g with off[g] <= i
     while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (off[mid] <= i) lo = mid; else hi = mid; }
@@ -159,10 +159,10 @@ __global__ void k_pen_cell_keys(const float *__restrict__ xyz, uint32_t n, const
     vals[i] = i;
 }
 
-__global__ void k_pen_cell_fill(const float *__restrict__ xyz, const uint32_t *__restrict__ skeys,
+__device__ void k_pen_cell_fill(const VB &vb, const float *__restrict__ xyz, const uint32_t *__restrict__ skeys,
                                 const uint32_t *__restrict__ svals, uint32_t n, uint32_t n_cells,
                                 float4 *__restrict__ pts, uint32_t *__restrict__ cell_start) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = vb.bx * blockDim.x + threadIdx.x;
     if (i < n) {
         const uint32_t p = svals[i];
         pts[i] = make_float4(xyz[3 * (size_t)p], xyz[3 * (size_t)p + 1], xyz[3 * (size_t)p + 2], 0.f);
@@ -202,12 +202,12 @@ void build_pen_grid(plade_ctx *ctx, PlaneCloudsDev &pc, const PlaneGeomHost &geo
     pc.cell_start.ensure((size_t)total + 2);
     pc.ckeys.ensure((size_t)n + 1); pc.ckeys2.ensure((size_t)n + 1); pc.cvals.ensure((size_t)n + 1); pc.cvals2.ensure((size_t)n + 1);
     if (n)
-        launch_raw(ctx, k_pen_cell_keys, dim3(cdiv(n, 256)), dim3(256), 0, pc.xyz.p, n, pc.d_off.p, P, pc.frames.p,
+        launch<k_pen_cell_keys, 256>(ctx, dim3(cdiv(n, 256)), 0, pc.xyz.p, n, pc.d_off.p, P, pc.frames.p,
                            1.f / cell, pc.ckeys.p, pc.cvals.p);
     int bits = 1;
     while ((1ull << bits) < total) ++bits;
     sort_pairs_u32(ctx, pc.ckeys.p, pc.ckeys2.p, pc.cvals.p, pc.cvals2.p, n, bits);
-    launch_raw(ctx, k_pen_cell_fill, dim3(cdiv(std::max(n, total + 1), 256)), dim3(256), 0, pc.xyz.p, pc.ckeys2.p,
+    launch<k_pen_cell_fill, 256>(ctx, dim3(cdiv(std::max(n, total + 1), 256)), 0, pc.xyz.p, pc.ckeys2.p,
                        pc.cvals2.p, n, total, pc.cell_pts.p, pc.cell_start.p);
     if (!staged) ctx->sync();   // `fr` must outlive the copy
 }
@@ -305,23 +305,23 @@ struct PenSide {
 // (util.cpp:1383, fp32 accumulation), PEN_MAXS + 1 entries computed once on the host -- it does not depend
 // on the item.  All distance tests are the reference's arithmetic on the reference's operands (source
 // points moved by the candidate with pcl_xform); the grids only select which points are looked at.
-__global__ __launch_bounds__(PEN_TPB) __attribute__((amdgpu_waves_per_eu(6))) void k_pen_walk(const PenItem *__restrict__ items, const uint32_t *__restrict__ pair_count,
+__device__ void k_pen_walk(const VB &vb, const PenItem *__restrict__ items, const uint32_t *__restrict__ pair_count,
                                                       const uint32_t *__restrict__ pair_order, PenTables tb,
                                                       const float *__restrict__ step_dist, PenSide S, PenSide T_, float cell,
                                                       float search_radius, int min_points, float min_distance,
                                                       uint32_t *__restrict__ cand_flags, uint32_t *__restrict__ overflow) {
     __shared__ uint32_t s_cnt_all[PEN_G][PEN_MAXS];
     __shared__ float s_dist[PEN_MAXS + 1];
-    const uint32_t pair = pair_order[blockIdx.x];   // heaviest plane pairs first (longest-processing-time order)
+    const uint32_t pair = pair_order[vb.bx];   // heaviest plane pairs first (longest-processing-time order)
     const uint32_t cnt = pair_count[pair];
-    if (blockIdx.y * PEN_G >= cnt) return;          // whole workgroup idle (uniform)
+    if (vb.by * PEN_G >= cnt) return;          // whole workgroup idle (uniform)
     for (int i = threadIdx.x; i <= PEN_MAXS; i += blockDim.x) s_dist[i] = step_dist[i];   // the step table in LDS
     __syncthreads();
     // the wave index as a scalar: everything derived from it (the item, its candidate, the two plane frames) is then loaded
     // with scalar loads into SGPRs instead of being replicated over the lanes' VGPRs: 142 -> 99 VGPRs, and the occupancy
     // hint above brings the kernel to 80 (6 waves per SIMD instead of 3; the LDS step counters allow 7)
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
-    const uint32_t slot = blockIdx.y * PEN_G + wave;
+    const uint32_t slot = vb.by * PEN_G + wave;
     if (slot >= cnt) return;
     uint32_t *s_cnt = s_cnt_all[wave];
     const PenItem it = items[(size_t)pair * tb.K + slot];
@@ -478,10 +478,10 @@ void penetration_filter(plade_ctx *ctx, const float *cand_rt_host, uint32_t K, c
     const float *d_steps = d + n_tab;
     const uint32_t *d_order = reinterpret_cast<const uint32_t *>(d + n_tab + PEN_MAXS + 1);
     if (ctx->params.closest_point_mode == 1)
-        launch_raw(ctx, (k_pen_setup<1, 128>), dim3(cdiv(total, 128)), dim3(128), 0, tb, length_threshold,
+        launch<k_pen_setup<1, 128>, 128>(ctx, dim3(cdiv(total, 128)), 0, tb, length_threshold,
                            angle_threshold, d_items, d_n, d_pair);
     else
-        launch_raw(ctx, (k_pen_setup<0, 256>), dim3(cdiv(total, 256)), dim3(256), 0, tb, length_threshold,
+        launch<k_pen_setup<0, 256>, 256>(ctx, dim3(cdiv(total, 256)), 0, tb, length_threshold,
                            angle_threshold, d_items, d_n, d_pair);
     // in-plane grids of both sides (cell = 2 r)
     const float cell = pen_grid_cell(length_threshold);
@@ -490,7 +490,7 @@ void penetration_filter(plade_ctx *ctx, const float *cand_rt_host, uint32_t K, c
     const PenSide sS{src_pts.frames.p, src_pts.cell_pts.p, src_pts.cell_start.p}, sT{tgt_pts.frames.p, tgt_pts.cell_pts.p, tgt_pts.cell_start.p};
     // a plane pair holds at most K items: grid.y covers the worst case, empty groups exit at once
     ctx->ev_begin("pen_walk", 0.0);
-    launch_raw(ctx, k_pen_walk, dim3(n_pairs, cdiv(K, PEN_G)), dim3(PEN_TPB), 0, d_items, d_pair, d_order, tb, d_steps,
+    launch<k_pen_walk, PEN_TPB, 6>(ctx, dim3(n_pairs, cdiv(K, PEN_G)), 0, d_items, d_pair, d_order, tb, d_steps,
                        sS, sT, cell, search_radius, 10, min_distance, d_flags, d_over);
     ctx->ev_end();
     std::vector<uint32_t> out(n_ctr);   // items, overflow, K candidate flags, per-pair item counts

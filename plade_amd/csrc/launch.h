@@ -43,10 +43,12 @@ template <> inline Pack<> make_pack<>() { return Pack<>{}; }
 template <class H, class... T> inline Pack<H, T...> make_pack_impl(H h, T... t) { Pack<H, T...> p; p.head = h; p.tail = make_pack<T...>(t...); return p; }
 template <class... A> inline Pack<A...> make_pack(A... a) { return make_pack_impl<A...>(a...); }
 
+// A kernel may take a larger struct as `const T &`: it is stored by value in the pack and the reference is bound to it THERE
+// (in the kernel-argument segment), so indexing it with a run-time index stays a scalar load instead of a copy in scratch.
 template <class F> struct BodyTraits;
 template <class... A> struct BodyTraits<void (*)(const VB &, A...)> {
-    using pack = Pack<A...>;
-    static pack make(A... a) { return make_pack<A...>(a...); }
+    using pack = Pack<std::decay_t<A>...>;
+    static pack make(std::decay_t<A>... a) { return make_pack<std::decay_t<A>...>(a...); }
 };
 
 struct BatchHdr { uint32_t n, start[BATCH_MAX + 1], gx[BATCH_MAX], gy[BATCH_MAX]; };
@@ -54,13 +56,14 @@ template <class P, int N> struct BatchPacks { P p[N]; };
 
 #ifdef __HIPCC__
 template <auto Body, class... Done>
-__device__ __forceinline__ void call_body(const VB &vb, const Pack<> &, Done... d) { Body(vb, d...); }
+__device__ __forceinline__ void call_body(const VB &vb, const Pack<> &, const Done &...d) { Body(vb, d...); }
 template <auto Body, class H, class... T, class... Done>
-__device__ __forceinline__ void call_body(const VB &vb, const Pack<H, T...> &p, Done... d) { call_body<Body>(vb, p.tail, d..., p.head); }
+__device__ __forceinline__ void call_body(const VB &vb, const Pack<H, T...> &p, const Done &...d) { call_body<Body>(vb, p.tail, d..., p.head); }
 
 // one launch for up to N pairs: workgroup blockIdx.x belongs to the pair e with start[e] <= blockIdx.x < start[e + 1]
-template <auto Body, int TPB, int N, class P>
-__global__ __launch_bounds__(TPB) void k_batch(const BatchHdr h, const BatchPacks<P, N> packs) {
+// (MINW: the second argument of __launch_bounds__, wavefronts per SIMD the register allocation must leave room for)
+template <auto Body, int TPB, int N, class P, int MINW = 1>
+__global__ __launch_bounds__(TPB, MINW) void k_batch(const BatchHdr h, const BatchPacks<P, N> packs) {
     uint32_t e = 0;
     if (N > 1) {
 #pragma unroll
@@ -113,7 +116,7 @@ hipStream_t ctx_stream(plade_ctx *c);
 Combiner *ctx_combiner(plade_ctx *c);
 
 #ifdef __HIPCC__
-template <auto Body, int TPB, class P>
+template <auto Body, int TPB, class P, int MINW>
 void launch_many_impl(hipStream_t st, int n, QEntry *const *es) {
     constexpr int N = sizeof(P) <= PACK_MAX ? BATCH_MAX : 1;
     for (int b = 0; b < n; b += N) {
@@ -133,12 +136,12 @@ void launch_many_impl(hipStream_t st, int n, QEntry *const *es) {
         }
         for (int q = k; q < BATCH_MAX; ++q) h.start[q + 1] = h.start[k];
         if (h.start[k] == 0) continue;
-        hipLaunchKernelGGL((k_batch<Body, TPB, N, P>), dim3(h.start[k]), dim3(TPB), smem, st, h, packs);
+        hipLaunchKernelGGL((k_batch<Body, TPB, N, P, MINW>), dim3(h.start[k]), dim3(TPB), smem, st, h, packs);
     }
 }
 
 // launch<k_foo, TPB>(ctx, grid, dynamic LDS bytes, arguments of k_foo behind its VB)
-template <auto Body, int TPB, class... Args>
+template <auto Body, int TPB, int MINW = 1, class... Args>
 void launch(plade_ctx *ctx, dim3 grid, size_t smem, Args... args) {
     using Tr = BodyTraits<decltype(Body)>;
     using P = typename Tr::pack;
@@ -155,7 +158,7 @@ void launch(plade_ctx *ctx, dim3 grid, size_t smem, Args... args) {
                 h.n = 1; h.gx[0] = grid.x; h.gy[0] = grid.y;
                 for (int q = 0; q < BATCH_MAX; ++q) h.start[q + 1] = grid.x * grid.y;
                 BatchPacks<P, 1> packs; packs.p[0] = p;
-                hipLaunchKernelGGL((k_batch<Body, TPB, 1, P>), dim3(grid.x * grid.y), dim3(TPB), smem, st, h, packs);
+                hipLaunchKernelGGL((k_batch<Body, TPB, 1, P, MINW>), dim3(grid.x * grid.y), dim3(TPB), smem, st, h, packs);
             };
             return;
         }
@@ -163,12 +166,12 @@ void launch(plade_ctx *ctx, dim3 grid, size_t smem, Args... args) {
         h.n = 1; h.gx[0] = grid.x; h.gy[0] = grid.y;
         for (int q = 0; q < BATCH_MAX; ++q) h.start[q + 1] = grid.x * grid.y;
         BatchPacks<P, 1> packs; packs.p[0] = p;
-        hipLaunchKernelGGL((k_batch<Body, TPB, 1, P>), dim3(grid.x * grid.y), dim3(TPB), smem, ctx_stream(ctx), h, packs);
+        hipLaunchKernelGGL((k_batch<Body, TPB, 1, P, MINW>), dim3(grid.x * grid.y), dim3(TPB), smem, ctx_stream(ctx), h, packs);
         return;
     }
     QEntry &e = cb->push(ctx);
     e.kind = QEntry::KERNEL;
-    e.launch_many = &launch_many_impl<Body, TPB, P>;
+    e.launch_many = &launch_many_impl<Body, TPB, P, MINW>;
     e.id = reinterpret_cast<const void *>(e.launch_many);     // one per (kernel, workgroup size): entries with the same id merge
     e.gx = grid.x; e.gy = grid.y; e.smem = (uint32_t)smem;
     memcpy(e.pack, static_cast<const void *>(&p), sizeof(P));

@@ -19,9 +19,9 @@ namespace {
 struct LengthIndex { float length; int index; };   // util.h:347-350
 inline bool cmp_greater(const LengthIndex &a, const LengthIndex &b) { return a.length > b.length; }  // util.h:360-365
 
-__global__ void k_gather_rt(const float4 *__restrict__ rt, const uint32_t *__restrict__ ids, uint32_t n,
+__device__ void k_gather_rt(const VB &vb, const float4 *__restrict__ rt, const uint32_t *__restrict__ ids, uint32_t n,
                             float *__restrict__ out /* n x 12 */) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = vb.bx * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t k = ids[i];
     const float4 r0 = rt[4 * (size_t)k], r1 = rt[4 * (size_t)k + 1], r2 = rt[4 * (size_t)k + 2];
@@ -472,7 +472,7 @@ bool run_registration(plade_ctx *ctx, RegistrationWork &W, const CloudDev &tgt, 
         std::vector<uint32_t> ids(K);
         for (uint32_t i = 0; i < K; ++i) ids[i] = seeds[cand_cluster[tested[i]]];
         PenGather pg{ids.data(), [&](const uint32_t *d_ids) {
-            launch_raw(ctx, k_gather_rt, dim3(cdiv(K, 64)), dim3(64), 0, W.cand.rt.p, d_ids, K, W.d_rt12.p);
+            launch<k_gather_rt, 64>(ctx, dim3(cdiv(K, 64)), 0, W.cand.rt.p, d_ids, K, W.d_rt12.p);
             ctx->d2h(rt12.data(), W.d_rt12.p, 48 * (size_t)K);   // valid after the wait at the end of the penetration filter
         }};
         penetration_filter(ctx, nullptr, K, C.geom, M.geom, C.pcl, M.pcl, lengthThreshold, angleThreshold, penflags, W.d_rt12.p, &pg);

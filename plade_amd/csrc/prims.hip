@@ -28,9 +28,8 @@ namespace {
 constexpr int SC_T = 256, SC_I = 16, SC_TILE = SC_T * SC_I;
 constexpr uint64_t SC_AGG = 1ull << 32, SC_PREFIX = 2ull << 32, SC_STATUS = 3ull << 32;
 
-__global__ __launch_bounds__(SC_T) void k_scan_u32(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, uint32_t n,
-                                                   uint64_t *__restrict__ state, uint32_t *__restrict__ ticket, uint32_t base,
-                                                   uint32_t gen) {
+__device__ void k_scan_u32(const VB &, const uint32_t *__restrict__ in, uint32_t *__restrict__ out, uint32_t n,
+                           uint64_t *__restrict__ state, uint32_t *__restrict__ ticket, uint32_t base, uint32_t gen) {
     __shared__ uint32_t s_tile, s_w[SC_T / 64], s_excl;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) s_tile = atomicAdd(ticket, 1u) - base;
@@ -122,7 +121,7 @@ void exclusive_scan_u32(plade_ctx *ctx, const uint32_t *in, uint32_t *out, size_
     if (!n) return;
     PLADE_REQUIRE(n < (1ull << 32), PLADE_ELIMIT, "scan: too many items");
     const ScanTicket t = scan_ticket(ctx, n, SC_TILE);
-    launch_raw(ctx, k_scan_u32, dim3(t.tiles), dim3(SC_T), 0, in, out, (uint32_t)n, t.state, t.ticket, t.base, t.gen);
+    launch<k_scan_u32, SC_T>(ctx, dim3(t.tiles), 0, in, out, (uint32_t)n, t.state, t.ticket, t.base, t.gen);
 }
 
 

@@ -73,18 +73,18 @@ __device__ __forceinline__ uint32_t digit_of(K key, int shift) { return (uint32_
 
 // ghist[p][d]: keys of digit d at place p (all-zero on entry)
 template <class K, int DB>
-__global__ __launch_bounds__(RS_THREADS) void k_rs_histogram(const K *__restrict__ keys_all, const RSSegs S, int passes,
-                                                             uint32_t *__restrict__ ghist_all, uint32_t *__restrict__ tile_ctr,
-                                                             uint32_t *__restrict__ look, size_t look_words) {
+__device__ void k_rs_histogram(const VB &vb, const K *__restrict__ keys_all, const RSSegs &S, int passes,
+                               uint32_t *__restrict__ ghist_all, uint32_t *__restrict__ tile_ctr,
+                               uint32_t *__restrict__ look, size_t look_words) {
     constexpr int NB = 1 << DB;
     __shared__ uint32_t s_h[RS_MAXP * NB];
     for (int i = threadIdx.x; i < passes * NB; i += RS_THREADS) s_h[i] = 0;
     // clear what the passes will use
-    for (size_t i = (size_t)blockIdx.x * RS_THREADS + threadIdx.x; i < look_words; i += (size_t)gridDim.x * RS_THREADS) look[i] = 0;
-    if (blockIdx.x == 0 && threadIdx.x < RS_MAXP) tile_ctr[threadIdx.x] = 0;
+    for (size_t i = (size_t)vb.bx * RS_THREADS + threadIdx.x; i < look_words; i += (size_t)vb.gx * RS_THREADS) look[i] = 0;
+    if (vb.bx == 0 && threadIdx.x < RS_MAXP) tile_ctr[threadIdx.x] = 0;
     __syncthreads();
     // RS_HBLOCKS workgroups per segment
-    const uint32_t seg = blockIdx.x / RS_HBLOCKS, hb = blockIdx.x % RS_HBLOCKS;
+    const uint32_t seg = vb.bx / RS_HBLOCKS, hb = vb.bx % RS_HBLOCKS;
     const K *__restrict__ keys = keys_all + S.off[seg];
     uint32_t *__restrict__ ghist = ghist_all + (size_t)seg * RS_GH_SEG;
     const uint32_t n = S.off[seg + 1] - S.off[seg];
@@ -108,11 +108,11 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_histogram(const K *__restrict
 }
 
 template <class K, int DB, int RS_IPT>
-__global__ __launch_bounds__(RS_THREADS) void k_rs_pass(const K *__restrict__ kin_all, K *__restrict__ kout_all,
-                                                        const uint32_t *__restrict__ vin_all, uint32_t *__restrict__ vout_all,
-                                                        const RSSegs S, int pass, const uint32_t *__restrict__ ghist_all,
-                                                        uint32_t *__restrict__ ghist_next, uint32_t zero_words, uint32_t *__restrict__ tile_ctr,
-                                                        uint32_t *__restrict__ look_all, unsigned long long *__restrict__ sup_all, uint32_t st_shift) {
+__device__ void k_rs_pass(const VB &, const K *__restrict__ kin_all, K *__restrict__ kout_all,
+                          const uint32_t *__restrict__ vin_all, uint32_t *__restrict__ vout_all,
+                          const RSSegs &S, int pass, const uint32_t *__restrict__ ghist_all,
+                          uint32_t *__restrict__ ghist_next, uint32_t zero_words, uint32_t *__restrict__ tile_ctr,
+                          uint32_t *__restrict__ look_all, unsigned long long *__restrict__ sup_all, uint32_t st_shift) {
     constexpr int NB = 1 << DB;
     constexpr int RS_TILE = RS_THREADS * RS_IPT;
     static_assert(NB <= RS_THREADS, "one lane per digit");
@@ -306,7 +306,7 @@ void radix_sort_run_ipt(plade_ctx *ctx, const K *ki, K *ko, const uint32_t *vi, 
     ctx->sort_segs[cur] = (uint32_t)nseg;
     ctx->sort_seq += 1;
     ki += seg_off[0]; ko += seg_off[0]; vi += seg_off[0]; vo += seg_off[0];
-    launch_raw(ctx, (k_rs_histogram<K, DB>), dim3(RS_HBLOCKS * nseg), dim3(RS_THREADS), 0, ki, S, passes, gh, t + off_ctr,
+    launch<k_rs_histogram<K, DB>, RS_THREADS>(ctx, dim3(RS_HBLOCKS * nseg), 0, ki, S, passes, gh, t + off_ctr,
                        t + off_look, look_words);
     const K *src_k = ki;
     const uint32_t *src_v = vi;
@@ -315,7 +315,7 @@ void radix_sort_run_ipt(plade_ctx *ctx, const K *ki, K *ko, const uint32_t *vi, 
         K *dst_k = to_out ? ko : tk;
         uint32_t *dst_v = to_out ? vo : tv;
         uint32_t *pass_look = t + off_look + (size_t)p * pass_words;
-        launch_raw(ctx, (k_rs_pass<K, DB, RS_IPT>), dim3(tiles), dim3(RS_THREADS), 0, src_k, dst_k, src_v, dst_v, S, p, gh,
+        launch<k_rs_pass<K, DB, RS_IPT>, RS_THREADS>(ctx, dim3(tiles), 0, src_k, dst_k, src_v, dst_v, S, p, gh,
                            gh_next, zero_words, t + off_ctr, pass_look, reinterpret_cast<unsigned long long *>(pass_look + (size_t)tiles * NB), st_shift);
         src_k = dst_k;
         src_v = dst_v;
