@@ -557,8 +557,11 @@ def main():
             if w == 0 or k < NR:
                 clouds[w].append((ctxs[w].upload(tg), ctxs[w].upload(sr)))
 
+    executed = [0] * (M + 1)      # registrations this process ran, per worker (profiles divide the kernel statistics by their sum)
+
     def step(i, w=0):       # one pair alone on resident clouds (latency figure, default-mode leg)
         ct, cs = clouds[w][i % (NP if w == 0 else NR)]
+        executed[M] += 1
         return ctxs[w].registration_dev(ct, cs)
 
     # Step number i registers pair i % NP; group number j holds the steps j*S .. j*S + S - 1 (consecutive pairs of the batch).
@@ -575,9 +578,11 @@ def main():
     def hgroup(j, w, nxt):
         cur = [(pairs[i % NP][0], pairs[i % NP][1]) for i in members(j)]
         nx = [(pairs[i % NP][0], pairs[i % NP][1]) for i in members(nxt)] if nxt is not None else None
+        executed[w] += len(cur)
         return ctxs[w].registration_pairs(cur, nx)
 
     def rgroup(j, w, nxt):
+        executed[w] += S
         return ctxs[w].registration_pairs_dev([clouds[w][i % NR] for i in members(j)])
 
     def run_pipeline(fn, lead_groups, count_groups):
@@ -929,6 +934,7 @@ def main():
             cli_e2e = {"value": None, "note": f"unavailable: {e}"}
 
     if rank == 0:
+        print(f"[bench] registrations executed by rank 0: {sum(executed)}", file=sys.stderr)
         total = world * n_timed
         line = {
             "metric": "scan-pair registrations/sec, 1M-pt synthetic pairs",

@@ -147,6 +147,7 @@ void Combiner::flush_locked(std::unique_lock<std::mutex> &lk) {
             for (const plade_ctx::PendingRead &r : c->pending_reads) reads.push_back(R{r.src, c->read_arena_dev + r.off, r.bytes});
         }
         const bool sleepy = lead->params.host_wait != 0;
+        const bool crowd = true;      // 100 / 200 us polls (50 / 100 measured the same throughput: tools/exp_ab.sh)
         if (sleepy) relax_timer_slack();
         if (!reads.empty()) {
             lead->ensure_read_arena();
@@ -170,7 +171,7 @@ void Combiner::flush_locked(std::unique_lock<std::mutex> &lk) {
                     if (e != hipSuccess && e != hipErrorNotReady) throw Err{-2, std::string("hipStreamQuery: ") + hipGetErrorString(e)};
                     if (e == hipSuccess && *flag != seq) throw Err{-2, "group hand-over: the stream finished without the flag"};
                 }
-                if (sleepy) poll_sleep((int)polls, true);
+                if (sleepy) poll_sleep((int)polls, crowd);
             }
             std::atomic_thread_fence(std::memory_order_acquire);
         } else {
@@ -180,7 +181,7 @@ void Combiner::flush_locked(std::unique_lock<std::mutex> &lk) {
                     const hipError_t e = hipStreamQuery(st);
                     if (e == hipSuccess) break;
                     if (e != hipErrorNotReady) throw Err{-2, std::string("hipStreamQuery: ") + hipGetErrorString(e)};
-                    poll_sleep(polls, true);
+                    poll_sleep(polls, crowd);
                 }
         }
     } catch (const Err &e) {

@@ -428,7 +428,9 @@ void overlap_counts(plade_ctx *ctx, OverlapWork &work, const float *d_sx, const 
         // GPU), of OV_KCH from a few hundred candidates on (BASELINE configs[4]: 10^4)
         const uint32_t ch = K <= 64 ? 2u : (K <= 512 ? 4u : (uint32_t)OV_KCH);
         const uint64_t nitems = (uint64_t)cdiv(n_s, OV_TPB) * cdiv(K, ch);
-        const uint32_t wgs = (uint32_t)std::min<uint64_t>(nitems, 2048);
+        // (in a group the launch is merged with those of up to seven other pairs: a quarter of the workgroups per pair fill the
+        //  part as well, and each of them stages the block mask -- up to 48 KB -- for four times the items)
+        const uint32_t wgs = (uint32_t)std::min<uint64_t>(nitems, ctx->comb ? 512u : 2048u);
         const uint32_t per = (uint32_t)((nitems + wgs - 1) / wgs);
         const uint32_t nw = (uint32_t)((grid.ncells + 63) / 64);
         const uint32_t mask_words = (nw + 31) / 32 * 4 <= OV_MASK_MAX ? (nw + 63) / 64 * 2 : 0u;   // whole 64-bit words of occ_blk
