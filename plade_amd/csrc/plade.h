@@ -63,6 +63,8 @@ bool load_ply_cloud(const std::string &file_name, pcl::PointCloud<pcl::PointNorm
 
 /** Select the GPU used by the calling thread's registrations (default 0). */
 void plade_select_device(int device);
+/** PLADE_TRACE_CLI=1: a time-stamped line on std::cerr (seconds since the first such call). */
+void plade_cli_trace(const char *what);
 /** GPUs this process sees (0 without one): the CLI's batch mode spreads the list over all of them by default. */
 int plade_gpu_count();
 

@@ -23,9 +23,23 @@ thread_local std::ostream *g_out = nullptr, *g_err = nullptr;
 std::ostream &con_out() { return g_out ? *g_out : std::cout; }
 std::ostream &con_err() { return g_err ? *g_err : std::cerr; }
 
+// PLADE_TRACE_CLI=1: what the process spends where, on std::cerr (seconds since the first call)
+double trace_now() {
+    static const auto t0 = std::chrono::steady_clock::now();
+    return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+bool trace_on() { static const bool v = getenv("PLADE_TRACE_CLI") != nullptr; return v; }
+void trace(const char *what) {
+    if (!trace_on()) return;
+    char b[160];
+    snprintf(b, sizeof(b), "[plade %8.3f s] %s\n", trace_now(), what);
+    std::cerr << b << std::flush;
+}
+
 plade_ctx *context() {
     if (g_ctx && g_ctx_device == g_device) return g_ctx;
     if (g_ctx) { plade_ctx_destroy(g_ctx); g_ctx = nullptr; }
+    trace("context: creating");
     if (plade_ctx_create(g_device, &g_ctx) != PLADE_OK) {
         con_err() << "PLADE: cannot create a GPU context on device " << g_device
                   << " (libplade_hip.so needs a gfx950 GPU; there is no CPU fallback)" << std::endl;
@@ -43,8 +57,25 @@ plade_ctx *context() {
     if (const char *w = getenv("PLADE_RANSAC_TOPUP")) { prm.ransac_topup = atoi(w) != 0; changed = true; }
     if (const char *w = getenv("PLADE_CLOSEST_POINT_MODE")) { prm.closest_point_mode = (!strcmp(w, "svd_fp32") || !strcmp(w, "1")) ? 1 : 0; changed = true; }
     if (changed) (void)plade_set_params(g_ctx, &prm);
+    trace("context: ready");
     return g_ctx;
 }
+
+// The staging arrays of a worker thread, page-locked: the library then uploads them by asynchronous DMA (~50 GB/s) instead of
+// through the runtime's bounce buffer (pageable memory: ~6-10 GB/s, and the call blocks meanwhile) -- at 48 MB per pair the
+// difference is most of a long list's wall time.  An array is registered once and again only when its allocation has moved.
+struct PinnedVec {
+    const float *ptr = nullptr; size_t bytes = 0; plade_ctx *owner = nullptr;
+    void release() { if (ptr && owner && owner == g_ctx) (void)plade_host_unpin(owner, ptr); ptr = nullptr; bytes = 0; owner = nullptr; }
+    void cover(plade_ctx *ctx, const std::vector<float> &v) {
+        const size_t want = v.capacity() * sizeof(float);
+        if (ptr == v.data() && bytes == want && owner == ctx) return;
+        release();
+        if (!ctx || !want) return;
+        if (plade_host_pin(ctx, v.data(), want) == PLADE_OK) { ptr = v.data(); bytes = want; owner = ctx; }
+    }
+};
+thread_local PinnedVec g_pins[2 * PLADE_GROUP_MAX];
 
 std::vector<float> flatten(const pcl::PointCloud<pcl::PointNormal> &c) {
     std::vector<float> a(6 * c.size());
@@ -88,12 +119,14 @@ std::string extension(const std::string &file_name) {  // util.cpp:525-531
 
 }  // namespace
 
+void plade_cli_trace(const char *what) { trace(what); }
 void plade_select_device(int device) { g_device = device; }
 int plade_gpu_count() { return plade_device_count(); }
 
 void plade_set_thread_console(std::ostream *out, std::ostream *err) { g_out = out; g_err = err; }
 
 void plade_release_thread_context() {
+    for (PinnedVec &p : g_pins) p.release();     // before the arrays themselves go with the thread
     if (g_ctx) { plade_ctx_destroy(g_ctx); g_ctx = nullptr; g_ctx_device = -1; }
 }
 
@@ -224,6 +257,7 @@ bool registration(Eigen::Matrix<float, 4, 4> &transformation, const std::string 
         return false;
     }
     thread_local std::vector<float> target_buf, source_buf;   // one pair of staging arrays per worker thread
+    trace("pair: reading the two files");
     if (!load_packed(target_cloud_file, target_buf)) {
         con_err() << "loading target point cloud failed" << std::endl;
         return false;
@@ -242,7 +276,9 @@ bool registration(Eigen::Matrix<float, 4, 4> &transformation, const std::string 
         con_out() << "---->>> ATTENTION: target and source have been switched for efficiency <<<----" << std::endl;
     }
     transformation.setIdentity();
+    trace("pair: files read");
     bool status = register_packed(transformation, tg, n_t, sr, n_s);
+    trace("pair: registered");
     if (!status) {
         con_err() << "registration failed" << std::endl;
         return false;
@@ -279,7 +315,11 @@ void registration_group(size_t count, Eigen::Matrix<float, 4, 4> *transformation
                 readers.emplace_back([file, l, buf]() { l->ok = plade::read_ply_pos_nrm(*file, *buf, l->err, &l->warnings) && !buf->empty(); });
             }
         }
+        // the worker's GPU context (HIP start-up on first use, streams, the first work areas) is set up while the files load
+        trace("group: reading");
+        (void)context();
         for (auto &t : readers) t.join();
+        trace("group: files read");
     }
     auto report = [&](const Loaded &l) {   // load_packed's messages
         if (!l.ok && !l.err.empty()) con_err() << l.err << std::endl;
@@ -311,6 +351,8 @@ void registration_group(size_t count, Eigen::Matrix<float, 4, 4> *transformation
     plade_set_thread_console(nullptr, nullptr);
     if (items.empty()) return;
     plade_ctx *ctx = context();
+    for (size_t q = 0; q < 2 * GMAX; ++q) if (!bufs[q].empty()) g_pins[q].cover(ctx, bufs[q]);
+    trace("group: staging arrays page-locked");
     const uint32_t k = (uint32_t)items.size();
     const float *tg[GMAX], *sr[GMAX];
     uint32_t n_t[GMAX], n_s[GMAX];
@@ -319,6 +361,7 @@ void registration_group(size_t count, Eigen::Matrix<float, 4, 4> *transformation
     for (uint32_t q = 0; q < k; ++q) { tg[q] = items[q].tg; sr[q] = items[q].sr; n_t[q] = (uint32_t)items[q].n_t; n_s[q] = (uint32_t)items[q].n_s; status[q] = PLADE_EDEVICE; }
     Watch w;
     int rc = ctx ? plade_registration_pairs(ctx, k, tg, n_t, sr, n_s, 0, nullptr, nullptr, nullptr, nullptr, T16, status) : PLADE_EDEVICE;
+    trace("group: registered");
     for (uint32_t q = 0; q < k; ++q) {
         const Item &it = items[q];
         plade_set_thread_console(out ? out[it.pair] : nullptr, err ? err[it.pair] : nullptr);
