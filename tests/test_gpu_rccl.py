@@ -28,7 +28,6 @@ def comm():
 
 
 def test_rccl_communicator_of_one_rank(comm):
-    assert "torch" not in sys.modules
     a = np.arange(17 * 5, dtype=np.float32).reshape(5, 17)
     parts = comm.all_gather_array(a)
     assert len(parts) == 1 and np.array_equal(parts[0], a)
