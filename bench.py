@@ -45,8 +45,18 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
 
-KERNEL_SYMBOLS = {"score_mark": "k_r_mark(", "score_multi": "k_r_rescore(", "overlap": "k_overlap(", "knn_spacing": "k_knn_grid(",
-                  "pen_walk": "k_pen_walk(", "cluster_edges": "k_cluster_edges("}
+KERNEL_SYMBOLS = {"score_mark": "k_r_mark(", "score_multi": "k_r_rescore(", "overlap": "k_overlap", "knn_spacing": "k_knn_grid",
+                  "pen_walk": "k_pen_walk", "cluster_edges": "k_cluster_edges", "sort_pass": "k_rs_pass", "sort_hist": "k_rs_histogram"}
+
+
+def _profile_registrations(csv_path, rows, name_key, calls_key):
+    """Registrations behind a committed rocprofv3 summary: the count the profiled command printed (tools/summarize_profiles.py keeps
+    it beside the summary, <round>_profile_meta.json); older summaries: one k_overlap launch per registration."""
+    meta = csv_path.rsplit("_", 2)[0] + "_profile_meta.json"
+    try:
+        return int(json.load(open(meta))["registrations"])
+    except Exception:
+        return next((int(r[calls_key]) for r in rows if "k_overlap(" in r[name_key]), 0)
 
 
 def pmc_traffic(tag, group=8):
@@ -63,14 +73,16 @@ def pmc_traffic(tag, group=8):
         rows = list(csv.DictReader(f))
     # registrations in the profile = launches of the verification kernel (one per registration, whatever the size of its group:
     # the profiled command also registers a few pairs alone)
-    regs = next((int(r["launches"]) for r in rows if "k_overlap(" in r["kernel"]), 0) or group * next((int(r["launches"]) for r in rows if "k_morton(" in r["kernel"]), 0)
-    for r in rows:
+    regs = _profile_registrations(files[-1], rows, "kernel", "launches") or group * next((int(r["launches"]) for r in rows if "k_morton(" in r["kernel"]), 0)
+    tot, hit = 0.0, False
+    for r in rows:      # (a kernel of the lock-step stages appears once per merged-launch width: summed)
         if sym in r["kernel"]:
             rd = float(r["hbm_read_bytes(FETCH_SIZE*1024*2)"])
             wr = float(r["hbm_write_bytes(WRITE_SIZE*1024)"])
             # counter average over all launches of the kernel x launches per registration = bytes per registration
-            return (rd + wr) * int(r["launches"]) / max(regs, 1), os.path.relpath(files[-1], ROOT)
-    return None, None
+            tot += (rd + wr) * int(r["launches"]) / max(regs, 1)
+            hit = True
+    return (tot, os.path.relpath(files[-1], ROOT)) if hit else (None, None)
 
 
 def rocprof_stats(tag, group=8):
@@ -86,6 +98,10 @@ def rocprof_stats(tag, group=8):
     rows = list(csv.DictReader(open(files[-1])))
     total = sum(float(r["TotalDurationNs"]) for r in rows) or 1.0
     def short(name):
+        import re
+        m = re.search(r"k_batch.*?(k_[a-z0-9_]+)", name)     # a kernel in its lock-step form (launch.h): k_batch<&k_xxx, ...>
+        if m:
+            return "k_batch<" + m.group(1) + ">"
         for junk in ("void ", "plade::", "(anonymous namespace)::"):
             name = name.replace(junk, "")
         return name.split("(")[0][:48]
@@ -93,17 +109,16 @@ def rocprof_stats(tag, group=8):
     out = {"file": os.path.relpath(files[-1], ROOT),
            "top_by_gpu_time": [{"kernel": short(r["Name"]), "share": round(float(r["TotalDurationNs"]) / total, 4),
                                 "avg_us": round(float(r["AverageNs"]) / 1e3, 2)} for r in top]}
-    regs = next((int(r["Calls"]) for r in rows if "k_overlap(" in r["Name"]), 0) or group * next((int(r["Calls"]) for r in rows if "k_morton(" in r["Name"]), 0)
+    regs = _profile_registrations(files[-1], rows, "Name", "Calls") or group * next((int(r["Calls"]) for r in rows if "k_morton(" in r["Name"]), 0)
     out["registrations_profiled"] = regs
     out["kernels_per_registration"] = round(sum(int(r["Calls"]) for r in rows if "rocclr" not in r["Name"]) / max(regs, 1), 1)
     out["copies_and_fills_per_registration"] = round(sum(int(r["Calls"]) for r in rows if "rocclr" in r["Name"]) / max(regs, 1), 1)
     out["gpu_ms_per_registration"] = round(total / 1e6 / max(regs, 1), 3)
-    for r in rows:
-        if sym in r["Name"]:
-            out.update({"avg_launch_us": float(r["AverageNs"]) / 1e3, "calls": int(r["Calls"]),
-                        "launches_per_registration": int(r["Calls"]) / max(regs, 1),
-                        "share_of_gpu_time": float(r["TotalDurationNs"]) / total})
-            break
+    calls = sum(int(r["Calls"]) for r in rows if sym in r["Name"])
+    if calls:
+        dur = sum(float(r["TotalDurationNs"]) for r in rows if sym in r["Name"])
+        out.update({"avg_launch_us": dur / calls / 1e3, "calls": calls, "launches_per_registration": calls / max(regs, 1),
+                    "share_of_gpu_time": dur / total})
     return out
 
 
@@ -412,8 +427,8 @@ def _cpu_budget():
 
 
 # busy host threads per rank, measured on the MI355X box in round 4 (tools/exp_groups.py, sleeping host waits, groups of 8 pairs,
-# host clouds): groups in flight -> busy threads (registrations/s): see profiles/r4_experiments.md
-BUSY_THREADS_BY_GROUPS = {1: 1.38, 2: 1.66, 3: 1.8, 4: 1.91}   # 578 / 700 / 741 / 766 registrations/s
+# host clouds): groups in flight -> busy threads (registrations/s): see profiles/r5_experiments.md
+BUSY_THREADS_BY_GROUPS = {1: 1.02, 2: 1.5, 3: 1.53, 4: 1.71}   # r5 (lock step, tools/exp_lockstep.sh): 457 / 665 / 717 / 786 registrations/s (6 groups: 1.88 threads, 774); r4: 1.38 / 1.66 / 1.8 / 1.91
 
 
 def inflight_for_budget(budget, local_world):
@@ -784,7 +799,7 @@ def main():
         ctx.unpin(tg); ctx.unpin(sr)
 
     # ---- roofline leg: one extra profiled step (HIP events on the ctx stream around every launch) ----
-    roofline = None
+    roofline = roofline_sort = None
     stage = {}
     latency_ms = None
     if rank == 0:
@@ -903,6 +918,24 @@ def main():
                     per_launch = (by / args.profiled_steps) / max(rp.get("launches_per_registration", work_per_step), 1e-9)
                     roofline["rocprof"]["algorithmic_bytes_per_launch_all"] = per_launch
                     roofline["rocprof"]["frac_at_rocprof_average"] = per_launch / (rp["avg_launch_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS
+        if st.get("k_sort_pass_seconds"):
+            secs, nl, by = st["k_sort_pass_seconds"], st["k_sort_pass_launches"], st["k_sort_pass_bytes"]
+            roofline_sort = {"bound": "hbm", "kernel": "sort_pass", "kernel_symbol": "k_rs_pass", "achieved": by / secs / 1e9,
+                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": by / secs / 1e9 / HBM_PEAK_GBS,
+                             "avg_launch_us": secs / nl * 1e6, "launches_per_step": nl / args.profiled_steps,
+                             "algorithmic_bytes_per_launch": by / nl, "algorithmic_bytes_per_step": by / args.profiled_steps,
+                             "seconds_per_step": secs / args.profiled_steps,
+                             "measured": "HIP events on the launch stream around every pass of the stable LSD radix sort (keys + values read "
+                                         "once and written once per pass: 2 n (sizeof key + 4) B), kernel-by-kernel leg under the load of the "
+                                         "other groups; in the timed region the sorts of a group's pairs behind the extraction are merged launches",
+                             "why": "the kernel family with the most GPU time after the RANSAC chain (rocprof.top_by_gpu_time)"}
+            traffic_reg, traffic_src = pmc_traffic("sort_pass", S)
+            if traffic_reg is not None:
+                roofline_sort["traffic_per_step"] = traffic_reg
+                roofline_sort["traffic_source"] = traffic_src
+            rp = rocprof_stats("sort_pass", S)
+            if rp and rp.get("avg_launch_us"):
+                roofline_sort["rocprof"] = {k: rp[k] for k in ("file", "avg_launch_us", "calls", "launches_per_registration", "share_of_gpu_time") if k in rp}
         stage_times = {k: v for k, v in st.items() if k.startswith("t_")}
         b_total = st.get("bytes_ransac", 0.0) + st.get("bytes_voxel", 0.0) + st.get("bytes_verify", 0.0)
         if roofline is not None:
@@ -992,6 +1025,7 @@ def main():
                          "occupancy_note": "secondary estimator (round 3's `value`): groups in flight x pairs per group / mean time a timed "
                                            "group occupied its worker (Little's law)"},
             "roofline": roofline,
+            "roofline_sort": roofline_sort,
             "cpu_baseline": cpu,
             "cpu_baseline_batch": cpu_batch,
             "cli_end_to_end": cli_e2e,

@@ -306,8 +306,10 @@ void radix_sort_run_ipt(plade_ctx *ctx, const K *ki, K *ko, const uint32_t *vi, 
     ctx->sort_segs[cur] = (uint32_t)nseg;
     ctx->sort_seq += 1;
     ki += seg_off[0]; ko += seg_off[0]; vi += seg_off[0]; vo += seg_off[0];
+    ctx->ev_begin("sort_hist", (double)n * sizeof(K));
     launch<k_rs_histogram<K, DB>, RS_THREADS>(ctx, dim3(RS_HBLOCKS * nseg), 0, ki, S, passes, gh, t + off_ctr,
                        t + off_look, look_words);
+    ctx->ev_end();
     const K *src_k = ki;
     const uint32_t *src_v = vi;
     for (int p = 0; p < passes; ++p) {
@@ -315,8 +317,10 @@ void radix_sort_run_ipt(plade_ctx *ctx, const K *ki, K *ko, const uint32_t *vi, 
         K *dst_k = to_out ? ko : tk;
         uint32_t *dst_v = to_out ? vo : tv;
         uint32_t *pass_look = t + off_look + (size_t)p * pass_words;
+        ctx->ev_begin("sort_pass", (double)n * 2.0 * (sizeof(K) + 4));   // algorithmic: keys + values read once, written once
         launch<k_rs_pass<K, DB, RS_IPT>, RS_THREADS>(ctx, dim3(tiles), 0, src_k, dst_k, src_v, dst_v, S, p, gh,
                            gh_next, zero_words, t + off_ctr, pass_look, reinterpret_cast<unsigned long long *>(pass_look + (size_t)tiles * NB), st_shift);
+        ctx->ev_end();
         src_k = dst_k;
         src_v = dst_v;
     }

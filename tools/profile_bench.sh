@@ -5,7 +5,7 @@
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out
-TAG=${1:-r4}
+TAG=${1:-r5}
 mkdir -p $O
 cd $R
 if [ -z "${ONLY_PROF:-}" ]; then
@@ -18,8 +18,8 @@ cd /tmp && export TMPDIR=/tmp
 # (lead-in of one round instead of eight: with ~170 registrations in one traced process rocprofv3 7.2 segfaults inside the
 #  profiled process, below hipGraphLaunch; ~110 are fine)
 export BENCH_LEAD_ROUNDS=1
-export BENCH_MIN_ROUNDS=4   # 96 timed steps = 24 groups of 4 (+ lead-in, warm-up, tail: ~45 groups per traced process)
-CMD="python $R/bench.py --steps 96 --warmup 8 --resident-steps 0 --no-cpu-baseline --no-cli --no-default-mode --profiled-steps 2"
+export BENCH_MIN_ROUNDS=${BENCH_MIN_ROUNDS:-6}   # 6 rounds of 32 in flight = 192 timed steps (+ lead-in, warm-up, tail)
+CMD="python $R/bench.py --pairs 16 --steps 96 --warmup 8 --resident-steps 0 --svd-steps 0 --no-cpu-baseline --no-cli --no-default-mode --no-parity --profiled-steps 0"
 rm -rf $O/prof_bench $O/prof_pmc_fetch $O/prof_pmc_write
 # every pass is tried up to three times
 prof() {   # prof <dir> <output name> <rocprofv3 options...>
