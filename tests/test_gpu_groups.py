@@ -266,3 +266,41 @@ def test_sides_of_a_pair_side_by_side_or_one_after_the_other(scenes, alone, side
         assert res[pos][0] and np.array_equal(res[pos][1], alone[i][1])
         _same(c.dump(pair=pos), alone[i][2], PLANE_KEYS + STAGE_KEYS)
     c.close()
+
+
+def test_lock_step_merges_the_pairs_launches_and_changes_nothing(scenes, alone, tmp_path):
+    """Behind the plane extraction the pairs of a group run in LOCK STEP (plade_amd/csrc/launch.h, combiner.hip): what the eight
+    host threads launch is collected per pair and issued merged -- one launch per kernel for all pairs, one copy kernel for
+    their uploads, one hand-over kernel and one wait for their read-backs.  The statistics of the call say how much was merged;
+    PLADE_NO_LOCKSTEP=1 (a process-wide A/B switch, hence the subprocess) runs every pair's tail on its own stream as round 4
+    did: both return the bits of the pairs alone."""
+    import os
+    import subprocess
+    import sys
+    order = [0, 1, 2, 1, 0, 2, 1, 0]
+    prs = [(scenes[k][0], scenes[k][1]) for k in order]
+    c = plade_amd.Context(0, orient_normals=1, dump=1)
+    res = c.registration_pairs(prs)
+    st = c.stats()
+    for q, (ok, T) in enumerate(res):
+        assert ok == alone[order[q]][0] and np.array_equal(T, alone[order[q]][1]), q
+        _same(c.dump(pair=q), alone[order[q]][2], PLANE_KEYS + STAGE_KEYS)
+    c.close()
+    asked, issued, waits = st["lockstep_operations_asked"], st["lockstep_commands_issued"], st["lockstep_group_waits"]
+    print(f"lock step, 8 pairs: {asked:.0f} launches / copies / fills asked for by the pairs -> {issued:.0f} commands on the stream, {waits:.0f} group waits")
+    assert asked > 300 and issued < 0.45 * asked and waits <= 40
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r)\n"
+        "import plade_amd\n"
+        "from plade_amd.synth import make_pair\n"
+        "sc = [tuple(np.ascontiguousarray(a, np.float32) for a in make_pair(n, seed=s)[:2]) for n, s in ((200000, 3), (120000, 7), (200000, 11))]\n"
+        "c = plade_amd.Context(0, orient_normals=1)\n"
+        "res = c.registration_pairs([sc[k] for k in %r])\n"
+        "assert 'lockstep_operations_asked' not in c.stats()\n"
+        "np.save(%r, np.stack([T for ok, T in res]))\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), order, str(tmp_path / "T.npy"))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PLADE_NO_LOCKSTEP="1"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-1500:]
+    Tn = np.load(tmp_path / "T.npy")
+    for q in range(len(order)):
+        assert np.array_equal(Tn[q], alone[order[q]][1]), q

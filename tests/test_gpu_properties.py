@@ -199,7 +199,7 @@ def test_extract_planes_full_size_partition(ctx, oracle, big_pair):
         assert cloud[ids, 3:].mean(0) @ coef[p, :3] > 0
 
 
-@pytest.mark.parametrize("seed", [0, 1])
+@pytest.mark.parametrize("seed", [0, 1, 2, 5])
 def test_registration_full_size_every_intermediate_equals_oracle(oracle, seed):
     """BASELINE configs[2] size: the oracle run on the planes the GPU extracted reproduces every dumped
     intermediate (lines, descriptors, matches, transforms, clusters, plane counts, penetration flags,
@@ -218,7 +218,7 @@ def test_registration_full_size_every_intermediate_equals_oracle(oracle, seed):
     assert len(common) >= 30
     for k in common:
         assert np.asarray(d[k]).shape == np.asarray(do[k]).shape and np.array_equal(d[k], do[k]), k
-    assert np.linalg.norm(T.astype(np.float64) - Tgt) < 1e-2
+    assert np.linalg.norm(T.astype(np.float64) - Tgt) < (1e-2 if seed < 2 else 1e-1)   # (the 64 bench scenes: <= 8.4e-2, GPU = oracle)
     # the PCL-faithful voxel order of the oracle (sort_mode 0: (voxel, point) pairs through an unstable std::sort, so the
     # fp32 sums inside a voxel run in another order) moves the transform by less than north_star's 1e-4, at this size too
     ok_f, T_f, _ = oracle.registration(tg, sr, tp, sp, voxel_sort_mode=0)
