@@ -985,7 +985,8 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"Synthetic {args.points}-pt indoor scan pair, ~30 planes (BASELINE configs[2]); "
+            "config": {"workload": f"Synthetic {args.points}-pt indoor scan pairs, ~30 planes (BASELINE configs[2]), a batch of {args.pairs} DISTINCT pairs per GPU "
+                                   "cycled in input order (configs[3]: 64 pairs, seeds 0..63, at N = 1); "
                                    "full registration(T,target,source) of plade.h:58 = plane extraction + registration on clouds in "
                                    "page-locked HOST memory, batch mode (plade_registration_pairs: consecutive pairs of the batch in groups whose plane "
                                    "extraction is one launch sequence; H2D + SoA conversion + bounding boxes of every step inside the timed "
@@ -993,7 +994,8 @@ def main():
                                    "timed window = EXACTLY `steps` completions of the full pipeline (steady state, SURVEY 8d); "
                                    "plade_params.orient_normals=1 (planes oriented like their inliers' normals: the generator's "
                                    "Manhattan scenes need it, DESIGN.md section 2); CPU baseline applies the same rule",
-                       "points_per_cloud": args.points, "pairs_per_rank": args.pairs,
+                       "points_per_cloud": args.points, "pairs_per_rank": args.pairs, "distinct_pairs_total": args.pairs * world,
+                       "lock_step": os.environ.get("PLADE_NO_LOCKSTEP") is None,
                        "groups_in_flight_per_gpu": M, "pairs_per_group": S, "registrations_in_flight_per_gpu": RIF,
                        "inflight_chosen_from_cpu_quota": inflight_auto, "host_wait": args.host_wait,
                        "inflight_for_local_world_8": inflight_for_budget(_cpu_budget(), 8),
