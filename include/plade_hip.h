@@ -11,6 +11,7 @@
  */
 #ifndef PLADE_HIP_H
 #define PLADE_HIP_H
+#include <stddef.h>
 #include <stdint.h>
 #ifdef __cplusplus
 extern "C" {

@@ -57,3 +57,14 @@ def test_product_never_touches_the_oracle():
     mk = open(os.path.join(ROOT, "Makefile")).read()
     lib_rule = mk.split("plade_amd/libplade_hip.so:")[1].split("\n\n")[0]
     assert "oracle" not in lib_rule
+
+
+def test_the_header_is_plain_c(tmp_path):
+    """The drop-in boundary is a C ABI: include/plade_hip.h must compile as C99 on its own (a cgo / ctypes / JNI binding includes
+    nothing else)."""
+    import subprocess
+    src = tmp_path / "t.c"
+    src.write_text('#include "plade_hip.h"\nint main(void) { plade_params p; plade_default_params(&p); return (int)sizeof(p) & 0; }\n')
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"), "-fsyntax-only", str(src)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
