@@ -103,3 +103,61 @@ def test_candidate_sharding_world2_gloo():
     centers = np.stack([[i, 0, 0] for i in range(K)]).astype(np.float32)
     want = _fake_counts(None, None, T, centers, 1.0, 0.1)
     assert np.array_equal(res[0], want) and np.array_equal(res[1], want)
+
+
+class _GlooArrayComm:
+    """The interface of plade_amd.rccl_comm.RcclComm (one all-gather of equally sized blocks per exchange step) over gloo: what the
+    RCCL branches of plade_amd/batch.py see on a multi-GPU node, on CPU."""
+    def __init__(self, rank, world):
+        self.rank, self.world = rank, world
+
+    def all_gather_array(self, a):
+        t = torch.from_numpy(np.ascontiguousarray(a).copy())
+        parts = [torch.empty_like(t) for _ in range(self.world)]
+        dist.all_gather(parts, t)
+        return [p.numpy() for p in parts]
+
+
+def _array_comm_worker(rank, world, port, n_items, K, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    comm = _GlooArrayComm(rank, world)
+    mine = shard(n_items, rank, world)
+    T = np.stack([_fake_T(i) for i in mine]) if mine else np.zeros((0, 4, 4), np.float32)
+    ok = np.array([i % 3 != 0 for i in mine], bool)
+    Tg, okg = gather_results(T, ok, n_items, rank, world, comm=comm)       # shards of unequal length: padded to one block size
+    Tc = np.stack([_fake_T(i) for i in range(K)])
+    centers = np.stack([[i, 0, 0] for i in range(K)]).astype(np.float32)
+    counts = sharded_overlap_counts(None, None, None, Tc, centers, 1.0, 0.1, rank, world, counter=_fake_counts, comm=comm)
+    q.put((rank, Tg, okg, counts))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_the_rccl_branches_with_equal_blocks_world3_gloo():
+    """plade_amd/batch.py over an all_gather_array communicator (RCCL on GPUs: plade_amd/rccl_comm.py): 3 ranks, 7 pairs (shards of 3, 2
+    and 2: padded), 11 candidates."""
+    world, n_items, K = 3, 7, 11
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_array_comm_worker, args=(r, world, port, n_items, K, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        r, Tg, okg, counts = q.get(timeout=120)
+        res[r] = (Tg, okg, counts)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    Tg, okg, _ = res[0]
+    for i in range(n_items):
+        assert np.array_equal(Tg[i], _fake_T(i)) and okg[i] == (i % 3 != 0)
+    assert res[1][0] is None and res[2][0] is None
+    Tc = np.stack([_fake_T(i) for i in range(K)])
+    centers = np.stack([[i, 0, 0] for i in range(K)]).astype(np.float32)
+    want = _fake_counts(None, None, Tc, centers, 1.0, 0.1)
+    for r in range(world):
+        assert np.array_equal(res[r][2], want)
