@@ -493,7 +493,7 @@ def main():
         local_rank = 0
     # No torch in the ranks.  `import torch` brings the HIP runtime bundled with the wheel (ROCm 7.0) into the process ahead
     # of the system's (7.2), and the library then runs on that one: measured 458 instead of 483 registrations/s at N = 1
-    # (tools/exp_throughput.py, EXP_TORCH=import) -- a penalty every rank would pay.  The path shards whole pairs and has
+    # (round 3's A/B: the same pipeline with and without `import torch` in the process) -- a penalty every rank would pay.  The path shards whole pairs and has
     # no data-path collective; what the ranks exchange -- the barriers around the timed region, three numbers to reduce and
     # 68 bytes of result per pair -- goes over their loopback rendezvous (plade_amd/rendezvous.py; the ranks of
     # `torch.distributed.run --nnodes=1` share one host).  The timed region is bracketed with hipDeviceSynchronize through
