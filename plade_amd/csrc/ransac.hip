@@ -62,7 +62,7 @@ constexpr int TPB = K1_TPB, PPT = K1_PPT, TILE = K1_TILE;   // scan kernels: 102
 constexpr int HCHUNK = 64;              // hypotheses per workgroup of the counting kernels (>= R_TOP)
 constexpr int FIT_COLS = 14;            // 12 LS-fit moments, weighted score, kept-point count
 constexpr uint32_t CC_MAXPIX = 1u << 20;
-constexpr int CC_LDS_PIX = 8192;
+constexpr int CC_LDS_PIX = 4096;   // (r5: 8192 cost the labelling workgroup 80 KB of LDS -- half a CU; with 40 KB the batch pipeline runs 2 % faster, and every plane of a scene at bitmap eps = 2 % of its extent still fits: 50 x 40 pixels)
 
 // ------------------------------------------------------------------------------------------------
 // device-resident state

@@ -176,7 +176,7 @@ def test_batch_mode_prefetch_returns_the_bits_of_the_plain_call():
 
 def test_tall_scene_takes_the_global_memory_labelling_path():
     """The bitmap cell is 2 % of max(dx, dy) -- Z is ignored (plane_extraction.cpp:71-80) -- so the walls of a tall, narrow
-    shaft rasterise to far more than the 8192 pixels the labelling kernel keeps in LDS: it labels in global memory instead,
+    shaft rasterise to far more than the 4096 pixels the labelling kernel keeps in LDS: it labels in global memory instead,
     and the walls come out whole."""
     import plade_amd
     rng = np.random.default_rng(4)

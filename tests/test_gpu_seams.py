@@ -246,7 +246,7 @@ def test_radix_sort_over_segments_sorts_every_array_on_its_own(ctx, sizes, bits)
 
 @pytest.mark.parametrize("filt", [True, False])
 def test_plane_component_bitmap_larger_than_the_lds_labelling(ctx, oracle, filt):
-    """Seam S1c on a bitmap of ~360 x 300 pixels (k_r_label keeps bitmaps of up to 8192 pixels in LDS; beyond that it labels
+    """Seam S1c on a bitmap of ~360 x 300 pixels (k_r_label keeps bitmaps of up to 4096 pixels in LDS; beyond that it labels
     in global memory): kept list = the oracle's (BitmapPrimitiveShape.cpp:97-265), LS fit and weighted score as for the
     small case."""
     rng = np.random.default_rng(12 + filt)
