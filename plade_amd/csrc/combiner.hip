@@ -228,8 +228,11 @@ void Combiner::leave(plade_ctx *c) {
     const int slot = c->comb_slot;
     --members;
     // what the pair still has queued stays in its slot and is issued with the next flush; if everybody else is already
-    // waiting (or gone), that flush is this thread's to run
-    if (members > 0 ? arrived >= members : !q[slot].empty()) {
+    // waiting -- or gone, with anything (of any pair) still queued -- that flush is this thread's to run
+    bool anything = false;
+    for (int s = 0; s < BATCH_MAX; ++s) anything = anything || !q[s].empty();
+    (void)slot;
+    if (members > 0 ? arrived >= members : anything) {
         const bool any_waiting = arrived > 0;
         flush_locked(lk);
         if (any_waiting) { arrived = 0; ++epoch; cv.notify_all(); }
