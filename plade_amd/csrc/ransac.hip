@@ -446,6 +446,51 @@ __device__ __forceinline__ int scan_group(const RKArgs &A, uint32_t &tile) {
     return g;
 }
 
+// number of points a full pass scans (= scan_src(C, S).n)
+template <class CA>
+__device__ __forceinline__ uint32_t scan_n(const CA &C, const RState *S) { return (C.view[0] && S->view_sel) ? S->view_n : C.cv.n; }
+
+// ------------------------------------------------------------------------------------------------
+// Virtual grids (r5).  The per-chain kernels of the acceptance chain used to be launched over (workgroups per chain) x (R_B
+// chains x R_G clouds) -- ~15 600 workgroups for a group of sixteen 1M-point clouds, of which a few dozen have anything to do
+// behind the first iteration; the rest read two words of the loop state and return.  Alone on the GPU that costs little (4.6 us
+// for 16 384 empty workgroups, tools/empty_grid.hip), but beside the long kernels of three other groups the empty workgroups
+// queue for the few free wave slots like everybody else (k_r_compact_raster: 27 us alone, 69-87 us in the pipeline).  Now such a
+// launch is a fixed, small number of workgroups: each builds the table of what every chain needs (one lane per chain, a few
+// loads) and strides over the concatenation of the chains' own grids.  No result depends on the shape of the grid: every offset
+// comes from counts.
+constexpr int CH_E = R_G * R_B;
+__device__ __forceinline__ uint32_t cdiv_d(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
+constexpr uint32_t VGRID_WGS = 2048;     // workgroups of a virtual-grid launch (the host launches min(this, what the old grid was))
+constexpr int OWN_MAX = 8;               // tiles a compaction workgroup owns per round
+__host__ __device__ inline uint32_t loop_grid(uint32_t nb) {
+    const uint32_t a = (nb + OWN_MAX - 1) / OWN_MAX;
+    return a > 1024u ? 1024u : (a < 32u ? 32u : a);
+}
+template <class F>
+__device__ __forceinline__ uint32_t chain_grid_build(const RKArgs &A, uint32_t *s_start /* CH_E + 1 */, uint32_t *s_carry, F need) {
+    static_assert(CH_E == 128 && TPB >= 128, "one lane per chain, two wavefronts");
+    const uint32_t e = threadIdx.x;
+    uint32_t n = 0;
+    if (e < (uint32_t)CH_E && e / R_B < A.ng) n = need(e / R_B, e % R_B);
+    uint32_t incl = n;
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
+    if (e == 63) *s_carry = incl;
+    __syncthreads();
+    if (e >= 64 && e < (uint32_t)CH_E) incl += *s_carry;
+    if (e < (uint32_t)CH_E) s_start[e + 1] = incl;
+    if (e == 0) s_start[0] = 0;
+    __syncthreads();
+    return s_start[CH_E];
+}
+__device__ __forceinline__ uint32_t chain_grid_find(const uint32_t *s_start, uint32_t vt) {   // e with start[e] <= vt < start[e + 1]
+    uint32_t lo = 0, hi = CH_E;
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (s_start[mid] <= vt) lo = mid; else hi = mid; }
+    return lo;
+}
+
 __device__ __forceinline__ void hcs_axes(const float *n, float *a0, float *a1) {
     float t[3];
     if (fabsf(n[0]) < 0.015625f && fabsf(n[1]) < 0.015625f) {  // (0,1,0) x n
@@ -1122,24 +1167,18 @@ __device__ __forceinline__ bool cc_dims(const float bb[4], uint32_t count, float
 //     all-zero on entry (the labelling kernel clears what it used).  grid (loop_grid(), chains of all clouds): a workgroup
 //     owns tiles blockIdx.x, blockIdx.x + gridDim.x, ... OWN_MAX of them per round (the host sizes gridDim.x so that one
 //     round usually does: loop_grid()); a workgroup whose tiles hold nothing of the list returns after one round of loads.
-constexpr int OWN_MAX = 8;
 static_assert(OWN_MAX * 32 == TPB, "32 lanes per owned tile");
 
-__global__ __launch_bounds__(TPB) void k_r_compact_raster(const RKArgs A, int k) {
-    __shared__ uint32_t s_w[TPB / 64];
-    __shared__ uint32_t s_pre[OWN_MAX], s_cnt[OWN_MAX];
-    const int g = blockIdx.y / R_B;
-    const uint32_t b = blockIdx.y % R_B;
-    if (g >= (int)A.ng) return;
+// one workgroup of a chain's own grid: number vx_i of vx (virtual grid: the kernel below)
+__device__ __forceinline__ void compact_raster_wg(const RKArgs &A, int k, int g, uint32_t b, uint32_t vx_i, uint32_t vx, uint32_t *s_w,
+                                                  uint32_t *s_pre, uint32_t *s_cnt) {
     const RCloudArgsK &C = cloud_args(A, g);
-    const uint32_t nb = C.L.nb;
     RState *S = C.st;
+    const uint32_t nb = cdiv_d(scan_n(C, S), TILE);   // tiles of what the mark pass scanned (it wrote no count beyond them)
     const ChainPtr ch = chain_of(C, b);
     PlaneState *st = &ch.hdr->st[k];
-    // (fetched together: one round trip for the workgroups that have nothing to do)
-    const uint32_t nc = S->nc, conv = st->converged, tot_early = ch.agg->tot;
-    const bool lead = blockIdx.x == 0;
-    if ((b >= nc) | (conv != 0u) | (!lead && tot_early == 0u)) return;
+    const uint32_t tot_early = ch.agg->tot;
+    const bool lead = vx_i == 0;
     const float fr[9] = {st->pos[0], st->pos[1], st->pos[2], st->a0[0], st->a0[1], st->a0[2], st->a1[0], st->a1[1], st->a1[2]};
     const float eps = S->bitmap_eps;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1159,9 +1198,9 @@ __global__ __launch_bounds__(TPB) void k_r_compact_raster(const RKArgs A, int k)
     }
     if (!ok || tot == 0) return;
     const float mnu = bbv[0], mnv = bbv[1];
-    for (uint32_t t0 = blockIdx.x; t0 < nb; t0 += gridDim.x * OWN_MAX) {
+    for (uint32_t t0 = vx_i; t0 < nb; t0 += vx * OWN_MAX) {
         // the owned tiles' counts, and for the non-empty ones the number of list entries in front of them
-        const uint32_t my_tile = t0 + (uint32_t)oj * gridDim.x;
+        const uint32_t my_tile = t0 + (uint32_t)oj * vx;
         const uint32_t my_cnt = my_tile < nb ? ch.bc1[my_tile] : 0u;
         uint32_t part = 0;
         if (my_cnt) {
@@ -1175,7 +1214,7 @@ __global__ __launch_bounds__(TPB) void k_r_compact_raster(const RKArgs A, int k)
         if (ol == 0) { s_pre[oj] = part; s_cnt[oj] = my_cnt; }
         __syncthreads();
         for (int j = 0; j < OWN_MAX; ++j) {
-            const uint32_t tile = t0 + j * gridDim.x;
+            const uint32_t tile = t0 + j * vx;
             if (tile >= nb) break;
             if (s_cnt[j] == 0) continue;   // uniform; most tiles of a plane's score list are empty
             const uint32_t m = ch.masks1[tile * TPB + threadIdx.x];
@@ -1219,6 +1258,30 @@ __global__ __launch_bounds__(TPB) void k_r_compact_raster(const RKArgs A, int k)
                     ++off;
                 }
         }
+    }
+}
+
+
+__global__ __launch_bounds__(TPB) void k_r_compact_raster(const RKArgs A, int k) {
+    __shared__ uint32_t s_w[TPB / 64];
+    __shared__ uint32_t s_pre[OWN_MAX], s_cnt[OWN_MAX];
+    __shared__ uint32_t s_start[CH_E + 1], s_carry;
+    // what every chain needs: nothing (no such chain / converged), its lead workgroup alone (an empty list: the slot's state is
+    // still written), or the grid that covers the view's tiles in one round
+    const uint32_t total = chain_grid_build(A, s_start, &s_carry, [&](uint32_t g, uint32_t b) -> uint32_t {
+        const RCloudArgsK &C = cloud_args(A, g);
+        const RState *S = C.st;
+        if (b >= S->nc) return 0u;
+        const ChainPtr ch = chain_of(C, b);
+        if (ch.hdr->st[k].converged) return 0u;
+        if (ch.agg->tot == 0u) return 1u;
+        const uint32_t nbv = cdiv_d(scan_n(C, S), TILE);
+        return max(1u, min(loop_grid(nbv), nbv));
+    });
+    for (uint32_t vt = blockIdx.x; vt < total; vt += gridDim.x) {
+        const uint32_t e = __builtin_amdgcn_readfirstlane(chain_grid_find(s_start, vt));   // (uniform: the table's loads stay scalar)
+        __syncthreads();   // the previous virtual workgroup's readers of the LDS arrays are done
+        compact_raster_wg(A, k, (int)(e / R_B), e % R_B, vt - s_start[e], s_start[e + 1] - s_start[e], s_w, s_pre, s_cnt);
     }
 }
 
@@ -1400,19 +1463,12 @@ __device__ __forceinline__ double wave_reduce_cols(const double (&a)[FIT_COLS], 
 // positions + per-tile counts).  The same pass accumulates, over the kept points, the LS-fit moments (12 sums),
 // Candidate::WeightedScore (ransac/Candidate.cpp:77-87 with weigh(), ScoreComputer.h:10-16) of the slot's plane and the
 // kept count: one row of FIT_COLS doubles per 1024 list positions, reduced by k_r_fit in a fixed order.
-__global__ __launch_bounds__(TPB) void k_r_select_cc(const RKArgs A, int k) {
-    __shared__ uint32_t s_w[4];
-    __shared__ double s[4][FIT_COLS];
-    const int g = blockIdx.y / R_B;
-    const uint32_t b = blockIdx.y % R_B;
-    if (g >= (int)A.ng) return;
+__device__ __forceinline__ void select_cc_wg(const RKArgs &A, int k, int g, uint32_t b, uint32_t vx_i, uint32_t vx, uint32_t *s_w,
+                                             double (*s)[FIT_COLS]) {
     const RCloudArgsK &C = cloud_args(A, g);
     const ChainPtr ch = chain_of(C, b);
     const PlaneState *st = &ch.hdr->st[k];
-    // everything the decision to leave needs is fetched together (the addresses come from the kernel arguments): one round trip
-    // for the many workgroups that have nothing to do instead of three dependent ones
-    const uint32_t nc = C.st->nc, conv = st->converged, serr = st->err, m = st->n_list, best = st->best_root;
-    if ((b >= nc) | (conv != 0u) | (serr != 0u) | ((uint64_t)blockIdx.x * 1024u >= m)) return;
+    const uint32_t m = st->n_list, best = st->best_root;
     const ScanSrc c = scan_src(C, C.st);       // the list entries are positions in what the mark pass scanned
     const float eps = C.st->eps3;
     const uint32_t *__restrict__ label = ch.label, *__restrict__ idx = ch.idxA(k);
@@ -1422,9 +1478,9 @@ __global__ __launch_bounds__(TPB) void k_r_select_cc(const RKArgs A, int k) {
     const float fr[9] = {st->pos[0], st->pos[1], st->pos[2], st->a0[0], st->a0[1], st->a0[2], st->a1[0], st->a1[1], st->a1[2]};
     const float mnu = st->bb[0], mnv = st->bb[1], beps = C.st->bitmap_eps;
     const int ue = (int)st->ue, ve = (int)st->ve;
-    // rows of 1024 list positions: this workgroup takes rows blockIdx.x, blockIdx.x + gridDim.x, ... (k_r_fit reads
+    // rows of 1024 list positions: workgroup vx_i of the chain's vx takes rows vx_i, vx_i + vx, ... (k_r_fit reads
     // ceil(m / 1024) rows)
-    for (uint32_t row = blockIdx.x; row * 1024u < m; row += gridDim.x) {
+    for (uint32_t row = vx_i; row * 1024u < m; row += vx) {
     const uint32_t base = row * 1024 + threadIdx.x * 4;
     uint32_t mk = 0, cnt = 0;
     double a[FIT_COLS];
@@ -1480,6 +1536,26 @@ __global__ __launch_bounds__(TPB) void k_r_select_cc(const RKArgs A, int k) {
     if (threadIdx.x == 0) ch.bc2(k)[row] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
     if (threadIdx.x < FIT_COLS)
         ch.part[(size_t)row * FIT_COLS + threadIdx.x] = (s[0][threadIdx.x] + s[1][threadIdx.x]) + (s[2][threadIdx.x] + s[3][threadIdx.x]);
+    }
+}
+
+
+__global__ __launch_bounds__(TPB) void k_r_select_cc(const RKArgs A, int k) {
+    __shared__ uint32_t s_w[4];
+    __shared__ double s[4][FIT_COLS];
+    __shared__ uint32_t s_start[CH_E + 1], s_carry;
+    // a chain's grid: one workgroup per row of 1024 list positions, at most loop_grid(tiles of its cloud) of them
+    const uint32_t total = chain_grid_build(A, s_start, &s_carry, [&](uint32_t g, uint32_t b) -> uint32_t {
+        const RCloudArgsK &C = cloud_args(A, g);
+        if (b >= C.st->nc) return 0u;
+        const PlaneState *st = &chain_of(C, b).hdr->st[k];
+        if (st->converged | st->err) return 0u;
+        return min(loop_grid(C.L.nb), cdiv_d(st->n_list, 1024u));
+    });
+    for (uint32_t vt = blockIdx.x; vt < total; vt += gridDim.x) {
+        const uint32_t e = __builtin_amdgcn_readfirstlane(chain_grid_find(s_start, vt));
+        __syncthreads();
+        select_cc_wg(A, k, (int)(e / R_B), e % R_B, vt - s_start[e], s_start[e + 1] - s_start[e], s_w, s);
     }
 }
 
@@ -1553,6 +1629,11 @@ __global__ __launch_bounds__(256) void k_r_fit(const RKArgs A, int k) {
     const double m = a[13];
     cur->n_kept = (uint32_t)m;
     if (!nxt) return;
+    // The reference's refit loop ends at the first refit whose weighted score does not beat its predecessor's
+    // (RansacShapeDetector.cpp:633-655; k_r_decide replays exactly that on the slots' results): no later slot of this chain is
+    // ever looked at, so they are flagged like the slots of a converged chain and their kernels return at once.  (On the bench's
+    // 64 pairs a quarter of the chains stop at refit 1 or 2.)
+    if (k >= 1 && !(a[12] > ch.hdr->st[k - 1].wscore)) { *nxt = *cur; nxt->converged = 1; nxt->err = 0; return; }
     nxt->err = 0;
     nxt->converged = 0;
     nxt->n_list = nxt->n_kept = 0;
@@ -1775,15 +1856,11 @@ __global__ __launch_bounds__(DEC_T) void k_r_decide(const RKArgs A) {
 
 // Point removal + output index lists of the accepted candidates: the chosen slot's list entries that belong to the
 // largest component, in list order (ordered compaction of the selection masks; offsets from the per-row counts as in
-// k_r_compact_raster).  grid (loop_grid(), jobs of all clouds)
-__global__ __launch_bounds__(TPB) void k_r_assign(const RKArgs A) {
-    __shared__ uint32_t s_pre[OWN_MAX][TPB / 64], s_w[TPB / 64];
-    const int g = blockIdx.y / R_B;
-    const uint32_t j = blockIdx.y % R_B;
-    if (g >= (int)A.ng) return;
+// k_r_compact_raster).  Virtual grid over the jobs of all clouds.
+__device__ __forceinline__ void assign_wg(const RKArgs &A, int g, uint32_t j, uint32_t vx_i, uint32_t vx, uint32_t (*s_pre)[TPB / 64],
+                                          uint32_t *s_w) {
     const RCloudArgsK &C = cloud_args(A, g);
     const RState *S = C.st;
-    if (j >= S->aj_n) return;
     const int k = (int)S->aj_slot[j];
     const ChainPtr ch = chain_of(C, S->aj_chain[j]);
     const uint32_t m = ch.hdr->st[k].n_list;
@@ -1796,14 +1873,14 @@ __global__ __launch_bounds__(TPB) void k_r_assign(const RKArgs A) {
     int32_t *__restrict__ out = out_off == 0xffffffffu ? nullptr : C.out_idx + out_off;
     const uint32_t *__restrict__ vmap = scan_src(C, S).map;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (uint32_t r0 = blockIdx.x; r0 < rows; r0 += gridDim.x * OWN_MAX) {
+    for (uint32_t r0 = vx_i; r0 < rows; r0 += vx * OWN_MAX) {
         uint32_t pre[OWN_MAX];
 #pragma unroll
         for (int q = 0; q < OWN_MAX; ++q) pre[q] = 0;
         for (uint32_t q = threadIdx.x; q < rows; q += TPB) {
             const uint32_t c = bc[q];
 #pragma unroll
-            for (int o = 0; o < OWN_MAX; ++o) pre[o] += q < r0 + o * gridDim.x ? c : 0u;
+            for (int o = 0; o < OWN_MAX; ++o) pre[o] += q < r0 + o * vx ? c : 0u;
         }
         for (int d = 32; d >= 1; d >>= 1) {
 #pragma unroll
@@ -1816,7 +1893,7 @@ __global__ __launch_bounds__(TPB) void k_r_assign(const RKArgs A) {
         }
         __syncthreads();
         for (int o = 0; o < OWN_MAX; ++o) {
-            const uint32_t row = r0 + o * gridDim.x;
+            const uint32_t row = r0 + o * vx;
             if (row >= rows) break;
             if (bc[row] == 0) continue;   // uniform
             const uint32_t mk = masks[row * TPB + threadIdx.x];
@@ -1850,6 +1927,25 @@ __global__ __launch_bounds__(TPB) void k_r_assign(const RKArgs A) {
                     ++off;
                 }
         }
+    }
+}
+
+
+__global__ __launch_bounds__(TPB) void k_r_assign(const RKArgs A) {
+    __shared__ uint32_t s_pre[OWN_MAX][TPB / 64], s_w[TPB / 64];
+    __shared__ uint32_t s_start[CH_E + 1], s_carry;
+    // a removal job's grid: one workgroup per row of its slot's list, at most loop_grid(tiles of its cloud)
+    const uint32_t total = chain_grid_build(A, s_start, &s_carry, [&](uint32_t g, uint32_t j) -> uint32_t {
+        const RCloudArgsK &C = cloud_args(A, g);
+        const RState *S = C.st;
+        if (j >= S->aj_n) return 0u;
+        const uint32_t m = chain_of(C, S->aj_chain[j]).hdr->st[S->aj_slot[j]].n_list;
+        return min(loop_grid(C.L.nb), cdiv_d(m, 1024u));
+    });
+    for (uint32_t vt = blockIdx.x; vt < total; vt += gridDim.x) {
+        const uint32_t e = __builtin_amdgcn_readfirstlane(chain_grid_find(s_start, vt));
+        __syncthreads();
+        assign_wg(A, (int)(e / R_B), e % R_B, vt - s_start[e], s_start[e + 1] - s_start[e], s_pre, s_w);
     }
 }
 
@@ -2293,7 +2389,6 @@ void args_commit(plade_ctx *ctx, RansacWork &W, RArgs &A) {
     }
 }
 
-inline uint32_t loop_grid(uint32_t nb) { return std::min(1024u, std::max(32u, cdiv(nb, OWN_MAX))); }
 
 // one iteration of the detect loop: 30 launches (32 without the top-up rule)
 void enqueue_iteration(plade_ctx *ctx, const RArgs &A) {
@@ -2325,13 +2420,13 @@ void enqueue_iteration(plade_ctx *ctx, const RArgs &A) {
         ctx->ev_begin("score_mark", 0.0);
         hipLaunchKernelGGL(k_r_mark, dim3(tiles), dim3(TPB), 0, st, A, k, ctx->ev_clock());
         ctx->ev_end();
-        hipLaunchKernelGGL(k_r_compact_raster, dim3(loop_grid(nb_max), R_B * ng), dim3(TPB), 0, st, A, k);
+        hipLaunchKernelGGL(k_r_compact_raster, dim3(std::min(VGRID_WGS, loop_grid(nb_max) * R_B * ng)), dim3(TPB), 0, st, A, k);
         hipLaunchKernelGGL(k_r_label, dim3(R_B * ng), dim3(1024), 0, st, A, k, 1);
-        hipLaunchKernelGGL(k_r_select_cc, dim3(loop_grid(nb_max), R_B * ng), dim3(TPB), 0, st, A, k);
+        hipLaunchKernelGGL(k_r_select_cc, dim3(std::min(VGRID_WGS, loop_grid(nb_max) * R_B * ng)), dim3(TPB), 0, st, A, k);
         hipLaunchKernelGGL(k_r_fit, dim3(R_B * ng), dim3(256), 0, st, A, k);
     }
     hipLaunchKernelGGL(k_r_decide, dim3(ng), dim3(DEC_T), 0, st, A);
-    hipLaunchKernelGGL(k_r_assign, dim3(loop_grid(nb_max), R_B * ng), dim3(TPB), 0, st, A);
+    hipLaunchKernelGGL(k_r_assign, dim3(std::min(VGRID_WGS, loop_grid(nb_max) * R_B * ng)), dim3(TPB), 0, st, A);
     // the scan view of the next iteration: the points this one left
     hipLaunchKernelGGL(k_view_count, dim3(tiles), dim3(TPB), 0, st, A);
     hipLaunchKernelGGL(k_view_compact, dim3(tiles), dim3(TPB), 0, st, A);
@@ -2675,11 +2770,11 @@ void plane_component(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, const
                        make_float4(point[0], point[1], point[2], 0.f), w_eps, bitmap_eps);
     const uint32_t nb = s.L.nb;
     hipLaunchKernelGGL(k_r_list_mark, dim3(nb), dim3(TPB), 0, st, A, m);
-    hipLaunchKernelGGL(k_r_compact_raster, dim3(loop_grid(nb), R_B), dim3(TPB), 0, st, A, 0);
+    hipLaunchKernelGGL(k_r_compact_raster, dim3(std::min(VGRID_WGS, loop_grid(nb))), dim3(TPB), 0, st, A, 0);
     hipLaunchKernelGGL(k_r_label, dim3(R_B), dim3(1024), 0, st, A, 0, closing_filter ? 1 : 0);
-    hipLaunchKernelGGL(k_r_select_cc, dim3(loop_grid(nb), R_B), dim3(TPB), 0, st, A, 0);
+    hipLaunchKernelGGL(k_r_select_cc, dim3(std::min(VGRID_WGS, loop_grid(nb))), dim3(TPB), 0, st, A, 0);
     hipLaunchKernelGGL(k_r_fit, dim3(R_B), dim3(256), 0, st, A, 0);
-    hipLaunchKernelGGL(k_r_assign, dim3(loop_grid(nb), R_B), dim3(TPB), 0, st, A);
+    hipLaunchKernelGGL(k_r_assign, dim3(std::min(VGRID_WGS, loop_grid(nb))), dim3(TPB), 0, st, A);
     PlaneState hst[2];
     ctx->d2h(hst, s.fixed.p, 2 * sizeof(PlaneState));   // chain 0's header
     ctx->sync(st);
@@ -2835,7 +2930,7 @@ void score_planes_seam(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, con
         const uint32_t nb = std::min((uint32_t)R_B, h - h0);
         hipLaunchKernelGGL(k_r_seam_chains, dim3(1), dim3(64), 0, st, A, d_planes.p + h0, nb, eps, cos_t);
         hipLaunchKernelGGL(k_r_mark, dim3(tiles), dim3(TPB), 0, st, A, 0, (unsigned long long *)nullptr);
-        hipLaunchKernelGGL(k_r_compact_raster, dim3(loop_grid(tiles), R_B), dim3(TPB), 0, st, A, 0);
+        hipLaunchKernelGGL(k_r_compact_raster, dim3(std::min(VGRID_WGS, loop_grid(tiles) * R_B)), dim3(TPB), 0, st, A, 0);
         hipLaunchKernelGGL(k_r_label, dim3(R_B), dim3(1024), 0, st, A, 0, 0);
         PlaneState hst[R_B];
         for (uint32_t b = 0; b < nb; ++b)
