@@ -491,6 +491,32 @@ __device__ __forceinline__ uint32_t chain_grid_find(const uint32_t *s_start, uin
     return lo;
 }
 
+// The scan kernels' virtual grid: the concatenation of what the clouds that take part in THIS launch really have to be scanned
+// over -- the tiles of their current views (a third of the cloud in the second iteration, a sixth in the third, ...) instead of
+// the tiles of all clouds of the sequence (the launch used to be that: workgroups of finished clouds and of the tiles beyond a
+// view returned at once, but they had to be dispatched).  One lane per cloud fills the table.
+template <class F>
+__device__ __forceinline__ uint32_t scan_grid_build(const RKArgs &A, uint32_t *s_start /* R_G + 1 */, F units) {
+    static_assert(R_G <= 64, "one lane of the first wavefront per cloud");
+    const uint32_t g = threadIdx.x;
+    if (g < 64) {
+        const uint32_t n = (g < (uint32_t)R_G && g < A.ng) ? units(g) : 0u;
+        uint32_t incl = n;
+#pragma unroll
+        for (int d = 1; d < R_G; d <<= 1) { const uint32_t o = __shfl_up(incl, d, 64); if (g >= (uint32_t)d) incl += o; }
+        if (g < (uint32_t)R_G) s_start[g + 1] = incl;
+        if (g == 0) s_start[0] = 0;
+    }
+    __syncthreads();
+    return s_start[R_G];
+}
+__device__ __forceinline__ int scan_grid_find(const uint32_t *s_start, uint32_t vt) {   // g with start[g] <= vt < start[g + 1]
+    int g = 0;
+#pragma unroll
+    for (int q = 1; q < R_G; ++q) g += vt >= s_start[q] ? 1 : 0;
+    return g;
+}
+
 __device__ __forceinline__ void hcs_axes(const float *n, float *a0, float *a1) {
     float t[3];
     if (fabsf(n[0]) < 0.015625f && fabsf(n[1]) < 0.015625f) {  // (0,1,0) x n
@@ -715,24 +741,34 @@ __device__ __forceinline__ unsigned long long slab_mask(const Tile &t, const flo
 }
 
 // K1 on the stratified subset: grid (subset tiles, hypothesis chunks, clouds)
+// (virtual grid: subset tiles x hypothesis chunks of the clouds that are sampling)
 __global__ __launch_bounds__(TPB) void k_r_score_sub(const RKArgs A) {
     __shared__ float4 s_pl[HCHUNK];
     __shared__ uint32_t s_cnt[TPB / 64][HCHUNK];
-    const RCloudArgsK &C = cloud_args(A, blockIdx.z);
+    __shared__ uint32_t s_start[R_G + 1];
+    const uint32_t total = scan_grid_build(A, s_start, [&](uint32_t g) -> uint32_t {
+        const RCloudArgsK &C = cloud_args(A, g);
+        const RState *S = C.st;
+        return (S->done || !S->sampling) ? 0u : cdiv_d(C.n_sub, TILE) * (R_H / HCHUNK);
+    });
+    for (uint32_t vt = blockIdx.x; vt < total; vt += gridDim.x) {
+    const int g = __builtin_amdgcn_readfirstlane(scan_grid_find(s_start, vt));
+    __syncthreads();   // the previous round's readers of the LDS arrays are done
+    const RCloudArgsK &C = cloud_args(A, g);
     RState *S = C.st;
-    if (S->done || !S->sampling) return;
-    if (blockIdx.x * TILE >= C.n_sub) return;
-    const uint32_t h0 = blockIdx.y * HCHUNK;
+    const uint32_t sub_tiles = cdiv_d(C.n_sub, TILE), v = vt - s_start[g];
+    const uint32_t bx = v % sub_tiles, by = v / sub_tiles;
+    const uint32_t h0 = by * HCHUNK;
     if (threadIdx.x < HCHUNK) s_pl[threadIdx.x] = C.hyp[h0 + threadIdx.x];
     const size_t sp = C.sub_pitch;
     const float eps = S->eps, cos_t = S->cos_t;
     Tile t;
     load_tile(t, C.sub, C.sub + sp, C.sub + 2 * sp, C.sub + 3 * sp, C.sub + 4 * sp, C.sub + 5 * sp,
               C.sub_assigned ? C.sub_assigned : C.assigned, C.sub_assigned ? nullptr : C.sub_index, C.n_sub,
-              blockIdx.x * TILE + threadIdx.x * PPT);
+              bx * TILE + threadIdx.x * PPT);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (blockIdx.y == 0) {   // unassigned points of the subset (estimates the support on the whole cloud)
+    if (by == 0) {   // unassigned points of the subset (estimates the support on the whole cloud)
         uint32_t un = 0;
 #pragma unroll
         for (int k = 0; k < PPT; ++k) un += (uint32_t)__popcll(__ballot(t.valid[k]));
@@ -757,6 +793,7 @@ __global__ __launch_bounds__(TPB) void k_r_score_sub(const RKArgs A) {
     if (threadIdx.x < HCHUNK) {
         const uint32_t tot = s_cnt[0][threadIdx.x] + s_cnt[1][threadIdx.x] + s_cnt[2][threadIdx.x] + s_cnt[3][threadIdx.x];
         if (tot) atomicAdd(&C.hyp_counts[h0 + threadIdx.x], tot);
+    }
     }
 }
 
@@ -855,14 +892,22 @@ __global__ __launch_bounds__(TPB) void k_r_rescore(const RKArgs A, int phase, un
     const ClockScope clock_scope(clk);
     __shared__ float4 s_pl[HCHUNK];
     __shared__ uint32_t s_cnt[TPB / 64][HCHUNK];
-    uint32_t tile;
-    const int g = scan_group(A, tile);
+    __shared__ uint32_t s_start[R_G + 1];
+    // virtual grid: the view tiles of the clouds whose pool is re-scored in this phase (at least one each: tile 0 keeps the launch counter)
+    const uint32_t total = scan_grid_build(A, s_start, [&](uint32_t g) -> uint32_t {
+        const RCloudArgsK &C = cloud_args(A, g);
+        const RState *S = C.st;
+        if (S->done || S->npool == 0 || (S->fresh != 0u) != (phase != 0)) return 0u;
+        return max(1u, cdiv_d(scan_n(C, S), TILE));
+    });
+    for (uint32_t vt = blockIdx.x; vt < total; vt += gridDim.x) {
+    const int g = __builtin_amdgcn_readfirstlane(scan_grid_find(s_start, vt));
+    const uint32_t tile = vt - s_start[g];
+    __syncthreads();   // the previous round's readers of the LDS arrays are done
     const RCloudArgsK &C = cloud_args(A, g);
     RState *S = C.st;
     const uint32_t np = S->npool;
-    if (S->done || np == 0 || (S->fresh != 0u) != (phase != 0)) return;
     const ScanSrc V = scan_src(C, S);
-    if (tile * TILE >= V.n && tile != 0) return;      // beyond the (compacted) view (tile 0 keeps the launch counter)
     if (threadIdx.x < np) s_pl[threadIdx.x] = S->pool_pl[threadIdx.x];
     const float eps = S->eps, cos_t = S->cos_t;
     Tile t;
@@ -892,6 +937,7 @@ __global__ __launch_bounds__(TPB) void k_r_rescore(const RKArgs A, int phase, un
         if (tot) atomicAdd(&S->pool_cnt[threadIdx.x], tot);
     }
     if (tile == 0 && threadIdx.x == 0) S->n_rescores[phase] += 1;
+    }
 }
 
 // CandidateFailureProbability (RansacShapeDetector.h:61-67, reqSamples = 3)
@@ -1021,12 +1067,20 @@ __global__ __launch_bounds__(TPB) void k_r_mark(const RKArgs A, int k, unsigned 
     __shared__ uint32_t s_skip[R_B], s_need[R_B];
     __shared__ uint32_t s_w[R_B][TPB / 64];
     __shared__ float s_bb[R_B][4][TPB / 64];
-    uint32_t tile;
-    const int g = scan_group(A, tile);
+    __shared__ uint32_t s_start[R_G + 1];
+    // virtual grid: the view tiles of the clouds that have chains in this iteration
+    const uint32_t total = scan_grid_build(A, s_start, [&](uint32_t g) -> uint32_t {
+        const RCloudArgsK &C = cloud_args(A, g);
+        const RState *S = C.st;
+        return S->nc == 0 ? 0u : max(1u, cdiv_d(scan_n(C, S), TILE));
+    });
+    for (uint32_t vt = blockIdx.x; vt < total; vt += gridDim.x) {
+    const int g = __builtin_amdgcn_readfirstlane(scan_grid_find(s_start, vt));
+    const uint32_t tile = vt - s_start[g];
+    __syncthreads();   // the previous round's readers of the LDS arrays are done
     const RCloudArgsK &C = cloud_args(A, g);
     RState *S = C.st;
     const uint32_t nc = S->nc;
-    if (nc == 0) return;
     if (threadIdx.x < nc) {
         const PlaneState *st = &chain_of(C, threadIdx.x).hdr->st[k];
         s_skip[threadIdx.x] = st->converged;
@@ -1059,7 +1113,7 @@ __global__ __launch_bounds__(TPB) void k_r_mark(const RKArgs A, int k, unsigned 
     if (needed == 0) {   // uniform: no slab reaches this tile (about half of all (tile, launch) pairs): nothing is loaded
         if (threadIdx.x < nc && !s_skip[threadIdx.x]) chain_of(C, threadIdx.x).bc1[tile] = 0u;
         if (tile == 0 && threadIdx.x == 0 && active) { S->n_mark_launches += 1; S->n_mark_chains += active; }
-        return;
+        continue;
     }
     Tile t;
     load_tile(t, V.x, V.y, V.z, V.nx, V.ny, V.nz, V.map ? nullptr : C.assigned, nullptr, V.n, tile * TILE + threadIdx.x * PPT);
@@ -1103,6 +1157,7 @@ __global__ __launch_bounds__(TPB) void k_r_mark(const RKArgs A, int k, unsigned 
                     fmaxf(fmaxf(s_bb[j][3][0], s_bb[j][3][1]), fmaxf(s_bb[j][3][2], s_bb[j][3][3])));
     }
     if (tile == 0 && threadIdx.x == 0 && active) { S->n_mark_launches += 1; S->n_mark_chains += active; }
+    }
 }
 
 // seam S1c: the score list is given by the caller.  Same outputs as k_r_mark for chain 0 over LIST POSITIONS
@@ -1959,13 +2014,19 @@ __global__ __launch_bounds__(TPB) void k_r_assign(const RKArgs A) {
 // compaction does), commit (flip the view, clear the sums).  Nothing to do (view_dirty = 0): the workgroups return at once.
 __global__ __launch_bounds__(TPB) void k_view_count(const RKArgs A) {
     __shared__ uint32_t s_w[TPB / 64];
-    uint32_t tile;
-    const int g = scan_group(A, tile);
+    __shared__ uint32_t s_start[R_G + 1];
+    const uint32_t total = scan_grid_build(A, s_start, [&](uint32_t g) -> uint32_t {   // virtual grid: the tiles of the views that are rebuilt
+        const RCloudArgsK &C = cloud_args(A, g);
+        const RState *S = C.st;
+        return (!C.view[0] || !S->view_dirty || S->done) ? 0u : cdiv_d(scan_n(C, S), TILE);
+    });
+    for (uint32_t vt = blockIdx.x; vt < total; vt += gridDim.x) {
+    const int g = __builtin_amdgcn_readfirstlane(scan_grid_find(s_start, vt));
+    const uint32_t tile = vt - s_start[g];
+    __syncthreads();
     const RCloudArgsK &C = cloud_args(A, g);
     RState *S = C.st;
-    if (!C.view[0] || !S->view_dirty || S->done) return;
     const ScanSrc V = scan_src(C, S);
-    if (tile * TILE >= V.n) return;
     const uint32_t first = tile * TILE + threadIdx.x * PPT;
     uint32_t c = 0;
 #pragma unroll
@@ -1980,20 +2041,29 @@ __global__ __launch_bounds__(TPB) void k_view_count(const RKArgs A) {
     if (threadIdx.x == 0) {
         const uint32_t tot = s_w[0] + s_w[1] + s_w[2] + s_w[3];
         C.view_cnt[tile] = tot;
-        if (tot) { atomicAdd(&C.view_sup[tile >> SUP_SHIFT], tot); atomicAdd(&S->view_next_n, tot); }
+        // (the view's new length is the sum of the supertile sums, taken by k_view_commit: an atomic per tile on ONE word per cloud
+        //  -- ~1000 of them in the first iteration -- was most of this kernel's duration)
+        if (tot) atomicAdd(&C.view_sup[tile >> SUP_SHIFT], tot);
+    }
     }
 }
 
 __global__ __launch_bounds__(TPB) void k_view_compact(const RKArgs A) {
     __shared__ uint32_t s_w[TPB / 64], s_pre;
-    uint32_t tile;
-    const int g = scan_group(A, tile);
+    __shared__ uint32_t s_start[R_G + 1];
+    const uint32_t total = scan_grid_build(A, s_start, [&](uint32_t g) -> uint32_t {
+        const RCloudArgsK &C = cloud_args(A, g);
+        const RState *S = C.st;
+        return (!C.view[0] || !S->view_dirty || S->done) ? 0u : cdiv_d(scan_n(C, S), TILE);
+    });
+    for (uint32_t vt = blockIdx.x; vt < total; vt += gridDim.x) {
+    const int g = __builtin_amdgcn_readfirstlane(scan_grid_find(s_start, vt));
+    const uint32_t tile = vt - s_start[g];
+    __syncthreads();
     const RCloudArgsK &C = cloud_args(A, g);
     const RState *S = C.st;
-    if (!C.view[0] || !S->view_dirty || S->done) return;
     const ScanSrc V = scan_src(C, S);
-    if (tile * TILE >= V.n) return;
-    if (C.view_cnt[tile] == 0) return;   // uniform
+    if (C.view_cnt[tile] == 0) continue;   // uniform
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // entries in front of this tile: complete supertiles + the tiles of its own supertile before it
     uint32_t part = 0;
@@ -2038,18 +2108,23 @@ __global__ __launch_bounds__(TPB) void k_view_compact(const RKArgs A) {
             dmap[off] = pos[q];
             ++off;
         }
+    }
 }
 
 __global__ __launch_bounds__(256) void k_view_commit(const RKArgs A) {
     const RCloudArgsK &C = cloud_args(A, blockIdx.x);
     RState *S = C.st;
     if (!C.view[0] || !S->view_dirty || S->done) { if (C.view[0] && threadIdx.x == 0 && S->view_dirty) S->view_dirty = 0; return; }
-    const uint32_t ntiles = (S->view_n + TILE - 1) / TILE;
-    for (uint32_t q = threadIdx.x; q < (ntiles >> SUP_SHIFT) + 1; q += blockDim.x) C.view_sup[q] = 0u;
+    __shared__ uint32_t s_sum[256 / 64];
+    const uint32_t ntiles = (scan_n(C, S) + TILE - 1) / TILE;
+    uint32_t sum = 0;
+    for (uint32_t q = threadIdx.x; q < (ntiles >> SUP_SHIFT) + 1; q += blockDim.x) { sum += C.view_sup[q]; C.view_sup[q] = 0u; }
+    for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d, 64);
+    if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6] = sum;
     __syncthreads();
     if (threadIdx.x == 0) {
         S->view_sel = S->view_sel == 1u ? 2u : 1u;
-        S->view_n = S->view_next_n;
+        S->view_n = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];   // the survivors counted by k_view_count
         S->view_next_n = 0;
         S->view_dirty = 0;
     }
@@ -2404,21 +2479,21 @@ void enqueue_iteration(plade_ctx *ctx, const RArgs &A) {
     // goes into the new round instead and these two launches are not part of the sequence)
     if (!A.topup) {
         ctx->ev_begin("score_multi", 0.0);
-        hipLaunchKernelGGL(k_r_rescore, dim3(tiles), dim3(TPB), 0, st, A, 0, ctx->ev_clock());
+        hipLaunchKernelGGL(k_r_rescore, dim3(std::min(VGRID_WGS, tiles)), dim3(TPB), 0, st, A, 0, ctx->ev_clock());
         ctx->ev_end();
         hipLaunchKernelGGL(k_r_select, dim3(ng), dim3(64), 0, st, A, 0);
     }
     // ... and if nothing is left (or at the start), a new round: sample, score on the subset, leaders, re-score, batch
     hipLaunchKernelGGL(k_r_sample, dim3(cdiv(R_H, 256), ng), dim3(256), 0, st, A);
-    hipLaunchKernelGGL(k_r_score_sub, dim3(sub_tiles, R_H / HCHUNK, ng), dim3(TPB), 0, st, A);
+    hipLaunchKernelGGL(k_r_score_sub, dim3(std::min(VGRID_WGS, sub_tiles * (R_H / HCHUNK) * ng)), dim3(TPB), 0, st, A);
     hipLaunchKernelGGL(k_r_leaders, dim3(ng), dim3(1024), 0, st, A);
     ctx->ev_begin("score_multi", 0.0);
-    hipLaunchKernelGGL(k_r_rescore, dim3(tiles), dim3(TPB), 0, st, A, 1, ctx->ev_clock());
+    hipLaunchKernelGGL(k_r_rescore, dim3(std::min(VGRID_WGS, tiles)), dim3(TPB), 0, st, A, 1, ctx->ev_clock());
     ctx->ev_end();
     hipLaunchKernelGGL(k_r_select, dim3(ng), dim3(64), 0, st, A, 1);
     for (int k = 0; k < 4; ++k) {
         ctx->ev_begin("score_mark", 0.0);
-        hipLaunchKernelGGL(k_r_mark, dim3(tiles), dim3(TPB), 0, st, A, k, ctx->ev_clock());
+        hipLaunchKernelGGL(k_r_mark, dim3(std::min(VGRID_WGS, tiles)), dim3(TPB), 0, st, A, k, ctx->ev_clock());
         ctx->ev_end();
         hipLaunchKernelGGL(k_r_compact_raster, dim3(std::min(VGRID_WGS, loop_grid(nb_max) * R_B * ng)), dim3(TPB), 0, st, A, k);
         hipLaunchKernelGGL(k_r_label, dim3(R_B * ng), dim3(1024), 0, st, A, k, 1);
@@ -2428,8 +2503,8 @@ void enqueue_iteration(plade_ctx *ctx, const RArgs &A) {
     hipLaunchKernelGGL(k_r_decide, dim3(ng), dim3(DEC_T), 0, st, A);
     hipLaunchKernelGGL(k_r_assign, dim3(std::min(VGRID_WGS, loop_grid(nb_max) * R_B * ng)), dim3(TPB), 0, st, A);
     // the scan view of the next iteration: the points this one left
-    hipLaunchKernelGGL(k_view_count, dim3(tiles), dim3(TPB), 0, st, A);
-    hipLaunchKernelGGL(k_view_compact, dim3(tiles), dim3(TPB), 0, st, A);
+    hipLaunchKernelGGL(k_view_count, dim3(std::min(VGRID_WGS, tiles)), dim3(TPB), 0, st, A);
+    hipLaunchKernelGGL(k_view_compact, dim3(std::min(VGRID_WGS, tiles)), dim3(TPB), 0, st, A);
     hipLaunchKernelGGL(k_view_commit, dim3(ng), dim3(256), 0, st, A);
 }
 
@@ -2917,7 +2992,7 @@ void score_planes_seam(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, con
     for (uint32_t h0 = 0; h0 < h; h0 += R_TOP) {
         const uint32_t nh = std::min(R_TOP, h - h0);
         hipLaunchKernelGGL(k_r_seam_pool, dim3(1), dim3(64), 0, st, A, d_planes.p + h0, nh, eps, cos_t);
-        hipLaunchKernelGGL(k_r_rescore, dim3(tiles), dim3(TPB), 0, st, A, 1, (unsigned long long *)nullptr);
+        hipLaunchKernelGGL(k_r_rescore, dim3(std::min(VGRID_WGS, tiles)), dim3(TPB), 0, st, A, 1, (unsigned long long *)nullptr);
         HIP_TRY(hipMemcpyAsync(counts + h0, reinterpret_cast<const char *>(s.state.p) + offsetof(RState, pool_cnt), 4 * (size_t)nh,
                                hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
@@ -2929,7 +3004,7 @@ void score_planes_seam(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, con
     for (uint32_t h0 = 0; h0 < h; h0 += R_B) {
         const uint32_t nb = std::min((uint32_t)R_B, h - h0);
         hipLaunchKernelGGL(k_r_seam_chains, dim3(1), dim3(64), 0, st, A, d_planes.p + h0, nb, eps, cos_t);
-        hipLaunchKernelGGL(k_r_mark, dim3(tiles), dim3(TPB), 0, st, A, 0, (unsigned long long *)nullptr);
+        hipLaunchKernelGGL(k_r_mark, dim3(std::min(VGRID_WGS, tiles)), dim3(TPB), 0, st, A, 0, (unsigned long long *)nullptr);
         hipLaunchKernelGGL(k_r_compact_raster, dim3(std::min(VGRID_WGS, loop_grid(tiles) * R_B)), dim3(TPB), 0, st, A, 0);
         hipLaunchKernelGGL(k_r_label, dim3(R_B), dim3(1024), 0, st, A, 0, 0);
         PlaneState hst[R_B];
@@ -2972,7 +3047,7 @@ void score_subset_seam(plade_ctx *ctx, RansacWork &W, const CloudDev &cloud, con
     for (uint32_t h0 = 0; h0 < h; h0 += R_H) {
         const uint32_t nh = std::min(R_H, h - h0);
         hipLaunchKernelGGL(k_r_seam_hyps, dim3(cdiv(R_H, 256)), dim3(256), 0, st, A, d_planes.p + h0, nh, eps, cos_t);
-        hipLaunchKernelGGL(k_r_score_sub, dim3(cdiv(m, TILE), R_H / HCHUNK, 1), dim3(TPB), 0, st, A);
+        hipLaunchKernelGGL(k_r_score_sub, dim3(std::min(VGRID_WGS, cdiv(m, TILE) * (R_H / HCHUNK))), dim3(TPB), 0, st, A);
         HIP_TRY(hipMemcpyAsync(counts + h0, A.c[0].hyp_counts, 4 * (size_t)nh, hipMemcpyDeviceToHost, st));
         if (n_unassigned)
             HIP_TRY(hipMemcpyAsync(n_unassigned, reinterpret_cast<const char *>(s.state.p) + offsetof(RState, sub_unassigned), 4,
