@@ -52,8 +52,70 @@ __device__ void k_cell_ids(const VB &vb, const float *__restrict__ xyz, uint32_t
     int cx = min(max((int)floorf((x - g.mnx) * g.inv), 0), g.dx - 1);
     int cy = min(max((int)floorf((y - g.mny) * g.inv), 0), g.dy - 1);
     int cz = min(max((int)floorf((z - g.mnz) * g.inv), 0), g.dz - 1);
-    keys[i] = blocked ? (block_of(cx, cy, cz, g.dx, g.dy) << 6) | local_of(cx, cy, cz) : (uint32_t)(cx + g.dx * (cy + g.dy * cz));
+    // blocked = 2: the dense row index -- linear id in the grid padded by two cells on every side
+    if (blocked == 2) keys[i] = (uint32_t)(cx + 2) + (uint32_t)(g.dx + 4) * ((uint32_t)(cy + 2) + (uint32_t)(g.dy + 4) * (uint32_t)(cz + 2));
+    else keys[i] = blocked ? (block_of(cx, cy, cz, g.dx, g.dy) << 6) | local_of(cx, cy, cz) : (uint32_t)(cx + g.dx * (cy + g.dy * cz));
     vals[i] = i;
+}
+
+// dense row index, three small kernels behind the sort (no fill, no atomics, no scan):
+// (1) the points in cell order
+__device__ void k_dense_points(const VB &vb, const float *__restrict__ xyz, uint32_t stride, const uint32_t *__restrict__ vals, uint32_t n,
+                               float4 *__restrict__ sorted) {
+    const uint32_t i = vb.bx * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t v = vals[i];
+    sorted[i] = make_float4(xyz[(size_t)v * stride], xyz[(size_t)v * stride + 1], xyz[(size_t)v * stride + 2], __uint_as_float(v));
+}
+// (2) row_start[L] = number of sorted keys < L, for 256 consecutive L per workgroup: one uniform binary search for the first of them
+// (scalar loads), then the few keys that fall into the workgroup's 256 cells are counted in LDS and prefix-summed
+__device__ void k_row_table(const VB &vb, const uint32_t *__restrict__ keys, uint32_t n, uint32_t table_n, uint32_t *__restrict__ row_start) {
+    __shared__ uint32_t s_hist[256], s_w[4];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t L0 = vb.bx * 256u;
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (keys[mid] < L0) lo = mid + 1; else hi = mid; }
+    s_hist[tid] = 0u;
+    __syncthreads();
+    for (uint32_t j0 = lo;; j0 += 256u) {   // uniform
+        const uint32_t j = j0 + tid;
+        const uint32_t k = j < n ? keys[j] : 0xffffffffu;
+        const bool in = k - L0 < 256u;      // (k >= L0: the keys are sorted)
+        if (in) atomicAdd(&s_hist[k - L0], 1u);
+        if (!__syncthreads_and(in ? 1 : 0)) break;
+    }
+    const uint32_t c = s_hist[tid];
+    uint32_t incl = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d, 64); if (lane >= (uint32_t)d) incl += o; }
+    if (lane == 63u) s_w[wave] = incl;
+    __syncthreads();
+    uint32_t off = lo;
+    for (uint32_t w = 0; w < wave; ++w) off += s_w[w];
+    if (L0 + tid < table_n) row_start[L0 + tid] = off + incl - c;
+}
+// (3) the near mask: one lane per block of (1 << ms)^3 padded cells -- is any cell of the block widened by one cell occupied?
+// (rows of the widened block = differences of row_start)
+__device__ void k_near_mask(const VB &vb, const uint32_t *__restrict__ row_start, GridParams g, int ms, uint32_t n_blocks,
+                            uint32_t *__restrict__ mask) {
+    const uint32_t b = vb.bx * blockDim.x + threadIdx.x;
+    const int DX = g.dx + 4, DY = g.dy + 4, DZ = g.dz + 4, S = 1 << ms;
+    const int MBX = ((DX - 1) >> ms) + 1, MBY = ((DY - 1) >> ms) + 1;
+    bool occ = false;
+    if (b < n_blocks) {
+        const int bx = (int)(b % (uint32_t)MBX), by = (int)((b / (uint32_t)MBX) % (uint32_t)MBY), bz = (int)(b / ((uint32_t)MBX * (uint32_t)MBY));
+        const int x0 = max(bx * S - 1, 0), x1 = min(bx * S + S, DX - 1), y0 = max(by * S - 1, 0), y1 = min(by * S + S, DY - 1),
+                  z0 = max(bz * S - 1, 0), z1 = min(bz * S + S, DZ - 1);
+        for (int z = z0; z <= z1 && !occ; ++z)
+            for (int y = y0; y <= y1 && !occ; ++y) {
+                const uint32_t a = (uint32_t)DX * ((uint32_t)y + (uint32_t)DY * (uint32_t)z);
+                occ = row_start[a + (uint32_t)x1 + 1u] != row_start[a + (uint32_t)x0];
+            }
+    }
+    const unsigned long long m = __ballot(occ);
+    const uint32_t lane = threadIdx.x & 63u, w0 = (vb.bx * blockDim.x + (threadIdx.x & ~63u)) >> 5;
+    if (lane == 0) mask[w0] = (uint32_t)m;
+    if (lane == 32) mask[w0 + 1u] = (uint32_t)(m >> 32);
 }
 
 __device__ void k_gather_cells(const VB &vb, const float *__restrict__ xyz, uint32_t stride, const uint32_t *__restrict__ keys,
@@ -151,10 +213,33 @@ void TargetGrid::build(plade_ctx *ctx, const float *d_xyz, uint32_t n_pts, uint3
     }
     gp.mnx = init[0]; gp.mny = init[1]; gp.mnz = init[2];
     gp.inv = 1.f / cell;
-    ncells = compact ? (size_t)((gp.dx + 3) >> 2) * ((gp.dy + 3) >> 2) * ((gp.dz + 3) >> 2) * 64 : (size_t)gp.dx * gp.dy * gp.dz;
+    static const bool old_index = getenv("PLADE_OVERLAP_INDEX_COMPACT") != nullptr;   // A/B hook: the bitmap + rank index of rounds 3-5
+    dense = compact && !old_index;
     keys.ensure(n); keys2.ensure(n); vals.ensure(n); vals2.ensure(n);
     sorted.ensure(n);
     GridParams g{gp.mnx, gp.mny, gp.mnz, gp.inv, gp.dx, gp.dy, gp.dz};
+    if (dense) {
+        DX = gp.dx + 4; DY = gp.dy + 4; DZ = gp.dz + 4;
+        ncells = (size_t)DX * DY * DZ;                       // <= ~49e6 (the cap above): a table of <= 200 MB
+        const size_t table = (ncells + 8 + 15) & ~(size_t)15;   // row_start[a + 3] of the last row; whole 64-byte fills
+        for (mask_shift = 2;; ++mask_shift) {                // the near mask must fit 32 KB of LDS
+            const size_t mb = (size_t)(((DX - 1) >> mask_shift) + 1) * (((DY - 1) >> mask_shift) + 1) * (((DZ - 1) >> mask_shift) + 1);
+            mask_words = (uint32_t)((mb + 31) / 32);
+            if (mask_words * 4u <= (32u << 10)) break;
+        }
+        const uint32_t n_blocks = (uint32_t)((size_t)(((DX - 1) >> mask_shift) + 1) * (((DY - 1) >> mask_shift) + 1) * (((DZ - 1) >> mask_shift) + 1));
+        row_start.ensure(table + 256); near_mask.ensure((size_t)mask_words + 64);
+        launch<k_cell_ids, 256>(ctx, dim3(cdiv(n, 256)), 0, d_xyz, n, stride, g, 2, keys.p, vals.p);
+        int bits = 1;
+        while (((size_t)1 << bits) < ncells) ++bits;
+        sort_pairs_u32(ctx, keys.p, keys2.p, vals.p, vals2.p, n, bits);
+        launch<k_dense_points, 256>(ctx, dim3(cdiv(n, 256)), 0, d_xyz, stride, vals2.p, n, sorted.p);
+        launch<k_row_table, 256>(ctx, dim3(cdiv(table, 256)), 0, keys2.p, n, (uint32_t)table, row_start.p);
+        launch<k_near_mask, 256>(ctx, dim3(cdiv(n_blocks, 256)), 0, row_start.p, g, mask_shift, n_blocks, near_mask.p);
+        HIP_TRY(hipGetLastError());
+        return;
+    }
+    ncells = compact ? (size_t)((gp.dx + 3) >> 2) * ((gp.dy + 3) >> 2) * ((gp.dz + 3) >> 2) * 64 : (size_t)gp.dx * gp.dy * gp.dz;
     launch<k_cell_ids, 256>(ctx, dim3(cdiv(n, 256)), 0, d_xyz, n, stride, g, compact ? 1 : 0, keys.p,
                        vals.p);
     int bits = 1;
@@ -184,6 +269,9 @@ void TargetGrid::build(plade_ctx *ctx, const float *d_xyz, uint32_t n_pts, uint3
 }
 
 constexpr int OV_TPB = 256;
+#ifndef OVD_W
+#define OVD_W 5                      // wavefronts per SIMD the dense kernel is compiled for (= persistent workgroups per CU)
+#endif
 constexpr int OV_KCH = 16;             // candidates per chunk at most (few candidates: chunks of 2, so that ~10 candidates fill the GPU)
 constexpr uint32_t OV_MASK_MAX = 48u << 10;   // bytes of LDS the block mask may take (3.9e5 blocks = 2.5e7 cells); above: no mask
 
@@ -328,6 +416,100 @@ __device__ void k_overlap(const VB &vb, const float *__restrict__ sx, const floa
     if (cur != 0xffffffffu && threadIdx.x < kc && s_cnt[threadIdx.x]) atomicAdd(&counts[k0 + threadIdx.x], (int32_t)s_cnt[threadIdx.x]);
 }
 
+// (r5) The same counts over the dense row index (TargetGrid::dense).  The bitmap + rank form above spends ~1 900 vector instructions per
+// wavefront and candidate (rocprofv3 SQ_INSTS_VALU: eight predicated block words, eight wanted-cell masks in 64-bit arithmetic, cells
+// taken four at a time in nested loops that run as long as the slowest lane) and the SIMDs' vector pipes were ~80 % busy while it ran:
+// it was bound by instruction issue, not by memory.  Here a probe is: one LDS bit (the near mask), nine 4-word table reads (row a of
+// three cells = the contiguous run [row_start[a], row_start[a + 3]) of the sorted points), the first point of every run fetched
+// together, the rest of a run one after the other -- a row of three cells of a voxel-downsampled surface holds 0-4 points.  Same
+// points, same fp32 distances, same strict comparisons: the counts are the bits of the other form (and of the oracle).
+__device__ void k_overlap_dense(const VB &vb, const float *__restrict__ sx, const float *__restrict__ sy, const float *__restrict__ sz,
+                                uint32_t n_s, const float4 *__restrict__ tgt, const uint32_t *__restrict__ row_start,
+                                const uint32_t *__restrict__ near_mask, uint32_t mask_words, int ms, GridParams g,
+                                const float *__restrict__ T /*K x 16*/, const float *__restrict__ centers /*K x 3*/, uint32_t K, float R2,
+                                float r2, int32_t *__restrict__ counts, uint32_t ch, uint32_t items_per_wg) {
+    __shared__ float s_T[OV_KCH][12];
+    __shared__ float s_c[OV_KCH][3];
+    __shared__ uint32_t s_cnt[OV_KCH];
+    extern __shared__ uint32_t s_mask[];
+    for (uint32_t i = threadIdx.x; i < mask_words; i += OV_TPB) s_mask[i] = near_mask[i];
+    const int lane = threadIdx.x & 63;
+    const uint32_t ntiles = (n_s + OV_TPB - 1) / OV_TPB, nchunks = (K + ch - 1) / ch;
+    const uint64_t nitems = (uint64_t)ntiles * nchunks;
+    const uint64_t it0 = (uint64_t)vb.bx * items_per_wg, it1 = min(nitems, it0 + items_per_wg);
+    const uint32_t DX = (uint32_t)g.dx + 4u, DY = (uint32_t)g.dy + 4u;
+    const uint32_t MBX = ((DX - 1u) >> ms) + 1u, MBY = ((DY - 1u) >> ms) + 1u;
+    const uint32_t RS = DX, SS = DX * DY;                 // next row, next slice
+    const float fdx = (float)(g.dx + 1), fdy = (float)(g.dy + 1), fdz = (float)(g.dz + 1);
+    uint32_t cur = 0xffffffffu, k0 = 0, kc = 0;
+    for (uint64_t item = it0; item < it1; ++item) {
+        const uint32_t chunk = (uint32_t)(item / ntiles), tile = (uint32_t)(item % ntiles);
+        if (chunk != cur) {   // uniform
+            __syncthreads();
+            if (cur != 0xffffffffu && threadIdx.x < kc && s_cnt[threadIdx.x]) atomicAdd(&counts[k0 + threadIdx.x], (int32_t)s_cnt[threadIdx.x]);
+            __syncthreads();
+            cur = chunk; k0 = chunk * ch; kc = min(ch, K - k0);
+            for (uint32_t i = threadIdx.x; i < kc * 12; i += OV_TPB) s_T[i / 12][i % 12] = T[(size_t)(k0 + i / 12) * 16 + i % 12];
+            for (uint32_t i = threadIdx.x; i < kc * 3; i += OV_TPB) s_c[i / 3][i % 3] = centers[(size_t)(k0 + i / 3) * 3 + i % 3];
+            if (threadIdx.x < OV_KCH) s_cnt[threadIdx.x] = 0u;
+            __syncthreads();
+        }
+        const uint32_t i = tile * OV_TPB + threadIdx.x;
+        const bool live = i < n_s;
+        const f3 p = live ? f3(sx[i], sy[i], sz[i]) : f3();
+        for (uint32_t kk = 0; kk < kc; ++kk) {
+            bool hit = false;
+            const f3 q_ = pcl_xform(s_T[kk], p);
+            // the probe's own cell, -1 .. d per axis (beyond that no cell of the grid is within one cell of it; a NaN fails the test)
+            const float fx = (q_.x - g.mnx) * g.inv, fy = (q_.y - g.mny) * g.inv, fz = (q_.z - g.mnz) * g.inv;
+            bool probe = live && fx >= -1.f && fy >= -1.f && fz >= -1.f && fx < fdx && fy < fdy && fz < fdz;
+            uint32_t base = 0;
+            if (probe) {
+                const uint32_t px = (uint32_t)((int)floorf(fx) + 2), py = (uint32_t)((int)floorf(fy) + 2), pz = (uint32_t)((int)floorf(fz) + 2);
+                const uint32_t b = (px >> ms) + MBX * ((py >> ms) + MBY * (pz >> ms));
+                probe = (s_mask[b >> 5] >> (b & 31u)) & 1u;
+                base = (px - 1u) + DX * ((py - 1u) + DY * (pz - 1u));
+            }
+            if (probe) {
+                const f3 c(s_c[kk][0], s_c[kk][1], s_c[kk][2]);
+                // nine rows, the probe's own first: (row, slice) offsets
+                uint32_t s9[9], e9[9];
+#pragma unroll
+                for (int r = 0; r < 9; ++r) {
+                    const int o = (r + 4) % 9;                         // 4 = the centre row (dy = 0, dz = 0)
+                    const uint32_t a = base + (uint32_t)(o % 3) * RS + (uint32_t)(o / 3) * SS;
+                    s9[r] = row_start[a];
+                    e9[r] = row_start[a + 3];
+                }
+                // point t of every run together (nine loads in flight), t = 0, 1, ...: the depth of the chain of dependent loads is the
+                // LONGEST run (1-3 points on a voxel-downsampled surface), not the sum of the runs.  (Requesting the next candidate's
+                // rows while this one's points are on their way -- a software pipeline over the chunk -- was built and is slower: at
+                // the 96 registers that keep five wavefronts per SIMD it spills, at 128 / four wavefronts it takes 189 ms against 160
+                // at the stress size.)
+                uint32_t longest = 0;
+#pragma unroll
+                for (int r = 0; r < 9; ++r) longest = max(longest, e9[r] - s9[r]);
+                for (uint32_t t = 0; t < longest && !hit; ++t) {
+                    float4 f9[9];
+#pragma unroll
+                    for (int r = 0; r < 9; ++r)
+                        if (s9[r] + t < e9[r]) f9[r] = tgt[s9[r] + t];
+#pragma unroll
+                    for (int r = 0; r < 9; ++r)
+                        if (s9[r] + t < e9[r] && !hit) {
+                            const f3 tp(f9[r].x, f9[r].y, f9[r].z);
+                            hit = flann_d2(q_, tp) < r2 && flann_d2(c, tp) < R2;
+                        }
+                }
+            }
+            const uint32_t h = (uint32_t)__popcll(__ballot(hit));
+            if (lane == 0 && h) atomicAdd(&s_cnt[kk], h);
+        }
+    }
+    __syncthreads();
+    if (cur != 0xffffffffu && threadIdx.x < kc && s_cnt[threadIdx.x]) atomicAdd(&counts[k0 + threadIdx.x], (int32_t)s_cnt[threadIdx.x]);
+}
+
 // source points into a spatially blocked order: key = blocked cell id in the source's own frame
 __device__ void k_init_minmax6(const VB &, int *__restrict__ out6) {   // (+inf x3, -inf x3) as ordered ints
     if (threadIdx.x < 3) out6[threadIdx.x] = ordered_int(INFINITY);
@@ -426,17 +608,30 @@ void overlap_counts(plade_ctx *ctx, OverlapWork &work, const float *d_sx, const 
     if (n_s) {
         // chunks of 2 candidates while there are few (the default <= 201, of which ~20 reach this stage: the items must fill the
         // GPU), of OV_KCH from a few hundred candidates on (BASELINE configs[4]: 10^4)
-        const uint32_t ch = K <= 64 ? 2u : (K <= 512 ? 4u : (uint32_t)OV_KCH);
+        uint32_t ch = K <= 64 ? 2u : (K <= 512 ? 4u : (uint32_t)OV_KCH);
+        if (grid.dense && K > 512) ch = 8u;   // (stress size, 2 launches of: chunks of 1 / 2 / 4 / 8 / 16 candidates: 178 / 160 / 157 / 150 / 160 ms)
         const uint64_t nitems = (uint64_t)cdiv(n_s, OV_TPB) * cdiv(K, ch);
         // (in a group the launch is merged with those of up to seven other pairs: a quarter of the workgroups per pair fill the
         //  part as well, and each of them stages the block mask -- up to 48 KB -- for four times the items)
-        const uint32_t wgs = (uint32_t)std::min<uint64_t>(nitems, ctx->comb ? 512u : 2048u);
+        // (dense form: the kernel waits on memory three quarters of its time, so what counts is that every SIMD holds its five
+        //  wavefronts from the first to the last item -- 1 280 persistent workgroups on the part's 256 CUs, shared out over the pairs
+        //  of a merged launch; 2 048 were 1.6 rounds)
+        const uint32_t fill = 256u * OVD_W / (uint32_t)std::max(1, ctx->comb ? ctx->comb->members : 1);
+        const uint32_t wgs = (uint32_t)std::min<uint64_t>(nitems, grid.dense ? std::max(64u, fill) : (ctx->comb ? 512u : 2048u));
         const uint32_t per = (uint32_t)((nitems + wgs - 1) / wgs);
-        const uint32_t nw = (uint32_t)((grid.ncells + 63) / 64);
-        const uint32_t mask_words = (nw + 31) / 32 * 4 <= OV_MASK_MAX ? (nw + 63) / 64 * 2 : 0u;   // whole 64-bit words of occ_blk
         // algorithmic bytes: K * n_s * 12 B source stream + n_t * 12 B target
         ctx->ev_begin("overlap", (double)K * n_s * 12.0 + (double)grid.n * 12.0);
         PLADE_REQUIRE(grid.compact, PLADE_EINVAL, "overlap: the target grid needs the compact occupancy index");
+        if (grid.dense) {
+            launch<k_overlap_dense, OV_TPB, OVD_W>(ctx, dim3(cdiv(nitems, per)), grid.mask_words * 4, d_sx, d_sy, d_sz, n_s, grid.sorted.p,
+                               grid.row_start.p, grid.near_mask.p, grid.mask_words, grid.mask_shift, g, d_T, d_centers, K, R2, r2, d_counts,
+                               ch, per);
+            ctx->ev_end();
+            HIP_TRY(hipGetLastError());
+            return;
+        }
+        const uint32_t nw = (uint32_t)((grid.ncells + 63) / 64);
+        const uint32_t mask_words = (nw + 31) / 32 * 4 <= OV_MASK_MAX ? (nw + 63) / 64 * 2 : 0u;   // whole 64-bit words of occ_blk
         launch<k_overlap, OV_TPB, 5>(ctx, dim3(cdiv(nitems, per)), mask_words * 4, d_sx, d_sy, d_sz, n_s, grid.sorted.p,
                            grid.occ_bits.p, grid.occ_rank.p, grid.occ_start.p, grid.cell_first.p, reinterpret_cast<const uint32_t *>(grid.occ_blk.p), mask_words, g,
                            d_T, d_centers, K, R2, r2, d_counts, ch, per);

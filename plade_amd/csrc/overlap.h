@@ -22,6 +22,16 @@ struct TargetGrid {
     DBuf<uint32_t> occ_start;            // per occupied cell (+ 1): first sorted position
     DBuf<float4> cell_first;             // per occupied cell: its first point, w = that position | 1 << 31 when it is the cell's only point
     bool compact = false;
+    // (r5) dense ROW index, the default form of the compact request: target points sorted by their linear cell id in a grid padded by
+    // two cells on every side (x fastest), and row_start[L] = number of points in cells < L.  The 27-cell neighbourhood of a probe is
+    // nine rows of three consecutive cells = nine contiguous runs [row_start[a], row_start[a + 3]) of `sorted`: no bit masks, no ranks,
+    // no per-cell look-ups (the verification kernel was bound by its ~1 900 vector instructions per wavefront and candidate, not by
+    // memory).  near_mask: one bit per block of (1 << mask_shift)^3 padded cells, set when an occupied cell lies within one cell of
+    // the block -- a probe whose own block is clear ends without a global load.
+    bool dense = false;
+    int DX = 0, DY = 0, DZ = 0, mask_shift = 2;
+    uint32_t mask_words = 0;
+    DBuf<uint32_t> row_start, near_mask;
     // d_xyz: device pointer, `stride` floats between points; min_cell = largest probe radius used.
     void build(plade_ctx *ctx, const float *d_xyz, uint32_t n_pts, uint32_t stride, float min_cell,
                const float *bbox_min = nullptr, const float *bbox_max = nullptr,   // known bbox skips a device round trip

@@ -274,3 +274,51 @@ def test_plane_component_bitmap_larger_than_the_lds_labelling(ctx, oracle, filt)
     assert np.abs(sgn * fit[:3] - rf[:3]).max() < 5e-5 and np.abs(fit[3:6] - rf[3:6]).max() < 2e-4
     wref = oracle.weighted_score(cloud, nrm, point, ref, 0.15)
     assert abs(ws - wref) <= 1e-4 * max(1.0, wref)
+
+
+def _overlap_case(seed=3):
+    rng = np.random.default_rng(seed)
+    cloud = sample_scene(40000, scene_seed=5, sample_seed=seed)
+    leaf = np.float32(0.12)
+    K = 37
+    Ts, cs = [], []
+    for k in range(K):
+        ang = rng.normal(0, 0.03 if k % 3 else 0.7)
+        c, s = np.cos(ang), np.sin(ang)
+        T = np.eye(4, dtype=np.float32)
+        T[:2, :2] = [[c, -s], [s, c]]
+        T[:3, 3] = rng.normal(0, 0.1 if k % 2 else 3.0, 3)
+        Ts.append(T)
+        cs.append((T[:3, :3] @ np.array([0.1, 0.2, 0.0], np.float32) + T[:3, 3]).astype(np.float32))
+    Ts = np.array(Ts, np.float32)
+    cs = np.array(cs, np.float32)
+    # candidates that throw the source far outside the target's grid, exactly one cell outside, and onto NaN
+    Ts[-1, :3, 3] = 1.0e6
+    Ts[-2, 0, 3] = np.nan
+    Ts[-3, :3, 3] = [float(cloud[:, 0].max() - cloud[:, 0].min()) + float(leaf), 0.0, 0.0]
+    return cloud, leaf, Ts, cs
+
+
+def test_overlap_dense_rows_equal_bitmap_index_and_oracle(ctx, oracle, tmp_path):
+    """The verification kernel's two target indices -- the dense row table (r5, the default) and the bitmap + rank index of
+    rounds 3-5 (PLADE_OVERLAP_INDEX_COMPACT=1, looked up once per process: a child process) -- count the same pairs, candidate by
+    candidate, incl. candidates that land outside the grid; and both equal the oracle (util.h:611-647)."""
+    import subprocess, sys, os
+    cloud, leaf, Ts, cs = _overlap_case()
+    tg = oracle.voxel_downsample(cloud, leaf, 1)
+    sr = np.ascontiguousarray(tg[::2] + np.float32(0.01))
+    radius = np.float32(6.0)
+    got = ctx.overlap_counts(sr, tg, Ts, cs, radius, leaf)
+    np.savez(tmp_path / "in.npz", sr=sr, tg=tg, Ts=Ts, cs=cs, radius=radius, leaf=leaf)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); import plade_amd; d = np.load(%r); c = plade_amd.Context(0); "
+            "np.save(%r, c.overlap_counts(d['sr'], d['tg'], d['Ts'], d['cs'], d['radius'], d['leaf']))"
+            % (root, str(tmp_path / "in.npz"), str(tmp_path / "out.npy")))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PLADE_OVERLAP_INDEX_COMPACT="1"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    old = np.load(tmp_path / "out.npy")
+    assert np.array_equal(np.asarray(got), old)
+    for k in range(0, len(Ts), 3):
+        if np.isnan(Ts[k]).any():
+            continue
+        assert got[k] == oracle.overlap_count(sr, tg, Ts[k], cs[k], radius, leaf), k
