@@ -616,7 +616,7 @@ void overlap_counts(plade_ctx *ctx, OverlapWork &work, const float *d_sx, const 
         // (dense form: the kernel waits on memory three quarters of its time, so what counts is that every SIMD holds its five
         //  wavefronts from the first to the last item -- 1 280 persistent workgroups on the part's 256 CUs, shared out over the pairs
         //  of a merged launch; 2 048 were 1.6 rounds)
-        const uint32_t fill = 256u * OVD_W / (uint32_t)std::max(1, ctx->comb ? ctx->comb->members : 1);
+        const uint32_t fill = 256u * OVD_W / (uint32_t)std::max(1, ctx->comb ? ctx->comb->size() : 1);
         const uint32_t wgs = (uint32_t)std::min<uint64_t>(nitems, grid.dense ? std::max(64u, fill) : (ctx->comb ? 512u : 2048u));
         const uint32_t per = (uint32_t)((nitems + wgs - 1) / wgs);
         // algorithmic bytes: K * n_s * 12 B source stream + n_t * 12 B target

@@ -107,6 +107,7 @@ struct Combiner {
     void leave(plade_ctx *c);                 // the pair is done (or gave up): whatever it still has queued is issued
     void wait(plade_ctx *c);                  // the pair's host wait: returns when everything it queued has run and its read-backs are in
     QEntry &push(plade_ctx *c);
+    int size() { std::lock_guard<std::mutex> lk(m); return members; }   // pairs taking part right now (a pair that fails leaves early)
 private:
     void flush_locked(std::unique_lock<std::mutex> &lk);
 };
