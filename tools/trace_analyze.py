@@ -41,7 +41,11 @@ for t, d in ev:
     cur += d
 hist[cur] += hi - last
 total_busy = sum(e - s for s, e, *_ in win)
-regs = sum(1 for r in win if "k_overlap" in r[4])   # one launch of the verification kernel per registration
+# registrations in the window: one launch of the verification kernel per registration when the pairs run on their own; a MERGED
+# launch (k_batch<k_overlap..., N = 8>) serves the pairs of a group -- PAIRS_PER_MERGED (environment, default 8) of them
+import os
+_ppm = int(os.environ.get("PAIRS_PER_MERGED", "8"))
+regs = sum((_ppm if ("k_batch" in r[4] and "ELi8ENS_4Pack" in r[4]) else 1) for r in win if "k_overlap" in r[4])
 per_q = collections.defaultdict(lambda: [0, 0])
 for s, e, q, st, n in win:
     per_q[q][0] += e - s
