@@ -154,18 +154,44 @@ def _match_set(d):
     return set(zip(q.tolist(), d["match_nbr"].tolist()))
 
 
-def parity_vs_reference_solver(device, pairs, seeds, n_check=2):
-    """CHECKER leg (outside every timed region; the oracle is test infrastructure): which arithmetic are the timed results
-    identical to?  For the first n_check bench pairs, as generated (axis-aligned rooms) and turned into a generic orientation:
-      * the GPU in its default mode (closed-form closest points: what `value` times) against the oracle in the same mode and
-        against the oracle with the reference's fp32 SVD solves (cv::solve, util.cpp:1183-1226, 1467-1497, restated from
-        OpenCV's lapack.cpp:533-812);
-      * the GPU with plade_params.closest_point_mode = 1 (the reference's solver on the GPU, k_svd.h) against that oracle mode.
-    flips = descriptor matches (query, neighbour) that are in one set and not in the other; dT = Frobenius norm of the
-    difference of the final 4 x 4.  The oracle runs on the planes the GPU extracted (the reference's RANSAC is time-seeded)."""
-    import plade_amd
+def _parity_worker(job):
+    """One pair of the parity leg in a process of its own (spawned: no HIP in it): the oracle in its default mode -- the
+    reference's fp32 SVD solves -- on the planes the GPU extracted, against what the GPU returned for the same pair."""
+    path, modes = job
+    import numpy as np
     from oracle.oracle import Oracle
     orc = Oracle()
+    z = np.load(path)
+    tp = (z["tp_coef"], z["tp_off"], z["tp_idx"])
+    sp = (z["sp_coef"], z["sp_off"], z["sp_idx"])
+    gpu_set = set(zip(z["m_q"].tolist(), z["m_nbr"].tolist()))
+    out = {}
+    for mode in modes:
+        orc.set_closest_point_mode(mode)
+        ok, T, d = orc.registration(z["tg"], z["sr"], tp, sp, voxel_sort_mode=1)
+        q = np.repeat(np.arange(len(d["match_offsets"]) - 1), np.diff(d["match_offsets"]))
+        o_set = set(zip(q.tolist(), d["match_nbr"].tolist()))
+        out[mode] = {"ok": bool(ok), "flips": len(gpu_set ^ o_set), "matches": int(len(d["match_nbr"])),
+                     "dT": float(np.linalg.norm(np.asarray(T, np.float64) - z["T"].astype(np.float64))),
+                     "T_bits_equal": bool(np.array_equal(np.asarray(T, np.float32), z["T"])),
+                     "overlap_counts_equal": bool(np.array_equal(d["overlap_counts"], z["overlap_counts"]))}
+    orc.reset_closest_point_mode()
+    return out
+
+
+def parity_vs_reference_solver(device, pairs, seeds, procs, n_generic=2):
+    """CHECKER leg (outside every timed region; the oracle is test infrastructure): are the timed results the reference's
+    arithmetic?  EVERY pair of the timed cycle, as generated (axis-aligned rooms: what `value` times), is registered once
+    more on the GPU in the timed mode (the library's default: closest_point_mode = 1, the reference's fp32 cv::solve,
+    util.cpp:1183-1226, 1467-1497, k_svd.h) with the intermediates kept, and the oracle -- same mode, restated from OpenCV's
+    lapack.cpp:533-812 -- registers the same clouds on the planes the GPU extracted (the reference's RANSAC is time-seeded).
+    flips = descriptor matches (query, neighbour) in one set and not in the other; dT = Frobenius norm of the difference of the
+    final 4 x 4; the integer overlap counts of every verified candidate are compared bit for bit.  The first n_generic pairs
+    are also checked turned into a generic orientation, and in the opt-in closed-form mode against both oracle modes."""
+    import multiprocessing as mp
+    import shutil
+    import tempfile
+    import plade_amd
     q = np.random.default_rng(4).normal(size=4)
     q /= np.linalg.norm(q)
     w, x, y, z = q
@@ -179,48 +205,61 @@ def parity_vs_reference_solver(device, pairs, seeds, n_check=2):
         o[:, 3:] = (c[:, 3:].astype(np.float64) @ R0.T).astype(np.float32)
         return o
 
-    def cmp(da, Ta, db, Tb):
-        return {"flips": len(_match_set(da) ^ _match_set(db)), "matches": int(len(da["match_nbr"])),
-                "dT": float(np.linalg.norm(np.asarray(Ta, np.float64) - np.asarray(Tb, np.float64)))}
-
     c = plade_amd.Context(device, dump=1, orient_normals=1)
-    out = {"pairs_checked_seeds": [int(sd) for sd in seeds[:n_check]]}
+    d_ = tempfile.mkdtemp(prefix="plade_parity_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    jobs, tags, gpu_T = [], [], {}
+
+    def stage(tag, a, b, mode, oracle_modes):
+        c.set_params(closest_point_mode=mode)
+        ok, T = c.registration(a, b)
+        d = c.dump()
+        path = os.path.join(d_, f"{len(jobs)}.npz")
+        mq = np.repeat(np.arange(len(d["match_offsets"]) - 1), np.diff(d["match_offsets"]))
+        np.savez(path, tg=a, sr=b, T=np.asarray(T, np.float32), overlap_counts=d["overlap_counts"], m_q=mq, m_nbr=d["match_nbr"],
+                 tp_coef=d["tgt_planes"].reshape(-1, 4), tp_off=d["tgt_plane_offsets"], tp_idx=d["tgt_plane_idx"],
+                 sp_coef=d["src_planes"].reshape(-1, 4), sp_off=d["src_plane_offsets"], sp_idx=d["src_plane_idx"])
+        jobs.append((path, oracle_modes))
+        tags.append((tag, bool(ok)))
+        gpu_T[tag] = np.asarray(T, np.float64)
+
     try:
-        for tag in ("as_generated", "generic"):
-            rows = []
-            for (tg, sr, _) in pairs[:n_check]:
-                a, b = (tg, sr) if tag == "as_generated" else (turned(tg), turned(sr))
-                c.set_params(closest_point_mode=0)
-                ok0, T0 = c.registration(a, b)
-                d0 = c.dump()
-                c.set_params(closest_point_mode=1)
-                ok1, T1 = c.registration(a, b)
-                d1 = c.dump()
-                tp = (d0["tgt_planes"].reshape(-1, 4), d0["tgt_plane_offsets"], d0["tgt_plane_idx"])
-                sp = (d0["src_planes"].reshape(-1, 4), d0["src_plane_offsets"], d0["src_plane_idx"])
-                orc.set_closest_point_mode(0)
-                okc, Tc, dc = orc.registration(a, b, tp, sp, voxel_sort_mode=1)
-                orc.set_closest_point_mode("svd_fp32")
-                oks, Ts, ds = orc.registration(a, b, tp, sp, voxel_sort_mode=1)
-                orc.set_closest_point_mode(0)
-                rows.append({"all_ok": bool(ok0 and ok1 and okc and oks),
-                             "gpu_default_vs_oracle_closed_form": cmp(d0, T0, dc, Tc),
-                             "gpu_default_vs_oracle_reference_solver": cmp(d0, T0, ds, Ts),
-                             "gpu_svd_fp32_vs_oracle_reference_solver": cmp(d1, T1, ds, Ts)})
-            agg = {"all_ok": all(r["all_ok"] for r in rows)}
-            for key in ("gpu_default_vs_oracle_closed_form", "gpu_default_vs_oracle_reference_solver", "gpu_svd_fp32_vs_oracle_reference_solver"):
-                agg[key] = {"flips": max(r[key]["flips"] for r in rows), "matches": min(r[key]["matches"] for r in rows),
-                            "dT": max(r[key]["dT"] for r in rows)}
-            # the two numbers the verdict asks for: the reference's solver on the GPU against the oracle's restatement of it
-            agg["flips"], agg["dT"] = agg["gpu_svd_fp32_vs_oracle_reference_solver"]["flips"], agg["gpu_svd_fp32_vs_oracle_reference_solver"]["dT"]
-            out[tag] = agg
-    finally:
-        orc.set_closest_point_mode(0)
+        for k, (tg, sr, _) in enumerate(pairs):
+            stage(("timed_mode", k), tg, sr, 1, (1,))
+        for k, (tg, sr, _) in enumerate(pairs[:n_generic]):
+            stage(("timed_mode_generic", k), turned(tg), turned(sr), 1, (1,))
+            stage(("closed_form", k), tg, sr, 0, (0, 1))
+            stage(("closed_form_generic", k), turned(tg), turned(sr), 0, (0, 1))
         c.close()
-    out["note"] = ("worst case over the checked pairs; `value` times the DEFAULT mode (closed form): bit-identical to the oracle in that "
-                   "mode; against the reference's fp32 SVD solves it is within 1e-5 on generic orientations and parts from them on "
-                   "axis-aligned scenes, where those solves are ill-conditioned (DESIGN.md section 2); closest_point_mode = 1 reproduces "
-                   "the solver bit for bit (flips 0, dT 0) and its rate is `svd_mode_rank0`")
+        with mp.get_context("spawn").Pool(max(1, min(int(procs), len(jobs), 16))) as pool:
+            res = pool.map(_parity_worker, jobs, chunksize=1)
+    finally:
+        shutil.rmtree(d_, ignore_errors=True)
+
+    def agg(rows):
+        return {"pairs": len(rows), "all_ok": all(r["ok"] for r in rows), "flips": max(r["flips"] for r in rows),
+                "matches_min": min(r["matches"] for r in rows), "matches_total": sum(r["matches"] for r in rows),
+                "dT": max(r["dT"] for r in rows), "T_bits_equal": all(r["T_bits_equal"] for r in rows),
+                "overlap_counts_equal": all(r["overlap_counts_equal"] for r in rows)}
+    by = {}
+    for (tag, ok), r in zip(tags, res):
+        for mode, v in r.items():
+            by.setdefault((tag[0], mode), []).append(dict(v, ok=v["ok"] and ok))
+    timed = agg(by[("timed_mode", 1)])
+    out = {"timed_mode": "closest_point_mode = 1 (the library's default): the reference's fp32 cv::solve(DECOMP_SVD) arithmetic",
+           "pairs_checked_seeds": [int(seeds[0]), int(seeds[len(pairs) - 1])],
+           "flips": timed["flips"], "dT": timed["dT"],
+           "as_generated_all_timed_pairs": timed,
+           "generic_orientation": agg(by[("timed_mode_generic", 1)]) if ("timed_mode_generic", 1) in by else None,
+           "closed_form_opt_in": {
+               "as_generated_vs_oracle_closed_form": agg(by[("closed_form", 0)]) if ("closed_form", 0) in by else None,
+               "as_generated_vs_oracle_reference_solver": agg(by[("closed_form", 1)]) if ("closed_form", 1) in by else None,
+               "generic_vs_oracle_closed_form": agg(by[("closed_form_generic", 0)]) if ("closed_form_generic", 0) in by else None,
+               "generic_vs_oracle_reference_solver": agg(by[("closed_form_generic", 1)]) if ("closed_form_generic", 1) in by else None},
+           "moved_closed_form_vs_timed_mode_frobenius": max(float(np.linalg.norm(gpu_T[("closed_form", k)] - gpu_T[("timed_mode", k)]))
+                                                            for k in range(min(n_generic, len(pairs)))) if n_generic else None,
+           "note": "worst case over the checked pairs; `value` times the DEFAULT mode = the reference's solver arithmetic, checked on every "
+                   "pair of the timed cycle against the oracle's restatement of it (flips 0, dT 0, integer overlap counts equal = bit "
+                   "parity); closest_point_mode = 0 (fp64 closed form) is an opt-in deviation whose rate is `closed_form_mode_rank0`"}
     return out
 
 
@@ -461,8 +500,8 @@ def main():
     ap.add_argument("--pairs", type=int, default=0,
                     help="distinct synthetic pairs per rank, seeds rank * pairs ... (cycled in input order); 0 = the batch of BASELINE "
                          "configs[3]: 64 pairs on one GPU, max(16, 64 / ranks) per rank on several")
-    ap.add_argument("--no-parity", action="store_true", help="skip the parity leg (GPU vs the oracle with the reference's fp32 SVD solver)")
-    ap.add_argument("--svd-steps", type=int, default=256, help="steps of the extra leg with closest_point_mode = svd_fp32; 0 = skip")
+    ap.add_argument("--no-parity", action="store_true", help="skip the parity leg (every timed pair on the GPU vs the oracle, both with the reference's fp32 SVD solver)")
+    ap.add_argument("--closed-form-steps", type=int, default=256, help="steps of the extra leg with closest_point_mode = 0 (opt-in closed form); 0 = skip")
     ap.add_argument("--host-wait", choices=["auto", "spin", "sleep"], default="auto",
                     help="how the host threads wait for the GPU (plade_params.host_wait): spinning waits keep ~1.7 CPUs busy "
                          "per registration in flight, sleeping ones ~0.5 at the same throughput; auto = sleep when more "
@@ -632,6 +671,7 @@ def main():
             for q, i in enumerate(members(j)):
                 steps.append((i, bool(out[j][q][0]), out[j][q][1]))
         run_pipeline.group_occupancy = occ      # seconds a timed group occupied its worker, by group number
+        run_pipeline.completions = done         # completion stamps of all groups, ascending
         return window, steps, count_groups * occupancy / M, done[-1] - ts
 
     # warm-up: every worker (context) registers every group composition once through BOTH entry points, so that no
@@ -665,6 +705,9 @@ def main():
     n_timed = timed_groups * S
     window, timed, occ_elapsed, span = run_pipeline(hgroup, lead_groups, timed_groups)
     host_occ = dict(run_pipeline.group_occupancy)
+    # the figure for exactly the K steps the driver asked for (in whole groups): the first ceil(K / S) completions of the window
+    req_groups = max(1, min(timed_groups, (args.steps + S - 1) // S))
+    req_window = run_pipeline.completions[lead_groups + req_groups - 1] - run_pipeline.completions[lead_groups - 1]
     elapsed = window
     cpu1, thr1 = time.process_time(), _cgroup_throttle()
     timed_ids = [t[0] for t in timed]
@@ -682,14 +725,14 @@ def main():
     bracketed = time.perf_counter() - t_begin
     total_ok = n_ok
     if comm is not None:
-        elapsed, bracketed, occ_elapsed = comm.all_reduce_max([elapsed, bracketed, occ_elapsed])
+        elapsed, bracketed, occ_elapsed, req_window = comm.all_reduce_max([elapsed, bracketed, occ_elapsed, req_window])
         total_ok = int(comm.all_reduce_sum([n_ok])[0])
     elif world > 1:
-        tmax = torch.tensor([elapsed, bracketed, occ_elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed, bracketed, occ_elapsed, req_window], dtype=torch.float64, device=dev)
         okt = torch.tensor([n_ok], dtype=torch.int64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(okt, op=dist.ReduceOp.SUM)
-        elapsed, bracketed, occ_elapsed = float(tmax[0].item()), float(tmax[1].item()), float(tmax[2].item())
+        elapsed, bracketed, occ_elapsed, req_window = (float(tmax[k].item()) for k in range(4))
         total_ok = int(okt.item())
 
     # every registration of the same pair, whichever context ran it and whatever its partners in the group were, must
@@ -743,29 +786,29 @@ def main():
                         "ms_per_step": r_win / (r_groups * S) * 1e3, "identical_to_host_cloud_results": bool(same),
                         "note": "clouds resident in HBM (plade_cloud_upload once, plade_registration_pairs_dev per group): no H2D, no SoA "
                                 "conversion, no bounding box in the step"}
-    # ---- the same host-cloud pipeline with the reference's own closest-point arithmetic (closest_point_mode = 1: fp32 SVD
-    #      solves, k_svd.h): the rate a host pays for bit-parity with the reference's solver on ill-conditioned scenes
-    svd_leg = None
-    if args.svd_steps > 0:
+    # ---- the same host-cloud pipeline with the opt-in closed-form closest points (closest_point_mode = 0: fp64 formula instead
+    #      of the reference's fp32 SVD solves): what the parity with the reference's solver costs
+    closed_leg = None
+    if args.closed_form_steps > 0:
         for c_ in ctxs:
-            c_.set_params(closest_point_mode=1)
-        s_groups = (args.svd_steps + S - 1) // S
+            c_.set_params(closest_point_mode=0)
+        s_groups = (args.closed_form_steps + S - 1) // S
         s_win, s_res, _, _ = run_pipeline(hgroup, 2 * M, s_groups)
         device_sync()
         for c_ in ctxs:
-            c_.set_params(closest_point_mode=0)
+            c_.set_params(closest_point_mode=1)
         s_err = [float(np.linalg.norm(T.astype(np.float64) - pairs[i % NP][2])) for (i, ok, T) in s_res]
-        svd_leg = {"value": s_groups * S / s_win, "unit": "registrations/s (this rank)", "steps": s_groups * S,
-                   "ms_per_step": s_win / (s_groups * S) * 1e3, "all_ok": all(ok for (_, ok, _) in s_res),
-                   "max_frobenius_vs_ground_truth": max(s_err) if s_err else None,
-                   "moved_vs_default_mode_max_frobenius": max(float(np.linalg.norm(T.astype(np.float64) - ref_result[i % NP].astype(np.float64)))
-                                                              for (i, ok, T) in s_res),
-                   "note": "plade_params.closest_point_mode = 1 on host clouds, same pipeline as `value`; on these axis-aligned scenes the "
-                           "reference's fp32 solves are ill-conditioned, so its results sit further from the ground truth than the default's"}
+        closed_leg = {"value": s_groups * S / s_win, "unit": "registrations/s (this rank)", "steps": s_groups * S,
+                      "ms_per_step": s_win / (s_groups * S) * 1e3, "all_ok": all(ok for (_, ok, _) in s_res),
+                      "max_frobenius_vs_ground_truth": max(s_err) if s_err else None,
+                      "moved_vs_timed_mode_max_frobenius": max(float(np.linalg.norm(T.astype(np.float64) - ref_result[i % NP].astype(np.float64)))
+                                                               for (i, ok, T) in s_res),
+                      "note": "plade_params.closest_point_mode = 0 on host clouds, same pipeline as `value`: NOT the reference's arithmetic (on "
+                              "these axis-aligned scenes the reference's fp32 solves are ill-conditioned and the two modes part, DESIGN.md section 2)"}
     parity = None
     if rank == 0 and world == 1 and not args.no_parity and not args.no_cpu_baseline:
         try:
-            parity = parity_vs_reference_solver(local_rank, pairs, seeds)
+            parity = parity_vs_reference_solver(local_rank, pairs, seeds, _cpu_budget())
         except Exception as e:   # the oracle is test infrastructure: its absence must not hide the GPU number
             parity = {"note": f"unavailable: {e}"}
     mb = sum(tg.nbytes + sr.nbytes for tg, sr, _ in pairs) / NP / 1e6
@@ -977,6 +1020,9 @@ def main():
             "steps": n_timed,
             "warmup": args.warmup,
             "requested_steps": args.steps,
+            "value_at_requested_steps": {"value": world * req_groups * S / req_window if req_window > 0 else None, "steps": req_groups * S,
+                                         "note": "the first ceil(requested_steps / pairs_per_group) group completions of the same timed window: "
+                                                 "with fewer steps than registrations in flight this samples less than one round of the pipeline"},
             "ms_per_step": elapsed / n_timed * 1e3,
             "higher_is_better": True,
             "scaling": "weak",
@@ -1006,7 +1052,7 @@ def main():
             "results_bit_identical_to_the_pair_alone_rank0": bool(identical),
             "value_by_seed": value_by_seed,
             "parity_vs_reference_solver": parity,
-            "svd_mode_rank0": svd_leg,
+            "closed_form_mode_rank0": closed_leg,
             "pair_generation_seconds": t_gen,
             "max_frobenius_vs_ground_truth_rank0": max(errs) if errs else None,
             "host_rank0": {"cpu_seconds_per_step": (cpu1 - cpu0) / ((lead_groups + timed_groups + M) * S),

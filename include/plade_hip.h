@@ -99,13 +99,13 @@ typedef struct plade_params {
     uint32_t group_max_points;
     int32_t prepare_sides;
     int32_t closest_point_mode;   /* arithmetic of ComputeNearstTwoPointsOfTwo3DLine (code/PLADE/util.cpp:1167-1229) and
-                          * ComputeIntersectionPointOf23DLine (util.cpp:1461-1500): 0 = exact closed form in fp64 (default; the
-                          * better-conditioned evaluation of the same inputs), 1 = "svd_fp32": the reference's own
-                          * cv::solve(A, B, X, DECOMP_SVD) on the 9 x 9 / 6 x 5 float systems, rounding for rounding
+                          * ComputeIntersectionPointOf23DLine (util.cpp:1461-1500): 1 = "svd_fp32" (DEFAULT = the reference's own
+                          * arithmetic): cv::solve(A, B, X, DECOMP_SVD) on the 9 x 9 / 6 x 5 float systems, rounding for rounding
                           * (opencv/modules/core/src/lapack.cpp:533-710, 751-812, 1335-1460; one system per lane,
-                          * plade_amd/csrc/k_svd.h) -- for hosts that must reproduce the reference's transform on scenes
-                          * where those solves are ill-conditioned (axis-aligned planes).
-                          * C++ API / CLI: env PLADE_CLOSEST_POINT_MODE=svd_fp32. */
+                          * plade_amd/csrc/k_svd.h); 0 = exact closed form in fp64: the better-conditioned evaluation of the
+                          * same inputs, an OPT-IN deviation (like orient_normals = 1) -- on axis-aligned scenes the
+                          * reference's solves are ill-conditioned and the two modes part.
+                          * C++ API / CLI: env PLADE_CLOSEST_POINT_MODE=closed_form. */
 } plade_params;
 void plade_default_params(plade_params *p);
 int plade_set_params(plade_ctx *ctx, const plade_params *p);
@@ -342,6 +342,16 @@ int plade_diag_launches(plade_ctx *ctx, uint32_t count, uint32_t blocks, uint32_
  * sequential partition with the recursion depth limited to `depth_limit` (< 0: the library's 2 lg n).  Host code only: no
  * context, no GPU. */
 int plade_diag_cluster_order(const float *sizes, uint32_t n, int32_t mode, int32_t depth_limit, int32_t *order);
+/* Host seam of the register form of the reference's least-squares solver (plade_amd/csrc/k_svd.h, RegSolver: cv::solve(...,
+ * DECOMP_SVD) of opencv/modules/core/src/lapack.cpp:533-812, 1335-1460 with every loop unrolled over compile-time bounds): the
+ * functions the kernels inline, instantiated for the host, so that the arithmetic can be compared with the oracle's
+ * restatement where there is no GPU.  kind 0: n systems of ComputeNearstTwoPointsOfTwo3DLine (code/PLADE/util.cpp:1167-1229;
+ * a = u1, b = p1, c = u2, d = p2, each n x 3; o1 = point1, o2 = point2); kind 1: of ComputeIntersectionPointOf23DLine
+ * (util.cpp:1461-1500; a = v1, b = p1, c = v2, d = p2; o1 = the point, o2 unused).  ok[i]: 1 solved, 0 a column of the system
+ * vanished (the kernels hand such a system to the general form, which completes it as lapack.cpp:650-699 does), -1 the
+ * reference's guard fired (identical directions / |v1.v2| > 0.9999).  Host code only: no context, no GPU. */
+int plade_diag_line_solver_host(int32_t kind, const float *a, const float *b, const float *c, const float *d, uint32_t n,
+                                float *o1, float *o2, int32_t *ok);
 /* Times `iters` launches of one hot kernel on resident synthetic-shaped data with HIP events on
  * the ctx stream (used by bench.py for the roofline figure): which = "score" | "overlap" | "match". */
 int plade_kernel_time(plade_ctx *ctx, const char *which, int iters, double *avg_seconds,

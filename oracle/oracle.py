@@ -87,9 +87,13 @@ class Oracle:
         L.orc_pen_walk.argtypes = [_p, _i, _p, _i, _p, _p, _p, _f, _f, _f, _p, _p, _p]
 
     def set_closest_point_mode(self, mode):
-        """0 / "closed_form": exact fp64 closed form (default, = the HIP path); 1 / "svd_fp32": the reference's fp32 cv::solve
-        (DECOMP_SVD) restated from OpenCV 2.4 (util.cpp:1183-1226, 1467-1497)."""
+        """1 / "svd_fp32" (default, = the HIP path's default): the reference's fp32 cv::solve (DECOMP_SVD) restated from OpenCV 2.4
+        (util.cpp:1183-1226, 1467-1497); 0 / "closed_form": exact fp64 closed form (the opt-in deviation of both)."""
         self.L.orc_set_closest_point_mode(1 if mode in (1, "svd_fp32") else 0)
+
+    def reset_closest_point_mode(self):
+        """Back to the default: the reference's arithmetic."""
+        self.L.orc_set_closest_point_mode(1)
 
     def intersection_point(self, v1, p1, v2, p2):
         out = np.zeros(3, np.float32)

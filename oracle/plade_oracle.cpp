@@ -627,7 +627,7 @@ int intersection_line(const float *pl1, const float *pl2, V3 &vec, V3 &pt) {
 // accumulators, eps = FLT_EPSILON * 2, minval = FLT_MIN, at most max(m, 30) sweeps) and back-substitutes with
 // SVBkSb(m, n, w, u = At (uT), v = Vt (vT), b, nb = 1) (:751-812, eps = (float)(DBL_EPSILON * 2)).
 // The SSE2 paths of VBLAS<float>::givens (:421-437) perform the same fp32 operations as the scalar tail, lane by lane.
-static int g_cp_mode = 0;            // 0 closed form (fp64), 1 svd_fp32
+static int g_cp_mode = 1;            // 1 svd_fp32 = the reference's arithmetic (default), 0 closed form (fp64)
 
 struct CvRng {                       // cv::RNG (core/operations.hpp: MWC, state * 4164903690 + carry)
     uint64_t state;

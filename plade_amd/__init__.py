@@ -22,7 +22,7 @@ ABI_SYMBOLS = [
     "plade_registration", "plade_registration_minsupport", "plade_cloud_upload", "plade_cloud_free",
     "plade_registration_dev", "plade_dump_get", "plade_stats_get", "plade_kernel_time", "plade_plane_component",
     "plade_sort_pairs", "plade_host_pin", "plade_host_unpin", "plade_score_planes_subset", "plade_registration_next", "plade_cluster_transforms", "plade_device_synchronize", "plade_selftest_readback",
-    "plade_registration_pairs", "plade_registration_pairs_dev", "plade_pair_ctx", "plade_set_candidate_shard", "plade_diag_launches", "plade_diag_cluster_order", "plade_sort_segments",
+    "plade_registration_pairs", "plade_registration_pairs_dev", "plade_pair_ctx", "plade_set_candidate_shard", "plade_diag_launches", "plade_diag_cluster_order", "plade_diag_line_solver_host", "plade_sort_segments",
     "plade_closest_points", "plade_lines_meet",
     "plade_device_count", "plade_comm_unique_id", "plade_comm_create", "plade_comm_all_gather", "plade_comm_destroy", "plade_comm_last_error",
     "plade_set_candidate_shard_comm",
@@ -94,6 +94,7 @@ def load_library(path=LIB_PATH):
     sig("plade_lines_meet", argtypes=[p, i32, p, p, p, p, u32, p, p])
     sig("plade_diag_launches", argtypes=[p, u32, u32, u32])
     sig("plade_diag_cluster_order", argtypes=[p, u32, i32, i32, p])
+    sig("plade_diag_line_solver_host", argtypes=[i32, p, p, p, p, u32, p, p, p])
     sig("plade_sort_segments", argtypes=[p, p, p, p, u32, C.c_int, p, p])
     sig("plade_set_candidate_shard", argtypes=[p, u32, u32, u32, EXCHANGE_FN, p])
     sig("plade_registration_minsupport", argtypes=[p, p, u32, p, u32, i32, i32, p])
@@ -150,6 +151,25 @@ def device_synchronize(device=0):
     rc = load_library().plade_device_synchronize(int(device))
     if rc != 0:
         raise PladeError(rc, "plade_device_synchronize failed")
+
+
+def default_params():
+    """plade_default_params (pure: needs no GPU): the library's shipped defaults = the reference's behaviour."""
+    prm = Params()
+    load_library().plade_default_params(C.byref(prm))
+    return prm
+
+
+def line_solver_host(kind, a, b, c, d):
+    """Host seam (no GPU): the register form of the reference's SVD solver as the kernels inline it -- kind 0: closest points of
+    n line pairs -> (q1, q2, ok), kind 1: meeting points -> (point, ok); ok 1 solved / 0 rank-deficient / -1 guard fired."""
+    a, b, c, d = (_f32(x).reshape(-1, 3) for x in (a, b, c, d))
+    n = len(a)
+    o1, o2, ok = np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32), np.zeros(n, np.int32)
+    rc = load_library().plade_diag_line_solver_host(int(kind), _ptr(a), _ptr(b), _ptr(c), _ptr(d), n, _ptr(o1), _ptr(o2), _ptr(ok))
+    if rc != 0:
+        raise PladeError(rc, "plade_diag_line_solver_host failed")
+    return (o1, o2, ok) if kind == 0 else (o1, ok)
 
 
 def cluster_order(sizes, mode=0, depth_limit=-1):

@@ -22,7 +22,7 @@ extern "C" void plade_default_params(plade_params *p) {
     p->match_cell_budget = 0;
     p->group_max_points = 48000000u;
     p->prepare_sides = 0;
-    p->closest_point_mode = 0;  // closed form; 1 = the reference's fp32 SVD solves (k_svd.h)
+    p->closest_point_mode = 1;  // the reference's fp32 SVD solves (k_svd.h); 0 = the fp64 closed form (opt-in deviation)
     // pure: no environment look-ups here -- programs that cannot pass plade_params (the CLI, the C++ registration()
     // overloads) read their opt-in switches themselves (plade_host.cpp: context())
 }

@@ -51,7 +51,6 @@ __device__ __forceinline__ void unordered_pair(uint32_t t, uint32_t L, uint32_t 
 }
 
 __device__ void k_closest_svd(const VB &vb, LinesView v, uint32_t n_pairs, float *__restrict__ cp) {
-    __shared__ float lds[LaneSolver<9, 9, CP_TPB>::WORDS_PER_LANE * CP_TPB];
     const uint32_t t = vb.bx * CP_TPB + threadIdx.x;
     if (t >= n_pairs) return;
     uint32_t i, j;
@@ -59,9 +58,8 @@ __device__ void k_closest_svd(const VB &vb, LinesView v, uint32_t n_pairs, float
     const f3 ci = line_iter(v, i, 3 + (int)j), cj = line_iter(v, j, 4 + (int)i);
     if (ci.x == cj.x && ci.y == cj.y && ci.z == cj.z) return;     // util.cpp:1173: the caller sees "-1"
     const f3 pti(v.pt[3 * i], v.pt[3 * i + 1], v.pt[3 * i + 2]), ptj(v.pt[3 * j], v.pt[3 * j + 1], v.pt[3 * j + 2]);
-    LaneSolver<9, 9, CP_TPB> solver(lds, threadIdx.x);
     f3 q1, q2;
-    closest_points_solver(solver, ci, pti, cj, ptj, q1, q2);
+    closest_points_svd(ci, pti, cj, ptj, q1, q2);
     float *o = cp + 6 * ((size_t)i * v.L + j);
     o[0] = q1.x; o[1] = q1.y; o[2] = q1.z; o[3] = q2.x; o[4] = q2.y; o[5] = q2.z;
 }
@@ -221,7 +219,6 @@ void build_pair_table(plade_ctx *ctx, const LineTableHost &lt, const float *norm
 template <int SVD>
 __global__ __launch_bounds__(CP_TPB) void k_closest_seam(const float *__restrict__ in, uint32_t n, float *__restrict__ q, double *__restrict__ len,
                                                          int32_t *__restrict__ ok) {
-    __shared__ float lds[SVD ? LaneSolver<9, 9, CP_TPB>::WORDS_PER_LANE * CP_TPB : 1];
     const uint32_t t = blockIdx.x * CP_TPB + threadIdx.x;
     if (t >= n) return;
     auto ld = [&](int a) { const float *p = in + 3 * ((size_t)a * n + t); return f3(p[0], p[1], p[2]); };
@@ -232,8 +229,7 @@ __global__ __launch_bounds__(CP_TPB) void k_closest_seam(const float *__restrict
     if (SVD) {
         good = !(u1.x == u2.x && u1.y == u2.y && u1.z == u2.z);
         if (good) {
-            LaneSolver<9, 9, CP_TPB> solver(lds, threadIdx.x);
-            closest_points_solver(solver, u1, p1, u2, p2, q1, q2);
+            closest_points_svd(u1, p1, u2, p2, q1, q2);
             l = norm_e(q1 - q2);
         }
     } else good = closest_points(u1, p1, u2, p2, q1, q2, l);
@@ -245,7 +241,6 @@ __global__ __launch_bounds__(CP_TPB) void k_closest_seam(const float *__restrict
 
 template <int SVD>
 __global__ __launch_bounds__(128) void k_meet_seam(const float *__restrict__ in, uint32_t n, float *__restrict__ out, int32_t *__restrict__ ok) {
-    __shared__ float lds[SVD ? LaneSolver<6, 5, 128>::WORDS_PER_LANE * 128 : 1];
     const uint32_t t = blockIdx.x * 128 + threadIdx.x;
     if (t >= n) return;
     auto ld = [&](int a) { const float *p = in + 3 * ((size_t)a * n + t); return f3(p[0], p[1], p[2]); };
@@ -254,7 +249,7 @@ __global__ __launch_bounds__(128) void k_meet_seam(const float *__restrict__ in,
     bool good;
     if (SVD) {
         good = !(fabsf(dot_e(v1, v2)) > 0.9999);
-        if (good) { LaneSolver<6, 5, 128> solver(lds, threadIdx.x); o = lines_meet_solver(solver, v1, p1, v2, p2); }
+        if (good) o = lines_meet_svd(v1, p1, v2, p2);
     } else good = lines_meet(v1, p1, v2, p2, o);
     ok[t] = good ? 1 : 0;
     out[3 * (size_t)t] = o.x; out[3 * (size_t)t + 1] = o.y; out[3 * (size_t)t + 2] = o.z;
@@ -293,6 +288,32 @@ static int line_seam(plade_ctx *ctx, int kind, int32_t mode, const float *a, con
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         return PLADE_OK;
     });
+}
+
+// Host seam of the register form of the reference's solver (k_svd.h, RegSolver): the same functions the kernels inline,
+// instantiated for the host.  ok: 1 solved, 0 rank-deficient (the kernels hand such a system to LaneSolver), -1 the guard of
+// the caller fired (identical directions, util.cpp:1173 / |v1.v2| > 0.9999, util.cpp:1463).  No context, no GPU.
+extern "C" int plade_diag_line_solver_host(int32_t kind, const float *a, const float *b, const float *c, const float *d, uint32_t n,
+                                           float *o1, float *o2, int32_t *ok) {
+    if (n && !(a && b && c && d && o1 && ok && (kind == 1 || o2)) || (kind != 0 && kind != 1)) return PLADE_EINVAL;
+    for (uint32_t t = 0; t < n; ++t) {
+        auto ld = [&](const float *p) { return f3(p[3 * (size_t)t], p[3 * (size_t)t + 1], p[3 * (size_t)t + 2]); };
+        if (kind == 0) {
+            const f3 u1 = normalized_e(ld(a)), u2 = normalized_e(ld(c));
+            f3 q1, q2;
+            if (u1.x == u2.x && u1.y == u2.y && u1.z == u2.z) { ok[t] = -1; continue; }
+            ok[t] = closest_points_regs(u1, ld(b), u2, ld(d), q1, q2) ? 1 : 0;
+            o1[3 * (size_t)t] = q1.x; o1[3 * (size_t)t + 1] = q1.y; o1[3 * (size_t)t + 2] = q1.z;
+            o2[3 * (size_t)t] = q2.x; o2[3 * (size_t)t + 1] = q2.y; o2[3 * (size_t)t + 2] = q2.z;
+        } else {
+            const f3 v1 = ld(a), v2 = ld(c);
+            f3 o;
+            if (fabsf(dot_e(v1, v2)) > 0.9999) { ok[t] = -1; continue; }
+            ok[t] = lines_meet_regs(v1, ld(b), v2, ld(d), o) ? 1 : 0;
+            o1[3 * (size_t)t] = o.x; o1[3 * (size_t)t + 1] = o.y; o1[3 * (size_t)t + 2] = o.z;
+        }
+    }
+    return PLADE_OK;
 }
 
 extern "C" int plade_closest_points(plade_ctx *ctx, int32_t mode, const float *u1, const float *p1, const float *u2, const float *p2, uint32_t n,

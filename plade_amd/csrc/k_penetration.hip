@@ -64,7 +64,6 @@ __device__ __forceinline__ int edge_hits(f3 lineVec, f3 linePoint, const f3 *c, 
 template <int SVD, int TPB>
 __device__ void k_pen_setup(const VB &vb, PenTables tb, float len_th, float ang_th, PenItem *__restrict__ items,
                                                    uint32_t *__restrict__ n_items, uint32_t *__restrict__ pair_count) {
-    __shared__ float lds[SVD ? LaneSolver<6, 5, TPB>::WORDS_PER_LANE * TPB : 1];
     const size_t idx = (size_t)vb.bx * blockDim.x + threadIdx.x;
     const size_t total = (size_t)tb.K * tb.ps * tb.pt;
     if (idx >= total) return;
@@ -97,8 +96,7 @@ __device__ void k_pen_setup(const VB &vb, PenTables tb, float len_th, float ang_
     auto meet = [&](f3 v1, f3 p1, f3 v2, f3 p2, f3 &out) -> bool {
         if (!SVD) return lines_meet(v1, p1, v2, p2, out);
         if (fabsf(dot_e(v1, v2)) > 0.9999) return false;    // util.cpp:1463
-        LaneSolver<6, 5, TPB> solver(lds, threadIdx.x);
-        out = lines_meet_solver(solver, v1, p1, v2, p2);
+        out = lines_meet_svd(v1, p1, v2, p2);
         return true;
     };
     const int n1 = edge_hits<SVD != 0>(lineVec, linePoint, c1, ip1, meet);

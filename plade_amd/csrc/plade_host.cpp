@@ -55,7 +55,7 @@ plade_ctx *context() {
     if (const char *w = getenv("PLADE_ORIENT_NORMALS")) { prm.orient_normals = atoi(w) != 0; changed = true; }
     if (const char *w = getenv("PLADE_UNORIENTED_NORMALS")) { prm.unoriented_normals = atoi(w) != 0; changed = true; }
     if (const char *w = getenv("PLADE_RANSAC_TOPUP")) { prm.ransac_topup = atoi(w) != 0; changed = true; }
-    if (const char *w = getenv("PLADE_CLOSEST_POINT_MODE")) { prm.closest_point_mode = (!strcmp(w, "svd_fp32") || !strcmp(w, "1")) ? 1 : 0; changed = true; }
+    if (const char *w = getenv("PLADE_CLOSEST_POINT_MODE")) { prm.closest_point_mode = (!strcmp(w, "closed_form") || !strcmp(w, "0")) ? 0 : 1; changed = true; }
     if (changed) (void)plade_set_params(g_ctx, &prm);
     trace("context: ready");
     return g_ctx;

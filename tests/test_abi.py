@@ -26,6 +26,11 @@ def test_params_defaults_match_reference_literals():
     p = plade_amd.Params()
     L.plade_default_params(ctypes.byref(p))
     assert (p.max_planes, p.min_planes, p.max_candidates, p.init_min_support) == (40, 10, 200, 10000)
+    # the arithmetic that selects results is the reference's by default: unflipped plane normals (plane_extraction.cpp:43-58)
+    # and the fp32 cv::solve(DECOMP_SVD) closest points (util.cpp:1183-1226); the better-conditioned variants are opt-ins
+    assert (p.orient_normals, p.unoriented_normals, p.closest_point_mode) == (0, 0, 1)
+    q = plade_amd.default_params()
+    assert q.closest_point_mode == 1
 
 
 def test_no_cpu_fallback_without_gpu():

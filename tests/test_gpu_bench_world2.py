@@ -25,7 +25,7 @@ def test_bench_two_ranks_on_one_gpu(with_torch):
         env["PLADE_BENCH_TORCH"] = "1"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "4",
-           "--points", "200000", "--inflight", "2", "--group", "2", "--pairs", "4", "--svd-steps", "8"]
+           "--points", "200000", "--inflight", "2", "--group", "2", "--pairs", "4", "--closed-form-steps", "8"]
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=540, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]

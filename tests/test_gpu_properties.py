@@ -262,7 +262,7 @@ def test_a6_closed_form_against_the_reference_solver_at_full_size(ctx, oracle, b
         return o
 
     def both_modes(a, b):
-        c = plade_amd.Context(0, dump=1, orient_normals=1)
+        c = plade_amd.Context(0, dump=1, orient_normals=1, closest_point_mode=0)
         ok, T = c.registration(a, b)
         d = c.dump()
         c.close()
@@ -275,7 +275,7 @@ def test_a6_closed_form_against_the_reference_solver_at_full_size(ctx, oracle, b
             oracle.set_closest_point_mode("svd_fp32")
             ok1, T1, d1 = oracle.registration(a, b, tp, sp, voxel_sort_mode=1)
         finally:
-            oracle.set_closest_point_mode(0)
+            oracle.reset_closest_point_mode()
         assert ok1
         lines = np.concatenate([d0["tgt_lines"].reshape(-1, 8), d0["src_lines"].reshape(-1, 8)])
         far = float((np.abs(lines[:, 3:6]).max(1) > 1e3).mean())

@@ -73,7 +73,7 @@ def test_closest_points_seam_bit_exact(ctx, oracle, mode):
             assert ln[i] == ol or (np.isnan(ln[i]) and np.isnan(ol)), (mode, i)
         assert n_fail >= 21      # the identical-direction pairs and the zero vectors
     finally:
-        oracle.set_closest_point_mode(0)
+        oracle.reset_closest_point_mode()
     if mode == 1:
         # the solver really is another arithmetic: on the far-base-point pairs it differs from the closed form by centimetres
         c1, _, _, _ = ctx.closest_points(U1, P1, U2, P2, mode=0)
@@ -100,7 +100,7 @@ def test_lines_meet_seam_bit_exact(ctx, oracle, mode):
             assert _same_bits(out[i], o), (mode, i, out[i], o)
         assert skipped >= 20
     finally:
-        oracle.set_closest_point_mode(0)
+        oracle.reset_closest_point_mode()
 
 
 def _every_intermediate(d, do, tag):
@@ -135,7 +135,7 @@ def test_registration_with_the_reference_solver_equals_oracle_on_the_reference_d
         oracle.set_closest_point_mode("svd_fp32")
         ok_o, T_o, do = oracle.registration(g["target"], g["source"], tp, sp, voxel_sort_mode=1)
     finally:
-        oracle.set_closest_point_mode(0)
+        oracle.reset_closest_point_mode()
     assert ok and ok_o and ok0 and np.array_equal(T, T_o)
     _every_intermediate(d, do, (fix, pre))
     assert _match_set(d) == _match_set(d0)
@@ -180,7 +180,7 @@ def test_full_size_pair_with_the_reference_solver_equals_oracle(oracle, orientat
         oracle.set_closest_point_mode("svd_fp32")
         ok_o, T_o, do = oracle.registration(tg, sr, tp, sp, voxel_sort_mode=1)
     finally:
-        oracle.set_closest_point_mode(0)
+        oracle.reset_closest_point_mode()
     assert ok and ok_o and ok0
     flips_vs_oracle = len(_match_set(d) ^ _match_set(do))
     flips_vs_closed = len(_match_set(d) ^ _match_set(d0))
@@ -200,5 +200,6 @@ def test_mode_is_validated(ctx):
     import plade_amd
     with pytest.raises(plade_amd.PladeError):
         ctx.set_params(closest_point_mode=2)
-    ctx.params.closest_point_mode = 0
-    ctx.set_params(closest_point_mode=0)
+    ctx.params.closest_point_mode = 1
+    ctx.set_params(closest_point_mode=1)
+

@@ -223,7 +223,7 @@ def test_a6_closed_form_against_the_reference_solver_on_line_pairs(oracle):
                 assert abs(d @ n1) <= 1e-5 * mag and abs(d @ n2) <= 1e-5 * mag
             assert worst <= bound, (scale, worst)
     finally:
-        oracle.set_closest_point_mode(0)
+        oracle.reset_closest_point_mode()
 
 
 @pytest.mark.parametrize("fix,pre", [("g8_polyhedron.npz", ""), ("g9_room.npz", ""), ("g9_room.npz", "b")])
@@ -245,7 +245,7 @@ def test_a6_closed_form_against_the_reference_solver_end_to_end(oracle, fix, pre
         oracle.set_closest_point_mode("svd_fp32")
         ok1, T1, d1 = oracle.registration(g["target"], g["source"], tp, sp, voxel_sort_mode=0)
     finally:
-        oracle.set_closest_point_mode(0)
+        oracle.reset_closest_point_mode()
     assert ok0 and ok1
     m0, m1 = _matches(d0), _matches(d1)
     assert len(m0 ^ m1) <= 2, (len(m0 ^ m1), len(m0))                                   # measured: 0
@@ -295,7 +295,7 @@ def test_a6_reference_solver_on_axis_aligned_scenes(oracle):
             lines = np.concatenate([d0["tgt_lines"].reshape(-1, 8), d0["src_lines"].reshape(-1, 8)])
             out[tag] = (T0.astype(np.float64), T1.astype(np.float64), float((np.abs(lines[:, 3:6]).max(1) > 1e3).mean()))
     finally:
-        oracle.set_closest_point_mode(0)
+        oracle.reset_closest_point_mode()
     T0, T1, far = out["generic"]
     assert far == 0.0 and np.linalg.norm(T0 - T1) <= 2e-5
     T0, T1, far = out["axis"]

@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B of environment switches on one box: every line of VARIANTS is "name ENV=... ENV=..." ; BENCH_ARGS extra bench flags
-run() { name=$1; shift; env "$@" python bench.py --pairs 16 --no-cpu-baseline --no-cli --no-default-mode --svd-steps 0 --resident-steps 0 --profiled-steps 0 --no-parity $BENCH_ARGS 2>&1 | python -c "
+run() { name=$1; shift; env "$@" python bench.py --pairs 16 --no-cpu-baseline --no-cli --no-default-mode --closed-form-steps 0 --resident-steps 0 --profiled-steps 0 --no-parity $BENCH_ARGS 2>&1 | python -c "
 import sys,json
 for l in sys.stdin:
     if l.startswith('{'):

@@ -1,7 +1,7 @@
 #!/bin/bash
 # lock step: hardware queues x groups in flight (resident legs off, 16 distinct pairs)
 for q in ${QUEUES:-4 8}; do for m in ${INFLIGHT:-4 6 8}; do
-GPU_MAX_HW_QUEUES=$q python bench.py --pairs 16 --inflight $m --no-cpu-baseline --no-cli --no-default-mode --svd-steps 0 --resident-steps 0 --profiled-steps 0 --no-parity ${BENCH_EXTRA:-} 2>&1 | python -c "
+GPU_MAX_HW_QUEUES=$q python bench.py --pairs 16 --inflight $m --no-cpu-baseline --no-cli --no-default-mode --closed-form-steps 0 --resident-steps 0 --profiled-steps 0 --no-parity ${BENCH_EXTRA:-} 2>&1 | python -c "
 import sys,json
 for l in sys.stdin:
     if l.startswith('{'):

@@ -4,7 +4,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 export BENCH_LEAD_ROUNDS=${BENCH_LEAD_ROUNDS:-1} BENCH_MIN_ROUNDS=${BENCH_MIN_ROUNDS:-6}
 rm -rf $O/prof_quick
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_quick -o q -- python $R/bench.py --pairs 16 --steps 96 --warmup 8 --resident-steps 0 --svd-steps 0 --no-cpu-baseline --no-cli --no-default-mode --no-parity --profiled-steps 0 ${BENCH_EXTRA:-} > $O/prof_quick.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_quick -o q -- python $R/bench.py --pairs 16 --steps 96 --warmup 8 --resident-steps 0 --closed-form-steps 0 --no-cpu-baseline --no-cli --no-default-mode --no-parity --profiled-steps 0 ${BENCH_EXTRA:-} > $O/prof_quick.log 2>&1
 grep "registrations executed" $O/prof_quick.log
 find $O/prof_quick -name "*kernel_trace.csv" -delete
 python3 - <<PY

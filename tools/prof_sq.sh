@@ -6,7 +6,7 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 export BENCH_LEAD_ROUNDS=1 BENCH_MIN_ROUNDS=${BENCH_MIN_ROUNDS:-6}
-CMD="python $R/bench.py --pairs 16 --steps 96 --warmup 8 --resident-steps 0 --svd-steps 0 --no-cpu-baseline --no-cli --no-default-mode --no-parity --profiled-steps 0"
+CMD="python $R/bench.py --pairs 16 --steps 96 --warmup 8 --resident-steps 0 --closed-form-steps 0 --no-cpu-baseline --no-cli --no-default-mode --no-parity --profiled-steps 0"
 rm -rf $O/prof_sq
 timeout 900 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU GRBM_GUI_ACTIVE --output-format csv -d $O/prof_sq -o sq -- $CMD > $O/prof_sq.log 2>&1
 grep "registrations executed" $O/prof_sq.log

@@ -19,7 +19,7 @@ cd /tmp && export TMPDIR=/tmp
 #  profiled process, below hipGraphLaunch; ~110 are fine)
 export BENCH_LEAD_ROUNDS=1
 export BENCH_MIN_ROUNDS=${BENCH_MIN_ROUNDS:-6}   # 6 rounds of 32 in flight = 192 timed steps (+ lead-in, warm-up, tail)
-CMD="python $R/bench.py --pairs 16 --steps 96 --warmup 8 --resident-steps 0 --svd-steps 0 --no-cpu-baseline --no-cli --no-default-mode --no-parity --profiled-steps 0"
+CMD="python $R/bench.py --pairs 16 --steps 96 --warmup 8 --resident-steps 0 --closed-form-steps 0 --no-cpu-baseline --no-cli --no-default-mode --no-parity --profiled-steps 0"
 rm -rf $O/prof_bench $O/prof_pmc_fetch $O/prof_pmc_write
 # every pass is tried up to three times
 prof() {   # prof <dir> <output name> <rocprofv3 options...>
