@@ -21,10 +21,15 @@ build/%.o: $(CSRC)/%.hip $(HIP_HDRS)
 	@mkdir -p build
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
-plade_amd/libplade_hip.so: $(HIP_OBJS)
+# host-only parts of the library (the PLY ingest: plade_ply_read of include/plade_hip.h and the CLI share it)
+build/ply_reader.o: $(CSRC)/ply_reader.cpp $(CSRC)/ply_reader.h include/plade_hip.h
+	@mkdir -p build
+	$(CXX) -O2 -std=c++17 -fPIC -Iinclude -I$(CSRC) -c $< -o $@
+
+plade_amd/libplade_hip.so: $(HIP_OBJS) build/ply_reader.o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^
 
-HOST_SRCS := $(CSRC)/main.cpp $(CSRC)/plade_host.cpp $(CSRC)/ply_reader.cpp
+HOST_SRCS := $(CSRC)/main.cpp $(CSRC)/plade_host.cpp
 plade_amd/PLADE: $(HOST_SRCS) $(CSRC)/plade.h $(CSRC)/plade_compat.h $(CSRC)/ply_reader.h plade_amd/libplade_hip.so
 	$(CXX) -O2 -std=c++17 -pthread -Iinclude -I$(CSRC) $(HOST_SRCS) -o $@ -Lplade_amd -lplade_hip -Wl,-rpath,'$$ORIGIN'
 

@@ -335,6 +335,16 @@ int plade_selftest_readback(plade_ctx *ctx, uint32_t n_ranges, uint32_t words, u
  * streams `mbytes` MB of scratch memory; returns when they have finished.  tools/exp_interference.py runs it beside the
  * registrations to measure what foreign kernel boundaries, workgroup dispatches and memory traffic cost them. */
 int plade_diag_launches(plade_ctx *ctx, uint32_t count, uint32_t blocks, uint32_t mbytes);
+/* PLY ingest of the CLI: replaces load_ply_cloud (code/PLADE/util.cpp:1505-1546) over PlyReader::read
+ * (code/PLADE/ply_reader.cpp:46-152, collect_elements :277-386) and rply (code/3rd_party/rply/rply.c).  Reads the `vertex`
+ * element's float / double properties x y z (or X Y Z) and nx ny nz of an ascii, binary_little_endian or binary_big_endian
+ * file into a malloc'ed n x 6 float array (x y z nx ny nz per point; free with plade_ply_free).  A binary file in the host's
+ * byte order whose vertex element is exactly `float x y z nx ny nz` is read with one bulk read.  Returns PLADE_OK, or
+ * PLADE_EINVAL with a message in `err` (NUL-terminated, truncated to err_cap) wherever the reference's function returns
+ * false: unreadable / malformed file, no vertex points, "the number of points does not equal to the number of normals in the
+ * file" (util.cpp:1533-1536), an empty cloud.  Host code only: no context, no GPU. */
+int plade_ply_read(const char *path, float **pos_nrm, uint64_t *n, char *err, size_t err_cap);
+void plade_ply_free(float *pos_nrm);
 /* Seam of the one host-side stage whose tie-breaking shapes the result: the order in which
  * std::sort(sortVec.begin(), sortVec.end(), myCompareGreater) (code/PLADE/util.cpp:335-345, util.h:347-365) leaves clusters
  * of the given sizes -- order[i] = index of the cluster at sorted position i.  mode 0: the library's implementation

@@ -23,7 +23,7 @@ ABI_SYMBOLS = [
     "plade_registration_dev", "plade_dump_get", "plade_stats_get", "plade_kernel_time", "plade_plane_component",
     "plade_sort_pairs", "plade_host_pin", "plade_host_unpin", "plade_score_planes_subset", "plade_registration_next", "plade_cluster_transforms", "plade_device_synchronize", "plade_selftest_readback",
     "plade_registration_pairs", "plade_registration_pairs_dev", "plade_pair_ctx", "plade_set_candidate_shard", "plade_diag_launches", "plade_diag_cluster_order", "plade_diag_line_solver_host", "plade_sort_segments",
-    "plade_closest_points", "plade_lines_meet",
+    "plade_closest_points", "plade_lines_meet", "plade_ply_read", "plade_ply_free",
     "plade_device_count", "plade_comm_unique_id", "plade_comm_create", "plade_comm_all_gather", "plade_comm_destroy", "plade_comm_last_error",
     "plade_set_candidate_shard_comm",
 ]
@@ -95,6 +95,8 @@ def load_library(path=LIB_PATH):
     sig("plade_diag_launches", argtypes=[p, u32, u32, u32])
     sig("plade_diag_cluster_order", argtypes=[p, u32, i32, i32, p])
     sig("plade_diag_line_solver_host", argtypes=[i32, p, p, p, p, u32, p, p, p])
+    sig("plade_ply_read", argtypes=[C.c_char_p, C.POINTER(C.POINTER(C.c_float)), C.POINTER(u64), C.c_char_p, C.c_size_t])
+    sig("plade_ply_free", argtypes=[C.POINTER(C.c_float)], restype=None)
     sig("plade_sort_segments", argtypes=[p, p, p, p, u32, C.c_int, p, p])
     sig("plade_set_candidate_shard", argtypes=[p, u32, u32, u32, EXCHANGE_FN, p])
     sig("plade_registration_minsupport", argtypes=[p, p, u32, p, u32, i32, i32, p])
@@ -158,6 +160,21 @@ def default_params():
     prm = Params()
     load_library().plade_default_params(C.byref(prm))
     return prm
+
+
+def read_ply(path):
+    """plade_ply_read (no GPU): the CLI's PLY ingest -> (N, 6) float32 array x y z nx ny nz; raises PladeError with the
+    reader's message where the reference's load_ply_cloud (code/PLADE/util.cpp:1505-1546) returns false."""
+    L = load_library()
+    ptr, n = C.POINTER(C.c_float)(), C.c_uint64(0)
+    err = C.create_string_buffer(512)
+    rc = L.plade_ply_read(os.fsencode(path), C.byref(ptr), C.byref(n), err, len(err))
+    if rc != 0:
+        raise PladeError(rc, err.value.decode(errors="replace"))
+    try:
+        return np.ctypeslib.as_array(ptr, shape=(n.value, 6)).copy()
+    finally:
+        L.plade_ply_free(ptr)
 
 
 def line_solver_host(kind, a, b, c, d):

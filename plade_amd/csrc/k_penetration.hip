@@ -59,15 +59,17 @@ __device__ __forceinline__ int edge_hits(f3 lineVec, f3 linePoint, const f3 *c, 
 }
 
 // items are grouped by plane pair: pair (i1, j1) owns slots [pair * K, pair * K + pair_count[pair])
-// SVD = 1 (plade_params.closest_point_mode = 1): the eight line / rectangle-edge meetings of a triple are the reference's
-// 6 x 5 float solves (k_svd.h), one lane's matrices in LDS (260 B per lane, hence 128 lanes per workgroup)
-template <int SVD, int TPB>
-__device__ void k_pen_setup(const VB &vb, PenTables tb, float len_th, float ang_th, PenItem *__restrict__ items,
-                                                   uint32_t *__restrict__ n_items, uint32_t *__restrict__ pair_count) {
-    const size_t idx = (size_t)vb.bx * blockDim.x + threadIdx.x;
-    const size_t total = (size_t)tb.K * tb.ps * tb.pt;
-    if (idx >= total) return;
+struct PenTriple {     // what a triple (candidate k, source plane i1, target plane j1) carries from the gate to its item
+    uint32_t k, i1, j1;
+    float plane1[4];
+    f3 lineVec, linePoint;
+    f3 c[8];           // rectangle of the transformed source plane (0..3), of the target plane (4..7)
+};
+
+// gate (util.cpp:487-492), plane/plane intersection line (util.cpp:1296), the two rectangles; false: the triple is out
+__device__ __forceinline__ bool pen_triple(const PenTables &tb, size_t idx, float len_th, float ang_th, PenTriple &t) {
     const uint32_t j1 = (uint32_t)(idx % tb.pt), i1 = (uint32_t)((idx / tb.pt) % tb.ps), k = (uint32_t)(idx / ((size_t)tb.pt * tb.ps));
+    t.k = k; t.i1 = i1; t.j1 = j1;
     const float *c = tb.cand + 12 * (size_t)k;
     m3 R;
     for (int r = 0; r < 3; ++r) for (int q = 0; q < 3; ++q) R.m[r][q] = c[3 * r + q];
@@ -75,33 +77,27 @@ __device__ void k_pen_setup(const VB &vb, PenTables tb, float len_th, float ang_
     const float T12[12] = {c[0], c[1], c[2], c[9], c[3], c[4], c[5], c[10], c[6], c[7], c[8], c[11]};
     const float *sc = tb.s_coef + 4 * (size_t)i1;
     const f3 pn = mul_e(R, f3(sc[0], sc[1], sc[2]));
-    float plane1[4] = {pn.x, pn.y, pn.z, 0.f};
-    plane1[3] = -(-sc[3] + dot_s(pn, T));
+    t.plane1[0] = pn.x; t.plane1[1] = pn.y; t.plane1[2] = pn.z;
+    t.plane1[3] = -(-sc[3] + dot_s(pn, T));
     const f3 c2m = mul_e(R, f3(tb.s_center[3 * i1], tb.s_center[3 * i1 + 1], tb.s_center[3 * i1 + 2])) + T;
     const float *tc = tb.t_coef + 4 * (size_t)j1;
     const f3 plane_A(tc[0], tc[1], tc[2]);
     const f3 tcen(tb.t_center[3 * j1], tb.t_center[3 * j1 + 1], tb.t_center[3 * j1 + 2]);
-    const double c2p = (double)((fabsf(dot_e(plane_A, c2m) + tc[3]) + fabsf(dot_e(pn, tcen) + plane1[3])) / 2);
-    if (c2p < (double)len_th && dot_e(pn, plane_A) > ang_th) return;  // util.cpp:489
-    f3 lineVec, linePoint;
-    if (!plane_plane_line(plane1, tc, lineVec, linePoint)) return;    // util.cpp:1296
-    f3 c1[4], c2[4];
+    const double c2p = (double)((fabsf(dot_e(plane_A, c2m) + tc[3]) + fabsf(dot_e(pn, tcen) + t.plane1[3])) / 2);
+    if (c2p < (double)len_th && dot_e(pn, plane_A) > ang_th) return false;  // util.cpp:489
+    if (!plane_plane_line(t.plane1, tc, t.lineVec, t.linePoint)) return false;    // util.cpp:1296
     for (int q = 0; q < 4; ++q) {
         const float *f = tb.s_four + 12 * (size_t)i1 + 3 * q;
-        c1[q] = pcl_xform(T12, f3(f[0], f[1], f[2]));
+        t.c[q] = pcl_xform(T12, f3(f[0], f[1], f[2]));
         const float *g = tb.t_four + 12 * (size_t)j1 + 3 * q;
-        c2[q] = f3(g[0], g[1], g[2]);
+        t.c[4 + q] = f3(g[0], g[1], g[2]);
     }
-    f3 ip1[4], ip2[4];
-    auto meet = [&](f3 v1, f3 p1, f3 v2, f3 p2, f3 &out) -> bool {
-        if (!SVD) return lines_meet(v1, p1, v2, p2, out);
-        if (fabsf(dot_e(v1, v2)) > 0.9999) return false;    // util.cpp:1463
-        out = lines_meet_svd(v1, p1, v2, p2);
-        return true;
-    };
-    const int n1 = edge_hits<SVD != 0>(lineVec, linePoint, c1, ip1, meet);
-    const int n2 = edge_hits<SVD != 0>(lineVec, linePoint, c2, ip2, meet);
-    if (n1 != 2 || n2 != 2) return;  // empty -> not penetrable; any other count -> "-1, continue"
+    return true;
+}
+
+// the clipped segments' overlap (util.cpp:1330-1378) -> the triple's item, in its plane pair's slots
+__device__ __forceinline__ void pen_emit(const PenTables &tb, const PenTriple &t, const f3 *ip1, const f3 *ip2, PenItem *__restrict__ items,
+                                         uint32_t *__restrict__ pair_count) {
     const f3 direc = normalized_e(ip1[1] - ip1[0]);
     const f3 inter[4] = {ip1[0], ip1[1], ip2[0], ip2[1]};
     float len[4];
@@ -117,14 +113,101 @@ __device__ void k_pen_setup(const VB &vb, PenTables tb, float len_th, float ang_
     if (0 == (ord[0] / 2 - ord[1] / 2)) return;  // no overlap of the two clipped segments
     const f3 sp = inter[ord[1]], ep = inter[ord[2]];
     const float length = norm_e(ep - sp);
-    (void)n_items;   // (a single counter bumped by every surviving triple serialises at the memory side)
-    const uint32_t pair = i1 * tb.pt + j1;
+    // (a single counter bumped by every surviving triple serialises at the memory side: one counter per plane pair)
+    const uint32_t pair = t.i1 * tb.pt + t.j1;
     const uint32_t slot = pair * tb.K + atomicAdd(&pair_count[pair], 1u);
     PenItem it;
-    it.k = k; it.i1 = i1; it.j1 = j1;
-    for (int q = 0; q < 4; ++q) it.plane1[q] = plane1[q];
+    it.k = t.k; it.i1 = t.i1; it.j1 = t.j1;
+    for (int q = 0; q < 4; ++q) it.plane1[q] = t.plane1[q];
     it.sx = sp.x; it.sy = sp.y; it.sz = sp.z; it.dx = direc.x; it.dy = direc.y; it.dz = direc.z; it.length = length;
     items[slot] = it;
+}
+
+// closest_point_mode = 0: one lane per triple, the eight line / rectangle-edge meetings by the closed form
+template <int TPB>
+__device__ void k_pen_setup(const VB &vb, PenTables tb, float len_th, float ang_th, PenItem *__restrict__ items,
+                            uint32_t *__restrict__ n_items, uint32_t *__restrict__ pair_count) {
+    (void)n_items;
+    const size_t idx = (size_t)vb.bx * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)tb.K * tb.ps * tb.pt;
+    if (idx >= total) return;
+    PenTriple t;
+    if (!pen_triple(tb, idx, len_th, ang_th, t)) return;
+    f3 ip1[4], ip2[4];
+    auto meet = [&](f3 v1, f3 p1, f3 v2, f3 p2, f3 &out) -> bool { return lines_meet(v1, p1, v2, p2, out); };
+    const int n1 = edge_hits<false>(t.lineVec, t.linePoint, t.c, ip1, meet);
+    const int n2 = edge_hits<false>(t.lineVec, t.linePoint, t.c + 4, ip2, meet);
+    if (n1 != 2 || n2 != 2) return;  // empty -> not penetrable; any other count -> "-1, continue"
+    pen_emit(tb, t, ip1, ip2, items, pair_count);
+}
+
+// closest_point_mode = 1 (the default): the eight meetings of a triple are the reference's 6 x 5 float solves (k_svd.h,
+// ~15 000 instructions each), and most triples need few of them -- the gate drops a triple, util.cpp:1463 drops an edge that is
+// parallel to the intersection line (two of a rectangle's four in a Manhattan scene).  One lane per triple would run eight
+// solves in sequence with most lanes idle, so a wavefront POOLS its solves: every lane publishes its line and its edges in
+// LDS, the needed (lane, edge) items are numbered by ballots, the 64 lanes take one item each per round (whoever's it is),
+// leave the meeting point where the edge was, and every lane then reads its own eight results and finishes as before.
+// Same systems, same arithmetic, same results -- only which lane evaluates which system changes.
+constexpr int PS_TPB = 64;
+__device__ void k_pen_setup_svd(const VB &vb, PenTables tb, float len_th, float ang_th, PenItem *__restrict__ items,
+                                uint32_t *__restrict__ n_items, uint32_t *__restrict__ pair_count) {
+    (void)n_items;
+    __shared__ float pub[54 * PS_TPB];        // word w of lane l at w * PS_TPB + l: line (6); per edge e: direction (3), corner (3)
+    __shared__ uint16_t queue[8 * PS_TPB];
+    const uint32_t lane = threadIdx.x;
+    const size_t idx = (size_t)vb.bx * PS_TPB + lane;
+    const size_t total = (size_t)tb.K * tb.ps * tb.pt;
+    PenTriple t;
+    const bool active = idx < total && pen_triple(tb, idx, len_th, ang_th, t);
+    uint32_t need = 0;
+    auto put = [&](int w, f3 v) { pub[(w + 0) * PS_TPB + lane] = v.x; pub[(w + 1) * PS_TPB + lane] = v.y; pub[(w + 2) * PS_TPB + lane] = v.z; };
+    auto get = [&](int w, uint32_t l) { return f3(pub[(w + 0) * PS_TPB + l], pub[(w + 1) * PS_TPB + l], pub[(w + 2) * PS_TPB + l]); };
+    if (active) {
+        put(0, t.lineVec); put(3, t.linePoint);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int base = e & 4, i = (e & 3) + 1;
+            const f3 a = t.c[base + (i - 1) % 4], b = t.c[base + i % 4];
+            const f3 tl = normalized_e(b - a);
+            if (!(fabsf(dot_e(t.lineVec, tl)) > 0.9999)) {    // util.cpp:1463
+                need |= 1u << e;
+                put(6 + 6 * e, tl); put(9 + 6 * e, a);
+            }
+        }
+    }
+    // number the items edge by edge, lane by lane
+    uint32_t n_items_wave = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const unsigned long long m = __ballot((need >> e) & 1u);
+        if ((need >> e) & 1u) queue[n_items_wave + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)(lane | (e << 6));
+        n_items_wave += (uint32_t)__popcll(m);
+    }
+    __syncthreads();
+    for (uint32_t first = 0; first < n_items_wave; first += PS_TPB) {
+        const uint32_t it = first + lane;
+        if (it < n_items_wave) {
+            const uint32_t q = queue[it], sl = q & 63u, e = q >> 6;
+            const f3 o = lines_meet_svd(get(0, sl), get(3, sl), get(6 + 6 * e, sl), get(9 + 6 * e, sl));
+            pub[(6 + 6 * e) * PS_TPB + sl] = o.x; pub[(7 + 6 * e) * PS_TPB + sl] = o.y; pub[(8 + 6 * e) * PS_TPB + sl] = o.z;
+        }
+    }
+    __syncthreads();
+    if (!active) return;
+    f3 ip1[4], ip2[4];
+    int n1 = 0, n2 = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        if (!((need >> e) & 1u)) continue;
+        const int base = e & 4, i = (e & 3) + 1;
+        const f3 a = t.c[base + (i - 1) % 4], b = t.c[base + i % 4];
+        const f3 ip = get(6 + 6 * e, lane);
+        if (dot_e(a - ip, b - ip) > 0) continue;
+        if (e < 4) { if (n1 < 4) ip1[n1] = ip; ++n1; }
+        else { if (n2 < 4) ip2[n2] = ip; ++n2; }
+    }
+    if (n1 != 2 || n2 != 2) return;  // empty -> not penetrable; any other count -> "-1, continue"
+    pen_emit(tb, t, ip1, ip2, items, pair_count);
 }
 
 constexpr int PEN_MAXS = 1024;   // search steps along one intersection segment
@@ -476,10 +559,10 @@ void penetration_filter(plade_ctx *ctx, const float *cand_rt_host, uint32_t K, c
     const float *d_steps = d + n_tab;
     const uint32_t *d_order = reinterpret_cast<const uint32_t *>(d + n_tab + PEN_MAXS + 1);
     if (ctx->params.closest_point_mode == 1)
-        launch<k_pen_setup<1, 128>, 128>(ctx, dim3(cdiv(total, 128)), 0, tb, length_threshold,
+        launch<k_pen_setup_svd, PS_TPB>(ctx, dim3(cdiv(total, PS_TPB)), 0, tb, length_threshold,
                            angle_threshold, d_items, d_n, d_pair);
     else
-        launch<k_pen_setup<0, 256>, 256>(ctx, dim3(cdiv(total, 256)), 0, tb, length_threshold,
+        launch<k_pen_setup<256>, 256>(ctx, dim3(cdiv(total, 256)), 0, tb, length_threshold,
                            angle_threshold, d_items, d_n, d_pair);
     // in-plane grids of both sides (cell = 2 r)
     const float cell = pen_grid_cell(length_threshold);
