@@ -100,8 +100,6 @@ def test_cli_malformed_ply_files_fail_cleanly(tmp_path):
         "huge.ply": b"ply\nformat binary_little_endian 1.0\nelement vertex 4000000000\n" + props.encode() + b"end_header\n" + b"\0" * 240,
         "beyond32.ply": b"ply\nformat binary_little_endian 1.0\nelement vertex 99999999999999\n" + props.encode() + b"end_header\n",
         "truncated.ply": b"ply\nformat binary_little_endian 1.0\nelement vertex 100\n" + props.encode() + b"end_header\n" + b"\0" * 100,
-        "neglist.ply": b"ply\nformat binary_little_endian 1.0\nelement face 1\nproperty list int int vertex_indices\n"
-                       b"element vertex 1\n" + props.encode() + b"end_header\n" + (-5).to_bytes(4, "little", signed=True) + b"\0" * 24,
         "nonsense.ply": b"ply\nformat ascii 1.0\nelement vertex 2\n" + props.encode() + b"end_header\n1 2 3 0 0 1\nfoo bar\n",
     }
     for name, blob in cases.items():
@@ -112,6 +110,13 @@ def test_cli_malformed_ply_files_fail_cleanly(tmp_path):
         assert r.returncode == 1, (name, r.returncode, r.stderr)
         assert "loading target point cloud failed" in r.stderr, (name, r.stderr)
         assert out.read_text().startswith("registration failed, an identity matrix is recorded:")
+    # a NEGATIVE list count is not an error for the reference (rply.c:833-846: the value loop simply does not run; golden case
+    # negative_list_length of tests/test_ply_reader.py): the face is empty, the vertex behind it is read
+    neglist = tmp_path / "neglist.ply"
+    neglist.write_bytes(b"ply\nformat binary_little_endian 1.0\nelement face 1\nproperty list int int vertex_indices\n"
+                        b"element vertex 1\n" + props.encode() + b"end_header\n" + (-5).to_bytes(4, "little", signed=True) + b"\0" * 20 + b"\0\0\x80\x3f")
+    import plade_amd
+    assert np.array_equal(plade_amd.read_ply(str(neglist)), np.array([[0, 0, 0, 0, 0, 1]], np.float32))
     # an ascii vertex line far longer than any fixed buffer parses (trailing blanks), and extra properties are ignored
     long_ascii = tmp_path / "long.ply"
     with open(long_ascii, "w") as f:
