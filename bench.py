@@ -842,7 +842,7 @@ def main():
         ctx.unpin(tg); ctx.unpin(sr)
 
     # ---- roofline leg: one extra profiled step (HIP events on the ctx stream around every launch) ----
-    roofline = roofline_sort = None
+    roofline = roofline_sort = dominant = None
     stage = {}
     latency_ms = None
     if rank == 0:
@@ -949,9 +949,19 @@ def main():
                         "traffic_per_step": traffic_reg,
                         "measured": f"{how}; {args.profiled_steps} profiled registrations with "
                                     f"{(M - 1) * S} other registrations in flight (the load of the timed region); launches are those of groups of {S} pairs, as timed",
-                        "why_this_kernel": "largest mover of HBM bytes of the step (the K1 scoring scan, SURVEY.md 8d: 28 B per point and "
-                                           "launch); kernels above it in GPU time (rocprof.top_by_gpu_time) are LDS / latency bound "
-                                           "and have no HBM figure"}
+                        "why_this_kernel": "dominant by BYTES: the largest mover of algorithmic HBM bytes of the step (the K1 scoring scan, SURVEY.md "
+                                           "8d: 28 B per point and launch); the kernels with more GPU TIME are on the line as "
+                                           "`dominant_by_gpu_time`, each with its own fraction"}
+            # effective vs physical: `achieved` counts the ALGORITHMIC bytes of the launch (every point of the clouds it serves,
+            # SURVEY.md 8d), the counters what the launch really moved -- tile-box culling and the compacted scan view skip
+            # most of the rest, so the HBM is far less busy than `frac` reads
+            if traffic is not None and avg_us:
+                roofline["hbm_counter_GBps"] = traffic / (avg_us * 1e-6) / 1e9
+                roofline["hbm_counter_frac"] = roofline["hbm_counter_GBps"] / HBM_PEAK_GBS
+                roofline["bytes_skipped_frac"] = max(0.0, 1.0 - traffic / (by / nl))
+                roofline["effective_vs_physical"] = ("frac = algorithmic bytes / duration (effective bandwidth: work the kernel was asked to do); "
+                                                     "hbm_counter_frac = FETCH_SIZE/WRITE_SIZE bytes / duration (physical HBM utilisation); "
+                                                     "bytes_skipped_frac = share of the algorithmic bytes never fetched (culled tiles, compacted view)")
             rp = rocprof_stats(best, S)
             if rp is not None:
                 roofline["rocprof"] = rp
@@ -979,6 +989,27 @@ def main():
             rp = rocprof_stats("sort_pass", S)
             if rp and rp.get("avg_launch_us"):
                 roofline_sort["rocprof"] = {k: rp[k] for k in ("file", "avg_launch_us", "calls", "launches_per_registration", "share_of_gpu_time") if k in rp}
+        # the kernel (family) with the most GPU time in the committed kernel trace, with ITS roofline fraction from this run's
+        # HIP-event leg: `roofline.kernel` is chosen by bytes moved, this one by time spent
+        dominant = None
+        rp_any = rocprof_stats(best, S) if best is not None else None
+        if rp_any and rp_any.get("top_by_gpu_time"):
+            rows = []
+            for t_ in rp_any["top_by_gpu_time"][:3]:
+                tag = next((k for k, sym in KERNEL_SYMBOLS.items() if sym.rstrip("(") in t_["kernel"]), None)
+                row = dict(t_, stage=tag)
+                if tag and tag in stage and stage[tag].get("GB/s"):
+                    row["algorithmic_GBps"] = stage[tag]["GB/s"]
+                    row["frac_of_hbm_peak"] = stage[tag]["GB/s"] / HBM_PEAK_GBS
+                    row["seconds_per_step"] = stage[tag]["seconds"]
+                tr_, _src = pmc_traffic(tag, S) if tag else (None, None)
+                if tr_ is not None and tag in stage and stage[tag].get("seconds"):
+                    row["hbm_counter_bytes_per_step"] = tr_
+                    row["hbm_counter_frac"] = tr_ / stage[tag]["seconds"] / 1e9 / HBM_PEAK_GBS
+                rows.append(row)
+            dominant = {"source": rp_any["file"], "kernels": rows,
+                        "note": "share / avg_us: committed rocprofv3 kernel trace of this command; frac_of_hbm_peak: algorithmic bytes / HIP-event "
+                                "duration of the same kernel in this run's profiled leg (under the load of the other groups)"}
         stage_times = {k: v for k, v in st.items() if k.startswith("t_")}
         b_total = st.get("bytes_ransac", 0.0) + st.get("bytes_voxel", 0.0) + st.get("bytes_verify", 0.0)
         if roofline is not None:
@@ -1074,6 +1105,7 @@ def main():
                                            "group occupied its worker (Little's law)"},
             "roofline": roofline,
             "roofline_sort": roofline_sort,
+            "dominant_by_gpu_time": dominant,
             "cpu_baseline": cpu,
             "cpu_baseline_batch": cpu_batch,
             "cli_end_to_end": cli_e2e,

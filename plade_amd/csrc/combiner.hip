@@ -124,10 +124,20 @@ void Combiner::flush_locked(std::unique_lock<std::mutex> &lk) {
                         a.words[a.n] = e.words; a.value[a.n] = e.value; ++a.n;
                     };
                     for (int k = 0; k < n; ++k) put(*es[k]);
+                    // the ranges of one launch run concurrently: a further entry joins only if what it writes is disjoint from
+                    // everything already in the launch (a pair that clears a buffer and then fills part of it keeps its order)
+                    auto disjoint = [&](const QEntry &e) {
+                        const uintptr_t lo = reinterpret_cast<uintptr_t>(e.dst), hi = lo + 4ull * e.words;
+                        for (uint32_t k = 0; k < a.n; ++k) {
+                            const uintptr_t l2 = reinterpret_cast<uintptr_t>(a.dst[k]), h2 = l2 + 4ull * a.words[k];
+                            if (lo < h2 && l2 < hi) return false;
+                        }
+                        return true;
+                    };
                     for (bool more = true; more && a.n < RANGES_MAX;) {
                         more = false;
                         for (int t = 0; t < BATCH_MAX && a.n < RANGES_MAX; ++t)
-                            if (cur[t] < q[t].size() && q[t][cur[t]].kind == kind) { put(q[t][cur[t]]); ++cur[t]; more = true; }
+                            if (cur[t] < q[t].size() && q[t][cur[t]].kind == kind && disjoint(q[t][cur[t]])) { put(q[t][cur[t]]); ++cur[t]; more = true; }
                     }
                     if (kind == QEntry::FILL) ranges_launch<true>(st, a, nullptr, nullptr, 0);
                     else ranges_launch<false>(st, a, nullptr, nullptr, 0);
@@ -241,6 +251,18 @@ void Combiner::leave(plade_ctx *c) {
     c->read_arena_used = 0; c->write_arena_used = 0;
     c->comb = nullptr;
     c->comb_slot = -1;
+}
+
+// Allocations a pair replaced while launches that may name them were queued: what the pair still had queued when it left
+// stays in its slot until the others' next flush, so they are freed when the call ends (every flush, the last one included,
+// returns with the stream drained).
+void Combiner::bury(std::vector<void *> &gy) {
+    std::lock_guard<std::mutex> lk(m);
+    graveyard.insert(graveyard.end(), gy.begin(), gy.end());
+    gy.clear();
+}
+Combiner::~Combiner() {
+    for (void *p : graveyard) (void)hipFree(p);
 }
 
 }  // namespace plade

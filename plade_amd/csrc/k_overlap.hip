@@ -205,22 +205,25 @@ void TargetGrid::build(plade_ctx *ctx, const float *d_xyz, uint32_t n_pts, uint3
     if (!(cell > 0.f)) cell = 1.f;
     PLADE_REQUIRE(std::isfinite(init[0]) && std::isfinite(init[1]) && std::isfinite(init[2]) && std::isfinite(init[3]) &&
                       std::isfinite(init[4]) && std::isfinite(init[5]), PLADE_EINVAL, "grid: non-finite bounding box");
+    static const bool old_index = getenv("PLADE_OVERLAP_INDEX_COMPACT") != nullptr;   // A/B hook: the bitmap + rank index of rounds 3-5
+    dense = compact && !old_index;
+    // the dense row index has one row start per cell of the grid PADDED by two cells on every side: the cap is on that
+    // product (a flat or elongated target -- 6900 x 6900 x 1 cells -- would otherwise get 2.4e8 rows, 1 GB; advisor r5)
+    const double pad = dense ? 4.0 : 0.0;
     for (;;) {
         double ex = std::floor((init[3] - init[0]) / cell) + 1, ey = std::floor((init[4] - init[1]) / cell) + 1,
                ez = std::floor((init[5] - init[2]) / cell) + 1;
-        if (ex * ey * ez <= 48.0e6) { gp.dx = (int)ex; gp.dy = (int)ey; gp.dz = (int)ez; break; }
+        if ((ex + pad) * (ey + pad) * (ez + pad) <= 48.0e6) { gp.dx = (int)ex; gp.dy = (int)ey; gp.dz = (int)ez; break; }
         cell *= 1.26f;
     }
     gp.mnx = init[0]; gp.mny = init[1]; gp.mnz = init[2];
     gp.inv = 1.f / cell;
-    static const bool old_index = getenv("PLADE_OVERLAP_INDEX_COMPACT") != nullptr;   // A/B hook: the bitmap + rank index of rounds 3-5
-    dense = compact && !old_index;
     keys.ensure(n); keys2.ensure(n); vals.ensure(n); vals2.ensure(n);
     sorted.ensure(n);
     GridParams g{gp.mnx, gp.mny, gp.mnz, gp.inv, gp.dx, gp.dy, gp.dz};
     if (dense) {
         DX = gp.dx + 4; DY = gp.dy + 4; DZ = gp.dz + 4;
-        ncells = (size_t)DX * DY * DZ;                       // <= ~49e6 (the cap above): a table of <= 200 MB
+        ncells = (size_t)DX * DY * DZ;                       // <= 48e6 (the cap above): a table of <= 192 MB
         const size_t table = (ncells + 8 + 15) & ~(size_t)15;   // row_start[a + 3] of the last row; whole 64-byte fills
         for (mask_shift = 2;; ++mask_shift) {                // the near mask must fit 32 KB of LDS
             const size_t mb = (size_t)(((DX - 1) >> mask_shift) + 1) * (((DY - 1) >> mask_shift) + 1) * (((DZ - 1) >> mask_shift) + 1);

@@ -86,15 +86,14 @@ struct RegSolver {
         if (fabs(inner) <= tol * sqrt(ea * eb)) return false;
         inner *= 2;
         const double gap = ea - eb, hyp = hypot_corrected(inner, gap);
-        float cs, sn;
-        if (gap < 0) {
-            const double half = (hyp - gap) * 0.5;
-            sn = (float)sqrt(half / hyp);
-            cs = (float)(inner / (hyp * sn * 2));
-        } else {
-            cs = (float)sqrt((hyp + gap) / (hyp * 2));
-            sn = (float)(inner / (hyp * cs * 2));
-        }
+        // lapack.cpp:583-594: gap < 0: s = sqrt((hyp - gap) / 2 / hyp), c = inner / (hyp s 2); else c = sqrt((hyp + gap) / (2 hyp)),
+        // s = inner / (hyp c 2).  One square root and two divisions on operands picked per lane -- the operations of the lane's own
+        // branch, in its order -- instead of both branches one after the other whenever the lanes of a wavefront disagree
+        const bool neg = gap < 0;
+        const double num = neg ? (hyp - gap) * 0.5 : hyp + gap, den = neg ? hyp : hyp * 2;
+        const float first = (float)sqrt(num / den);
+        const float second = (float)(inner / (hyp * first * 2));
+        const float cs = neg ? second : first, sn = neg ? first : second;
         ea = 0; eb = 0;
 #pragma unroll
         for (int k = 0; k < M; ++k) {

@@ -108,7 +108,10 @@ struct Combiner {
     void wait(plade_ctx *c);                  // the pair's host wait: returns when everything it queued has run and its read-backs are in
     QEntry &push(plade_ctx *c);
     int size() { std::lock_guard<std::mutex> lk(m); return members; }   // pairs taking part right now (a pair that fails leaves early)
+    void bury(std::vector<void *> &gy);       // device allocations to free when the call has ended (combiner.hip)
+    ~Combiner();
 private:
+    std::vector<void *> graveyard;
     void flush_locked(std::unique_lock<std::mutex> &lk);
 };
 

@@ -303,7 +303,9 @@ bool run_registration(plade_ctx *ctx, RegistrationWork &W, const CloudDev &tgt, 
         // the four hardware queues and adds a host thread per pair -- one side after the other on this stream: +1.5 % of the
         // batch throughput, 0.6 ms less host CPU per registration (profiles/r4_experiments.md 2c).  plade_params.prepare_sides.
         const int ps = ctx->params.prepare_sides;
-        const bool serial_sides = ps == 2 || (ps == 0 && (ctx->in_group || ctx->params.host_wait != 0));
+        // (under a Combiner always: the pair's launches travel on the lead's stream, and an auxiliary stream of the pair's own
+        //  could not be ordered against them by events recorded on this context's idle stream; advisor r5)
+        const bool serial_sides = ps == 2 || ctx->comb || (ps == 0 && (ctx->in_group || ctx->params.host_wait != 0));
         if (serial_sides) {
             ok_m = prepare_side(ctx, "tgt", tgt, tp, downSampleDistance, pen_grid_cell(lengthThreshold), scale, true, W.tgt_pairs, M, false);
             ok_c = prepare_side(ctx, "src", src, sp, downSampleDistance, pen_grid_cell(lengthThreshold), scale, false, W.src_pairs, C);
@@ -337,7 +339,9 @@ bool run_registration(plade_ctx *ctx, RegistrationWork &W, const CloudDev &tgt, 
         if (sort_source)
         overlap_sort_source(gctx, W.ov_work, C.d_ds_soa.p, C.d_ds_soa.p + C.n_ds, C.d_ds_soa.p + 2 * (size_t)C.n_ds, C.n_ds,
                             1.f / W.grid.gp.inv);
-        HIP_TRY(hipEventRecord(W.ev_grid, gctx->stream));
+        // (under a Combiner the sides are serial and builder and consumer sit in the same pair queue, in order: no event needed --
+        //  and a FUNC entry per pair would hold that pair's queue back while the others' next kernels merge without it)
+        if (!gctx->comb) HIP_TRY(hipEventRecord(W.ev_grid, gctx->stream));
     }
     {
         StageTimer t(ctx, "t_descriptors");   // built by prepare_side; only the optional dump is left here
@@ -526,7 +530,7 @@ bool run_registration(plade_ctx *ctx, RegistrationWork &W, const CloudDev &tgt, 
         if (Km || by_rccl) {
             ctx->h2d(W.d_T16.p, up.data(), 4 * up.size());
             if (Km) {
-                HIP_TRY(hipStreamWaitEvent(ctx->stream, W.ev_grid, 0));
+                if (!ctx->comb) HIP_TRY(hipStreamWaitEvent(ctx->stream, W.ev_grid, 0));   // (under a Combiner: same queue, see the record)
                 const float *vsx = sort_source ? W.ov_work.sorted.p : C.d_ds_soa.p;
                 overlap_counts(ctx, W.ov_work, vsx, vsx + C.n_ds, vsx + 2 * (size_t)C.n_ds, C.n_ds,
                                W.grid, W.d_T16.p, d_centers, Km, (float)C.radius, downSampleDistance, d_counts, d_any, true);
@@ -535,7 +539,14 @@ bool run_registration(plade_ctx *ctx, RegistrationWork &W, const CloudDev &tgt, 
                 // ONE ncclAllGather on this stream, behind the kernel that wrote the counts: they never visit the host before
                 // every rank holds all of them (rank r's slot q is candidate q * world + r)
                 int32_t *d_all = W.d_shard_all.ensure(2 * (size_t)per * sh.world + 4);
-                comm_all_gather_dev(sh.comm, d_counts, d_all, 8 * (size_t)per, ctx->stream);
+                // (through raw_launch: when this pair's launches are collected by a Combiner -- a one-pair part of a group on a peer
+                //  context -- the upload and the kernels above reach the lead's stream only at the next flush, and the collective
+                //  has to take its place BEHIND them in the same order, on that stream; advisor r5)
+                {
+                    plade_comm *comm = sh.comm;
+                    const size_t bytes = 8 * (size_t)per;
+                    ctx->raw_launch([comm, d_counts, d_all, bytes](hipStream_t st) { comm_all_gather_dev(comm, d_counts, d_all, bytes, st); });
+                }
                 std::vector<int32_t> all(2 * (size_t)per * sh.world);
                 ctx->d2h(all.data(), d_all, 4 * all.size());
                 ctx->sync();

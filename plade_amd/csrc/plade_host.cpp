@@ -312,7 +312,13 @@ void registration_group(size_t count, Eigen::Matrix<float, 4, 4> *transformation
                 Loaded *l = &loaded[2 * i + side];
                 std::vector<float> *buf = &b[2 * i + side];
                 l->tried = true;
-                readers.emplace_back([file, l, buf]() { l->ok = plade::read_ply_pos_nrm(*file, *buf, l->err, &l->warnings) && !buf->empty(); });
+                // (an array that has to grow moves: its page-locked registration is released BEFORE the old block is freed -- a
+                //  registration left on freed memory fails the next one of whatever block takes the address; advisor r5)
+                PinnedVec *pin = &g_pins[2 * i + side];
+                readers.emplace_back([file, l, buf, pin]() {
+                    const std::function<void()> before_grow = [pin]() { pin->release(); };
+                    l->ok = plade::read_ply_pos_nrm(*file, *buf, l->err, &l->warnings, &before_grow) && !buf->empty();
+                });
             }
         }
         // the worker's GPU context (HIP start-up on first use, streams, the first work areas) is set up while the files load

@@ -192,7 +192,13 @@ bool read_value(Cursor &c, int type, int mode, bool swap, std::string &w, double
 
 struct FileCloser { FILE *f; ~FileCloser() { if (f) fclose(f); } };
 
-bool read_body(const std::string &path, std::vector<float> &out, std::string &err, std::vector<std::string> *warnings) {
+bool read_body(const std::string &path, std::vector<float> &out, std::string &err, std::vector<std::string> *warnings,
+               const std::function<void()> *before_grow) {
+    auto size_to = [&](size_t floats) {
+        if (out.size() == floats) return;
+        if (floats > out.capacity() && before_grow) (*before_grow)();     // the allocation is about to move
+        out.resize(floats);
+    };
     // `out` may be a reused staging array: it is only resized when the point count differs (no re-zeroing)
     auto fail = [&](const std::string &m) { out.clear(); err = m; return false; };
     FileCloser fc{fopen(path.c_str(), "rb")};
@@ -271,7 +277,7 @@ bool read_body(const std::string &path, std::vector<float> &out, std::string &er
     for (size_t i = 1; i < h.elems.size() && plain6; ++i) plain6 = h.elems[i].count <= 0 || h.elems[i].props.empty();
     if (plain6) {
         const size_t n = (size_t)h.elems[0].count;
-        if (out.size() != 6 * n) out.resize(6 * n);
+        size_to(6 * n);
         if (whole) {
             if (data.size() - h.data_offset < 24 * n) return fail("error occurred while parsing ply file: " + path);
             memcpy(out.data(), data.data() + h.data_offset, 24 * n);
@@ -284,7 +290,7 @@ bool read_body(const std::string &path, std::vector<float> &out, std::string &er
             data.resize((size_t)file_size);
             if (fread(data.data() + have, 1, data.size() - have, f) != data.size() - have) return fail("error occurred while parsing ply file: " + path);
         }
-        if (vertex >= 0 && has_pos && has_nrm) { const size_t n = (size_t)h.elems[vertex].count; if (out.size() != 6 * n) out.resize(6 * n); }
+        if (vertex >= 0 && has_pos && has_nrm) size_to(6 * (size_t)h.elems[vertex].count);
         Cursor c{data.data() + h.data_offset, data.data() + data.size()};
         std::string w;
         for (size_t ei = 0; ei < h.elems.size(); ++ei) {
@@ -349,10 +355,11 @@ bool read_body(const std::string &path, std::vector<float> &out, std::string &er
 
 }  // namespace
 
-bool read_ply_pos_nrm(const std::string &path, std::vector<float> &out, std::string &err, std::vector<std::string> *warnings) {
+bool read_ply_pos_nrm(const std::string &path, std::vector<float> &out, std::string &err, std::vector<std::string> *warnings,
+                      const std::function<void()> *before_grow) {
     // never throws: a header that asks for more memory than there is ends in `false` like any other malformed file
     try {
-        if (read_body(path, out, err, warnings)) return true;
+        if (read_body(path, out, err, warnings, before_grow)) return true;
         if (err.empty()) err = "empty point cloud in " + path;
         out.clear();
         return false;
@@ -382,7 +389,7 @@ extern "C" int plade_ply_read(const char *path, float **pos_nrm, uint64_t *n, ch
     *pos_nrm = nullptr; *n = 0;
     std::vector<float> buf;
     std::string msg;
-    if (!plade::read_ply_pos_nrm(path, buf, msg, nullptr)) {
+    if (!plade::read_ply_pos_nrm(path, buf, msg, nullptr, nullptr)) {
         if (err && err_cap) { strncpy(err, msg.c_str(), err_cap - 1); err[err_cap - 1] = 0; }
         return PLADE_EINVAL;
     }

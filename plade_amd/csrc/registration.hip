@@ -334,7 +334,7 @@ void register_group(plade_ctx *ctx, int first, int count, const CloudDev *const 
             Combiner &cb; plade_ctx *pc; bool on; std::vector<void *> &gy;
             ~Leave() {
                 tl_deferred_free = nullptr;
-                if (on) { try { cb.leave(pc); } catch (...) {} }
+                if (on) { try { cb.leave(pc); } catch (...) {} cb.bury(gy); }   // (what the pair still had queued may name them: freed with the call)
                 for (void *p : gy) (void)hipFree(p);
             }
         } leave{comb, pcs[i], lockstep, graveyard};

@@ -14,6 +14,14 @@ if ROOT not in sys.path:
 # PLADE_ORIENT_NORMALS=1 in their env (ORIENTED_ENV).  The shipped default (orient_normals = 0) is exercised by
 # tests/test_gpu_faithful.py (library, end to end against the oracle) and tests/test_gpu_cli.py (the CLI).
 ORIENTED = {"orient_normals": 1}
+# Accuracy against the GENERATOR's ground truth.  The library's default arithmetic for the closest points of two lines is the
+# reference's (plade_params.closest_point_mode = 1: cv::solve(DECOMP_SVD) on fp32 9 x 9 systems, bit-identical to the oracle's
+# restatement); on these axis-aligned synthetic rooms those solves are ill-conditioned (intersection lines with base points
+# kilometres away) and the registration lands 1e-2 ... 1.4e-1 (Frobenius) from the ground truth -- the
+# reference would, too.  Tests that ask "did it register the pair" use GT_TOL; tests that pin an accuracy (equivariance, the
+# 1e-3 of the bench scene) ask for the better-conditioned opt-in, CLOSED_FORM, like ORIENTED above.
+GT_TOL = 0.2
+CLOSED_FORM = {"closest_point_mode": 0}
 ORIENTED_ENV = {"PLADE_ORIENT_NORMALS": "1"}
 os.environ.pop("PLADE_ORIENT_NORMALS", None)     # nothing is inherited from the caller's shell
 os.environ.pop("PLADE_UNORIENTED_NORMALS", None)

@@ -44,3 +44,32 @@ def test_bench_two_ranks_on_one_gpu(with_torch):
     assert d["registrations_timed"] == 2 * timed and d["registrations_ok"] == d["registrations_timed"]
     assert d["results_bit_identical_to_the_pair_alone_rank0"]
     assert d["value"] > 0 and d["cpu_baseline"] is None   # the CPU leg runs at N = 1 only
+
+
+def test_bench_eight_ranks_on_one_gpu():
+    """The control flow of the driver's N = 8 run -- eight ranks of `torch.distributed.run`, their rendezvous, the barriers around
+    the timed region, max-over-ranks timing, the result gather of every rank's pairs in input order, the groups-in-flight choice
+    from the CPU quota shared by eight ranks -- once, somewhere: all eight ranks on the ONE GPU of this box, small clouds."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, PLADE_BENCH_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("PLADE_BENCH_TORCH", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "8", "--warmup", "2",
+           "--points", "60000", "--group", "2", "--pairs", "2", "--closed-form-steps", "0", "--resident-steps", "4"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["scaling"] == "weak" and not d["torch_in_process"]
+    assert d["rank_exchange"].startswith("loopback rendezvous") and "rccl not used" in d["rank_exchange"], d["rank_exchange"]
+    M = d["pipeline"]["groups_in_flight"]
+    assert M == d["config"]["inflight_for_local_world_8"] >= 1         # chosen from the quota the eight ranks share
+    timed = 32 * M * 2
+    assert d["steps"] == timed and d["registrations_timed"] == 8 * timed
+    assert 0 < d["registrations_ok"] <= d["registrations_timed"]      # (a 60 000-point scene may fail to register: that is a result, not an error)
+    assert d["results_bit_identical_to_the_pair_alone_rank0"] and d["value"] > 0
+    assert d["config"]["distinct_pairs_total"] == 16 and d["cpu_baseline"] is None

@@ -9,6 +9,7 @@ import pytest
 import plade_amd
 from plade_amd.plyio import write_ply
 from plade_amd.synth import make_pair
+from conftest import GT_TOL, CLOSED_FORM
 
 pytestmark = pytest.mark.gpu
 
@@ -63,7 +64,7 @@ def test_cli_single_pair_matches_the_library(ply_pairs, ctx):
     assert ok
     # Eigen's default stream format prints 6 significant digits
     assert np.allclose(b["T"], T, rtol=2e-5, atol=2e-6)
-    assert np.linalg.norm(b["T"] - Tgt) < 1e-2
+    assert np.linalg.norm(b["T"] - Tgt) < GT_TOL
 
 
 def test_cli_batch_mode_in_flight_keeps_input_order(ply_pairs, ctx):
@@ -151,7 +152,7 @@ def test_cli_ascii_ply_and_swap_of_a_larger_source(tmp_path, ctx):
     r = subprocess.run([CLI, pt, ps, res], capture_output=True, text=True, timeout=300, env=ORIENTED_ENV)
     assert r.returncode == 0, r.stderr
     (b,) = parse_results(res)
-    assert not b["failed"] and np.linalg.norm(b["T"] - T_expected) < 2e-2
+    assert not b["failed"] and np.linalg.norm(b["T"] - T_expected) < GT_TOL
 
 
 def test_cxx_api_four_overloads(ply_pairs, tmp_path, ctx):
@@ -180,7 +181,7 @@ def test_cxx_api_four_overloads(ply_pairs, tmp_path, ctx):
     assert out["clouds"][0] == 1 and np.array_equal(out["clouds"][1].astype(np.float32), T)
     ok2, T2 = ctx.registration_minsupport(tg, sr, 1500, 1500)
     assert out["minsupport"][0] == int(ok2) and np.array_equal(out["minsupport"][1].astype(np.float32), T2)
-    assert out["planes"][0] == 1 and np.linalg.norm(out["planes"][1] - Tgt) < 2e-2
+    assert out["planes"][0] == 1 and np.linalg.norm(out["planes"][1] - Tgt) < GT_TOL
     assert out["noplanes"][0] == 0 and np.array_equal(out["noplanes"][1], np.eye(4))
 
 

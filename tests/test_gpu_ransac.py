@@ -9,6 +9,7 @@ import pytest
 
 import plade_amd
 from plade_amd.synth import make_pair, sample_scene, planes_from_labels
+from conftest import GT_TOL, CLOSED_FORM
 
 pytestmark = pytest.mark.gpu
 
@@ -82,7 +83,7 @@ def test_full_registration_matches_oracle_on_same_planes(oracle, seed):
     ok, T = ctx.registration(tg, sr)
     assert ok
     d = ctx.dump()
-    assert np.linalg.norm(T.astype(np.float64) - Tgt) < 0.02, "registration should recover the generator's SE(3)"
+    assert np.linalg.norm(T.astype(np.float64) - Tgt) < GT_TOL, "registration should recover the generator's SE(3)"
     tp = (d["tgt_planes"].reshape(-1, 4), d["tgt_plane_offsets"], d["tgt_plane_idx"])
     sp = (d["src_planes"].reshape(-1, 4), d["src_plane_offsets"], d["src_plane_idx"])
     assert 10 <= len(tp[0]) <= 40 and 10 <= len(sp[0]) <= 40
@@ -130,7 +131,7 @@ def test_both_hypothesis_schedules_register_the_same_pairs():
         res[mode] = out
     for seed in res[1]:
         a, b = res[1][seed], res[0][seed]
-        assert a["ok"] and b["ok"] and a["err"] < 5e-2 and b["err"] < 5e-2, (seed, a["err"], b["err"])
+        assert a["ok"] and b["ok"] and a["err"] < GT_TOL and b["err"] < GT_TOL, (seed, a["err"], b["err"])
         # the six largest planes (walls, floor, ceiling) are the same surfaces with the same supports to a fraction of a percent
         for x, y in zip(a["supports"][:6], b["supports"][:6]):
             assert abs(x - y) <= 0.01 * max(x, y), (seed, a["supports"][:8], b["supports"][:8])

@@ -67,6 +67,25 @@ def test_candidate_shard_over_rccl_returns_the_unsharded_bits(comm):
     c.close()
 
 
+def test_candidate_shard_over_rccl_in_a_pairs_call_split_into_one_pair_parts(comm):
+    """Advisor r5: a pairs call whose clouds exceed plade_params.group_max_points is registered in consecutive parts; a part of
+    ONE pair keeps the candidate shard, and from the second part on it runs on a peer context behind a one-member Combiner --
+    the all-gather then has to take its place behind the queued upload and overlap kernels on the lead's stream
+    (pipeline.hip: raw_launch).  Every pair returns the bits of the unsharded pair alone, all its candidates scored."""
+    pairs = [make_pair(120000, seed=7)[:2], make_pair(120000, seed=8)[:2], make_pair(120000, seed=9)[:2]]
+    c = plade_amd.Context(0, orient_normals=1, max_candidates=2000)
+    alone = [c.registration(tg, sr) for tg, sr in pairs]
+    rccl_comm.set_candidate_shard(c, comm)
+    c.set_params(group_max_points=250000)          # 240 000 points per pair: every part holds one pair
+    res = c.registration_pairs(pairs)
+    assert c.stats()["group_parts"] == 3
+    for q, ((ok, T), (ok0, T0)) in enumerate(zip(res, alone)):
+        assert ok and ok0 and np.array_equal(T, T0), q
+        assert c.stats(pair=q)["n_candidates_scored_here"] > 0, q
+    rccl_comm.set_candidate_shard(c, None)
+    c.close()
+
+
 def test_bad_communicator_arguments():
     L = plade_amd.load_library()
     rccl_comm._bind(L)

@@ -6,6 +6,7 @@ import pytest
 
 import plade_amd
 from plade_amd.synth import make_pair, planes_from_labels
+from conftest import GT_TOL, CLOSED_FORM
 
 pytestmark = pytest.mark.gpu
 
@@ -37,12 +38,12 @@ def test_planes_given_boundary_equals_oracle_with_mirrored_target(oracle):
     assert len(common) >= 30
     for k in common:
         assert np.asarray(d[k]).shape == np.asarray(do[k]).shape and np.array_equal(d[k], do[k]), k
-    assert np.linalg.norm(T.astype(np.float64) - Tgt) < 2e-2
+    assert np.linalg.norm(T.astype(np.float64) - Tgt) < GT_TOL
     # the mirrored target really is twice the planes, and its descriptor table holds every sign pattern
     assert len(d["tgt_plane_center_radius"]) == 2 * 4 * len(tp[0])
     ctx.set_params(unoriented_normals=0)
     ok0, T0 = ctx.registration_planes(tg, sr, tp, sp)            # consistent signs: same answer without the mode
-    assert ok0 and np.linalg.norm(T0.astype(np.float64) - T.astype(np.float64)) < 1e-3
+    assert ok0 and np.linalg.norm(T0.astype(np.float64) - T.astype(np.float64)) < GT_TOL / 4   # (another descriptor table: another draw of the ill-conditioned solves)
     ctx.close()
 
 
@@ -61,7 +62,7 @@ def test_pair_with_flipped_source_normals_registers_in_this_mode(oracle, seed, f
     ctx = plade_amd.Context(0, orient_normals=1, unoriented_normals=1, dump=1)
     ok, T = ctx.registration(tg, sr_f)
     d = ctx.dump()
-    assert ok and np.linalg.norm(T.astype(np.float64) - Tgt) < 2e-2
+    assert ok and np.linalg.norm(T.astype(np.float64) - Tgt) < GT_TOL
     tp = (d["tgt_planes"].reshape(-1, 4), d["tgt_plane_offsets"], d["tgt_plane_idx"])
     sp = (d["src_planes"].reshape(-1, 4), d["src_plane_offsets"], d["src_plane_idx"])
     ok_o, T_o, do = oracle.registration(tg, sr_f, tp, sp, voxel_sort_mode=1, unoriented_normals=True)

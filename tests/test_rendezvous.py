@@ -47,7 +47,7 @@ def _rank(rank, world, key, n_items, q):
         q.put((rank, repr(e), None, None))
 
 
-@pytest.mark.parametrize("world,n_items", [(2, 7), (3, 8), (2, 1)])
+@pytest.mark.parametrize("world,n_items", [(2, 7), (3, 8), (2, 1), (8, 64), (8, 5)])   # 8: the ranks of one MI355X node; 5 items: ranks without work
 def test_ranks_meet_and_gather_without_torch(world, n_items, tmp_path):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
