@@ -69,9 +69,31 @@ QEntry &Combiner::push(plade_ctx *c) {
     return v.back();
 }
 
+// PLADE_TRACE_LOCKSTEP=1 (printing only): one line per group wait -- the host time since the previous wait ended, what was
+// queued, how long issuing it and waiting for the GPU took, and the first kernel of the batch (tools/lockstep_timeline.py)
+static bool trace_lockstep() { static const bool v = getenv("PLADE_TRACE_LOCKSTEP") != nullptr; return v; }
+
 void Combiner::flush_locked(std::unique_lock<std::mutex> &lk) {
     (void)lk;
     ++waits;
+    const bool tr = trace_lockstep();
+    const Clock::time_point t_in = Clock::now();
+    size_t n_q = 0;
+    uint64_t issued0 = launches_issued;
+    if (tr) for (int s = 0; s < BATCH_MAX; ++s) n_q += q[s].size();
+    Clock::time_point t_issued = t_in;
+    struct TraceOut {
+        Combiner *c; bool on; const Clock::time_point &t_in, &t_issued; size_t &n_q; uint64_t &issued0;
+        ~TraceOut() {
+            if (!on) return;
+            const Clock::time_point t_out = Clock::now();
+            auto us = [](Clock::time_point a, Clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+            fprintf(stderr, "[lockstep] %p stage %s wait %llu members %d host_gap_us %.0f queued %zu commands %llu issue_us %.0f gpu_wait_us %.0f\n", (void *)c, c->trace_stage,
+                    (unsigned long long)c->waits, c->members, c->t_last_out.time_since_epoch().count() ? us(c->t_last_out, t_in) : 0.0, n_q,
+                    (unsigned long long)(c->launches_issued - issued0), us(t_in, t_issued), us(t_issued, t_out));
+            c->t_last_out = t_out;
+        }
+    } trace_out{this, tr, t_in, t_issued, n_q, issued0};
     try {
         HIP_TRY(hipSetDevice(lead->device));
         hipStream_t st = lead->stream;
@@ -147,6 +169,7 @@ void Combiner::flush_locked(std::unique_lock<std::mutex> &lk) {
             }
         }
         for (int s = 0; s < BATCH_MAX; ++s) q[s].clear();
+        t_issued = Clock::now();
         // the read-backs of all pairs: one hand-over kernel per 32 ranges, the last one raises the lead's flag
         struct R { const void *src; char *dst; size_t bytes; };
         std::vector<R> reads;
@@ -203,6 +226,7 @@ void Combiner::flush_locked(std::unique_lock<std::mutex> &lk) {
 
 void Combiner::wait(plade_ctx *c) {
     std::unique_lock<std::mutex> lk(m);
+    trace_stage = c->stage_name;       // (the last pair to arrive names the wait)
     const double c0 = thread_cpu_seconds();
     ++arrived;
     const uint64_t my_epoch = epoch;

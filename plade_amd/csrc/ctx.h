@@ -93,6 +93,7 @@ struct plade_ctx {
     plade_ctx *peers[PLADE_GROUP_MAX - 1] = {};   // the contexts of pairs 1.. of a group (plade_registration_pairs): stream, aux, work areas
     hipEvent_t ev_group = nullptr;   // end of a group's joint plane extraction on `stream` (the peers' streams wait for it)
     bool in_group = false;      // this context carries one pair of a group of several (register_group)
+    const char *stage_name = "";       // the innermost StageTimer alive on this context (trace lines)
     plade::Combiner *comb = nullptr;   // ... whose launches, small copies and waits are merged with those of the other pairs (launch.h)
     int comb_slot = -1;
     plade_ctx *aux = nullptr;   // second stream + work areas: stages of the source cloud that are independent of the
@@ -516,8 +517,10 @@ struct StageTimer {
     const char *name;
     Clock::time_point t0;
     double cpu0;      // CPU time of the calling thread (helper threads account for themselves)
-    StageTimer(plade_ctx *c, const char *n) : ctx(c), name(n), t0(Clock::now()), cpu0(plade::thread_cpu_seconds()) {}
+    const char *outer;
+    StageTimer(plade_ctx *c, const char *n) : ctx(c), name(n), t0(Clock::now()), cpu0(plade::thread_cpu_seconds()), outer(c->stage_name) { c->stage_name = n; }
     ~StageTimer() {
+        ctx->stage_name = outer;
         ctx->stats.add(name, secs_since(t0));
         ctx->stats.add(std::string("cpu") + (name + 1), plade::thread_cpu_seconds() - cpu0);   // "t_x" -> "cpu_x"
     }

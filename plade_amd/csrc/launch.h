@@ -110,6 +110,8 @@ struct Combiner {
     int size() { std::lock_guard<std::mutex> lk(m); return members; }   // pairs taking part right now (a pair that fails leaves early)
     void bury(std::vector<void *> &gy);       // device allocations to free when the call has ended (combiner.hip)
     ~Combiner();
+    const char *trace_stage = "";
+    std::chrono::steady_clock::time_point t_last_out{};   // PLADE_TRACE_LOCKSTEP: when the previous group wait returned
 private:
     std::vector<void *> graveyard;
     void flush_locked(std::unique_lock<std::mutex> &lk);
