@@ -6,7 +6,10 @@ if len(sys.argv) > 2 and sys.argv[1] == "--parse":
     rows = collections.defaultdict(list)
     per_call = collections.defaultdict(int)
     first = {}
-    for l in open(sys.argv[2]):
+    lines = [l for l in open(sys.argv[2]) if l.startswith("[lockstep]")]
+    lines = lines[len(lines) // 2:]          # the second half of the run: first-use allocations and graph captures are behind it
+    while lines and " wait 1 " not in lines[0]: lines.pop(0)
+    for l in lines:
         m = re.match(r"\[lockstep\] (\S+) stage (\S*) wait (\d+) members (\d+) host_gap_us (\d+) queued (\d+) commands (\d+) issue_us (\d+) gpu_wait_us (\d+)", l)
         if not m: continue
         comb, stage, w, mem, gap, qd, cmd, iss, gw = m.groups()
