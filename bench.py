@@ -465,9 +465,9 @@ def _cpu_budget():
     return n
 
 
-# busy host threads per rank, measured on the MI355X box in round 4 (tools/exp_groups.py, sleeping host waits, groups of 8 pairs,
+# busy host threads per rank, measured on the MI355X box in round 4 (sleeping host waits, groups of 8 pairs,
 # host clouds): groups in flight -> busy threads (registrations/s): see profiles/r5_experiments.md
-BUSY_THREADS_BY_GROUPS = {1: 1.02, 2: 1.5, 3: 1.53, 4: 1.71}   # r5 (lock step, tools/exp_lockstep.sh): 457 / 665 / 717 / 786 registrations/s (6 groups: 1.88 threads, 774); r4: 1.38 / 1.66 / 1.8 / 1.91
+BUSY_THREADS_BY_GROUPS = {1: 1.02, 2: 1.5, 3: 1.53, 4: 1.71}   # r5 (lock step, profiles/r5_experiments.md 2): 457 / 665 / 717 / 786 registrations/s (6 groups: 1.88 threads, 774); r4: 1.38 / 1.66 / 1.8 / 1.91
 
 
 def inflight_for_budget(budget, local_world):

@@ -158,8 +158,10 @@ __device__ void k_rs_pass(const VB &, const K *__restrict__ kin_all, K *__restri
     for (int r = 0; r < RS_IPT; ++r) {
         const uint32_t i = base + r * 64 + lane;
         const bool ok = i < n;
-        key[r] = ok ? kin[i] : (K)0;
-        val[r] = ok ? vin[i] : 0u;
+        // (each key and value is read once per pass: non-temporal, so that the streams do not evict the look-back words, the
+        //  histograms and the other groups' tables from L2 / the Infinity Cache)
+        key[r] = ok ? __builtin_nontemporal_load(kin + i) : (K)0;
+        val[r] = ok ? __builtin_nontemporal_load(vin + i) : 0u;
     }
     const unsigned long long lt = (1ull << lane) - 1ull;
     volatile uint32_t *cnt = s_cnt[wave];
