@@ -844,15 +844,17 @@ def main():
     # ---- roofline leg: one extra profiled step (HIP events on the ctx stream around every launch) ----
     roofline = roofline_sort = dominant = None
     stage = {}
-    latency_ms = None
+    latency_ms = latency_by_scene = None
     if rank == 0:
         lat = []
         ctx.set_params(host_wait=0)   # alone, a spinning wait is the faster one
-        for i in range(4):   # one registration at a time: the latency figure
+        for i in range(NP):   # one registration at a time, every scene of the cycle once: the latency figure is the MEDIAN over the scenes
             t1 = time.perf_counter()
             step(i)
             lat.append(time.perf_counter() - t1)
-        latency_ms = min(lat) * 1e3
+        latency_ms = sorted(lat)[len(lat) // 2] * 1e3
+        latency_by_scene = {"min": min(lat) * 1e3, "median": latency_ms, "max": max(lat) * 1e3, "scenes": len(lat),
+                            "note": "one plade_registration_dev at a time on resident clouds, spinning host waits, every scene of the cycle once"}
         # Profiled steps (HIP events on the launch stream around every launch of the scan kernels) on context 0 WHILE the
         # other contexts keep registering, i.e. under the load of the timed region: the average launch duration must be
         # the one `rocprofv3 --kernel-trace --stats` reports for this command (profiles/), not that of an idle GPU.
@@ -1078,6 +1080,7 @@ def main():
                        "inflight_for_local_world_8": inflight_for_budget(_cpu_budget(), 8),
                        "parallelism": f"independent pairs sharded over {world} GPU(s), {M} groups of {S} pairs in flight per GPU"},
             "single_registration_latency_ms": latency_ms,
+            "single_registration_latency_by_scene_ms": latency_by_scene,
             "registrations_timed": total,
             "registrations_ok": total_ok,
             "results_bit_identical_to_the_pair_alone_rank0": bool(identical),
