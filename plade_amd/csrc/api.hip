@@ -27,6 +27,85 @@ extern "C" void plade_default_params(plade_params *p) {
     // overloads) read their opt-in switches themselves (plade_host.cpp: context())
 }
 
+// ---- device memory (common.h) --------------------------------------------------------------------------------------------------
+namespace plade {
+namespace {
+struct Slab { char *base = nullptr; size_t used = 0; uint32_t live = 0; int device = 0; };
+struct SmallPool {
+    static constexpr size_t SLAB = 32u << 20, SMALL = 1u << 20, GRAN = 256;
+    std::mutex m;
+    std::vector<Slab> slabs;            // (a few dozen per process: linear searches)
+    std::vector<size_t> empty;          // slabs whose blocks have all come back (not the device's current one)
+    std::map<int, size_t> current;      // device -> the slab being filled
+    bool enabled = getenv("PLADE_EXP_NO_POOL") == nullptr;   // A/B timing hook
+    void *alloc(size_t bytes) {
+        int dev = 0;
+        HIP_TRY(hipGetDevice(&dev));
+        const size_t need = (bytes + GRAN - 1) & ~(GRAN - 1);
+        std::lock_guard<std::mutex> lk(m);
+        auto it = current.find(dev);
+        if (it == current.end() || slabs[it->second].used + need > SLAB) {
+            size_t pick = (size_t)-1;
+            if (it != current.end() && slabs[it->second].live == 0) pick = it->second;      // nothing of it is in use: start it over
+            for (size_t q = 0; q < empty.size() && pick == (size_t)-1; ++q)
+                if (slabs[empty[q]].device == dev) { pick = empty[q]; empty.erase(empty.begin() + (long)q); }
+            if (pick == (size_t)-1) {
+                Slab s;
+                s.device = dev;
+                HIP_TRY(hipMalloc((void **)&s.base, SLAB));
+                slabs.push_back(s);
+                pick = slabs.size() - 1;
+            } else {
+                // its blocks have all been returned, but kernels queued earlier may still be using them (hipFree would have waited too)
+                HIP_TRY(hipDeviceSynchronize());
+                slabs[pick].used = 0;
+            }
+            if (it != current.end() && it->second != pick && slabs[it->second].live == 0) empty.push_back(it->second);
+            current[dev] = pick;
+            it = current.find(dev);
+        }
+        Slab &s = slabs[it->second];
+        void *p = s.base + s.used;
+        s.used += need;
+        ++s.live;
+        return p;
+    }
+    bool release(void *p) {     // false: not a pool block
+        std::lock_guard<std::mutex> lk(m);
+        for (size_t q = 0; q < slabs.size(); ++q) {
+            Slab &s = slabs[q];
+            if ((char *)p >= s.base && (char *)p < s.base + SLAB) {
+                if (--s.live == 0) {
+                    auto it = current.find(s.device);
+                    if (it == current.end() || it->second != q) empty.push_back(q);
+                }
+                return true;
+            }
+        }
+        return false;
+    }
+};
+SmallPool &small_pool() { static SmallPool *p = new SmallPool; return *p; }   // (never destroyed: frees may arrive during process exit)
+}  // namespace
+
+void *dev_alloc(size_t bytes) {
+    const auto t0 = std::chrono::steady_clock::now();
+    void *p = nullptr;
+    SmallPool &sp = small_pool();
+    if (sp.enabled && bytes <= SmallPool::SMALL) p = sp.alloc(bytes);
+    else HIP_TRY(hipMalloc(&p, bytes));
+    AllocStats &as = alloc_stats();
+    as.calls += 1; as.bytes += bytes;
+    as.nanos += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+    return p;
+}
+void dev_free(void *p) {
+    if (!p) return;
+    if (small_pool().release(p)) return;
+    (void)hipFree(p);
+}
+}  // namespace plade
+
 extern "C" const char *plade_version(void) { return "plade-hip 0.1 (gfx950)"; }
 
 extern "C" int plade_ctx_create(int device, plade_ctx **out) {

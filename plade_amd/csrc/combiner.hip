@@ -251,7 +251,7 @@ void Combiner::wait(plade_ctx *c) {
     c->write_arena_used = 0;
     ++c->wait_epoch;
     if (tl_deferred_free && !tl_deferred_free->empty()) {   // everything that could name them has run
-        for (void *p : *tl_deferred_free) (void)hipFree(p);
+        for (void *p : *tl_deferred_free) dev_free(p);
         tl_deferred_free->clear();
     }
 }
@@ -286,7 +286,7 @@ void Combiner::bury(std::vector<void *> &gy) {
     gy.clear();
 }
 Combiner::~Combiner() {
-    for (void *p : graveyard) (void)hipFree(p);
+    for (void *p : graveyard) dev_free(p);
 }
 
 }  // namespace plade

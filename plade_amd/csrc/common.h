@@ -89,6 +89,13 @@ struct Err {
 struct AllocStats { std::atomic<uint64_t> calls{0}, bytes{0}, nanos{0}; };
 inline AllocStats &alloc_stats() { static AllocStats s; return s; }
 
+// Device memory of the work areas.  A registration context owns ~700 buffers, most of them a few KB to a few hundred KB, and
+// every one used to be a hipMalloc of its own (1 400 calls and 150 ms for the CLI's 64-pair list, 90 us each): blocks of up to
+// 1 MB now come out of 32 MB slabs (api.hip: bump allocation, 256-byte granules, one lock; a slab whose blocks have all been
+// returned is recycled behind a device synchronisation, as hipFree would have waited); larger blocks are hipMalloc / hipFree.
+void *dev_alloc(size_t bytes);
+void dev_free(void *p);
+
 // While the pairs of a group run in lock step (launch.h) what a pair launches is queued, not issued: an allocation that is
 // replaced by a larger one meanwhile may still be named by queued launches, so it is kept until the pair's next wait has
 // returned (hipFree on a stream-ordered path waits for the device; here the work has not even been queued).
@@ -99,20 +106,16 @@ template <class T>
 struct DBuf {
     T *p = nullptr;
     size_t cap = 0;
-    ~DBuf() { if (p) (void)hipFree(p); }
+    ~DBuf() { if (p) dev_free(p); }
     DBuf() = default;
     DBuf(const DBuf &) = delete;
     DBuf &operator=(const DBuf &) = delete;
     T *ensure(size_t n) {
         if (n > cap) {
-            if (p) { if (tl_deferred_free) tl_deferred_free->push_back(p); else HIP_TRY(hipFree(p)); }
+            if (p) { if (tl_deferred_free) tl_deferred_free->push_back(p); else dev_free(p); }
             p = nullptr;
             size_t want = n + n / 4 + 64;
-            const auto t0 = std::chrono::steady_clock::now();
-            HIP_TRY(hipMalloc((void **)&p, want * sizeof(T)));
-            AllocStats &as = alloc_stats();
-            as.calls += 1; as.bytes += want * sizeof(T);
-            as.nanos += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+            p = static_cast<T *>(dev_alloc(want * sizeof(T)));
             cap = want;
         }
         return p;

@@ -281,5 +281,6 @@ int main(int argc, char **argv) {
     // Everything the user asked for is on disk and on the console: leave without tearing the HIP runtime down and handing
     // gigabytes of work areas back one allocation at a time (~0.1 s of a 0.4 s single-pair process; the OS reclaims them at once)
     std::cout.flush(); std::cerr.flush(); fflush(nullptr);
+    if (getenv("PLADE_CLI_FULL_EXIT")) return rc;     // (profilers and PLADE_DEBUG_ALLOC report from the normal exit path)
     _exit(rc);
 }

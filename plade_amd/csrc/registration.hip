@@ -335,7 +335,7 @@ void register_group(plade_ctx *ctx, int first, int count, const CloudDev *const 
             ~Leave() {
                 tl_deferred_free = nullptr;
                 if (on) { try { cb.leave(pc); } catch (...) {} cb.bury(gy); }   // (what the pair still had queued may name them: freed with the call)
-                for (void *p : gy) (void)hipFree(p);
+                for (void *p : gy) dev_free(p);
             }
         } leave{comb, pcs[i], lockstep, graveyard};
         if (lockstep) tl_deferred_free = &graveyard;
