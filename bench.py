@@ -467,7 +467,7 @@ def _cpu_budget():
 
 # busy host threads per rank, measured on the MI355X box in round 4 (sleeping host waits, groups of 8 pairs,
 # host clouds): groups in flight -> busy threads (registrations/s): see profiles/r5_experiments.md
-BUSY_THREADS_BY_GROUPS = {1: 1.02, 2: 1.5, 3: 1.53, 4: 1.71}   # r5 (lock step, profiles/r5_experiments.md 2): 457 / 665 / 717 / 786 registrations/s (6 groups: 1.88 threads, 774); r4: 1.38 / 1.66 / 1.8 / 1.91
+BUSY_THREADS_BY_GROUPS = {1: 1.02, 2: 1.5, 3: 1.52, 4: 1.78}   # r6 (reference arithmetic, profiles/r6_experiments.md 5): 3 groups 680-693 registrations/s at 1.46-1.52 threads, 4 groups 733-734 at 1.75-1.78; 1 / 2 groups: r5 (457 / 665)
 
 
 def inflight_for_budget(budget, local_world):
