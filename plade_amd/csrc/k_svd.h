@@ -9,13 +9,14 @@
 // sweeps, rotations also applied to an identity that becomes V^T), the column norms are the singular values (ordered by a
 // selection sort), rows that ended up empty are replaced by sign vectors made orthogonal to the others, and the solution
 // is V diag(1/w) U^T b with float products summed in double (lapack.cpp:751-812).  On axis-aligned scenes the result of
-// those solves is ill-conditioned, so a host that wants the REFERENCE's transform there needs every
-// rounding of that procedure -- this file performs them in the same order, one system per lane:
+// those solves is ill-conditioned, so reproducing the REFERENCE's transform there needs every rounding of that
+// procedure -- this file performs them in the same order, one system per lane, in two forms:
 //
-//   * a lane's matrices (rows of A^T, rows of V^T, squared norms) live in LDS, word e of lane l at e * TPB + l, so the 64
-//     lanes of a wavefront touch 64 neighbouring banks whatever (row, column) they address -- the rotation pairs, the
-//     selection sort and the completion step address rows by run-time index, which registers cannot do;
-//   * the two rows of a rotation are pulled into registers once, rotated there and written back;
+//   * RegSolver (below, host + device): the whole system in registers, every loop over compile-time bounds -- what the kernels
+//     run (k_closest_svd, k_pen_setup_svd) and what plade_diag_line_solver_host instantiates on the host;
+//   * LaneSolver (device): the general form with run-time row indices -- the selection sort and the sign-vector completion of a
+//     vanished column (lapack.cpp:650-699) address rows by index, which registers cannot do -- on a lane's own words of LDS or of
+//     scratch memory.  Since round 6 it only serves the rare systems RegSolver hands back (a column of norm <= FLT_MIN).
 //   * lanes converge after different numbers of sweeps; a lane that is done simply leaves the loop.
 //
 // hypot(): the reference calls the C library's.  glibc 2.35's dbl-64 kernel (no FMA, no rescaling between 2^-459 and
