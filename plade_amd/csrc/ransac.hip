@@ -2075,6 +2075,17 @@ __global__ __launch_bounds__(TPB) void k_view_compact(const RKArgs A) {
         if (lane == 0) s_pre = part;
     }
     const uint32_t first = tile * TILE + threadIdx.x * PPT;
+    // the lane's four points of all six arrays as 16-byte loads, issued BEFORE anything is known about them: the chain
+    // map -> taken -> prefix -> coordinates was four dependent round trips (the wavefronts of this kernel waited 94 % of their
+    // time, profiles/r6_pmc_sq.csv); now the coordinates travel beside the map and the flags (the arrays are padded to whole
+    // 16-byte groups, as the scan kernels rely on)
+    static_assert(PPT == 4, "one float4 per lane and array");
+    float4 cx4 = make_float4(0.f, 0.f, 0.f, 0.f), cy4 = cx4, cz4 = cx4, nx4 = cx4, ny4 = cx4, nz4 = cx4;
+    if (first < V.n) {
+        cx4 = *reinterpret_cast<const float4 *>(V.x + first); cy4 = *reinterpret_cast<const float4 *>(V.y + first);
+        cz4 = *reinterpret_cast<const float4 *>(V.z + first); nx4 = *reinterpret_cast<const float4 *>(V.nx + first);
+        ny4 = *reinterpret_cast<const float4 *>(V.ny + first); nz4 = *reinterpret_cast<const float4 *>(V.nz + first);
+    }
     uint32_t pos[PPT], m = 0;
 #pragma unroll
     for (int q = 0; q < PPT; ++q) {
@@ -2099,12 +2110,13 @@ __global__ __launch_bounds__(TPB) void k_view_compact(const RKArgs A) {
     float *b = C.view[dst_sel];
     uint32_t *dmap = C.view_map[dst_sel];
     const size_t pitch = ((size_t)C.cv.n + 3) & ~(size_t)3;
+    const float ax[4] = {cx4.x, cx4.y, cx4.z, cx4.w}, ay[4] = {cy4.x, cy4.y, cy4.z, cy4.w}, az[4] = {cz4.x, cz4.y, cz4.z, cz4.w};
+    const float bx[4] = {nx4.x, nx4.y, nx4.z, nx4.w}, by[4] = {ny4.x, ny4.y, ny4.z, ny4.w}, bz[4] = {nz4.x, nz4.y, nz4.z, nz4.w};
 #pragma unroll
     for (int q = 0; q < PPT; ++q)
         if (m & (1u << q)) {
-            const uint32_t at = first + q;
-            b[off] = V.x[at]; b[pitch + off] = V.y[at]; b[2 * pitch + off] = V.z[at];
-            b[3 * pitch + off] = V.nx[at]; b[4 * pitch + off] = V.ny[at]; b[5 * pitch + off] = V.nz[at];
+            b[off] = ax[q]; b[pitch + off] = ay[q]; b[2 * pitch + off] = az[q];
+            b[3 * pitch + off] = bx[q]; b[4 * pitch + off] = by[q]; b[5 * pitch + off] = bz[q];
             dmap[off] = pos[q];
             ++off;
         }
