@@ -118,6 +118,18 @@ __device__ void k_near_mask(const VB &vb, const uint32_t *__restrict__ row_start
     if (lane == 32) mask[w0 + 1u] = (uint32_t)(m >> 32);
 }
 
+// (4, r6) row occupancy: bit a = "the run of three cells that starts at cell a holds a point" (row_start[a + 3] != row_start[a]).
+// 1 bit per padded cell = 256 KB at the bench's shape: unlike the 8 MB of row words it stays in every XCD's L2, and six of the nine
+// runs around a probe on a surface are empty -- their row words need not be fetched at all.
+__device__ void k_row_occ(const VB &vb, const uint32_t *__restrict__ row_start, uint32_t table_n, uint32_t *__restrict__ occ) {
+    const uint32_t a = vb.bx * blockDim.x + threadIdx.x;
+    const bool on = a + 3u < table_n && row_start[a + 3u] != row_start[a];
+    const unsigned long long m = __ballot(on);
+    const uint32_t lane = threadIdx.x & 63u, w0 = (vb.bx * blockDim.x + (threadIdx.x & ~63u)) >> 5;
+    if (lane == 0) occ[w0] = (uint32_t)m;
+    if (lane == 32) occ[w0 + 1u] = (uint32_t)(m >> 32);
+}
+
 __device__ void k_gather_cells(const VB &vb, const float *__restrict__ xyz, uint32_t stride, const uint32_t *__restrict__ keys,
                                const uint32_t *__restrict__ vals, uint32_t n, float4 *__restrict__ sorted,
                                uint32_t *__restrict__ cell_start, uint32_t *__restrict__ cell_end) {
@@ -239,6 +251,12 @@ void TargetGrid::build(plade_ctx *ctx, const float *d_xyz, uint32_t n_pts, uint3
         launch<k_dense_points, 256>(ctx, dim3(cdiv(n, 256)), 0, d_xyz, stride, vals2.p, n, sorted.p);
         launch<k_row_table, 256>(ctx, dim3(cdiv(table, 256)), 0, keys2.p, n, (uint32_t)table, row_start.p);
         launch<k_near_mask, 256>(ctx, dim3(cdiv(n_blocks, 256)), 0, row_start.p, g, mask_shift, n_blocks, near_mask.p);
+        static const bool no_occ = getenv("PLADE_OVERLAP_NO_ROW_OCC") != nullptr;   // A/B timing hook
+        row_occ_on = !no_occ;
+        if (row_occ_on) {
+            row_occ.ensure(table / 32 + 64);
+            launch<k_row_occ, 256>(ctx, dim3(cdiv(table, 256)), 0, row_start.p, (uint32_t)table, row_occ.p);
+        }
         HIP_TRY(hipGetLastError());
         return;
     }
@@ -428,7 +446,8 @@ __device__ void k_overlap(const VB &vb, const float *__restrict__ sx, const floa
 // points, same fp32 distances, same strict comparisons: the counts are the bits of the other form (and of the oracle).
 __device__ void k_overlap_dense(const VB &vb, const float *__restrict__ sx, const float *__restrict__ sy, const float *__restrict__ sz,
                                 uint32_t n_s, const float4 *__restrict__ tgt, const uint32_t *__restrict__ row_start,
-                                const uint32_t *__restrict__ near_mask, uint32_t mask_words, int ms, GridParams g,
+                                const uint32_t *__restrict__ near_mask, uint32_t mask_words, int ms,
+                                const uint32_t *__restrict__ row_occ /* or null */, GridParams g,
                                 const float *__restrict__ T /*K x 16*/, const float *__restrict__ centers /*K x 3*/, uint32_t K, float R2,
                                 float r2, int32_t *__restrict__ counts, uint32_t ch, uint32_t items_per_wg) {
     __shared__ float s_T[OV_KCH][12];
@@ -476,13 +495,25 @@ __device__ void k_overlap_dense(const VB &vb, const float *__restrict__ sx, cons
             if (probe) {
                 const f3 c(s_c[kk][0], s_c[kk][1], s_c[kk][2]);
                 // nine rows, the probe's own first: (row, slice) offsets
-                uint32_t s9[9], e9[9];
+                uint32_t s9[9], e9[9], a9[9];
+                uint32_t occ9 = 0x1ffu;
 #pragma unroll
                 for (int r = 0; r < 9; ++r) {
                     const int o = (r + 4) % 9;                         // 4 = the centre row (dy = 0, dz = 0)
-                    const uint32_t a = base + (uint32_t)(o % 3) * RS + (uint32_t)(o / 3) * SS;
-                    s9[r] = row_start[a];
-                    e9[r] = row_start[a + 3];
+                    a9[r] = base + (uint32_t)(o % 3) * RS + (uint32_t)(o / 3) * SS;
+                }
+                if (row_occ) {       // nine bits of a table that stays in L2: which runs hold a point at all
+                    uint32_t w9[9];
+#pragma unroll
+                    for (int r = 0; r < 9; ++r) w9[r] = row_occ[a9[r] >> 5];
+                    occ9 = 0u;
+#pragma unroll
+                    for (int r = 0; r < 9; ++r) occ9 |= ((w9[r] >> (a9[r] & 31u)) & 1u) << r;
+                }
+#pragma unroll
+                for (int r = 0; r < 9; ++r) {
+                    s9[r] = 0u; e9[r] = 0u;
+                    if ((occ9 >> r) & 1u) { s9[r] = row_start[a9[r]]; e9[r] = row_start[a9[r] + 3]; }
                 }
                 // point t of every run together (nine loads in flight), t = 0, 1, ...: the depth of the chain of dependent loads is the
                 // LONGEST run (1-3 points on a voxel-downsampled surface), not the sum of the runs.  (Requesting the next candidate's
@@ -627,7 +658,8 @@ void overlap_counts(plade_ctx *ctx, OverlapWork &work, const float *d_sx, const 
         PLADE_REQUIRE(grid.compact, PLADE_EINVAL, "overlap: the target grid needs the compact occupancy index");
         if (grid.dense) {
             launch<k_overlap_dense, OV_TPB, OVD_W>(ctx, dim3(cdiv(nitems, per)), grid.mask_words * 4, d_sx, d_sy, d_sz, n_s, grid.sorted.p,
-                               grid.row_start.p, grid.near_mask.p, grid.mask_words, grid.mask_shift, g, d_T, d_centers, K, R2, r2, d_counts,
+                               grid.row_start.p, grid.near_mask.p, grid.mask_words, grid.mask_shift,
+                               grid.row_occ_on ? (const uint32_t *)grid.row_occ.p : (const uint32_t *)nullptr, g, d_T, d_centers, K, R2, r2, d_counts,
                                ch, per);
             ctx->ev_end();
             HIP_TRY(hipGetLastError());

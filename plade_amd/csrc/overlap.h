@@ -32,6 +32,8 @@ struct TargetGrid {
     int DX = 0, DY = 0, DZ = 0, mask_shift = 2;
     uint32_t mask_words = 0;
     DBuf<uint32_t> row_start, near_mask;
+    DBuf<uint32_t> row_occ;       // (r6) bit a: the run of three cells starting at cell a is not empty (k_row_occ)
+    bool row_occ_on = false;
     // d_xyz: device pointer, `stride` floats between points; min_cell = largest probe radius used.
     void build(plade_ctx *ctx, const float *d_xyz, uint32_t n_pts, uint32_t stride, float min_cell,
                const float *bbox_min = nullptr, const float *bbox_max = nullptr,   // known bbox skips a device round trip
