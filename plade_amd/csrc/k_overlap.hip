@@ -520,9 +520,18 @@ __device__ void k_overlap_dense(const VB &vb, const float *__restrict__ sx, cons
                 // rows while this one's points are on their way -- a software pipeline over the chunk -- was built and is slower: at
                 // the 96 registers that keep five wavefronts per SIMD it spills, at 128 / four wavefronts it takes 189 ms against 160
                 // at the stress size.)
+                // the probe's own run first, alone: where the clouds overlap most hits are found there, and the other eight runs'
+                // points are then never requested (the lanes that hit sit out the rounds below)
+                for (uint32_t j = s9[0]; j < e9[0] && !hit; ++j) {
+                    const float4 f = tgt[j];
+                    const f3 tp(f.x, f.y, f.z);
+                    hit = flann_d2(q_, tp) < r2 && flann_d2(c, tp) < R2;
+                }
+                e9[0] = s9[0];
                 uint32_t longest = 0;
 #pragma unroll
                 for (int r = 0; r < 9; ++r) longest = max(longest, e9[r] - s9[r]);
+                if (hit) longest = 0;
                 for (uint32_t t = 0; t < longest && !hit; ++t) {
                     float4 f9[9];
 #pragma unroll
