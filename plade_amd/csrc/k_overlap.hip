@@ -502,19 +502,10 @@ __device__ void k_overlap_dense(const VB &vb, const float *__restrict__ sx, cons
                     const int o = (r + 4) % 9;                         // 4 = the centre row (dy = 0, dz = 0)
                     a9[r] = base + (uint32_t)(o % 3) * RS + (uint32_t)(o / 3) * SS;
                 }
-                if (row_occ) {       // nine bits of a table that stays in L2: which runs hold a point at all
-                    uint32_t w9[9];
+                if (row_occ) occ9 = (row_occ[a9[0] >> 5] >> (a9[0] & 31u)) & 1u;     // the own run's bit now, the others' if it misses
 #pragma unroll
-                    for (int r = 0; r < 9; ++r) w9[r] = row_occ[a9[r] >> 5];
-                    occ9 = 0u;
-#pragma unroll
-                    for (int r = 0; r < 9; ++r) occ9 |= ((w9[r] >> (a9[r] & 31u)) & 1u) << r;
-                }
-#pragma unroll
-                for (int r = 0; r < 9; ++r) {
-                    s9[r] = 0u; e9[r] = 0u;
-                    if ((occ9 >> r) & 1u) { s9[r] = row_start[a9[r]]; e9[r] = row_start[a9[r] + 3]; }
-                }
+                for (int r = 0; r < 9; ++r) { s9[r] = 0u; e9[r] = 0u; }
+                if (occ9 & 1u) { s9[0] = row_start[a9[0]]; e9[0] = row_start[a9[0] + 3]; }
                 // point t of every run together (nine loads in flight), t = 0, 1, ...: the depth of the chain of dependent loads is the
                 // LONGEST run (1-3 points on a voxel-downsampled surface), not the sum of the runs.  (Requesting the next candidate's
                 // rows while this one's points are on their way -- a software pipeline over the chunk -- was built and is slower: at
@@ -528,6 +519,18 @@ __device__ void k_overlap_dense(const VB &vb, const float *__restrict__ sx, cons
                     hit = flann_d2(q_, tp) < r2 && flann_d2(c, tp) < R2;
                 }
                 e9[0] = s9[0];
+                if (!hit) {      // the bits and row words of the other non-empty runs: only for the lanes whose own run did not settle it
+                    if (row_occ) {
+                        uint32_t w9[9];
+#pragma unroll
+                        for (int r = 1; r < 9; ++r) w9[r] = row_occ[a9[r] >> 5];
+#pragma unroll
+                        for (int r = 1; r < 9; ++r) occ9 |= ((w9[r] >> (a9[r] & 31u)) & 1u) << r;
+                    }
+#pragma unroll
+                    for (int r = 1; r < 9; ++r)
+                        if ((occ9 >> r) & 1u) { s9[r] = row_start[a9[r]]; e9[r] = row_start[a9[r] + 3]; }
+                }
                 uint32_t longest = 0;
 #pragma unroll
                 for (int r = 0; r < 9; ++r) longest = max(longest, e9[r] - s9[r]);
