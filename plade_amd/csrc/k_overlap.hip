@@ -506,13 +506,12 @@ __device__ void k_overlap_dense(const VB &vb, const float *__restrict__ sx, cons
 #pragma unroll
                 for (int r = 0; r < 9; ++r) { s9[r] = 0u; e9[r] = 0u; }
                 if (occ9 & 1u) { s9[0] = row_start[a9[0]]; e9[0] = row_start[a9[0] + 3]; }
-                // point t of every run together (nine loads in flight), t = 0, 1, ...: the depth of the chain of dependent loads is the
-                // LONGEST run (1-3 points on a voxel-downsampled surface), not the sum of the runs.  (Requesting the next candidate's
-                // rows while this one's points are on their way -- a software pipeline over the chunk -- was built and is slower: at
-                // the 96 registers that keep five wavefronts per SIMD it spills, at 128 / four wavefronts it takes 189 ms against 160
-                // at the stress size.)
-                // the probe's own run first, alone: where the clouds overlap most hits are found there, and the other eight runs'
-                // points are then never requested (the lanes that hit sit out the rounds below)
+                // (r6) The probe's OWN run first -- its bit, its row words, its points --: where the clouds overlap most hits are found
+                // there and nothing of the other eight runs is then requested.  The lanes that missed go on: the other runs' bits,
+                // the row words of the non-empty ones, then point t of every remaining run together, t = 0, 1, ... (loads in flight;
+                // the depth of that chain is the LONGEST run, 1-3 points on a voxel-downsampled surface, not the sum of the runs).
+                // (A software pipeline over the chunk -- the next candidate's rows requested while this one's points are on their
+                // way -- was built in r5 and is slower: it spills at the 96 registers that keep five wavefronts per SIMD.)
                 for (uint32_t j = s9[0]; j < e9[0] && !hit; ++j) {
                     const float4 f = tgt[j];
                     const f3 tp(f.x, f.y, f.z);
